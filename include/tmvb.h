@@ -1,0 +1,153 @@
+/*
+ * tmvb.h -- C ABI of libtmvb_hip.so, the MI355X (gfx950) variational-inference engine that
+ * replaces TopicModelsVB.jl's OpenCL backend (gpuLDA / gpuCTM / gpuCTPF) behind the package's
+ * `TopicModel / train! / @gpu` surface.
+ *
+ * Every entry point cites the reference interface it replaces (file:line relative to the
+ * reference repository root).  The reference drives its device through one Julia function per
+ * kernel pair (update_phi!, update_gamma!, ...); this engine fuses the per-document sweep into one
+ * kernel, so the per-document operator triple maps onto a single `*_estep` call that follows the
+ * CPU path's per-document semantics (src/LDA.jl:170-180), which is the parity target -- not the
+ * OpenCL path's global-median rule (src/gpuLDA.jl:361).
+ *
+ * Conventions
+ *   - plain C types only; no torch / HIP types in signatures (streams and device pointers travel
+ *     as void*).
+ *   - all host matrices are column-major K x (.) Float64, exactly the memory of the reference's
+ *     Matrix{Float64} (beta) or of hcat(model.gamma...) (per-document vectors).
+ *   - term / reader ids are 0-based (the reference subtracts 1 on upload, src/modelutils.jl:371).
+ *   - every call returns a status code; tmvb_last_error() gives the message of the last failure on
+ *     the calling thread.  Calls are synchronous on return unless stated otherwise.
+ *   - the library copies host data in/out during the call and never retains host pointers.
+ *   - quirk Q1: the reference overwrites (does not accumulate) duplicate term ids inside one
+ *     document (src/LDA.jl:131); this engine accumulates.  Corpora must be condensed
+ *     (src/Corpus.jl:523) for parity; tmvb_corpus_create reports duplicates via
+ *     tmvb_corpus_info.
+ */
+#ifndef TMVB_H
+#define TMVB_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TMVB_ABI_VERSION 1
+
+/* status codes (reference: ArgumentError src/gpuLDA.jl:349-351, TopicModelError
+ * src/modelutils.jl:1-5, CorpusError src/Corpus.jl:85-89) */
+#define TMVB_OK          0
+#define TMVB_EINVAL      1   /* bad argument            -> ArgumentError   */
+#define TMVB_ESHAPE      2   /* inconsistent sizes      -> TopicModelError */
+#define TMVB_ECORPUS     3   /* corpus failed check_corp -> CorpusError    */
+#define TMVB_ENOMEM      4
+#define TMVB_EHIP        5   /* HIP runtime failure */
+#define TMVB_ENONFINITE  6   /* non-finite statistic / state */
+#define TMVB_ENODEVICE   7   /* no usable gfx950 device */
+
+typedef struct tmvb_ctx    tmvb_ctx;
+typedef struct tmvb_corpus tmvb_corpus;
+typedef struct tmvb_lda    tmvb_lda;
+typedef struct tmvb_ctm    tmvb_ctm;
+typedef struct tmvb_ctpf   tmvb_ctpf;
+
+int         tmvb_abi_version(void);
+const char* tmvb_last_error(void);
+
+/* Number of visible HIP devices (0 when there is no GPU); never fails. */
+int tmvb_device_count(void);
+
+/* ---- context: replaces cl.create_compute_context() (src/gpuLDA.jl:64) ----
+ * One context = one GPU + one in-order stream.  `hip_stream` may be NULL (the library creates its
+ * own stream) or an existing hipStream_t owned by the caller (e.g. the host framework's current
+ * stream, so that its collectives are ordered with the engine's kernels). */
+int tmvb_ctx_create(int32_t device_id, void* hip_stream, tmvb_ctx** out);
+int tmvb_ctx_destroy(tmvb_ctx* ctx);
+int tmvb_ctx_synchronize(tmvb_ctx* ctx);
+
+/* ---- corpus upload: the corpus half of update_buffer! (src/modelutils.jl:370-388, :438-472) ----
+ * doc_ptr[M+1], terms[nnz], counts[nnz]; rdr_ptr/readers/ratings may be NULL when U == 0.
+ * Validates the check_doc / check_corp rules (src/Corpus.jl:41-50, :111-122): ids in range,
+ * counts and ratings positive, offsets monotone. */
+int tmvb_corpus_create(tmvb_ctx* ctx, int64_t M, int64_t V, int64_t U,
+                       const int64_t* doc_ptr, const int32_t* terms, const int32_t* counts,
+                       const int64_t* rdr_ptr, const int32_t* readers, const int32_t* ratings,
+                       tmvb_corpus** out);
+int tmvb_corpus_destroy(tmvb_corpus* corp);
+
+typedef struct {
+    int64_t M, V, U, nnz, nR;
+    int64_t sum_counts, sum_ratings;
+    int64_t max_doc_len, max_readers;
+    int64_t n_empty_docs;
+    int64_t n_docs_with_duplicate_terms;   /* quirk Q1 */
+    int64_t n_docs_with_duplicate_readers;
+} tmvb_corpus_info_t;
+int tmvb_corpus_info(const tmvb_corpus* corp, tmvb_corpus_info_t* out);
+
+/* ============================== LDA (src/gpuLDA.jl, oracle src/LDA.jl) ============================== */
+
+/* gpuLDA(corp, K) (src/gpuLDA.jl:45-84).  State is initialised as the constructor does
+ * (alpha=1, gamma=1, Elogtheta=psi(1)-psi(K)) except beta, which the reference draws from
+ * Dirichlet(V,1) with Julia's RNG (:57): beta is uniform 1/V until tmvb_lda_set_state. */
+int tmvb_lda_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb_lda** out);
+int tmvb_lda_destroy(tmvb_lda* h);
+
+/* State half of update_buffer! (src/modelutils.jl:390-396) / the field copies of @gpu
+ * (src/macros.jl:115-134).  NULL pointers leave the field unchanged; beta_old / Elogtheta_old
+ * default to copies of beta / Elogtheta (they only feed the pre-training ELBO, src/macros.jl:126-132).
+ * alpha[K], beta[K*V], gamma[K*M], Elogtheta[K*M]. */
+int tmvb_lda_set_state(tmvb_lda* h, const double* alpha, const double* beta, const double* beta_old,
+                       const double* gamma, const double* Elogtheta, const double* Elogtheta_old,
+                       const double* elbo);
+/* update_host! (src/modelutils.jl:501-516) without phi (never materialised).  NULL = skip. */
+int tmvb_lda_get_state(tmvb_lda* h, double* alpha, double* beta, double* beta_old,
+                       double* gamma, double* Elogtheta, double* Elogtheta_old, double* elbo);
+
+/* update_phi! / update_gamma! / update_Elogtheta! sweeps + update_beta!(model, d) for every
+ * document, with the CPU path's per-document early exit (src/LDA.jl:170-180; replaces the launches
+ * at src/gpuLDA.jl:338-339, :294, :263-264, :202).  Accumulates the beta sufficient statistics
+ * (the reference's beta_temp) on the device.  Asynchronous on the context's stream. */
+int tmvb_lda_estep(tmvb_lda* h, int32_t viter, double vtol);
+
+/* Packed sufficient statistics for the host's collective (new: the reference is single-device).
+ * Layout: float32 [ S (K*V, column-major) | Elogtheta_sum (K) ]; *n_f32 = K*V + K.
+ * tmvb_lda_reduce_docs must have run after the E-step for the tail to be valid.
+ * A multi-process host all-reduces (sum) this buffer between tmvb_lda_reduce_docs and
+ * tmvb_lda_update_beta; every rank then runs the identical M-step. */
+int tmvb_lda_stats(tmvb_lda* h, void** dev_ptr, int64_t* n_f32);
+/* Use caller-owned device memory (>= K*V+K floats) for the packed statistics. */
+int tmvb_lda_bind_stats(tmvb_lda* h, void* dev_ptr, int64_t n_f32);
+/* Elogtheta_sum = sum_d Elogtheta[:,d] (src/LDA.jl:98; replaces the kernel at src/gpuLDA.jl:264). */
+int tmvb_lda_reduce_docs(tmvb_lda* h);
+/* Document-sharded runs: M_total = corpus-wide document count used by update_alpha!;
+ * distributed != 0 makes update_alpha! read Elogtheta_sum from the (all-reduced) statistics tail. */
+int tmvb_lda_set_distributed(tmvb_lda* h, int64_t M_total, int32_t distributed);
+
+/* update_beta!(model) (src/LDA.jl:121-125; replaces src/gpuLDA.jl:201-204): beta_old <- beta,
+ * beta <- row-normalised statistics, statistics <- 0. */
+int tmvb_lda_update_beta(tmvb_lda* h);
+/* update_alpha! (src/LDA.jl:97-118; replaces the host fp32 loop at src/gpuLDA.jl:132-154):
+ * fp64 Newton on the device. */
+int tmvb_lda_update_alpha(tmvb_lda* h, int32_t niter, double ntol);
+/* update_elbo! (src/LDA.jl:83-93) evaluated on the device from the current state; returns the sum
+ * over this context's documents (a multi-process host adds the ranks' values) and stores it. */
+int tmvb_lda_update_elbo(tmvb_lda* h, double* elbo);
+
+/* train! (src/gpuLDA.jl:347-376 signature, src/LDA.jl:161-187 semantics incl. check_elbo!
+ * src/modelutils.jl:574-585).  checkelbo <= 0 means Inf.  elbo_traj[iter] (may be NULL) receives the
+ * ELBO per outer iteration (NaN where not evaluated).  Single-context only. */
+int tmvb_lda_train(tmvb_lda* h, int32_t iter, double tol, int32_t niter, double ntol,
+                   int32_t viter, double vtol, int32_t checkelbo,
+                   double* elbo_traj, int32_t* iters_done);
+
+/* Diagnostics: histogram of sweeps per document of the last E-step (hist[0..viter]). */
+int tmvb_lda_sweep_hist(tmvb_lda* h, int64_t* hist, int32_t nbins);
+/* Timing of the last tmvb_lda_estep on the context's stream, from HIP events (ms). */
+int tmvb_lda_last_estep_ms(tmvb_lda* h, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TMVB_H */

@@ -1,0 +1,210 @@
+"""
+GPU parity tests for the LDA path: HIP engine (through the C ABI) vs the fp64 oracle and the
+committed golden fixtures.  Stated fp64->fp32 tolerances:
+  teacher-forced single step : gamma, Elogtheta rel <= 2e-4; beta rel <= 1e-4 on entries > 1e-6;
+                               alpha rel <= 1e-4; ELBO rel <= 1e-6
+  free running               : ELBO rel <= 1e-4 per iteration
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+RTOL_STATE = 2e-4
+RTOL_BETA = 1e-4
+RTOL_ALPHA = 1e-4
+RTOL_ELBO_STEP = 1e-6
+RTOL_ELBO_FREE = 1e-4
+
+
+def load(name):
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    return {k: z[k] for k in z.files}
+
+
+def make_pair(tmvb, oracle, g):
+    K, V = int(g["K"]), int(g["V"])
+    pc = tmvb.PackedCorpus(g["doc_ptr"], g["terms"], g["counts"], V)
+    gm = tmvb.gpuLDA(pc, K)
+    gm.beta = np.asfortranarray(g["beta0"]); gm.beta_old = gm.beta.copy(order="F")
+    gm.update_buffer()
+    om = oracle.LDA(oracle.CSR(g["doc_ptr"], g["terms"], g["counts"], V), K, g["beta0"])
+    return gm, om
+
+
+def rel(a, b, floor=0.0):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    return np.abs(a - b) / np.maximum(np.abs(b), floor if floor else 1e-300)
+
+
+def force(gm, om):
+    """teacher forcing: reset the device state to the oracle's state"""
+    gm.alpha = om.alpha.copy(); gm.beta = om.beta.copy(order="F"); gm.beta_old = om.beta_old.copy(order="F")
+    gm.gamma = om.gamma.copy(order="F"); gm.Elogtheta = om.Elogtheta.copy(order="F")
+    gm.Elogtheta_old = om.Elogtheta_old.copy(order="F")
+    gm.update_buffer()
+
+
+@pytest.mark.parametrize("name", ["lda_m40_v60_k3", "lda_m40_v60_k7", "lda_m30_v50_k70_empty"])
+def test_teacher_forced_fixed_sweeps(tmvb, oracle, name):
+    """vtol=0 pins every document to exactly `viter` sweeps on both sides: pure arithmetic parity."""
+    g = load(name)
+    gm, om = make_pair(tmvb, oracle, g)
+    for it in range(4):
+        force(gm, om)
+        gm.estep(viter=3, vtol=0.0); gm.reduce_docs()
+        om.estep(viter=3, vtol=0.0)
+        gm.update_beta(); om.update_beta()
+        gm.update_alpha(); om.update_alpha()
+        e_g = gm.update_elbo(); e_o = om.update_elbo()
+        gm.update_host()
+        assert rel(gm.gamma, om.gamma).max() <= RTOL_STATE, (it, "gamma")
+        assert rel(gm.Elogtheta, om.Elogtheta).max() <= RTOL_STATE, (it, "Elogtheta")
+        assert rel(gm.Elogtheta_old, om.Elogtheta_old).max() <= RTOL_STATE, (it, "Elogtheta_old")
+        big = om.beta > 1e-6
+        assert rel(gm.beta[big], om.beta[big]).max() <= RTOL_BETA, (it, "beta")
+        assert np.abs(gm.beta - om.beta).max() <= 1e-7
+        assert rel(gm.beta_old, om.beta_old, 1e-6).max() <= 1e-6, (it, "beta_old")
+        assert rel(gm.alpha, om.alpha).max() <= RTOL_ALPHA, (it, "alpha")
+        assert abs(e_g - e_o) <= RTOL_ELBO_STEP * abs(e_o), (it, e_g, e_o)
+        # check_model post-conditions (src/modelutils.jl:255-279)
+        np.testing.assert_allclose(gm.beta.sum(axis=1), 1.0, rtol=1e-5)
+        assert np.all(gm.gamma > 0) and np.all(gm.Elogtheta <= 0)
+
+
+@pytest.mark.parametrize("name", ["lda_m40_v60_k3", "lda_m40_v60_k7"])
+def test_teacher_forced_default_exit_rule(tmvb, oracle, name):
+    """Default vtol: per-document early exit (src/LDA.jl:175).  Documents whose sweep count matches the
+    oracle's must match tightly; mismatches (||delta|| straddling vtol in fp32) are counted."""
+    g = load(name)
+    gm, om = make_pair(tmvb, oracle, g)
+    mism = tot = 0
+    for it in range(4):
+        force(gm, om)
+        gm.estep(); gm.reduce_docs()
+        sw_o = om.estep()
+        gm.update_beta(); om.update_beta()
+        gm.update_alpha(); om.update_alpha()
+        gm.update_host()
+        hist_g = gm.sweep_hist(); hist_o = np.bincount(sw_o, minlength=11)
+        mism += int(np.abs(hist_g - hist_o).sum()) // 2; tot += len(sw_o)
+        if np.array_equal(hist_g, hist_o):
+            assert rel(gm.gamma, om.gamma).max() <= RTOL_STATE
+            assert rel(gm.alpha, om.alpha).max() <= RTOL_ALPHA
+    assert mism <= 0.05 * tot, f"{mism}/{tot} documents changed sweep count"
+
+
+@pytest.mark.parametrize("name", ["lda_m40_v60_k3", "lda_m40_v60_k7", "lda_m30_v50_k70_empty"])
+def test_free_running_train_vs_golden(tmvb, name):
+    g = load(name)
+    K, V = int(g["K"]), int(g["V"])
+    gm = tmvb.gpuLDA(tmvb.PackedCorpus(g["doc_ptr"], g["terms"], g["counts"], V), K)
+    gm.beta = np.asfortranarray(g["beta0"]); gm.beta_old = gm.beta.copy(order="F")
+    traj = gm.train(iter=int(g["iters"]), tol=0.0, checkelbo=1, printelbo=False)
+    gold = g["elbo_traj"]
+    assert len(traj) == len(gold)            # ELBO increases every iteration on these fixtures
+    assert np.all(np.abs(traj - gold) <= RTOL_ELBO_FREE * np.abs(gold)), (traj, gold)
+    assert rel(gm.alpha, g["alpha"]).max() <= 5e-3
+    assert np.abs(gm.beta - g["beta"]).max() <= 5e-4
+    # topics = descending sortperm of beta rows (src/gpuLDA.jl:374), 1-based
+    assert sorted(gm.topics[0].tolist()) == list(range(1, V + 1))
+
+
+def test_long_documents_stream_through_the_tile(tmvb, oracle):
+    """Documents longer than the largest LDS tile take the chunked path (re-gather per sweep)."""
+    rng = np.random.default_rng(5)
+    V, K = 2600, 7
+    docs = []
+    for n in (2000, 1500, 1100, 40, 3, 0, 900):
+        t = np.sort(rng.choice(V, size=n, replace=False)); c = rng.integers(1, 4, size=n)
+        docs.append((t, c))
+    doc_ptr = np.concatenate([[0], np.cumsum([len(t) for t, _ in docs])])
+    terms = np.concatenate([t for t, _ in docs]).astype(np.int32); counts = np.concatenate([c for _, c in docs]).astype(np.int32)
+    beta0 = tmvb.dirichlet_rows(K, V, seed=3)
+    g = dict(K=K, V=V, doc_ptr=doc_ptr, terms=terms, counts=counts, beta0=beta0)
+    gm, om = make_pair(tmvb, oracle, g)
+    for it in range(3):
+        force(gm, om)
+        gm.estep(viter=4, vtol=0.0); gm.reduce_docs(); om.estep(viter=4, vtol=0.0)
+        gm.update_beta(); om.update_beta()
+        gm.update_alpha(); om.update_alpha()
+        e_g = gm.update_elbo(); e_o = om.update_elbo()
+        gm.update_host()
+        assert rel(gm.gamma, om.gamma).max() <= RTOL_STATE
+        big = om.beta > 1e-6
+        assert rel(gm.beta[big], om.beta[big]).max() <= RTOL_BETA
+        assert abs(e_g - e_o) <= RTOL_ELBO_STEP * abs(e_o)
+
+
+def test_k1_closed_form_on_device(tmvb):
+    """K=1: phi == 1, gamma_d = alpha + C_d + eps, beta = empirical unigram distribution."""
+    rng = np.random.default_rng(0)
+    V, M = 9, 12
+    docs = []
+    for _ in range(M):
+        t = np.sort(rng.choice(V, size=rng.integers(1, 6), replace=False)); c = rng.integers(1, 5, size=len(t))
+        docs.append((t, c))
+    doc_ptr = np.concatenate([[0], np.cumsum([len(t) for t, _ in docs])])
+    pc = tmvb.PackedCorpus(doc_ptr, np.concatenate([t for t, _ in docs]), np.concatenate([c for _, c in docs]), V)
+    gm = tmvb.gpuLDA(pc, 1)
+    gm.estep(); gm.reduce_docs(); gm.update_beta(); gm.update_host()
+    np.testing.assert_allclose(gm.gamma[0], 1.0 + pc.C, rtol=1e-6)
+    emp = np.bincount(pc.terms, weights=pc.counts, minlength=V)
+    np.testing.assert_allclose(gm.beta[0], emp / emp.sum(), rtol=1e-6)
+
+
+def test_argument_and_corpus_errors(tmvb):
+    pc = tmvb.PackedCorpus([0, 2], [0, 1], [1, 1], 3)
+    with pytest.raises(ValueError):
+        tmvb.gpuLDA(pc, 0)                                   # src/gpuLDA.jl:47
+    gm = tmvb.gpuLDA(pc, 2)
+    with pytest.raises(ValueError):
+        gm.train(iter=-1, printelbo=False)                   # src/gpuLDA.jl:350
+    with pytest.raises(ValueError):
+        gm.train(tol=-1.0, printelbo=False)                  # src/gpuLDA.jl:349
+    with pytest.raises(ValueError):
+        gm.train(checkelbo=0, printelbo=False)               # src/gpuLDA.jl:351
+    bad = tmvb.PackedCorpus([0, 2], [0, 7], [1, 1], 3)       # term id outside the vocabulary
+    with pytest.raises(tmvb.CorpusError):
+        tmvb.gpuLDA(bad, 2)
+    bad2 = tmvb.PackedCorpus([0, 2], [0, 1], [1, 0], 3)      # non-positive count (check_doc)
+    with pytest.raises(tmvb.CorpusError):
+        tmvb.gpuLDA(bad2, 2)
+
+
+def test_gpu_macro_round_trip(tmvb, oracle):
+    """`@gpu train!(model)` (src/macros.jl:113-150): host LDA -> device -> host, beta renormalised in fp64."""
+    g = load("lda_m40_v60_k7")
+    K, V = int(g["K"]), int(g["V"])
+    m = tmvb.LDA(tmvb.PackedCorpus(g["doc_ptr"], g["terms"], g["counts"], V), K)
+    m.beta = np.asfortranarray(g["beta0"]); m.beta_old = m.beta.copy(order="F")
+    traj = tmvb.gpu_train(m, iter=int(g["iters"]), tol=0.0, printelbo=False)
+    tmvb.check_model(m)                                     # Float64 stochasticity tolerance holds after :147
+    assert np.all(np.abs(traj - g["elbo_traj"]) <= RTOL_ELBO_FREE * np.abs(g["elbo_traj"]))
+    assert np.array_equal(m.Elogtheta, m.Elogtheta_old) and np.array_equal(m.beta, m.beta_old)
+
+
+def test_nsf_scale_invariants(tmvb):
+    """Size-independent properties at a few thousand NSF-shaped documents (full-size run is bench.py):
+    sum_i(gamma_id - alpha_i) = C_d, beta rows stochastic, total statistics mass = total token count."""
+    pc = tmvb.syn_nsf(M=6000, V=25319, seed=1)
+    K = 50
+    gm = tmvb.gpuLDA(pc, K)
+    alpha0 = gm.alpha.copy()
+    gm.estep(); gm.reduce_docs()
+    import ctypes as C
+    ptr, n = gm.stats()
+    gm.update_host()
+    mass = (gm.gamma - alpha0[:, None]).sum(axis=0)
+    np.testing.assert_allclose(mass, pc.C, rtol=2e-5)
+    gm.update_beta(); gm.update_alpha(); gm.update_host()
+    np.testing.assert_allclose(gm.beta.sum(axis=1), 1.0, rtol=1e-5)
+    assert np.all(gm.alpha > 0) and np.all(np.isfinite(gm.alpha))
+    e1 = gm.update_elbo()
+    gm.estep(); gm.reduce_docs(); gm.update_beta(); gm.update_alpha()
+    e2 = gm.update_elbo()
+    assert np.isfinite(e1) and np.isfinite(e2) and e2 > e1

@@ -1,0 +1,16 @@
+"""
+topicmodelsvb.jl_amd -- MI355X (gfx950) variational-inference engine behind TopicModelsVB.jl's
+`TopicModel / train! / @gpu` surface.  Product code: HIP kernels + C ABI in csrc/ (built into
+libtmvb_hip.so), and this thin host mirror of the reference's operator interface.
+
+Import through the `tmvb_amd` shim at the repo root (the directory name is not a legal module name).
+"""
+from ._lib import (CorpusError, DocumentError, EngineError, TopicModelError, build, exported_symbols, lib, LIB_PATH)
+from .corpus import (Corpus, Document, PackedCorpus, check_corp, check_doc, dirichlet_rows, readcorp, syn_citeu,
+                     syn_nsf, synthetic_lda_corpus, writecorp)
+from .lda import LDA, DeviceContext, DeviceCorpus, check_model, gpuLDA, gpu_train
+
+__all__ = ["CorpusError", "DocumentError", "EngineError", "TopicModelError", "build", "exported_symbols", "lib", "LIB_PATH",
+           "Corpus", "Document", "PackedCorpus", "check_corp", "check_doc", "dirichlet_rows", "readcorp", "writecorp",
+           "syn_citeu", "syn_nsf", "synthetic_lda_corpus", "LDA", "DeviceContext", "DeviceCorpus", "check_model", "gpuLDA",
+           "gpu_train"]

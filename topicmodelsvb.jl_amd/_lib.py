@@ -1,0 +1,111 @@
+"""
+ctypes binding of libtmvb_hip.so (the C ABI declared in include/tmvb.h).
+
+There is NO CPU fallback: if the shared library is missing, or no gfx950 device is visible, every
+compute entry point raises.  `build()` cross-compiles the library with hipcc for gfx950 (works
+without a GPU) -- the built .so lives in-tree next to this file.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_HERE, "libtmvb_hip.so")
+SOURCES = ["tmvb_core.hip", "tmvb_lda.hip", "tmvb_ctm.hip", "tmvb_ctpf.hip"]
+
+OK, EINVAL, ESHAPE, ECORPUS, ENOMEM, EHIP, ENONFINITE, ENODEVICE = range(8)
+
+
+class TopicModelError(Exception):
+    """src/modelutils.jl:1-5"""
+
+
+class CorpusError(Exception):
+    """src/Corpus.jl:85-89"""
+
+
+class DocumentError(Exception):
+    """src/Corpus.jl:30-34"""
+
+
+class EngineError(RuntimeError):
+    """HIP runtime / device failure inside libtmvb_hip.so"""
+
+
+class CorpusInfo(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("M", "V", "U", "nnz", "nR", "sum_counts", "sum_ratings", "max_doc_len",
+                                         "max_readers", "n_empty_docs", "n_docs_with_duplicate_terms",
+                                         "n_docs_with_duplicate_readers")]
+
+
+def _sources():
+    out = []
+    for s in SOURCES:
+        p = os.path.join(_HERE, "csrc", s)
+        if os.path.exists(p):
+            out.append(p)
+    return out
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 build of libtmvb_hip.so (in-tree)."""
+    srcs = _sources()
+    deps = srcs + [os.path.join(_HERE, "csrc", "tmvb_internal.h"), os.path.join(_ROOT, "include", "tmvb.h")]
+    if not force and os.path.exists(LIB_PATH):
+        if all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps if os.path.exists(d)):
+            return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-Wno-pass-failed",
+           "-I", os.path.join(_ROOT, "include"), "-I", os.path.join(_HERE, "csrc"), "-o", LIB_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+P_i64 = C.POINTER(C.c_int64)
+P_i32 = C.POINTER(C.c_int32)
+P_dbl = C.POINTER(C.c_double)
+VP = C.c_void_p
+
+
+def exported_symbols():
+    """Every function include/tmvb.h declares (used by the loader test)."""
+    import re
+    hdr = open(os.path.join(_ROOT, "include", "tmvb.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(tmvb_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EngineError(f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc, gfx950). "
+                              "The HIP engine has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        L.tmvb_last_error.restype = C.c_char_p
+        L.tmvb_abi_version.restype = C.c_int
+        L.tmvb_device_count.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def check(rc: int):
+    if rc == OK:
+        return
+    msg = lib().tmvb_last_error().decode("utf-8", "replace")
+    if rc == EINVAL:
+        raise ValueError(msg)              # the reference throws ArgumentError
+    if rc in (ESHAPE, ENONFINITE):
+        raise TopicModelError(msg)
+    if rc == ECORPUS:
+        raise CorpusError(msg)
+    if rc == ENOMEM:
+        raise MemoryError(msg)
+    raise EngineError(msg)

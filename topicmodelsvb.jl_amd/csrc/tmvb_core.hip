@@ -1,0 +1,223 @@
+// tmvb_core.hip -- context, error reporting and corpus upload of libtmvb_hip.so.
+//
+// Replaces: cl.create_compute_context() (src/gpuLDA.jl:64) and the corpus half of update_buffer!
+// (src/modelutils.jl:370-388, :438-472).  The reference uploads flat `terms/counts` + `N_cumsum`
+// and an inverted index (`terms_sortperm`, `J_cumsum`); this engine needs no inverted index
+// (phi is never materialised, statistics are scattered) but adds a length-sorted processing
+// order so that the hardware dispatcher sees the longest documents first.
+#include "tmvb_internal.h"
+
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+
+static thread_local std::string g_last_error;
+
+void tmvb_set_error(const char* fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+extern "C" int tmvb_abi_version(void) { return TMVB_ABI_VERSION; }
+extern "C" const char* tmvb_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int tmvb_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+extern "C" int tmvb_ctx_create(int32_t device_id, void* hip_stream, tmvb_ctx** out)
+{
+    TMVB_REQUIRE(out != nullptr, TMVB_EINVAL, "tmvb_ctx_create: out is NULL");
+    *out = nullptr;
+    int n = tmvb_device_count();
+    TMVB_REQUIRE(n > 0, TMVB_ENODEVICE, "tmvb_ctx_create: no HIP device visible (the HIP engine has no CPU fallback)");
+    TMVB_REQUIRE(device_id >= 0 && device_id < n, TMVB_EINVAL, "tmvb_ctx_create: device_id %d out of range [0,%d)", device_id, n);
+    TMVB_HIP(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    TMVB_HIP(hipGetDeviceProperties(&prop, device_id));
+    TMVB_REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0, TMVB_ENODEVICE,
+                 "tmvb_ctx_create: device %d is %s; this library is built for gfx950 only", device_id, prop.gcnArchName);
+    tmvb_ctx* c = new tmvb_ctx();
+    c->device = device_id;
+    c->num_cu = prop.multiProcessorCount;
+    if (hip_stream) {
+        c->stream = (hipStream_t)hip_stream;
+        c->own_stream = false;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete c;
+            tmvb_set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+            return TMVB_EHIP;
+        }
+        c->own_stream = true;
+    }
+    *out = c;
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_ctx_destroy(tmvb_ctx* ctx)
+{
+    if (!ctx) return TMVB_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_ctx_synchronize(tmvb_ctx* ctx)
+{
+    TMVB_REQUIRE(ctx != nullptr, TMVB_EINVAL, "tmvb_ctx_synchronize: ctx is NULL");
+    TMVB_HIP(hipSetDevice(ctx->device));
+    TMVB_HIP(hipStreamSynchronize(ctx->stream));
+    return TMVB_OK;
+}
+
+template <typename T>
+static int upload(tmvb_ctx* ctx, T** dptr, const T* h, size_t n)
+{
+    *dptr = nullptr;
+    size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    hipError_t e = hipMalloc((void**)dptr, bytes);
+    if (e != hipSuccess) {
+        tmvb_set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+        return TMVB_ENOMEM;
+    }
+    if (n) TMVB_HIP(hipMemcpyAsync(*dptr, h, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_corpus_create(tmvb_ctx* ctx, int64_t M, int64_t V, int64_t U,
+                                  const int64_t* doc_ptr, const int32_t* terms, const int32_t* counts,
+                                  const int64_t* rdr_ptr, const int32_t* readers, const int32_t* ratings,
+                                  tmvb_corpus** out)
+{
+    TMVB_REQUIRE(out != nullptr, TMVB_EINVAL, "tmvb_corpus_create: out is NULL");
+    *out = nullptr;
+    TMVB_REQUIRE(ctx != nullptr, TMVB_EINVAL, "tmvb_corpus_create: ctx is NULL");
+    TMVB_REQUIRE(M >= 0 && V >= 0 && U >= 0, TMVB_EINVAL, "tmvb_corpus_create: negative size");
+    TMVB_REQUIRE(M < (int64_t)INT32_MAX && V < (int64_t)INT32_MAX && U < (int64_t)INT32_MAX, TMVB_EINVAL,
+                 "tmvb_corpus_create: M, V, U must fit int32");
+    TMVB_REQUIRE(doc_ptr != nullptr, TMVB_EINVAL, "tmvb_corpus_create: doc_ptr is NULL");
+    TMVB_REQUIRE(doc_ptr[0] == 0, TMVB_ECORPUS, "doc_ptr[0] must be 0");
+    for (int64_t d = 0; d < M; ++d)
+        TMVB_REQUIRE(doc_ptr[d + 1] >= doc_ptr[d], TMVB_ECORPUS, "document %lld failed check: doc_ptr not monotone", (long long)(d + 1));
+    int64_t nnz = doc_ptr[M];
+    TMVB_REQUIRE(nnz == 0 || (terms && counts), TMVB_EINVAL, "tmvb_corpus_create: terms/counts are NULL");
+    bool has_r = rdr_ptr != nullptr;
+    int64_t nR = 0;
+    if (has_r) {
+        TMVB_REQUIRE(rdr_ptr[0] == 0, TMVB_ECORPUS, "rdr_ptr[0] must be 0");
+        for (int64_t d = 0; d < M; ++d)
+            TMVB_REQUIRE(rdr_ptr[d + 1] >= rdr_ptr[d], TMVB_ECORPUS, "document %lld failed check: rdr_ptr not monotone", (long long)(d + 1));
+        nR = rdr_ptr[M];
+        TMVB_REQUIRE(nR == 0 || (readers && ratings), TMVB_EINVAL, "tmvb_corpus_create: readers/ratings are NULL");
+    }
+    tmvb_corpus* c = new tmvb_corpus();
+    c->ctx = ctx;
+    tmvb_corpus_info_t& I = c->info;
+    I.M = M; I.V = V; I.U = U; I.nnz = nnz; I.nR = nR;
+    c->h_doc_len.resize(M);
+    c->h_rdr_len.assign(M, 0);
+    // check_doc (src/Corpus.jl:41-50) + check_corp (src/Corpus.jl:111-122), 0-based ids
+    std::vector<int32_t> seen_t(V, -1), seen_r(U, -1);
+    for (int64_t d = 0; d < M; ++d) {
+        int64_t a = doc_ptr[d], b = doc_ptr[d + 1];
+        c->h_doc_len[d] = b - a;
+        I.max_doc_len = std::max(I.max_doc_len, b - a);
+        if (b == a) I.n_empty_docs++;
+        bool dup = false;
+        for (int64_t q = a; q < b; ++q) {
+            if (terms[q] < 0 || terms[q] >= V) {
+                delete c;
+                tmvb_set_error("document %lld failed check: term id %d outside the vocabulary [0,%lld)", (long long)(d + 1), terms[q], (long long)V);
+                return TMVB_ECORPUS;
+            }
+            if (counts[q] <= 0) {
+                delete c;
+                tmvb_set_error("document %lld failed check: all counts must be positive integers", (long long)(d + 1));
+                return TMVB_ECORPUS;
+            }
+            I.sum_counts += counts[q];
+            if (seen_t[terms[q]] == (int32_t)d) dup = true;
+            seen_t[terms[q]] = (int32_t)d;
+        }
+        if (dup) I.n_docs_with_duplicate_terms++;
+        if (has_r) {
+            int64_t ra = rdr_ptr[d], rb = rdr_ptr[d + 1];
+            c->h_rdr_len[d] = rb - ra;
+            I.max_readers = std::max(I.max_readers, rb - ra);
+            bool dupr = false;
+            for (int64_t q = ra; q < rb; ++q) {
+                if (readers[q] < 0 || readers[q] >= U) {
+                    delete c;
+                    tmvb_set_error("document %lld failed check: reader id %d outside the users [0,%lld)", (long long)(d + 1), readers[q], (long long)U);
+                    return TMVB_ECORPUS;
+                }
+                if (ratings[q] <= 0) {
+                    delete c;
+                    tmvb_set_error("document %lld failed check: all ratings must be positive integers", (long long)(d + 1));
+                    return TMVB_ECORPUS;
+                }
+                I.sum_ratings += ratings[q];
+                if (seen_r[readers[q]] == (int32_t)d) dupr = true;
+                seen_r[readers[q]] = (int32_t)d;
+            }
+            if (dupr) I.n_docs_with_duplicate_readers++;
+        }
+    }
+    // processing order: longest document first (stable), so that the hardware dispatcher's
+    // in-order workgroup issue behaves like longest-processing-time-first scheduling.
+    c->h_doc_order.resize(M);
+    std::iota(c->h_doc_order.begin(), c->h_doc_order.end(), 0);
+    std::stable_sort(c->h_doc_order.begin(), c->h_doc_order.end(), [&](int32_t x, int32_t y) {
+        int64_t lx = c->h_doc_len[x] + c->h_rdr_len[x], ly = c->h_doc_len[y] + c->h_rdr_len[y];
+        return lx > ly;
+    });
+    (void)hipSetDevice(ctx->device);
+    int rc;
+    std::vector<int64_t> zero_ptr;
+    if (!has_r) zero_ptr.assign(M + 1, 0);
+    if ((rc = upload(ctx, &c->d_doc_ptr, doc_ptr, (size_t)M + 1)) != TMVB_OK ||
+        (rc = upload(ctx, &c->d_terms, terms, (size_t)nnz)) != TMVB_OK ||
+        (rc = upload(ctx, &c->d_counts, counts, (size_t)nnz)) != TMVB_OK ||
+        (rc = upload(ctx, &c->d_rdr_ptr, has_r ? rdr_ptr : zero_ptr.data(), (size_t)M + 1)) != TMVB_OK ||
+        (rc = upload(ctx, &c->d_readers, readers, (size_t)nR)) != TMVB_OK ||
+        (rc = upload(ctx, &c->d_ratings, ratings, (size_t)nR)) != TMVB_OK ||
+        (rc = upload(ctx, &c->d_doc_order, c->h_doc_order.data(), (size_t)M)) != TMVB_OK) {
+        tmvb_corpus_destroy(c);
+        return rc;
+    }
+    TMVB_HIP(hipStreamSynchronize(ctx->stream));
+    *out = c;
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_corpus_destroy(tmvb_corpus* c)
+{
+    if (!c) return TMVB_OK;
+    if (c->ctx) (void)hipSetDevice(c->ctx->device);
+    (void)hipFree(c->d_doc_ptr); (void)hipFree(c->d_terms); (void)hipFree(c->d_counts);
+    (void)hipFree(c->d_rdr_ptr); (void)hipFree(c->d_readers); (void)hipFree(c->d_ratings);
+    (void)hipFree(c->d_doc_order);
+    delete c;
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_corpus_info(const tmvb_corpus* c, tmvb_corpus_info_t* out)
+{
+    TMVB_REQUIRE(c != nullptr && out != nullptr, TMVB_EINVAL, "tmvb_corpus_info: NULL argument");
+    *out = c->info;
+    return TMVB_OK;
+}

@@ -1,0 +1,224 @@
+// tmvb_internal.h -- shared host/device helpers of libtmvb_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdarg>
+#include <cmath>
+#include <string>
+#include <vector>
+
+#include "tmvb.h"
+
+// ------------------------------------------------------------------------------------ errors
+void tmvb_set_error(const char* fmt, ...);
+
+#define TMVB_HIP(call)                                                                         \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            tmvb_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__,    \
+                           __LINE__);                                                          \
+            return TMVB_EHIP;                                                                  \
+        }                                                                                      \
+    } while (0)
+
+#define TMVB_REQUIRE(cond, code, ...)                                                          \
+    do {                                                                                       \
+        if (!(cond)) {                                                                         \
+            tmvb_set_error(__VA_ARGS__);                                                       \
+            return (code);                                                                     \
+        }                                                                                      \
+    } while (0)
+
+// ------------------------------------------------------------------------------------ handles
+struct tmvb_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int num_cu = 256;
+    size_t lds_per_cu = 160 * 1024;
+};
+
+// One launch bucket of the per-document kernels: documents [first, first+count) of doc_order,
+// all with at most `tile_rows` rows (or more, for the last bucket, which streams chunks).
+struct tmvb_bucket {
+    int64_t first = 0, count = 0;
+    int32_t tile_rows = 0;
+};
+
+struct tmvb_corpus {
+    tmvb_ctx* ctx = nullptr;
+    tmvb_corpus_info_t info{};
+    // device CSR
+    int64_t* d_doc_ptr = nullptr;
+    int32_t* d_terms = nullptr;
+    int32_t* d_counts = nullptr;
+    int64_t* d_rdr_ptr = nullptr;
+    int32_t* d_readers = nullptr;
+    int32_t* d_ratings = nullptr;
+    // processing order: documents sorted by descending length (longest first)
+    int32_t* d_doc_order = nullptr;
+    std::vector<int32_t> h_doc_order;
+    std::vector<int64_t> h_doc_len;     // N_d
+    std::vector<int64_t> h_rdr_len;     // R_d
+};
+
+// EPSILON of the reference (src/utils.jl:3) = 2^-99, exactly representable in fp32.
+#define TMVB_EPS_F 1.5777218104420236e-30f
+#define TMVB_EPS_D 1.5777218104420236e-30
+
+// host fp64 digamma (same published algorithm as the device version below)
+static inline double tmvb_digamma_host(double x)
+{
+    double psi = 0.0;
+    if (x < 7.0) {
+        int n = 7 - (int)std::floor(x);
+        for (int v = 1; v < n; ++v) psi -= 1.0 / (x + (double)v);
+        psi -= 1.0 / x;
+        x += (double)n;
+    }
+    double t = 1.0 / x;
+    psi += std::log(x) - 0.5 * t;
+    t *= t;
+    double p = -0.4432598039215686;
+    p = p * t + 0.08333333333333333;
+    p = p * t + -0.021092796092796094;
+    p = p * t + 0.007575757575757576;
+    p = p * t + -0.004166666666666667;
+    p = p * t + 0.003968253968253968;
+    p = p * t + -0.008333333333333333;
+    p = p * t + 0.08333333333333333;
+    return psi - t * p;
+}
+
+static inline int tmvb_kpad(int K)
+{
+    // row stride of the LDS topic tile: smallest 4*odd >= K  (conflict-free ds_read_b128 by rows)
+    int q = (K + 3) / 4;
+    if ((q & 1) == 0) ++q;
+    return 4 * q;
+}
+
+// ------------------------------------------------------------------------------------ device
+#if defined(__HIPCC__)
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+// sum over the 64 lanes of a wave, result uniform (held in an SGPR)
+__device__ __forceinline__ float wave_sum(float v)
+{
+    v += dpp_f<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_f<0x141>(v);   // row_half_mirror
+    v += dpp_f<0x140>(v);   // row_mirror  -> every lane of a 16-lane row holds the row sum
+    float r = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    r += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    r += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    r += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return r;
+}
+
+__device__ __forceinline__ float wave_max(float v)
+{
+    v = fmaxf(v, dpp_f<0xB1>(v));
+    v = fmaxf(v, dpp_f<0x4E>(v));
+    v = fmaxf(v, dpp_f<0x141>(v));
+    v = fmaxf(v, dpp_f<0x140>(v));
+    float r = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    r = fmaxf(r, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16)));
+    r = fmaxf(r, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32)));
+    r = fmaxf(r, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48)));
+    return r;
+}
+
+__device__ __forceinline__ double wave_sum_d(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// digamma, x > 0, fp32.  Same algorithm as the reference's helper (src/utils.jl:21-53):
+// upward recurrence then the asymptotic series; done branch-free with a fixed 6-step shift,
+// and 4 series terms (the 5th is < 1e-10 at x >= 6).
+__device__ __forceinline__ float digamma_f(float x)
+{
+    bool small = x < 6.0f;
+    float y = small ? x + 6.0f : x;
+    float rec = 0.0f;
+    if (small) {
+        // sum_{v=0}^{5} 1/(x+v) as two rational halves to save reciprocals
+        float a0 = x, a1 = x + 1.0f, a2 = x + 2.0f, a3 = x + 3.0f, a4 = x + 4.0f, a5 = x + 5.0f;
+        float p01 = a0 * a1, p23 = a2 * a3, p45 = a4 * a5;
+        // 1/a0+1/a1 = (a0+a1)/p01 etc.
+        float n01 = a0 + a1, n23 = a2 + a3, n45 = a4 + a5;
+        rec = n01 / p01 + (n23 / p23 + n45 / p45);
+    }
+    float t = 1.0f / y;
+    float psi = logf(y) - 0.5f * t;
+    float w = t * t;
+    float p = -0.004166666666666667f;
+    p = p * w + 0.003968253968253968f;
+    p = p * w + -0.008333333333333333f;
+    p = p * w + 0.08333333333333333f;
+    psi -= w * p;
+    return psi - rec;
+}
+
+// fp64 digamma / trigamma: the published SpecialFunctions.jl algorithm (recurrence to x>=7 / 8,
+// then 8-term asymptotic series), used by the alpha Newton step and the ELBO kernels.
+__device__ __forceinline__ double digamma_d(double x)
+{
+    double psi = 0.0;
+    if (x < 7.0) {
+        int n = 7 - (int)floor(x);
+        for (int v = 1; v < n; ++v) psi -= 1.0 / (x + (double)v);
+        psi -= 1.0 / x;
+        x += (double)n;
+    }
+    double t = 1.0 / x;
+    psi += log(x) - 0.5 * t;
+    t *= t;
+    double p = -0.4432598039215686;
+    p = p * t + 0.08333333333333333;
+    p = p * t + -0.021092796092796094;
+    p = p * t + 0.007575757575757576;
+    p = p * t + -0.004166666666666667;
+    p = p * t + 0.003968253968253968;
+    p = p * t + -0.008333333333333333;
+    p = p * t + 0.08333333333333333;
+    return psi - t * p;
+}
+
+__device__ __forceinline__ double trigamma_d(double x)
+{
+    double psi = 0.0;
+    if (x < 8.0) {
+        int n = 8 - (int)floor(x);
+        psi += 1.0 / (x * x);
+        for (int v = 1; v < n; ++v) {
+            double y = x + (double)v;
+            psi += 1.0 / (y * y);
+        }
+        x += (double)n;
+    }
+    double t = 1.0 / x, w = t * t;
+    psi += t + 0.5 * w;
+    double p = -7.092156862745098;
+    p = p * w + 1.1666666666666667;
+    p = p * w + -0.2531135531135531;
+    p = p * w + 0.07575757575757576;
+    p = p * w + -0.03333333333333333;
+    p = p * w + 0.023809523809523808;
+    p = p * w + -0.03333333333333333;
+    p = p * w + 0.16666666666666666;
+    return psi + t * w * p;
+}
+
+#endif  // __HIPCC__

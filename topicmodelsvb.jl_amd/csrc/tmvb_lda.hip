@@ -1,0 +1,863 @@
+// tmvb_lda.hip -- LDA variational-Bayes engine for gfx950 (MI355X).
+//
+// Path: the per-document coordinate ascent of src/LDA.jl:170-180 (update_phi! :150, update_gamma!
+// :143, update_Elogtheta! :136, exit test :175, update_beta!(d) :129) fused into ONE kernel, plus
+// the corpus-wide M-step (update_beta! :121, update_alpha! :97) and update_elbo! (:83) on device.
+// It replaces the seven OpenCL kernels of src/gpuLDA.jl:156-333 but follows the CPU path's
+// semantics (per-document early exit), not the OpenCL path's global-median rule (:361).
+//
+// Data layout in HBM (fp32 state, int32 ids, column-major K x .):
+//   beta[2][K*V] (current / old, ping-pong)   stats[K*V + K] (S = the reference's beta_temp, then
+//   Elogtheta_sum)   gamma, Elogtheta, Elogtheta_old [K*M]   CSR doc_ptr i64[M+1], terms/counts
+//   i32[nnz]   doc_order i32[M] (longest document first).
+//
+// E-step kernel design (one 64-lane wave = one document, one wave per workgroup):
+//   phi is never materialised.  With e = exp(Elogtheta_d) and B = beta[:, terms_d] (N_d x K tile,
+//   gathered ONCE per outer iteration into LDS and reused by all <= viter sweeps), a sweep is two
+//   matrix-vector products through LDS plus K digammas:
+//       s_n = K eps + sum_i B[n][i] e_i              (lane = token, ds_read_b128 rows, stride 4*odd)
+//       w_n = c_n / s_n
+//       gamma_i = alpha_i + eps + e_i sum_n w_n B[n][i] + eps sum_n w_n     (lane = topic)
+//       Elogtheta_i = psi(gamma_i) - psi(sum gamma)
+//   On exit the last sweep's phi.*counts' = w_n (B[n][i] e_i + eps) is scattered into S with
+//   hardware fp32 atomics (coalesced K-float columns).
+//   Documents longer than the LDS tile stream their tokens in chunks (re-gathered per sweep).
+//
+// Roofline: HBM-bound gather/scatter.  Algorithmic bytes per outer iteration:
+//   nnz*(8 + 4K + 4K) + 12*M*K + 12*K*V + 4*(M+1).
+#include "tmvb_internal.h"
+
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+
+#define LDA_MAX_NSLOT 16                      // K <= 1024
+#define LDA_MAX_TILE_BYTES (64 * 1024)
+#define LDA_REDUCE_BLOCKS 256
+
+struct LdaParams {
+    int K, KP;
+    int64_t V;
+    const int64_t* doc_ptr;
+    const int32_t* terms;
+    const int32_t* counts;
+    const int32_t* doc_order;
+    const float* alpha;
+    const float* beta;
+    float* S;
+    float* gamma;
+    float* elog;
+    float* elog_old;
+    uint8_t* sweeps;
+    int viter;
+    float vtol;
+};
+
+// ------------------------------------------------------------------------------ E-step kernel
+template <int NSLOT>
+__global__ __launch_bounds__(64) void lda_estep_kernel(LdaParams p, int64_t first, int tile_rows)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x;
+    const int K = p.K, KP = p.KP;
+    float* Bt = lds;                         // [tile_rows][KP]   beta columns of the document's terms
+    float* e_l = Bt + (size_t)tile_rows * KP;  // [KP]            exp(Elogtheta), zero padded
+    float* w_l = e_l + KP;                   // [tile_rows]       c_n / s_n
+    float* c_l = w_l + tile_rows;            // [tile_rows]       counts as float
+    int* t_l = (int*)(c_l + tile_rows);      // [tile_rows]       term ids
+
+    const int d = p.doc_order[first + blockIdx.x];
+    const int64_t off = p.doc_ptr[d];
+    const int N = (int)(p.doc_ptr[d + 1] - off);
+    const bool single = N <= tile_rows;
+
+    float alpha[NSLOT], elog[NSLOT], elog_old[NSLOT], gam[NSLOT], e[NSLOT];
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+        int i = lane + 64 * s;
+        alpha[s] = (i < K) ? p.alpha[i] : 0.0f;
+        elog[s] = (i < K) ? p.elog[(int64_t)d * K + i] : 0.0f;
+        elog_old[s] = elog[s];
+        gam[s] = 0.0f;
+        e[s] = 0.0f;
+    }
+
+    // gather one chunk of the document into LDS: ids, counts and the beta columns
+    auto load_chunk = [&](int c0, int rows) {
+        for (int n = lane; n < rows; n += 64) {
+            t_l[n] = p.terms[off + c0 + n];
+            c_l[n] = (float)p.counts[off + c0 + n];
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int n = 0; n < rows; ++n) {
+            const int t = __builtin_amdgcn_readfirstlane(t_l[n]);
+            const float* bcol = p.beta + (int64_t)t * K;
+#pragma unroll
+            for (int s = 0; s < NSLOT; ++s) {
+                int i = lane + 64 * s;
+                if (i < KP) Bt[n * KP + i] = (i < K) ? bcol[i] : 0.0f;
+            }
+        }
+        __syncthreads();
+    };
+
+    // phase 1: lane = token.  w_n = c_n / (K eps + B[n,:] . e); returns this lane's sum of w
+    auto phase1 = [&](int rows) -> float {
+        float wl = 0.0f;
+        const float4* er = (const float4*)e_l;
+        for (int n = lane; n < rows; n += 64) {
+            const float4* br = (const float4*)(Bt + n * KP);
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll 4
+            for (int q = 0; q < KP / 4; ++q) {
+                float4 b = br[q], ev = er[q];
+                s0 = fmaf(b.x, ev.x, s0); s1 = fmaf(b.y, ev.y, s1);
+                s2 = fmaf(b.z, ev.z, s2); s3 = fmaf(b.w, ev.w, s3);
+            }
+            float sn = ((s0 + s1) + (s2 + s3)) + (float)K * TMVB_EPS_F;
+            float w = c_l[n] / sn;
+            w_l[n] = w;
+            wl += w;
+        }
+        __syncthreads();
+        return wl;
+    };
+
+    int sweeps = 0;
+    for (int v = 0; v < p.viter; ++v) {
+        ++sweeps;
+        // e = exp(Elogtheta)   (update_phi!, src/LDA.jl:152)
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+            int i = lane + 64 * s;
+            e[s] = (i < K) ? expf(elog[s]) : 0.0f;
+            if (i < KP) e_l[i] = e[s];
+        }
+        __syncthreads();
+        float g[NSLOT];
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) g[s] = 0.0f;
+        float wl = 0.0f;
+        for (int c0 = 0; c0 < N; c0 += tile_rows) {
+            const int rows = min(tile_rows, N - c0);
+            if (!(single && v > 0)) load_chunk(c0, rows);
+            wl += phase1(rows);
+            // phase 2: lane = topic.  g_i += sum_n w_n B[n][i]
+#pragma unroll 4
+            for (int n = 0; n < rows; ++n) {
+                const float w = w_l[n];
+#pragma unroll
+                for (int s = 0; s < NSLOT; ++s) {
+                    int i = lane + 64 * s;
+                    if (i < K) g[s] = fmaf(w, Bt[n * KP + i], g[s]);
+                }
+            }
+            if (!single) __syncthreads();
+        }
+        const float wsum = wave_sum(wl);
+        // update_gamma!  src/LDA.jl:145:  gamma = EPS + (alpha + phi*counts)
+        float gl = 0.0f;
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+            int i = lane + 64 * s;
+            gam[s] = TMVB_EPS_F + (alpha[s] + fmaf(e[s], g[s], TMVB_EPS_F * wsum));
+            if (i < K) gl += gam[s];
+        }
+        const float gsum = wave_sum(gl);
+        const float dgs = digamma_f(gsum);
+        // update_Elogtheta!  src/LDA.jl:137-138 and the exit test :175
+        float dl = 0.0f;
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+            int i = lane + 64 * s;
+            elog_old[s] = elog[s];
+            if (i < K) {
+                elog[s] = digamma_f(gam[s]) - dgs;
+                float df = elog[s] - elog_old[s];
+                dl = fmaf(df, df, dl);
+            }
+        }
+        const float dist2 = wave_sum(dl);
+        if (sqrtf(dist2) < p.vtol) break;
+    }
+
+    if (sweeps > 0) {
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+            int i = lane + 64 * s;
+            if (i < K) {
+                p.gamma[(int64_t)d * K + i] = gam[s];
+                p.elog[(int64_t)d * K + i] = elog[s];
+                p.elog_old[(int64_t)d * K + i] = elog_old[s];
+            }
+        }
+        // update_beta!(model, d)  src/LDA.jl:131: S[:,terms] += phi .* counts' with the LAST sweep's
+        // phi = w_n (B[n][i] e_i + eps)  (e is still exp(Elogtheta_old)).
+        for (int c0 = 0; c0 < N; c0 += tile_rows) {
+            const int rows = min(tile_rows, N - c0);
+            if (!single) {
+                load_chunk(c0, rows);
+                (void)phase1(rows);
+            }
+#pragma unroll 4
+            for (int n = 0; n < rows; ++n) {
+                const int t = __builtin_amdgcn_readfirstlane(t_l[n]);
+                const float w = w_l[n];
+                float* scol = p.S + (int64_t)t * K;
+#pragma unroll
+                for (int s = 0; s < NSLOT; ++s) {
+                    int i = lane + 64 * s;
+                    if (i < K) unsafeAtomicAdd(scol + i, w * fmaf(Bt[n * KP + i], e[s], TMVB_EPS_F));
+                }
+            }
+            if (!single) __syncthreads();
+        }
+    }
+    if (lane == 0) p.sweeps[d] = (uint8_t)min(sweeps, 255);
+}
+
+// ------------------------------------------------------------------------------ reductions
+// partial[block][K] (double) = sum over a strided subset of columns of X (K x ncols, fp32)
+template <int NSLOT>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, int64_t ncols, int K,
+                                                             double* __restrict__ partial)
+{
+    __shared__ double red[4][64 * NSLOT];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t gw = (int64_t)blockIdx.x * 4 + wv, nw = (int64_t)gridDim.x * 4;
+    double acc[NSLOT];
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) acc[s] = 0.0;
+    for (int64_t c = gw; c < ncols; c += nw) {
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+            int i = lane + 64 * s;
+            if (i < K) acc[s] += (double)X[c * K + i];
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) red[wv][lane + 64 * s] = acc[s];
+    __syncthreads();
+    for (int i = threadIdx.x; i < K; i += 256)
+        partial[(int64_t)blockIdx.x * K + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+}
+
+// out_d[i] = sum_b partial[b][i] in a fixed order (deterministic); optional fp32 copy
+__global__ void colsum_final_kernel(const double* __restrict__ partial, int nblocks, int K,
+                                    double* __restrict__ out_d, float* __restrict__ out_f)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < K; i += gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int b = 0; b < nblocks; ++b) s += partial[(int64_t)b * K + i];
+        if (out_d) out_d[i] = s;
+        if (out_f) out_f[i] = (float)s;
+    }
+}
+
+// update_beta!(model)  src/LDA.jl:121-125:  beta_new = S ./ rowsum(S);  S <- 0
+__global__ __launch_bounds__(256) void lda_beta_norm_kernel(float* __restrict__ S, const double* __restrict__ rowsum,
+                                                            float* __restrict__ beta_new, int K, int64_t total)
+{
+    extern __shared__ double rinv[];
+    for (int i = threadIdx.x; i < K; i += blockDim.x) rinv[i] = 1.0 / rowsum[i];
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    for (int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; q < total; q += stride) {
+        int i = (int)(q % K);
+        if (q + 3 < total) {
+            float4 v = *(const float4*)(S + q);
+            float4 o;
+            o.x = (float)((double)v.x * rinv[i]); i = (i + 1 == K) ? 0 : i + 1;
+            o.y = (float)((double)v.y * rinv[i]); i = (i + 1 == K) ? 0 : i + 1;
+            o.z = (float)((double)v.z * rinv[i]); i = (i + 1 == K) ? 0 : i + 1;
+            o.w = (float)((double)v.w * rinv[i]);
+            *(float4*)(beta_new + q) = o;
+            *(float4*)(S + q) = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            for (int64_t r = q; r < total; ++r) {
+                beta_new[r] = (float)((double)S[r] * rinv[i]);
+                S[r] = 0.0f;
+                i = (i + 1 == K) ? 0 : i + 1;
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ double wave_min_d(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// update_alpha!  src/LDA.jl:97-118, fp64, one wave (lane = topic).
+template <int NSLOT>
+__global__ __launch_bounds__(64) void lda_alpha_kernel(int K, double Md, const double* __restrict__ esum_d,
+                                                       const float* __restrict__ esum_f, double* __restrict__ alpha_d,
+                                                       float* __restrict__ alpha_f, int niter, double ntol,
+                                                       int* __restrict__ iters_out)
+{
+    const int lane = threadIdx.x;
+    double a[NSLOT], es[NSLOT], grad[NSLOT], hinv[NSLOT], pp[NSLOT];
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+        int i = lane + 64 * s;
+        a[s] = (i < K) ? alpha_d[i] : 1.0;
+        es[s] = (i < K) ? (esum_f ? (double)esum_f[i] : esum_d[i]) : 0.0;
+    }
+    double nu = (double)K;
+    int it = 0;
+    for (int t = 0; t < niter; ++t) {
+        ++it;
+        double rho = 1.0;
+        double l = 0.0;
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) if (lane + 64 * s < K) l += a[s];
+        const double asum = wave_sum_d(l);
+        const double dgs = digamma_d(asum);
+        double gh = 0.0, hs = 0.0, gn2 = 0.0;
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+            if (lane + 64 * s < K) {
+                grad[s] = nu / a[s] + Md * (dgs - digamma_d(a[s])) + es[s];          // :103
+                hinv[s] = -1.0 / (Md * trigamma_d(a[s]) + nu / (a[s] * a[s]));       // :104
+                gh += grad[s] * hinv[s]; hs += hinv[s]; gn2 += grad[s] * grad[s];
+            } else { grad[s] = 0.0; hinv[s] = 0.0; }
+        }
+        gh = wave_sum_d(gh); hs = wave_sum_d(hs); gn2 = wave_sum_d(gn2);
+        const double c = gh / (1.0 / (Md * trigamma_d(asum)) + hs);                  // :105
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) pp[s] = (grad[s] - c) * hinv[s];
+        for (int guard = 0; guard < 1200; ++guard) {                                 // :107-109
+            double mn = INFINITY;
+#pragma unroll
+            for (int s = 0; s < NSLOT; ++s) if (lane + 64 * s < K) mn = fmin(mn, a[s] - rho * pp[s]);
+            mn = wave_min_d(mn);
+            if (mn < 0.0) rho *= 0.5; else break;
+        }
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {                                            // :110 @finite
+            if (lane + 64 * s < K) {
+                double na = fabs(a[s] - rho * pp[s]);
+                na = fmin(na, 1.7976931348623157e308);
+                a[s] = (a[s] > 0.0) ? na : ((a[s] < 0.0) ? -na : 0.0);
+            }
+        }
+        if ((rho * sqrt(gn2) < ntol) && (nu / (double)K < ntol)) break;              // :112
+        nu *= 0.5;                                                                   // :115
+    }
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+        int i = lane + 64 * s;
+        if (i < K) {
+            double v = a[s] + TMVB_EPS_D;                                            // :117
+            alpha_d[i] = v;
+            alpha_f[i] = (float)v;
+        }
+    }
+    if (lane == 0 && iters_out) *iters_out = it;
+}
+
+// ------------------------------------------------------------------------------ ELBO
+// update_elbo!  src/LDA.jl:83-93 per document (terms :50-80 without the corpus-level constant of
+// Elogptheta, added by lda_elbo_final_kernel).  One wave per document, lane = topic.
+template <int NSLOT>
+__global__ __launch_bounds__(64) void lda_elbo_kernel(int K, const int64_t* __restrict__ doc_ptr,
+                                                      const int32_t* __restrict__ terms, const int32_t* __restrict__ counts,
+                                                      const double* __restrict__ alpha_d, const float* __restrict__ beta,
+                                                      const float* __restrict__ beta_old, const float* __restrict__ gamma,
+                                                      const float* __restrict__ elog, const float* __restrict__ elog_old,
+                                                      double* __restrict__ doc_val)
+{
+    const int lane = threadIdx.x;
+    const int d = blockIdx.x;
+    const int64_t off = doc_ptr[d];
+    const int N = (int)(doc_ptr[d + 1] - off);
+    float eo[NSLOT];
+    double pc[NSLOT], acc = 0.0;
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+        int i = lane + 64 * s;
+        eo[s] = (i < K) ? expf(elog_old[(int64_t)d * K + i]) : 0.0f;
+        pc[s] = 0.0;
+    }
+    for (int n = 0; n < N; ++n) {
+        const int t = terms[off + n];
+        const float c = (float)counts[off + n];
+        float x[NSLOT], xl = 0.0f;
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+            int i = lane + 64 * s;
+            x[s] = (i < K) ? fmaf(beta_old[(int64_t)t * K + i], eo[s], TMVB_EPS_F) : 0.0f;   // :87
+            xl += x[s];
+        }
+        const float inv = 1.0f / wave_sum(xl);                                               // :88
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+            int i = lane + 64 * s;
+            if (i < K) {
+                float ph = x[s] * inv;
+                double cp = (double)(c * ph);
+                pc[s] += cp;
+                acc += cp * (double)logf(beta[(int64_t)t * K + i] + TMVB_EPS_F);             // Elogpw :65
+                if (ph > 0.0f) acc -= cp * (double)logf(ph);                                 // -Elogqz :78
+            }
+        }
+    }
+    double gl = 0.0;
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+        int i = lane + 64 * s;
+        if (i < K) {
+            double el = (double)elog[(int64_t)d * K + i];
+            double g = (double)gamma[(int64_t)d * K + i];
+            acc += (alpha_d[i] - 1.0) * el;                                                  // Elogptheta :51 (dot part)
+            acc += pc[s] * el;                                                               // Elogpz :58
+            if (K > 1) acc += lgamma(g) - (g - 1.0) * digamma_d(g);                          // -Elogqtheta :72 (utils.jl:172-176)
+            gl += g;
+        }
+    }
+    const double g0 = wave_sum_d(gl);
+    double tot = wave_sum_d(acc);
+    if (K > 1) tot += -lgamma(g0) + (g0 - (double)K) * digamma_d(g0);
+    if (lane == 0) doc_val[d] = tot;
+}
+
+// elbo = sum_d doc_val[d] + M * (lgamma(sum alpha) - sum lgamma(alpha))   (src/LDA.jl:51, finite())
+__global__ __launch_bounds__(1024) void lda_elbo_final_kernel(const double* __restrict__ doc_val, int64_t M, int K,
+                                                              const double* __restrict__ alpha_d, double* __restrict__ out)
+{
+    __shared__ double red[1024];
+    double s = 0.0;
+    for (int64_t d = threadIdx.x; d < M; d += 1024) s += doc_val[d];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double asum = 0.0, lg = 0.0;
+        for (int i = 0; i < K; ++i) { asum += alpha_d[i]; lg += lgamma(alpha_d[i]); }
+        double a = lgamma(asum);
+        a = fmin(fmax(a, -1.7976931348623157e308), 1.7976931348623157e308);
+        lg = fmin(fmax(lg, -1.7976931348623157e308), 1.7976931348623157e308);
+        out[0] = red[0] + (double)M * (a - lg);
+    }
+}
+
+// ------------------------------------------------------------------------------ host side
+struct tmvb_lda {
+    tmvb_ctx* ctx = nullptr;
+    tmvb_corpus* corp = nullptr;
+    int K = 0, KP = 0, nslot = 1;
+    int64_t M = 0, V = 0;
+    int64_t M_total = 0;
+    bool distributed = false;
+    // device state
+    double* d_alpha_d = nullptr;
+    float* d_alpha_f = nullptr;
+    float* d_beta[2] = {nullptr, nullptr};
+    int cur = 0;                       // d_beta[cur] = beta, d_beta[cur^1] = beta_old
+    float* d_stats = nullptr;          // S (K*V) | Elogtheta_sum (K)
+    bool own_stats = true;
+    float* d_gamma = nullptr;
+    float* d_elog = nullptr;
+    float* d_elog_old = nullptr;
+    uint8_t* d_sweeps = nullptr;
+    int32_t* d_doc_order = nullptr;
+    double* d_partial = nullptr;       // [LDA_REDUCE_BLOCKS][K]
+    double* d_rowsum = nullptr;        // [K]
+    double* d_esum = nullptr;          // [K]
+    double* d_doc_val = nullptr;       // [M]
+    double* d_elbo = nullptr;          // [1]
+    int* d_iters = nullptr;
+    double elbo = 0.0;
+    std::vector<tmvb_bucket> buckets;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+};
+
+template <typename F>
+static int dispatch_nslot(int nslot, F&& f)
+{
+    switch (nslot) {
+        case 1: return f(std::integral_constant<int, 1>());
+        case 2: return f(std::integral_constant<int, 2>());
+        case 3: case 4: return f(std::integral_constant<int, 4>());
+        case 5: case 6: case 7: case 8: return f(std::integral_constant<int, 8>());
+        default: return f(std::integral_constant<int, 16>());
+    }
+}
+
+static size_t lda_tile_bytes(int rows, int KP) { return ((size_t)rows * KP + KP + 3 * (size_t)rows) * sizeof(float); }
+
+static void lda_build_buckets(tmvb_lda* h, std::vector<int32_t>& order)
+{
+    const std::vector<int64_t>& len = h->corp->h_doc_len;
+    order.resize(h->M);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return len[x] > len[y]; });
+    std::vector<int> tiles;
+    for (int r = 16; lda_tile_bytes(r, h->KP) <= LDA_MAX_TILE_BYTES && r <= 4096; r *= 2) tiles.push_back(r);
+    if (tiles.empty()) tiles.push_back(4);
+    h->buckets.clear();
+    int64_t pos = 0;
+    // documents longer than the largest tile stream chunks through the largest tile
+    int tmax = tiles.back();
+    int64_t cnt = 0;
+    while (pos + cnt < h->M && len[order[pos + cnt]] > tmax) ++cnt;
+    if (cnt) h->buckets.push_back({pos, cnt, tmax});
+    pos += cnt;
+    for (int b = (int)tiles.size() - 1; b >= 0; --b) {
+        int64_t lo = (b > 0) ? tiles[b - 1] : -1;
+        cnt = 0;
+        while (pos + cnt < h->M && len[order[pos + cnt]] > lo) ++cnt;
+        if (cnt) h->buckets.push_back({pos, cnt, tiles[b]});
+        pos += cnt;
+    }
+}
+
+template <typename T>
+static int dmalloc(T** p, size_t n)
+{
+    *p = nullptr;
+    size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    hipError_t e = hipMalloc((void**)p, bytes);
+    if (e != hipSuccess) {
+        tmvb_set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+        return TMVB_ENOMEM;
+    }
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_lda_destroy(tmvb_lda* h)
+{
+    if (!h) return TMVB_OK;
+    if (h->ctx) (void)hipSetDevice(h->ctx->device);
+    (void)hipFree(h->d_alpha_d); (void)hipFree(h->d_alpha_f); (void)hipFree(h->d_beta[0]); (void)hipFree(h->d_beta[1]);
+    if (h->own_stats) (void)hipFree(h->d_stats);
+    (void)hipFree(h->d_gamma); (void)hipFree(h->d_elog); (void)hipFree(h->d_elog_old); (void)hipFree(h->d_sweeps);
+    (void)hipFree(h->d_doc_order); (void)hipFree(h->d_partial); (void)hipFree(h->d_rowsum); (void)hipFree(h->d_esum);
+    (void)hipFree(h->d_doc_val); (void)hipFree(h->d_elbo); (void)hipFree(h->d_iters);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    delete h;
+    return TMVB_OK;
+}
+
+static int upload_f32(tmvb_ctx* ctx, float* dst, const double* src, size_t n)
+{
+    std::vector<float> tmp(n);
+    for (size_t q = 0; q < n; ++q) tmp[q] = (float)src[q];
+    TMVB_HIP(hipMemcpyAsync(dst, tmp.data(), n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    TMVB_HIP(hipStreamSynchronize(ctx->stream));
+    return TMVB_OK;
+}
+
+static int download_f32(tmvb_ctx* ctx, double* dst, const float* src, size_t n)
+{
+    std::vector<float> tmp(n);
+    TMVB_HIP(hipMemcpyAsync(tmp.data(), src, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    TMVB_HIP(hipStreamSynchronize(ctx->stream));
+    for (size_t q = 0; q < n; ++q) dst[q] = (double)tmp[q];
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_lda_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb_lda** out)
+{
+    TMVB_REQUIRE(out != nullptr, TMVB_EINVAL, "tmvb_lda_create: out is NULL");
+    *out = nullptr;
+    TMVB_REQUIRE(ctx && corp, TMVB_EINVAL, "tmvb_lda_create: NULL context or corpus");
+    TMVB_REQUIRE(K > 0, TMVB_EINVAL, "number of topics must be a positive integer.");   // src/gpuLDA.jl:47
+    TMVB_REQUIRE(K <= 64 * LDA_MAX_NSLOT, TMVB_EINVAL, "tmvb_lda_create: K=%d exceeds the supported maximum %d", K, 64 * LDA_MAX_NSLOT);
+    TMVB_HIP(hipSetDevice(ctx->device));
+    tmvb_lda* h = new tmvb_lda();
+    h->ctx = ctx; h->corp = corp; h->K = K; h->KP = tmvb_kpad(K); h->nslot = (K + 63) / 64;
+    h->M = corp->info.M; h->V = corp->info.V; h->M_total = h->M;
+    const size_t KV = (size_t)K * h->V, KM = (size_t)K * h->M;
+    int rc;
+    if ((rc = dmalloc(&h->d_alpha_d, K)) || (rc = dmalloc(&h->d_alpha_f, K)) || (rc = dmalloc(&h->d_beta[0], KV)) ||
+        (rc = dmalloc(&h->d_beta[1], KV)) || (rc = dmalloc(&h->d_stats, KV + K)) || (rc = dmalloc(&h->d_gamma, KM)) ||
+        (rc = dmalloc(&h->d_elog, KM)) || (rc = dmalloc(&h->d_elog_old, KM)) || (rc = dmalloc(&h->d_sweeps, (size_t)h->M)) ||
+        (rc = dmalloc(&h->d_doc_order, (size_t)h->M)) || (rc = dmalloc(&h->d_partial, (size_t)LDA_REDUCE_BLOCKS * K)) ||
+        (rc = dmalloc(&h->d_rowsum, K)) || (rc = dmalloc(&h->d_esum, K)) || (rc = dmalloc(&h->d_doc_val, (size_t)h->M)) ||
+        (rc = dmalloc(&h->d_elbo, 1)) || (rc = dmalloc(&h->d_iters, 1))) {
+        tmvb_lda_destroy(h);
+        return rc;
+    }
+    std::vector<int32_t> order;
+    lda_build_buckets(h, order);
+    if (h->M) TMVB_HIP(hipMemcpyAsync(h->d_doc_order, order.data(), (size_t)h->M * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    TMVB_HIP(hipMemsetAsync(h->d_stats, 0, (KV + K) * sizeof(float), ctx->stream));
+    TMVB_HIP(hipMemsetAsync(h->d_sweeps, 0, std::max<size_t>((size_t)h->M, 1), ctx->stream));
+    TMVB_HIP(hipEventCreate(&h->ev0));
+    TMVB_HIP(hipEventCreate(&h->ev1));
+    // constructor state, src/gpuLDA.jl:53-61 (beta: uniform, see tmvb.h)
+    std::vector<double> alpha(K, 1.0), beta(KV, h->V ? 1.0 / (double)h->V : 0.0), gamma(KM, 1.0);
+    const double e0 = -0.5772156649015329 - tmvb_digamma_host((double)K);   // -(eulergamma + digamma(K)), src/gpuLDA.jl:57
+    std::vector<double> elog(KM, e0);
+    TMVB_HIP(hipStreamSynchronize(ctx->stream));
+    rc = tmvb_lda_set_state(h, alpha.data(), beta.data(), nullptr, gamma.data(), elog.data(), nullptr, nullptr);
+    if (rc) { tmvb_lda_destroy(h); return rc; }
+    *out = h;
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_lda_set_state(tmvb_lda* h, const double* alpha, const double* beta, const double* beta_old,
+                                  const double* gamma, const double* Elogtheta, const double* Elogtheta_old,
+                                  const double* elbo)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_lda_set_state: handle is NULL");
+    tmvb_ctx* ctx = h->ctx;
+    TMVB_HIP(hipSetDevice(ctx->device));
+    const size_t K = h->K, KV = K * (size_t)h->V, KM = K * (size_t)h->M;
+    int rc;
+    if (alpha) {
+        for (size_t i = 0; i < K; ++i)   // check_model: alpha finite and positive (src/modelutils.jl:262-264)
+            TMVB_REQUIRE(std::isfinite(alpha[i]) && alpha[i] > 0.0, TMVB_ENONFINITE, "alpha must be finite and positive.");
+        TMVB_HIP(hipMemcpyAsync(h->d_alpha_d, alpha, K * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        if ((rc = upload_f32(ctx, h->d_alpha_f, alpha, K))) return rc;
+    }
+    if (beta) {
+        if ((rc = upload_f32(ctx, h->d_beta[h->cur], beta, KV))) return rc;
+        if (!beta_old && (rc = upload_f32(ctx, h->d_beta[h->cur ^ 1], beta, KV))) return rc;
+    }
+    if (beta_old && (rc = upload_f32(ctx, h->d_beta[h->cur ^ 1], beta_old, KV))) return rc;
+    if (gamma && (rc = upload_f32(ctx, h->d_gamma, gamma, KM))) return rc;
+    if (Elogtheta) {
+        if ((rc = upload_f32(ctx, h->d_elog, Elogtheta, KM))) return rc;
+        if (!Elogtheta_old && (rc = upload_f32(ctx, h->d_elog_old, Elogtheta, KM))) return rc;
+    }
+    if (Elogtheta_old && (rc = upload_f32(ctx, h->d_elog_old, Elogtheta_old, KM))) return rc;
+    if (elbo) h->elbo = *elbo;
+    TMVB_HIP(hipStreamSynchronize(ctx->stream));
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_lda_get_state(tmvb_lda* h, double* alpha, double* beta, double* beta_old, double* gamma,
+                                  double* Elogtheta, double* Elogtheta_old, double* elbo)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_lda_get_state: handle is NULL");
+    tmvb_ctx* ctx = h->ctx;
+    TMVB_HIP(hipSetDevice(ctx->device));
+    const size_t K = h->K, KV = K * (size_t)h->V, KM = K * (size_t)h->M;
+    int rc;
+    if (alpha) {
+        TMVB_HIP(hipMemcpyAsync(alpha, h->d_alpha_d, K * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        TMVB_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    if (beta && (rc = download_f32(ctx, beta, h->d_beta[h->cur], KV))) return rc;
+    if (beta_old && (rc = download_f32(ctx, beta_old, h->d_beta[h->cur ^ 1], KV))) return rc;
+    if (gamma && (rc = download_f32(ctx, gamma, h->d_gamma, KM))) return rc;
+    if (Elogtheta && (rc = download_f32(ctx, Elogtheta, h->d_elog, KM))) return rc;
+    if (Elogtheta_old && (rc = download_f32(ctx, Elogtheta_old, h->d_elog_old, KM))) return rc;
+    if (elbo) *elbo = h->elbo;
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_lda_estep(tmvb_lda* h, int32_t viter, double vtol)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_lda_estep: handle is NULL");
+    TMVB_REQUIRE(viter >= 0, TMVB_EINVAL, "iteration parameters must be nonnegative.");     // src/gpuLDA.jl:350
+    TMVB_REQUIRE(vtol >= 0, TMVB_EINVAL, "tolerance parameters must be nonnegative.");      // src/gpuLDA.jl:349
+    tmvb_ctx* ctx = h->ctx;
+    TMVB_HIP(hipSetDevice(ctx->device));
+    LdaParams p;
+    p.K = h->K; p.KP = h->KP; p.V = h->V;
+    p.doc_ptr = h->corp->d_doc_ptr; p.terms = h->corp->d_terms; p.counts = h->corp->d_counts;
+    p.doc_order = h->d_doc_order;
+    p.alpha = h->d_alpha_f; p.beta = h->d_beta[h->cur]; p.S = h->d_stats;
+    p.gamma = h->d_gamma; p.elog = h->d_elog; p.elog_old = h->d_elog_old; p.sweeps = h->d_sweeps;
+    p.viter = viter; p.vtol = (float)vtol;
+    TMVB_HIP(hipEventRecord(h->ev0, ctx->stream));
+    for (const tmvb_bucket& b : h->buckets) {
+        const size_t lds = lda_tile_bytes(b.tile_rows, h->KP);
+        int rc = dispatch_nslot(h->nslot, [&](auto ns) -> int {
+            constexpr int NS = decltype(ns)::value;
+            hipLaunchKernelGGL((lda_estep_kernel<NS>), dim3((unsigned)b.count), dim3(64), lds, ctx->stream, p, b.first, b.tile_rows);
+            return TMVB_OK;
+        });
+        if (rc) return rc;
+        TMVB_HIP(hipGetLastError());
+    }
+    TMVB_HIP(hipEventRecord(h->ev1, ctx->stream));
+    h->timed = true;
+    return TMVB_OK;
+}
+
+static int colsum(tmvb_lda* h, const float* X, int64_t ncols, double* out_d, float* out_f)
+{
+    tmvb_ctx* ctx = h->ctx;
+    int nb = (int)std::min<int64_t>(LDA_REDUCE_BLOCKS, std::max<int64_t>(1, (ncols + 3) / 4));
+    int rc = dispatch_nslot(h->nslot, [&](auto ns) -> int {
+        constexpr int NS = decltype(ns)::value;
+        hipLaunchKernelGGL((colsum_partial_kernel<NS>), dim3(nb), dim3(256), 0, ctx->stream, X, ncols, h->K, h->d_partial);
+        return TMVB_OK;
+    });
+    if (rc) return rc;
+    TMVB_HIP(hipGetLastError());
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((h->K + 255) / 256), dim3(256), 0, ctx->stream, h->d_partial, nb, h->K, out_d, out_f);
+    TMVB_HIP(hipGetLastError());
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_lda_reduce_docs(tmvb_lda* h)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_lda_reduce_docs: handle is NULL");
+    TMVB_HIP(hipSetDevice(h->ctx->device));
+    return colsum(h, h->d_elog, h->M, h->d_esum, h->d_stats + (size_t)h->K * h->V);
+}
+
+extern "C" int tmvb_lda_stats(tmvb_lda* h, void** dev_ptr, int64_t* n_f32)
+{
+    TMVB_REQUIRE(h && dev_ptr && n_f32, TMVB_EINVAL, "tmvb_lda_stats: NULL argument");
+    *dev_ptr = h->d_stats;
+    *n_f32 = (int64_t)h->K * h->V + h->K;
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_lda_bind_stats(tmvb_lda* h, void* dev_ptr, int64_t n_f32)
+{
+    TMVB_REQUIRE(h && dev_ptr, TMVB_EINVAL, "tmvb_lda_bind_stats: NULL argument");
+    const int64_t need = (int64_t)h->K * h->V + h->K;
+    TMVB_REQUIRE(n_f32 >= need, TMVB_ESHAPE, "tmvb_lda_bind_stats: buffer holds %lld floats, need %lld", (long long)n_f32, (long long)need);
+    TMVB_HIP(hipSetDevice(h->ctx->device));
+    TMVB_HIP(hipMemcpyAsync(dev_ptr, h->d_stats, (size_t)need * sizeof(float), hipMemcpyDeviceToDevice, h->ctx->stream));
+    TMVB_HIP(hipStreamSynchronize(h->ctx->stream));
+    if (h->own_stats) (void)hipFree(h->d_stats);
+    h->d_stats = (float*)dev_ptr;
+    h->own_stats = false;
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_lda_set_distributed(tmvb_lda* h, int64_t M_total, int32_t distributed)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_lda_set_distributed: handle is NULL");
+    TMVB_REQUIRE(M_total >= h->M, TMVB_ESHAPE, "tmvb_lda_set_distributed: M_total < local M");
+    h->M_total = M_total;
+    h->distributed = distributed != 0;
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_lda_update_beta(tmvb_lda* h)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_lda_update_beta: handle is NULL");
+    tmvb_ctx* ctx = h->ctx;
+    TMVB_HIP(hipSetDevice(ctx->device));
+    int rc = colsum(h, h->d_stats, h->V, h->d_rowsum, nullptr);
+    if (rc) return rc;
+    const int64_t total = (int64_t)h->K * h->V;
+    int nb = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (total / 4 + 255) / 256));
+    hipLaunchKernelGGL(lda_beta_norm_kernel, dim3(nb), dim3(256), (size_t)h->K * sizeof(double), ctx->stream,
+                       h->d_stats, h->d_rowsum, h->d_beta[h->cur ^ 1], h->K, total);
+    TMVB_HIP(hipGetLastError());
+    h->cur ^= 1;   // beta_old <- beta, beta <- new   (src/LDA.jl:122-123)
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_lda_update_alpha(tmvb_lda* h, int32_t niter, double ntol)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_lda_update_alpha: handle is NULL");
+    TMVB_REQUIRE(niter >= 0, TMVB_EINVAL, "iteration parameters must be nonnegative.");
+    TMVB_REQUIRE(ntol >= 0, TMVB_EINVAL, "tolerance parameters must be nonnegative.");
+    tmvb_ctx* ctx = h->ctx;
+    TMVB_HIP(hipSetDevice(ctx->device));
+    const float* ef = h->distributed ? h->d_stats + (size_t)h->K * h->V : nullptr;
+    int rc = dispatch_nslot(h->nslot, [&](auto ns) -> int {
+        constexpr int NS = decltype(ns)::value;
+        hipLaunchKernelGGL((lda_alpha_kernel<NS>), dim3(1), dim3(64), 0, ctx->stream, h->K, (double)h->M_total, h->d_esum, ef,
+                           h->d_alpha_d, h->d_alpha_f, niter, ntol, h->d_iters);
+        return TMVB_OK;
+    });
+    if (rc) return rc;
+    TMVB_HIP(hipGetLastError());
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_lda_update_elbo(tmvb_lda* h, double* elbo)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_lda_update_elbo: handle is NULL");
+    tmvb_ctx* ctx = h->ctx;
+    TMVB_HIP(hipSetDevice(ctx->device));
+    if (h->M > 0) {
+        int rc = dispatch_nslot(h->nslot, [&](auto ns) -> int {
+            constexpr int NS = decltype(ns)::value;
+            hipLaunchKernelGGL((lda_elbo_kernel<NS>), dim3((unsigned)h->M), dim3(64), 0, ctx->stream, h->K, h->corp->d_doc_ptr,
+                               h->corp->d_terms, h->corp->d_counts, h->d_alpha_d, h->d_beta[h->cur], h->d_beta[h->cur ^ 1],
+                               h->d_gamma, h->d_elog, h->d_elog_old, h->d_doc_val);
+            return TMVB_OK;
+        });
+        if (rc) return rc;
+        TMVB_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(lda_elbo_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, h->d_doc_val, h->M, h->K, h->d_alpha_d, h->d_elbo);
+    TMVB_HIP(hipGetLastError());
+    double v = 0.0;
+    TMVB_HIP(hipMemcpyAsync(&v, h->d_elbo, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    TMVB_HIP(hipStreamSynchronize(ctx->stream));
+    h->elbo = v;
+    if (elbo) *elbo = v;
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_lda_train(tmvb_lda* h, int32_t iter, double tol, int32_t niter, double ntol, int32_t viter,
+                              double vtol, int32_t checkelbo, double* elbo_traj, int32_t* iters_done)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_lda_train: handle is NULL");
+    // src/gpuLDA.jl:349-351
+    TMVB_REQUIRE(tol >= 0 && ntol >= 0 && vtol >= 0, TMVB_EINVAL, "tolerance parameters must be nonnegative.");
+    TMVB_REQUIRE(iter >= 0 && niter >= 0 && viter >= 0, TMVB_EINVAL, "iteration parameters must be nonnegative.");
+    TMVB_REQUIRE(!h->distributed, TMVB_EINVAL, "tmvb_lda_train drives one context; a document-sharded host composes estep/reduce_docs/update_* itself");
+    if (iters_done) *iters_done = 0;
+    if (h->corp->info.nnz == 0) iter = 0;                                   // src/gpuLDA.jl:352
+    int rc;
+    double e_old = h->elbo;
+    if (checkelbo > 0 && checkelbo <= iter) {                               // :353
+        if ((rc = tmvb_lda_update_elbo(h, &e_old))) return rc;
+    }
+    int done = 0;
+    for (int k = 1; k <= iter; ++k) {
+        ++done;
+        if ((rc = tmvb_lda_estep(h, viter, vtol))) return rc;               // :355-364 (CPU semantics src/LDA.jl:170-180)
+        if ((rc = tmvb_lda_reduce_docs(h))) return rc;
+        if ((rc = tmvb_lda_update_beta(h))) return rc;                      // :365
+        if ((rc = tmvb_lda_update_alpha(h, niter, ntol))) return rc;        // :366
+        if (elbo_traj) elbo_traj[k - 1] = NAN;
+        if (checkelbo > 0 && (k % checkelbo) == 0) {                        // check_elbo! src/modelutils.jl:574-585
+            double e_new;
+            if ((rc = tmvb_lda_update_elbo(h, &e_new))) return rc;
+            TMVB_REQUIRE(std::isfinite(e_new), TMVB_ENONFINITE, "elbo must be finite.");
+            if (elbo_traj) elbo_traj[k - 1] = e_new;
+            double delta = e_new - e_old;
+            e_old = e_new;
+            if (delta < tol) break;
+        }
+    }
+    TMVB_HIP(hipStreamSynchronize(h->ctx->stream));
+    if (iters_done) *iters_done = done;
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_lda_sweep_hist(tmvb_lda* h, int64_t* hist, int32_t nbins)
+{
+    TMVB_REQUIRE(h && hist && nbins > 0, TMVB_EINVAL, "tmvb_lda_sweep_hist: bad argument");
+    std::vector<uint8_t> sw((size_t)h->M);
+    TMVB_HIP(hipSetDevice(h->ctx->device));
+    if (h->M) TMVB_HIP(hipMemcpyAsync(sw.data(), h->d_sweeps, (size_t)h->M, hipMemcpyDeviceToHost, h->ctx->stream));
+    TMVB_HIP(hipStreamSynchronize(h->ctx->stream));
+    for (int b = 0; b < nbins; ++b) hist[b] = 0;
+    for (uint8_t s : sw) hist[std::min<int>(s, nbins - 1)]++;
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_lda_last_estep_ms(tmvb_lda* h, float* ms)
+{
+    TMVB_REQUIRE(h && ms, TMVB_EINVAL, "tmvb_lda_last_estep_ms: NULL argument");
+    TMVB_REQUIRE(h->timed, TMVB_EINVAL, "tmvb_lda_last_estep_ms: no E-step has run");
+    TMVB_HIP(hipSetDevice(h->ctx->device));
+    TMVB_HIP(hipEventSynchronize(h->ev1));
+    TMVB_HIP(hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return TMVB_OK;
+}
