@@ -144,6 +144,8 @@ int tmvb_lda_train(tmvb_lda* h, int32_t iter, double tol, int32_t niter, double 
 
 /* Diagnostics: histogram of sweeps per document of the last E-step (hist[0..viter]). */
 int tmvb_lda_sweep_hist(tmvb_lda* h, int64_t* hist, int32_t nbins);
+/* Number of kernel launches one tmvb_lda_estep issues (one per document-length bucket). */
+int tmvb_lda_estep_launches(tmvb_lda* h, int32_t* n);
 /* Timing of the last tmvb_lda_estep on the context's stream, from HIP events (ms). */
 int tmvb_lda_last_estep_ms(tmvb_lda* h, float* ms);
 

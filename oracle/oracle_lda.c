@@ -124,7 +124,7 @@ int orc_lda_estep_omp(int64_t M, int64_t V, int64_t K,
                       double* gamma, double* Elogtheta, double* Elogtheta_old,
                       int viter, double vtol, int nthreads)
 {
-    (void)M;
+    (void)M; (void)V;
     int used = 1;
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
@@ -134,19 +134,24 @@ int orc_lda_estep_omp(int64_t M, int64_t V, int64_t K,
 #pragma omp single
         used = omp_get_num_threads();
         double* phi = (double*)malloc(sizeof(double) * (size_t)(K * mx));
-        double* stage = (double*)malloc(sizeof(double) * (size_t)(K * mx));
-        double* bt = (double*)calloc((size_t)(K * V), sizeof(double));
-#pragma omp for schedule(dynamic, 64)
+#pragma omp for schedule(dynamic, 16)
         for (int64_t d = d0; d < d1; ++d) {
             int64_t off = doc_ptr[d], Nd = doc_ptr[d + 1] - off;
             orc_lda_doc_sweeps(K, Nd, terms + off, counts + off, alpha, beta,
                                gamma + d * K, Elogtheta + d * K, Elogtheta_old + d * K,
                                phi, viter, vtol);
-            lda_update_beta_doc(K, Nd, terms + off, counts + off, phi, bt, stage);
+            /* shared statistics, atomic accumulation (condensed corpora: no duplicate ids) */
+            for (int64_t n = 0; n < Nd; ++n) {
+                double* bt = beta_temp + (int64_t)terms[off + n] * K;
+                double c = (double)counts[off + n];
+                for (int64_t i = 0; i < K; ++i) {
+                    double v = phi[n * K + i] * c;
+#pragma omp atomic update
+                    bt[i] += v;
+                }
+            }
         }
-#pragma omp critical
-        for (int64_t q = 0; q < K * V; ++q) beta_temp[q] += bt[q];
-        free(phi); free(stage); free(bt);
+        free(phi);
     }
 #else
     (void)nthreads;

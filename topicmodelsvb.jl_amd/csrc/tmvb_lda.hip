@@ -36,15 +36,16 @@
 #define LDA_REDUCE_BLOCKS 256
 
 struct LdaParams {
-    int K, KP;
+    int K, KP, LPR;          // topics, padded row stride (4*odd), 16-byte chunks per row (KP/4)
+    unsigned lpr_magic;      // floor(2^32 / LPR) + 1  (exact f / LPR for f < 2^20)
     int64_t V;
     const int64_t* doc_ptr;
     const int32_t* terms;
     const int32_t* counts;
     const int32_t* doc_order;
     const float* alpha;
-    const float* beta;
-    float* S;
+    const float* beta;       // [V][KP], pad columns zero
+    float* S;                // [V][K] dense (packed statistics)
     float* gamma;
     float* elog;
     float* elog_old;
@@ -53,18 +54,31 @@ struct LdaParams {
     float vtol;
 };
 
+template <int CTRL>
+__device__ __forceinline__ float4 dpp_add4(float4 v)
+{
+    v.x += dpp_f<CTRL>(v.x); v.y += dpp_f<CTRL>(v.y); v.z += dpp_f<CTRL>(v.z); v.w += dpp_f<CTRL>(v.w);
+    return v;
+}
+
+// one wave per workgroup: __syncthreads() lowers to an LDS fence (the s_barrier is elided)
+#define WAVE_LDS_FENCE() __syncthreads()
+
 // ------------------------------------------------------------------------------ E-step kernel
-template <int NSLOT>
+// LPR_T: compile-time chunks-per-row (0 = use p.LPR); NSLOT = ceil(K/64).
+template <int NSLOT, int LPR_T>
 __global__ __launch_bounds__(64) void lda_estep_kernel(LdaParams p, int64_t first, int tile_rows)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x;
-    const int K = p.K, KP = p.KP;
-    float* Bt = lds;                         // [tile_rows][KP]   beta columns of the document's terms
-    float* e_l = Bt + (size_t)tile_rows * KP;  // [KP]            exp(Elogtheta), zero padded
-    float* w_l = e_l + KP;                   // [tile_rows]       c_n / s_n
-    float* c_l = w_l + tile_rows;            // [tile_rows]       counts as float
-    int* t_l = (int*)(c_l + tile_rows);      // [tile_rows]       term ids
+    const int K = p.K;
+    const int LPR = LPR_T ? LPR_T : p.LPR;
+    const int KP = 4 * LPR;
+    float* Bt = lds;                           // [tile_rows][KP]  beta columns of the document's terms
+    float* e_l = Bt + (size_t)tile_rows * KP;  // [KP]             exp(Elogtheta), zero padded
+    float* w_l = e_l + KP;                     // [tile_rows]      c_n / s_n
+    float* c_l = w_l + tile_rows;              // [tile_rows]      counts as float
+    int* t_l = (int*)(c_l + tile_rows);        // [tile_rows]      term ids
 
     const int d = p.doc_order[first + blockIdx.x];
     const int64_t off = p.doc_ptr[d];
@@ -82,24 +96,28 @@ __global__ __launch_bounds__(64) void lda_estep_kernel(LdaParams p, int64_t firs
         e[s] = 0.0f;
     }
 
-    // gather one chunk of the document into LDS: ids, counts and the beta columns
+    // Gather one chunk of the document into LDS.  The tile is a contiguous run of 16-byte chunks
+    // (row stride = LPR chunks), so every LDS-DMA instruction (global_load_lds_dwordx4) moves 64
+    // consecutive chunks = 1 KiB straight from L2/HBM into LDS with no VGPR round trip.
     auto load_chunk = [&](int c0, int rows) {
         for (int n = lane; n < rows; n += 64) {
             t_l[n] = p.terms[off + c0 + n];
             c_l[n] = (float)p.counts[off + c0 + n];
         }
-        __syncthreads();
-#pragma unroll 8
-        for (int n = 0; n < rows; ++n) {
-            const int t = __builtin_amdgcn_readfirstlane(t_l[n]);
-            const float* bcol = p.beta + (int64_t)t * K;
-#pragma unroll
-            for (int s = 0; s < NSLOT; ++s) {
-                int i = lane + 64 * s;
-                if (i < KP) Bt[n * KP + i] = (i < K) ? bcol[i] : 0.0f;
+        WAVE_LDS_FENCE();
+        const int nch = rows * LPR;
+#pragma unroll 4
+        for (int f0 = 0; f0 < nch; f0 += 64) {
+            const int f = f0 + lane;
+            if (f < nch) {
+                const int n = (LPR == 1) ? f : (int)__umulhi((unsigned)f, p.lpr_magic);
+                const int c = f - n * LPR;
+                const float* src = p.beta + ((int64_t)t_l[n] * KP + 4 * c);
+                __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(Bt + (size_t)f0 * 4), 16, 0, 0);
             }
         }
-        __syncthreads();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        WAVE_LDS_FENCE();
     };
 
     // phase 1: lane = token.  w_n = c_n / (K eps + B[n,:] . e); returns this lane's sum of w
@@ -107,21 +125,64 @@ __global__ __launch_bounds__(64) void lda_estep_kernel(LdaParams p, int64_t firs
         float wl = 0.0f;
         const float4* er = (const float4*)e_l;
         for (int n = lane; n < rows; n += 64) {
-            const float4* br = (const float4*)(Bt + n * KP);
+            const float4* br = (const float4*)(Bt + (size_t)n * KP);
             float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            if (LPR_T) {
+#pragma unroll
+                for (int q = 0; q < LPR_T; ++q) {
+                    float4 b = br[q], ev = er[q];
+                    s0 = fmaf(b.x, ev.x, s0); s1 = fmaf(b.y, ev.y, s1);
+                    s2 = fmaf(b.z, ev.z, s2); s3 = fmaf(b.w, ev.w, s3);
+                }
+            } else {
 #pragma unroll 4
-            for (int q = 0; q < KP / 4; ++q) {
-                float4 b = br[q], ev = er[q];
-                s0 = fmaf(b.x, ev.x, s0); s1 = fmaf(b.y, ev.y, s1);
-                s2 = fmaf(b.z, ev.z, s2); s3 = fmaf(b.w, ev.w, s3);
+                for (int q = 0; q < LPR; ++q) {
+                    float4 b = br[q], ev = er[q];
+                    s0 = fmaf(b.x, ev.x, s0); s1 = fmaf(b.y, ev.y, s1);
+                    s2 = fmaf(b.z, ev.z, s2); s3 = fmaf(b.w, ev.w, s3);
+                }
             }
             float sn = ((s0 + s1) + (s2 + s3)) + (float)K * TMVB_EPS_F;
             float w = c_l[n] / sn;
             w_l[n] = w;
             wl += w;
         }
-        __syncthreads();
+        WAVE_LDS_FENCE();
         return wl;
+    };
+
+    // phase 2: lane = 4*ql + r handles topic quad q = 16 s + ql for the tokens n = r (mod 4);
+    // acc[s] += w_n * B[n][4q..4q+3]  (one ds_read_b128 per 4 fmas)
+    const int r4 = lane & 3, ql = lane >> 2;
+    auto phase2 = [&](int rows, float4* acc) {
+        const int nfull = rows >> 2;
+#pragma unroll 4
+        for (int m = 0; m < nfull; ++m) {
+            const int n = 4 * m + r4;
+            const float w = w_l[n];
+#pragma unroll
+            for (int s = 0; s < NSLOT; ++s) {
+                const int q = 16 * s + ql;
+                if (q < LPR) {
+                    const float4 b = *(const float4*)(Bt + (size_t)n * KP + 4 * q);
+                    acc[s].x = fmaf(w, b.x, acc[s].x); acc[s].y = fmaf(w, b.y, acc[s].y);
+                    acc[s].z = fmaf(w, b.z, acc[s].z); acc[s].w = fmaf(w, b.w, acc[s].w);
+                }
+            }
+        }
+        const int n = 4 * nfull + r4;
+        if (n < rows) {
+            const float w = w_l[n];
+#pragma unroll
+            for (int s = 0; s < NSLOT; ++s) {
+                const int q = 16 * s + ql;
+                if (q < LPR) {
+                    const float4 b = *(const float4*)(Bt + (size_t)n * KP + 4 * q);
+                    acc[s].x = fmaf(w, b.x, acc[s].x); acc[s].y = fmaf(w, b.y, acc[s].y);
+                    acc[s].z = fmaf(w, b.z, acc[s].z); acc[s].w = fmaf(w, b.w, acc[s].w);
+                }
+            }
+        }
     };
 
     int sweeps = 0;
@@ -134,26 +195,17 @@ __global__ __launch_bounds__(64) void lda_estep_kernel(LdaParams p, int64_t firs
             e[s] = (i < K) ? expf(elog[s]) : 0.0f;
             if (i < KP) e_l[i] = e[s];
         }
-        __syncthreads();
-        float g[NSLOT];
+        WAVE_LDS_FENCE();
+        float4 acc[NSLOT];
 #pragma unroll
-        for (int s = 0; s < NSLOT; ++s) g[s] = 0.0f;
+        for (int s = 0; s < NSLOT; ++s) acc[s] = make_float4(0.f, 0.f, 0.f, 0.f);
         float wl = 0.0f;
         for (int c0 = 0; c0 < N; c0 += tile_rows) {
             const int rows = min(tile_rows, N - c0);
             if (!(single && v > 0)) load_chunk(c0, rows);
             wl += phase1(rows);
-            // phase 2: lane = topic.  g_i += sum_n w_n B[n][i]
-#pragma unroll 4
-            for (int n = 0; n < rows; ++n) {
-                const float w = w_l[n];
-#pragma unroll
-                for (int s = 0; s < NSLOT; ++s) {
-                    int i = lane + 64 * s;
-                    if (i < K) g[s] = fmaf(w, Bt[n * KP + i], g[s]);
-                }
-            }
-            if (!single) __syncthreads();
+            phase2(rows, acc);
+            if (!single) WAVE_LDS_FENCE();
         }
         const float wsum = wave_sum(wl);
         // update_gamma!  src/LDA.jl:145:  gamma = EPS + (alpha + phi*counts)
@@ -161,7 +213,10 @@ __global__ __launch_bounds__(64) void lda_estep_kernel(LdaParams p, int64_t firs
 #pragma unroll
         for (int s = 0; s < NSLOT; ++s) {
             int i = lane + 64 * s;
-            gam[s] = TMVB_EPS_F + (alpha[s] + fmaf(e[s], g[s], TMVB_EPS_F * wsum));
+            float4 a = dpp_add4<0xB1>(acc[s]);      // quad_perm [1,0,3,2]
+            a = dpp_add4<0x4E>(a);                  // quad_perm [2,3,0,1]: all 4 lanes hold the quad's sums
+            const float g = (r4 == 0) ? a.x : (r4 == 1) ? a.y : (r4 == 2) ? a.z : a.w;   // topic 4q + r = i
+            gam[s] = TMVB_EPS_F + (alpha[s] + fmaf(e[s], g, TMVB_EPS_F * wsum));
             if (i < K) gl += gam[s];
         }
         const float gsum = wave_sum(gl);
@@ -200,7 +255,7 @@ __global__ __launch_bounds__(64) void lda_estep_kernel(LdaParams p, int64_t firs
                 load_chunk(c0, rows);
                 (void)phase1(rows);
             }
-#pragma unroll 4
+#pragma unroll 8
             for (int n = 0; n < rows; ++n) {
                 const int t = __builtin_amdgcn_readfirstlane(t_l[n]);
                 const float w = w_l[n];
@@ -208,10 +263,10 @@ __global__ __launch_bounds__(64) void lda_estep_kernel(LdaParams p, int64_t firs
 #pragma unroll
                 for (int s = 0; s < NSLOT; ++s) {
                     int i = lane + 64 * s;
-                    if (i < K) unsafeAtomicAdd(scol + i, w * fmaf(Bt[n * KP + i], e[s], TMVB_EPS_F));
+                    if (i < K) unsafeAtomicAdd(scol + i, w * fmaf(Bt[(size_t)n * KP + i], e[s], TMVB_EPS_F));
                 }
             }
-            if (!single) __syncthreads();
+            if (!single) WAVE_LDS_FENCE();
         }
     }
     if (lane == 0) p.sweeps[d] = (uint8_t)min(sweeps, 255);
@@ -256,31 +311,24 @@ __global__ void colsum_final_kernel(const double* __restrict__ partial, int nblo
 }
 
 // update_beta!(model)  src/LDA.jl:121-125:  beta_new = S ./ rowsum(S);  S <- 0
+// S is dense [V][K]; beta_new is the padded gather layout [V][KP] (pad columns zero).
 __global__ __launch_bounds__(256) void lda_beta_norm_kernel(float* __restrict__ S, const double* __restrict__ rowsum,
-                                                            float* __restrict__ beta_new, int K, int64_t total)
+                                                            float* __restrict__ beta_new, int K, int KP, int64_t V)
 {
     extern __shared__ double rinv[];
     for (int i = threadIdx.x; i < K; i += blockDim.x) rinv[i] = 1.0 / rowsum[i];
     __syncthreads();
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
-    for (int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; q < total; q += stride) {
-        int i = (int)(q % K);
-        if (q + 3 < total) {
-            float4 v = *(const float4*)(S + q);
-            float4 o;
-            o.x = (float)((double)v.x * rinv[i]); i = (i + 1 == K) ? 0 : i + 1;
-            o.y = (float)((double)v.y * rinv[i]); i = (i + 1 == K) ? 0 : i + 1;
-            o.z = (float)((double)v.z * rinv[i]); i = (i + 1 == K) ? 0 : i + 1;
-            o.w = (float)((double)v.w * rinv[i]);
-            *(float4*)(beta_new + q) = o;
-            *(float4*)(S + q) = make_float4(0.f, 0.f, 0.f, 0.f);
-        } else {
-            for (int64_t r = q; r < total; ++r) {
-                beta_new[r] = (float)((double)S[r] * rinv[i]);
-                S[r] = 0.0f;
-                i = (i + 1 == K) ? 0 : i + 1;
-            }
+    const int64_t total = V * KP;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += stride) {
+        const int64_t j = q / KP;
+        const int i = (int)(q - j * KP);
+        float o = 0.0f;
+        if (i < K) {
+            o = (float)((double)S[j * K + i] * rinv[i]);
+            S[j * K + i] = 0.0f;
         }
+        beta_new[q] = o;
     }
 }
 
@@ -363,7 +411,7 @@ __global__ __launch_bounds__(64) void lda_alpha_kernel(int K, double Md, const d
 // update_elbo!  src/LDA.jl:83-93 per document (terms :50-80 without the corpus-level constant of
 // Elogptheta, added by lda_elbo_final_kernel).  One wave per document, lane = topic.
 template <int NSLOT>
-__global__ __launch_bounds__(64) void lda_elbo_kernel(int K, const int64_t* __restrict__ doc_ptr,
+__global__ __launch_bounds__(64) void lda_elbo_kernel(int K, int KP, const int64_t* __restrict__ doc_ptr,
                                                       const int32_t* __restrict__ terms, const int32_t* __restrict__ counts,
                                                       const double* __restrict__ alpha_d, const float* __restrict__ beta,
                                                       const float* __restrict__ beta_old, const float* __restrict__ gamma,
@@ -389,7 +437,7 @@ __global__ __launch_bounds__(64) void lda_elbo_kernel(int K, const int64_t* __re
 #pragma unroll
         for (int s = 0; s < NSLOT; ++s) {
             int i = lane + 64 * s;
-            x[s] = (i < K) ? fmaf(beta_old[(int64_t)t * K + i], eo[s], TMVB_EPS_F) : 0.0f;   // :87
+            x[s] = (i < K) ? fmaf(beta_old[(int64_t)t * KP + i], eo[s], TMVB_EPS_F) : 0.0f;   // :87
             xl += x[s];
         }
         const float inv = 1.0f / wave_sum(xl);                                               // :88
@@ -400,7 +448,7 @@ __global__ __launch_bounds__(64) void lda_elbo_kernel(int K, const int64_t* __re
                 float ph = x[s] * inv;
                 double cp = (double)(c * ph);
                 pc[s] += cp;
-                acc += cp * (double)logf(beta[(int64_t)t * K + i] + TMVB_EPS_F);             // Elogpw :65
+                acc += cp * (double)logf(beta[(int64_t)t * KP + i] + TMVB_EPS_F);             // Elogpw :65
                 if (ph > 0.0f) acc -= cp * (double)logf(ph);                                 // -Elogqz :78
             }
         }
@@ -477,6 +525,11 @@ struct tmvb_lda {
     std::vector<tmvb_bucket> buckets;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    // the length buckets of one E-step are independent: they are issued round-robin on a few
+    // auxiliary streams (fork/join on the context's stream) so that their tails overlap
+    static constexpr int NAUX = 4;
+    hipStream_t aux[NAUX] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[NAUX] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 template <typename F>
@@ -499,8 +552,13 @@ static void lda_build_buckets(tmvb_lda* h, std::vector<int32_t>& order)
     order.resize(h->M);
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return len[x] > len[y]; });
+    // tile heights: LDS per wave bounds the waves per CU, so buckets are kept narrow
+    // (16-row steps to 128, 32-row steps to 256, then doubling) within 64 KiB per wave
     std::vector<int> tiles;
-    for (int r = 16; lda_tile_bytes(r, h->KP) <= LDA_MAX_TILE_BYTES && r <= 4096; r *= 2) tiles.push_back(r);
+    for (int r = 16; r <= 8192; r += (r < 128 ? 16 : (r < 256 ? 32 : r))) {
+        if (lda_tile_bytes(r, h->KP) > LDA_MAX_TILE_BYTES) break;
+        tiles.push_back(r);
+    }
     if (tiles.empty()) tiles.push_back(4);
     h->buckets.clear();
     int64_t pos = 0;
@@ -516,6 +574,16 @@ static void lda_build_buckets(tmvb_lda* h, std::vector<int32_t>& order)
         while (pos + cnt < h->M && len[order[pos + cnt]] > lo) ++cnt;
         if (cnt) h->buckets.push_back({pos, cnt, tiles[b]});
         pos += cnt;
+    }
+    // merge tiny buckets into their larger neighbour (a launch needs enough waves to matter)
+    for (size_t b = 1; b < h->buckets.size();) {
+        if (h->buckets[b].count < 512 && h->buckets[b - 1].first + h->buckets[b - 1].count == h->buckets[b].first &&
+            !(b == 1 && len[order[0]] > tmax)) {
+            h->buckets[b - 1].count += h->buckets[b].count;
+            h->buckets.erase(h->buckets.begin() + b);
+        } else {
+            ++b;
+        }
     }
 }
 
@@ -543,6 +611,11 @@ extern "C" int tmvb_lda_destroy(tmvb_lda* h)
     (void)hipFree(h->d_doc_val); (void)hipFree(h->d_elbo); (void)hipFree(h->d_iters);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    for (int a = 0; a < tmvb_lda::NAUX; ++a) {
+        if (h->ev_join[a]) (void)hipEventDestroy(h->ev_join[a]);
+        if (h->aux[a]) (void)hipStreamDestroy(h->aux[a]);
+    }
     delete h;
     return TMVB_OK;
 }
@@ -565,6 +638,29 @@ static int download_f32(tmvb_ctx* ctx, double* dst, const float* src, size_t n)
     return TMVB_OK;
 }
 
+// host K x V (column-major) <-> device [V][KP] padded
+static int upload_beta(tmvb_lda* h, float* dst, const double* src)
+{
+    const size_t K = h->K, KP = h->KP, V = h->V;
+    std::vector<float> tmp(V * KP + 4, 0.0f);
+    for (size_t j = 0; j < V; ++j)
+        for (size_t i = 0; i < K; ++i) tmp[j * KP + i] = (float)src[j * K + i];
+    TMVB_HIP(hipMemcpyAsync(dst, tmp.data(), tmp.size() * sizeof(float), hipMemcpyHostToDevice, h->ctx->stream));
+    TMVB_HIP(hipStreamSynchronize(h->ctx->stream));
+    return TMVB_OK;
+}
+
+static int download_beta(tmvb_lda* h, double* dst, const float* src)
+{
+    const size_t K = h->K, KP = h->KP, V = h->V;
+    std::vector<float> tmp(V * KP);
+    TMVB_HIP(hipMemcpyAsync(tmp.data(), src, tmp.size() * sizeof(float), hipMemcpyDeviceToHost, h->ctx->stream));
+    TMVB_HIP(hipStreamSynchronize(h->ctx->stream));
+    for (size_t j = 0; j < V; ++j)
+        for (size_t i = 0; i < K; ++i) dst[j * K + i] = (double)tmp[j * KP + i];
+    return TMVB_OK;
+}
+
 extern "C" int tmvb_lda_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb_lda** out)
 {
     TMVB_REQUIRE(out != nullptr, TMVB_EINVAL, "tmvb_lda_create: out is NULL");
@@ -577,9 +673,10 @@ extern "C" int tmvb_lda_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
     h->ctx = ctx; h->corp = corp; h->K = K; h->KP = tmvb_kpad(K); h->nslot = (K + 63) / 64;
     h->M = corp->info.M; h->V = corp->info.V; h->M_total = h->M;
     const size_t KV = (size_t)K * h->V, KM = (size_t)K * h->M;
+    const size_t KPV = (size_t)h->KP * h->V + 4;      // padded gather layout (+ slack for 16-byte reads)
     int rc;
-    if ((rc = dmalloc(&h->d_alpha_d, K)) || (rc = dmalloc(&h->d_alpha_f, K)) || (rc = dmalloc(&h->d_beta[0], KV)) ||
-        (rc = dmalloc(&h->d_beta[1], KV)) || (rc = dmalloc(&h->d_stats, KV + K)) || (rc = dmalloc(&h->d_gamma, KM)) ||
+    if ((rc = dmalloc(&h->d_alpha_d, K)) || (rc = dmalloc(&h->d_alpha_f, K)) || (rc = dmalloc(&h->d_beta[0], KPV)) ||
+        (rc = dmalloc(&h->d_beta[1], KPV)) || (rc = dmalloc(&h->d_stats, KV + K)) || (rc = dmalloc(&h->d_gamma, KM)) ||
         (rc = dmalloc(&h->d_elog, KM)) || (rc = dmalloc(&h->d_elog_old, KM)) || (rc = dmalloc(&h->d_sweeps, (size_t)h->M)) ||
         (rc = dmalloc(&h->d_doc_order, (size_t)h->M)) || (rc = dmalloc(&h->d_partial, (size_t)LDA_REDUCE_BLOCKS * K)) ||
         (rc = dmalloc(&h->d_rowsum, K)) || (rc = dmalloc(&h->d_esum, K)) || (rc = dmalloc(&h->d_doc_val, (size_t)h->M)) ||
@@ -594,6 +691,13 @@ extern "C" int tmvb_lda_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
     TMVB_HIP(hipMemsetAsync(h->d_sweeps, 0, std::max<size_t>((size_t)h->M, 1), ctx->stream));
     TMVB_HIP(hipEventCreate(&h->ev0));
     TMVB_HIP(hipEventCreate(&h->ev1));
+    TMVB_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    for (int a = 0; a < tmvb_lda::NAUX; ++a) {
+        TMVB_HIP(hipStreamCreateWithFlags(&h->aux[a], hipStreamNonBlocking));
+        TMVB_HIP(hipEventCreateWithFlags(&h->ev_join[a], hipEventDisableTiming));
+    }
+    TMVB_HIP(hipMemsetAsync(h->d_beta[0], 0, KPV * sizeof(float), ctx->stream));
+    TMVB_HIP(hipMemsetAsync(h->d_beta[1], 0, KPV * sizeof(float), ctx->stream));
     // constructor state, src/gpuLDA.jl:53-61 (beta: uniform, see tmvb.h)
     std::vector<double> alpha(K, 1.0), beta(KV, h->V ? 1.0 / (double)h->V : 0.0), gamma(KM, 1.0);
     const double e0 = -0.5772156649015329 - tmvb_digamma_host((double)K);   // -(eulergamma + digamma(K)), src/gpuLDA.jl:57
@@ -621,10 +725,10 @@ extern "C" int tmvb_lda_set_state(tmvb_lda* h, const double* alpha, const double
         if ((rc = upload_f32(ctx, h->d_alpha_f, alpha, K))) return rc;
     }
     if (beta) {
-        if ((rc = upload_f32(ctx, h->d_beta[h->cur], beta, KV))) return rc;
-        if (!beta_old && (rc = upload_f32(ctx, h->d_beta[h->cur ^ 1], beta, KV))) return rc;
+        if ((rc = upload_beta(h, h->d_beta[h->cur], beta))) return rc;
+        if (!beta_old && (rc = upload_beta(h, h->d_beta[h->cur ^ 1], beta))) return rc;
     }
-    if (beta_old && (rc = upload_f32(ctx, h->d_beta[h->cur ^ 1], beta_old, KV))) return rc;
+    if (beta_old && (rc = upload_beta(h, h->d_beta[h->cur ^ 1], beta_old))) return rc;
     if (gamma && (rc = upload_f32(ctx, h->d_gamma, gamma, KM))) return rc;
     if (Elogtheta) {
         if ((rc = upload_f32(ctx, h->d_elog, Elogtheta, KM))) return rc;
@@ -648,8 +752,8 @@ extern "C" int tmvb_lda_get_state(tmvb_lda* h, double* alpha, double* beta, doub
         TMVB_HIP(hipMemcpyAsync(alpha, h->d_alpha_d, K * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         TMVB_HIP(hipStreamSynchronize(ctx->stream));
     }
-    if (beta && (rc = download_f32(ctx, beta, h->d_beta[h->cur], KV))) return rc;
-    if (beta_old && (rc = download_f32(ctx, beta_old, h->d_beta[h->cur ^ 1], KV))) return rc;
+    if (beta && (rc = download_beta(h, beta, h->d_beta[h->cur]))) return rc;
+    if (beta_old && (rc = download_beta(h, beta_old, h->d_beta[h->cur ^ 1]))) return rc;
     if (gamma && (rc = download_f32(ctx, gamma, h->d_gamma, KM))) return rc;
     if (Elogtheta && (rc = download_f32(ctx, Elogtheta, h->d_elog, KM))) return rc;
     if (Elogtheta_old && (rc = download_f32(ctx, Elogtheta_old, h->d_elog_old, KM))) return rc;
@@ -665,22 +769,46 @@ extern "C" int tmvb_lda_estep(tmvb_lda* h, int32_t viter, double vtol)
     tmvb_ctx* ctx = h->ctx;
     TMVB_HIP(hipSetDevice(ctx->device));
     LdaParams p;
-    p.K = h->K; p.KP = h->KP; p.V = h->V;
+    p.K = h->K; p.KP = h->KP; p.LPR = h->KP / 4; p.lpr_magic = (unsigned)(0x100000000ull / (unsigned)p.LPR) + 1u; p.V = h->V;
     p.doc_ptr = h->corp->d_doc_ptr; p.terms = h->corp->d_terms; p.counts = h->corp->d_counts;
     p.doc_order = h->d_doc_order;
     p.alpha = h->d_alpha_f; p.beta = h->d_beta[h->cur]; p.S = h->d_stats;
     p.gamma = h->d_gamma; p.elog = h->d_elog; p.elog_old = h->d_elog_old; p.sweeps = h->d_sweeps;
     p.viter = viter; p.vtol = (float)vtol;
     TMVB_HIP(hipEventRecord(h->ev0, ctx->stream));
-    for (const tmvb_bucket& b : h->buckets) {
+    const int nb = (int)h->buckets.size();
+    const int naux = std::min(nb, (int)tmvb_lda::NAUX);
+    if (naux > 1) {
+        TMVB_HIP(hipEventRecord(h->ev_fork, ctx->stream));
+        for (int a = 0; a < naux; ++a) TMVB_HIP(hipStreamWaitEvent(h->aux[a], h->ev_fork, 0));
+    }
+    for (int bi = 0; bi < nb; ++bi) {
+        const tmvb_bucket& b = h->buckets[bi];
+        hipStream_t st = (naux > 1) ? h->aux[bi % naux] : ctx->stream;
         const size_t lds = lda_tile_bytes(b.tile_rows, h->KP);
         int rc = dispatch_nslot(h->nslot, [&](auto ns) -> int {
             constexpr int NS = decltype(ns)::value;
-            hipLaunchKernelGGL((lda_estep_kernel<NS>), dim3((unsigned)b.count), dim3(64), lds, ctx->stream, p, b.first, b.tile_rows);
+            const dim3 grid((unsigned)b.count), block(64);
+            if (NS == 1 && p.LPR == 13)
+                hipLaunchKernelGGL((lda_estep_kernel<1, 13>), grid, block, lds, st, p, b.first, b.tile_rows);
+            else if (NS == 1 && p.LPR == 3)
+                hipLaunchKernelGGL((lda_estep_kernel<1, 3>), grid, block, lds, st, p, b.first, b.tile_rows);
+            else if (NS == 1 && p.LPR == 5)
+                hipLaunchKernelGGL((lda_estep_kernel<1, 5>), grid, block, lds, st, p, b.first, b.tile_rows);
+            else if (NS == 2 && p.LPR == 25)
+                hipLaunchKernelGGL((lda_estep_kernel<2, 25>), grid, block, lds, st, p, b.first, b.tile_rows);
+            else
+                hipLaunchKernelGGL((lda_estep_kernel<NS, 0>), grid, block, lds, st, p, b.first, b.tile_rows);
             return TMVB_OK;
         });
         if (rc) return rc;
         TMVB_HIP(hipGetLastError());
+    }
+    if (naux > 1) {
+        for (int a = 0; a < naux; ++a) {
+            TMVB_HIP(hipEventRecord(h->ev_join[a], h->aux[a]));
+            TMVB_HIP(hipStreamWaitEvent(ctx->stream, h->ev_join[a], 0));
+        }
     }
     TMVB_HIP(hipEventRecord(h->ev1, ctx->stream));
     h->timed = true;
@@ -748,10 +876,10 @@ extern "C" int tmvb_lda_update_beta(tmvb_lda* h)
     TMVB_HIP(hipSetDevice(ctx->device));
     int rc = colsum(h, h->d_stats, h->V, h->d_rowsum, nullptr);
     if (rc) return rc;
-    const int64_t total = (int64_t)h->K * h->V;
-    int nb = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (total / 4 + 255) / 256));
+    const int64_t total = (int64_t)h->KP * h->V;
+    int nb = (int)std::min<int64_t>(2048, std::max<int64_t>(1, (total + 255) / 256));
     hipLaunchKernelGGL(lda_beta_norm_kernel, dim3(nb), dim3(256), (size_t)h->K * sizeof(double), ctx->stream,
-                       h->d_stats, h->d_rowsum, h->d_beta[h->cur ^ 1], h->K, total);
+                       h->d_stats, h->d_rowsum, h->d_beta[h->cur ^ 1], h->K, h->KP, h->V);
     TMVB_HIP(hipGetLastError());
     h->cur ^= 1;   // beta_old <- beta, beta <- new   (src/LDA.jl:122-123)
     return TMVB_OK;
@@ -784,7 +912,7 @@ extern "C" int tmvb_lda_update_elbo(tmvb_lda* h, double* elbo)
     if (h->M > 0) {
         int rc = dispatch_nslot(h->nslot, [&](auto ns) -> int {
             constexpr int NS = decltype(ns)::value;
-            hipLaunchKernelGGL((lda_elbo_kernel<NS>), dim3((unsigned)h->M), dim3(64), 0, ctx->stream, h->K, h->corp->d_doc_ptr,
+            hipLaunchKernelGGL((lda_elbo_kernel<NS>), dim3((unsigned)h->M), dim3(64), 0, ctx->stream, h->K, h->KP, h->corp->d_doc_ptr,
                                h->corp->d_terms, h->corp->d_counts, h->d_alpha_d, h->d_beta[h->cur], h->d_beta[h->cur ^ 1],
                                h->d_gamma, h->d_elog, h->d_elog_old, h->d_doc_val);
             return TMVB_OK;
@@ -849,6 +977,13 @@ extern "C" int tmvb_lda_sweep_hist(tmvb_lda* h, int64_t* hist, int32_t nbins)
     TMVB_HIP(hipStreamSynchronize(h->ctx->stream));
     for (int b = 0; b < nbins; ++b) hist[b] = 0;
     for (uint8_t s : sw) hist[std::min<int>(s, nbins - 1)]++;
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_lda_estep_launches(tmvb_lda* h, int32_t* n)
+{
+    TMVB_REQUIRE(h && n, TMVB_EINVAL, "tmvb_lda_estep_launches: NULL argument");
+    *n = (int32_t)h->buckets.size();
     return TMVB_OK;
 }
 

@@ -248,6 +248,11 @@ class gpuLDA:
         check(lib().tmvb_lda_sweep_hist(self.handle, h.ctypes.data_as(P_i64), C.c_int32(nbins)))
         return h
 
+    def estep_launches(self) -> int:
+        n = C.c_int32(0)
+        check(lib().tmvb_lda_estep_launches(self.handle, C.byref(n)))
+        return n.value
+
     def last_estep_ms(self) -> float:
         ms = C.c_float(0.0)
         check(lib().tmvb_lda_last_estep_ms(self.handle, C.byref(ms)))
