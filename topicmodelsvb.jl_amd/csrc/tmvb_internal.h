@@ -48,6 +48,31 @@ struct tmvb_bucket {
     int32_t tile_rows = 0;
 };
 
+// Inverted (id-major) index over a CSR token stream, cut into chunks of at most TMVB_CHUNK tokens.
+// Same information as the reference's terms_sortperm / J_cumsum (src/modelutils.jl:372-381) and
+// readers_sortperm / Y_cumsum (:443-472); used by the gather-side statistics kernels, which rebuild
+// phi .* counts' from (w_token, E_doc) instead of reading a materialised phi buffer.
+#define TMVB_CHUNK 256
+struct tmvb_inv_index {
+    bool built = false;
+    int64_t n_ids = 0, nnz = 0;
+    int32_t* d_doc = nullptr;          // [nnz] document of each token, id-major order
+    int32_t* d_pos = nullptr;          // [nnz] CSR position of each token, id-major order
+    int64_t n_chunks = 0;
+    int32_t* d_chunk_id = nullptr;     // [n_chunks] id (term / reader) the chunk belongs to
+    int32_t* d_chunk_begin = nullptr;  // [n_chunks] token range in id-major order
+    int32_t* d_chunk_end = nullptr;
+    int32_t* d_chunk_out = nullptr;    // [n_chunks] -1: only chunk of its id (direct write); else partial slot
+    int64_t n_multi = 0;               // ids split over several chunks
+    int32_t* d_multi_id = nullptr;     // [n_multi]
+    int32_t* d_multi_first = nullptr;  // [n_multi] first partial slot
+    int32_t* d_multi_count = nullptr;  // [n_multi] number of partial slots
+    int64_t n_slots = 0;
+};
+int tmvb_build_inv_index(tmvb_ctx* ctx, int64_t M, int64_t n_ids, const int64_t* h_ptr, const int32_t* h_ids,
+                         tmvb_inv_index* out);
+void tmvb_free_inv_index(tmvb_inv_index* ix);
+
 struct tmvb_corpus {
     tmvb_ctx* ctx = nullptr;
     tmvb_corpus_info_t info{};
@@ -63,7 +88,13 @@ struct tmvb_corpus {
     std::vector<int32_t> h_doc_order;
     std::vector<int64_t> h_doc_len;     // N_d
     std::vector<int64_t> h_rdr_len;     // R_d
+    // host copies kept for building the inverted indices lazily
+    std::vector<int64_t> h_doc_ptr, h_rdr_ptr;
+    std::vector<int32_t> h_terms, h_readers;
+    tmvb_inv_index term_index, reader_index;
 };
+int tmvb_corpus_term_index(tmvb_corpus* c);
+int tmvb_corpus_reader_index(tmvb_corpus* c);
 
 // EPSILON of the reference (src/utils.jl:3) = 2^-99, exactly representable in fp32.
 #define TMVB_EPS_F 1.5777218104420236e-30f

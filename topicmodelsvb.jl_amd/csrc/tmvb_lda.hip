@@ -26,8 +26,10 @@
 // Roofline: HBM-bound gather/scatter.  Algorithmic bytes per outer iteration:
 //   nnz*(8 + 4K + 4K) + 12*M*K + 12*K*V + 4*(M+1).
 #include "tmvb_internal.h"
+#include "tmvb_termstats.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 
@@ -45,13 +47,15 @@ struct LdaParams {
     const int32_t* doc_order;
     const float* alpha;
     const float* beta;       // [V][KP], pad columns zero
-    float* S;                // [V][K] dense (packed statistics)
+    float* wtok;             // [nnz] last-sweep c_n / s_n per token (CSR order)
+    float* E;                // [M][K] last-sweep exp(Elogtheta_old)
     float* gamma;
     float* elog;
     float* elog_old;
     uint8_t* sweeps;
     int viter;
     float vtol;
+    int debug;               // TMVB_DEBUG_FLAGS (profiling experiments only): 1 = skip the statistics pass
 };
 
 template <int CTRL>
@@ -150,6 +154,10 @@ __global__ __launch_bounds__(64) void lda_estep_kernel(LdaParams p, int64_t firs
         WAVE_LDS_FENCE();
         return wl;
     };
+    // documents that stream chunks keep the latest w in HBM every sweep (the last one survives)
+    auto store_w = [&](int c0, int rows) {
+        for (int n = lane; n < rows; n += 64) p.wtok[off + c0 + n] = w_l[n];
+    };
 
     // phase 2: lane = 4*ql + r handles topic quad q = 16 s + ql for the tokens n = r (mod 4);
     // acc[s] += w_n * B[n][4q..4q+3]  (one ds_read_b128 per 4 fmas)
@@ -204,6 +212,7 @@ __global__ __launch_bounds__(64) void lda_estep_kernel(LdaParams p, int64_t firs
             const int rows = min(tile_rows, N - c0);
             if (!(single && v > 0)) load_chunk(c0, rows);
             wl += phase1(rows);
+            if (!single) store_w(c0, rows);
             phase2(rows, acc);
             if (!single) WAVE_LDS_FENCE();
         }
@@ -247,27 +256,17 @@ __global__ __launch_bounds__(64) void lda_estep_kernel(LdaParams p, int64_t firs
                 p.elog_old[(int64_t)d * K + i] = elog_old[s];
             }
         }
-        // update_beta!(model, d)  src/LDA.jl:131: S[:,terms] += phi .* counts' with the LAST sweep's
-        // phi = w_n (B[n][i] e_i + eps)  (e is still exp(Elogtheta_old)).
-        for (int c0 = 0; c0 < N; c0 += tile_rows) {
-            const int rows = min(tile_rows, N - c0);
-            if (!single) {
-                load_chunk(c0, rows);
-                (void)phase1(rows);
-            }
-#pragma unroll 8
-            for (int n = 0; n < rows; ++n) {
-                const int t = __builtin_amdgcn_readfirstlane(t_l[n]);
-                const float w = w_l[n];
-                float* scol = p.S + (int64_t)t * K;
+        // update_beta!(model, d)  src/LDA.jl:131 is deferred to the gather-side statistics pass
+        // (tmvb_termstats.h): the LAST sweep's phi .* counts' = w_n (beta[i,t_n] e_i + eps) is rebuilt
+        // there from w (per token) and e = exp(Elogtheta_old) (per document), so only those are stored.
 #pragma unroll
-                for (int s = 0; s < NSLOT; ++s) {
-                    int i = lane + 64 * s;
-                    if (i < K) unsafeAtomicAdd(scol + i, w * fmaf(Bt[(size_t)n * KP + i], e[s], TMVB_EPS_F));
-                }
-            }
-            if (!single) WAVE_LDS_FENCE();
+        for (int s = 0; s < NSLOT; ++s) {
+            int i = lane + 64 * s;
+            if (i < K) p.E[(int64_t)d * K + i] = e[s];
         }
+        if (single) store_w(0, N);
+    } else {
+        for (int n = lane; n < N; n += 64) p.wtok[off + n] = 0.0f;   // viter = 0: no responsibilities
     }
     if (lane == 0) p.sweeps[d] = (uint8_t)min(sweeps, 255);
 }
@@ -514,6 +513,9 @@ struct tmvb_lda {
     float* d_elog = nullptr;
     float* d_elog_old = nullptr;
     uint8_t* d_sweeps = nullptr;
+    float* d_wtok = nullptr;           // [nnz]
+    float* d_E = nullptr;              // [K*M]
+    float* d_ts_partial = nullptr;     // [n_slots][K+1]
     int32_t* d_doc_order = nullptr;
     double* d_partial = nullptr;       // [LDA_REDUCE_BLOCKS][K]
     double* d_rowsum = nullptr;        // [K]
@@ -606,6 +608,7 @@ extern "C" int tmvb_lda_destroy(tmvb_lda* h)
     if (h->ctx) (void)hipSetDevice(h->ctx->device);
     (void)hipFree(h->d_alpha_d); (void)hipFree(h->d_alpha_f); (void)hipFree(h->d_beta[0]); (void)hipFree(h->d_beta[1]);
     if (h->own_stats) (void)hipFree(h->d_stats);
+    (void)hipFree(h->d_wtok); (void)hipFree(h->d_E); (void)hipFree(h->d_ts_partial);
     (void)hipFree(h->d_gamma); (void)hipFree(h->d_elog); (void)hipFree(h->d_elog_old); (void)hipFree(h->d_sweeps);
     (void)hipFree(h->d_doc_order); (void)hipFree(h->d_partial); (void)hipFree(h->d_rowsum); (void)hipFree(h->d_esum);
     (void)hipFree(h->d_doc_val); (void)hipFree(h->d_elbo); (void)hipFree(h->d_iters);
@@ -680,7 +683,9 @@ extern "C" int tmvb_lda_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
         (rc = dmalloc(&h->d_elog, KM)) || (rc = dmalloc(&h->d_elog_old, KM)) || (rc = dmalloc(&h->d_sweeps, (size_t)h->M)) ||
         (rc = dmalloc(&h->d_doc_order, (size_t)h->M)) || (rc = dmalloc(&h->d_partial, (size_t)LDA_REDUCE_BLOCKS * K)) ||
         (rc = dmalloc(&h->d_rowsum, K)) || (rc = dmalloc(&h->d_esum, K)) || (rc = dmalloc(&h->d_doc_val, (size_t)h->M)) ||
-        (rc = dmalloc(&h->d_elbo, 1)) || (rc = dmalloc(&h->d_iters, 1))) {
+        (rc = dmalloc(&h->d_elbo, 1)) || (rc = dmalloc(&h->d_iters, 1)) || (rc = dmalloc(&h->d_wtok, (size_t)corp->info.nnz)) ||
+        (rc = dmalloc(&h->d_E, KM)) || (rc = tmvb_corpus_term_index(corp)) ||
+        (rc = dmalloc(&h->d_ts_partial, (size_t)corp->term_index.n_slots * (K + 1)))) {
         tmvb_lda_destroy(h);
         return rc;
     }
@@ -772,9 +777,10 @@ extern "C" int tmvb_lda_estep(tmvb_lda* h, int32_t viter, double vtol)
     p.K = h->K; p.KP = h->KP; p.LPR = h->KP / 4; p.lpr_magic = (unsigned)(0x100000000ull / (unsigned)p.LPR) + 1u; p.V = h->V;
     p.doc_ptr = h->corp->d_doc_ptr; p.terms = h->corp->d_terms; p.counts = h->corp->d_counts;
     p.doc_order = h->d_doc_order;
-    p.alpha = h->d_alpha_f; p.beta = h->d_beta[h->cur]; p.S = h->d_stats;
+    p.alpha = h->d_alpha_f; p.beta = h->d_beta[h->cur]; p.wtok = h->d_wtok; p.E = h->d_E;
     p.gamma = h->d_gamma; p.elog = h->d_elog; p.elog_old = h->d_elog_old; p.sweeps = h->d_sweeps;
     p.viter = viter; p.vtol = (float)vtol;
+    { const char* dbg = getenv("TMVB_DEBUG_FLAGS"); p.debug = dbg ? atoi(dbg) : 0; }
     TMVB_HIP(hipEventRecord(h->ev0, ctx->stream));
     const int nb = (int)h->buckets.size();
     const int naux = std::min(nb, (int)tmvb_lda::NAUX);
@@ -809,6 +815,26 @@ extern "C" int tmvb_lda_estep(tmvb_lda* h, int32_t viter, double vtol)
             TMVB_HIP(hipEventRecord(h->ev_join[a], h->aux[a]));
             TMVB_HIP(hipStreamWaitEvent(ctx->stream, h->ev_join[a], 0));
         }
+    }
+    // gather-side statistics: S[:, j] = beta[:, j] .* sum_tokens w E[:, doc] + eps sum w   (update_beta!(model, d))
+    const tmvb_inv_index& ix = h->corp->term_index;
+    if (!(p.debug & 1) && ix.n_chunks > 0) {
+        TermStatsParams tp;
+        tp.K = h->K; tp.tstride = h->KP; tp.ostride = h->K;
+        tp.tok_doc = ix.d_doc; tp.tok_pos = ix.d_pos; tp.chunk_id = ix.d_chunk_id; tp.chunk_begin = ix.d_chunk_begin;
+        tp.chunk_end = ix.d_chunk_end; tp.chunk_out = ix.d_chunk_out; tp.n_chunks = (int)ix.n_chunks;
+        tp.w = h->d_wtok; tp.E = h->d_E; tp.T = h->d_beta[h->cur]; tp.eps = TMVB_EPS_F; tp.base = 0.0f;
+        tp.out = h->d_stats; tp.partial = h->d_ts_partial;
+        int rc = dispatch_nslot(h->nslot, [&](auto ns) -> int {
+            constexpr int NS = decltype(ns)::value;
+            hipLaunchKernelGGL((termstats_chunk_kernel<NS>), dim3((unsigned)((ix.n_chunks + 3) / 4)), dim3(256), 0, ctx->stream, tp);
+            if (ix.n_multi > 0)
+                hipLaunchKernelGGL((termstats_multi_kernel<NS>), dim3((unsigned)((ix.n_multi + 3) / 4)), dim3(256), 0, ctx->stream, tp,
+                                   ix.d_multi_id, ix.d_multi_first, ix.d_multi_count, (int)ix.n_multi);
+            return TMVB_OK;
+        });
+        if (rc) return rc;
+        TMVB_HIP(hipGetLastError());
     }
     TMVB_HIP(hipEventRecord(h->ev1, ctx->stream));
     h->timed = true;
