@@ -48,7 +48,8 @@ struct LdaParams {
     const float* alpha;
     const float* beta;       // [V][KP], pad columns zero
     float* wtok;             // [nnz] last-sweep c_n / s_n per token (CSR order)
-    float* E;                // [M][K] last-sweep exp(Elogtheta_old)
+    float* E;                // [M][estride] last-sweep exp(Elogtheta_old) (estride = KP, pads zero, when K <= 256)
+    int estride;
     float* gamma;
     float* elog;
     float* elog_old;
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(64) void lda_estep_kernel(LdaParams p, int64_t firs
 #pragma unroll
         for (int s = 0; s < NSLOT; ++s) {
             int i = lane + 64 * s;
-            if (i < K) p.E[(int64_t)d * K + i] = e[s];
+            if (i < p.estride) p.E[(int64_t)d * p.estride + i] = e[s];   // e is 0 beyond K
         }
         if (single) store_w(0, N);
     } else {
@@ -283,6 +284,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     double acc[NSLOT];
 #pragma unroll
     for (int s = 0; s < NSLOT; ++s) acc[s] = 0.0;
+#pragma unroll 8
     for (int64_t c = gw; c < ncols; c += nw) {
 #pragma unroll
         for (int s = 0; s < NSLOT; ++s) {
@@ -297,13 +299,17 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
         partial[(int64_t)blockIdx.x * K + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
 }
 
-// out_d[i] = sum_b partial[b][i] in a fixed order (deterministic); optional fp32 copy
-__global__ void colsum_final_kernel(const double* __restrict__ partial, int nblocks, int K,
-                                    double* __restrict__ out_d, float* __restrict__ out_f)
+// out_d[i] = sum_b partial[b][i]: one wave per output, fixed reduction tree (deterministic); optional fp32 copy
+__global__ __launch_bounds__(256) void colsum_final_kernel(const double* __restrict__ partial, int nblocks, int K,
+                                                           double* __restrict__ out_d, float* __restrict__ out_f)
 {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < K; i += gridDim.x * blockDim.x) {
-        double s = 0.0;
-        for (int b = 0; b < nblocks; ++b) s += partial[(int64_t)b * K + i];
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= K) return;
+    double s = 0.0;
+    for (int b = lane; b < nblocks; b += 64) s += partial[(int64_t)b * K + i];
+    s = wave_sum_d(s);
+    if (lane == 0) {
         if (out_d) out_d[i] = s;
         if (out_f) out_f[i] = (float)s;
     }
@@ -514,7 +520,8 @@ struct tmvb_lda {
     float* d_elog_old = nullptr;
     uint8_t* d_sweeps = nullptr;
     float* d_wtok = nullptr;           // [nnz]
-    float* d_E = nullptr;              // [K*M]
+    float* d_E = nullptr;              // [M][estride]
+    int estride = 0;
     float* d_ts_partial = nullptr;     // [n_slots][K+1]
     int32_t* d_doc_order = nullptr;
     double* d_partial = nullptr;       // [LDA_REDUCE_BLOCKS][K]
@@ -675,6 +682,7 @@ extern "C" int tmvb_lda_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
     tmvb_lda* h = new tmvb_lda();
     h->ctx = ctx; h->corp = corp; h->K = K; h->KP = tmvb_kpad(K); h->nslot = (K + 63) / 64;
     h->M = corp->info.M; h->V = corp->info.V; h->M_total = h->M;
+    h->estride = (h->KP / 4 <= 64) ? h->KP : K;
     const size_t KV = (size_t)K * h->V, KM = (size_t)K * h->M;
     const size_t KPV = (size_t)h->KP * h->V + 4;      // padded gather layout (+ slack for 16-byte reads)
     int rc;
@@ -684,7 +692,7 @@ extern "C" int tmvb_lda_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
         (rc = dmalloc(&h->d_doc_order, (size_t)h->M)) || (rc = dmalloc(&h->d_partial, (size_t)LDA_REDUCE_BLOCKS * K)) ||
         (rc = dmalloc(&h->d_rowsum, K)) || (rc = dmalloc(&h->d_esum, K)) || (rc = dmalloc(&h->d_doc_val, (size_t)h->M)) ||
         (rc = dmalloc(&h->d_elbo, 1)) || (rc = dmalloc(&h->d_iters, 1)) || (rc = dmalloc(&h->d_wtok, (size_t)corp->info.nnz)) ||
-        (rc = dmalloc(&h->d_E, KM)) || (rc = tmvb_corpus_term_index(corp)) ||
+        (rc = dmalloc(&h->d_E, (size_t)h->KP * h->M + 4)) || (rc = tmvb_corpus_term_index(corp)) ||
         (rc = dmalloc(&h->d_ts_partial, (size_t)corp->term_index.n_slots * (K + 1)))) {
         tmvb_lda_destroy(h);
         return rc;
@@ -777,7 +785,7 @@ extern "C" int tmvb_lda_estep(tmvb_lda* h, int32_t viter, double vtol)
     p.K = h->K; p.KP = h->KP; p.LPR = h->KP / 4; p.lpr_magic = (unsigned)(0x100000000ull / (unsigned)p.LPR) + 1u; p.V = h->V;
     p.doc_ptr = h->corp->d_doc_ptr; p.terms = h->corp->d_terms; p.counts = h->corp->d_counts;
     p.doc_order = h->d_doc_order;
-    p.alpha = h->d_alpha_f; p.beta = h->d_beta[h->cur]; p.wtok = h->d_wtok; p.E = h->d_E;
+    p.alpha = h->d_alpha_f; p.beta = h->d_beta[h->cur]; p.wtok = h->d_wtok; p.E = h->d_E; p.estride = h->estride;
     p.gamma = h->d_gamma; p.elog = h->d_elog; p.elog_old = h->d_elog_old; p.sweeps = h->d_sweeps;
     p.viter = viter; p.vtol = (float)vtol;
     { const char* dbg = getenv("TMVB_DEBUG_FLAGS"); p.debug = dbg ? atoi(dbg) : 0; }
@@ -827,9 +835,17 @@ extern "C" int tmvb_lda_estep(tmvb_lda* h, int32_t viter, double vtol)
         tp.out = h->d_stats; tp.partial = h->d_ts_partial;
         int rc = dispatch_nslot(h->nslot, [&](auto ns) -> int {
             constexpr int NS = decltype(ns)::value;
-            hipLaunchKernelGGL((termstats_chunk_kernel<NS>), dim3((unsigned)((ix.n_chunks + 3) / 4)), dim3(256), 0, ctx->stream, tp);
+            const dim3 grid((unsigned)((ix.n_chunks + 3) / 4)), block(256);
+            const int lpr = h->KP / 4;
+            if (h->estride == h->KP) {
+                if (lpr == 13) hipLaunchKernelGGL((termstats_chunk4_kernel<13>), grid, block, 0, ctx->stream, tp, lpr);
+                else if (lpr == 25) hipLaunchKernelGGL((termstats_chunk4_kernel<25>), grid, block, 0, ctx->stream, tp, lpr);
+                else hipLaunchKernelGGL((termstats_chunk4_kernel<0>), grid, block, 0, ctx->stream, tp, lpr);
+            } else {
+                hipLaunchKernelGGL((termstats_chunk_kernel<NS>), grid, block, 0, ctx->stream, tp);
+            }
             if (ix.n_multi > 0)
-                hipLaunchKernelGGL((termstats_multi_kernel<NS>), dim3((unsigned)((ix.n_multi + 3) / 4)), dim3(256), 0, ctx->stream, tp,
+                hipLaunchKernelGGL((termstats_multi_kernel<NS>), dim3((unsigned)ix.n_multi), dim3(256), 0, ctx->stream, tp,
                                    ix.d_multi_id, ix.d_multi_first, ix.d_multi_count, (int)ix.n_multi);
             return TMVB_OK;
         });
@@ -852,7 +868,7 @@ static int colsum(tmvb_lda* h, const float* X, int64_t ncols, double* out_d, flo
     });
     if (rc) return rc;
     TMVB_HIP(hipGetLastError());
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((h->K + 255) / 256), dim3(256), 0, ctx->stream, h->d_partial, nb, h->K, out_d, out_f);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((h->K + 3) / 4), dim3(256), 0, ctx->stream, h->d_partial, nb, h->K, out_d, out_f);
     TMVB_HIP(hipGetLastError());
     return TMVB_OK;
 }

@@ -24,7 +24,7 @@ struct TermStatsParams {
     const int32_t* chunk_out;
     int n_chunks;
     const float* w;              // [nnz] per-token weight, CSR order
-    const float* E;              // [M][K] per-document factor
+    const float* E;              // per-document factor: [M][K] (scalar kernel) or [M][KP] zero padded (chunk4 kernel)
     const float* T;              // [n_ids][tstride] per-id factor
     float eps;                   // additive epsilon (LDA: EPSILON, others 0)
     float base;                  // value added to every written entry (CTPF priors a / e; else 0)
@@ -83,22 +83,100 @@ __global__ __launch_bounds__(256) void termstats_chunk_kernel(TermStatsParams p)
     }
 }
 
-// ids whose tokens span several chunks: sum their partials in chunk order (deterministic)
+// Vectorised variant for K <= 256 (LPR = KP/4 <= 64 sixteen-byte chunks per row): E is stored with
+// the padded row stride KP, a lane owns one float4 column chunk c = lane % LPR of row slot
+// rs = lane / LPR, so ONE global_load_dwordx4 instruction fetches RPI = 64 / LPR document rows
+// (832 B per wave instruction at K = 50 instead of 200 B).  Row slots are combined at the end in a
+// fixed order through LDS.
+template <int LPR_T>
+__global__ __launch_bounds__(256) void termstats_chunk4_kernel(TermStatsParams p, int LPR_rt)
+{
+    __shared__ int2 dw_l[4][64];           // per wave: (doc, w bits) of the 64 tokens in flight
+    __shared__ float4 red_l[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int c = blockIdx.x * 4 + wv;
+    const int LPR = LPR_T ? LPR_T : LPR_rt;
+    const int KP = 4 * LPR;
+    const int RPI = 64 / LPR;              // rows per instruction
+    const int rs = lane / LPR, cc = lane - rs * LPR;
+    const bool lane_on = rs < RPI;
+    const bool active = c < p.n_chunks;
+    const int j = active ? p.chunk_id[c] : 0;
+    const int b = active ? p.chunk_begin[c] : 0, e = active ? p.chunk_end[c] : 0;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float wl = 0.0f;
+    for (int t0 = b; t0 < e; t0 += 64) {
+        const int tok = t0 + lane;
+        const bool valid = tok < e;
+        const int dd = valid ? p.tok_doc[tok] : 0;
+        const float wv_ = valid ? p.w[p.tok_pos[tok]] : 0.0f;
+        wl += wv_;
+        dw_l[wv][lane] = make_int2(dd, __builtin_bit_cast(int, wv_));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int cnt = min(64, e - t0);
+        if (lane_on) {
+#pragma unroll 8
+            for (int k = rs; k < cnt; k += RPI) {
+                const int2 dw = dw_l[wv][k];
+                const float4 ev = *(const float4*)(p.E + (int64_t)dw.x * KP + 4 * cc);
+                const float wk = __builtin_bit_cast(float, dw.y);
+                acc.x = fmaf(wk, ev.x, acc.x); acc.y = fmaf(wk, ev.y, acc.y);
+                acc.z = fmaf(wk, ev.z, acc.z); acc.w = fmaf(wk, ev.w, acc.w);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    const float wsum = wave_sum(wl);
+    red_l[wv][lane] = acc;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (!active || lane >= LPR) return;
+    float4 tot = red_l[wv][lane];
+    for (int r = 1; r < RPI; ++r) {
+        const float4 o = red_l[wv][lane + r * LPR];
+        tot.x += o.x; tot.y += o.y; tot.z += o.z; tot.w += o.w;
+    }
+    const float tv[4] = {tot.x, tot.y, tot.z, tot.w};
+    const int slot = p.chunk_out[c];
+    const int K = p.K;
+    if (slot < 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = 4 * lane + u;
+            if (i < K) p.out[(int64_t)j * p.ostride + i] = p.base + fmaf(p.T[(int64_t)j * p.tstride + i], tv[u], p.eps * wsum);
+        }
+    } else {
+        float* pr = p.partial + (int64_t)slot * (K + 1);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = 4 * lane + u;
+            if (i < K) pr[i] = tv[u];
+        }
+        if (lane == 0) pr[K] = wsum;
+    }
+}
+
+// ids whose tokens span several chunks: one workgroup per id, its 4 waves sum interleaved partial
+// slots, then wave 0 combines the 4 sums in a fixed order (deterministic)
 template <int NSLOT>
 __global__ __launch_bounds__(256) void termstats_multi_kernel(TermStatsParams p, const int32_t* __restrict__ multi_id,
                                                               const int32_t* __restrict__ multi_first,
                                                               const int32_t* __restrict__ multi_count, int n_multi)
 {
-    const int lane = threadIdx.x & 63;
-    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (m >= n_multi) return;
+    __shared__ float red[4][64 * NSLOT + 1];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int m = blockIdx.x;
     const int K = p.K;
     const int j = multi_id[m], first = multi_first[m], cnt = multi_count[m];
     float acc[NSLOT];
 #pragma unroll
     for (int s = 0; s < NSLOT; ++s) acc[s] = 0.0f;
     float wsum = 0.0f;
-    for (int c = 0; c < cnt; ++c) {
+#pragma unroll 8
+    for (int c = wv; c < cnt; c += 4) {
         const float* pr = p.partial + (int64_t)(first + c) * (K + 1);
 #pragma unroll
         for (int s = 0; s < NSLOT; ++s) {
@@ -108,8 +186,17 @@ __global__ __launch_bounds__(256) void termstats_multi_kernel(TermStatsParams p,
         wsum += pr[K];
     }
 #pragma unroll
+    for (int s = 0; s < NSLOT; ++s) red[wv][lane + 64 * s] = acc[s];
+    if (lane == 0) red[wv][64 * NSLOT] = wsum;
+    __syncthreads();
+    if (wv != 0) return;
+    const float ws = (red[0][64 * NSLOT] + red[1][64 * NSLOT]) + (red[2][64 * NSLOT] + red[3][64 * NSLOT]);
+#pragma unroll
     for (int s = 0; s < NSLOT; ++s) {
         const int i = lane + 64 * s;
-        if (i < K) p.out[(int64_t)j * p.ostride + i] = p.base + fmaf(p.T[(int64_t)j * p.tstride + i], acc[s], p.eps * wsum);
+        if (i < K) {
+            const float a = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+            p.out[(int64_t)j * p.ostride + i] = p.base + fmaf(p.T[(int64_t)j * p.tstride + i], a, p.eps * ws);
+        }
     }
 }
