@@ -221,13 +221,13 @@ int tmvb_build_inv_index(tmvb_ctx* ctx, int64_t M, int64_t n_ids, const int64_t*
     std::vector<int64_t> cnt(n_ids + 1, 0);
     for (int64_t q = 0; q < nnz; ++q) cnt[h_ids[q] + 1]++;
     for (int64_t j = 0; j < n_ids; ++j) cnt[j + 1] += cnt[j];
-    std::vector<int32_t> doc(nnz), pos(nnz);
+    std::vector<int32_t> doc(nnz), pos(nnz), inv(nnz);
     {
         std::vector<int64_t> cur(cnt.begin(), cnt.end() - 1);
         for (int64_t d = 0; d < M; ++d)
             for (int64_t q = h_ptr[d]; q < h_ptr[d + 1]; ++q) {
                 int64_t w = cur[h_ids[q]]++;
-                doc[w] = (int32_t)d; pos[w] = (int32_t)q;
+                doc[w] = (int32_t)d; pos[w] = (int32_t)q; inv[q] = (int32_t)w;
             }
     }
     std::vector<int32_t> cid, cb, ce, co, mid, mfirst, mcount;
@@ -247,6 +247,7 @@ int tmvb_build_inv_index(tmvb_ctx* ctx, int64_t M, int64_t n_ids, const int64_t*
     ix->n_chunks = (int64_t)cid.size(); ix->n_multi = (int64_t)mid.size(); ix->n_slots = slots;
     int rc;
     if ((rc = upload(ctx, &ix->d_doc, doc.data(), doc.size())) || (rc = upload(ctx, &ix->d_pos, pos.data(), pos.size())) ||
+        (rc = upload(ctx, &ix->d_inv, inv.data(), inv.size())) ||
         (rc = upload(ctx, &ix->d_chunk_id, cid.data(), cid.size())) || (rc = upload(ctx, &ix->d_chunk_begin, cb.data(), cb.size())) ||
         (rc = upload(ctx, &ix->d_chunk_end, ce.data(), ce.size())) || (rc = upload(ctx, &ix->d_chunk_out, co.data(), co.size())) ||
         (rc = upload(ctx, &ix->d_multi_id, mid.data(), mid.size())) || (rc = upload(ctx, &ix->d_multi_first, mfirst.data(), mfirst.size())) ||
@@ -259,7 +260,7 @@ int tmvb_build_inv_index(tmvb_ctx* ctx, int64_t M, int64_t n_ids, const int64_t*
 
 void tmvb_free_inv_index(tmvb_inv_index* ix)
 {
-    (void)hipFree(ix->d_doc); (void)hipFree(ix->d_pos); (void)hipFree(ix->d_chunk_id); (void)hipFree(ix->d_chunk_begin);
+    (void)hipFree(ix->d_doc); (void)hipFree(ix->d_pos); (void)hipFree(ix->d_inv); (void)hipFree(ix->d_chunk_id); (void)hipFree(ix->d_chunk_begin);
     (void)hipFree(ix->d_chunk_end); (void)hipFree(ix->d_chunk_out); (void)hipFree(ix->d_multi_id);
     (void)hipFree(ix->d_multi_first); (void)hipFree(ix->d_multi_count);
     *ix = tmvb_inv_index();

@@ -46,6 +46,7 @@ struct tmvb_ctx {
 struct tmvb_bucket {
     int64_t first = 0, count = 0;
     int32_t tile_rows = 0;
+    int32_t reg_tiles = 0;     // > 0: register-tile kernel with this many 64-token tiles (no LDS tile)
 };
 
 // Inverted (id-major) index over a CSR token stream, cut into chunks of at most TMVB_CHUNK tokens.
@@ -58,6 +59,7 @@ struct tmvb_inv_index {
     int64_t n_ids = 0, nnz = 0;
     int32_t* d_doc = nullptr;          // [nnz] document of each token, id-major order
     int32_t* d_pos = nullptr;          // [nnz] CSR position of each token, id-major order
+    int32_t* d_inv = nullptr;          // [nnz] id-major position of each CSR token (inverse of d_pos)
     int64_t n_chunks = 0;
     int32_t* d_chunk_id = nullptr;     // [n_chunks] id (term / reader) the chunk belongs to
     int32_t* d_chunk_begin = nullptr;  // [n_chunks] token range in id-major order

@@ -47,7 +47,8 @@ struct LdaParams {
     const int32_t* doc_order;
     const float* alpha;
     const float* beta;       // [V][KP], pad columns zero
-    float* wtok;             // [nnz] last-sweep c_n / s_n per token (CSR order)
+    float* wtok;             // [nnz] last-sweep c_n / s_n per token, stored in term-major (inverted index) order
+    const int32_t* tok_inv;  // [nnz] term-major position of each CSR token
     float* E;                // [M][estride] last-sweep exp(Elogtheta_old) (estride = KP, pads zero, when K <= 256)
     int estride;
     float* gamma;
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(64) void lda_estep_kernel(LdaParams p, int64_t firs
     };
     // documents that stream chunks keep the latest w in HBM every sweep (the last one survives)
     auto store_w = [&](int c0, int rows) {
-        for (int n = lane; n < rows; n += 64) p.wtok[off + c0 + n] = w_l[n];
+        for (int n = lane; n < rows; n += 64) p.wtok[p.tok_inv[off + c0 + n]] = w_l[n];
     };
 
     // phase 2: lane = 4*ql + r handles topic quad q = 16 s + ql for the tokens n = r (mod 4);
@@ -267,9 +268,198 @@ __global__ __launch_bounds__(64) void lda_estep_kernel(LdaParams p, int64_t firs
         }
         if (single) store_w(0, N);
     } else {
-        for (int n = lane; n < N; n += 64) p.wtok[off + n] = 0.0f;   // viter = 0: no responsibilities
+        for (int n = lane; n < N; n += 64) p.wtok[p.tok_inv[off + n]] = 0.0f;   // viter = 0: no responsibilities
     }
     if (lane == 0) p.sweeps[d] = (uint8_t)min(sweeps, 255);
+}
+
+// ------------------------------------------------------------------------------ register-tile E-step
+// For K <= 64 and documents of at most 64*T unique terms the whole N_d x KP topic tile lives in
+// VGPRs (lane = token, register = topic): the register file (512 KiB per CU) is 3x the LDS, so the
+// tile costs no LDS and the sweeps run without a single LDS wait.
+//   phase 1  s_n = K eps + sum_q B[n][q] e_q     R = KP fmas per tile with e_q as an SGPR operand
+//   phase 2  g_q = sum_n w_n B[n][q]             R products per tile, then a 6-stage reduce-scatter
+//            over the 64 lanes (v_permlane32_swap, v_permlane16_swap, 4 DPP stages; ~2.2 R
+//            instructions): afterwards lane L holds the total of topic pi(L)
+// pi (topic_of_lane / lane_of_topic) is computed on the host by replaying the same pairing.
+// NOTE: hipcc 7.2 mis-selects __builtin_amdgcn_permlane{32,16}_swap when both results feed one add
+// (it emits `v_add v, r0, r0`), so the swap is issued through inline asm.  hipcc inserts no hazard
+// wait states inside asm: the leading s_nop covers a preceding VALU write of the operands.
+__device__ __forceinline__ void swap_add32(float& a, float b)
+{
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    a += b;                                   // lanes < 32: a.lo + a.hi, lanes >= 32: b.lo + b.hi
+}
+__device__ __forceinline__ void swap_add16(float& a, float b)
+{
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    a += b;                                   // even rows: sums of a, odd rows: sums of b
+}
+template <int CTRL>
+__device__ __forceinline__ void dpp_stage(float& a, float b, bool hi)
+{
+    const float keep = hi ? b : a, give = hi ? a : b;
+    a = keep + dpp_f<CTRL>(give);
+}
+
+template <int R>
+__device__ __forceinline__ float lane_reduce_scatter(float (&p)[R], int lane)
+{
+    constexpr int m0 = R, h0 = (m0 + 1) / 2;
+#pragma unroll
+    for (int i = 0; i < h0; ++i) swap_add32(p[i], (i + h0 < m0) ? p[i + h0] : p[i]);
+    constexpr int m1 = h0, h1 = (m1 + 1) / 2;
+#pragma unroll
+    for (int i = 0; i < h1; ++i) swap_add16(p[i], (i + h1 < m1) ? p[i + h1] : p[i]);
+    constexpr int m2 = h1, h2 = (m2 + 1) / 2;
+    const bool b8 = lane & 8, b4 = lane & 4, b2 = lane & 2, b1 = lane & 1;
+#pragma unroll
+    for (int i = 0; i < h2; ++i) {
+        if (i + h2 < m2) dpp_stage<0x140>(p[i], p[i + h2], b8);      // row_mirror
+        else p[i] += dpp_f<0x140>(p[i]);
+    }
+    constexpr int m3 = h2, h3 = (m3 + 1) / 2;
+#pragma unroll
+    for (int i = 0; i < h3; ++i) {
+        if (i + h3 < m3) dpp_stage<0x141>(p[i], p[i + h3], b4);      // row_half_mirror
+        else p[i] += dpp_f<0x141>(p[i]);
+    }
+    constexpr int m4 = h3, h4 = (m4 + 1) / 2;
+#pragma unroll
+    for (int i = 0; i < h4; ++i) {
+        if (i + h4 < m4) dpp_stage<0x4E>(p[i], p[i + h4], b2);       // quad_perm [2,3,0,1]
+        else p[i] += dpp_f<0x4E>(p[i]);
+    }
+    constexpr int m5 = h4;
+    static_assert(m5 <= 2, "reduce-scatter supports up to 64 registers");
+    if (m5 == 2) dpp_stage<0xB1>(p[0], p[1], b1);                    // quad_perm [1,0,3,2]
+    else p[0] += dpp_f<0xB1>(p[0]);
+    return p[0];
+}
+
+template <int LPR, int T>
+__global__ __launch_bounds__(64) void lda_estep_reg_kernel(LdaParams p, int64_t first,
+                                                           const int* __restrict__ topic_of_lane,
+                                                           const int* __restrict__ lane_of_topic)
+{
+    constexpr int R = 4 * LPR;
+    const int lane = threadIdx.x;
+    const int K = p.K;
+    const int d = p.doc_order[first + blockIdx.x];
+    const int64_t off = p.doc_ptr[d];
+    const int N = (int)(p.doc_ptr[d + 1] - off);
+
+    // token role: lane n owns tokens n + 64 t
+    float B[T][R], c[T], w[T];
+    int wpos[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int n = lane + 64 * t;
+        if (n < N) {
+            const int term = p.terms[off + n];
+            c[t] = (float)p.counts[off + n];
+            wpos[t] = p.tok_inv[off + n];
+            const float4* row = (const float4*)(p.beta + (int64_t)term * R);
+#pragma unroll
+            for (int q = 0; q < LPR; ++q) {
+                const float4 v = row[q];
+                B[t][4 * q] = v.x; B[t][4 * q + 1] = v.y; B[t][4 * q + 2] = v.z; B[t][4 * q + 3] = v.w;
+            }
+        } else {
+            c[t] = 0.0f; wpos[t] = -1;
+#pragma unroll
+            for (int q = 0; q < R; ++q) B[t][q] = 0.0f;
+        }
+        w[t] = 0.0f;
+    }
+    // topic role: lane L owns topic pi(L) (duplicates are marked -1 by the host)
+    const int mytopic = topic_of_lane[lane];
+    const bool on = mytopic >= 0 && mytopic < K;
+    const float alpha = on ? p.alpha[mytopic] : 0.0f;
+    float elog = on ? p.elog[(int64_t)d * K + mytopic] : 0.0f;
+    float elog_old = elog, gam = 0.0f, e = 0.0f;
+    int lot[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) lot[q] = lane_of_topic[q];
+
+    int sweeps = 0;
+    for (int v = 0; v < p.viter; ++v) {
+        ++sweeps;
+        e = on ? expf(elog) : 0.0f;                                   // update_phi!, src/LDA.jl:152
+        float es[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) es[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e), lot[q]));
+        float wl = 0.0f;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+            for (int q = 0; q < R; q += 4) {
+                s0 = fmaf(B[t][q], es[q], s0); s1 = fmaf(B[t][q + 1], es[q + 1], s1);
+                s2 = fmaf(B[t][q + 2], es[q + 2], s2); s3 = fmaf(B[t][q + 3], es[q + 3], s3);
+            }
+            const float sn = ((s0 + s1) + (s2 + s3)) + (float)K * TMVB_EPS_F;
+            w[t] = c[t] / sn;
+            wl += w[t];
+        }
+        const float wsum = wave_sum(wl);
+        float pr[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            float a = w[0] * B[0][q];
+#pragma unroll
+            for (int t = 1; t < T; ++t) a = fmaf(w[t], B[t][q], a);
+            pr[q] = a;
+        }
+        const float g = lane_reduce_scatter<R>(pr, lane);
+        gam = TMVB_EPS_F + (alpha + fmaf(e, g, TMVB_EPS_F * wsum));   // update_gamma!, src/LDA.jl:145
+        const float gsum = wave_sum(on ? gam : 0.0f);
+        const float dgs = digamma_f(gsum);
+        elog_old = elog;                                              // update_Elogtheta!, :137-138
+        float dl = 0.0f;
+        if (on) {
+            elog = digamma_f(gam) - dgs;
+            const float df = elog - elog_old;
+            dl = df * df;
+        }
+        const float dist2 = wave_sum(dl);
+        if (sqrtf(dist2) < p.vtol) break;                             // :175
+    }
+    if (sweeps > 0) {
+        if (on) {
+            p.gamma[(int64_t)d * K + mytopic] = gam;
+            p.elog[(int64_t)d * K + mytopic] = elog;
+            p.elog_old[(int64_t)d * K + mytopic] = elog_old;
+        }
+        if (mytopic >= 0 && mytopic < p.estride) p.E[(int64_t)d * p.estride + mytopic] = e;
+#pragma unroll
+        for (int t = 0; t < T; ++t) if (wpos[t] >= 0) p.wtok[wpos[t]] = w[t];
+    } else {
+#pragma unroll
+        for (int t = 0; t < T; ++t) if (wpos[t] >= 0) p.wtok[wpos[t]] = 0.0f;
+    }
+    if (lane == 0) p.sweeps[d] = (uint8_t)min(sweeps, 255);
+}
+
+// host replay of lane_reduce_scatter's pairing: which topic ends up in which lane
+static void lda_reg_lane_maps(int R, std::vector<int>& topic_of_lane, std::vector<int>& lane_of_topic)
+{
+    std::vector<std::vector<int>> regs(R, std::vector<int>(64));
+    for (int q = 0; q < R; ++q) for (int l = 0; l < 64; ++l) regs[q][l] = q;
+    const int Ds[6] = {32, 16, 8, 4, 2, 1};
+    for (int st = 0; st < 6; ++st) {
+        const int D = Ds[st], m = (int)regs.size(), h = (m + 1) / 2;
+        std::vector<std::vector<int>> nxt(h, std::vector<int>(64));
+        for (int i = 0; i < h; ++i)
+            for (int l = 0; l < 64; ++l) nxt[i][l] = (i + h < m && (l & D)) ? regs[i + h][l] : regs[i][l];
+        regs.swap(nxt);
+    }
+    topic_of_lane.assign(64, -1);
+    lane_of_topic.assign(R, -1);
+    for (int l = 0; l < 64; ++l) {
+        int q = regs[0][l];
+        if (lane_of_topic[q] < 0) { lane_of_topic[q] = l; topic_of_lane[l] = q; }   // first lane is the primary
+    }
 }
 
 // ------------------------------------------------------------------------------ reductions
@@ -523,6 +713,9 @@ struct tmvb_lda {
     float* d_E = nullptr;              // [M][estride]
     int estride = 0;
     float* d_ts_partial = nullptr;     // [n_slots][K+1]
+    int* d_topic_of_lane = nullptr;    // register-tile kernel lane maps
+    int* d_lane_of_topic = nullptr;
+    bool reg_path = false;             // K <= 64 with a specialised LPR: short documents use lda_estep_reg_kernel
     int32_t* d_doc_order = nullptr;
     double* d_partial = nullptr;       // [LDA_REDUCE_BLOCKS][K]
     double* d_rowsum = nullptr;        // [K]
@@ -555,44 +748,58 @@ static int dispatch_nslot(int nslot, F&& f)
 
 static size_t lda_tile_bytes(int rows, int KP) { return ((size_t)rows * KP + KP + 3 * (size_t)rows) * sizeof(float); }
 
+static bool lda_reg_lpr_supported(int lpr) { return lpr == 1 || lpr == 3 || lpr == 5 || lpr == 13; }
+#define LDA_REG_MAX_TILES 4
+
 static void lda_build_buckets(tmvb_lda* h, std::vector<int32_t>& order)
 {
     const std::vector<int64_t>& len = h->corp->h_doc_len;
     order.resize(h->M);
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return len[x] > len[y]; });
-    // tile heights: LDS per wave bounds the waves per CU, so buckets are kept narrow
-    // (16-row steps to 128, 32-row steps to 256, then doubling) within 64 KiB per wave
-    std::vector<int> tiles;
-    for (int r = 16; r <= 8192; r += (r < 128 ? 16 : (r < 256 ? 32 : r))) {
-        if (lda_tile_bytes(r, h->KP) > LDA_MAX_TILE_BYTES) break;
-        tiles.push_back(r);
-    }
-    if (tiles.empty()) tiles.push_back(4);
     h->buckets.clear();
+    const int64_t reg_max = h->reg_path ? 64 * LDA_REG_MAX_TILES : -1;
+    // documents longer than reg_max: LDS-tile kernel, tile heights in 32-row steps within 64 KiB
+    int64_t n_lds = 0;
+    while (n_lds < h->M && len[order[n_lds]] > reg_max) ++n_lds;
     int64_t pos = 0;
-    // documents longer than the largest tile stream chunks through the largest tile
-    int tmax = tiles.back();
-    int64_t cnt = 0;
-    while (pos + cnt < h->M && len[order[pos + cnt]] > tmax) ++cnt;
-    if (cnt) h->buckets.push_back({pos, cnt, tmax});
-    pos += cnt;
-    for (int b = (int)tiles.size() - 1; b >= 0; --b) {
-        int64_t lo = (b > 0) ? tiles[b - 1] : -1;
-        cnt = 0;
-        while (pos + cnt < h->M && len[order[pos + cnt]] > lo) ++cnt;
-        if (cnt) h->buckets.push_back({pos, cnt, tiles[b]});
-        pos += cnt;
-    }
-    // merge tiny buckets into their larger neighbour (a launch needs enough waves to matter)
-    for (size_t b = 1; b < h->buckets.size();) {
-        if (h->buckets[b].count < 512 && h->buckets[b - 1].first + h->buckets[b - 1].count == h->buckets[b].first &&
-            !(b == 1 && len[order[0]] > tmax)) {
-            h->buckets[b - 1].count += h->buckets[b].count;
-            h->buckets.erase(h->buckets.begin() + b);
-        } else {
-            ++b;
+    if (n_lds > 0) {
+        std::vector<int> tiles;
+        for (int r = 32; r <= 8192; r += (r < 256 ? 32 : r)) {
+            if (lda_tile_bytes(r, h->KP) > LDA_MAX_TILE_BYTES) break;
+            tiles.push_back(r);
         }
+        if (tiles.empty()) tiles.push_back(4);
+        const int tmax = tiles.back();
+        int64_t cnt = 0;
+        while (pos + cnt < n_lds && len[order[pos + cnt]] > tmax) ++cnt;   // stream chunks through the largest tile
+        if (cnt) h->buckets.push_back({pos, cnt, tmax, 0});
+        pos += cnt;
+        for (int b = (int)tiles.size() - 1; b >= 0 && pos < n_lds; --b) {
+            const int64_t lo = (b > 0) ? tiles[b - 1] : -1;
+            cnt = 0;
+            while (pos + cnt < n_lds && len[order[pos + cnt]] > lo) ++cnt;
+            if (cnt) h->buckets.push_back({pos, cnt, tiles[b], 0});
+            pos += cnt;
+        }
+        // merge small LDS buckets into their larger neighbour
+        for (size_t b = 1; b < h->buckets.size();) {
+            if (h->buckets[b].count < 512 && h->buckets[b - 1].tile_rows >= h->buckets[b].tile_rows &&
+                len[order[h->buckets[b - 1].first + h->buckets[b - 1].count - 1]] <= h->buckets[b - 1].tile_rows) {
+                h->buckets[b - 1].count += h->buckets[b].count;
+                h->buckets.erase(h->buckets.begin() + b);
+            } else {
+                ++b;
+            }
+        }
+    }
+    // register-tile buckets: T = ceil(N / 64) tiles of 64 tokens
+    for (int T = LDA_REG_MAX_TILES; T >= 1 && pos < h->M; --T) {
+        const int64_t lo = 64 * (int64_t)(T - 1);
+        int64_t cnt = 0;
+        while (pos + cnt < h->M && (len[order[pos + cnt]] > lo || T == 1)) ++cnt;
+        if (cnt) h->buckets.push_back({pos, cnt, 0, T});
+        pos += cnt;
     }
 }
 
@@ -616,6 +823,7 @@ extern "C" int tmvb_lda_destroy(tmvb_lda* h)
     (void)hipFree(h->d_alpha_d); (void)hipFree(h->d_alpha_f); (void)hipFree(h->d_beta[0]); (void)hipFree(h->d_beta[1]);
     if (h->own_stats) (void)hipFree(h->d_stats);
     (void)hipFree(h->d_wtok); (void)hipFree(h->d_E); (void)hipFree(h->d_ts_partial);
+    (void)hipFree(h->d_topic_of_lane); (void)hipFree(h->d_lane_of_topic);
     (void)hipFree(h->d_gamma); (void)hipFree(h->d_elog); (void)hipFree(h->d_elog_old); (void)hipFree(h->d_sweeps);
     (void)hipFree(h->d_doc_order); (void)hipFree(h->d_partial); (void)hipFree(h->d_rowsum); (void)hipFree(h->d_esum);
     (void)hipFree(h->d_doc_val); (void)hipFree(h->d_elbo); (void)hipFree(h->d_iters);
@@ -696,6 +904,14 @@ extern "C" int tmvb_lda_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
         (rc = dmalloc(&h->d_ts_partial, (size_t)corp->term_index.n_slots * (K + 1)))) {
         tmvb_lda_destroy(h);
         return rc;
+    }
+    h->reg_path = (K <= 64) && lda_reg_lpr_supported(h->KP / 4);
+    if (h->reg_path) {
+        std::vector<int> tol, lot;
+        lda_reg_lane_maps(h->KP, tol, lot);
+        if ((rc = dmalloc(&h->d_topic_of_lane, 64)) || (rc = dmalloc(&h->d_lane_of_topic, (size_t)h->KP))) { tmvb_lda_destroy(h); return rc; }
+        TMVB_HIP(hipMemcpy(h->d_topic_of_lane, tol.data(), 64 * sizeof(int), hipMemcpyHostToDevice));
+        TMVB_HIP(hipMemcpy(h->d_lane_of_topic, lot.data(), (size_t)h->KP * sizeof(int), hipMemcpyHostToDevice));
     }
     std::vector<int32_t> order;
     lda_build_buckets(h, order);
@@ -785,7 +1001,7 @@ extern "C" int tmvb_lda_estep(tmvb_lda* h, int32_t viter, double vtol)
     p.K = h->K; p.KP = h->KP; p.LPR = h->KP / 4; p.lpr_magic = (unsigned)(0x100000000ull / (unsigned)p.LPR) + 1u; p.V = h->V;
     p.doc_ptr = h->corp->d_doc_ptr; p.terms = h->corp->d_terms; p.counts = h->corp->d_counts;
     p.doc_order = h->d_doc_order;
-    p.alpha = h->d_alpha_f; p.beta = h->d_beta[h->cur]; p.wtok = h->d_wtok; p.E = h->d_E; p.estride = h->estride;
+    p.alpha = h->d_alpha_f; p.beta = h->d_beta[h->cur]; p.wtok = h->d_wtok; p.tok_inv = h->corp->term_index.d_inv; p.E = h->d_E; p.estride = h->estride;
     p.gamma = h->d_gamma; p.elog = h->d_elog; p.elog_old = h->d_elog_old; p.sweeps = h->d_sweeps;
     p.viter = viter; p.vtol = (float)vtol;
     { const char* dbg = getenv("TMVB_DEBUG_FLAGS"); p.debug = dbg ? atoi(dbg) : 0; }
@@ -799,6 +1015,26 @@ extern "C" int tmvb_lda_estep(tmvb_lda* h, int32_t viter, double vtol)
     for (int bi = 0; bi < nb; ++bi) {
         const tmvb_bucket& b = h->buckets[bi];
         hipStream_t st = (naux > 1) ? h->aux[bi % naux] : ctx->stream;
+        if (b.reg_tiles > 0) {
+            const dim3 grid((unsigned)b.count), block(64);
+            const int* tol = h->d_topic_of_lane; const int* lot = h->d_lane_of_topic;
+#define LDA_REG_LAUNCH(LPRV, TV) hipLaunchKernelGGL((lda_estep_reg_kernel<LPRV, TV>), grid, block, 0, st, p, b.first, tol, lot)
+#define LDA_REG_LAUNCH_T(LPRV)                                                                  \
+            switch (b.reg_tiles) {                                                              \
+                case 1: LDA_REG_LAUNCH(LPRV, 1); break;                                         \
+                case 2: LDA_REG_LAUNCH(LPRV, 2); break;                                         \
+                case 3: LDA_REG_LAUNCH(LPRV, 3); break;                                         \
+                default: LDA_REG_LAUNCH(LPRV, 4); break;                                        \
+            }
+            switch (p.LPR) {
+                case 1: LDA_REG_LAUNCH_T(1); break;
+                case 3: LDA_REG_LAUNCH_T(3); break;
+                case 5: LDA_REG_LAUNCH_T(5); break;
+                default: LDA_REG_LAUNCH_T(13); break;
+            }
+            TMVB_HIP(hipGetLastError());
+            continue;
+        }
         const size_t lds = lda_tile_bytes(b.tile_rows, h->KP);
         int rc = dispatch_nslot(h->nslot, [&](auto ns) -> int {
             constexpr int NS = decltype(ns)::value;

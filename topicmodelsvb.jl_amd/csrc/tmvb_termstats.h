@@ -23,7 +23,7 @@ struct TermStatsParams {
     const int32_t* chunk_end;
     const int32_t* chunk_out;
     int n_chunks;
-    const float* w;              // [nnz] per-token weight, CSR order
+    const float* w;              // [nnz] per-token weight, id-major (inverted index) order
     const float* E;              // per-document factor: [M][K] (scalar kernel) or [M][KP] zero padded (chunk4 kernel)
     const float* T;              // [n_ids][tstride] per-id factor
     float eps;                   // additive epsilon (LDA: EPSILON, others 0)
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void termstats_chunk_kernel(TermStatsParams p)
         const int tok = t0 + lane;
         const bool valid = tok < e;
         const int dd = valid ? p.tok_doc[tok] : 0;
-        const float wv = valid ? p.w[p.tok_pos[tok]] : 0.0f;
+        const float wv = valid ? p.w[tok] : 0.0f;
         wl += wv;
         const int cnt = min(64, e - t0);
 #pragma unroll 8
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void termstats_chunk4_kernel(TermStatsParams p
         const int tok = t0 + lane;
         const bool valid = tok < e;
         const int dd = valid ? p.tok_doc[tok] : 0;
-        const float wv_ = valid ? p.w[p.tok_pos[tok]] : 0.0f;
+        const float wv_ = valid ? p.w[tok] : 0.0f;
         wl += wv_;
         dw_l[wv][lane] = make_int2(dd, __builtin_bit_cast(int, wv_));
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
