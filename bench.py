@@ -47,14 +47,30 @@ def mstep_bytes(K, V):
     return 12 * K * V
 
 
+def pmc_traffic(K, M, nnz):
+    """HBM traffic of one E-step from the committed rocprofv3 PMC summary (separate --pmc FETCH_SIZE /
+    --pmc WRITE_SIZE passes of this same command, profiles/r1_lda_k50_pmc.*), corrected as
+    MI355X_MICROARCH.md's HBM section prescribes for gfx950 (2 x FETCH_SIZE; KB units).  Only returned
+    when the workload is the one the counters were collected on; otherwise null."""
+    path = os.path.join(ROOT, "profiles", "r1_lda_k50_pmc.json")
+    if not (K == 50 and M == 128804 and nnz == 10929864 and os.path.exists(path)):
+        return None
+    rows = json.load(open(path))
+    tot = 0.0
+    for name, r in rows.items():
+        if "lda_estep" in name or "termstats" in name:
+            tot += (2.0 * r["fetch_kb_per_dispatch"] + r["write_kb_per_dispatch"]) * 1024.0
+    return tot
+
+
 def cpu_baseline(tm, corpus, K, beta0, warmup, budget_s=20.0):
     """fp64 oracle (oracle/*.c) on a bounded sample of the same workload, all host cores (OpenMP
     document-parallel E-step) and single thread; scaled to full-corpus iterations/s by nnz."""
     import numpy as np
     from oracle import oracle as oc
     oc.build()
-    ncores = os.cpu_count() or 1
-    sample_docs = min(corpus.M, 6000)
+    ncores = min(os.cpu_count() or 1, 64)      # threads actually used (private K x V statistics per thread)
+    sample_docs = min(corpus.M, 16000)
     sh = corpus.shard(0, sample_docs)
     frac = sh.nnz / max(corpus.nnz, 1)
 
@@ -71,8 +87,9 @@ def cpu_baseline(tm, corpus, K, beta0, warmup, budget_s=20.0):
                 break
         return done / (time.perf_counter() - t0)
 
+    run(ncores, 1)                             # OpenMP runtime start-up outside the timing
     omp = run(ncores, 8)
-    one = run(1, 2) if ncores > 1 else omp   # serial path (threads=0 -> serial in the C oracle; 1 = OpenMP with one thread)
+    one = run(1, 2) if ncores > 1 else omp
     return {
         "value": omp * frac, "unit": "VB iters/sec", "cores": ncores, "kind": "port",
         "single_thread_value": one * frac,
@@ -172,9 +189,11 @@ def main():
                        "K": K, "M": corpus.M, "V": V, "nnz": corpus.nnz, "sum_counts": int(corpus.counts.sum()),
                        "parallelism": f"doc-shard x{world}, 1 all-reduce of {K * V + K} f32 per iteration" if world > 1 else "single GPU",
                        "sweep_hist_last_step": sweep_hist},
-            "roofline": {"bound": "hbm", "kernel": "lda_estep_kernel (all length buckets of one E-step)",
+            "roofline": {"bound": "hbm", "kernel": "LDA E-step = lda_estep_reg_kernel/lda_estep_kernel (one launch per document-length bucket, concurrent on 4 streams) + termstats_chunk4_kernel + termstats_multi_kernel",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes_per_estep": b_e, "estep_ms": ms,
+                         "traffic": pmc_traffic(K, shard.M, shard.nnz) if world == 1 else None,
+                         "traffic_source": "profiles/r1_lda_k50_pmc.txt (rocprofv3 --pmc, separate passes; 2*FETCH_SIZE+WRITE_SIZE summed over the E-step's kernels)",
+                         "algorithmic_bytes_per_estep": b_e, "estep_ms": ms,
                          "estep_ms_min": float(np.min(estep_ms)), "estep_ms_max": float(np.max(estep_ms)),
                          "launches_per_estep": n_launch,
                          "whole_iteration_GBs": (b_e + mstep_bytes(K, V)) / (elapsed / args.steps) / 1e9},

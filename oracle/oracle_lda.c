@@ -129,30 +129,39 @@ int orc_lda_estep_omp(int64_t M, int64_t V, int64_t K,
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
     int64_t mx = max_doc_len(doc_ptr, d0, d1);
+    int nt = omp_get_max_threads();
+    double** bts = (double**)calloc((size_t)nt, sizeof(double*));
 #pragma omp parallel
     {
 #pragma omp single
         used = omp_get_num_threads();
+        int tid = omp_get_thread_num();
         double* phi = (double*)malloc(sizeof(double) * (size_t)(K * mx));
+        double* bt = (double*)calloc((size_t)(K * V), sizeof(double));   /* private statistics */
+        bts[tid] = bt;
 #pragma omp for schedule(dynamic, 16)
         for (int64_t d = d0; d < d1; ++d) {
             int64_t off = doc_ptr[d], Nd = doc_ptr[d + 1] - off;
             orc_lda_doc_sweeps(K, Nd, terms + off, counts + off, alpha, beta,
                                gamma + d * K, Elogtheta + d * K, Elogtheta_old + d * K,
                                phi, viter, vtol);
-            /* shared statistics, atomic accumulation (condensed corpora: no duplicate ids) */
             for (int64_t n = 0; n < Nd; ++n) {
-                double* bt = beta_temp + (int64_t)terms[off + n] * K;
+                double* col = bt + (int64_t)terms[off + n] * K;
                 double c = (double)counts[off + n];
-                for (int64_t i = 0; i < K; ++i) {
-                    double v = phi[n * K + i] * c;
-#pragma omp atomic update
-                    bt[i] += v;
-                }
+                for (int64_t i = 0; i < K; ++i) col[i] += phi[n * K + i] * c;
             }
         }
         free(phi);
+        /* parallel reduction of the private statistics over the K*V entries */
+#pragma omp for schedule(static)
+        for (int64_t q = 0; q < K * V; ++q) {
+            double sacc = 0.0;
+            for (int t = 0; t < nt; ++t) if (bts[t]) sacc += bts[t][q];
+            beta_temp[q] += sacc;
+        }
+        free(bt);
     }
+    free(bts);
 #else
     (void)nthreads;
     orc_lda_estep(M, V, K, doc_ptr, terms, counts, d0, d1, alpha, beta, beta_temp,
