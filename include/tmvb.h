@@ -149,6 +149,52 @@ int tmvb_lda_estep_launches(tmvb_lda* h, int32_t* n);
 /* Timing of the last tmvb_lda_estep on the context's stream, from HIP events (ms). */
 int tmvb_lda_last_estep_ms(tmvb_lda* h, float* ms);
 
+/* ============================== CTM (src/gpuCTM.jl, oracle src/CTM.jl) ============================== */
+
+/* gpuCTM(corp, K) (src/gpuCTM.jl:45-98).  Constructor state as src/CTM.jl:37-48 (mu=0, sigma=invsigma=I,
+ * lambda=0, vsq=1, logzeta=0.5); beta is uniform until tmvb_ctm_set_state (the reference draws it with
+ * Julia's RNG).  This release instantiates the register Gauss-Jordan solve for K in 1..4, 9..12, 17..20,
+ * 49..52; other K return TMVB_EINVAL. */
+int tmvb_ctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb_ctm** out);
+int tmvb_ctm_destroy(tmvb_ctm* h);
+
+/* update_buffer! state half (src/modelutils.jl:420-431) / @gpu field copies (src/macros.jl:152-175).
+ * mu[K], sigma[K*K], invsigma[K*K], beta[K*V], lambda[K*M], vsq[K*M], logzeta[M]; NULL = unchanged;
+ * beta_old / lambda_old default to beta / lambda. */
+int tmvb_ctm_set_state(tmvb_ctm* h, const double* mu, const double* sigma, const double* invsigma,
+                       const double* beta, const double* beta_old, const double* lambda,
+                       const double* lambda_old, const double* vsq, const double* logzeta, const double* elbo);
+/* update_host! (src/modelutils.jl:519-537) without phi. */
+int tmvb_ctm_get_state(tmvb_ctm* h, double* mu, double* sigma, double* invsigma, double* beta, double* beta_old,
+                       double* lambda, double* lambda_old, double* vsq, double* logzeta, double* elbo);
+
+/* update_phi! / update_logzeta! / update_vsq! / update_lambda! sweeps + update_beta!(model, d) for every
+ * document with the CPU path's semantics (src/CTM.jl:194-205; replaces the launches at
+ * src/gpuCTM.jl:478-479, :425, :390, :342, :254).  Asynchronous on the context's stream. */
+int tmvb_ctm_estep(tmvb_ctm* h, int32_t niter, double ntol, int32_t viter, double vtol);
+/* sum_d lambda_d, sum_d vsq_d and the scatter matrix sum_d (lambda_d - mu)(lambda_d - mu)^T (f32 MFMA) with
+ * the current (= previous-iteration) mu, into the statistics tail. */
+int tmvb_ctm_reduce_docs(tmvb_ctm* h);
+/* Packed statistics for the host's all-reduce: float32 [ S (K*V) | sum_lambda (K) | sum_vsq (K) | scatter (K*K) ]. */
+int tmvb_ctm_stats(tmvb_ctm* h, void** dev_ptr, int64_t* n_f32);
+int tmvb_ctm_bind_stats(tmvb_ctm* h, void* dev_ptr, int64_t n_f32);
+int tmvb_ctm_set_distributed(tmvb_ctm* h, int64_t M_total, int32_t distributed);
+/* update_beta! (src/CTM.jl:114-118; replaces src/gpuCTM.jl:253-256). */
+int tmvb_ctm_update_beta(tmvb_ctm* h);
+/* update_sigma! (src/CTM.jl:108-111; replaces src/gpuCTM.jl:200-206 incl. the host `inv`): uses the
+ * PREVIOUS mu (call before tmvb_ctm_update_mu, as train! does, src/CTM.jl:207-208). */
+int tmvb_ctm_update_sigma(tmvb_ctm* h);
+/* update_mu! (src/CTM.jl:102-104; replaces src/gpuCTM.jl:166-168). */
+int tmvb_ctm_update_mu(tmvb_ctm* h);
+/* update_elbo! (src/CTM.jl:89-98) on the device; sum over this context's documents. */
+int tmvb_ctm_update_elbo(tmvb_ctm* h, double* elbo);
+/* train! (src/gpuCTM.jl:487-519 signature, src/CTM.jl:185-213 semantics). */
+int tmvb_ctm_train(tmvb_ctm* h, int32_t iter, double tol, int32_t niter, double ntol,
+                   int32_t viter, double vtol, int32_t checkelbo, double* elbo_traj, int32_t* iters_done);
+/* Diagnostics of the last E-step: sweeps-per-document histogram and total lambda-Newton steps. */
+int tmvb_ctm_sweep_hist(tmvb_ctm* h, int64_t* hist, int32_t nbins, int64_t* newton_steps);
+int tmvb_ctm_last_estep_ms(tmvb_ctm* h, float* ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,137 @@
+"""
+GPU parity tests for the CTM path: HIP engine (C ABI) vs the fp64 oracle and the committed golden fixture.
+Tolerances (fp64 -> fp32 state; fp64 Newton gradients on device):
+  teacher-forced single step : lambda abs <= 2e-3 + rel 2e-3 (fp32 Gauss-Jordan steps, exit at ||g|| < ntol),
+                               vsq rel <= 2e-3, logzeta abs <= 1e-3, beta rel <= 5e-4 on entries > 1e-6,
+                               mu abs <= 1e-4, sigma abs <= 2e-4 * max|sigma|, ELBO rel <= 2e-6
+  free running               : ELBO rel <= 2e-4 per iteration
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    return {k: z[k] for k in z.files}
+
+
+def make_pair(tmvb, oracle, g):
+    K, V = int(g["K"]), int(g["V"])
+    gm = tmvb.gpuCTM(tmvb.PackedCorpus(g["doc_ptr"], g["terms"], g["counts"], V), K)
+    gm.beta = np.asfortranarray(g["beta0"]); gm.beta_old = gm.beta.copy(order="F")
+    gm.update_buffer()
+    om = oracle.CTM(oracle.CSR(g["doc_ptr"], g["terms"], g["counts"], V), K, g["beta0"])
+    return gm, om
+
+
+def force(gm, om):
+    gm.mu = om.mu.copy(); gm.sigma = om.sigma.copy(order="F"); gm.invsigma = om.invsigma.copy(order="F")
+    gm.beta = om.beta.copy(order="F"); gm.beta_old = om.beta_old.copy(order="F")
+    gm.lam = om.lam.copy(order="F"); gm.lam_old = om.lam_old.copy(order="F")
+    gm.vsq = om.vsq.copy(order="F"); gm.logzeta = om.logzeta.copy()
+    gm.update_buffer()
+
+
+def step(m):
+    m.estep()
+    if hasattr(m, "reduce_docs"):
+        m.reduce_docs(); m.update_beta(); m.update_sigma(); m.update_mu()
+    else:
+        m.update_beta(); m.update_sigma_mu()
+
+
+def synth_case(tmvb, K, M=60, V=300, seed=3):
+    pc = tmvb.syn_nsf(M=M, V=V, seed=seed)
+    return dict(K=K, V=V, doc_ptr=pc.doc_ptr, terms=pc.terms, counts=pc.counts, beta0=tmvb.dirichlet_rows(K, V, seed=5))
+
+
+@pytest.mark.parametrize("case", ["golden_k5", "syn_k12", "syn_k50"])
+def test_teacher_forced_step(tmvb, oracle, case):
+    g = load("ctm_m40_v60_k5") if case == "golden_k5" else synth_case(tmvb, 12 if case == "syn_k12" else 50)
+    gm, om = make_pair(tmvb, oracle, g)
+    for it in range(3):
+        force(gm, om)
+        step(gm); step(om)
+        e_g = gm.update_elbo(); e_o = om.update_elbo()
+        gm.update_host()
+        assert np.all(np.abs(gm.lam - om.lam) <= 2e-3 + 2e-3 * np.abs(om.lam)), (it, np.abs(gm.lam - om.lam).max())
+        assert np.all(np.abs(gm.vsq - om.vsq) <= 2e-3 * om.vsq), (it, "vsq")
+        assert np.abs(gm.logzeta - om.logzeta).max() <= 1e-3, (it, "logzeta")
+        big = om.beta > 1e-6
+        assert (np.abs(gm.beta[big] - om.beta[big]) / om.beta[big]).max() <= 5e-4, (it, "beta")
+        assert np.abs(gm.mu - om.mu).max() <= 1e-4, (it, "mu")
+        assert np.abs(gm.sigma - om.sigma).max() <= 2e-4 * np.abs(om.sigma).max(), (it, "sigma")
+        assert np.abs(gm.invsigma - om.invsigma).max() <= 1e-3 * np.abs(om.invsigma).max(), (it, "invsigma")
+        assert abs(e_g - e_o) <= 2e-6 * abs(e_o), (it, e_g, e_o)
+        np.testing.assert_allclose(gm.beta.sum(axis=1), 1.0, rtol=1e-5)
+        assert np.all(gm.vsq > 0)
+        np.linalg.cholesky(gm.sigma)                     # check_model: sigma positive-definite
+
+
+def test_sigma_uses_previous_mu_quirk_q2(tmvb, oracle):
+    """update_sigma! runs before update_mu! (src/CTM.jl:207-208): sigma is centred on the OLD mu."""
+    g = synth_case(tmvb, 12, M=40, V=120, seed=8)
+    gm, om = make_pair(tmvb, oracle, g)
+    step(gm); step(om)                                # mu moves away from 0
+    force(gm, om)
+    mu_old = om.mu.copy()
+    step(gm); gm.update_host()
+    L = gm.lam - mu_old[:, None]
+    expect = (np.diag(gm.vsq.sum(axis=1)) + L @ L.T) / gm.M
+    assert np.abs(gm.sigma - expect).max() <= 5e-4 * np.abs(expect).max()
+    L2 = gm.lam - gm.mu[:, None]
+    wrong = (np.diag(gm.vsq.sum(axis=1)) + L2 @ L2.T) / gm.M
+    assert np.abs(expect - wrong).max() > 10 * np.abs(gm.sigma - expect).max()
+
+
+def test_free_running_train_vs_golden(tmvb):
+    g = load("ctm_m40_v60_k5")
+    K, V = int(g["K"]), int(g["V"])
+    gm = tmvb.gpuCTM(tmvb.PackedCorpus(g["doc_ptr"], g["terms"], g["counts"], V), K)
+    gm.beta = np.asfortranarray(g["beta0"]); gm.beta_old = gm.beta.copy(order="F")
+    traj = gm.train(iter=int(g["iters"]), tol=0.0, printelbo=False)
+    gold = g["elbo_traj"]
+    assert len(traj) == len(gold)
+    assert np.all(np.abs(traj - gold) <= 2e-4 * np.abs(gold)), (traj, gold)
+    assert np.abs(gm.mu - g["mu"]).max() <= 5e-3
+    assert np.abs(gm.beta - g["beta"]).max() <= 1e-3
+
+
+def test_gpu_macro_round_trip_and_errors(tmvb):
+    g = load("ctm_m40_v60_k5")
+    K, V = int(g["K"]), int(g["V"])
+    pc = tmvb.PackedCorpus(g["doc_ptr"], g["terms"], g["counts"], V)
+    m = tmvb.CTM(pc, K)
+    m.beta = np.asfortranarray(g["beta0"]); m.beta_old = m.beta.copy(order="F")
+    traj = tmvb.gpu_train_ctm(m, iter=3, tol=0.0, printelbo=False)
+    tmvb.check_model_ctm(m)
+    assert len(traj) == 3 and np.array_equal(m.lam, m.lam_old)
+    with pytest.raises(ValueError):
+        tmvb.gpuCTM(pc, 0)
+    with pytest.raises(ValueError):
+        tmvb.gpuCTM(pc, 30)                      # K outside the instantiated Gauss-Jordan sizes
+    gm = tmvb.gpuCTM(pc, K)
+    with pytest.raises(ValueError):
+        gm.train(niter=-1, printelbo=False)
+
+
+def test_nsf_shaped_invariants_k50(tmvb):
+    pc = tmvb.syn_nsf(M=3000, V=25319, seed=2)
+    gm = tmvb.gpuCTM(pc, 50)
+    e0 = None
+    for it in range(2):
+        gm.estep(); gm.reduce_docs(); gm.update_beta(); gm.update_sigma(); gm.update_mu()
+        e = gm.update_elbo()
+        assert np.isfinite(e) and (e0 is None or e > e0)
+        e0 = e
+    gm.update_host()
+    np.testing.assert_allclose(gm.beta.sum(axis=1), 1.0, rtol=1e-5)
+    assert np.all(np.isfinite(gm.lam)) and np.all(gm.vsq > 0)
+    np.linalg.cholesky(gm.sigma)
+    hist, nsteps = gm.sweep_hist()
+    assert hist.sum() == pc.M and nsteps >= pc.M

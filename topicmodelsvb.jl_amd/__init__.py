@@ -9,8 +9,9 @@ from ._lib import (CorpusError, DocumentError, EngineError, TopicModelError, bui
 from .corpus import (Corpus, Document, PackedCorpus, check_corp, check_doc, dirichlet_rows, readcorp, syn_citeu,
                      syn_nsf, synthetic_lda_corpus, writecorp)
 from .lda import LDA, DeviceContext, DeviceCorpus, check_model, gpuLDA, gpu_train
+from .ctm import CTM, check_model_ctm, gpuCTM, gpu_train_ctm
 
 __all__ = ["CorpusError", "DocumentError", "EngineError", "TopicModelError", "build", "exported_symbols", "lib", "LIB_PATH",
            "Corpus", "Document", "PackedCorpus", "check_corp", "check_doc", "dirichlet_rows", "readcorp", "writecorp",
            "syn_citeu", "syn_nsf", "synthetic_lda_corpus", "LDA", "DeviceContext", "DeviceCorpus", "check_model", "gpuLDA",
-           "gpu_train"]
+           "gpu_train", "CTM", "check_model_ctm", "gpuCTM", "gpu_train_ctm"]

@@ -58,8 +58,25 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps if os.path.exists(d)):
             return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-Wno-pass-failed",
-           "-I", os.path.join(_ROOT, "include"), "-I", os.path.join(_HERE, "csrc"), "-o", LIB_PATH] + srcs
+    flags = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wno-pass-failed",
+             "-I", os.path.join(_ROOT, "include"), "-I", os.path.join(_HERE, "csrc")]
+    objdir = os.path.join(_HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    procs, objs = [], []
+    for src in srcs:                      # one hipcc per translation unit, in parallel
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        hdrs = [d for d in deps if d.endswith(".h")]
+        if not force and os.path.exists(obj) and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in [src] + hdrs):
+            continue
+        cmd = [hipcc] + flags + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -1,0 +1,315 @@
+// tmvb_common_kernels.h -- device kernels and host helpers shared by the LDA / CTM / CTPF engines:
+// deterministic column sums, the beta normalisation of update_beta!, wave helpers, small host
+// upload/download utilities and the tile-size / bucket logic of the per-document kernels.
+#pragma once
+#include "tmvb_internal.h"
+#include "tmvb_termstats.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+
+#define TMVB_MAX_NSLOT 16                      // K <= 1024
+#define TMVB_MAX_TILE_BYTES (64 * 1024)
+#define TMVB_REDUCE_BLOCKS 256
+
+// one wave per workgroup: __syncthreads() lowers to an LDS fence (the s_barrier is elided)
+#define WAVE_LDS_FENCE() __syncthreads()
+
+template <int CTRL>
+__device__ __forceinline__ float4 dpp_add4(float4 v)
+{
+    v.x += dpp_f<CTRL>(v.x); v.y += dpp_f<CTRL>(v.y); v.z += dpp_f<CTRL>(v.z); v.w += dpp_f<CTRL>(v.w);
+    return v;
+}
+
+
+// NOTE: hipcc 7.2 mis-selects __builtin_amdgcn_permlane{32,16}_swap when both results feed one add
+// (it emits `v_add v, r0, r0`), so the swap is issued through inline asm.  hipcc inserts no hazard
+// wait states inside asm: the leading s_nop covers a preceding VALU write of the operands.
+__device__ __forceinline__ void swap_add32(float& a, float b)
+{
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    a += b;                                   // lanes < 32: a.lo + a.hi, lanes >= 32: b.lo + b.hi
+}
+__device__ __forceinline__ void swap_add16(float& a, float b)
+{
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    a += b;                                   // even rows: sums of a, odd rows: sums of b
+}
+template <int CTRL>
+__device__ __forceinline__ void dpp_stage(float& a, float b, bool hi)
+{
+    const float keep = hi ? b : a, give = hi ? a : b;
+    a = keep + dpp_f<CTRL>(give);
+}
+
+template <int R>
+__device__ __forceinline__ float lane_reduce_scatter(float (&p)[R], int lane)
+{
+    constexpr int m0 = R, h0 = (m0 + 1) / 2;
+#pragma unroll
+    for (int i = 0; i < h0; ++i) swap_add32(p[i], (i + h0 < m0) ? p[i + h0] : p[i]);
+    constexpr int m1 = h0, h1 = (m1 + 1) / 2;
+#pragma unroll
+    for (int i = 0; i < h1; ++i) swap_add16(p[i], (i + h1 < m1) ? p[i + h1] : p[i]);
+    constexpr int m2 = h1, h2 = (m2 + 1) / 2;
+    const bool b8 = lane & 8, b4 = lane & 4, b2 = lane & 2, b1 = lane & 1;
+#pragma unroll
+    for (int i = 0; i < h2; ++i) {
+        if (i + h2 < m2) dpp_stage<0x140>(p[i], p[i + h2], b8);      // row_mirror
+        else p[i] += dpp_f<0x140>(p[i]);
+    }
+    constexpr int m3 = h2, h3 = (m3 + 1) / 2;
+#pragma unroll
+    for (int i = 0; i < h3; ++i) {
+        if (i + h3 < m3) dpp_stage<0x141>(p[i], p[i + h3], b4);      // row_half_mirror
+        else p[i] += dpp_f<0x141>(p[i]);
+    }
+    constexpr int m4 = h3, h4 = (m4 + 1) / 2;
+#pragma unroll
+    for (int i = 0; i < h4; ++i) {
+        if (i + h4 < m4) dpp_stage<0x4E>(p[i], p[i + h4], b2);       // quad_perm [2,3,0,1]
+        else p[i] += dpp_f<0x4E>(p[i]);
+    }
+    constexpr int m5 = h4;
+    static_assert(m5 <= 2, "reduce-scatter supports up to 64 registers");
+    if (m5 == 2) dpp_stage<0xB1>(p[0], p[1], b1);                    // quad_perm [1,0,3,2]
+    else p[0] += dpp_f<0xB1>(p[0]);
+    return p[0];
+}
+
+
+// host replay of lane_reduce_scatter's pairing: which topic ends up in which lane
+static inline void tmvb_reg_lane_maps(int R, std::vector<int>& topic_of_lane, std::vector<int>& lane_of_topic)
+{
+    std::vector<std::vector<int>> regs(R, std::vector<int>(64));
+    for (int q = 0; q < R; ++q) for (int l = 0; l < 64; ++l) regs[q][l] = q;
+    const int Ds[6] = {32, 16, 8, 4, 2, 1};
+    for (int st = 0; st < 6; ++st) {
+        const int D = Ds[st], m = (int)regs.size(), h = (m + 1) / 2;
+        std::vector<std::vector<int>> nxt(h, std::vector<int>(64));
+        for (int i = 0; i < h; ++i)
+            for (int l = 0; l < 64; ++l) nxt[i][l] = (i + h < m && (l & D)) ? regs[i + h][l] : regs[i][l];
+        regs.swap(nxt);
+    }
+    topic_of_lane.assign(64, -1);
+    lane_of_topic.assign(R, -1);
+    for (int l = 0; l < 64; ++l) {
+        int q = regs[0][l];
+        if (lane_of_topic[q] < 0) { lane_of_topic[q] = l; topic_of_lane[l] = q; }   // first lane is the primary
+    }
+}
+
+
+// ------------------------------------------------------------------------------ reductions
+// partial[block][K] (double) = sum over a strided subset of columns of X (K x ncols, fp32)
+template <int NSLOT>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, int64_t ncols, int K,
+                                                             double* __restrict__ partial)
+{
+    __shared__ double red[4][64 * NSLOT];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t gw = (int64_t)blockIdx.x * 4 + wv, nw = (int64_t)gridDim.x * 4;
+    double acc[NSLOT];
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) acc[s] = 0.0;
+#pragma unroll 8
+    for (int64_t c = gw; c < ncols; c += nw) {
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+            int i = lane + 64 * s;
+            if (i < K) acc[s] += (double)X[c * K + i];
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) red[wv][lane + 64 * s] = acc[s];
+    __syncthreads();
+    for (int i = threadIdx.x; i < K; i += 256)
+        partial[(int64_t)blockIdx.x * K + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+}
+
+// out_d[i] = sum_b partial[b][i]: one wave per output, fixed reduction tree (deterministic); optional fp32 copy
+static __global__ __launch_bounds__(256) void colsum_final_kernel(const double* __restrict__ partial, int nblocks, int K,
+                                                           double* __restrict__ out_d, float* __restrict__ out_f)
+{
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= K) return;
+    double s = 0.0;
+    for (int b = lane; b < nblocks; b += 64) s += partial[(int64_t)b * K + i];
+    s = wave_sum_d(s);
+    if (lane == 0) {
+        if (out_d) out_d[i] = s;
+        if (out_f) out_f[i] = (float)s;
+    }
+}
+
+// update_beta!(model)  src/LDA.jl:121-125:  beta_new = S ./ rowsum(S);  S <- 0
+// S is dense [V][K]; beta_new is the padded gather layout [V][KP] (pad columns zero).
+static __global__ __launch_bounds__(256) void beta_norm_kernel(float* __restrict__ S, const double* __restrict__ rowsum,
+                                                            float* __restrict__ beta_new, int K, int KP, int64_t V)
+{
+    extern __shared__ double rinv[];
+    for (int i = threadIdx.x; i < K; i += blockDim.x) rinv[i] = 1.0 / rowsum[i];
+    __syncthreads();
+    const int64_t total = V * KP;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += stride) {
+        const int64_t j = q / KP;
+        const int i = (int)(q - j * KP);
+        float o = 0.0f;
+        if (i < K) {
+            o = (float)((double)S[j * K + i] * rinv[i]);
+            S[j * K + i] = 0.0f;
+        }
+        beta_new[q] = o;
+    }
+}
+
+__device__ __forceinline__ double wave_min_d(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+
+template <typename F>
+static int dispatch_nslot(int nslot, F&& f)
+{
+    switch (nslot) {
+        case 1: return f(std::integral_constant<int, 1>());
+        case 2: return f(std::integral_constant<int, 2>());
+        case 3: case 4: return f(std::integral_constant<int, 4>());
+        case 5: case 6: case 7: case 8: return f(std::integral_constant<int, 8>());
+        default: return f(std::integral_constant<int, 16>());
+    }
+}
+
+static size_t tmvb_tile_bytes(int rows, int KP) { return ((size_t)rows * KP + KP + 3 * (size_t)rows) * sizeof(float); }
+
+
+template <typename T>
+static int dmalloc(T** p, size_t n)
+{
+    *p = nullptr;
+    size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    hipError_t e = hipMalloc((void**)p, bytes);
+    if (e != hipSuccess) {
+        tmvb_set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+        return TMVB_ENOMEM;
+    }
+    return TMVB_OK;
+}
+
+
+static int upload_f32(tmvb_ctx* ctx, float* dst, const double* src, size_t n)
+{
+    std::vector<float> tmp(n);
+    for (size_t q = 0; q < n; ++q) tmp[q] = (float)src[q];
+    TMVB_HIP(hipMemcpyAsync(dst, tmp.data(), n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    TMVB_HIP(hipStreamSynchronize(ctx->stream));
+    return TMVB_OK;
+}
+
+static int download_f32(tmvb_ctx* ctx, double* dst, const float* src, size_t n)
+{
+    std::vector<float> tmp(n);
+    TMVB_HIP(hipMemcpyAsync(tmp.data(), src, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    TMVB_HIP(hipStreamSynchronize(ctx->stream));
+    for (size_t q = 0; q < n; ++q) dst[q] = (double)tmp[q];
+    return TMVB_OK;
+}
+
+
+
+// deterministic column sums of a K x ncols fp32 matrix into out_d (fp64) and/or out_f (fp32)
+static inline int tmvb_colsum(tmvb_ctx* ctx, int nslot, int K, const float* X, int64_t ncols, double* d_partial,
+                              double* out_d, float* out_f)
+{
+    int nb = (int)std::min<int64_t>(TMVB_REDUCE_BLOCKS, std::max<int64_t>(1, (ncols + 3) / 4));
+    int rc = dispatch_nslot(nslot, [&](auto ns) -> int {
+        constexpr int NS = decltype(ns)::value;
+        hipLaunchKernelGGL((colsum_partial_kernel<NS>), dim3(nb), dim3(256), 0, ctx->stream, X, ncols, K, d_partial);
+        return TMVB_OK;
+    });
+    if (rc) return rc;
+    TMVB_HIP(hipGetLastError());
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((K + 3) / 4), dim3(256), 0, ctx->stream, d_partial, nb, K, out_d, out_f);
+    TMVB_HIP(hipGetLastError());
+    return TMVB_OK;
+}
+
+// gather-side statistics pass over an inverted index (tmvb_termstats.h)
+static inline int tmvb_launch_termstats(tmvb_ctx* ctx, int nslot, int KP, bool e_padded, const tmvb_inv_index& ix,
+                                        TermStatsParams tp)
+{
+    if (ix.n_chunks <= 0) return TMVB_OK;
+    tp.tok_doc = ix.d_doc; tp.tok_pos = ix.d_pos; tp.chunk_id = ix.d_chunk_id; tp.chunk_begin = ix.d_chunk_begin;
+    tp.chunk_end = ix.d_chunk_end; tp.chunk_out = ix.d_chunk_out; tp.n_chunks = (int)ix.n_chunks;
+    int rc = dispatch_nslot(nslot, [&](auto ns) -> int {
+        constexpr int NS = decltype(ns)::value;
+        const dim3 grid((unsigned)((ix.n_chunks + 3) / 4)), block(256);
+        const int lpr = KP / 4;
+        if (e_padded) {
+            if (lpr == 13) hipLaunchKernelGGL((termstats_chunk4_kernel<13>), grid, block, 0, ctx->stream, tp, lpr);
+            else if (lpr == 25) hipLaunchKernelGGL((termstats_chunk4_kernel<25>), grid, block, 0, ctx->stream, tp, lpr);
+            else hipLaunchKernelGGL((termstats_chunk4_kernel<0>), grid, block, 0, ctx->stream, tp, lpr);
+        } else {
+            hipLaunchKernelGGL((termstats_chunk_kernel<NS>), grid, block, 0, ctx->stream, tp);
+        }
+        if (ix.n_multi > 0)
+            hipLaunchKernelGGL((termstats_multi_kernel<NS>), dim3((unsigned)ix.n_multi), dim3(256), 0, ctx->stream, tp,
+                               ix.d_multi_id, ix.d_multi_first, ix.d_multi_count, (int)ix.n_multi);
+        return TMVB_OK;
+    });
+    if (rc) return rc;
+    TMVB_HIP(hipGetLastError());
+    return TMVB_OK;
+}
+
+// LDS-tile buckets for the documents of `order` (sorted by descending length) that are longer than
+// `min_len_exclusive`; `extra_rows` = per-row side arrays (floats) next to the KP-float tile row.
+// Returns the number of documents bucketed (a prefix of `order`).
+static inline int64_t tmvb_build_lds_buckets(const std::vector<int64_t>& len, const std::vector<int32_t>& order, int64_t M,
+                                             int KP, int64_t min_len_exclusive, int extra_rows,
+                                             std::vector<tmvb_bucket>& buckets)
+{
+    (void)extra_rows;
+    int64_t n_lds = 0;
+    while (n_lds < M && len[order[n_lds]] > min_len_exclusive) ++n_lds;
+    int64_t pos = 0;
+    if (n_lds == 0) return 0;
+    std::vector<int> tiles;
+    for (int r = 32; r <= 8192; r += (r < 256 ? 32 : r)) {
+        if (tmvb_tile_bytes(r, KP) > TMVB_MAX_TILE_BYTES) break;
+        tiles.push_back(r);
+    }
+    if (tiles.empty()) tiles.push_back(4);
+    const size_t b0 = buckets.size();
+    const int tmax = tiles.back();
+    int64_t cnt = 0;
+    while (pos + cnt < n_lds && len[order[pos + cnt]] > tmax) ++cnt;   // stream chunks through the largest tile
+    if (cnt) buckets.push_back({pos, cnt, tmax, 0});
+    pos += cnt;
+    for (int b = (int)tiles.size() - 1; b >= 0 && pos < n_lds; --b) {
+        const int64_t lo = (b > 0) ? tiles[b - 1] : -1;
+        cnt = 0;
+        while (pos + cnt < n_lds && len[order[pos + cnt]] > lo) ++cnt;
+        if (cnt) buckets.push_back({pos, cnt, tiles[b], 0});
+        pos += cnt;
+    }
+    // merge small buckets into their larger neighbour (a launch needs enough waves to matter)
+    for (size_t b = b0 + 1; b < buckets.size();) {
+        if (buckets[b].count < 512 && buckets[b - 1].tile_rows >= buckets[b].tile_rows &&
+            len[order[buckets[b - 1].first + buckets[b - 1].count - 1]] <= buckets[b - 1].tile_rows) {
+            buckets[b - 1].count += buckets[b].count;
+            buckets.erase(buckets.begin() + b);
+        } else {
+            ++b;
+        }
+    }
+    return pos;
+}

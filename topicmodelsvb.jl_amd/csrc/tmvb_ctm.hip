@@ -1,0 +1,937 @@
+// tmvb_ctm.hip -- correlated topic model (CTM) variational-Bayes engine for gfx950 (MI355X).
+//
+// Path: the per-document coordinate ascent of src/CTM.jl:194-205 (update_phi! :175, update_logzeta!
+// :169, update_vsq! :146, update_lambda! :129, exit test :200, update_beta!(d) :122) fused into ONE
+// kernel per document, plus the M-step (update_beta! :114, update_sigma! :108 -- which uses the
+// PREVIOUS mu, quirk Q2 -- update_mu! :102) and update_elbo! (:89) on the device.  It replaces the
+// nine OpenCL kernels of src/gpuCTM.jl:144-473 but follows the CPU path's semantics (per-document
+// exit rule, exact Newton steps), not the OpenCL path's (global median rule :503, softmax max
+// initialised to 0 :404,:456, host-side fp32 `inv` :203-205).
+//
+// Per-document kernel (one 64-lane wave = one document, lane = topic = matrix row):
+//   * phi = softmax_K(log beta[:,terms] + lambda) is evaluated in linear space through the same LDS
+//     topic tile as the LDA fallback kernel: with e_i = exp(lambda_i - max lambda),
+//     s_n = sum_i B[n][i] e_i, w_n = c_n / s_n, (phi*counts)_i = e_i sum_n w_n B[n][i]; the tile is
+//     gathered once per outer iteration by LDS-DMA and reused by every sweep.
+//   * logzeta, the K scalar Newton iterations on vsq and the gradient of the lambda Newton step are
+//     evaluated in fp64 (the exit tests ||g|| < ntol sit at the fp32 noise floor for large documents).
+//   * the K x K Newton system (invsigma + C_d diag(e^{...})) delta = g is solved by Gauss-Jordan
+//     elimination held ENTIRELY IN REGISTERS: lane i owns row i (KP VGPRs), the pivot row is broadcast
+//     with v_readlane (SGPR operands of the FMAs), ~KP^2 VALU instructions per solve, no LDS, no
+//     pivoting (the matrix is SPD).  The reference solves this with LAPACK on the CPU (:136) or a
+//     K-work-item Gauss-Jordan in OpenCL local memory (src/utils.jl:60-90).
+//   * the statistics scatter update_beta!(d) is deferred to the gather-side pass (tmvb_termstats.h).
+// M-step: the K x M * M x K scatter matrix sum_d (lambda_d - mu)(lambda_d - mu)^T runs on f32 MFMA
+// (v_mfma_f32_32x32x2_f32); sigma assembly, its inverse and log-determinant run in fp64 in one
+// workgroup.
+#include "tmvb_common_kernels.h"
+
+#define CTM_MAX_K 64
+
+struct CtmParams {
+    int K, KP, LPR;
+    unsigned lpr_magic;
+    const int64_t* doc_ptr;
+    const int32_t* terms;
+    const int32_t* counts;
+    const int32_t* doc_order;
+    const int32_t* tok_inv;
+    const float* beta;        // [V][KP] padded gather layout
+    const float* invsigma;    // [KP][KP] fp32, pads zero (symmetric)
+    const float* mu;          // [K]
+    float* lambda;            // [M][K]
+    float* lambda_old;        // [M][K]
+    float* vsq;               // [M][K]
+    float* logzeta;           // [M]
+    float* wtok;              // [nnz] term-major
+    float* E;                 // [M][KP]
+    uint8_t* sweeps;
+    unsigned long long* newton_steps;
+    int niter;
+    double ntol;
+    int viter;
+    double vtol;
+};
+
+__device__ __forceinline__ float readlane_f(float v, int l)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+__device__ __forceinline__ double readlane_d(double v, int l)
+{
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), l);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double wave_max_d(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Gauss-Jordan solve of H x = g, lane i owns row i (registers H[0..R)), SPD, no pivoting.
+// At pivot j the pivot row's entries reach every lane as SGPR operands (v_readlane of lane j).
+template <int R>
+__device__ __forceinline__ float gj_solve_rows(float (&H)[R], float g, int lane)
+{
+    float dinv = 0.0f;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const float p = readlane_f(H[j], j);
+        const float rp = 1.0f / p;
+        const bool me = lane == j;
+        const float f = me ? 0.0f : H[j] * rp;
+        dinv = me ? rp : dinv;
+#pragma unroll
+        for (int k = j + 1; k < R; ++k) H[k] = fmaf(-f, readlane_f(H[k], j), H[k]);
+        g = fmaf(-f, readlane_f(g, j), g);
+    }
+    return g * dinv;
+}
+
+// ------------------------------------------------------------------------------ E-step kernel
+template <int R>
+__global__ __launch_bounds__(64) void ctm_estep_kernel(CtmParams p, int64_t first, int tile_rows)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int LPR = R / 4, KP = R;
+    const int lane = threadIdx.x;
+    const int K = p.K;
+    float* Bt = lds;
+    float* e_l = Bt + (size_t)tile_rows * KP;
+    float* w_l = e_l + KP;
+    float* c_l = w_l + tile_rows;
+    int* t_l = (int*)(c_l + tile_rows);
+
+    const int d = p.doc_order[first + blockIdx.x];
+    const int64_t off = p.doc_ptr[d];
+    const int N = (int)(p.doc_ptr[d + 1] - off);
+    const bool single = N <= tile_rows;
+    const bool on = lane < K;
+
+    // C_d = sum of counts (src/CTM.jl:33)
+    float cl = 0.0f;
+    for (int n = lane; n < N; n += 64) cl += (float)p.counts[off + n];
+    const double Cd = (double)wave_sum(cl);
+
+    // row `lane` of invsigma is re-read (L1/L2 resident, 10 KB) at every Newton step instead of being
+    // pinned in KP registers: the register budget decides the waves per SIMD
+    const float* isrow = p.invsigma + (size_t)min(lane, KP - 1) * KP;
+    const double isdiag = on ? (double)p.invsigma[(size_t)lane * KP + lane] : 1.0;
+    const double mu = on ? (double)p.mu[lane] : 0.0;
+    double lam = on ? (double)p.lambda[(int64_t)d * K + lane] : 0.0;
+    double vs = on ? (double)p.vsq[(int64_t)d * K + lane] : 1.0;
+    double lam_old = lam, lz = (double)p.logzeta[d];
+    float e = 0.0f;
+
+    auto load_chunk = [&](int c0, int rows) {
+        for (int n = lane; n < rows; n += 64) {
+            t_l[n] = p.terms[off + c0 + n];
+            c_l[n] = (float)p.counts[off + c0 + n];
+        }
+        WAVE_LDS_FENCE();
+        const int nch = rows * LPR;
+#pragma unroll 4
+        for (int f0 = 0; f0 < nch; f0 += 64) {
+            const int f = f0 + lane;
+            if (f < nch) {
+                const int n = (LPR == 1) ? f : (int)__umulhi((unsigned)f, p.lpr_magic);
+                const int c = f - n * LPR;
+                const float* src = p.beta + ((int64_t)t_l[n] * KP + 4 * c);
+                __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(Bt + (size_t)f0 * 4), 16, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        WAVE_LDS_FENCE();
+    };
+    auto phase1 = [&](int rows) {
+        const float4* er = (const float4*)e_l;
+        for (int n = lane; n < rows; n += 64) {
+            const float4* br = (const float4*)(Bt + (size_t)n * KP);
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+            for (int q = 0; q < LPR; ++q) {
+                float4 b = br[q], ev = er[q];
+                s0 = fmaf(b.x, ev.x, s0); s1 = fmaf(b.y, ev.y, s1);
+                s2 = fmaf(b.z, ev.z, s2); s3 = fmaf(b.w, ev.w, s3);
+            }
+            w_l[n] = c_l[n] / ((s0 + s1) + (s2 + s3));
+        }
+        WAVE_LDS_FENCE();
+    };
+    auto store_w = [&](int c0, int rows) {
+        for (int n = lane; n < rows; n += 64) p.wtok[p.tok_inv[off + c0 + n]] = w_l[n];
+    };
+    const int r4 = lane & 3, ql = lane >> 2;
+    auto phase2 = [&](int rows, float4& acc) {
+        const int nfull = rows >> 2;
+        if (ql < LPR) {
+#pragma unroll 4
+            for (int m = 0; m < nfull; ++m) {
+                const int n = 4 * m + r4;
+                const float w = w_l[n];
+                const float4 b = *(const float4*)(Bt + (size_t)n * KP + 4 * ql);
+                acc.x = fmaf(w, b.x, acc.x); acc.y = fmaf(w, b.y, acc.y);
+                acc.z = fmaf(w, b.z, acc.z); acc.w = fmaf(w, b.w, acc.w);
+            }
+            const int n = 4 * nfull + r4;
+            if (n < rows) {
+                const float w = w_l[n];
+                const float4 b = *(const float4*)(Bt + (size_t)n * KP + 4 * ql);
+                acc.x = fmaf(w, b.x, acc.x); acc.y = fmaf(w, b.y, acc.y);
+                acc.z = fmaf(w, b.z, acc.z); acc.w = fmaf(w, b.w, acc.w);
+            }
+        }
+    };
+
+    int sweeps = 0;
+    unsigned nsteps = 0;
+    for (int v = 0; v < p.viter; ++v) {
+        ++sweeps;
+        // update_phi!  src/CTM.jl:175-178 (additive_logistic, src/utils.jl:114-122), linear space
+        const float lmax = wave_max(on ? (float)lam : -INFINITY);
+        e = on ? expf((float)lam - lmax) : 0.0f;
+        if (lane < KP) e_l[lane] = e;
+        WAVE_LDS_FENCE();
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int c0 = 0; c0 < N; c0 += tile_rows) {
+            const int rows = min(tile_rows, N - c0);
+            if (!(single && v > 0)) load_chunk(c0, rows);
+            phase1(rows);
+            if (!single) store_w(c0, rows);
+            phase2(rows, acc);
+            if (!single) WAVE_LDS_FENCE();
+        }
+        acc = dpp_add4<0xB1>(acc);
+        acc = dpp_add4<0x4E>(acc);
+        const float gsel = (r4 == 0) ? acc.x : (r4 == 1) ? acc.y : (r4 == 2) ? acc.z : acc.w;
+        const double phic = on ? (double)(e * gsel) : 0.0;                  // (phi * counts)_i
+        // update_logzeta!  :169-171
+        {
+            const double x = on ? lam + 0.5 * vs : -INFINITY;
+            const double m = wave_max_d(x);
+            lz = m + log(wave_sum_d(on ? exp(x - m) : 0.0));
+        }
+        // update_vsq!  :146-165  (one scalar Newton iteration per topic = per lane)
+        if (on) {
+            for (int t = 0; t < p.niter; ++t) {
+                double rho = 1.0;
+                const double ex = exp(lam + 0.5 * vs - lz);
+                const double grad = -0.5 * (isdiag + Cd * ex - 1.0 / vs);                  // :150
+                const double ihd = -1.0 / (0.25 * Cd * ex + 0.5 / (vs * vs));             // :151
+                const double pp = ihd * grad;
+                while (vs - rho * pp <= 0.0) rho *= 0.5;                                   // :154
+                vs -= rho * pp;
+                if (rho * fabs(grad) < p.ntol) break;                                      // :159
+            }
+            vs += TMVB_EPS_D;                                                              // :164
+        }
+        // update_lambda!  :129-142
+        lam_old = lam;
+        for (int t = 0; t < p.niter; ++t) {
+            ++nsteps;
+            const double ex = on ? exp(lam + 0.5 * vs - lz) : 0.0;
+            // -H = invsigma + C_d Diag(e^{...})   :135 ; pad rows are unit rows
+            float H[R];
+#pragma unroll
+            for (int q = 0; q < LPR; ++q) {
+                float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (lane < KP) hv = *(const float4*)(isrow + 4 * q);
+                H[4 * q] = hv.x; H[4 * q + 1] = hv.y; H[4 * q + 2] = hv.z; H[4 * q + 3] = hv.w;
+            }
+            // invsigma * (mu - lambda): row `lane` dot the broadcast vector, fp64
+            const double dm = mu - lam;
+            double mv = 0.0;
+#pragma unroll
+            for (int j = 0; j < R; ++j) mv = fma((double)H[j], readlane_d(dm, j), mv);
+            const double gd = on ? (mv + phic - Cd * ex) : 0.0;                            // :134
+            const double gn2 = wave_sum_d(gd * gd);
+            const float dval = on ? (float)(Cd * ex) : 1.0f;
+#pragma unroll
+            for (int k = 0; k < R; ++k) H[k] += ((lane == k) ? dval : 0.0f);
+            const float delta = gj_solve_rows<R>(H, (float)gd, lane);
+            if (on) lam += (double)delta;                                                  // :136
+            if (sqrt(gn2) < p.ntol) break;                                                 // :138
+        }
+        const double df = on ? lam - lam_old : 0.0;
+        const double dist2 = wave_sum_d(df * df);
+        if (sqrt(dist2) < p.vtol) break;                                                   // :200
+    }
+
+    if (sweeps > 0) {
+        if (on) {
+            p.lambda[(int64_t)d * K + lane] = (float)lam;
+            p.lambda_old[(int64_t)d * K + lane] = (float)lam_old;
+            p.vsq[(int64_t)d * K + lane] = (float)vs;
+        }
+        if (lane == 0) p.logzeta[d] = (float)lz;
+        if (lane < KP) p.E[(int64_t)d * KP + lane] = e;       // e = exp(lambda_old - max): last-sweep phi factor
+        if (single) store_w(0, N);
+    } else {
+        for (int n = lane; n < N; n += 64) p.wtok[p.tok_inv[off + n]] = 0.0f;
+    }
+    if (lane == 0) {
+        p.sweeps[d] = (uint8_t)min(sweeps, 255);
+        if (p.newton_steps) atomicAdd(p.newton_steps, (unsigned long long)nsteps);
+    }
+}
+
+// ------------------------------------------------------------------------------ M-step: sigma
+// Scatter matrix sum_d (lambda_d - mu)(lambda_d - mu)^T on f32 MFMA.  X = Lambda - mu is K x M; a
+// wave owns a slab of documents and accumulates the 64 x 64 (padded) product in four
+// v_mfma_f32_32x32x2_f32 accumulators; the contraction index of the MFMA is the document.
+// A operand: lane l holds A[i = l & 31][k = l >> 5]; B operand: B[k = l >> 5][j = l & 31].
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(64) void ctm_scatter_mfma_kernel(const float* __restrict__ lambda, const float* __restrict__ mu,
+                                                              int K, int64_t M, int64_t docs_per_wave,
+                                                              float* __restrict__ partial /* [nwaves][64*64] */)
+{
+    const int lane = threadIdx.x;
+    const int64_t d0 = (int64_t)blockIdx.x * docs_per_wave;
+    const int64_t d1 = min(M, d0 + docs_per_wave);
+    const int i = lane & 31, kk = lane >> 5;
+    const float mu0 = (i < K) ? mu[i] : 0.0f;
+    const float mu1 = (32 + i < K) ? mu[32 + i] : 0.0f;
+    f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};
+    for (int64_t d = d0; d < d1; d += 2) {
+        const int64_t dd = d + kk;
+        float a0 = 0.0f, a1 = 0.0f;
+        if (dd < d1) {
+            if (i < K) a0 = lambda[dd * K + i] - mu0;
+            if (32 + i < K) a1 = lambda[dd * K + 32 + i] - mu1;
+        }
+        c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, a0, c00, 0, 0, 0);
+        c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, a1, c01, 0, 0, 0);
+        c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, a0, c10, 0, 0, 0);
+        c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, a1, c11, 0, 0, 0);
+    }
+    // C/D layout of 32x32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    float* out = partial + (size_t)blockIdx.x * 4096;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = lane & 31;
+        out[row * 64 + col] = c00[r];
+        out[row * 64 + 32 + col] = c01[r];
+        out[(32 + row) * 64 + col] = c10[r];
+        out[(32 + row) * 64 + 32 + col] = c11[r];
+    }
+}
+
+// scatter[i*K + j] = sum_w partial[w][i*64 + j]  (fixed order)
+__global__ __launch_bounds__(256) void ctm_scatter_reduce_kernel(const float* __restrict__ partial, int nwaves, int K,
+                                                                 float* __restrict__ scatter)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= K * K) return;
+    const int i = q / K, j = q - i * K;
+    double s = 0.0;
+    for (int w = 0; w < nwaves; ++w) s += (double)partial[(size_t)w * 4096 + i * 64 + j];
+    scatter[q] = (float)s;
+}
+
+// update_sigma! (src/CTM.jl:108-111) then update_mu! (:102-104), one workgroup, fp64:
+// sigma = (diagm(sum vsq) + scatter) / M  (Symmetric() reads the upper triangle), invsigma = inv(sigma)
+// by Gauss-Jordan on [sigma | I] in LDS, logdet(invsigma) = -sum log pivots; mu = sum lambda / M.
+__global__ __launch_bounds__(256) void ctm_sigma_mu_kernel(int K, int KP, double Md, const float* __restrict__ stats_tail,
+                                                           double* __restrict__ sigma_d, double* __restrict__ invsigma_d,
+                                                           float* __restrict__ invsigma_f, double* __restrict__ mu_d,
+                                                           float* __restrict__ mu_f, double* __restrict__ logdet_inv,
+                                                           int* __restrict__ status, int do_sigma, int do_mu)
+{
+    extern __shared__ double sm[];       // [K][2K] augmented
+    const float* sum_lambda = stats_tail;
+    const float* sum_vsq = stats_tail + K;
+    const float* scatter = stats_tail + 2 * K;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    if (do_sigma) {
+        const int W = 2 * K;
+        for (int q = tid; q < K * K; q += nt) {
+            const int i = q / K, j = q - i * K;
+            const int a = min(i, j), b = max(i, j);            // upper triangle (a <= b)
+            double v = (double)scatter[a * K + b];
+            if (i == j) v += (double)sum_vsq[i];
+            v /= Md;
+            sm[i * W + j] = v;
+            sm[i * W + K + j] = (i == j) ? 1.0 : 0.0;
+            sigma_d[j * K + i] = v;                            // column-major (symmetric anyway)
+        }
+        __syncthreads();
+        __shared__ double piv_s;
+        __shared__ double ld_s;
+        __shared__ int bad_s;
+        if (tid == 0) { ld_s = 0.0; bad_s = 0; }
+        __syncthreads();
+        for (int j = 0; j < K; ++j) {
+            if (tid == 0) {
+                const double pv = sm[j * W + j];
+                piv_s = pv;
+                if (!(pv > 0.0)) bad_s = 1;
+                ld_s += log(pv);
+            }
+            __syncthreads();
+            const double rp = 1.0 / piv_s;
+            for (int c = tid; c < W; c += nt) sm[j * W + c] *= rp;          // normalise pivot row
+            __syncthreads();
+            for (int q = tid; q < K * W; q += nt) {
+                const int i = q / W, c = q - i * W;
+                if (i != j && c != j) sm[i * W + c] -= sm[i * W + j] * sm[j * W + c];
+            }
+            __syncthreads();
+            for (int i = tid; i < K; i += nt) if (i != j) sm[i * W + j] = 0.0;
+            __syncthreads();
+        }
+        for (int q = tid; q < KP * KP; q += nt) {
+            const int i = q / KP, j = q - i * KP;
+            float v = 0.0f;
+            if (i < K && j < K) {
+                const double s = 0.5 * (sm[i * W + K + j] + sm[j * W + K + i]);   // inv(::Symmetric) is Symmetric
+                invsigma_d[j * K + i] = s;
+                v = (float)s;
+            }
+            invsigma_f[q] = v;
+        }
+        if (tid == 0) { *logdet_inv = -ld_s; *status = bad_s; }
+    }
+    if (do_mu) {
+        for (int i = tid; i < K; i += nt) {
+            const double m = (double)sum_lambda[i] / Md;
+            mu_d[i] = m;
+            mu_f[i] = (float)m;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ ELBO
+// update_elbo!  src/CTM.jl:89-98 per document (terms :56-86).  One wave per document, lane = topic.
+__global__ __launch_bounds__(64) void ctm_elbo_kernel(int K, int KP, const int64_t* __restrict__ doc_ptr,
+                                                      const int32_t* __restrict__ terms, const int32_t* __restrict__ counts,
+                                                      const double* __restrict__ mu_d, const double* __restrict__ invsigma_d,
+                                                      const double* __restrict__ logdet_inv,
+                                                      const float* __restrict__ beta, const float* __restrict__ beta_old,
+                                                      const float* __restrict__ lambda, const float* __restrict__ lambda_old,
+                                                      const float* __restrict__ vsq, const float* __restrict__ logzeta,
+                                                      double* __restrict__ doc_val)
+{
+    const int lane = threadIdx.x;
+    const int d = blockIdx.x;
+    const int64_t off = doc_ptr[d];
+    const int N = (int)(doc_ptr[d + 1] - off);
+    const bool on = lane < K;
+    const float lo = on ? lambda_old[(int64_t)d * K + lane] : -INFINITY;
+    const float lmax = wave_max(lo);
+    const float eo = on ? expf(lo - lmax) : 0.0f;
+    const double l = on ? (double)lambda[(int64_t)d * K + lane] : 0.0;
+    const double v = on ? (double)vsq[(int64_t)d * K + lane] : 1.0;
+    const double lz = (double)logzeta[d];
+    double acc = 0.0, Cd = 0.0;
+    for (int n = 0; n < N; ++n) {
+        const int t = terms[off + n];
+        const float c = (float)counts[off + n];
+        Cd += (double)c;
+        const float x = on ? beta_old[(int64_t)t * KP + lane] * eo : 0.0f;           // :93
+        const float inv = 1.0f / wave_sum(x);
+        if (on) {
+            const float ph = x * inv;
+            const double cp = (double)(c * ph);
+            acc += cp * l;                                                            // Elogpz :64 (first part)
+            acc += cp * (double)logf(beta[(int64_t)t * KP + lane] + TMVB_EPS_F);      // Elogpw :71
+            if (ph > 0.0f) acc -= cp * (double)logf(ph);                              // -Elogqz :84
+        }
+    }
+    // Elogpeta :57
+    const double df = on ? l - mu_d[lane] : 0.0;
+    double mv = 0.0;
+    for (int j = 0; j < K; ++j) mv = fma(on ? invsigma_d[(int64_t)j * K + lane] : 0.0, readlane_d(df, j), mv);
+    if (on) {
+        acc += -0.5 * (invsigma_d[(int64_t)lane * K + lane] * v + df * mv);
+        acc -= Cd * exp(l + 0.5 * v - lz);                                            // Elogpz :64 (second part)
+        acc += 0.5 * log(v);                                                          // -Elogqeta :77
+    }
+    double tot = wave_sum_d(acc);
+    const double TWO_PI_LOG = 1.8378770664093453;   // log(2 pi)
+    tot += 0.5 * (*logdet_inv - (double)K * TWO_PI_LOG);
+    tot -= Cd * (lz - 1.0);
+    tot += 0.5 * (double)K * (1.0 + TWO_PI_LOG);
+    if (lane == 0) doc_val[d] = tot;
+}
+
+__global__ __launch_bounds__(1024) void sum_docs_kernel(const double* __restrict__ doc_val, int64_t M, double* __restrict__ out)
+{
+    __shared__ double red[1024];
+    double s = 0.0;
+    for (int64_t d = threadIdx.x; d < M; d += 1024) s += doc_val[d];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0];
+}
+
+// ------------------------------------------------------------------------------ host side
+struct tmvb_ctm {
+    tmvb_ctx* ctx = nullptr;
+    tmvb_corpus* corp = nullptr;
+    int K = 0, KP = 0;
+    int64_t M = 0, V = 0, M_total = 0;
+    bool distributed = false;
+    float* d_beta[2] = {nullptr, nullptr};
+    int cur = 0;
+    float* d_stats = nullptr;          // S (K*V) | sum_lambda (K) | sum_vsq (K) | scatter (K*K)
+    bool own_stats = true;
+    float* d_lambda = nullptr; float* d_lambda_old = nullptr; float* d_vsq = nullptr; float* d_logzeta = nullptr;
+    float* d_wtok = nullptr; float* d_E = nullptr; float* d_ts_partial = nullptr;
+    float* d_invsigma_f = nullptr; float* d_mu_f = nullptr;
+    double* d_sigma = nullptr; double* d_invsigma = nullptr; double* d_mu = nullptr; double* d_logdet = nullptr;
+    float* d_scatter_partial = nullptr; int n_scatter_waves = 0; int64_t docs_per_wave = 0;
+    uint8_t* d_sweeps = nullptr; int32_t* d_doc_order = nullptr;
+    double* d_partial = nullptr; double* d_rowsum = nullptr; double* d_doc_val = nullptr; double* d_elbo = nullptr;
+    unsigned long long* d_newton = nullptr; int* d_status = nullptr;
+    double elbo = 0.0;
+    std::vector<tmvb_bucket> buckets;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    static constexpr int NAUX = 4;
+    hipStream_t aux[NAUX] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[NAUX] = {nullptr, nullptr, nullptr, nullptr};
+    int64_t stats_len() const { return (int64_t)K * V + 2 * K + (int64_t)K * K; }
+    float* tail() const { return d_stats + (size_t)K * V; }
+};
+
+static bool ctm_kp_supported(int kp) { return kp == 4 || kp == 12 || kp == 20 || kp == 52; }
+
+extern "C" int tmvb_ctm_destroy(tmvb_ctm* h)
+{
+    if (!h) return TMVB_OK;
+    if (h->ctx) (void)hipSetDevice(h->ctx->device);
+    (void)hipFree(h->d_beta[0]); (void)hipFree(h->d_beta[1]);
+    if (h->own_stats) (void)hipFree(h->d_stats);
+    (void)hipFree(h->d_lambda); (void)hipFree(h->d_lambda_old); (void)hipFree(h->d_vsq); (void)hipFree(h->d_logzeta);
+    (void)hipFree(h->d_wtok); (void)hipFree(h->d_E); (void)hipFree(h->d_ts_partial); (void)hipFree(h->d_invsigma_f);
+    (void)hipFree(h->d_mu_f); (void)hipFree(h->d_sigma); (void)hipFree(h->d_invsigma); (void)hipFree(h->d_mu);
+    (void)hipFree(h->d_logdet); (void)hipFree(h->d_scatter_partial); (void)hipFree(h->d_sweeps); (void)hipFree(h->d_doc_order);
+    (void)hipFree(h->d_partial); (void)hipFree(h->d_rowsum); (void)hipFree(h->d_doc_val); (void)hipFree(h->d_elbo);
+    (void)hipFree(h->d_newton); (void)hipFree(h->d_status);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    for (int a = 0; a < tmvb_ctm::NAUX; ++a) {
+        if (h->ev_join[a]) (void)hipEventDestroy(h->ev_join[a]);
+        if (h->aux[a]) (void)hipStreamDestroy(h->aux[a]);
+    }
+    delete h;
+    return TMVB_OK;
+}
+
+static int ctm_upload_beta(tmvb_ctm* h, float* dst, const double* src)
+{
+    const size_t K = h->K, KP = h->KP, V = h->V;
+    std::vector<float> tmp(V * KP + 4, 0.0f);
+    for (size_t j = 0; j < V; ++j)
+        for (size_t i = 0; i < K; ++i) tmp[j * KP + i] = (float)src[j * K + i];
+    TMVB_HIP(hipMemcpyAsync(dst, tmp.data(), tmp.size() * sizeof(float), hipMemcpyHostToDevice, h->ctx->stream));
+    TMVB_HIP(hipStreamSynchronize(h->ctx->stream));
+    return TMVB_OK;
+}
+
+static int ctm_download_beta(tmvb_ctm* h, double* dst, const float* src)
+{
+    const size_t K = h->K, KP = h->KP, V = h->V;
+    std::vector<float> tmp(V * KP);
+    TMVB_HIP(hipMemcpyAsync(tmp.data(), src, tmp.size() * sizeof(float), hipMemcpyDeviceToHost, h->ctx->stream));
+    TMVB_HIP(hipStreamSynchronize(h->ctx->stream));
+    for (size_t j = 0; j < V; ++j)
+        for (size_t i = 0; i < K; ++i) dst[j * K + i] = (double)tmp[j * KP + i];
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_ctm_set_state(tmvb_ctm* h, const double* mu, const double* sigma, const double* invsigma,
+                                  const double* beta, const double* beta_old, const double* lambda,
+                                  const double* lambda_old, const double* vsq, const double* logzeta, const double* elbo);
+
+extern "C" int tmvb_ctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb_ctm** out)
+{
+    TMVB_REQUIRE(out != nullptr, TMVB_EINVAL, "tmvb_ctm_create: out is NULL");
+    *out = nullptr;
+    TMVB_REQUIRE(ctx && corp, TMVB_EINVAL, "tmvb_ctm_create: NULL context or corpus");
+    TMVB_REQUIRE(K > 0, TMVB_EINVAL, "number of topics must be a positive integer.");       // src/gpuCTM.jl constructor
+    TMVB_REQUIRE(K <= CTM_MAX_K && ctm_kp_supported(tmvb_kpad(K)), TMVB_EINVAL,
+                 "tmvb_ctm_create: this release supports K in 1..4, 9..12, 17..20, 49..52 (register Gauss-Jordan instantiations); got K=%d", K);
+    TMVB_HIP(hipSetDevice(ctx->device));
+    tmvb_ctm* h = new tmvb_ctm();
+    h->ctx = ctx; h->corp = corp; h->K = K; h->KP = tmvb_kpad(K);
+    h->M = corp->info.M; h->V = corp->info.V; h->M_total = h->M;
+    const size_t KM = (size_t)K * h->M, KPV = (size_t)h->KP * h->V + 4;
+    h->docs_per_wave = 256;
+    h->n_scatter_waves = (int)std::max<int64_t>(1, (h->M + h->docs_per_wave - 1) / h->docs_per_wave);
+    int rc;
+    if ((rc = dmalloc(&h->d_beta[0], KPV)) || (rc = dmalloc(&h->d_beta[1], KPV)) || (rc = dmalloc(&h->d_stats, (size_t)h->stats_len())) ||
+        (rc = dmalloc(&h->d_lambda, KM)) || (rc = dmalloc(&h->d_lambda_old, KM)) || (rc = dmalloc(&h->d_vsq, KM)) ||
+        (rc = dmalloc(&h->d_logzeta, (size_t)h->M)) || (rc = dmalloc(&h->d_wtok, (size_t)corp->info.nnz)) ||
+        (rc = dmalloc(&h->d_E, (size_t)h->KP * h->M + 4)) || (rc = tmvb_corpus_term_index(corp)) ||
+        (rc = dmalloc(&h->d_ts_partial, (size_t)corp->term_index.n_slots * (K + 1))) ||
+        (rc = dmalloc(&h->d_invsigma_f, (size_t)h->KP * h->KP)) || (rc = dmalloc(&h->d_mu_f, K)) ||
+        (rc = dmalloc(&h->d_sigma, (size_t)K * K)) || (rc = dmalloc(&h->d_invsigma, (size_t)K * K)) || (rc = dmalloc(&h->d_mu, K)) ||
+        (rc = dmalloc(&h->d_logdet, 1)) || (rc = dmalloc(&h->d_scatter_partial, (size_t)h->n_scatter_waves * 4096)) ||
+        (rc = dmalloc(&h->d_sweeps, (size_t)h->M)) || (rc = dmalloc(&h->d_doc_order, (size_t)h->M)) ||
+        (rc = dmalloc(&h->d_partial, (size_t)TMVB_REDUCE_BLOCKS * K)) || (rc = dmalloc(&h->d_rowsum, K)) ||
+        (rc = dmalloc(&h->d_doc_val, (size_t)h->M)) || (rc = dmalloc(&h->d_elbo, 1)) || (rc = dmalloc(&h->d_newton, 1)) ||
+        (rc = dmalloc(&h->d_status, 1))) {
+        tmvb_ctm_destroy(h);
+        return rc;
+    }
+    std::vector<int32_t> order((size_t)h->M);
+    std::iota(order.begin(), order.end(), 0);
+    const std::vector<int64_t>& len = corp->h_doc_len;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return len[x] > len[y]; });
+    tmvb_build_lds_buckets(len, order, h->M, h->KP, -1, 3, h->buckets);
+    if (h->M) TMVB_HIP(hipMemcpyAsync(h->d_doc_order, order.data(), (size_t)h->M * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    TMVB_HIP(hipMemsetAsync(h->d_stats, 0, (size_t)h->stats_len() * sizeof(float), ctx->stream));
+    TMVB_HIP(hipMemsetAsync(h->d_sweeps, 0, std::max<size_t>((size_t)h->M, 1), ctx->stream));
+    TMVB_HIP(hipMemsetAsync(h->d_newton, 0, sizeof(unsigned long long), ctx->stream));
+    TMVB_HIP(hipMemsetAsync(h->d_status, 0, sizeof(int), ctx->stream));
+    TMVB_HIP(hipMemsetAsync(h->d_beta[0], 0, KPV * sizeof(float), ctx->stream));
+    TMVB_HIP(hipMemsetAsync(h->d_beta[1], 0, KPV * sizeof(float), ctx->stream));
+    TMVB_HIP(hipEventCreate(&h->ev0));
+    TMVB_HIP(hipEventCreate(&h->ev1));
+    TMVB_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    for (int a = 0; a < tmvb_ctm::NAUX; ++a) {
+        TMVB_HIP(hipStreamCreateWithFlags(&h->aux[a], hipStreamNonBlocking));
+        TMVB_HIP(hipEventCreateWithFlags(&h->ev_join[a], hipEventDisableTiming));
+    }
+    TMVB_HIP(hipStreamSynchronize(ctx->stream));
+    // constructor state, src/CTM.jl:37-48: mu = 0, sigma = invsigma = I, lambda = 0, vsq = 1, logzeta = 0.5; beta uniform
+    std::vector<double> mu(K, 0.0), eye((size_t)K * K, 0.0), beta((size_t)K * h->V, h->V ? 1.0 / (double)h->V : 0.0);
+    for (int i = 0; i < K; ++i) eye[(size_t)i * K + i] = 1.0;
+    std::vector<double> lam(KM, 0.0), vsq(KM, 1.0), lz((size_t)h->M, 0.5);
+    rc = tmvb_ctm_set_state(h, mu.data(), eye.data(), eye.data(), beta.data(), nullptr, lam.data(), nullptr, vsq.data(), lz.data(), nullptr);
+    if (rc) { tmvb_ctm_destroy(h); return rc; }
+    *out = h;
+    return TMVB_OK;
+}
+
+static double host_logdet_spd(const double* A, int K, bool* ok)
+{
+    std::vector<double> L(A, A + (size_t)K * K);
+    double ld = 0.0;
+    *ok = true;
+    for (int j = 0; j < K; ++j) {
+        double dd = L[(size_t)j * K + j];
+        for (int k = 0; k < j; ++k) dd -= L[(size_t)k * K + j] * L[(size_t)k * K + j];
+        if (!(dd > 0.0)) { *ok = false; return NAN; }
+        dd = std::sqrt(dd);
+        L[(size_t)j * K + j] = dd;
+        ld += 2.0 * std::log(dd);
+        for (int i = j + 1; i < K; ++i) {
+            double s = L[(size_t)j * K + i];
+            for (int k = 0; k < j; ++k) s -= L[(size_t)k * K + i] * L[(size_t)k * K + j];
+            L[(size_t)j * K + i] = s / dd;
+        }
+    }
+    return ld;
+}
+
+extern "C" int tmvb_ctm_set_state(tmvb_ctm* h, const double* mu, const double* sigma, const double* invsigma,
+                                  const double* beta, const double* beta_old, const double* lambda,
+                                  const double* lambda_old, const double* vsq, const double* logzeta, const double* elbo)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_ctm_set_state: handle is NULL");
+    tmvb_ctx* ctx = h->ctx;
+    TMVB_HIP(hipSetDevice(ctx->device));
+    const size_t K = h->K, KP = h->KP, KM = K * (size_t)h->M;
+    int rc;
+    if (mu) {
+        for (size_t i = 0; i < K; ++i) TMVB_REQUIRE(std::isfinite(mu[i]), TMVB_ENONFINITE, "mu must be finite.");
+        TMVB_HIP(hipMemcpyAsync(h->d_mu, mu, K * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        if ((rc = upload_f32(ctx, h->d_mu_f, mu, K))) return rc;
+    }
+    if (sigma) TMVB_HIP(hipMemcpyAsync(h->d_sigma, sigma, K * K * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if (invsigma) {
+        bool ok;
+        double ld = host_logdet_spd(invsigma, (int)K, &ok);
+        TMVB_REQUIRE(ok, TMVB_ESHAPE, "invsigma must be positive-definite.");               // check_model, src/modelutils.jl:116
+        std::vector<float> pad(KP * KP, 0.0f);
+        for (size_t i = 0; i < K; ++i)
+            for (size_t j = 0; j < K; ++j) pad[i * KP + j] = (float)invsigma[j * K + i];
+        TMVB_HIP(hipMemcpyAsync(h->d_invsigma, invsigma, K * K * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        TMVB_HIP(hipMemcpyAsync(h->d_invsigma_f, pad.data(), pad.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        TMVB_HIP(hipMemcpyAsync(h->d_logdet, &ld, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        TMVB_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    if (beta) {
+        if ((rc = ctm_upload_beta(h, h->d_beta[h->cur], beta))) return rc;
+        if (!beta_old && (rc = ctm_upload_beta(h, h->d_beta[h->cur ^ 1], beta))) return rc;
+    }
+    if (beta_old && (rc = ctm_upload_beta(h, h->d_beta[h->cur ^ 1], beta_old))) return rc;
+    if (lambda) {
+        if ((rc = upload_f32(ctx, h->d_lambda, lambda, KM))) return rc;
+        if (!lambda_old && (rc = upload_f32(ctx, h->d_lambda_old, lambda, KM))) return rc;
+    }
+    if (lambda_old && (rc = upload_f32(ctx, h->d_lambda_old, lambda_old, KM))) return rc;
+    if (vsq) {
+        for (size_t q = 0; q < KM; ++q) TMVB_REQUIRE(vsq[q] > 0.0 && std::isfinite(vsq[q]), TMVB_ENONFINITE, "vsq must be positive.");
+        if ((rc = upload_f32(ctx, h->d_vsq, vsq, KM))) return rc;
+    }
+    if (logzeta && (rc = upload_f32(ctx, h->d_logzeta, logzeta, (size_t)h->M))) return rc;
+    if (elbo) h->elbo = *elbo;
+    TMVB_HIP(hipStreamSynchronize(ctx->stream));
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_ctm_get_state(tmvb_ctm* h, double* mu, double* sigma, double* invsigma, double* beta, double* beta_old,
+                                  double* lambda, double* lambda_old, double* vsq, double* logzeta, double* elbo)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_ctm_get_state: handle is NULL");
+    tmvb_ctx* ctx = h->ctx;
+    TMVB_HIP(hipSetDevice(ctx->device));
+    const size_t K = h->K, KM = K * (size_t)h->M;
+    int rc;
+    if (mu) TMVB_HIP(hipMemcpyAsync(mu, h->d_mu, K * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (sigma) TMVB_HIP(hipMemcpyAsync(sigma, h->d_sigma, K * K * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (invsigma) TMVB_HIP(hipMemcpyAsync(invsigma, h->d_invsigma, K * K * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    TMVB_HIP(hipStreamSynchronize(ctx->stream));
+    if (beta && (rc = ctm_download_beta(h, beta, h->d_beta[h->cur]))) return rc;
+    if (beta_old && (rc = ctm_download_beta(h, beta_old, h->d_beta[h->cur ^ 1]))) return rc;
+    if (lambda && (rc = download_f32(ctx, lambda, h->d_lambda, KM))) return rc;
+    if (lambda_old && (rc = download_f32(ctx, lambda_old, h->d_lambda_old, KM))) return rc;
+    if (vsq && (rc = download_f32(ctx, vsq, h->d_vsq, KM))) return rc;
+    if (logzeta && (rc = download_f32(ctx, logzeta, h->d_logzeta, (size_t)h->M))) return rc;
+    if (elbo) *elbo = h->elbo;
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_ctm_estep(tmvb_ctm* h, int32_t niter, double ntol, int32_t viter, double vtol)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_ctm_estep: handle is NULL");
+    TMVB_REQUIRE(viter >= 0 && niter >= 0, TMVB_EINVAL, "iteration parameters must be nonnegative.");   // src/gpuCTM.jl:490
+    TMVB_REQUIRE(vtol >= 0 && ntol >= 0, TMVB_EINVAL, "tolerance parameters must be nonnegative.");     // src/gpuCTM.jl:489
+    tmvb_ctx* ctx = h->ctx;
+    TMVB_HIP(hipSetDevice(ctx->device));
+    CtmParams p;
+    p.K = h->K; p.KP = h->KP; p.LPR = h->KP / 4; p.lpr_magic = (unsigned)(0x100000000ull / (unsigned)p.LPR) + 1u;
+    p.doc_ptr = h->corp->d_doc_ptr; p.terms = h->corp->d_terms; p.counts = h->corp->d_counts;
+    p.doc_order = h->d_doc_order; p.tok_inv = h->corp->term_index.d_inv;
+    p.beta = h->d_beta[h->cur]; p.invsigma = h->d_invsigma_f; p.mu = h->d_mu_f;
+    p.lambda = h->d_lambda; p.lambda_old = h->d_lambda_old; p.vsq = h->d_vsq; p.logzeta = h->d_logzeta;
+    p.wtok = h->d_wtok; p.E = h->d_E; p.sweeps = h->d_sweeps; p.newton_steps = h->d_newton;
+    p.niter = niter; p.ntol = ntol; p.viter = viter; p.vtol = vtol;
+    TMVB_HIP(hipEventRecord(h->ev0, ctx->stream));
+    TMVB_HIP(hipMemsetAsync(h->d_newton, 0, sizeof(unsigned long long), ctx->stream));
+    const int nb = (int)h->buckets.size();
+    const int naux = std::min(nb, (int)tmvb_ctm::NAUX);
+    if (naux > 1) {
+        TMVB_HIP(hipEventRecord(h->ev_fork, ctx->stream));
+        for (int a = 0; a < naux; ++a) TMVB_HIP(hipStreamWaitEvent(h->aux[a], h->ev_fork, 0));
+    }
+    for (int bi = 0; bi < nb; ++bi) {
+        const tmvb_bucket& b = h->buckets[bi];
+        hipStream_t st = (naux > 1) ? h->aux[bi % naux] : ctx->stream;
+        const size_t lds = tmvb_tile_bytes(b.tile_rows, h->KP);
+        const dim3 grid((unsigned)b.count), block(64);
+        switch (h->KP) {
+            case 4: hipLaunchKernelGGL((ctm_estep_kernel<4>), grid, block, lds, st, p, b.first, b.tile_rows); break;
+            case 12: hipLaunchKernelGGL((ctm_estep_kernel<12>), grid, block, lds, st, p, b.first, b.tile_rows); break;
+            case 20: hipLaunchKernelGGL((ctm_estep_kernel<20>), grid, block, lds, st, p, b.first, b.tile_rows); break;
+            default: hipLaunchKernelGGL((ctm_estep_kernel<52>), grid, block, lds, st, p, b.first, b.tile_rows); break;
+        }
+        TMVB_HIP(hipGetLastError());
+    }
+    if (naux > 1) {
+        for (int a = 0; a < naux; ++a) {
+            TMVB_HIP(hipEventRecord(h->ev_join[a], h->aux[a]));
+            TMVB_HIP(hipStreamWaitEvent(ctx->stream, h->ev_join[a], 0));
+        }
+    }
+    // update_beta!(model, d)  src/CTM.jl:122-125 as the gather-side statistics pass (no epsilon in CTM's phi)
+    TermStatsParams tp;
+    tp.K = h->K; tp.tstride = h->KP; tp.ostride = h->K;
+    tp.w = h->d_wtok; tp.E = h->d_E; tp.T = h->d_beta[h->cur]; tp.eps = 0.0f; tp.base = 0.0f;
+    tp.out = h->d_stats; tp.partial = h->d_ts_partial;
+    int rc = tmvb_launch_termstats(ctx, 1, h->KP, true, h->corp->term_index, tp);
+    if (rc) return rc;
+    TMVB_HIP(hipEventRecord(h->ev1, ctx->stream));
+    h->timed = true;
+    return TMVB_OK;
+}
+
+// sum_d lambda_d, sum_d vsq_d and the scatter matrix (with the CURRENT = previous-iteration mu) into the statistics tail
+extern "C" int tmvb_ctm_reduce_docs(tmvb_ctm* h)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_ctm_reduce_docs: handle is NULL");
+    tmvb_ctx* ctx = h->ctx;
+    TMVB_HIP(hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = tmvb_colsum(ctx, 1, h->K, h->d_lambda, h->M, h->d_partial, nullptr, h->tail()))) return rc;
+    if ((rc = tmvb_colsum(ctx, 1, h->K, h->d_vsq, h->M, h->d_partial, nullptr, h->tail() + h->K))) return rc;
+    if (h->M > 0) {
+        hipLaunchKernelGGL(ctm_scatter_mfma_kernel, dim3(h->n_scatter_waves), dim3(64), 0, ctx->stream, h->d_lambda, h->d_mu_f, h->K,
+                           h->M, h->docs_per_wave, h->d_scatter_partial);
+        TMVB_HIP(hipGetLastError());
+        hipLaunchKernelGGL(ctm_scatter_reduce_kernel, dim3((h->K * h->K + 255) / 256), dim3(256), 0, ctx->stream, h->d_scatter_partial,
+                           h->n_scatter_waves, h->K, h->tail() + 2 * h->K);
+        TMVB_HIP(hipGetLastError());
+    } else {
+        TMVB_HIP(hipMemsetAsync(h->tail() + 2 * h->K, 0, (size_t)h->K * h->K * sizeof(float), ctx->stream));
+    }
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_ctm_stats(tmvb_ctm* h, void** dev_ptr, int64_t* n_f32)
+{
+    TMVB_REQUIRE(h && dev_ptr && n_f32, TMVB_EINVAL, "tmvb_ctm_stats: NULL argument");
+    *dev_ptr = h->d_stats;
+    *n_f32 = h->stats_len();
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_ctm_bind_stats(tmvb_ctm* h, void* dev_ptr, int64_t n_f32)
+{
+    TMVB_REQUIRE(h && dev_ptr, TMVB_EINVAL, "tmvb_ctm_bind_stats: NULL argument");
+    TMVB_REQUIRE(n_f32 >= h->stats_len(), TMVB_ESHAPE, "tmvb_ctm_bind_stats: buffer holds %lld floats, need %lld", (long long)n_f32, (long long)h->stats_len());
+    TMVB_HIP(hipSetDevice(h->ctx->device));
+    TMVB_HIP(hipMemcpyAsync(dev_ptr, h->d_stats, (size_t)h->stats_len() * sizeof(float), hipMemcpyDeviceToDevice, h->ctx->stream));
+    TMVB_HIP(hipStreamSynchronize(h->ctx->stream));
+    if (h->own_stats) (void)hipFree(h->d_stats);
+    h->d_stats = (float*)dev_ptr;
+    h->own_stats = false;
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_ctm_set_distributed(tmvb_ctm* h, int64_t M_total, int32_t distributed)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_ctm_set_distributed: handle is NULL");
+    TMVB_REQUIRE(M_total >= h->M, TMVB_ESHAPE, "tmvb_ctm_set_distributed: M_total < local M");
+    h->M_total = M_total;
+    h->distributed = distributed != 0;
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_ctm_update_beta(tmvb_ctm* h)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_ctm_update_beta: handle is NULL");
+    tmvb_ctx* ctx = h->ctx;
+    TMVB_HIP(hipSetDevice(ctx->device));
+    int rc = tmvb_colsum(ctx, 1, h->K, h->d_stats, h->V, h->d_partial, h->d_rowsum, nullptr);
+    if (rc) return rc;
+    const int64_t total = (int64_t)h->KP * h->V;
+    int nb = (int)std::min<int64_t>(2048, std::max<int64_t>(1, (total + 255) / 256));
+    hipLaunchKernelGGL(beta_norm_kernel, dim3(nb), dim3(256), (size_t)h->K * sizeof(double), ctx->stream,
+                       h->d_stats, h->d_rowsum, h->d_beta[h->cur ^ 1], h->K, h->KP, h->V);
+    TMVB_HIP(hipGetLastError());
+    h->cur ^= 1;
+    return TMVB_OK;
+}
+
+static int ctm_sigma_mu(tmvb_ctm* h, int do_sigma, int do_mu)
+{
+    tmvb_ctx* ctx = h->ctx;
+    TMVB_HIP(hipSetDevice(ctx->device));
+    const size_t lds = (size_t)h->K * 2 * h->K * sizeof(double);
+    hipLaunchKernelGGL(ctm_sigma_mu_kernel, dim3(1), dim3(256), lds, ctx->stream, h->K, h->KP, (double)h->M_total, h->tail(),
+                       h->d_sigma, h->d_invsigma, h->d_invsigma_f, h->d_mu, h->d_mu_f, h->d_logdet, h->d_status, do_sigma, do_mu);
+    TMVB_HIP(hipGetLastError());
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_ctm_update_sigma(tmvb_ctm* h)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_ctm_update_sigma: handle is NULL");
+    return ctm_sigma_mu(h, 1, 0);
+}
+
+extern "C" int tmvb_ctm_update_mu(tmvb_ctm* h)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_ctm_update_mu: handle is NULL");
+    return ctm_sigma_mu(h, 0, 1);
+}
+
+extern "C" int tmvb_ctm_update_elbo(tmvb_ctm* h, double* elbo)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_ctm_update_elbo: handle is NULL");
+    tmvb_ctx* ctx = h->ctx;
+    TMVB_HIP(hipSetDevice(ctx->device));
+    if (h->M > 0) {
+        hipLaunchKernelGGL(ctm_elbo_kernel, dim3((unsigned)h->M), dim3(64), 0, ctx->stream, h->K, h->KP, h->corp->d_doc_ptr,
+                           h->corp->d_terms, h->corp->d_counts, h->d_mu, h->d_invsigma, h->d_logdet, h->d_beta[h->cur],
+                           h->d_beta[h->cur ^ 1], h->d_lambda, h->d_lambda_old, h->d_vsq, h->d_logzeta, h->d_doc_val);
+        TMVB_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(sum_docs_kernel, dim3(1), dim3(1024), 0, ctx->stream, h->d_doc_val, h->M, h->d_elbo);
+    TMVB_HIP(hipGetLastError());
+    double v = 0.0;
+    int st = 0;
+    TMVB_HIP(hipMemcpyAsync(&v, h->d_elbo, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    TMVB_HIP(hipMemcpyAsync(&st, h->d_status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    TMVB_HIP(hipStreamSynchronize(ctx->stream));
+    TMVB_REQUIRE(st == 0, TMVB_ENONFINITE, "sigma must be positive-definite.");
+    h->elbo = v;
+    if (elbo) *elbo = v;
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_ctm_train(tmvb_ctm* h, int32_t iter, double tol, int32_t niter, double ntol, int32_t viter,
+                              double vtol, int32_t checkelbo, double* elbo_traj, int32_t* iters_done)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_ctm_train: handle is NULL");
+    TMVB_REQUIRE(tol >= 0 && ntol >= 0 && vtol >= 0, TMVB_EINVAL, "tolerance parameters must be nonnegative.");   // src/gpuCTM.jl:489
+    TMVB_REQUIRE(iter >= 0 && niter >= 0 && viter >= 0, TMVB_EINVAL, "iteration parameters must be nonnegative."); // :490
+    TMVB_REQUIRE(!h->distributed, TMVB_EINVAL, "tmvb_ctm_train drives one context; a document-sharded host composes the operators itself");
+    if (iters_done) *iters_done = 0;
+    if (h->corp->info.nnz == 0) iter = 0;
+    int rc;
+    double e_old = h->elbo;
+    if (checkelbo > 0 && checkelbo <= iter) {
+        if ((rc = tmvb_ctm_update_elbo(h, &e_old))) return rc;
+    }
+    int done = 0;
+    for (int k = 1; k <= iter; ++k) {
+        ++done;
+        if ((rc = tmvb_ctm_estep(h, niter, ntol, viter, vtol))) return rc;      // src/CTM.jl:194-205
+        if ((rc = tmvb_ctm_reduce_docs(h))) return rc;
+        if ((rc = tmvb_ctm_update_beta(h))) return rc;                          // :206
+        if ((rc = tmvb_ctm_update_sigma(h))) return rc;                         // :207 (previous mu)
+        if ((rc = tmvb_ctm_update_mu(h))) return rc;                            // :208
+        if (elbo_traj) elbo_traj[k - 1] = NAN;
+        if (checkelbo > 0 && (k % checkelbo) == 0) {
+            double e_new;
+            if ((rc = tmvb_ctm_update_elbo(h, &e_new))) return rc;
+            TMVB_REQUIRE(std::isfinite(e_new), TMVB_ENONFINITE, "elbo must be finite.");
+            if (elbo_traj) elbo_traj[k - 1] = e_new;
+            double delta = e_new - e_old;
+            e_old = e_new;
+            if (delta < tol) break;
+        }
+    }
+    TMVB_HIP(hipStreamSynchronize(h->ctx->stream));
+    if (iters_done) *iters_done = done;
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_ctm_sweep_hist(tmvb_ctm* h, int64_t* hist, int32_t nbins, int64_t* newton_steps)
+{
+    TMVB_REQUIRE(h && hist && nbins > 0, TMVB_EINVAL, "tmvb_ctm_sweep_hist: bad argument");
+    std::vector<uint8_t> sw((size_t)h->M);
+    unsigned long long ns = 0;
+    TMVB_HIP(hipSetDevice(h->ctx->device));
+    if (h->M) TMVB_HIP(hipMemcpyAsync(sw.data(), h->d_sweeps, (size_t)h->M, hipMemcpyDeviceToHost, h->ctx->stream));
+    TMVB_HIP(hipMemcpyAsync(&ns, h->d_newton, sizeof(ns), hipMemcpyDeviceToHost, h->ctx->stream));
+    TMVB_HIP(hipStreamSynchronize(h->ctx->stream));
+    for (int b = 0; b < nbins; ++b) hist[b] = 0;
+    for (uint8_t s : sw) hist[std::min<int>(s, nbins - 1)]++;
+    if (newton_steps) *newton_steps = (int64_t)ns;
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_ctm_last_estep_ms(tmvb_ctm* h, float* ms)
+{
+    TMVB_REQUIRE(h && ms, TMVB_EINVAL, "tmvb_ctm_last_estep_ms: NULL argument");
+    TMVB_REQUIRE(h->timed, TMVB_EINVAL, "tmvb_ctm_last_estep_ms: no E-step has run");
+    TMVB_HIP(hipSetDevice(h->ctx->device));
+    TMVB_HIP(hipEventSynchronize(h->ev1));
+    TMVB_HIP(hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return TMVB_OK;
+}

@@ -25,17 +25,13 @@
 //
 // Roofline: HBM-bound gather/scatter.  Algorithmic bytes per outer iteration:
 //   nnz*(8 + 4K + 4K) + 12*M*K + 12*K*V + 4*(M+1).
-#include "tmvb_internal.h"
-#include "tmvb_termstats.h"
+#include "tmvb_common_kernels.h"
 
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
 
-#define LDA_MAX_NSLOT 16                      // K <= 1024
-#define LDA_MAX_TILE_BYTES (64 * 1024)
-#define LDA_REDUCE_BLOCKS 256
 
 struct LdaParams {
     int K, KP, LPR;          // topics, padded row stride (4*odd), 16-byte chunks per row (KP/4)
@@ -60,15 +56,6 @@ struct LdaParams {
     int debug;               // TMVB_DEBUG_FLAGS (profiling experiments only): 1 = skip the statistics pass
 };
 
-template <int CTRL>
-__device__ __forceinline__ float4 dpp_add4(float4 v)
-{
-    v.x += dpp_f<CTRL>(v.x); v.y += dpp_f<CTRL>(v.y); v.z += dpp_f<CTRL>(v.z); v.w += dpp_f<CTRL>(v.w);
-    return v;
-}
-
-// one wave per workgroup: __syncthreads() lowers to an LDS fence (the s_barrier is elided)
-#define WAVE_LDS_FENCE() __syncthreads()
 
 // ------------------------------------------------------------------------------ E-step kernel
 // LPR_T: compile-time chunks-per-row (0 = use p.LPR); NSLOT = ceil(K/64).
@@ -282,61 +269,6 @@ __global__ __launch_bounds__(64) void lda_estep_kernel(LdaParams p, int64_t firs
 //            over the 64 lanes (v_permlane32_swap, v_permlane16_swap, 4 DPP stages; ~2.2 R
 //            instructions): afterwards lane L holds the total of topic pi(L)
 // pi (topic_of_lane / lane_of_topic) is computed on the host by replaying the same pairing.
-// NOTE: hipcc 7.2 mis-selects __builtin_amdgcn_permlane{32,16}_swap when both results feed one add
-// (it emits `v_add v, r0, r0`), so the swap is issued through inline asm.  hipcc inserts no hazard
-// wait states inside asm: the leading s_nop covers a preceding VALU write of the operands.
-__device__ __forceinline__ void swap_add32(float& a, float b)
-{
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-    a += b;                                   // lanes < 32: a.lo + a.hi, lanes >= 32: b.lo + b.hi
-}
-__device__ __forceinline__ void swap_add16(float& a, float b)
-{
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-    a += b;                                   // even rows: sums of a, odd rows: sums of b
-}
-template <int CTRL>
-__device__ __forceinline__ void dpp_stage(float& a, float b, bool hi)
-{
-    const float keep = hi ? b : a, give = hi ? a : b;
-    a = keep + dpp_f<CTRL>(give);
-}
-
-template <int R>
-__device__ __forceinline__ float lane_reduce_scatter(float (&p)[R], int lane)
-{
-    constexpr int m0 = R, h0 = (m0 + 1) / 2;
-#pragma unroll
-    for (int i = 0; i < h0; ++i) swap_add32(p[i], (i + h0 < m0) ? p[i + h0] : p[i]);
-    constexpr int m1 = h0, h1 = (m1 + 1) / 2;
-#pragma unroll
-    for (int i = 0; i < h1; ++i) swap_add16(p[i], (i + h1 < m1) ? p[i + h1] : p[i]);
-    constexpr int m2 = h1, h2 = (m2 + 1) / 2;
-    const bool b8 = lane & 8, b4 = lane & 4, b2 = lane & 2, b1 = lane & 1;
-#pragma unroll
-    for (int i = 0; i < h2; ++i) {
-        if (i + h2 < m2) dpp_stage<0x140>(p[i], p[i + h2], b8);      // row_mirror
-        else p[i] += dpp_f<0x140>(p[i]);
-    }
-    constexpr int m3 = h2, h3 = (m3 + 1) / 2;
-#pragma unroll
-    for (int i = 0; i < h3; ++i) {
-        if (i + h3 < m3) dpp_stage<0x141>(p[i], p[i + h3], b4);      // row_half_mirror
-        else p[i] += dpp_f<0x141>(p[i]);
-    }
-    constexpr int m4 = h3, h4 = (m4 + 1) / 2;
-#pragma unroll
-    for (int i = 0; i < h4; ++i) {
-        if (i + h4 < m4) dpp_stage<0x4E>(p[i], p[i + h4], b2);       // quad_perm [2,3,0,1]
-        else p[i] += dpp_f<0x4E>(p[i]);
-    }
-    constexpr int m5 = h4;
-    static_assert(m5 <= 2, "reduce-scatter supports up to 64 registers");
-    if (m5 == 2) dpp_stage<0xB1>(p[0], p[1], b1);                    // quad_perm [1,0,3,2]
-    else p[0] += dpp_f<0xB1>(p[0]);
-    return p[0];
-}
-
 template <int LPR, int T>
 __global__ __launch_bounds__(64) void lda_estep_reg_kernel(LdaParams p, int64_t first,
                                                            const int* __restrict__ topic_of_lane,
@@ -439,99 +371,6 @@ __global__ __launch_bounds__(64) void lda_estep_reg_kernel(LdaParams p, int64_t 
         for (int t = 0; t < T; ++t) if (wpos[t] >= 0) p.wtok[wpos[t]] = 0.0f;
     }
     if (lane == 0) p.sweeps[d] = (uint8_t)min(sweeps, 255);
-}
-
-// host replay of lane_reduce_scatter's pairing: which topic ends up in which lane
-static void lda_reg_lane_maps(int R, std::vector<int>& topic_of_lane, std::vector<int>& lane_of_topic)
-{
-    std::vector<std::vector<int>> regs(R, std::vector<int>(64));
-    for (int q = 0; q < R; ++q) for (int l = 0; l < 64; ++l) regs[q][l] = q;
-    const int Ds[6] = {32, 16, 8, 4, 2, 1};
-    for (int st = 0; st < 6; ++st) {
-        const int D = Ds[st], m = (int)regs.size(), h = (m + 1) / 2;
-        std::vector<std::vector<int>> nxt(h, std::vector<int>(64));
-        for (int i = 0; i < h; ++i)
-            for (int l = 0; l < 64; ++l) nxt[i][l] = (i + h < m && (l & D)) ? regs[i + h][l] : regs[i][l];
-        regs.swap(nxt);
-    }
-    topic_of_lane.assign(64, -1);
-    lane_of_topic.assign(R, -1);
-    for (int l = 0; l < 64; ++l) {
-        int q = regs[0][l];
-        if (lane_of_topic[q] < 0) { lane_of_topic[q] = l; topic_of_lane[l] = q; }   // first lane is the primary
-    }
-}
-
-// ------------------------------------------------------------------------------ reductions
-// partial[block][K] (double) = sum over a strided subset of columns of X (K x ncols, fp32)
-template <int NSLOT>
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, int64_t ncols, int K,
-                                                             double* __restrict__ partial)
-{
-    __shared__ double red[4][64 * NSLOT];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int64_t gw = (int64_t)blockIdx.x * 4 + wv, nw = (int64_t)gridDim.x * 4;
-    double acc[NSLOT];
-#pragma unroll
-    for (int s = 0; s < NSLOT; ++s) acc[s] = 0.0;
-#pragma unroll 8
-    for (int64_t c = gw; c < ncols; c += nw) {
-#pragma unroll
-        for (int s = 0; s < NSLOT; ++s) {
-            int i = lane + 64 * s;
-            if (i < K) acc[s] += (double)X[c * K + i];
-        }
-    }
-#pragma unroll
-    for (int s = 0; s < NSLOT; ++s) red[wv][lane + 64 * s] = acc[s];
-    __syncthreads();
-    for (int i = threadIdx.x; i < K; i += 256)
-        partial[(int64_t)blockIdx.x * K + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
-}
-
-// out_d[i] = sum_b partial[b][i]: one wave per output, fixed reduction tree (deterministic); optional fp32 copy
-__global__ __launch_bounds__(256) void colsum_final_kernel(const double* __restrict__ partial, int nblocks, int K,
-                                                           double* __restrict__ out_d, float* __restrict__ out_f)
-{
-    const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= K) return;
-    double s = 0.0;
-    for (int b = lane; b < nblocks; b += 64) s += partial[(int64_t)b * K + i];
-    s = wave_sum_d(s);
-    if (lane == 0) {
-        if (out_d) out_d[i] = s;
-        if (out_f) out_f[i] = (float)s;
-    }
-}
-
-// update_beta!(model)  src/LDA.jl:121-125:  beta_new = S ./ rowsum(S);  S <- 0
-// S is dense [V][K]; beta_new is the padded gather layout [V][KP] (pad columns zero).
-__global__ __launch_bounds__(256) void lda_beta_norm_kernel(float* __restrict__ S, const double* __restrict__ rowsum,
-                                                            float* __restrict__ beta_new, int K, int KP, int64_t V)
-{
-    extern __shared__ double rinv[];
-    for (int i = threadIdx.x; i < K; i += blockDim.x) rinv[i] = 1.0 / rowsum[i];
-    __syncthreads();
-    const int64_t total = V * KP;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += stride) {
-        const int64_t j = q / KP;
-        const int i = (int)(q - j * KP);
-        float o = 0.0f;
-        if (i < K) {
-            o = (float)((double)S[j * K + i] * rinv[i]);
-            S[j * K + i] = 0.0f;
-        }
-        beta_new[q] = o;
-    }
-}
-
-__device__ __forceinline__ double wave_min_d(double v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
-    return v;
 }
 
 // update_alpha!  src/LDA.jl:97-118, fp64, one wave (lane = topic).
@@ -717,7 +556,7 @@ struct tmvb_lda {
     int* d_lane_of_topic = nullptr;
     bool reg_path = false;             // K <= 64 with a specialised LPR: short documents use lda_estep_reg_kernel
     int32_t* d_doc_order = nullptr;
-    double* d_partial = nullptr;       // [LDA_REDUCE_BLOCKS][K]
+    double* d_partial = nullptr;       // [TMVB_REDUCE_BLOCKS][K]
     double* d_rowsum = nullptr;        // [K]
     double* d_esum = nullptr;          // [K]
     double* d_doc_val = nullptr;       // [M]
@@ -734,20 +573,6 @@ struct tmvb_lda {
     hipEvent_t ev_fork = nullptr, ev_join[NAUX] = {nullptr, nullptr, nullptr, nullptr};
 };
 
-template <typename F>
-static int dispatch_nslot(int nslot, F&& f)
-{
-    switch (nslot) {
-        case 1: return f(std::integral_constant<int, 1>());
-        case 2: return f(std::integral_constant<int, 2>());
-        case 3: case 4: return f(std::integral_constant<int, 4>());
-        case 5: case 6: case 7: case 8: return f(std::integral_constant<int, 8>());
-        default: return f(std::integral_constant<int, 16>());
-    }
-}
-
-static size_t lda_tile_bytes(int rows, int KP) { return ((size_t)rows * KP + KP + 3 * (size_t)rows) * sizeof(float); }
-
 static bool lda_reg_lpr_supported(int lpr) { return lpr == 1 || lpr == 3 || lpr == 5 || lpr == 13; }
 #define LDA_REG_MAX_TILES 4
 
@@ -759,40 +584,8 @@ static void lda_build_buckets(tmvb_lda* h, std::vector<int32_t>& order)
     std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return len[x] > len[y]; });
     h->buckets.clear();
     const int64_t reg_max = h->reg_path ? 64 * LDA_REG_MAX_TILES : -1;
-    // documents longer than reg_max: LDS-tile kernel, tile heights in 32-row steps within 64 KiB
-    int64_t n_lds = 0;
-    while (n_lds < h->M && len[order[n_lds]] > reg_max) ++n_lds;
-    int64_t pos = 0;
-    if (n_lds > 0) {
-        std::vector<int> tiles;
-        for (int r = 32; r <= 8192; r += (r < 256 ? 32 : r)) {
-            if (lda_tile_bytes(r, h->KP) > LDA_MAX_TILE_BYTES) break;
-            tiles.push_back(r);
-        }
-        if (tiles.empty()) tiles.push_back(4);
-        const int tmax = tiles.back();
-        int64_t cnt = 0;
-        while (pos + cnt < n_lds && len[order[pos + cnt]] > tmax) ++cnt;   // stream chunks through the largest tile
-        if (cnt) h->buckets.push_back({pos, cnt, tmax, 0});
-        pos += cnt;
-        for (int b = (int)tiles.size() - 1; b >= 0 && pos < n_lds; --b) {
-            const int64_t lo = (b > 0) ? tiles[b - 1] : -1;
-            cnt = 0;
-            while (pos + cnt < n_lds && len[order[pos + cnt]] > lo) ++cnt;
-            if (cnt) h->buckets.push_back({pos, cnt, tiles[b], 0});
-            pos += cnt;
-        }
-        // merge small LDS buckets into their larger neighbour
-        for (size_t b = 1; b < h->buckets.size();) {
-            if (h->buckets[b].count < 512 && h->buckets[b - 1].tile_rows >= h->buckets[b].tile_rows &&
-                len[order[h->buckets[b - 1].first + h->buckets[b - 1].count - 1]] <= h->buckets[b - 1].tile_rows) {
-                h->buckets[b - 1].count += h->buckets[b].count;
-                h->buckets.erase(h->buckets.begin() + b);
-            } else {
-                ++b;
-            }
-        }
-    }
+    // documents longer than reg_max: LDS-tile kernel
+    int64_t pos = tmvb_build_lds_buckets(len, order, h->M, h->KP, reg_max, 3, h->buckets);
     // register-tile buckets: T = ceil(N / 64) tiles of 64 tokens
     for (int T = LDA_REG_MAX_TILES; T >= 1 && pos < h->M; --T) {
         const int64_t lo = 64 * (int64_t)(T - 1);
@@ -801,19 +594,6 @@ static void lda_build_buckets(tmvb_lda* h, std::vector<int32_t>& order)
         if (cnt) h->buckets.push_back({pos, cnt, 0, T});
         pos += cnt;
     }
-}
-
-template <typename T>
-static int dmalloc(T** p, size_t n)
-{
-    *p = nullptr;
-    size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
-    hipError_t e = hipMalloc((void**)p, bytes);
-    if (e != hipSuccess) {
-        tmvb_set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
-        return TMVB_ENOMEM;
-    }
-    return TMVB_OK;
 }
 
 extern "C" int tmvb_lda_destroy(tmvb_lda* h)
@@ -835,24 +615,6 @@ extern "C" int tmvb_lda_destroy(tmvb_lda* h)
         if (h->aux[a]) (void)hipStreamDestroy(h->aux[a]);
     }
     delete h;
-    return TMVB_OK;
-}
-
-static int upload_f32(tmvb_ctx* ctx, float* dst, const double* src, size_t n)
-{
-    std::vector<float> tmp(n);
-    for (size_t q = 0; q < n; ++q) tmp[q] = (float)src[q];
-    TMVB_HIP(hipMemcpyAsync(dst, tmp.data(), n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    TMVB_HIP(hipStreamSynchronize(ctx->stream));
-    return TMVB_OK;
-}
-
-static int download_f32(tmvb_ctx* ctx, double* dst, const float* src, size_t n)
-{
-    std::vector<float> tmp(n);
-    TMVB_HIP(hipMemcpyAsync(tmp.data(), src, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-    TMVB_HIP(hipStreamSynchronize(ctx->stream));
-    for (size_t q = 0; q < n; ++q) dst[q] = (double)tmp[q];
     return TMVB_OK;
 }
 
@@ -885,7 +647,7 @@ extern "C" int tmvb_lda_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
     *out = nullptr;
     TMVB_REQUIRE(ctx && corp, TMVB_EINVAL, "tmvb_lda_create: NULL context or corpus");
     TMVB_REQUIRE(K > 0, TMVB_EINVAL, "number of topics must be a positive integer.");   // src/gpuLDA.jl:47
-    TMVB_REQUIRE(K <= 64 * LDA_MAX_NSLOT, TMVB_EINVAL, "tmvb_lda_create: K=%d exceeds the supported maximum %d", K, 64 * LDA_MAX_NSLOT);
+    TMVB_REQUIRE(K <= 64 * TMVB_MAX_NSLOT, TMVB_EINVAL, "tmvb_lda_create: K=%d exceeds the supported maximum %d", K, 64 * TMVB_MAX_NSLOT);
     TMVB_HIP(hipSetDevice(ctx->device));
     tmvb_lda* h = new tmvb_lda();
     h->ctx = ctx; h->corp = corp; h->K = K; h->KP = tmvb_kpad(K); h->nslot = (K + 63) / 64;
@@ -897,7 +659,7 @@ extern "C" int tmvb_lda_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
     if ((rc = dmalloc(&h->d_alpha_d, K)) || (rc = dmalloc(&h->d_alpha_f, K)) || (rc = dmalloc(&h->d_beta[0], KPV)) ||
         (rc = dmalloc(&h->d_beta[1], KPV)) || (rc = dmalloc(&h->d_stats, KV + K)) || (rc = dmalloc(&h->d_gamma, KM)) ||
         (rc = dmalloc(&h->d_elog, KM)) || (rc = dmalloc(&h->d_elog_old, KM)) || (rc = dmalloc(&h->d_sweeps, (size_t)h->M)) ||
-        (rc = dmalloc(&h->d_doc_order, (size_t)h->M)) || (rc = dmalloc(&h->d_partial, (size_t)LDA_REDUCE_BLOCKS * K)) ||
+        (rc = dmalloc(&h->d_doc_order, (size_t)h->M)) || (rc = dmalloc(&h->d_partial, (size_t)TMVB_REDUCE_BLOCKS * K)) ||
         (rc = dmalloc(&h->d_rowsum, K)) || (rc = dmalloc(&h->d_esum, K)) || (rc = dmalloc(&h->d_doc_val, (size_t)h->M)) ||
         (rc = dmalloc(&h->d_elbo, 1)) || (rc = dmalloc(&h->d_iters, 1)) || (rc = dmalloc(&h->d_wtok, (size_t)corp->info.nnz)) ||
         (rc = dmalloc(&h->d_E, (size_t)h->KP * h->M + 4)) || (rc = tmvb_corpus_term_index(corp)) ||
@@ -908,7 +670,7 @@ extern "C" int tmvb_lda_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
     h->reg_path = (K <= 64) && lda_reg_lpr_supported(h->KP / 4);
     if (h->reg_path) {
         std::vector<int> tol, lot;
-        lda_reg_lane_maps(h->KP, tol, lot);
+        tmvb_reg_lane_maps(h->KP, tol, lot);
         if ((rc = dmalloc(&h->d_topic_of_lane, 64)) || (rc = dmalloc(&h->d_lane_of_topic, (size_t)h->KP))) { tmvb_lda_destroy(h); return rc; }
         TMVB_HIP(hipMemcpy(h->d_topic_of_lane, tol.data(), 64 * sizeof(int), hipMemcpyHostToDevice));
         TMVB_HIP(hipMemcpy(h->d_lane_of_topic, lot.data(), (size_t)h->KP * sizeof(int), hipMemcpyHostToDevice));
@@ -1035,7 +797,7 @@ extern "C" int tmvb_lda_estep(tmvb_lda* h, int32_t viter, double vtol)
             TMVB_HIP(hipGetLastError());
             continue;
         }
-        const size_t lds = lda_tile_bytes(b.tile_rows, h->KP);
+        const size_t lds = tmvb_tile_bytes(b.tile_rows, h->KP);
         int rc = dispatch_nslot(h->nslot, [&](auto ns) -> int {
             constexpr int NS = decltype(ns)::value;
             const dim3 grid((unsigned)b.count), block(64);
@@ -1065,26 +827,9 @@ extern "C" int tmvb_lda_estep(tmvb_lda* h, int32_t viter, double vtol)
     if (!(p.debug & 1) && ix.n_chunks > 0) {
         TermStatsParams tp;
         tp.K = h->K; tp.tstride = h->KP; tp.ostride = h->K;
-        tp.tok_doc = ix.d_doc; tp.tok_pos = ix.d_pos; tp.chunk_id = ix.d_chunk_id; tp.chunk_begin = ix.d_chunk_begin;
-        tp.chunk_end = ix.d_chunk_end; tp.chunk_out = ix.d_chunk_out; tp.n_chunks = (int)ix.n_chunks;
         tp.w = h->d_wtok; tp.E = h->d_E; tp.T = h->d_beta[h->cur]; tp.eps = TMVB_EPS_F; tp.base = 0.0f;
         tp.out = h->d_stats; tp.partial = h->d_ts_partial;
-        int rc = dispatch_nslot(h->nslot, [&](auto ns) -> int {
-            constexpr int NS = decltype(ns)::value;
-            const dim3 grid((unsigned)((ix.n_chunks + 3) / 4)), block(256);
-            const int lpr = h->KP / 4;
-            if (h->estride == h->KP) {
-                if (lpr == 13) hipLaunchKernelGGL((termstats_chunk4_kernel<13>), grid, block, 0, ctx->stream, tp, lpr);
-                else if (lpr == 25) hipLaunchKernelGGL((termstats_chunk4_kernel<25>), grid, block, 0, ctx->stream, tp, lpr);
-                else hipLaunchKernelGGL((termstats_chunk4_kernel<0>), grid, block, 0, ctx->stream, tp, lpr);
-            } else {
-                hipLaunchKernelGGL((termstats_chunk_kernel<NS>), grid, block, 0, ctx->stream, tp);
-            }
-            if (ix.n_multi > 0)
-                hipLaunchKernelGGL((termstats_multi_kernel<NS>), dim3((unsigned)ix.n_multi), dim3(256), 0, ctx->stream, tp,
-                                   ix.d_multi_id, ix.d_multi_first, ix.d_multi_count, (int)ix.n_multi);
-            return TMVB_OK;
-        });
+        int rc = tmvb_launch_termstats(ctx, h->nslot, h->KP, h->estride == h->KP, ix, tp);
         if (rc) return rc;
         TMVB_HIP(hipGetLastError());
     }
@@ -1095,18 +840,7 @@ extern "C" int tmvb_lda_estep(tmvb_lda* h, int32_t viter, double vtol)
 
 static int colsum(tmvb_lda* h, const float* X, int64_t ncols, double* out_d, float* out_f)
 {
-    tmvb_ctx* ctx = h->ctx;
-    int nb = (int)std::min<int64_t>(LDA_REDUCE_BLOCKS, std::max<int64_t>(1, (ncols + 3) / 4));
-    int rc = dispatch_nslot(h->nslot, [&](auto ns) -> int {
-        constexpr int NS = decltype(ns)::value;
-        hipLaunchKernelGGL((colsum_partial_kernel<NS>), dim3(nb), dim3(256), 0, ctx->stream, X, ncols, h->K, h->d_partial);
-        return TMVB_OK;
-    });
-    if (rc) return rc;
-    TMVB_HIP(hipGetLastError());
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((h->K + 3) / 4), dim3(256), 0, ctx->stream, h->d_partial, nb, h->K, out_d, out_f);
-    TMVB_HIP(hipGetLastError());
-    return TMVB_OK;
+    return tmvb_colsum(h->ctx, h->nslot, h->K, X, ncols, h->d_partial, out_d, out_f);
 }
 
 extern "C" int tmvb_lda_reduce_docs(tmvb_lda* h)
@@ -1156,7 +890,7 @@ extern "C" int tmvb_lda_update_beta(tmvb_lda* h)
     if (rc) return rc;
     const int64_t total = (int64_t)h->KP * h->V;
     int nb = (int)std::min<int64_t>(2048, std::max<int64_t>(1, (total + 255) / 256));
-    hipLaunchKernelGGL(lda_beta_norm_kernel, dim3(nb), dim3(256), (size_t)h->K * sizeof(double), ctx->stream,
+    hipLaunchKernelGGL(beta_norm_kernel, dim3(nb), dim3(256), (size_t)h->K * sizeof(double), ctx->stream,
                        h->d_stats, h->d_rowsum, h->d_beta[h->cur ^ 1], h->K, h->KP, h->V);
     TMVB_HIP(hipGetLastError());
     h->cur ^= 1;   // beta_old <- beta, beta <- new   (src/LDA.jl:122-123)
