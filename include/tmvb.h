@@ -195,6 +195,40 @@ int tmvb_ctm_train(tmvb_ctm* h, int32_t iter, double tol, int32_t niter, double 
 int tmvb_ctm_sweep_hist(tmvb_ctm* h, int64_t* hist, int32_t nbins, int64_t* newton_steps);
 int tmvb_ctm_last_estep_ms(tmvb_ctm* h, float* ms);
 
+/* ============================== CTPF (src/gpuCTPF.jl, oracle src/CTPF.jl) ============================== */
+
+/* gpuCTPF(corp, K) (src/gpuCTPF.jl:68-152).  Constructor state as src/CTPF.jl:81-100 (he=1, rates=1, gimel=zayin=1,
+ * hyper-parameters a..h = 0.1); alef is 1 until tmvb_ctpf_set_state (the reference draws it with Julia's RNG, :83).
+ * K <= 64 in this release. */
+int tmvb_ctpf_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb_ctpf** out);
+int tmvb_ctpf_destroy(tmvb_ctpf* h);
+/* update_buffer! state half (src/modelutils.jl:474-493).  hyper[8] = a..h; alef[K*V], he[K*U], bet/vav/dalet/het[K],
+ * gimel/zayin[K*M]; NULL = unchanged.  The *_old copies are set equal to the new values. */
+int tmvb_ctpf_set_state(tmvb_ctpf* h, const double* hyper, const double* alef, const double* he, const double* bet,
+                        const double* vav, const double* dalet, const double* het, const double* gimel,
+                        const double* zayin, const double* elbo);
+/* update_host! (src/modelutils.jl:539-570) without phi / xi.  rates[8*K] = bet, vav, dalet, het, then their *_old. */
+int tmvb_ctpf_get_state(tmvb_ctpf* h, double* alef, double* alef_old, double* he, double* he_old, double* rates,
+                        double* gimel, double* gimel_old, double* zayin, double* zayin_old, double* elbo);
+/* update_xi! / update_phi! / update_zayin! / update_gimel! sweeps + update_he!(d) / update_alef!(d) for every
+ * document, CPU-path semantics (src/CTPF.jl:353-365; replaces src/gpuCTPF.jl:667-668, :599-600, :511, :382, :448, :315). */
+int tmvb_ctpf_estep(tmvb_ctpf* h, int32_t viter, double vtol);
+/* sum_d gimel_d, sum_d zayin_d into the statistics tail. */
+int tmvb_ctpf_reduce_docs(tmvb_ctpf* h);
+/* Packed statistics: float32 [ alef_stats (K*V) | he_stats (K*U) | sum_gimel (K) | sum_zayin (K) ] (priors NOT included). */
+int tmvb_ctpf_stats(tmvb_ctpf* h, void** dev_ptr, int64_t* n_f32);
+int tmvb_ctpf_bind_stats(tmvb_ctpf* h, void* dev_ptr, int64_t n_f32);
+int tmvb_ctpf_set_distributed(tmvb_ctpf* h, int32_t distributed);
+/* update_he!, update_alef!, update_dalet!, update_het!, update_bet!, update_vav! in that order
+ * (src/CTPF.jl:366-371; replaces src/gpuCTPF.jl:448, :315, :418, :539, :344, :482). */
+int tmvb_ctpf_mstep(tmvb_ctpf* h);
+/* train! (src/gpuCTPF.jl:677-705).  checkelbo must be <= 0 (Inf): the CTPF ELBO is not evaluated on the device
+ * in this release. */
+int tmvb_ctpf_train(tmvb_ctpf* h, int32_t iter, double tol, int32_t viter, double vtol, int32_t checkelbo,
+                    double* elbo_traj, int32_t* iters_done);
+int tmvb_ctpf_sweep_hist(tmvb_ctpf* h, int64_t* hist, int32_t nbins);
+int tmvb_ctpf_last_estep_ms(tmvb_ctpf* h, float* ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,114 @@
+"""
+GPU parity tests for the CTPF path: HIP engine (C ABI) vs the fp64 oracle and the golden fixtures.
+Tolerances (fp64 -> fp32): teacher-forced single step: gimel, zayin rel <= 5e-4; alef, he rel <= 5e-4;
+rates (bet, vav, dalet, het) rel <= 1e-4.  Free running 4 iterations: state rel <= 2e-2 (no ELBO on device).
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    return {k: z[k] for k in z.files}
+
+
+def make_pair(tmvb, oracle, g):
+    K, V, U = int(g["K"]), int(g["V"]), int(g["U"])
+    pc = tmvb.PackedCorpus(g["doc_ptr"], g["terms"], g["counts"], V, g["rdr_ptr"], g["readers"], g["ratings"], U)
+    gm = tmvb.gpuCTPF(pc, K)
+    gm.alef = np.asfortranarray(g["alef0"]); gm.update_buffer()
+    om = oracle.CTPF(oracle.CSR(g["doc_ptr"], g["terms"], g["counts"], V, g["rdr_ptr"], g["readers"], g["ratings"], U), K, g["alef0"])
+    return gm, om
+
+
+def force(gm, om):
+    for n in ("alef", "he", "bet", "vav", "dalet", "het", "gimel", "zayin"):
+        setattr(gm, n, np.array(getattr(om, n), copy=True, order="F"))
+    gm.update_buffer()
+
+
+def rel(a, b):
+    return (np.abs(np.asarray(a) - np.asarray(b)) / np.abs(b)).max()
+
+
+def synth_case(tmvb, K, M=80, V=300, U=60, seed=4):
+    pc = tmvb.syn_citeu(M=M, V=V, U=U, seed=seed)
+    rng = np.random.default_rng(seed)
+    ratings = rng.integers(1, 4, size=pc.nR).astype(np.int32)        # exercise ratings > 1
+    return dict(K=K, V=V, U=U, doc_ptr=pc.doc_ptr, terms=pc.terms, counts=pc.counts, rdr_ptr=pc.rdr_ptr, readers=pc.readers,
+                ratings=ratings, alef0=np.exp(tmvb.dirichlet_rows(K, V, seed=6) - 0.5))
+
+
+@pytest.mark.parametrize("case", ["ctpf_m40_v60_u15_k4", "ctpf_m30_v40_u12_k6_r1", "syn_k12", "syn_k50"])
+def test_teacher_forced_step(tmvb, oracle, case):
+    g = load(case) if case.startswith("ctpf_") else synth_case(tmvb, 12 if case == "syn_k12" else 50)
+    gm, om = make_pair(tmvb, oracle, g)
+    for it in range(3):
+        force(gm, om)
+        gm.estep(); gm.reduce_docs(); gm.mstep()
+        sw = om.estep(); om.mstep()
+        gm.update_host()
+        hist_g = gm.sweep_hist(); hist_o = np.bincount(sw, minlength=11)
+        if np.array_equal(hist_g, hist_o):                     # same per-document exit decisions
+            assert rel(gm.gimel, om.gimel) <= 5e-4, (it, "gimel")
+            assert rel(gm.zayin, om.zayin) <= 5e-4, (it, "zayin")
+            assert rel(gm.alef, om.alef) <= 5e-4, (it, "alef")
+            assert rel(gm.he, om.he) <= 5e-4, (it, "he")
+            for n in ("bet", "vav", "dalet", "het"):
+                assert rel(getattr(gm, n), getattr(om, n)) <= 1e-4, (it, n)
+        else:
+            assert np.abs(hist_g - hist_o).sum() <= 0.1 * gm.M
+        assert rel(gm.alef_old, om.alef_old) <= 1e-6 and rel(gm.dalet_old, om.dalet_old) <= 1e-12
+        assert np.all(gm.alef > 0) and np.all(gm.he > 0) and np.all(gm.gimel > 0) and np.all(gm.zayin > 0)
+
+
+def test_fixed_sweeps_exact_arithmetic(tmvb, oracle):
+    g = synth_case(tmvb, 50, M=60, V=200, U=40, seed=9)
+    gm, om = make_pair(tmvb, oracle, g)
+    for it in range(2):
+        force(gm, om)
+        gm.estep(viter=3, vtol=0.0); gm.reduce_docs(); gm.mstep()
+        om.estep(viter=3, vtol=0.0); om.mstep()
+        gm.update_host()
+        assert rel(gm.gimel, om.gimel) <= 2e-4 and rel(gm.zayin, om.zayin) <= 2e-4
+        assert rel(gm.alef, om.alef) <= 2e-4 and rel(gm.he, om.he) <= 2e-4
+        assert rel(gm.vav, om.vav) <= 1e-5 and rel(gm.bet, om.bet) <= 1e-5
+
+
+@pytest.mark.parametrize("name", ["ctpf_m40_v60_u15_k4", "ctpf_m30_v40_u12_k6_r1"])
+def test_free_running_train_vs_golden(tmvb, name):
+    g = load(name)
+    K, V, U = int(g["K"]), int(g["V"]), int(g["U"])
+    pc = tmvb.PackedCorpus(g["doc_ptr"], g["terms"], g["counts"], V, g["rdr_ptr"], g["readers"], g["ratings"], U)
+    m = tmvb.CTPF(pc, K)
+    m.alef = np.asfortranarray(g["alef0"]); m.alef_old = m.alef.copy(order="F")
+    tmvb.gpu_train_ctpf(m, iter=int(g["iters"]), printelbo=False)
+    tmvb.check_model_ctpf(m)
+    for n in ("alef", "he", "bet", "vav", "dalet", "het", "gimel", "zayin"):
+        assert rel(getattr(m, n), g[n]) <= 2e-2, n
+
+
+def test_errors(tmvb):
+    pc = tmvb.syn_citeu(M=20, V=50, U=10, seed=1)
+    with pytest.raises(ValueError):
+        tmvb.gpuCTPF(pc, 0)
+    gm = tmvb.gpuCTPF(pc, 4)
+    with pytest.raises(ValueError):
+        gm.train(iter=2, checkelbo=1, printelbo=False)      # ELBO not on the device in this release
+    with pytest.raises(ValueError):
+        gm.train(viter=-1, printelbo=False)
+
+
+def test_citeu_shaped_invariants_k50(tmvb):
+    """SYN-CITEU-shaped: total he mass = e*K*U + total ratings; total alef mass = a*K*V + total counts."""
+    pc = tmvb.syn_citeu(M=2000, V=8000, U=5551, seed=3)
+    gm = tmvb.gpuCTPF(pc, 50)
+    gm.estep(); gm.reduce_docs(); gm.mstep(); gm.update_host()
+    np.testing.assert_allclose(gm.alef.sum(), 0.1 * 50 * pc.V + pc.counts.sum(), rtol=2e-5)
+    np.testing.assert_allclose(gm.he.sum(), 0.1 * 50 * pc.U + pc.ratings.sum(), rtol=2e-5)
+    assert np.all(gm.bet > 0) and np.all(gm.vav > 0) and np.all(np.isfinite(gm.gimel))

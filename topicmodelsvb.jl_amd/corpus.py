@@ -288,8 +288,8 @@ def syn_citeu(M=16980, V=8000, U=5551, seed=20260929) -> PackedCorpus:
     doc_ptr, terms, counts = synthetic_lda_corpus(M, V, seed, Kstar=20, len_mu=4.5, len_sigma=0.5, len_max=600)
     rng = np.random.Generator(np.random.PCG64(seed + 1))
     # readers per document: 1 + heavy-tailed, mean ~ 12; at least 150 documents with one reader
-    R = 1 + np.minimum(np.floor(rng.pareto(1.3, size=M) * 3.6), 400).astype(np.int64)
-    R[rng.choice(M, size=160, replace=False)] = 1
+    R = 1 + np.minimum(np.floor(rng.pareto(1.3, size=M) * 3.6), min(400, U - 1)).astype(np.int64)
+    R[rng.choice(M, size=min(160, max(M // 10, 1)), replace=False)] = 1
     pop = 1.0 / np.arange(1, U + 1, dtype=np.float64)
     rng.shuffle(pop)
     pop /= pop.sum()

@@ -284,7 +284,7 @@ static inline int64_t tmvb_build_lds_buckets(const std::vector<int64_t>& len, co
     if (n_lds == 0) return 0;
     std::vector<int> tiles;
     for (int r = 32; r <= 8192; r += (r < 256 ? 32 : r)) {
-        if (tmvb_tile_bytes(r, KP) > TMVB_MAX_TILE_BYTES) break;
+        if (tmvb_tile_bytes(r, KP) + (size_t)extra_rows * 0 + 2 * (size_t)KP * sizeof(float) > TMVB_MAX_TILE_BYTES) break;
         tiles.push_back(r);
     }
     if (tiles.empty()) tiles.push_back(4);

@@ -1,0 +1,628 @@
+// tmvb_ctpf.hip -- collaborative topic Poisson factorization (CTPF) engine for gfx950 (MI355X).
+//
+// Path: the per-document coordinate ascent of src/CTPF.jl:353-365 (update_xi! :334, update_phi! :327,
+// update_zayin! :318, update_gimel! :309, exit test :359, update_he!(d) :274, update_alef!(d) :259) fused
+// into ONE kernel per document, and the global updates in the reference's order (:366-371: he, alef,
+// dalet, het, bet, vav).  It replaces the twelve OpenCL kernels of src/gpuCTPF.jl:288-661 but follows
+// the CPU path (per-document exit rule; `log vav` in xi, src/CTPF.jl:336, where the OpenCL kernel uses
+// `log bet`, src/gpuCTPF.jl:624).
+//
+// Both softmaxes factor through per-iteration tables (the digammas of alef / he do not change inside
+// an outer iteration):  TA[i,j] = exp(psi(alef[i,j])),  TH[i,u] = exp(psi(he[i,u])).
+//   phi[i,n]      = TA[i,t_n] e_i / s_n,           e_i  = exp(psi(gimel_i) - log dalet_i - log bet_i - max)
+//   xi_top[i,u]   = TH[i,r_u] ea_i / s'_u,         ea_i = exp(psi(gimel_i) - log dalet_i - log vav_i - max')
+//   xi_bot[i,u]   = TH[i,r_u] eb_i / s'_u,         eb_i = exp(psi(zayin_i) - log het_i   - log vav_i - max')
+// with s_n = sum_i TA[i,t_n] e_i and s'_u = sum_i TH[i,r_u] (ea_i + eb_i): the same two matrix-vector
+// products through an LDS tile as the LDA kernel, once over the document's term rows and once over
+// its reader rows; 2 fp32 digammas per topic per sweep instead of K (N_d + 2 R_d).
+// The scatters update_alef!(d) / update_he!(d) are gather-side statistics passes over the term and
+// the reader inverted indices (tmvb_termstats.h); HBM-bound like LDA.
+#include "tmvb_common_kernels.h"
+
+struct CtpfParams {
+    int K, KP, LPR;
+    unsigned lpr_magic;
+    const int64_t* doc_ptr;
+    const int32_t* terms;
+    const int32_t* counts;
+    const int64_t* rdr_ptr;
+    const int32_t* readers;
+    const int32_t* ratings;
+    const int32_t* doc_order;
+    const int32_t* tok_inv;     // term-major position of each CSR token
+    const int32_t* rdr_inv;     // reader-major position of each CSR reader entry
+    const float* TA;            // [V][KP] exp(psi(alef)), pads zero
+    const float* TH;            // [U][KP] exp(psi(he)), pads zero
+    const float* lrates;        // [4][K]: log bet, log vav, log dalet, log het
+    float hc, hg;               // hyper-parameters c, g (src/CTPF.jl:81)
+    float* gimel; float* gimel_old; float* zayin; float* zayin_old;   // [M][K]
+    float* wtok;                // [nnz] term-major   c_n / s_n
+    float* wrdr;                // [nR]  reader-major rating_u / s'_u
+    float* E1;                  // [M][KP] e      (phi factor)
+    float* E2;                  // [M][KP] ea+eb  (xi_top + xi_bot factor)
+    uint8_t* sweeps;
+    int viter;
+    float vtol;
+};
+
+template <int LPR_T>
+__global__ __launch_bounds__(64) void ctpf_estep_kernel(CtpfParams p, int64_t first, int tile_rows)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x;
+    const int K = p.K;
+    const int LPR = LPR_T ? LPR_T : p.LPR;
+    const int KP = 4 * LPR;
+    float* Bt = lds;                           // [tile_rows][KP] term rows then reader rows
+    float* e_l = Bt + (size_t)tile_rows * KP;  // [KP] phi factor e
+    float* f_l = e_l + KP;                     // [KP] xi factor ea + eb
+    float* w_l = f_l + KP;                     // [tile_rows]
+    float* c_l = w_l + tile_rows;              // [tile_rows] counts / ratings as float
+    int* t_l = (int*)(c_l + tile_rows);        // [tile_rows] term / reader ids
+
+    const int d = p.doc_order[first + blockIdx.x];
+    const int64_t off = p.doc_ptr[d], roff = p.rdr_ptr[d];
+    const int N = (int)(p.doc_ptr[d + 1] - off), Rd = (int)(p.rdr_ptr[d + 1] - roff);
+    const bool single = (N + Rd) <= tile_rows;     // both row sets stay resident in the tile
+    const bool on = lane < K;
+
+    const float lb = on ? p.lrates[lane] : 0.f, lv = on ? p.lrates[K + lane] : 0.f;
+    const float ld = on ? p.lrates[2 * K + lane] : 0.f, lh = on ? p.lrates[3 * K + lane] : 0.f;
+    float gim = on ? p.gimel[(int64_t)d * K + lane] : 1.0f, zay = on ? p.zayin[(int64_t)d * K + lane] : 1.0f;
+    float gim_old = gim, zay_old = zay, e = 0.f, ea = 0.f, eb = 0.f;
+
+    // rows [r0, r0+rows) of the tile <- table rows of ids[c0..c0+rows)
+    auto load_rows = [&](const float* table, const int32_t* ids, const int32_t* vals, int64_t base, int c0, int rows, int r0) {
+        for (int n = lane; n < rows; n += 64) {
+            t_l[r0 + n] = ids[base + c0 + n];
+            c_l[r0 + n] = (float)vals[base + c0 + n];
+        }
+        WAVE_LDS_FENCE();
+        const int nch = rows * LPR;
+#pragma unroll 4
+        for (int f0 = 0; f0 < nch; f0 += 64) {
+            const int f = f0 + lane;
+            if (f < nch) {
+                const int n = (LPR == 1) ? f : (int)__umulhi((unsigned)f, p.lpr_magic);
+                const int c = f - n * LPR;
+                const float* src = table + ((int64_t)t_l[r0 + n] * KP + 4 * c);
+                __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(Bt + ((size_t)r0 * KP + (size_t)f0 * 4)), 16, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        WAVE_LDS_FENCE();
+    };
+    // w[r0+n] = val_n / (row_n . fac)
+    auto phase1 = [&](const float* fac, int rows, int r0) {
+        const float4* er = (const float4*)fac;
+        for (int n = lane; n < rows; n += 64) {
+            const float4* br = (const float4*)(Bt + (size_t)(r0 + n) * KP);
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll 4
+            for (int q = 0; q < LPR; ++q) {
+                float4 b = br[q], ev = er[q];
+                s0 = fmaf(b.x, ev.x, s0); s1 = fmaf(b.y, ev.y, s1);
+                s2 = fmaf(b.z, ev.z, s2); s3 = fmaf(b.w, ev.w, s3);
+            }
+            w_l[r0 + n] = c_l[r0 + n] / ((s0 + s1) + (s2 + s3));
+        }
+        WAVE_LDS_FENCE();
+    };
+    const int r4 = lane & 3, ql = lane >> 2;
+    auto phase2 = [&](int rows, int r0, float4& acc) {
+        if (ql >= LPR) return;
+        const int nfull = rows >> 2;
+#pragma unroll 4
+        for (int m = 0; m < nfull; ++m) {
+            const int n = r0 + 4 * m + r4;
+            const float w = w_l[n];
+            const float4 b = *(const float4*)(Bt + (size_t)n * KP + 4 * ql);
+            acc.x = fmaf(w, b.x, acc.x); acc.y = fmaf(w, b.y, acc.y); acc.z = fmaf(w, b.z, acc.z); acc.w = fmaf(w, b.w, acc.w);
+        }
+        const int n = 4 * nfull + r4;
+        if (n < rows) {
+            const float w = w_l[r0 + n];
+            const float4 b = *(const float4*)(Bt + (size_t)(r0 + n) * KP + 4 * ql);
+            acc.x = fmaf(w, b.x, acc.x); acc.y = fmaf(w, b.y, acc.y); acc.z = fmaf(w, b.z, acc.z); acc.w = fmaf(w, b.w, acc.w);
+        }
+    };
+    auto quad_select = [&](float4 a) -> float {
+        a = dpp_add4<0xB1>(a);
+        a = dpp_add4<0x4E>(a);
+        return (r4 == 0) ? a.x : (r4 == 1) ? a.y : (r4 == 2) ? a.z : a.w;
+    };
+    auto store_w = [&](float* dst, const int32_t* inv, int64_t base, int c0, int rows, int r0) {
+        for (int n = lane; n < rows; n += 64) dst[inv[base + c0 + n]] = w_l[r0 + n];
+    };
+
+    int sweeps = 0;
+    for (int v = 0; v < p.viter; ++v) {
+        ++sweeps;
+        const float dg = on ? digamma_f(gim) : 0.f, dz = on ? digamma_f(zay) : 0.f;
+        const float x = dg - ld - lb;                 // update_phi!  src/CTPF.jl:329
+        const float a = dg - ld - lv, b = dz - lh - lv;   // update_xi!  :336
+        const float mx = wave_max(on ? x : -INFINITY);
+        const float mab = wave_max(on ? fmaxf(a, b) : -INFINITY);
+        e = on ? expf(x - mx) : 0.f;
+        ea = on ? expf(a - mab) : 0.f;
+        eb = on ? expf(b - mab) : 0.f;
+        if (lane < KP) { e_l[lane] = e; f_l[lane] = ea + eb; }
+        WAVE_LDS_FENCE();
+        float4 accG = make_float4(0.f, 0.f, 0.f, 0.f), accH = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (single) {
+            if (v == 0) {
+                if (N) load_rows(p.TA, p.terms, p.counts, off, 0, N, 0);
+                if (Rd) load_rows(p.TH, p.readers, p.ratings, roff, 0, Rd, N);
+            }
+            phase1(e_l, N, 0);
+            phase1(f_l, Rd, N);
+            phase2(N, 0, accG);
+            phase2(Rd, N, accH);
+        } else {
+            for (int c0 = 0; c0 < N; c0 += tile_rows) {
+                const int rows = min(tile_rows, N - c0);
+                load_rows(p.TA, p.terms, p.counts, off, c0, rows, 0);
+                phase1(e_l, rows, 0);
+                store_w(p.wtok, p.tok_inv, off, c0, rows, 0);
+                phase2(rows, 0, accG);
+                WAVE_LDS_FENCE();
+            }
+            for (int c0 = 0; c0 < Rd; c0 += tile_rows) {
+                const int rows = min(tile_rows, Rd - c0);
+                load_rows(p.TH, p.readers, p.ratings, roff, c0, rows, 0);
+                phase1(f_l, rows, 0);
+                store_w(p.wrdr, p.rdr_inv, roff, c0, rows, 0);
+                phase2(rows, 0, accH);
+                WAVE_LDS_FENCE();
+            }
+        }
+        const float G = quad_select(accG), Hh = quad_select(accH);
+        zay_old = zay; gim_old = gim;
+        float dl = 0.f;
+        if (on) {
+            zay = p.hg + eb * Hh;                      // update_zayin!  :322
+            gim = (p.hc + e * G) + ea * Hh;            // update_gimel!  :313
+            const float df = gim - gim_old;
+            dl = df * df;
+        }
+        if (sqrtf(wave_sum(dl)) < p.vtol) break;       // :359
+    }
+
+    if (sweeps > 0) {
+        if (on) {
+            p.gimel[(int64_t)d * K + lane] = gim; p.gimel_old[(int64_t)d * K + lane] = gim_old;
+            p.zayin[(int64_t)d * K + lane] = zay; p.zayin_old[(int64_t)d * K + lane] = zay_old;
+        }
+        if (lane < KP) { p.E1[(int64_t)d * KP + lane] = e; p.E2[(int64_t)d * KP + lane] = ea + eb; }
+        if (single) {
+            store_w(p.wtok, p.tok_inv, off, 0, N, 0);
+            store_w(p.wrdr, p.rdr_inv, roff, 0, Rd, N);
+        }
+    } else {
+        for (int n = lane; n < N; n += 64) p.wtok[p.tok_inv[off + n]] = 0.f;
+        for (int n = lane; n < Rd; n += 64) p.wrdr[p.rdr_inv[roff + n]] = 0.f;
+    }
+    if (lane == 0) p.sweeps[d] = (uint8_t)min(sweeps, 255);
+}
+
+// shape update + table refresh:  X[id][i] = prior + stats[id][i];  T[id][i] = exp(psi(X));  stats <- 0
+// (update_alef!/update_he! src/CTPF.jl:251-255, :266-270: X <- X_temp, X_temp <- prior)
+__global__ __launch_bounds__(256) void ctpf_shape_kernel(float* __restrict__ stats, float prior, float* __restrict__ X,
+                                                         float* __restrict__ T, int K, int KP, int64_t n_ids, int refresh_only)
+{
+    const int64_t total = n_ids * KP;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += stride) {
+        const int64_t j = q / KP;
+        const int i = (int)(q - j * KP);
+        float t = 0.0f;
+        if (i < K) {
+            float x;
+            if (refresh_only) x = X[j * K + i];
+            else { x = prior + stats[j * K + i]; X[j * K + i] = x; stats[j * K + i] = 0.0f; }
+            t = expf(digamma_f(x));
+        }
+        T[q] = t;
+    }
+}
+
+// dalet, het, bet, vav in the reference's order (src/CTPF.jl:368-371), fp64, one wave
+template <int NSLOT>
+__global__ __launch_bounds__(64) void ctpf_rates_kernel(int K, double hb, double hd, double hf, double hh,
+                                                        const double* __restrict__ rs_alef, const double* __restrict__ rs_he,
+                                                        const double* __restrict__ sum_gimel, const double* __restrict__ sum_zayin,
+                                                        double* __restrict__ rates /* [8][K]: bet,vav,dalet,het, then *_old */,
+                                                        float* __restrict__ lrates /* [4][K] logs */)
+{
+    for (int i = threadIdx.x; i < K; i += 64) {
+        const double bet = rates[i], vav = rates[K + i], dalet = rates[2 * K + i], het = rates[3 * K + i];
+        const double dalet_n = (hd + rs_alef[i] / bet) + rs_he[i] / vav;          // :297 (old bet, vav)
+        const double het_n = hh + rs_he[i] / vav;                                 // :304
+        const double bet_n = hb + sum_gimel[i] / dalet_n;                         // :283 (new dalet)
+        const double vav_n = (hf + sum_gimel[i] / dalet_n) + sum_zayin[i] / het_n;   // :290
+        rates[4 * K + i] = bet; rates[5 * K + i] = vav; rates[6 * K + i] = dalet; rates[7 * K + i] = het;
+        rates[i] = bet_n; rates[K + i] = vav_n; rates[2 * K + i] = dalet_n; rates[3 * K + i] = het_n;
+        lrates[i] = (float)log(bet_n); lrates[K + i] = (float)log(vav_n);
+        lrates[2 * K + i] = (float)log(dalet_n); lrates[3 * K + i] = (float)log(het_n);
+    }
+}
+
+// ------------------------------------------------------------------------------ host side
+struct tmvb_ctpf {
+    tmvb_ctx* ctx = nullptr;
+    tmvb_corpus* corp = nullptr;
+    int K = 0, KP = 0, nslot = 1;
+    int64_t M = 0, V = 0, U = 0;
+    bool distributed = false;
+    double hyper[8] = {0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1};   // a..h, src/CTPF.jl:81
+    float* d_alef = nullptr; float* d_alef_old = nullptr;          // [V][K] dense
+    float* d_he = nullptr; float* d_he_old = nullptr;              // [U][K] dense
+    float* d_TA = nullptr; float* d_TH = nullptr;                  // padded tables
+    float* d_stats = nullptr; bool own_stats = true;               // alef_stats (K*V) | he_stats (K*U) | sum_gimel (K) | sum_zayin (K)
+    double* d_rates = nullptr; float* d_lrates = nullptr;          // [8][K], [4][K]
+    float* d_gimel = nullptr; float* d_gimel_old = nullptr; float* d_zayin = nullptr; float* d_zayin_old = nullptr;
+    float* d_wtok = nullptr; float* d_wrdr = nullptr; float* d_E1 = nullptr; float* d_E2 = nullptr;
+    float* d_ts_partial = nullptr;
+    uint8_t* d_sweeps = nullptr; int32_t* d_doc_order = nullptr;
+    double* d_partial = nullptr; double* d_rs_alef = nullptr; double* d_rs_he = nullptr; double* d_sum_g = nullptr; double* d_sum_z = nullptr;
+    double elbo = 0.0;
+    std::vector<tmvb_bucket> buckets;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    static constexpr int NAUX = 4;
+    hipStream_t aux[NAUX] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[NAUX] = {nullptr, nullptr, nullptr, nullptr};
+    int64_t stats_len() const { return (int64_t)K * V + (int64_t)K * U + 2 * K; }
+    float* he_stats() const { return d_stats + (size_t)K * V; }
+    float* tail() const { return d_stats + (size_t)K * V + (size_t)K * U; }
+};
+
+static size_t ctpf_tile_bytes(int rows, int KP) { return ((size_t)rows * KP + 2 * (size_t)KP + 3 * (size_t)rows) * sizeof(float); }
+
+extern "C" int tmvb_ctpf_destroy(tmvb_ctpf* h)
+{
+    if (!h) return TMVB_OK;
+    if (h->ctx) (void)hipSetDevice(h->ctx->device);
+    (void)hipFree(h->d_alef); (void)hipFree(h->d_alef_old); (void)hipFree(h->d_he); (void)hipFree(h->d_he_old);
+    (void)hipFree(h->d_TA); (void)hipFree(h->d_TH);
+    if (h->own_stats) (void)hipFree(h->d_stats);
+    (void)hipFree(h->d_rates); (void)hipFree(h->d_lrates); (void)hipFree(h->d_gimel); (void)hipFree(h->d_gimel_old);
+    (void)hipFree(h->d_zayin); (void)hipFree(h->d_zayin_old); (void)hipFree(h->d_wtok); (void)hipFree(h->d_wrdr);
+    (void)hipFree(h->d_E1); (void)hipFree(h->d_E2); (void)hipFree(h->d_ts_partial); (void)hipFree(h->d_sweeps);
+    (void)hipFree(h->d_doc_order); (void)hipFree(h->d_partial); (void)hipFree(h->d_rs_alef); (void)hipFree(h->d_rs_he);
+    (void)hipFree(h->d_sum_g); (void)hipFree(h->d_sum_z);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    for (int a = 0; a < tmvb_ctpf::NAUX; ++a) {
+        if (h->ev_join[a]) (void)hipEventDestroy(h->ev_join[a]);
+        if (h->aux[a]) (void)hipStreamDestroy(h->aux[a]);
+    }
+    delete h;
+    return TMVB_OK;
+}
+
+static int ctpf_refresh_tables(tmvb_ctpf* h)
+{
+    tmvb_ctx* ctx = h->ctx;
+    int nb = (int)std::min<int64_t>(2048, std::max<int64_t>(1, ((int64_t)h->KP * h->V + 255) / 256));
+    hipLaunchKernelGGL(ctpf_shape_kernel, dim3(nb), dim3(256), 0, ctx->stream, (float*)nullptr, 0.0f, h->d_alef, h->d_TA, h->K, h->KP, h->V, 1);
+    TMVB_HIP(hipGetLastError());
+    if (h->U > 0) {
+        nb = (int)std::min<int64_t>(2048, std::max<int64_t>(1, ((int64_t)h->KP * h->U + 255) / 256));
+        hipLaunchKernelGGL(ctpf_shape_kernel, dim3(nb), dim3(256), 0, ctx->stream, (float*)nullptr, 0.0f, h->d_he, h->d_TH, h->K, h->KP, h->U, 1);
+        TMVB_HIP(hipGetLastError());
+    }
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_ctpf_set_state(tmvb_ctpf* h, const double* hyper, const double* alef, const double* he, const double* bet,
+                                   const double* vav, const double* dalet, const double* het, const double* gimel,
+                                   const double* zayin, const double* elbo);
+
+extern "C" int tmvb_ctpf_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb_ctpf** out)
+{
+    TMVB_REQUIRE(out != nullptr, TMVB_EINVAL, "tmvb_ctpf_create: out is NULL");
+    *out = nullptr;
+    TMVB_REQUIRE(ctx && corp, TMVB_EINVAL, "tmvb_ctpf_create: NULL context or corpus");
+    TMVB_REQUIRE(K > 0, TMVB_EINVAL, "number of topics must be a positive integer.");
+    TMVB_REQUIRE(K <= 64, TMVB_EINVAL, "tmvb_ctpf_create: this release supports K <= 64; got K=%d", K);
+    TMVB_HIP(hipSetDevice(ctx->device));
+    tmvb_ctpf* h = new tmvb_ctpf();
+    h->ctx = ctx; h->corp = corp; h->K = K; h->KP = tmvb_kpad(K);
+    h->M = corp->info.M; h->V = corp->info.V; h->U = corp->info.U;
+    const size_t KM = (size_t)K * h->M, KV = (size_t)K * h->V, KU = (size_t)K * h->U;
+    int rc;
+    if ((rc = tmvb_corpus_term_index(corp)) || (rc = tmvb_corpus_reader_index(corp))) { tmvb_ctpf_destroy(h); return rc; }
+    const size_t slots = (size_t)std::max(corp->term_index.n_slots, corp->reader_index.n_slots);
+    if ((rc = dmalloc(&h->d_alef, KV)) || (rc = dmalloc(&h->d_alef_old, KV)) || (rc = dmalloc(&h->d_he, KU)) || (rc = dmalloc(&h->d_he_old, KU)) ||
+        (rc = dmalloc(&h->d_TA, (size_t)h->KP * h->V + 4)) || (rc = dmalloc(&h->d_TH, (size_t)h->KP * h->U + 4)) ||
+        (rc = dmalloc(&h->d_stats, (size_t)h->stats_len())) || (rc = dmalloc(&h->d_rates, 8 * (size_t)K)) || (rc = dmalloc(&h->d_lrates, 4 * (size_t)K)) ||
+        (rc = dmalloc(&h->d_gimel, KM)) || (rc = dmalloc(&h->d_gimel_old, KM)) || (rc = dmalloc(&h->d_zayin, KM)) || (rc = dmalloc(&h->d_zayin_old, KM)) ||
+        (rc = dmalloc(&h->d_wtok, (size_t)corp->info.nnz)) || (rc = dmalloc(&h->d_wrdr, (size_t)corp->info.nR)) ||
+        (rc = dmalloc(&h->d_E1, (size_t)h->KP * h->M + 4)) || (rc = dmalloc(&h->d_E2, (size_t)h->KP * h->M + 4)) ||
+        (rc = dmalloc(&h->d_ts_partial, slots * (K + 1))) || (rc = dmalloc(&h->d_sweeps, (size_t)h->M)) || (rc = dmalloc(&h->d_doc_order, (size_t)h->M)) ||
+        (rc = dmalloc(&h->d_partial, (size_t)TMVB_REDUCE_BLOCKS * K)) || (rc = dmalloc(&h->d_rs_alef, K)) || (rc = dmalloc(&h->d_rs_he, K)) ||
+        (rc = dmalloc(&h->d_sum_g, K)) || (rc = dmalloc(&h->d_sum_z, K))) {
+        tmvb_ctpf_destroy(h);
+        return rc;
+    }
+    // processing order by rows (terms + readers), longest first; LDS buckets on the combined row count
+    std::vector<int64_t> len((size_t)h->M);
+    for (int64_t d = 0; d < h->M; ++d) len[d] = corp->h_doc_len[d] + corp->h_rdr_len[d];
+    std::vector<int32_t> order((size_t)h->M);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return len[x] > len[y]; });
+    tmvb_build_lds_buckets(len, order, h->M, h->KP, -1, 3, h->buckets);
+    if (h->M) TMVB_HIP(hipMemcpyAsync(h->d_doc_order, order.data(), (size_t)h->M * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    TMVB_HIP(hipMemsetAsync(h->d_stats, 0, (size_t)h->stats_len() * sizeof(float), ctx->stream));
+    TMVB_HIP(hipMemsetAsync(h->d_sweeps, 0, std::max<size_t>((size_t)h->M, 1), ctx->stream));
+    TMVB_HIP(hipEventCreate(&h->ev0));
+    TMVB_HIP(hipEventCreate(&h->ev1));
+    TMVB_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    for (int a = 0; a < tmvb_ctpf::NAUX; ++a) {
+        TMVB_HIP(hipStreamCreateWithFlags(&h->aux[a], hipStreamNonBlocking));
+        TMVB_HIP(hipEventCreateWithFlags(&h->ev_join[a], hipEventDisableTiming));
+    }
+    TMVB_HIP(hipStreamSynchronize(ctx->stream));
+    // constructor state src/CTPF.jl:81-100: he = 1, rates = 1, gimel = zayin = 1; alef is drawn with Julia's RNG (:83): 1 here
+    std::vector<double> alef(KV, 1.0), he(KU, 1.0), ones(K, 1.0), gz(KM, 1.0);
+    rc = tmvb_ctpf_set_state(h, nullptr, alef.data(), he.data(), ones.data(), ones.data(), ones.data(), ones.data(), gz.data(), gz.data(), nullptr);
+    if (rc) { tmvb_ctpf_destroy(h); return rc; }
+    *out = h;
+    return TMVB_OK;
+}
+
+static int positive_finite(const double* x, size_t n) { for (size_t q = 0; q < n; ++q) if (!(x[q] > 0.0) || !std::isfinite(x[q])) return 0; return 1; }
+
+extern "C" int tmvb_ctpf_set_state(tmvb_ctpf* h, const double* hyper, const double* alef, const double* he, const double* bet,
+                                   const double* vav, const double* dalet, const double* het, const double* gimel,
+                                   const double* zayin, const double* elbo)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_ctpf_set_state: handle is NULL");
+    tmvb_ctx* ctx = h->ctx;
+    TMVB_HIP(hipSetDevice(ctx->device));
+    const size_t K = h->K, KM = K * (size_t)h->M, KV = K * (size_t)h->V, KU = K * (size_t)h->U;
+    int rc;
+    if (hyper) {
+        const char* nm = "abcdefgh";
+        for (int q = 0; q < 8; ++q) TMVB_REQUIRE(hyper[q] > 0.0, TMVB_ESHAPE, "%c must be positive.", nm[q]);   // src/modelutils.jl:188-195
+        memcpy(h->hyper, hyper, sizeof(h->hyper));
+    }
+    if (alef) {
+        TMVB_REQUIRE(positive_finite(alef, KV), TMVB_ENONFINITE, "alef must be positive.");
+        if ((rc = upload_f32(ctx, h->d_alef, alef, KV)) || (rc = upload_f32(ctx, h->d_alef_old, alef, KV))) return rc;
+    }
+    if (he) {
+        TMVB_REQUIRE(positive_finite(he, KU), TMVB_ENONFINITE, "he must be positive.");
+        if ((rc = upload_f32(ctx, h->d_he, he, KU)) || (rc = upload_f32(ctx, h->d_he_old, he, KU))) return rc;
+    }
+    const double* rv[4] = {bet, vav, dalet, het};
+    const char* rn[4] = {"bet", "vav", "dalet", "het"};
+    for (int r = 0; r < 4; ++r) {
+        if (!rv[r]) continue;
+        TMVB_REQUIRE(positive_finite(rv[r], K), TMVB_ENONFINITE, "%s must be positive.", rn[r]);
+        std::vector<float> lg(K);
+        for (size_t i = 0; i < K; ++i) lg[i] = (float)std::log(rv[r][i]);
+        TMVB_HIP(hipMemcpyAsync(h->d_rates + r * K, rv[r], K * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        TMVB_HIP(hipMemcpyAsync(h->d_rates + (4 + r) * K, rv[r], K * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        TMVB_HIP(hipMemcpyAsync(h->d_lrates + r * K, lg.data(), K * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        TMVB_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    if (gimel) {
+        TMVB_REQUIRE(positive_finite(gimel, KM), TMVB_ENONFINITE, "gimel must be positive.");
+        if ((rc = upload_f32(ctx, h->d_gimel, gimel, KM)) || (rc = upload_f32(ctx, h->d_gimel_old, gimel, KM))) return rc;
+    }
+    if (zayin) {
+        TMVB_REQUIRE(positive_finite(zayin, KM), TMVB_ENONFINITE, "zayin must be positive.");
+        if ((rc = upload_f32(ctx, h->d_zayin, zayin, KM)) || (rc = upload_f32(ctx, h->d_zayin_old, zayin, KM))) return rc;
+    }
+    if (elbo) h->elbo = *elbo;
+    if (alef || he) { if ((rc = ctpf_refresh_tables(h))) return rc; }
+    TMVB_HIP(hipStreamSynchronize(ctx->stream));
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_ctpf_get_state(tmvb_ctpf* h, double* alef, double* alef_old, double* he, double* he_old,
+                                   double* rates /* [8][K]: bet,vav,dalet,het,bet_old,vav_old,dalet_old,het_old */,
+                                   double* gimel, double* gimel_old, double* zayin, double* zayin_old, double* elbo)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_ctpf_get_state: handle is NULL");
+    tmvb_ctx* ctx = h->ctx;
+    TMVB_HIP(hipSetDevice(ctx->device));
+    const size_t K = h->K, KM = K * (size_t)h->M, KV = K * (size_t)h->V, KU = K * (size_t)h->U;
+    int rc;
+    if (alef && (rc = download_f32(ctx, alef, h->d_alef, KV))) return rc;
+    if (alef_old && (rc = download_f32(ctx, alef_old, h->d_alef_old, KV))) return rc;
+    if (he && KU && (rc = download_f32(ctx, he, h->d_he, KU))) return rc;
+    if (he_old && KU && (rc = download_f32(ctx, he_old, h->d_he_old, KU))) return rc;
+    if (rates) {
+        TMVB_HIP(hipMemcpyAsync(rates, h->d_rates, 8 * K * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        TMVB_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    if (gimel && (rc = download_f32(ctx, gimel, h->d_gimel, KM))) return rc;
+    if (gimel_old && (rc = download_f32(ctx, gimel_old, h->d_gimel_old, KM))) return rc;
+    if (zayin && (rc = download_f32(ctx, zayin, h->d_zayin, KM))) return rc;
+    if (zayin_old && (rc = download_f32(ctx, zayin_old, h->d_zayin_old, KM))) return rc;
+    if (elbo) *elbo = h->elbo;
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_ctpf_estep(tmvb_ctpf* h, int32_t viter, double vtol)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_ctpf_estep: handle is NULL");
+    TMVB_REQUIRE(viter >= 0, TMVB_EINVAL, "iteration parameters must be nonnegative.");     // src/gpuCTPF.jl:680
+    TMVB_REQUIRE(vtol >= 0, TMVB_EINVAL, "tolerance parameters must be nonnegative.");      // src/gpuCTPF.jl:679
+    tmvb_ctx* ctx = h->ctx;
+    TMVB_HIP(hipSetDevice(ctx->device));
+    CtpfParams p;
+    p.K = h->K; p.KP = h->KP; p.LPR = h->KP / 4; p.lpr_magic = (unsigned)(0x100000000ull / (unsigned)p.LPR) + 1u;
+    p.doc_ptr = h->corp->d_doc_ptr; p.terms = h->corp->d_terms; p.counts = h->corp->d_counts;
+    p.rdr_ptr = h->corp->d_rdr_ptr; p.readers = h->corp->d_readers; p.ratings = h->corp->d_ratings;
+    p.doc_order = h->d_doc_order; p.tok_inv = h->corp->term_index.d_inv; p.rdr_inv = h->corp->reader_index.d_inv;
+    p.TA = h->d_TA; p.TH = h->d_TH; p.lrates = h->d_lrates; p.hc = (float)h->hyper[2]; p.hg = (float)h->hyper[6];
+    p.gimel = h->d_gimel; p.gimel_old = h->d_gimel_old; p.zayin = h->d_zayin; p.zayin_old = h->d_zayin_old;
+    p.wtok = h->d_wtok; p.wrdr = h->d_wrdr; p.E1 = h->d_E1; p.E2 = h->d_E2; p.sweeps = h->d_sweeps;
+    p.viter = viter; p.vtol = (float)vtol;
+    TMVB_HIP(hipEventRecord(h->ev0, ctx->stream));
+    const int nb = (int)h->buckets.size();
+    const int naux = std::min(nb, (int)tmvb_ctpf::NAUX);
+    if (naux > 1) {
+        TMVB_HIP(hipEventRecord(h->ev_fork, ctx->stream));
+        for (int a = 0; a < naux; ++a) TMVB_HIP(hipStreamWaitEvent(h->aux[a], h->ev_fork, 0));
+    }
+    for (int bi = 0; bi < nb; ++bi) {
+        const tmvb_bucket& b = h->buckets[bi];
+        hipStream_t st = (naux > 1) ? h->aux[bi % naux] : ctx->stream;
+        const size_t lds = ctpf_tile_bytes(b.tile_rows, h->KP);
+        const dim3 grid((unsigned)b.count), block(64);
+        if (p.LPR == 13) hipLaunchKernelGGL((ctpf_estep_kernel<13>), grid, block, lds, st, p, b.first, b.tile_rows);
+        else if (p.LPR == 3) hipLaunchKernelGGL((ctpf_estep_kernel<3>), grid, block, lds, st, p, b.first, b.tile_rows);
+        else hipLaunchKernelGGL((ctpf_estep_kernel<0>), grid, block, lds, st, p, b.first, b.tile_rows);
+        TMVB_HIP(hipGetLastError());
+    }
+    if (naux > 1) {
+        for (int a = 0; a < naux; ++a) {
+            TMVB_HIP(hipEventRecord(h->ev_join[a], h->aux[a]));
+            TMVB_HIP(hipStreamWaitEvent(ctx->stream, h->ev_join[a], 0));
+        }
+    }
+    // update_alef!(model, d) / update_he!(model, d) (src/CTPF.jl:259-262, :274-277) as gather-side statistics
+    TermStatsParams tp;
+    tp.K = h->K; tp.tstride = h->KP; tp.ostride = h->K; tp.eps = 0.0f; tp.base = 0.0f; tp.partial = h->d_ts_partial;
+    tp.w = h->d_wtok; tp.E = h->d_E1; tp.T = h->d_TA; tp.out = h->d_stats;
+    int rc = tmvb_launch_termstats(ctx, 1, h->KP, true, h->corp->term_index, tp);
+    if (rc) return rc;
+    if (h->U > 0) {
+        tp.w = h->d_wrdr; tp.E = h->d_E2; tp.T = h->d_TH; tp.out = h->he_stats();
+        if ((rc = tmvb_launch_termstats(ctx, 1, h->KP, true, h->corp->reader_index, tp))) return rc;
+    }
+    TMVB_HIP(hipEventRecord(h->ev1, ctx->stream));
+    h->timed = true;
+    return TMVB_OK;
+}
+
+// sum_d gimel_d, sum_d zayin_d into the statistics tail (src/CTPF.jl:283, :290)
+extern "C" int tmvb_ctpf_reduce_docs(tmvb_ctpf* h)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_ctpf_reduce_docs: handle is NULL");
+    TMVB_HIP(hipSetDevice(h->ctx->device));
+    int rc;
+    if ((rc = tmvb_colsum(h->ctx, 1, h->K, h->d_gimel, h->M, h->d_partial, h->d_sum_g, h->tail()))) return rc;
+    return tmvb_colsum(h->ctx, 1, h->K, h->d_zayin, h->M, h->d_partial, h->d_sum_z, h->tail() + h->K);
+}
+
+extern "C" int tmvb_ctpf_stats(tmvb_ctpf* h, void** dev_ptr, int64_t* n_f32)
+{
+    TMVB_REQUIRE(h && dev_ptr && n_f32, TMVB_EINVAL, "tmvb_ctpf_stats: NULL argument");
+    *dev_ptr = h->d_stats;
+    *n_f32 = h->stats_len();
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_ctpf_bind_stats(tmvb_ctpf* h, void* dev_ptr, int64_t n_f32)
+{
+    TMVB_REQUIRE(h && dev_ptr, TMVB_EINVAL, "tmvb_ctpf_bind_stats: NULL argument");
+    TMVB_REQUIRE(n_f32 >= h->stats_len(), TMVB_ESHAPE, "tmvb_ctpf_bind_stats: buffer holds %lld floats, need %lld", (long long)n_f32, (long long)h->stats_len());
+    TMVB_HIP(hipSetDevice(h->ctx->device));
+    TMVB_HIP(hipMemcpyAsync(dev_ptr, h->d_stats, (size_t)h->stats_len() * sizeof(float), hipMemcpyDeviceToDevice, h->ctx->stream));
+    TMVB_HIP(hipStreamSynchronize(h->ctx->stream));
+    if (h->own_stats) (void)hipFree(h->d_stats);
+    h->d_stats = (float*)dev_ptr;
+    h->own_stats = false;
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_ctpf_set_distributed(tmvb_ctpf* h, int32_t distributed)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_ctpf_set_distributed: handle is NULL");
+    h->distributed = distributed != 0;
+    return TMVB_OK;
+}
+
+// update_he!, update_alef!, update_dalet!, update_het!, update_bet!, update_vav! in the reference's order
+// (src/CTPF.jl:366-371); the gimel / zayin sums come from the (all-reduced) statistics tail when distributed.
+extern "C" int tmvb_ctpf_mstep(tmvb_ctpf* h)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_ctpf_mstep: handle is NULL");
+    tmvb_ctx* ctx = h->ctx;
+    TMVB_HIP(hipSetDevice(ctx->device));
+    const size_t KV = (size_t)h->K * h->V, KU = (size_t)h->K * h->U;
+    int rc;
+    if (h->distributed) {     // tail -> fp64 sums
+        if ((rc = tmvb_colsum(ctx, 1, h->K, h->tail(), 1, h->d_partial, h->d_sum_g, nullptr))) return rc;
+        if ((rc = tmvb_colsum(ctx, 1, h->K, h->tail() + h->K, 1, h->d_partial, h->d_sum_z, nullptr))) return rc;
+    }
+    // he_old <- he; he <- e + stats; TH refresh    (:266-270)
+    if (h->U > 0) {
+        TMVB_HIP(hipMemcpyAsync(h->d_he_old, h->d_he, KU * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+        int nb = (int)std::min<int64_t>(2048, std::max<int64_t>(1, ((int64_t)h->KP * h->U + 255) / 256));
+        hipLaunchKernelGGL(ctpf_shape_kernel, dim3(nb), dim3(256), 0, ctx->stream, h->he_stats(), (float)h->hyper[4], h->d_he, h->d_TH, h->K, h->KP, h->U, 0);
+        TMVB_HIP(hipGetLastError());
+    }
+    // alef_old <- alef; alef <- a + stats; TA refresh   (:251-255)
+    TMVB_HIP(hipMemcpyAsync(h->d_alef_old, h->d_alef, KV * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    {
+        int nb = (int)std::min<int64_t>(2048, std::max<int64_t>(1, ((int64_t)h->KP * h->V + 255) / 256));
+        hipLaunchKernelGGL(ctpf_shape_kernel, dim3(nb), dim3(256), 0, ctx->stream, h->d_stats, (float)h->hyper[0], h->d_alef, h->d_TA, h->K, h->KP, h->V, 0);
+        TMVB_HIP(hipGetLastError());
+    }
+    if ((rc = tmvb_colsum(ctx, 1, h->K, h->d_alef, h->V, h->d_partial, h->d_rs_alef, nullptr))) return rc;
+    if (h->U > 0) {
+        if ((rc = tmvb_colsum(ctx, 1, h->K, h->d_he, h->U, h->d_partial, h->d_rs_he, nullptr))) return rc;
+    } else {
+        TMVB_HIP(hipMemsetAsync(h->d_rs_he, 0, (size_t)h->K * sizeof(double), ctx->stream));
+    }
+    hipLaunchKernelGGL((ctpf_rates_kernel<1>), dim3(1), dim3(64), 0, ctx->stream, h->K, h->hyper[1], h->hyper[3], h->hyper[5], h->hyper[7],
+                       h->d_rs_alef, h->d_rs_he, h->d_sum_g, h->d_sum_z, h->d_rates, h->d_lrates);
+    TMVB_HIP(hipGetLastError());
+    return TMVB_OK;
+}
+
+// train! (src/gpuCTPF.jl:677-705 signature, src/CTPF.jl:344-376 semantics).  The CTPF ELBO
+// (src/CTPF.jl:111-247) is not evaluated on the device in this release: checkelbo must be Inf (<= 0),
+// the setting the reference's own README uses for CTPF timing.
+extern "C" int tmvb_ctpf_train(tmvb_ctpf* h, int32_t iter, double tol, int32_t viter, double vtol, int32_t checkelbo,
+                               double* elbo_traj, int32_t* iters_done)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_ctpf_train: handle is NULL");
+    TMVB_REQUIRE(tol >= 0 && vtol >= 0, TMVB_EINVAL, "tolerance parameters must be nonnegative.");
+    TMVB_REQUIRE(iter >= 0 && viter >= 0, TMVB_EINVAL, "iteration parameters must be nonnegative.");
+    TMVB_REQUIRE(checkelbo <= 0, TMVB_EINVAL, "tmvb_ctpf_train: the CTPF ELBO is not evaluated on the device in this release; pass checkelbo = Inf");
+    TMVB_REQUIRE(!h->distributed, TMVB_EINVAL, "tmvb_ctpf_train drives one context");
+    if (iters_done) *iters_done = 0;
+    if (h->corp->info.nnz == 0) iter = 0;                                   // src/gpuCTPF.jl:682
+    int rc, done = 0;
+    for (int k = 1; k <= iter; ++k) {
+        ++done;
+        if ((rc = tmvb_ctpf_estep(h, viter, vtol))) return rc;
+        if ((rc = tmvb_ctpf_reduce_docs(h))) return rc;
+        if ((rc = tmvb_ctpf_mstep(h))) return rc;
+        if (elbo_traj) elbo_traj[k - 1] = NAN;
+    }
+    TMVB_HIP(hipStreamSynchronize(h->ctx->stream));
+    if (iters_done) *iters_done = done;
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_ctpf_sweep_hist(tmvb_ctpf* h, int64_t* hist, int32_t nbins)
+{
+    TMVB_REQUIRE(h && hist && nbins > 0, TMVB_EINVAL, "tmvb_ctpf_sweep_hist: bad argument");
+    std::vector<uint8_t> sw((size_t)h->M);
+    TMVB_HIP(hipSetDevice(h->ctx->device));
+    if (h->M) TMVB_HIP(hipMemcpyAsync(sw.data(), h->d_sweeps, (size_t)h->M, hipMemcpyDeviceToHost, h->ctx->stream));
+    TMVB_HIP(hipStreamSynchronize(h->ctx->stream));
+    for (int b = 0; b < nbins; ++b) hist[b] = 0;
+    for (uint8_t s : sw) hist[std::min<int>(s, nbins - 1)]++;
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_ctpf_last_estep_ms(tmvb_ctpf* h, float* ms)
+{
+    TMVB_REQUIRE(h && ms, TMVB_EINVAL, "tmvb_ctpf_last_estep_ms: NULL argument");
+    TMVB_REQUIRE(h->timed, TMVB_EINVAL, "tmvb_ctpf_last_estep_ms: no E-step has run");
+    TMVB_HIP(hipSetDevice(h->ctx->device));
+    TMVB_HIP(hipEventSynchronize(h->ev1));
+    TMVB_HIP(hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return TMVB_OK;
+}
