@@ -126,10 +126,16 @@ def main():
 
     if not torch.cuda.is_available() or tm.lib().tmvb_device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: the HIP engine has no CPU fallback")
+    backend = os.environ.get("TMVB_DIST_BACKEND", "nccl")          # "gloo" only to smoke-test the N>1 plumbing on one GPU
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     K, V = args.K, args.vocab
     t0 = time.perf_counter()

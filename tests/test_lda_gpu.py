@@ -208,3 +208,28 @@ def test_nsf_scale_invariants(tmvb):
     gm.estep(); gm.reduce_docs(); gm.update_beta(); gm.update_alpha()
     e2 = gm.update_elbo()
     assert np.isfinite(e1) and np.isfinite(e2) and e2 > e1
+
+
+def test_full_size_nsf_properties(tmvb):
+    """BASELINE.json's full size (SYN-NSF M=128804, V=25319, K=50) through size-independent properties:
+    per-document mass conservation, stochastic beta, statistics mass = token count, increasing ELBO,
+    run-to-run bitwise reproducibility of the (atomics-free) statistics."""
+    pc = tmvb.syn_nsf()
+    K = 50
+    gm = tmvb.gpuLDA(pc, K)
+    alpha0 = gm.alpha.copy()
+    gm.estep(); gm.reduce_docs(); gm.update_host()
+    np.testing.assert_allclose((gm.gamma - alpha0[:, None]).sum(axis=0), pc.C, rtol=3e-5)
+    assert np.all(gm.gamma > 0) and np.all(gm.Elogtheta <= 0)
+    gm.update_beta(); gm.update_alpha(); gm.update_host()
+    np.testing.assert_allclose(gm.beta.sum(axis=1), 1.0, rtol=1e-5)
+    beta1 = gm.beta.copy()
+    e1 = gm.update_elbo()
+    # same state again in a second model: identical bits (deterministic reductions, no atomics)
+    gm2 = tmvb.gpuLDA(pc, K)
+    gm2.estep(); gm2.reduce_docs(); gm2.update_beta(); gm2.update_alpha(); gm2.update_host()
+    assert np.array_equal(gm2.beta, beta1) and np.array_equal(gm2.alpha, gm.alpha)
+    gm.estep(); gm.reduce_docs(); gm.update_beta(); gm.update_alpha()
+    e2 = gm.update_elbo()
+    assert np.isfinite(e1) and e2 > e1
+    assert gm.sweep_hist().sum() == pc.M
