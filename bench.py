@@ -186,11 +186,11 @@ def main():
         b_e = estep_bytes(shard.nnz, shard.M, K)
         achieved = b_e / (ms * 1e-3) / 1e9
         result = {
-            "metric": "VB iters/sec, LDA K=50 on NSF-shaped corpus (M=128804, V=25319)",
+            "metric": f"VB iters/sec, LDA K={K} on NSF-shaped corpus (M={corpus.M}, V={V})",
             "value": args.steps / elapsed, "unit": "VB iters/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "LDA K=50, SYN-NSF (synthetic NSF-shaped corpus, seed 20260928), train! defaults "
+            "config": {"workload": f"LDA K={K}, SYN-NSF (synthetic NSF-shaped corpus, seed 20260928), train! defaults "
                                    "viter=10 vtol=1/K^2 niter=1000 ntol=1/K^2 checkelbo=Inf, cold start",
                        "K": K, "M": corpus.M, "V": V, "nnz": corpus.nnz, "sum_counts": int(corpus.counts.sum()),
                        "parallelism": f"doc-shard x{world}, 1 all-reduce of {K * V + K} f32 per iteration" if world > 1 else "single GPU",

@@ -11,7 +11,7 @@ __global__ void k(float* out, const int* tol)
 }
 template <int R> void run()
 {
-    std::vector<int> tol, lot; lda_reg_lane_maps(R, tol, lot);
+    std::vector<int> tol, lot; tmvb_reg_lane_maps(R, tol, lot);
     float* d; hipMalloc(&d, 64 * 4); int* dt; hipMalloc(&dt, 64 * 4);
     k<R><<<1, 64>>>(d, dt);
     float h[64]; hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);

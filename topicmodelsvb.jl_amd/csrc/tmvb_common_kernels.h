@@ -27,7 +27,8 @@ __device__ __forceinline__ float4 dpp_add4(float4 v)
 
 // NOTE: hipcc 7.2 mis-selects __builtin_amdgcn_permlane{32,16}_swap when both results feed one add
 // (it emits `v_add v, r0, r0`), so the swap is issued through inline asm.  hipcc inserts no hazard
-// wait states inside asm: the leading s_nop covers a preceding VALU write of the operands.
+// wait states inside asm, and the swap DOES need them around VALU producers/consumers of its operands:
+// without the s_nop pair the T=1 register kernel summed garbage into topic 0 (found on hardware).
 __device__ __forceinline__ void swap_add32(float& a, float b)
 {
     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
@@ -243,17 +244,24 @@ static inline int tmvb_colsum(tmvb_ctx* ctx, int nslot, int K, const float* X, i
 }
 
 // gather-side statistics pass over an inverted index (tmvb_termstats.h)
+// true when the statistics pass recomputes the per-token weights (no wtok stores needed in the document kernels)
+static inline bool tmvb_termstats_recomputes(int KP, bool e_padded) { return e_padded && KP / 4 <= 16; }
+
 static inline int tmvb_launch_termstats(tmvb_ctx* ctx, int nslot, int KP, bool e_padded, const tmvb_inv_index& ix,
                                         TermStatsParams tp)
 {
     if (ix.n_chunks <= 0) return TMVB_OK;
     tp.tok_doc = ix.d_doc; tp.tok_pos = ix.d_pos; tp.chunk_id = ix.d_chunk_id; tp.chunk_begin = ix.d_chunk_begin;
     tp.chunk_end = ix.d_chunk_end; tp.chunk_out = ix.d_chunk_out; tp.n_chunks = (int)ix.n_chunks;
+    tp.tok_val = ix.d_val;
     int rc = dispatch_nslot(nslot, [&](auto ns) -> int {
         constexpr int NS = decltype(ns)::value;
         const dim3 grid((unsigned)((ix.n_chunks + 3) / 4)), block(256);
         const int lpr = KP / 4;
-        if (e_padded) {
+        if (e_padded && lpr <= 16) {       // recompute w from (T row, E row, count): no per-token weights in memory
+            if (lpr == 13) hipLaunchKernelGGL((termstats_recompute_kernel<13>), grid, block, 0, ctx->stream, tp, lpr);
+            else hipLaunchKernelGGL((termstats_recompute_kernel<0>), grid, block, 0, ctx->stream, tp, lpr);
+        } else if (e_padded) {
             if (lpr == 13) hipLaunchKernelGGL((termstats_chunk4_kernel<13>), grid, block, 0, ctx->stream, tp, lpr);
             else if (lpr == 25) hipLaunchKernelGGL((termstats_chunk4_kernel<25>), grid, block, 0, ctx->stream, tp, lpr);
             else hipLaunchKernelGGL((termstats_chunk4_kernel<0>), grid, block, 0, ctx->stream, tp, lpr);

@@ -202,9 +202,11 @@ extern "C" int tmvb_corpus_create(tmvb_ctx* ctx, int64_t M, int64_t V, int64_t U
     TMVB_HIP(hipStreamSynchronize(ctx->stream));
     c->h_doc_ptr.assign(doc_ptr, doc_ptr + M + 1);
     c->h_terms.assign(terms, terms + nnz);
+    c->h_counts.assign(counts, counts + nnz);
     if (has_r) {
         c->h_rdr_ptr.assign(rdr_ptr, rdr_ptr + M + 1);
         c->h_readers.assign(readers, readers + nR);
+        c->h_ratings.assign(ratings, ratings + nR);
     } else {
         c->h_rdr_ptr.assign(M + 1, 0);
     }
@@ -213,7 +215,7 @@ extern "C" int tmvb_corpus_create(tmvb_ctx* ctx, int64_t M, int64_t V, int64_t U
 }
 
 int tmvb_build_inv_index(tmvb_ctx* ctx, int64_t M, int64_t n_ids, const int64_t* h_ptr, const int32_t* h_ids,
-                         tmvb_inv_index* ix)
+                         const int32_t* h_vals, tmvb_inv_index* ix)
 {
     const int64_t nnz = h_ptr[M];
     TMVB_REQUIRE(nnz < (int64_t)INT32_MAX, TMVB_EINVAL, "inverted index: token count must fit int32");
@@ -222,12 +224,13 @@ int tmvb_build_inv_index(tmvb_ctx* ctx, int64_t M, int64_t n_ids, const int64_t*
     for (int64_t q = 0; q < nnz; ++q) cnt[h_ids[q] + 1]++;
     for (int64_t j = 0; j < n_ids; ++j) cnt[j + 1] += cnt[j];
     std::vector<int32_t> doc(nnz), pos(nnz), inv(nnz);
+    std::vector<float> val(nnz);
     {
         std::vector<int64_t> cur(cnt.begin(), cnt.end() - 1);
         for (int64_t d = 0; d < M; ++d)
             for (int64_t q = h_ptr[d]; q < h_ptr[d + 1]; ++q) {
                 int64_t w = cur[h_ids[q]]++;
-                doc[w] = (int32_t)d; pos[w] = (int32_t)q; inv[q] = (int32_t)w;
+                doc[w] = (int32_t)d; pos[w] = (int32_t)q; inv[q] = (int32_t)w; val[w] = (float)h_vals[q];
             }
     }
     std::vector<int32_t> cid, cb, ce, co, mid, mfirst, mcount;
@@ -247,7 +250,7 @@ int tmvb_build_inv_index(tmvb_ctx* ctx, int64_t M, int64_t n_ids, const int64_t*
     ix->n_chunks = (int64_t)cid.size(); ix->n_multi = (int64_t)mid.size(); ix->n_slots = slots;
     int rc;
     if ((rc = upload(ctx, &ix->d_doc, doc.data(), doc.size())) || (rc = upload(ctx, &ix->d_pos, pos.data(), pos.size())) ||
-        (rc = upload(ctx, &ix->d_inv, inv.data(), inv.size())) ||
+        (rc = upload(ctx, &ix->d_inv, inv.data(), inv.size())) || (rc = upload(ctx, &ix->d_val, val.data(), val.size())) ||
         (rc = upload(ctx, &ix->d_chunk_id, cid.data(), cid.size())) || (rc = upload(ctx, &ix->d_chunk_begin, cb.data(), cb.size())) ||
         (rc = upload(ctx, &ix->d_chunk_end, ce.data(), ce.size())) || (rc = upload(ctx, &ix->d_chunk_out, co.data(), co.size())) ||
         (rc = upload(ctx, &ix->d_multi_id, mid.data(), mid.size())) || (rc = upload(ctx, &ix->d_multi_first, mfirst.data(), mfirst.size())) ||
@@ -260,7 +263,7 @@ int tmvb_build_inv_index(tmvb_ctx* ctx, int64_t M, int64_t n_ids, const int64_t*
 
 void tmvb_free_inv_index(tmvb_inv_index* ix)
 {
-    (void)hipFree(ix->d_doc); (void)hipFree(ix->d_pos); (void)hipFree(ix->d_inv); (void)hipFree(ix->d_chunk_id); (void)hipFree(ix->d_chunk_begin);
+    (void)hipFree(ix->d_doc); (void)hipFree(ix->d_pos); (void)hipFree(ix->d_inv); (void)hipFree(ix->d_val); (void)hipFree(ix->d_chunk_id); (void)hipFree(ix->d_chunk_begin);
     (void)hipFree(ix->d_chunk_end); (void)hipFree(ix->d_chunk_out); (void)hipFree(ix->d_multi_id);
     (void)hipFree(ix->d_multi_first); (void)hipFree(ix->d_multi_count);
     *ix = tmvb_inv_index();
@@ -270,14 +273,14 @@ int tmvb_corpus_term_index(tmvb_corpus* c)
 {
     if (c->term_index.built) return TMVB_OK;
     (void)hipSetDevice(c->ctx->device);
-    return tmvb_build_inv_index(c->ctx, c->info.M, c->info.V, c->h_doc_ptr.data(), c->h_terms.data(), &c->term_index);
+    return tmvb_build_inv_index(c->ctx, c->info.M, c->info.V, c->h_doc_ptr.data(), c->h_terms.data(), c->h_counts.data(), &c->term_index);
 }
 
 int tmvb_corpus_reader_index(tmvb_corpus* c)
 {
     if (c->reader_index.built) return TMVB_OK;
     (void)hipSetDevice(c->ctx->device);
-    return tmvb_build_inv_index(c->ctx, c->info.M, c->info.U, c->h_rdr_ptr.data(), c->h_readers.data(), &c->reader_index);
+    return tmvb_build_inv_index(c->ctx, c->info.M, c->info.U, c->h_rdr_ptr.data(), c->h_readers.data(), c->h_ratings.data(), &c->reader_index);
 }
 
 extern "C" int tmvb_corpus_destroy(tmvb_corpus* c)

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(64) void ctm_estep_kernel(CtmParams p, int64_t firs
         WAVE_LDS_FENCE();
     };
     auto store_w = [&](int c0, int rows) {
-        for (int n = lane; n < rows; n += 64) p.wtok[p.tok_inv[off + c0 + n]] = w_l[n];
+        (void)c0; (void)rows;     // K <= 64: the statistics pass recomputes w_n = c_n / s_n from (beta row, E row, count)
     };
     const int r4 = lane & 3, ql = lane >> 2;
     auto phase2 = [&](int rows, float4& acc) {
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(64) void ctm_estep_kernel(CtmParams p, int64_t firs
         if (lane < KP) p.E[(int64_t)d * KP + lane] = e;       // e = exp(lambda_old - max): last-sweep phi factor
         if (single) store_w(0, N);
     } else {
-        for (int n = lane; n < N; n += 64) p.wtok[p.tok_inv[off + n]] = 0.0f;
+        if (lane < KP) p.E[(int64_t)d * KP + lane] = 0.0f;    // viter = 0: no responsibilities
     }
     if (lane == 0) {
         p.sweeps[d] = (uint8_t)min(sweeps, 255);
@@ -749,7 +749,7 @@ extern "C" int tmvb_ctm_estep(tmvb_ctm* h, int32_t niter, double ntol, int32_t v
     // update_beta!(model, d)  src/CTM.jl:122-125 as the gather-side statistics pass (no epsilon in CTM's phi)
     TermStatsParams tp;
     tp.K = h->K; tp.tstride = h->KP; tp.ostride = h->K;
-    tp.w = h->d_wtok; tp.E = h->d_E; tp.T = h->d_beta[h->cur]; tp.eps = 0.0f; tp.base = 0.0f;
+    tp.w = h->d_wtok; tp.E = h->d_E; tp.T = h->d_beta[h->cur]; tp.eps = 0.0f; tp.base = 0.0f; tp.keps = 0.0f;
     tp.out = h->d_stats; tp.partial = h->d_ts_partial;
     int rc = tmvb_launch_termstats(ctx, 1, h->KP, true, h->corp->term_index, tp);
     if (rc) return rc;

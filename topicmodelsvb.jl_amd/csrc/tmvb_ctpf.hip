@@ -132,7 +132,7 @@ __global__ __launch_bounds__(64) void ctpf_estep_kernel(CtpfParams p, int64_t fi
         return (r4 == 0) ? a.x : (r4 == 1) ? a.y : (r4 == 2) ? a.z : a.w;
     };
     auto store_w = [&](float* dst, const int32_t* inv, int64_t base, int c0, int rows, int r0) {
-        for (int n = lane; n < rows; n += 64) dst[inv[base + c0 + n]] = w_l[r0 + n];
+        (void)dst; (void)inv; (void)base; (void)c0; (void)rows; (void)r0;   // K <= 64: weights are recomputed by the statistics pass
     };
 
     int sweeps = 0;
@@ -199,8 +199,7 @@ __global__ __launch_bounds__(64) void ctpf_estep_kernel(CtpfParams p, int64_t fi
             store_w(p.wrdr, p.rdr_inv, roff, 0, Rd, N);
         }
     } else {
-        for (int n = lane; n < N; n += 64) p.wtok[p.tok_inv[off + n]] = 0.f;
-        for (int n = lane; n < Rd; n += 64) p.wrdr[p.rdr_inv[roff + n]] = 0.f;
+        if (lane < KP) { p.E1[(int64_t)d * KP + lane] = 0.f; p.E2[(int64_t)d * KP + lane] = 0.f; }   // viter = 0
     }
     if (lane == 0) p.sweeps[d] = (uint8_t)min(sweeps, 255);
 }
@@ -489,7 +488,7 @@ extern "C" int tmvb_ctpf_estep(tmvb_ctpf* h, int32_t viter, double vtol)
     }
     // update_alef!(model, d) / update_he!(model, d) (src/CTPF.jl:259-262, :274-277) as gather-side statistics
     TermStatsParams tp;
-    tp.K = h->K; tp.tstride = h->KP; tp.ostride = h->K; tp.eps = 0.0f; tp.base = 0.0f; tp.partial = h->d_ts_partial;
+    tp.K = h->K; tp.tstride = h->KP; tp.ostride = h->K; tp.eps = 0.0f; tp.base = 0.0f; tp.keps = 0.0f; tp.partial = h->d_ts_partial;
     tp.w = h->d_wtok; tp.E = h->d_E1; tp.T = h->d_TA; tp.out = h->d_stats;
     int rc = tmvb_launch_termstats(ctx, 1, h->KP, true, h->corp->term_index, tp);
     if (rc) return rc;

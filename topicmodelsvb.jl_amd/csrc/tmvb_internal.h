@@ -60,6 +60,7 @@ struct tmvb_inv_index {
     int32_t* d_doc = nullptr;          // [nnz] document of each token, id-major order
     int32_t* d_pos = nullptr;          // [nnz] CSR position of each token, id-major order
     int32_t* d_inv = nullptr;          // [nnz] id-major position of each CSR token (inverse of d_pos)
+    float* d_val = nullptr;            // [nnz] count / rating of each token, id-major order
     int64_t n_chunks = 0;
     int32_t* d_chunk_id = nullptr;     // [n_chunks] id (term / reader) the chunk belongs to
     int32_t* d_chunk_begin = nullptr;  // [n_chunks] token range in id-major order
@@ -72,7 +73,7 @@ struct tmvb_inv_index {
     int64_t n_slots = 0;
 };
 int tmvb_build_inv_index(tmvb_ctx* ctx, int64_t M, int64_t n_ids, const int64_t* h_ptr, const int32_t* h_ids,
-                         tmvb_inv_index* out);
+                         const int32_t* h_vals, tmvb_inv_index* out);
 void tmvb_free_inv_index(tmvb_inv_index* ix);
 
 struct tmvb_corpus {
@@ -92,7 +93,7 @@ struct tmvb_corpus {
     std::vector<int64_t> h_rdr_len;     // R_d
     // host copies kept for building the inverted indices lazily
     std::vector<int64_t> h_doc_ptr, h_rdr_ptr;
-    std::vector<int32_t> h_terms, h_readers;
+    std::vector<int32_t> h_terms, h_readers, h_counts, h_ratings;
     tmvb_inv_index term_index, reader_index;
 };
 int tmvb_corpus_term_index(tmvb_corpus* c);

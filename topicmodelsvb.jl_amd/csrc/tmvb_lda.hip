@@ -54,6 +54,7 @@ struct LdaParams {
     int viter;
     float vtol;
     int debug;               // TMVB_DEBUG_FLAGS (profiling experiments only): 1 = skip the statistics pass
+    int store_w;             // 0 when the statistics pass recomputes w (K <= 64): no per-token stores at all
 };
 
 
@@ -145,6 +146,7 @@ __global__ __launch_bounds__(64) void lda_estep_kernel(LdaParams p, int64_t firs
     };
     // documents that stream chunks keep the latest w in HBM every sweep (the last one survives)
     auto store_w = [&](int c0, int rows) {
+        if (!p.store_w) return;
         for (int n = lane; n < rows; n += 64) p.wtok[p.tok_inv[off + c0 + n]] = w_l[n];
     };
 
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(64) void lda_estep_kernel(LdaParams p, int64_t firs
         }
         if (single) store_w(0, N);
     } else {
-        for (int n = lane; n < N; n += 64) p.wtok[p.tok_inv[off + n]] = 0.0f;   // viter = 0: no responsibilities
+        if (p.store_w) for (int n = lane; n < N; n += 64) p.wtok[p.tok_inv[off + n]] = 0.0f;   // viter = 0: no responsibilities
     }
     if (lane == 0) p.sweeps[d] = (uint8_t)min(sweeps, 255);
 }
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(64) void lda_estep_reg_kernel(LdaParams p, int64_t 
         if (n < N) {
             const int term = p.terms[off + n];
             c[t] = (float)p.counts[off + n];
-            wpos[t] = p.tok_inv[off + n];
+            wpos[t] = p.store_w ? p.tok_inv[off + n] : 0;
             const float4* row = (const float4*)(p.beta + (int64_t)term * R);
 #pragma unroll
             for (int q = 0; q < LPR; ++q) {
@@ -365,10 +367,12 @@ __global__ __launch_bounds__(64) void lda_estep_reg_kernel(LdaParams p, int64_t 
         }
         if (mytopic >= 0 && mytopic < p.estride) p.E[(int64_t)d * p.estride + mytopic] = e;
 #pragma unroll
-        for (int t = 0; t < T; ++t) if (wpos[t] >= 0) p.wtok[wpos[t]] = w[t];
+        for (int t = 0; t < T; ++t) if (wpos[t] >= 0 && p.store_w) p.wtok[wpos[t]] = w[t];
     } else {
+        // viter = 0: no responsibilities; E = 0 makes the statistics pass produce eps-only columns
+        if (mytopic >= 0 && mytopic < p.estride) p.E[(int64_t)d * p.estride + mytopic] = 0.0f;
 #pragma unroll
-        for (int t = 0; t < T; ++t) if (wpos[t] >= 0) p.wtok[wpos[t]] = 0.0f;
+        for (int t = 0; t < T; ++t) if (wpos[t] >= 0 && p.store_w) p.wtok[wpos[t]] = 0.0f;
     }
     if (lane == 0) p.sweeps[d] = (uint8_t)min(sweeps, 255);
 }
@@ -767,6 +771,7 @@ extern "C" int tmvb_lda_estep(tmvb_lda* h, int32_t viter, double vtol)
     p.gamma = h->d_gamma; p.elog = h->d_elog; p.elog_old = h->d_elog_old; p.sweeps = h->d_sweeps;
     p.viter = viter; p.vtol = (float)vtol;
     { const char* dbg = getenv("TMVB_DEBUG_FLAGS"); p.debug = dbg ? atoi(dbg) : 0; }
+    p.store_w = tmvb_termstats_recomputes(h->KP, h->estride == h->KP) ? 0 : 1;
     TMVB_HIP(hipEventRecord(h->ev0, ctx->stream));
     const int nb = (int)h->buckets.size();
     const int naux = std::min(nb, (int)tmvb_lda::NAUX);
@@ -827,7 +832,7 @@ extern "C" int tmvb_lda_estep(tmvb_lda* h, int32_t viter, double vtol)
     if (!(p.debug & 1) && ix.n_chunks > 0) {
         TermStatsParams tp;
         tp.K = h->K; tp.tstride = h->KP; tp.ostride = h->K;
-        tp.w = h->d_wtok; tp.E = h->d_E; tp.T = h->d_beta[h->cur]; tp.eps = TMVB_EPS_F; tp.base = 0.0f;
+        tp.w = h->d_wtok; tp.E = h->d_E; tp.T = h->d_beta[h->cur]; tp.eps = TMVB_EPS_F; tp.base = 0.0f; tp.keps = (float)h->K * TMVB_EPS_F;
         tp.out = h->d_stats; tp.partial = h->d_ts_partial;
         int rc = tmvb_launch_termstats(ctx, h->nslot, h->KP, h->estride == h->KP, ix, tp);
         if (rc) return rc;

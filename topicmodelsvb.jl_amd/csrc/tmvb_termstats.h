@@ -23,7 +23,9 @@ struct TermStatsParams {
     const int32_t* chunk_end;
     const int32_t* chunk_out;
     int n_chunks;
-    const float* w;              // [nnz] per-token weight, id-major (inverted index) order
+    const float* w;              // [nnz] per-token weight, id-major (inverted index) order (legacy kernels)
+    const float* tok_val;        // [nnz] count / rating per token, id-major order (recompute kernel)
+    float keps;                  // K * eps added to the recomputed normaliser (LDA), 0 otherwise
     const float* E;              // per-document factor: [M][K] (scalar kernel) or [M][KP] zero padded (chunk4 kernel)
     const float* T;              // [n_ids][tstride] per-id factor
     float eps;                   // additive epsilon (LDA: EPSILON, others 0)
@@ -147,6 +149,89 @@ __global__ __launch_bounds__(256) void termstats_chunk4_kernel(TermStatsParams p
         for (int u = 0; u < 4; ++u) {
             const int i = 4 * lane + u;
             if (i < K) p.out[(int64_t)j * p.ostride + i] = p.base + fmaf(p.T[(int64_t)j * p.tstride + i], tv[u], p.eps * wsum);
+        }
+    } else {
+        float* pr = p.partial + (int64_t)slot * (K + 1);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = 4 * lane + u;
+            if (i < K) pr[i] = tv[u];
+        }
+        if (lane == 0) pr[K] = wsum;
+    }
+}
+
+// Recompute variant for K <= 64 (LPR <= 16): the per-token weight w_n = val_n / s_n is NOT read from
+// memory -- a per-token value written in document order and read in id order has one scattered side,
+// and the scattered 4-byte stores cost 0.24 ms of the 0.9 ms document pass at NSF scale -- but
+// recomputed here: s_n = keps + sum_i T[i,j] E[i,doc_n] needs only the id's T row (fixed per chunk, in
+// registers) and the document's E row, which this kernel fetches anyway.  16 lanes per row slot
+// (LPR active), 4 row slots per wave instruction; the 16-lane dot product is a 4-step DPP row reduction.
+template <int LPR_T>
+__global__ __launch_bounds__(256) void termstats_recompute_kernel(TermStatsParams p, int LPR_rt)
+{
+    __shared__ int2 dw_l[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int c = blockIdx.x * 4 + wv;
+    const int LPR = LPR_T ? LPR_T : LPR_rt;
+    const int KP = 4 * LPR;
+    const int rs = lane >> 4, cc = lane & 15;
+    const bool lane_on = cc < LPR;
+    const bool active = c < p.n_chunks;
+    const int j = active ? p.chunk_id[c] : 0;
+    const int b = active ? p.chunk_begin[c] : 0, e = active ? p.chunk_end[c] : 0;
+    float4 tj = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (active && lane_on) tj = *(const float4*)(p.T + (int64_t)j * p.tstride + 4 * cc);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float wl = 0.0f;
+    for (int t0 = b; t0 < e; t0 += 64) {
+        const int tok = t0 + lane;
+        const bool valid = tok < e;
+        dw_l[wv][lane] = make_int2(valid ? p.tok_doc[tok] : 0, __builtin_bit_cast(int, valid ? p.tok_val[tok] : 0.0f));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int cnt = min(64, e - t0);
+#pragma unroll 4
+        for (int k = 0; k < cnt; k += 4) {
+            const int kk = k + rs;
+            const bool row_on = kk < cnt;
+            const int2 dw = dw_l[wv][min(kk, 63)];
+            float4 ev = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row_on && lane_on) ev = *(const float4*)(p.E + (int64_t)dw.x * KP + 4 * cc);
+            float part = fmaf(tj.x, ev.x, fmaf(tj.y, ev.y, fmaf(tj.z, ev.z, tj.w * ev.w)));
+            part += dpp_f<0xB1>(part);
+            part += dpp_f<0x4E>(part);
+            part += dpp_f<0x141>(part);
+            part += dpp_f<0x140>(part);                       // all 16 lanes of the slot hold s_n - keps
+            const float val = row_on ? __builtin_bit_cast(float, dw.y) : 0.0f;
+            const float wk = val / (part + p.keps);
+            const float wz = row_on ? wk : 0.0f;
+            acc.x = fmaf(wz, ev.x, acc.x); acc.y = fmaf(wz, ev.y, acc.y);
+            acc.z = fmaf(wz, ev.z, acc.z); acc.w = fmaf(wz, ev.w, acc.w);
+            wl += wz;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // combine the 4 row slots (lanes cc, cc+16, cc+32, cc+48) in a fixed order
+    float4 tot = acc;
+    float wsum = wl;
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {
+        tot.x += __shfl_xor(tot.x, o, 64); tot.y += __shfl_xor(tot.y, o, 64);
+        tot.z += __shfl_xor(tot.z, o, 64); tot.w += __shfl_xor(tot.w, o, 64);
+        wsum += __shfl_xor(wsum, o, 64);
+    }
+    if (!active || lane >= LPR) return;
+    const float tv[4] = {tot.x, tot.y, tot.z, tot.w};
+    const float tjv[4] = {tj.x, tj.y, tj.z, tj.w};
+    const int slot = p.chunk_out[c];
+    const int K = p.K;
+    if (slot < 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = 4 * lane + u;
+            if (i < K) p.out[(int64_t)j * p.ostride + i] = p.base + fmaf(tjv[u], tv[u], p.eps * wsum);
         }
     } else {
         float* pr = p.partial + (int64_t)slot * (K + 1);
