@@ -53,7 +53,8 @@ def _sources():
 def build(force: bool = False, verbose: bool = False) -> str:
     """hipcc --offload-arch=gfx950 build of libtmvb_hip.so (in-tree)."""
     srcs = _sources()
-    deps = srcs + [os.path.join(_HERE, "csrc", "tmvb_internal.h"), os.path.join(_ROOT, "include", "tmvb.h")]
+    deps = srcs + [os.path.join(_HERE, "csrc", h) for h in sorted(os.listdir(os.path.join(_HERE, "csrc"))) if h.endswith(".h")] \
+        + [os.path.join(_ROOT, "include", "tmvb.h")]
     if not force and os.path.exists(LIB_PATH):
         if all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps if os.path.exists(d)):
             return LIB_PATH
