@@ -1,0 +1,49 @@
+"""predict / topicdist (src/modelutils.jl:831-855, :886-913, :946-958) on the HIP engine
+vs the oracle's E-step with the same frozen globals."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_lda_predict_matches_oracle_estep(tmvb, oracle):
+    K = 12
+    train = tmvb.syn_nsf(M=200, V=800, seed=21)
+    new = tmvb.syn_nsf(M=60, V=800, seed=22)
+    m = tmvb.LDA(train, K)
+    tmvb.gpu_train(m, iter=5, tol=0.0, checkelbo=float("inf"), printelbo=False)
+    p = tmvb.predict(new, m, iter=10)
+    om = oracle.LDA(oracle.CSR(new.doc_ptr, new.terms, new.counts, new.V), K, m.beta)
+    om.alpha[:] = m.alpha
+    sw = om.estep(viter=10)
+    assert p.gamma.shape == (K, new.M)
+    same = np.ones(new.M, bool)          # compare documents tightly; sweep-count flips are rare and bounded below
+    r = np.abs(p.gamma - om.gamma) / om.gamma
+    assert np.quantile(r.max(axis=0), 0.9) <= 5e-4 and r.max() <= 5e-2
+    td = tmvb.topicdist(p, 1)
+    np.testing.assert_allclose(td, p.gamma[:, 0] / p.gamma[:, 0].sum())
+    assert abs(td.sum() - 1.0) < 1e-12 and len(tmvb.topicdist(p, range(1, 4))) == 3
+    with pytest.raises(tmvb.CorpusError):
+        tmvb.topicdist(p, new.M + 1)
+    with pytest.raises(tmvb.CorpusError):
+        tmvb.predict(tmvb.syn_nsf(M=10, V=700, seed=1), m)      # different vocabulary
+
+
+def test_ctm_predict_matches_oracle_estep(tmvb, oracle):
+    K = 12
+    # CTM's phi has no epsilon (src/CTM.jl:177): a held-out term never seen in training has beta = 0 for every topic
+    # and log(0) poisons the document in the reference too -- keep the vocabulary small enough to be covered
+    train = tmvb.syn_nsf(M=300, V=120, seed=31)
+    new = tmvb.syn_nsf(M=40, V=120, seed=32)
+    m = tmvb.CTM(train, K)
+    tmvb.gpu_train_ctm(m, iter=3, tol=0.0, checkelbo=float("inf"), printelbo=False)
+    p = tmvb.predict_ctm(new, m, iter=10)
+    om = oracle.CTM(oracle.CSR(new.doc_ptr, new.terms, new.counts, new.V), K, m.beta)
+    om.mu[:] = m.mu; om.sigma[:] = m.sigma; om.invsigma[:] = m.invsigma
+    om.estep(viter=10)
+    assert np.array_equal(np.isnan(p.lam), np.isnan(om.lam))          # same (absent) NaN pattern as the oracle
+    ok = ~np.isnan(om.lam).any(axis=0)
+    assert ok.sum() >= 30
+    assert np.quantile(np.abs(p.lam - om.lam)[:, ok].max(axis=0), 0.9) <= 5e-3
+    td = tmvb.topicdist_ctm(p, 2)
+    assert abs(td.sum() - 1.0) < 1e-12 and np.all(td > 0)

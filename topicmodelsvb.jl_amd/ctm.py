@@ -208,3 +208,43 @@ def gpu_train_ctm(model: CTM, device_id: int = 0, **kwargs):
     model.vsq, model.logzeta, model.elbo = g.vsq, g.logzeta, g.elbo
     g.close()
     return traj
+
+
+def predict_ctm(corp, train_model, iter: int = 10, tol: float | None = None, niter: int = 1000, ntol: float | None = None,
+                device_id: int = 0) -> CTM:
+    """predict(corp, train_model::Union{CTM, gpuCTM}; iter, tol, niter, ntol)  src/modelutils.jl:886-913: one pass of the
+    fused CTM E-step with the trained mu / sigma / beta frozen."""
+    K = train_model.K
+    tol = 1.0 / K ** 2 if tol is None else tol
+    ntol = 1.0 / K ** 2 if ntol is None else ntol
+    pc = _packed(corp)
+    if pc.V != train_model.V:
+        from ._lib import CorpusError
+        raise CorpusError("predict corpus and train_model corpus must have identical vocabularies.")
+    if tol < 0 or ntol < 0:
+        raise ValueError("tolerance parameters must be nonnegative.")
+    if iter < 0 or niter < 0:
+        raise ValueError("iteration parameters must be nonnegative.")
+    host = CTM(pc, K)
+    host.mu, host.sigma, host.invsigma = np.array(train_model.mu), np.asfortranarray(train_model.sigma), np.asfortranarray(train_model.invsigma)
+    host.beta = np.asfortranarray(train_model.beta); host.beta_old = host.beta.copy(order="F")
+    g = gpuCTM(None, K, device_id=device_id, _from=host)
+    g.estep(niter, ntol, iter, tol)
+    g.update_host()
+    for n in ("lam", "lam_old", "vsq", "logzeta"):
+        setattr(host, n, getattr(g, n))
+    host.topics = train_model.topics
+    g.close()
+    return host
+
+
+def topicdist_ctm(model, d):
+    """topicdist(model::Union{CTM, gpuCTM}, d)  src/modelutils.jl:953-958: additive_logistic(lambda + vsq/2)."""
+    if not isinstance(d, (int, np.integer)):
+        return [topicdist_ctm(model, int(x)) for x in d]
+    if not (1 <= d <= model.M):
+        from ._lib import CorpusError
+        raise CorpusError("document index outside corpus range.")
+    x = model.lam[:, d - 1] + 0.5 * model.vsq[:, d - 1]
+    x = np.exp(x - x.max())
+    return x / x.sum()

@@ -329,3 +329,43 @@ def gpu_train(model: LDA, device_id: int = 0, **kwargs):
     model.elbo = g.elbo
     g.close()
     return traj
+
+
+def predict(corp, train_model, iter: int = 10, tol: float | None = None, device_id: int = 0) -> LDA:
+    """predict(corp, train_model::Union{LDA, gpuLDA}; iter=10, tol=1/K^2)  src/modelutils.jl:831-855:
+    topic distributions of unseen documents with the trained alpha / beta frozen -- one pass of the fused
+    E-step kernel (<= iter sweeps per document, same exit rule), no M-step."""
+    K = train_model.K
+    tol = 1.0 / K ** 2 if tol is None else tol
+    pc = _packed(corp)
+    if pc.V != train_model.V:
+        from ._lib import CorpusError
+        raise CorpusError("predict corpus and train_model corpus must have identical vocabularies.")
+    if tol < 0:
+        raise ValueError("tolerance parameter must be nonnegative.")
+    if iter < 0:
+        raise ValueError("iteration parameter must be nonnegative.")
+    g = gpuLDA(pc, K, device_id=device_id)
+    g.alpha = np.array(train_model.alpha, dtype=np.float64)
+    g.beta = np.asfortranarray(train_model.beta); g.beta_old = g.beta.copy(order="F")
+    g.update_buffer()
+    g.estep(iter, tol)
+    g.update_host()
+    out = LDA(pc, K)
+    for n in ("alpha", "beta", "beta_old", "gamma", "Elogtheta", "Elogtheta_old"):
+        setattr(out, n, getattr(g, n))
+    out.topics = train_model.topics
+    g.close()
+    return out
+
+
+def topicdist(model, d):
+    """topicdist(model::Union{LDA, gpuLDA}, d)  src/modelutils.jl:946-951 (d is 1-based like the reference;
+    a list / range of indices returns a list)."""
+    if not isinstance(d, (int, np.integer)):
+        return [topicdist(model, int(x)) for x in d]
+    if not (1 <= d <= model.M):
+        from ._lib import CorpusError
+        raise CorpusError("document index outside corpus range.")
+    g = model.gamma[:, d - 1]
+    return g / g.sum()
