@@ -233,3 +233,24 @@ def test_full_size_nsf_properties(tmvb):
     e2 = gm.update_elbo()
     assert np.isfinite(e1) and e2 > e1
     assert gm.sweep_hist().sum() == pc.M
+
+
+@pytest.mark.parametrize("K", [50, 100])
+def test_register_tile_paths_k50_k100(tmvb, oracle, K):
+    """K=50 (one result slot per lane) and K=100 (two slots; stored-weight statistics kernel) register-tile
+    kernels incl. multi-tile documents, teacher-forced against the oracle with pinned sweep counts."""
+    pc = tmvb.syn_nsf(M=120, V=900, seed=17)           # document lengths ~30..250 -> 1..4 tiles
+    g = dict(K=K, V=pc.V, doc_ptr=pc.doc_ptr, terms=pc.terms, counts=pc.counts, beta0=tmvb.dirichlet_rows(K, pc.V, seed=3))
+    gm, om = make_pair(tmvb, oracle, g)
+    for it in range(3):
+        force(gm, om)
+        gm.estep(viter=4, vtol=0.0); gm.reduce_docs(); om.estep(viter=4, vtol=0.0)
+        gm.update_beta(); om.update_beta()
+        gm.update_alpha(); om.update_alpha()
+        e_g = gm.update_elbo(); e_o = om.update_elbo()
+        gm.update_host()
+        assert rel(gm.gamma, om.gamma).max() <= RTOL_STATE, (it, "gamma")
+        big = om.beta > 1e-6
+        assert rel(gm.beta[big], om.beta[big]).max() <= RTOL_BETA, (it, "beta")
+        assert rel(gm.alpha, om.alpha).max() <= RTOL_ALPHA
+        assert abs(e_g - e_o) <= RTOL_ELBO_STEP * abs(e_o)

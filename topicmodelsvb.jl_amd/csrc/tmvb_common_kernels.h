@@ -74,16 +74,20 @@ __device__ __forceinline__ float lane_reduce_scatter(float (&p)[R], int lane)
         if (i + h4 < m4) dpp_stage<0x4E>(p[i], p[i + h4], b2);       // quad_perm [2,3,0,1]
         else p[i] += dpp_f<0x4E>(p[i]);
     }
-    constexpr int m5 = h4;
-    static_assert(m5 <= 2, "reduce-scatter supports up to 64 registers");
-    if (m5 == 2) dpp_stage<0xB1>(p[0], p[1], b1);                    // quad_perm [1,0,3,2]
-    else p[0] += dpp_f<0xB1>(p[0]);
+    constexpr int m5 = h4, h5 = (m5 + 1) / 2;
+#pragma unroll
+    for (int i = 0; i < h5; ++i) {
+        if (i + h5 < m5) dpp_stage<0xB1>(p[i], p[i + h5], b1);       // quad_perm [1,0,3,2]
+        else p[i] += dpp_f<0xB1>(p[i]);
+    }
+    // p[0 .. ceil(R/64)) now hold the totals: lane L of result register s owns topic pi(s, L)
     return p[0];
 }
 
-
-// host replay of lane_reduce_scatter's pairing: which topic ends up in which lane
-static inline void tmvb_reg_lane_maps(int R, std::vector<int>& topic_of_lane, std::vector<int>& lane_of_topic)
+// host replay of lane_reduce_scatter's pairing: which topic ends up in which (result register, lane).
+// topic_of_lane[s * 64 + L] = topic owned by lane L of result register s (-1 for duplicates);
+// lane_of_topic[q] = s * 64 + L of the primary owner of topic q.
+static inline int tmvb_reg_lane_maps(int R, std::vector<int>& topic_of_lane, std::vector<int>& lane_of_topic)
 {
     std::vector<std::vector<int>> regs(R, std::vector<int>(64));
     for (int q = 0; q < R; ++q) for (int l = 0; l < 64; ++l) regs[q][l] = q;
@@ -95,12 +99,15 @@ static inline void tmvb_reg_lane_maps(int R, std::vector<int>& topic_of_lane, st
             for (int l = 0; l < 64; ++l) nxt[i][l] = (i + h < m && (l & D)) ? regs[i + h][l] : regs[i][l];
         regs.swap(nxt);
     }
-    topic_of_lane.assign(64, -1);
+    const int NS = (int)regs.size();
+    topic_of_lane.assign((size_t)NS * 64, -1);
     lane_of_topic.assign(R, -1);
-    for (int l = 0; l < 64; ++l) {
-        int q = regs[0][l];
-        if (lane_of_topic[q] < 0) { lane_of_topic[q] = l; topic_of_lane[l] = q; }   // first lane is the primary
-    }
+    for (int sl = 0; sl < NS; ++sl)
+        for (int l = 0; l < 64; ++l) {
+            int q = regs[sl][l];
+            if (lane_of_topic[q] < 0) { lane_of_topic[q] = sl * 64 + l; topic_of_lane[(size_t)sl * 64 + l] = q; }
+        }
+    return NS;
 }
 
 

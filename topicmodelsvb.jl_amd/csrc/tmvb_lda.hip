@@ -306,33 +306,58 @@ __global__ __launch_bounds__(64) void lda_estep_reg_kernel(LdaParams p, int64_t 
         }
         w[t] = 0.0f;
     }
-    // topic role: lane L owns topic pi(L) (duplicates are marked -1 by the host)
-    const int mytopic = topic_of_lane[lane];
-    const bool on = mytopic >= 0 && mytopic < K;
-    const float alpha = on ? p.alpha[mytopic] : 0.0f;
-    float elog = on ? p.elog[(int64_t)d * K + mytopic] : 0.0f;
-    float elog_old = elog, gam = 0.0f, e = 0.0f;
-    int lot[R];
+    // topic role: lane L of result slot sl owns topic pi(sl, L) (duplicates are marked -1 by the host)
+    constexpr int NS = (R + 63) / 64;
+    int mytopic[NS];
+    bool on[NS];
+    float alpha[NS], elog[NS], elog_old[NS], gam[NS], e[NS];
 #pragma unroll
-    for (int q = 0; q < R; ++q) lot[q] = lane_of_topic[q];
+    for (int sl = 0; sl < NS; ++sl) {
+        mytopic[sl] = topic_of_lane[sl * 64 + lane];
+        on[sl] = mytopic[sl] >= 0 && mytopic[sl] < K;
+        alpha[sl] = on[sl] ? p.alpha[mytopic[sl]] : 0.0f;
+        elog[sl] = on[sl] ? p.elog[(int64_t)d * K + mytopic[sl]] : 0.0f;
+        elog_old[sl] = elog[sl]; gam[sl] = 0.0f; e[sl] = 0.0f;
+    }
 
     int sweeps = 0;
     for (int v = 0; v < p.viter; ++v) {
         ++sweeps;
-        e = on ? expf(elog) : 0.0f;                                   // update_phi!, src/LDA.jl:152
-        float es[R];
 #pragma unroll
-        for (int q = 0; q < R; ++q) es[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e), lot[q]));
+        for (int sl = 0; sl < NS; ++sl) e[sl] = on[sl] ? expf(elog[sl]) : 0.0f;     // update_phi!, src/LDA.jl:152
+        // phase 1 in blocks of 32 topics: the e_q of a block live in SGPRs only while the block is consumed
+        float sacc[T][4];
+#pragma unroll
+        for (int t = 0; t < T; ++t) { sacc[t][0] = 0.f; sacc[t][1] = 0.f; sacc[t][2] = 0.f; sacc[t][3] = 0.f; }
+#pragma unroll
+        for (int q0 = 0; q0 < R; q0 += 32) {
+            constexpr int QB = 32;
+            float es[QB];
+#pragma unroll
+            for (int q = 0; q < QB; ++q) {
+                if (q0 + q < R) {
+                    const int lt = lane_of_topic[q0 + q];
+                    const float src = (NS == 1 || lt < 64) ? e[0] : e[NS - 1];
+                    es[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, src), lt & 63));
+                } else {
+                    es[q] = 0.0f;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+#pragma unroll
+                for (int q = 0; q < QB; q += 4) {
+                    if (q0 + q < R) {
+                        sacc[t][0] = fmaf(B[t][q0 + q], es[q], sacc[t][0]); sacc[t][1] = fmaf(B[t][q0 + q + 1], es[q + 1], sacc[t][1]);
+                        sacc[t][2] = fmaf(B[t][q0 + q + 2], es[q + 2], sacc[t][2]); sacc[t][3] = fmaf(B[t][q0 + q + 3], es[q + 3], sacc[t][3]);
+                    }
+                }
+            }
+        }
         float wl = 0.0f;
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll
-            for (int q = 0; q < R; q += 4) {
-                s0 = fmaf(B[t][q], es[q], s0); s1 = fmaf(B[t][q + 1], es[q + 1], s1);
-                s2 = fmaf(B[t][q + 2], es[q + 2], s2); s3 = fmaf(B[t][q + 3], es[q + 3], s3);
-            }
-            const float sn = ((s0 + s1) + (s2 + s3)) + (float)K * TMVB_EPS_F;
+            const float sn = ((sacc[t][0] + sacc[t][1]) + (sacc[t][2] + sacc[t][3])) + (float)K * TMVB_EPS_F;
             w[t] = c[t] / sn;
             wl += w[t];
         }
@@ -345,32 +370,45 @@ __global__ __launch_bounds__(64) void lda_estep_reg_kernel(LdaParams p, int64_t 
             for (int t = 1; t < T; ++t) a = fmaf(w[t], B[t][q], a);
             pr[q] = a;
         }
-        const float g = lane_reduce_scatter<R>(pr, lane);
-        gam = TMVB_EPS_F + (alpha + fmaf(e, g, TMVB_EPS_F * wsum));   // update_gamma!, src/LDA.jl:145
-        const float gsum = wave_sum(on ? gam : 0.0f);
+        (void)lane_reduce_scatter<R>(pr, lane);
+        float gl = 0.0f;
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) {
+            gam[sl] = TMVB_EPS_F + (alpha[sl] + fmaf(e[sl], pr[sl], TMVB_EPS_F * wsum));   // update_gamma!, src/LDA.jl:145
+            if (on[sl]) gl += gam[sl];
+        }
+        const float gsum = wave_sum(gl);
         const float dgs = digamma_f(gsum);
-        elog_old = elog;                                              // update_Elogtheta!, :137-138
         float dl = 0.0f;
-        if (on) {
-            elog = digamma_f(gam) - dgs;
-            const float df = elog - elog_old;
-            dl = df * df;
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) {
+            elog_old[sl] = elog[sl];                                  // update_Elogtheta!, :137-138
+            if (on[sl]) {
+                elog[sl] = digamma_f(gam[sl]) - dgs;
+                const float df = elog[sl] - elog_old[sl];
+                dl = fmaf(df, df, dl);
+            }
         }
         const float dist2 = wave_sum(dl);
         if (sqrtf(dist2) < p.vtol) break;                             // :175
     }
     if (sweeps > 0) {
-        if (on) {
-            p.gamma[(int64_t)d * K + mytopic] = gam;
-            p.elog[(int64_t)d * K + mytopic] = elog;
-            p.elog_old[(int64_t)d * K + mytopic] = elog_old;
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) {
+            if (on[sl]) {
+                p.gamma[(int64_t)d * K + mytopic[sl]] = gam[sl];
+                p.elog[(int64_t)d * K + mytopic[sl]] = elog[sl];
+                p.elog_old[(int64_t)d * K + mytopic[sl]] = elog_old[sl];
+            }
+            if (mytopic[sl] >= 0 && mytopic[sl] < p.estride) p.E[(int64_t)d * p.estride + mytopic[sl]] = e[sl];
         }
-        if (mytopic >= 0 && mytopic < p.estride) p.E[(int64_t)d * p.estride + mytopic] = e;
 #pragma unroll
         for (int t = 0; t < T; ++t) if (wpos[t] >= 0 && p.store_w) p.wtok[wpos[t]] = w[t];
     } else {
         // viter = 0: no responsibilities; E = 0 makes the statistics pass produce eps-only columns
-        if (mytopic >= 0 && mytopic < p.estride) p.E[(int64_t)d * p.estride + mytopic] = 0.0f;
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl)
+            if (mytopic[sl] >= 0 && mytopic[sl] < p.estride) p.E[(int64_t)d * p.estride + mytopic[sl]] = 0.0f;
 #pragma unroll
         for (int t = 0; t < T; ++t) if (wpos[t] >= 0 && p.store_w) p.wtok[wpos[t]] = 0.0f;
     }
@@ -577,8 +615,9 @@ struct tmvb_lda {
     hipEvent_t ev_fork = nullptr, ev_join[NAUX] = {nullptr, nullptr, nullptr, nullptr};
 };
 
-static bool lda_reg_lpr_supported(int lpr) { return lpr == 1 || lpr == 3 || lpr == 5 || lpr == 13; }
-#define LDA_REG_MAX_TILES 4
+static bool lda_reg_lpr_supported(int lpr) { return lpr == 1 || lpr == 3 || lpr == 5 || lpr == 13 || lpr == 25; }
+// 64-token register tiles per document: the tile costs T * KP VGPRs of the 512 available per lane
+static int lda_reg_max_tiles(int lpr) { return lpr <= 13 ? 4 : 2; }   // KP = 100: T = 3 would spill (512 VGPRs)
 
 static void lda_build_buckets(tmvb_lda* h, std::vector<int32_t>& order)
 {
@@ -587,11 +626,12 @@ static void lda_build_buckets(tmvb_lda* h, std::vector<int32_t>& order)
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return len[x] > len[y]; });
     h->buckets.clear();
-    const int64_t reg_max = h->reg_path ? 64 * LDA_REG_MAX_TILES : -1;
+    const int max_tiles = lda_reg_max_tiles(h->KP / 4);
+    const int64_t reg_max = h->reg_path ? 64 * max_tiles : -1;
     // documents longer than reg_max: LDS-tile kernel
     int64_t pos = tmvb_build_lds_buckets(len, order, h->M, h->KP, reg_max, 3, h->buckets);
     // register-tile buckets: T = ceil(N / 64) tiles of 64 tokens
-    for (int T = LDA_REG_MAX_TILES; T >= 1 && pos < h->M; --T) {
+    for (int T = max_tiles; T >= 1 && pos < h->M; --T) {
         const int64_t lo = 64 * (int64_t)(T - 1);
         int64_t cnt = 0;
         while (pos + cnt < h->M && (len[order[pos + cnt]] > lo || T == 1)) ++cnt;
@@ -671,12 +711,12 @@ extern "C" int tmvb_lda_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
         tmvb_lda_destroy(h);
         return rc;
     }
-    h->reg_path = (K <= 64) && lda_reg_lpr_supported(h->KP / 4);
+    h->reg_path = (K <= 128) && lda_reg_lpr_supported(h->KP / 4);
     if (h->reg_path) {
         std::vector<int> tol, lot;
         tmvb_reg_lane_maps(h->KP, tol, lot);
-        if ((rc = dmalloc(&h->d_topic_of_lane, 64)) || (rc = dmalloc(&h->d_lane_of_topic, (size_t)h->KP))) { tmvb_lda_destroy(h); return rc; }
-        TMVB_HIP(hipMemcpy(h->d_topic_of_lane, tol.data(), 64 * sizeof(int), hipMemcpyHostToDevice));
+        if ((rc = dmalloc(&h->d_topic_of_lane, tol.size())) || (rc = dmalloc(&h->d_lane_of_topic, (size_t)h->KP))) { tmvb_lda_destroy(h); return rc; }
+        TMVB_HIP(hipMemcpy(h->d_topic_of_lane, tol.data(), tol.size() * sizeof(int), hipMemcpyHostToDevice));
         TMVB_HIP(hipMemcpy(h->d_lane_of_topic, lot.data(), (size_t)h->KP * sizeof(int), hipMemcpyHostToDevice));
     }
     std::vector<int32_t> order;
@@ -797,6 +837,12 @@ extern "C" int tmvb_lda_estep(tmvb_lda* h, int32_t viter, double vtol)
                 case 1: LDA_REG_LAUNCH_T(1); break;
                 case 3: LDA_REG_LAUNCH_T(3); break;
                 case 5: LDA_REG_LAUNCH_T(5); break;
+                case 25:
+                    switch (b.reg_tiles) {
+                        case 1: LDA_REG_LAUNCH(25, 1); break;
+                        default: LDA_REG_LAUNCH(25, 2); break;
+                    }
+                    break;
                 default: LDA_REG_LAUNCH_T(13); break;
             }
             TMVB_HIP(hipGetLastError());
