@@ -51,6 +51,7 @@ struct CtmParams {
     double ntol;
     int viter;
     double vtol;
+    int debug;                // TMVB_DEBUG_FLAGS (profiling experiments only): 1 = skip vsq Newton, 2 = diagonal solve instead of GJ
 };
 
 __device__ __forceinline__ float readlane_f(float v, int l)
@@ -79,14 +80,21 @@ __device__ __forceinline__ float gj_solve_rows(float (&H)[R], float g, int lane)
     float dinv = 0.0f;
 #pragma unroll
     for (int j = 0; j < R; ++j) {
-        const float p = readlane_f(H[j], j);
-        const float rp = 1.0f / p;
+        // broadcast the pivot row first (back-to-back v_readlane into SGPRs), then consume it: a VALU that
+        // reads an SGPR written by the immediately preceding v_readlane costs a wait state per pair
+        float srow[R];
+#pragma unroll
+        for (int k = j; k < R; ++k) srow[k] = readlane_f(H[k], j);
+        const float sg = readlane_f(g, j);
+        __builtin_amdgcn_sched_barrier(0);
+        const float rp = 1.0f / srow[j];
         const bool me = lane == j;
         const float f = me ? 0.0f : H[j] * rp;
         dinv = me ? rp : dinv;
 #pragma unroll
-        for (int k = j + 1; k < R; ++k) H[k] = fmaf(-f, readlane_f(H[k], j), H[k]);
-        g = fmaf(-f, readlane_f(g, j), g);
+        for (int k = j + 1; k < R; ++k) H[k] = fmaf(-f, srow[k], H[k]);
+        g = fmaf(-f, sg, g);
+        __builtin_amdgcn_sched_barrier(0);
     }
     return g * dinv;
 }
@@ -215,7 +223,7 @@ __global__ __launch_bounds__(64) void ctm_estep_kernel(CtmParams p, int64_t firs
             lz = m + log(wave_sum_d(on ? exp(x - m) : 0.0));
         }
         // update_vsq!  :146-165  (one scalar Newton iteration per topic = per lane)
-        if (on) {
+        if (on && !(p.debug & 1)) {
             for (int t = 0; t < p.niter; ++t) {
                 double rho = 1.0;
                 const double ex = exp(lam + 0.5 * vs - lz);
@@ -251,7 +259,9 @@ __global__ __launch_bounds__(64) void ctm_estep_kernel(CtmParams p, int64_t firs
             const float dval = on ? (float)(Cd * ex) : 1.0f;
 #pragma unroll
             for (int k = 0; k < R; ++k) H[k] += ((lane == k) ? dval : 0.0f);
-            const float delta = gj_solve_rows<R>(H, (float)gd, lane);
+            float delta;
+            if (p.debug & 2) delta = (float)gd / (float)(isdiag + Cd * ex);
+            else delta = gj_solve_rows<R>(H, (float)gd, lane);
             if (on) lam += (double)delta;                                                  // :136
             if (sqrt(gn2) < p.ntol) break;                                                 // :138
         }
@@ -719,6 +729,7 @@ extern "C" int tmvb_ctm_estep(tmvb_ctm* h, int32_t niter, double ntol, int32_t v
     p.lambda = h->d_lambda; p.lambda_old = h->d_lambda_old; p.vsq = h->d_vsq; p.logzeta = h->d_logzeta;
     p.wtok = h->d_wtok; p.E = h->d_E; p.sweeps = h->d_sweeps; p.newton_steps = h->d_newton;
     p.niter = niter; p.ntol = ntol; p.viter = viter; p.vtol = vtol;
+    { const char* dbg = getenv("TMVB_DEBUG_FLAGS"); p.debug = dbg ? atoi(dbg) : 0; }
     TMVB_HIP(hipEventRecord(h->ev0, ctx->stream));
     TMVB_HIP(hipMemsetAsync(h->d_newton, 0, sizeof(unsigned long long), ctx->stream));
     const int nb = (int)h->buckets.size();
