@@ -222,8 +222,12 @@ int tmvb_ctpf_set_distributed(tmvb_ctpf* h, int32_t distributed);
 /* update_he!, update_alef!, update_dalet!, update_het!, update_bet!, update_vav! in that order
  * (src/CTPF.jl:366-371; replaces src/gpuCTPF.jl:448, :315, :418, :539, :344, :482). */
 int tmvb_ctpf_mstep(tmvb_ctpf* h);
-/* train! (src/gpuCTPF.jl:677-705).  checkelbo must be <= 0 (Inf): the CTPF ELBO is not evaluated on the device
- * in this release. */
+/* update_elbo! (src/CTPF.jl:234-247) on the device.  The Binomial sums of Elogpya/Elogpyb/Elogpz and of the Multinomial
+ * entropies cancel identically in :243 and are not evaluated.  _parts returns the per-document part (sum over this
+ * context's documents) and the global (beta, eta) part separately for document-sharded hosts. */
+int tmvb_ctpf_update_elbo(tmvb_ctpf* h, double* elbo);
+int tmvb_ctpf_update_elbo_parts(tmvb_ctpf* h, double* doc_part, double* global_part);
+/* train! (src/gpuCTPF.jl:677-705 signature, src/CTPF.jl:344-376 semantics).  checkelbo <= 0 means Inf. */
 int tmvb_ctpf_train(tmvb_ctpf* h, int32_t iter, double tol, int32_t viter, double vtol, int32_t checkelbo,
                     double* elbo_traj, int32_t* iters_done);
 int tmvb_ctpf_sweep_hist(tmvb_ctpf* h, int64_t* hist, int32_t nbins);

@@ -67,6 +67,20 @@ def test_teacher_forced_step(tmvb, oracle, case):
         assert np.all(gm.alef > 0) and np.all(gm.he > 0) and np.all(gm.gimel > 0) and np.all(gm.zayin > 0)
 
 
+@pytest.mark.parametrize("case", ["ctpf_m40_v60_u15_k4", "syn_k12", "syn_k50"])
+def test_device_elbo_matches_oracle(tmvb, oracle, case):
+    """update_elbo! (src/CTPF.jl:234-247) on the device (Binomial sums cancelled analytically) vs the oracle's
+    term-by-term evaluation, after one teacher-forced step with pinned sweep counts; rel <= 2e-5."""
+    g = load(case) if case.startswith("ctpf_") else synth_case(tmvb, 12 if case == "syn_k12" else 50, M=50, V=200, U=40)
+    gm, om = make_pair(tmvb, oracle, g)
+    for it in range(2):
+        force(gm, om)
+        gm.estep(viter=3, vtol=0.0); gm.reduce_docs(); gm.mstep()
+        om.estep(viter=3, vtol=0.0); om.mstep()
+        e_g = gm.update_elbo(); e_o = om.update_elbo()
+        assert np.isfinite(e_g) and abs(e_g - e_o) <= 2e-5 * abs(e_o), (it, e_g, e_o)
+
+
 def test_fixed_sweeps_exact_arithmetic(tmvb, oracle):
     g = synth_case(tmvb, 50, M=60, V=200, U=40, seed=9)
     gm, om = make_pair(tmvb, oracle, g)
@@ -87,8 +101,10 @@ def test_free_running_train_vs_golden(tmvb, name):
     pc = tmvb.PackedCorpus(g["doc_ptr"], g["terms"], g["counts"], V, g["rdr_ptr"], g["readers"], g["ratings"], U)
     m = tmvb.CTPF(pc, K)
     m.alef = np.asfortranarray(g["alef0"]); m.alef_old = m.alef.copy(order="F")
-    tmvb.gpu_train_ctpf(m, iter=int(g["iters"]), printelbo=False)
+    traj = tmvb.gpu_train_ctpf(m, iter=int(g["iters"]), tol=0.0, checkelbo=1, printelbo=False)
     tmvb.check_model_ctpf(m)
+    gold = g["elbo_traj"]
+    assert len(traj) == len(gold) and np.all(np.abs(traj - gold) <= 2e-3 * np.abs(gold)), (traj, gold)
     for n in ("alef", "he", "bet", "vav", "dalet", "het", "gimel", "zayin"):
         assert rel(getattr(m, n), g[n]) <= 2e-2, n
 
@@ -99,7 +115,7 @@ def test_errors(tmvb):
         tmvb.gpuCTPF(pc, 0)
     gm = tmvb.gpuCTPF(pc, 4)
     with pytest.raises(ValueError):
-        gm.train(iter=2, checkelbo=1, printelbo=False)      # ELBO not on the device in this release
+        gm.train(iter=2, checkelbo=0, printelbo=False)      # src/gpuCTPF.jl:681
     with pytest.raises(ValueError):
         gm.train(viter=-1, printelbo=False)
 

@@ -246,6 +246,131 @@ __global__ __launch_bounds__(64) void ctpf_rates_kernel(int K, double hb, double
     }
 }
 
+// ------------------------------------------------------------------------------ ELBO (src/CTPF.jl:111-247)
+// The Binomial sums  sum_y pdf(Binomial(n,p),y) lgamma(y+1)  enter Elogpya/Elogpyb/Elogpz with a minus sign
+// (src/CTPF.jl:116,:127,:138) and -Elogqy/-Elogqz through entropy(Multinomial) with a plus sign (:183,:192): they
+// cancel identically in update_elbo! (:243), so the device evaluates the remaining closed form
+//   sum_u [ ra <xi_u, log-rates + psi(he)> - lgamma(ra+1) + ra H(xi_u) ] + sum_n [ c <phi_n, ...> - lgamma(c+1) + c H(phi_n) ].
+__device__ __forceinline__ double gamma_entropy_d(double a, double rate)   // entropy(Gamma(shape a, scale 1/rate))
+{
+    return a - log(rate) + lgamma(a) + (1.0 - a) * digamma_d(a);
+}
+
+// per-document part; one wave per document, lane = topic (K <= 64)
+__global__ __launch_bounds__(64) void ctpf_elbo_doc_kernel(int K, const int64_t* __restrict__ doc_ptr, const int32_t* __restrict__ terms,
+                                                           const int32_t* __restrict__ counts, const int64_t* __restrict__ rdr_ptr,
+                                                           const int32_t* __restrict__ readers, const int32_t* __restrict__ ratings,
+                                                           const float* __restrict__ alef, const float* __restrict__ alef_old,
+                                                           const float* __restrict__ he, const float* __restrict__ he_old,
+                                                           const double* __restrict__ rates /* [8][K] */, const double* __restrict__ rs_alef,
+                                                           const double* __restrict__ rs_he, const float* __restrict__ gimel,
+                                                           const float* __restrict__ gimel_old, const float* __restrict__ zayin,
+                                                           const float* __restrict__ zayin_old, double hc, double hd, double hg, double hh,
+                                                           double* __restrict__ doc_val)
+{
+    const int lane = threadIdx.x;
+    const int d = blockIdx.x;
+    const bool on = lane < K;
+    const int i = on ? lane : 0;
+    const double bet = rates[i], vav = rates[K + i], dalet = rates[2 * K + i], het = rates[3 * K + i];
+    const double bet_o = rates[4 * K + i], vav_o = rates[5 * K + i], dalet_o = rates[6 * K + i], het_o = rates[7 * K + i];
+    const double gi = on ? (double)gimel[(int64_t)d * K + i] : 1.0, za = on ? (double)zayin[(int64_t)d * K + i] : 1.0;
+    const double gio = on ? (double)gimel_old[(int64_t)d * K + i] : 1.0, zao = on ? (double)zayin_old[(int64_t)d * K + i] : 1.0;
+    // softmax arguments rebuilt from the *_old variables (:240-241)
+    const float xo = (float)(digamma_d(gio) - log(dalet_o) - log(bet_o));
+    const float ao = (float)(digamma_d(gio) - log(dalet_o) - log(vav_o));
+    const float bo = (float)(digamma_d(zao) - log(het_o) - log(vav_o));
+    // log-rate parts of the current variables
+    const double lt = digamma_d(gi) - log(dalet);       // E[log theta]
+    const double le = digamma_d(za) - log(het);         // E[log epsilon]
+    const double lbet = log(bet), lvav = log(vav);
+    double acc = 0.0;
+    // tokens: Elogpz - Elogqz (without the cancelling Binomial sums)
+    const int64_t off = doc_ptr[d];
+    const int N = (int)(doc_ptr[d + 1] - off);
+    for (int n = 0; n < N; ++n) {
+        const int t = terms[off + n];
+        const double c = (double)counts[off + n];
+        const float x = on ? xo + digamma_f(alef_old[(int64_t)t * K + i]) : -INFINITY;
+        const float mx = wave_max(x);
+        const float ex = on ? expf(x - mx) : 0.0f;
+        const float ph = ex / wave_sum(ex);
+        if (on) {
+            acc += c * (double)ph * (lt + (double)digamma_f(alef[(int64_t)t * K + i]) - lbet);
+            if (ph > 0.0f) acc -= c * (double)ph * (double)logf(ph);          // + c H(phi_n)
+        }
+        if (lane == 0) acc -= lgamma(c + 1.0);
+    }
+    // readers: Elogpya + Elogpyb - Elogqy
+    const int64_t roff = rdr_ptr[d];
+    const int Rd = (int)(rdr_ptr[d + 1] - roff);
+    for (int u = 0; u < Rd; ++u) {
+        const int r = readers[roff + u];
+        const double ra = (double)ratings[roff + u];
+        const float dho = on ? digamma_f(he_old[(int64_t)r * K + i]) : 0.0f;
+        const float a = on ? ao + dho : -INFINITY, b = on ? bo + dho : -INFINITY;
+        const float mx = wave_max(fmaxf(a, b));
+        const float ea = on ? expf(a - mx) : 0.0f, eb = on ? expf(b - mx) : 0.0f;
+        const float inv = 1.0f / wave_sum(ea + eb);
+        if (on) {
+            const double xt = (double)(ea * inv), xb = (double)(eb * inv);
+            const double dh = (double)digamma_f(he[(int64_t)r * K + i]);
+            acc += ra * xt * (lt + dh - lvav) + ra * xb * (le + dh - lvav);
+            if (xt > 0.0) acc -= ra * xt * log(xt);
+            if (xb > 0.0) acc -= ra * xb * log(xb);
+        }
+        if (lane == 0) acc -= lgamma(ra + 1.0);
+    }
+    if (on) {
+        acc -= gi / (dalet * vav) * rs_he[i] + za / (het * vav) * rs_he[i] + gi / (dalet * bet) * rs_alef[i];   // :112,:123,:134
+        acc += (hc - 1.0) * lt - hd * gi / dalet;                       // Elogptheta :156
+        acc += (hg - 1.0) * le - hh * za / het;                         // Elogpepsilon :174
+        acc += gamma_entropy_d(gi, dalet) + gamma_entropy_d(za, het);   // -Elogqtheta, -Elogqepsilon
+    }
+    double tot = wave_sum_d(acc);
+    tot += (double)K * (hc * log(hd) - lgamma(hc)) + (double)K * (hg * log(hh) - lgamma(hg));
+    if (lane == 0) doc_val[d] = tot;
+}
+
+// global part over the entries of a K x n shape matrix X with rate vector `rate`:
+//   sum [ (prior_shape - 1)(psi(x) - log rate_i) - prior_rate x / rate_i + entropy(Gamma(x, 1/rate_i)) ]
+// (Elogpbeta - Elogqbeta :144-150,:198-204 with (a, b, alef, bet); Elogpeta - Elogqeta :162-168,:216-222 with (e, f, he, vav))
+__global__ __launch_bounds__(256) void ctpf_elbo_global_kernel(const float* __restrict__ X, int64_t n_ids, int K, const double* __restrict__ rate,
+                                                               double ps, double pr, double* __restrict__ partial)
+{
+    __shared__ double red[256];
+    double s = 0.0;
+    const int64_t total = n_ids * K;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(q % K);
+        const double x = (double)X[q], r = rate[i];
+        s += (ps - 1.0) * (digamma_d(x) - log(r)) - pr * x / r + gamma_entropy_d(x, r);
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(1024) void ctpf_elbo_final_kernel(const double* __restrict__ doc_val, int64_t M, const double* __restrict__ partial,
+                                                               int npartial, double constant, double* __restrict__ out)
+{
+    __shared__ double red[1024];
+    double s = 0.0;
+    for (int64_t d = threadIdx.x; d < M; d += 1024) s += doc_val[d];
+    for (int q = threadIdx.x; q < npartial; q += 1024) s += partial[q];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0] + constant;
+}
+
 // ------------------------------------------------------------------------------ host side
 struct tmvb_ctpf {
     tmvb_ctx* ctx = nullptr;
@@ -263,6 +388,7 @@ struct tmvb_ctpf {
     float* d_wtok = nullptr; float* d_wrdr = nullptr; float* d_E1 = nullptr; float* d_E2 = nullptr;
     float* d_ts_partial = nullptr;
     uint8_t* d_sweeps = nullptr; int32_t* d_doc_order = nullptr;
+    double* d_doc_val = nullptr; double* d_elbo_partial = nullptr; double* d_elbo = nullptr;
     double* d_partial = nullptr; double* d_rs_alef = nullptr; double* d_rs_he = nullptr; double* d_sum_g = nullptr; double* d_sum_z = nullptr;
     double elbo = 0.0;
     std::vector<tmvb_bucket> buckets;
@@ -289,7 +415,7 @@ extern "C" int tmvb_ctpf_destroy(tmvb_ctpf* h)
     (void)hipFree(h->d_zayin); (void)hipFree(h->d_zayin_old); (void)hipFree(h->d_wtok); (void)hipFree(h->d_wrdr);
     (void)hipFree(h->d_E1); (void)hipFree(h->d_E2); (void)hipFree(h->d_ts_partial); (void)hipFree(h->d_sweeps);
     (void)hipFree(h->d_doc_order); (void)hipFree(h->d_partial); (void)hipFree(h->d_rs_alef); (void)hipFree(h->d_rs_he);
-    (void)hipFree(h->d_sum_g); (void)hipFree(h->d_sum_z);
+    (void)hipFree(h->d_sum_g); (void)hipFree(h->d_sum_z); (void)hipFree(h->d_doc_val); (void)hipFree(h->d_elbo_partial); (void)hipFree(h->d_elbo);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -342,7 +468,8 @@ extern "C" int tmvb_ctpf_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmv
         (rc = dmalloc(&h->d_E1, (size_t)h->KP * h->M + 4)) || (rc = dmalloc(&h->d_E2, (size_t)h->KP * h->M + 4)) ||
         (rc = dmalloc(&h->d_ts_partial, slots * (K + 1))) || (rc = dmalloc(&h->d_sweeps, (size_t)h->M)) || (rc = dmalloc(&h->d_doc_order, (size_t)h->M)) ||
         (rc = dmalloc(&h->d_partial, (size_t)TMVB_REDUCE_BLOCKS * K)) || (rc = dmalloc(&h->d_rs_alef, K)) || (rc = dmalloc(&h->d_rs_he, K)) ||
-        (rc = dmalloc(&h->d_sum_g, K)) || (rc = dmalloc(&h->d_sum_z, K))) {
+        (rc = dmalloc(&h->d_sum_g, K)) || (rc = dmalloc(&h->d_sum_z, K)) || (rc = dmalloc(&h->d_doc_val, (size_t)h->M)) ||
+        (rc = dmalloc(&h->d_elbo_partial, 1024)) || (rc = dmalloc(&h->d_elbo, 1))) {
         tmvb_ctpf_destroy(h);
         return rc;
     }
@@ -578,26 +705,84 @@ extern "C" int tmvb_ctpf_mstep(tmvb_ctpf* h)
     return TMVB_OK;
 }
 
-// train! (src/gpuCTPF.jl:677-705 signature, src/CTPF.jl:344-376 semantics).  The CTPF ELBO
-// (src/CTPF.jl:111-247) is not evaluated on the device in this release: checkelbo must be Inf (<= 0),
-// the setting the reference's own README uses for CTPF timing.
+// update_elbo! (src/CTPF.jl:234-247) on the device; returns the sum over this context's documents plus -- on every
+// rank -- the global (beta, eta) terms, so a multi-process host must add the ranks' per-document parts only once
+// with the global part (tmvb_ctpf_update_elbo_parts).
+extern "C" int tmvb_ctpf_update_elbo_parts(tmvb_ctpf* h, double* doc_part, double* global_part)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_ctpf_update_elbo: handle is NULL");
+    tmvb_ctx* ctx = h->ctx;
+    TMVB_HIP(hipSetDevice(ctx->device));
+    int rc;
+    // rowsums of the CURRENT shapes (Elogpya/Elogpyb/Elogpz use sum(he, dims=2), sum(alef, dims=2))
+    if ((rc = tmvb_colsum(ctx, 1, h->K, h->d_alef, h->V, h->d_partial, h->d_rs_alef, nullptr))) return rc;
+    if (h->U > 0) { if ((rc = tmvb_colsum(ctx, 1, h->K, h->d_he, h->U, h->d_partial, h->d_rs_he, nullptr))) return rc; }
+    else TMVB_HIP(hipMemsetAsync(h->d_rs_he, 0, (size_t)h->K * sizeof(double), ctx->stream));
+    const double* hy = h->hyper;
+    double res[2] = {0.0, 0.0};
+    // global part
+    const int nb = 256;
+    hipLaunchKernelGGL(ctpf_elbo_global_kernel, dim3(nb), dim3(256), 0, ctx->stream, h->d_alef, h->V, h->K, h->d_rates, hy[0], hy[1], h->d_elbo_partial);
+    hipLaunchKernelGGL(ctpf_elbo_global_kernel, dim3(nb), dim3(256), 0, ctx->stream, h->d_he, h->U, h->K, h->d_rates + h->K, hy[4], hy[5], h->d_elbo_partial + nb);
+    TMVB_HIP(hipGetLastError());
+    const double cst = (double)h->V * h->K * (hy[0] * std::log(hy[1]) - std::lgamma(hy[0])) + (double)h->U * h->K * (hy[4] * std::log(hy[5]) - std::lgamma(hy[4]));
+    hipLaunchKernelGGL(ctpf_elbo_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, h->d_doc_val, (int64_t)0, h->d_elbo_partial, 2 * nb, cst, h->d_elbo);
+    TMVB_HIP(hipMemcpyAsync(&res[1], h->d_elbo, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    TMVB_HIP(hipStreamSynchronize(ctx->stream));
+    // per-document part
+    if (h->M > 0) {
+        hipLaunchKernelGGL(ctpf_elbo_doc_kernel, dim3((unsigned)h->M), dim3(64), 0, ctx->stream, h->K, h->corp->d_doc_ptr, h->corp->d_terms,
+                           h->corp->d_counts, h->corp->d_rdr_ptr, h->corp->d_readers, h->corp->d_ratings, h->d_alef, h->d_alef_old, h->d_he,
+                           h->d_he_old, h->d_rates, h->d_rs_alef, h->d_rs_he, h->d_gimel, h->d_gimel_old, h->d_zayin, h->d_zayin_old,
+                           hy[2], hy[3], hy[6], hy[7], h->d_doc_val);
+        TMVB_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(ctpf_elbo_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, h->d_doc_val, h->M, h->d_elbo_partial, 0, 0.0, h->d_elbo);
+    TMVB_HIP(hipMemcpyAsync(&res[0], h->d_elbo, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    TMVB_HIP(hipStreamSynchronize(ctx->stream));
+    if (doc_part) *doc_part = res[0];
+    if (global_part) *global_part = res[1];
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_ctpf_update_elbo(tmvb_ctpf* h, double* elbo)
+{
+    double dp = 0.0, gp = 0.0;
+    int rc = tmvb_ctpf_update_elbo_parts(h, &dp, &gp);
+    if (rc) return rc;
+    h->elbo = dp + gp;
+    if (elbo) *elbo = h->elbo;
+    return TMVB_OK;
+}
+
+// train! (src/gpuCTPF.jl:677-705 signature, src/CTPF.jl:344-376 semantics incl. check_elbo!).  checkelbo <= 0 means Inf.
 extern "C" int tmvb_ctpf_train(tmvb_ctpf* h, int32_t iter, double tol, int32_t viter, double vtol, int32_t checkelbo,
                                double* elbo_traj, int32_t* iters_done)
 {
     TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_ctpf_train: handle is NULL");
     TMVB_REQUIRE(tol >= 0 && vtol >= 0, TMVB_EINVAL, "tolerance parameters must be nonnegative.");
     TMVB_REQUIRE(iter >= 0 && viter >= 0, TMVB_EINVAL, "iteration parameters must be nonnegative.");
-    TMVB_REQUIRE(checkelbo <= 0, TMVB_EINVAL, "tmvb_ctpf_train: the CTPF ELBO is not evaluated on the device in this release; pass checkelbo = Inf");
     TMVB_REQUIRE(!h->distributed, TMVB_EINVAL, "tmvb_ctpf_train drives one context");
     if (iters_done) *iters_done = 0;
     if (h->corp->info.nnz == 0) iter = 0;                                   // src/gpuCTPF.jl:682
     int rc, done = 0;
+    double e_old = h->elbo;
+    if (checkelbo > 0 && checkelbo <= iter) { if ((rc = tmvb_ctpf_update_elbo(h, &e_old))) return rc; }   // :683
     for (int k = 1; k <= iter; ++k) {
         ++done;
         if ((rc = tmvb_ctpf_estep(h, viter, vtol))) return rc;
         if ((rc = tmvb_ctpf_reduce_docs(h))) return rc;
         if ((rc = tmvb_ctpf_mstep(h))) return rc;
         if (elbo_traj) elbo_traj[k - 1] = NAN;
+        if (checkelbo > 0 && (k % checkelbo) == 0) {                        // check_elbo! src/modelutils.jl:574-585
+            double e_new;
+            if ((rc = tmvb_ctpf_update_elbo(h, &e_new))) return rc;
+            TMVB_REQUIRE(std::isfinite(e_new), TMVB_ENONFINITE, "elbo must be finite.");
+            if (elbo_traj) elbo_traj[k - 1] = e_new;
+            const double delta = e_new - e_old;
+            e_old = e_new;
+            if (delta < tol) break;
+        }
     }
     TMVB_HIP(hipStreamSynchronize(h->ctx->stream));
     if (iters_done) *iters_done = done;

@@ -112,6 +112,12 @@ class gpuCTPF:
     def reduce_docs(self): check(lib().tmvb_ctpf_reduce_docs(self.handle))
     def mstep(self): check(lib().tmvb_ctpf_mstep(self.handle))
 
+    def update_elbo(self) -> float:
+        out = C.c_double(0.0)
+        check(lib().tmvb_ctpf_update_elbo(self.handle, C.byref(out)))
+        self.elbo = out.value
+        return out.value
+
     def stats(self):
         p, n = VP(), C.c_int64(0)
         check(lib().tmvb_ctpf_stats(self.handle, C.byref(p), C.byref(n)))
@@ -136,9 +142,9 @@ class gpuCTPF:
     def synchronize(self):
         self.ctx.synchronize()
 
-    def train(self, iter: int = 150, tol: float = 1.0, viter: int = 10, vtol: float | None = None, checkelbo=math.inf,
+    def train(self, iter: int = 150, tol: float = 1.0, viter: int = 10, vtol: float | None = None, checkelbo=1,
               printelbo: bool = True):
-        """train!(model::gpuCTPF; ...) src/gpuCTPF.jl:677-705.  checkelbo must be Inf in this release."""
+        """train!(model::gpuCTPF; ...) src/gpuCTPF.jl:677-705."""
         vtol = 1.0 / self.K ** 2 if vtol is None else vtol
         check_model_ctpf(self)
         _validate_train_args([tol, vtol], [iter, viter], checkelbo)
@@ -150,6 +156,13 @@ class gpuCTPF:
                                     C.c_int32(ce), _pd(traj), C.byref(done)))
         if iter > 0:
             self.update_host()
+        if printelbo and ce:
+            prev = None
+            for k, e in enumerate(traj[:done.value], start=1):
+                if not np.isnan(e):
+                    if prev is not None:
+                        print(k, " ∆elbo: ", round(e - prev, 3))
+                    prev = e
         Ebeta = self.alef / self.bet[:, None]                                                     # :707-708
         self.topics = [np.argsort(-Ebeta[i, :], kind="stable") + 1 for i in range(self.K)]
         return traj[:done.value]
