@@ -39,6 +39,19 @@ __device__ __forceinline__ void swap_add16(float& a, float b)
     asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
     a += b;                                   // even rows: sums of a, odd rows: sums of b
 }
+// two independent swaps under one pair of hazard nops
+__device__ __forceinline__ void swap_add32_x2(float& a0, float b0, float& a1, float b1)
+{
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\ts_nop 1"
+                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1));
+    a0 += b0; a1 += b1;
+}
+__device__ __forceinline__ void swap_add16_x2(float& a0, float b0, float& a1, float b1)
+{
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 1"
+                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1));
+    a0 += b0; a1 += b1;
+}
 template <int CTRL>
 __device__ __forceinline__ void dpp_stage(float& a, float b, bool hi)
 {
@@ -51,10 +64,14 @@ __device__ __forceinline__ float lane_reduce_scatter(float (&p)[R], int lane)
 {
     constexpr int m0 = R, h0 = (m0 + 1) / 2;
 #pragma unroll
-    for (int i = 0; i < h0; ++i) swap_add32(p[i], (i + h0 < m0) ? p[i + h0] : p[i]);
+    for (int i = 0; i + 1 < h0; i += 2)
+        swap_add32_x2(p[i], (i + h0 < m0) ? p[i + h0] : p[i], p[i + 1], (i + 1 + h0 < m0) ? p[i + 1 + h0] : p[i + 1]);
+    if (h0 & 1) swap_add32(p[h0 - 1], (h0 - 1 + h0 < m0) ? p[h0 - 1 + h0] : p[h0 - 1]);
     constexpr int m1 = h0, h1 = (m1 + 1) / 2;
 #pragma unroll
-    for (int i = 0; i < h1; ++i) swap_add16(p[i], (i + h1 < m1) ? p[i + h1] : p[i]);
+    for (int i = 0; i + 1 < h1; i += 2)
+        swap_add16_x2(p[i], (i + h1 < m1) ? p[i + h1] : p[i], p[i + 1], (i + 1 + h1 < m1) ? p[i + 1 + h1] : p[i + 1]);
+    if (h1 & 1) swap_add16(p[h1 - 1], (h1 - 1 + h1 < m1) ? p[h1 - 1 + h1] : p[h1 - 1]);
     constexpr int m2 = h1, h2 = (m2 + 1) / 2;
     const bool b8 = lane & 8, b4 = lane & 4, b2 = lane & 2, b1 = lane & 1;
 #pragma unroll
@@ -83,6 +100,41 @@ __device__ __forceinline__ float lane_reduce_scatter(float (&p)[R], int lane)
     // p[0 .. ceil(R/64)) now hold the totals: lane L of result register s owns topic pi(s, L)
     return p[0];
 }
+
+// Compile-time replay of lane_reduce_scatter's pairing: lane_of_topic[q] = s * 64 + L of the primary owner
+// of topic q, topic_of_lane[s * 64 + L] = the topic owned there (-1 for duplicates), spare = a slot of the
+// last result register that owns no topic (-1 if none).  With the map a constant, the e_q broadcasts of the
+// register-tile kernel are v_readlane with an IMMEDIATE lane (no selector SGPRs, no SGPR spills).
+template <int R>
+struct RegLaneMap {
+    static constexpr int NS = (R + 63) / 64;
+    int lane_of_topic[R];
+    int topic_of_lane[NS * 64];
+    int spare;
+    constexpr RegLaneMap() : lane_of_topic{}, topic_of_lane{}, spare(-1)
+    {
+        int cur[R][64] = {}, nxt[R][64] = {};
+        for (int q = 0; q < R; ++q) for (int l = 0; l < 64; ++l) cur[q][l] = q;
+        int m = R;
+        const int Ds[6] = {32, 16, 8, 4, 2, 1};
+        for (int st = 0; st < 6; ++st) {
+            const int D = Ds[st], h = (m + 1) / 2;
+            for (int i = 0; i < h; ++i)
+                for (int l = 0; l < 64; ++l) nxt[i][l] = (i + h < m && (l & D)) ? cur[i + h][l] : cur[i][l];
+            for (int i = 0; i < h; ++i) for (int l = 0; l < 64; ++l) cur[i][l] = nxt[i][l];
+            m = h;
+        }
+        for (int q = 0; q < R; ++q) lane_of_topic[q] = -1;
+        for (int i = 0; i < NS * 64; ++i) topic_of_lane[i] = -1;
+        for (int sl = 0; sl < NS; ++sl)
+            for (int l = 0; l < 64; ++l) {
+                const int q = cur[sl][l];
+                if (lane_of_topic[q] < 0) { lane_of_topic[q] = sl * 64 + l; topic_of_lane[sl * 64 + l] = q; }
+            }
+        for (int l = 63; l >= 0; --l) if (topic_of_lane[(NS - 1) * 64 + l] < 0) { spare = (NS - 1) * 64 + l; break; }
+    }
+};
+template <int R> constexpr RegLaneMap<R> kRegLaneMap{};
 
 // host replay of lane_reduce_scatter's pairing: which topic ends up in which (result register, lane).
 // topic_of_lane[s * 64 + L] = topic owned by lane L of result register s (-1 for duplicates);
@@ -255,9 +307,10 @@ static inline int tmvb_colsum(tmvb_ctx* ctx, int nslot, int K, const float* X, i
 static inline bool tmvb_termstats_recomputes(int KP, bool e_padded) { return e_padded && KP / 4 <= 16; }
 
 static inline int tmvb_launch_termstats(tmvb_ctx* ctx, int nslot, int KP, bool e_padded, const tmvb_inv_index& ix,
-                                        TermStatsParams tp)
+                                        TermStatsParams tp, hipStream_t on_stream = nullptr)
 {
     if (ix.n_chunks <= 0) return TMVB_OK;
+    hipStream_t st = on_stream ? on_stream : ctx->stream;
     tp.tok_doc = ix.d_doc; tp.tok_pos = ix.d_pos; tp.chunk_id = ix.d_chunk_id; tp.chunk_begin = ix.d_chunk_begin;
     tp.chunk_end = ix.d_chunk_end; tp.chunk_out = ix.d_chunk_out; tp.n_chunks = (int)ix.n_chunks;
     tp.tok_val = ix.d_val;
@@ -266,17 +319,17 @@ static inline int tmvb_launch_termstats(tmvb_ctx* ctx, int nslot, int KP, bool e
         const dim3 grid((unsigned)((ix.n_chunks + 3) / 4)), block(256);
         const int lpr = KP / 4;
         if (e_padded && lpr <= 16) {       // recompute w from (T row, E row, count): no per-token weights in memory
-            if (lpr == 13) hipLaunchKernelGGL((termstats_recompute_kernel<13>), grid, block, 0, ctx->stream, tp, lpr);
-            else hipLaunchKernelGGL((termstats_recompute_kernel<0>), grid, block, 0, ctx->stream, tp, lpr);
+            if (lpr == 13) hipLaunchKernelGGL((termstats_recompute_kernel<13>), grid, block, 0, st, tp, lpr);
+            else hipLaunchKernelGGL((termstats_recompute_kernel<0>), grid, block, 0, st, tp, lpr);
         } else if (e_padded) {
-            if (lpr == 13) hipLaunchKernelGGL((termstats_chunk4_kernel<13>), grid, block, 0, ctx->stream, tp, lpr);
-            else if (lpr == 25) hipLaunchKernelGGL((termstats_chunk4_kernel<25>), grid, block, 0, ctx->stream, tp, lpr);
-            else hipLaunchKernelGGL((termstats_chunk4_kernel<0>), grid, block, 0, ctx->stream, tp, lpr);
+            if (lpr == 13) hipLaunchKernelGGL((termstats_chunk4_kernel<13>), grid, block, 0, st, tp, lpr);
+            else if (lpr == 25) hipLaunchKernelGGL((termstats_chunk4_kernel<25>), grid, block, 0, st, tp, lpr);
+            else hipLaunchKernelGGL((termstats_chunk4_kernel<0>), grid, block, 0, st, tp, lpr);
         } else {
-            hipLaunchKernelGGL((termstats_chunk_kernel<NS>), grid, block, 0, ctx->stream, tp);
+            hipLaunchKernelGGL((termstats_chunk_kernel<NS>), grid, block, 0, st, tp);
         }
         if (ix.n_multi > 0)
-            hipLaunchKernelGGL((termstats_multi_kernel<NS>), dim3((unsigned)ix.n_multi), dim3(256), 0, ctx->stream, tp,
+            hipLaunchKernelGGL((termstats_multi_kernel<NS>), dim3((unsigned)ix.n_multi), dim3(256), 0, st, tp,
                                ix.d_multi_id, ix.d_multi_first, ix.d_multi_count, (int)ix.n_multi);
         return TMVB_OK;
     });

@@ -215,23 +215,30 @@ extern "C" int tmvb_corpus_create(tmvb_ctx* ctx, int64_t M, int64_t V, int64_t U
 }
 
 int tmvb_build_inv_index(tmvb_ctx* ctx, int64_t M, int64_t n_ids, const int64_t* h_ptr, const int32_t* h_ids,
-                         const int32_t* h_vals, tmvb_inv_index* ix)
+                         const int32_t* h_vals, tmvb_inv_index* ix, const int32_t* doc_piece, int piece)
 {
-    const int64_t nnz = h_ptr[M];
-    TMVB_REQUIRE(nnz < (int64_t)INT32_MAX, TMVB_EINVAL, "inverted index: token count must fit int32");
-    ix->n_ids = n_ids; ix->nnz = nnz;
+    const int64_t nnz_all = h_ptr[M];
+    TMVB_REQUIRE(nnz_all < (int64_t)INT32_MAX, TMVB_EINVAL, "inverted index: token count must fit int32");
+    auto in_piece = [&](int64_t d) { return doc_piece == nullptr || doc_piece[d] == piece; };
     std::vector<int64_t> cnt(n_ids + 1, 0);
-    for (int64_t q = 0; q < nnz; ++q) cnt[h_ids[q] + 1]++;
+    for (int64_t d = 0; d < M; ++d)
+        if (in_piece(d))
+            for (int64_t q = h_ptr[d]; q < h_ptr[d + 1]; ++q) cnt[h_ids[q] + 1]++;
     for (int64_t j = 0; j < n_ids; ++j) cnt[j + 1] += cnt[j];
-    std::vector<int32_t> doc(nnz), pos(nnz), inv(nnz);
+    const int64_t nnz = cnt[n_ids];
+    ix->n_ids = n_ids; ix->nnz = nnz;
+    std::vector<int32_t> doc(nnz), pos(nnz), inv(doc_piece ? 0 : nnz_all);
     std::vector<float> val(nnz);
     {
         std::vector<int64_t> cur(cnt.begin(), cnt.end() - 1);
-        for (int64_t d = 0; d < M; ++d)
+        for (int64_t d = 0; d < M; ++d) {
+            if (!in_piece(d)) continue;
             for (int64_t q = h_ptr[d]; q < h_ptr[d + 1]; ++q) {
                 int64_t w = cur[h_ids[q]]++;
-                doc[w] = (int32_t)d; pos[w] = (int32_t)q; inv[q] = (int32_t)w; val[w] = (float)h_vals[q];
+                doc[w] = (int32_t)d; pos[w] = (int32_t)q; val[w] = (float)h_vals[q];
+                if (!doc_piece) inv[q] = (int32_t)w;
             }
+        }
     }
     std::vector<int32_t> cid, cb, ce, co, mid, mfirst, mcount;
     int64_t slots = 0;

@@ -47,6 +47,7 @@ struct tmvb_bucket {
     int64_t first = 0, count = 0;
     int32_t tile_rows = 0;
     int32_t reg_tiles = 0;     // > 0: register-tile kernel with this many 64-token tiles (no LDS tile)
+    int32_t piece = 0;         // pipelined E-step: which statistics pass consumes this bucket's documents
 };
 
 // Inverted (id-major) index over a CSR token stream, cut into chunks of at most TMVB_CHUNK tokens.
@@ -72,8 +73,9 @@ struct tmvb_inv_index {
     int32_t* d_multi_count = nullptr;  // [n_multi] number of partial slots
     int64_t n_slots = 0;
 };
+// doc_piece != NULL restricts the index to the documents d with doc_piece[d] == piece (pipelined E-step)
 int tmvb_build_inv_index(tmvb_ctx* ctx, int64_t M, int64_t n_ids, const int64_t* h_ptr, const int32_t* h_ids,
-                         const int32_t* h_vals, tmvb_inv_index* out);
+                         const int32_t* h_vals, tmvb_inv_index* out, const int32_t* doc_piece = nullptr, int piece = 0);
 void tmvb_free_inv_index(tmvb_inv_index* ix);
 
 struct tmvb_corpus {
@@ -178,6 +180,29 @@ __device__ __forceinline__ double wave_sum_d(double v)
     return v;
 }
 
+// a / b through v_rcp_f32 and one Newton step (4 VALU instructions; the IEEE sequence is 10).  The
+// refined reciprocal is within 1 ulp; b must be finite, non-zero and normal (true at every call site:
+// s_n >= K eps, digamma arguments >= eps).
+__device__ __forceinline__ float fast_rcp(float b)
+{
+    float r = __builtin_amdgcn_rcpf(b);
+    return fmaf(fmaf(-b, r, 1.0f), r, r);
+}
+__device__ __forceinline__ float fast_div(float a, float b) { return a * fast_rcp(b); }
+
+// exp(x) for the E-step (x = Elogtheta <= 0 in exact arithmetic): 2^n * 2^f with the product x*log2(e)
+// carried in two floats, 8 VALU instructions (libm expf: 18); relative error < 2 ulp.  x is clamped
+// at -150 (result 0 either way) so that -inf cannot turn into inf - inf.
+__device__ __forceinline__ float fast_exp(float x)
+{
+    x = fmaxf(x, -150.0f);
+    const float t = x * 1.44269502162933349609375f;
+    const float n = __builtin_rintf(t);
+    float f = fmaf(x, 1.44269502162933349609375f, -n);
+    f = fmaf(x, 1.925963033500011e-08f, f);              // low part of log2(e)
+    return __builtin_amdgcn_ldexpf(__builtin_amdgcn_exp2f(f), (int)n);
+}
+
 // digamma, x > 0, fp32.  Same algorithm as the reference's helper (src/utils.jl:21-53):
 // upward recurrence then the asymptotic series; done branch-free with a fixed 6-step shift,
 // and 4 series terms (the 5th is < 1e-10 at x >= 6).
@@ -192,9 +217,9 @@ __device__ __forceinline__ float digamma_f(float x)
         float p01 = a0 * a1, p23 = a2 * a3, p45 = a4 * a5;
         // 1/a0+1/a1 = (a0+a1)/p01 etc.
         float n01 = a0 + a1, n23 = a2 + a3, n45 = a4 + a5;
-        rec = n01 / p01 + (n23 / p23 + n45 / p45);
+        rec = fast_div(n01, p01) + (fast_div(n23, p23) + fast_div(n45, p45));
     }
-    float t = 1.0f / y;
+    float t = fast_rcp(y);
     float psi = logf(y) - 0.5f * t;
     float w = t * t;
     float p = -0.004166666666666667f;

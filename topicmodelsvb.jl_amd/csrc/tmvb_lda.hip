@@ -26,12 +26,15 @@
 // Roofline: HBM-bound gather/scatter.  Algorithmic bytes per outer iteration:
 //   nnz*(8 + 4K + 4K) + 12*M*K + 12*K*V + 4*(M+1).
 #include "tmvb_common_kernels.h"
+#include <utility>
 
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
 
+
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 struct LdaParams {
     int K, KP, LPR;          // topics, padded row stride (4*odd), 16-byte chunks per row (KP/4)
@@ -262,6 +265,35 @@ __global__ __launch_bounds__(64) void lda_estep_kernel(LdaParams p, int64_t firs
     if (lane == 0) p.sweeps[d] = (uint8_t)min(sweeps, 255);
 }
 
+// e_q broadcasts of one block of <= 32 topics: v_readlane with an immediate lane (the lane map is a
+// compile-time constant), results in SGPR pairs consumed directly by v_pk_fma_f32.
+template <int R, int Q> struct LaneOfTopic { static constexpr int value = kRegLaneMap<R>.lane_of_topic[Q]; };
+
+template <int R, int Q0, int NS, int... I>
+__device__ __forceinline__ void lda_bcast_e(float (&es)[sizeof...(I)], const float (&e)[NS], std::integer_sequence<int, I...>)
+{
+    ((es[I] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(
+                  __builtin_bit_cast(int, LaneOfTopic<R, Q0 + I>::value < 64 ? e[0] : e[NS - 1]),
+                  LaneOfTopic<R, Q0 + I>::value & 63))), ...);
+}
+
+// phase 1 for topics [Q0, Q0 + 32): sacc[t] += B[t][q] e_q, two topics per packed fma
+template <int R, int T, int Q0>
+__device__ __forceinline__ void lda_phase1_block(const v2f (&B2)[T][R / 2], const float (&e)[(R + 63) / 64], v2f (&sacc)[T][2])
+{
+    constexpr int QB = (R - Q0 < 32) ? R - Q0 : 32;
+    float es[QB];
+    lda_bcast_e<R, Q0>(es, e, std::make_integer_sequence<int, QB>{});
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+#pragma unroll
+        for (int q = 0; q < QB; q += 2) {
+            const v2f e2 = v2f{es[q], es[q + 1]};
+            sacc[t][(q >> 1) & 1] = __builtin_elementwise_fma(B2[t][(Q0 + q) / 2], e2, sacc[t][(q >> 1) & 1]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------ register-tile E-step
 // For K <= 64 and documents of at most 64*T unique terms the whole N_d x KP topic tile lives in
 // VGPRs (lane = token, register = topic): the register file (512 KiB per CU) is 3x the LDS, so the
@@ -283,8 +315,10 @@ __global__ __launch_bounds__(64) void lda_estep_reg_kernel(LdaParams p, int64_t 
     const int64_t off = p.doc_ptr[d];
     const int N = (int)(p.doc_ptr[d + 1] - off);
 
-    // token role: lane n owns tokens n + 64 t
-    float B[T][R], c[T], w[T];
+    // token role: lane n owns tokens n + 64 t; the tile is held as topic PAIRS so that both phases run on
+    // packed fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32: two fp32 lanes-ops per issue slot)
+    v2f B2[T][R / 2];
+    float c[T], w[T];
     int wpos[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) {
@@ -297,17 +331,19 @@ __global__ __launch_bounds__(64) void lda_estep_reg_kernel(LdaParams p, int64_t 
 #pragma unroll
             for (int q = 0; q < LPR; ++q) {
                 const float4 v = row[q];
-                B[t][4 * q] = v.x; B[t][4 * q + 1] = v.y; B[t][4 * q + 2] = v.z; B[t][4 * q + 3] = v.w;
+                B2[t][2 * q] = v2f{v.x, v.y}; B2[t][2 * q + 1] = v2f{v.z, v.w};
             }
         } else {
             c[t] = 0.0f; wpos[t] = -1;
 #pragma unroll
-            for (int q = 0; q < R; ++q) B[t][q] = 0.0f;
+            for (int q = 0; q < R / 2; ++q) B2[t][q] = v2f{0.0f, 0.0f};
         }
         w[t] = 0.0f;
     }
     // topic role: lane L of result slot sl owns topic pi(sl, L) (duplicates are marked -1 by the host)
     constexpr int NS = (R + 63) / 64;
+    constexpr int SPARE = kRegLaneMap<R>.spare;                    // a lane of the last result slot that owns no topic
+    static_assert(SPARE >= 0, "register-tile kernel needs a spare lane for digamma(sum gamma)");
     int mytopic[NS];
     bool on[NS];
     float alpha[NS], elog[NS], elog_old[NS], gam[NS], e[NS];
@@ -319,56 +355,37 @@ __global__ __launch_bounds__(64) void lda_estep_reg_kernel(LdaParams p, int64_t 
         elog[sl] = on[sl] ? p.elog[(int64_t)d * K + mytopic[sl]] : 0.0f;
         elog_old[sl] = elog[sl]; gam[sl] = 0.0f; e[sl] = 0.0f;
     }
+    (void)lane_of_topic;
 
     int sweeps = 0;
     for (int v = 0; v < p.viter; ++v) {
         ++sweeps;
 #pragma unroll
-        for (int sl = 0; sl < NS; ++sl) e[sl] = on[sl] ? expf(elog[sl]) : 0.0f;     // update_phi!, src/LDA.jl:152
+        for (int sl = 0; sl < NS; ++sl) e[sl] = on[sl] ? fast_exp(elog[sl]) : 0.0f;     // update_phi!, src/LDA.jl:152
         // phase 1 in blocks of 32 topics: the e_q of a block live in SGPRs only while the block is consumed
-        float sacc[T][4];
+        v2f sacc[T][2];
 #pragma unroll
-        for (int t = 0; t < T; ++t) { sacc[t][0] = 0.f; sacc[t][1] = 0.f; sacc[t][2] = 0.f; sacc[t][3] = 0.f; }
-#pragma unroll
-        for (int q0 = 0; q0 < R; q0 += 32) {
-            constexpr int QB = 32;
-            float es[QB];
-#pragma unroll
-            for (int q = 0; q < QB; ++q) {
-                if (q0 + q < R) {
-                    const int lt = lane_of_topic[q0 + q];
-                    const float src = (NS == 1 || lt < 64) ? e[0] : e[NS - 1];
-                    es[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, src), lt & 63));
-                } else {
-                    es[q] = 0.0f;
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < T; ++t) {
-#pragma unroll
-                for (int q = 0; q < QB; q += 4) {
-                    if (q0 + q < R) {
-                        sacc[t][0] = fmaf(B[t][q0 + q], es[q], sacc[t][0]); sacc[t][1] = fmaf(B[t][q0 + q + 1], es[q + 1], sacc[t][1]);
-                        sacc[t][2] = fmaf(B[t][q0 + q + 2], es[q + 2], sacc[t][2]); sacc[t][3] = fmaf(B[t][q0 + q + 3], es[q + 3], sacc[t][3]);
-                    }
-                }
-            }
-        }
+        for (int t = 0; t < T; ++t) { sacc[t][0] = v2f{0.f, 0.f}; sacc[t][1] = v2f{0.f, 0.f}; }
+        lda_phase1_block<R, T, 0>(B2, e, sacc);
+        if constexpr (R > 32) lda_phase1_block<R, T, 32>(B2, e, sacc);
+        if constexpr (R > 64) lda_phase1_block<R, T, 64>(B2, e, sacc);
+        if constexpr (R > 96) lda_phase1_block<R, T, 96>(B2, e, sacc);
         float wl = 0.0f;
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-            const float sn = ((sacc[t][0] + sacc[t][1]) + (sacc[t][2] + sacc[t][3])) + (float)K * TMVB_EPS_F;
-            w[t] = c[t] / sn;
+            const v2f s2 = sacc[t][0] + sacc[t][1];
+            const float sn = (s2.x + s2.y) + (float)K * TMVB_EPS_F;
+            w[t] = fast_div(c[t], sn);
             wl += w[t];
         }
         const float wsum = wave_sum(wl);
         float pr[R];
 #pragma unroll
-        for (int q = 0; q < R; ++q) {
-            float a = w[0] * B[0][q];
+        for (int q = 0; q < R / 2; ++q) {
+            v2f a = B2[0][q] * v2f{w[0], w[0]};
 #pragma unroll
-            for (int t = 1; t < T; ++t) a = fmaf(w[t], B[t][q], a);
-            pr[q] = a;
+            for (int t = 1; t < T; ++t) a = __builtin_elementwise_fma(B2[t][q], v2f{w[t], w[t]}, a);
+            pr[2 * q] = a.x; pr[2 * q + 1] = a.y;
         }
         (void)lane_reduce_scatter<R>(pr, lane);
         float gl = 0.0f;
@@ -378,13 +395,18 @@ __global__ __launch_bounds__(64) void lda_estep_reg_kernel(LdaParams p, int64_t 
             if (on[sl]) gl += gam[sl];
         }
         const float gsum = wave_sum(gl);
-        const float dgs = digamma_f(gsum);
+        // digamma(gamma_k) and digamma(sum gamma) in ONE evaluation: the spare lane takes the sum
+        float dg[NS];
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl)
+            dg[sl] = digamma_f((sl == NS - 1 && lane == (SPARE & 63)) ? gsum : gam[sl]);
+        const float dgs = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dg[NS - 1]), SPARE & 63));
         float dl = 0.0f;
 #pragma unroll
         for (int sl = 0; sl < NS; ++sl) {
             elog_old[sl] = elog[sl];                                  // update_Elogtheta!, :137-138
             if (on[sl]) {
-                elog[sl] = digamma_f(gam[sl]) - dgs;
+                elog[sl] = dg[sl] - dgs;
                 const float df = elog[sl] - elog_old[sl];
                 dl = fmaf(df, df, dl);
             }
@@ -613,6 +635,11 @@ struct tmvb_lda {
     static constexpr int NAUX = 4;
     hipStream_t aux[NAUX] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[NAUX] = {nullptr, nullptr, nullptr, nullptr};
+    // pipelined E-step (large corpora, recomputed-weight statistics): the documents are cut into `pieces`
+    // of about equal token count, each with its own inverted index; the HBM-bound statistics pass of piece
+    // p runs on the context's stream while the VALU-bound document kernels of piece p+1 run on aux[0].
+    std::vector<tmvb_inv_index> pieces;
+    std::vector<hipEvent_t> ev_piece;
 };
 
 static bool lda_reg_lpr_supported(int lpr) { return lpr == 1 || lpr == 3 || lpr == 5 || lpr == 13 || lpr == 25; }
@@ -640,6 +667,46 @@ static void lda_build_buckets(tmvb_lda* h, std::vector<int32_t>& order)
     }
 }
 
+static int lda_piece_count(const tmvb_lda* h)
+{
+    if (!tmvb_termstats_recomputes(h->KP, h->estride == h->KP) || !h->reg_path) return 1;
+    if (const char* e = getenv("TMVB_LDA_PIECES")) return std::max(1, std::min(16, atoi(e)));
+    return h->corp->info.nnz >= (int64_t)(1 << 21) ? 4 : 1;
+}
+
+// Cut the register-tile buckets where the running token count crosses a multiple of nnz / P.  The LDS-tile
+// (long-document) buckets go with the LAST piece: they are issued first, on their own stream, and have the
+// whole E-step to finish.  Fills doc_piece[d] and replaces h->buckets.
+static void lda_cut_pieces(tmvb_lda* h, const std::vector<int32_t>& order, int P, std::vector<int32_t>& doc_piece)
+{
+    const std::vector<int64_t>& len = h->corp->h_doc_len;
+    const int64_t nnz = std::max<int64_t>(h->corp->info.nnz, 1);
+    doc_piece.assign(h->M, 0);
+    std::vector<tmvb_bucket> cut;
+    int64_t run = 0;
+    for (const tmvb_bucket& b : h->buckets) {
+        if (b.reg_tiles == 0) {
+            tmvb_bucket c = b; c.piece = P - 1;
+            for (int64_t q = b.first; q < b.first + b.count; ++q) doc_piece[order[q]] = P - 1;
+            cut.push_back(c);
+            continue;
+        }
+        int64_t start = b.first;
+        int piece = (int)std::min<int64_t>(P - 1, run * P / nnz);
+        for (int64_t q = b.first; q < b.first + b.count; ++q) {
+            const int pq = (int)std::min<int64_t>(P - 1, run * P / nnz);
+            if (pq != piece) {
+                if (q > start) { tmvb_bucket c = b; c.first = start; c.count = q - start; c.piece = piece; cut.push_back(c); }
+                start = q; piece = pq;
+            }
+            doc_piece[order[q]] = pq;
+            run += len[order[q]];
+        }
+        if (b.first + b.count > start) { tmvb_bucket c = b; c.first = start; c.count = b.first + b.count - start; c.piece = piece; cut.push_back(c); }
+    }
+    h->buckets.swap(cut);
+}
+
 extern "C" int tmvb_lda_destroy(tmvb_lda* h)
 {
     if (!h) return TMVB_OK;
@@ -654,6 +721,8 @@ extern "C" int tmvb_lda_destroy(tmvb_lda* h)
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    for (tmvb_inv_index& ix : h->pieces) tmvb_free_inv_index(&ix);
+    for (hipEvent_t e : h->ev_piece) if (e) (void)hipEventDestroy(e);
     for (int a = 0; a < tmvb_lda::NAUX; ++a) {
         if (h->ev_join[a]) (void)hipEventDestroy(h->ev_join[a]);
         if (h->aux[a]) (void)hipStreamDestroy(h->aux[a]);
@@ -706,8 +775,7 @@ extern "C" int tmvb_lda_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
         (rc = dmalloc(&h->d_doc_order, (size_t)h->M)) || (rc = dmalloc(&h->d_partial, (size_t)TMVB_REDUCE_BLOCKS * K)) ||
         (rc = dmalloc(&h->d_rowsum, K)) || (rc = dmalloc(&h->d_esum, K)) || (rc = dmalloc(&h->d_doc_val, (size_t)h->M)) ||
         (rc = dmalloc(&h->d_elbo, 1)) || (rc = dmalloc(&h->d_iters, 1)) || (rc = dmalloc(&h->d_wtok, (size_t)corp->info.nnz)) ||
-        (rc = dmalloc(&h->d_E, (size_t)h->KP * h->M + 4)) || (rc = tmvb_corpus_term_index(corp)) ||
-        (rc = dmalloc(&h->d_ts_partial, (size_t)corp->term_index.n_slots * (K + 1)))) {
+        (rc = dmalloc(&h->d_E, (size_t)h->KP * h->M + 4))) {
         tmvb_lda_destroy(h);
         return rc;
     }
@@ -721,6 +789,27 @@ extern "C" int tmvb_lda_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
     }
     std::vector<int32_t> order;
     lda_build_buckets(h, order);
+    {
+        const int P = lda_piece_count(h);
+        size_t slots = 0;
+        if (P > 1) {
+            std::vector<int32_t> doc_piece;
+            lda_cut_pieces(h, order, P, doc_piece);
+            h->pieces.resize(P);
+            h->ev_piece.assign(P, nullptr);
+            for (int q = 0; q < P && !rc; ++q) {
+                rc = tmvb_build_inv_index(ctx, h->M, h->V, corp->h_doc_ptr.data(), corp->h_terms.data(), corp->h_counts.data(),
+                                          &h->pieces[q], doc_piece.data(), q);
+                slots = std::max(slots, (size_t)h->pieces[q].n_slots);
+                if (!rc && hipEventCreateWithFlags(&h->ev_piece[q], hipEventDisableTiming) != hipSuccess) rc = TMVB_EHIP;
+            }
+        } else {
+            rc = tmvb_corpus_term_index(corp);
+            slots = (size_t)corp->term_index.n_slots;
+        }
+        if (!rc) rc = dmalloc(&h->d_ts_partial, slots * (K + 1));
+        if (rc) { tmvb_lda_destroy(h); return rc; }
+    }
     if (h->M) TMVB_HIP(hipMemcpyAsync(h->d_doc_order, order.data(), (size_t)h->M * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     TMVB_HIP(hipMemsetAsync(h->d_stats, 0, (KV + K) * sizeof(float), ctx->stream));
     TMVB_HIP(hipMemsetAsync(h->d_sweeps, 0, std::max<size_t>((size_t)h->M, 1), ctx->stream));
@@ -807,21 +896,50 @@ extern "C" int tmvb_lda_estep(tmvb_lda* h, int32_t viter, double vtol)
     p.K = h->K; p.KP = h->KP; p.LPR = h->KP / 4; p.lpr_magic = (unsigned)(0x100000000ull / (unsigned)p.LPR) + 1u; p.V = h->V;
     p.doc_ptr = h->corp->d_doc_ptr; p.terms = h->corp->d_terms; p.counts = h->corp->d_counts;
     p.doc_order = h->d_doc_order;
-    p.alpha = h->d_alpha_f; p.beta = h->d_beta[h->cur]; p.wtok = h->d_wtok; p.tok_inv = h->corp->term_index.d_inv; p.E = h->d_E; p.estride = h->estride;
+    p.alpha = h->d_alpha_f; p.beta = h->d_beta[h->cur]; p.wtok = h->d_wtok; p.tok_inv = h->pieces.empty() ? h->corp->term_index.d_inv : nullptr; p.E = h->d_E; p.estride = h->estride;
     p.gamma = h->d_gamma; p.elog = h->d_elog; p.elog_old = h->d_elog_old; p.sweeps = h->d_sweeps;
     p.viter = viter; p.vtol = (float)vtol;
     { const char* dbg = getenv("TMVB_DEBUG_FLAGS"); p.debug = dbg ? atoi(dbg) : 0; }
     p.store_w = tmvb_termstats_recomputes(h->KP, h->estride == h->KP) ? 0 : 1;
     TMVB_HIP(hipEventRecord(h->ev0, ctx->stream));
     const int nb = (int)h->buckets.size();
+    const int P = (int)h->pieces.size();               // 0: one statistics pass after all document kernels
     const int naux = std::min(nb, (int)tmvb_lda::NAUX);
-    if (naux > 1) {
+    if (naux > 1 || P > 1) {
         TMVB_HIP(hipEventRecord(h->ev_fork, ctx->stream));
-        for (int a = 0; a < naux; ++a) TMVB_HIP(hipStreamWaitEvent(h->aux[a], h->ev_fork, 0));
+        for (int a = 0; a < (P > 1 ? 2 : naux); ++a) TMVB_HIP(hipStreamWaitEvent(h->aux[a], h->ev_fork, 0));
     }
+    TermStatsParams tp;
+    tp.K = h->K; tp.tstride = h->KP; tp.ostride = h->K;
+    tp.w = h->d_wtok; tp.E = h->d_E; tp.T = h->d_beta[h->cur]; tp.eps = TMVB_EPS_F; tp.base = 0.0f; tp.keps = (float)h->K * TMVB_EPS_F;
+    tp.out = h->d_stats; tp.partial = h->d_ts_partial;
+    // gather-side statistics of the documents whose kernels precede `after` on its stream:
+    //   S[:, j] += beta[:, j] .* sum_tokens w E[:, doc] + eps sum w     (update_beta!(model, d))
+    auto stats_pass = [&](const tmvb_inv_index& ix) -> int {
+        if ((p.debug & 1) || ix.n_chunks <= 0) return TMVB_OK;
+        return tmvb_launch_termstats(ctx, h->nslot, h->KP, h->estride == h->KP, ix, tp);
+    };
+    int piece_open = 0;                                 // pieces [0, piece_open) have their statistics pass issued
+    auto close_pieces = [&](int upto) -> int {          // document kernels of pieces < upto are all issued
+        for (; piece_open < upto; ++piece_open) {
+            if (piece_open == P - 1) {                  // the last piece also holds the long documents (aux[1])
+                TMVB_HIP(hipEventRecord(h->ev_join[1], h->aux[1]));
+                TMVB_HIP(hipStreamWaitEvent(h->aux[0], h->ev_join[1], 0));
+            }
+            TMVB_HIP(hipEventRecord(h->ev_piece[piece_open], h->aux[0]));
+            TMVB_HIP(hipStreamWaitEvent(ctx->stream, h->ev_piece[piece_open], 0));
+            int rc = stats_pass(h->pieces[piece_open]);
+            if (rc) return rc;
+        }
+        return TMVB_OK;
+    };
     for (int bi = 0; bi < nb; ++bi) {
         const tmvb_bucket& b = h->buckets[bi];
         hipStream_t st = (naux > 1) ? h->aux[bi % naux] : ctx->stream;
+        if (P > 1) {
+            st = b.reg_tiles > 0 ? h->aux[0] : h->aux[1];
+            if (b.reg_tiles > 0) { int rc = close_pieces(b.piece); if (rc) return rc; }
+        }
         if (b.reg_tiles > 0) {
             const dim3 grid((unsigned)b.count), block(64);
             const int* tol = h->d_topic_of_lane; const int* lot = h->d_lane_of_topic;
@@ -867,22 +985,18 @@ extern "C" int tmvb_lda_estep(tmvb_lda* h, int32_t viter, double vtol)
         if (rc) return rc;
         TMVB_HIP(hipGetLastError());
     }
-    if (naux > 1) {
-        for (int a = 0; a < naux; ++a) {
-            TMVB_HIP(hipEventRecord(h->ev_join[a], h->aux[a]));
-            TMVB_HIP(hipStreamWaitEvent(ctx->stream, h->ev_join[a], 0));
-        }
-    }
-    // gather-side statistics: S[:, j] = beta[:, j] .* sum_tokens w E[:, doc] + eps sum w   (update_beta!(model, d))
-    const tmvb_inv_index& ix = h->corp->term_index;
-    if (!(p.debug & 1) && ix.n_chunks > 0) {
-        TermStatsParams tp;
-        tp.K = h->K; tp.tstride = h->KP; tp.ostride = h->K;
-        tp.w = h->d_wtok; tp.E = h->d_E; tp.T = h->d_beta[h->cur]; tp.eps = TMVB_EPS_F; tp.base = 0.0f; tp.keps = (float)h->K * TMVB_EPS_F;
-        tp.out = h->d_stats; tp.partial = h->d_ts_partial;
-        int rc = tmvb_launch_termstats(ctx, h->nslot, h->KP, h->estride == h->KP, ix, tp);
+    if (P > 1) {
+        int rc = close_pieces(P);
         if (rc) return rc;
-        TMVB_HIP(hipGetLastError());
+    } else {
+        if (naux > 1) {
+            for (int a = 0; a < naux; ++a) {
+                TMVB_HIP(hipEventRecord(h->ev_join[a], h->aux[a]));
+                TMVB_HIP(hipStreamWaitEvent(ctx->stream, h->ev_join[a], 0));
+            }
+        }
+        int rc = stats_pass(h->corp->term_index);
+        if (rc) return rc;
     }
     TMVB_HIP(hipEventRecord(h->ev1, ctx->stream));
     h->timed = true;

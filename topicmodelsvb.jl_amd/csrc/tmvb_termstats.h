@@ -8,7 +8,9 @@
 // with a per-token scalar w_n and a per-document K-vector E, so the statistics column of an id j is
 //       out[i,j] = T[i,j] * sum_{tokens n of j} w_n E[i, doc_n]  + eps * sum w_n .
 // One wave per chunk of <= TMVB_CHUNK tokens of one id (lane = topic): coalesced K-float reads of E
-// rows, no atomics, fixed summation order => bitwise reproducible statistics.
+// rows, no atomics, fixed summation order => bitwise reproducible statistics.  The kernels ACCUMULATE into
+// `out` (the reference's `X_temp +=`): an id is written by exactly one wave per pass, passes are ordered on
+// one stream, and the M-step resets the statistics (update_beta! / update_alef! / update_he!).
 #pragma once
 #include "tmvb_internal.h"
 
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(256) void termstats_chunk_kernel(TermStatsParams p)
 #pragma unroll
         for (int s = 0; s < NSLOT; ++s) {
             const int i = lane + 64 * s;
-            if (i < K) p.out[(int64_t)j * p.ostride + i] = p.base + fmaf(p.T[(int64_t)j * p.tstride + i], acc[s], p.eps * wsum);
+            if (i < K) p.out[(int64_t)j * p.ostride + i] += p.base + fmaf(p.T[(int64_t)j * p.tstride + i], acc[s], p.eps * wsum);
         }
     } else {
         float* pr = p.partial + (int64_t)slot * (K + 1);
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(256) void termstats_chunk4_kernel(TermStatsParams p
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int i = 4 * lane + u;
-            if (i < K) p.out[(int64_t)j * p.ostride + i] = p.base + fmaf(p.T[(int64_t)j * p.tstride + i], tv[u], p.eps * wsum);
+            if (i < K) p.out[(int64_t)j * p.ostride + i] += p.base + fmaf(p.T[(int64_t)j * p.tstride + i], tv[u], p.eps * wsum);
         }
     } else {
         float* pr = p.partial + (int64_t)slot * (K + 1);
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(256) void termstats_recompute_kernel(TermStatsParam
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int i = 4 * lane + u;
-            if (i < K) p.out[(int64_t)j * p.ostride + i] = p.base + fmaf(tjv[u], tv[u], p.eps * wsum);
+            if (i < K) p.out[(int64_t)j * p.ostride + i] += p.base + fmaf(tjv[u], tv[u], p.eps * wsum);
         }
     } else {
         float* pr = p.partial + (int64_t)slot * (K + 1);
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(256) void termstats_multi_kernel(TermStatsParams p,
         const int i = lane + 64 * s;
         if (i < K) {
             const float a = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
-            p.out[(int64_t)j * p.ostride + i] = p.base + fmaf(p.T[(int64_t)j * p.tstride + i], a, p.eps * ws);
+            p.out[(int64_t)j * p.ostride + i] += p.base + fmaf(p.T[(int64_t)j * p.tstride + i], a, p.eps * ws);
         }
     }
 }
