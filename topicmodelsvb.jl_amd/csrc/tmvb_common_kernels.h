@@ -287,17 +287,18 @@ static int download_f32(tmvb_ctx* ctx, double* dst, const float* src, size_t n)
 
 // deterministic column sums of a K x ncols fp32 matrix into out_d (fp64) and/or out_f (fp32)
 static inline int tmvb_colsum(tmvb_ctx* ctx, int nslot, int K, const float* X, int64_t ncols, double* d_partial,
-                              double* out_d, float* out_f)
+                              double* out_d, float* out_f, hipStream_t on_stream = nullptr)
 {
+    hipStream_t st = on_stream ? on_stream : ctx->stream;
     int nb = (int)std::min<int64_t>(TMVB_REDUCE_BLOCKS, std::max<int64_t>(1, (ncols + 3) / 4));
     int rc = dispatch_nslot(nslot, [&](auto ns) -> int {
         constexpr int NS = decltype(ns)::value;
-        hipLaunchKernelGGL((colsum_partial_kernel<NS>), dim3(nb), dim3(256), 0, ctx->stream, X, ncols, K, d_partial);
+        hipLaunchKernelGGL((colsum_partial_kernel<NS>), dim3(nb), dim3(256), 0, st, X, ncols, K, d_partial);
         return TMVB_OK;
     });
     if (rc) return rc;
     TMVB_HIP(hipGetLastError());
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((K + 3) / 4), dim3(256), 0, ctx->stream, d_partial, nb, K, out_d, out_f);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((K + 3) / 4), dim3(256), 0, st, d_partial, nb, K, out_d, out_f);
     TMVB_HIP(hipGetLastError());
     return TMVB_OK;
 }

@@ -640,6 +640,15 @@ struct tmvb_lda {
     // p runs on the context's stream while the VALU-bound document kernels of piece p+1 run on aux[0].
     std::vector<tmvb_inv_index> pieces;
     std::vector<hipEvent_t> ev_piece;
+    // side chain: the Elogtheta column sums depend on the document kernels only, so they run on aux[SIDE]
+    // under the statistics pass; update_alpha! (one wave of fp64 Newton steps) runs there under update_beta!.
+    // The context's stream waits for the side chain before either entry point returns, so callers see the
+    // usual single-stream ordering.
+    static constexpr int SIDE = 2;
+    hipEvent_t ev_docs = nullptr, ev_side = nullptr, ev_mark = nullptr;
+    double* d_partial_side = nullptr;
+    bool esum_fresh = false;           // d_esum / statistics tail hold the sums of the current Elogtheta
+    bool mark_valid = false;           // ev_mark was recorded at the entry of the preceding update_beta call
 };
 
 static bool lda_reg_lpr_supported(int lpr) { return lpr == 1 || lpr == 3 || lpr == 5 || lpr == 13 || lpr == 25; }
@@ -721,6 +730,10 @@ extern "C" int tmvb_lda_destroy(tmvb_lda* h)
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_docs) (void)hipEventDestroy(h->ev_docs);
+    if (h->ev_side) (void)hipEventDestroy(h->ev_side);
+    if (h->ev_mark) (void)hipEventDestroy(h->ev_mark);
+    (void)hipFree(h->d_partial_side);
     for (tmvb_inv_index& ix : h->pieces) tmvb_free_inv_index(&ix);
     for (hipEvent_t e : h->ev_piece) if (e) (void)hipEventDestroy(e);
     for (int a = 0; a < tmvb_lda::NAUX; ++a) {
@@ -816,6 +829,10 @@ extern "C" int tmvb_lda_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
     TMVB_HIP(hipEventCreate(&h->ev0));
     TMVB_HIP(hipEventCreate(&h->ev1));
     TMVB_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    TMVB_HIP(hipEventCreateWithFlags(&h->ev_docs, hipEventDisableTiming));
+    TMVB_HIP(hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming));
+    TMVB_HIP(hipEventCreateWithFlags(&h->ev_mark, hipEventDisableTiming));
+    if ((rc = dmalloc(&h->d_partial_side, (size_t)TMVB_REDUCE_BLOCKS * K))) { tmvb_lda_destroy(h); return rc; }
     for (int a = 0; a < tmvb_lda::NAUX; ++a) {
         TMVB_HIP(hipStreamCreateWithFlags(&h->aux[a], hipStreamNonBlocking));
         TMVB_HIP(hipEventCreateWithFlags(&h->ev_join[a], hipEventDisableTiming));
@@ -838,6 +855,7 @@ extern "C" int tmvb_lda_set_state(tmvb_lda* h, const double* alpha, const double
                                   const double* elbo)
 {
     TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_lda_set_state: handle is NULL");
+    h->mark_valid = false; h->esum_fresh = false;
     tmvb_ctx* ctx = h->ctx;
     TMVB_HIP(hipSetDevice(ctx->device));
     const size_t K = h->K, KV = K * (size_t)h->V, KM = K * (size_t)h->M;
@@ -868,6 +886,7 @@ extern "C" int tmvb_lda_get_state(tmvb_lda* h, double* alpha, double* beta, doub
                                   double* Elogtheta, double* Elogtheta_old, double* elbo)
 {
     TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_lda_get_state: handle is NULL");
+    h->mark_valid = false;
     tmvb_ctx* ctx = h->ctx;
     TMVB_HIP(hipSetDevice(ctx->device));
     const size_t K = h->K, KV = K * (size_t)h->V, KM = K * (size_t)h->M;
@@ -891,6 +910,7 @@ extern "C" int tmvb_lda_estep(tmvb_lda* h, int32_t viter, double vtol)
     TMVB_REQUIRE(viter >= 0, TMVB_EINVAL, "iteration parameters must be nonnegative.");     // src/gpuLDA.jl:350
     TMVB_REQUIRE(vtol >= 0, TMVB_EINVAL, "tolerance parameters must be nonnegative.");      // src/gpuLDA.jl:349
     tmvb_ctx* ctx = h->ctx;
+    h->mark_valid = false; h->esum_fresh = false;
     TMVB_HIP(hipSetDevice(ctx->device));
     LdaParams p;
     p.K = h->K; p.KP = h->KP; p.LPR = h->KP / 4; p.lpr_magic = (unsigned)(0x100000000ull / (unsigned)p.LPR) + 1u; p.V = h->V;
@@ -985,9 +1005,11 @@ extern "C" int tmvb_lda_estep(tmvb_lda* h, int32_t viter, double vtol)
         if (rc) return rc;
         TMVB_HIP(hipGetLastError());
     }
+    hipStream_t side = h->aux[tmvb_lda::SIDE];
     if (P > 1) {
         int rc = close_pieces(P);
         if (rc) return rc;
+        TMVB_HIP(hipStreamWaitEvent(side, h->ev_piece[P - 1], 0));       // recorded after the last document kernel
     } else {
         if (naux > 1) {
             for (int a = 0; a < naux; ++a) {
@@ -995,8 +1017,18 @@ extern "C" int tmvb_lda_estep(tmvb_lda* h, int32_t viter, double vtol)
                 TMVB_HIP(hipStreamWaitEvent(ctx->stream, h->ev_join[a], 0));
             }
         }
+        TMVB_HIP(hipEventRecord(h->ev_docs, ctx->stream));
+        TMVB_HIP(hipStreamWaitEvent(side, h->ev_docs, 0));
         int rc = stats_pass(h->corp->term_index);
         if (rc) return rc;
+    }
+    // Elogtheta_sum (update_alpha!'s input, src/LDA.jl:98) under the statistics pass
+    {
+        int rc = tmvb_colsum(ctx, h->nslot, h->K, h->d_elog, h->M, h->d_partial_side, h->d_esum, h->d_stats + (size_t)h->K * h->V, side);
+        if (rc) return rc;
+        TMVB_HIP(hipEventRecord(h->ev_side, side));
+        TMVB_HIP(hipStreamWaitEvent(ctx->stream, h->ev_side, 0));
+        h->esum_fresh = true;
     }
     TMVB_HIP(hipEventRecord(h->ev1, ctx->stream));
     h->timed = true;
@@ -1012,6 +1044,8 @@ extern "C" int tmvb_lda_reduce_docs(tmvb_lda* h)
 {
     TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_lda_reduce_docs: handle is NULL");
     TMVB_HIP(hipSetDevice(h->ctx->device));
+    h->mark_valid = false;
+    if (h->esum_fresh) { h->esum_fresh = false; return TMVB_OK; }   // enqueued by tmvb_lda_estep (side chain)
     return colsum(h, h->d_elog, h->M, h->d_esum, h->d_stats + (size_t)h->K * h->V);
 }
 
@@ -1028,6 +1062,7 @@ extern "C" int tmvb_lda_bind_stats(tmvb_lda* h, void* dev_ptr, int64_t n_f32)
     TMVB_REQUIRE(h && dev_ptr, TMVB_EINVAL, "tmvb_lda_bind_stats: NULL argument");
     const int64_t need = (int64_t)h->K * h->V + h->K;
     TMVB_REQUIRE(n_f32 >= need, TMVB_ESHAPE, "tmvb_lda_bind_stats: buffer holds %lld floats, need %lld", (long long)n_f32, (long long)need);
+    h->mark_valid = false;
     TMVB_HIP(hipSetDevice(h->ctx->device));
     TMVB_HIP(hipMemcpyAsync(dev_ptr, h->d_stats, (size_t)need * sizeof(float), hipMemcpyDeviceToDevice, h->ctx->stream));
     TMVB_HIP(hipStreamSynchronize(h->ctx->stream));
@@ -1041,6 +1076,7 @@ extern "C" int tmvb_lda_set_distributed(tmvb_lda* h, int64_t M_total, int32_t di
 {
     TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_lda_set_distributed: handle is NULL");
     TMVB_REQUIRE(M_total >= h->M, TMVB_ESHAPE, "tmvb_lda_set_distributed: M_total < local M");
+    h->mark_valid = false;
     h->M_total = M_total;
     h->distributed = distributed != 0;
     return TMVB_OK;
@@ -1051,6 +1087,8 @@ extern "C" int tmvb_lda_update_beta(tmvb_lda* h)
     TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_lda_update_beta: handle is NULL");
     tmvb_ctx* ctx = h->ctx;
     TMVB_HIP(hipSetDevice(ctx->device));
+    TMVB_HIP(hipEventRecord(h->ev_mark, ctx->stream));      // update_alpha! may start from here (it shares nothing with update_beta!)
+    h->mark_valid = true;
     int rc = colsum(h, h->d_stats, h->V, h->d_rowsum, nullptr);
     if (rc) return rc;
     const int64_t total = (int64_t)h->KP * h->V;
@@ -1070,20 +1108,27 @@ extern "C" int tmvb_lda_update_alpha(tmvb_lda* h, int32_t niter, double ntol)
     tmvb_ctx* ctx = h->ctx;
     TMVB_HIP(hipSetDevice(ctx->device));
     const float* ef = h->distributed ? h->d_stats + (size_t)h->K * h->V : nullptr;
+    hipStream_t side = h->aux[tmvb_lda::SIDE];
+    if (!h->mark_valid) TMVB_HIP(hipEventRecord(h->ev_mark, ctx->stream));
+    h->mark_valid = false;
+    TMVB_HIP(hipStreamWaitEvent(side, h->ev_mark, 0));
     int rc = dispatch_nslot(h->nslot, [&](auto ns) -> int {
         constexpr int NS = decltype(ns)::value;
-        hipLaunchKernelGGL((lda_alpha_kernel<NS>), dim3(1), dim3(64), 0, ctx->stream, h->K, (double)h->M_total, h->d_esum, ef,
+        hipLaunchKernelGGL((lda_alpha_kernel<NS>), dim3(1), dim3(64), 0, side, h->K, (double)h->M_total, h->d_esum, ef,
                            h->d_alpha_d, h->d_alpha_f, niter, ntol, h->d_iters);
         return TMVB_OK;
     });
     if (rc) return rc;
     TMVB_HIP(hipGetLastError());
+    TMVB_HIP(hipEventRecord(h->ev_side, side));
+    TMVB_HIP(hipStreamWaitEvent(ctx->stream, h->ev_side, 0));
     return TMVB_OK;
 }
 
 extern "C" int tmvb_lda_update_elbo(tmvb_lda* h, double* elbo)
 {
     TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_lda_update_elbo: handle is NULL");
+    h->mark_valid = false;
     tmvb_ctx* ctx = h->ctx;
     TMVB_HIP(hipSetDevice(ctx->device));
     if (h->M > 0) {
