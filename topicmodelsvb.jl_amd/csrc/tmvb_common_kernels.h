@@ -39,18 +39,22 @@ __device__ __forceinline__ void swap_add16(float& a, float b)
     asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
     a += b;                                   // even rows: sums of a, odd rows: sums of b
 }
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+
 // two independent swaps under one pair of hazard nops
 __device__ __forceinline__ void swap_add32_x2(float& a0, float b0, float& a1, float b1)
 {
     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\ts_nop 1"
                  : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1));
-    a0 += b0; a1 += b1;
+    const v2f_t s = v2f_t{a0, a1} + v2f_t{b0, b1};       // one v_pk_add_f32
+    a0 = s.x; a1 = s.y;
 }
 __device__ __forceinline__ void swap_add16_x2(float& a0, float b0, float& a1, float b1)
 {
     asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 1"
                  : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1));
-    a0 += b0; a1 += b1;
+    const v2f_t s = v2f_t{a0, a1} + v2f_t{b0, b1};
+    a0 = s.x; a1 = s.y;
 }
 template <int CTRL>
 __device__ __forceinline__ void dpp_stage(float& a, float b, bool hi)
@@ -67,11 +71,13 @@ __device__ __forceinline__ float lane_reduce_scatter(float (&p)[R], int lane)
     for (int i = 0; i + 1 < h0; i += 2)
         swap_add32_x2(p[i], (i + h0 < m0) ? p[i + h0] : p[i], p[i + 1], (i + 1 + h0 < m0) ? p[i + 1 + h0] : p[i + 1]);
     if (h0 & 1) swap_add32(p[h0 - 1], (h0 - 1 + h0 < m0) ? p[h0 - 1 + h0] : p[h0 - 1]);
-    constexpr int m1 = h0, h1 = (m1 + 1) / 2;
+    // stage 16 pairs whole register PAIRS (units) so that the adds stay packed: with U = m1 / 2 units, unit u
+    // meets unit u + ceil(U / 2); for odd U the middle unit folds its own two halves.  (R % 4 == 0 => m1 even.)
+    static_assert(R % 4 == 0, "lane_reduce_scatter: R must be a multiple of 4");
+    constexpr int m1 = h0, U = m1 / 2, H = (U + 1) / 2, h1 = (m1 + 1) / 2;
 #pragma unroll
-    for (int i = 0; i + 1 < h1; i += 2)
-        swap_add16_x2(p[i], (i + h1 < m1) ? p[i + h1] : p[i], p[i + 1], (i + 1 + h1 < m1) ? p[i + 1 + h1] : p[i + 1]);
-    if (h1 & 1) swap_add16(p[h1 - 1], (h1 - 1 + h1 < m1) ? p[h1 - 1 + h1] : p[h1 - 1]);
+    for (int u = 0; u < U / 2; ++u) swap_add16_x2(p[2 * u], p[2 * (u + H)], p[2 * u + 1], p[2 * (u + H) + 1]);
+    if (U & 1) swap_add16(p[U - 1], p[U]);
     constexpr int m2 = h1, h2 = (m2 + 1) / 2;
     const bool b8 = lane & 8, b4 = lane & 4, b2 = lane & 2, b1 = lane & 1;
 #pragma unroll
@@ -119,8 +125,16 @@ struct RegLaneMap {
         const int Ds[6] = {32, 16, 8, 4, 2, 1};
         for (int st = 0; st < 6; ++st) {
             const int D = Ds[st], h = (m + 1) / 2;
-            for (int i = 0; i < h; ++i)
-                for (int l = 0; l < 64; ++l) nxt[i][l] = (i + h < m && (l & D)) ? cur[i + h][l] : cur[i][l];
+            if (st == 1) {                      // unit pairing of stage 16 (see lane_reduce_scatter)
+                const int U = m / 2, H = (U + 1) / 2;
+                for (int u = 0; u < U / 2; ++u)
+                    for (int c = 0; c < 2; ++c)
+                        for (int l = 0; l < 64; ++l) nxt[2 * u + c][l] = (l & D) ? cur[2 * (u + H) + c][l] : cur[2 * u + c][l];
+                if (U & 1) for (int l = 0; l < 64; ++l) nxt[U - 1][l] = (l & D) ? cur[U][l] : cur[U - 1][l];
+            } else {
+                for (int i = 0; i < h; ++i)
+                    for (int l = 0; l < 64; ++l) nxt[i][l] = (i + h < m && (l & D)) ? cur[i + h][l] : cur[i][l];
+            }
             for (int i = 0; i < h; ++i) for (int l = 0; l < 64; ++l) cur[i][l] = nxt[i][l];
             m = h;
         }
@@ -136,30 +150,22 @@ struct RegLaneMap {
 };
 template <int R> constexpr RegLaneMap<R> kRegLaneMap{};
 
-// host replay of lane_reduce_scatter's pairing: which topic ends up in which (result register, lane).
-// topic_of_lane[s * 64 + L] = topic owned by lane L of result register s (-1 for duplicates);
-// lane_of_topic[q] = s * 64 + L of the primary owner of topic q.
+// host copy of the compile-time map (the register-tile kernels exist for these R only)
 static inline int tmvb_reg_lane_maps(int R, std::vector<int>& topic_of_lane, std::vector<int>& lane_of_topic)
 {
-    std::vector<std::vector<int>> regs(R, std::vector<int>(64));
-    for (int q = 0; q < R; ++q) for (int l = 0; l < 64; ++l) regs[q][l] = q;
-    const int Ds[6] = {32, 16, 8, 4, 2, 1};
-    for (int st = 0; st < 6; ++st) {
-        const int D = Ds[st], m = (int)regs.size(), h = (m + 1) / 2;
-        std::vector<std::vector<int>> nxt(h, std::vector<int>(64));
-        for (int i = 0; i < h; ++i)
-            for (int l = 0; l < 64; ++l) nxt[i][l] = (i + h < m && (l & D)) ? regs[i + h][l] : regs[i][l];
-        regs.swap(nxt);
+    auto copy = [&](const auto& m) {
+        topic_of_lane.assign(m.topic_of_lane, m.topic_of_lane + sizeof(m.topic_of_lane) / sizeof(int));
+        lane_of_topic.assign(m.lane_of_topic, m.lane_of_topic + sizeof(m.lane_of_topic) / sizeof(int));
+        return (int)(sizeof(m.topic_of_lane) / sizeof(int) / 64);
+    };
+    switch (R) {
+        case 4: return copy(kRegLaneMap<4>);
+        case 12: return copy(kRegLaneMap<12>);
+        case 20: return copy(kRegLaneMap<20>);
+        case 52: return copy(kRegLaneMap<52>);
+        case 100: return copy(kRegLaneMap<100>);
+        default: return 0;
     }
-    const int NS = (int)regs.size();
-    topic_of_lane.assign((size_t)NS * 64, -1);
-    lane_of_topic.assign(R, -1);
-    for (int sl = 0; sl < NS; ++sl)
-        for (int l = 0; l < 64; ++l) {
-            int q = regs[sl][l];
-            if (lane_of_topic[q] < 0) { lane_of_topic[q] = sl * 64 + l; topic_of_lane[(size_t)sl * 64 + l] = q; }
-        }
-    return NS;
 }
 
 

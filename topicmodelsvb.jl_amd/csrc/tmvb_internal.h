@@ -153,11 +153,12 @@ __device__ __forceinline__ float wave_sum(float v)
     v += dpp_f<0x4E>(v);    // quad_perm [2,3,0,1]
     v += dpp_f<0x141>(v);   // row_half_mirror
     v += dpp_f<0x140>(v);   // row_mirror  -> every lane of a 16-lane row holds the row sum
-    float r = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
-    r += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
-    r += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
-    r += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
-    return r;
+    // gfx9 wave-level DPP: rows 1 and 3 add lane 15 of the row before, then rows 2 and 3 add lane 31:
+    // lane 63 holds the wave total ((r0 + r1) + (r2 + r3), a fixed order)
+    // (inline asm: the builtin form is not folded into v_add_f32_dpp; s_nop = VALU-write -> DPP-read wait states)
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 0" : "+v"(v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 __device__ __forceinline__ float wave_max(float v)
