@@ -615,6 +615,7 @@ struct tmvb_lda {
     float* d_wtok = nullptr;           // [nnz]
     float* d_E = nullptr;              // [M][estride]
     int estride = 0;
+    bool e_padded = false;             // E rows are zero padded to >= KP floats (float4 statistics kernels)
     float* d_ts_partial = nullptr;     // [n_slots][K+1]
     int* d_topic_of_lane = nullptr;    // register-tile kernel lane maps
     int* d_lane_of_topic = nullptr;
@@ -678,7 +679,7 @@ static void lda_build_buckets(tmvb_lda* h, std::vector<int32_t>& order)
 
 static int lda_piece_count(const tmvb_lda* h)
 {
-    if (!tmvb_termstats_recomputes(h->KP, h->estride == h->KP) || !h->reg_path) return 1;
+    if (!tmvb_termstats_recomputes(h->KP, h->e_padded) || !h->reg_path) return 1;
     if (const char* e = getenv("TMVB_LDA_PIECES")) return std::max(1, std::min(16, atoi(e)));
     return h->corp->info.nnz >= (int64_t)(1 << 21) ? 4 : 1;
 }
@@ -778,7 +779,9 @@ extern "C" int tmvb_lda_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
     tmvb_lda* h = new tmvb_lda();
     h->ctx = ctx; h->corp = corp; h->K = K; h->KP = tmvb_kpad(K); h->nslot = (K + 63) / 64;
     h->M = corp->info.M; h->V = corp->info.V; h->M_total = h->M;
-    h->estride = (h->KP / 4 <= 64) ? h->KP : K;
+    h->e_padded = h->KP / 4 <= 64;
+    // padded rows start on 128-byte lines when they span more than one (K = 50: 52 -> 64 floats)
+    h->estride = h->e_padded ? (h->KP > 32 ? (h->KP + 31) / 32 * 32 : h->KP) : K;
     const size_t KV = (size_t)K * h->V, KM = (size_t)K * h->M;
     const size_t KPV = (size_t)h->KP * h->V + 4;      // padded gather layout (+ slack for 16-byte reads)
     int rc;
@@ -788,7 +791,7 @@ extern "C" int tmvb_lda_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
         (rc = dmalloc(&h->d_doc_order, (size_t)h->M)) || (rc = dmalloc(&h->d_partial, (size_t)TMVB_REDUCE_BLOCKS * K)) ||
         (rc = dmalloc(&h->d_rowsum, K)) || (rc = dmalloc(&h->d_esum, K)) || (rc = dmalloc(&h->d_doc_val, (size_t)h->M)) ||
         (rc = dmalloc(&h->d_elbo, 1)) || (rc = dmalloc(&h->d_iters, 1)) || (rc = dmalloc(&h->d_wtok, (size_t)corp->info.nnz)) ||
-        (rc = dmalloc(&h->d_E, (size_t)h->KP * h->M + 4))) {
+        (rc = dmalloc(&h->d_E, (size_t)((h->KP + 31) / 32 * 32) * h->M + 4))) {
         tmvb_lda_destroy(h);
         return rc;
     }
@@ -920,7 +923,7 @@ extern "C" int tmvb_lda_estep(tmvb_lda* h, int32_t viter, double vtol)
     p.gamma = h->d_gamma; p.elog = h->d_elog; p.elog_old = h->d_elog_old; p.sweeps = h->d_sweeps;
     p.viter = viter; p.vtol = (float)vtol;
     { const char* dbg = getenv("TMVB_DEBUG_FLAGS"); p.debug = dbg ? atoi(dbg) : 0; }
-    p.store_w = tmvb_termstats_recomputes(h->KP, h->estride == h->KP) ? 0 : 1;
+    p.store_w = tmvb_termstats_recomputes(h->KP, h->e_padded) ? 0 : 1;
     TMVB_HIP(hipEventRecord(h->ev0, ctx->stream));
     const int nb = (int)h->buckets.size();
     const int P = (int)h->pieces.size();               // 0: one statistics pass after all document kernels
@@ -932,12 +935,12 @@ extern "C" int tmvb_lda_estep(tmvb_lda* h, int32_t viter, double vtol)
     TermStatsParams tp;
     tp.K = h->K; tp.tstride = h->KP; tp.ostride = h->K;
     tp.w = h->d_wtok; tp.E = h->d_E; tp.T = h->d_beta[h->cur]; tp.eps = TMVB_EPS_F; tp.base = 0.0f; tp.keps = (float)h->K * TMVB_EPS_F;
-    tp.out = h->d_stats; tp.partial = h->d_ts_partial;
+    tp.out = h->d_stats; tp.partial = h->d_ts_partial; tp.estride = h->e_padded ? h->estride : 0;
     // gather-side statistics of the documents whose kernels precede `after` on its stream:
     //   S[:, j] += beta[:, j] .* sum_tokens w E[:, doc] + eps sum w     (update_beta!(model, d))
     auto stats_pass = [&](const tmvb_inv_index& ix) -> int {
         if ((p.debug & 1) || ix.n_chunks <= 0) return TMVB_OK;
-        return tmvb_launch_termstats(ctx, h->nslot, h->KP, h->estride == h->KP, ix, tp);
+        return tmvb_launch_termstats(ctx, h->nslot, h->KP, h->e_padded, ix, tp);
     };
     int piece_open = 0;                                 // pieces [0, piece_open) have their statistics pass issued
     auto close_pieces = [&](int upto) -> int {          // document kernels of pieces < upto are all issued

@@ -28,7 +28,9 @@ struct TermStatsParams {
     const float* w;              // [nnz] per-token weight, id-major (inverted index) order (legacy kernels)
     const float* tok_val;        // [nnz] count / rating per token, id-major order (recompute kernel)
     float keps;                  // K * eps added to the recomputed normaliser (LDA), 0 otherwise
-    const float* E;              // per-document factor: [M][K] (scalar kernel) or [M][KP] zero padded (chunk4 kernel)
+    const float* E;              // per-document factor: [M][K] (scalar kernel) or [M][estride] zero padded (float4 kernels)
+    int estride = 0;             // row stride of the padded E (>= KP; 0 = KP).  A 128-byte-aligned stride makes every
+                                 // gathered row touch the minimum number of cache lines (13% faster gather at K = 50)
     const float* T;              // [n_ids][tstride] per-id factor
     float eps;                   // additive epsilon (LDA: EPSILON, others 0)
     float base;                  // value added to every written entry (CTPF priors a / e; else 0)
@@ -101,6 +103,7 @@ __global__ __launch_bounds__(256) void termstats_chunk4_kernel(TermStatsParams p
     const int c = blockIdx.x * 4 + wv;
     const int LPR = LPR_T ? LPR_T : LPR_rt;
     const int KP = 4 * LPR;
+    const int ES = p.estride ? p.estride : KP;
     const int RPI = 64 / LPR;              // rows per instruction
     const int rs = lane / LPR, cc = lane - rs * LPR;
     const bool lane_on = rs < RPI;
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(256) void termstats_chunk4_kernel(TermStatsParams p
 #pragma unroll 8
             for (int k = rs; k < cnt; k += RPI) {
                 const int2 dw = dw_l[wv][k];
-                const float4 ev = *(const float4*)(p.E + (int64_t)dw.x * KP + 4 * cc);
+                const float4 ev = *(const float4*)(p.E + (int64_t)dw.x * ES + 4 * cc);
                 const float wk = __builtin_bit_cast(float, dw.y);
                 acc.x = fmaf(wk, ev.x, acc.x); acc.y = fmaf(wk, ev.y, acc.y);
                 acc.z = fmaf(wk, ev.z, acc.z); acc.w = fmaf(wk, ev.w, acc.w);
@@ -177,6 +180,7 @@ __global__ __launch_bounds__(256) void termstats_recompute_kernel(TermStatsParam
     const int c = blockIdx.x * 4 + wv;
     const int LPR = LPR_T ? LPR_T : LPR_rt;
     const int KP = 4 * LPR;
+    const int ES = p.estride ? p.estride : KP;
     const int rs = lane >> 4, cc = lane & 15;
     const bool lane_on = cc < LPR;
     const bool active = c < p.n_chunks;
@@ -200,7 +204,7 @@ __global__ __launch_bounds__(256) void termstats_recompute_kernel(TermStatsParam
             const bool row_on = kk < cnt;
             const int2 dw = dw_l[wv][min(kk, 63)];
             float4 ev = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row_on && lane_on) ev = *(const float4*)(p.E + (int64_t)dw.x * KP + 4 * cc);
+            if (row_on && lane_on) ev = *(const float4*)(p.E + (int64_t)dw.x * ES + 4 * cc);
             float part = fmaf(tj.x, ev.x, fmaf(tj.y, ev.y, fmaf(tj.z, ev.z, tj.w * ev.w)));
             part += dpp_f<0xB1>(part);
             part += dpp_f<0x4E>(part);
