@@ -188,7 +188,9 @@ __global__ __launch_bounds__(256) void termstats_recompute_kernel(TermStatsParam
     const int b = active ? p.chunk_begin[c] : 0, e = active ? p.chunk_end[c] : 0;
     float4 tj = make_float4(0.f, 0.f, 0.f, 0.f);
     if (active && lane_on) tj = *(const float4*)(p.T + (int64_t)j * p.tstride + 4 * cc);
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const v2f tlo = v2f{tj.x, tj.y}, thi = v2f{tj.z, tj.w};
+    v2f alo = v2f{0.f, 0.f}, ahi = v2f{0.f, 0.f};          // packed fp32 accumulators (v_pk_fma_f32)
     float wl = 0.0f;
     for (int t0 = b; t0 < e; t0 += 64) {
         const int tok = t0 + lane;
@@ -198,27 +200,29 @@ __global__ __launch_bounds__(256) void termstats_recompute_kernel(TermStatsParam
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const int cnt = min(64, e - t0);
-#pragma unroll 4
+#pragma unroll 8
         for (int k = 0; k < cnt; k += 4) {
             const int kk = k + rs;
             const bool row_on = kk < cnt;
             const int2 dw = dw_l[wv][min(kk, 63)];
             float4 ev = make_float4(0.f, 0.f, 0.f, 0.f);
             if (row_on && lane_on) ev = *(const float4*)(p.E + (int64_t)dw.x * ES + 4 * cc);
-            float part = fmaf(tj.x, ev.x, fmaf(tj.y, ev.y, fmaf(tj.z, ev.z, tj.w * ev.w)));
+            const v2f elo = v2f{ev.x, ev.y}, ehi = v2f{ev.z, ev.w};
+            const v2f d2 = __builtin_elementwise_fma(tlo, elo, thi * ehi);
+            float part = d2.x + d2.y;
             part += dpp_f<0xB1>(part);
             part += dpp_f<0x4E>(part);
             part += dpp_f<0x141>(part);
             part += dpp_f<0x140>(part);                       // all 16 lanes of the slot hold s_n - keps
-            const float val = row_on ? __builtin_bit_cast(float, dw.y) : 0.0f;
-            const float wk = val / (part + p.keps);
-            const float wz = row_on ? wk : 0.0f;
-            acc.x = fmaf(wz, ev.x, acc.x); acc.y = fmaf(wz, ev.y, acc.y);
-            acc.z = fmaf(wz, ev.z, acc.z); acc.w = fmaf(wz, ev.w, acc.w);
+            const float wz = row_on ? fast_div(__builtin_bit_cast(float, dw.y), part + p.keps) : 0.0f;
+            const v2f w2 = v2f{wz, wz};
+            alo = __builtin_elementwise_fma(w2, elo, alo);
+            ahi = __builtin_elementwise_fma(w2, ehi, ahi);
             wl += wz;
         }
         __builtin_amdgcn_wave_barrier();
     }
+    float4 acc = make_float4(alo.x, alo.y, ahi.x, ahi.y);
     // combine the 4 row slots (lanes cc, cc+16, cc+32, cc+48) in a fixed order
     float4 tot = acc;
     float wsum = wl;
