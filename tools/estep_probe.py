@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """E-step timing probe on SYN-NSF: times tmvb_lda_estep alone under different settings."""
 import os, sys, time
+os.environ.setdefault("TMVB_ESTEP_TIMING", "1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import tmvb_amd

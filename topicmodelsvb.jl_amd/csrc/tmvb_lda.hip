@@ -649,6 +649,8 @@ struct tmvb_lda {
     hipEvent_t ev_docs = nullptr, ev_side = nullptr, ev_mark = nullptr;
     double* d_partial_side = nullptr;
     bool esum_fresh = false;           // d_esum / statistics tail hold the sums of the current Elogtheta
+    bool esum_side = false;            // ... and they were produced on the side stream by the last E-step
+    bool timing = false;               // TMVB_ESTEP_TIMING=1: record the events behind tmvb_lda_last_estep_ms
     bool mark_valid = false;           // ev_mark was recorded at the entry of the preceding update_beta call
 };
 
@@ -829,6 +831,7 @@ extern "C" int tmvb_lda_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
     if (h->M) TMVB_HIP(hipMemcpyAsync(h->d_doc_order, order.data(), (size_t)h->M * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     TMVB_HIP(hipMemsetAsync(h->d_stats, 0, (KV + K) * sizeof(float), ctx->stream));
     TMVB_HIP(hipMemsetAsync(h->d_sweeps, 0, std::max<size_t>((size_t)h->M, 1), ctx->stream));
+    { const char* t = getenv("TMVB_ESTEP_TIMING"); h->timing = t && atoi(t) != 0; }
     TMVB_HIP(hipEventCreate(&h->ev0));
     TMVB_HIP(hipEventCreate(&h->ev1));
     TMVB_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
@@ -858,7 +861,7 @@ extern "C" int tmvb_lda_set_state(tmvb_lda* h, const double* alpha, const double
                                   const double* elbo)
 {
     TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_lda_set_state: handle is NULL");
-    h->mark_valid = false; h->esum_fresh = false;
+    h->mark_valid = false; h->esum_fresh = false; h->esum_side = false;
     tmvb_ctx* ctx = h->ctx;
     TMVB_HIP(hipSetDevice(ctx->device));
     const size_t K = h->K, KV = K * (size_t)h->V, KM = K * (size_t)h->M;
@@ -913,7 +916,7 @@ extern "C" int tmvb_lda_estep(tmvb_lda* h, int32_t viter, double vtol)
     TMVB_REQUIRE(viter >= 0, TMVB_EINVAL, "iteration parameters must be nonnegative.");     // src/gpuLDA.jl:350
     TMVB_REQUIRE(vtol >= 0, TMVB_EINVAL, "tolerance parameters must be nonnegative.");      // src/gpuLDA.jl:349
     tmvb_ctx* ctx = h->ctx;
-    h->mark_valid = false; h->esum_fresh = false;
+    h->mark_valid = false; h->esum_fresh = false; h->esum_side = false;
     TMVB_HIP(hipSetDevice(ctx->device));
     LdaParams p;
     p.K = h->K; p.KP = h->KP; p.LPR = h->KP / 4; p.lpr_magic = (unsigned)(0x100000000ull / (unsigned)p.LPR) + 1u; p.V = h->V;
@@ -924,7 +927,7 @@ extern "C" int tmvb_lda_estep(tmvb_lda* h, int32_t viter, double vtol)
     p.viter = viter; p.vtol = (float)vtol;
     { const char* dbg = getenv("TMVB_DEBUG_FLAGS"); p.debug = dbg ? atoi(dbg) : 0; }
     p.store_w = tmvb_termstats_recomputes(h->KP, h->e_padded) ? 0 : 1;
-    TMVB_HIP(hipEventRecord(h->ev0, ctx->stream));
+    if (h->timing) TMVB_HIP(hipEventRecord(h->ev0, ctx->stream));
     const int nb = (int)h->buckets.size();
     const int P = (int)h->pieces.size();               // 0: one statistics pass after all document kernels
     const int naux = std::min(nb, (int)tmvb_lda::NAUX);
@@ -1031,9 +1034,9 @@ extern "C" int tmvb_lda_estep(tmvb_lda* h, int32_t viter, double vtol)
         if (rc) return rc;
         TMVB_HIP(hipEventRecord(h->ev_side, side));
         TMVB_HIP(hipStreamWaitEvent(ctx->stream, h->ev_side, 0));
-        h->esum_fresh = true;
+        h->esum_fresh = true; h->esum_side = true;
     }
-    TMVB_HIP(hipEventRecord(h->ev1, ctx->stream));
+    if (h->timing) TMVB_HIP(hipEventRecord(h->ev1, ctx->stream));
     h->timed = true;
     return TMVB_OK;
 }
@@ -1049,6 +1052,7 @@ extern "C" int tmvb_lda_reduce_docs(tmvb_lda* h)
     TMVB_HIP(hipSetDevice(h->ctx->device));
     h->mark_valid = false;
     if (h->esum_fresh) { h->esum_fresh = false; return TMVB_OK; }   // enqueued by tmvb_lda_estep (side chain)
+    h->esum_side = false;
     return colsum(h, h->d_elog, h->M, h->d_esum, h->d_stats + (size_t)h->K * h->V);
 }
 
@@ -1112,9 +1116,14 @@ extern "C" int tmvb_lda_update_alpha(tmvb_lda* h, int32_t niter, double ntol)
     TMVB_HIP(hipSetDevice(ctx->device));
     const float* ef = h->distributed ? h->d_stats + (size_t)h->K * h->V : nullptr;
     hipStream_t side = h->aux[tmvb_lda::SIDE];
-    if (!h->mark_valid) TMVB_HIP(hipEventRecord(h->ev_mark, ctx->stream));
+    // One context: the Newton step needs nothing but Elogtheta_sum, which the E-step left on this very
+    // stream, so it starts under the statistics pass.  Document-sharded: it needs the all-reduced sums, i.e.
+    // the context's stream as of the preceding update_beta call (or as of now).
+    if (h->distributed || !h->esum_side) {
+        if (!h->mark_valid) TMVB_HIP(hipEventRecord(h->ev_mark, ctx->stream));
+        TMVB_HIP(hipStreamWaitEvent(side, h->ev_mark, 0));
+    }
     h->mark_valid = false;
-    TMVB_HIP(hipStreamWaitEvent(side, h->ev_mark, 0));
     int rc = dispatch_nslot(h->nslot, [&](auto ns) -> int {
         constexpr int NS = decltype(ns)::value;
         hipLaunchKernelGGL((lda_alpha_kernel<NS>), dim3(1), dim3(64), 0, side, h->K, (double)h->M_total, h->d_esum, ef,
@@ -1215,6 +1224,7 @@ extern "C" int tmvb_lda_estep_launches(tmvb_lda* h, int32_t* n)
 extern "C" int tmvb_lda_last_estep_ms(tmvb_lda* h, float* ms)
 {
     TMVB_REQUIRE(h && ms, TMVB_EINVAL, "tmvb_lda_last_estep_ms: NULL argument");
+    TMVB_REQUIRE(h->timing, TMVB_EINVAL, "tmvb_lda_last_estep_ms: E-step timing is off (set TMVB_ESTEP_TIMING=1 before creating the model)");
     TMVB_REQUIRE(h->timed, TMVB_EINVAL, "tmvb_lda_last_estep_ms: no E-step has run");
     TMVB_HIP(hipSetDevice(h->ctx->device));
     TMVB_HIP(hipEventSynchronize(h->ev1));
