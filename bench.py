@@ -59,7 +59,9 @@ def pmc_traffic(K, M, nnz):
     tot = 0.0
     for name, r in rows.items():
         if "lda_estep" in name or "termstats" in name:
-            tot += (2.0 * r["fetch_kb_per_dispatch"] + r["write_kb_per_dispatch"]) * 1024.0
+            if "fetch_kb_per_iteration" not in r:
+                return None
+            tot += (2.0 * r["fetch_kb_per_iteration"] + r["write_kb_per_iteration"]) * 1024.0
     return tot
 
 
@@ -195,10 +197,10 @@ def main():
                        "K": K, "M": corpus.M, "V": V, "nnz": corpus.nnz, "sum_counts": int(corpus.counts.sum()),
                        "parallelism": f"doc-shard x{world}, 1 all-reduce of {K * V + K} f32 per iteration" if world > 1 else "single GPU",
                        "sweep_hist_last_step": sweep_hist},
-            "roofline": {"bound": "hbm", "kernel": "LDA E-step = lda_estep_reg_kernel/lda_estep_kernel (one launch per document-length bucket, concurrent on 4 streams) + termstats_chunk4_kernel + termstats_multi_kernel",
+            "roofline": {"bound": "hbm", "kernel": "LDA E-step = lda_estep_reg_kernel<13,T> / lda_estep_kernel over 4 document pieces on one stream, termstats_recompute_kernel<13> + termstats_multi_kernel of piece p on the context stream under the document kernels of piece p+1; timed start-to-end with events on the context stream",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(K, shard.M, shard.nnz) if world == 1 else None,
-                         "traffic_source": "profiles/r1_lda_k50_pmc.txt (rocprofv3 --pmc, separate passes; 2*FETCH_SIZE+WRITE_SIZE summed over the E-step's kernels)",
+                         "traffic_source": "profiles/r1_lda_k50_pmc.txt (rocprofv3 --pmc, separate passes; 2*FETCH_SIZE+WRITE_SIZE summed over all dispatches of the E-step's kernels in one iteration)",
                          "algorithmic_bytes_per_estep": b_e, "estep_ms": ms,
                          "estep_ms_min": float(np.min(estep_ms)), "estep_ms_max": float(np.max(estep_ms)),
                          "launches_per_estep": n_launch,

@@ -643,8 +643,9 @@ struct tmvb_lda {
     std::vector<hipEvent_t> ev_piece;
     // side chain: the Elogtheta column sums depend on the document kernels only, so they run on aux[SIDE]
     // under the statistics pass; update_alpha! (one wave of fp64 Newton steps) runs there under update_beta!.
-    // The context's stream waits for the side chain before either entry point returns, so callers see the
-    // usual single-stream ordering.
+    // The context's stream joins the side chain lazily (lda_join_side): before anything that reads or rewrites
+    // alpha / Elogtheta_sum on it, and before a document-sharded caller all-reduces the statistics buffer;
+    // the next E-step's document kernels wait for the side chain directly.
     static constexpr int SIDE = 2;
     hipEvent_t ev_docs = nullptr, ev_side = nullptr, ev_mark = nullptr;
     double* d_partial_side = nullptr;
@@ -652,6 +653,7 @@ struct tmvb_lda {
     bool esum_side = false;            // ... and they were produced on the side stream by the last E-step
     bool timing = false;               // TMVB_ESTEP_TIMING=1: record the events behind tmvb_lda_last_estep_ms
     bool mark_valid = false;           // ev_mark was recorded at the entry of the preceding update_beta call
+    bool side_pending = false;         // ev_side marks side-stream work the context's stream has not waited for yet
 };
 
 static bool lda_reg_lpr_supported(int lpr) { return lpr == 1 || lpr == 3 || lpr == 5 || lpr == 13 || lpr == 25; }
@@ -693,6 +695,22 @@ static void lda_cut_pieces(tmvb_lda* h, const std::vector<int32_t>& order, int P
 {
     const std::vector<int64_t>& len = h->corp->h_doc_len;
     const int64_t nnz = std::max<int64_t>(h->corp->info.nnz, 1);
+    // cumulative token fractions at which a piece ends: the last pieces are smaller, because the statistics
+    // pass of the last piece has no document kernels left to hide under
+    std::vector<double> cum(P);
+    {
+        double tot = 0.0;
+        for (int q = 0; q < P; ++q) { cum[q] = 1.0 + 0.5 * (double)(P - 1 - q) / (double)std::max(P - 1, 1); tot += cum[q]; }
+        double run = 0.0;
+        for (int q = 0; q < P; ++q) { run += cum[q] / tot; cum[q] = run; }
+        if (const char* e = getenv("TMVB_LDA_PIECE_FRACS")) {          // tuning: "0.3,0.58,0.82"
+            std::vector<double> f;
+            for (const char* c = e; *c;) { char* end; f.push_back(strtod(c, &end)); c = (*end == ',') ? end + 1 : end; if (end == c && *c) break; }
+            for (int q = 0; q + 1 < P && q < (int)f.size(); ++q) cum[q] = f[q];
+        }
+        cum[P - 1] = 2.0;
+    }
+    auto piece_of = [&](int64_t run) { const double x = (double)run / (double)nnz; int q = 0; while (q < P - 1 && x >= cum[q]) ++q; return q; };
     doc_piece.assign(h->M, 0);
     std::vector<tmvb_bucket> cut;
     int64_t run = 0;
@@ -704,9 +722,9 @@ static void lda_cut_pieces(tmvb_lda* h, const std::vector<int32_t>& order, int P
             continue;
         }
         int64_t start = b.first;
-        int piece = (int)std::min<int64_t>(P - 1, run * P / nnz);
+        int piece = piece_of(run);
         for (int64_t q = b.first; q < b.first + b.count; ++q) {
-            const int pq = (int)std::min<int64_t>(P - 1, run * P / nnz);
+            const int pq = piece_of(run);
             if (pq != piece) {
                 if (q > start) { tmvb_bucket c = b; c.first = start; c.count = q - start; c.piece = piece; cut.push_back(c); }
                 start = q; piece = pq;
@@ -719,10 +737,21 @@ static void lda_cut_pieces(tmvb_lda* h, const std::vector<int32_t>& order, int P
     h->buckets.swap(cut);
 }
 
+static int lda_join_side(tmvb_lda* h)
+{
+    if (h->side_pending) {
+        TMVB_HIP(hipStreamWaitEvent(h->ctx->stream, h->ev_side, 0));
+        h->side_pending = false;
+    }
+    return TMVB_OK;
+}
+
 extern "C" int tmvb_lda_destroy(tmvb_lda* h)
 {
     if (!h) return TMVB_OK;
     if (h->ctx) (void)hipSetDevice(h->ctx->device);
+    for (int a = 0; a < tmvb_lda::NAUX; ++a) if (h->aux[a]) (void)hipStreamSynchronize(h->aux[a]);
+    if (h->ctx) (void)hipStreamSynchronize(h->ctx->stream);
     (void)hipFree(h->d_alpha_d); (void)hipFree(h->d_alpha_f); (void)hipFree(h->d_beta[0]); (void)hipFree(h->d_beta[1]);
     if (h->own_stats) (void)hipFree(h->d_stats);
     (void)hipFree(h->d_wtok); (void)hipFree(h->d_E); (void)hipFree(h->d_ts_partial);
@@ -864,6 +893,7 @@ extern "C" int tmvb_lda_set_state(tmvb_lda* h, const double* alpha, const double
     h->mark_valid = false; h->esum_fresh = false; h->esum_side = false;
     tmvb_ctx* ctx = h->ctx;
     TMVB_HIP(hipSetDevice(ctx->device));
+    { int jrc = lda_join_side(h); if (jrc) return jrc; }
     const size_t K = h->K, KV = K * (size_t)h->V, KM = K * (size_t)h->M;
     int rc;
     if (alpha) {
@@ -895,6 +925,7 @@ extern "C" int tmvb_lda_get_state(tmvb_lda* h, double* alpha, double* beta, doub
     h->mark_valid = false;
     tmvb_ctx* ctx = h->ctx;
     TMVB_HIP(hipSetDevice(ctx->device));
+    { int jrc = lda_join_side(h); if (jrc) return jrc; }
     const size_t K = h->K, KV = K * (size_t)h->V, KM = K * (size_t)h->M;
     int rc;
     if (alpha) {
@@ -933,7 +964,13 @@ extern "C" int tmvb_lda_estep(tmvb_lda* h, int32_t viter, double vtol)
     const int naux = std::min(nb, (int)tmvb_lda::NAUX);
     if (naux > 1 || P > 1) {
         TMVB_HIP(hipEventRecord(h->ev_fork, ctx->stream));
-        for (int a = 0; a < (P > 1 ? 2 : naux); ++a) TMVB_HIP(hipStreamWaitEvent(h->aux[a], h->ev_fork, 0));
+        for (int a = 0; a < (P > 1 ? 2 : naux); ++a) {
+            TMVB_HIP(hipStreamWaitEvent(h->aux[a], h->ev_fork, 0));
+            if (h->side_pending) TMVB_HIP(hipStreamWaitEvent(h->aux[a], h->ev_side, 0));   // update_alpha! of the last iteration
+        }
+    } else {
+        int jrc = lda_join_side(h);
+        if (jrc) return jrc;
     }
     TermStatsParams tp;
     tp.K = h->K; tp.tstride = h->KP; tp.ostride = h->K;
@@ -1033,7 +1070,7 @@ extern "C" int tmvb_lda_estep(tmvb_lda* h, int32_t viter, double vtol)
         int rc = tmvb_colsum(ctx, h->nslot, h->K, h->d_elog, h->M, h->d_partial_side, h->d_esum, h->d_stats + (size_t)h->K * h->V, side);
         if (rc) return rc;
         TMVB_HIP(hipEventRecord(h->ev_side, side));
-        TMVB_HIP(hipStreamWaitEvent(ctx->stream, h->ev_side, 0));
+        h->side_pending = true;
         h->esum_fresh = true; h->esum_side = true;
     }
     if (h->timing) TMVB_HIP(hipEventRecord(h->ev1, ctx->stream));
@@ -1051,14 +1088,20 @@ extern "C" int tmvb_lda_reduce_docs(tmvb_lda* h)
     TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_lda_reduce_docs: handle is NULL");
     TMVB_HIP(hipSetDevice(h->ctx->device));
     h->mark_valid = false;
-    if (h->esum_fresh) { h->esum_fresh = false; return TMVB_OK; }   // enqueued by tmvb_lda_estep (side chain)
+    if (h->esum_fresh) {                                  // enqueued by tmvb_lda_estep (side chain)
+        h->esum_fresh = false;
+        return h->distributed ? lda_join_side(h) : TMVB_OK;   // a sharded caller all-reduces the tail next, on this stream
+    }
     h->esum_side = false;
+    { int jrc = lda_join_side(h); if (jrc) return jrc; }
     return colsum(h, h->d_elog, h->M, h->d_esum, h->d_stats + (size_t)h->K * h->V);
 }
 
 extern "C" int tmvb_lda_stats(tmvb_lda* h, void** dev_ptr, int64_t* n_f32)
 {
     TMVB_REQUIRE(h && dev_ptr && n_f32, TMVB_EINVAL, "tmvb_lda_stats: NULL argument");
+    TMVB_HIP(hipSetDevice(h->ctx->device));
+    { int jrc = lda_join_side(h); if (jrc) return jrc; }
     *dev_ptr = h->d_stats;
     *n_f32 = (int64_t)h->K * h->V + h->K;
     return TMVB_OK;
@@ -1071,6 +1114,7 @@ extern "C" int tmvb_lda_bind_stats(tmvb_lda* h, void* dev_ptr, int64_t n_f32)
     TMVB_REQUIRE(n_f32 >= need, TMVB_ESHAPE, "tmvb_lda_bind_stats: buffer holds %lld floats, need %lld", (long long)n_f32, (long long)need);
     h->mark_valid = false;
     TMVB_HIP(hipSetDevice(h->ctx->device));
+    { int jrc = lda_join_side(h); if (jrc) return jrc; }
     TMVB_HIP(hipMemcpyAsync(dev_ptr, h->d_stats, (size_t)need * sizeof(float), hipMemcpyDeviceToDevice, h->ctx->stream));
     TMVB_HIP(hipStreamSynchronize(h->ctx->stream));
     if (h->own_stats) (void)hipFree(h->d_stats);
@@ -1084,6 +1128,8 @@ extern "C" int tmvb_lda_set_distributed(tmvb_lda* h, int64_t M_total, int32_t di
     TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_lda_set_distributed: handle is NULL");
     TMVB_REQUIRE(M_total >= h->M, TMVB_ESHAPE, "tmvb_lda_set_distributed: M_total < local M");
     h->mark_valid = false;
+    TMVB_HIP(hipSetDevice(h->ctx->device));
+    { int jrc = lda_join_side(h); if (jrc) return jrc; }
     h->M_total = M_total;
     h->distributed = distributed != 0;
     return TMVB_OK;
@@ -1094,8 +1140,10 @@ extern "C" int tmvb_lda_update_beta(tmvb_lda* h)
     TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_lda_update_beta: handle is NULL");
     tmvb_ctx* ctx = h->ctx;
     TMVB_HIP(hipSetDevice(ctx->device));
-    TMVB_HIP(hipEventRecord(h->ev_mark, ctx->stream));      // update_alpha! may start from here (it shares nothing with update_beta!)
-    h->mark_valid = true;
+    if (h->distributed || !h->esum_side) {                  // update_alpha! may start from here (it shares nothing with update_beta!)
+        TMVB_HIP(hipEventRecord(h->ev_mark, ctx->stream));
+        h->mark_valid = true;
+    }
     int rc = colsum(h, h->d_stats, h->V, h->d_rowsum, nullptr);
     if (rc) return rc;
     const int64_t total = (int64_t)h->KP * h->V;
@@ -1133,7 +1181,7 @@ extern "C" int tmvb_lda_update_alpha(tmvb_lda* h, int32_t niter, double ntol)
     if (rc) return rc;
     TMVB_HIP(hipGetLastError());
     TMVB_HIP(hipEventRecord(h->ev_side, side));
-    TMVB_HIP(hipStreamWaitEvent(ctx->stream, h->ev_side, 0));
+    h->side_pending = true;
     return TMVB_OK;
 }
 
@@ -1143,6 +1191,7 @@ extern "C" int tmvb_lda_update_elbo(tmvb_lda* h, double* elbo)
     h->mark_valid = false;
     tmvb_ctx* ctx = h->ctx;
     TMVB_HIP(hipSetDevice(ctx->device));
+    { int jrc = lda_join_side(h); if (jrc) return jrc; }
     if (h->M > 0) {
         int rc = dispatch_nslot(h->nslot, [&](auto ns) -> int {
             constexpr int NS = decltype(ns)::value;
@@ -1197,6 +1246,7 @@ extern "C" int tmvb_lda_train(tmvb_lda* h, int32_t iter, double tol, int32_t nit
             if (delta < tol) break;
         }
     }
+    if ((rc = lda_join_side(h))) return rc;
     TMVB_HIP(hipStreamSynchronize(h->ctx->stream));
     if (iters_done) *iters_done = done;
     return TMVB_OK;
