@@ -1,0 +1,65 @@
+"""
+Document-sharded HIP path, world size 2, on ONE MI355X: both ranks put their shard on cuda:0 and
+exchange the packed statistics through the gloo backend (the collective's transport is not the point
+here; RCCL needs one GPU per rank).  Checks the engine-side ordering of the sharded flow -- side-stream
+Elogtheta sums joined before the all-reduce, update_alpha after it, the next E-step after update_alpha
+-- against the single-context HIP run of the same corpus, and that both ranks hold identical globals.
+"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, initfile, out_dir, iters, pieces):
+    sys.path.insert(0, ROOT)
+    os.environ["TMVB_LDA_PIECES"] = str(pieces)     # 1: one statistics pass; 3: pipelined document pieces
+    import torch.distributed as dist
+    import tmvb_amd
+    from tmvb_amd_pkg.dist import HipLDAEngine, ShardedLDA
+    dist.init_process_group("gloo", init_method=f"file://{initfile}", rank=rank, world_size=world)
+    tm = tmvb_amd.pkg
+    corpus = tm.syn_nsf(M=6000, V=3000, seed=11)
+    K = 50
+    beta0 = tm.dirichlet_rows(K, corpus.V, seed=3)
+    d0, d1 = corpus.shard_bounds(world)[rank]
+    eng = HipLDAEngine(corpus.shard(d0, d1), K, beta0, corpus.M, 0, distributed=True)
+    tr = ShardedLDA(eng)
+    traj = tr.train(iter=iters, tol=0.0, checkelbo=1, K=K)
+    eng.model.update_host()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), traj=np.array(traj), alpha=eng.model.alpha, beta=eng.model.beta,
+             gamma=eng.model.gamma, d0=d0, d1=d1)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("pieces", [1, 3])
+def test_sharded_hip_world2_matches_single_context(tmvb, pieces):
+    import torch.multiprocessing as mp
+    world, iters = 2, 5
+    with tempfile.TemporaryDirectory() as td:
+        mp.spawn(_worker, args=(world, os.path.join(td, "init"), td, iters, pieces), nprocs=world, join=True)
+        res = [dict(np.load(os.path.join(td, f"rank{r}.npz"))) for r in range(world)]
+    corpus = tmvb.syn_nsf(M=6000, V=3000, seed=11)
+    K = 50
+    gm = tmvb.gpuLDA(corpus, K)
+    gm.beta = np.asfortranarray(tmvb.dirichlet_rows(K, corpus.V, seed=3)); gm.beta_old = gm.beta.copy(order="F")
+    gm.update_buffer()
+    traj = gm.train(iter=iters, tol=0.0, checkelbo=1, printelbo=False)
+    gm.update_host()
+    # identical M-step on every rank: bitwise equal globals (the all-reduce returns the same sums to both)
+    assert np.array_equal(res[0]["alpha"], res[1]["alpha"]) and np.array_equal(res[0]["beta"], res[1]["beta"])
+    for r in res:
+        # fp32 statistics summed in a different order (per shard, then across ranks): tolerance, not bits
+        np.testing.assert_allclose(r["traj"], np.array(traj)[:len(r["traj"])], rtol=2e-6)
+        np.testing.assert_allclose(r["alpha"], gm.alpha, rtol=2e-4)
+        big = gm.beta > 1e-6
+        np.testing.assert_allclose(r["beta"][big], gm.beta[big], rtol=2e-3)
+        g = gm.gamma[:, int(r["d0"]):int(r["d1"])]
+        assert np.quantile(np.abs(r["gamma"] - g) / np.maximum(np.abs(g), 1e-3), 0.999) < 5e-3
+    assert int(res[0]["d1"]) == int(res[1]["d0"]) and int(res[1]["d1"]) == corpus.M
