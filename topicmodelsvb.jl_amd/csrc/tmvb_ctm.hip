@@ -77,6 +77,13 @@ __device__ __forceinline__ double wave_max_d(double v)
 template <int R>
 __device__ __forceinline__ float gj_solve_rows(float (&H)[R], float g, int lane)
 {
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    static_assert(R % 2 == 0, "gj_solve_rows: R must be even");
+    // the row is held as column pairs so that the rank-1 update runs on v_pk_fma_f32 with the pivot row's
+    // entries as SGPR pairs (the kernel is VALU-issue bound: packed fp32 halves the update's instruction count)
+    v2f H2[R / 2];
+#pragma unroll
+    for (int q = 0; q < R / 2; ++q) H2[q] = v2f{H[2 * q], H[2 * q + 1]};
     float dinv = 0.0f;
 #pragma unroll
     for (int j = 0; j < R; ++j) {
@@ -84,16 +91,20 @@ __device__ __forceinline__ float gj_solve_rows(float (&H)[R], float g, int lane)
         // reads an SGPR written by the immediately preceding v_readlane costs a wait state per pair
         float srow[R];
 #pragma unroll
-        for (int k = j; k < R; ++k) srow[k] = readlane_f(H[k], j);
+        for (int k = j; k < R; ++k) srow[k] = readlane_f((k & 1) ? H2[k / 2].y : H2[k / 2].x, j);
         const float sg = readlane_f(g, j);
         __builtin_amdgcn_sched_barrier(0);
-        const float rp = 1.0f / srow[j];
+        const float rp = fast_rcp(srow[j]);
         const bool me = lane == j;
-        const float f = me ? 0.0f : H[j] * rp;
+        const float hj = (j & 1) ? H2[j / 2].y : H2[j / 2].x;
+        const float f = me ? 0.0f : hj * rp;
         dinv = me ? rp : dinv;
+        const float nf = -f;
+        if ((j & 1) == 0) H2[j / 2].y = fmaf(nf, srow[j + 1], H2[j / 2].y);     // column j + 1 shares j's pair
 #pragma unroll
-        for (int k = j + 1; k < R; ++k) H[k] = fmaf(-f, srow[k], H[k]);
-        g = fmaf(-f, sg, g);
+        for (int q = j / 2 + 1; q < R / 2; ++q)
+            H2[q] = __builtin_elementwise_fma(v2f{nf, nf}, v2f{srow[2 * q], srow[2 * q + 1]}, H2[q]);
+        g = fmaf(nf, sg, g);
         __builtin_amdgcn_sched_barrier(0);
     }
     return g * dinv;
