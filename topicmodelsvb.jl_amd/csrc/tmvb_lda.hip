@@ -853,6 +853,8 @@ extern "C" int tmvb_lda_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
         } else {
             rc = tmvb_corpus_term_index(corp);
             slots = (size_t)corp->term_index.n_slots;
+            h->ev_piece.assign(1, nullptr);
+            if (!rc && hipEventCreateWithFlags(&h->ev_piece[0], hipEventDisableTiming) != hipSuccess) rc = TMVB_EHIP;
         }
         if (!rc) rc = dmalloc(&h->d_ts_partial, slots * (K + 1));
         if (rc) { tmvb_lda_destroy(h); return rc; }
@@ -959,18 +961,17 @@ extern "C" int tmvb_lda_estep(tmvb_lda* h, int32_t viter, double vtol)
     { const char* dbg = getenv("TMVB_DEBUG_FLAGS"); p.debug = dbg ? atoi(dbg) : 0; }
     p.store_w = tmvb_termstats_recomputes(h->KP, h->e_padded) ? 0 : 1;
     if (h->timing) TMVB_HIP(hipEventRecord(h->ev0, ctx->stream));
+    // Stream plan: the register-tile buckets run back to back on aux[0] (piece after piece), the LDS-tile
+    // buckets (long documents; every bucket when K has no register-tile instantiation) on aux[1] -- a single
+    // long document is a latency-bound 0.1-0.2 ms and must not queue ahead of the short ones -- and the
+    // statistics pass of each piece on the context's stream.  (More streams only alias the same hardware queues.)
     const int nb = (int)h->buckets.size();
-    const int P = (int)h->pieces.size();               // 0: one statistics pass after all document kernels
-    const int naux = std::min(nb, (int)tmvb_lda::NAUX);
-    if (naux > 1 || P > 1) {
-        TMVB_HIP(hipEventRecord(h->ev_fork, ctx->stream));
-        for (int a = 0; a < (P > 1 ? 2 : naux); ++a) {
-            TMVB_HIP(hipStreamWaitEvent(h->aux[a], h->ev_fork, 0));
-            if (h->side_pending) TMVB_HIP(hipStreamWaitEvent(h->aux[a], h->ev_side, 0));   // update_alpha! of the last iteration
-        }
-    } else {
-        int jrc = lda_join_side(h);
-        if (jrc) return jrc;
+    const int P = std::max<int>((int)h->pieces.size(), 1);      // 1: one statistics pass over the corpus' own index
+    auto piece_index = [&](int q) -> const tmvb_inv_index& { return h->pieces.empty() ? h->corp->term_index : h->pieces[q]; };
+    TMVB_HIP(hipEventRecord(h->ev_fork, ctx->stream));
+    for (int a = 0; a < 2; ++a) {
+        TMVB_HIP(hipStreamWaitEvent(h->aux[a], h->ev_fork, 0));
+        if (h->side_pending) TMVB_HIP(hipStreamWaitEvent(h->aux[a], h->ev_side, 0));   // update_alpha! of the last iteration
     }
     TermStatsParams tp;
     tp.K = h->K; tp.tstride = h->KP; tp.ostride = h->K;
@@ -991,18 +992,16 @@ extern "C" int tmvb_lda_estep(tmvb_lda* h, int32_t viter, double vtol)
             }
             TMVB_HIP(hipEventRecord(h->ev_piece[piece_open], h->aux[0]));
             TMVB_HIP(hipStreamWaitEvent(ctx->stream, h->ev_piece[piece_open], 0));
-            int rc = stats_pass(h->pieces[piece_open]);
+            int rc = stats_pass(piece_index(piece_open));
             if (rc) return rc;
         }
         return TMVB_OK;
     };
     for (int bi = 0; bi < nb; ++bi) {
         const tmvb_bucket& b = h->buckets[bi];
-        hipStream_t st = (naux > 1) ? h->aux[bi % naux] : ctx->stream;
-        if (P > 1) {
-            st = b.reg_tiles > 0 ? h->aux[0] : h->aux[1];
-            if (b.reg_tiles > 0) { int rc = close_pieces(b.piece); if (rc) return rc; }
-        }
+        hipStream_t st = b.reg_tiles > 0 ? h->aux[0] : h->aux[1];
+        if (!h->reg_path) st = h->aux[(bi & 1) ^ 1];          // LDS-tile buckets only: alternate the two streams
+        if (b.reg_tiles > 0) { int rc = close_pieces(b.piece); if (rc) return rc; }
         if (b.reg_tiles > 0) {
             const dim3 grid((unsigned)b.count), block(64);
             const int* tol = h->d_topic_of_lane; const int* lot = h->d_lane_of_topic;
@@ -1049,21 +1048,10 @@ extern "C" int tmvb_lda_estep(tmvb_lda* h, int32_t viter, double vtol)
         TMVB_HIP(hipGetLastError());
     }
     hipStream_t side = h->aux[tmvb_lda::SIDE];
-    if (P > 1) {
+    {
         int rc = close_pieces(P);
         if (rc) return rc;
         TMVB_HIP(hipStreamWaitEvent(side, h->ev_piece[P - 1], 0));       // recorded after the last document kernel
-    } else {
-        if (naux > 1) {
-            for (int a = 0; a < naux; ++a) {
-                TMVB_HIP(hipEventRecord(h->ev_join[a], h->aux[a]));
-                TMVB_HIP(hipStreamWaitEvent(ctx->stream, h->ev_join[a], 0));
-            }
-        }
-        TMVB_HIP(hipEventRecord(h->ev_docs, ctx->stream));
-        TMVB_HIP(hipStreamWaitEvent(side, h->ev_docs, 0));
-        int rc = stats_pass(h->corp->term_index);
-        if (rc) return rc;
     }
     // Elogtheta_sum (update_alpha!'s input, src/LDA.jl:98) under the statistics pass
     {
