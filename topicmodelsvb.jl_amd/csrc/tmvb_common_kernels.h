@@ -12,6 +12,7 @@
 
 #define TMVB_MAX_NSLOT 16                      // K <= 1024
 #define TMVB_MAX_TILE_BYTES (64 * 1024)
+#define TMVB_BIG_TILE_BYTES (156 * 1024)         // of the 160 KiB per CU: needs hipFuncAttributeMaxDynamicSharedMemorySize
 #define TMVB_REDUCE_BLOCKS 256
 
 // one wave per workgroup: __syncthreads() lowers to an LDS fence (the s_barrier is elided)
@@ -350,7 +351,7 @@ static inline int tmvb_launch_termstats(tmvb_ctx* ctx, int nslot, int KP, bool e
 // Returns the number of documents bucketed (a prefix of `order`).
 static inline int64_t tmvb_build_lds_buckets(const std::vector<int64_t>& len, const std::vector<int32_t>& order, int64_t M,
                                              int KP, int64_t min_len_exclusive, int extra_rows,
-                                             std::vector<tmvb_bucket>& buckets)
+                                             std::vector<tmvb_bucket>& buckets, size_t max_tile_bytes = TMVB_MAX_TILE_BYTES)
 {
     (void)extra_rows;
     int64_t n_lds = 0;
@@ -358,8 +359,8 @@ static inline int64_t tmvb_build_lds_buckets(const std::vector<int64_t>& len, co
     int64_t pos = 0;
     if (n_lds == 0) return 0;
     std::vector<int> tiles;
-    for (int r = 32; r <= 8192; r += (r < 256 ? 32 : r)) {
-        if (tmvb_tile_bytes(r, KP) + (size_t)extra_rows * 0 + 2 * (size_t)KP * sizeof(float) > TMVB_MAX_TILE_BYTES) break;
+    for (int r = 32; r <= 8192; r += (r < 256 ? 32 : 128)) {
+        if (tmvb_tile_bytes(r, KP) + (size_t)extra_rows * 0 + 2 * (size_t)KP * sizeof(float) > max_tile_bytes) break;
         tiles.push_back(r);
     }
     if (tiles.empty()) tiles.push_back(4);

@@ -670,7 +670,9 @@ static void lda_build_buckets(tmvb_lda* h, std::vector<int32_t>& order)
     const int max_tiles = lda_reg_max_tiles(h->KP / 4);
     const int64_t reg_max = h->reg_path ? 64 * max_tiles : -1;
     // documents longer than reg_max: LDS-tile kernel
-    int64_t pos = tmvb_build_lds_buckets(len, order, h->M, h->KP, reg_max, 3, h->buckets);
+    // long documents get up to 156 KiB of LDS (one workgroup per CU): a tile that holds the whole document is
+    // gathered once per E-step, a streamed one once per sweep
+    int64_t pos = tmvb_build_lds_buckets(len, order, h->M, h->KP, reg_max, 3, h->buckets, TMVB_BIG_TILE_BYTES);
     // register-tile buckets: T = ceil(N / 64) tiles of 64 tokens
     for (int T = max_tiles; T >= 1 && pos < h->M; --T) {
         const int64_t lo = 64 * (int64_t)(T - 1);
@@ -1032,17 +1034,17 @@ extern "C" int tmvb_lda_estep(tmvb_lda* h, int32_t viter, double vtol)
         int rc = dispatch_nslot(h->nslot, [&](auto ns) -> int {
             constexpr int NS = decltype(ns)::value;
             const dim3 grid((unsigned)b.count), block(64);
-            if (NS == 1 && p.LPR == 13)
-                hipLaunchKernelGGL((lda_estep_kernel<1, 13>), grid, block, lds, st, p, b.first, b.tile_rows);
-            else if (NS == 1 && p.LPR == 3)
-                hipLaunchKernelGGL((lda_estep_kernel<1, 3>), grid, block, lds, st, p, b.first, b.tile_rows);
-            else if (NS == 1 && p.LPR == 5)
-                hipLaunchKernelGGL((lda_estep_kernel<1, 5>), grid, block, lds, st, p, b.first, b.tile_rows);
-            else if (NS == 2 && p.LPR == 25)
-                hipLaunchKernelGGL((lda_estep_kernel<2, 25>), grid, block, lds, st, p, b.first, b.tile_rows);
-            else
-                hipLaunchKernelGGL((lda_estep_kernel<NS, 0>), grid, block, lds, st, p, b.first, b.tile_rows);
-            return TMVB_OK;
+            auto launch = [&](auto kern) -> int {
+                if (lds > TMVB_MAX_TILE_BYTES)
+                    TMVB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(kern, grid, block, lds, st, p, b.first, b.tile_rows);
+                return TMVB_OK;
+            };
+            if (NS == 1 && p.LPR == 13) return launch(lda_estep_kernel<1, 13>);
+            if (NS == 1 && p.LPR == 3) return launch(lda_estep_kernel<1, 3>);
+            if (NS == 1 && p.LPR == 5) return launch(lda_estep_kernel<1, 5>);
+            if (NS == 2 && p.LPR == 25) return launch(lda_estep_kernel<2, 25>);
+            return launch(lda_estep_kernel<NS, 0>);
         });
         if (rc) return rc;
         TMVB_HIP(hipGetLastError());
