@@ -153,8 +153,8 @@ int tmvb_lda_last_estep_ms(tmvb_lda* h, float* ms);
 
 /* gpuCTM(corp, K) (src/gpuCTM.jl:45-98).  Constructor state as src/CTM.jl:37-48 (mu=0, sigma=invsigma=I,
  * lambda=0, vsq=1, logzeta=0.5); beta is uniform until tmvb_ctm_set_state (the reference draws it with
- * Julia's RNG).  This release instantiates the register Gauss-Jordan solve for K in 1..4, 9..12, 17..20,
- * 49..52; other K return TMVB_EINVAL. */
+ * Julia's RNG).  The lambda Newton systems are solved in registers with lane = matrix row, which limits this
+ * release to K <= 60 (KP = 4*odd <= 60 lanes); larger K return TMVB_EINVAL. */
 int tmvb_ctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb_ctm** out);
 int tmvb_ctm_destroy(tmvb_ctm* h);
 

@@ -50,9 +50,10 @@ def synth_case(tmvb, K, M=60, V=300, seed=3):
     return dict(K=K, V=V, doc_ptr=pc.doc_ptr, terms=pc.terms, counts=pc.counts, beta0=tmvb.dirichlet_rows(K, V, seed=5))
 
 
-@pytest.mark.parametrize("case", ["golden_k5", "syn_k12", "syn_k50"])
+@pytest.mark.parametrize("case", ["golden_k5", "syn_k3", "syn_k12", "syn_k17", "syn_k25", "syn_k33", "syn_k41", "syn_k50", "syn_k57"])
 def test_teacher_forced_step(tmvb, oracle, case):
-    g = load("ctm_m40_v60_k5") if case == "golden_k5" else synth_case(tmvb, 12 if case == "syn_k12" else 50)
+    # one case per register Gauss-Jordan instantiation (KP = 4, 12, 20, 28, 36, 44, 52, 60)
+    g = load("ctm_m40_v60_k5") if case == "golden_k5" else synth_case(tmvb, int(case.split("_k")[1]))
     gm, om = make_pair(tmvb, oracle, g)
     for it in range(3):
         force(gm, om)
@@ -114,7 +115,7 @@ def test_gpu_macro_round_trip_and_errors(tmvb):
     with pytest.raises(ValueError):
         tmvb.gpuCTM(pc, 0)
     with pytest.raises(ValueError):
-        tmvb.gpuCTM(pc, 30)                      # K outside the instantiated Gauss-Jordan sizes
+        tmvb.gpuCTM(pc, 61)                      # lane = matrix row: K <= 60 in this release
     gm = tmvb.gpuCTM(pc, K)
     with pytest.raises(ValueError):
         gm.train(niter=-1, printelbo=False)

@@ -523,7 +523,7 @@ struct tmvb_ctm {
     float* tail() const { return d_stats + (size_t)K * V; }
 };
 
-static bool ctm_kp_supported(int kp) { return kp == 4 || kp == 12 || kp == 20 || kp == 52; }
+static bool ctm_kp_supported(int kp) { return kp >= 4 && kp <= 60 && kp % 8 == 4; }   // KP = 4 * odd, lane = matrix row
 
 extern "C" int tmvb_ctm_destroy(tmvb_ctm* h)
 {
@@ -581,7 +581,7 @@ extern "C" int tmvb_ctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
     TMVB_REQUIRE(ctx && corp, TMVB_EINVAL, "tmvb_ctm_create: NULL context or corpus");
     TMVB_REQUIRE(K > 0, TMVB_EINVAL, "number of topics must be a positive integer.");       // src/gpuCTM.jl constructor
     TMVB_REQUIRE(K <= CTM_MAX_K && ctm_kp_supported(tmvb_kpad(K)), TMVB_EINVAL,
-                 "tmvb_ctm_create: this release supports K in 1..4, 9..12, 17..20, 49..52 (register Gauss-Jordan instantiations); got K=%d", K);
+                 "tmvb_ctm_create: the register Gauss-Jordan kernel (lane = matrix row) supports K <= 60; got K=%d", K);
     TMVB_HIP(hipSetDevice(ctx->device));
     tmvb_ctm* h = new tmvb_ctm();
     h->ctx = ctx; h->corp = corp; h->K = K; h->KP = tmvb_kpad(K);
@@ -758,6 +758,10 @@ extern "C" int tmvb_ctm_estep(tmvb_ctm* h, int32_t niter, double ntol, int32_t v
             case 4: hipLaunchKernelGGL((ctm_estep_kernel<4>), grid, block, lds, st, p, b.first, b.tile_rows); break;
             case 12: hipLaunchKernelGGL((ctm_estep_kernel<12>), grid, block, lds, st, p, b.first, b.tile_rows); break;
             case 20: hipLaunchKernelGGL((ctm_estep_kernel<20>), grid, block, lds, st, p, b.first, b.tile_rows); break;
+            case 28: hipLaunchKernelGGL((ctm_estep_kernel<28>), grid, block, lds, st, p, b.first, b.tile_rows); break;
+            case 36: hipLaunchKernelGGL((ctm_estep_kernel<36>), grid, block, lds, st, p, b.first, b.tile_rows); break;
+            case 44: hipLaunchKernelGGL((ctm_estep_kernel<44>), grid, block, lds, st, p, b.first, b.tile_rows); break;
+            case 60: hipLaunchKernelGGL((ctm_estep_kernel<60>), grid, block, lds, st, p, b.first, b.tile_rows); break;
             default: hipLaunchKernelGGL((ctm_estep_kernel<52>), grid, block, lds, st, p, b.first, b.tile_rows); break;
         }
         TMVB_HIP(hipGetLastError());
