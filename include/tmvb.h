@@ -232,6 +232,16 @@ int tmvb_ctpf_train(tmvb_ctpf* h, int32_t iter, double tol, int32_t viter, doubl
                     double* elbo_traj, int32_t* iters_done);
 int tmvb_ctpf_sweep_hist(tmvb_ctpf* h, int64_t* hist, int32_t nbins);
 int tmvb_ctpf_last_estep_ms(tmvb_ctpf* h, float* ms);
+/* Recommendation post-processing at the end of train!(model::CTPF) (src/CTPF.jl:379-399; src/gpuCTPF.jl:711-731 runs the
+ * same code on the host).  From the resident state:
+ *   scores (or NULL)  double[M*U], column-major M x U as model.scores: sum_k he[k,u]/vav[k] (gimel[k,d]/dalet[k] + zayin[k,d]/het[k])
+ *   drecs  (or NULL)  int32[M*U]: row d holds the 0-based users that are not readers of document d, by descending
+ *                     score, equal scores in descending index order (= reverse(sortperm(...))); drec_count[d] entries valid
+ *   urecs             int32[U*M]: row u holds the 0-based documents outside user u's library, same order; urec_count[u] valid
+ * drecs/urecs/drec_count/urec_count are given together or all NULL.  ms_scores / ms_rank (or NULL): device time of the
+ * score pass and of the two segmented sorts. */
+int tmvb_ctpf_recommend(tmvb_ctpf* h, double* scores, int32_t* drecs, int32_t* drec_count, int32_t* urecs,
+                        int32_t* urec_count, float* ms_scores, float* ms_rank);
 
 #ifdef __cplusplus
 }

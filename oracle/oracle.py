@@ -340,3 +340,29 @@ class CTPF:
                                     C.c_int(iter), c_dbl(tol), C.c_int(viter), c_dbl(vtol), C.c_int(ce), _pd(traj))
         self.elbo = elbo.value
         return traj[:done]
+
+    def recommend(self):
+        """Tail of train!(model::CTPF), src/CTPF.jl:379-399, restated with NumPy (fp64):
+            Eeta = he ./ vav                                                         :379
+            scores[d, :] = sum(Eeta .* (gimel[d] ./ dalet + zayin[d] ./ het), dims=1) :380-384
+            urecs[u] = findall(ur)[reverse(sortperm(scores[ur, u]))], ur = docs not in libs[u]      :386-391
+            drecs[d] = findall(nr)[reverse(sortperm(scores[d, nr]))], nr = users not readers of d   :393-398
+        sortperm is stable ascending (Julia's default for vectors), so reverse() yields descending scores with
+        equal scores in DESCENDING candidate order.  Indices are 0-based here.  Returns (scores M x U, drecs, urecs)."""
+        c = self.corp
+        Eeta = self.he / self.vav[:, None]
+        X = self.gimel / self.dalet[:, None] + self.zayin / self.het[:, None]        # K x M
+        scores = np.empty((self.M, self.U))
+        for d in range(self.M):
+            scores[d, :] = np.sum(Eeta * X[:, d][:, None], axis=0)
+        read = np.zeros((self.M, self.U), dtype=bool)
+        for d in range(self.M):
+            read[d, c.readers[c.rdr_ptr[d]:c.rdr_ptr[d + 1]]] = True
+        urecs, drecs = [], []
+        for u in range(self.U):
+            cand = np.flatnonzero(~read[:, u])
+            urecs.append(cand[np.argsort(scores[cand, u], kind="stable")[::-1]])
+        for d in range(self.M):
+            cand = np.flatnonzero(~read[d, :])
+            drecs.append(cand[np.argsort(scores[d, cand], kind="stable")[::-1]])
+        return scores, drecs, urecs

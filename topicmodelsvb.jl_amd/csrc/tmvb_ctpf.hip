@@ -789,6 +789,14 @@ extern "C" int tmvb_ctpf_train(tmvb_ctpf* h, int32_t iter, double tol, int32_t v
     return TMVB_OK;
 }
 
+int tmvb_ctpf_view_of(tmvb_ctpf* h, tmvb_ctpf_view* v)
+{
+    TMVB_REQUIRE(h && v, TMVB_EINVAL, "tmvb_ctpf_recommend: handle is NULL");
+    v->ctx = h->ctx; v->corp = h->corp; v->K = h->K; v->M = h->M; v->U = h->U;
+    v->gimel = h->d_gimel; v->zayin = h->d_zayin; v->he = h->d_he; v->rates = h->d_rates;
+    return TMVB_OK;
+}
+
 extern "C" int tmvb_ctpf_sweep_hist(tmvb_ctpf* h, int64_t* hist, int32_t nbins)
 {
     TMVB_REQUIRE(h && hist && nbins > 0, TMVB_EINVAL, "tmvb_ctpf_sweep_hist: bad argument");

@@ -98,6 +98,15 @@ struct tmvb_corpus {
     std::vector<int32_t> h_terms, h_readers, h_counts, h_ratings;
     tmvb_inv_index term_index, reader_index;
 };
+// read-only view of a CTPF handle's resident state for the recommendation pass (tmvb_ctpf_recs.hip)
+struct tmvb_ctpf_view {
+    tmvb_ctx* ctx; tmvb_corpus* corp;
+    int K; int64_t M, U;
+    const float* gimel; const float* zayin;     // [M][K]
+    const float* he;                             // [U][K]
+    const double* rates;                         // [8][K]: bet, vav, dalet, het, *_old
+};
+int tmvb_ctpf_view_of(tmvb_ctpf* h, tmvb_ctpf_view* v);
 int tmvb_corpus_term_index(tmvb_corpus* c);
 int tmvb_corpus_reader_index(tmvb_corpus* c);
 

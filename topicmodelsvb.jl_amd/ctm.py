@@ -182,7 +182,7 @@ class gpuCTM:
                     if prev is not None:
                         print(k, " ∆elbo: ", round(e - prev, 3))
                     prev = e
-        self.topics = [np.argsort(-self.beta[i, :], kind="stable") + 1 for i in range(self.K)]
+        self.topics = [np.argsort(self.beta[i, :], kind="stable")[::-1] + 1 for i in range(self.K)]
         return traj
 
     def close(self):

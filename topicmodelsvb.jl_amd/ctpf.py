@@ -8,6 +8,8 @@ Host-side mirror of the reference's CTPF / gpuCTPF interface above the C ABI.
                                             update_alef!(d); CPU-path semantics src/CTPF.jl:353-365
       .mstep()                              update_he!/alef!/dalet!/het!/bet!/vav! in that order, src/CTPF.jl:366-371
       .train(iter=150, tol=1.0, viter=10, vtol=1/K^2, checkelbo=Inf, printelbo=True)   src/gpuCTPF.jl:677-705
+      .recommend(scores=True)               scores / drecs / urecs of the end of train!, src/CTPF.jl:379-399 (device GEMM +
+                                            segmented sort; the reference does it on the host, src/gpuCTPF.jl:711-731)
 """
 from __future__ import annotations
 
@@ -22,7 +24,7 @@ from .lda import DeviceContext, DeviceCorpus, _F, _packed, _pd, _validate_train_
 
 
 class CTPF:
-    """Host (fp64) CTPF state, src/CTPF.jl:6-108 (scores / libs / recs are out of scope)."""
+    """Host (fp64) CTPF state, src/CTPF.jl:6-108.  scores / drecs / urecs are filled by train! (1-based ids, like topics)."""
 
     def __init__(self, corp, K: int, seed: int = 7):
         if not (isinstance(K, (int, np.integer)) and K > 0):
@@ -41,6 +43,14 @@ class CTPF:
         for n in ("gimel", "zayin"):
             setattr(self, n, np.ones((K, M), order="F")); setattr(self, n + "_old", np.ones((K, M), order="F"))
         self.elbo = 0.0
+        # libs[u] = documents user u has read (src/CTPF.jl:62-65), 1-based; recommendations start unranked (:67-79)
+        self.libs = [[] for _ in range(U)]
+        for d in range(M):
+            for u in self.corp.readers[self.corp.rdr_ptr[d]:self.corp.rdr_ptr[d + 1]]:
+                self.libs[int(u)].append(d + 1)
+        self.scores = None
+        self.drecs = None
+        self.urecs = None
 
     def hyper(self):
         return np.array([self.a, self.b, self.c, self.d, self.e, self.f, self.g, self.h], dtype=np.float64)
@@ -66,7 +76,7 @@ class gpuCTPF:
 
     _FIELDS = ("corp", "K", "M", "V", "U", "N", "C", "R", "topics", "a", "b", "c", "d", "e", "f", "g", "h", "alef", "alef_old",
                "he", "he_old", "bet", "bet_old", "vav", "vav_old", "dalet", "dalet_old", "het", "het_old", "gimel", "gimel_old",
-               "zayin", "zayin_old", "elbo")
+               "zayin", "zayin_old", "elbo", "libs", "scores", "drecs", "urecs")
 
     def __init__(self, corp, K: int, seed: int = 7, ctx: DeviceContext | None = None, device_id: int = 0, stream=None,
                  _from: CTPF | None = None):
@@ -142,9 +152,30 @@ class gpuCTPF:
     def synchronize(self):
         self.ctx.synchronize()
 
+    def recommend(self, scores: bool = True):
+        """scores (M x U fp64), drecs[d], urecs[u] from the device-resident state (src/CTPF.jl:379-399).  Ids are 1-based.
+        Returns (ms_scores, ms_rank): device time of the score pass and of the two segmented sorts."""
+        M, U = self.M, self.U
+        if M == 0 or U == 0:
+            self.scores = np.zeros((M, U), order="F"); self.drecs = [np.arange(1, U + 1) for _ in range(M)]
+            self.urecs = [np.arange(1, M + 1) for _ in range(U)]
+            return 0.0, 0.0
+        sc = np.empty((M, U), order="F") if scores else None
+        dr = np.empty((M, U), dtype=np.int32); dc = np.empty(M, dtype=np.int32)
+        ur = np.empty((U, M), dtype=np.int32); uc = np.empty(U, dtype=np.int32)
+        ms0, ms1 = C.c_float(0.0), C.c_float(0.0)
+        p32 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+        check(lib().tmvb_ctpf_recommend(self.handle, _pd(sc) if scores else None, p32(dr), p32(dc), p32(ur), p32(uc),
+                                        C.byref(ms0), C.byref(ms1)))
+        if scores:
+            self.scores = sc
+        self.drecs = [dr[d, :dc[d]] + 1 for d in range(M)]
+        self.urecs = [ur[u, :uc[u]] + 1 for u in range(U)]
+        return ms0.value, ms1.value
+
     def train(self, iter: int = 150, tol: float = 1.0, viter: int = 10, vtol: float | None = None, checkelbo=1,
-              printelbo: bool = True):
-        """train!(model::gpuCTPF; ...) src/gpuCTPF.jl:677-705."""
+              printelbo: bool = True, recs: bool = True):
+        """train!(model::gpuCTPF; ...) src/gpuCTPF.jl:677-705.  recs=False skips the M x U recommendation tail (:711-731)."""
         vtol = 1.0 / self.K ** 2 if vtol is None else vtol
         check_model_ctpf(self)
         _validate_train_args([tol, vtol], [iter, viter], checkelbo)
@@ -164,7 +195,9 @@ class gpuCTPF:
                         print(k, " ∆elbo: ", round(e - prev, 3))
                     prev = e
         Ebeta = self.alef / self.bet[:, None]                                                     # :707-708
-        self.topics = [np.argsort(-Ebeta[i, :], kind="stable") + 1 for i in range(self.K)]
+        self.topics = [np.argsort(Ebeta[i, :], kind="stable")[::-1] + 1 for i in range(self.K)]   # reverse(sortperm(.))
+        if recs:
+            self.recommend()                                                                      # :711-731
         return traj[:done.value]
 
     def close(self):
@@ -183,7 +216,7 @@ def gpu_train_ctpf(model: CTPF, device_id: int = 0, **kwargs):
     """`@gpu train!(model::CTPF; kwargs...)` (src/macros.jl:197-272)."""
     g = gpuCTPF(None, model.K, device_id=device_id, _from=model)
     traj = g.train(**kwargs)
-    for n in ("topics", "alef", "he", "bet", "vav", "dalet", "het", "gimel", "zayin", "elbo"):
+    for n in ("topics", "alef", "he", "bet", "vav", "dalet", "het", "gimel", "zayin", "elbo", "scores", "drecs", "urecs"):
         setattr(model, n, getattr(g, n))
     for n in ("alef", "he", "bet", "vav", "dalet", "het", "gimel", "zayin"):
         setattr(model, n + "_old", np.array(getattr(g, n), copy=True, order="F"))

@@ -290,7 +290,7 @@ class gpuLDA:
                     if prev is not None:
                         print(k, " ∆elbo: ", round(e - prev, 3))
                     prev = e
-        self.topics = [np.argsort(-self.beta[i, :], kind="stable") + 1 for i in range(self.K)]   # :374
+        self.topics = [np.argsort(self.beta[i, :], kind="stable")[::-1] + 1 for i in range(self.K)]   # :374
         return traj
 
     def close(self):
