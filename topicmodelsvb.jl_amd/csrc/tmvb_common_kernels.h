@@ -64,17 +64,25 @@ __device__ __forceinline__ void dpp_stage(float& a, float b, bool hi)
     a = keep + dpp_f<CTRL>(give);
 }
 
-template <int R>
-__device__ __forceinline__ float lane_reduce_scatter(float (&p)[R], int lane)
+// The products enter as a functor prod2(j) -> (value 2j, value 2j + 1) and are formed right before their stage-32
+// swap, so only R / 2 partial sums (not R products) are ever live next to the register tile.
+template <int R, class F>
+__device__ __forceinline__ void lane_reduce_scatter(F&& prod2, float (&res)[(R + 63) / 64], int lane)
 {
-    constexpr int m0 = R, h0 = (m0 + 1) / 2;
+    static_assert(R % 4 == 0, "lane_reduce_scatter: R must be a multiple of 4");
+    constexpr int h0 = R / 2;
+    float p[h0 + 1];
+    // stage 32: value i meets value i + R / 2, i.e. pair j meets pair j + R / 4
 #pragma unroll
-    for (int i = 0; i + 1 < h0; i += 2)
-        swap_add32_x2(p[i], (i + h0 < m0) ? p[i + h0] : p[i], p[i + 1], (i + 1 + h0 < m0) ? p[i + 1 + h0] : p[i + 1]);
-    if (h0 & 1) swap_add32(p[h0 - 1], (h0 - 1 + h0 < m0) ? p[h0 - 1 + h0] : p[h0 - 1]);
+    for (int j = 0; j < R / 4; ++j) {
+        const v2f_t a = prod2(j), b = prod2(j + R / 4);
+        float ax = a.x, ay = a.y;
+        swap_add32_x2(ax, b.x, ay, b.y);
+        p[2 * j] = ax; p[2 * j + 1] = ay;
+        if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // keep the products from being hoisted (register pressure)
+    }
     // stage 16 pairs whole register PAIRS (units) so that the adds stay packed: with U = m1 / 2 units, unit u
     // meets unit u + ceil(U / 2); for odd U the middle unit folds its own two halves.  (R % 4 == 0 => m1 even.)
-    static_assert(R % 4 == 0, "lane_reduce_scatter: R must be a multiple of 4");
     constexpr int m1 = h0, U = m1 / 2, H = (U + 1) / 2, h1 = (m1 + 1) / 2;
 #pragma unroll
     for (int u = 0; u < U / 2; ++u) swap_add16_x2(p[2 * u], p[2 * (u + H)], p[2 * u + 1], p[2 * (u + H) + 1]);
@@ -105,7 +113,8 @@ __device__ __forceinline__ float lane_reduce_scatter(float (&p)[R], int lane)
         else p[i] += dpp_f<0xB1>(p[i]);
     }
     // p[0 .. ceil(R/64)) now hold the totals: lane L of result register s owns topic pi(s, L)
-    return p[0];
+#pragma unroll
+    for (int s = 0; s < (R + 63) / 64; ++s) res[s] = p[s];
 }
 
 // Compile-time replay of lane_reduce_scatter's pairing: lane_of_topic[q] = s * 64 + L of the primary owner

@@ -379,15 +379,13 @@ __global__ __launch_bounds__(64) void lda_estep_reg_kernel(LdaParams p, int64_t 
             wl += w[t];
         }
         const float wsum = wave_sum(wl);
-        float pr[R];
-#pragma unroll
-        for (int q = 0; q < R / 2; ++q) {
+        float pr[NS];
+        lane_reduce_scatter<R>([&](int q) {
             v2f a = B2[0][q] * v2f{w[0], w[0]};
 #pragma unroll
             for (int t = 1; t < T; ++t) a = __builtin_elementwise_fma(B2[t][q], v2f{w[t], w[t]}, a);
-            pr[2 * q] = a.x; pr[2 * q + 1] = a.y;
-        }
-        (void)lane_reduce_scatter<R>(pr, lane);
+            return a;
+        }, pr, lane);
         float gl = 0.0f;
 #pragma unroll
         for (int sl = 0; sl < NS; ++sl) {
@@ -658,7 +656,7 @@ struct tmvb_lda {
 
 static bool lda_reg_lpr_supported(int lpr) { return lpr == 1 || lpr == 3 || lpr == 5 || lpr == 13 || lpr == 25; }
 // 64-token register tiles per document: the tile costs T * KP VGPRs of the 512 available per lane
-static int lda_reg_max_tiles(int lpr) { return lpr <= 13 ? 4 : 2; }   // KP = 100: T = 3 would spill (512 VGPRs)
+static int lda_reg_max_tiles(int lpr) { return lpr <= 13 ? 4 : 3; }   // KP = 100: 3 tiles = 300 of the 512 VGPRs
 
 static void lda_build_buckets(tmvb_lda* h, std::vector<int32_t>& order)
 {
@@ -1022,7 +1020,8 @@ extern "C" int tmvb_lda_estep(tmvb_lda* h, int32_t viter, double vtol)
                 case 25:
                     switch (b.reg_tiles) {
                         case 1: LDA_REG_LAUNCH(25, 1); break;
-                        default: LDA_REG_LAUNCH(25, 2); break;
+                        case 2: LDA_REG_LAUNCH(25, 2); break;
+                        default: LDA_REG_LAUNCH(25, 3); break;
                     }
                     break;
                 default: LDA_REG_LAUNCH_T(13); break;
