@@ -65,28 +65,36 @@ __device__ __forceinline__ void dpp_stage(float& a, float b, bool hi)
 }
 
 // The products enter as a functor prod2(j) -> (value 2j, value 2j + 1) and are formed right before their stage-32
-// swap, so only R / 2 partial sums (not R products) are ever live next to the register tile.
+// swap; stages 32 and 16 are fused per output pair, so only R / 4 partial sums (not R products) are ever live
+// next to the register tile.  Stage 32: value i meets value i + R / 2 (pair j meets pair j + R / 4).  Stage 16
+// pairs whole register PAIRS (units) so that the adds stay packed: of the U = R / 4 units left by stage 32, unit u
+// meets unit u + ceil(U / 2); for odd U the middle unit folds its own two halves.
 template <int R, class F>
 __device__ __forceinline__ void lane_reduce_scatter(F&& prod2, float (&res)[(R + 63) / 64], int lane)
 {
     static_assert(R % 4 == 0, "lane_reduce_scatter: R must be a multiple of 4");
-    constexpr int h0 = R / 2;
-    float p[h0 + 1];
-    // stage 32: value i meets value i + R / 2, i.e. pair j meets pair j + R / 4
-#pragma unroll
-    for (int j = 0; j < R / 4; ++j) {
+    constexpr int U = R / 4, H = (U + 1) / 2, m1 = R / 2, h1 = (m1 + 1) / 2;
+    float p[h1 + 1];
+    auto stage32 = [&](int j, float& x, float& y) {
         const v2f_t a = prod2(j), b = prod2(j + R / 4);
-        float ax = a.x, ay = a.y;
-        swap_add32_x2(ax, b.x, ay, b.y);
-        p[2 * j] = ax; p[2 * j + 1] = ay;
-        if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // keep the products from being hoisted (register pressure)
-    }
-    // stage 16 pairs whole register PAIRS (units) so that the adds stay packed: with U = m1 / 2 units, unit u
-    // meets unit u + ceil(U / 2); for odd U the middle unit folds its own two halves.  (R % 4 == 0 => m1 even.)
-    constexpr int m1 = h0, U = m1 / 2, H = (U + 1) / 2, h1 = (m1 + 1) / 2;
+        x = a.x; y = a.y;
+        swap_add32_x2(x, b.x, y, b.y);
+    };
 #pragma unroll
-    for (int u = 0; u < U / 2; ++u) swap_add16_x2(p[2 * u], p[2 * (u + H)], p[2 * u + 1], p[2 * (u + H) + 1]);
-    if (U & 1) swap_add16(p[U - 1], p[U]);
+    for (int u = 0; u < U / 2; ++u) {
+        float ax, ay, bx, by;
+        stage32(u, ax, ay);
+        stage32(u + H, bx, by);
+        swap_add16_x2(ax, bx, ay, by);
+        p[2 * u] = ax; p[2 * u + 1] = ay;
+        if ((u & 1) == 1) __builtin_amdgcn_sched_barrier(0);     // keep later products from being hoisted (register pressure)
+    }
+    if (U & 1) {
+        float cx, cy;
+        stage32(U / 2, cx, cy);
+        swap_add16(cx, cy);
+        p[U - 1] = cx;
+    }
     constexpr int m2 = h1, h2 = (m2 + 1) / 2;
     const bool b8 = lane & 8, b4 = lane & 4, b2 = lane & 2, b1 = lane & 1;
 #pragma unroll
