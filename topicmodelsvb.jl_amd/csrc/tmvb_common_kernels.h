@@ -329,7 +329,7 @@ static inline int tmvb_colsum(tmvb_ctx* ctx, int nslot, int K, const float* X, i
 
 // gather-side statistics pass over an inverted index (tmvb_termstats.h)
 // true when the statistics pass recomputes the per-token weights (no wtok stores needed in the document kernels)
-static inline bool tmvb_termstats_recomputes(int KP, bool e_padded) { return e_padded && KP / 4 <= 16; }
+static inline bool tmvb_termstats_recomputes(int KP, bool e_padded) { return e_padded && KP / 4 <= 32; }
 
 static inline int tmvb_launch_termstats(tmvb_ctx* ctx, int nslot, int KP, bool e_padded, const tmvb_inv_index& ix,
                                         TermStatsParams tp, hipStream_t on_stream = nullptr)
@@ -343,9 +343,11 @@ static inline int tmvb_launch_termstats(tmvb_ctx* ctx, int nslot, int KP, bool e
         constexpr int NS = decltype(ns)::value;
         const dim3 grid((unsigned)((ix.n_chunks + 3) / 4)), block(256);
         const int lpr = KP / 4;
-        if (e_padded && lpr <= 16) {       // recompute w from (T row, E row, count): no per-token weights in memory
-            if (lpr == 13) hipLaunchKernelGGL((termstats_recompute_kernel<13>), grid, block, 0, st, tp, lpr);
-            else hipLaunchKernelGGL((termstats_recompute_kernel<0>), grid, block, 0, st, tp, lpr);
+        if (e_padded && lpr <= 32) {       // recompute w from (T row, E row, count): no per-token weights in memory
+            if (lpr == 13) hipLaunchKernelGGL((termstats_recompute_kernel<13, 16>), grid, block, 0, st, tp, lpr);
+            else if (lpr == 25) hipLaunchKernelGGL((termstats_recompute_kernel<25, 32>), grid, block, 0, st, tp, lpr);
+            else if (lpr <= 16) hipLaunchKernelGGL((termstats_recompute_kernel<0, 16>), grid, block, 0, st, tp, lpr);
+            else hipLaunchKernelGGL((termstats_recompute_kernel<0, 32>), grid, block, 0, st, tp, lpr);
         } else if (e_padded) {
             if (lpr == 13) hipLaunchKernelGGL((termstats_chunk4_kernel<13>), grid, block, 0, st, tp, lpr);
             else if (lpr == 25) hipLaunchKernelGGL((termstats_chunk4_kernel<25>), grid, block, 0, st, tp, lpr);

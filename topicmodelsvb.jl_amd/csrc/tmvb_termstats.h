@@ -166,22 +166,25 @@ __global__ __launch_bounds__(256) void termstats_chunk4_kernel(TermStatsParams p
     }
 }
 
-// Recompute variant for K <= 64 (LPR <= 16): the per-token weight w_n = val_n / s_n is NOT read from
+// Recompute variant for K <= 128 (LPR <= 32): the per-token weight w_n = val_n / s_n is NOT read from
 // memory -- a per-token value written in document order and read in id order has one scattered side,
 // and the scattered 4-byte stores cost 0.24 ms of the 0.9 ms document pass at NSF scale -- but
 // recomputed here: s_n = keps + sum_i T[i,j] E[i,doc_n] needs only the id's T row (fixed per chunk, in
-// registers) and the document's E row, which this kernel fetches anyway.  16 lanes per row slot
-// (LPR active), 4 row slots per wave instruction; the 16-lane dot product is a 4-step DPP row reduction.
-template <int LPR_T>
+// registers) and the document's E row, which this kernel fetches anyway.  LANES = 16 or 32 lanes per row
+// slot (LPR active), 64 / LANES row slots per wave instruction; the dot product is a 4-step DPP row reduction
+// (+ one v_permlane16_swap step joining the two 16-lane rows of a 32-lane slot).
+template <int LPR_T, int LANES>
 __global__ __launch_bounds__(256) void termstats_recompute_kernel(TermStatsParams p, int LPR_rt)
 {
+    static_assert(LANES == 16 || LANES == 32, "termstats_recompute_kernel: 16 or 32 lanes per row slot");
+    constexpr int SLOTS = 64 / LANES;
     __shared__ int2 dw_l[4][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int c = blockIdx.x * 4 + wv;
     const int LPR = LPR_T ? LPR_T : LPR_rt;
     const int KP = 4 * LPR;
     const int ES = p.estride ? p.estride : KP;
-    const int rs = lane >> 4, cc = lane & 15;
+    const int rs = lane / LANES, cc = lane % LANES;
     const bool lane_on = cc < LPR;
     const bool active = c < p.n_chunks;
     const int j = active ? p.chunk_id[c] : 0;
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(256) void termstats_recompute_kernel(TermStatsParam
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const int cnt = min(64, e - t0);
 #pragma unroll 8
-        for (int k = 0; k < cnt; k += 4) {
+        for (int k = 0; k < cnt; k += SLOTS) {
             const int kk = k + rs;
             const bool row_on = kk < cnt;
             const int2 dw = dw_l[wv][min(kk, 63)];
@@ -213,7 +216,12 @@ __global__ __launch_bounds__(256) void termstats_recompute_kernel(TermStatsParam
             part += dpp_f<0xB1>(part);
             part += dpp_f<0x4E>(part);
             part += dpp_f<0x141>(part);
-            part += dpp_f<0x140>(part);                       // all 16 lanes of the slot hold s_n - keps
+            part += dpp_f<0x140>(part);                       // all 16 lanes of a row hold the row's sum
+            if (LANES == 32) {                                // rows 2r and 2r+1 form one slot: add the sibling row
+                float sib = part;
+                asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(part), "+v"(sib));
+                part += sib;                                  // every lane of the slot holds s_n - keps
+            }
             const float wz = row_on ? fast_div(__builtin_bit_cast(float, dw.y), part + p.keps) : 0.0f;
             const v2f w2 = v2f{wz, wz};
             alo = __builtin_elementwise_fma(w2, elo, alo);
@@ -223,11 +231,11 @@ __global__ __launch_bounds__(256) void termstats_recompute_kernel(TermStatsParam
         __builtin_amdgcn_wave_barrier();
     }
     float4 acc = make_float4(alo.x, alo.y, ahi.x, ahi.y);
-    // combine the 4 row slots (lanes cc, cc+16, cc+32, cc+48) in a fixed order
+    // combine the row slots (lanes cc, cc + LANES, ...) in a fixed order
     float4 tot = acc;
     float wsum = wl;
 #pragma unroll
-    for (int o = 16; o <= 32; o <<= 1) {
+    for (int o = LANES; o <= 32; o <<= 1) {
         tot.x += __shfl_xor(tot.x, o, 64); tot.y += __shfl_xor(tot.y, o, 64);
         tot.z += __shfl_xor(tot.z, o, 64); tot.w += __shfl_xor(tot.w, o, 64);
         wsum += __shfl_xor(wsum, o, 64);
