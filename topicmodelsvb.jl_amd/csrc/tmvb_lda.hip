@@ -322,21 +322,18 @@ __global__ __launch_bounds__(64) void lda_estep_reg_kernel(LdaParams p, int64_t 
     int wpos[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) {
+        // branch-free: a lane past the document's last token reads term 0's row with count 0, so its weight
+        // w = c / s is exactly 0 and nothing of the row reaches gamma (no zero-filled tile, no divergent tile load)
         const int n = lane + 64 * t;
-        if (n < N) {
-            const int term = p.terms[off + n];
-            c[t] = (float)p.counts[off + n];
-            wpos[t] = p.store_w ? p.tok_inv[off + n] : 0;
-            const float4* row = (const float4*)(p.beta + (int64_t)term * R);
+        const bool in = n < N;
+        const int term = in ? p.terms[off + n] : 0;
+        c[t] = in ? (float)p.counts[off + n] : 0.0f;
+        wpos[t] = in ? (p.store_w ? p.tok_inv[off + n] : 0) : -1;
+        const float4* row = (const float4*)(p.beta + (int64_t)term * R);
 #pragma unroll
-            for (int q = 0; q < LPR; ++q) {
-                const float4 v = row[q];
-                B2[t][2 * q] = v2f{v.x, v.y}; B2[t][2 * q + 1] = v2f{v.z, v.w};
-            }
-        } else {
-            c[t] = 0.0f; wpos[t] = -1;
-#pragma unroll
-            for (int q = 0; q < R / 2; ++q) B2[t][q] = v2f{0.0f, 0.0f};
+        for (int q = 0; q < LPR; ++q) {
+            const float4 v = row[q];
+            B2[t][2 * q] = v2f{v.x, v.y}; B2[t][2 * q + 1] = v2f{v.z, v.w};
         }
         w[t] = 0.0f;
     }
