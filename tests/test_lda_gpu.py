@@ -235,10 +235,11 @@ def test_full_size_nsf_properties(tmvb):
     assert gm.sweep_hist().sum() == pc.M
 
 
-@pytest.mark.parametrize("K", [50, 100])
+@pytest.mark.parametrize("K", [3, 10, 18, 25, 33, 41, 50, 57, 64, 72, 81, 90, 100])
 def test_register_tile_paths_k50_k100(tmvb, oracle, K):
-    """K=50 (one result slot per lane) and K=100 (two slots; stored-weight statistics kernel) register-tile
-    kernels incl. multi-tile documents, teacher-forced against the oracle with pinned sweep counts."""
+    """One K per register-tile instantiation (KP = 4, 12, 20, ..., 100; one result slot per lane up to KP = 60,
+    two from KP = 68; statistics recomputed with 16- or 32-lane row slots) incl. multi-tile documents,
+    teacher-forced against the oracle with pinned sweep counts."""
     pc = tmvb.syn_nsf(M=120, V=900, seed=17)           # document lengths ~30..250 -> 1..4 tiles
     g = dict(K=K, V=pc.V, doc_ptr=pc.doc_ptr, terms=pc.terms, counts=pc.counts, beta0=tmvb.dirichlet_rows(K, pc.V, seed=3))
     gm, om = make_pair(tmvb, oracle, g)

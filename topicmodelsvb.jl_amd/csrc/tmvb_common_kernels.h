@@ -168,7 +168,7 @@ struct RegLaneMap {
 };
 template <int R> constexpr RegLaneMap<R> kRegLaneMap{};
 
-// host copy of the compile-time map (the register-tile kernels exist for these R only)
+// host copy of the compile-time map (the register-tile kernels exist for R = 4 * odd <= 100)
 static inline int tmvb_reg_lane_maps(int R, std::vector<int>& topic_of_lane, std::vector<int>& lane_of_topic)
 {
     auto copy = [&](const auto& m) {
@@ -177,11 +177,11 @@ static inline int tmvb_reg_lane_maps(int R, std::vector<int>& topic_of_lane, std
         return (int)(sizeof(m.topic_of_lane) / sizeof(int) / 64);
     };
     switch (R) {
-        case 4: return copy(kRegLaneMap<4>);
-        case 12: return copy(kRegLaneMap<12>);
-        case 20: return copy(kRegLaneMap<20>);
-        case 52: return copy(kRegLaneMap<52>);
-        case 100: return copy(kRegLaneMap<100>);
+#define TMVB_LANE_MAP_CASE(RV) case RV: return copy(kRegLaneMap<RV>);
+        TMVB_LANE_MAP_CASE(4) TMVB_LANE_MAP_CASE(12) TMVB_LANE_MAP_CASE(20) TMVB_LANE_MAP_CASE(28) TMVB_LANE_MAP_CASE(36)
+        TMVB_LANE_MAP_CASE(44) TMVB_LANE_MAP_CASE(52) TMVB_LANE_MAP_CASE(60) TMVB_LANE_MAP_CASE(68) TMVB_LANE_MAP_CASE(76)
+        TMVB_LANE_MAP_CASE(84) TMVB_LANE_MAP_CASE(92) TMVB_LANE_MAP_CASE(100)
+#undef TMVB_LANE_MAP_CASE
         default: return 0;
     }
 }

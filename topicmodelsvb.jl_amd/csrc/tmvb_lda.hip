@@ -588,6 +588,16 @@ __global__ __launch_bounds__(1024) void lda_elbo_final_kernel(const double* __re
     }
 }
 
+// register-tile launch for a bucket of `tiles`-tile documents (instantiates T = 1..TMAX only)
+template <int LPR, int TMAX>
+static void lda_launch_reg(int tiles, dim3 grid, dim3 block, hipStream_t st, const LdaParams& p, int64_t first, const int* tol, const int* lot)
+{
+    if (tiles <= 1) hipLaunchKernelGGL((lda_estep_reg_kernel<LPR, 1>), grid, block, 0, st, p, first, tol, lot);
+    else if (tiles == 2 || TMAX == 2) hipLaunchKernelGGL((lda_estep_reg_kernel<LPR, (TMAX >= 2 ? 2 : 1)>), grid, block, 0, st, p, first, tol, lot);
+    else if (tiles == 3 || TMAX == 3) hipLaunchKernelGGL((lda_estep_reg_kernel<LPR, (TMAX >= 3 ? 3 : 1)>), grid, block, 0, st, p, first, tol, lot);
+    else hipLaunchKernelGGL((lda_estep_reg_kernel<LPR, (TMAX >= 4 ? 4 : 1)>), grid, block, 0, st, p, first, tol, lot);
+}
+
 // ------------------------------------------------------------------------------ host side
 struct tmvb_lda {
     tmvb_ctx* ctx = nullptr;
@@ -651,9 +661,11 @@ struct tmvb_lda {
     bool side_pending = false;         // ev_side marks side-stream work the context's stream has not waited for yet
 };
 
-static bool lda_reg_lpr_supported(int lpr) { return lpr == 1 || lpr == 3 || lpr == 5 || lpr == 13 || lpr == 25; }
+static bool lda_reg_lpr_supported(int lpr) { return lpr >= 1 && lpr <= 25 && (lpr & 1); }   // every KP = 4 * odd <= 100
 // 64-token register tiles per document: the tile costs T * KP VGPRs of the 512 available per lane
-static int lda_reg_max_tiles(int lpr) { return lpr <= 13 ? 4 : 3; }   // KP = 100: 3 tiles = 300 of the 512 VGPRs
+// tiles * KP + KP / 4 + ~35 VGPRs must stay within the 256 architectural VGPRs (beyond that the tile spills to AGPRs;
+// measured still ahead of the LDS-tile kernel at KP = 100, T = 3)
+static int lda_reg_max_tiles(int lpr) { return lpr <= 13 ? 4 : (lpr <= 17 || lpr == 25) ? 3 : 2; }
 
 static void lda_build_buckets(tmvb_lda* h, std::vector<int32_t>& order)
 {
@@ -1002,26 +1014,13 @@ extern "C" int tmvb_lda_estep(tmvb_lda* h, int32_t viter, double vtol)
         if (b.reg_tiles > 0) {
             const dim3 grid((unsigned)b.count), block(64);
             const int* tol = h->d_topic_of_lane; const int* lot = h->d_lane_of_topic;
-#define LDA_REG_LAUNCH(LPRV, TV) hipLaunchKernelGGL((lda_estep_reg_kernel<LPRV, TV>), grid, block, 0, st, p, b.first, tol, lot)
-#define LDA_REG_LAUNCH_T(LPRV)                                                                  \
-            switch (b.reg_tiles) {                                                              \
-                case 1: LDA_REG_LAUNCH(LPRV, 1); break;                                         \
-                case 2: LDA_REG_LAUNCH(LPRV, 2); break;                                         \
-                case 3: LDA_REG_LAUNCH(LPRV, 3); break;                                         \
-                default: LDA_REG_LAUNCH(LPRV, 4); break;                                        \
-            }
             switch (p.LPR) {
-                case 1: LDA_REG_LAUNCH_T(1); break;
-                case 3: LDA_REG_LAUNCH_T(3); break;
-                case 5: LDA_REG_LAUNCH_T(5); break;
-                case 25:
-                    switch (b.reg_tiles) {
-                        case 1: LDA_REG_LAUNCH(25, 1); break;
-                        case 2: LDA_REG_LAUNCH(25, 2); break;
-                        default: LDA_REG_LAUNCH(25, 3); break;
-                    }
-                    break;
-                default: LDA_REG_LAUNCH_T(13); break;
+#define LDA_REG_CASE(LPRV, TMAX) case LPRV: lda_launch_reg<LPRV, TMAX>(b.reg_tiles, grid, block, st, p, b.first, tol, lot); break;
+                LDA_REG_CASE(1, 4) LDA_REG_CASE(3, 4) LDA_REG_CASE(5, 4) LDA_REG_CASE(7, 4) LDA_REG_CASE(9, 4) LDA_REG_CASE(11, 4)
+                LDA_REG_CASE(13, 4) LDA_REG_CASE(15, 3) LDA_REG_CASE(17, 3) LDA_REG_CASE(19, 2) LDA_REG_CASE(21, 2) LDA_REG_CASE(23, 2)
+                LDA_REG_CASE(25, 3)
+#undef LDA_REG_CASE
+                default: TMVB_REQUIRE(false, TMVB_EINVAL, "tmvb_lda_estep: no register-tile kernel for KP=%d", h->KP);
             }
             TMVB_HIP(hipGetLastError());
             continue;
