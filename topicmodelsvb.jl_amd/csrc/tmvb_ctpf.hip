@@ -18,6 +18,7 @@
 // The scatters update_alef!(d) / update_he!(d) are gather-side statistics passes over the term and
 // the reader inverted indices (tmvb_termstats.h); HBM-bound like LDA.
 #include "tmvb_common_kernels.h"
+#include "tmvb_regtile.h"
 
 struct CtpfParams {
     int K, KP, LPR;
@@ -202,6 +203,136 @@ __global__ __launch_bounds__(64) void ctpf_estep_kernel(CtpfParams p, int64_t fi
         if (lane < KP) { p.E1[(int64_t)d * KP + lane] = 0.f; p.E2[(int64_t)d * KP + lane] = 0.f; }   // viter = 0
     }
     if (lane == 0) p.sweeps[d] = (uint8_t)min(sweeps, 255);
+}
+
+// ------------------------------------------------------------------------------ register-tile E-step
+// Documents with at most 64 T unique terms and at most 64 readers: the TA rows of the terms (T tiles) and the TH
+// rows of the readers (one tile) live in VGPRs as topic pairs, exactly as in lda_estep_reg_kernel (tmvb_lda.hip):
+// per sweep two packed matrix-vector passes per tile set and two cross-lane reduce-scatters
+//   s_n = sum_i TA[n][i] e_i,  w_n = c_n / s_n,  G_i = sum_n w_n TA[n][i]          (update_phi!,  src/CTPF.jl:327-330)
+//   s_u = sum_i TH[u][i] f_i,  w_u = r_u / s_u,  H_i = sum_u w_u TH[u][i], f = ea + eb  (update_xi!, :334-337)
+//   zayin_i = g + eb_i H_i ;  gimel_i = c + e_i G_i + ea_i H_i                      (:318-323, :309-314)
+// with e, ea, eb = exp(psi(.) - log rates - max) as in ctpf_estep_kernel.  A lane past the last term / reader
+// carries count 0 (its weight is exactly 0), so the tiles are loaded without branches.
+template <int LPR, int T>
+__global__ __launch_bounds__(64) void ctpf_estep_reg_kernel(CtpfParams p, int64_t first, const int* __restrict__ topic_of_lane)
+{
+    constexpr int R = 4 * LPR;
+    static_assert(R <= 64, "ctpf_estep_reg_kernel: one result slot per lane");
+    const int lane = threadIdx.x;
+    const int K = p.K;
+    const int d = p.doc_order[first + blockIdx.x];
+    const int64_t off = p.doc_ptr[d], roff = p.rdr_ptr[d];
+    const int N = (int)(p.doc_ptr[d + 1] - off), Rd = (int)(p.rdr_ptr[d + 1] - roff);
+
+    v2f A2[T][R / 2], H2[1][R / 2];
+    float c[T], rr;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int n = lane + 64 * t;
+        const bool in = n < N;
+        const int term = in ? p.terms[off + n] : 0;
+        c[t] = in ? (float)p.counts[off + n] : 0.0f;
+        const float4* row = (const float4*)(p.TA + (int64_t)term * R);
+#pragma unroll
+        for (int q = 0; q < LPR; ++q) {
+            const float4 v = row[q];
+            A2[t][2 * q] = v2f{v.x, v.y}; A2[t][2 * q + 1] = v2f{v.z, v.w};
+        }
+    }
+    {
+        const bool in = lane < Rd;
+        const int u = in ? p.readers[roff + lane] : 0;
+        rr = in ? (float)p.ratings[roff + lane] : 0.0f;
+        if (Rd > 0) {                                   // uniform: a corpus without readers has no TH table
+            const float4* row = (const float4*)(p.TH + (int64_t)u * R);
+#pragma unroll
+            for (int q = 0; q < LPR; ++q) {
+                const float4 v = row[q];
+                H2[0][2 * q] = v2f{v.x, v.y}; H2[0][2 * q + 1] = v2f{v.z, v.w};
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < R / 2; ++q) H2[0][q] = v2f{1.0f, 1.0f};
+        }
+    }
+    // topic role: this lane owns topic pi(lane) after the reduce-scatter (-1: duplicate / pad)
+    const int mytopic = topic_of_lane[lane];
+    const bool on = mytopic >= 0 && mytopic < K;
+    const int mt = on ? mytopic : 0;
+    const float lb = on ? p.lrates[mt] : 0.f, lv = on ? p.lrates[K + mt] : 0.f;
+    const float ld = on ? p.lrates[2 * K + mt] : 0.f, lh = on ? p.lrates[3 * K + mt] : 0.f;
+    float gim = on ? p.gimel[(int64_t)d * K + mt] : 1.0f, zay = on ? p.zayin[(int64_t)d * K + mt] : 1.0f;
+    float gim_old = gim, zay_old = zay;
+    float e[1] = {0.f}, f[1] = {0.f}, ea = 0.f, eb = 0.f;
+
+    int sweeps = 0;
+    for (int v = 0; v < p.viter; ++v) {
+        ++sweeps;
+        const float dg = digamma_f(gim), dz = digamma_f(zay);
+        const float x = dg - ld - lb;                     // update_phi!  src/CTPF.jl:329
+        const float a = dg - ld - lv, b = dz - lh - lv;   // update_xi!  :336
+        const float mx = wave_max(on ? x : -INFINITY);
+        const float mab = wave_max(on ? fmaxf(a, b) : -INFINITY);
+        e[0] = on ? fast_exp(x - mx) : 0.f;
+        ea = on ? fast_exp(a - mab) : 0.f;
+        eb = on ? fast_exp(b - mab) : 0.f;
+        f[0] = ea + eb;
+        // terms
+        v2f sacc[T][2];
+#pragma unroll
+        for (int t = 0; t < T; ++t) { sacc[t][0] = v2f{0.f, 0.f}; sacc[t][1] = v2f{0.f, 0.f}; }
+        regtile_phase1_block<R, T, 0>(A2, e, sacc);
+        if constexpr (R > 32) regtile_phase1_block<R, T, 32>(A2, e, sacc);
+        float w[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const v2f s2 = sacc[t][0] + sacc[t][1];
+            w[t] = fast_div(c[t], s2.x + s2.y);
+        }
+        float G[1];
+        lane_reduce_scatter<R>([&](int q) {
+            v2f acc = A2[0][q] * v2f{w[0], w[0]};
+#pragma unroll
+            for (int t = 1; t < T; ++t) acc = __builtin_elementwise_fma(A2[t][q], v2f{w[t], w[t]}, acc);
+            return acc;
+        }, G, lane);
+        // readers
+        v2f hacc[1][2] = {{v2f{0.f, 0.f}, v2f{0.f, 0.f}}};
+        regtile_phase1_block<R, 1, 0>(H2, f, hacc);
+        if constexpr (R > 32) regtile_phase1_block<R, 1, 32>(H2, f, hacc);
+        const v2f hs = hacc[0][0] + hacc[0][1];
+        const float wr = fast_div(rr, hs.x + hs.y);
+        float Hh[1];
+        lane_reduce_scatter<R>([&](int q) { return H2[0][q] * v2f{wr, wr}; }, Hh, lane);
+        zay_old = zay; gim_old = gim;
+        float dl = 0.f;
+        if (on) {
+            zay = p.hg + eb * Hh[0];                      // update_zayin!  :322
+            gim = (p.hc + e[0] * G[0]) + ea * Hh[0];      // update_gimel!  :313
+            const float df = gim - gim_old;
+            dl = df * df;
+        }
+        if (sqrtf(wave_sum(dl)) < p.vtol) break;          // :359
+    }
+    const bool mine = mytopic >= 0 && mytopic < R;
+    if (sweeps > 0) {
+        if (on) {
+            p.gimel[(int64_t)d * K + mt] = gim; p.gimel_old[(int64_t)d * K + mt] = gim_old;
+            p.zayin[(int64_t)d * K + mt] = zay; p.zayin_old[(int64_t)d * K + mt] = zay_old;
+        }
+        if (mine) { p.E1[(int64_t)d * R + mytopic] = e[0]; p.E2[(int64_t)d * R + mytopic] = f[0]; }
+    } else {
+        if (mine) { p.E1[(int64_t)d * R + mytopic] = 0.f; p.E2[(int64_t)d * R + mytopic] = 0.f; }   // viter = 0
+    }
+    if (lane == 0) p.sweeps[d] = (uint8_t)min(sweeps, 255);
+}
+
+template <int LPR>
+static void ctpf_launch_reg(int tiles, dim3 grid, hipStream_t st, const CtpfParams& p, int64_t first, const int* tol)
+{
+    if (tiles <= 1) hipLaunchKernelGGL((ctpf_estep_reg_kernel<LPR, 1>), grid, dim3(64), 0, st, p, first, tol);
+    else hipLaunchKernelGGL((ctpf_estep_reg_kernel<LPR, 2>), grid, dim3(64), 0, st, p, first, tol);
 }
 
 // shape update + table refresh:  X[id][i] = prior + stats[id][i];  T[id][i] = exp(psi(X));  stats <- 0
@@ -391,6 +522,8 @@ struct tmvb_ctpf {
     double* d_doc_val = nullptr; double* d_elbo_partial = nullptr; double* d_elbo = nullptr;
     double* d_partial = nullptr; double* d_rs_alef = nullptr; double* d_rs_he = nullptr; double* d_sum_g = nullptr; double* d_sum_z = nullptr;
     double elbo = 0.0;
+    int* d_topic_of_lane = nullptr;     // register-tile kernel: topic owned by each lane after the reduce-scatter
+    bool reg_path = false;              // KP = 4 * odd <= 60: short documents (<= 128 terms, <= 64 readers) use ctpf_estep_reg_kernel
     std::vector<tmvb_bucket> buckets;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
@@ -409,7 +542,7 @@ extern "C" int tmvb_ctpf_destroy(tmvb_ctpf* h)
     if (!h) return TMVB_OK;
     if (h->ctx) (void)hipSetDevice(h->ctx->device);
     (void)hipFree(h->d_alef); (void)hipFree(h->d_alef_old); (void)hipFree(h->d_he); (void)hipFree(h->d_he_old);
-    (void)hipFree(h->d_TA); (void)hipFree(h->d_TH);
+    (void)hipFree(h->d_TA); (void)hipFree(h->d_TH); (void)hipFree(h->d_topic_of_lane);
     if (h->own_stats) (void)hipFree(h->d_stats);
     (void)hipFree(h->d_rates); (void)hipFree(h->d_lrates); (void)hipFree(h->d_gimel); (void)hipFree(h->d_gimel_old);
     (void)hipFree(h->d_zayin); (void)hipFree(h->d_zayin_old); (void)hipFree(h->d_wtok); (void)hipFree(h->d_wrdr);
@@ -473,13 +606,34 @@ extern "C" int tmvb_ctpf_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmv
         tmvb_ctpf_destroy(h);
         return rc;
     }
-    // processing order by rows (terms + readers), longest first; LDS buckets on the combined row count
+    // processing order: first the documents of the LDS-tile kernel by rows (terms + readers), longest first, in LDS
+    // buckets on the combined row count; then the register-tile documents (<= 128 terms and <= 64 readers) by tiles
+    h->reg_path = (h->KP / 4) <= 15 && ((h->KP / 4) & 1);
+    if (h->reg_path) {
+        std::vector<int> tol, lot;
+        tmvb_reg_lane_maps(h->KP, tol, lot);
+        if ((rc = dmalloc(&h->d_topic_of_lane, tol.size()))) { tmvb_ctpf_destroy(h); return rc; }
+        TMVB_HIP(hipMemcpy(h->d_topic_of_lane, tol.data(), tol.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
     std::vector<int64_t> len((size_t)h->M);
-    for (int64_t d = 0; d < h->M; ++d) len[d] = corp->h_doc_len[d] + corp->h_rdr_len[d];
-    std::vector<int32_t> order((size_t)h->M);
-    std::iota(order.begin(), order.end(), 0);
+    std::vector<int32_t> order, reg2, reg1;
+    for (int64_t d = 0; d < h->M; ++d) {
+        len[d] = corp->h_doc_len[d] + corp->h_rdr_len[d];
+        const bool reg = h->reg_path && corp->h_doc_len[d] <= 128 && corp->h_rdr_len[d] <= 64;
+        if (!reg) order.push_back((int32_t)d);
+        else if (corp->h_doc_len[d] > 64) reg2.push_back((int32_t)d);
+        else reg1.push_back((int32_t)d);
+    }
     std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return len[x] > len[y]; });
-    tmvb_build_lds_buckets(len, order, h->M, h->KP, -1, 3, h->buckets);
+    const int64_t n_lds = (int64_t)order.size();
+    tmvb_build_lds_buckets(len, order, n_lds, h->KP, -1, 3, h->buckets);
+    auto by_terms = [&](int32_t x, int32_t y) { return corp->h_doc_len[x] > corp->h_doc_len[y]; };
+    std::stable_sort(reg2.begin(), reg2.end(), by_terms);
+    std::stable_sort(reg1.begin(), reg1.end(), by_terms);
+    if (!reg2.empty()) h->buckets.push_back({(int64_t)order.size(), (int64_t)reg2.size(), 0, 2});
+    order.insert(order.end(), reg2.begin(), reg2.end());
+    if (!reg1.empty()) h->buckets.push_back({(int64_t)order.size(), (int64_t)reg1.size(), 0, 1});
+    order.insert(order.end(), reg1.begin(), reg1.end());
     if (h->M) TMVB_HIP(hipMemcpyAsync(h->d_doc_order, order.data(), (size_t)h->M * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     TMVB_HIP(hipMemsetAsync(h->d_stats, 0, (size_t)h->stats_len() * sizeof(float), ctx->stream));
     TMVB_HIP(hipMemsetAsync(h->d_sweeps, 0, std::max<size_t>((size_t)h->M, 1), ctx->stream));
@@ -591,27 +745,35 @@ extern "C" int tmvb_ctpf_estep(tmvb_ctpf* h, int32_t viter, double vtol)
     p.wtok = h->d_wtok; p.wrdr = h->d_wrdr; p.E1 = h->d_E1; p.E2 = h->d_E2; p.sweeps = h->d_sweeps;
     p.viter = viter; p.vtol = (float)vtol;
     TMVB_HIP(hipEventRecord(h->ev0, ctx->stream));
+    // stream plan as in tmvb_lda_estep: register-tile buckets back to back on aux[0], LDS-tile buckets on aux[1]
     const int nb = (int)h->buckets.size();
-    const int naux = std::min(nb, (int)tmvb_ctpf::NAUX);
-    if (naux > 1) {
-        TMVB_HIP(hipEventRecord(h->ev_fork, ctx->stream));
-        for (int a = 0; a < naux; ++a) TMVB_HIP(hipStreamWaitEvent(h->aux[a], h->ev_fork, 0));
-    }
+    TMVB_HIP(hipEventRecord(h->ev_fork, ctx->stream));
+    for (int a = 0; a < 2; ++a) TMVB_HIP(hipStreamWaitEvent(h->aux[a], h->ev_fork, 0));
     for (int bi = 0; bi < nb; ++bi) {
         const tmvb_bucket& b = h->buckets[bi];
-        hipStream_t st = (naux > 1) ? h->aux[bi % naux] : ctx->stream;
-        const size_t lds = ctpf_tile_bytes(b.tile_rows, h->KP);
         const dim3 grid((unsigned)b.count), block(64);
+        if (b.reg_tiles > 0) {
+            hipStream_t st = h->aux[0];
+            switch (p.LPR) {
+#define CTPF_REG_CASE(LPRV) case LPRV: ctpf_launch_reg<LPRV>(b.reg_tiles, grid, st, p, b.first, h->d_topic_of_lane); break;
+                CTPF_REG_CASE(1) CTPF_REG_CASE(3) CTPF_REG_CASE(5) CTPF_REG_CASE(7) CTPF_REG_CASE(9) CTPF_REG_CASE(11) CTPF_REG_CASE(13)
+                CTPF_REG_CASE(15)
+#undef CTPF_REG_CASE
+                default: TMVB_REQUIRE(false, TMVB_EINVAL, "tmvb_ctpf_estep: no register-tile kernel for KP=%d", h->KP);
+            }
+            TMVB_HIP(hipGetLastError());
+            continue;
+        }
+        hipStream_t st = h->reg_path ? h->aux[1] : h->aux[(bi & 1) ^ 1];
+        const size_t lds = ctpf_tile_bytes(b.tile_rows, h->KP);
         if (p.LPR == 13) hipLaunchKernelGGL((ctpf_estep_kernel<13>), grid, block, lds, st, p, b.first, b.tile_rows);
         else if (p.LPR == 3) hipLaunchKernelGGL((ctpf_estep_kernel<3>), grid, block, lds, st, p, b.first, b.tile_rows);
         else hipLaunchKernelGGL((ctpf_estep_kernel<0>), grid, block, lds, st, p, b.first, b.tile_rows);
         TMVB_HIP(hipGetLastError());
     }
-    if (naux > 1) {
-        for (int a = 0; a < naux; ++a) {
-            TMVB_HIP(hipEventRecord(h->ev_join[a], h->aux[a]));
-            TMVB_HIP(hipStreamWaitEvent(ctx->stream, h->ev_join[a], 0));
-        }
+    for (int a = 0; a < 2; ++a) {
+        TMVB_HIP(hipEventRecord(h->ev_join[a], h->aux[a]));
+        TMVB_HIP(hipStreamWaitEvent(ctx->stream, h->ev_join[a], 0));
     }
     // update_alef!(model, d) / update_he!(model, d) (src/CTPF.jl:259-262, :274-277) as gather-side statistics
     TermStatsParams tp;

@@ -26,15 +26,13 @@
 // Roofline: HBM-bound gather/scatter.  Algorithmic bytes per outer iteration:
 //   nnz*(8 + 4K + 4K) + 12*M*K + 12*K*V + 4*(M+1).
 #include "tmvb_common_kernels.h"
-#include <utility>
+#include "tmvb_regtile.h"
 
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
 
-
-typedef float v2f __attribute__((ext_vector_type(2)));
 
 struct LdaParams {
     int K, KP, LPR;          // topics, padded row stride (4*odd), 16-byte chunks per row (KP/4)
@@ -265,35 +263,6 @@ __global__ __launch_bounds__(64) void lda_estep_kernel(LdaParams p, int64_t firs
     if (lane == 0) p.sweeps[d] = (uint8_t)min(sweeps, 255);
 }
 
-// e_q broadcasts of one block of <= 32 topics: v_readlane with an immediate lane (the lane map is a
-// compile-time constant), results in SGPR pairs consumed directly by v_pk_fma_f32.
-template <int R, int Q> struct LaneOfTopic { static constexpr int value = kRegLaneMap<R>.lane_of_topic[Q]; };
-
-template <int R, int Q0, int NS, int... I>
-__device__ __forceinline__ void lda_bcast_e(float (&es)[sizeof...(I)], const float (&e)[NS], std::integer_sequence<int, I...>)
-{
-    ((es[I] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(
-                  __builtin_bit_cast(int, LaneOfTopic<R, Q0 + I>::value < 64 ? e[0] : e[NS - 1]),
-                  LaneOfTopic<R, Q0 + I>::value & 63))), ...);
-}
-
-// phase 1 for topics [Q0, Q0 + 32): sacc[t] += B[t][q] e_q, two topics per packed fma
-template <int R, int T, int Q0>
-__device__ __forceinline__ void lda_phase1_block(const v2f (&B2)[T][R / 2], const float (&e)[(R + 63) / 64], v2f (&sacc)[T][2])
-{
-    constexpr int QB = (R - Q0 < 32) ? R - Q0 : 32;
-    float es[QB];
-    lda_bcast_e<R, Q0>(es, e, std::make_integer_sequence<int, QB>{});
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-#pragma unroll
-        for (int q = 0; q < QB; q += 2) {
-            const v2f e2 = v2f{es[q], es[q + 1]};
-            sacc[t][(q >> 1) & 1] = __builtin_elementwise_fma(B2[t][(Q0 + q) / 2], e2, sacc[t][(q >> 1) & 1]);
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------ register-tile E-step
 // For K <= 64 and documents of at most 64*T unique terms the whole N_d x KP topic tile lives in
 // VGPRs (lane = token, register = topic): the register file (512 KiB per CU) is 3x the LDS, so the
@@ -363,10 +332,10 @@ __global__ __launch_bounds__(64) void lda_estep_reg_kernel(LdaParams p, int64_t 
         v2f sacc[T][2];
 #pragma unroll
         for (int t = 0; t < T; ++t) { sacc[t][0] = v2f{0.f, 0.f}; sacc[t][1] = v2f{0.f, 0.f}; }
-        lda_phase1_block<R, T, 0>(B2, e, sacc);
-        if constexpr (R > 32) lda_phase1_block<R, T, 32>(B2, e, sacc);
-        if constexpr (R > 64) lda_phase1_block<R, T, 64>(B2, e, sacc);
-        if constexpr (R > 96) lda_phase1_block<R, T, 96>(B2, e, sacc);
+        regtile_phase1_block<R, T, 0>(B2, e, sacc);
+        if constexpr (R > 32) regtile_phase1_block<R, T, 32>(B2, e, sacc);
+        if constexpr (R > 64) regtile_phase1_block<R, T, 64>(B2, e, sacc);
+        if constexpr (R > 96) regtile_phase1_block<R, T, 96>(B2, e, sacc);
         float wl = 0.0f;
 #pragma unroll
         for (int t = 0; t < T; ++t) {
