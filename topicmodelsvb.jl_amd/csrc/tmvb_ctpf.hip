@@ -517,7 +517,7 @@ struct tmvb_ctpf {
     double* d_rates = nullptr; float* d_lrates = nullptr;          // [8][K], [4][K]
     float* d_gimel = nullptr; float* d_gimel_old = nullptr; float* d_zayin = nullptr; float* d_zayin_old = nullptr;
     float* d_wtok = nullptr; float* d_wrdr = nullptr; float* d_E1 = nullptr; float* d_E2 = nullptr;
-    float* d_ts_partial = nullptr;
+    float* d_ts_partial = nullptr; float* d_ts_partial2 = nullptr;   // multi-chunk partials of the term / reader statistics passes
     uint8_t* d_sweeps = nullptr; int32_t* d_doc_order = nullptr;
     double* d_doc_val = nullptr; double* d_elbo_partial = nullptr; double* d_elbo = nullptr;
     double* d_partial = nullptr; double* d_rs_alef = nullptr; double* d_rs_he = nullptr; double* d_sum_g = nullptr; double* d_sum_z = nullptr;
@@ -546,7 +546,7 @@ extern "C" int tmvb_ctpf_destroy(tmvb_ctpf* h)
     if (h->own_stats) (void)hipFree(h->d_stats);
     (void)hipFree(h->d_rates); (void)hipFree(h->d_lrates); (void)hipFree(h->d_gimel); (void)hipFree(h->d_gimel_old);
     (void)hipFree(h->d_zayin); (void)hipFree(h->d_zayin_old); (void)hipFree(h->d_wtok); (void)hipFree(h->d_wrdr);
-    (void)hipFree(h->d_E1); (void)hipFree(h->d_E2); (void)hipFree(h->d_ts_partial); (void)hipFree(h->d_sweeps);
+    (void)hipFree(h->d_E1); (void)hipFree(h->d_E2); (void)hipFree(h->d_ts_partial); (void)hipFree(h->d_ts_partial2); (void)hipFree(h->d_sweeps);
     (void)hipFree(h->d_doc_order); (void)hipFree(h->d_partial); (void)hipFree(h->d_rs_alef); (void)hipFree(h->d_rs_he);
     (void)hipFree(h->d_sum_g); (void)hipFree(h->d_sum_z); (void)hipFree(h->d_doc_val); (void)hipFree(h->d_elbo_partial); (void)hipFree(h->d_elbo);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -599,7 +599,7 @@ extern "C" int tmvb_ctpf_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmv
         (rc = dmalloc(&h->d_gimel, KM)) || (rc = dmalloc(&h->d_gimel_old, KM)) || (rc = dmalloc(&h->d_zayin, KM)) || (rc = dmalloc(&h->d_zayin_old, KM)) ||
         (rc = dmalloc(&h->d_wtok, (size_t)corp->info.nnz)) || (rc = dmalloc(&h->d_wrdr, (size_t)corp->info.nR)) ||
         (rc = dmalloc(&h->d_E1, (size_t)h->KP * h->M + 4)) || (rc = dmalloc(&h->d_E2, (size_t)h->KP * h->M + 4)) ||
-        (rc = dmalloc(&h->d_ts_partial, slots * (K + 1))) || (rc = dmalloc(&h->d_sweeps, (size_t)h->M)) || (rc = dmalloc(&h->d_doc_order, (size_t)h->M)) ||
+        (rc = dmalloc(&h->d_ts_partial, slots * (K + 1))) || (rc = dmalloc(&h->d_ts_partial2, slots * (K + 1))) || (rc = dmalloc(&h->d_sweeps, (size_t)h->M)) || (rc = dmalloc(&h->d_doc_order, (size_t)h->M)) ||
         (rc = dmalloc(&h->d_partial, (size_t)TMVB_REDUCE_BLOCKS * K)) || (rc = dmalloc(&h->d_rs_alef, K)) || (rc = dmalloc(&h->d_rs_he, K)) ||
         (rc = dmalloc(&h->d_sum_g, K)) || (rc = dmalloc(&h->d_sum_z, K)) || (rc = dmalloc(&h->d_doc_val, (size_t)h->M)) ||
         (rc = dmalloc(&h->d_elbo_partial, 1024)) || (rc = dmalloc(&h->d_elbo, 1))) {
@@ -626,7 +626,7 @@ extern "C" int tmvb_ctpf_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmv
     }
     std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return len[x] > len[y]; });
     const int64_t n_lds = (int64_t)order.size();
-    tmvb_build_lds_buckets(len, order, n_lds, h->KP, -1, 3, h->buckets);
+    tmvb_build_lds_buckets(len, order, n_lds, h->KP, -1, 3, h->buckets, h->reg_path ? TMVB_BIG_TILE_BYTES : TMVB_MAX_TILE_BYTES);
     auto by_terms = [&](int32_t x, int32_t y) { return corp->h_doc_len[x] > corp->h_doc_len[y]; };
     std::stable_sort(reg2.begin(), reg2.end(), by_terms);
     std::stable_sort(reg1.begin(), reg1.end(), by_terms);
@@ -766,9 +766,14 @@ extern "C" int tmvb_ctpf_estep(tmvb_ctpf* h, int32_t viter, double vtol)
         }
         hipStream_t st = h->reg_path ? h->aux[1] : h->aux[(bi & 1) ^ 1];
         const size_t lds = ctpf_tile_bytes(b.tile_rows, h->KP);
-        if (p.LPR == 13) hipLaunchKernelGGL((ctpf_estep_kernel<13>), grid, block, lds, st, p, b.first, b.tile_rows);
-        else if (p.LPR == 3) hipLaunchKernelGGL((ctpf_estep_kernel<3>), grid, block, lds, st, p, b.first, b.tile_rows);
-        else hipLaunchKernelGGL((ctpf_estep_kernel<0>), grid, block, lds, st, p, b.first, b.tile_rows);
+        auto launch = [&](auto kern) -> int {
+            if (lds > TMVB_MAX_TILE_BYTES)                // long documents: the whole row set resident in up to 156 KiB of LDS
+                TMVB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, grid, block, lds, st, p, b.first, b.tile_rows);
+            return TMVB_OK;
+        };
+        int lrc = (p.LPR == 13) ? launch(ctpf_estep_kernel<13>) : (p.LPR == 3) ? launch(ctpf_estep_kernel<3>) : launch(ctpf_estep_kernel<0>);
+        if (lrc) return lrc;
         TMVB_HIP(hipGetLastError());
     }
     for (int a = 0; a < 2; ++a) {
@@ -779,11 +784,16 @@ extern "C" int tmvb_ctpf_estep(tmvb_ctpf* h, int32_t viter, double vtol)
     TermStatsParams tp;
     tp.K = h->K; tp.tstride = h->KP; tp.ostride = h->K; tp.eps = 0.0f; tp.base = 0.0f; tp.keps = 0.0f; tp.partial = h->d_ts_partial;
     tp.w = h->d_wtok; tp.E = h->d_E1; tp.T = h->d_TA; tp.out = h->d_stats;
+    // the two passes are independent (alef / he statistics): the reader pass runs on aux[0] under the term pass
+    TMVB_HIP(hipEventRecord(h->ev_fork, ctx->stream));
     int rc = tmvb_launch_termstats(ctx, 1, h->KP, true, h->corp->term_index, tp);
     if (rc) return rc;
     if (h->U > 0) {
-        tp.w = h->d_wrdr; tp.E = h->d_E2; tp.T = h->d_TH; tp.out = h->he_stats();
-        if ((rc = tmvb_launch_termstats(ctx, 1, h->KP, true, h->corp->reader_index, tp))) return rc;
+        tp.w = h->d_wrdr; tp.E = h->d_E2; tp.T = h->d_TH; tp.out = h->he_stats(); tp.partial = h->d_ts_partial2;
+        TMVB_HIP(hipStreamWaitEvent(h->aux[0], h->ev_fork, 0));
+        if ((rc = tmvb_launch_termstats(ctx, 1, h->KP, true, h->corp->reader_index, tp, h->aux[0]))) return rc;
+        TMVB_HIP(hipEventRecord(h->ev_join[0], h->aux[0]));
+        TMVB_HIP(hipStreamWaitEvent(ctx->stream, h->ev_join[0], 0));
     }
     TMVB_HIP(hipEventRecord(h->ev1, ctx->stream));
     h->timed = true;
