@@ -338,6 +338,7 @@ static void ctpf_launch_reg(int tiles, dim3 grid, hipStream_t st, const CtpfPara
 // shape update + table refresh:  X[id][i] = prior + stats[id][i];  T[id][i] = exp(psi(X));  stats <- 0
 // (update_alef!/update_he! src/CTPF.jl:251-255, :266-270: X <- X_temp, X_temp <- prior)
 __global__ __launch_bounds__(256) void ctpf_shape_kernel(float* __restrict__ stats, float prior, float* __restrict__ X,
+                                                         float* __restrict__ X_old /* or NULL */,
                                                          float* __restrict__ T, int K, int KP, int64_t n_ids, int refresh_only)
 {
     const int64_t total = n_ids * KP;
@@ -349,7 +350,10 @@ __global__ __launch_bounds__(256) void ctpf_shape_kernel(float* __restrict__ sta
         if (i < K) {
             float x;
             if (refresh_only) x = X[j * K + i];
-            else { x = prior + stats[j * K + i]; X[j * K + i] = x; stats[j * K + i] = 0.0f; }
+            else {
+                if (X_old) X_old[j * K + i] = X[j * K + i];               // X_old <- X  (src/CTPF.jl:252, :267)
+                x = prior + stats[j * K + i]; X[j * K + i] = x; stats[j * K + i] = 0.0f;
+            }
             t = expf(digamma_f(x));
         }
         T[q] = t;
@@ -520,7 +524,7 @@ struct tmvb_ctpf {
     float* d_ts_partial = nullptr; float* d_ts_partial2 = nullptr;   // multi-chunk partials of the term / reader statistics passes
     uint8_t* d_sweeps = nullptr; int32_t* d_doc_order = nullptr;
     double* d_doc_val = nullptr; double* d_elbo_partial = nullptr; double* d_elbo = nullptr;
-    double* d_partial = nullptr; double* d_rs_alef = nullptr; double* d_rs_he = nullptr; double* d_sum_g = nullptr; double* d_sum_z = nullptr;
+    double* d_partial = nullptr; double* d_partial2 = nullptr; double* d_rs_alef = nullptr; double* d_rs_he = nullptr; double* d_sum_g = nullptr; double* d_sum_z = nullptr;
     double elbo = 0.0;
     int* d_topic_of_lane = nullptr;     // register-tile kernel: topic owned by each lane after the reduce-scatter
     bool reg_path = false;              // KP = 4 * odd <= 60: short documents (<= 128 terms, <= 64 readers) use ctpf_estep_reg_kernel
@@ -547,7 +551,7 @@ extern "C" int tmvb_ctpf_destroy(tmvb_ctpf* h)
     (void)hipFree(h->d_rates); (void)hipFree(h->d_lrates); (void)hipFree(h->d_gimel); (void)hipFree(h->d_gimel_old);
     (void)hipFree(h->d_zayin); (void)hipFree(h->d_zayin_old); (void)hipFree(h->d_wtok); (void)hipFree(h->d_wrdr);
     (void)hipFree(h->d_E1); (void)hipFree(h->d_E2); (void)hipFree(h->d_ts_partial); (void)hipFree(h->d_ts_partial2); (void)hipFree(h->d_sweeps);
-    (void)hipFree(h->d_doc_order); (void)hipFree(h->d_partial); (void)hipFree(h->d_rs_alef); (void)hipFree(h->d_rs_he);
+    (void)hipFree(h->d_doc_order); (void)hipFree(h->d_partial); (void)hipFree(h->d_partial2); (void)hipFree(h->d_rs_alef); (void)hipFree(h->d_rs_he);
     (void)hipFree(h->d_sum_g); (void)hipFree(h->d_sum_z); (void)hipFree(h->d_doc_val); (void)hipFree(h->d_elbo_partial); (void)hipFree(h->d_elbo);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -564,11 +568,11 @@ static int ctpf_refresh_tables(tmvb_ctpf* h)
 {
     tmvb_ctx* ctx = h->ctx;
     int nb = (int)std::min<int64_t>(2048, std::max<int64_t>(1, ((int64_t)h->KP * h->V + 255) / 256));
-    hipLaunchKernelGGL(ctpf_shape_kernel, dim3(nb), dim3(256), 0, ctx->stream, (float*)nullptr, 0.0f, h->d_alef, h->d_TA, h->K, h->KP, h->V, 1);
+    hipLaunchKernelGGL(ctpf_shape_kernel, dim3(nb), dim3(256), 0, ctx->stream, (float*)nullptr, 0.0f, h->d_alef, (float*)nullptr, h->d_TA, h->K, h->KP, h->V, 1);
     TMVB_HIP(hipGetLastError());
     if (h->U > 0) {
         nb = (int)std::min<int64_t>(2048, std::max<int64_t>(1, ((int64_t)h->KP * h->U + 255) / 256));
-        hipLaunchKernelGGL(ctpf_shape_kernel, dim3(nb), dim3(256), 0, ctx->stream, (float*)nullptr, 0.0f, h->d_he, h->d_TH, h->K, h->KP, h->U, 1);
+        hipLaunchKernelGGL(ctpf_shape_kernel, dim3(nb), dim3(256), 0, ctx->stream, (float*)nullptr, 0.0f, h->d_he, (float*)nullptr, h->d_TH, h->K, h->KP, h->U, 1);
         TMVB_HIP(hipGetLastError());
     }
     return TMVB_OK;
@@ -600,7 +604,7 @@ extern "C" int tmvb_ctpf_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmv
         (rc = dmalloc(&h->d_wtok, (size_t)corp->info.nnz)) || (rc = dmalloc(&h->d_wrdr, (size_t)corp->info.nR)) ||
         (rc = dmalloc(&h->d_E1, (size_t)h->KP * h->M + 4)) || (rc = dmalloc(&h->d_E2, (size_t)h->KP * h->M + 4)) ||
         (rc = dmalloc(&h->d_ts_partial, slots * (K + 1))) || (rc = dmalloc(&h->d_ts_partial2, slots * (K + 1))) || (rc = dmalloc(&h->d_sweeps, (size_t)h->M)) || (rc = dmalloc(&h->d_doc_order, (size_t)h->M)) ||
-        (rc = dmalloc(&h->d_partial, (size_t)TMVB_REDUCE_BLOCKS * K)) || (rc = dmalloc(&h->d_rs_alef, K)) || (rc = dmalloc(&h->d_rs_he, K)) ||
+        (rc = dmalloc(&h->d_partial, (size_t)TMVB_REDUCE_BLOCKS * K)) || (rc = dmalloc(&h->d_partial2, (size_t)TMVB_REDUCE_BLOCKS * K)) || (rc = dmalloc(&h->d_rs_alef, K)) || (rc = dmalloc(&h->d_rs_he, K)) ||
         (rc = dmalloc(&h->d_sum_g, K)) || (rc = dmalloc(&h->d_sum_z, K)) || (rc = dmalloc(&h->d_doc_val, (size_t)h->M)) ||
         (rc = dmalloc(&h->d_elbo_partial, 1024)) || (rc = dmalloc(&h->d_elbo, 1))) {
         tmvb_ctpf_destroy(h);
@@ -807,7 +811,7 @@ extern "C" int tmvb_ctpf_reduce_docs(tmvb_ctpf* h)
     TMVB_HIP(hipSetDevice(h->ctx->device));
     int rc;
     if ((rc = tmvb_colsum(h->ctx, 1, h->K, h->d_gimel, h->M, h->d_partial, h->d_sum_g, h->tail()))) return rc;
-    return tmvb_colsum(h->ctx, 1, h->K, h->d_zayin, h->M, h->d_partial, h->d_sum_z, h->tail() + h->K);
+    return tmvb_colsum(h->ctx, 1, h->K, h->d_zayin, h->M, h->d_partial2, h->d_sum_z, h->tail() + h->K);
 }
 
 extern "C" int tmvb_ctpf_stats(tmvb_ctpf* h, void** dev_ptr, int64_t* n_f32)
@@ -845,32 +849,30 @@ extern "C" int tmvb_ctpf_mstep(tmvb_ctpf* h)
     TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_ctpf_mstep: handle is NULL");
     tmvb_ctx* ctx = h->ctx;
     TMVB_HIP(hipSetDevice(ctx->device));
-    const size_t KV = (size_t)h->K * h->V, KU = (size_t)h->K * h->U;
     int rc;
     if (h->distributed) {     // tail -> fp64 sums
         if ((rc = tmvb_colsum(ctx, 1, h->K, h->tail(), 1, h->d_partial, h->d_sum_g, nullptr))) return rc;
         if ((rc = tmvb_colsum(ctx, 1, h->K, h->tail() + h->K, 1, h->d_partial, h->d_sum_z, nullptr))) return rc;
     }
-    // he_old <- he; he <- e + stats; TH refresh    (:266-270)
+    // he_old <- he; he <- e + stats; TH refresh; rowsum(he)    (:266-270)
+    // (measured: putting this branch on a second stream gains nothing -- the kernels are 5-8 us each and a
+    //  cross-stream dependency costs as much)
+    hipStream_t hs = ctx->stream;
     if (h->U > 0) {
-        TMVB_HIP(hipMemcpyAsync(h->d_he_old, h->d_he, KU * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
         int nb = (int)std::min<int64_t>(2048, std::max<int64_t>(1, ((int64_t)h->KP * h->U + 255) / 256));
-        hipLaunchKernelGGL(ctpf_shape_kernel, dim3(nb), dim3(256), 0, ctx->stream, h->he_stats(), (float)h->hyper[4], h->d_he, h->d_TH, h->K, h->KP, h->U, 0);
+        hipLaunchKernelGGL(ctpf_shape_kernel, dim3(nb), dim3(256), 0, hs, h->he_stats(), (float)h->hyper[4], h->d_he, h->d_he_old, h->d_TH, h->K, h->KP, h->U, 0);
         TMVB_HIP(hipGetLastError());
-    }
-    // alef_old <- alef; alef <- a + stats; TA refresh   (:251-255)
-    TMVB_HIP(hipMemcpyAsync(h->d_alef_old, h->d_alef, KV * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
-    {
-        int nb = (int)std::min<int64_t>(2048, std::max<int64_t>(1, ((int64_t)h->KP * h->V + 255) / 256));
-        hipLaunchKernelGGL(ctpf_shape_kernel, dim3(nb), dim3(256), 0, ctx->stream, h->d_stats, (float)h->hyper[0], h->d_alef, h->d_TA, h->K, h->KP, h->V, 0);
-        TMVB_HIP(hipGetLastError());
-    }
-    if ((rc = tmvb_colsum(ctx, 1, h->K, h->d_alef, h->V, h->d_partial, h->d_rs_alef, nullptr))) return rc;
-    if (h->U > 0) {
-        if ((rc = tmvb_colsum(ctx, 1, h->K, h->d_he, h->U, h->d_partial, h->d_rs_he, nullptr))) return rc;
+        if ((rc = tmvb_colsum(ctx, 1, h->K, h->d_he, h->U, h->d_partial2, h->d_rs_he, nullptr, hs))) return rc;
     } else {
         TMVB_HIP(hipMemsetAsync(h->d_rs_he, 0, (size_t)h->K * sizeof(double), ctx->stream));
     }
+    // alef_old <- alef; alef <- a + stats; TA refresh; rowsum(alef)   (:251-255)
+    {
+        int nb = (int)std::min<int64_t>(2048, std::max<int64_t>(1, ((int64_t)h->KP * h->V + 255) / 256));
+        hipLaunchKernelGGL(ctpf_shape_kernel, dim3(nb), dim3(256), 0, ctx->stream, h->d_stats, (float)h->hyper[0], h->d_alef, h->d_alef_old, h->d_TA, h->K, h->KP, h->V, 0);
+        TMVB_HIP(hipGetLastError());
+    }
+    if ((rc = tmvb_colsum(ctx, 1, h->K, h->d_alef, h->V, h->d_partial, h->d_rs_alef, nullptr))) return rc;
     hipLaunchKernelGGL((ctpf_rates_kernel<1>), dim3(1), dim3(64), 0, ctx->stream, h->K, h->hyper[1], h->hyper[3], h->hyper[5], h->hyper[7],
                        h->d_rs_alef, h->d_rs_he, h->d_sum_g, h->d_sum_z, h->d_rates, h->d_lrates);
     TMVB_HIP(hipGetLastError());
