@@ -86,6 +86,23 @@ typedef struct {
 } tmvb_corpus_info_t;
 int tmvb_corpus_info(const tmvb_corpus* corp, tmvb_corpus_info_t* out);
 
+/* ---- docfile ingest: the document part of readcorp (src/Corpus.jl:277-299) straight into the packed CSR ----
+ * The reference's text format: one document = a block of 1 + counts + readers + ratings lines of `delim`-separated
+ * positive integers (terms; then counts, readers, ratings as switched on).  Missing counts / ratings default to 1
+ * (src/Corpus.jl:18-21).  Ids are converted to 0-based.  With condense != 0 equal term ids of a document are merged and
+ * their counts added, terms sorted ascending (condense_corp!, src/Corpus.jl:523-531) -- the form the engine needs
+ * (quirk Q1).  A block that does not parse fails with TMVB_ECORPUS and the reference's message
+ * "document d beginning on line l failed to load." (:295).  The arrays are allocated by the library; release each
+ * with tmvb_host_free.  V_seen / U_seen = 1 + the largest 0-based term / reader id read (0 if none). */
+typedef struct {
+    int64_t M, nnz, nR, V_seen, U_seen;
+    int64_t* doc_ptr;  int32_t* terms;   int32_t* counts;     /* [M+1], [nnz], [nnz] */
+    int64_t* rdr_ptr;  int32_t* readers; int32_t* ratings;    /* [M+1], [nR], [nR] */
+} tmvb_docfile_t;
+int tmvb_docfile_read(const char* path, char delim, int32_t counts, int32_t readers, int32_t ratings, int32_t condense,
+                      tmvb_docfile_t* out);
+void tmvb_docfile_free(tmvb_docfile_t* f);
+
 /* ============================== LDA (src/gpuLDA.jl, oracle src/LDA.jl) ============================== */
 
 /* gpuLDA(corp, K) (src/gpuLDA.jl:45-84).  State is initialised as the constructor does

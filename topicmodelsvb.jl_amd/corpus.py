@@ -134,6 +134,35 @@ def readcorp(docfile="", vocabfile="", userfile="", titlefile="", delim=",", cou
     return corp
 
 
+def readcorp_packed(docfile, delim=",", counts=False, readers=False, ratings=False, condense=True, V=None, U=None):
+    """The document part of readcorp (src/Corpus.jl:277-299) through the library's streaming parser
+    (`tmvb_docfile_read`, include/tmvb.h): the reference's docfile format straight into the packed 0-based CSR, without
+    per-document Python objects (NSF-sized files parse in well under a second).  condense=True merges equal term ids of
+    a document (condense_corp!, src/Corpus.jl:523-531), the form the engine needs.  V / U default to the largest id seen."""
+    import ctypes as C
+    from ._lib import check, lib
+
+    class _DocFile(C.Structure):
+        _fields_ = [("M", C.c_int64), ("nnz", C.c_int64), ("nR", C.c_int64), ("V_seen", C.c_int64), ("U_seen", C.c_int64),
+                    ("doc_ptr", C.POINTER(C.c_int64)), ("terms", C.POINTER(C.c_int32)), ("counts", C.POINTER(C.c_int32)),
+                    ("rdr_ptr", C.POINTER(C.c_int64)), ("readers", C.POINTER(C.c_int32)), ("ratings", C.POINTER(C.c_int32))]
+
+    f = _DocFile()
+    L = lib()
+    L.tmvb_docfile_free.restype = None
+    check(L.tmvb_docfile_read(str(docfile).encode(), C.c_char(delim.encode()), C.c_int32(bool(counts)), C.c_int32(bool(readers)),
+                              C.c_int32(bool(ratings)), C.c_int32(bool(condense)), C.byref(f)))
+    try:
+        arr = lambda ptr, n, dt: np.ctypeslib.as_array(ptr, shape=(max(int(n), 1),))[:int(n)].astype(dt, copy=True)
+        pc = PackedCorpus(arr(f.doc_ptr, f.M + 1, np.int64), arr(f.terms, f.nnz, np.int32), arr(f.counts, f.nnz, np.int32),
+                          int(V) if V is not None else int(f.V_seen),
+                          arr(f.rdr_ptr, f.M + 1, np.int64), arr(f.readers, f.nR, np.int32), arr(f.ratings, f.nR, np.int32),
+                          int(U) if U is not None else int(f.U_seen))
+    finally:
+        L.tmvb_docfile_free(C.byref(f))
+    return pc
+
+
 def _read_keyed(path):
     out = {}
     with open(path) as f:

@@ -7,6 +7,11 @@
 // order so that the hardware dispatcher sees the longest documents first.
 #include "tmvb_internal.h"
 
+#include <cstdio>
+#include <cstring>
+#include <type_traits>
+#include <utility>
+
 #include <algorithm>
 #include <cstring>
 #include <numeric>
@@ -307,5 +312,129 @@ extern "C" int tmvb_corpus_info(const tmvb_corpus* c, tmvb_corpus_info_t* out)
 {
     TMVB_REQUIRE(c != nullptr && out != nullptr, TMVB_EINVAL, "tmvb_corpus_info: NULL argument");
     *out = c->info;
+    return TMVB_OK;
+}
+
+// ------------------------------------------------------------------------------ docfile ingest
+// readcorp's document loop (src/Corpus.jl:285-299) as one streaming pass over the file: no per-document
+// objects, integers parsed in place, output directly in the packed CSR the engine uploads.
+static bool parse_int_line(const char* b, const char* e, char delim, std::vector<int64_t>& out)
+{
+    out.clear();
+    const char* q = b;
+    while (q < e && (*q == ' ' || *q == '\r')) ++q;
+    if (q == e) return true;                                   // empty line = empty list
+    for (;;) {
+        while (q < e && *q == ' ') ++q;
+        bool neg = false;
+        if (q < e && (*q == '-' || *q == '+')) { neg = (*q == '-'); ++q; }
+        if (q == e || *q < '0' || *q > '9') return false;
+        int64_t v = 0;
+        while (q < e && *q >= '0' && *q <= '9') { v = v * 10 + (*q - '0'); if (v > (int64_t)1 << 40) return false; ++q; }
+        out.push_back(neg ? -v : v);
+        while (q < e && (*q == ' ' || *q == '\r')) ++q;
+        if (q == e) return true;
+        if (*q != delim) return false;
+        ++q;
+    }
+}
+
+extern "C" void tmvb_docfile_free(tmvb_docfile_t* f)
+{
+    if (!f) return;
+    free(f->doc_ptr); free(f->terms); free(f->counts); free(f->rdr_ptr); free(f->readers); free(f->ratings);
+    memset(f, 0, sizeof(*f));
+}
+
+extern "C" int tmvb_docfile_read(const char* path, char delim, int32_t counts, int32_t readers, int32_t ratings, int32_t condense,
+                                 tmvb_docfile_t* out)
+{
+    TMVB_REQUIRE(path && out, TMVB_EINVAL, "tmvb_docfile_read: NULL argument");
+    memset(out, 0, sizeof(*out));
+    if (ratings && !readers) ratings = 0;                       // "ratings require readers" (src/Corpus.jl:278)
+    FILE* fp = fopen(path, "rb");
+    TMVB_REQUIRE(fp != nullptr, TMVB_ECORPUS, "tmvb_docfile_read: cannot open %s", path);
+    std::vector<char> buf;
+    {
+        fseek(fp, 0, SEEK_END);
+        const long sz = ftell(fp);
+        fseek(fp, 0, SEEK_SET);
+        buf.resize(sz > 0 ? (size_t)sz : 0);
+        const size_t got = buf.empty() ? 0 : fread(buf.data(), 1, buf.size(), fp);
+        fclose(fp);
+        TMVB_REQUIRE(got == buf.size(), TMVB_ECORPUS, "tmvb_docfile_read: short read of %s", path);
+    }
+    const int block = 1 + (counts != 0) + (readers != 0) + (ratings != 0);
+    std::vector<int64_t> doc_ptr{0}, rdr_ptr{0};
+    std::vector<int32_t> terms, cnts, rdrs, rats;
+    std::vector<int64_t> line[4];
+    std::vector<std::pair<int64_t, int64_t>> tc;
+    const char* q = buf.data();
+    const char* end = q + buf.size();
+    int64_t d = 0, lineno = 0, max_t = -1, max_u = -1;
+    while (q < end) {
+        ++d;
+        const int64_t first_line = lineno + 1;
+        bool ok = true;
+        int have = 0;
+        for (int l = 0; l < block && q < end; ++l, ++have) {
+            const char* nl = (const char*)memchr(q, '\n', (size_t)(end - q));
+            const char* le = nl ? nl : end;
+            ok = parse_int_line(q, le, delim, line[l]) && ok;
+            q = nl ? nl + 1 : end;
+            ++lineno;
+        }
+        for (int l = have; l < block; ++l) line[l].clear();     // a truncated last block: missing lines are empty (zip semantics)
+        const std::vector<int64_t>& T = line[0];
+        int li = 1;
+        const std::vector<int64_t>* C = counts ? &line[li++] : nullptr;
+        const std::vector<int64_t>* R = readers ? &line[li++] : nullptr;
+        const std::vector<int64_t>* G = ratings ? &line[li++] : nullptr;
+        // check_doc (src/Corpus.jl:41-50): positive ids / counts / ratings, equal lengths
+        ok = ok && (!C || C->size() == T.size()) && (!G || (R && G->size() == R->size()));
+        for (int64_t v : T) ok = ok && v > 0 && v <= INT32_MAX;
+        if (C) for (int64_t v : *C) ok = ok && v > 0 && v <= INT32_MAX;
+        if (R) for (int64_t v : *R) ok = ok && v > 0 && v <= INT32_MAX;
+        if (G) for (int64_t v : *G) ok = ok && v > 0 && v <= INT32_MAX;
+        if (!ok) {
+            tmvb_set_error("document %lld beginning on line %lld failed to load.", (long long)d, (long long)first_line);   // :295
+            return TMVB_ECORPUS;
+        }
+        if (condense) {
+            tc.clear();
+            for (size_t n = 0; n < T.size(); ++n) tc.emplace_back(T[n] - 1, C ? (*C)[n] : 1);
+            std::sort(tc.begin(), tc.end());
+            for (size_t n = 0; n < tc.size();) {
+                int64_t cs = 0; size_t m = n;
+                while (m < tc.size() && tc[m].first == tc[n].first) cs += tc[m++].second;
+                terms.push_back((int32_t)tc[n].first); cnts.push_back((int32_t)std::min<int64_t>(cs, INT32_MAX));
+                n = m;
+            }
+        } else {
+            for (size_t n = 0; n < T.size(); ++n) { terms.push_back((int32_t)(T[n] - 1)); cnts.push_back(C ? (int32_t)(*C)[n] : 1); }
+        }
+        for (int64_t v : T) max_t = std::max(max_t, v - 1);
+        if (R) for (size_t n = 0; n < R->size(); ++n) {
+            rdrs.push_back((int32_t)((*R)[n] - 1)); rats.push_back(G ? (int32_t)(*G)[n] : 1);
+            max_u = std::max(max_u, (*R)[n] - 1);
+        }
+        doc_ptr.push_back((int64_t)terms.size());
+        rdr_ptr.push_back((int64_t)rdrs.size());
+    }
+    auto give = [](auto& v, auto** dst) -> bool {
+        typedef typename std::remove_reference<decltype(v[0])>::type E;
+        *dst = (E*)malloc(std::max<size_t>(v.size(), 1) * sizeof(E));
+        if (!*dst) return false;
+        if (!v.empty()) memcpy(*dst, v.data(), v.size() * sizeof(E));
+        return true;
+    };
+    out->M = (int64_t)doc_ptr.size() - 1; out->nnz = (int64_t)terms.size(); out->nR = (int64_t)rdrs.size();
+    out->V_seen = max_t + 1; out->U_seen = max_u + 1;
+    if (!give(doc_ptr, &out->doc_ptr) || !give(terms, &out->terms) || !give(cnts, &out->counts) || !give(rdr_ptr, &out->rdr_ptr) ||
+        !give(rdrs, &out->readers) || !give(rats, &out->ratings)) {
+        tmvb_docfile_free(out);
+        tmvb_set_error("tmvb_docfile_read: out of host memory");
+        return TMVB_ENOMEM;
+    }
     return TMVB_OK;
 }
