@@ -65,6 +65,10 @@ int tmvb_device_count(void);
 int tmvb_ctx_create(int32_t device_id, void* hip_stream, tmvb_ctx** out);
 int tmvb_ctx_destroy(tmvb_ctx* ctx);
 int tmvb_ctx_synchronize(tmvb_ctx* ctx);
+/* Diagnostics: evaluate the engine's fp32 device special functions on host data (the accuracy pins of the tests).
+ * which: 0 = digamma (x > 0; src/utils.jl:21-53's algorithm), 1 = exp as used for exp(Elogtheta) (x <= 0 in exact
+ * arithmetic), 2 = the rcp-based reciprocal 1/x. */
+int tmvb_special_f32(tmvb_ctx* ctx, int32_t which, const float* x, float* y, int64_t n);
 
 /* ---- corpus upload: the corpus half of update_buffer! (src/modelutils.jl:370-388, :438-472) ----
  * doc_ptr[M+1], terms[nnz], counts[nnz]; rdr_ptr/readers/ratings may be NULL when U == 0.

@@ -315,6 +315,34 @@ extern "C" int tmvb_corpus_info(const tmvb_corpus* c, tmvb_corpus_info_t* out)
     return TMVB_OK;
 }
 
+// ------------------------------------------------------------------------------ special-function diagnostics
+__global__ __launch_bounds__(256) void special_f32_kernel(int which, const float* __restrict__ x, float* __restrict__ y, int64_t n)
+{
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    const float v = x[q];
+    y[q] = which == 0 ? digamma_f(v) : which == 1 ? fast_exp(v) : fast_rcp(v);
+}
+
+extern "C" int tmvb_special_f32(tmvb_ctx* ctx, int32_t which, const float* x, float* y, int64_t n)
+{
+    TMVB_REQUIRE(ctx && x && y && n >= 0 && which >= 0 && which <= 2, TMVB_EINVAL, "tmvb_special_f32: bad argument");
+    if (n == 0) return TMVB_OK;
+    TMVB_HIP(hipSetDevice(ctx->device));
+    float *dx = nullptr, *dy = nullptr;
+    TMVB_HIP(hipMalloc((void**)&dx, (size_t)n * sizeof(float)));
+    if (hipMalloc((void**)&dy, (size_t)n * sizeof(float)) != hipSuccess) { (void)hipFree(dx); tmvb_set_error("tmvb_special_f32: hipMalloc failed"); return TMVB_ENOMEM; }
+    hipError_t e = hipMemcpyAsync(dx, x, (size_t)n * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(special_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, which, dx, dy, n);
+        e = hipMemcpyAsync(y, dy, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(dx); (void)hipFree(dy);
+    TMVB_REQUIRE(e == hipSuccess, TMVB_EHIP, "tmvb_special_f32: %s", hipGetErrorString(e));
+    return TMVB_OK;
+}
+
 // ------------------------------------------------------------------------------ docfile ingest
 // readcorp's document loop (src/Corpus.jl:285-299) as one streaming pass over the file: no per-document
 // objects, integers parsed in place, output directly in the packed CSR the engine uploads.
