@@ -186,7 +186,7 @@ __global__ __launch_bounds__(64) void ctpf_estep_kernel(CtpfParams p, int64_t fi
             const float df = gim - gim_old;
             dl = df * df;
         }
-        if (sqrtf(wave_sum(dl)) < p.vtol) break;       // :359
+        if (__builtin_amdgcn_sqrtf(wave_sum(dl)) < p.vtol) break;       // :359
     }
 
     if (sweeps > 0) {
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(64) void ctpf_estep_reg_kernel(CtpfParams p, int64_
             const float df = gim - gim_old;
             dl = df * df;
         }
-        if (sqrtf(wave_sum(dl)) < p.vtol) break;          // :359
+        if (__builtin_amdgcn_sqrtf(wave_sum(dl)) < p.vtol) break;          // :359
     }
     const bool mine = mytopic >= 0 && mytopic < R;
     if (sweeps > 0) {

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(64) void lda_estep_kernel(LdaParams p, int64_t firs
             }
         }
         const float dist2 = wave_sum(dl);
-        if (sqrtf(dist2) < p.vtol) break;
+        if (__builtin_amdgcn_sqrtf(dist2) < p.vtol) break;   // v_sqrt_f32 (1 ulp) on the wave-uniform sum
     }
 
     if (sweeps > 0) {
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(64) void lda_estep_reg_kernel(LdaParams p, int64_t 
             }
         }
         const float dist2 = wave_sum(dl);
-        if (sqrtf(dist2) < p.vtol) break;                             // :175
+        if (__builtin_amdgcn_sqrtf(dist2) < p.vtol) break;   // v_sqrt_f32 (1 ulp) on the wave-uniform sum                             // :175
     }
     if (sweeps > 0) {
 #pragma unroll
