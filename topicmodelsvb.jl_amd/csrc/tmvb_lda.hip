@@ -1,30 +1,32 @@
 // tmvb_lda.hip -- LDA variational-Bayes engine for gfx950 (MI355X).
 //
 // Path: the per-document coordinate ascent of src/LDA.jl:170-180 (update_phi! :150, update_gamma!
-// :143, update_Elogtheta! :136, exit test :175, update_beta!(d) :129) fused into ONE kernel, plus
+// :143, update_Elogtheta! :136, exit test :175, update_beta!(d) :129) fused per document, plus
 // the corpus-wide M-step (update_beta! :121, update_alpha! :97) and update_elbo! (:83) on device.
 // It replaces the seven OpenCL kernels of src/gpuLDA.jl:156-333 but follows the CPU path's
 // semantics (per-document early exit), not the OpenCL path's global-median rule (:361).
 //
-// Data layout in HBM (fp32 state, int32 ids, column-major K x .):
-//   beta[2][K*V] (current / old, ping-pong)   stats[K*V + K] (S = the reference's beta_temp, then
-//   Elogtheta_sum)   gamma, Elogtheta, Elogtheta_old [K*M]   CSR doc_ptr i64[M+1], terms/counts
-//   i32[nnz]   doc_order i32[M] (longest document first).
+// Data layout in HBM (fp32 state, int32 ids):
+//   beta[2][V][KP] (gather layout, current / old ping-pong, KP = 4*odd >= K)
+//   stats[K*V + K] (S = the reference's beta_temp, then Elogtheta_sum; the all-reduce payload)
+//   gamma, Elogtheta, Elogtheta_old [M][K]   E [M][ES] (last-sweep exp(Elogtheta), 128-byte-aligned rows)
+//   CSR doc_ptr i64[M+1], terms/counts i32[nnz]; doc_order i32[M] (processing order);
+//   one inverted (term-major) index per document piece.
 //
-// E-step kernel design (one 64-lane wave = one document, one wave per workgroup):
-//   phi is never materialised.  With e = exp(Elogtheta_d) and B = beta[:, terms_d] (N_d x K tile,
-//   gathered ONCE per outer iteration into LDS and reused by all <= viter sweeps), a sweep is two
-//   matrix-vector products through LDS plus K digammas:
-//       s_n = K eps + sum_i B[n][i] e_i              (lane = token, ds_read_b128 rows, stride 4*odd)
-//       w_n = c_n / s_n
-//       gamma_i = alpha_i + eps + e_i sum_n w_n B[n][i] + eps sum_n w_n     (lane = topic)
-//       Elogtheta_i = psi(gamma_i) - psi(sum gamma)
-//   On exit the last sweep's phi.*counts' = w_n (B[n][i] e_i + eps) is scattered into S with
-//   hardware fp32 atomics (coalesced K-float columns).
-//   Documents longer than the LDS tile stream their tokens in chunks (re-gathered per sweep).
+// Kernels (one 64-lane wave = one document; phi is never materialised):
+//   lda_estep_reg_kernel<LPR,T>  documents of <= 64 T unique terms, any K <= 100: the N_d x KP tile lives in VGPRs
+//                                as topic pairs; per sweep  s_n = K eps + sum_i B[n][i] e_i  (v_pk_fma_f32 with SGPR
+//                                pairs), w_n = c_n / s_n, g_i = sum_n w_n B[n][i] (cross-lane reduce-scatter),
+//                                gamma_i = eps + alpha_i + e_i g_i + eps sum w, Elogtheta = psi(gamma) - psi(sum gamma)
+//   lda_estep_kernel<NSLOT,LPR>  any K <= 1024 / longer documents: the same arithmetic with the tile in LDS
+//                                (LDS-DMA gather, up to 156 KiB per document)
+//   termstats_* (tmvb_termstats.h)  update_beta!(model, d) as a gather over the inverted index, no atomics:
+//                                S[:, j] += beta[:, j] .* sum_tokens w E[:, doc] + eps sum w, w recomputed in place
+//   lda_alpha_kernel, beta_norm_kernel, lda_elbo_kernel   M-step and ELBO
+// tmvb_lda_estep pipelines the statistics pass of document piece p under the document kernels of piece p + 1.
 //
-// Roofline: HBM-bound gather/scatter.  Algorithmic bytes per outer iteration:
-//   nnz*(8 + 4K + 4K) + 12*M*K + 12*K*V + 4*(M+1).
+// Roofline: HBM/gather-bound by byte count, VALU-issue bound in practice.  Algorithmic
+// bytes per outer iteration: nnz*(8 + 4K + 4K) + 12*M*K + 12*K*V + 4*(M+1).
 #include "tmvb_common_kernels.h"
 #include "tmvb_regtile.h"
 
@@ -271,11 +273,10 @@ __global__ __launch_bounds__(64) void lda_estep_kernel(LdaParams p, int64_t firs
 //   phase 2  g_q = sum_n w_n B[n][q]             R products per tile, then a 6-stage reduce-scatter
 //            over the 64 lanes (v_permlane32_swap, v_permlane16_swap, 4 DPP stages; ~2.2 R
 //            instructions): afterwards lane L holds the total of topic pi(L)
-// pi (topic_of_lane / lane_of_topic) is computed on the host by replaying the same pairing.
+// pi is the compile-time map kRegLaneMap<R> (tmvb_common_kernels.h); the host uploads topic_of_lane from it.
 template <int LPR, int T>
 __global__ __launch_bounds__(64) void lda_estep_reg_kernel(LdaParams p, int64_t first,
-                                                           const int* __restrict__ topic_of_lane,
-                                                           const int* __restrict__ lane_of_topic)
+                                                           const int* __restrict__ topic_of_lane)
 {
     constexpr int R = 4 * LPR;
     const int lane = threadIdx.x;
@@ -321,7 +322,6 @@ __global__ __launch_bounds__(64) void lda_estep_reg_kernel(LdaParams p, int64_t 
         elog[sl] = on[sl] ? p.elog[(int64_t)d * K + mytopic[sl]] : 0.0f;
         elog_old[sl] = elog[sl]; gam[sl] = 0.0f; e[sl] = 0.0f;
     }
-    (void)lane_of_topic;
 
     int sweeps = 0;
     for (int v = 0; v < p.viter; ++v) {
@@ -559,12 +559,12 @@ __global__ __launch_bounds__(1024) void lda_elbo_final_kernel(const double* __re
 
 // register-tile launch for a bucket of `tiles`-tile documents (instantiates T = 1..TMAX only)
 template <int LPR, int TMAX>
-static void lda_launch_reg(int tiles, dim3 grid, dim3 block, hipStream_t st, const LdaParams& p, int64_t first, const int* tol, const int* lot)
+static void lda_launch_reg(int tiles, dim3 grid, dim3 block, hipStream_t st, const LdaParams& p, int64_t first, const int* tol)
 {
-    if (tiles <= 1) hipLaunchKernelGGL((lda_estep_reg_kernel<LPR, 1>), grid, block, 0, st, p, first, tol, lot);
-    else if (tiles == 2 || TMAX == 2) hipLaunchKernelGGL((lda_estep_reg_kernel<LPR, (TMAX >= 2 ? 2 : 1)>), grid, block, 0, st, p, first, tol, lot);
-    else if (tiles == 3 || TMAX == 3) hipLaunchKernelGGL((lda_estep_reg_kernel<LPR, (TMAX >= 3 ? 3 : 1)>), grid, block, 0, st, p, first, tol, lot);
-    else hipLaunchKernelGGL((lda_estep_reg_kernel<LPR, (TMAX >= 4 ? 4 : 1)>), grid, block, 0, st, p, first, tol, lot);
+    if (tiles <= 1) hipLaunchKernelGGL((lda_estep_reg_kernel<LPR, 1>), grid, block, 0, st, p, first, tol);
+    else if (tiles == 2 || TMAX == 2) hipLaunchKernelGGL((lda_estep_reg_kernel<LPR, (TMAX >= 2 ? 2 : 1)>), grid, block, 0, st, p, first, tol);
+    else if (tiles == 3 || TMAX == 3) hipLaunchKernelGGL((lda_estep_reg_kernel<LPR, (TMAX >= 3 ? 3 : 1)>), grid, block, 0, st, p, first, tol);
+    else hipLaunchKernelGGL((lda_estep_reg_kernel<LPR, (TMAX >= 4 ? 4 : 1)>), grid, block, 0, st, p, first, tol);
 }
 
 // ------------------------------------------------------------------------------ host side
@@ -592,7 +592,6 @@ struct tmvb_lda {
     bool e_padded = false;             // E rows are zero padded to >= KP floats (float4 statistics kernels)
     float* d_ts_partial = nullptr;     // [n_slots][K+1]
     int* d_topic_of_lane = nullptr;    // register-tile kernel lane maps
-    int* d_lane_of_topic = nullptr;
     bool reg_path = false;             // K <= 64 with a specialised LPR: short documents use lda_estep_reg_kernel
     int32_t* d_doc_order = nullptr;
     double* d_partial = nullptr;       // [TMVB_REDUCE_BLOCKS][K]
@@ -733,7 +732,7 @@ extern "C" int tmvb_lda_destroy(tmvb_lda* h)
     (void)hipFree(h->d_alpha_d); (void)hipFree(h->d_alpha_f); (void)hipFree(h->d_beta[0]); (void)hipFree(h->d_beta[1]);
     if (h->own_stats) (void)hipFree(h->d_stats);
     (void)hipFree(h->d_wtok); (void)hipFree(h->d_E); (void)hipFree(h->d_ts_partial);
-    (void)hipFree(h->d_topic_of_lane); (void)hipFree(h->d_lane_of_topic);
+    (void)hipFree(h->d_topic_of_lane);
     (void)hipFree(h->d_gamma); (void)hipFree(h->d_elog); (void)hipFree(h->d_elog_old); (void)hipFree(h->d_sweeps);
     (void)hipFree(h->d_doc_order); (void)hipFree(h->d_partial); (void)hipFree(h->d_rowsum); (void)hipFree(h->d_esum);
     (void)hipFree(h->d_doc_val); (void)hipFree(h->d_elbo); (void)hipFree(h->d_iters);
@@ -799,7 +798,8 @@ extern "C" int tmvb_lda_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
         (rc = dmalloc(&h->d_elog, KM)) || (rc = dmalloc(&h->d_elog_old, KM)) || (rc = dmalloc(&h->d_sweeps, (size_t)h->M)) ||
         (rc = dmalloc(&h->d_doc_order, (size_t)h->M)) || (rc = dmalloc(&h->d_partial, (size_t)TMVB_REDUCE_BLOCKS * K)) ||
         (rc = dmalloc(&h->d_rowsum, K)) || (rc = dmalloc(&h->d_esum, K)) || (rc = dmalloc(&h->d_doc_val, (size_t)h->M)) ||
-        (rc = dmalloc(&h->d_elbo, 1)) || (rc = dmalloc(&h->d_iters, 1)) || (rc = dmalloc(&h->d_wtok, (size_t)corp->info.nnz)) ||
+        (rc = dmalloc(&h->d_elbo, 1)) || (rc = dmalloc(&h->d_iters, 1)) || (rc = dmalloc(&h->d_wtok, tmvb_termstats_recomputes(h->KP, h->KP / 4 <= 64) ? (size_t)1 : (size_t)corp->info.nnz)) ||   // stored weights: K > 128 only
+       
         (rc = dmalloc(&h->d_E, (size_t)((h->KP + 31) / 32 * 32) * h->M + 4))) {
         tmvb_lda_destroy(h);
         return rc;
@@ -808,9 +808,8 @@ extern "C" int tmvb_lda_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
     if (h->reg_path) {
         std::vector<int> tol, lot;
         tmvb_reg_lane_maps(h->KP, tol, lot);
-        if ((rc = dmalloc(&h->d_topic_of_lane, tol.size())) || (rc = dmalloc(&h->d_lane_of_topic, (size_t)h->KP))) { tmvb_lda_destroy(h); return rc; }
+        if ((rc = dmalloc(&h->d_topic_of_lane, tol.size()))) { tmvb_lda_destroy(h); return rc; }
         TMVB_HIP(hipMemcpy(h->d_topic_of_lane, tol.data(), tol.size() * sizeof(int), hipMemcpyHostToDevice));
-        TMVB_HIP(hipMemcpy(h->d_lane_of_topic, lot.data(), (size_t)h->KP * sizeof(int), hipMemcpyHostToDevice));
     }
     std::vector<int32_t> order;
     lda_build_buckets(h, order);
@@ -982,9 +981,9 @@ extern "C" int tmvb_lda_estep(tmvb_lda* h, int32_t viter, double vtol)
         if (b.reg_tiles > 0) { int rc = close_pieces(b.piece); if (rc) return rc; }
         if (b.reg_tiles > 0) {
             const dim3 grid((unsigned)b.count), block(64);
-            const int* tol = h->d_topic_of_lane; const int* lot = h->d_lane_of_topic;
+            const int* tol = h->d_topic_of_lane;
             switch (p.LPR) {
-#define LDA_REG_CASE(LPRV, TMAX) case LPRV: lda_launch_reg<LPRV, TMAX>(b.reg_tiles, grid, block, st, p, b.first, tol, lot); break;
+#define LDA_REG_CASE(LPRV, TMAX) case LPRV: lda_launch_reg<LPRV, TMAX>(b.reg_tiles, grid, block, st, p, b.first, tol); break;
                 LDA_REG_CASE(1, 4) LDA_REG_CASE(3, 4) LDA_REG_CASE(5, 4) LDA_REG_CASE(7, 4) LDA_REG_CASE(9, 4) LDA_REG_CASE(11, 4)
                 LDA_REG_CASE(13, 4) LDA_REG_CASE(15, 3) LDA_REG_CASE(17, 3) LDA_REG_CASE(19, 2) LDA_REG_CASE(21, 2) LDA_REG_CASE(23, 2)
                 LDA_REG_CASE(25, 3)
