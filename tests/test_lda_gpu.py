@@ -235,9 +235,10 @@ def test_full_size_nsf_properties(tmvb):
     assert gm.sweep_hist().sum() == pc.M
 
 
-@pytest.mark.parametrize("K", [3, 10, 18, 25, 33, 41, 50, 57, 64, 72, 81, 90, 100])
-def test_register_tile_paths_k50_k100(tmvb, oracle, K):
-    """One K per register-tile instantiation (KP = 4, 12, 20, ..., 100; one result slot per lane up to KP = 60,
+@pytest.mark.parametrize("K", [3, 10, 18, 25, 33, 41, 50, 57, 64, 72, 81, 90, 100, 130, 300])
+def test_every_kernel_path_by_k(tmvb, oracle, K):
+    """K = 130 (LDS-tile kernel, float4 statistics kernel with stored weights) and K = 300 (scalar statistics kernel),
+    and one K per register-tile instantiation (KP = 4, 12, 20, ..., 100; one result slot per lane up to KP = 60,
     two from KP = 68; statistics recomputed with 16- or 32-lane row slots) incl. multi-tile documents,
     teacher-forced against the oracle with pinned sweep counts."""
     pc = tmvb.syn_nsf(M=120, V=900, seed=17)           # document lengths ~30..250 -> 1..4 tiles
