@@ -873,7 +873,7 @@ extern "C" int tmvb_lda_set_state(tmvb_lda* h, const double* alpha, const double
     tmvb_ctx* ctx = h->ctx;
     TMVB_HIP(hipSetDevice(ctx->device));
     { int jrc = lda_join_side(h); if (jrc) return jrc; }
-    const size_t K = h->K, KV = K * (size_t)h->V, KM = K * (size_t)h->M;
+    const size_t K = h->K, KM = K * (size_t)h->M;
     int rc;
     if (alpha) {
         for (size_t i = 0; i < K; ++i)   // check_model: alpha finite and positive (src/modelutils.jl:262-264)
@@ -905,7 +905,7 @@ extern "C" int tmvb_lda_get_state(tmvb_lda* h, double* alpha, double* beta, doub
     tmvb_ctx* ctx = h->ctx;
     TMVB_HIP(hipSetDevice(ctx->device));
     { int jrc = lda_join_side(h); if (jrc) return jrc; }
-    const size_t K = h->K, KV = K * (size_t)h->V, KM = K * (size_t)h->M;
+    const size_t K = h->K, KM = K * (size_t)h->M;
     int rc;
     if (alpha) {
         TMVB_HIP(hipMemcpyAsync(alpha, h->d_alpha_d, K * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

@@ -272,6 +272,7 @@ __global__ __launch_bounds__(256) void termstats_multi_kernel(TermStatsParams p,
     __shared__ float red[4][64 * NSLOT + 1];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int m = blockIdx.x;
+    if (m >= n_multi) return;
     const int K = p.K;
     const int j = multi_id[m], first = multi_first[m], cnt = multi_count[m];
     float acc[NSLOT];
