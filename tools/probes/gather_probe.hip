@@ -30,8 +30,8 @@ __global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ t
 int main()
 {
     const int64_t n = 11300000;
-    for (int rows : {25319, 128804}) {
-        for (int stride : {52, 64}) {
+    for (int rows : {4096, 8192, 16384, 32768, 65536, 128804}) {
+        for (int stride : {64}) {
             std::vector<int> h(n);
             unsigned s = 12345u;
             for (int64_t i = 0; i < n; ++i) { s = s * 1664525u + 1013904223u; h[i] = (int)((s >> 8) % (unsigned)rows); }

@@ -30,6 +30,13 @@
 #include "tmvb_common_kernels.h"
 #include "tmvb_regtile.h"
 
+// e_q of the first TMVB_LDA_E_LDS topics reach the lanes through LDS (one ds_write, broadcast ds_read_b128) instead of
+// v_readlane: moves a quarter of phase 1's issue slots from the saturated VALU to the idle LDS pipe (+2 % measured at
+// 32 and at 52 of 52 topics; 0 = all v_readlane)
+#ifndef TMVB_LDA_E_LDS
+#define TMVB_LDA_E_LDS 32
+#endif
+
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -323,6 +330,9 @@ __global__ __launch_bounds__(64) void lda_estep_reg_kernel(LdaParams p, int64_t 
         elog_old[sl] = elog[sl]; gam[sl] = 0.0f; e[sl] = 0.0f;
     }
 
+#if TMVB_LDA_E_LDS
+    __shared__ __attribute__((aligned(16))) float e_lds[R];
+#endif
     int sweeps = 0;
     for (int v = 0; v < p.viter; ++v) {
         ++sweeps;
@@ -332,10 +342,31 @@ __global__ __launch_bounds__(64) void lda_estep_reg_kernel(LdaParams p, int64_t 
         v2f sacc[T][2];
 #pragma unroll
         for (int t = 0; t < T; ++t) { sacc[t][0] = v2f{0.f, 0.f}; sacc[t][1] = v2f{0.f, 0.f}; }
+#if TMVB_LDA_E_LDS
+        constexpr int ELDS = (TMVB_LDA_E_LDS < R) ? TMVB_LDA_E_LDS : R;
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) if (mytopic[sl] >= 0 && mytopic[sl] < ELDS) e_lds[mytopic[sl]] = e[sl];
+        WAVE_LDS_FENCE();
+#pragma unroll
+        for (int j = 0; j < ELDS / 4; ++j) {
+            const float4 ev = ((const float4*)e_lds)[j];
+            const v2f ea = v2f{ev.x, ev.y}, eb = v2f{ev.z, ev.w};
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                sacc[t][0] = __builtin_elementwise_fma(B2[t][2 * j], ea, sacc[t][0]);
+                sacc[t][1] = __builtin_elementwise_fma(B2[t][2 * j + 1], eb, sacc[t][1]);
+            }
+        }
+        if constexpr (ELDS <= 0) regtile_phase1_block<R, T, 0>(B2, e, sacc);
+        if constexpr (R > 32 && ELDS <= 32) regtile_phase1_block<R, T, 32>(B2, e, sacc);
+        if constexpr (R > 64 && ELDS <= 64) regtile_phase1_block<R, T, 64>(B2, e, sacc);
+        if constexpr (R > 96 && ELDS <= 96) regtile_phase1_block<R, T, 96>(B2, e, sacc);
+#else
         regtile_phase1_block<R, T, 0>(B2, e, sacc);
         if constexpr (R > 32) regtile_phase1_block<R, T, 32>(B2, e, sacc);
         if constexpr (R > 64) regtile_phase1_block<R, T, 64>(B2, e, sacc);
         if constexpr (R > 96) regtile_phase1_block<R, T, 96>(B2, e, sacc);
+#endif
         float wl = 0.0f;
 #pragma unroll
         for (int t = 0; t < T; ++t) {
