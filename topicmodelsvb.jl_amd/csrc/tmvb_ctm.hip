@@ -26,6 +26,8 @@
 // workgroup.
 #include "tmvb_common_kernels.h"
 
+#include <utility>
+
 #define CTM_MAX_K 64
 
 struct CtmParams {
@@ -74,39 +76,61 @@ __device__ __forceinline__ double wave_max_d(double v)
 
 // Gauss-Jordan solve of H x = g, lane i owns row i (registers H[0..R)), SPD, no pivoting.
 // At pivot j the pivot row's entries reach every lane as SGPR operands (v_readlane of lane j).
+typedef float gj_v2f __attribute__((ext_vector_type(2)));
+
+// One pivot of the elimination with the pivot index a template constant (a `#pragma unroll` loop over 52 pivots with
+// blocked broadcasts inside is not fully unrolled by hipcc 7.2, and a dynamic pivot index sends the row to scratch).
+// The row is held as column pairs so that the rank-1 update runs on v_pk_fma_f32 with the pivot row's entries as
+// SGPR pairs (the kernel is VALU-issue bound: packed fp32 halves the update's instruction count).  The pivot row is
+// broadcast in blocks of <= 16 pairs: back-to-back v_readlane into SGPRs, then the FMAs that consume them (a VALU
+// that reads an SGPR written by the immediately preceding v_readlane costs a wait state per pair; 52 live SGPRs
+// would spill to VGPR lanes).
+template <int R, int J>
+__device__ __forceinline__ void gj_pivot(gj_v2f (&H2)[R / 2], float& g, float& dinv, int lane)
+{
+    typedef gj_v2f v2f;
+    constexpr int jp = J / 2;                               // pair holding column J
+    constexpr int NQ = R / 2 - (jp + 1);                    // pairs right of the pivot's pair
+    const bool me = lane == J;
+    const float pj = readlane_f((J & 1) ? H2[jp].y : H2[jp].x, J);
+    const float pj1 = (J & 1) ? 0.0f : readlane_f(H2[jp].y, J);
+    const float sg = readlane_f(g, J);
+    const float rp = fast_rcp(pj);
+    const float hj = (J & 1) ? H2[jp].y : H2[jp].x;
+    const float f = me ? 0.0f : hj * rp;
+    dinv = me ? rp : dinv;
+    const float nf = -f;
+    if ((J & 1) == 0) H2[jp].y = fmaf(nf, pj1, H2[jp].y);           // column J + 1 shares J's pair
+    g = fmaf(nf, sg, g);
+#pragma unroll
+    for (int q0 = 0; q0 < NQ; q0 += 16) {
+        float sx[16], sy[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            if (q0 + q < NQ) { sx[q] = readlane_f(H2[jp + 1 + q0 + q].x, J); sy[q] = readlane_f(H2[jp + 1 + q0 + q].y, J); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            if (q0 + q < NQ) H2[jp + 1 + q0 + q] = __builtin_elementwise_fma(v2f{nf, nf}, v2f{sx[q], sy[q]}, H2[jp + 1 + q0 + q]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int R, int... J>
+__device__ __forceinline__ void gj_all_pivots(gj_v2f (&H2)[R / 2], float& g, float& dinv, int lane, std::integer_sequence<int, J...>)
+{
+    (gj_pivot<R, J>(H2, g, dinv, lane), ...);
+}
+
 template <int R>
 __device__ __forceinline__ float gj_solve_rows(float (&H)[R], float g, int lane)
 {
-    typedef float v2f __attribute__((ext_vector_type(2)));
     static_assert(R % 2 == 0, "gj_solve_rows: R must be even");
-    // the row is held as column pairs so that the rank-1 update runs on v_pk_fma_f32 with the pivot row's
-    // entries as SGPR pairs (the kernel is VALU-issue bound: packed fp32 halves the update's instruction count)
-    v2f H2[R / 2];
+    gj_v2f H2[R / 2];
 #pragma unroll
-    for (int q = 0; q < R / 2; ++q) H2[q] = v2f{H[2 * q], H[2 * q + 1]};
+    for (int q = 0; q < R / 2; ++q) H2[q] = gj_v2f{H[2 * q], H[2 * q + 1]};
     float dinv = 0.0f;
-#pragma unroll
-    for (int j = 0; j < R; ++j) {
-        // broadcast the pivot row first (back-to-back v_readlane into SGPRs), then consume it: a VALU that
-        // reads an SGPR written by the immediately preceding v_readlane costs a wait state per pair
-        float srow[R];
-#pragma unroll
-        for (int k = j; k < R; ++k) srow[k] = readlane_f((k & 1) ? H2[k / 2].y : H2[k / 2].x, j);
-        const float sg = readlane_f(g, j);
-        __builtin_amdgcn_sched_barrier(0);
-        const float rp = fast_rcp(srow[j]);
-        const bool me = lane == j;
-        const float hj = (j & 1) ? H2[j / 2].y : H2[j / 2].x;
-        const float f = me ? 0.0f : hj * rp;
-        dinv = me ? rp : dinv;
-        const float nf = -f;
-        if ((j & 1) == 0) H2[j / 2].y = fmaf(nf, srow[j + 1], H2[j / 2].y);     // column j + 1 shares j's pair
-#pragma unroll
-        for (int q = j / 2 + 1; q < R / 2; ++q)
-            H2[q] = __builtin_elementwise_fma(v2f{nf, nf}, v2f{srow[2 * q], srow[2 * q + 1]}, H2[q]);
-        g = fmaf(nf, sg, g);
-        __builtin_amdgcn_sched_barrier(0);
-    }
+    gj_all_pivots<R>(H2, g, dinv, lane, std::make_integer_sequence<int, R>{});
     return g * dinv;
 }
 
