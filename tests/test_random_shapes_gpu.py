@@ -115,3 +115,15 @@ def test_ctpf_random_shapes(tmvb, oracle, seed):
         assert rel(gm.alef, om.alef) <= 5e-4 and rel(gm.he, om.he) <= 5e-4
         for n in ("bet", "vav", "dalet", "het"):
             assert rel(getattr(gm, n), getattr(om, n)) <= 1e-4
+
+
+def test_empty_corpora(tmvb):
+    """gpuLDA(Corpus(), 1) must be constructible (the @gpu macro builds its device model on an empty corpus,
+    src/macros.jl:114) and train! on a corpus whose documents are all empty runs zero iterations (src/LDA.jl:166)."""
+    empty = tmvb.PackedCorpus(np.zeros(1, np.int64), np.zeros(0, np.int32), np.zeros(0, np.int32), 0)
+    blank = tmvb.PackedCorpus(np.zeros(4, np.int64), np.zeros(0, np.int32), np.zeros(0, np.int32), 7)
+    for cls in (tmvb.gpuLDA, tmvb.gpuCTM, tmvb.gpuCTPF):
+        m = cls(empty, 1)
+        assert len(m.train(iter=2, checkelbo=1, printelbo=False)) == 0
+        m = cls(blank, 3)
+        assert len(m.train(iter=2, checkelbo=1, printelbo=False)) == 0
