@@ -166,7 +166,11 @@ function hipCTM(model::CTM; device::Integer=0)
 	m = hipCTM(model.K, model.M, model.V, model.N, model.C, model.corp, model.topics, model.mu, Matrix(model.sigma),
 		Matrix(model.invsigma), model.beta, copy(model.beta), model.lambda, deepcopy(model.lambda), model.vsq, model.logzeta,
 		model.elbo, ctx[], dcorp, h[])
-	finalizer(x -> ccall((:tmvb_ctm_destroy, LIBTMVB), Cint, (Ptr{Cvoid},), x.handle), m)
+	finalizer(m) do x
+		ccall((:tmvb_ctm_destroy, LIBTMVB), Cint, (Ptr{Cvoid},), x.handle)
+		ccall((:tmvb_corpus_destroy, LIBTMVB), Cint, (Ptr{Cvoid},), x.dcorp)
+		ccall((:tmvb_ctx_destroy, LIBTMVB), Cint, (Ptr{Cvoid},), x.ctx)
+	end
 	m
 end
 
@@ -232,7 +236,11 @@ function hipCTPF(model::CTPF; device::Integer=0)
 	m = hipCTPF(model.K, model.M, model.V, model.U, model.corp, model.topics, model.scores, model.libs, model.drecs, model.urecs,
 		Float64[model.a, model.b, model.c, model.d, model.e, model.f, model.g, model.h], model.alef, model.he,
 		model.bet, model.vav, model.dalet, model.het, model.gimel, model.zayin, model.elbo, ctx[], dcorp, h[])
-	finalizer(x -> ccall((:tmvb_ctpf_destroy, LIBTMVB), Cint, (Ptr{Cvoid},), x.handle), m)
+	finalizer(m) do x
+		ccall((:tmvb_ctpf_destroy, LIBTMVB), Cint, (Ptr{Cvoid},), x.handle)
+		ccall((:tmvb_corpus_destroy, LIBTMVB), Cint, (Ptr{Cvoid},), x.dcorp)
+		ccall((:tmvb_ctx_destroy, LIBTMVB), Cint, (Ptr{Cvoid},), x.ctx)
+	end
 	m
 end
 
