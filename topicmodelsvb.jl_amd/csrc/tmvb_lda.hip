@@ -693,7 +693,10 @@ static int lda_piece_count(const tmvb_lda* h)
 {
     if (!tmvb_termstats_recomputes(h->KP, h->e_padded) || !h->reg_path) return 1;
     if (const char* e = getenv("TMVB_LDA_PIECES")) return std::max(1, std::min(16, atoi(e)));
-    return h->corp->info.nnz >= (int64_t)(1 << 21) ? 4 : 1;
+    // measured on SYN-NSF shards (tools/probes/pieces_sweep.sh): 2.7 M and 5.5 M tokens are fastest with 2 pieces,
+    // 10.9 M with 4; below ~2 M the extra launches cost more than the overlap returns
+    const int64_t nnz = h->corp->info.nnz;
+    return nnz >= (int64_t)(1 << 23) ? 4 : nnz >= (int64_t)(1 << 21) ? 2 : 1;
 }
 
 // Cut the register-tile buckets where the running token count crosses a multiple of nnz / P.  The LDS-tile
