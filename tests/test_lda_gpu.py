@@ -236,11 +236,14 @@ def test_full_size_nsf_properties(tmvb):
 
 
 @pytest.mark.parametrize("K", [3, 10, 18, 25, 33, 41, 50, 57, 64, 72, 81, 90, 100, 130, 300])
-def test_every_kernel_path_by_k(tmvb, oracle, K):
+@pytest.mark.parametrize("merged", [True, False])
+def test_every_kernel_path_by_k(tmvb, oracle, K, merged, monkeypatch):
     """K = 130 (LDS-tile kernel, float4 statistics kernel with stored weights) and K = 300 (scalar statistics kernel),
     and one K per register-tile instantiation (KP = 4, 12, 20, ..., 100; one result slot per lane up to KP = 60,
     two from KP = 68; statistics recomputed with 16- or 32-lane row slots) incl. multi-tile documents,
     teacher-forced against the oracle with pinned sweep counts."""
+    if not merged:                                     # one launch per tile count (what large corpora use) instead of
+        monkeypatch.setenv("TMVB_LDA_NO_MERGE", "1")   # the single mixed-tile launch of small corpora
     pc = tmvb.syn_nsf(M=120, V=900, seed=17)           # document lengths ~30..250 -> 1..4 tiles
     g = dict(K=K, V=pc.V, doc_ptr=pc.doc_ptr, terms=pc.terms, counts=pc.counts, beta0=tmvb.dirichlet_rows(K, pc.V, seed=3))
     gm, om = make_pair(tmvb, oracle, g)

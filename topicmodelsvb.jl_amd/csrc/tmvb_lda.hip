@@ -282,15 +282,12 @@ __global__ __launch_bounds__(64) void lda_estep_kernel(LdaParams p, int64_t firs
 //            instructions): afterwards lane L holds the total of topic pi(L)
 // pi is the compile-time map kRegLaneMap<R> (tmvb_common_kernels.h); the host uploads topic_of_lane from it.
 template <int LPR, int T>
-__global__ __launch_bounds__(64) void lda_estep_reg_kernel(LdaParams p, int64_t first,
-                                                           const int* __restrict__ topic_of_lane)
+__device__ __forceinline__ void lda_estep_reg_body(const LdaParams& p, const int d, const int64_t off, const int N,
+                                                   const int* __restrict__ topic_of_lane)
 {
     constexpr int R = 4 * LPR;
     const int lane = threadIdx.x;
     const int K = p.K;
-    const int d = p.doc_order[first + blockIdx.x];
-    const int64_t off = p.doc_ptr[d];
-    const int N = (int)(p.doc_ptr[d + 1] - off);
 
     // token role: lane n owns tokens n + 64 t; the tile is held as topic PAIRS so that both phases run on
     // packed fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32: two fp32 lanes-ops per issue slot)
@@ -430,6 +427,33 @@ __global__ __launch_bounds__(64) void lda_estep_reg_kernel(LdaParams p, int64_t 
         for (int t = 0; t < T; ++t) if (wpos[t] >= 0 && p.store_w) p.wtok[wpos[t]] = 0.0f;
     }
     if (lane == 0) p.sweeps[d] = (uint8_t)min(sweeps, 255);
+}
+
+template <int LPR, int T>
+__global__ __launch_bounds__(64) void lda_estep_reg_kernel(LdaParams p, int64_t first,
+                                                           const int* __restrict__ topic_of_lane)
+{
+    const int d = p.doc_order[first + blockIdx.x];
+    const int64_t off = p.doc_ptr[d];
+    lda_estep_reg_body<LPR, T>(p, d, off, (int)(p.doc_ptr[d + 1] - off), topic_of_lane);
+}
+
+// All register-tile documents of a SMALL corpus / shard in one launch: the tile count is read per document
+// (wave-uniform) and the matching instantiation of the body is called.  Three kernel tails fewer than one launch
+// per tile count; the price is the register allocation of the widest body for every wave, which only pays when
+// the launch is latency- rather than occupancy-bound (tmvb_lda_estep uses it below ~2 M tokens).
+template <int LPR, int TMAX>
+__global__ __launch_bounds__(64) void lda_estep_reg_any_kernel(LdaParams p, int64_t first,
+                                                               const int* __restrict__ topic_of_lane)
+{
+    const int d = p.doc_order[first + blockIdx.x];
+    const int64_t off = p.doc_ptr[d];
+    const int N = (int)(p.doc_ptr[d + 1] - off);
+    const int tiles = __builtin_amdgcn_readfirstlane((N + 63) >> 6);
+    if (TMAX >= 4 && tiles >= 4) lda_estep_reg_body<LPR, (TMAX >= 4 ? 4 : 1)>(p, d, off, N, topic_of_lane);
+    else if (TMAX >= 3 && tiles == 3) lda_estep_reg_body<LPR, (TMAX >= 3 ? 3 : 1)>(p, d, off, N, topic_of_lane);
+    else if (TMAX >= 2 && tiles == 2) lda_estep_reg_body<LPR, (TMAX >= 2 ? 2 : 1)>(p, d, off, N, topic_of_lane);
+    else lda_estep_reg_body<LPR, 1>(p, d, off, N, topic_of_lane);
 }
 
 // update_alpha!  src/LDA.jl:97-118, fp64, one wave (lane = topic).
@@ -588,11 +612,14 @@ __global__ __launch_bounds__(1024) void lda_elbo_final_kernel(const double* __re
     }
 }
 
+#define TMVB_REG_ANY_TILES 99   // bucket of register-tile documents with mixed tile counts (lda_estep_reg_any_kernel)
+
 // register-tile launch for a bucket of `tiles`-tile documents (instantiates T = 1..TMAX only)
 template <int LPR, int TMAX>
 static void lda_launch_reg(int tiles, dim3 grid, dim3 block, hipStream_t st, const LdaParams& p, int64_t first, const int* tol)
 {
-    if (tiles <= 1) hipLaunchKernelGGL((lda_estep_reg_kernel<LPR, 1>), grid, block, 0, st, p, first, tol);
+    if (tiles == TMVB_REG_ANY_TILES) hipLaunchKernelGGL((lda_estep_reg_any_kernel<LPR, TMAX>), grid, block, 0, st, p, first, tol);
+    else if (tiles <= 1) hipLaunchKernelGGL((lda_estep_reg_kernel<LPR, 1>), grid, block, 0, st, p, first, tol);
     else if (tiles == 2 || TMAX == 2) hipLaunchKernelGGL((lda_estep_reg_kernel<LPR, (TMAX >= 2 ? 2 : 1)>), grid, block, 0, st, p, first, tol);
     else if (tiles == 3 || TMAX == 3) hipLaunchKernelGGL((lda_estep_reg_kernel<LPR, (TMAX >= 3 ? 3 : 1)>), grid, block, 0, st, p, first, tol);
     else hipLaunchKernelGGL((lda_estep_reg_kernel<LPR, (TMAX >= 4 ? 4 : 1)>), grid, block, 0, st, p, first, tol);
@@ -666,6 +693,8 @@ static bool lda_reg_lpr_supported(int lpr) { return lpr >= 1 && lpr <= 25 && (lp
 // measured still ahead of the LDS-tile kernel at KP = 100, T = 3)
 static int lda_reg_max_tiles(int lpr) { return lpr <= 13 ? 4 : (lpr <= 17 || lpr == 25) ? 3 : 2; }
 
+static int lda_piece_count(const tmvb_lda* h);
+
 static void lda_build_buckets(tmvb_lda* h, std::vector<int32_t>& order)
 {
     const std::vector<int64_t>& len = h->corp->h_doc_len;
@@ -679,6 +708,11 @@ static void lda_build_buckets(tmvb_lda* h, std::vector<int32_t>& order)
     // long documents get up to 156 KiB of LDS (one workgroup per CU): a tile that holds the whole document is
     // gathered once per E-step, a streamed one once per sweep
     int64_t pos = tmvb_build_lds_buckets(len, order, h->M, h->KP, reg_max, 3, h->buckets, TMVB_BIG_TILE_BYTES);
+    // small corpora (one statistics pass): ONE launch for all register-tile documents, longest first
+    if (h->reg_path && pos < h->M && lda_piece_count(h) == 1 && getenv("TMVB_LDA_NO_MERGE") == nullptr) {
+        h->buckets.push_back({pos, h->M - pos, 0, TMVB_REG_ANY_TILES});
+        return;
+    }
     // register-tile buckets: T = ceil(N / 64) tiles of 64 tokens
     for (int T = max_tiles; T >= 1 && pos < h->M; --T) {
         const int64_t lo = 64 * (int64_t)(T - 1);
