@@ -327,6 +327,54 @@ static inline int tmvb_colsum(tmvb_ctx* ctx, int nslot, int K, const float* X, i
     return TMVB_OK;
 }
 
+// Two independent column sums in one pair of launches (blockIdx.y selects the job): the CTPF M-step is a chain of
+// 5-8 us kernels, so halving the launches is what counts there.  K <= 64.
+struct tmvb_colsum_job { const float* X; int64_t ncols; double* partial; double* out_d; float* out_f; };
+
+static __global__ __launch_bounds__(256) void colsum2_partial_kernel(tmvb_colsum_job j0, tmvb_colsum_job j1, int K)
+{
+    __shared__ double red[4][64];
+    const tmvb_colsum_job j = blockIdx.y ? j1 : j0;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t gw = (int64_t)blockIdx.x * 4 + wv, nw = (int64_t)gridDim.x * 4;
+    double acc = 0.0;
+    if (lane < K) {
+#pragma unroll 8
+        for (int64_t c = gw; c < j.ncols; c += nw) acc += (double)j.X[c * K + lane];
+    }
+    red[wv][lane] = acc;
+    __syncthreads();
+    if ((int)threadIdx.x < K) j.partial[(int64_t)blockIdx.x * K + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+static __global__ __launch_bounds__(256) void colsum2_final_kernel(tmvb_colsum_job j0, tmvb_colsum_job j1, int nblocks, int K)
+{
+    const tmvb_colsum_job j = blockIdx.y ? j1 : j0;
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= K) return;
+    double s = 0.0;
+    for (int b = lane; b < nblocks; b += 64) s += j.partial[(int64_t)b * K + i];
+    s = wave_sum_d(s);
+    if (lane == 0) {
+        if (j.out_d) j.out_d[i] = s;
+        if (j.out_f) j.out_f[i] = (float)s;
+    }
+}
+
+// same partition of the columns over TMVB_REDUCE_BLOCKS blocks for both jobs (a job with fewer columns just has idle blocks),
+// hence the same summation order as tmvb_colsum with that block count
+static inline int tmvb_colsum2(tmvb_ctx* ctx, int K, tmvb_colsum_job j0, tmvb_colsum_job j1)
+{
+    TMVB_REQUIRE(K <= 64, TMVB_EINVAL, "tmvb_colsum2: K <= 64");
+    const int64_t nmax = std::max(j0.ncols, j1.ncols);
+    const int nb = (int)std::min<int64_t>(TMVB_REDUCE_BLOCKS, std::max<int64_t>(1, (nmax + 3) / 4));
+    hipLaunchKernelGGL(colsum2_partial_kernel, dim3(nb, 2), dim3(256), 0, ctx->stream, j0, j1, K);
+    hipLaunchKernelGGL(colsum2_final_kernel, dim3((K + 3) / 4, 2), dim3(256), 0, ctx->stream, j0, j1, nb, K);
+    TMVB_HIP(hipGetLastError());
+    return TMVB_OK;
+}
+
 // gather-side statistics pass over an inverted index (tmvb_termstats.h)
 // true when the statistics pass recomputes the per-token weights (no wtok stores needed in the document kernels)
 static inline bool tmvb_termstats_recomputes(int KP, bool e_padded) { return e_padded && KP / 4 <= 32; }

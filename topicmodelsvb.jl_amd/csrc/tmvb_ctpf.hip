@@ -810,8 +810,9 @@ extern "C" int tmvb_ctpf_reduce_docs(tmvb_ctpf* h)
     TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_ctpf_reduce_docs: handle is NULL");
     TMVB_HIP(hipSetDevice(h->ctx->device));
     int rc;
-    if ((rc = tmvb_colsum(h->ctx, 1, h->K, h->d_gimel, h->M, h->d_partial, h->d_sum_g, h->tail()))) return rc;
-    return tmvb_colsum(h->ctx, 1, h->K, h->d_zayin, h->M, h->d_partial2, h->d_sum_z, h->tail() + h->K);
+    (void)rc;
+    return tmvb_colsum2(h->ctx, h->K, {h->d_gimel, h->M, h->d_partial, h->d_sum_g, h->tail()},
+                        {h->d_zayin, h->M, h->d_partial2, h->d_sum_z, h->tail() + h->K});
 }
 
 extern "C" int tmvb_ctpf_stats(tmvb_ctpf* h, void** dev_ptr, int64_t* n_f32)
@@ -862,7 +863,6 @@ extern "C" int tmvb_ctpf_mstep(tmvb_ctpf* h)
         int nb = (int)std::min<int64_t>(2048, std::max<int64_t>(1, ((int64_t)h->KP * h->U + 255) / 256));
         hipLaunchKernelGGL(ctpf_shape_kernel, dim3(nb), dim3(256), 0, hs, h->he_stats(), (float)h->hyper[4], h->d_he, h->d_he_old, h->d_TH, h->K, h->KP, h->U, 0);
         TMVB_HIP(hipGetLastError());
-        if ((rc = tmvb_colsum(ctx, 1, h->K, h->d_he, h->U, h->d_partial2, h->d_rs_he, nullptr, hs))) return rc;
     } else {
         TMVB_HIP(hipMemsetAsync(h->d_rs_he, 0, (size_t)h->K * sizeof(double), ctx->stream));
     }
@@ -872,7 +872,9 @@ extern "C" int tmvb_ctpf_mstep(tmvb_ctpf* h)
         hipLaunchKernelGGL(ctpf_shape_kernel, dim3(nb), dim3(256), 0, ctx->stream, h->d_stats, (float)h->hyper[0], h->d_alef, h->d_alef_old, h->d_TA, h->K, h->KP, h->V, 0);
         TMVB_HIP(hipGetLastError());
     }
-    if ((rc = tmvb_colsum(ctx, 1, h->K, h->d_alef, h->V, h->d_partial, h->d_rs_alef, nullptr))) return rc;
+    if (h->U > 0) {       // rowsum(alef) and rowsum(he) in one pair of launches
+        if ((rc = tmvb_colsum2(ctx, h->K, {h->d_alef, h->V, h->d_partial, h->d_rs_alef, nullptr}, {h->d_he, h->U, h->d_partial2, h->d_rs_he, nullptr}))) return rc;
+    } else if ((rc = tmvb_colsum(ctx, 1, h->K, h->d_alef, h->V, h->d_partial, h->d_rs_alef, nullptr))) return rc;
     hipLaunchKernelGGL((ctpf_rates_kernel<1>), dim3(1), dim3(64), 0, ctx->stream, h->K, h->hyper[1], h->hyper[3], h->hyper[5], h->hyper[7],
                        h->d_rs_alef, h->d_rs_he, h->d_sum_g, h->d_sum_z, h->d_rates, h->d_lrates);
     TMVB_HIP(hipGetLastError());
