@@ -114,6 +114,22 @@ def test_free_running_train_vs_golden(tmvb, name):
     assert sorted(gm.topics[0].tolist()) == list(range(1, V + 1))
 
 
+def test_free_running_medium_corpus_tracks_the_oracle(tmvb, oracle):
+    """25 free-running iterations on a 1 500-document corpus (K = 20): the device trajectory must not drift from the
+    fp64 oracle's -- ELBO rel <= 1e-4 at every iteration, same stop decision under the signed rule (Q4)."""
+    pc = tmvb.syn_nsf(M=1500, V=2000, seed=23)
+    K = 20
+    beta0 = tmvb.dirichlet_rows(K, pc.V, seed=4)
+    gm = tmvb.gpuLDA(pc, K)
+    gm.beta = np.asfortranarray(beta0); gm.beta_old = gm.beta.copy(order="F")
+    om = oracle.LDA(oracle.CSR(pc.doc_ptr, pc.terms, pc.counts, pc.V), K, beta0)
+    t_g = gm.train(iter=25, tol=1.0, checkelbo=1, printelbo=False)
+    t_o = om.train(iter=25, tol=1.0, checkelbo=1)
+    assert abs(len(t_g) - len(t_o)) <= 1                       # stop iteration +-1 (SURVEY.md section 8c)
+    n = min(len(t_g), len(t_o))
+    assert np.all(np.abs(t_g[:n] - t_o[:n]) <= RTOL_ELBO_FREE * np.abs(t_o[:n])), (t_g, t_o)
+
+
 def test_long_documents_stream_through_the_tile(tmvb, oracle):
     """Documents longer than the largest LDS tile take the chunked path (re-gather per sweep)."""
     rng = np.random.default_rng(5)
