@@ -17,6 +17,8 @@
 
 // one wave per workgroup: __syncthreads() lowers to an LDS fence (the s_barrier is elided)
 #define WAVE_LDS_FENCE() __syncthreads()
+// LDS fence for data private to ONE wave of a multi-wave workgroup (no s_barrier)
+#define WAVE_PRIVATE_LDS_FENCE() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
 template <int CTRL>
 __device__ __forceinline__ float4 dpp_add4(float4 v)

@@ -48,6 +48,7 @@ struct tmvb_bucket {
     int32_t tile_rows = 0;
     int32_t reg_tiles = 0;     // > 0: register-tile kernel with this many 64-token tiles (no LDS tile)
     int32_t piece = 0;         // pipelined E-step: which statistics pass consumes this bucket's documents
+    int32_t waves = 1;         // > 1: register-tile kernel with one workgroup of `waves` waves per (long) document
 };
 
 // Inverted (id-major) index over a CSR token stream, cut into chunks of at most TMVB_CHUNK tokens.

@@ -281,12 +281,18 @@ __global__ __launch_bounds__(64) void lda_estep_kernel(LdaParams p, int64_t firs
 //            over the 64 lanes (v_permlane32_swap, v_permlane16_swap, 4 DPP stages; ~2.2 R
 //            instructions): afterwards lane L holds the total of topic pi(L)
 // pi is the compile-time map kRegLaneMap<R> (tmvb_common_kernels.h); the host uploads topic_of_lane from it.
-template <int LPR, int T>
+// W > 1: W waves (one workgroup) share a LONG document -- wave w holds the tokens lane + 64 (w + W t) in its own
+// register tiles, the per-wave partial sums g_i (and sum w) are exchanged through a few hundred bytes of LDS once
+// per sweep (one __syncthreads, double-buffered), and every wave then updates gamma / Elogtheta redundantly and
+// bit-identically, so the exit test stays wave-uniform across the workgroup.  Same VALU-efficient arithmetic as the
+// single-wave kernel for documents of up to 64 T W unique terms.
+template <int LPR, int T, int W = 1>
 __device__ __forceinline__ void lda_estep_reg_body(const LdaParams& p, const int d, const int64_t off, const int N,
                                                    const int* __restrict__ topic_of_lane)
 {
     constexpr int R = 4 * LPR;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = (W > 1) ? (int)(threadIdx.x >> 6) : 0;
     const int K = p.K;
 
     // token role: lane n owns tokens n + 64 t; the tile is held as topic PAIRS so that both phases run on
@@ -298,7 +304,7 @@ __device__ __forceinline__ void lda_estep_reg_body(const LdaParams& p, const int
     for (int t = 0; t < T; ++t) {
         // branch-free: a lane past the document's last token reads term 0's row with count 0, so its weight
         // w = c / s is exactly 0 and nothing of the row reaches gamma (no zero-filled tile, no divergent tile load)
-        const int n = lane + 64 * t;
+        const int n = lane + 64 * (wave + W * t);
         const bool in = n < N;
         const int term = in ? p.terms[off + n] : 0;
         c[t] = in ? (float)p.counts[off + n] : 0.0f;
@@ -328,8 +334,10 @@ __device__ __forceinline__ void lda_estep_reg_body(const LdaParams& p, const int
     }
 
 #if TMVB_LDA_E_LDS
-    __shared__ __attribute__((aligned(16))) float e_lds[R];
+    __shared__ __attribute__((aligned(16))) float e_lds_all[W][R];
+    float* e_lds = e_lds_all[wave];
 #endif
+    __shared__ float xch[2][W > 1 ? W : 1][W > 1 ? R + 1 : 1];      // W > 1: per-wave partial (g | sum w), by sweep parity
     int sweeps = 0;
     for (int v = 0; v < p.viter; ++v) {
         ++sweeps;
@@ -343,7 +351,7 @@ __device__ __forceinline__ void lda_estep_reg_body(const LdaParams& p, const int
         constexpr int ELDS = (TMVB_LDA_E_LDS < R) ? TMVB_LDA_E_LDS : R;
 #pragma unroll
         for (int sl = 0; sl < NS; ++sl) if (mytopic[sl] >= 0 && mytopic[sl] < ELDS) e_lds[mytopic[sl]] = e[sl];
-        WAVE_LDS_FENCE();
+        if constexpr (W > 1) WAVE_PRIVATE_LDS_FENCE(); else WAVE_LDS_FENCE();
 #pragma unroll
         for (int j = 0; j < ELDS / 4; ++j) {
             const float4 ev = ((const float4*)e_lds)[j];
@@ -380,10 +388,27 @@ __device__ __forceinline__ void lda_estep_reg_body(const LdaParams& p, const int
             for (int t = 1; t < T; ++t) a = __builtin_elementwise_fma(B2[t][q], v2f{w[t], w[t]}, a);
             return a;
         }, pr, lane);
+        float wtot = wsum;
+        if constexpr (W > 1) {
+            float (*xb)[R + 1] = xch[v & 1];
+#pragma unroll
+            for (int sl = 0; sl < NS; ++sl) if (mytopic[sl] >= 0) xb[wave][mytopic[sl]] = pr[sl];
+            if (lane == 0) xb[wave][R] = wsum;
+            __syncthreads();
+            wtot = 0.0f;
+#pragma unroll
+            for (int sl = 0; sl < NS; ++sl) pr[sl] = 0.0f;
+#pragma unroll
+            for (int ww = 0; ww < W; ++ww) {                    // fixed order: identical totals in every wave
+#pragma unroll
+                for (int sl = 0; sl < NS; ++sl) pr[sl] += xb[ww][mytopic[sl] >= 0 ? mytopic[sl] : 0];
+                wtot += xb[ww][R];
+            }
+        }
         float gl = 0.0f;
 #pragma unroll
         for (int sl = 0; sl < NS; ++sl) {
-            gam[sl] = TMVB_EPS_F + (alpha[sl] + fmaf(e[sl], pr[sl], TMVB_EPS_F * wsum));   // update_gamma!, src/LDA.jl:145
+            gam[sl] = TMVB_EPS_F + (alpha[sl] + fmaf(e[sl], pr[sl], TMVB_EPS_F * wtot));   // update_gamma!, src/LDA.jl:145
             if (on[sl]) gl += gam[sl];
         }
         const float gsum = wave_sum(gl);
@@ -409,6 +434,7 @@ __device__ __forceinline__ void lda_estep_reg_body(const LdaParams& p, const int
     if (sweeps > 0) {
 #pragma unroll
         for (int sl = 0; sl < NS; ++sl) {
+            if (wave != 0) break;                                // every wave holds the same state: wave 0 stores it
             if (on[sl]) {
                 p.gamma[(int64_t)d * K + mytopic[sl]] = gam[sl];
                 p.elog[(int64_t)d * K + mytopic[sl]] = elog[sl];
@@ -422,11 +448,11 @@ __device__ __forceinline__ void lda_estep_reg_body(const LdaParams& p, const int
         // viter = 0: no responsibilities; E = 0 makes the statistics pass produce eps-only columns
 #pragma unroll
         for (int sl = 0; sl < NS; ++sl)
-            if (mytopic[sl] >= 0 && mytopic[sl] < p.estride) p.E[(int64_t)d * p.estride + mytopic[sl]] = 0.0f;
+            if (wave == 0 && mytopic[sl] >= 0 && mytopic[sl] < p.estride) p.E[(int64_t)d * p.estride + mytopic[sl]] = 0.0f;
 #pragma unroll
         for (int t = 0; t < T; ++t) if (wpos[t] >= 0 && p.store_w) p.wtok[wpos[t]] = 0.0f;
     }
-    if (lane == 0) p.sweeps[d] = (uint8_t)min(sweeps, 255);
+    if (lane == 0 && wave == 0) p.sweeps[d] = (uint8_t)min(sweeps, 255);
 }
 
 template <int LPR, int T>
@@ -436,6 +462,17 @@ __global__ __launch_bounds__(64) void lda_estep_reg_kernel(LdaParams p, int64_t 
     const int d = p.doc_order[first + blockIdx.x];
     const int64_t off = p.doc_ptr[d];
     lda_estep_reg_body<LPR, T>(p, d, off, (int)(p.doc_ptr[d + 1] - off), topic_of_lane);
+}
+
+// long documents: one workgroup of TMVB_LONG_WAVES waves per document (see lda_estep_reg_body, W > 1)
+#define TMVB_LONG_WAVES 4
+template <int LPR, int T>
+__global__ __launch_bounds__(64 * TMVB_LONG_WAVES) void lda_estep_reg_long_kernel(LdaParams p, int64_t first,
+                                                                                 const int* __restrict__ topic_of_lane)
+{
+    const int d = p.doc_order[first + blockIdx.x];
+    const int64_t off = p.doc_ptr[d];
+    lda_estep_reg_body<LPR, T, TMVB_LONG_WAVES>(p, d, off, (int)(p.doc_ptr[d + 1] - off), topic_of_lane);
 }
 
 // All register-tile documents of a SMALL corpus / shard in one launch: the tile count is read per document
@@ -618,6 +655,13 @@ __global__ __launch_bounds__(1024) void lda_elbo_final_kernel(const double* __re
 template <int LPR, int TMAX>
 static void lda_launch_reg(int tiles, dim3 grid, dim3 block, hipStream_t st, const LdaParams& p, int64_t first, const int* tol)
 {
+    if (block.x > 64) {            // one workgroup of TMVB_LONG_WAVES waves per long document
+        if (tiles <= 1) hipLaunchKernelGGL((lda_estep_reg_long_kernel<LPR, 1>), grid, block, 0, st, p, first, tol);
+        else if (tiles == 2 || TMAX == 2) hipLaunchKernelGGL((lda_estep_reg_long_kernel<LPR, (TMAX >= 2 ? 2 : 1)>), grid, block, 0, st, p, first, tol);
+        else if (tiles == 3 || TMAX == 3) hipLaunchKernelGGL((lda_estep_reg_long_kernel<LPR, (TMAX >= 3 ? 3 : 1)>), grid, block, 0, st, p, first, tol);
+        else hipLaunchKernelGGL((lda_estep_reg_long_kernel<LPR, (TMAX >= 4 ? 4 : 1)>), grid, block, 0, st, p, first, tol);
+        return;
+    }
     if (tiles == TMVB_REG_ANY_TILES) hipLaunchKernelGGL((lda_estep_reg_any_kernel<LPR, TMAX>), grid, block, 0, st, p, first, tol);
     else if (tiles <= 1) hipLaunchKernelGGL((lda_estep_reg_kernel<LPR, 1>), grid, block, 0, st, p, first, tol);
     else if (tiles == 2 || TMAX == 2) hipLaunchKernelGGL((lda_estep_reg_kernel<LPR, (TMAX >= 2 ? 2 : 1)>), grid, block, 0, st, p, first, tol);
@@ -707,7 +751,20 @@ static void lda_build_buckets(tmvb_lda* h, std::vector<int32_t>& order)
     // documents longer than reg_max: LDS-tile kernel
     // long documents get up to 156 KiB of LDS (one workgroup per CU): a tile that holds the whole document is
     // gathered once per E-step, a streamed one once per sweep
-    int64_t pos = tmvb_build_lds_buckets(len, order, h->M, h->KP, reg_max, 3, h->buckets, TMVB_BIG_TILE_BYTES);
+    // Documents between 64 T and 64 T W unique terms keep the register-tile arithmetic with one workgroup of
+    // W = TMVB_LONG_WAVES waves each (lda_estep_reg_long_kernel); only what is longer still goes through LDS.
+    const bool long_reg = h->reg_path && getenv("TMVB_LDA_NO_LONG") == nullptr;
+    const int64_t long_max = long_reg ? reg_max * TMVB_LONG_WAVES : reg_max;
+    int64_t pos = tmvb_build_lds_buckets(len, order, h->M, h->KP, long_max, 3, h->buckets, TMVB_BIG_TILE_BYTES);
+    if (long_reg) {
+        for (int T = max_tiles; T >= 1 && pos < h->M; --T) {   // (KP = 100, T = 3 spills to AGPRs and is still 2.8x the LDS kernel)
+            const int64_t lo = std::max<int64_t>(64 * TMVB_LONG_WAVES * (int64_t)(T - 1), reg_max);
+            int64_t cnt = 0;
+            while (pos + cnt < h->M && len[order[pos + cnt]] > lo) ++cnt;
+            if (cnt) { tmvb_bucket b{pos, cnt, 0, T}; b.waves = TMVB_LONG_WAVES; h->buckets.push_back(b); }
+            pos += cnt;
+        }
+    }
     // small corpora (one statistics pass): ONE launch for all register-tile documents, longest first
     if (h->reg_path && pos < h->M && lda_piece_count(h) == 1 && getenv("TMVB_LDA_NO_MERGE") == nullptr) {
         h->buckets.push_back({pos, h->M - pos, 0, TMVB_REG_ANY_TILES});
@@ -760,7 +817,7 @@ static void lda_cut_pieces(tmvb_lda* h, const std::vector<int32_t>& order, int P
     std::vector<tmvb_bucket> cut;
     int64_t run = 0;
     for (const tmvb_bucket& b : h->buckets) {
-        if (b.reg_tiles == 0) {
+        if (b.reg_tiles == 0 || b.waves > 1) {               // LDS-tile and workgroup-per-document buckets: last piece, aux[1]
             tmvb_bucket c = b; c.piece = P - 1;
             for (int64_t q = b.first; q < b.first + b.count; ++q) doc_piece[order[q]] = P - 1;
             cut.push_back(c);
@@ -1044,11 +1101,12 @@ extern "C" int tmvb_lda_estep(tmvb_lda* h, int32_t viter, double vtol)
     };
     for (int bi = 0; bi < nb; ++bi) {
         const tmvb_bucket& b = h->buckets[bi];
-        hipStream_t st = b.reg_tiles > 0 ? h->aux[0] : h->aux[1];
+        const bool chain = b.reg_tiles > 0 && b.waves == 1;   // single-wave register buckets: the piece chain on aux[0]
+        hipStream_t st = chain ? h->aux[0] : h->aux[1];
         if (!h->reg_path) st = h->aux[(bi & 1) ^ 1];          // LDS-tile buckets only: alternate the two streams
-        if (b.reg_tiles > 0) { int rc = close_pieces(b.piece); if (rc) return rc; }
+        if (chain) { int rc = close_pieces(b.piece); if (rc) return rc; }
         if (b.reg_tiles > 0) {
-            const dim3 grid((unsigned)b.count), block(64);
+            const dim3 grid((unsigned)b.count), block(64 * (unsigned)b.waves);
             const int* tol = h->d_topic_of_lane;
             switch (p.LPR) {
 #define LDA_REG_CASE(LPRV, TMAX) case LPRV: lda_launch_reg<LPRV, TMAX>(b.reg_tiles, grid, block, st, p, b.first, tol); break;
