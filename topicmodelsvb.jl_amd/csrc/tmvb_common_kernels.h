@@ -234,23 +234,36 @@ static __global__ __launch_bounds__(256) void colsum_final_kernel(const double* 
 
 // update_beta!(model)  src/LDA.jl:121-125:  beta_new = S ./ rowsum(S);  S <- 0
 // S is dense [V][K]; beta_new is the padded gather layout [V][KP] (pad columns zero).
+// pw_partial (or NULL): per-block fp64 partial of sum_{i,j} S[j][i] * log(beta_new[j][i] + eps) = E_q[log p(w)] of the
+// ELBO (src/LDA.jl:65 summed over the corpus: sum_n c_n phi_in = S), fixed summation order per block.
 static __global__ __launch_bounds__(256) void beta_norm_kernel(float* __restrict__ S, const double* __restrict__ rowsum,
-                                                            float* __restrict__ beta_new, int K, int KP, int64_t V)
+                                                            float* __restrict__ beta_new, int K, int KP, int64_t V,
+                                                            double* __restrict__ pw_partial, float eps)
 {
     extern __shared__ double rinv[];
+    __shared__ double red[4];
     for (int i = threadIdx.x; i < K; i += blockDim.x) rinv[i] = 1.0 / rowsum[i];
     __syncthreads();
     const int64_t total = V * KP;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    double pw = 0.0;
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += stride) {
         const int64_t j = q / KP;
         const int i = (int)(q - j * KP);
         float o = 0.0f;
         if (i < K) {
-            o = (float)((double)S[j * K + i] * rinv[i]);
+            const float sv = S[j * K + i];
+            o = (float)((double)sv * rinv[i]);
+            if (pw_partial) pw += (double)sv * (double)logf(o + eps);
             S[j * K + i] = 0.0f;
         }
         beta_new[q] = o;
+    }
+    if (pw_partial) {
+        pw = wave_sum_d(pw);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = pw;
+        __syncthreads();
+        if (threadIdx.x == 0) pw_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
     }
 }
 

@@ -870,7 +870,7 @@ extern "C" int tmvb_ctm_update_beta(tmvb_ctm* h)
     const int64_t total = (int64_t)h->KP * h->V;
     int nb = (int)std::min<int64_t>(2048, std::max<int64_t>(1, (total + 255) / 256));
     hipLaunchKernelGGL(beta_norm_kernel, dim3(nb), dim3(256), (size_t)h->K * sizeof(double), ctx->stream,
-                       h->d_stats, h->d_rowsum, h->d_beta[h->cur ^ 1], h->K, h->KP, h->V);
+                       h->d_stats, h->d_rowsum, h->d_beta[h->cur ^ 1], h->K, h->KP, h->V, (double*)nullptr, 0.0f);
     TMVB_HIP(hipGetLastError());
     h->cur ^= 1;
     return TMVB_OK;

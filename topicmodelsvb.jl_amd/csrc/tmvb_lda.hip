@@ -626,14 +626,105 @@ __global__ __launch_bounds__(64) void lda_elbo_kernel(int K, int KP, const int64
     if (lane == 0) doc_val[d] = tot;
 }
 
+#ifndef TMVB_ELBO_SKIP_TAIL
+#define TMVB_ELBO_SKIP_TAIL 0
+#endif
+// Token-parallel ELBO for K <= 100 (KP = 4 * LPR): lane = token, the beta_old and beta rows of the token in VGPRs,
+// e_old_k = exp(Elogtheta_old_k) and Elogtheta_k as SGPR operands (v_readlane with an immediate lane: here lane = topic
+// in natural order, the state is read straight from memory), every token term of update_elbo! (src/LDA.jl:58, :65, :78,
+// phi rebuilt from beta_old / Elogtheta_old, :87-88) accumulated per lane in fp64 -- no per-token wave reduction, no
+// cross-lane traffic until one final sum.  ~10 wave instructions per token instead of ~110 in lda_elbo_kernel.
+// WITH_PW = false: E_q[log p(w)] comes from update_beta! (tmvb_lda::d_pw_partial); the beta rows are not read.
+template <int LPR, bool WITH_PW>
+__global__ __launch_bounds__(64) void lda_elbo_reg_kernel(int K, const int32_t* __restrict__ doc_order, const int64_t* __restrict__ doc_ptr,
+                                                          const int32_t* __restrict__ terms, const int32_t* __restrict__ counts,
+                                                          const double* __restrict__ alpha_d, const float* __restrict__ beta,
+                                                          const float* __restrict__ beta_old, const float* __restrict__ gamma,
+                                                          const float* __restrict__ elog, const float* __restrict__ elog_old,
+                                                          double* __restrict__ doc_val)
+{
+    constexpr int R = 4 * LPR, NS = (R + 63) / 64;
+    const int lane = threadIdx.x;
+    const int d = doc_order[blockIdx.x];                        // longest documents first (doc_val is indexed by document)
+    const int64_t off = doc_ptr[d];
+    const int N = (int)(doc_ptr[d + 1] - off);
+    float eo[NS], el[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int i = lane + 64 * s;
+        eo[s] = (i < K) ? expf(elog_old[(int64_t)d * K + i]) : 0.0f;
+        el[s] = (i < K) ? elog[(int64_t)d * K + i] : 0.0f;
+    }
+    double acc = 0.0;
+    for (int n0 = 0; n0 < N; n0 += 64) {
+        const int n = n0 + lane;
+        const bool in = n < N;
+        const int term = in ? terms[off + n] : 0;
+        const float c = in ? (float)counts[off + n] : 0.0f;
+        const float4* ro = (const float4*)(beta_old + (int64_t)term * R);
+        const float4* rn = (const float4*)(beta + (int64_t)term * R);
+        float bo[R], bn[WITH_PW ? R : 1];
+#pragma unroll
+        for (int q = 0; q < LPR; ++q) {
+            const float4 a = ro[q];
+            bo[4 * q] = a.x; bo[4 * q + 1] = a.y; bo[4 * q + 2] = a.z; bo[4 * q + 3] = a.w;
+            if constexpr (WITH_PW) {
+                const float4 b = rn[q];
+                bn[4 * q] = b.x; bn[4 * q + 1] = b.y; bn[4 * q + 2] = b.z; bn[4 * q + 3] = b.w;
+            }
+        }
+        // With x_k = beta_old_k e_old_k + eps, s = sum_k x_k and phi_k = x_k / s (:87-88), the token's terms are
+        //   sum_k phi_k (Elogtheta_k + log(beta_k + eps) - log phi_k) = (1/s) sum_k x_k (Elogtheta_k + log((beta_k + eps) / x_k)) + log s
+        // (sum_k phi_k = 1): two v_log_f32 per (token, topic) -- good to 1 ulp of log2, arguments are normal numbers
+        // >= eps; libm logf is ~9x the instructions -- and four more VALU instructions.
+        float s0 = 0.0f, s1 = 0.0f, t0 = 0.0f, t1 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            if (k < R - 7 || k < K) {                                                // KP = 4 * odd >= K: at most 7 pad columns
+                const float ek = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, eo[k >> 6]), k & 63));
+                const float lk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, el[k >> 6]), k & 63));
+                const float x = fmaf(bo[k], ek, TMVB_EPS_F);
+                const float dl = (WITH_PW ? __builtin_amdgcn_logf(bn[WITH_PW ? k : 0] + TMVB_EPS_F) : 0.0f) - __builtin_amdgcn_logf(x);
+                const float u = fmaf(dl, 0.693147180559945f, lk);
+                if (k & 1) { s1 += x; t1 = fmaf(x, u, t1); } else { s0 += x; t0 = fmaf(x, u, t0); }
+            }
+        }
+        const float ssum = s0 + s1;
+        const float t = fmaf(t0 + t1, 1.0f / ssum, 0.693147180559945f * __builtin_amdgcn_logf(ssum));
+        acc += (double)c * (double)t;
+    }
+    // per-document topic terms, lane = topic
+    double gl = 0.0;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int i = lane + 64 * s;
+        if (i < K) {
+            const double g = (double)gamma[(int64_t)d * K + i];
+            acc += (alpha_d[i] - 1.0) * (double)el[s];                               // Elogptheta :51 (dot part)
+            if (K > 1 && !TMVB_ELBO_SKIP_TAIL) acc += lgamma(g) - (g - 1.0) * digamma_d(g);                  // -Elogqtheta :72 (utils.jl:172-176)
+            gl += g;
+        }
+    }
+    const double g0 = wave_sum_d(gl);
+    double tot = wave_sum_d(acc);
+    if (K > 1 && !TMVB_ELBO_SKIP_TAIL) tot += -lgamma(g0) + (g0 - (double)K) * digamma_d(g0);
+    if (lane == 0) doc_val[d] = tot;
+}
+
 // elbo = sum_d doc_val[d] + M * (lgamma(sum alpha) - sum lgamma(alpha))   (src/LDA.jl:51, finite())
 __global__ __launch_bounds__(1024) void lda_elbo_final_kernel(const double* __restrict__ doc_val, int64_t M, int K,
-                                                              const double* __restrict__ alpha_d, double* __restrict__ out)
+                                                              const double* __restrict__ alpha_d, double* __restrict__ out,
+                                                              const double* __restrict__ pw_partial, int pw_blocks)
 {
     __shared__ double red[1024];
-    double s = 0.0;
-    for (int64_t d = threadIdx.x; d < M; d += 1024) s += doc_val[d];
-    red[threadIdx.x] = s;
+    double s8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};      // 8 independent chains: the loads overlap (fixed order)
+    for (int64_t d0 = threadIdx.x; d0 < M; d0 += 8 * 1024) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int64_t d = d0 + (int64_t)u * 1024; if (d < M) s8[u] += doc_val[d]; }
+    }
+    double pwl = 0.0;                                             // E_q[log p(w)] partials of update_beta!, if in use
+    if (pw_partial) for (int b = threadIdx.x; b < pw_blocks; b += 1024) pwl += pw_partial[b];
+    red[threadIdx.x] = (((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]))) + pwl;
     __syncthreads();
     for (int o = 512; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
@@ -728,6 +819,13 @@ struct tmvb_lda {
     bool esum_side = false;            // ... and they were produced on the side stream by the last E-step
     bool timing = false;               // TMVB_ESTEP_TIMING=1: record the events behind tmvb_lda_last_estep_ms
     bool mark_valid = false;           // ev_mark was recorded at the entry of the preceding update_beta call
+    // E_q[log p(w)] = sum S .* log(beta_new + eps) falls out of update_beta! (the statistics ARE sum_n c_n phi_in), so the
+    // ELBO pass right after an iteration needs neither the beta rows nor their logarithms (one context only: a
+    // document-sharded rank holds the global S after the all-reduce but only its own documents)
+    double* d_pw_partial = nullptr;    // [2048] per-block partials of the last update_beta!
+    int pw_blocks = 0;
+    bool stats_fresh = false;          // S holds the statistics of an E-step that update_beta! has not consumed yet
+    bool pw_valid = false;             // d_pw_partial belongs to the current (beta, beta_old, Elogtheta_old) state
     bool side_pending = false;         // ev_side marks side-stream work the context's stream has not waited for yet
 };
 
@@ -867,7 +965,7 @@ extern "C" int tmvb_lda_destroy(tmvb_lda* h)
     if (h->ev_docs) (void)hipEventDestroy(h->ev_docs);
     if (h->ev_side) (void)hipEventDestroy(h->ev_side);
     if (h->ev_mark) (void)hipEventDestroy(h->ev_mark);
-    (void)hipFree(h->d_partial_side);
+    (void)hipFree(h->d_partial_side); (void)hipFree(h->d_pw_partial);
     for (tmvb_inv_index& ix : h->pieces) tmvb_free_inv_index(&ix);
     for (hipEvent_t e : h->ev_piece) if (e) (void)hipEventDestroy(e);
     for (int a = 0; a < tmvb_lda::NAUX; ++a) {
@@ -971,7 +1069,7 @@ extern "C" int tmvb_lda_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
     TMVB_HIP(hipEventCreateWithFlags(&h->ev_docs, hipEventDisableTiming));
     TMVB_HIP(hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming));
     TMVB_HIP(hipEventCreateWithFlags(&h->ev_mark, hipEventDisableTiming));
-    if ((rc = dmalloc(&h->d_partial_side, (size_t)TMVB_REDUCE_BLOCKS * K))) { tmvb_lda_destroy(h); return rc; }
+    if ((rc = dmalloc(&h->d_partial_side, (size_t)TMVB_REDUCE_BLOCKS * K)) || (rc = dmalloc(&h->d_pw_partial, 2048))) { tmvb_lda_destroy(h); return rc; }
     for (int a = 0; a < tmvb_lda::NAUX; ++a) {
         TMVB_HIP(hipStreamCreateWithFlags(&h->aux[a], hipStreamNonBlocking));
         TMVB_HIP(hipEventCreateWithFlags(&h->ev_join[a], hipEventDisableTiming));
@@ -994,7 +1092,7 @@ extern "C" int tmvb_lda_set_state(tmvb_lda* h, const double* alpha, const double
                                   const double* elbo)
 {
     TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_lda_set_state: handle is NULL");
-    h->mark_valid = false; h->esum_fresh = false; h->esum_side = false;
+    h->mark_valid = false; h->esum_fresh = false; h->esum_side = false; h->pw_valid = false; h->stats_fresh = false;
     tmvb_ctx* ctx = h->ctx;
     TMVB_HIP(hipSetDevice(ctx->device));
     { int jrc = lda_join_side(h); if (jrc) return jrc; }
@@ -1152,6 +1250,7 @@ extern "C" int tmvb_lda_estep(tmvb_lda* h, int32_t viter, double vtol)
         h->side_pending = true;
         h->esum_fresh = true; h->esum_side = true;
     }
+    h->stats_fresh = !(p.debug & 1); h->pw_valid = false;
     if (h->timing) TMVB_HIP(hipEventRecord(h->ev1, ctx->stream));
     h->timed = true;
     return TMVB_OK;
@@ -1228,8 +1327,11 @@ extern "C" int tmvb_lda_update_beta(tmvb_lda* h)
     const int64_t total = (int64_t)h->KP * h->V;
     int nb = (int)std::min<int64_t>(2048, std::max<int64_t>(1, (total + 255) / 256));
     hipLaunchKernelGGL(beta_norm_kernel, dim3(nb), dim3(256), (size_t)h->K * sizeof(double), ctx->stream,
-                       h->d_stats, h->d_rowsum, h->d_beta[h->cur ^ 1], h->K, h->KP, h->V);
+                       h->d_stats, h->d_rowsum, h->d_beta[h->cur ^ 1], h->K, h->KP, h->V, h->d_pw_partial, TMVB_EPS_F);
     TMVB_HIP(hipGetLastError());
+    h->pw_blocks = nb;
+    h->pw_valid = h->stats_fresh && !h->distributed;
+    h->stats_fresh = false;
     h->cur ^= 1;   // beta_old <- beta, beta <- new   (src/LDA.jl:122-123)
     return TMVB_OK;
 }
@@ -1271,7 +1373,26 @@ extern "C" int tmvb_lda_update_elbo(tmvb_lda* h, double* elbo)
     tmvb_ctx* ctx = h->ctx;
     TMVB_HIP(hipSetDevice(ctx->device));
     { int jrc = lda_join_side(h); if (jrc) return jrc; }
-    if (h->M > 0) {
+    bool use_pw = false;
+    if (h->M > 0 && h->reg_path && getenv("TMVB_LDA_ELBO_LEGACY") == nullptr) {
+        const dim3 grid((unsigned)h->M), block(64);
+        use_pw = h->pw_valid && getenv("TMVB_LDA_ELBO_NO_PW") == nullptr;
+        switch (h->KP / 4) {
+#define LDA_ELBO_CASE(LPRV) case LPRV: \
+            if (use_pw) hipLaunchKernelGGL((lda_elbo_reg_kernel<LPRV, false>), grid, block, 0, ctx->stream, h->K, h->d_doc_order, h->corp->d_doc_ptr, \
+                               h->corp->d_terms, h->corp->d_counts, h->d_alpha_d, h->d_beta[h->cur], h->d_beta[h->cur ^ 1], \
+                               h->d_gamma, h->d_elog, h->d_elog_old, h->d_doc_val); \
+            else hipLaunchKernelGGL((lda_elbo_reg_kernel<LPRV, true>), grid, block, 0, ctx->stream, h->K, h->d_doc_order, h->corp->d_doc_ptr, \
+                               h->corp->d_terms, h->corp->d_counts, h->d_alpha_d, h->d_beta[h->cur], h->d_beta[h->cur ^ 1], \
+                               h->d_gamma, h->d_elog, h->d_elog_old, h->d_doc_val); \
+            break;
+            LDA_ELBO_CASE(1) LDA_ELBO_CASE(3) LDA_ELBO_CASE(5) LDA_ELBO_CASE(7) LDA_ELBO_CASE(9) LDA_ELBO_CASE(11) LDA_ELBO_CASE(13)
+            LDA_ELBO_CASE(15) LDA_ELBO_CASE(17) LDA_ELBO_CASE(19) LDA_ELBO_CASE(21) LDA_ELBO_CASE(23) LDA_ELBO_CASE(25)
+#undef LDA_ELBO_CASE
+            default: TMVB_REQUIRE(false, TMVB_EINVAL, "tmvb_lda_update_elbo: no token-parallel kernel for KP=%d", h->KP);
+        }
+        TMVB_HIP(hipGetLastError());
+    } else if (h->M > 0) {
         int rc = dispatch_nslot(h->nslot, [&](auto ns) -> int {
             constexpr int NS = decltype(ns)::value;
             hipLaunchKernelGGL((lda_elbo_kernel<NS>), dim3((unsigned)h->M), dim3(64), 0, ctx->stream, h->K, h->KP, h->corp->d_doc_ptr,
@@ -1282,7 +1403,8 @@ extern "C" int tmvb_lda_update_elbo(tmvb_lda* h, double* elbo)
         if (rc) return rc;
         TMVB_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(lda_elbo_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, h->d_doc_val, h->M, h->K, h->d_alpha_d, h->d_elbo);
+    hipLaunchKernelGGL(lda_elbo_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, h->d_doc_val, h->M, h->K, h->d_alpha_d, h->d_elbo,
+                       use_pw ? h->d_pw_partial : (const double*)nullptr, h->pw_blocks);
     TMVB_HIP(hipGetLastError());
     double v = 0.0;
     TMVB_HIP(hipMemcpyAsync(&v, h->d_elbo, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
