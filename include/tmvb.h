@@ -153,7 +153,10 @@ int tmvb_lda_update_beta(tmvb_lda* h);
  * fp64 Newton on the device. */
 int tmvb_lda_update_alpha(tmvb_lda* h, int32_t niter, double ntol);
 /* update_elbo! (src/LDA.jl:83-93) evaluated on the device from the current state; returns the sum
- * over this context's documents (a multi-process host adds the ranks' values) and stores it. */
+ * over this context's documents (a multi-process host adds the ranks' values) and stores it.  Right after
+ * estep -> update_beta the corpus-level term E_q[log p(w)] = sum S .* log(beta + eps) comes from update_beta's statistics;
+ * a document-sharded context (global S after the all-reduce) contributes the share M / M_total of it, so the ranks'
+ * values still add up to the ELBO. */
 int tmvb_lda_update_elbo(tmvb_lda* h, double* elbo);
 
 /* train! (src/gpuLDA.jl:347-376 signature, src/LDA.jl:161-187 semantics incl. check_elbo!

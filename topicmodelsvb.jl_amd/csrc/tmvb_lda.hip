@@ -714,7 +714,7 @@ __global__ __launch_bounds__(64) void lda_elbo_reg_kernel(int K, const int32_t* 
 // elbo = sum_d doc_val[d] + M * (lgamma(sum alpha) - sum lgamma(alpha))   (src/LDA.jl:51, finite())
 __global__ __launch_bounds__(1024) void lda_elbo_final_kernel(const double* __restrict__ doc_val, int64_t M, int K,
                                                               const double* __restrict__ alpha_d, double* __restrict__ out,
-                                                              const double* __restrict__ pw_partial, int pw_blocks)
+                                                              const double* __restrict__ pw_partial, int pw_blocks, double pw_share)
 {
     __shared__ double red[1024];
     double s8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};      // 8 independent chains: the loads overlap (fixed order)
@@ -723,7 +723,7 @@ __global__ __launch_bounds__(1024) void lda_elbo_final_kernel(const double* __re
         for (int u = 0; u < 8; ++u) { const int64_t d = d0 + (int64_t)u * 1024; if (d < M) s8[u] += doc_val[d]; }
     }
     double pwl = 0.0;                                             // E_q[log p(w)] partials of update_beta!, if in use
-    if (pw_partial) for (int b = threadIdx.x; b < pw_blocks; b += 1024) pwl += pw_partial[b];
+    if (pw_partial) for (int b = threadIdx.x; b < pw_blocks; b += 1024) pwl += pw_share * pw_partial[b];
     red[threadIdx.x] = (((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]))) + pwl;
     __syncthreads();
     for (int o = 512; o > 0; o >>= 1) {
@@ -820,8 +820,9 @@ struct tmvb_lda {
     bool timing = false;               // TMVB_ESTEP_TIMING=1: record the events behind tmvb_lda_last_estep_ms
     bool mark_valid = false;           // ev_mark was recorded at the entry of the preceding update_beta call
     // E_q[log p(w)] = sum S .* log(beta_new + eps) falls out of update_beta! (the statistics ARE sum_n c_n phi_in), so the
-    // ELBO pass right after an iteration needs neither the beta rows nor their logarithms (one context only: a
-    // document-sharded rank holds the global S after the all-reduce but only its own documents)
+    // ELBO pass right after an iteration needs neither the beta rows nor their logarithms.  A document-sharded rank
+    // holds the GLOBAL S after the all-reduce: it contributes the share M / M_total of the global term to its local
+    // ELBO, and the shares add up to one in the host's all-reduce of the local values
     double* d_pw_partial = nullptr;    // [2048] per-block partials of the last update_beta!
     int pw_blocks = 0;
     bool stats_fresh = false;          // S holds the statistics of an E-step that update_beta! has not consumed yet
@@ -1330,7 +1331,7 @@ extern "C" int tmvb_lda_update_beta(tmvb_lda* h)
                        h->d_stats, h->d_rowsum, h->d_beta[h->cur ^ 1], h->K, h->KP, h->V, h->d_pw_partial, TMVB_EPS_F);
     TMVB_HIP(hipGetLastError());
     h->pw_blocks = nb;
-    h->pw_valid = h->stats_fresh && !h->distributed;
+    h->pw_valid = h->stats_fresh;
     h->stats_fresh = false;
     h->cur ^= 1;   // beta_old <- beta, beta <- new   (src/LDA.jl:122-123)
     return TMVB_OK;
@@ -1404,7 +1405,8 @@ extern "C" int tmvb_lda_update_elbo(tmvb_lda* h, double* elbo)
         TMVB_HIP(hipGetLastError());
     }
     hipLaunchKernelGGL(lda_elbo_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, h->d_doc_val, h->M, h->K, h->d_alpha_d, h->d_elbo,
-                       use_pw ? h->d_pw_partial : (const double*)nullptr, h->pw_blocks);
+                       use_pw ? h->d_pw_partial : (const double*)nullptr, h->pw_blocks,
+                       h->distributed && h->M_total > 0 ? (double)h->M / (double)h->M_total : 1.0);
     TMVB_HIP(hipGetLastError());
     double v = 0.0;
     TMVB_HIP(hipMemcpyAsync(&v, h->d_elbo, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
