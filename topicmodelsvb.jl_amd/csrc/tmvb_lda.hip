@@ -730,9 +730,13 @@ __global__ __launch_bounds__(1024) void lda_elbo_final_kernel(const double* __re
         if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
         __syncthreads();
     }
+    // lgamma(alpha_i) in parallel (K <= 1024 = blockDim), summed in index order by thread 0
+    __shared__ double lga[1024];
+    if ((int)threadIdx.x < K) lga[threadIdx.x] = lgamma(alpha_d[threadIdx.x]);
+    __syncthreads();
     if (threadIdx.x == 0) {
         double asum = 0.0, lg = 0.0;
-        for (int i = 0; i < K; ++i) { asum += alpha_d[i]; lg += lgamma(alpha_d[i]); }
+        for (int i = 0; i < K; ++i) { asum += alpha_d[i]; lg += lga[i]; }
         double a = lgamma(asum);
         a = fmin(fmax(a, -1.7976931348623157e308), 1.7976931348623157e308);
         lg = fmin(fmax(lg, -1.7976931348623157e308), 1.7976931348623157e308);
