@@ -63,3 +63,90 @@ def test_sharded_hip_world2_matches_single_context(tmvb, pieces):
         g = gm.gamma[:, int(r["d0"]):int(r["d1"])]
         assert np.quantile(np.abs(r["gamma"] - g) / np.maximum(np.abs(g), 1e-3), 0.999) < 5e-3
     assert int(res[0]["d1"]) == int(res[1]["d0"]) and int(res[1]["d1"]) == corpus.M
+
+
+# ---------------------------------------------------------------------------------------------- CTM / CTPF
+def _worker_ctm(rank, world, initfile, out_dir, iters):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import tmvb_amd
+    from tmvb_amd_pkg.dist import HipCTMEngine, ShardedCTM
+    dist.init_process_group("gloo", init_method=f"file://{initfile}", rank=rank, world_size=world)
+    tm = tmvb_amd.pkg
+    corpus = tm.syn_nsf(M=1200, V=500, seed=12)
+    K = 12
+    beta0 = tm.dirichlet_rows(K, corpus.V, seed=3)
+    d0, d1 = corpus.shard_bounds(world)[rank]
+    eng = HipCTMEngine(corpus.shard(d0, d1), K, beta0, corpus.M, 0, distributed=True)
+    traj = ShardedCTM(eng).train(iter=iters, tol=0.0, checkelbo=1)
+    eng.model.update_host()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), traj=np.array(traj), mu=eng.model.mu, sigma=eng.model.sigma, beta=eng.model.beta,
+             lam=eng.model.lam, d0=d0, d1=d1)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_ctm_world2_matches_single_context(tmvb):
+    import torch.multiprocessing as mp
+    world, iters = 2, 4
+    with tempfile.TemporaryDirectory() as td:
+        mp.spawn(_worker_ctm, args=(world, os.path.join(td, "init"), td, iters), nprocs=world, join=True)
+        res = [dict(np.load(os.path.join(td, f"rank{r}.npz"))) for r in range(world)]
+    corpus = tmvb.syn_nsf(M=1200, V=500, seed=12)
+    K = 12
+    gm = tmvb.gpuCTM(corpus, K)
+    gm.beta = np.asfortranarray(tmvb.dirichlet_rows(K, corpus.V, seed=3)); gm.beta_old = gm.beta.copy(order="F")
+    gm.update_buffer()
+    traj = gm.train(iter=iters, tol=0.0, checkelbo=1, printelbo=False)
+    gm.update_host()
+    assert np.array_equal(res[0]["mu"], res[1]["mu"]) and np.array_equal(res[0]["sigma"], res[1]["sigma"]) and np.array_equal(res[0]["beta"], res[1]["beta"])
+    for r in res:
+        np.testing.assert_allclose(r["traj"], np.array(traj)[:len(r["traj"])], rtol=5e-6)
+        np.testing.assert_allclose(r["mu"], gm.mu, atol=2e-4)
+        np.testing.assert_allclose(r["sigma"], gm.sigma, atol=5e-4 * max(1.0, np.abs(gm.sigma).max()))
+        lam = gm.lam[:, int(r["d0"]):int(r["d1"])]
+        assert np.quantile(np.abs(r["lam"] - lam), 0.999) < 5e-3 * max(1.0, np.abs(lam).max())
+
+
+def _worker_ctpf(rank, world, initfile, out_dir, iters):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import tmvb_amd
+    from tmvb_amd_pkg.dist import HipCTPFEngine, ShardedCTPF
+    dist.init_process_group("gloo", init_method=f"file://{initfile}", rank=rank, world_size=world)
+    tm = tmvb_amd.pkg
+    corpus = tm.syn_citeu(M=900, V=700, U=120, seed=13)
+    K = 20
+    alef0 = np.exp(tm.dirichlet_rows(K, corpus.V, seed=4) - 0.5)
+    d0, d1 = corpus.shard_bounds(world)[rank]
+    eng = HipCTPFEngine(corpus.shard(d0, d1), K, alef0, 0, distributed=True)
+    traj = ShardedCTPF(eng).train(iter=iters, tol=0.0, checkelbo=1)
+    eng.model.update_host()
+    m = eng.model
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), traj=np.array(traj), alef=m.alef, he=m.he, bet=m.bet, vav=m.vav, dalet=m.dalet,
+             het=m.het, gimel=m.gimel, d0=d0, d1=d1)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_ctpf_world2_matches_single_context(tmvb):
+    import torch.multiprocessing as mp
+    world, iters = 2, 4
+    with tempfile.TemporaryDirectory() as td:
+        mp.spawn(_worker_ctpf, args=(world, os.path.join(td, "init"), td, iters), nprocs=world, join=True)
+        res = [dict(np.load(os.path.join(td, f"rank{r}.npz"))) for r in range(world)]
+    corpus = tmvb.syn_citeu(M=900, V=700, U=120, seed=13)
+    K = 20
+    gm = tmvb.gpuCTPF(corpus, K)
+    gm.alef = np.asfortranarray(np.exp(tmvb.dirichlet_rows(K, corpus.V, seed=4) - 0.5)); gm.update_buffer()
+    traj = gm.train(iter=iters, tol=0.0, checkelbo=1, printelbo=False, recs=False)
+    for n in ("alef", "he", "bet", "vav", "dalet", "het"):
+        assert np.array_equal(res[0][n], res[1][n]), n                  # identical M-step on every rank
+    for r in res:
+        np.testing.assert_allclose(r["traj"], np.array(traj)[:len(r["traj"])], rtol=5e-6)
+        np.testing.assert_allclose(r["alef"], gm.alef, rtol=2e-3)
+        np.testing.assert_allclose(r["he"], gm.he, rtol=2e-3)
+        for n in ("bet", "vav", "dalet", "het"):
+            np.testing.assert_allclose(r[n], getattr(gm, n), rtol=2e-4)
+        g = gm.gimel[:, int(r["d0"]):int(r["d1"])]
+        assert np.quantile(np.abs(r["gimel"] - g) / np.abs(g), 0.999) < 5e-3

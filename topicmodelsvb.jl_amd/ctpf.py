@@ -128,6 +128,12 @@ class gpuCTPF:
         self.elbo = out.value
         return out.value
 
+    def update_elbo_parts(self):
+        """(per-document part summed over this context's documents, global (beta, eta) part) for document-sharded hosts."""
+        a, b = C.c_double(0.0), C.c_double(0.0)
+        check(lib().tmvb_ctpf_update_elbo_parts(self.handle, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def stats(self):
         p, n = VP(), C.c_int64(0)
         check(lib().tmvb_ctpf_stats(self.handle, C.byref(p), C.byref(n)))

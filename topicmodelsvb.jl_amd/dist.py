@@ -123,3 +123,131 @@ class ShardedLDA:
             else:
                 traj.append(float("nan"))
         return traj
+
+
+# ---------------------------------------------------------------------------------------------- CTM / CTPF
+# Same scheme for the other two models: the packed statistics buffers are
+#   CTM   [S (K*V) | sum lambda (K) | sum vsq (K) | scatter (K*K)]     then update_beta!, update_sigma! (previous mu), update_mu!
+#   CTPF  [alef_stats (K*V) | he_stats (K*U) | sum gimel (K) | sum zayin (K)]   then the six updates of src/CTPF.jl:366-371
+# One all-reduce per outer iteration, identical M-step on every rank.
+
+class _HipEngine:
+    """Device-backed model on this rank's shard with a torch-owned statistics buffer on a dedicated stream."""
+
+    def _setup(self, device_index):
+        import torch
+        from .lda import DeviceContext
+        self.torch = torch
+        torch.cuda.set_device(device_index)
+        self.stream = torch.cuda.Stream(device=device_index)
+        assert self.stream.cuda_stream != 0
+        self.ctx = DeviceContext(device_index, self.stream.cuda_stream)
+
+    def _bind(self, device_index):
+        _, n = self.model.stats()
+        self.stats = self.torch.zeros(n, dtype=self.torch.float32, device=f"cuda:{device_index}")
+        self.model.bind_stats(self.stats.data_ptr(), n)
+        self.device = self.stats.device
+
+    def stats_tensor(self): return self.stats
+    def reduce_docs(self): self.model.reduce_docs()
+    def synchronize(self): self.model.synchronize()
+
+
+class HipCTMEngine(_HipEngine):
+    def __init__(self, shard_corpus, K, beta0, M_total, device_index, distributed):
+        from .ctm import gpuCTM
+        self._setup(device_index)
+        self.model = gpuCTM(shard_corpus, K, ctx=self.ctx)
+        self.model.beta = np.asfortranarray(beta0); self.model.beta_old = self.model.beta.copy(order="F")
+        self.model.update_buffer()
+        self._bind(device_index)
+        self.model.set_distributed(M_total, distributed)
+
+    def estep(self, niter, ntol, viter, vtol): self.model.estep(niter, ntol, viter, vtol)
+    def mstep(self):
+        self.model.update_beta(); self.model.update_sigma(); self.model.update_mu()     # src/CTM.jl:206-208
+    def local_elbo(self): return self.model.update_elbo()
+
+
+class HipCTPFEngine(_HipEngine):
+    def __init__(self, shard_corpus, K, alef0, device_index, distributed):
+        from .ctpf import gpuCTPF
+        self._setup(device_index)
+        self.model = gpuCTPF(shard_corpus, K, ctx=self.ctx)
+        self.model.alef = np.asfortranarray(alef0)
+        self.model.update_buffer()
+        self._bind(device_index)
+        self.model.set_distributed(distributed)
+
+    def estep(self, viter, vtol): self.model.estep(viter, vtol)
+    def mstep(self): self.model.mstep()                                                 # src/CTPF.jl:366-371
+    def elbo_parts(self): return self.model.update_elbo_parts()
+
+
+class _ShardedBase(ShardedLDA):
+    def _loop(self, iter, tol, checkelbo, step, on_iter=None):
+        if not tol >= 0:
+            raise ValueError("tolerance parameters must be nonnegative.")
+        if not iter >= 0:
+            raise ValueError("iteration parameters must be nonnegative.")
+        if not ((isinstance(checkelbo, (int, np.integer)) and checkelbo > 0) or checkelbo == math.inf):
+            raise ValueError("checkelbo parameter must be a positive integer or Inf.")
+        traj = []
+        if checkelbo <= iter:
+            self.elbo = self.update_elbo()
+        for k in range(1, iter + 1):
+            step()
+            if checkelbo != math.inf and k % checkelbo == 0:            # check_elbo! src/modelutils.jl:574-585
+                new = self.update_elbo()
+                delta, self.elbo = new - self.elbo, new
+                traj.append(new)
+                if on_iter:
+                    on_iter(k, new)
+                if delta < tol:
+                    break
+            else:
+                traj.append(float("nan"))
+        return traj
+
+
+class ShardedCTM(_ShardedBase):
+    """train! (src/CTM.jl:185-213 semantics) over document shards."""
+
+    def iterate(self, niter, ntol, viter, vtol):
+        e = self.engine
+        e.estep(niter, ntol, viter, vtol)        # src/CTM.jl:194-205
+        e.reduce_docs()
+        self.allreduce_stats()
+        e.mstep()
+
+    def train(self, iter=150, tol=1.0, niter=1000, ntol=None, viter=10, vtol=None, checkelbo=1, on_iter=None):
+        K = self.engine.model.K
+        ntol = 1.0 / K ** 2 if ntol is None else ntol
+        vtol = 1.0 / K ** 2 if vtol is None else vtol
+        return self._loop(iter, tol, checkelbo, lambda: self.iterate(niter, ntol, viter, vtol), on_iter)
+
+
+class ShardedCTPF(_ShardedBase):
+    """train! (src/CTPF.jl:344-376 semantics, without the recommendation tail) over document shards."""
+
+    def iterate(self, viter, vtol):
+        e = self.engine
+        e.estep(viter, vtol)                     # src/CTPF.jl:353-365
+        e.reduce_docs()
+        self.allreduce_stats()
+        e.mstep()
+
+    def update_elbo(self):
+        doc_part, global_part = self.engine.elbo_parts()
+        if self.dist and self.world_size > 1:
+            import torch
+            t = torch.tensor([doc_part], dtype=torch.float64, device=getattr(self.engine, "device", "cpu"))
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+            doc_part = float(t.item())
+        return doc_part + global_part
+
+    def train(self, iter=150, tol=1.0, viter=10, vtol=None, checkelbo=math.inf, on_iter=None):
+        K = self.engine.model.K
+        vtol = 1.0 / K ** 2 if vtol is None else vtol
+        return self._loop(iter, tol, checkelbo, lambda: self.iterate(viter, vtol), on_iter)
