@@ -130,15 +130,18 @@ def test_free_running_medium_corpus_tracks_the_oracle(tmvb, oracle):
     assert np.all(np.abs(t_g[:n] - t_o[:n]) <= RTOL_ELBO_FREE * np.abs(t_o[:n])), (t_g, t_o)
 
 
+@pytest.mark.parametrize("pieces", [None, 2])
 @pytest.mark.parametrize("K", [7, 50])
-def test_long_documents_stream_through_the_tile(tmvb, oracle, K):
+def test_long_documents_stream_through_the_tile(tmvb, oracle, K, pieces, monkeypatch):
     """Long documents: 300 / 600 / 900 unique terms run on the 4-wave register kernel (2, 3, 4 tiles per wave at K = 50),
     1100+ on the LDS-tile kernel -- resident in a 156 KiB tile at K = 7, streamed in chunks (re-gathered per sweep) at
     K = 50, where the tile holds ~700 rows."""
+    if pieces:                                         # pipelined statistics passes: the long documents belong to the last piece
+        monkeypatch.setenv("TMVB_LDA_PIECES", str(pieces))
     rng = np.random.default_rng(5)
     V = 2600
     docs = []
-    for n in (2000, 1500, 1100, 40, 3, 0, 900, 600, 300):
+    for n in (2000, 1500, 1100, 40, 3, 0, 900, 600, 300, 70, 130, 20, 250):
         t = np.sort(rng.choice(V, size=n, replace=False)); c = rng.integers(1, 4, size=n)
         docs.append((t, c))
     doc_ptr = np.concatenate([[0], np.cumsum([len(t) for t, _ in docs])])
