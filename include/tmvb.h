@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define TMVB_ABI_VERSION 1
+#define TMVB_ABI_VERSION 2
 
 /* status codes (reference: ArgumentError src/gpuLDA.jl:349-351, TopicModelError
  * src/modelutils.jl:1-5, CorpusError src/Corpus.jl:85-89) */
@@ -45,12 +45,14 @@ extern "C" {
 #define TMVB_EHIP        5   /* HIP runtime failure */
 #define TMVB_ENONFINITE  6   /* non-finite statistic / state */
 #define TMVB_ENODEVICE   7   /* no usable gfx950 device */
+#define TMVB_ERCCL       8   /* RCCL / host-collective failure (document-sharded runs) */
 
 typedef struct tmvb_ctx    tmvb_ctx;
 typedef struct tmvb_corpus tmvb_corpus;
 typedef struct tmvb_lda    tmvb_lda;
 typedef struct tmvb_ctm    tmvb_ctm;
 typedef struct tmvb_ctpf   tmvb_ctpf;
+typedef struct tmvb_comm   tmvb_comm;
 
 int         tmvb_abi_version(void);
 const char* tmvb_last_error(void);
@@ -69,6 +71,38 @@ int tmvb_ctx_synchronize(tmvb_ctx* ctx);
  * which: 0 = digamma (x > 0; src/utils.jl:21-53's algorithm), 1 = exp as used for exp(Elogtheta) (x <= 0 in exact
  * arithmetic), 2 = the rcp-based reciprocal 1/x. */
 int tmvb_special_f32(tmvb_ctx* ctx, int32_t which, const float* x, float* y, int64_t n);
+
+
+/* ---- communicator: document-sharded multi-GPU behind the C ABI (new: the reference is single-device, src/gpuLDA.jl:64;
+ * the closest precedent is the v0.6 batch accumulation `newbeta +=`, v0.6/src/gpuLDA.jl:200-225) ----
+ * Documents are conditionally independent given the globals, so every GPU runs the fused E-step on its own contiguous
+ * document shard and the ONLY exchange per outer iteration is one all-reduce (sum, f32) of the packed sufficient
+ * statistics (tmvb_*_stats); every rank then runs the identical deterministic M-step.  A communicator carries that
+ * all-reduce.  Three ways to make one:
+ *   tmvb_comm_create_rccl      one process per GPU: rank 0 calls tmvb_comm_unique_id and hands the 128 bytes to the other
+ *                              ranks by any host channel (MPI.jl / Distributed.jl / a file / torch.distributed); every
+ *                              rank then calls this (ncclCommInitRank) -- RCCL over xGMI.
+ *   tmvb_comm_create_rccl_all  one process, one host thread, n GPUs (ncclCommInitAll); the n communicators are used
+ *                              together through the *_train_group entry points.
+ *   tmvb_comm_create_host      a host-supplied all-reduce on HOST memory (MPI_Allreduce, gloo, ...): the library stages
+ *                              the buffer through pinned memory.  For hosts without RCCL connectivity and for tests.
+ * All collectives are enqueued on the context's stream. */
+#define TMVB_UNIQUE_ID_BYTES 128
+#define TMVB_F32 0
+#define TMVB_F64 1
+int tmvb_comm_unique_id(void* id_out /* TMVB_UNIQUE_ID_BYTES */);
+int tmvb_comm_create_rccl(tmvb_ctx* ctx, const void* unique_id, int32_t nranks, int32_t rank, tmvb_comm** out);
+int tmvb_comm_create_rccl_all(tmvb_ctx* const* ctxs, int32_t n, tmvb_comm** out /* [n] */);
+/* sum-all-reduce `count` elements of `dtype` (TMVB_F32 / TMVB_F64) in place in host_buf across the ranks; 0 = success */
+typedef int (*tmvb_host_allreduce_fn)(void* user, void* host_buf, int64_t count, int32_t dtype);
+int tmvb_comm_create_host(tmvb_ctx* ctx, int32_t nranks, int32_t rank, tmvb_host_allreduce_fn fn, void* user, tmvb_comm** out);
+int tmvb_comm_destroy(tmvb_comm* comm);
+/* backend: 0 = RCCL, 1 = host callback */
+int tmvb_comm_info(const tmvb_comm* comm, int32_t* nranks, int32_t* rank, int32_t* backend);
+/* In-place sum-all-reduce of device memory on the communicator's context stream (asynchronous for RCCL). */
+int tmvb_comm_allreduce(tmvb_comm* comm, void* dev_ptr, int64_t count, int32_t dtype);
+/* RCCL version code linked into the library (ncclGetVersion), 0 when it cannot be queried. */
+int tmvb_rccl_version(void);
 
 /* ---- corpus upload: the corpus half of update_buffer! (src/modelutils.jl:370-388, :438-472) ----
  * doc_ptr[M+1], terms[nnz], counts[nnz]; rdr_ptr/readers/ratings may be NULL when U == 0.
@@ -161,10 +195,22 @@ int tmvb_lda_update_elbo(tmvb_lda* h, double* elbo);
 
 /* train! (src/gpuLDA.jl:347-376 signature, src/LDA.jl:161-187 semantics incl. check_elbo!
  * src/modelutils.jl:574-585).  checkelbo <= 0 means Inf.  elbo_traj[iter] (may be NULL) receives the
- * ELBO per outer iteration (NaN where not evaluated).  Single-context only. */
+ * ELBO per outer iteration (NaN where not evaluated); *elbo_baseline (may be NULL) the ELBO evaluated before the first
+ * iteration (src/LDA.jl:167; the value the first printed delta refers to), or the stored model.elbo when it is not
+ * evaluated.  With a communicator attached (tmvb_lda_set_comm) this is the document-sharded train!: every rank calls it
+ * with the same arguments; one all-reduce of the packed statistics per iteration, and of the ELBO when it is checked,
+ * so all ranks stop at the same iteration. */
 int tmvb_lda_train(tmvb_lda* h, int32_t iter, double tol, int32_t niter, double ntol,
                    int32_t viter, double vtol, int32_t checkelbo,
-                   double* elbo_traj, int32_t* iters_done);
+                   double* elbo_traj, int32_t* iters_done, double* elbo_baseline);
+/* Attach (comm != NULL) or detach a communicator: the handle's corpus is this rank's document shard of a corpus of
+ * M_total documents.  Implies tmvb_lda_set_distributed.  The communicator is not owned by the handle. */
+int tmvb_lda_set_comm(tmvb_lda* h, tmvb_comm* comm, int64_t M_total);
+/* One host thread, n GPUs: hs[i] carries the i-th communicator of tmvb_comm_create_rccl_all (n = 1: same as
+ * tmvb_lda_train).  The n all-reduces of an iteration are issued as one RCCL group. */
+int tmvb_lda_train_group(tmvb_lda* const* hs, int32_t n, int32_t iter, double tol, int32_t niter, double ntol,
+                         int32_t viter, double vtol, int32_t checkelbo,
+                         double* elbo_traj, int32_t* iters_done, double* elbo_baseline);
 
 /* Diagnostics: histogram of sweeps per document of the last E-step (hist[0..viter]). */
 int tmvb_lda_sweep_hist(tmvb_lda* h, int64_t* hist, int32_t nbins);
@@ -212,9 +258,14 @@ int tmvb_ctm_update_sigma(tmvb_ctm* h);
 int tmvb_ctm_update_mu(tmvb_ctm* h);
 /* update_elbo! (src/CTM.jl:89-98) on the device; sum over this context's documents. */
 int tmvb_ctm_update_elbo(tmvb_ctm* h, double* elbo);
-/* train! (src/gpuCTM.jl:487-519 signature, src/CTM.jl:185-213 semantics). */
+/* train! (src/gpuCTM.jl:487-519 signature, src/CTM.jl:185-213 semantics); elbo_baseline / communicator as for LDA. */
 int tmvb_ctm_train(tmvb_ctm* h, int32_t iter, double tol, int32_t niter, double ntol,
-                   int32_t viter, double vtol, int32_t checkelbo, double* elbo_traj, int32_t* iters_done);
+                   int32_t viter, double vtol, int32_t checkelbo, double* elbo_traj, int32_t* iters_done,
+                   double* elbo_baseline);
+int tmvb_ctm_set_comm(tmvb_ctm* h, tmvb_comm* comm, int64_t M_total);
+int tmvb_ctm_train_group(tmvb_ctm* const* hs, int32_t n, int32_t iter, double tol, int32_t niter, double ntol,
+                         int32_t viter, double vtol, int32_t checkelbo, double* elbo_traj, int32_t* iters_done,
+                         double* elbo_baseline);
 /* Diagnostics of the last E-step: sweeps-per-document histogram and total lambda-Newton steps. */
 int tmvb_ctm_sweep_hist(tmvb_ctm* h, int64_t* hist, int32_t nbins, int64_t* newton_steps);
 int tmvb_ctm_last_estep_ms(tmvb_ctm* h, float* ms);
@@ -231,6 +282,12 @@ int tmvb_ctpf_destroy(tmvb_ctpf* h);
 int tmvb_ctpf_set_state(tmvb_ctpf* h, const double* hyper, const double* alef, const double* he, const double* bet,
                         const double* vav, const double* dalet, const double* het, const double* gimel,
                         const double* zayin, const double* elbo);
+/* The *_old fields of update_buffer! (src/modelutils.jl:474-493): update_elbo! rebuilds phi / xi from them
+ * (src/CTPF.jl:239-240) and @gpu copies them (src/macros.jl:229-260), so a trained model that is uploaded again must
+ * bring them along or its baseline ELBO differs.  Call after tmvb_ctpf_set_state; NULL = leave unchanged. */
+int tmvb_ctpf_set_state_old(tmvb_ctpf* h, const double* alef_old, const double* he_old, const double* bet_old,
+                            const double* vav_old, const double* dalet_old, const double* het_old,
+                            const double* gimel_old, const double* zayin_old);
 /* update_host! (src/modelutils.jl:539-570) without phi / xi.  rates[8*K] = bet, vav, dalet, het, then their *_old. */
 int tmvb_ctpf_get_state(tmvb_ctpf* h, double* alef, double* alef_old, double* he, double* he_old, double* rates,
                         double* gimel, double* gimel_old, double* zayin, double* zayin_old, double* elbo);
@@ -251,9 +308,13 @@ int tmvb_ctpf_mstep(tmvb_ctpf* h);
  * context's documents) and the global (beta, eta) part separately for document-sharded hosts. */
 int tmvb_ctpf_update_elbo(tmvb_ctpf* h, double* elbo);
 int tmvb_ctpf_update_elbo_parts(tmvb_ctpf* h, double* doc_part, double* global_part);
-/* train! (src/gpuCTPF.jl:677-705 signature, src/CTPF.jl:344-376 semantics).  checkelbo <= 0 means Inf. */
+/* train! (src/gpuCTPF.jl:677-705 signature, src/CTPF.jl:344-376 semantics).  checkelbo <= 0 means Inf.
+ * elbo_baseline / communicator as for LDA (the per-document ELBO part is all-reduced, the global part added once). */
 int tmvb_ctpf_train(tmvb_ctpf* h, int32_t iter, double tol, int32_t viter, double vtol, int32_t checkelbo,
-                    double* elbo_traj, int32_t* iters_done);
+                    double* elbo_traj, int32_t* iters_done, double* elbo_baseline);
+int tmvb_ctpf_set_comm(tmvb_ctpf* h, tmvb_comm* comm);
+int tmvb_ctpf_train_group(tmvb_ctpf* const* hs, int32_t n, int32_t iter, double tol, int32_t viter, double vtol,
+                          int32_t checkelbo, double* elbo_traj, int32_t* iters_done, double* elbo_baseline);
 int tmvb_ctpf_sweep_hist(tmvb_ctpf* h, int64_t* hist, int32_t nbins);
 int tmvb_ctpf_last_estep_ms(tmvb_ctpf* h, float* ms);
 /* Recommendation post-processing at the end of train!(model::CTPF) (src/CTPF.jl:379-399; src/gpuCTPF.jl:711-731 runs the

@@ -13,7 +13,7 @@ def test_library_loads_and_exports_header_symbols(tmvb):
     assert len(syms) >= 20
     for s in syms:
         assert hasattr(L, s), f"libtmvb_hip.so does not export {s}"
-    assert tmvb.lib().tmvb_abi_version() == 1
+    assert tmvb.lib().tmvb_abi_version() == 2
 
 
 def test_no_cpu_fallback_without_device(tmvb):

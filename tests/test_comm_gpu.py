@@ -1,0 +1,241 @@
+"""
+The collective BEHIND the C ABI (include/tmvb.h "communicator", csrc/tmvb_comm.hip, csrc/tmvb_train.h): a host that only
+knows `train` gets the document-sharded run -- the all-reduce of the packed statistics happens inside libtmvb_hip.so.
+
+  * RCCL itself runs here on ONE GPU: ncclCommInitRank with nranks = 1 and ncclCommInitAll with one device (RCCL needs
+    one GPU per rank, the test box has one) -- the link, the unique-id plumbing, the stream ordering of
+    ncclAllReduce between reduce_docs and update_beta, and the group path of *_train_group;
+  * the world-size-2 flow (two processes, both shards on cuda:0) runs through the host transport
+    (tmvb_comm_create_host) with gloo carrying the sums: same library loop, same all-reduce call sites, only the
+    transport differs.  LDA K=50, LDA K=100 (config 3 of BASELINE.json, sharded), CTM, CTPF.
+"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _lda(tmvb, corpus, K, ctx=None):
+    gm = tmvb.gpuLDA(corpus, K, ctx=ctx)
+    gm.beta = np.asfortranarray(tmvb.dirichlet_rows(K, corpus.V, seed=3)); gm.beta_old = gm.beta.copy(order="F")
+    gm.update_buffer()
+    return gm
+
+
+def test_rccl_links_and_reports_a_version(tmvb):
+    assert tmvb.rccl_version() >= 20000          # 2.x
+
+
+def test_rccl_single_rank_allreduce_and_train(tmvb):
+    """ncclCommInitRank(nranks = 1): the all-reduce is the identity, so the sharded loop must reproduce the
+    single-context train! bit for bit."""
+    corpus = tmvb.syn_nsf(M=3000, V=2000, seed=21)
+    K = 50
+    ref = _lda(tmvb, corpus, K)
+    t_ref = ref.train(iter=4, tol=0.0, checkelbo=1, printelbo=False)
+
+    gm = _lda(tmvb, corpus, K)
+    comm = tmvb.Communicator.rccl(gm.ctx, tmvb.Communicator.unique_id(), 1, 0)
+    assert comm.info() == {"nranks": 1, "rank": 0, "backend": "rccl"}
+    gm.set_comm(comm, corpus.M)
+    t = gm.train(iter=4, tol=0.0, checkelbo=1, printelbo=False)
+    np.testing.assert_array_equal(t, t_ref)
+    np.testing.assert_array_equal(gm.beta, ref.beta)
+    np.testing.assert_array_equal(gm.alpha, ref.alpha)
+    np.testing.assert_array_equal(gm.gamma, ref.gamma)
+    assert gm.elbo_baseline == ref.elbo_baseline
+    # a bare all-reduce of the statistics buffer through the C ABI
+    ptr, n = gm.stats()
+    comm.allreduce(ptr, n)
+    gm.synchronize()
+    gm.set_comm(None, corpus.M)
+    comm.close()
+
+
+def test_rccl_init_all_group_train_one_device(tmvb):
+    """ncclCommInitAll over one device + tmvb_lda_train_group(n = 1): the one-host-thread entry point."""
+    import ctypes as C
+    corpus = tmvb.syn_nsf(M=2000, V=1500, seed=22)
+    K = 20
+    ref = _lda(tmvb, corpus, K)
+    t_ref = ref.train(iter=3, tol=0.0, checkelbo=1, printelbo=False)
+    gm = _lda(tmvb, corpus, K)
+    comm, = tmvb.Communicator.rccl_all([gm.ctx])
+    gm.set_comm(comm, corpus.M)
+    L = tmvb.lib()
+    traj = np.full(3, np.nan); done = C.c_int32(0); base = C.c_double(0.0)
+    hs = (C.c_void_p * 1)(gm.handle)
+    rc = L.tmvb_lda_train_group(hs, C.c_int32(1), C.c_int32(3), C.c_double(0.0), C.c_int32(1000), C.c_double(1.0 / K ** 2),
+                                C.c_int32(10), C.c_double(1.0 / K ** 2), C.c_int32(1), traj.ctypes.data_as(C.POINTER(C.c_double)),
+                                C.byref(done), C.byref(base))
+    assert rc == 0, L.tmvb_last_error()
+    assert done.value == 3
+    np.testing.assert_array_equal(traj, t_ref)
+    gm.set_comm(None, corpus.M)
+    comm.close()
+
+
+def test_sharded_handle_without_comm_is_refused(tmvb):
+    corpus = tmvb.syn_nsf(M=300, V=400, seed=23)
+    gm = _lda(tmvb, corpus, 8)
+    gm.set_distributed(2 * corpus.M, True)
+    with pytest.raises(ValueError, match="communicator"):
+        gm.train(iter=1, printelbo=False)
+
+
+def test_host_callback_failure_maps_to_erccl(tmvb):
+    corpus = tmvb.syn_nsf(M=300, V=400, seed=24)
+    gm = _lda(tmvb, corpus, 8)
+
+    def boom(a):
+        raise RuntimeError("transport down")
+    comm = tmvb.Communicator.host(gm.ctx, 2, 0, boom)
+    gm.set_comm(comm, 2 * corpus.M)
+    with pytest.raises(tmvb.EngineError, match="callback"):
+        gm.train(iter=1, printelbo=False)
+    gm.set_comm(None, corpus.M)
+    comm.close()
+
+
+# ------------------------------------------------------------------------------------------ world size 2, one GPU
+def _gloo_sum(dist):
+    import torch
+
+    def fn(a):
+        t = torch.from_numpy(a)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return fn
+
+
+def _worker(rank, world, initfile, out_dir, model, K, iters):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import tmvb_amd
+    dist.init_process_group("gloo", init_method=f"file://{initfile}", rank=rank, world_size=world)
+    tm = tmvb_amd.pkg
+    ctx = tm.DeviceContext(0)
+    comm = tm.Communicator.host(ctx, world, rank, _gloo_sum(dist))
+    out = {}
+    if model == "lda":
+        corpus = tm.syn_nsf(M=5000, V=3000, seed=11)
+        d0, d1 = corpus.shard_bounds(world)[rank]
+        gm = tm.gpuLDA(corpus.shard(d0, d1), K, ctx=ctx)
+        gm.beta = np.asfortranarray(tm.dirichlet_rows(K, corpus.V, seed=3)); gm.beta_old = gm.beta.copy(order="F")
+        gm.update_buffer()
+        gm.set_comm(comm, corpus.M)
+        traj = gm.train(iter=iters, tol=0.0, checkelbo=1, printelbo=False)
+        out = dict(alpha=gm.alpha, beta=gm.beta, gamma=gm.gamma, base=gm.elbo_baseline)
+    elif model == "ctm":
+        corpus = tm.syn_nsf(M=1200, V=500, seed=12)
+        d0, d1 = corpus.shard_bounds(world)[rank]
+        gm = tm.gpuCTM(corpus.shard(d0, d1), K, ctx=ctx)
+        gm.beta = np.asfortranarray(tm.dirichlet_rows(K, corpus.V, seed=3)); gm.beta_old = gm.beta.copy(order="F")
+        gm.update_buffer()
+        gm.set_comm(comm, corpus.M)
+        traj = gm.train(iter=iters, tol=0.0, checkelbo=1, printelbo=False)
+        out = dict(mu=gm.mu, sigma=gm.sigma, beta=gm.beta, lam=gm.lam, base=gm.elbo_baseline)
+    else:
+        corpus = tm.syn_citeu(M=900, V=700, U=120, seed=13)
+        d0, d1 = corpus.shard_bounds(world)[rank]
+        gm = tm.gpuCTPF(corpus.shard(d0, d1), K, ctx=ctx)
+        gm.alef = np.asfortranarray(np.exp(tm.dirichlet_rows(K, corpus.V, seed=4) - 0.5)); gm.alef_old = gm.alef.copy(order="F")
+        gm.update_buffer()
+        gm.set_comm(comm)
+        traj = gm.train(iter=iters, tol=0.0, checkelbo=1, printelbo=False, recs=False)
+        out = dict(alef=gm.alef, he=gm.he, bet=gm.bet, vav=gm.vav, dalet=gm.dalet, het=gm.het, gimel=gm.gimel, base=gm.elbo_baseline)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), traj=np.array(traj), d0=d0, d1=d1, **out)
+    gm.close(); comm.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(model, K, iters):
+    import torch.multiprocessing as mp
+    world = 2
+    with tempfile.TemporaryDirectory() as td:
+        mp.spawn(_worker, args=(world, os.path.join(td, "init"), td, model, K, iters), nprocs=world, join=True)
+        return [dict(np.load(os.path.join(td, f"rank{r}.npz"))) for r in range(world)]
+
+
+@pytest.mark.parametrize("K", [50, 100])
+def test_in_library_sharded_lda_world2(tmvb, K):
+    """K = 100 is BASELINE.json's config 3 (LDA K=100, document-sharded) at test size."""
+    iters = 5
+    res = _run("lda", K, iters)
+    corpus = tmvb.syn_nsf(M=5000, V=3000, seed=11)
+    gm = _lda(tmvb, corpus, K)
+    traj = gm.train(iter=iters, tol=0.0, checkelbo=1, printelbo=False)
+    assert np.array_equal(res[0]["alpha"], res[1]["alpha"]) and np.array_equal(res[0]["beta"], res[1]["beta"])
+    assert np.array_equal(res[0]["traj"], res[1]["traj"])            # the same stop decision on every rank
+    for r in res:
+        assert len(r["traj"]) == iters
+        np.testing.assert_allclose(r["traj"], np.array(traj), rtol=2e-6)
+        np.testing.assert_allclose(float(r["base"]), gm.elbo_baseline, rtol=1e-9)
+        np.testing.assert_allclose(r["alpha"], gm.alpha, rtol=2e-4)
+        big = gm.beta > 1e-6
+        np.testing.assert_allclose(r["beta"][big], gm.beta[big], rtol=2e-3)
+        g = gm.gamma[:, int(r["d0"]):int(r["d1"])]
+        assert np.quantile(np.abs(r["gamma"] - g) / np.maximum(np.abs(g), 1e-3), 0.999) < 5e-3
+    assert int(res[0]["d1"]) == int(res[1]["d0"]) and int(res[1]["d1"]) == corpus.M
+
+
+def test_in_library_sharded_ctm_world2(tmvb):
+    K, iters = 12, 4
+    res = _run("ctm", K, iters)
+    corpus = tmvb.syn_nsf(M=1200, V=500, seed=12)
+    gm = tmvb.gpuCTM(corpus, K)
+    gm.beta = np.asfortranarray(tmvb.dirichlet_rows(K, corpus.V, seed=3)); gm.beta_old = gm.beta.copy(order="F")
+    gm.update_buffer()
+    traj = gm.train(iter=iters, tol=0.0, checkelbo=1, printelbo=False)
+    assert np.array_equal(res[0]["mu"], res[1]["mu"]) and np.array_equal(res[0]["sigma"], res[1]["sigma"]) and np.array_equal(res[0]["beta"], res[1]["beta"])
+    for r in res:
+        np.testing.assert_allclose(r["traj"], np.array(traj), rtol=5e-6)
+        np.testing.assert_allclose(r["mu"], gm.mu, atol=2e-4)
+        np.testing.assert_allclose(r["sigma"], gm.sigma, atol=5e-4 * max(1.0, np.abs(gm.sigma).max()))
+        lam = gm.lam[:, int(r["d0"]):int(r["d1"])]
+        assert np.quantile(np.abs(r["lam"] - lam), 0.999) < 5e-3 * max(1.0, np.abs(lam).max())
+
+
+def test_in_library_sharded_ctpf_world2(tmvb):
+    K, iters = 20, 4
+    res = _run("ctpf", K, iters)
+    corpus = tmvb.syn_citeu(M=900, V=700, U=120, seed=13)
+    gm = tmvb.gpuCTPF(corpus, K)
+    gm.alef = np.asfortranarray(np.exp(tmvb.dirichlet_rows(K, corpus.V, seed=4) - 0.5)); gm.alef_old = gm.alef.copy(order="F")
+    gm.update_buffer()
+    traj = gm.train(iter=iters, tol=0.0, checkelbo=1, printelbo=False, recs=False)
+    for n in ("alef", "he", "bet", "vav", "dalet", "het"):
+        assert np.array_equal(res[0][n], res[1][n]), n
+    for r in res:
+        np.testing.assert_allclose(r["traj"], np.array(traj), rtol=5e-6)
+        np.testing.assert_allclose(r["alef"], gm.alef, rtol=2e-3)
+        for n in ("bet", "vav", "dalet", "het"):
+            np.testing.assert_allclose(r[n], getattr(gm, n), rtol=2e-4)
+        g = gm.gimel[:, int(r["d0"]):int(r["d1"])]
+        assert np.quantile(np.abs(r["gimel"] - g) / np.abs(g), 0.999) < 5e-3
+
+
+def test_ctpf_train_twice_equals_one_run(tmvb):
+    """the *_old fields travel with update_buffer (tmvb_ctpf_set_state_old), so a second train() on a trained
+    model starts from the same baseline ELBO as the uninterrupted run."""
+    corpus = tmvb.syn_citeu(M=400, V=300, U=60, seed=31)
+    K = 10
+    alef0 = np.asfortranarray(np.exp(tmvb.dirichlet_rows(K, corpus.V, seed=4) - 0.5))
+
+    def fresh():
+        m = tmvb.gpuCTPF(corpus, K)
+        m.alef = alef0.copy(order="F"); m.alef_old = alef0.copy(order="F"); m.update_buffer()
+        return m
+    one = fresh()
+    t_one = one.train(iter=6, tol=0.0, checkelbo=1, printelbo=False, recs=False)
+    two = fresh()
+    t_a = two.train(iter=3, tol=0.0, checkelbo=1, printelbo=False, recs=False)
+    t_b = two.train(iter=3, tol=0.0, checkelbo=1, printelbo=False, recs=False)
+    # the second call's baseline is the ELBO the first call ended on (fp32 state went through fp64 host arrays: exact)
+    np.testing.assert_allclose(two.elbo_baseline, t_a[-1], rtol=1e-10)
+    np.testing.assert_allclose(np.concatenate([t_a, t_b]), t_one, rtol=1e-6)   # host-side log(rate) vs device, 1 ulp in fp32

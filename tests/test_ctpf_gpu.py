@@ -21,7 +21,7 @@ def make_pair(tmvb, oracle, g):
     K, V, U = int(g["K"]), int(g["V"]), int(g["U"])
     pc = tmvb.PackedCorpus(g["doc_ptr"], g["terms"], g["counts"], V, g["rdr_ptr"], g["readers"], g["ratings"], U)
     gm = tmvb.gpuCTPF(pc, K)
-    gm.alef = np.asfortranarray(g["alef0"]); gm.update_buffer()
+    gm.alef = np.asfortranarray(g["alef0"]); gm.alef_old = gm.alef.copy(order="F"); gm.update_buffer()
     om = oracle.CTPF(oracle.CSR(g["doc_ptr"], g["terms"], g["counts"], V, g["rdr_ptr"], g["readers"], g["ratings"], U), K, g["alef0"])
     return gm, om
 

@@ -138,7 +138,7 @@ def test_sharded_ctpf_world2_matches_single_context(tmvb):
     corpus = tmvb.syn_citeu(M=900, V=700, U=120, seed=13)
     K = 20
     gm = tmvb.gpuCTPF(corpus, K)
-    gm.alef = np.asfortranarray(np.exp(tmvb.dirichlet_rows(K, corpus.V, seed=4) - 0.5)); gm.update_buffer()
+    gm.alef = np.asfortranarray(np.exp(tmvb.dirichlet_rows(K, corpus.V, seed=4) - 0.5)); gm.alef_old = gm.alef.copy(order="F"); gm.update_buffer()
     traj = gm.train(iter=iters, tol=0.0, checkelbo=1, printelbo=False, recs=False)
     for n in ("alef", "he", "bet", "vav", "dalet", "het"):
         assert np.array_equal(res[0][n], res[1][n]), n                  # identical M-step on every rank

@@ -102,7 +102,7 @@ def test_ctpf_random_shapes(tmvb, oracle, seed):
     alef0 = np.exp(tmvb.dirichlet_rows(K, V, seed=seed) - 0.5)
     pc = tmvb.PackedCorpus(c["doc_ptr"], c["terms"], c["counts"], V, c["rdr_ptr"], c["readers"], c["ratings"], U)
     gm = tmvb.gpuCTPF(pc, K)
-    gm.alef = np.asfortranarray(alef0); gm.update_buffer()
+    gm.alef = np.asfortranarray(alef0); gm.alef_old = gm.alef.copy(order="F"); gm.update_buffer()
     om = oracle.CTPF(oracle.CSR(c["doc_ptr"], c["terms"], c["counts"], V, c["rdr_ptr"], c["readers"], c["ratings"], U), K, alef0)
     for it in range(2):
         for n in ("alef", "he", "bet", "vav", "dalet", "het", "gimel", "zayin"):

@@ -14,9 +14,9 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "libtmvb_hip.so")
-SOURCES = ["tmvb_core.hip", "tmvb_lda.hip", "tmvb_ctm.hip", "tmvb_ctpf.hip", "tmvb_ctpf_recs.hip"]
+SOURCES = ["tmvb_core.hip", "tmvb_comm.hip", "tmvb_lda.hip", "tmvb_ctm.hip", "tmvb_ctpf.hip", "tmvb_ctpf_recs.hip"]
 
-OK, EINVAL, ESHAPE, ECORPUS, ENOMEM, EHIP, ENONFINITE, ENODEVICE = range(8)
+OK, EINVAL, ESHAPE, ECORPUS, ENOMEM, EHIP, ENONFINITE, ENODEVICE, ERCCL = range(9)
 
 
 class TopicModelError(Exception):
@@ -77,7 +77,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for cmd, pr in procs:
         if pr.wait() != 0:
             raise subprocess.CalledProcessError(pr.returncode, cmd)
-    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH] + objs
+    rocm_lib = os.path.join(os.path.dirname(os.path.dirname(hipcc)), "lib")
+    # RCCL carries the document-sharded all-reduce (tmvb_comm.hip)
+    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH] + objs + ["-L" + rocm_lib, "-lrccl", "-Wl,-rpath," + rocm_lib]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

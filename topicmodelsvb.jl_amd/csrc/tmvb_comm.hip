@@ -1,0 +1,173 @@
+// tmvb_comm.hip -- the collective of the document-sharded runs, behind the C ABI.
+//
+// The reference is single-device (one OpenCL queue, src/gpuLDA.jl:64); its only multi-batch precedent is the v0.6
+// `newbeta +=` accumulation (v0.6/src/gpuLDA.jl:200-225).  Here documents shard across the GPUs of one node and the one
+// exchange per outer iteration is a sum-all-reduce of the packed sufficient statistics.
+// Backends: RCCL (ncclCommInitRank with a host-broadcast unique id for one process per GPU, ncclCommInitAll for one host
+// thread driving n GPUs) and a host-callback transport that stages the buffer through pinned memory (MPI / gloo hosts,
+// single-GPU tests).  Host code only; no kernels.
+#include "tmvb_internal.h"
+
+#include <rccl/rccl.h>
+
+#include <cstring>
+
+struct tmvb_comm {
+    tmvb_ctx* ctx = nullptr;
+    int nranks = 1, rank = 0;
+    int backend = 0;                      // 0 = RCCL, 1 = host callback
+    ncclComm_t nccl = nullptr;
+    tmvb_host_allreduce_fn fn = nullptr;
+    void* user = nullptr;
+    void* pinned = nullptr;               // host staging buffer (backend 1)
+    size_t pinned_bytes = 0;
+};
+
+#define TMVB_NCCL(call)                                                                         \
+    do {                                                                                        \
+        ncclResult_t r_ = (call);                                                               \
+        if (r_ != ncclSuccess) {                                                                \
+            tmvb_set_error("%s failed: %s (%s:%d)", #call, ncclGetErrorString(r_), __FILE__,    \
+                           __LINE__);                                                           \
+            return TMVB_ERCCL;                                                                  \
+        }                                                                                       \
+    } while (0)
+
+extern "C" int tmvb_rccl_version(void)
+{
+    int v = 0;
+    if (ncclGetVersion(&v) != ncclSuccess) return 0;
+    return v;
+}
+
+extern "C" int tmvb_comm_unique_id(void* id_out)
+{
+    TMVB_REQUIRE(id_out != nullptr, TMVB_EINVAL, "tmvb_comm_unique_id: id_out is NULL");
+    static_assert(sizeof(ncclUniqueId) == TMVB_UNIQUE_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId id;
+    TMVB_NCCL(ncclGetUniqueId(&id));
+    memcpy(id_out, &id, sizeof(id));
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_comm_create_rccl(tmvb_ctx* ctx, const void* unique_id, int32_t nranks, int32_t rank, tmvb_comm** out)
+{
+    TMVB_REQUIRE(out != nullptr, TMVB_EINVAL, "tmvb_comm_create_rccl: out is NULL");
+    *out = nullptr;
+    TMVB_REQUIRE(ctx && unique_id, TMVB_EINVAL, "tmvb_comm_create_rccl: NULL context or unique id");
+    TMVB_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, TMVB_EINVAL, "tmvb_comm_create_rccl: rank %d not in [0,%d)", rank, nranks);
+    TMVB_HIP(hipSetDevice(ctx->device));
+    ncclUniqueId id;
+    memcpy(&id, unique_id, sizeof(id));
+    ncclComm_t c = nullptr;
+    TMVB_NCCL(ncclCommInitRank(&c, nranks, id, rank));
+    tmvb_comm* h = new tmvb_comm();
+    h->ctx = ctx; h->nranks = nranks; h->rank = rank; h->backend = 0; h->nccl = c;
+    *out = h;
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_comm_create_rccl_all(tmvb_ctx* const* ctxs, int32_t n, tmvb_comm** out)
+{
+    TMVB_REQUIRE(ctxs && out && n >= 1, TMVB_EINVAL, "tmvb_comm_create_rccl_all: bad argument");
+    std::vector<int> devs(n);
+    for (int i = 0; i < n; ++i) {
+        TMVB_REQUIRE(ctxs[i] != nullptr, TMVB_EINVAL, "tmvb_comm_create_rccl_all: context %d is NULL", i);
+        devs[i] = ctxs[i]->device;
+        for (int j = 0; j < i; ++j)
+            TMVB_REQUIRE(devs[j] != devs[i], TMVB_EINVAL, "tmvb_comm_create_rccl_all: device %d appears twice (one rank per GPU)", devs[i]);
+        out[i] = nullptr;
+    }
+    std::vector<ncclComm_t> comms(n, nullptr);
+    TMVB_NCCL(ncclCommInitAll(comms.data(), n, devs.data()));
+    for (int i = 0; i < n; ++i) {
+        tmvb_comm* h = new tmvb_comm();
+        h->ctx = ctxs[i]; h->nranks = n; h->rank = i; h->backend = 0; h->nccl = comms[i];
+        out[i] = h;
+    }
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_comm_create_host(tmvb_ctx* ctx, int32_t nranks, int32_t rank, tmvb_host_allreduce_fn fn, void* user, tmvb_comm** out)
+{
+    TMVB_REQUIRE(out != nullptr, TMVB_EINVAL, "tmvb_comm_create_host: out is NULL");
+    *out = nullptr;
+    TMVB_REQUIRE(ctx && fn, TMVB_EINVAL, "tmvb_comm_create_host: NULL context or callback");
+    TMVB_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, TMVB_EINVAL, "tmvb_comm_create_host: rank %d not in [0,%d)", rank, nranks);
+    tmvb_comm* h = new tmvb_comm();
+    h->ctx = ctx; h->nranks = nranks; h->rank = rank; h->backend = 1; h->fn = fn; h->user = user;
+    *out = h;
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_comm_destroy(tmvb_comm* c)
+{
+    if (!c) return TMVB_OK;
+    if (c->ctx) (void)hipSetDevice(c->ctx->device);
+    if (c->nccl) (void)ncclCommDestroy(c->nccl);
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    delete c;
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_comm_info(const tmvb_comm* c, int32_t* nranks, int32_t* rank, int32_t* backend)
+{
+    TMVB_REQUIRE(c != nullptr, TMVB_EINVAL, "tmvb_comm_info: comm is NULL");
+    if (nranks) *nranks = c->nranks;
+    if (rank) *rank = c->rank;
+    if (backend) *backend = c->backend;
+    return TMVB_OK;
+}
+
+static int comm_allreduce_one(tmvb_comm* c, void* dev_ptr, int64_t count, int32_t dtype)
+{
+    TMVB_REQUIRE(c && dev_ptr, TMVB_EINVAL, "tmvb_comm_allreduce: NULL argument");
+    TMVB_REQUIRE(count >= 0 && (dtype == TMVB_F32 || dtype == TMVB_F64), TMVB_EINVAL, "tmvb_comm_allreduce: bad count or dtype");
+    if (count == 0) return TMVB_OK;
+    tmvb_ctx* ctx = c->ctx;
+    TMVB_HIP(hipSetDevice(ctx->device));
+    if (c->backend == 0) {
+        TMVB_NCCL(ncclAllReduce(dev_ptr, dev_ptr, (size_t)count, dtype == TMVB_F32 ? ncclFloat32 : ncclFloat64, ncclSum, c->nccl, ctx->stream));
+        return TMVB_OK;
+    }
+    const size_t bytes = (size_t)count * (dtype == TMVB_F32 ? 4 : 8);
+    if (bytes > c->pinned_bytes) {
+        if (c->pinned) (void)hipHostFree(c->pinned);
+        c->pinned = nullptr; c->pinned_bytes = 0;
+        hipError_t e = hipHostMalloc(&c->pinned, bytes, hipHostMallocDefault);
+        if (e != hipSuccess) { tmvb_set_error("hipHostMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e)); return TMVB_ENOMEM; }
+        c->pinned_bytes = bytes;
+    }
+    TMVB_HIP(hipMemcpyAsync(c->pinned, dev_ptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    TMVB_HIP(hipStreamSynchronize(ctx->stream));
+    const int rc = c->fn(c->user, c->pinned, count, dtype);
+    TMVB_REQUIRE(rc == 0, TMVB_ERCCL, "tmvb_comm_allreduce: the host all-reduce callback returned %d", rc);
+    TMVB_HIP(hipMemcpyAsync(dev_ptr, c->pinned, bytes, hipMemcpyHostToDevice, ctx->stream));
+    TMVB_HIP(hipStreamSynchronize(ctx->stream));     // the staging buffer is reused by the next call
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_comm_allreduce(tmvb_comm* c, void* dev_ptr, int64_t count, int32_t dtype)
+{
+    return comm_allreduce_one(c, dev_ptr, count, dtype);
+}
+
+// n collectives issued by ONE host thread (ncclCommInitAll communicators): they must sit inside one RCCL group,
+// otherwise the first call blocks waiting for peers that this same thread has not launched yet.
+int tmvb_comm_allreduce_group(tmvb_comm* const* comms, void* const* dev_ptrs, const int64_t* counts, int n, int32_t dtype)
+{
+    if (n == 1) return comm_allreduce_one(comms[0], dev_ptrs[0], counts[0], dtype);
+    bool all_rccl = true;
+    for (int i = 0; i < n; ++i) {
+        TMVB_REQUIRE(comms[i] != nullptr, TMVB_EINVAL, "grouped all-reduce: handle %d has no communicator", i);
+        all_rccl = all_rccl && comms[i]->backend == 0;
+    }
+    TMVB_REQUIRE(all_rccl, TMVB_EINVAL, "grouped all-reduce over several local handles needs RCCL communicators (tmvb_comm_create_rccl_all)");
+    TMVB_NCCL(ncclGroupStart());
+    int rc = TMVB_OK;
+    for (int i = 0; i < n && rc == TMVB_OK; ++i) rc = comm_allreduce_one(comms[i], dev_ptrs[i], counts[i], dtype);
+    ncclResult_t r = ncclGroupEnd();
+    if (rc) return rc;
+    if (r != ncclSuccess) { tmvb_set_error("ncclGroupEnd failed: %s", ncclGetErrorString(r)); return TMVB_ERCCL; }
+    return TMVB_OK;
+}

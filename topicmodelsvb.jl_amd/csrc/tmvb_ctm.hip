@@ -25,6 +25,7 @@
 // (v_mfma_f32_32x32x2_f32); sigma assembly, its inverse and log-determinant run in fp64 in one
 // workgroup.
 #include "tmvb_common_kernels.h"
+#include "tmvb_train.h"
 
 #include <utility>
 
@@ -524,6 +525,7 @@ struct tmvb_ctm {
     int K = 0, KP = 0;
     int64_t M = 0, V = 0, M_total = 0;
     bool distributed = false;
+    tmvb_comm* comm = nullptr;         // document-sharded train!: the all-reduce of the packed statistics (not owned)
     float* d_beta[2] = {nullptr, nullptr};
     int cur = 0;
     float* d_stats = nullptr;          // S (K*V) | sum_lambda (K) | sum_vsq (K) | scatter (K*K)
@@ -923,42 +925,61 @@ extern "C" int tmvb_ctm_update_elbo(tmvb_ctm* h, double* elbo)
     return TMVB_OK;
 }
 
-extern "C" int tmvb_ctm_train(tmvb_ctm* h, int32_t iter, double tol, int32_t niter, double ntol, int32_t viter,
-                              double vtol, int32_t checkelbo, double* elbo_traj, int32_t* iters_done)
+extern "C" int tmvb_ctm_set_comm(tmvb_ctm* h, tmvb_comm* comm, int64_t M_total)
 {
-    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_ctm_train: handle is NULL");
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_ctm_set_comm: handle is NULL");
+    int rc = tmvb_ctm_set_distributed(h, comm ? M_total : h->M, comm != nullptr);
+    if (rc) return rc;
+    h->comm = comm;
+    return TMVB_OK;
+}
+
+namespace {
+struct CtmTrainOps {
+    int niter, viter; double ntol, vtol;
+    int estep(tmvb_ctm* h) { return tmvb_ctm_estep(h, niter, ntol, viter, vtol); }     // src/CTM.jl:194-205
+    int reduce(tmvb_ctm* h) { return tmvb_ctm_reduce_docs(h); }
+    int before_allreduce(tmvb_ctm*) { return TMVB_OK; }
+    float* stats(tmvb_ctm* h) { return h->d_stats; }
+    int64_t stats_len(tmvb_ctm* h) { return h->stats_len(); }
+    int mstep(tmvb_ctm* h)
+    {
+        int rc = tmvb_ctm_update_beta(h);                                              // :206
+        if (!rc) rc = tmvb_ctm_update_sigma(h);                                        // :207 (previous mu, quirk Q2)
+        if (!rc) rc = tmvb_ctm_update_mu(h);                                           // :208
+        return rc;
+    }
+    int elbo_local(tmvb_ctm* h, double* s, double* once) { *once = 0.0; return tmvb_ctm_update_elbo(h, s); }
+    double* elbo_dev(tmvb_ctm* h) { return h->d_elbo; }
+    tmvb_comm* comm(tmvb_ctm* h) { return h->comm; }
+    bool distributed(tmvb_ctm* h) { return h->distributed; }
+    tmvb_ctx* ctx(tmvb_ctm* h) { return h->ctx; }
+    int64_t nnz(tmvb_ctm* h) { return h->corp->info.nnz; }
+    void set_elbo(tmvb_ctm* h, double v) { h->elbo = v; }
+    double get_elbo(tmvb_ctm* h) { return h->elbo; }
+    int finish(tmvb_ctm* h)
+    {
+        TMVB_HIP(hipSetDevice(h->ctx->device));
+        TMVB_HIP(hipStreamSynchronize(h->ctx->stream));
+        return TMVB_OK;
+    }
+};
+}  // namespace
+
+extern "C" int tmvb_ctm_train_group(tmvb_ctm* const* hs, int32_t n, int32_t iter, double tol, int32_t niter, double ntol, int32_t viter,
+                                    double vtol, int32_t checkelbo, double* elbo_traj, int32_t* iters_done, double* elbo_baseline)
+{
     TMVB_REQUIRE(tol >= 0 && ntol >= 0 && vtol >= 0, TMVB_EINVAL, "tolerance parameters must be nonnegative.");   // src/gpuCTM.jl:489
     TMVB_REQUIRE(iter >= 0 && niter >= 0 && viter >= 0, TMVB_EINVAL, "iteration parameters must be nonnegative."); // :490
-    TMVB_REQUIRE(!h->distributed, TMVB_EINVAL, "tmvb_ctm_train drives one context; a document-sharded host composes the operators itself");
-    if (iters_done) *iters_done = 0;
-    if (h->corp->info.nnz == 0) iter = 0;
-    int rc;
-    double e_old = h->elbo;
-    if (checkelbo > 0 && checkelbo <= iter) {
-        if ((rc = tmvb_ctm_update_elbo(h, &e_old))) return rc;
-    }
-    int done = 0;
-    for (int k = 1; k <= iter; ++k) {
-        ++done;
-        if ((rc = tmvb_ctm_estep(h, niter, ntol, viter, vtol))) return rc;      // src/CTM.jl:194-205
-        if ((rc = tmvb_ctm_reduce_docs(h))) return rc;
-        if ((rc = tmvb_ctm_update_beta(h))) return rc;                          // :206
-        if ((rc = tmvb_ctm_update_sigma(h))) return rc;                         // :207 (previous mu)
-        if ((rc = tmvb_ctm_update_mu(h))) return rc;                            // :208
-        if (elbo_traj) elbo_traj[k - 1] = NAN;
-        if (checkelbo > 0 && (k % checkelbo) == 0) {
-            double e_new;
-            if ((rc = tmvb_ctm_update_elbo(h, &e_new))) return rc;
-            TMVB_REQUIRE(std::isfinite(e_new), TMVB_ENONFINITE, "elbo must be finite.");
-            if (elbo_traj) elbo_traj[k - 1] = e_new;
-            double delta = e_new - e_old;
-            e_old = e_new;
-            if (delta < tol) break;
-        }
-    }
-    TMVB_HIP(hipStreamSynchronize(h->ctx->stream));
-    if (iters_done) *iters_done = done;
-    return TMVB_OK;
+    CtmTrainOps ops{niter, viter, ntol, vtol};
+    return tmvb_train_group_loop("tmvb_ctm_train", hs, n, iter, tol, checkelbo, elbo_traj, iters_done, elbo_baseline, ops);
+}
+
+extern "C" int tmvb_ctm_train(tmvb_ctm* h, int32_t iter, double tol, int32_t niter, double ntol, int32_t viter,
+                              double vtol, int32_t checkelbo, double* elbo_traj, int32_t* iters_done, double* elbo_baseline)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_ctm_train: handle is NULL");
+    return tmvb_ctm_train_group(&h, 1, iter, tol, niter, ntol, viter, vtol, checkelbo, elbo_traj, iters_done, elbo_baseline);
 }
 
 extern "C" int tmvb_ctm_sweep_hist(tmvb_ctm* h, int64_t* hist, int32_t nbins, int64_t* newton_steps)

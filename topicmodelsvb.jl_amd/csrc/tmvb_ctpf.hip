@@ -18,6 +18,7 @@
 // The scatters update_alef!(d) / update_he!(d) are gather-side statistics passes over the term and
 // the reader inverted indices (tmvb_termstats.h); HBM-bound like LDA.
 #include "tmvb_common_kernels.h"
+#include "tmvb_train.h"
 #include "tmvb_regtile.h"
 
 struct CtpfParams {
@@ -513,6 +514,7 @@ struct tmvb_ctpf {
     int K = 0, KP = 0, nslot = 1;
     int64_t M = 0, V = 0, U = 0;
     bool distributed = false;
+    tmvb_comm* comm = nullptr;          // document-sharded train!: the all-reduce of the packed statistics (not owned)
     double hyper[8] = {0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1};   // a..h, src/CTPF.jl:81
     float* d_alef = nullptr; float* d_alef_old = nullptr;          // [V][K] dense
     float* d_he = nullptr; float* d_he_old = nullptr;              // [U][K] dense
@@ -703,6 +705,46 @@ extern "C" int tmvb_ctpf_set_state(tmvb_ctpf* h, const double* hyper, const doub
     }
     if (elbo) h->elbo = *elbo;
     if (alef || he) { if ((rc = ctpf_refresh_tables(h))) return rc; }
+    TMVB_HIP(hipStreamSynchronize(ctx->stream));
+    return TMVB_OK;
+}
+
+// The *_old fields of update_buffer! (src/modelutils.jl:474-493).  update_elbo! rebuilds phi / xi from them
+// (src/CTPF.jl:239-240), so a model that is uploaded again after training must bring them along: tmvb_ctpf_set_state sets
+// every *_old equal to the current value (the constructor state), this call overrides them.  NULL = leave unchanged.
+extern "C" int tmvb_ctpf_set_state_old(tmvb_ctpf* h, const double* alef_old, const double* he_old, const double* bet_old,
+                                       const double* vav_old, const double* dalet_old, const double* het_old,
+                                       const double* gimel_old, const double* zayin_old)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_ctpf_set_state_old: handle is NULL");
+    tmvb_ctx* ctx = h->ctx;
+    TMVB_HIP(hipSetDevice(ctx->device));
+    const size_t K = h->K, KM = K * (size_t)h->M, KV = K * (size_t)h->V, KU = K * (size_t)h->U;
+    int rc;
+    if (alef_old) {
+        TMVB_REQUIRE(positive_finite(alef_old, KV), TMVB_ENONFINITE, "alef_old must be positive.");
+        if ((rc = upload_f32(ctx, h->d_alef_old, alef_old, KV))) return rc;
+    }
+    if (he_old) {
+        TMVB_REQUIRE(positive_finite(he_old, KU), TMVB_ENONFINITE, "he_old must be positive.");
+        if ((rc = upload_f32(ctx, h->d_he_old, he_old, KU))) return rc;
+    }
+    const double* rv[4] = {bet_old, vav_old, dalet_old, het_old};
+    const char* rn[4] = {"bet_old", "vav_old", "dalet_old", "het_old"};
+    for (int r = 0; r < 4; ++r) {
+        if (!rv[r]) continue;
+        TMVB_REQUIRE(positive_finite(rv[r], K), TMVB_ENONFINITE, "%s must be positive.", rn[r]);
+        TMVB_HIP(hipMemcpyAsync(h->d_rates + (4 + r) * K, rv[r], K * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        TMVB_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    if (gimel_old) {
+        TMVB_REQUIRE(positive_finite(gimel_old, KM), TMVB_ENONFINITE, "gimel_old must be positive.");
+        if ((rc = upload_f32(ctx, h->d_gimel_old, gimel_old, KM))) return rc;
+    }
+    if (zayin_old) {
+        TMVB_REQUIRE(positive_finite(zayin_old, KM), TMVB_ENONFINITE, "zayin_old must be positive.");
+        if ((rc = upload_f32(ctx, h->d_zayin_old, zayin_old, KM))) return rc;
+    }
     TMVB_HIP(hipStreamSynchronize(ctx->stream));
     return TMVB_OK;
 }
@@ -932,37 +974,56 @@ extern "C" int tmvb_ctpf_update_elbo(tmvb_ctpf* h, double* elbo)
 }
 
 // train! (src/gpuCTPF.jl:677-705 signature, src/CTPF.jl:344-376 semantics incl. check_elbo!).  checkelbo <= 0 means Inf.
+extern "C" int tmvb_ctpf_set_comm(tmvb_ctpf* h, tmvb_comm* comm)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_ctpf_set_comm: handle is NULL");
+    int rc = tmvb_ctpf_set_distributed(h, comm != nullptr);
+    if (rc) return rc;
+    h->comm = comm;
+    return TMVB_OK;
+}
+
+namespace {
+struct CtpfTrainOps {
+    int viter; double vtol;
+    int estep(tmvb_ctpf* h) { return tmvb_ctpf_estep(h, viter, vtol); }               // src/CTPF.jl:353-365
+    int reduce(tmvb_ctpf* h) { return tmvb_ctpf_reduce_docs(h); }
+    int before_allreduce(tmvb_ctpf*) { return TMVB_OK; }
+    float* stats(tmvb_ctpf* h) { return h->d_stats; }
+    int64_t stats_len(tmvb_ctpf* h) { return h->stats_len(); }
+    int mstep(tmvb_ctpf* h) { return tmvb_ctpf_mstep(h); }                            // :366-371
+    // the per-document part adds up over the shards; the (beta, eta) part is global and identical on every rank
+    int elbo_local(tmvb_ctpf* h, double* s, double* once) { return tmvb_ctpf_update_elbo_parts(h, s, once); }
+    double* elbo_dev(tmvb_ctpf* h) { return h->d_elbo; }
+    tmvb_comm* comm(tmvb_ctpf* h) { return h->comm; }
+    bool distributed(tmvb_ctpf* h) { return h->distributed; }
+    tmvb_ctx* ctx(tmvb_ctpf* h) { return h->ctx; }
+    int64_t nnz(tmvb_ctpf* h) { return h->corp->info.nnz; }
+    void set_elbo(tmvb_ctpf* h, double v) { h->elbo = v; }
+    double get_elbo(tmvb_ctpf* h) { return h->elbo; }
+    int finish(tmvb_ctpf* h)
+    {
+        TMVB_HIP(hipSetDevice(h->ctx->device));
+        TMVB_HIP(hipStreamSynchronize(h->ctx->stream));
+        return TMVB_OK;
+    }
+};
+}  // namespace
+
+extern "C" int tmvb_ctpf_train_group(tmvb_ctpf* const* hs, int32_t n, int32_t iter, double tol, int32_t viter, double vtol,
+                                     int32_t checkelbo, double* elbo_traj, int32_t* iters_done, double* elbo_baseline)
+{
+    TMVB_REQUIRE(tol >= 0 && vtol >= 0, TMVB_EINVAL, "tolerance parameters must be nonnegative.");     // src/gpuCTPF.jl:679
+    TMVB_REQUIRE(iter >= 0 && viter >= 0, TMVB_EINVAL, "iteration parameters must be nonnegative.");   // :680
+    CtpfTrainOps ops{viter, vtol};
+    return tmvb_train_group_loop("tmvb_ctpf_train", hs, n, iter, tol, checkelbo, elbo_traj, iters_done, elbo_baseline, ops);
+}
+
 extern "C" int tmvb_ctpf_train(tmvb_ctpf* h, int32_t iter, double tol, int32_t viter, double vtol, int32_t checkelbo,
-                               double* elbo_traj, int32_t* iters_done)
+                               double* elbo_traj, int32_t* iters_done, double* elbo_baseline)
 {
     TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_ctpf_train: handle is NULL");
-    TMVB_REQUIRE(tol >= 0 && vtol >= 0, TMVB_EINVAL, "tolerance parameters must be nonnegative.");
-    TMVB_REQUIRE(iter >= 0 && viter >= 0, TMVB_EINVAL, "iteration parameters must be nonnegative.");
-    TMVB_REQUIRE(!h->distributed, TMVB_EINVAL, "tmvb_ctpf_train drives one context");
-    if (iters_done) *iters_done = 0;
-    if (h->corp->info.nnz == 0) iter = 0;                                   // src/gpuCTPF.jl:682
-    int rc, done = 0;
-    double e_old = h->elbo;
-    if (checkelbo > 0 && checkelbo <= iter) { if ((rc = tmvb_ctpf_update_elbo(h, &e_old))) return rc; }   // :683
-    for (int k = 1; k <= iter; ++k) {
-        ++done;
-        if ((rc = tmvb_ctpf_estep(h, viter, vtol))) return rc;
-        if ((rc = tmvb_ctpf_reduce_docs(h))) return rc;
-        if ((rc = tmvb_ctpf_mstep(h))) return rc;
-        if (elbo_traj) elbo_traj[k - 1] = NAN;
-        if (checkelbo > 0 && (k % checkelbo) == 0) {                        // check_elbo! src/modelutils.jl:574-585
-            double e_new;
-            if ((rc = tmvb_ctpf_update_elbo(h, &e_new))) return rc;
-            TMVB_REQUIRE(std::isfinite(e_new), TMVB_ENONFINITE, "elbo must be finite.");
-            if (elbo_traj) elbo_traj[k - 1] = e_new;
-            const double delta = e_new - e_old;
-            e_old = e_new;
-            if (delta < tol) break;
-        }
-    }
-    TMVB_HIP(hipStreamSynchronize(h->ctx->stream));
-    if (iters_done) *iters_done = done;
-    return TMVB_OK;
+    return tmvb_ctpf_train_group(&h, 1, iter, tol, viter, vtol, checkelbo, elbo_traj, iters_done, elbo_baseline);
 }
 
 int tmvb_ctpf_view_of(tmvb_ctpf* h, tmvb_ctpf_view* v)

@@ -109,6 +109,8 @@ struct tmvb_ctpf_view {
 };
 int tmvb_ctpf_view_of(tmvb_ctpf* h, tmvb_ctpf_view* v);
 int tmvb_corpus_term_index(tmvb_corpus* c);
+// n sum-all-reduces issued by one host thread inside one RCCL group (tmvb_comm.hip)
+int tmvb_comm_allreduce_group(tmvb_comm* const* comms, void* const* dev_ptrs, const int64_t* counts, int n, int32_t dtype);
 int tmvb_corpus_reader_index(tmvb_corpus* c);
 
 // EPSILON of the reference (src/utils.jl:3) = 2^-99, exactly representable in fp32.

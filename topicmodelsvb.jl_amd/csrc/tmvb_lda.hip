@@ -28,6 +28,7 @@
 // Roofline: HBM/gather-bound by byte count, VALU-issue bound in practice.  Algorithmic
 // bytes per outer iteration: nnz*(8 + 4K + 4K) + 12*M*K + 12*K*V + 4*(M+1).
 #include "tmvb_common_kernels.h"
+#include "tmvb_train.h"
 #include "tmvb_regtile.h"
 
 // e_q of the first TMVB_LDA_E_LDS topics reach the lanes through LDS (one ds_write, broadcast ds_read_b128) instead of
@@ -772,6 +773,7 @@ struct tmvb_lda {
     int64_t M = 0, V = 0;
     int64_t M_total = 0;
     bool distributed = false;
+    tmvb_comm* comm = nullptr;         // document-sharded train!: the all-reduce of the packed statistics (not owned)
     // device state
     double* d_alpha_d = nullptr;
     float* d_alpha_f = nullptr;
@@ -1422,43 +1424,58 @@ extern "C" int tmvb_lda_update_elbo(tmvb_lda* h, double* elbo)
     return TMVB_OK;
 }
 
-extern "C" int tmvb_lda_train(tmvb_lda* h, int32_t iter, double tol, int32_t niter, double ntol, int32_t viter,
-                              double vtol, int32_t checkelbo, double* elbo_traj, int32_t* iters_done)
+extern "C" int tmvb_lda_set_comm(tmvb_lda* h, tmvb_comm* comm, int64_t M_total)
 {
-    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_lda_train: handle is NULL");
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_lda_set_comm: handle is NULL");
+    int rc = tmvb_lda_set_distributed(h, comm ? M_total : h->M, comm != nullptr);
+    if (rc) return rc;
+    h->comm = comm;
+    return TMVB_OK;
+}
+
+namespace {
+struct LdaTrainOps {
+    int niter, viter; double ntol, vtol;
+    int estep(tmvb_lda* h) { return tmvb_lda_estep(h, viter, vtol); }                 // src/LDA.jl:170-180
+    int reduce(tmvb_lda* h) { return tmvb_lda_reduce_docs(h); }                       // :98
+    int before_allreduce(tmvb_lda* h) { TMVB_HIP(hipSetDevice(h->ctx->device)); return lda_join_side(h); }
+    float* stats(tmvb_lda* h) { return h->d_stats; }
+    int64_t stats_len(tmvb_lda* h) { return (int64_t)h->K * h->V + h->K; }
+    int mstep(tmvb_lda* h) { int rc = tmvb_lda_update_beta(h); return rc ? rc : tmvb_lda_update_alpha(h, niter, ntol); }   // :181-182
+    int elbo_local(tmvb_lda* h, double* s, double* once) { *once = 0.0; return tmvb_lda_update_elbo(h, s); }
+    double* elbo_dev(tmvb_lda* h) { return h->d_elbo; }
+    tmvb_comm* comm(tmvb_lda* h) { return h->comm; }
+    bool distributed(tmvb_lda* h) { return h->distributed; }
+    tmvb_ctx* ctx(tmvb_lda* h) { return h->ctx; }
+    int64_t nnz(tmvb_lda* h) { return h->corp->info.nnz; }
+    void set_elbo(tmvb_lda* h, double v) { h->elbo = v; }
+    double get_elbo(tmvb_lda* h) { return h->elbo; }
+    int finish(tmvb_lda* h)
+    {
+        TMVB_HIP(hipSetDevice(h->ctx->device));
+        int rc = lda_join_side(h);
+        if (rc) return rc;
+        TMVB_HIP(hipStreamSynchronize(h->ctx->stream));
+        return TMVB_OK;
+    }
+};
+}  // namespace
+
+extern "C" int tmvb_lda_train_group(tmvb_lda* const* hs, int32_t n, int32_t iter, double tol, int32_t niter, double ntol, int32_t viter,
+                                    double vtol, int32_t checkelbo, double* elbo_traj, int32_t* iters_done, double* elbo_baseline)
+{
     // src/gpuLDA.jl:349-351
     TMVB_REQUIRE(tol >= 0 && ntol >= 0 && vtol >= 0, TMVB_EINVAL, "tolerance parameters must be nonnegative.");
     TMVB_REQUIRE(iter >= 0 && niter >= 0 && viter >= 0, TMVB_EINVAL, "iteration parameters must be nonnegative.");
-    TMVB_REQUIRE(!h->distributed, TMVB_EINVAL, "tmvb_lda_train drives one context; a document-sharded host composes estep/reduce_docs/update_* itself");
-    if (iters_done) *iters_done = 0;
-    if (h->corp->info.nnz == 0) iter = 0;                                   // src/gpuLDA.jl:352
-    int rc;
-    double e_old = h->elbo;
-    if (checkelbo > 0 && checkelbo <= iter) {                               // :353
-        if ((rc = tmvb_lda_update_elbo(h, &e_old))) return rc;
-    }
-    int done = 0;
-    for (int k = 1; k <= iter; ++k) {
-        ++done;
-        if ((rc = tmvb_lda_estep(h, viter, vtol))) return rc;               // :355-364 (CPU semantics src/LDA.jl:170-180)
-        if ((rc = tmvb_lda_reduce_docs(h))) return rc;
-        if ((rc = tmvb_lda_update_beta(h))) return rc;                      // :365
-        if ((rc = tmvb_lda_update_alpha(h, niter, ntol))) return rc;        // :366
-        if (elbo_traj) elbo_traj[k - 1] = NAN;
-        if (checkelbo > 0 && (k % checkelbo) == 0) {                        // check_elbo! src/modelutils.jl:574-585
-            double e_new;
-            if ((rc = tmvb_lda_update_elbo(h, &e_new))) return rc;
-            TMVB_REQUIRE(std::isfinite(e_new), TMVB_ENONFINITE, "elbo must be finite.");
-            if (elbo_traj) elbo_traj[k - 1] = e_new;
-            double delta = e_new - e_old;
-            e_old = e_new;
-            if (delta < tol) break;
-        }
-    }
-    if ((rc = lda_join_side(h))) return rc;
-    TMVB_HIP(hipStreamSynchronize(h->ctx->stream));
-    if (iters_done) *iters_done = done;
-    return TMVB_OK;
+    LdaTrainOps ops{niter, viter, ntol, vtol};
+    return tmvb_train_group_loop("tmvb_lda_train", hs, n, iter, tol, checkelbo, elbo_traj, iters_done, elbo_baseline, ops);
+}
+
+extern "C" int tmvb_lda_train(tmvb_lda* h, int32_t iter, double tol, int32_t niter, double ntol, int32_t viter,
+                              double vtol, int32_t checkelbo, double* elbo_traj, int32_t* iters_done, double* elbo_baseline)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_lda_train: handle is NULL");
+    return tmvb_lda_train_group(&h, 1, iter, tol, niter, ntol, viter, vtol, checkelbo, elbo_traj, iters_done, elbo_baseline);
 }
 
 extern "C" int tmvb_lda_sweep_hist(tmvb_lda* h, int64_t* hist, int32_t nbins)

@@ -1,0 +1,129 @@
+// tmvb_train.h -- the outer loop of train! (src/LDA.jl:161-187, src/CTM.jl:185-213, src/CTPF.jl:344-376) with
+// check_elbo! (src/modelutils.jl:574-585), written once for the three models and for any number of local handles.
+//
+// One handle without a communicator is the reference's single-device train!.  With communicators the same loop is the
+// document-sharded run of SURVEY.md section 8e: E-step on every local shard, ONE sum-all-reduce of the packed statistics
+// per outer iteration (RCCL over xGMI, or the host transport), the identical M-step on every shard, and -- when the ELBO
+// is checked -- one 8-byte all-reduce of the per-document part so that every rank takes the same stop decision.
+// n > 1 local handles = one host thread driving n GPUs (tmvb_comm_create_rccl_all); the n collectives of a step sit in
+// one RCCL group.
+#pragma once
+#include "tmvb_internal.h"
+
+// Ops (per model):
+//   int      estep(H*)                      E-step sweeps + per-document statistics, asynchronous
+//   int      reduce(H*)                     per-document sums into the statistics tail
+//   int      before_allreduce(H*)           join side streams so that the context stream owns the whole buffer
+//   float*   stats(H*), int64_t stats_len(H*)
+//   int      mstep(H*)                      the M-step, identical on every rank
+//   int      elbo_local(H*, double* summable, double* once)   synchronous; `summable` adds up over shards, `once` is global
+//   double*  elbo_dev(H*)                   one device double usable as all-reduce scratch
+//   tmvb_comm* comm(H*), bool distributed(H*), tmvb_ctx* ctx(H*), int64_t nnz(H*), void set_elbo(H*, double), double get_elbo(H*)
+//   int      finish(H*)                     join + synchronize
+
+template <class H, class Ops>
+static int tmvb_group_sum_f64(H* const* hs, int n, Ops& ops, double local_sum, double* out)
+{
+    if (!ops.comm(hs[0])) { *out = local_sum; return TMVB_OK; }
+    std::vector<tmvb_comm*> comms(n);
+    std::vector<void*> ptrs(n);
+    std::vector<int64_t> counts(n, 1);
+    std::vector<double> vals(n, 0.0);
+    vals[0] = local_sum;                    // hs[0] carries this process' sum, the other local handles carry zero
+    for (int i = 0; i < n; ++i) {
+        tmvb_ctx* ctx = ops.ctx(hs[i]);
+        TMVB_HIP(hipSetDevice(ctx->device));
+        TMVB_HIP(hipMemcpyAsync(ops.elbo_dev(hs[i]), &vals[i], sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        TMVB_HIP(hipStreamSynchronize(ctx->stream));
+        comms[i] = ops.comm(hs[i]); ptrs[i] = ops.elbo_dev(hs[i]);
+    }
+    int rc = tmvb_comm_allreduce_group(comms.data(), ptrs.data(), counts.data(), n, TMVB_F64);
+    if (rc) return rc;
+    tmvb_ctx* c0 = ops.ctx(hs[0]);
+    TMVB_HIP(hipSetDevice(c0->device));
+    double v = 0.0;
+    TMVB_HIP(hipMemcpyAsync(&v, ops.elbo_dev(hs[0]), sizeof(double), hipMemcpyDeviceToHost, c0->stream));
+    TMVB_HIP(hipStreamSynchronize(c0->stream));
+    for (int i = 1; i < n; ++i) {           // the other local streams must also have finished their share of the group
+        TMVB_HIP(hipSetDevice(ops.ctx(hs[i])->device));
+        TMVB_HIP(hipStreamSynchronize(ops.ctx(hs[i])->stream));
+    }
+    *out = v;
+    return TMVB_OK;
+}
+
+template <class H, class Ops>
+static int tmvb_group_elbo(H* const* hs, int n, Ops& ops, double* out)
+{
+    double sum = 0.0, once = 0.0;
+    for (int i = 0; i < n; ++i) {
+        double s = 0.0, g = 0.0;
+        int rc = ops.elbo_local(hs[i], &s, &g);
+        if (rc) return rc;
+        sum += s; once = g;
+    }
+    double tot = 0.0;
+    int rc = tmvb_group_sum_f64(hs, n, ops, sum, &tot);
+    if (rc) return rc;
+    *out = tot + once;
+    for (int i = 0; i < n; ++i) ops.set_elbo(hs[i], *out);
+    return TMVB_OK;
+}
+
+template <class H, class Ops>
+static int tmvb_train_group_loop(const char* who, H* const* hs, int n, int iter, double tol, int checkelbo, double* elbo_traj,
+                                 int32_t* iters_done, double* elbo_baseline, Ops& ops)
+{
+    TMVB_REQUIRE(hs != nullptr && n >= 1, TMVB_EINVAL, "%s: no handles", who);
+    for (int i = 0; i < n; ++i) TMVB_REQUIRE(hs[i] != nullptr, TMVB_EINVAL, "%s: handle %d is NULL", who, i);
+    if (iters_done) *iters_done = 0;
+    const bool sharded = ops.comm(hs[0]) != nullptr;
+    for (int i = 0; i < n; ++i) {
+        TMVB_REQUIRE((ops.comm(hs[i]) != nullptr) == sharded, TMVB_EINVAL, "%s: some handles have a communicator and some do not", who);
+        TMVB_REQUIRE(sharded || !ops.distributed(hs[i]), TMVB_EINVAL,
+                     "%s: a document-sharded handle needs a communicator (tmvb_*_set_comm), or the host composes estep/reduce_docs/update_* itself", who);
+    }
+    TMVB_REQUIRE(sharded || n == 1, TMVB_EINVAL, "%s: several local handles need communicators (tmvb_comm_create_rccl_all)", who);
+    int rc;
+    {   // iter = 0 when every document of the WHOLE corpus is empty (src/LDA.jl:166)
+        double local = 0.0, total = 0.0;
+        for (int i = 0; i < n; ++i) local += (double)ops.nnz(hs[i]);
+        if ((rc = tmvb_group_sum_f64(hs, n, ops, local, &total))) return rc;
+        if (total == 0.0) iter = 0;
+    }
+    double e_old = ops.get_elbo(hs[0]);
+    if (checkelbo > 0 && checkelbo <= iter) {                                   // src/LDA.jl:167
+        if ((rc = tmvb_group_elbo(hs, n, ops, &e_old))) return rc;
+    }
+    if (elbo_baseline) *elbo_baseline = e_old;
+    std::vector<tmvb_comm*> comms(n);
+    std::vector<void*> ptrs(n);
+    std::vector<int64_t> counts(n);
+    int done = 0;
+    for (int k = 1; k <= iter; ++k) {
+        ++done;
+        for (int i = 0; i < n; ++i) if ((rc = ops.estep(hs[i]))) return rc;
+        for (int i = 0; i < n; ++i) if ((rc = ops.reduce(hs[i]))) return rc;
+        if (sharded) {
+            for (int i = 0; i < n; ++i) {
+                if ((rc = ops.before_allreduce(hs[i]))) return rc;
+                comms[i] = ops.comm(hs[i]); ptrs[i] = ops.stats(hs[i]); counts[i] = ops.stats_len(hs[i]);
+            }
+            if ((rc = tmvb_comm_allreduce_group(comms.data(), ptrs.data(), counts.data(), n, TMVB_F32))) return rc;
+        }
+        for (int i = 0; i < n; ++i) if ((rc = ops.mstep(hs[i]))) return rc;
+        if (elbo_traj) elbo_traj[k - 1] = NAN;
+        if (checkelbo > 0 && (k % checkelbo) == 0) {                            // check_elbo! src/modelutils.jl:574-585
+            double e_new;
+            if ((rc = tmvb_group_elbo(hs, n, ops, &e_new))) return rc;
+            TMVB_REQUIRE(std::isfinite(e_new), TMVB_ENONFINITE, "elbo must be finite.");
+            if (elbo_traj) elbo_traj[k - 1] = e_new;
+            const double delta = e_new - e_old;
+            e_old = e_new;
+            if (delta < tol) break;                                             // signed, quirk Q4
+        }
+    }
+    for (int i = 0; i < n; ++i) if ((rc = ops.finish(hs[i]))) return rc;
+    if (iters_done) *iters_done = done;
+    return TMVB_OK;
+}

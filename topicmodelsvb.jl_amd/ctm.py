@@ -20,7 +20,7 @@ import numpy as np
 
 from ._lib import TopicModelError, check, lib, P_dbl, P_i64, VP
 from .corpus import dirichlet_rows
-from .lda import DeviceContext, DeviceCorpus, _F, _packed, _pd, _validate_train_args
+from .lda import DeviceContext, DeviceCorpus, _F, _packed, _pd, _print_delbo, _validate_train_args
 
 
 class CTM:
@@ -158,6 +158,12 @@ class gpuCTM:
     def synchronize(self):
         self.ctx.synchronize()
 
+    def set_comm(self, comm, M_total: int):
+        """Attach a communicator (comm.py): document-sharded train!, every rank calls train() with the same arguments."""
+        self.M_total = int(M_total) if comm is not None else self.M
+        self._comm = comm
+        check(lib().tmvb_ctm_set_comm(self.handle, comm.handle if comm is not None else VP(None), C.c_int64(self.M_total)))
+
     def train(self, iter: int = 150, tol: float = 1.0, niter: int = 1000, ntol: float | None = None, viter: int = 10,
               vtol: float | None = None, checkelbo=1, printelbo: bool = True):
         """train!(model::gpuCTM; ...) src/gpuCTM.jl:487-519."""
@@ -168,20 +174,15 @@ class gpuCTM:
         self.update_buffer()
         ce = 0 if checkelbo == math.inf else int(checkelbo)
         traj = np.full(max(iter, 1), np.nan)
-        done = C.c_int32(0)
-        e0 = self.elbo
+        done, base = C.c_int32(0), C.c_double(float(self.elbo))
         check(lib().tmvb_ctm_train(self.handle, C.c_int32(iter), C.c_double(tol), C.c_int32(niter), C.c_double(ntol),
-                                   C.c_int32(viter), C.c_double(vtol), C.c_int32(ce), _pd(traj), C.byref(done)))
+                                   C.c_int32(viter), C.c_double(vtol), C.c_int32(ce), _pd(traj), C.byref(done), C.byref(base)))
         traj = traj[:done.value]
+        self.elbo_baseline = base.value
         if iter > 0:
             self.update_host()
         if printelbo and ce:
-            prev = None
-            for k, e in enumerate(traj, start=1):
-                if not np.isnan(e):
-                    if prev is not None:
-                        print(k, " ∆elbo: ", round(e - prev, 3))
-                    prev = e
+            _print_delbo(traj, base.value)
         self.topics = [np.argsort(self.beta[i, :], kind="stable")[::-1] + 1 for i in range(self.K)]
         return traj
 

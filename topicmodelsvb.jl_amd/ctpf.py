@@ -20,7 +20,7 @@ import numpy as np
 
 from ._lib import TopicModelError, check, lib, P_i64, VP
 from .corpus import dirichlet_rows
-from .lda import DeviceContext, DeviceCorpus, _F, _packed, _pd, _validate_train_args
+from .lda import DeviceContext, DeviceCorpus, _F, _packed, _pd, _print_delbo, _validate_train_args
 
 
 class CTPF:
@@ -99,6 +99,10 @@ class gpuCTPF:
         check(lib().tmvb_ctpf_set_state(self.handle, _pd(hy), _pd(_F(self.alef, (K, V))), _pd(_F(self.he, (K, U))),
                                         _pd(vec(self.bet)), _pd(vec(self.vav)), _pd(vec(self.dalet)), _pd(vec(self.het)),
                                         _pd(_F(self.gimel, (K, M))), _pd(_F(self.zayin, (K, M))), C.byref(elbo)))
+        # the *_old fields feed update_elbo! (src/CTPF.jl:239-240) and are part of update_buffer! (src/modelutils.jl:474-493)
+        check(lib().tmvb_ctpf_set_state_old(self.handle, _pd(_F(self.alef_old, (K, V))), _pd(_F(self.he_old, (K, U))),
+                                            _pd(vec(self.bet_old)), _pd(vec(self.vav_old)), _pd(vec(self.dalet_old)),
+                                            _pd(vec(self.het_old)), _pd(_F(self.gimel_old, (K, M))), _pd(_F(self.zayin_old, (K, M)))))
 
     def update_host(self):
         K, M, V, U = self.K, self.M, self.V, self.U
@@ -145,6 +149,11 @@ class gpuCTPF:
     def set_distributed(self, distributed: bool = True):
         check(lib().tmvb_ctpf_set_distributed(self.handle, C.c_int32(1 if distributed else 0)))
 
+    def set_comm(self, comm):
+        """Attach a communicator (comm.py): document-sharded train!, every rank calls train() with the same arguments."""
+        self._comm = comm
+        check(lib().tmvb_ctpf_set_comm(self.handle, comm.handle if comm is not None else VP(None)))
+
     def sweep_hist(self, nbins: int = 11):
         h = np.zeros(nbins, dtype=np.int64)
         check(lib().tmvb_ctpf_sweep_hist(self.handle, h.ctypes.data_as(P_i64), C.c_int32(nbins)))
@@ -188,18 +197,14 @@ class gpuCTPF:
         self.update_buffer()
         ce = 0 if checkelbo == math.inf else int(checkelbo)
         traj = np.full(max(iter, 1), np.nan)
-        done = C.c_int32(0)
+        done, base = C.c_int32(0), C.c_double(float(self.elbo))
         check(lib().tmvb_ctpf_train(self.handle, C.c_int32(iter), C.c_double(tol), C.c_int32(viter), C.c_double(vtol),
-                                    C.c_int32(ce), _pd(traj), C.byref(done)))
+                                    C.c_int32(ce), _pd(traj), C.byref(done), C.byref(base)))
+        self.elbo_baseline = base.value
         if iter > 0:
             self.update_host()
         if printelbo and ce:
-            prev = None
-            for k, e in enumerate(traj[:done.value], start=1):
-                if not np.isnan(e):
-                    if prev is not None:
-                        print(k, " ∆elbo: ", round(e - prev, 3))
-                    prev = e
+            _print_delbo(traj[:done.value], base.value)
         Ebeta = self.alef / self.bet[:, None]                                                     # :707-708
         self.topics = [np.argsort(Ebeta[i, :], kind="stable")[::-1] + 1 for i in range(self.K)]   # reverse(sortperm(.))
         if recs:

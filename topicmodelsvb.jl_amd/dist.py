@@ -175,7 +175,7 @@ class HipCTPFEngine(_HipEngine):
         from .ctpf import gpuCTPF
         self._setup(device_index)
         self.model = gpuCTPF(shard_corpus, K, ctx=self.ctx)
-        self.model.alef = np.asfortranarray(alef0)
+        self.model.alef = np.asfortranarray(alef0); self.model.alef_old = self.model.alef.copy(order="F")
         self.model.update_buffer()
         self._bind(device_index)
         self.model.set_distributed(distributed)

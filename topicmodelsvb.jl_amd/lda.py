@@ -169,6 +169,16 @@ def _validate_train_args(tols, iters, checkelbo):
         raise ValueError("checkelbo parameter must be a positive integer or Inf.")
 
 
+def _print_delbo(traj, baseline):
+    """The printing half of check_elbo! (src/modelutils.jl:578-579): one line per checked iteration, the first one
+    against the ELBO evaluated before the first iteration."""
+    prev = baseline
+    for k, e in enumerate(traj, start=1):
+        if not np.isnan(e):
+            print(k, " ∆elbo: ", round(e - prev, 3))
+            prev = e
+
+
 class gpuLDA:
     """GPU accelerated latent Dirichlet allocation model (src/gpuLDA.jl:6-85) on libtmvb_hip.so."""
 
@@ -261,6 +271,13 @@ class gpuLDA:
     def synchronize(self):
         self.ctx.synchronize()
 
+    def set_comm(self, comm, M_total: int):
+        """Attach a communicator (comm.py): this model's corpus is one document shard of M_total documents and
+        train() becomes the sharded train! -- every rank calls it with the same arguments."""
+        self.M_total = int(M_total) if comm is not None else self.M
+        self._comm = comm
+        check(lib().tmvb_lda_set_comm(self.handle, comm.handle if comm is not None else VP(None), C.c_int64(self.M_total)))
+
     # ---- train!
     def train(self, iter: int = 150, tol: float = 1.0, niter: int = 1000, ntol: float | None = None, viter: int = 10,
               vtol: float | None = None, checkelbo=1, printelbo: bool = True):
@@ -272,24 +289,15 @@ class gpuLDA:
         self.update_buffer()
         ce = 0 if checkelbo == math.inf else int(checkelbo)
         traj = np.full(max(iter, 1), np.nan)
-        done = C.c_int32(0)
-        e_prev = self.elbo
-        if printelbo and ce:
-            # the library evaluates the trajectory; printing mirrors check_elbo! (src/modelutils.jl:578)
-            pass
+        done, base = C.c_int32(0), C.c_double(float(self.elbo))
         check(lib().tmvb_lda_train(self.handle, C.c_int32(iter), C.c_double(tol), C.c_int32(niter), C.c_double(ntol),
-                                   C.c_int32(viter), C.c_double(vtol), C.c_int32(ce), _pd(traj), C.byref(done)))
+                                   C.c_int32(viter), C.c_double(vtol), C.c_int32(ce), _pd(traj), C.byref(done), C.byref(base)))
         traj = traj[:done.value]
+        self.elbo_baseline = base.value
         if iter > 0:
             self.update_host()                                       # :373
         if printelbo and ce:
-            first = self.elbo if done.value == 0 else None
-            prev = None
-            for k, e in enumerate(traj, start=1):
-                if not np.isnan(e):
-                    if prev is not None:
-                        print(k, " ∆elbo: ", round(e - prev, 3))
-                    prev = e
+            _print_delbo(traj, base.value)
         self.topics = [np.argsort(self.beta[i, :], kind="stable")[::-1] + 1 for i in range(self.K)]   # :374
         return traj
 
