@@ -7,20 +7,28 @@ bench.py -- VB outer iterations per second of the LDA hot path on SYN-NSF (M=128
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one outer iteration of train! (src/LDA.jl:169-183) with checkelbo=Inf: fused E-step over
-this rank's documents, the Elogtheta_sum reduction, ONE all-reduce of the packed K*V+K statistics
-(N>1), then update_beta! and update_alpha! on every rank.  The corpus and the state are resident in
-HBM before the timed region; training starts cold (alpha=1, gamma=1, beta0 ~ Dirichlet(V,1) seed 7),
-W warm-up iterations, then exactly K timed iterations between barrier+synchronize pairs; the time is
-the MAX over ranks.  The corpus is fixed as N grows ("scaling": "strong").
+A "step" is one outer iteration of train! (src/LDA.jl:169-183) with checkelbo=Inf: fused E-step over this rank's
+documents, the Elogtheta_sum reduction, ONE all-reduce of the packed K*V+K statistics (N>1; RCCL inside libtmvb_hip.so
+through tmvb_comm_allreduce, the communicator's unique id bootstrapped over torch.distributed), then update_beta! and
+update_alpha! on every rank.  The corpus and the state are resident in HBM before the timed region.
+
+STEADY STATE (round-1 review): the per-document sweep counts grow over the first ~50 iterations of a cold start
+(5.3 -> 6+ sweeps per document), so iterations 6-25 of a cold start overstate the rate by ~15 %.  The model is therefore
+first brought to its operating point with `--burnin` (default 60) untimed iterations -- state preparation, like the
+corpus upload -- then W warm-up iterations, then exactly K timed iterations between barrier+synchronize pairs; the time
+is the MAX over ranks.  `value` is that steady-state rate; the cold-start rate of the same W+K window (what round 1
+reported) is carried in "cold_start".  The corpus is fixed as N grows ("scaling": "strong").
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline     : the E-step kernel against the HBM roofline (algorithmic bytes, HIP-event timing on
-                 the launch stream), and
-  cpu_baseline : the fp64 oracle (a port of the reference's CPU path -- the reference itself is Julia
-                 and cannot run here) timed on this host's cores on a bounded document sample.
+  roofline     : the E-step against the HBM roofline (algorithmic bytes, HIP-event timing on the launch stream),
+  elbo_plateau : wall time until check_elbo!'s own stop rule (delta_elbo < tol = 1.0, src/modelutils.jl:580) fires from
+                 a cold start with checkelbo = 1 -- or "reached": false after the iteration cap,
+  cpu_baseline : the fp64 oracle (a port of the reference's CPU path -- the reference itself is Julia and cannot run
+                 here) timed on this host's cores on the FULL corpus.
 """
 import argparse
+import ctypes as C
+import hashlib
 import json
 import os
 import sys
@@ -47,57 +55,121 @@ def mstep_bytes(K, V):
     return 12 * K * V
 
 
+def kernel_source_hash():
+    """sha256 over the kernel sources: PMC numbers collected on other kernels are stale."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "topicmodelsvb.jl_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(K, M, nnz):
-    """HBM traffic of one E-step from the committed rocprofv3 PMC summary (separate --pmc FETCH_SIZE /
-    --pmc WRITE_SIZE passes of this same command, profiles/r1_lda_k50_pmc.*), corrected as
-    MI355X_MICROARCH.md's HBM section prescribes for gfx950 (2 x FETCH_SIZE; KB units).  Only returned
-    when the workload is the one the counters were collected on; otherwise null."""
-    path = os.path.join(ROOT, "profiles", "r1_lda_k50_pmc.json")
-    if not (K == 50 and M == 128804 and nnz == 10929864 and os.path.exists(path)):
-        return None
+    """HBM traffic of one E-step from the committed rocprofv3 PMC summary (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE
+    passes of this same command, tools/pmc_summary.py), corrected as MI355X_MICROARCH.md's HBM section prescribes for
+    gfx950 (2 x FETCH_SIZE; KB units).  Returned only when the summary was collected on this workload AND on the kernel
+    sources this run is built from (source hash stamped into the summary); otherwise null with the reason."""
+    for name in ("r2_lda_k50_pmc.json", "r1_lda_k50_pmc.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            break
+    else:
+        return None, "no PMC summary under profiles/"
+    if not (K == 50 and M == 128804 and nnz == 10929864):
+        return None, "PMC summary is for SYN-NSF K=50 on one GPU"
     rows = json.load(open(path))
+    meta = rows.get("_meta", {})
+    if meta.get("kernel_source_hash") != kernel_source_hash():
+        return None, f"{name} was collected on kernel sources {meta.get('kernel_source_hash')}, this build is {kernel_source_hash()} (stale)"
     tot = 0.0
-    for name, r in rows.items():
-        if "lda_estep" in name or "termstats" in name:
+    for kname, r in rows.items():
+        if "lda_estep" in kname or "termstats" in kname:
             if "fetch_kb_per_iteration" not in r:
-                return None
+                return None, "incomplete PMC summary"
             tot += (2.0 * r["fetch_kb_per_iteration"] + r["write_kb_per_iteration"]) * 1024.0
-    return tot
+    return tot, f"profiles/{name} (rocprofv3 --pmc, separate passes; 2*FETCH_SIZE+WRITE_SIZE summed over the E-step's dispatches of one iteration)"
 
 
-def cpu_baseline(tm, corpus, K, beta0, warmup, budget_s=20.0):
-    """fp64 oracle (oracle/*.c) on a bounded sample of the same workload, all host cores (OpenMP
-    document-parallel E-step) and single thread; scaled to full-corpus iterations/s by nnz."""
-    import numpy as np
+def usable_cpus():
+    """CPUs this process may really use: the affinity mask and the cgroup CPU quota (containers often see every host
+    core in os.cpu_count() while being limited to a few)."""
+    n = os.cpu_count() or 1
+    info = {"os_cpu_count": n}
+    try:
+        info["sched_affinity"] = len(os.sched_getaffinity(0))
+        n = min(n, info["sched_affinity"])
+    except Exception:
+        pass
+    try:
+        q = open("/sys/fs/cgroup/cpu.max").read().split()          # cgroup v2: "<quota> <period>" or "max <period>"
+        if q[0] != "max":
+            info["cgroup_cpu_quota"] = float(q[0]) / float(q[1])
+            n = min(n, max(1, int(info["cgroup_cpu_quota"] + 0.5)))
+    except Exception:
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                info["cgroup_cpu_quota"] = quota / period
+                n = min(n, max(1, int(quota / period + 0.5)))
+        except Exception:
+            pass
+    return n, info
+
+
+def cpu_baseline(tm, corpus, K, beta0, budget_s=24.0):
+    """fp64 oracle (oracle/*.c) on the FULL corpus: OpenMP document-parallel E-step on every host core, per-thread
+    statistics allocated once; then one single-thread iteration (the reference is single-threaded) if the budget allows."""
     from oracle import oracle as oc
     oc.build()
-    ncores = min(os.cpu_count() or 1, 64)      # threads actually used (private K x V statistics per thread)
-    sample_docs = min(corpus.M, 16000)
-    sh = corpus.shard(0, sample_docs)
-    frac = sh.nnz / max(corpus.nnz, 1)
+    host_cores, cpu_info = usable_cpus()
+    threads = host_cores
+    csr = oc.CSR(corpus.doc_ptr, corpus.terms, corpus.counts, corpus.V)
 
-    def run(threads, iters):
-        m = oc.LDA(oc.CSR(sh.doc_ptr, sh.terms, sh.counts, sh.V), K, beta0)
-        for _ in range(warmup):
-            m.estep(omp_threads=threads); m.update_beta(); m.update_alpha()
+    def run(nthreads, warm, max_iters, budget):
+        m = oc.LDA(csr, K, beta0)
+        for _ in range(warm):
+            m.estep(omp_threads=nthreads); m.update_beta(); m.update_alpha()
         t0 = time.perf_counter()
         done = 0
-        for _ in range(iters):
-            m.estep(omp_threads=threads); m.update_beta(); m.update_alpha()
+        while done < max_iters:
+            m.estep(omp_threads=nthreads); m.update_beta(); m.update_alpha()
             done += 1
-            if time.perf_counter() - t0 > budget_s / 2:
+            if time.perf_counter() - t0 > budget:
                 break
-        return done / (time.perf_counter() - t0)
+        return done / (time.perf_counter() - t0), done
 
-    run(ncores, 1)                             # OpenMP runtime start-up outside the timing
-    omp = run(ncores, 8)
-    one = run(1, 2) if ncores > 1 else omp
+    t0 = time.perf_counter()
+    # the private-statistics reduction grows with the thread count, so the fastest team is not always the widest:
+    # try all usable CPUs, a half and a quarter (1 warm-up + 2 timed iterations each) and keep the best
+    tried = {}
+    for nt in sorted({host_cores, max(1, host_cores // 2), max(1, host_cores // 4)}, reverse=True):
+        tried[nt], _ = run(nt, 1, 2, budget_s / 8)
+        oc.lib().orc_omp_pool_free()
+    threads = max(tried, key=tried.get)
+    omp, n_omp = tried[threads], 2
+    left = budget_s - (time.perf_counter() - t0)
+    single, n_single, single_note = None, 0, "skipped (budget)"
+    if host_cores > 1 and left >= 9.0:                           # a full single-thread iteration takes ~6 s at this size
+        single, n_single = run(0, 0, 1, left)
+        single_note = f"{n_single} full-corpus iteration from the cold start"
+    elif host_cores > 1 and left > 2.0:
+        sh = corpus.shard(0, min(16000, corpus.M))
+        m = oc.LDA(oc.CSR(sh.doc_ptr, sh.terms, sh.counts, sh.V), K, beta0)
+        t1 = time.perf_counter()
+        m.estep(); m.update_beta(); m.update_alpha()
+        single = (sh.nnz / max(corpus.nnz, 1)) / (time.perf_counter() - t1)
+        single_note = f"1 iteration on the first {sh.M} documents ({sh.nnz} nnz), scaled by the nnz fraction"
+    oc.lib().orc_omp_pool_free()
     return {
-        "value": omp * frac, "unit": "VB iters/sec", "cores": ncores, "kind": "port",
-        "single_thread_value": one * frac,
-        "sample": f"fp64 C oracle (port of src/LDA.jl train!), first {sample_docs} docs of the workload "
-                  f"({sh.nnz} of {corpus.nnz} nnz), {warmup} warm-up + timed iterations from the same cold start, "
-                  f"OpenMP E-step on {ncores} threads; value = sample iters/s x nnz fraction {frac:.4f}",
+        "value": omp, "unit": "VB iters/sec", "cores": threads, "host_cpus": cpu_info, "kind": "port",
+        "omp_threads_tried": {str(k): v for k, v in tried.items()},
+        "single_thread_value": single,
+        "sample": f"fp64 C oracle (port of src/LDA.jl train!; the Julia reference cannot run here) on the FULL workload "
+                  f"({corpus.M} docs, {corpus.nnz} nnz), same cold start (alpha=1, gamma=1, beta0 seed 7): 1 warm-up + {n_omp} timed "
+                  f"iterations with the OpenMP document-parallel E-step on {threads} threads (the CPUs usable by this process: affinity mask and cgroup quota, see host_cpus), per-thread "
+                  f"statistics allocated once; single thread: {single_note}.  Cold-start iterations run fewer sweeps per "
+                  f"document than the GPU's steady-state window, which favours the CPU figure.",
     }
 
 
@@ -106,11 +178,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--burnin", type=int, default=60, help="untimed iterations that bring the model to its steady state before warm-up")
     ap.add_argument("--K", type=int, default=50)
     ap.add_argument("--docs", type=int, default=128804)
     ap.add_argument("--vocab", type=int, default=25319)
+    ap.add_argument("--collective", choices=["lib", "torch"], default="lib",
+                    help="lib: RCCL inside libtmvb_hip.so (tmvb_comm_allreduce); torch: torch.distributed all_reduce on the bound buffer")
+    ap.add_argument("--plateau-cap", type=int, default=4000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-plateau", action="store_true")
+    ap.add_argument("--no-cold", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -128,16 +205,16 @@ def main():
 
     if not torch.cuda.is_available() or tm.lib().tmvb_device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: the HIP engine has no CPU fallback")
-    backend = os.environ.get("TMVB_DIST_BACKEND", "nccl")          # "gloo" only to smoke-test the N>1 plumbing on one GPU
-    if backend != "nccl":
+    one_gpu_debug = os.environ.get("TMVB_DIST_BACKEND", "nccl") != "nccl"    # "gloo": smoke-test the N>1 plumbing on ONE GPU
+    if one_gpu_debug:
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        # the default group (gloo) carries only host-side control traffic: barriers, the RCCL unique id (through its
+        # store), the max over ranks.  The data path is RCCL inside the library; --collective torch (or a failed
+        # in-library init) makes a second, nccl (= RCCL) group for torch.distributed's all_reduce instead.
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     K, V = args.K, args.vocab
     t0 = time.perf_counter()
@@ -148,83 +225,191 @@ def main():
     beta0 = tm.dirichlet_rows(K, V, seed=7)
     log(f"[rank {rank}] corpus M={corpus.M} V={V} nnz={corpus.nnz} sum_counts={int(corpus.counts.sum())} "
         f"shard docs [{d0},{d1}) nnz={shard.nnz}  ({time.perf_counter() - t0:.1f}s to generate)")
-
-    eng = HipLDAEngine(shard, K, beta0, corpus.M, local_rank, distributed=(world > 1))
-    tr = ShardedLDA(eng)
     niter, ntol, viter, vtol = 1000, 1.0 / K ** 2, 10, 1.0 / K ** 2   # defaults of train! (src/LDA.jl:161)
+    L = tm.lib()
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        tr.iterate(niter, ntol, viter, vtol)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    barrier()
-    t_start = time.perf_counter()
-    for s in range(args.steps):
-        e = eng
-        ev[s][0].record(eng.stream)           # HIP events on the stream the kernels are launched on
-        e.estep(viter, vtol)
-        ev[s][1].record(eng.stream)
-        e.reduce_docs()
-        tr.allreduce_stats()
-        e.update_beta()
-        e.update_alpha(niter, ntol)
-    barrier()
-    elapsed = time.perf_counter() - t_start
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    estep_ms = [a.elapsed_time(b) for a, b in ev]
+    # ---- the collective: RCCL inside the library, torch.distributed as the alternative
+    collective = "none"
+    comm_holder = {}
+
+    def make_engine():
+        eng = HipLDAEngine(shard, K, beta0, corpus.M, local_rank, distributed=(world > 1))
+        return eng
+
+    def attach_comm(eng):
+        """Returns the all-reduce callable for this engine."""
+        nonlocal collective
+        tr = ShardedLDA(eng)
+        if world == 1:
+            return lambda: None, None
+        use_lib = args.collective == "lib" and not one_gpu_debug
+        comm = None
+        if use_lib:
+            ok = 1
+            try:
+                comm = tm.Communicator.torch_bootstrap(eng.ctx)
+            except Exception as e:                               # agree on the fallback across ranks
+                log(f"[rank {rank}] in-library RCCL communicator failed: {e}")
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                if comm is not None:
+                    comm.close()
+                comm, use_lib = None, False
+        if use_lib:
+            collective = f"RCCL {tm.rccl_version()} inside libtmvb_hip.so (tmvb_comm_allreduce on the context stream)"
+            eng.model.set_comm(comm, corpus.M)
+            ptr, n = eng.model.stats()
+            return (lambda: comm.allreduce(ptr, n)), comm
+        if one_gpu_debug:
+            collective = "host transport + gloo (one-GPU plumbing check, not a measurement)"
+            import numpy as _np
+
+            def gsum(a):
+                t = torch.from_numpy(a); dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            comm = tm.Communicator.host(eng.ctx, world, rank, gsum)
+            eng.model.set_comm(comm, corpus.M)
+            ptr, n = eng.model.stats()
+            return (lambda: comm.allreduce(ptr, n)), comm
+        collective = "torch.distributed all_reduce (nccl = RCCL) on the bound statistics buffer"
+        if "nccl" not in comm_holder:
+            comm_holder["nccl"] = dist.new_group(backend="nccl")
+        tr.group = comm_holder["nccl"]
+        return tr.allreduce_stats, None
+
+    def run_window(eng, allreduce, burnin, warmup, steps):
+        def one():
+            eng.estep(viter, vtol); eng.reduce_docs(); allreduce(); eng.update_beta(); eng.update_alpha(niter, ntol)
+        for _ in range(burnin + warmup):
+            one()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        barrier()
+        t_start = time.perf_counter()
+        for s in range(steps):
+            ev[s][0].record(eng.stream)           # HIP events on the stream the kernels are launched on
+            eng.estep(viter, vtol)
+            ev[s][1].record(eng.stream)
+            eng.reduce_docs()
+            allreduce()
+            eng.update_beta()
+            eng.update_alpha(niter, ntol)
+        barrier()
+        elapsed = time.perf_counter() - t_start
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)          # gloo (CPU tensor)
+            elapsed = float(t.item())
+        return elapsed, [a.elapsed_time(b) for a, b in ev]
+
+    # ---- steady-state window (the headline)
+    eng = make_engine()
+    allreduce, comm = attach_comm(eng)
+    elapsed, estep_ms = run_window(eng, allreduce, args.burnin, args.warmup, args.steps)
     sweep_hist = eng.model.sweep_hist(viter + 1).tolist()
     n_launch = eng.model.estep_launches()
+
+    # ---- cold-start window (round 1's number), fresh state
+    cold = None
+    if not args.no_cold:
+        eng_c = make_engine()
+        ar_c, comm_c = attach_comm(eng_c)
+        el_c, ms_c = run_window(eng_c, ar_c, 0, args.warmup, args.steps)
+        cold = {"value": args.steps / el_c, "ms_per_step": 1e3 * el_c / args.steps, "estep_ms": float(np.mean(ms_c)),
+                "window": f"iterations {args.warmup + 1}..{args.warmup + args.steps} from alpha=1, gamma=1, beta0",
+                "sweep_hist_last_step": eng_c.model.sweep_hist(viter + 1).tolist()}
+        eng_c.model.set_comm(None, shard.M) if comm_c is not None else None
+        if comm_c is not None:
+            comm_c.close()
+        eng_c.model.close(); del eng_c
 
     result = None
     if rank == 0:
         ms = float(np.mean(estep_ms))
         b_e = estep_bytes(shard.nnz, shard.M, K)
         achieved = b_e / (ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(K, shard.M, shard.nnz) if world == 1 else (None, "collected on one GPU only")
         result = {
             "metric": f"VB iters/sec, LDA K={K} on NSF-shaped corpus (M={corpus.M}, V={V})",
             "value": args.steps / elapsed, "unit": "VB iters/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"LDA K={K}, SYN-NSF (synthetic NSF-shaped corpus, seed 20260928), train! defaults "
-                                   "viter=10 vtol=1/K^2 niter=1000 ntol=1/K^2 checkelbo=Inf, cold start",
-                       "K": K, "M": corpus.M, "V": V, "nnz": corpus.nnz, "sum_counts": int(corpus.counts.sum()),
+                                   f"viter=10 vtol=1/K^2 niter=1000 ntol=1/K^2 checkelbo=Inf; steady state: {args.burnin} untimed burn-in "
+                                   f"iterations from the cold start (state preparation), then {args.warmup} warm-up + {args.steps} timed",
+                       "K": K, "M": corpus.M, "V": V, "nnz": corpus.nnz, "sum_counts": int(corpus.counts.sum()), "burnin": args.burnin,
                        "parallelism": f"doc-shard x{world}, 1 all-reduce of {K * V + K} f32 per iteration" if world > 1 else "single GPU",
+                       "collective": collective,
                        "sweep_hist_last_step": sweep_hist},
-            "roofline": {"bound": "hbm", "kernel": "LDA E-step = lda_estep_reg_kernel<13,T> / lda_estep_kernel over 4 document pieces on one stream, termstats_recompute_kernel<13> + termstats_multi_kernel of piece p on the context stream under the document kernels of piece p+1; timed start-to-end with events on the context stream",
+            "roofline": {"bound": "hbm", "kernel": "LDA E-step = the per-document register-tile / LDS-tile sweep kernels (lda_estep_reg*_kernel, lda_estep_kernel) over the document pieces + the gather-side statistics passes (termstats_recompute_kernel, termstats_multi_kernel) of every piece; one 'launch' = one E-step, timed start-to-end with HIP events on the context stream",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(K, shard.M, shard.nnz) if world == 1 else None,
-                         "traffic_source": "profiles/r1_lda_k50_pmc.txt (rocprofv3 --pmc, separate passes; 2*FETCH_SIZE+WRITE_SIZE summed over all dispatches of the E-step's kernels in one iteration)",
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel_source_hash": kernel_source_hash(),
                          "algorithmic_bytes_per_estep": b_e, "estep_ms": ms,
                          "estep_ms_min": float(np.min(estep_ms)), "estep_ms_max": float(np.max(estep_ms)),
                          "launches_per_estep": n_launch,
                          "whole_iteration_GBs": (b_e + mstep_bytes(K, V)) / (elapsed / args.steps) / 1e9},
+            "cold_start": cold,
             "cpu_baseline": None,
         }
-    # time to ELBO plateau (second half of the BASELINE metric): fresh cold start, checkelbo=1, tol=1.0
+
+    # ---- time to ELBO plateau (second half of the BASELINE metric): fresh cold start, checkelbo=1, tol=1.0, the
+    # library's own train! loop (sharded through the communicator when N>1), in chunks so that the wall clock of the
+    # trajectory is known; the stop rule carries across chunks (every chunk re-evaluates its baseline ELBO)
     if not args.no_plateau:
-        eng2 = HipLDAEngine(shard, K, beta0, corpus.M, local_rank, distributed=(world > 1))
-        tr2 = ShardedLDA(eng2)
-        barrier()
-        t1 = time.perf_counter()
-        stamps = []
-        traj = tr2.train(iter=150, tol=1.0, checkelbo=1, K=K, on_iter=lambda k, e: stamps.append(time.perf_counter() - t1))
-        barrier()
-        t_plateau = time.perf_counter() - t1
-        if rank == 0:
-            result["elbo_plateau"] = {"seconds": t_plateau, "iterations": len(traj), "stop_rule": "delta_elbo < tol=1.0 (src/modelutils.jl:580)",
-                                      "elbo_first": traj[0], "elbo_last": traj[-1],
-                                      "elbo_vs_wallclock": [[round(stamps[i], 4), traj[i]] for i in sorted(set(list(range(0, len(traj), max(1, len(traj) // 12))) + [len(traj) - 1]))]}
+        eng2 = make_engine()
+        ar2, comm2 = attach_comm(eng2)
+        if world > 1 and comm2 is None:
+            log("elbo_plateau needs the in-library communicator; skipped")
+            if rank == 0:
+                result["elbo_plateau"] = None
+        else:
+            chunk, cap = 50, args.plateau_cap
+            h = eng2.model.handle
+            traj_all, stamps, reached = [], [], False
+            buf = np.full(chunk, np.nan)
+            done, base = C.c_int32(0), C.c_double(0.0)
+            barrier()
+            t1 = time.perf_counter()
+            t_prev = 0.0
+            while len(traj_all) < cap:
+                tm._lib.check(L.tmvb_lda_train(h, C.c_int32(chunk), C.c_double(1.0), C.c_int32(niter), C.c_double(ntol), C.c_int32(viter),
+                                               C.c_double(vtol), C.c_int32(1), buf.ctypes.data_as(C.POINTER(C.c_double)), C.byref(done), C.byref(base)))
+                now = time.perf_counter() - t1
+                nd = done.value
+                traj_all.extend(buf[:nd].tolist())
+                stamps.extend([t_prev + (now - t_prev) * (i + 1) / max(nd, 1) for i in range(nd)])
+                t_prev = now
+                if nd < chunk:
+                    reached = True
+                    break
+            barrier()
+            t_plateau = time.perf_counter() - t1
+            if rank == 0:
+                n = len(traj_all)
+                idx = sorted(set(list(range(0, n, max(1, n // 14))) + [n - 1]))
+                last_delta = traj_all[-1] - (traj_all[-2] if n > 1 else base.value)
+                result["elbo_plateau"] = {
+                    "reached": reached, "seconds": t_plateau, "iterations": n, "iteration_cap": cap,
+                    "stop_rule": "delta_elbo < tol=1.0, signed (check_elbo!, src/modelutils.jl:574-585), checkelbo=1",
+                    "last_delta": last_delta, "elbo_first": traj_all[0], "elbo_last": traj_all[-1],
+                    "seconds_per_checked_iteration": t_plateau / max(n, 1),
+                    "elbo_vs_wallclock": [[round(stamps[i], 4), traj_all[i]] for i in idx],
+                    "note": "wall clock includes one update_elbo! per iteration; timestamps are interpolated inside chunks of 50 iterations"}
+        if comm2 is not None:
+            eng2.model.set_comm(None, shard.M); comm2.close()
+        eng2.model.close(); del eng2
+
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(tm, corpus, K, beta0, args.warmup)
+            result["cpu_baseline"] = cpu_baseline(tm, corpus, K, beta0)
         print(json.dumps(result), flush=True)
+    if comm is not None:
+        eng.model.set_comm(None, shard.M); comm.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

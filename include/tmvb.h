@@ -212,8 +212,10 @@ int tmvb_lda_train_group(tmvb_lda* const* hs, int32_t n, int32_t iter, double to
                          int32_t viter, double vtol, int32_t checkelbo,
                          double* elbo_traj, int32_t* iters_done, double* elbo_baseline);
 
-/* Diagnostics: histogram of sweeps per document of the last E-step (hist[0..viter]). */
+/* Diagnostics: histogram of sweeps per document of the last E-step (hist[0..viter]), and the per-document counts
+ * themselves (out[M], corpus document order, saturating at 255). */
 int tmvb_lda_sweep_hist(tmvb_lda* h, int64_t* hist, int32_t nbins);
+int tmvb_lda_doc_sweeps(tmvb_lda* h, uint8_t* out);
 /* Number of kernel launches one tmvb_lda_estep issues (one per document-length bucket). */
 int tmvb_lda_estep_launches(tmvb_lda* h, int32_t* n);
 /* Timing of the last tmvb_lda_estep on the context's stream, from HIP events (ms). */
@@ -268,6 +270,7 @@ int tmvb_ctm_train_group(tmvb_ctm* const* hs, int32_t n, int32_t iter, double to
                          double* elbo_baseline);
 /* Diagnostics of the last E-step: sweeps-per-document histogram and total lambda-Newton steps. */
 int tmvb_ctm_sweep_hist(tmvb_ctm* h, int64_t* hist, int32_t nbins, int64_t* newton_steps);
+int tmvb_ctm_doc_sweeps(tmvb_ctm* h, uint8_t* out);
 int tmvb_ctm_last_estep_ms(tmvb_ctm* h, float* ms);
 
 /* ============================== CTPF (src/gpuCTPF.jl, oracle src/CTPF.jl) ============================== */
@@ -316,6 +319,7 @@ int tmvb_ctpf_set_comm(tmvb_ctpf* h, tmvb_comm* comm);
 int tmvb_ctpf_train_group(tmvb_ctpf* const* hs, int32_t n, int32_t iter, double tol, int32_t viter, double vtol,
                           int32_t checkelbo, double* elbo_traj, int32_t* iters_done, double* elbo_baseline);
 int tmvb_ctpf_sweep_hist(tmvb_ctpf* h, int64_t* hist, int32_t nbins);
+int tmvb_ctpf_doc_sweeps(tmvb_ctpf* h, uint8_t* out);
 int tmvb_ctpf_last_estep_ms(tmvb_ctpf* h, float* ms);
 /* Recommendation post-processing at the end of train!(model::CTPF) (src/CTPF.jl:379-399; src/gpuCTPF.jl:711-731 runs the
  * same code on the host).  From the resident state:

@@ -117,6 +117,30 @@ int orc_lda_estep(int64_t M, int64_t V, int64_t K,
     return 0;
 }
 
+/* Per-thread private statistics of the OpenMP E-step (K x V doubles each).  They are allocated ONCE and kept across
+ * calls: allocating and page-faulting nthreads x K x V x 8 bytes (648 MB at NSF K=50, 64 threads) in every iteration
+ * was a fixed cost several times the arithmetic (round-1 review), which made the CPU baseline look slower than it is. */
+static double** g_pool = NULL;
+static int g_pool_n = 0;
+static int64_t g_pool_len = 0;
+
+void orc_omp_pool_free(void)
+{
+    for (int t = 0; t < g_pool_n; ++t) free(g_pool[t]);
+    free(g_pool);
+    g_pool = NULL; g_pool_n = 0; g_pool_len = 0;
+}
+
+static int pool_reserve(int nt, int64_t len)
+{
+    if (g_pool && g_pool_n >= nt && g_pool_len >= len) return 0;
+    orc_omp_pool_free();
+    g_pool = (double**)calloc((size_t)nt, sizeof(double*));
+    if (!g_pool) return -1;
+    g_pool_n = nt; g_pool_len = len;
+    return 0;                            /* the buffers themselves are first-touched by their own threads */
+}
+
 int orc_lda_estep_omp(int64_t M, int64_t V, int64_t K,
                       const int64_t* doc_ptr, const int32_t* terms, const int32_t* counts,
                       int64_t d0, int64_t d1,
@@ -130,15 +154,18 @@ int orc_lda_estep_omp(int64_t M, int64_t V, int64_t K,
     if (nthreads > 0) omp_set_num_threads(nthreads);
     int64_t mx = max_doc_len(doc_ptr, d0, d1);
     int nt = omp_get_max_threads();
-    double** bts = (double**)calloc((size_t)nt, sizeof(double*));
+    if (pool_reserve(nt, K * V)) return -1;
+    double** bts = g_pool;
 #pragma omp parallel
     {
 #pragma omp single
         used = omp_get_num_threads();
         int tid = omp_get_thread_num();
         double* phi = (double*)malloc(sizeof(double) * (size_t)(K * mx));
-        double* bt = (double*)calloc((size_t)(K * V), sizeof(double));   /* private statistics */
-        bts[tid] = bt;
+        if (!bts[tid]) bts[tid] = (double*)malloc(sizeof(double) * (size_t)(K * V));   /* first call only */
+        double* bt = bts[tid];
+        memset(bt, 0, sizeof(double) * (size_t)(K * V));
+#pragma omp barrier
 #pragma omp for schedule(dynamic, 16)
         for (int64_t d = d0; d < d1; ++d) {
             int64_t off = doc_ptr[d], Nd = doc_ptr[d + 1] - off;
@@ -152,16 +179,15 @@ int orc_lda_estep_omp(int64_t M, int64_t V, int64_t K,
             }
         }
         free(phi);
-        /* parallel reduction of the private statistics over the K*V entries */
+        /* parallel reduction of the private statistics over the K*V entries (threads that joined the team) */
+        const int team = omp_get_num_threads();
 #pragma omp for schedule(static)
         for (int64_t q = 0; q < K * V; ++q) {
             double sacc = 0.0;
-            for (int t = 0; t < nt; ++t) if (bts[t]) sacc += bts[t][q];
+            for (int t = 0; t < team; ++t) sacc += bts[t][q];
             beta_temp[q] += sacc;
         }
-        free(bt);
     }
-    free(bts);
 #else
     (void)nthreads;
     orc_lda_estep(M, V, K, doc_ptr, terms, counts, d0, d1, alpha, beta, beta_temp,

@@ -57,6 +57,8 @@ int orc_lda_estep(int64_t M, int64_t V, int64_t K,
 
 /* Same E-step, OpenMP document-parallel with per-thread beta_temp (for the CPU timing
  * baseline only; summation order differs from the serial path). Returns threads used. */
+/* releases the per-thread statistics buffers the OpenMP E-steps keep between calls */
+void orc_omp_pool_free(void);
 int orc_lda_estep_omp(int64_t M, int64_t V, int64_t K,
                       const int64_t* doc_ptr, const int32_t* terms, const int32_t* counts,
                       int64_t d0, int64_t d1,

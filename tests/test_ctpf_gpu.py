@@ -53,16 +53,18 @@ def test_teacher_forced_step(tmvb, oracle, case):
         gm.estep(); gm.reduce_docs(); gm.mstep()
         sw = om.estep(); om.mstep()
         gm.update_host()
-        hist_g = gm.sweep_hist(); hist_o = np.bincount(sw, minlength=11)
-        if np.array_equal(hist_g, hist_o):                     # same per-document exit decisions
-            assert rel(gm.gimel, om.gimel) <= 5e-4, (it, "gimel")
-            assert rel(gm.zayin, om.zayin) <= 5e-4, (it, "zayin")
+        sw_g = gm.doc_sweeps()
+        same = sw_g == np.asarray(sw)
+        assert np.array_equal(gm.sweep_hist(), np.bincount(sw_g, minlength=11))
+        # documents whose exit sweep agrees with the oracle's are compared one by one; the others are counted
+        assert (~same).sum() <= 0.05 * gm.M, (it, int((~same).sum()))
+        assert rel(gm.gimel[:, same], om.gimel[:, same]) <= 5e-4, (it, "gimel")
+        assert rel(gm.zayin[:, same], om.zayin[:, same]) <= 5e-4, (it, "zayin")
+        if same.all():                                         # the globals see every document
             assert rel(gm.alef, om.alef) <= 5e-4, (it, "alef")
             assert rel(gm.he, om.he) <= 5e-4, (it, "he")
             for n in ("bet", "vav", "dalet", "het"):
                 assert rel(getattr(gm, n), getattr(om, n)) <= 1e-4, (it, n)
-        else:
-            assert np.abs(hist_g - hist_o).sum() <= 0.1 * gm.M
         assert rel(gm.alef_old, om.alef_old) <= 1e-6 and rel(gm.dalet_old, om.dalet_old) <= 1e-12
         assert np.all(gm.alef > 0) and np.all(gm.he > 0) and np.all(gm.gimel > 0) and np.all(gm.zayin > 0)
 

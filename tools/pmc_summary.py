@@ -33,6 +33,12 @@ def main():
         rows[k] = {"calls": max(f[1], w[1]), "iterations": iters, "fetch_kb_per_iteration": f[2] / iters,
                    "write_kb_per_iteration": w[2] / iters}
     if js:
+        # stamp the kernel sources the counters were collected on: bench.py reports roofline.traffic only when
+        # the stamp matches the sources of the running build (a stale summary yields null)
+        import os
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from bench import kernel_source_hash
+        rows["_meta"] = {"kernel_source_hash": kernel_source_hash(), "iterations": iters}
         json.dump(rows, open(js, "w"), indent=1)
 
 

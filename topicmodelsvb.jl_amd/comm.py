@@ -67,15 +67,22 @@ class Communicator:
         check(lib().tmvb_comm_create_host(ctx.handle, C.c_int32(nranks), C.c_int32(rank), cb, None, C.byref(h)))
         return cls(h, ctx, keep=cb)
 
+    _boot_count = 0
+
     @classmethod
-    def torch_bootstrap(cls, ctx, group=None):
-        """One process per GPU under torchrun: rank 0 draws the RCCL unique id, torch.distributed (any backend) carries
-        the 128 bytes to the other ranks, every rank joins with ncclCommInitRank inside the library."""
+    def torch_bootstrap(cls, ctx):
+        """One process per GPU under torchrun: rank 0 draws the RCCL unique id, the key-value store of the already
+        initialised torch.distributed default group (backend-independent) carries the 128 bytes to the other ranks,
+        every rank joins with ncclCommInitRank inside the library."""
         import torch.distributed as dist
-        rank, world = dist.get_rank(group), dist.get_world_size(group)
-        box = [cls.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0, group=group)
-        return cls.rccl(ctx, box[0], world, rank)
+        rank, world = dist.get_rank(), dist.get_world_size()
+        store = dist.distributed_c10d._get_default_store()
+        key = f"tmvb_rccl_unique_id_{cls._boot_count}"
+        cls._boot_count += 1
+        if rank == 0:
+            store.set(key, cls.unique_id())
+        uid = bytes(store.get(key))          # blocks until rank 0 has published it
+        return cls.rccl(ctx, uid, world, rank)
 
     def info(self):
         n, r, b = C.c_int32(0), C.c_int32(0), C.c_int32(0)

@@ -982,6 +982,17 @@ extern "C" int tmvb_ctm_train(tmvb_ctm* h, int32_t iter, double tol, int32_t nit
     return tmvb_ctm_train_group(&h, 1, iter, tol, niter, ntol, viter, vtol, checkelbo, elbo_traj, iters_done, elbo_baseline);
 }
 
+// per-document sweep counts of the last E-step (document order of the corpus), for parity tests that compare the
+// state of exactly those documents whose exit sweep agrees with the oracle's
+extern "C" int tmvb_ctm_doc_sweeps(tmvb_ctm* h, uint8_t* out)
+{
+    TMVB_REQUIRE(h && (out || h->M == 0), TMVB_EINVAL, "tmvb_ctm_doc_sweeps: NULL argument");
+    TMVB_HIP(hipSetDevice(h->ctx->device));
+    if (h->M) TMVB_HIP(hipMemcpyAsync(out, h->d_sweeps, (size_t)h->M, hipMemcpyDeviceToHost, h->ctx->stream));
+    TMVB_HIP(hipStreamSynchronize(h->ctx->stream));
+    return TMVB_OK;
+}
+
 extern "C" int tmvb_ctm_sweep_hist(tmvb_ctm* h, int64_t* hist, int32_t nbins, int64_t* newton_steps)
 {
     TMVB_REQUIRE(h && hist && nbins > 0, TMVB_EINVAL, "tmvb_ctm_sweep_hist: bad argument");

@@ -1034,6 +1034,17 @@ int tmvb_ctpf_view_of(tmvb_ctpf* h, tmvb_ctpf_view* v)
     return TMVB_OK;
 }
 
+// per-document sweep counts of the last E-step (document order of the corpus), for parity tests that compare the
+// state of exactly those documents whose exit sweep agrees with the oracle's
+extern "C" int tmvb_ctpf_doc_sweeps(tmvb_ctpf* h, uint8_t* out)
+{
+    TMVB_REQUIRE(h && (out || h->M == 0), TMVB_EINVAL, "tmvb_ctpf_doc_sweeps: NULL argument");
+    TMVB_HIP(hipSetDevice(h->ctx->device));
+    if (h->M) TMVB_HIP(hipMemcpyAsync(out, h->d_sweeps, (size_t)h->M, hipMemcpyDeviceToHost, h->ctx->stream));
+    TMVB_HIP(hipStreamSynchronize(h->ctx->stream));
+    return TMVB_OK;
+}
+
 extern "C" int tmvb_ctpf_sweep_hist(tmvb_ctpf* h, int64_t* hist, int32_t nbins)
 {
     TMVB_REQUIRE(h && hist && nbins > 0, TMVB_EINVAL, "tmvb_ctpf_sweep_hist: bad argument");

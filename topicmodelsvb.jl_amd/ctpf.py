@@ -159,6 +159,12 @@ class gpuCTPF:
         check(lib().tmvb_ctpf_sweep_hist(self.handle, h.ctypes.data_as(P_i64), C.c_int32(nbins)))
         return h
 
+    def doc_sweeps(self):
+        """Sweeps each document ran in the last E-step (uint8 per document, corpus order)."""
+        out = np.zeros(max(self.M, 1), dtype=np.uint8)
+        check(lib().tmvb_ctpf_doc_sweeps(self.handle, out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out[:self.M]
+
     def last_estep_ms(self) -> float:
         ms = C.c_float(0.0)
         check(lib().tmvb_ctpf_last_estep_ms(self.handle, C.byref(ms)))

@@ -263,6 +263,12 @@ class gpuLDA:
         check(lib().tmvb_lda_estep_launches(self.handle, C.byref(n)))
         return n.value
 
+    def doc_sweeps(self):
+        """Sweeps each document ran in the last E-step (uint8 per document, corpus order)."""
+        out = np.zeros(max(self.M, 1), dtype=np.uint8)
+        check(lib().tmvb_lda_doc_sweeps(self.handle, out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out[:self.M]
+
     def last_estep_ms(self) -> float:
         ms = C.c_float(0.0)
         check(lib().tmvb_lda_last_estep_ms(self.handle, C.byref(ms)))
