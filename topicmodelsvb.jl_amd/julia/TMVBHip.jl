@@ -1,28 +1,142 @@
 # TMVBHip.jl -- ccall shim: TopicModelsVB.jl's `@gpu train!` on libtmvb_hip.so (MI355X / gfx950).
 #
-# Drop this file into src/ and `include("TMVBHip.jl")` after gpuCTPF.jl (src/TopicModelsVB.jl:28).
-# It keeps the package's surface: `hipLDA <: TopicModel` has the fields of gpuLDA that `@gpu`,
-# `predict`, `topicdist`, `showtopics` read (src/gpuLDA.jl:6-21), `train!(::hipLDA; ...)` has the
-# signature and defaults of src/gpuLDA.jl:347, argument errors are ArgumentError, state errors
-# TopicModelError, corpus errors CorpusError.
+# Drop this file into src/ and `include("TMVBHip.jl")` after gpuCTPF.jl (src/TopicModelsVB.jl:28); `gpu_macro.jl`
+# (same directory) replaces `macro gpu` (src/macros.jl:106-284).  The shim keeps the package's surface:
+#   * hipLDA / hipCTM / hipCTPF <: TopicModel carry the fields that `@gpu`, `predict`, `topicdist`, `showtopics` read
+#     (src/gpuLDA.jl:6-21, src/gpuCTM.jl:6-24, src/gpuCTPF.jl:6-46);
+#   * one Julia function per device operator, as the reference has (src/gpuLDA.jl:132-340, src/gpuCTM.jl:166-480,
+#     src/gpuCTPF.jl:314-670) -- the per-document operator chain of a sweep is ONE fused kernel here, so
+#     update_phi!/update_gamma!/update_Elogtheta! (LDA), update_phi!/update_logzeta!/update_vsq!/update_lambda! (CTM) and
+#     update_xi!/update_phi!/update_zayin!/update_gimel! (CTPF) are reached through `update_estep!`;
+#   * train! has the signatures and defaults of src/gpuLDA.jl:347, src/gpuCTM.jl:487, src/gpuCTPF.jl:677; argument errors
+#     are ArgumentError, state errors TopicModelError, corpus errors CorpusError, with the reference's messages;
+#   * predict / topicdist methods for the hip types (src/modelutils.jl:831-913, :946-970);
+#   * NEW: document-sharded multi-GPU train! behind the same call -- `hipComm` wraps the library's communicator (RCCL
+#     over xGMI, or a host all-reduce callback), `train!(::Vector{hipLDA})` drives n GPUs from one host thread.
 #
-# NOTE: Julia is not installed in the build image of this repository, so this file has not been
-# executed there; every call it makes is mirrored (and tested on the GPU) by the Python host in
-# topicmodelsvb.jl_amd/lda.py through the same C ABI (include/tmvb.h).
+# NOTE: Julia is not installed in the build image of this repository, so this file has not been executed there.  Every
+# ccall below is checked against include/tmvb.h by tests/test_julia_shim_static.py (name, arity, argument classes), and
+# every call sequence is mirrored -- and tested on the GPU -- by the Python host in topicmodelsvb.jl_amd/*.py through
+# the same C ABI.
 
 const LIBTMVB = get(ENV, "TMVB_HIP_LIB", "libtmvb_hip.so")
 
-const TMVB_OK, TMVB_EINVAL, TMVB_ESHAPE, TMVB_ECORPUS = 0, 1, 2, 3
+const TMVB_OK, TMVB_EINVAL, TMVB_ESHAPE, TMVB_ECORPUS, TMVB_ENOMEM, TMVB_EHIP, TMVB_ENONFINITE, TMVB_ENODEVICE, TMVB_ERCCL = 0, 1, 2, 3, 4, 5, 6, 7, 8
+const TMVB_UNIQUE_ID_BYTES = 128
 
 function tmvb_check(rc::Integer)
 	rc == TMVB_OK && return nothing
 	msg = unsafe_string(ccall((:tmvb_last_error, LIBTMVB), Cstring, ()))
-	rc == TMVB_EINVAL  && throw(ArgumentError(msg))
-	rc == TMVB_ESHAPE  && throw(TopicModelError(msg))
-	rc == TMVB_ECORPUS && throw(CorpusError(msg))
-	rc == 6            && throw(TopicModelError(msg))   # TMVB_ENONFINITE
-	error("libtmvb_hip: " * msg)
+	rc == TMVB_EINVAL     && throw(ArgumentError(msg))
+	rc == TMVB_ESHAPE     && throw(TopicModelError(msg))
+	rc == TMVB_ENONFINITE && throw(TopicModelError(msg))
+	rc == TMVB_ECORPUS    && throw(CorpusError(msg))
+	rc == TMVB_ENOMEM     && throw(OutOfMemoryError())
+	error("libtmvb_hip (status $rc): " * msg)
 end
+
+# ---------------------------------------------------------------------------------------------- context and corpus
+
+"cl.create_compute_context() (src/gpuLDA.jl:64): one GPU + one in-order stream."
+function tmvb_context(device::Integer)
+	ctx = Ref{Ptr{Cvoid}}(C_NULL)
+	tmvb_check(ccall((:tmvb_ctx_create, LIBTMVB), Cint, (Int32, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), device, C_NULL, ctx))
+	return ctx[]
+end
+
+"Corpus half of update_buffer! (src/modelutils.jl:370-388, :438-472): flat 0-based CSR."
+function tmvb_upload_corpus(ctx::Ptr{Cvoid}, corp::Corpus)
+	M, V, U = size(corp)
+	doc_ptr = Int64[0; cumsum([length(doc.terms) for doc in corp])]
+	terms   = Int32.(reduce(vcat, [doc.terms for doc in corp]; init=Int[]) .- 1)
+	counts  = Int32.(reduce(vcat, [doc.counts for doc in corp]; init=Int[]))
+	rdr_ptr = Int64[0; cumsum([length(doc.readers) for doc in corp])]
+	readers = Int32.(reduce(vcat, [doc.readers for doc in corp]; init=Int[]) .- 1)
+	ratings = Int32.(reduce(vcat, [doc.ratings for doc in corp]; init=Int[]))
+	h = Ref{Ptr{Cvoid}}(C_NULL)
+	GC.@preserve doc_ptr terms counts rdr_ptr readers ratings begin
+		tmvb_check(ccall((:tmvb_corpus_create, LIBTMVB), Cint,
+			(Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Int64}, Ptr{Int32}, Ptr{Int32}, Ptr{Int64}, Ptr{Int32}, Ptr{Int32}, Ref{Ptr{Cvoid}}),
+			ctx, M, V, U, doc_ptr, terms, counts, U > 0 ? pointer(rdr_ptr) : C_NULL,
+			U > 0 ? pointer(readers) : C_NULL, U > 0 ? pointer(ratings) : C_NULL, h))
+	end
+	return h[]
+end
+
+tmvb_destroy_corpus(dcorp::Ptr{Cvoid}) = ccall((:tmvb_corpus_destroy, LIBTMVB), Cint, (Ptr{Cvoid},), dcorp)
+tmvb_destroy_context(ctx::Ptr{Cvoid}) = ccall((:tmvb_ctx_destroy, LIBTMVB), Cint, (Ptr{Cvoid},), ctx)
+
+cols(m::Matrix{Float64}) = [m[:,d] for d in 1:size(m, 2)]
+checkelbo_arg(checkelbo::Real) = checkelbo == Inf ? Int32(0) : Int32(checkelbo)
+
+function check_train_args(tols, iters, checkelbo)
+	all(tols .>= 0)														|| throw(ArgumentError("tolerance parameters must be nonnegative."))
+	all(iters .>= 0)													|| throw(ArgumentError("iteration parameters must be nonnegative."))
+	(isa(checkelbo, Integer) & (checkelbo > 0)) | (checkelbo == Inf)	|| throw(ArgumentError("checkelbo parameter must be a positive integer or Inf."))
+end
+
+"The printing half of check_elbo! (src/modelutils.jl:578-579); the first delta refers to the ELBO evaluated before the first iteration."
+function print_delbo(traj::Vector{Float64}, done::Integer, baseline::Float64)
+	prev = baseline
+	for k in 1:done
+		isnan(traj[k]) && continue
+		println(k, " ∆elbo: ", round(traj[k] - prev, digits=3))
+		prev = traj[k]
+	end
+end
+
+# ---------------------------------------------------------------------------------------------- communicator (new)
+# Document-sharded runs: every GPU holds a contiguous document shard; ONE all-reduce of the packed sufficient statistics
+# per outer iteration happens inside the library (include/tmvb.h, "communicator").
+
+mutable struct hipComm
+	handle::Ptr{Cvoid}
+	keep::Any                       # the @cfunction closure of a host transport must outlive the communicator
+end
+
+"128 bytes that rank 0 hands to every other rank (MPI.bcast, Distributed.jl, a file ...)."
+function tmvb_unique_id()
+	id = zeros(UInt8, TMVB_UNIQUE_ID_BYTES)
+	tmvb_check(ccall((:tmvb_comm_unique_id, LIBTMVB), Cint, (Ptr{UInt8},), id))
+	return id
+end
+
+"One process per GPU: ncclCommInitRank inside the library."
+function hipComm(ctx::Ptr{Cvoid}, unique_id::Vector{UInt8}, nranks::Integer, rank::Integer)
+	length(unique_id) == TMVB_UNIQUE_ID_BYTES || throw(ArgumentError("unique id must be $TMVB_UNIQUE_ID_BYTES bytes."))
+	h = Ref{Ptr{Cvoid}}(C_NULL)
+	tmvb_check(ccall((:tmvb_comm_create_rccl, LIBTMVB), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Int32, Int32, Ref{Ptr{Cvoid}}), ctx, unique_id, nranks, rank, h))
+	return finalizer(c -> ccall((:tmvb_comm_destroy, LIBTMVB), Cint, (Ptr{Cvoid},), c.handle), hipComm(h[], nothing))
+end
+
+"One host thread, n GPUs: ncclCommInitAll over the contexts of the given models."
+function hipComms(ctxs::Vector{Ptr{Cvoid}})
+	out = fill(C_NULL, length(ctxs))
+	tmvb_check(ccall((:tmvb_comm_create_rccl_all, LIBTMVB), Cint, (Ptr{Ptr{Cvoid}}, Int32, Ptr{Ptr{Cvoid}}), ctxs, length(ctxs), out))
+	return [finalizer(c -> ccall((:tmvb_comm_destroy, LIBTMVB), Cint, (Ptr{Cvoid},), c.handle), hipComm(h, nothing)) for h in out]
+end
+
+"""
+Host transport: `allreduce!(buf)` must leave the element-wise sum over all ranks in `buf` (a Vector{Float32} or
+Vector{Float64} view of pinned host memory), e.g. `buf -> MPI.Allreduce!(buf, +, comm)`.
+"""
+function hipComm(ctx::Ptr{Cvoid}, allreduce!::Function, nranks::Integer, rank::Integer)
+	function tramp(user::Ptr{Cvoid}, buf::Ptr{Cvoid}, count::Int64, dtype::Int32)::Cint
+		try
+			T = dtype == 0 ? Float32 : Float64
+			allreduce!(unsafe_wrap(Array, Ptr{T}(buf), count))
+			return Cint(0)
+		catch
+			return Cint(1)
+		end
+	end
+	cb = @cfunction($tramp, Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int32))
+	h = Ref{Ptr{Cvoid}}(C_NULL)
+	tmvb_check(ccall((:tmvb_comm_create_host, LIBTMVB), Cint, (Ptr{Cvoid}, Int32, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), ctx, nranks, rank, cb, C_NULL, h))
+	return finalizer(c -> ccall((:tmvb_comm_destroy, LIBTMVB), Cint, (Ptr{Cvoid},), c.handle), hipComm(h[], cb))
+end
+
+# ---------------------------------------------------------------------------------------------- LDA
 
 mutable struct hipLDA <: TopicModel
 	K::Int
@@ -42,39 +156,21 @@ mutable struct hipLDA <: TopicModel
 	ctx::Ptr{Cvoid}
 	dcorp::Ptr{Cvoid}
 	handle::Ptr{Cvoid}
+	comm::Union{hipComm, Nothing}
 end
 
-"Corpus half of update_buffer! (src/modelutils.jl:370-388): flat 0-based CSR."
-function tmvb_upload_corpus(ctx::Ptr{Cvoid}, corp::Corpus)
-	M, V, U = size(corp)
-	doc_ptr = Int64[0; cumsum([length(doc.terms) for doc in corp])]
-	terms   = Int32.(vcat([doc.terms for doc in corp]...) .- 1)
-	counts  = Int32.(vcat([doc.counts for doc in corp]...))
-	rdr_ptr = Int64[0; cumsum([length(doc.readers) for doc in corp])]
-	readers = Int32.(vcat([doc.readers for doc in corp]...) .- 1)
-	ratings = Int32.(vcat([doc.ratings for doc in corp]...))
-	h = Ref{Ptr{Cvoid}}(C_NULL)
-	GC.@preserve doc_ptr terms counts rdr_ptr readers ratings begin
-		tmvb_check(ccall((:tmvb_corpus_create, LIBTMVB), Cint,
-			(Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Int64}, Ptr{Int32}, Ptr{Int32}, Ptr{Int64}, Ptr{Int32}, Ptr{Int32}, Ref{Ptr{Cvoid}}),
-			ctx, M, V, U, doc_ptr, terms, counts, U > 0 ? pointer(rdr_ptr) : C_NULL,
-			U > 0 ? pointer(readers) : C_NULL, U > 0 ? pointer(ratings) : C_NULL, h))
-	end
-	return h[]
-end
-
+"gpuLDA(corp, K) (src/gpuLDA.jl:45-84), built from the host model whose state it takes over (src/macros.jl:113-134)."
 function hipLDA(model::LDA; device::Integer=0)
-	ctx = Ref{Ptr{Cvoid}}(C_NULL)
-	tmvb_check(ccall((:tmvb_ctx_create, LIBTMVB), Cint, (Int32, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), device, C_NULL, ctx))
-	dcorp = tmvb_upload_corpus(ctx[], model.corp)
+	ctx = tmvb_context(device)
+	dcorp = tmvb_upload_corpus(ctx, model.corp)
 	h = Ref{Ptr{Cvoid}}(C_NULL)
-	tmvb_check(ccall((:tmvb_lda_create, LIBTMVB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Ref{Ptr{Cvoid}}), ctx[], dcorp, model.K, h))
+	tmvb_check(ccall((:tmvb_lda_create, LIBTMVB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Ref{Ptr{Cvoid}}), ctx, dcorp, model.K, h))
 	m = hipLDA(model.K, model.M, model.V, model.N, model.C, model.corp, model.topics, model.alpha, model.beta,
-		model.beta_old, model.Elogtheta, model.Elogtheta_old, model.gamma, model.elbo, ctx[], dcorp, h[])
+		model.beta_old, model.Elogtheta, model.Elogtheta_old, model.gamma, model.elbo, ctx, dcorp, h[], nothing)
 	finalizer(m) do x
 		ccall((:tmvb_lda_destroy, LIBTMVB), Cint, (Ptr{Cvoid},), x.handle)
-		ccall((:tmvb_corpus_destroy, LIBTMVB), Cint, (Ptr{Cvoid},), x.dcorp)
-		ccall((:tmvb_ctx_destroy, LIBTMVB), Cint, (Ptr{Cvoid},), x.ctx)
+		tmvb_destroy_corpus(x.dcorp)
+		tmvb_destroy_context(x.ctx)
 	end
 	return m
 end
@@ -100,13 +196,12 @@ function update_host!(model::hipLDA)
 		(Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Float64}),
 		model.handle, alpha, beta, beta_old, gamma, El, Elo, elbo))
 	model.alpha, model.beta, model.beta_old = alpha, beta, beta_old
-	model.gamma = [gamma[:,d] for d in 1:M]
-	model.Elogtheta = [El[:,d] for d in 1:M]
-	model.Elogtheta_old = [Elo[:,d] for d in 1:M]
+	model.gamma, model.Elogtheta, model.Elogtheta_old = cols(gamma), cols(El), cols(Elo)
 	model.elbo = elbo[]
 end
 
 # one Julia function per device operator, as in src/gpuLDA.jl:132-340
+"update_phi! / update_gamma! / update_Elogtheta! sweeps + update_beta!(model, d) of every document (src/LDA.jl:170-180)."
 update_estep!(model::hipLDA, viter::Integer, vtol::Real) = tmvb_check(ccall((:tmvb_lda_estep, LIBTMVB), Cint, (Ptr{Cvoid}, Int32, Float64), model.handle, viter, vtol))
 update_Elogtheta_sum!(model::hipLDA) = tmvb_check(ccall((:tmvb_lda_reduce_docs, LIBTMVB), Cint, (Ptr{Cvoid},), model.handle))
 update_beta!(model::hipLDA) = tmvb_check(ccall((:tmvb_lda_update_beta, LIBTMVB), Cint, (Ptr{Cvoid},), model.handle))
@@ -117,36 +212,77 @@ function update_elbo!(model::hipLDA)
 	model.elbo = e[]
 end
 
+"Attach a communicator: this model's corpus is one document shard of a corpus of M_total documents."
+function set_comm!(model::hipLDA, comm::Union{hipComm, Nothing}, M_total::Integer)
+	tmvb_check(ccall((:tmvb_lda_set_comm, LIBTMVB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64), model.handle, comm === nothing ? C_NULL : comm.handle, M_total))
+	model.comm = comm
+	nothing
+end
+
 """
     train!(model::hipLDA; iter=150, tol=1.0, niter=1000, ntol=1/K^2, viter=10, vtol=1/K^2, checkelbo=1, printelbo=true)
 
-Same signature and semantics as train!(::gpuLDA) (src/gpuLDA.jl:347-376) with the CPU path's
-per-document exit rule (src/LDA.jl:175).
+Same signature as train!(::gpuLDA) (src/gpuLDA.jl:347-376), semantics of the CPU path (src/LDA.jl:161-187: per-document
+exit rule :175).  With a communicator attached every rank calls it with the same arguments (document-sharded train!).
 """
 function train!(model::hipLDA; iter::Integer=150, tol::Real=1.0, niter::Integer=1000, ntol::Real=1/model.K^2, viter::Integer=10, vtol::Real=1/model.K^2, checkelbo::Real=1, printelbo::Bool=true)
-	all([tol, ntol, vtol] .>= 0)										|| throw(ArgumentError("tolerance parameters must be nonnegative."))
-	all([iter, niter, viter] .>= 0)										|| throw(ArgumentError("iteration parameters must be nonnegative."))
-	(isa(checkelbo, Integer) & (checkelbo > 0)) | (checkelbo == Inf)	|| throw(ArgumentError("checkelbo parameter must be a positive integer or Inf."))
+	check_train_args([tol, ntol, vtol], [iter, niter, viter], checkelbo)
 	update_buffer!(model)
-	traj = fill(NaN, max(iter, 1)); done = Ref{Int32}(0)
+	traj = fill(NaN, max(iter, 1)); done = Ref{Int32}(0); base = Ref{Float64}(model.elbo)
 	tmvb_check(ccall((:tmvb_lda_train, LIBTMVB), Cint,
-		(Ptr{Cvoid}, Int32, Float64, Int32, Float64, Int32, Float64, Int32, Ptr{Float64}, Ref{Int32}),
-		model.handle, iter, tol, niter, ntol, viter, vtol, checkelbo == Inf ? 0 : Int(checkelbo), traj, done))
-	if printelbo
-		prev = model.elbo
-		for k in 1:done[]
-			isnan(traj[k]) && continue
-			println(k, " ∆elbo: ", round(traj[k] - prev, digits=3)); prev = traj[k]
-		end
-	end
+		(Ptr{Cvoid}, Int32, Float64, Int32, Float64, Int32, Float64, Int32, Ptr{Float64}, Ref{Int32}, Ref{Float64}),
+		model.handle, iter, tol, niter, ntol, viter, vtol, checkelbo_arg(checkelbo), traj, done, base))
+	printelbo && print_delbo(traj, done[], base[])
 	(iter > 0) && update_host!(model)
 	model.topics = [reverse(sortperm(vec(model.beta[i,:]))) for i in 1:model.K]
 	nothing
 end
 
+"""
+    train!(models::Vector{hipLDA}; kwargs...)
+
+One host thread, n GPUs: models[i] holds the i-th document shard on device i and the i-th communicator of
+`hipComms([m.ctx for m in models])` (attach with set_comm!).  The n all-reduces of an iteration form one RCCL group.
+"""
+function train!(models::Vector{hipLDA}; iter::Integer=150, tol::Real=1.0, niter::Integer=1000, ntol::Real=1/models[1].K^2, viter::Integer=10, vtol::Real=1/models[1].K^2, checkelbo::Real=1, printelbo::Bool=true)
+	check_train_args([tol, ntol, vtol], [iter, niter, viter], checkelbo)
+	foreach(update_buffer!, models)
+	hs = Ptr{Cvoid}[m.handle for m in models]
+	traj = fill(NaN, max(iter, 1)); done = Ref{Int32}(0); base = Ref{Float64}(models[1].elbo)
+	tmvb_check(ccall((:tmvb_lda_train_group, LIBTMVB), Cint,
+		(Ptr{Ptr{Cvoid}}, Int32, Int32, Float64, Int32, Float64, Int32, Float64, Int32, Ptr{Float64}, Ref{Int32}, Ref{Float64}),
+		hs, length(hs), iter, tol, niter, ntol, viter, vtol, checkelbo_arg(checkelbo), traj, done, base))
+	printelbo && print_delbo(traj, done[], base[])
+	for m in models
+		(iter > 0) && update_host!(m)
+		m.topics = [reverse(sortperm(vec(m.beta[i,:]))) for i in 1:m.K]
+	end
+	nothing
+end
+
+"predict (src/modelutils.jl:831-855) on the device: the fused E-step with the trained alpha / beta frozen, no M-step."
+function predict(corp::Corpus, train_model::hipLDA; iter::Integer=10, tol::Real=1/train_model.K^2)
+	check_corp(corp)
+	(corp.vocab == train_model.corp.vocab)	|| throw(CorpusError("predict corpus and train_model corpus must have identical vocabularies."))
+	(tol >= 0)								|| throw(ArgumentError("tolerance parameter must be nonnegative."))
+	(iter >= 0)								|| throw(ArgumentError("iteration parameter must be nonnegative."))
+	host = LDA(corp, train_model.K)
+	host.alpha, host.beta, host.beta_old, host.topics = train_model.alpha, train_model.beta, copy(train_model.beta), train_model.topics
+	dev = hipLDA(host)
+	update_buffer!(dev)
+	update_estep!(dev, iter, tol)
+	update_host!(dev)
+	host.gamma, host.Elogtheta, host.Elogtheta_old = dev.gamma, dev.Elogtheta, dev.Elogtheta_old
+	return host
+end
+
+function topicdist(model::hipLDA, d::Integer)       # src/modelutils.jl:946-951
+	(d <= length(model.corp)) || throw(CorpusError("document index outside corpus range."))
+	return model.gamma[d] / sum(model.gamma[d])
+end
+
 # ---------------------------------------------------------------------------------------------- CTM
-# gpuCTM replacement (src/gpuCTM.jl:6-98).  Same pattern as hipLDA: the handle owns the device state, the Julia
-# fields are the host copies that update_buffer!/update_host! move.
+# gpuCTM replacement (src/gpuCTM.jl:6-98).
 
 mutable struct hipCTM <: TopicModel
 	K::Int; M::Int; V::Int; N::Vector{Int}; C::Vector{Int}
@@ -156,41 +292,67 @@ mutable struct hipCTM <: TopicModel
 	lambda::VectorList{Float64}; lambda_old::VectorList{Float64}; vsq::VectorList{Float64}; logzeta::Vector{Float64}
 	elbo::Float64
 	ctx::Ptr{Cvoid}; dcorp::Ptr{Cvoid}; handle::Ptr{Cvoid}
+	comm::Union{hipComm, Nothing}
 end
 
 function hipCTM(model::CTM; device::Integer=0)
-	ctx = Ref{Ptr{Cvoid}}(C_NULL); h = Ref{Ptr{Cvoid}}(C_NULL)
-	tmvb_check(ccall((:tmvb_ctx_create, LIBTMVB), Cint, (Int32, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), device, C_NULL, ctx))
-	dcorp = tmvb_upload_corpus(ctx[], model.corp)
-	tmvb_check(ccall((:tmvb_ctm_create, LIBTMVB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Ref{Ptr{Cvoid}}), ctx[], dcorp, model.K, h))
+	ctx = tmvb_context(device)
+	dcorp = tmvb_upload_corpus(ctx, model.corp)
+	h = Ref{Ptr{Cvoid}}(C_NULL)
+	tmvb_check(ccall((:tmvb_ctm_create, LIBTMVB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Ref{Ptr{Cvoid}}), ctx, dcorp, model.K, h))
 	m = hipCTM(model.K, model.M, model.V, model.N, model.C, model.corp, model.topics, model.mu, Matrix(model.sigma),
-		Matrix(model.invsigma), model.beta, copy(model.beta), model.lambda, deepcopy(model.lambda), model.vsq, model.logzeta,
-		model.elbo, ctx[], dcorp, h[])
+		Matrix(model.invsigma), model.beta, model.beta_old, model.lambda, model.lambda_old, model.vsq, model.logzeta,
+		model.elbo, ctx, dcorp, h[], nothing)
 	finalizer(m) do x
 		ccall((:tmvb_ctm_destroy, LIBTMVB), Cint, (Ptr{Cvoid},), x.handle)
-		ccall((:tmvb_corpus_destroy, LIBTMVB), Cint, (Ptr{Cvoid},), x.dcorp)
-		ccall((:tmvb_ctx_destroy, LIBTMVB), Cint, (Ptr{Cvoid},), x.ctx)
+		tmvb_destroy_corpus(x.dcorp)
+		tmvb_destroy_context(x.ctx)
 	end
-	m
+	return m
 end
 
-function update_buffer!(model::hipCTM)      # src/modelutils.jl:400-436
-	lam = hcat(model.lambda...); vsq = hcat(model.vsq...); elbo = Ref(model.elbo)
-	GC.@preserve model lam vsq tmvb_check(ccall((:tmvb_ctm_set_state, LIBTMVB), Cint,
-		(Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Float64}),
-		model.handle, model.mu, model.sigma, model.invsigma, model.beta, C_NULL, lam, C_NULL, vsq, model.logzeta, elbo))
+"update_buffer! (src/modelutils.jl:400-436): beta_old / lambda_old travel too (update_elbo! rebuilds phi from them, src/CTM.jl:93)."
+function update_buffer!(model::hipCTM)
+	beta, beta_old = Matrix{Float64}(model.beta), Matrix{Float64}(model.beta_old)
+	lam, lam_old, vsq = hcat(model.lambda...), hcat(model.lambda_old...), hcat(model.vsq...)
+	elbo = Ref{Float64}(model.elbo)
+	GC.@preserve beta beta_old lam lam_old vsq begin
+		tmvb_check(ccall((:tmvb_ctm_set_state, LIBTMVB), Cint,
+			(Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Float64}),
+			model.handle, model.mu, model.sigma, model.invsigma, beta, beta_old, lam, lam_old, vsq, model.logzeta, elbo))
+	end
 end
 
 function update_host!(model::hipCTM)        # src/modelutils.jl:519-537
 	K, M, V = model.K, model.M, model.V
 	mu = zeros(K); sg = zeros(K, K); isg = zeros(K, K); beta = zeros(K, V); beta_old = zeros(K, V)
-	lam = zeros(K, M); lam_old = zeros(K, M); vsq = zeros(K, M); lz = zeros(M); elbo = Ref(0.0)
+	lam = zeros(K, M); lam_old = zeros(K, M); vsq = zeros(K, M); lz = zeros(M); elbo = Ref{Float64}(0.0)
 	tmvb_check(ccall((:tmvb_ctm_get_state, LIBTMVB), Cint,
 		(Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Float64}),
 		model.handle, mu, sg, isg, beta, beta_old, lam, lam_old, vsq, lz, elbo))
 	model.mu, model.sigma, model.invsigma, model.beta, model.beta_old = mu, sg, isg, beta, beta_old
-	model.lambda = [lam[:,d] for d in 1:M]; model.lambda_old = [lam_old[:,d] for d in 1:M]
-	model.vsq = [vsq[:,d] for d in 1:M]; model.logzeta = lz; model.elbo = elbo[]
+	model.lambda, model.lambda_old, model.vsq = cols(lam), cols(lam_old), cols(vsq)
+	model.logzeta = lz; model.elbo = elbo[]
+end
+
+# one Julia function per device operator (src/gpuCTM.jl:166-480)
+"update_phi! / update_logzeta! / update_vsq! / update_lambda! sweeps + update_beta!(model, d) of every document (src/CTM.jl:194-205)."
+update_estep!(model::hipCTM, niter::Integer, ntol::Real, viter::Integer, vtol::Real) = tmvb_check(ccall((:tmvb_ctm_estep, LIBTMVB), Cint, (Ptr{Cvoid}, Int32, Float64, Int32, Float64), model.handle, niter, ntol, viter, vtol))
+"sum_d lambda_d, sum_d vsq_d and the MFMA scatter matrix with the current (= previous) mu."
+update_doc_sums!(model::hipCTM) = tmvb_check(ccall((:tmvb_ctm_reduce_docs, LIBTMVB), Cint, (Ptr{Cvoid},), model.handle))
+update_beta!(model::hipCTM) = tmvb_check(ccall((:tmvb_ctm_update_beta, LIBTMVB), Cint, (Ptr{Cvoid},), model.handle))      # src/gpuCTM.jl:253
+update_sigma!(model::hipCTM) = tmvb_check(ccall((:tmvb_ctm_update_sigma, LIBTMVB), Cint, (Ptr{Cvoid},), model.handle))    # :200 -- before update_mu! (quirk Q2)
+update_mu!(model::hipCTM) = tmvb_check(ccall((:tmvb_ctm_update_mu, LIBTMVB), Cint, (Ptr{Cvoid},), model.handle))          # :166
+function update_elbo!(model::hipCTM)
+	e = Ref{Float64}(0.0)
+	tmvb_check(ccall((:tmvb_ctm_update_elbo, LIBTMVB), Cint, (Ptr{Cvoid}, Ref{Float64}), model.handle, e))
+	model.elbo = e[]
+end
+
+function set_comm!(model::hipCTM, comm::Union{hipComm, Nothing}, M_total::Integer)
+	tmvb_check(ccall((:tmvb_ctm_set_comm, LIBTMVB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64), model.handle, comm === nothing ? C_NULL : comm.handle, M_total))
+	model.comm = comm
+	nothing
 end
 
 """
@@ -199,17 +361,54 @@ end
 Signature of train!(::gpuCTM) (src/gpuCTM.jl:487-519), semantics of the CPU path (src/CTM.jl:185-213).
 """
 function train!(model::hipCTM; iter::Integer=150, tol::Real=1.0, niter::Integer=1000, ntol::Real=1/model.K^2, viter::Integer=10, vtol::Real=1/model.K^2, checkelbo::Real=1, printelbo::Bool=true)
-	all([tol, ntol, vtol] .>= 0)										|| throw(ArgumentError("tolerance parameters must be nonnegative."))
-	all([iter, niter, viter] .>= 0)										|| throw(ArgumentError("iteration parameters must be nonnegative."))
-	(isa(checkelbo, Integer) & (checkelbo > 0)) | (checkelbo == Inf)	|| throw(ArgumentError("checkelbo parameter must be a positive integer or Inf."))
+	check_train_args([tol, ntol, vtol], [iter, niter, viter], checkelbo)
 	update_buffer!(model)
-	traj = fill(NaN, max(iter, 1)); done = Ref{Int32}(0)
+	traj = fill(NaN, max(iter, 1)); done = Ref{Int32}(0); base = Ref{Float64}(model.elbo)
 	tmvb_check(ccall((:tmvb_ctm_train, LIBTMVB), Cint,
-		(Ptr{Cvoid}, Int32, Float64, Int32, Float64, Int32, Float64, Int32, Ptr{Float64}, Ref{Int32}),
-		model.handle, iter, tol, niter, ntol, viter, vtol, checkelbo == Inf ? 0 : Int(checkelbo), traj, done))
+		(Ptr{Cvoid}, Int32, Float64, Int32, Float64, Int32, Float64, Int32, Ptr{Float64}, Ref{Int32}, Ref{Float64}),
+		model.handle, iter, tol, niter, ntol, viter, vtol, checkelbo_arg(checkelbo), traj, done, base))
+	printelbo && print_delbo(traj, done[], base[])
 	(iter > 0) && update_host!(model)
 	model.topics = [reverse(sortperm(vec(model.beta[i,:]))) for i in 1:model.K]
 	nothing
+end
+
+function train!(models::Vector{hipCTM}; iter::Integer=150, tol::Real=1.0, niter::Integer=1000, ntol::Real=1/models[1].K^2, viter::Integer=10, vtol::Real=1/models[1].K^2, checkelbo::Real=1, printelbo::Bool=true)
+	check_train_args([tol, ntol, vtol], [iter, niter, viter], checkelbo)
+	foreach(update_buffer!, models)
+	hs = Ptr{Cvoid}[m.handle for m in models]
+	traj = fill(NaN, max(iter, 1)); done = Ref{Int32}(0); base = Ref{Float64}(models[1].elbo)
+	tmvb_check(ccall((:tmvb_ctm_train_group, LIBTMVB), Cint,
+		(Ptr{Ptr{Cvoid}}, Int32, Int32, Float64, Int32, Float64, Int32, Float64, Int32, Ptr{Float64}, Ref{Int32}, Ref{Float64}),
+		hs, length(hs), iter, tol, niter, ntol, viter, vtol, checkelbo_arg(checkelbo), traj, done, base))
+	printelbo && print_delbo(traj, done[], base[])
+	for m in models
+		(iter > 0) && update_host!(m)
+		m.topics = [reverse(sortperm(vec(m.beta[i,:]))) for i in 1:m.K]
+	end
+	nothing
+end
+
+"predict (src/modelutils.jl:886-913) on the device: the fused CTM E-step with mu / sigma / beta frozen."
+function predict(corp::Corpus, train_model::hipCTM; iter::Integer=10, tol::Real=1/train_model.K^2, niter::Integer=1000, ntol::Real=1/train_model.K^2)
+	check_corp(corp)
+	(corp.vocab == train_model.corp.vocab)	|| throw(CorpusError("predict corpus and train_model corpus must have identical vocabularies."))
+	all([tol, ntol] .>= 0)					|| throw(ArgumentError("tolerance parameters must be nonnegative."))
+	all([iter, niter] .>= 0)				|| throw(ArgumentError("iteration parameters must be nonnegative."))
+	host = CTM(corp, train_model.K)
+	host.mu, host.sigma, host.invsigma = train_model.mu, Symmetric(train_model.sigma), Symmetric(train_model.invsigma)
+	host.beta, host.beta_old, host.topics = train_model.beta, copy(train_model.beta), train_model.topics
+	dev = hipCTM(host)
+	update_buffer!(dev)
+	update_estep!(dev, niter, ntol, iter, tol)
+	update_host!(dev)
+	host.lambda, host.lambda_old, host.vsq, host.logzeta = dev.lambda, dev.lambda_old, dev.vsq, dev.logzeta
+	return host
+end
+
+function topicdist(model::hipCTM, d::Integer)       # src/modelutils.jl:953-958
+	(d <= length(model.corp)) || throw(CorpusError("document index outside corpus range."))
+	return additive_logistic(model.lambda[d] + 0.5 * model.vsq[d])
 end
 
 # ---------------------------------------------------------------------------------------------- CTPF
@@ -218,51 +417,86 @@ end
 
 mutable struct hipCTPF <: TopicModel
 	K::Int; M::Int; V::Int; U::Int
+	N::Vector{Int}; C::Vector{Int}; R::Vector{Int}
 	corp::Corpus; topics::VectorList{Int}
 	scores::Matrix{Float64}; libs::VectorList{Int}; drecs::VectorList{Int}; urecs::VectorList{Int}
 	hyper::Vector{Float64}                                   # a, b, c, d, e, f, g, h  (src/CTPF.jl:81)
-	alef::Matrix{Float64}; he::Matrix{Float64}
-	bet::Vector{Float64}; vav::Vector{Float64}; dalet::Vector{Float64}; het::Vector{Float64}
-	gimel::VectorList{Float64}; zayin::VectorList{Float64}
+	alef::Matrix{Float64}; alef_old::Matrix{Float64}; he::Matrix{Float64}; he_old::Matrix{Float64}
+	bet::Vector{Float64}; bet_old::Vector{Float64}; vav::Vector{Float64}; vav_old::Vector{Float64}
+	dalet::Vector{Float64}; dalet_old::Vector{Float64}; het::Vector{Float64}; het_old::Vector{Float64}
+	gimel::VectorList{Float64}; gimel_old::VectorList{Float64}; zayin::VectorList{Float64}; zayin_old::VectorList{Float64}
 	elbo::Float64
 	ctx::Ptr{Cvoid}; dcorp::Ptr{Cvoid}; handle::Ptr{Cvoid}
+	comm::Union{hipComm, Nothing}
 end
 
 function hipCTPF(model::CTPF; device::Integer=0)
-	ctx = Ref{Ptr{Cvoid}}(C_NULL); h = Ref{Ptr{Cvoid}}(C_NULL)
-	tmvb_check(ccall((:tmvb_ctx_create, LIBTMVB), Cint, (Int32, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), device, C_NULL, ctx))
-	dcorp = tmvb_upload_corpus(ctx[], model.corp)
-	tmvb_check(ccall((:tmvb_ctpf_create, LIBTMVB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Ref{Ptr{Cvoid}}), ctx[], dcorp, model.K, h))
-	m = hipCTPF(model.K, model.M, model.V, model.U, model.corp, model.topics, model.scores, model.libs, model.drecs, model.urecs,
-		Float64[model.a, model.b, model.c, model.d, model.e, model.f, model.g, model.h], model.alef, model.he,
-		model.bet, model.vav, model.dalet, model.het, model.gimel, model.zayin, model.elbo, ctx[], dcorp, h[])
+	ctx = tmvb_context(device)
+	dcorp = tmvb_upload_corpus(ctx, model.corp)
+	h = Ref{Ptr{Cvoid}}(C_NULL)
+	tmvb_check(ccall((:tmvb_ctpf_create, LIBTMVB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Ref{Ptr{Cvoid}}), ctx, dcorp, model.K, h))
+	m = hipCTPF(model.K, model.M, model.V, model.U, model.N, model.C, model.R, model.corp, model.topics, model.scores, model.libs,
+		model.drecs, model.urecs, Float64[model.a, model.b, model.c, model.d, model.e, model.f, model.g, model.h],
+		model.alef, model.alef_old, model.he, model.he_old, model.bet, model.bet_old, model.vav, model.vav_old,
+		model.dalet, model.dalet_old, model.het, model.het_old, model.gimel, model.gimel_old, model.zayin, model.zayin_old,
+		model.elbo, ctx, dcorp, h[], nothing)
 	finalizer(m) do x
 		ccall((:tmvb_ctpf_destroy, LIBTMVB), Cint, (Ptr{Cvoid},), x.handle)
-		ccall((:tmvb_corpus_destroy, LIBTMVB), Cint, (Ptr{Cvoid},), x.dcorp)
-		ccall((:tmvb_ctx_destroy, LIBTMVB), Cint, (Ptr{Cvoid},), x.ctx)
+		tmvb_destroy_corpus(x.dcorp)
+		tmvb_destroy_context(x.ctx)
 	end
-	m
+	return m
 end
 
-function update_buffer!(model::hipCTPF)     # src/modelutils.jl:438-494
-	gim = hcat(model.gimel...); zay = hcat(model.zayin...); elbo = Ref(model.elbo)
-	GC.@preserve model gim zay tmvb_check(ccall((:tmvb_ctpf_set_state, LIBTMVB), Cint,
-		(Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Float64}),
-		model.handle, model.hyper, model.alef, model.he, model.bet, model.vav, model.dalet, model.het, gim, zay, elbo))
+"update_buffer! (src/modelutils.jl:438-494), the *_old fields included (update_elbo! rebuilds phi / xi from them, src/CTPF.jl:239-240)."
+function update_buffer!(model::hipCTPF)
+	gim, zay = hcat(model.gimel...), hcat(model.zayin...)
+	gim_old, zay_old = hcat(model.gimel_old...), hcat(model.zayin_old...)
+	elbo = Ref{Float64}(model.elbo)
+	GC.@preserve gim zay gim_old zay_old begin
+		tmvb_check(ccall((:tmvb_ctpf_set_state, LIBTMVB), Cint,
+			(Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Float64}),
+			model.handle, model.hyper, model.alef, model.he, model.bet, model.vav, model.dalet, model.het, gim, zay, elbo))
+		tmvb_check(ccall((:tmvb_ctpf_set_state_old, LIBTMVB), Cint,
+			(Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+			model.handle, model.alef_old, model.he_old, model.bet_old, model.vav_old, model.dalet_old, model.het_old, gim_old, zay_old))
+	end
 end
 
 function update_host!(model::hipCTPF)       # src/modelutils.jl:539-570
 	K, M, V, U = model.K, model.M, model.V, model.U
-	alef = zeros(K, V); he = zeros(K, U); rates = zeros(8K); gim = zeros(K, M); zay = zeros(K, M); elbo = Ref(0.0)
+	alef = zeros(K, V); alef_old = zeros(K, V); he = zeros(K, U); he_old = zeros(K, U); rates = zeros(8K)
+	gim = zeros(K, M); gim_old = zeros(K, M); zay = zeros(K, M); zay_old = zeros(K, M); elbo = Ref{Float64}(0.0)
 	tmvb_check(ccall((:tmvb_ctpf_get_state, LIBTMVB), Cint,
 		(Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Float64}),
-		model.handle, alef, C_NULL, he, C_NULL, rates, gim, C_NULL, zay, C_NULL, elbo))
-	model.alef, model.he = alef, he
+		model.handle, alef, alef_old, he, he_old, rates, gim, gim_old, zay, zay_old, elbo))
+	model.alef, model.alef_old, model.he, model.he_old = alef, alef_old, he, he_old
 	model.bet, model.vav, model.dalet, model.het = rates[1:K], rates[K+1:2K], rates[2K+1:3K], rates[3K+1:4K]
-	model.gimel = [gim[:,d] for d in 1:M]; model.zayin = [zay[:,d] for d in 1:M]; model.elbo = elbo[]
+	model.bet_old, model.vav_old, model.dalet_old, model.het_old = rates[4K+1:5K], rates[5K+1:6K], rates[6K+1:7K], rates[7K+1:8K]
+	model.gimel, model.gimel_old, model.zayin, model.zayin_old = cols(gim), cols(gim_old), cols(zay), cols(zay_old)
+	model.elbo = elbo[]
 end
 
-# scores / drecs / urecs of src/CTPF.jl:379-399 from the device-resident state (ids converted to 1-based)
+# one Julia function per device operator (src/gpuCTPF.jl:314-670)
+"update_xi! / update_phi! / update_zayin! / update_gimel! sweeps + update_he!(d) / update_alef!(d) of every document (src/CTPF.jl:353-365)."
+update_estep!(model::hipCTPF, viter::Integer, vtol::Real) = tmvb_check(ccall((:tmvb_ctpf_estep, LIBTMVB), Cint, (Ptr{Cvoid}, Int32, Float64), model.handle, viter, vtol))
+"sum_d gimel_d, sum_d zayin_d (inputs of update_bet! / update_vav!)."
+update_doc_sums!(model::hipCTPF) = tmvb_check(ccall((:tmvb_ctpf_reduce_docs, LIBTMVB), Cint, (Ptr{Cvoid},), model.handle))
+"update_he!, update_alef!, update_dalet!, update_het!, update_bet!, update_vav! in the reference's order (src/CTPF.jl:366-371)."
+update_globals!(model::hipCTPF) = tmvb_check(ccall((:tmvb_ctpf_mstep, LIBTMVB), Cint, (Ptr{Cvoid},), model.handle))
+function update_elbo!(model::hipCTPF)
+	e = Ref{Float64}(0.0)
+	tmvb_check(ccall((:tmvb_ctpf_update_elbo, LIBTMVB), Cint, (Ptr{Cvoid}, Ref{Float64}), model.handle, e))
+	model.elbo = e[]
+end
+
+function set_comm!(model::hipCTPF, comm::Union{hipComm, Nothing})
+	tmvb_check(ccall((:tmvb_ctpf_set_comm, LIBTMVB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), model.handle, comm === nothing ? C_NULL : comm.handle))
+	model.comm = comm
+	nothing
+end
+
+"scores / drecs / urecs of src/CTPF.jl:379-399 from the device-resident state (ids converted to 1-based)."
 function update_recs!(model::hipCTPF)
 	M, U = model.M, model.U
 	scores = zeros(M, U); dr = zeros(Int32, U, M); dc = zeros(Int32, M); ur = zeros(Int32, M, U); uc = zeros(Int32, U)
@@ -282,28 +516,21 @@ end
 Signature of train!(::gpuCTPF) (src/gpuCTPF.jl:677-733), semantics of the CPU path (src/CTPF.jl:344-400).
 """
 function train!(model::hipCTPF; iter::Integer=150, tol::Real=1.0, viter::Integer=10, vtol::Real=1/model.K^2, checkelbo::Real=Inf, printelbo::Bool=true)
-	all([tol, vtol] .>= 0)												|| throw(ArgumentError("tolerance parameters must be nonnegative."))
-	all([iter, viter] .>= 0)											|| throw(ArgumentError("iteration parameters must be nonnegative."))
-	(isa(checkelbo, Integer) & (checkelbo > 0)) | (checkelbo == Inf)	|| throw(ArgumentError("checkelbo parameter must be a positive integer or Inf."))
+	check_train_args([tol, vtol], [iter, viter], checkelbo)
 	update_buffer!(model)
-	traj = fill(NaN, max(iter, 1)); done = Ref{Int32}(0)
+	traj = fill(NaN, max(iter, 1)); done = Ref{Int32}(0); base = Ref{Float64}(model.elbo)
 	tmvb_check(ccall((:tmvb_ctpf_train, LIBTMVB), Cint,
-		(Ptr{Cvoid}, Int32, Float64, Int32, Float64, Int32, Ptr{Float64}, Ref{Int32}),
-		model.handle, iter, tol, viter, vtol, checkelbo == Inf ? 0 : Int(checkelbo), traj, done))
+		(Ptr{Cvoid}, Int32, Float64, Int32, Float64, Int32, Ptr{Float64}, Ref{Int32}, Ref{Float64}),
+		model.handle, iter, tol, viter, vtol, checkelbo_arg(checkelbo), traj, done, base))
+	printelbo && print_delbo(traj, done[], base[])
 	(iter > 0) && update_host!(model)
 	Ebeta = model.alef ./ model.bet
 	model.topics = [reverse(sortperm(vec(Ebeta[i,:]))) for i in 1:model.K]      # src/CTPF.jl:376-377
-	update_recs!(model)                                                         # :379-399
+	(model.comm === nothing) && update_recs!(model)                             # :379-399 (a shard ranks only its own documents)
 	nothing
 end
 
-# Inside `macro gpu` (src/macros.jl:113-150) the LDA branch becomes:
-#
-#     if isa(model, LDA)
-#         gpumodel = hipLDA(model)
-#         train!(gpumodel; kwargs...)
-#         model.topics, model.alpha, model.beta = gpumodel.topics, gpumodel.alpha, gpumodel.beta
-#         model.Elogtheta = gpumodel.Elogtheta;  model.Elogtheta_old = deepcopy(model.Elogtheta)
-#         model.gamma, model.elbo = gpumodel.gamma, gpumodel.elbo
-#         model.beta ./= sum(model.beta, dims=2);  model.beta_old = copy(model.beta)      # :147-148
-#         nothing
+function topicdist(model::hipCTPF, d::Integer)      # src/modelutils.jl:960-965
+	(d <= length(model.corp)) || throw(CorpusError("document index outside corpus range."))
+	return model.gimel[d] / sum(model.gimel[d])
+end
