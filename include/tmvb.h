@@ -225,8 +225,8 @@ int tmvb_lda_last_estep_ms(tmvb_lda* h, float* ms);
 
 /* gpuCTM(corp, K) (src/gpuCTM.jl:45-98).  Constructor state as src/CTM.jl:37-48 (mu=0, sigma=invsigma=I,
  * lambda=0, vsq=1, logzeta=0.5); beta is uniform until tmvb_ctm_set_state (the reference draws it with
- * Julia's RNG).  The lambda Newton systems are solved in registers with lane = matrix row, which limits this
- * release to K <= 60 (KP = 4*odd <= 60 lanes); larger K return TMVB_EINVAL. */
+ * Julia's RNG).  K <= 128.  For K <= 60 the lambda Newton systems are solved in registers (lane = matrix row); for
+ * 60 < K <= 128 the Newton matrix lives in LDS (two topic slots per lane) -- same arithmetic, slower per flop. */
 int tmvb_ctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb_ctm** out);
 int tmvb_ctm_destroy(tmvb_ctm* h);
 
@@ -277,7 +277,7 @@ int tmvb_ctm_last_estep_ms(tmvb_ctm* h, float* ms);
 
 /* gpuCTPF(corp, K) (src/gpuCTPF.jl:68-152).  Constructor state as src/CTPF.jl:81-100 (he=1, rates=1, gimel=zayin=1,
  * hyper-parameters a..h = 0.1); alef is 1 until tmvb_ctpf_set_state (the reference draws it with Julia's RNG, :83).
- * K <= 64 in this release. */
+ * K <= 128 (lane l owns topics l and l + 64); the register-tile fast path covers K <= 60. */
 int tmvb_ctpf_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb_ctpf** out);
 int tmvb_ctpf_destroy(tmvb_ctpf* h);
 /* update_buffer! state half (src/modelutils.jl:474-493).  hyper[8] = a..h; alef[K*V], he[K*U], bet/vav/dalet/het[K],

@@ -5,6 +5,7 @@ Tolerances (fp64 -> fp32 state; fp64 Newton gradients on device):
                                vsq rel <= 2e-3, logzeta abs <= 1e-3, beta rel <= 5e-4 on entries > 1e-6,
                                mu abs <= 1e-4, sigma abs <= 2e-4 * max|sigma|, ELBO rel <= 2e-6
   free running               : ELBO rel <= 2e-4 per iteration
+K <= 60 runs the register Gauss-Jordan kernel, 60 < K <= 128 the LDS Newton solve (ctm_estep_generic_kernel).
 """
 import os
 
@@ -50,9 +51,11 @@ def synth_case(tmvb, K, M=60, V=300, seed=3):
     return dict(K=K, V=V, doc_ptr=pc.doc_ptr, terms=pc.terms, counts=pc.counts, beta0=tmvb.dirichlet_rows(K, V, seed=5))
 
 
-@pytest.mark.parametrize("case", ["golden_k5", "syn_k3", "syn_k12", "syn_k17", "syn_k25", "syn_k33", "syn_k41", "syn_k50", "syn_k57"])
+@pytest.mark.parametrize("case", ["golden_k5", "syn_k3", "syn_k12", "syn_k17", "syn_k25", "syn_k33", "syn_k41", "syn_k50", "syn_k57",
+                                  "syn_k61", "syn_k64", "syn_k100", "syn_k128"])
 def test_teacher_forced_step(tmvb, oracle, case):
-    # one case per register Gauss-Jordan instantiation (KP = 4, 12, 20, 28, 36, 44, 52, 60)
+    # one case per register Gauss-Jordan instantiation (KP = 4, 12, 20, 28, 36, 44, 52, 60), then the LDS Newton solve
+    # of the K > 60 path with one (KP = 68 rows need two slots already) and two topic slots per lane
     g = load("ctm_m40_v60_k5") if case == "golden_k5" else synth_case(tmvb, int(case.split("_k")[1]))
     gm, om = make_pair(tmvb, oracle, g)
     for it in range(3):
@@ -103,6 +106,21 @@ def test_free_running_train_vs_golden(tmvb):
     assert np.abs(gm.beta - g["beta"]).max() <= 1e-3
 
 
+def test_k100_free_running_tracks_the_oracle(tmvb, oracle):
+    """K = 100 (beyond the reference-size K = 50; the OpenCL backend has no K cap, src/gpuCTM.jl:258-337): three free
+    running iterations through train! against the oracle."""
+    g = synth_case(tmvb, 100, M=80, V=400, seed=14)
+    gm, om = make_pair(tmvb, oracle, g)
+    traj = gm.train(iter=3, tol=0.0, checkelbo=1, printelbo=False)
+    for it in range(3):
+        step(om)
+    e_o = om.update_elbo()
+    assert abs(traj[-1] - e_o) <= 2e-4 * abs(e_o), (traj, e_o)
+    assert np.abs(gm.mu - om.mu).max() <= 5e-3
+    assert np.abs(gm.sigma - om.sigma).max() <= 5e-3 * np.abs(om.sigma).max()
+    np.linalg.cholesky(gm.sigma)
+
+
 def test_gpu_macro_round_trip_and_errors(tmvb):
     g = load("ctm_m40_v60_k5")
     K, V = int(g["K"]), int(g["V"])
@@ -115,7 +133,7 @@ def test_gpu_macro_round_trip_and_errors(tmvb):
     with pytest.raises(ValueError):
         tmvb.gpuCTM(pc, 0)
     with pytest.raises(ValueError):
-        tmvb.gpuCTM(pc, 61)                      # lane = matrix row: K <= 60 in this release
+        tmvb.gpuCTM(pc, 129)                     # two topic slots per lane: K <= 128
     gm = tmvb.gpuCTM(pc, K)
     with pytest.raises(ValueError):
         gm.train(niter=-1, printelbo=False)

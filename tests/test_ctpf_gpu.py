@@ -44,9 +44,10 @@ def synth_case(tmvb, K, M=80, V=300, U=60, seed=4):
                 ratings=ratings, alef0=np.exp(tmvb.dirichlet_rows(K, V, seed=6) - 0.5))
 
 
-@pytest.mark.parametrize("case", ["ctpf_m40_v60_u15_k4", "ctpf_m30_v40_u12_k6_r1", "syn_k12", "syn_k50"])
+@pytest.mark.parametrize("case", ["ctpf_m40_v60_u15_k4", "ctpf_m30_v40_u12_k6_r1", "syn_k12", "syn_k50", "syn_k64", "syn_k77", "syn_k100", "syn_k128"])
 def test_teacher_forced_step(tmvb, oracle, case):
-    g = load(case) if case.startswith("ctpf_") else synth_case(tmvb, 12 if case == "syn_k12" else 50)
+    # K = 100 is the reference's own published CTPF size (plots.R:4,17); K > 64 runs two topic slots per lane
+    g = load(case) if case.startswith("ctpf_") else synth_case(tmvb, int(case.split("_k")[1]))
     gm, om = make_pair(tmvb, oracle, g)
     for it in range(3):
         force(gm, om)
@@ -69,11 +70,11 @@ def test_teacher_forced_step(tmvb, oracle, case):
         assert np.all(gm.alef > 0) and np.all(gm.he > 0) and np.all(gm.gimel > 0) and np.all(gm.zayin > 0)
 
 
-@pytest.mark.parametrize("case", ["ctpf_m40_v60_u15_k4", "syn_k12", "syn_k50"])
+@pytest.mark.parametrize("case", ["ctpf_m40_v60_u15_k4", "syn_k12", "syn_k50", "syn_k100"])
 def test_device_elbo_matches_oracle(tmvb, oracle, case):
     """update_elbo! (src/CTPF.jl:234-247) on the device (Binomial sums cancelled analytically) vs the oracle's
     term-by-term evaluation, after one teacher-forced step with pinned sweep counts; rel <= 2e-5."""
-    g = load(case) if case.startswith("ctpf_") else synth_case(tmvb, 12 if case == "syn_k12" else 50, M=50, V=200, U=40)
+    g = load(case) if case.startswith("ctpf_") else synth_case(tmvb, int(case.split("_k")[1]), M=50, V=200, U=40)
     gm, om = make_pair(tmvb, oracle, g)
     for it in range(2):
         force(gm, om)
@@ -111,10 +112,29 @@ def test_free_running_train_vs_golden(tmvb, name):
         assert rel(getattr(m, n), g[n]) <= 2e-2, n
 
 
+def test_k100_train_and_recommend(tmvb, oracle):
+    """The reference's published CTPF configuration is K = 100: free-running train! against the oracle, then the
+    recommendation tail on the K = 100 state."""
+    g = synth_case(tmvb, 100, M=120, V=400, U=70, seed=12)
+    gm, om = make_pair(tmvb, oracle, g)
+    traj = gm.train(iter=4, tol=0.0, checkelbo=1, printelbo=False, recs=True)
+    for it in range(4):
+        om.estep(); om.mstep()
+    e_o = om.update_elbo()
+    assert abs(traj[-1] - e_o) <= 2e-3 * abs(e_o)
+    for n in ("bet", "vav", "dalet", "het"):
+        assert rel(getattr(gm, n), getattr(om, n)) <= 2e-2, n
+    sc = (om.gimel / om.dalet[:, None] + om.zayin / om.het[:, None]).T @ (om.he / om.vav[:, None])
+    assert np.abs(gm.scores - sc).max() <= 2e-2 * np.abs(sc).max()
+    assert len(gm.drecs) == gm.M and len(gm.urecs) == gm.U
+
+
 def test_errors(tmvb):
     pc = tmvb.syn_citeu(M=20, V=50, U=10, seed=1)
     with pytest.raises(ValueError):
         tmvb.gpuCTPF(pc, 0)
+    with pytest.raises(ValueError):
+        tmvb.gpuCTPF(pc, 129)                    # two topic slots per lane: K <= 128
     gm = tmvb.gpuCTPF(pc, 4)
     with pytest.raises(ValueError):
         gm.train(iter=2, checkelbo=0, printelbo=False)      # src/gpuCTPF.jl:681

@@ -18,6 +18,26 @@ HBM_PEAK_GBS = 8000.0
 F32_PEAK_TFLOPS = 157.3
 
 
+def cpu_line(kind, make, step, frac, sample_note, budget_s=12.0):
+    """cpu_baseline of a configuration: the fp64 C oracle (port of the reference's CPU path) on a bounded document sample
+    of the same workload, OpenMP document-parallel E-step on the CPUs this process may use (cgroup quota / affinity),
+    scaled to full-corpus iterations/s by the sample's share of the work (`frac`); one single-thread iteration beside it."""
+    from bench import usable_cpus
+    threads, info = usable_cpus()
+    m = make()
+    step(m, threads)                                    # warm-up: OpenMP start-up, first touch
+    t0 = time.perf_counter(); n = 0
+    while n < 4 and time.perf_counter() - t0 < budget_s / 2:
+        step(m, threads); n += 1
+    omp = n / (time.perf_counter() - t0)
+    m1 = make()
+    t1 = time.perf_counter(); step(m1, 0); one = 1.0 / (time.perf_counter() - t1)
+    return {"value": omp * frac, "unit": "VB iters/sec", "cores": threads, "host_cpus": info, "kind": "port",
+            "single_thread_value": one * frac,
+            "sample": f"fp64 C oracle ({kind}), {sample_note}; 1 warm-up + {n} timed iterations on {threads} OpenMP threads, "
+                      f"1 single-thread iteration; value = sample iters/s x work fraction {frac:.4f}"}
+
+
 def timed(fn, steps, warmup, sync):
     for _ in range(warmup):
         fn()
@@ -38,7 +58,14 @@ def lda100():
         gm.estep(10, 1.0 / K ** 2); gm.reduce_docs(); gm.update_beta(); gm.update_alpha(1000, 1.0 / K ** 2)
     sec = timed(it, 20, 3, gm.synchronize)
     B = pc.nnz * (8 + 8 * K) + 12 * pc.M * K + 12 * K * pc.V + 4 * (pc.M + 1)
-    return {"metric": "VB iters/sec, LDA K=100 on NSF-shaped corpus (config 3, one GPU)", "value": 1.0 / sec, "unit": "VB iters/sec",
+    from oracle import oracle as oc
+    sh = pc.shard(0, 24000)
+    beta0 = tm.dirichlet_rows(K, pc.V, seed=7)
+    def ostep(m, nt):
+        m.estep(omp_threads=nt); m.update_beta(); m.update_alpha()
+    cpu = cpu_line("port of src/LDA.jl train!", lambda: oc.LDA(oc.CSR(sh.doc_ptr, sh.terms, sh.counts, sh.V), K, beta0), ostep,
+                   sh.nnz / pc.nnz, f"first {sh.M} documents of SYN-NSF ({sh.nnz} of {pc.nnz} nnz), K=100, cold start")
+    return {"cpu_baseline": cpu, "metric": "VB iters/sec, LDA K=100 on NSF-shaped corpus (config 3, one GPU)", "value": 1.0 / sec, "unit": "VB iters/sec",
             "ms_per_step": 1e3 * sec, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "LDA K=100, SYN-NSF, train! defaults, cold start, 3 warm-up + 20 timed iterations", "M": pc.M, "V": pc.V, "nnz": pc.nnz},
             "roofline": {"bound": "hbm", "achieved": B / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": B / sec / 1e9 / HBM_PEAK_GBS,
@@ -57,7 +84,14 @@ def ctm():
     sweeps = int(sum(i * int(h) for i, h in enumerate(hist)))
     B = pc.nnz * (8 + 8 * K) + 16 * pc.M * K + 8 * pc.M + 12 * K * pc.V + 8 * K * K
     F = newton * (K ** 3 / 3.0 + 4 * K * K) + 6.0 * K * pc.nnz * (sweeps / pc.M)
-    return {"metric": "VB iters/sec, CTM K=50 on NSF-shaped corpus (config 4)", "value": 1.0 / sec, "unit": "VB iters/sec",
+    from oracle import oracle as oc
+    sh = pc.shard(0, 1500)
+    beta0 = tm.dirichlet_rows(K, pc.V, seed=7)
+    def ostep(m, nt):
+        m.estep(omp_threads=nt); m.update_beta(); m.update_sigma_mu()
+    cpu = cpu_line("port of src/CTM.jl train!", lambda: oc.CTM(oc.CSR(sh.doc_ptr, sh.terms, sh.counts, sh.V), K, beta0), ostep,
+                   sh.M / pc.M, f"first {sh.M} documents of SYN-NSF (the Newton solves scale with the document count), K=50, cold start")
+    return {"cpu_baseline": cpu, "metric": "VB iters/sec, CTM K=50 on NSF-shaped corpus (config 4)", "value": 1.0 / sec, "unit": "VB iters/sec",
             "ms_per_step": 1e3 * sec, "dtype": "f32 (fp64 gradients / logzeta / vsq)", "data": "synthetic",
             "config": {"workload": "CTM K=50, SYN-NSF, train! defaults (niter=1000 ntol=1/K^2 viter=10 vtol=1/K^2), cold start, 2 warm-up + 6 timed iterations",
                        "M": pc.M, "V": pc.V, "nnz": pc.nnz, "lambda_newton_steps_last_iteration": int(newton), "sweeps_last_iteration": sweeps},
@@ -75,7 +109,14 @@ def ctpf():
     sec = timed(it, 50, 5, gm.synchronize)
     B = pc.nnz * (8 + 8 * K) + pc.nR * (8 + 8 * K) + 16 * pc.M * K + 12 * K * (pc.V + pc.U)
     ms_s, ms_r = gm.recommend(scores=False)
-    return {"metric": "VB iters/sec, CTPF K=50 on CiteULike-shaped corpus (config 5)", "value": 1.0 / sec, "unit": "VB iters/sec",
+    from oracle import oracle as oc
+    sh = pc.shard(0, 3000)
+    alef0 = np.exp(tm.dirichlet_rows(K, pc.V, seed=7) - 0.5)
+    def ostep(m, nt):
+        m.estep(omp_threads=nt); m.mstep()
+    cpu = cpu_line("port of src/CTPF.jl train!", lambda: oc.CTPF(oc.CSR(sh.doc_ptr, sh.terms, sh.counts, sh.V, sh.rdr_ptr, sh.readers, sh.ratings, sh.U), K, alef0),
+                   ostep, (sh.nnz + sh.nR) / (pc.nnz + pc.nR), f"first {sh.M} documents of SYN-CITEU ({sh.nnz}+{sh.nR} of {pc.nnz}+{pc.nR} term+reader entries), K=50, cold start")
+    return {"cpu_baseline": cpu, "metric": "VB iters/sec, CTPF K=50 on CiteULike-shaped corpus (config 5)", "value": 1.0 / sec, "unit": "VB iters/sec",
             "ms_per_step": 1e3 * sec, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "CTPF K=50, SYN-CITEU with readers, train! defaults (viter=10 vtol=1/K^2 checkelbo=Inf), cold start, 5 warm-up + 50 timed iterations",
                        "M": pc.M, "V": pc.V, "U": pc.U, "nnz": pc.nnz, "nR": pc.nR},

@@ -130,6 +130,7 @@ extern "C" int tmvb_corpus_create(tmvb_ctx* ctx, int64_t M, int64_t V, int64_t U
         TMVB_REQUIRE(nR == 0 || (readers && ratings), TMVB_EINVAL, "tmvb_corpus_create: readers/ratings are NULL");
     }
     tmvb_corpus* c = new tmvb_corpus();
+    tmvb_create_guard<tmvb_corpus, tmvb_corpus_destroy> guard{c};      // every early return below destroys c
     c->ctx = ctx;
     tmvb_corpus_info_t& I = c->info;
     I.M = M; I.V = V; I.U = U; I.nnz = nnz; I.nR = nR;
@@ -201,7 +202,6 @@ extern "C" int tmvb_corpus_create(tmvb_ctx* ctx, int64_t M, int64_t V, int64_t U
         (rc = upload(ctx, &c->d_readers, readers, (size_t)nR)) != TMVB_OK ||
         (rc = upload(ctx, &c->d_ratings, ratings, (size_t)nR)) != TMVB_OK ||
         (rc = upload(ctx, &c->d_doc_order, c->h_doc_order.data(), (size_t)M)) != TMVB_OK) {
-        tmvb_corpus_destroy(c);
         return rc;
     }
     TMVB_HIP(hipStreamSynchronize(ctx->stream));
@@ -215,6 +215,7 @@ extern "C" int tmvb_corpus_create(tmvb_ctx* ctx, int64_t M, int64_t V, int64_t U
     } else {
         c->h_rdr_ptr.assign(M + 1, 0);
     }
+    guard.release();
     *out = c;
     return TMVB_OK;
 }

@@ -29,7 +29,7 @@
 
 #include <utility>
 
-#define CTM_MAX_K 64
+#define CTM_MAX_K 128
 
 struct CtmParams {
     int K, KP, LPR;
@@ -55,6 +55,7 @@ struct CtmParams {
     int viter;
     double vtol;
     int debug;                // TMVB_DEBUG_FLAGS (profiling experiments only): 1 = skip vsq Newton, 2 = diagonal solve instead of GJ
+    int store_w;              // KP > 128: the statistics pass reads stored per-token weights instead of recomputing them
 };
 
 __device__ __forceinline__ float readlane_f(float v, int l)
@@ -324,6 +325,265 @@ __global__ __launch_bounds__(64) void ctm_estep_kernel(CtmParams p, int64_t firs
     }
 }
 
+// ------------------------------------------------------------------------------ E-step kernel, any K <= 128
+// The register Gauss-Jordan above needs one lane per matrix row and KP VGPRs per row (K <= 60).  Larger models keep
+// the Newton matrix in LDS instead: lane l owns the topics / matrix rows l and l + 64 (NS = 2 slots), the K x K matrix
+// -H = invsigma + C_d Diag(e^{...}) (src/CTM.jl:135) is rebuilt in LDS at every Newton step (row stride KP = 4 * odd:
+// the lanes' ds_read_b128 of their own rows are conflict free, the pivot row is a uniform-address broadcast read) and
+// eliminated in place, one wave per document.  The topic tile is streamed through a fixed 32-row LDS window (gathered
+// again every sweep).  Same arithmetic, exit tests and fp64 gradients as ctm_estep_kernel; ~K^3 LDS traffic per solve
+// makes it several times slower per flop -- it is the K > 60 path, not the tuned one.
+#define CTM_GENERIC_TILE_ROWS 32
+static size_t ctm_generic_lds_bytes(int KP)
+{
+    return ((size_t)KP * KP + (size_t)CTM_GENERIC_TILE_ROWS * KP + 2 * (size_t)KP + 3 * CTM_GENERIC_TILE_ROWS) * sizeof(float) + (size_t)KP * sizeof(double);
+}
+
+template <int NS>
+__global__ __launch_bounds__(64) void ctm_estep_generic_kernel(CtmParams p, int64_t first)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x;
+    const int K = p.K, KP = p.KP, LPR = p.LPR;
+    constexpr int tile_rows = CTM_GENERIC_TILE_ROWS;
+    float* A = lds;                                     // [KP][KP] Newton matrix
+    float* Bt = A + (size_t)KP * KP;                    // [tile_rows][KP] topic tile window
+    float* e_l = Bt + (size_t)tile_rows * KP;           // [KP]
+    float* g_l = e_l + KP;                              // [KP] right-hand side of the solve
+    float* w_l = g_l + KP;                              // [tile_rows]
+    float* c_l = w_l + tile_rows;
+    int* t_l = (int*)(c_l + tile_rows);
+    double* dm_l = (double*)(t_l + tile_rows);          // [KP] mu - lambda (8-byte aligned: KP is a multiple of 4, so the float blocks above total a multiple of 8 floats)
+
+    const int d = p.doc_order[first + blockIdx.x];
+    const int64_t off = p.doc_ptr[d];
+    const int N = (int)(p.doc_ptr[d + 1] - off);
+
+    float cl = 0.0f;
+    for (int n = lane; n < N; n += 64) cl += (float)p.counts[off + n];
+    const double Cd = (double)wave_sum(cl);
+
+    bool on[NS], row[NS];
+    double isdiag[NS], mu[NS], lam[NS], vs[NS], lam_old[NS], phic[NS];
+    float e[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int i = lane + 64 * s;
+        on[s] = i < K; row[s] = on[s];          // the K x K system only: pad columns of invsigma are zero, pad rows are never touched
+        isdiag[s] = on[s] ? (double)p.invsigma[(size_t)i * KP + i] : 1.0;
+        mu[s] = on[s] ? (double)p.mu[i] : 0.0;
+        lam[s] = on[s] ? (double)p.lambda[(int64_t)d * K + i] : 0.0;
+        vs[s] = on[s] ? (double)p.vsq[(int64_t)d * K + i] : 1.0;
+        lam_old[s] = lam[s]; phic[s] = 0.0; e[s] = 0.0f;
+    }
+    double lz = (double)p.logzeta[d];
+
+    auto load_chunk = [&](int c0, int rows) {
+        for (int n = lane; n < rows; n += 64) {
+            t_l[n] = p.terms[off + c0 + n];
+            c_l[n] = (float)p.counts[off + c0 + n];
+        }
+        WAVE_LDS_FENCE();
+        const int nch = rows * LPR;
+        for (int f0 = 0; f0 < nch; f0 += 64) {
+            const int f = f0 + lane;
+            if (f < nch) {
+                const int n = (LPR == 1) ? f : (int)__umulhi((unsigned)f, p.lpr_magic);
+                const int c = f - n * LPR;
+                const float* src = p.beta + ((int64_t)t_l[n] * KP + 4 * c);
+                __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(Bt + (size_t)f0 * 4), 16, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        WAVE_LDS_FENCE();
+    };
+    auto phase1 = [&](int rows) {
+        const float4* er = (const float4*)e_l;
+        for (int n = lane; n < rows; n += 64) {
+            const float4* br = (const float4*)(Bt + (size_t)n * KP);
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            for (int q = 0; q < LPR; ++q) {
+                float4 b = br[q], ev = er[q];
+                s0 = fmaf(b.x, ev.x, s0); s1 = fmaf(b.y, ev.y, s1);
+                s2 = fmaf(b.z, ev.z, s2); s3 = fmaf(b.w, ev.w, s3);
+            }
+            w_l[n] = c_l[n] / ((s0 + s1) + (s2 + s3));
+        }
+        WAVE_LDS_FENCE();
+    };
+    const int r4 = lane & 3, ql = lane >> 2;
+    auto phase2 = [&](int rows, float4 (&acc)[NS]) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int q = ql + 16 * s;
+            if (q >= LPR) continue;
+            for (int n = r4; n < rows; n += 4) {
+                const float w = w_l[n];
+                const float4 b = *(const float4*)(Bt + (size_t)n * KP + 4 * q);
+                acc[s].x = fmaf(w, b.x, acc[s].x); acc[s].y = fmaf(w, b.y, acc[s].y);
+                acc[s].z = fmaf(w, b.z, acc[s].z); acc[s].w = fmaf(w, b.w, acc[s].w);
+            }
+        }
+    };
+
+    int sweeps = 0;
+    unsigned nsteps = 0;
+    for (int v = 0; v < p.viter; ++v) {
+        ++sweeps;
+        // update_phi!  src/CTM.jl:175-178, linear space (no epsilon)
+        float lml = -INFINITY;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) if (on[s]) lml = fmaxf(lml, (float)lam[s]);
+        const float lmax = wave_max(lml);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            e[s] = on[s] ? expf((float)lam[s] - lmax) : 0.0f;
+            if (on[s]) e_l[lane + 64 * s] = e[s];
+        }
+        for (int i = K + lane; i < KP; i += 64) e_l[i] = 0.0f;                          // pads
+        WAVE_LDS_FENCE();
+        float4 acc[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) acc[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int c0 = 0; c0 < N; c0 += tile_rows) {
+            const int rows = min(tile_rows, N - c0);
+            load_chunk(c0, rows);
+            phase1(rows);
+            if (p.store_w)                       // last executed sweep wins (the exit sweep is not known in advance)
+                for (int n = lane; n < rows; n += 64) p.wtok[p.tok_inv[off + c0 + n]] = w_l[n];
+            phase2(rows, acc);
+            WAVE_LDS_FENCE();
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            float4 a = dpp_add4<0xB1>(acc[s]);
+            a = dpp_add4<0x4E>(a);
+            const float gsel = (r4 == 0) ? a.x : (r4 == 1) ? a.y : (r4 == 2) ? a.z : a.w;
+            phic[s] = on[s] ? (double)(e[s] * gsel) : 0.0;                          // (phi * counts)_i
+        }
+        // update_logzeta!  :169-171
+        {
+            double xm = -INFINITY;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) if (on[s]) xm = fmax(xm, lam[s] + 0.5 * vs[s]);
+            const double m = wave_max_d(xm);
+            double sl = 0.0;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) if (on[s]) sl += exp(lam[s] + 0.5 * vs[s] - m);
+            lz = m + log(wave_sum_d(sl));
+        }
+        // update_vsq!  :146-165
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (!on[s]) continue;
+            for (int t = 0; t < p.niter; ++t) {
+                double rho = 1.0;
+                const double ex = exp(lam[s] + 0.5 * vs[s] - lz);
+                const double grad = -0.5 * (isdiag[s] + Cd * ex - 1.0 / vs[s]);
+                const double ihd = -1.0 / (0.25 * Cd * ex + 0.5 / (vs[s] * vs[s]));
+                const double pp = ihd * grad;
+                while (vs[s] - rho * pp <= 0.0) rho *= 0.5;
+                vs[s] -= rho * pp;
+                if (rho * fabs(grad) < p.ntol) break;
+            }
+            vs[s] += TMVB_EPS_D;
+        }
+        // update_lambda!  :129-142
+#pragma unroll
+        for (int s = 0; s < NS; ++s) lam_old[s] = lam[s];
+        for (int t = 0; t < p.niter; ++t) {
+            ++nsteps;
+            double ex[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                ex[s] = on[s] ? exp(lam[s] + 0.5 * vs[s] - lz) : 0.0;
+                if (on[s]) dm_l[lane + 64 * s] = mu[s] - lam[s];
+            }
+            for (int i = K + lane; i < KP; i += 64) dm_l[i] = 0.0;
+            // A <- invsigma (pads zero), row by row
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                if (!row[s]) continue;
+                const float4* src = (const float4*)(p.invsigma + (size_t)(lane + 64 * s) * KP);
+                float4* dst = (float4*)(A + (size_t)(lane + 64 * s) * KP);
+                for (int q = 0; q < LPR; ++q) dst[q] = src[q];
+            }
+            WAVE_LDS_FENCE();
+            double gn2l = 0.0;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                if (!row[s]) continue;
+                const int i = lane + 64 * s;
+                const float* ar = A + (size_t)i * KP;
+                double mv = 0.0;
+                for (int c = 0; c < KP; ++c) mv = fma((double)ar[c], dm_l[c], mv);      // invsigma (mu - lambda), fp64
+                const double gd = on[s] ? (mv + phic[s] - Cd * ex[s]) : 0.0;            // :134
+                gn2l += gd * gd;
+                g_l[i] = (float)gd;
+                A[(size_t)i * KP + i] += (float)(Cd * ex[s]);                           // -H = invsigma + C_d Diag(.)  :135
+            }
+            const double gn2 = wave_sum_d(gn2l);
+            WAVE_LDS_FENCE();
+            // Gauss-Jordan in LDS, no pivoting (SPD)
+            for (int j = 0; j < K; ++j) {
+                const float rp = fast_rcp(A[(size_t)j * KP + j]);
+                const float gj = g_l[j];
+                const int c0 = (j + 1) & ~3;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const int i = lane + 64 * s;
+                    if (!row[s] || i == j) continue;
+                    float* ar = A + (size_t)i * KP;
+                    const float nf = -ar[j] * rp;
+                    for (int c = c0; c < KP; c += 4) {
+                        const float4 pv = *(const float4*)(A + (size_t)j * KP + c);
+                        float4 av = *(float4*)(ar + c);
+                        av.x = fmaf(nf, pv.x, av.x); av.y = fmaf(nf, pv.y, av.y); av.z = fmaf(nf, pv.z, av.z); av.w = fmaf(nf, pv.w, av.w);
+                        *(float4*)(ar + c) = av;
+                    }
+                    for (int c = j + 1; c < c0; ++c) ar[c] = fmaf(nf, A[(size_t)j * KP + c], ar[c]);   // head of the row up to the aligned part
+                    g_l[i] = fmaf(nf, gj, g_l[i]);
+                }
+                WAVE_LDS_FENCE();
+            }
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int i = lane + 64 * s;
+                if (on[s]) lam[s] += (double)(g_l[i] * fast_rcp(A[(size_t)i * KP + i]));   // :136
+            }
+            WAVE_LDS_FENCE();
+            if (sqrt(gn2) < p.ntol) break;                                                  // :138
+        }
+        double d2l = 0.0;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) if (on[s]) { const double df = lam[s] - lam_old[s]; d2l += df * df; }
+        if (sqrt(wave_sum_d(d2l)) < p.vtol) break;                                          // :200
+    }
+
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int i = lane + 64 * s;
+        if (sweeps > 0) {
+            if (on[s]) {
+                p.lambda[(int64_t)d * K + i] = (float)lam[s];
+                p.lambda_old[(int64_t)d * K + i] = (float)lam_old[s];
+                p.vsq[(int64_t)d * K + i] = (float)vs[s];
+            }
+            if (on[s]) p.E[(int64_t)d * KP + i] = e[s];
+        } else if (on[s]) {
+            p.E[(int64_t)d * KP + i] = 0.0f;
+        }
+    }
+    for (int i = K + lane; i < KP; i += 64) p.E[(int64_t)d * KP + i] = 0.0f;              // pads
+    if (sweeps == 0 && p.store_w)
+        for (int n = lane; n < N; n += 64) p.wtok[p.tok_inv[off + n]] = 0.0f;             // viter = 0: no responsibilities
+    if (lane == 0) {
+        if (sweeps > 0) p.logzeta[d] = (float)lz;
+        p.sweeps[d] = (uint8_t)min(sweeps, 255);
+        if (p.newton_steps) atomicAdd(p.newton_steps, (unsigned long long)nsteps);
+    }
+}
+
 // ------------------------------------------------------------------------------ M-step: sigma
 // Scatter matrix sum_d (lambda_d - mu)(lambda_d - mu)^T on f32 MFMA.  X = Lambda - mu is K x M; a
 // wave owns a slab of documents and accumulates the 64 x 64 (padded) product in four
@@ -331,77 +591,74 @@ __global__ __launch_bounds__(64) void ctm_estep_kernel(CtmParams p, int64_t firs
 // A operand: lane l holds A[i = l & 31][k = l >> 5]; B operand: B[k = l >> 5][j = l & 31].
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// blockIdx.y = 32 x 32 tile (bi, bj) of the K x K product, NB = ceil(K / 32) tiles per side (any K <= 128)
 __global__ __launch_bounds__(64) void ctm_scatter_mfma_kernel(const float* __restrict__ lambda, const float* __restrict__ mu,
-                                                              int K, int64_t M, int64_t docs_per_wave,
-                                                              float* __restrict__ partial /* [nwaves][64*64] */)
+                                                              int K, int NB, int64_t M, int64_t docs_per_wave,
+                                                              float* __restrict__ partial /* [nwaves][NB*NB][32*32] */)
 {
     const int lane = threadIdx.x;
+    const int bi = blockIdx.y / NB, bj = blockIdx.y - bi * NB;
     const int64_t d0 = (int64_t)blockIdx.x * docs_per_wave;
     const int64_t d1 = min(M, d0 + docs_per_wave);
     const int i = lane & 31, kk = lane >> 5;
-    const float mu0 = (i < K) ? mu[i] : 0.0f;
-    const float mu1 = (32 + i < K) ? mu[32 + i] : 0.0f;
-    f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};
+    const int ri = 32 * bi + i, rj = 32 * bj + i;
+    const float mui = (ri < K) ? mu[ri] : 0.0f;
+    const float muj = (rj < K) ? mu[rj] : 0.0f;
+    f32x16 c = {0};
     for (int64_t d = d0; d < d1; d += 2) {
         const int64_t dd = d + kk;
-        float a0 = 0.0f, a1 = 0.0f;
+        float a = 0.0f, bq = 0.0f;
         if (dd < d1) {
-            if (i < K) a0 = lambda[dd * K + i] - mu0;
-            if (32 + i < K) a1 = lambda[dd * K + 32 + i] - mu1;
+            if (ri < K) a = lambda[dd * K + ri] - mui;
+            if (rj < K) bq = lambda[dd * K + rj] - muj;
         }
-        c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, a0, c00, 0, 0, 0);
-        c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, a1, c01, 0, 0, 0);
-        c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, a0, c10, 0, 0, 0);
-        c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, a1, c11, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, c, 0, 0, 0);
     }
     // C/D layout of 32x32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    float* out = partial + (size_t)blockIdx.x * 4096;
+    float* out = partial + ((size_t)blockIdx.x * NB * NB + blockIdx.y) * 1024;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = lane & 31;
-        out[row * 64 + col] = c00[r];
-        out[row * 64 + 32 + col] = c01[r];
-        out[(32 + row) * 64 + col] = c10[r];
-        out[(32 + row) * 64 + 32 + col] = c11[r];
+        out[row * 32 + col] = c[r];
     }
 }
 
-// scatter[i*K + j] = sum_w partial[w][i*64 + j]  (fixed order)
-__global__ __launch_bounds__(256) void ctm_scatter_reduce_kernel(const float* __restrict__ partial, int nwaves, int K,
+// scatter[i*K + j] = sum_w partial[w][tile(i,j)][(i % 32) * 32 + j % 32]  (fixed order)
+__global__ __launch_bounds__(256) void ctm_scatter_reduce_kernel(const float* __restrict__ partial, int nwaves, int K, int NB,
                                                                  float* __restrict__ scatter)
 {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= K * K) return;
     const int i = q / K, j = q - i * K;
+    const size_t tile = (size_t)(i >> 5) * NB + (j >> 5), in = (size_t)(i & 31) * 32 + (j & 31);
     double s = 0.0;
-    for (int w = 0; w < nwaves; ++w) s += (double)partial[(size_t)w * 4096 + i * 64 + j];
+    for (int w = 0; w < nwaves; ++w) s += (double)partial[((size_t)w * NB * NB + tile) * 1024 + in];
     scatter[q] = (float)s;
 }
 
 // update_sigma! (src/CTM.jl:108-111) then update_mu! (:102-104), one workgroup, fp64:
 // sigma = (diagm(sum vsq) + scatter) / M  (Symmetric() reads the upper triangle), invsigma = inv(sigma)
-// by Gauss-Jordan on [sigma | I] in LDS, logdet(invsigma) = -sum log pivots; mu = sum lambda / M.
+// by IN-PLACE Gauss-Jordan inversion in LDS (K x K doubles: 128 KiB at K = 128), logdet(invsigma) = -sum log pivots;
+// mu = sum lambda / M.
 __global__ __launch_bounds__(256) void ctm_sigma_mu_kernel(int K, int KP, double Md, const float* __restrict__ stats_tail,
                                                            double* __restrict__ sigma_d, double* __restrict__ invsigma_d,
                                                            float* __restrict__ invsigma_f, double* __restrict__ mu_d,
                                                            float* __restrict__ mu_f, double* __restrict__ logdet_inv,
                                                            int* __restrict__ status, int do_sigma, int do_mu)
 {
-    extern __shared__ double sm[];       // [K][2K] augmented
+    extern __shared__ double sm[];       // [K][K]
     const float* sum_lambda = stats_tail;
     const float* sum_vsq = stats_tail + K;
     const float* scatter = stats_tail + 2 * K;
     const int tid = threadIdx.x, nt = blockDim.x;
     if (do_sigma) {
-        const int W = 2 * K;
         for (int q = tid; q < K * K; q += nt) {
             const int i = q / K, j = q - i * K;
             const int a = min(i, j), b = max(i, j);            // upper triangle (a <= b)
             double v = (double)scatter[a * K + b];
             if (i == j) v += (double)sum_vsq[i];
             v /= Md;
-            sm[i * W + j] = v;
-            sm[i * W + K + j] = (i == j) ? 1.0 : 0.0;
+            sm[i * K + j] = v;
             sigma_d[j * K + i] = v;                            // column-major (symmetric anyway)
         }
         __syncthreads();
@@ -412,28 +669,30 @@ __global__ __launch_bounds__(256) void ctm_sigma_mu_kernel(int K, int KP, double
         __syncthreads();
         for (int j = 0; j < K; ++j) {
             if (tid == 0) {
-                const double pv = sm[j * W + j];
+                const double pv = sm[j * K + j];
                 piv_s = pv;
                 if (!(pv > 0.0)) bad_s = 1;
                 ld_s += log(pv);
+                sm[j * K + j] = 1.0;                            // the pivot column becomes the inverse's column
             }
             __syncthreads();
             const double rp = 1.0 / piv_s;
-            for (int c = tid; c < W; c += nt) sm[j * W + c] *= rp;          // normalise pivot row
+            for (int c = tid; c < K; c += nt) sm[j * K + c] *= rp;          // normalise pivot row
             __syncthreads();
-            for (int q = tid; q < K * W; q += nt) {
-                const int i = q / W, c = q - i * W;
-                if (i != j && c != j) sm[i * W + c] -= sm[i * W + j] * sm[j * W + c];
+            // row_i -= f_i row_j with f_i = a_ij taken before it is cleared; one thread owns (i, c) for all c of its stride
+            for (int q = tid; q < K * K; q += nt) {
+                const int i = q / K, c = q - i * K;
+                if (i != j && c != j) sm[i * K + c] -= sm[i * K + j] * sm[j * K + c];
             }
             __syncthreads();
-            for (int i = tid; i < K; i += nt) if (i != j) sm[i * W + j] = 0.0;
+            for (int i = tid; i < K; i += nt) if (i != j) sm[i * K + j] = -sm[i * K + j] * sm[j * K + j];
             __syncthreads();
         }
         for (int q = tid; q < KP * KP; q += nt) {
             const int i = q / KP, j = q - i * KP;
             float v = 0.0f;
             if (i < K && j < K) {
-                const double s = 0.5 * (sm[i * W + K + j] + sm[j * W + K + i]);   // inv(::Symmetric) is Symmetric
+                const double s = 0.5 * (sm[i * K + j] + sm[j * K + i]);   // inv(::Symmetric) is Symmetric
                 invsigma_d[j * K + i] = s;
                 v = (float)s;
             }
@@ -451,7 +710,8 @@ __global__ __launch_bounds__(256) void ctm_sigma_mu_kernel(int K, int KP, double
 }
 
 // ------------------------------------------------------------------------------ ELBO
-// update_elbo!  src/CTM.jl:89-98 per document (terms :56-86).  One wave per document, lane = topic.
+// update_elbo!  src/CTM.jl:89-98 per document (terms :56-86).  One wave per document, lane l owns topics l + 64 s.
+template <int NS>
 __global__ __launch_bounds__(64) void ctm_elbo_kernel(int K, int KP, const int64_t* __restrict__ doc_ptr,
                                                       const int32_t* __restrict__ terms, const int32_t* __restrict__ counts,
                                                       const double* __restrict__ mu_d, const double* __restrict__ invsigma_d,
@@ -465,36 +725,60 @@ __global__ __launch_bounds__(64) void ctm_elbo_kernel(int K, int KP, const int64
     const int d = blockIdx.x;
     const int64_t off = doc_ptr[d];
     const int N = (int)(doc_ptr[d + 1] - off);
-    const bool on = lane < K;
-    const float lo = on ? lambda_old[(int64_t)d * K + lane] : -INFINITY;
-    const float lmax = wave_max(lo);
-    const float eo = on ? expf(lo - lmax) : 0.0f;
-    const double l = on ? (double)lambda[(int64_t)d * K + lane] : 0.0;
-    const double v = on ? (double)vsq[(int64_t)d * K + lane] : 1.0;
+    bool on[NS]; int ix[NS];
+    float eo[NS];
+    double l[NS], v[NS], df[NS];
+    float lml = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        on[s] = lane + 64 * s < K;
+        ix[s] = on[s] ? lane + 64 * s : 0;
+        eo[s] = on[s] ? lambda_old[(int64_t)d * K + ix[s]] : -INFINITY;
+        lml = fmaxf(lml, eo[s]);
+    }
+    const float lmax = wave_max(lml);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        eo[s] = on[s] ? expf(eo[s] - lmax) : 0.0f;
+        l[s] = on[s] ? (double)lambda[(int64_t)d * K + ix[s]] : 0.0;
+        v[s] = on[s] ? (double)vsq[(int64_t)d * K + ix[s]] : 1.0;
+        df[s] = on[s] ? l[s] - mu_d[ix[s]] : 0.0;
+    }
     const double lz = (double)logzeta[d];
     double acc = 0.0, Cd = 0.0;
     for (int n = 0; n < N; ++n) {
         const int t = terms[off + n];
         const float c = (float)counts[off + n];
         Cd += (double)c;
-        const float x = on ? beta_old[(int64_t)t * KP + lane] * eo : 0.0f;           // :93
-        const float inv = 1.0f / wave_sum(x);
-        if (on) {
-            const float ph = x * inv;
+        float x[NS], xl = 0.0f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { x[s] = on[s] ? beta_old[(int64_t)t * KP + ix[s]] * eo[s] : 0.0f; xl += x[s]; }   // :93
+        const float inv = 1.0f / wave_sum(xl);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (!on[s]) continue;
+            const float ph = x[s] * inv;
             const double cp = (double)(c * ph);
-            acc += cp * l;                                                            // Elogpz :64 (first part)
-            acc += cp * (double)logf(beta[(int64_t)t * KP + lane] + TMVB_EPS_F);      // Elogpw :71
-            if (ph > 0.0f) acc -= cp * (double)logf(ph);                              // -Elogqz :84
+            acc += cp * l[s];                                                             // Elogpz :64 (first part)
+            acc += cp * (double)logf(beta[(int64_t)t * KP + ix[s]] + TMVB_EPS_F);         // Elogpw :71
+            if (ph > 0.0f) acc -= cp * (double)logf(ph);                                  // -Elogqz :84
         }
     }
     // Elogpeta :57
-    const double df = on ? l - mu_d[lane] : 0.0;
-    double mv = 0.0;
-    for (int j = 0; j < K; ++j) mv = fma(on ? invsigma_d[(int64_t)j * K + lane] : 0.0, readlane_d(df, j), mv);
-    if (on) {
-        acc += -0.5 * (invsigma_d[(int64_t)lane * K + lane] * v + df * mv);
-        acc -= Cd * exp(l + 0.5 * v - lz);                                            // Elogpz :64 (second part)
-        acc += 0.5 * log(v);                                                          // -Elogqeta :77
+    double mv[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) mv[s] = 0.0;
+    for (int j = 0; j < K; ++j) {
+        const double dj = (j < 64) ? readlane_d(df[0], j & 63) : readlane_d(df[NS - 1], j & 63);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) mv[s] = fma(on[s] ? invsigma_d[(int64_t)j * K + ix[s]] : 0.0, dj, mv[s]);
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        if (!on[s]) continue;
+        acc += -0.5 * (invsigma_d[(int64_t)ix[s] * K + ix[s]] * v[s] + df[s] * mv[s]);
+        acc -= Cd * exp(l[s] + 0.5 * v[s] - lz);                                          // Elogpz :64 (second part)
+        acc += 0.5 * log(v[s]);                                                           // -Elogqeta :77
     }
     double tot = wave_sum_d(acc);
     const double TWO_PI_LOG = 1.8378770664093453;   // log(2 pi)
@@ -526,6 +810,9 @@ struct tmvb_ctm {
     int64_t M = 0, V = 0, M_total = 0;
     bool distributed = false;
     tmvb_comm* comm = nullptr;         // document-sharded train!: the all-reduce of the packed statistics (not owned)
+    int nslot = 1;                     // topic slots per lane of the lane = topic kernels ((K + 63) / 64)
+    int NB = 2;                        // 32 x 32 tiles per side of the MFMA scatter product
+    bool generic = false;              // K > 60: LDS Newton solve (ctm_estep_generic_kernel)
     float* d_beta[2] = {nullptr, nullptr};
     int cur = 0;
     float* d_stats = nullptr;          // S (K*V) | sum_lambda (K) | sum_vsq (K) | scatter (K*K)
@@ -606,11 +893,13 @@ extern "C" int tmvb_ctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
     *out = nullptr;
     TMVB_REQUIRE(ctx && corp, TMVB_EINVAL, "tmvb_ctm_create: NULL context or corpus");
     TMVB_REQUIRE(K > 0, TMVB_EINVAL, "number of topics must be a positive integer.");       // src/gpuCTM.jl constructor
-    TMVB_REQUIRE(K <= CTM_MAX_K && ctm_kp_supported(tmvb_kpad(K)), TMVB_EINVAL,
-                 "tmvb_ctm_create: the register Gauss-Jordan kernel (lane = matrix row) supports K <= 60; got K=%d", K);
+    TMVB_REQUIRE(K <= CTM_MAX_K, TMVB_EINVAL, "tmvb_ctm_create: K <= %d (two topic slots per lane); got K=%d", CTM_MAX_K, K);
     TMVB_HIP(hipSetDevice(ctx->device));
     tmvb_ctm* h = new tmvb_ctm();
+    tmvb_create_guard<tmvb_ctm, tmvb_ctm_destroy> guard{h};      // every early return below destroys h
     h->ctx = ctx; h->corp = corp; h->K = K; h->KP = tmvb_kpad(K);
+    h->nslot = (K + 63) / 64; h->NB = (K + 31) / 32;
+    h->generic = !ctm_kp_supported(h->KP);          // the register Gauss-Jordan kernel holds one matrix row per lane: K <= 60
     h->M = corp->info.M; h->V = corp->info.V; h->M_total = h->M;
     const size_t KM = (size_t)K * h->M, KPV = (size_t)h->KP * h->V + 4;
     h->docs_per_wave = 256;
@@ -623,12 +912,11 @@ extern "C" int tmvb_ctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
         (rc = dmalloc(&h->d_ts_partial, (size_t)corp->term_index.n_slots * (K + 1))) ||
         (rc = dmalloc(&h->d_invsigma_f, (size_t)h->KP * h->KP)) || (rc = dmalloc(&h->d_mu_f, K)) ||
         (rc = dmalloc(&h->d_sigma, (size_t)K * K)) || (rc = dmalloc(&h->d_invsigma, (size_t)K * K)) || (rc = dmalloc(&h->d_mu, K)) ||
-        (rc = dmalloc(&h->d_logdet, 1)) || (rc = dmalloc(&h->d_scatter_partial, (size_t)h->n_scatter_waves * 4096)) ||
+        (rc = dmalloc(&h->d_logdet, 1)) || (rc = dmalloc(&h->d_scatter_partial, (size_t)h->n_scatter_waves * h->NB * h->NB * 1024)) ||
         (rc = dmalloc(&h->d_sweeps, (size_t)h->M)) || (rc = dmalloc(&h->d_doc_order, (size_t)h->M)) ||
         (rc = dmalloc(&h->d_partial, (size_t)TMVB_REDUCE_BLOCKS * K)) || (rc = dmalloc(&h->d_rowsum, K)) ||
         (rc = dmalloc(&h->d_doc_val, (size_t)h->M)) || (rc = dmalloc(&h->d_elbo, 1)) || (rc = dmalloc(&h->d_newton, 1)) ||
         (rc = dmalloc(&h->d_status, 1))) {
-        tmvb_ctm_destroy(h);
         return rc;
     }
     std::vector<int32_t> order((size_t)h->M);
@@ -656,7 +944,8 @@ extern "C" int tmvb_ctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
     for (int i = 0; i < K; ++i) eye[(size_t)i * K + i] = 1.0;
     std::vector<double> lam(KM, 0.0), vsq(KM, 1.0), lz((size_t)h->M, 0.5);
     rc = tmvb_ctm_set_state(h, mu.data(), eye.data(), eye.data(), beta.data(), nullptr, lam.data(), nullptr, vsq.data(), lz.data(), nullptr);
-    if (rc) { tmvb_ctm_destroy(h); return rc; }
+    if (rc) return rc;
+    guard.release();
     *out = h;
     return TMVB_OK;
 }
@@ -767,9 +1056,21 @@ extern "C" int tmvb_ctm_estep(tmvb_ctm* h, int32_t niter, double ntol, int32_t v
     p.wtok = h->d_wtok; p.E = h->d_E; p.sweeps = h->d_sweeps; p.newton_steps = h->d_newton;
     p.niter = niter; p.ntol = ntol; p.viter = viter; p.vtol = vtol;
     { const char* dbg = getenv("TMVB_DEBUG_FLAGS"); p.debug = dbg ? atoi(dbg) : 0; }
+    p.store_w = tmvb_termstats_recomputes(h->KP, true) ? 0 : 1;
     TMVB_HIP(hipEventRecord(h->ev0, ctx->stream));
     TMVB_HIP(hipMemsetAsync(h->d_newton, 0, sizeof(unsigned long long), ctx->stream));
-    const int nb = (int)h->buckets.size();
+    if (h->generic && h->M > 0) {
+        const size_t lds = ctm_generic_lds_bytes(h->KP);
+        auto launch = [&](auto kern) -> int {
+            TMVB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3((unsigned)h->M), dim3(64), lds, ctx->stream, p, (int64_t)0);
+            return TMVB_OK;
+        };
+        int lrc = (h->KP > 64) ? launch(ctm_estep_generic_kernel<2>) : launch(ctm_estep_generic_kernel<1>);
+        if (lrc) return lrc;
+        TMVB_HIP(hipGetLastError());
+    }
+    const int nb = h->generic ? 0 : (int)h->buckets.size();
     const int naux = std::min(nb, (int)tmvb_ctm::NAUX);
     if (naux > 1) {
         TMVB_HIP(hipEventRecord(h->ev_fork, ctx->stream));
@@ -803,7 +1104,7 @@ extern "C" int tmvb_ctm_estep(tmvb_ctm* h, int32_t niter, double ntol, int32_t v
     tp.K = h->K; tp.tstride = h->KP; tp.ostride = h->K;
     tp.w = h->d_wtok; tp.E = h->d_E; tp.T = h->d_beta[h->cur]; tp.eps = 0.0f; tp.base = 0.0f; tp.keps = 0.0f;
     tp.out = h->d_stats; tp.partial = h->d_ts_partial;
-    int rc = tmvb_launch_termstats(ctx, 1, h->KP, true, h->corp->term_index, tp);
+    int rc = tmvb_launch_termstats(ctx, h->nslot, h->KP, true, h->corp->term_index, tp);
     if (rc) return rc;
     TMVB_HIP(hipEventRecord(h->ev1, ctx->stream));
     h->timed = true;
@@ -817,14 +1118,14 @@ extern "C" int tmvb_ctm_reduce_docs(tmvb_ctm* h)
     tmvb_ctx* ctx = h->ctx;
     TMVB_HIP(hipSetDevice(ctx->device));
     int rc;
-    if ((rc = tmvb_colsum(ctx, 1, h->K, h->d_lambda, h->M, h->d_partial, nullptr, h->tail()))) return rc;
-    if ((rc = tmvb_colsum(ctx, 1, h->K, h->d_vsq, h->M, h->d_partial, nullptr, h->tail() + h->K))) return rc;
+    if ((rc = tmvb_colsum(ctx, h->nslot, h->K, h->d_lambda, h->M, h->d_partial, nullptr, h->tail()))) return rc;
+    if ((rc = tmvb_colsum(ctx, h->nslot, h->K, h->d_vsq, h->M, h->d_partial, nullptr, h->tail() + h->K))) return rc;
     if (h->M > 0) {
-        hipLaunchKernelGGL(ctm_scatter_mfma_kernel, dim3(h->n_scatter_waves), dim3(64), 0, ctx->stream, h->d_lambda, h->d_mu_f, h->K,
-                           h->M, h->docs_per_wave, h->d_scatter_partial);
+        hipLaunchKernelGGL(ctm_scatter_mfma_kernel, dim3(h->n_scatter_waves, h->NB * h->NB), dim3(64), 0, ctx->stream, h->d_lambda, h->d_mu_f,
+                           h->K, h->NB, h->M, h->docs_per_wave, h->d_scatter_partial);
         TMVB_HIP(hipGetLastError());
         hipLaunchKernelGGL(ctm_scatter_reduce_kernel, dim3((h->K * h->K + 255) / 256), dim3(256), 0, ctx->stream, h->d_scatter_partial,
-                           h->n_scatter_waves, h->K, h->tail() + 2 * h->K);
+                           h->n_scatter_waves, h->K, h->NB, h->tail() + 2 * h->K);
         TMVB_HIP(hipGetLastError());
     } else {
         TMVB_HIP(hipMemsetAsync(h->tail() + 2 * h->K, 0, (size_t)h->K * h->K * sizeof(float), ctx->stream));
@@ -867,7 +1168,7 @@ extern "C" int tmvb_ctm_update_beta(tmvb_ctm* h)
     TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_ctm_update_beta: handle is NULL");
     tmvb_ctx* ctx = h->ctx;
     TMVB_HIP(hipSetDevice(ctx->device));
-    int rc = tmvb_colsum(ctx, 1, h->K, h->d_stats, h->V, h->d_partial, h->d_rowsum, nullptr);
+    int rc = tmvb_colsum(ctx, h->nslot, h->K, h->d_stats, h->V, h->d_partial, h->d_rowsum, nullptr);
     if (rc) return rc;
     const int64_t total = (int64_t)h->KP * h->V;
     int nb = (int)std::min<int64_t>(2048, std::max<int64_t>(1, (total + 255) / 256));
@@ -882,7 +1183,8 @@ static int ctm_sigma_mu(tmvb_ctm* h, int do_sigma, int do_mu)
 {
     tmvb_ctx* ctx = h->ctx;
     TMVB_HIP(hipSetDevice(ctx->device));
-    const size_t lds = (size_t)h->K * 2 * h->K * sizeof(double);
+    const size_t lds = (size_t)h->K * h->K * sizeof(double);
+    if (lds > 48 * 1024) TMVB_HIP(hipFuncSetAttribute((const void*)ctm_sigma_mu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(ctm_sigma_mu_kernel, dim3(1), dim3(256), lds, ctx->stream, h->K, h->KP, (double)h->M_total, h->tail(),
                        h->d_sigma, h->d_invsigma, h->d_invsigma_f, h->d_mu, h->d_mu_f, h->d_logdet, h->d_status, do_sigma, do_mu);
     TMVB_HIP(hipGetLastError());
@@ -907,9 +1209,14 @@ extern "C" int tmvb_ctm_update_elbo(tmvb_ctm* h, double* elbo)
     tmvb_ctx* ctx = h->ctx;
     TMVB_HIP(hipSetDevice(ctx->device));
     if (h->M > 0) {
-        hipLaunchKernelGGL(ctm_elbo_kernel, dim3((unsigned)h->M), dim3(64), 0, ctx->stream, h->K, h->KP, h->corp->d_doc_ptr,
-                           h->corp->d_terms, h->corp->d_counts, h->d_mu, h->d_invsigma, h->d_logdet, h->d_beta[h->cur],
-                           h->d_beta[h->cur ^ 1], h->d_lambda, h->d_lambda_old, h->d_vsq, h->d_logzeta, h->d_doc_val);
+        if (h->nslot == 1)
+            hipLaunchKernelGGL((ctm_elbo_kernel<1>), dim3((unsigned)h->M), dim3(64), 0, ctx->stream, h->K, h->KP, h->corp->d_doc_ptr,
+                               h->corp->d_terms, h->corp->d_counts, h->d_mu, h->d_invsigma, h->d_logdet, h->d_beta[h->cur],
+                               h->d_beta[h->cur ^ 1], h->d_lambda, h->d_lambda_old, h->d_vsq, h->d_logzeta, h->d_doc_val);
+        else
+            hipLaunchKernelGGL((ctm_elbo_kernel<2>), dim3((unsigned)h->M), dim3(64), 0, ctx->stream, h->K, h->KP, h->corp->d_doc_ptr,
+                               h->corp->d_terms, h->corp->d_counts, h->d_mu, h->d_invsigma, h->d_logdet, h->d_beta[h->cur],
+                               h->d_beta[h->cur ^ 1], h->d_lambda, h->d_lambda_old, h->d_vsq, h->d_logzeta, h->d_doc_val);
         TMVB_HIP(hipGetLastError());
     }
     hipLaunchKernelGGL(sum_docs_kernel, dim3(1), dim3(1024), 0, ctx->stream, h->d_doc_val, h->M, h->d_elbo);

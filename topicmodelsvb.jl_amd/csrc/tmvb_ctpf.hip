@@ -45,9 +45,11 @@ struct CtpfParams {
     uint8_t* sweeps;
     int viter;
     float vtol;
+    int store_w;                // KP > 128: the statistics passes read stored weights instead of recomputing them
 };
 
-template <int LPR_T>
+// NS = topic slots per lane (lane l owns topics l, l + 64, ...): NS = 1 for K <= 64, NS = 2 for K <= 128.
+template <int LPR_T, int NS>
 __global__ __launch_bounds__(64) void ctpf_estep_kernel(CtpfParams p, int64_t first, int tile_rows)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -66,12 +68,18 @@ __global__ __launch_bounds__(64) void ctpf_estep_kernel(CtpfParams p, int64_t fi
     const int64_t off = p.doc_ptr[d], roff = p.rdr_ptr[d];
     const int N = (int)(p.doc_ptr[d + 1] - off), Rd = (int)(p.rdr_ptr[d + 1] - roff);
     const bool single = (N + Rd) <= tile_rows;     // both row sets stay resident in the tile
-    const bool on = lane < K;
 
-    const float lb = on ? p.lrates[lane] : 0.f, lv = on ? p.lrates[K + lane] : 0.f;
-    const float ld = on ? p.lrates[2 * K + lane] : 0.f, lh = on ? p.lrates[3 * K + lane] : 0.f;
-    float gim = on ? p.gimel[(int64_t)d * K + lane] : 1.0f, zay = on ? p.zayin[(int64_t)d * K + lane] : 1.0f;
-    float gim_old = gim, zay_old = zay, e = 0.f, ea = 0.f, eb = 0.f;
+    bool on[NS];
+    float lb[NS], lv[NS], ld[NS], lh[NS], gim[NS], zay[NS], gim_old[NS], zay_old[NS], e[NS], ea[NS], eb[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int i = lane + 64 * s;
+        on[s] = i < K;
+        lb[s] = on[s] ? p.lrates[i] : 0.f; lv[s] = on[s] ? p.lrates[K + i] : 0.f;
+        ld[s] = on[s] ? p.lrates[2 * K + i] : 0.f; lh[s] = on[s] ? p.lrates[3 * K + i] : 0.f;
+        gim[s] = on[s] ? p.gimel[(int64_t)d * K + i] : 1.0f; zay[s] = on[s] ? p.zayin[(int64_t)d * K + i] : 1.0f;
+        gim_old[s] = gim[s]; zay_old[s] = zay[s]; e[s] = 0.f; ea[s] = 0.f; eb[s] = 0.f;
+    }
 
     // rows [r0, r0+rows) of the tile <- table rows of ids[c0..c0+rows)
     auto load_rows = [&](const float* table, const int32_t* ids, const int32_t* vals, int64_t base, int c0, int rows, int r0) {
@@ -111,46 +119,63 @@ __global__ __launch_bounds__(64) void ctpf_estep_kernel(CtpfParams p, int64_t fi
         WAVE_LDS_FENCE();
     };
     const int r4 = lane & 3, ql = lane >> 2;
-    auto phase2 = [&](int rows, int r0, float4& acc) {
-        if (ql >= LPR) return;
+    auto phase2 = [&](int rows, int r0, float4 (&acc)[NS]) {
         const int nfull = rows >> 2;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int q = ql + 16 * s;                 // topic quad of slot s: topics 4 q .. 4 q + 3
+            if (q >= LPR) continue;
 #pragma unroll 4
-        for (int m = 0; m < nfull; ++m) {
-            const int n = r0 + 4 * m + r4;
-            const float w = w_l[n];
-            const float4 b = *(const float4*)(Bt + (size_t)n * KP + 4 * ql);
-            acc.x = fmaf(w, b.x, acc.x); acc.y = fmaf(w, b.y, acc.y); acc.z = fmaf(w, b.z, acc.z); acc.w = fmaf(w, b.w, acc.w);
-        }
-        const int n = 4 * nfull + r4;
-        if (n < rows) {
-            const float w = w_l[r0 + n];
-            const float4 b = *(const float4*)(Bt + (size_t)(r0 + n) * KP + 4 * ql);
-            acc.x = fmaf(w, b.x, acc.x); acc.y = fmaf(w, b.y, acc.y); acc.z = fmaf(w, b.z, acc.z); acc.w = fmaf(w, b.w, acc.w);
+            for (int m = 0; m < nfull; ++m) {
+                const int n = r0 + 4 * m + r4;
+                const float w = w_l[n];
+                const float4 b = *(const float4*)(Bt + (size_t)n * KP + 4 * q);
+                acc[s].x = fmaf(w, b.x, acc[s].x); acc[s].y = fmaf(w, b.y, acc[s].y); acc[s].z = fmaf(w, b.z, acc[s].z); acc[s].w = fmaf(w, b.w, acc[s].w);
+            }
+            const int n = 4 * nfull + r4;
+            if (n < rows) {
+                const float w = w_l[r0 + n];
+                const float4 b = *(const float4*)(Bt + (size_t)(r0 + n) * KP + 4 * q);
+                acc[s].x = fmaf(w, b.x, acc[s].x); acc[s].y = fmaf(w, b.y, acc[s].y); acc[s].z = fmaf(w, b.z, acc[s].z); acc[s].w = fmaf(w, b.w, acc[s].w);
+            }
         }
     };
-    auto quad_select = [&](float4 a) -> float {
+    auto quad_select = [&](float4 a) -> float {      // lane l ends with the sum for topic 4 (l >> 2) + (l & 3) = l of its slot
         a = dpp_add4<0xB1>(a);
         a = dpp_add4<0x4E>(a);
         return (r4 == 0) ? a.x : (r4 == 1) ? a.y : (r4 == 2) ? a.z : a.w;
     };
+    // KP > 128 only: per-token / per-reader weights of the last executed sweep for the stored-weight statistics kernels
     auto store_w = [&](float* dst, const int32_t* inv, int64_t base, int c0, int rows, int r0) {
-        (void)dst; (void)inv; (void)base; (void)c0; (void)rows; (void)r0;   // K <= 64: weights are recomputed by the statistics pass
+        if (!p.store_w) return;
+        for (int n = lane; n < rows; n += 64) dst[inv[base + c0 + n]] = w_l[r0 + n];
     };
 
     int sweeps = 0;
     for (int v = 0; v < p.viter; ++v) {
         ++sweeps;
-        const float dg = on ? digamma_f(gim) : 0.f, dz = on ? digamma_f(zay) : 0.f;
-        const float x = dg - ld - lb;                 // update_phi!  src/CTPF.jl:329
-        const float a = dg - ld - lv, b = dz - lh - lv;   // update_xi!  :336
-        const float mx = wave_max(on ? x : -INFINITY);
-        const float mab = wave_max(on ? fmaxf(a, b) : -INFINITY);
-        e = on ? expf(x - mx) : 0.f;
-        ea = on ? expf(a - mab) : 0.f;
-        eb = on ? expf(b - mab) : 0.f;
-        if (lane < KP) { e_l[lane] = e; f_l[lane] = ea + eb; }
+        float x[NS], a[NS], b[NS], mxl = -INFINITY, mabl = -INFINITY;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const float dg = on[s] ? digamma_f(gim[s]) : 0.f, dz = on[s] ? digamma_f(zay[s]) : 0.f;
+            x[s] = dg - ld[s] - lb[s];                                  // update_phi!  src/CTPF.jl:329
+            a[s] = dg - ld[s] - lv[s]; b[s] = dz - lh[s] - lv[s];       // update_xi!  :336
+            if (on[s]) { mxl = fmaxf(mxl, x[s]); mabl = fmaxf(mabl, fmaxf(a[s], b[s])); }
+        }
+        const float mx = wave_max(mxl);
+        const float mab = wave_max(mabl);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            e[s] = on[s] ? expf(x[s] - mx) : 0.f;
+            ea[s] = on[s] ? expf(a[s] - mab) : 0.f;
+            eb[s] = on[s] ? expf(b[s] - mab) : 0.f;
+            if (on[s]) { e_l[lane + 64 * s] = e[s]; f_l[lane + 64 * s] = ea[s] + eb[s]; }
+        }
+        for (int i = K + lane; i < KP; i += 64) { e_l[i] = 0.f; f_l[i] = 0.f; }           // pads
         WAVE_LDS_FENCE();
-        float4 accG = make_float4(0.f, 0.f, 0.f, 0.f), accH = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 accG[NS], accH[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { accG[s] = make_float4(0.f, 0.f, 0.f, 0.f); accH[s] = make_float4(0.f, 0.f, 0.f, 0.f); }
         if (single) {
             if (v == 0) {
                 if (N) load_rows(p.TA, p.terms, p.counts, off, 0, N, 0);
@@ -178,30 +203,41 @@ __global__ __launch_bounds__(64) void ctpf_estep_kernel(CtpfParams p, int64_t fi
                 WAVE_LDS_FENCE();
             }
         }
-        const float G = quad_select(accG), Hh = quad_select(accH);
-        zay_old = zay; gim_old = gim;
         float dl = 0.f;
-        if (on) {
-            zay = p.hg + eb * Hh;                      // update_zayin!  :322
-            gim = (p.hc + e * G) + ea * Hh;            // update_gimel!  :313
-            const float df = gim - gim_old;
-            dl = df * df;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const float G = quad_select(accG[s]), Hh = quad_select(accH[s]);
+            zay_old[s] = zay[s]; gim_old[s] = gim[s];
+            if (on[s]) {
+                zay[s] = p.hg + eb[s] * Hh;                       // update_zayin!  :322
+                gim[s] = (p.hc + e[s] * G) + ea[s] * Hh;          // update_gimel!  :313
+                const float df = gim[s] - gim_old[s];
+                dl = fmaf(df, df, dl);
+            }
         }
         if (__builtin_amdgcn_sqrtf(wave_sum(dl)) < p.vtol) break;       // :359
     }
 
-    if (sweeps > 0) {
-        if (on) {
-            p.gimel[(int64_t)d * K + lane] = gim; p.gimel_old[(int64_t)d * K + lane] = gim_old;
-            p.zayin[(int64_t)d * K + lane] = zay; p.zayin_old[(int64_t)d * K + lane] = zay_old;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int i = lane + 64 * s;
+        if (sweeps > 0) {
+            if (on[s]) {
+                p.gimel[(int64_t)d * K + i] = gim[s]; p.gimel_old[(int64_t)d * K + i] = gim_old[s];
+                p.zayin[(int64_t)d * K + i] = zay[s]; p.zayin_old[(int64_t)d * K + i] = zay_old[s];
+            }
+            if (on[s]) { p.E1[(int64_t)d * KP + i] = e[s]; p.E2[(int64_t)d * KP + i] = ea[s] + eb[s]; }
+        } else {
+            if (on[s]) { p.E1[(int64_t)d * KP + i] = 0.f; p.E2[(int64_t)d * KP + i] = 0.f; }   // viter = 0
         }
-        if (lane < KP) { p.E1[(int64_t)d * KP + lane] = e; p.E2[(int64_t)d * KP + lane] = ea + eb; }
-        if (single) {
-            store_w(p.wtok, p.tok_inv, off, 0, N, 0);
-            store_w(p.wrdr, p.rdr_inv, roff, 0, Rd, N);
-        }
-    } else {
-        if (lane < KP) { p.E1[(int64_t)d * KP + lane] = 0.f; p.E2[(int64_t)d * KP + lane] = 0.f; }   // viter = 0
+    }
+    for (int i = K + lane; i < KP; i += 64) { p.E1[(int64_t)d * KP + i] = 0.f; p.E2[(int64_t)d * KP + i] = 0.f; }   // pads
+    if (sweeps > 0 && single) {
+        store_w(p.wtok, p.tok_inv, off, 0, N, 0);
+        store_w(p.wrdr, p.rdr_inv, roff, 0, Rd, N);
+    } else if (sweeps == 0 && p.store_w) {
+        for (int n = lane; n < N; n += 64) p.wtok[p.tok_inv[off + n]] = 0.f;
+        for (int n = lane; n < Rd; n += 64) p.wrdr[p.rdr_inv[roff + n]] = 0.f;
     }
     if (lane == 0) p.sweeps[d] = (uint8_t)min(sweeps, 255);
 }
@@ -392,7 +428,8 @@ __device__ __forceinline__ double gamma_entropy_d(double a, double rate)   // en
     return a - log(rate) + lgamma(a) + (1.0 - a) * digamma_d(a);
 }
 
-// per-document part; one wave per document, lane = topic (K <= 64)
+// per-document part; one wave per document, lane l owns topics l + 64 s (NS slots)
+template <int NS>
 __global__ __launch_bounds__(64) void ctpf_elbo_doc_kernel(int K, const int64_t* __restrict__ doc_ptr, const int32_t* __restrict__ terms,
                                                            const int32_t* __restrict__ counts, const int64_t* __restrict__ rdr_ptr,
                                                            const int32_t* __restrict__ readers, const int32_t* __restrict__ ratings,
@@ -406,20 +443,27 @@ __global__ __launch_bounds__(64) void ctpf_elbo_doc_kernel(int K, const int64_t*
 {
     const int lane = threadIdx.x;
     const int d = blockIdx.x;
-    const bool on = lane < K;
-    const int i = on ? lane : 0;
-    const double bet = rates[i], vav = rates[K + i], dalet = rates[2 * K + i], het = rates[3 * K + i];
-    const double bet_o = rates[4 * K + i], vav_o = rates[5 * K + i], dalet_o = rates[6 * K + i], het_o = rates[7 * K + i];
-    const double gi = on ? (double)gimel[(int64_t)d * K + i] : 1.0, za = on ? (double)zayin[(int64_t)d * K + i] : 1.0;
-    const double gio = on ? (double)gimel_old[(int64_t)d * K + i] : 1.0, zao = on ? (double)zayin_old[(int64_t)d * K + i] : 1.0;
-    // softmax arguments rebuilt from the *_old variables (:240-241)
-    const float xo = (float)(digamma_d(gio) - log(dalet_o) - log(bet_o));
-    const float ao = (float)(digamma_d(gio) - log(dalet_o) - log(vav_o));
-    const float bo = (float)(digamma_d(zao) - log(het_o) - log(vav_o));
-    // log-rate parts of the current variables
-    const double lt = digamma_d(gi) - log(dalet);       // E[log theta]
-    const double le = digamma_d(za) - log(het);         // E[log epsilon]
-    const double lbet = log(bet), lvav = log(vav);
+    bool on[NS]; int ix[NS];
+    double bet[NS], vav[NS], dalet[NS], het[NS], gi[NS], za[NS], lt[NS], le[NS], lbet[NS], lvav[NS];
+    float xo[NS], ao[NS], bo[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        on[s] = lane + 64 * s < K;
+        const int i = on[s] ? lane + 64 * s : 0;
+        ix[s] = i;
+        bet[s] = rates[i]; vav[s] = rates[K + i]; dalet[s] = rates[2 * K + i]; het[s] = rates[3 * K + i];
+        const double bet_o = rates[4 * K + i], vav_o = rates[5 * K + i], dalet_o = rates[6 * K + i], het_o = rates[7 * K + i];
+        gi[s] = on[s] ? (double)gimel[(int64_t)d * K + i] : 1.0; za[s] = on[s] ? (double)zayin[(int64_t)d * K + i] : 1.0;
+        const double gio = on[s] ? (double)gimel_old[(int64_t)d * K + i] : 1.0, zao = on[s] ? (double)zayin_old[(int64_t)d * K + i] : 1.0;
+        // softmax arguments rebuilt from the *_old variables (:240-241)
+        xo[s] = (float)(digamma_d(gio) - log(dalet_o) - log(bet_o));
+        ao[s] = (float)(digamma_d(gio) - log(dalet_o) - log(vav_o));
+        bo[s] = (float)(digamma_d(zao) - log(het_o) - log(vav_o));
+        // log-rate parts of the current variables
+        lt[s] = digamma_d(gi[s]) - log(dalet[s]);       // E[log theta]
+        le[s] = digamma_d(za[s]) - log(het[s]);         // E[log epsilon]
+        lbet[s] = log(bet[s]); lvav[s] = log(vav[s]);
+    }
     double acc = 0.0;
     // tokens: Elogpz - Elogqz (without the cancelling Binomial sums)
     const int64_t off = doc_ptr[d];
@@ -427,13 +471,24 @@ __global__ __launch_bounds__(64) void ctpf_elbo_doc_kernel(int K, const int64_t*
     for (int n = 0; n < N; ++n) {
         const int t = terms[off + n];
         const double c = (double)counts[off + n];
-        const float x = on ? xo + digamma_f(alef_old[(int64_t)t * K + i]) : -INFINITY;
-        const float mx = wave_max(x);
-        const float ex = on ? expf(x - mx) : 0.0f;
-        const float ph = ex / wave_sum(ex);
-        if (on) {
-            acc += c * (double)ph * (lt + (double)digamma_f(alef[(int64_t)t * K + i]) - lbet);
-            if (ph > 0.0f) acc -= c * (double)ph * (double)logf(ph);          // + c H(phi_n)
+        float x[NS], ml = -INFINITY;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            x[s] = on[s] ? xo[s] + digamma_f(alef_old[(int64_t)t * K + ix[s]]) : -INFINITY;
+            ml = fmaxf(ml, x[s]);
+        }
+        const float mx = wave_max(ml);
+        float ex[NS], sl = 0.0f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { ex[s] = on[s] ? expf(x[s] - mx) : 0.0f; sl += ex[s]; }
+        const float inv = 1.0f / wave_sum(sl);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const float ph = ex[s] * inv;
+            if (on[s]) {
+                acc += c * (double)ph * (lt[s] + (double)digamma_f(alef[(int64_t)t * K + ix[s]]) - lbet[s]);
+                if (ph > 0.0f) acc -= c * (double)ph * (double)logf(ph);          // + c H(phi_n)
+            }
         }
         if (lane == 0) acc -= lgamma(c + 1.0);
     }
@@ -443,25 +498,42 @@ __global__ __launch_bounds__(64) void ctpf_elbo_doc_kernel(int K, const int64_t*
     for (int u = 0; u < Rd; ++u) {
         const int r = readers[roff + u];
         const double ra = (double)ratings[roff + u];
-        const float dho = on ? digamma_f(he_old[(int64_t)r * K + i]) : 0.0f;
-        const float a = on ? ao + dho : -INFINITY, b = on ? bo + dho : -INFINITY;
-        const float mx = wave_max(fmaxf(a, b));
-        const float ea = on ? expf(a - mx) : 0.0f, eb = on ? expf(b - mx) : 0.0f;
-        const float inv = 1.0f / wave_sum(ea + eb);
-        if (on) {
-            const double xt = (double)(ea * inv), xb = (double)(eb * inv);
-            const double dh = (double)digamma_f(he[(int64_t)r * K + i]);
-            acc += ra * xt * (lt + dh - lvav) + ra * xb * (le + dh - lvav);
-            if (xt > 0.0) acc -= ra * xt * log(xt);
-            if (xb > 0.0) acc -= ra * xb * log(xb);
+        float a[NS], b[NS], ml = -INFINITY;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const float dho = on[s] ? digamma_f(he_old[(int64_t)r * K + ix[s]]) : 0.0f;
+            a[s] = on[s] ? ao[s] + dho : -INFINITY; b[s] = on[s] ? bo[s] + dho : -INFINITY;
+            ml = fmaxf(ml, fmaxf(a[s], b[s]));
+        }
+        const float mx = wave_max(ml);
+        float ea[NS], eb[NS], sl = 0.0f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            ea[s] = on[s] ? expf(a[s] - mx) : 0.0f; eb[s] = on[s] ? expf(b[s] - mx) : 0.0f;
+            sl += ea[s] + eb[s];
+        }
+        const float inv = 1.0f / wave_sum(sl);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (on[s]) {
+                const double xt = (double)(ea[s] * inv), xb = (double)(eb[s] * inv);
+                const double dh = (double)digamma_f(he[(int64_t)r * K + ix[s]]);
+                acc += ra * xt * (lt[s] + dh - lvav[s]) + ra * xb * (le[s] + dh - lvav[s]);
+                if (xt > 0.0) acc -= ra * xt * log(xt);
+                if (xb > 0.0) acc -= ra * xb * log(xb);
+            }
         }
         if (lane == 0) acc -= lgamma(ra + 1.0);
     }
-    if (on) {
-        acc -= gi / (dalet * vav) * rs_he[i] + za / (het * vav) * rs_he[i] + gi / (dalet * bet) * rs_alef[i];   // :112,:123,:134
-        acc += (hc - 1.0) * lt - hd * gi / dalet;                       // Elogptheta :156
-        acc += (hg - 1.0) * le - hh * za / het;                         // Elogpepsilon :174
-        acc += gamma_entropy_d(gi, dalet) + gamma_entropy_d(za, het);   // -Elogqtheta, -Elogqepsilon
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        if (on[s]) {
+            const int i = ix[s];
+            acc -= gi[s] / (dalet[s] * vav[s]) * rs_he[i] + za[s] / (het[s] * vav[s]) * rs_he[i] + gi[s] / (dalet[s] * bet[s]) * rs_alef[i];   // :112,:123,:134
+            acc += (hc - 1.0) * lt[s] - hd * gi[s] / dalet[s];                    // Elogptheta :156
+            acc += (hg - 1.0) * le[s] - hh * za[s] / het[s];                      // Elogpepsilon :174
+            acc += gamma_entropy_d(gi[s], dalet[s]) + gamma_entropy_d(za[s], het[s]);   // -Elogqtheta, -Elogqepsilon
+        }
     }
     double tot = wave_sum_d(acc);
     tot += (double)K * (hc * log(hd) - lgamma(hc)) + (double)K * (hg * log(hh) - lgamma(hg));
@@ -590,14 +662,15 @@ extern "C" int tmvb_ctpf_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmv
     *out = nullptr;
     TMVB_REQUIRE(ctx && corp, TMVB_EINVAL, "tmvb_ctpf_create: NULL context or corpus");
     TMVB_REQUIRE(K > 0, TMVB_EINVAL, "number of topics must be a positive integer.");
-    TMVB_REQUIRE(K <= 64, TMVB_EINVAL, "tmvb_ctpf_create: this release supports K <= 64; got K=%d", K);
+    TMVB_REQUIRE(K <= 128, TMVB_EINVAL, "tmvb_ctpf_create: K <= 128 (two topic slots per lane); got K=%d", K);
     TMVB_HIP(hipSetDevice(ctx->device));
     tmvb_ctpf* h = new tmvb_ctpf();
-    h->ctx = ctx; h->corp = corp; h->K = K; h->KP = tmvb_kpad(K);
+    tmvb_create_guard<tmvb_ctpf, tmvb_ctpf_destroy> guard{h};      // every early return below destroys h
+    h->ctx = ctx; h->corp = corp; h->K = K; h->KP = tmvb_kpad(K); h->nslot = (K + 63) / 64;
     h->M = corp->info.M; h->V = corp->info.V; h->U = corp->info.U;
     const size_t KM = (size_t)K * h->M, KV = (size_t)K * h->V, KU = (size_t)K * h->U;
     int rc;
-    if ((rc = tmvb_corpus_term_index(corp)) || (rc = tmvb_corpus_reader_index(corp))) { tmvb_ctpf_destroy(h); return rc; }
+    if ((rc = tmvb_corpus_term_index(corp)) || (rc = tmvb_corpus_reader_index(corp))) return rc;
     const size_t slots = (size_t)std::max(corp->term_index.n_slots, corp->reader_index.n_slots);
     if ((rc = dmalloc(&h->d_alef, KV)) || (rc = dmalloc(&h->d_alef_old, KV)) || (rc = dmalloc(&h->d_he, KU)) || (rc = dmalloc(&h->d_he_old, KU)) ||
         (rc = dmalloc(&h->d_TA, (size_t)h->KP * h->V + 4)) || (rc = dmalloc(&h->d_TH, (size_t)h->KP * h->U + 4)) ||
@@ -609,7 +682,6 @@ extern "C" int tmvb_ctpf_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmv
         (rc = dmalloc(&h->d_partial, (size_t)TMVB_REDUCE_BLOCKS * K)) || (rc = dmalloc(&h->d_partial2, (size_t)TMVB_REDUCE_BLOCKS * K)) || (rc = dmalloc(&h->d_rs_alef, K)) || (rc = dmalloc(&h->d_rs_he, K)) ||
         (rc = dmalloc(&h->d_sum_g, K)) || (rc = dmalloc(&h->d_sum_z, K)) || (rc = dmalloc(&h->d_doc_val, (size_t)h->M)) ||
         (rc = dmalloc(&h->d_elbo_partial, 1024)) || (rc = dmalloc(&h->d_elbo, 1))) {
-        tmvb_ctpf_destroy(h);
         return rc;
     }
     // processing order: first the documents of the LDS-tile kernel by rows (terms + readers), longest first, in LDS
@@ -618,7 +690,7 @@ extern "C" int tmvb_ctpf_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmv
     if (h->reg_path) {
         std::vector<int> tol, lot;
         tmvb_reg_lane_maps(h->KP, tol, lot);
-        if ((rc = dmalloc(&h->d_topic_of_lane, tol.size()))) { tmvb_ctpf_destroy(h); return rc; }
+        if ((rc = dmalloc(&h->d_topic_of_lane, tol.size()))) return rc;
         TMVB_HIP(hipMemcpy(h->d_topic_of_lane, tol.data(), tol.size() * sizeof(int), hipMemcpyHostToDevice));
     }
     std::vector<int64_t> len((size_t)h->M);
@@ -654,7 +726,8 @@ extern "C" int tmvb_ctpf_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmv
     // constructor state src/CTPF.jl:81-100: he = 1, rates = 1, gimel = zayin = 1; alef is drawn with Julia's RNG (:83): 1 here
     std::vector<double> alef(KV, 1.0), he(KU, 1.0), ones(K, 1.0), gz(KM, 1.0);
     rc = tmvb_ctpf_set_state(h, nullptr, alef.data(), he.data(), ones.data(), ones.data(), ones.data(), ones.data(), gz.data(), gz.data(), nullptr);
-    if (rc) { tmvb_ctpf_destroy(h); return rc; }
+    if (rc) return rc;
+    guard.release();
     *out = h;
     return TMVB_OK;
 }
@@ -790,6 +863,7 @@ extern "C" int tmvb_ctpf_estep(tmvb_ctpf* h, int32_t viter, double vtol)
     p.gimel = h->d_gimel; p.gimel_old = h->d_gimel_old; p.zayin = h->d_zayin; p.zayin_old = h->d_zayin_old;
     p.wtok = h->d_wtok; p.wrdr = h->d_wrdr; p.E1 = h->d_E1; p.E2 = h->d_E2; p.sweeps = h->d_sweeps;
     p.viter = viter; p.vtol = (float)vtol;
+    p.store_w = tmvb_termstats_recomputes(h->KP, true) ? 0 : 1;
     TMVB_HIP(hipEventRecord(h->ev0, ctx->stream));
     // stream plan as in tmvb_lda_estep: register-tile buckets back to back on aux[0], LDS-tile buckets on aux[1]
     const int nb = (int)h->buckets.size();
@@ -818,7 +892,8 @@ extern "C" int tmvb_ctpf_estep(tmvb_ctpf* h, int32_t viter, double vtol)
             hipLaunchKernelGGL(kern, grid, block, lds, st, p, b.first, b.tile_rows);
             return TMVB_OK;
         };
-        int lrc = (p.LPR == 13) ? launch(ctpf_estep_kernel<13>) : (p.LPR == 3) ? launch(ctpf_estep_kernel<3>) : launch(ctpf_estep_kernel<0>);
+        int lrc = (h->nslot == 2) ? ((p.LPR == 25) ? launch(ctpf_estep_kernel<25, 2>) : launch(ctpf_estep_kernel<0, 2>))
+                  : (p.LPR == 13) ? launch(ctpf_estep_kernel<13, 1>) : (p.LPR == 3) ? launch(ctpf_estep_kernel<3, 1>) : launch(ctpf_estep_kernel<0, 1>);
         if (lrc) return lrc;
         TMVB_HIP(hipGetLastError());
     }
@@ -832,12 +907,12 @@ extern "C" int tmvb_ctpf_estep(tmvb_ctpf* h, int32_t viter, double vtol)
     tp.w = h->d_wtok; tp.E = h->d_E1; tp.T = h->d_TA; tp.out = h->d_stats;
     // the two passes are independent (alef / he statistics): the reader pass runs on aux[0] under the term pass
     TMVB_HIP(hipEventRecord(h->ev_fork, ctx->stream));
-    int rc = tmvb_launch_termstats(ctx, 1, h->KP, true, h->corp->term_index, tp);
+    int rc = tmvb_launch_termstats(ctx, h->nslot, h->KP, true, h->corp->term_index, tp);
     if (rc) return rc;
     if (h->U > 0) {
         tp.w = h->d_wrdr; tp.E = h->d_E2; tp.T = h->d_TH; tp.out = h->he_stats(); tp.partial = h->d_ts_partial2;
         TMVB_HIP(hipStreamWaitEvent(h->aux[0], h->ev_fork, 0));
-        if ((rc = tmvb_launch_termstats(ctx, 1, h->KP, true, h->corp->reader_index, tp, h->aux[0]))) return rc;
+        if ((rc = tmvb_launch_termstats(ctx, h->nslot, h->KP, true, h->corp->reader_index, tp, h->aux[0]))) return rc;
         TMVB_HIP(hipEventRecord(h->ev_join[0], h->aux[0]));
         TMVB_HIP(hipStreamWaitEvent(ctx->stream, h->ev_join[0], 0));
     }
@@ -851,8 +926,10 @@ extern "C" int tmvb_ctpf_reduce_docs(tmvb_ctpf* h)
 {
     TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_ctpf_reduce_docs: handle is NULL");
     TMVB_HIP(hipSetDevice(h->ctx->device));
-    int rc;
-    (void)rc;
+    if (h->K > 64) {           // the paired kernel holds one topic per lane
+        int rc = tmvb_colsum(h->ctx, h->nslot, h->K, h->d_gimel, h->M, h->d_partial, h->d_sum_g, h->tail());
+        return rc ? rc : tmvb_colsum(h->ctx, h->nslot, h->K, h->d_zayin, h->M, h->d_partial2, h->d_sum_z, h->tail() + h->K);
+    }
     return tmvb_colsum2(h->ctx, h->K, {h->d_gimel, h->M, h->d_partial, h->d_sum_g, h->tail()},
                         {h->d_zayin, h->M, h->d_partial2, h->d_sum_z, h->tail() + h->K});
 }
@@ -894,8 +971,8 @@ extern "C" int tmvb_ctpf_mstep(tmvb_ctpf* h)
     TMVB_HIP(hipSetDevice(ctx->device));
     int rc;
     if (h->distributed) {     // tail -> fp64 sums
-        if ((rc = tmvb_colsum(ctx, 1, h->K, h->tail(), 1, h->d_partial, h->d_sum_g, nullptr))) return rc;
-        if ((rc = tmvb_colsum(ctx, 1, h->K, h->tail() + h->K, 1, h->d_partial, h->d_sum_z, nullptr))) return rc;
+        if ((rc = tmvb_colsum(ctx, h->nslot, h->K, h->tail(), 1, h->d_partial, h->d_sum_g, nullptr))) return rc;
+        if ((rc = tmvb_colsum(ctx, h->nslot, h->K, h->tail() + h->K, 1, h->d_partial, h->d_sum_z, nullptr))) return rc;
     }
     // he_old <- he; he <- e + stats; TH refresh; rowsum(he)    (:266-270)
     // (measured: putting this branch on a second stream gains nothing -- the kernels are 5-8 us each and a
@@ -914,9 +991,12 @@ extern "C" int tmvb_ctpf_mstep(tmvb_ctpf* h)
         hipLaunchKernelGGL(ctpf_shape_kernel, dim3(nb), dim3(256), 0, ctx->stream, h->d_stats, (float)h->hyper[0], h->d_alef, h->d_alef_old, h->d_TA, h->K, h->KP, h->V, 0);
         TMVB_HIP(hipGetLastError());
     }
-    if (h->U > 0) {       // rowsum(alef) and rowsum(he) in one pair of launches
+    if (h->U > 0 && h->K <= 64) {       // rowsum(alef) and rowsum(he) in one pair of launches
         if ((rc = tmvb_colsum2(ctx, h->K, {h->d_alef, h->V, h->d_partial, h->d_rs_alef, nullptr}, {h->d_he, h->U, h->d_partial2, h->d_rs_he, nullptr}))) return rc;
-    } else if ((rc = tmvb_colsum(ctx, 1, h->K, h->d_alef, h->V, h->d_partial, h->d_rs_alef, nullptr))) return rc;
+    } else {
+        if ((rc = tmvb_colsum(ctx, h->nslot, h->K, h->d_alef, h->V, h->d_partial, h->d_rs_alef, nullptr))) return rc;
+        if (h->U > 0 && (rc = tmvb_colsum(ctx, h->nslot, h->K, h->d_he, h->U, h->d_partial2, h->d_rs_he, nullptr))) return rc;
+    }
     hipLaunchKernelGGL((ctpf_rates_kernel<1>), dim3(1), dim3(64), 0, ctx->stream, h->K, h->hyper[1], h->hyper[3], h->hyper[5], h->hyper[7],
                        h->d_rs_alef, h->d_rs_he, h->d_sum_g, h->d_sum_z, h->d_rates, h->d_lrates);
     TMVB_HIP(hipGetLastError());
@@ -933,8 +1013,8 @@ extern "C" int tmvb_ctpf_update_elbo_parts(tmvb_ctpf* h, double* doc_part, doubl
     TMVB_HIP(hipSetDevice(ctx->device));
     int rc;
     // rowsums of the CURRENT shapes (Elogpya/Elogpyb/Elogpz use sum(he, dims=2), sum(alef, dims=2))
-    if ((rc = tmvb_colsum(ctx, 1, h->K, h->d_alef, h->V, h->d_partial, h->d_rs_alef, nullptr))) return rc;
-    if (h->U > 0) { if ((rc = tmvb_colsum(ctx, 1, h->K, h->d_he, h->U, h->d_partial, h->d_rs_he, nullptr))) return rc; }
+    if ((rc = tmvb_colsum(ctx, h->nslot, h->K, h->d_alef, h->V, h->d_partial, h->d_rs_alef, nullptr))) return rc;
+    if (h->U > 0) { if ((rc = tmvb_colsum(ctx, h->nslot, h->K, h->d_he, h->U, h->d_partial, h->d_rs_he, nullptr))) return rc; }
     else TMVB_HIP(hipMemsetAsync(h->d_rs_he, 0, (size_t)h->K * sizeof(double), ctx->stream));
     const double* hy = h->hyper;
     double res[2] = {0.0, 0.0};
@@ -949,10 +1029,16 @@ extern "C" int tmvb_ctpf_update_elbo_parts(tmvb_ctpf* h, double* doc_part, doubl
     TMVB_HIP(hipStreamSynchronize(ctx->stream));
     // per-document part
     if (h->M > 0) {
-        hipLaunchKernelGGL(ctpf_elbo_doc_kernel, dim3((unsigned)h->M), dim3(64), 0, ctx->stream, h->K, h->corp->d_doc_ptr, h->corp->d_terms,
-                           h->corp->d_counts, h->corp->d_rdr_ptr, h->corp->d_readers, h->corp->d_ratings, h->d_alef, h->d_alef_old, h->d_he,
-                           h->d_he_old, h->d_rates, h->d_rs_alef, h->d_rs_he, h->d_gimel, h->d_gimel_old, h->d_zayin, h->d_zayin_old,
-                           hy[2], hy[3], hy[6], hy[7], h->d_doc_val);
+        if (h->nslot == 1)
+            hipLaunchKernelGGL((ctpf_elbo_doc_kernel<1>), dim3((unsigned)h->M), dim3(64), 0, ctx->stream, h->K, h->corp->d_doc_ptr, h->corp->d_terms,
+                               h->corp->d_counts, h->corp->d_rdr_ptr, h->corp->d_readers, h->corp->d_ratings, h->d_alef, h->d_alef_old, h->d_he,
+                               h->d_he_old, h->d_rates, h->d_rs_alef, h->d_rs_he, h->d_gimel, h->d_gimel_old, h->d_zayin, h->d_zayin_old,
+                               hy[2], hy[3], hy[6], hy[7], h->d_doc_val);
+        else
+            hipLaunchKernelGGL((ctpf_elbo_doc_kernel<2>), dim3((unsigned)h->M), dim3(64), 0, ctx->stream, h->K, h->corp->d_doc_ptr, h->corp->d_terms,
+                               h->corp->d_counts, h->corp->d_rdr_ptr, h->corp->d_readers, h->corp->d_ratings, h->d_alef, h->d_alef_old, h->d_he,
+                               h->d_he_old, h->d_rates, h->d_rs_alef, h->d_rs_he, h->d_gimel, h->d_gimel_old, h->d_zayin, h->d_zayin_old,
+                               hy[2], hy[3], hy[6], hy[7], h->d_doc_val);
         TMVB_HIP(hipGetLastError());
     }
     hipLaunchKernelGGL(ctpf_elbo_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, h->d_doc_val, h->M, h->d_elbo_partial, 0, 0.0, h->d_elbo);

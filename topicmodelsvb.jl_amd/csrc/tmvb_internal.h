@@ -32,6 +32,15 @@ void tmvb_set_error(const char* fmt, ...);
         }                                                                                      \
     } while (0)
 
+// Destroys a half-built handle on every early return of its *_create (TMVB_HIP / TMVB_REQUIRE return from the middle of
+// the function); release() on success.
+template <class H, int (*Destroy)(H*)>
+struct tmvb_create_guard {
+    H* h;
+    ~tmvb_create_guard() { if (h) (void)Destroy(h); }
+    void release() { h = nullptr; }
+};
+
 // ------------------------------------------------------------------------------------ handles
 struct tmvb_ctx {
     int device = 0;

@@ -268,7 +268,10 @@ __global__ __launch_bounds__(64) void lda_estep_kernel(LdaParams p, int64_t firs
         }
         if (single) store_w(0, N);
     } else {
-        if (p.store_w) for (int n = lane; n < N; n += 64) p.wtok[p.tok_inv[off + n]] = 0.0f;   // viter = 0: no responsibilities
+        // viter = 0: no responsibilities.  E = 0 makes the recomputing statistics pass produce eps-only columns (the
+        // register-tile kernel does the same); the stored-weight pass reads w = 0.
+        for (int i = lane; i < p.estride; i += 64) p.E[(int64_t)d * p.estride + i] = 0.0f;
+        if (p.store_w) for (int n = lane; n < N; n += 64) p.wtok[p.tok_inv[off + n]] = 0.0f;
     }
     if (lane == 0) p.sweeps[d] = (uint8_t)min(sweeps, 255);
 }
@@ -1017,6 +1020,7 @@ extern "C" int tmvb_lda_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
     TMVB_REQUIRE(K <= 64 * TMVB_MAX_NSLOT, TMVB_EINVAL, "tmvb_lda_create: K=%d exceeds the supported maximum %d", K, 64 * TMVB_MAX_NSLOT);
     TMVB_HIP(hipSetDevice(ctx->device));
     tmvb_lda* h = new tmvb_lda();
+    tmvb_create_guard<tmvb_lda, tmvb_lda_destroy> guard{h};      // every early return below destroys h
     h->ctx = ctx; h->corp = corp; h->K = K; h->KP = tmvb_kpad(K); h->nslot = (K + 63) / 64;
     h->M = corp->info.M; h->V = corp->info.V; h->M_total = h->M;
     h->e_padded = h->KP / 4 <= 64;
@@ -1033,14 +1037,13 @@ extern "C" int tmvb_lda_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
         (rc = dmalloc(&h->d_elbo, 1)) || (rc = dmalloc(&h->d_iters, 1)) || (rc = dmalloc(&h->d_wtok, tmvb_termstats_recomputes(h->KP, h->KP / 4 <= 64) ? (size_t)1 : (size_t)corp->info.nnz)) ||   // stored weights: K > 128 only
        
         (rc = dmalloc(&h->d_E, (size_t)((h->KP + 31) / 32 * 32) * h->M + 4))) {
-        tmvb_lda_destroy(h);
         return rc;
     }
     h->reg_path = (K <= 128) && lda_reg_lpr_supported(h->KP / 4);
     if (h->reg_path) {
         std::vector<int> tol, lot;
         tmvb_reg_lane_maps(h->KP, tol, lot);
-        if ((rc = dmalloc(&h->d_topic_of_lane, tol.size()))) { tmvb_lda_destroy(h); return rc; }
+        if ((rc = dmalloc(&h->d_topic_of_lane, tol.size()))) return rc;
         TMVB_HIP(hipMemcpy(h->d_topic_of_lane, tol.data(), tol.size() * sizeof(int), hipMemcpyHostToDevice));
     }
     std::vector<int32_t> order;
@@ -1066,7 +1069,7 @@ extern "C" int tmvb_lda_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
             if (!rc && hipEventCreateWithFlags(&h->ev_piece[0], hipEventDisableTiming) != hipSuccess) rc = TMVB_EHIP;
         }
         if (!rc) rc = dmalloc(&h->d_ts_partial, slots * (K + 1));
-        if (rc) { tmvb_lda_destroy(h); return rc; }
+        if (rc) return rc;
     }
     if (h->M) TMVB_HIP(hipMemcpyAsync(h->d_doc_order, order.data(), (size_t)h->M * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     TMVB_HIP(hipMemsetAsync(h->d_stats, 0, (KV + K) * sizeof(float), ctx->stream));
@@ -1078,20 +1081,22 @@ extern "C" int tmvb_lda_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
     TMVB_HIP(hipEventCreateWithFlags(&h->ev_docs, hipEventDisableTiming));
     TMVB_HIP(hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming));
     TMVB_HIP(hipEventCreateWithFlags(&h->ev_mark, hipEventDisableTiming));
-    if ((rc = dmalloc(&h->d_partial_side, (size_t)TMVB_REDUCE_BLOCKS * K)) || (rc = dmalloc(&h->d_pw_partial, 2048))) { tmvb_lda_destroy(h); return rc; }
+    if ((rc = dmalloc(&h->d_partial_side, (size_t)TMVB_REDUCE_BLOCKS * K)) || (rc = dmalloc(&h->d_pw_partial, 2048))) return rc;
     for (int a = 0; a < tmvb_lda::NAUX; ++a) {
         TMVB_HIP(hipStreamCreateWithFlags(&h->aux[a], hipStreamNonBlocking));
         TMVB_HIP(hipEventCreateWithFlags(&h->ev_join[a], hipEventDisableTiming));
     }
     TMVB_HIP(hipMemsetAsync(h->d_beta[0], 0, KPV * sizeof(float), ctx->stream));
     TMVB_HIP(hipMemsetAsync(h->d_beta[1], 0, KPV * sizeof(float), ctx->stream));
+    TMVB_HIP(hipMemsetAsync(h->d_E, 0, ((size_t)((h->KP + 31) / 32 * 32) * h->M + 4) * sizeof(float), ctx->stream));
     // constructor state, src/gpuLDA.jl:53-61 (beta: uniform, see tmvb.h)
     std::vector<double> alpha(K, 1.0), beta(KV, h->V ? 1.0 / (double)h->V : 0.0), gamma(KM, 1.0);
     const double e0 = -0.5772156649015329 - tmvb_digamma_host((double)K);   // -(eulergamma + digamma(K)), src/gpuLDA.jl:57
     std::vector<double> elog(KM, e0);
     TMVB_HIP(hipStreamSynchronize(ctx->stream));
     rc = tmvb_lda_set_state(h, alpha.data(), beta.data(), nullptr, gamma.data(), elog.data(), nullptr, nullptr);
-    if (rc) { tmvb_lda_destroy(h); return rc; }
+    if (rc) return rc;
+    guard.release();
     *out = h;
     return TMVB_OK;
 }
@@ -1152,11 +1157,29 @@ extern "C" int tmvb_lda_get_state(tmvb_lda* h, double* alpha, double* beta, doub
     return TMVB_OK;
 }
 
+static int lda_estep_impl(tmvb_lda* h, int32_t viter, double vtol);
+
 extern "C" int tmvb_lda_estep(tmvb_lda* h, int32_t viter, double vtol)
 {
     TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_lda_estep: handle is NULL");
     TMVB_REQUIRE(viter >= 0, TMVB_EINVAL, "iteration parameters must be nonnegative.");     // src/gpuLDA.jl:350
     TMVB_REQUIRE(vtol >= 0, TMVB_EINVAL, "tolerance parameters must be nonnegative.");      // src/gpuLDA.jl:349
+    const int rc = lda_estep_impl(h, viter, vtol);
+    if (rc != TMVB_OK) {
+        // a launch or an event call failed half way: drain the forked streams and drop the half-updated bookkeeping so
+        // that the handle is in a defined state (the statistics are not valid; the caller sees the error)
+        const std::string msg = tmvb_last_error();
+        for (int a = 0; a < tmvb_lda::NAUX; ++a) if (h->aux[a]) (void)hipStreamSynchronize(h->aux[a]);
+        (void)hipStreamSynchronize(h->ctx->stream);
+        (void)hipGetLastError();
+        h->side_pending = false; h->esum_fresh = false; h->esum_side = false; h->stats_fresh = false; h->pw_valid = false; h->mark_valid = false;
+        tmvb_set_error("%s", msg.c_str());
+    }
+    return rc;
+}
+
+static int lda_estep_impl(tmvb_lda* h, int32_t viter, double vtol)
+{
     tmvb_ctx* ctx = h->ctx;
     h->mark_valid = false; h->esum_fresh = false; h->esum_side = false;
     TMVB_HIP(hipSetDevice(ctx->device));
@@ -1177,8 +1200,16 @@ extern "C" int tmvb_lda_estep(tmvb_lda* h, int32_t viter, double vtol)
     const int nb = (int)h->buckets.size();
     const int P = std::max<int>((int)h->pieces.size(), 1);      // 1: one statistics pass over the corpus' own index
     auto piece_index = [&](int q) -> const tmvb_inv_index& { return h->pieces.empty() ? h->corp->term_index : h->pieces[q]; };
+    // One statistics pass (small corpora, one GPU's shard of a sharded run): the critical chain document kernels ->
+    // statistics -> M-step stays on the context's stream, so that it pays kernel boundaries (~2 us) instead of
+    // cross-stream event hops (~30 us each way, a quarter of a 0.3 ms iteration); only the latency-bound long
+    // documents fork to aux[1].  Pipelined pieces need the two chains on two streams.
+    hipStream_t chain_st = (P == 1 && h->reg_path) ? ctx->stream : h->aux[0];
+    if (chain_st == ctx->stream) { int jrc = lda_join_side(h); if (jrc) return jrc; }   // update_alpha! of the last iteration
     TMVB_HIP(hipEventRecord(h->ev_fork, ctx->stream));
     for (int a = 0; a < 2; ++a) {
+        if (h->aux[a] == chain_st) continue;
+        if (a == 0 && chain_st == ctx->stream) continue;                                 // aux[0] is unused in this plan
         TMVB_HIP(hipStreamWaitEvent(h->aux[a], h->ev_fork, 0));
         if (h->side_pending) TMVB_HIP(hipStreamWaitEvent(h->aux[a], h->ev_side, 0));   // update_alpha! of the last iteration
     }
@@ -1197,10 +1228,10 @@ extern "C" int tmvb_lda_estep(tmvb_lda* h, int32_t viter, double vtol)
         for (; piece_open < upto; ++piece_open) {
             if (piece_open == P - 1) {                  // the last piece also holds the long documents (aux[1])
                 TMVB_HIP(hipEventRecord(h->ev_join[1], h->aux[1]));
-                TMVB_HIP(hipStreamWaitEvent(h->aux[0], h->ev_join[1], 0));
+                TMVB_HIP(hipStreamWaitEvent(chain_st, h->ev_join[1], 0));
             }
-            TMVB_HIP(hipEventRecord(h->ev_piece[piece_open], h->aux[0]));
-            TMVB_HIP(hipStreamWaitEvent(ctx->stream, h->ev_piece[piece_open], 0));
+            TMVB_HIP(hipEventRecord(h->ev_piece[piece_open], chain_st));
+            if (chain_st != ctx->stream) TMVB_HIP(hipStreamWaitEvent(ctx->stream, h->ev_piece[piece_open], 0));
             int rc = stats_pass(piece_index(piece_open));
             if (rc) return rc;
         }
@@ -1209,7 +1240,7 @@ extern "C" int tmvb_lda_estep(tmvb_lda* h, int32_t viter, double vtol)
     for (int bi = 0; bi < nb; ++bi) {
         const tmvb_bucket& b = h->buckets[bi];
         const bool chain = b.reg_tiles > 0 && b.waves == 1;   // single-wave register buckets: the piece chain on aux[0]
-        hipStream_t st = chain ? h->aux[0] : h->aux[1];
+        hipStream_t st = chain ? chain_st : h->aux[1];
         if (!h->reg_path) st = h->aux[(bi & 1) ^ 1];          // LDS-tile buckets only: alternate the two streams
         if (chain) { int rc = close_pieces(b.piece); if (rc) return rc; }
         if (b.reg_tiles > 0) {
