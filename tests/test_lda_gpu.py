@@ -240,12 +240,12 @@ def test_nsf_scale_invariants(tmvb):
     assert np.isfinite(e1) and np.isfinite(e2) and e2 > e1
 
 
-def test_full_size_nsf_properties(tmvb):
-    """BASELINE.json's full size (SYN-NSF M=128804, V=25319, K=50) through size-independent properties:
-    per-document mass conservation, stochastic beta, statistics mass = token count, increasing ELBO,
-    run-to-run bitwise reproducibility of the (atomics-free) statistics."""
+@pytest.mark.parametrize("K", [50, 100])
+def test_full_size_nsf_properties(tmvb, K):
+    """BASELINE.json's full size (SYN-NSF M=128804, V=25319; K=50 = config 2, K=100 = config 3's model on one GPU) through
+    size-independent properties: per-document mass conservation, stochastic beta, statistics mass = token count,
+    increasing ELBO, run-to-run bitwise reproducibility of the (atomics-free) statistics."""
     pc = tmvb.syn_nsf()
-    K = 50
     gm = tmvb.gpuLDA(pc, K)
     alpha0 = gm.alpha.copy()
     gm.estep(); gm.reduce_docs(); gm.update_host()

@@ -275,6 +275,7 @@ __global__ __launch_bounds__(64) void ctm_estep_kernel(CtmParams p, int64_t firs
         }
         // update_lambda!  :129-142
         lam_old = lam;
+        double mv = 0.0;
         for (int t = 0; t < p.niter; ++t) {
             ++nsteps;
             const double ex = on ? exp(lam + 0.5 * vs - lz) : 0.0;
@@ -286,11 +287,16 @@ __global__ __launch_bounds__(64) void ctm_estep_kernel(CtmParams p, int64_t firs
                 if (lane < KP) hv = *(const float4*)(isrow + 4 * q);
                 H[4 * q] = hv.x; H[4 * q + 1] = hv.y; H[4 * q + 2] = hv.z; H[4 * q + 3] = hv.w;
             }
-            // invsigma * (mu - lambda): row `lane` dot the broadcast vector, fp64
-            const double dm = mu - lam;
-            double mv = 0.0;
+            // invsigma * (mu - lambda): row `lane` dot the broadcast vector, fp64 -- evaluated at the first Newton step
+            // of a sweep only.  The step solves (invsigma + D) delta = g, hence invsigma * delta = g - D delta up to the
+            // residual of the fp32 solve (~1e-6 |g|, and g shrinks quadratically): the next step's product follows
+            // from this one without another K^2 pass (104 v_readlane + 52 fp64 fma per step).
+            if (t == 0 || (p.debug & 8)) {
+                const double dm = mu - lam;
+                mv = 0.0;
 #pragma unroll
-            for (int j = 0; j < R; ++j) mv = fma((double)H[j], readlane_d(dm, j), mv);
+                for (int j = 0; j < R; ++j) mv = fma((double)H[j], readlane_d(dm, j), mv);
+            }
             const double gd = on ? (mv + phic - Cd * ex) : 0.0;                            // :134
             const double gn2 = wave_sum_d(gd * gd);
             const float dval = on ? (float)(Cd * ex) : 1.0f;
@@ -299,7 +305,10 @@ __global__ __launch_bounds__(64) void ctm_estep_kernel(CtmParams p, int64_t firs
             float delta;
             if (p.debug & 2) delta = (float)gd / (float)(isdiag + Cd * ex);
             else delta = gj_solve_rows<R>(H, (float)gd, lane);
-            if (on) lam += (double)delta;                                                  // :136
+            if (on) {
+                lam += (double)delta;                                                      // :136
+                mv -= (double)(float)gd - (double)dval * (double)delta;                    // invsigma (mu - lambda_new)
+            }
             if (sqrt(gn2) < p.ntol) break;                                                 // :138
         }
         const double df = on ? lam - lam_old : 0.0;
@@ -923,7 +932,16 @@ extern "C" int tmvb_ctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
     std::iota(order.begin(), order.end(), 0);
     const std::vector<int64_t>& len = corp->h_doc_len;
     std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return len[x] > len[y]; });
-    tmvb_build_lds_buckets(len, order, h->M, h->KP, -1, 3, h->buckets);
+    {
+        // The resident topic tile decides the waves per CU of the Newton-bound kernel (K = 50: a 96-row tile is 21 KB,
+        // 7 waves per CU), and the Newton steps -- 97 % of the kernel -- never touch it.  A 32-row window (8 KB) that
+        // longer documents stream through every sweep (L2-resident beta rows, LDS-DMA) lets the register file decide
+        // the occupancy instead: 7.76 -> 5.97 ms per E-step on 32 000 SYN-NSF documents (64 / 24 / 16 / 8 KB: 7.76 / 6.80 /
+        // 6.03 / 5.94 ms).  TMVB_CTM_MAX_TILE_KB overrides.
+        size_t cap = 8 * 1024;
+        if (const char* e = getenv("TMVB_CTM_MAX_TILE_KB")) cap = std::max<size_t>(4, (size_t)atoi(e)) * 1024;
+        tmvb_build_lds_buckets(len, order, h->M, h->KP, -1, 3, h->buckets, cap);
+    }
     if (h->M) TMVB_HIP(hipMemcpyAsync(h->d_doc_order, order.data(), (size_t)h->M * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     TMVB_HIP(hipMemsetAsync(h->d_stats, 0, (size_t)h->stats_len() * sizeof(float), ctx->stream));
     TMVB_HIP(hipMemsetAsync(h->d_sweeps, 0, std::max<size_t>((size_t)h->M, 1), ctx->stream));
@@ -1081,16 +1099,11 @@ extern "C" int tmvb_ctm_estep(tmvb_ctm* h, int32_t niter, double ntol, int32_t v
         hipStream_t st = (naux > 1) ? h->aux[bi % naux] : ctx->stream;
         const size_t lds = tmvb_tile_bytes(b.tile_rows, h->KP);
         const dim3 grid((unsigned)b.count), block(64);
-        switch (h->KP) {
-            case 4: hipLaunchKernelGGL((ctm_estep_kernel<4>), grid, block, lds, st, p, b.first, b.tile_rows); break;
-            case 12: hipLaunchKernelGGL((ctm_estep_kernel<12>), grid, block, lds, st, p, b.first, b.tile_rows); break;
-            case 20: hipLaunchKernelGGL((ctm_estep_kernel<20>), grid, block, lds, st, p, b.first, b.tile_rows); break;
-            case 28: hipLaunchKernelGGL((ctm_estep_kernel<28>), grid, block, lds, st, p, b.first, b.tile_rows); break;
-            case 36: hipLaunchKernelGGL((ctm_estep_kernel<36>), grid, block, lds, st, p, b.first, b.tile_rows); break;
-            case 44: hipLaunchKernelGGL((ctm_estep_kernel<44>), grid, block, lds, st, p, b.first, b.tile_rows); break;
-            case 60: hipLaunchKernelGGL((ctm_estep_kernel<60>), grid, block, lds, st, p, b.first, b.tile_rows); break;
-            default: hipLaunchKernelGGL((ctm_estep_kernel<52>), grid, block, lds, st, p, b.first, b.tile_rows); break;
-        }
+#define CTM_CASE(KPV) case KPV: hipLaunchKernelGGL((ctm_estep_kernel<KPV>), grid, block, lds, st, p, b.first, b.tile_rows); break;
+        // (measured: compiling for 4 waves per SIMD -- 128 VGPRs, 17 spilled -- changes nothing: 5.98 vs 5.97 ms)
+        switch (h->KP) { CTM_CASE(4) CTM_CASE(12) CTM_CASE(20) CTM_CASE(28) CTM_CASE(36) CTM_CASE(44) CTM_CASE(60)
+                         default: hipLaunchKernelGGL((ctm_estep_kernel<52>), grid, block, lds, st, p, b.first, b.tile_rows); break; }
+#undef CTM_CASE
         TMVB_HIP(hipGetLastError());
     }
     if (naux > 1) {
