@@ -87,20 +87,35 @@ typedef float gj_v2f __attribute__((ext_vector_type(2)));
 // broadcast in blocks of <= 16 pairs: back-to-back v_readlane into SGPRs, then the FMAs that consume them (a VALU
 // that reads an SGPR written by the immediately preceding v_readlane costs a wait state per pair; 52 live SGPRs
 // would spill to VGPR lanes).
+// (lane == J) ? a : b with the lane mask built in VCC by two SALU instructions inside the asm statement.  Written as
+// `lane == J` the 52 + 52 compare results are loop invariant: the compiler hoists them out of the Newton loop, spills
+// the 208 mask SGPRs to VGPR lanes and reloads each with two v_readlane -- ~150 extra VALU instructions per solve (a
+// literal "s" operand is hoisted and spilled the same way).
+template <int J>
+__device__ __forceinline__ float select_lane(float a, float b)
+{
+    float r;
+    asm("s_mov_b64 vcc, 0\n\ts_bitset1_b64 vcc, %3\n\tv_cndmask_b32_e32 %0, %1, %2, vcc" : "=v"(r) : "v"(b), "v"(a), "n"(J) : "vcc");
+    return r;
+}
+
 template <int R, int J>
 __device__ __forceinline__ void gj_pivot(gj_v2f (&H2)[R / 2], float& g, float& dinv, int lane)
 {
     typedef gj_v2f v2f;
     constexpr int jp = J / 2;                               // pair holding column J
     constexpr int NQ = R / 2 - (jp + 1);                    // pairs right of the pivot's pair
-    const bool me = lane == J;
     const float pj = readlane_f((J & 1) ? H2[jp].y : H2[jp].x, J);
     const float pj1 = (J & 1) ? 0.0f : readlane_f(H2[jp].y, J);
     const float sg = readlane_f(g, J);
-    const float rp = fast_rcp(pj);
+    // v_rcp_f32 is within 1 ulp: the multipliers carry a 1e-7 relative error like every other fp32 operation of the
+    // elimination, and the two refinement instructions per pivot are saved
+    const float rp = __builtin_amdgcn_rcpf(pj);
     const float hj = (J & 1) ? H2[jp].y : H2[jp].x;
-    const float f = me ? 0.0f : hj * rp;
-    dinv = me ? rp : dinv;
+    // Gauss-JORDAN: row J stays live (later pivots keep eliminating their columns from it), so lane J sits out its own
+    // step (f = 0) and remembers the reciprocal of its pivot for the final x_J = g_J / pivot_J
+    const float f = select_lane<J>(0.0f, hj * rp);
+    dinv = select_lane<J>(rp, dinv);
     const float nf = -f;
     if ((J & 1) == 0) H2[jp].y = fmaf(nf, pj1, H2[jp].y);           // column J + 1 shares J's pair
     g = fmaf(nf, sg, g);
@@ -124,13 +139,19 @@ __device__ __forceinline__ void gj_all_pivots(gj_v2f (&H2)[R / 2], float& g, flo
     (gj_pivot<R, J>(H2, g, dinv, lane), ...);
 }
 
+template <int R, int... Q>
+__device__ __forceinline__ void gj_patch_diag(const float (&H)[R], float diag, gj_v2f (&H2)[R / 2], std::integer_sequence<int, Q...>)
+{
+    ((H2[Q] = gj_v2f{select_lane<2 * Q>(diag, H[2 * Q]), select_lane<2 * Q + 1>(diag, H[2 * Q + 1])}), ...);
+}
+
+// H: row `lane` of the matrix WITHOUT its diagonal element, which arrives separately (diag) and is patched in here.
 template <int R>
-__device__ __forceinline__ float gj_solve_rows(float (&H)[R], float g, int lane)
+__device__ __forceinline__ float gj_solve_rows(float (&H)[R], float diag, float g, int lane)
 {
     static_assert(R % 2 == 0, "gj_solve_rows: R must be even");
     gj_v2f H2[R / 2];
-#pragma unroll
-    for (int q = 0; q < R / 2; ++q) H2[q] = gj_v2f{H[2 * q], H[2 * q + 1]};
+    gj_patch_diag<R>(H, diag, H2, std::make_integer_sequence<int, R / 2>{});
     float dinv = 0.0f;
     gj_all_pivots<R>(H2, g, dinv, lane, std::make_integer_sequence<int, R>{});
     return g * dinv;
@@ -165,6 +186,7 @@ __global__ __launch_bounds__(64) void ctm_estep_kernel(CtmParams p, int64_t firs
     // pinned in KP registers: the register budget decides the waves per SIMD
     const float* isrow = p.invsigma + (size_t)min(lane, KP - 1) * KP;
     const double isdiag = on ? (double)p.invsigma[(size_t)lane * KP + lane] : 1.0;
+    const float isdiag_f = (lane < KP) ? p.invsigma[(size_t)lane * KP + lane] : 0.0f;   // the fp32 entry the row load would bring (pads: 0)
     const double mu = on ? (double)p.mu[lane] : 0.0;
     double lam = on ? (double)p.lambda[(int64_t)d * K + lane] : 0.0;
     double vs = on ? (double)p.vsq[(int64_t)d * K + lane] : 1.0;
@@ -275,7 +297,6 @@ __global__ __launch_bounds__(64) void ctm_estep_kernel(CtmParams p, int64_t firs
         }
         // update_lambda!  :129-142
         lam_old = lam;
-        double mv = 0.0;
         for (int t = 0; t < p.niter; ++t) {
             ++nsteps;
             const double ex = on ? exp(lam + 0.5 * vs - lz) : 0.0;
@@ -287,28 +308,22 @@ __global__ __launch_bounds__(64) void ctm_estep_kernel(CtmParams p, int64_t firs
                 if (lane < KP) hv = *(const float4*)(isrow + 4 * q);
                 H[4 * q] = hv.x; H[4 * q + 1] = hv.y; H[4 * q + 2] = hv.z; H[4 * q + 3] = hv.w;
             }
-            // invsigma * (mu - lambda): row `lane` dot the broadcast vector, fp64 -- evaluated at the first Newton step
-            // of a sweep only.  The step solves (invsigma + D) delta = g, hence invsigma * delta = g - D delta up to the
-            // residual of the fp32 solve (~1e-6 |g|, and g shrinks quadratically): the next step's product follows
-            // from this one without another K^2 pass (104 v_readlane + 52 fp64 fma per step).
-            if (t == 0 || (p.debug & 8)) {
-                const double dm = mu - lam;
-                mv = 0.0;
+            // invsigma * (mu - lambda): row `lane` dot the broadcast vector, fp64.  (Carrying the product across the
+            // Newton steps of a sweep -- invsigma delta = g - D delta -- saves 4 % but feeds every solve's residual,
+            // ~K eps |A| |delta|, straight into the next gradient, at the size of ntol for the first step of a sweep;
+            // measured and dropped.)
+            const double dm = mu - lam;
+            double mv = 0.0;
 #pragma unroll
-                for (int j = 0; j < R; ++j) mv = fma((double)H[j], readlane_d(dm, j), mv);
-            }
+            for (int j = 0; j < R; ++j) mv = fma((double)H[j], readlane_d(dm, j), mv);
             const double gd = on ? (mv + phic - Cd * ex) : 0.0;                            // :134
             const double gn2 = wave_sum_d(gd * gd);
             const float dval = on ? (float)(Cd * ex) : 1.0f;
-#pragma unroll
-            for (int k = 0; k < R; ++k) H[k] += ((lane == k) ? dval : 0.0f);
+            const float diag = (lane < KP ? (float)isdiag_f : 0.0f) + dval;     // -H_ii = invsigma_ii + C_d e^{...}; pad rows: unit
             float delta;
             if (p.debug & 2) delta = (float)gd / (float)(isdiag + Cd * ex);
-            else delta = gj_solve_rows<R>(H, (float)gd, lane);
-            if (on) {
-                lam += (double)delta;                                                      // :136
-                mv -= (double)(float)gd - (double)dval * (double)delta;                    // invsigma (mu - lambda_new)
-            }
+            else delta = gj_solve_rows<R>(H, diag, (float)gd, lane);
+            if (on) lam += (double)delta;                                                  // :136
             if (sqrt(gn2) < p.ntol) break;                                                 // :138
         }
         const double df = on ? lam - lam_old : 0.0;
