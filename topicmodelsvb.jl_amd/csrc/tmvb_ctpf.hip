@@ -865,15 +865,18 @@ extern "C" int tmvb_ctpf_estep(tmvb_ctpf* h, int32_t viter, double vtol)
     p.viter = viter; p.vtol = (float)vtol;
     p.store_w = tmvb_termstats_recomputes(h->KP, true) ? 0 : 1;
     TMVB_HIP(hipEventRecord(h->ev0, ctx->stream));
-    // stream plan as in tmvb_lda_estep: register-tile buckets back to back on aux[0], LDS-tile buckets on aux[1]
+    // stream plan as in tmvb_lda_estep for one statistics pass: the register-tile buckets run back to back on the
+    // context's stream (the critical chain document kernels -> statistics -> M-step pays kernel boundaries, not ~20 us
+    // cross-stream hops: the whole iteration is 0.3 ms), the LDS-tile buckets (long documents) on aux[1]
     const int nb = (int)h->buckets.size();
+    hipStream_t chain_st = ctx->stream;                          // only used when h->reg_path
     TMVB_HIP(hipEventRecord(h->ev_fork, ctx->stream));
-    for (int a = 0; a < 2; ++a) TMVB_HIP(hipStreamWaitEvent(h->aux[a], h->ev_fork, 0));
+    for (int a = h->reg_path ? 1 : 0; a < 2; ++a) TMVB_HIP(hipStreamWaitEvent(h->aux[a], h->ev_fork, 0));
     for (int bi = 0; bi < nb; ++bi) {
         const tmvb_bucket& b = h->buckets[bi];
         const dim3 grid((unsigned)b.count), block(64);
         if (b.reg_tiles > 0) {
-            hipStream_t st = h->aux[0];
+            hipStream_t st = chain_st;
             switch (p.LPR) {
 #define CTPF_REG_CASE(LPRV) case LPRV: ctpf_launch_reg<LPRV>(b.reg_tiles, grid, st, p, b.first, h->d_topic_of_lane); break;
                 CTPF_REG_CASE(1) CTPF_REG_CASE(3) CTPF_REG_CASE(5) CTPF_REG_CASE(7) CTPF_REG_CASE(9) CTPF_REG_CASE(11) CTPF_REG_CASE(13)
@@ -898,6 +901,7 @@ extern "C" int tmvb_ctpf_estep(tmvb_ctpf* h, int32_t viter, double vtol)
         TMVB_HIP(hipGetLastError());
     }
     for (int a = 0; a < 2; ++a) {
+        if (a == 0 && h->reg_path) continue;                  // aux[0] carried nothing in this plan
         TMVB_HIP(hipEventRecord(h->ev_join[a], h->aux[a]));
         TMVB_HIP(hipStreamWaitEvent(ctx->stream, h->ev_join[a], 0));
     }
