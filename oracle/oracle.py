@@ -33,7 +33,7 @@ class Hyper(C.Structure):
 
 
 def build(force: bool = False) -> str:
-    srcs = [os.path.join(_HERE, f) for f in ("oracle_special.c", "oracle_lda.c", "oracle_ctm.c", "oracle_ctpf.c", "tmvb_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("oracle_special.c", "oracle_lda.c", "oracle_ctm.c", "oracle_ctpf.c", "oracle_flda.c", "tmvb_oracle.h")]
     if not force and os.path.exists(_LIB_PATH):
         try:
             if all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in srcs):
@@ -56,6 +56,8 @@ def lib():
         _lib.orc_lda_update_elbo.restype = c_dbl
         _lib.orc_ctm_update_elbo.restype = c_dbl
         _lib.orc_ctpf_update_elbo.restype = c_dbl
+        _lib.orc_flda_update_elbo.restype = c_dbl
+        _lib.orc_flda_update_eta.restype = c_dbl
     return _lib
 
 
@@ -201,6 +203,76 @@ class LDA:
         self.elbo = elbo.value
         self.sweep_hist = hist
         return traj[:done]
+
+
+# ------------------------------------------------------------------------------------- fLDA
+class fLDA(LDA):
+    """State + operators of src/fLDA.jl (filtered LDA), backed by the C oracle.  tau / tau_old are flat [nnz] arrays in
+    CSR token order.  kappa0: background distribution (the reference draws it from Dirichlet(V, 1), src/fLDA.jl:40)."""
+
+    def __init__(self, corp: CSR, K: int, beta0, kappa0):
+        super().__init__(corp, K, beta0)
+        self.eta = 0.5                                                    # :38
+        self.kappa = np.ascontiguousarray(kappa0, dtype=np.float64).copy()
+        self.kappa_old = self.kappa.copy()
+        self.kappa_temp = np.zeros(self.V)
+        nnz = len(corp.terms)
+        self.tau = np.full(nnz, self.eta)                                 # :49
+        self.tau_old = self.tau.copy()
+
+    def estep(self, viter=10, vtol=None, d0=0, d1=None):
+        vtol = 1.0 / self.K ** 2 if vtol is None else vtol
+        d1 = self.M if d1 is None else d1
+        sw = np.zeros(max(d1 - d0, 1), dtype=np.int32)
+        rc = lib().orc_flda_estep(*self._corp_args(), c_i64(d0), c_i64(d1), c_dbl(self.eta), _pd(self.alpha), _pd(self.kappa),
+                                  _pd(self.beta), _pd(self.beta_temp), _pd(self.kappa_temp), _pd(self.gamma), _pd(self.Elogtheta),
+                                  _pd(self.Elogtheta_old), _pd(self.tau), _pd(self.tau_old), C.c_int(viter), c_dbl(vtol), _pi32(sw))
+        assert rc == 0
+        return sw[: d1 - d0]
+
+    def update_kappa(self):
+        lib().orc_flda_update_kappa(c_i64(self.V), _pd(self.kappa), _pd(self.kappa_old), _pd(self.kappa_temp))
+
+    def update_eta(self):
+        c = self.corp
+        self.eta = float(lib().orc_flda_update_eta(c_i64(self.M), _pi64(c.doc_ptr), _pi32(c.counts), _pd(self.tau)))
+        return self.eta
+
+    def mstep(self, niter=1000, ntol=None):
+        """update_beta!, update_kappa!, update_alpha!, update_eta! in the order of src/fLDA.jl:237-240"""
+        self.update_beta(); self.update_kappa(); self.update_alpha(niter, ntol); self.update_eta()
+
+    def update_elbo(self, d0=0, d1=None, store=True):
+        d1 = self.M if d1 is None else d1
+        e = lib().orc_flda_update_elbo(*self._corp_args(), c_i64(d0), c_i64(d1), c_dbl(self.eta), _pd(self.alpha), _pd(self.kappa),
+                                       _pd(self.beta), _pd(self.beta_old), _pd(self.gamma), _pd(self.Elogtheta), _pd(self.Elogtheta_old),
+                                       _pd(self.tau), _pd(self.tau_old))
+        if store:
+            self.elbo = e
+        return e
+
+    def train(self, iter=150, tol=1.0, niter=1000, ntol=None, viter=10, vtol=None, checkelbo=1):
+        """train!  src/fLDA.jl:213-247 incl. check_elbo! (src/modelutils.jl:574-585, signed stop rule)."""
+        ce = 0 if checkelbo in (None, float("inf")) else int(checkelbo)
+        if len(self.corp.terms) == 0:
+            iter = 0
+        if ce and ce <= iter:
+            self.update_elbo()
+        traj = []
+        self.sweep_hist = np.zeros(viter + 1, dtype=np.int64)
+        for k in range(1, iter + 1):
+            sw = self.estep(viter, vtol)
+            self.sweep_hist = np.bincount(sw, minlength=viter + 1).astype(np.int64) if self.M else self.sweep_hist
+            self.mstep(niter, ntol)
+            if ce and k % ce == 0:
+                old = self.elbo
+                new = self.update_elbo()
+                traj.append(new)
+                if new - old < tol:
+                    break
+            else:
+                traj.append(float("nan"))
+        return np.array(traj)
 
 
 # ------------------------------------------------------------------------------------- CTM

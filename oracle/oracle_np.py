@@ -160,6 +160,116 @@ class LDA:
         return traj
 
 
+class fLDA(LDA):
+    """src/fLDA.jl:6-60 (state): filtered LDA.  beta0 and kappa0 must be supplied (the reference draws both from
+    Dirichlet(V, 1) with Julia's RNG, :40-42)."""
+
+    def __init__(self, docs, V, K, beta0, kappa0):
+        super().__init__(docs, V, K, beta0)
+        self.eta = 0.5                                                  # :38
+        self.kappa = np.array(kappa0, dtype=np.float64).copy()
+        self.kappa_old = self.kappa.copy()
+        self.kappa_temp = np.zeros(V)
+        self.tau = [np.full(len(t), self.eta) for t, _ in self.docs]    # :49
+        self.tau_old = [x.copy() for x in self.tau]
+
+    # :188-191
+    def update_phi(self, d):
+        terms, _ = self.docs[d]
+        self.phi = additive_logistic_cols(self.tau[d][None, :] * np.log(self.beta[:, terms] + EPSILON) + self.Elogtheta[d][:, None])
+
+    # :180-185
+    def update_tau(self, d):
+        self.tau_old[d] = self.tau[d]
+        terms, _ = self.docs[d]
+        with np.errstate(divide="ignore", over="ignore"):
+            prod = np.prod(self.beta[:, terms] ** (-self.phi), axis=0) if len(terms) else np.zeros(0)
+        self.tau[d] = self.eta / (EPSILON + (self.eta + (1.0 - self.eta) * (self.kappa[terms] * prod)))
+
+    # :159-162, :145-148 (duplicate ids: last write wins)
+    def update_beta_doc(self, d):
+        terms, counts = self.docs[d]
+        self.beta_temp[:, terms] = self.beta_temp[:, terms] + self.phi * (self.tau[d] * counts)[None, :]
+
+    def update_kappa_doc(self, d):
+        terms, counts = self.docs[d]
+        self.kappa_temp[terms] = self.kappa_temp[terms] + (1.0 - self.tau[d]) * counts
+
+    # :138-142
+    def update_kappa(self):
+        self.kappa_old = self.kappa
+        self.kappa = self.kappa_temp / self.kappa_temp.sum()
+        self.kappa_temp = np.zeros(self.V)
+
+    # :122-124
+    def update_eta(self):
+        self.eta = float(sum(np.dot(self.tau[d], self.docs[d][1]) for d in range(self.M)) / sum(c.sum() for _, c in self.docs))
+
+    # :108-118 and :62-105
+    def update_elbo(self):
+        elbo = 0.0
+        a = self.alpha
+        for d in range(self.M):
+            terms, counts = self.docs[d]
+            phi = additive_logistic_cols(self.tau_old[d][None, :] * np.log(self.beta_old[:, terms] + EPSILON) + self.Elogtheta_old[d][:, None])
+            El, g, tau = self.Elogtheta[d], self.gamma[d], self.tau[d]
+            e_ptheta = gammaln(a.sum()) - gammaln(a).sum() + np.dot(a - 1.0, El)
+            tc = float(np.dot(tau, counts))
+            e_pc = math.log(EPSILON + self.eta ** tc * (1.0 - self.eta) ** (float(counts.sum()) - tc))
+            e_pz = np.dot(phi @ counts, El) if len(terms) else 0.0
+            e_pw = (float(np.sum((phi * np.log(self.beta[:, terms] + EPSILON)) @ (counts * tau))) if len(terms) else 0.0) \
+                + float(np.dot(counts * (1.0 - tau), np.log(self.kappa[terms] + EPSILON)))
+            if self.K == 1:
+                ent = 0.0
+            else:
+                g0 = g.sum()
+                ent = gammaln(g).sum() - gammaln(g0) + (g0 - self.K) * digamma(g0) - np.dot(g - 1.0, digamma(g))
+            e_qc = -sum(c * _xlogx_entropy(np.array([t, 1.0 - t])) for t, c in zip(tau, counts))
+            e_qz = -sum(c * _xlogx_entropy(phi[:, n]) for n, c in enumerate(counts))
+            elbo += e_ptheta + e_pc + e_pz + e_pw + ent - e_qc - e_qz
+        self.elbo = float(elbo)
+        return self.elbo
+
+    # :213-247 + modelutils.jl:574-585
+    def train(self, iter=150, tol=1.0, niter=1000, ntol=None, viter=10, vtol=None, checkelbo=1):
+        ntol = 1.0 / self.K ** 2 if ntol is None else ntol
+        vtol = 1.0 / self.K ** 2 if vtol is None else vtol
+        traj = []
+        if all(len(t) == 0 for t, _ in self.docs):
+            iter = 0
+        if checkelbo <= iter:
+            self.update_elbo()
+        for k in range(1, iter + 1):
+            sw = []
+            for d in range(self.M):
+                s = 0
+                for _ in range(viter):
+                    s += 1
+                    self.update_phi(d)
+                    self.update_tau(d)
+                    self.update_gamma(d)
+                    self.update_Elogtheta(d)
+                    if np.linalg.norm(self.Elogtheta[d] - self.Elogtheta_old[d]) < vtol:
+                        break
+                sw.append(s)
+                self.update_beta_doc(d)
+                self.update_kappa_doc(d)
+            self.sweeps.append(sw)
+            self.update_beta()
+            self.update_kappa()
+            self.update_alpha(niter, ntol)
+            self.update_eta()
+            if checkelbo != math.inf and k % checkelbo == 0:
+                old = self.elbo
+                new = self.update_elbo()
+                traj.append(new)
+                if (new - old) < tol:
+                    break
+            else:
+                traj.append(float("nan"))
+        return traj
+
+
 class CTM:
     """src/CTM.jl:6-53"""
 

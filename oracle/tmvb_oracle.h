@@ -191,6 +191,26 @@ int orc_ctpf_train(int64_t M, int64_t V, int64_t U, int64_t K,
                    double* elbo, int iter, double tol, int viter, double vtol,
                    int checkelbo, double* elbo_traj);
 
+
+/* ---- filtered LDA (src/fLDA.jl) ---- tau / tau_old: flat [nnz] arrays in CSR token order */
+int orc_flda_doc_sweeps(int64_t K, int64_t Nd, const int32_t* terms, const int32_t* counts,
+                        double eta, const double* alpha, const double* kappa, const double* beta,
+                        double* gamma_d, double* Elogtheta_d, double* Elogtheta_old_d,
+                        double* tau_d, double* tau_old_d, double* phi, int viter, double vtol);
+/* sweeps + update_beta!(model, d) + update_kappa!(model, d) over documents [d0, d1)  (src/fLDA.jl:222-236) */
+int orc_flda_estep(int64_t M, int64_t V, int64_t K,
+                   const int64_t* doc_ptr, const int32_t* terms, const int32_t* counts,
+                   int64_t d0, int64_t d1, double eta, const double* alpha, const double* kappa, const double* beta,
+                   double* beta_temp, double* kappa_temp, double* gamma, double* Elogtheta, double* Elogtheta_old,
+                   double* tau, double* tau_old, int viter, double vtol, int32_t* sweeps_out);
+void orc_flda_update_kappa(int64_t V, double* kappa, double* kappa_old, double* kappa_temp);       /* :138-142 */
+double orc_flda_update_eta(int64_t M, const int64_t* doc_ptr, const int32_t* counts, const double* tau);   /* :122-124 */
+double orc_flda_update_elbo(int64_t M, int64_t V, int64_t K,
+                            const int64_t* doc_ptr, const int32_t* terms, const int32_t* counts,
+                            int64_t d0, int64_t d1, double eta, const double* alpha, const double* kappa,
+                            const double* beta, const double* beta_old, const double* gamma, const double* Elogtheta,
+                            const double* Elogtheta_old, const double* tau, const double* tau_old);   /* :108-118 */
+
 #ifdef __cplusplus
 }
 #endif

@@ -86,11 +86,32 @@ def ctpf_case(name, seed, M, V, U, K, iters, maxRat):
                         gimel=np.stack(m.gimel, 1), zayin=np.stack(m.zayin, 1), elbo_traj=np.array(traj))
 
 
+def flda_case(name, seed, M, V, K, iters, empty_every=0):
+    rng = np.random.default_rng(seed)
+    docs = mkcorp(rng, M, V, empty_every=empty_every)
+    beta0 = beta_init(rng, K, V)
+    kappa0 = beta_init(rng, 1, V)[0]
+    m = onp.fLDA(docs, V, K, beta0, kappa0)
+    traj = m.train(iter=iters, tol=-1e300)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), M=M, V=V, K=K, iters=iters, beta0=beta0, kappa0=kappa0, **pack(docs),
+                        eta=m.eta, alpha=m.alpha, kappa=m.kappa, beta=m.beta, beta_old=m.beta_old, gamma=np.stack(m.gamma, 1),
+                        Elogtheta=np.stack(m.Elogtheta, 1), Elogtheta_old=np.stack(m.Elogtheta_old, 1),
+                        tau=np.concatenate(m.tau) if m.tau else np.zeros(0), tau_old=np.concatenate(m.tau_old) if m.tau_old else np.zeros(0),
+                        elbo_traj=np.array(traj), sweeps=np.array(m.sweeps, np.int32))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "flda":          # only the filtered-model fixtures (added in round 2)
+        flda_case("flda_m40_v60_k5", 41, 40, 60, 5, 4)
+        flda_case("flda_m30_v50_k9_empty", 42, 30, 50, 9, 3, empty_every=7)
+        print("fLDA golden fixtures written to", HERE)
+        sys.exit(0)
     lda_case("lda_m40_v60_k3", 11, 40, 60, 3, 5)
     lda_case("lda_m40_v60_k7", 12, 40, 60, 7, 5)
     lda_case("lda_m30_v50_k70_empty", 13, 30, 50, 70, 3, empty_every=7)
     ctm_case("ctm_m40_v60_k5", 21, 40, 60, 5, 4)
     ctpf_case("ctpf_m40_v60_u15_k4", 31, 40, 60, 15, 4, 4, maxRat=3)
     ctpf_case("ctpf_m30_v40_u12_k6_r1", 32, 30, 40, 12, 6, 3, maxRat=1)
+    flda_case("flda_m40_v60_k5", 41, 40, 60, 5, 4)
+    flda_case("flda_m30_v50_k9_empty", 42, 30, 50, 9, 3, empty_every=7)
     print("golden fixtures written to", HERE)

@@ -31,6 +31,23 @@ def test_lda_golden(oracle, name):
     assert np.array_equal(hist, m.sweep_hist)
 
 
+@pytest.mark.parametrize("name", ["flda_m40_v60_k5", "flda_m30_v50_k9_empty"])
+def test_flda_golden(oracle, name):
+    """filtered LDA (src/fLDA.jl): the C oracle against the fixture of the independent NumPy restatement"""
+    g = load(name)
+    m = oracle.fLDA(oracle.CSR(g["doc_ptr"], g["terms"], g["counts"], int(g["V"])), int(g["K"]), g["beta0"], g["kappa0"])
+    traj = m.train(iter=int(g["iters"]), tol=-1e300)
+    np.testing.assert_allclose(traj, g["elbo_traj"], rtol=1e-11)
+    np.testing.assert_allclose(m.eta, float(g["eta"]), rtol=1e-12)
+    np.testing.assert_allclose(m.alpha, g["alpha"], rtol=1e-10)
+    np.testing.assert_allclose(m.kappa, g["kappa"], rtol=1e-10, atol=1e-300)
+    np.testing.assert_allclose(m.beta, g["beta"], rtol=1e-10, atol=1e-300)
+    np.testing.assert_allclose(m.gamma, g["gamma"], rtol=1e-10)
+    np.testing.assert_allclose(m.tau, g["tau"], rtol=1e-10)
+    np.testing.assert_allclose(m.tau_old, g["tau_old"], rtol=1e-10)
+    assert np.array_equal(np.bincount(g["sweeps"][-1].ravel(), minlength=11), m.sweep_hist)
+
+
 def test_ctm_golden(oracle):
     g = load("ctm_m40_v60_k5")
     m = oracle.CTM(csr(oracle, g), int(g["K"]), g["beta0"])
