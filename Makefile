@@ -5,7 +5,7 @@ HIPCC ?= /opt/rocm/bin/hipcc
 ARCH  ?= gfx950
 ROCM  ?= /opt/rocm
 CSRC  := topicmodelsvb.jl_amd/csrc
-SRCS  := $(CSRC)/tmvb_core.hip $(CSRC)/tmvb_comm.hip $(CSRC)/tmvb_lda.hip $(CSRC)/tmvb_ctm.hip $(CSRC)/tmvb_ctpf.hip $(CSRC)/tmvb_ctpf_recs.hip
+SRCS  := $(CSRC)/tmvb_core.hip $(CSRC)/tmvb_comm.hip $(CSRC)/tmvb_lda.hip $(CSRC)/tmvb_flda.hip $(CSRC)/tmvb_ctm.hip $(CSRC)/tmvb_ctpf.hip $(CSRC)/tmvb_ctpf_recs.hip
 HDRS  := $(wildcard $(CSRC)/*.h) include/tmvb.h
 OBJS  := $(patsubst $(CSRC)/%.hip,topicmodelsvb.jl_amd/build/%.hip.o,$(SRCS))
 FLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Wno-pass-failed -I include -I $(CSRC)

@@ -53,6 +53,7 @@ typedef struct tmvb_lda    tmvb_lda;
 typedef struct tmvb_ctm    tmvb_ctm;
 typedef struct tmvb_ctpf   tmvb_ctpf;
 typedef struct tmvb_comm   tmvb_comm;
+typedef struct tmvb_flda   tmvb_flda;
 
 int         tmvb_abi_version(void);
 const char* tmvb_last_error(void);
@@ -220,6 +221,40 @@ int tmvb_lda_doc_sweeps(tmvb_lda* h, uint8_t* out);
 int tmvb_lda_estep_launches(tmvb_lda* h, int32_t* n);
 /* Timing of the last tmvb_lda_estep on the context's stream, from HIP events (ms). */
 int tmvb_lda_last_estep_ms(tmvb_lda* h, float* ms);
+
+/* ============================== fLDA (new device path; oracle src/fLDA.jl) ==============================
+ * Filtered LDA: LDA plus a per-token Bernoulli switch tau_n (prior eta) and a background distribution kappa.  The reference
+ * has NO accelerator path for it (`@gpu train!` on an fLDA does nothing, src/macros.jl:274-278); SURVEY.md section 8 f4 names
+ * it as the next row.  The entry points mirror the LDA ones; the per-document operator chain update_phi! / update_tau! /
+ * update_gamma! / update_Elogtheta! (src/fLDA.jl:188, :180, :173, :166) is one fused kernel.  K <= 128.
+ * tau / tau_old are flat double[nnz] arrays in the CSR token order of tmvb_corpus_create (= vcat(model.tau...)). */
+int tmvb_flda_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb_flda** out);           /* fLDA(corp, K), src/fLDA.jl:28-60 */
+int tmvb_flda_destroy(tmvb_flda* h);
+/* NULL = unchanged; kappa_old / beta_old / Elogtheta_old / tau_old default to the current values.  eta[1], alpha[K], kappa[V],
+ * beta[K*V], gamma[K*M], Elogtheta[K*M], tau[nnz]. */
+int tmvb_flda_set_state(tmvb_flda* h, const double* eta, const double* alpha, const double* kappa, const double* kappa_old,
+                        const double* beta, const double* beta_old, const double* gamma, const double* Elogtheta,
+                        const double* Elogtheta_old, const double* tau, const double* tau_old, const double* elbo);
+int tmvb_flda_get_state(tmvb_flda* h, double* eta, double* alpha, double* kappa, double* kappa_old, double* beta, double* beta_old,
+                        double* gamma, double* Elogtheta, double* Elogtheta_old, double* tau, double* tau_old, double* elbo);
+/* sweeps of src/fLDA.jl:224-233 + update_beta!(model, d) (:159) + update_kappa!(model, d) (:145) for every document */
+int tmvb_flda_estep(tmvb_flda* h, int32_t viter, double vtol);
+int tmvb_flda_reduce_docs(tmvb_flda* h);                                /* Elogtheta_sum, src/fLDA.jl:129 */
+/* Packed statistics: float32 [ S (K*V) | kappa_stats (V) | Elogtheta_sum (K) ]. */
+int tmvb_flda_stats(tmvb_flda* h, void** dev_ptr, int64_t* n_f32);
+int tmvb_flda_update_beta(tmvb_flda* h);                                /* update_beta! (:152) and update_kappa! (:138) */
+int tmvb_flda_update_alpha(tmvb_flda* h, int32_t niter, double ntol);   /* update_alpha! (:128-150) */
+int tmvb_flda_update_eta(tmvb_flda* h);                                 /* update_eta! (:122-124); after update_beta */
+int tmvb_flda_update_elbo(tmvb_flda* h, double* elbo);                  /* update_elbo! (:108-118) */
+/* train! (src/fLDA.jl:213-247); arguments as tmvb_lda_train. */
+int tmvb_flda_train(tmvb_flda* h, int32_t iter, double tol, int32_t niter, double ntol, int32_t viter, double vtol,
+                    int32_t checkelbo, double* elbo_traj, int32_t* iters_done, double* elbo_baseline);
+/* Document-sharded run: the shard belongs to a corpus of M_total documents and C_total tokens (sum of all counts). */
+int tmvb_flda_set_comm(tmvb_flda* h, tmvb_comm* comm, int64_t M_total, int64_t C_total);
+int tmvb_flda_train_group(tmvb_flda* const* hs, int32_t n, int32_t iter, double tol, int32_t niter, double ntol, int32_t viter,
+                          double vtol, int32_t checkelbo, double* elbo_traj, int32_t* iters_done, double* elbo_baseline);
+int tmvb_flda_doc_sweeps(tmvb_flda* h, uint8_t* out);
+int tmvb_flda_last_estep_ms(tmvb_flda* h, float* ms);
 
 /* ============================== CTM (src/gpuCTM.jl, oracle src/CTM.jl) ============================== */
 

@@ -14,7 +14,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "libtmvb_hip.so")
-SOURCES = ["tmvb_core.hip", "tmvb_comm.hip", "tmvb_lda.hip", "tmvb_ctm.hip", "tmvb_ctpf.hip", "tmvb_ctpf_recs.hip"]
+SOURCES = ["tmvb_core.hip", "tmvb_comm.hip", "tmvb_lda.hip", "tmvb_flda.hip", "tmvb_ctm.hip", "tmvb_ctpf.hip", "tmvb_ctpf_recs.hip"]
 
 OK, EINVAL, ESHAPE, ECORPUS, ENOMEM, EHIP, ENONFINITE, ENODEVICE, ERCCL = range(9)
 

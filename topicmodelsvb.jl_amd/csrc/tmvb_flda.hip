@@ -1,0 +1,874 @@
+// tmvb_flda.hip -- filtered latent Dirichlet allocation (fLDA) engine for gfx950 (MI355X).
+//
+// Path: the per-document coordinate ascent of src/fLDA.jl:222-236 (update_phi! :188, update_tau! :180, update_gamma!
+// :173, update_Elogtheta! :166, exit test :230, update_beta!(d) :159, update_kappa!(d) :145) fused into ONE kernel per
+// document, the M-step (update_beta! :152, update_kappa! :138, update_alpha! :128, update_eta! :122) and update_elbo!
+// (:108) on the device.  The reference has NO accelerator path for the filtered models (`@gpu` does nothing for them,
+// src/macros.jl:274-278; SURVEY.md section 8 f4 lists them as the next row after the docfile ingest): this is new.
+//
+// fLDA adds to LDA a Bernoulli switch tau_n per token ("topical or background?", prior eta) and a background
+// distribution kappa over the vocabulary.  The switch enters phi as an EXPONENT,
+//       phi[i,n] = softmax_i( tau_n log(beta[i,t_n] + eps) + Elogtheta_i ),
+// so phi no longer factors as (beta row) x (document vector) / normaliser: every (token, topic) pair costs an exp per
+// sweep, and the register-tile / gather-side factorisations of tmvb_lda.hip do not apply.  The kernels below work on
+// the table L = log(beta + eps) ([V][KP], refreshed by update_beta!):
+//   * document kernel: the document's L rows sit in an LDS tile; phase A (lane = token) runs the column softmax in two
+//     passes over the row (max, then sum and sum p L) -- no cross-lane traffic -- and updates tau_n from
+//     prod_i beta^-phi = exp(-sum_i phi_i L_i); phase B (lane = topic quad x token residue) accumulates
+//     (phi * counts)_i with one v_exp_f32 per pair; gamma / Elogtheta as in the LDA kernel.
+//   * statistics: a gather over the term-major inverted index that REBUILDS phi of the last sweep from
+//     (tau_old_n, Elogtheta_old_d, log-sum-exp_n): S[i,j] = sum_n tau_n c_n phi_in, kappa_stat[j] = sum_n (1 - tau_n) c_n.
+//     No atomics, fixed summation order.
+// Stated deviation: the reference forms prod_i beta[i,t]^-phi[i,n] from beta WITHOUT epsilon (:184); the device uses
+// the one table log(beta + eps).  The two differ only for entries beta < ~1e-23 that still carry phi > 0 (an exact 0
+// makes the reference's tau_n exactly 0); fp32 beta cannot represent the distinction below 1e-38 anyway.
+#include "tmvb_common_kernels.h"
+#include "tmvb_train.h"
+#include "tmvb_dirichlet.h"
+
+struct FldaParams {
+    int K, KP, LPR;
+    unsigned lpr_magic;
+    const int64_t* doc_ptr;
+    const int32_t* terms;
+    const int32_t* counts;
+    const int32_t* doc_order;
+    const float* L;            // [V][KP] log(beta + eps), pads 0
+    const float* kappa;        // [V]
+    const double* eta;         // [1] device resident (update_eta! never leaves the GPU)
+    const float* alpha;        // [K]
+    float* gamma; float* elog; float* elog_old;    // [M][K]
+    float* tau; float* tau_old;                    // [nnz] CSR order
+    float* lse;                // [nnz] log-sum-exp of the last sweep's phi column (input of the statistics pass)
+    uint8_t* sweeps;
+    int viter;
+    float vtol;
+};
+
+static size_t flda_tile_bytes(int rows, int KP) { return ((size_t)rows * KP + KP + 6 * (size_t)rows) * sizeof(float); }
+
+template <int NS>
+__global__ __launch_bounds__(64) void flda_estep_kernel(FldaParams p, int64_t first, int tile_rows)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x;
+    const int K = p.K, KP = p.KP, LPR = p.LPR;
+    float* Bt = lds;                                   // [tile_rows][KP] rows of L
+    float* el_l = Bt + (size_t)tile_rows * KP;         // [KP] Elogtheta (pads -inf)
+    float* tp_l = el_l + KP;                           // [tile_rows] tau before this sweep's update_tau! (phi uses it)
+    float* tn_l = tp_l + tile_rows;                    // [tile_rows] tau after it
+    float* m_l = tn_l + tile_rows;                     // [tile_rows] column maximum
+    float* w_l = m_l + tile_rows;                      // [tile_rows] c_n / s_n
+    float* c_l = w_l + tile_rows;                      // [tile_rows] counts
+    int* t_l = (int*)(c_l + tile_rows);                // [tile_rows] term ids
+
+    const int d = p.doc_order[first + blockIdx.x];
+    const int64_t off = p.doc_ptr[d];
+    const int N = (int)(p.doc_ptr[d + 1] - off);
+    const bool single = N <= tile_rows;
+    const float eta = (float)p.eta[0];
+
+    bool on[NS];
+    float alpha[NS], elog[NS], elog_old[NS], gam[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int i = lane + 64 * s;
+        on[s] = i < K;
+        alpha[s] = on[s] ? p.alpha[i] : 0.0f;
+        elog[s] = on[s] ? p.elog[(int64_t)d * K + i] : 0.0f;
+        elog_old[s] = elog[s]; gam[s] = 0.0f;
+    }
+
+    auto load_chunk = [&](int c0, int rows, bool with_tau) {
+        for (int n = lane; n < rows; n += 64) {
+            t_l[n] = p.terms[off + c0 + n];
+            c_l[n] = (float)p.counts[off + c0 + n];
+            if (with_tau) tn_l[n] = p.tau[off + c0 + n];
+        }
+        WAVE_LDS_FENCE();
+        const int nch = rows * LPR;
+        for (int f0 = 0; f0 < nch; f0 += 64) {
+            const int f = f0 + lane;
+            if (f < nch) {
+                const int n = (LPR == 1) ? f : (int)__umulhi((unsigned)f, p.lpr_magic);
+                const int c = f - n * LPR;
+                const float* src = p.L + ((int64_t)t_l[n] * KP + 4 * c);
+                __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(Bt + (size_t)f0 * 4), 16, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        WAVE_LDS_FENCE();
+    };
+    // update_phi! (:188-191) normalisers and update_tau! (:180-185), lane = token
+    auto phase_a = [&](int c0, int rows, bool store) {
+        const float4* er = (const float4*)el_l;
+        for (int n = lane; n < rows; n += 64) {
+            const float4* br = (const float4*)(Bt + (size_t)n * KP);
+            const float tp = tn_l[n];                                   // tau entering this sweep
+            float m = -INFINITY;
+            for (int q = 0; q < LPR; ++q) {
+                const float4 b = br[q], ev = er[q];
+                m = fmaxf(m, fmaxf(fmaxf(fmaf(tp, b.x, ev.x), fmaf(tp, b.y, ev.y)), fmaxf(fmaf(tp, b.z, ev.z), fmaf(tp, b.w, ev.w))));
+            }
+            float s = 0.0f, a = 0.0f;
+            for (int q = 0; q < LPR; ++q) {
+                const float4 b = br[q], ev = er[q];
+                const float p0 = __expf(fmaf(tp, b.x, ev.x) - m), p1 = __expf(fmaf(tp, b.y, ev.y) - m);
+                const float p2 = __expf(fmaf(tp, b.z, ev.z) - m), p3 = __expf(fmaf(tp, b.w, ev.w) - m);
+                s += (p0 + p1) + (p2 + p3);
+                a = fmaf(p0, b.x, a); a = fmaf(p1, b.y, a); a = fmaf(p2, b.z, a); a = fmaf(p3, b.w, a);   // pads: p = 0
+            }
+            const float A = a / s;                                       // sum_i phi_i log(beta_i + eps) <= 0
+            const float prod = __expf(fminf(-A, 87.0f));                 // prod_i beta^-phi  (:184)
+            const float tnew = eta / (TMVB_EPS_F + (eta + (1.0f - eta) * (p.kappa[t_l[n]] * prod)));
+            tp_l[n] = tp; tn_l[n] = tnew; m_l[n] = m; w_l[n] = c_l[n] / s;
+            if (store) {
+                p.tau_old[off + c0 + n] = tp; p.tau[off + c0 + n] = tnew; p.lse[off + c0 + n] = m + __logf(s);
+            }
+        }
+        WAVE_LDS_FENCE();
+    };
+    const int r4 = lane & 3, ql = lane >> 2;
+    // (phi * counts)_i  (update_gamma!, :175), lane = (topic quad, token residue)
+    auto phase_b = [&](int rows, float4 (&acc)[NS]) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int q = ql + 16 * s;
+            if (q >= LPR) continue;
+            const float4 ev = *(const float4*)(el_l + 4 * q);
+            for (int n = r4; n < rows; n += 4) {
+                const float tp = tp_l[n], m = m_l[n], w = w_l[n];
+                const float4 b = *(const float4*)(Bt + (size_t)n * KP + 4 * q);
+                acc[s].x = fmaf(w, __expf(fmaf(tp, b.x, ev.x) - m), acc[s].x);
+                acc[s].y = fmaf(w, __expf(fmaf(tp, b.y, ev.y) - m), acc[s].y);
+                acc[s].z = fmaf(w, __expf(fmaf(tp, b.z, ev.z) - m), acc[s].z);
+                acc[s].w = fmaf(w, __expf(fmaf(tp, b.w, ev.w) - m), acc[s].w);
+            }
+        }
+    };
+
+    int sweeps = 0;
+    for (int v = 0; v < p.viter; ++v) {
+        ++sweeps;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) if (on[s]) el_l[lane + 64 * s] = elog[s];
+        for (int i = K + lane; i < KP; i += 64) el_l[i] = -INFINITY;    // pads: exp(-inf) = 0
+        WAVE_LDS_FENCE();
+        float4 acc[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) acc[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (single) {
+            if (v == 0 && N) load_chunk(0, N, true);
+            phase_a(0, N, false);                      // tau lives in the tile; stored once at the end
+            phase_b(N, acc);
+        } else {
+            for (int c0 = 0; c0 < N; c0 += tile_rows) {
+                const int rows = min(tile_rows, N - c0);
+                load_chunk(c0, rows, true);
+                phase_a(c0, rows, true);               // the last executed sweep's values remain
+                phase_b(rows, acc);
+                WAVE_LDS_FENCE();
+            }
+        }
+        float gl = 0.0f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            float4 a = dpp_add4<0xB1>(acc[s]);
+            a = dpp_add4<0x4E>(a);
+            const float g = (r4 == 0) ? a.x : (r4 == 1) ? a.y : (r4 == 2) ? a.z : a.w;
+            gam[s] = TMVB_EPS_F + (alpha[s] + g);                       // update_gamma!  :175
+            if (on[s]) gl += gam[s];
+        }
+        const float dgs = digamma_f(wave_sum(gl));
+        float dl = 0.0f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            elog_old[s] = elog[s];                                      // update_Elogtheta!  :167-168
+            if (on[s]) {
+                elog[s] = digamma_f(gam[s]) - dgs;
+                const float df = elog[s] - elog_old[s];
+                dl = fmaf(df, df, dl);
+            }
+        }
+        if (__builtin_amdgcn_sqrtf(wave_sum(dl)) < p.vtol) break;       // :230
+    }
+
+    if (sweeps > 0) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int i = lane + 64 * s;
+            if (on[s]) {
+                p.gamma[(int64_t)d * K + i] = gam[s];
+                p.elog[(int64_t)d * K + i] = elog[s];
+                p.elog_old[(int64_t)d * K + i] = elog_old[s];
+            }
+        }
+        if (single)
+            for (int n = lane; n < N; n += 64) {
+                p.tau_old[off + n] = tp_l[n]; p.tau[off + n] = tn_l[n];
+                p.lse[off + n] = m_l[n] + __logf(c_l[n] / w_l[n]);      // m + log s
+            }
+    } else {
+        for (int n = lane; n < N; n += 64) p.lse[off + n] = INFINITY;   // viter = 0: no responsibilities (phi = 0 in the statistics)
+    }
+    if (lane == 0) p.sweeps[d] = (uint8_t)min(sweeps, 255);
+}
+
+// ------------------------------------------------------------------------------ statistics
+// update_beta!(model, d) (src/fLDA.jl:161) and update_kappa!(model, d) (:147) as ONE gather over the term-major
+// inverted index: for every token n of term j
+//     S[i, j] += tau_n c_n phi[i, n],   phi[i, n] = exp(tau_old_n L[j][i] + Elogtheta_old[i, doc_n] - lse_n)
+//     kstat[j] += (1 - tau_n) c_n
+// One wave per chunk of <= TMVB_CHUNK tokens of one term (lane = topic), partial slots for multi-chunk terms.
+struct FldaStatsParams {
+    int K, KP;
+    const int32_t* tok_doc; const int32_t* tok_pos; const float* tok_val;
+    const int32_t* chunk_id; const int32_t* chunk_begin; const int32_t* chunk_end; const int32_t* chunk_out;
+    int n_chunks;
+    const float* L; const float* elog_old; const float* tau; const float* tau_old; const float* lse;
+    float* S;          // [V][K]
+    float* kstat;      // [V]
+    float* partial;    // [n_slots][K + 1]
+};
+
+template <int NS>
+__global__ __launch_bounds__(256) void flda_stats_kernel(FldaStatsParams p)
+{
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= p.n_chunks) return;
+    const int K = p.K;
+    const int j = p.chunk_id[c];
+    const int b = p.chunk_begin[c], e = p.chunk_end[c];
+    float Lj[NS], acc[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int i = lane + 64 * s;
+        Lj[s] = (i < K) ? p.L[(int64_t)j * p.KP + i] : 0.0f;
+        acc[s] = 0.0f;
+    }
+    float kl = 0.0f;
+    for (int t0 = b; t0 < e; t0 += 64) {
+        const int tok = t0 + lane;
+        const bool valid = tok < e;
+        const int dd = valid ? p.tok_doc[tok] : 0;
+        const int pos = valid ? p.tok_pos[tok] : 0;
+        const float cn = valid ? p.tok_val[tok] : 0.0f;
+        const float tn = valid ? p.tau[pos] : 0.0f, tp = valid ? p.tau_old[pos] : 0.0f, ls = valid ? p.lse[pos] : INFINITY;
+        const float vn = tn * cn;
+        kl += cn - vn;                                                  // (1 - tau_n) c_n
+        const int cnt = min(64, e - t0);
+        for (int k = 0; k < cnt; ++k) {
+            const int dk = __builtin_amdgcn_readlane(dd, k);
+            const float vk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vn), k));
+            const float tk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tp), k));
+            const float lk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ls), k));
+            const float* erow = p.elog_old + (int64_t)dk * K;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int i = lane + 64 * s;
+                if (i < K) acc[s] = fmaf(vk, __expf(fmaf(tk, Lj[s], erow[i]) - lk), acc[s]);
+            }
+        }
+    }
+    const float ksum = wave_sum(kl);
+    const int slot = p.chunk_out[c];
+    if (slot < 0) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int i = lane + 64 * s;
+            if (i < K) p.S[(int64_t)j * K + i] += acc[s];
+        }
+        if (lane == 0) p.kstat[j] += ksum;
+    } else {
+        float* pr = p.partial + (int64_t)slot * (K + 1);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int i = lane + 64 * s;
+            if (i < K) pr[i] = acc[s];
+        }
+        if (lane == 0) pr[K] = ksum;
+    }
+}
+
+// terms split over several chunks: partial slots summed in a fixed order
+template <int NS>
+__global__ __launch_bounds__(64) void flda_stats_multi_kernel(FldaStatsParams p, const int32_t* __restrict__ multi_id,
+                                                              const int32_t* __restrict__ multi_first,
+                                                              const int32_t* __restrict__ multi_count, int n_multi)
+{
+    const int lane = threadIdx.x;
+    const int m = blockIdx.x;
+    if (m >= n_multi) return;
+    const int K = p.K;
+    const int j = multi_id[m], first = multi_first[m], cnt = multi_count[m];
+    float acc[NS], ks = 0.0f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) acc[s] = 0.0f;
+    for (int c = 0; c < cnt; ++c) {
+        const float* pr = p.partial + (int64_t)(first + c) * (K + 1);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int i = lane + 64 * s;
+            if (i < K) acc[s] += pr[i];
+        }
+        ks += pr[K];
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int i = lane + 64 * s;
+        if (i < K) p.S[(int64_t)j * K + i] += acc[s];
+    }
+    if (lane == 0) p.kstat[j] += ks;
+}
+
+// ------------------------------------------------------------------------------ M-step
+// L = log(beta + eps) in the padded layout (pads 0)
+__global__ __launch_bounds__(256) void flda_logbeta_kernel(const float* __restrict__ beta, float* __restrict__ L, int K, int KP, int64_t V)
+{
+    const int64_t total = V * KP;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(q % KP);
+        L[q] = (i < K) ? logf(beta[q] + TMVB_EPS_F) : 0.0f;
+    }
+}
+
+// update_kappa!(model) (src/fLDA.jl:138-142) and update_eta! (:122-124) in one workgroup:
+//   kappa_old <- kappa; kappa <- kstat / sum(kstat); kstat <- 0;
+//   eta = sum_d dot(tau_d, counts_d) / sum(C) = 1 - sum(kstat) / C_total     (sum_n (1 - tau_n) c_n = sum(kstat))
+// do_eta = 0 leaves eta alone (the reference's order runs update_alpha! between the two, which touches neither).
+__global__ __launch_bounds__(1024) void flda_kappa_eta_kernel(float* __restrict__ kstat, float* __restrict__ kappa, float* __restrict__ kappa_old,
+                                                              int64_t V, double C_total, double* __restrict__ eta, int do_kappa, int do_eta,
+                                                              double* __restrict__ ksum_keep)
+{
+    __shared__ double red[1024];
+    if (do_kappa) {
+        double s = 0.0;
+        for (int64_t j = threadIdx.x; j < V; j += 1024) s += (double)kstat[j];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int o = 512; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        const double tot = red[0];
+        for (int64_t j = threadIdx.x; j < V; j += 1024) {
+            kappa_old[j] = kappa[j];
+            kappa[j] = (float)((double)kstat[j] / tot);
+            kstat[j] = 0.0f;
+        }
+        if (threadIdx.x == 0) *ksum_keep = tot;
+    }
+    if (do_eta && threadIdx.x == 0) eta[0] = 1.0 - *ksum_keep / C_total;
+}
+
+// ------------------------------------------------------------------------------ ELBO
+// update_elbo!  src/fLDA.jl:108-118 per document (terms :62-105 without the corpus-level constant of Elogptheta, added by
+// lda_elbo_final_kernel).  One wave per document, lane l owns topics l + 64 s.  phi is rebuilt from tau_old, beta_old,
+// Elogtheta_old (:112).
+template <int NS>
+__global__ __launch_bounds__(64) void flda_elbo_kernel(int K, int KP, const int64_t* __restrict__ doc_ptr,
+                                                       const int32_t* __restrict__ terms, const int32_t* __restrict__ counts,
+                                                       const double* __restrict__ alpha_d, const double* __restrict__ eta_d,
+                                                       const float* __restrict__ kappa, const float* __restrict__ beta,
+                                                       const float* __restrict__ beta_old, const float* __restrict__ gamma,
+                                                       const float* __restrict__ elog, const float* __restrict__ elog_old,
+                                                       const float* __restrict__ tau, const float* __restrict__ tau_old,
+                                                       double* __restrict__ doc_val)
+{
+    const int lane = threadIdx.x;
+    const int d = blockIdx.x;
+    const int64_t off = doc_ptr[d];
+    const int N = (int)(doc_ptr[d + 1] - off);
+    bool on[NS]; int ix[NS];
+    float eo[NS];
+    double pc[NS], acc = 0.0, ta = 0.0, Cd = 0.0;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        on[s] = lane + 64 * s < K;
+        ix[s] = on[s] ? lane + 64 * s : 0;
+        eo[s] = on[s] ? elog_old[(int64_t)d * K + ix[s]] : -INFINITY;
+        pc[s] = 0.0;
+    }
+    for (int n = 0; n < N; ++n) {
+        const int t = terms[off + n];
+        const float c = (float)counts[off + n];
+        const float tn = tau[off + n], to = tau_old[off + n];
+        float x[NS], ml = -INFINITY;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            x[s] = on[s] ? fmaf(to, logf(beta_old[(int64_t)t * KP + ix[s]] + TMVB_EPS_F), eo[s]) : -INFINITY;   // :112
+            ml = fmaxf(ml, x[s]);
+        }
+        const float mx = wave_max(ml);
+        float ex[NS], sl = 0.0f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { ex[s] = on[s] ? expf(x[s] - mx) : 0.0f; sl += ex[s]; }
+        const float inv = 1.0f / wave_sum(sl);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (!on[s]) continue;
+            const float ph = ex[s] * inv;
+            const double cp = (double)(c * ph);
+            pc[s] += cp;
+            acc += cp * (double)tn * (double)logf(beta[(int64_t)t * KP + ix[s]] + TMVB_EPS_F);     // Elogpw :83, topical part
+            if (ph > 0.0f) acc -= cp * (double)logf(ph);                                           // -Elogqz :101-104
+        }
+        if (lane == 0) {
+            acc += (double)c * (1.0 - (double)tn) * (double)logf(kappa[t] + TMVB_EPS_F);           // Elogpw :83, background part
+            if (tn > 0.0f && tn < 1.0f) acc -= (double)c * ((double)tn * log((double)tn) + (1.0 - (double)tn) * log(1.0 - (double)tn));   // -Elogqc :94-97
+        }
+        ta += (double)tn * (double)c; Cd += (double)c;
+    }
+    double gl = 0.0;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        if (!on[s]) continue;
+        const double el = (double)elog[(int64_t)d * K + ix[s]];
+        const double g = (double)gamma[(int64_t)d * K + ix[s]];
+        acc += (alpha_d[ix[s]] - 1.0) * el;                                                        // Elogptheta :63 (dot part)
+        acc += pc[s] * el;                                                                         // Elogpz :77
+        if (K > 1) acc += lgamma(g) - (g - 1.0) * digamma_d(g);                                    // -Elogqtheta :89 (utils.jl:172-176)
+        gl += g;
+    }
+    const double g0 = wave_sum_d(gl);
+    double tot = wave_sum_d(acc);
+    if (K > 1) tot += -lgamma(g0) + (g0 - (double)K) * digamma_d(g0);
+    // Elogpc :69-71: the powers are formed first, so the term saturates at log(eps) for documents of more than ~100 tokens
+    const double eta = eta_d[0];
+    tot += log(TMVB_EPS_D + pow(eta, ta) * pow(1.0 - eta, Cd - ta));
+    if (lane == 0) doc_val[d] = tot;
+}
+
+// ------------------------------------------------------------------------------ host side
+struct tmvb_flda {
+    tmvb_ctx* ctx = nullptr;
+    tmvb_corpus* corp = nullptr;
+    int K = 0, KP = 0, nslot = 1;
+    int64_t M = 0, V = 0, M_total = 0, nnz = 0;
+    double C_total = 0.0;
+    bool distributed = false;
+    tmvb_comm* comm = nullptr;
+    double* d_alpha_d = nullptr; float* d_alpha_f = nullptr;
+    float* d_beta[2] = {nullptr, nullptr}; int cur = 0;        // padded [V][KP]
+    float* d_L = nullptr;                                      // log(beta + eps)
+    float* d_kappa = nullptr; float* d_kappa_old = nullptr;    // [V]
+    double* d_eta = nullptr; double* d_ksum = nullptr;
+    float* d_stats = nullptr;                                  // S (K*V) | kstat (V) | Elogtheta_sum (K)
+    float* d_gamma = nullptr; float* d_elog = nullptr; float* d_elog_old = nullptr;
+    float* d_tau = nullptr; float* d_tau_old = nullptr; float* d_lse = nullptr;
+    float* d_ts_partial = nullptr;
+    uint8_t* d_sweeps = nullptr; int32_t* d_doc_order = nullptr;
+    double* d_partial = nullptr; double* d_rowsum = nullptr; double* d_esum = nullptr; double* d_doc_val = nullptr; double* d_elbo = nullptr;
+    int* d_iters = nullptr;
+    double elbo = 0.0;
+    std::vector<tmvb_bucket> buckets;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    int64_t stats_len() const { return (int64_t)K * V + V + K; }
+    float* kstat() const { return d_stats + (size_t)K * V; }
+    float* esum_f() const { return d_stats + (size_t)K * V + (size_t)V; }
+};
+
+extern "C" int tmvb_flda_destroy(tmvb_flda* h)
+{
+    if (!h) return TMVB_OK;
+    if (h->ctx) { (void)hipSetDevice(h->ctx->device); (void)hipStreamSynchronize(h->ctx->stream); }
+    (void)hipFree(h->d_alpha_d); (void)hipFree(h->d_alpha_f); (void)hipFree(h->d_beta[0]); (void)hipFree(h->d_beta[1]); (void)hipFree(h->d_L);
+    (void)hipFree(h->d_kappa); (void)hipFree(h->d_kappa_old); (void)hipFree(h->d_eta); (void)hipFree(h->d_ksum); (void)hipFree(h->d_stats);
+    (void)hipFree(h->d_gamma); (void)hipFree(h->d_elog); (void)hipFree(h->d_elog_old); (void)hipFree(h->d_tau); (void)hipFree(h->d_tau_old);
+    (void)hipFree(h->d_lse); (void)hipFree(h->d_ts_partial); (void)hipFree(h->d_sweeps); (void)hipFree(h->d_doc_order); (void)hipFree(h->d_partial);
+    (void)hipFree(h->d_rowsum); (void)hipFree(h->d_esum); (void)hipFree(h->d_doc_val); (void)hipFree(h->d_elbo); (void)hipFree(h->d_iters);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    delete h;
+    return TMVB_OK;
+}
+
+static int flda_upload_beta(tmvb_flda* h, float* dst, const double* src)
+{
+    const size_t K = h->K, KP = h->KP, V = h->V;
+    std::vector<float> tmp(V * KP + 4, 0.0f);
+    for (size_t j = 0; j < V; ++j)
+        for (size_t i = 0; i < K; ++i) tmp[j * KP + i] = (float)src[j * K + i];
+    TMVB_HIP(hipMemcpyAsync(dst, tmp.data(), tmp.size() * sizeof(float), hipMemcpyHostToDevice, h->ctx->stream));
+    TMVB_HIP(hipStreamSynchronize(h->ctx->stream));
+    return TMVB_OK;
+}
+
+static int flda_download_beta(tmvb_flda* h, double* dst, const float* src)
+{
+    const size_t K = h->K, KP = h->KP, V = h->V;
+    std::vector<float> tmp(V * KP);
+    TMVB_HIP(hipMemcpyAsync(tmp.data(), src, tmp.size() * sizeof(float), hipMemcpyDeviceToHost, h->ctx->stream));
+    TMVB_HIP(hipStreamSynchronize(h->ctx->stream));
+    for (size_t j = 0; j < V; ++j)
+        for (size_t i = 0; i < K; ++i) dst[j * K + i] = (double)tmp[j * KP + i];
+    return TMVB_OK;
+}
+
+static int flda_refresh_L(tmvb_flda* h)
+{
+    const int64_t total = (int64_t)h->KP * h->V;
+    const int nb = (int)std::min<int64_t>(2048, std::max<int64_t>(1, (total + 255) / 256));
+    hipLaunchKernelGGL(flda_logbeta_kernel, dim3(nb), dim3(256), 0, h->ctx->stream, h->d_beta[h->cur], h->d_L, h->K, h->KP, h->V);
+    TMVB_HIP(hipGetLastError());
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_flda_set_state(tmvb_flda* h, const double* eta, const double* alpha, const double* kappa, const double* kappa_old,
+                                   const double* beta, const double* beta_old, const double* gamma, const double* Elogtheta,
+                                   const double* Elogtheta_old, const double* tau, const double* tau_old, const double* elbo);
+
+extern "C" int tmvb_flda_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb_flda** out)
+{
+    TMVB_REQUIRE(out != nullptr, TMVB_EINVAL, "tmvb_flda_create: out is NULL");
+    *out = nullptr;
+    TMVB_REQUIRE(ctx && corp, TMVB_EINVAL, "tmvb_flda_create: NULL context or corpus");
+    TMVB_REQUIRE(K > 0, TMVB_EINVAL, "number of topics must be a positive integer.");      // src/fLDA.jl:30
+    TMVB_REQUIRE(K <= 128, TMVB_EINVAL, "tmvb_flda_create: K <= 128 (two topic slots per lane); got K=%d", K);
+    TMVB_HIP(hipSetDevice(ctx->device));
+    tmvb_flda* h = new tmvb_flda();
+    tmvb_create_guard<tmvb_flda, tmvb_flda_destroy> guard{h};
+    h->ctx = ctx; h->corp = corp; h->K = K; h->KP = tmvb_kpad(K); h->nslot = (K + 63) / 64;
+    h->M = corp->info.M; h->V = corp->info.V; h->M_total = h->M; h->nnz = corp->info.nnz;
+    h->C_total = (double)corp->info.sum_counts;
+    const size_t KM = (size_t)K * h->M, KPV = (size_t)h->KP * h->V + 4, NZ = (size_t)h->nnz;
+    int rc;
+    if ((rc = tmvb_corpus_term_index(corp))) return rc;
+    if ((rc = dmalloc(&h->d_alpha_d, K)) || (rc = dmalloc(&h->d_alpha_f, K)) || (rc = dmalloc(&h->d_beta[0], KPV)) || (rc = dmalloc(&h->d_beta[1], KPV)) ||
+        (rc = dmalloc(&h->d_L, KPV)) || (rc = dmalloc(&h->d_kappa, (size_t)h->V)) || (rc = dmalloc(&h->d_kappa_old, (size_t)h->V)) ||
+        (rc = dmalloc(&h->d_eta, 1)) || (rc = dmalloc(&h->d_ksum, 1)) || (rc = dmalloc(&h->d_stats, (size_t)h->stats_len())) ||
+        (rc = dmalloc(&h->d_gamma, KM)) || (rc = dmalloc(&h->d_elog, KM)) || (rc = dmalloc(&h->d_elog_old, KM)) ||
+        (rc = dmalloc(&h->d_tau, NZ)) || (rc = dmalloc(&h->d_tau_old, NZ)) || (rc = dmalloc(&h->d_lse, NZ)) ||
+        (rc = dmalloc(&h->d_ts_partial, (size_t)corp->term_index.n_slots * (K + 1))) || (rc = dmalloc(&h->d_sweeps, (size_t)h->M)) ||
+        (rc = dmalloc(&h->d_doc_order, (size_t)h->M)) || (rc = dmalloc(&h->d_partial, (size_t)TMVB_REDUCE_BLOCKS * K)) ||
+        (rc = dmalloc(&h->d_rowsum, K)) || (rc = dmalloc(&h->d_esum, K)) || (rc = dmalloc(&h->d_doc_val, (size_t)h->M)) ||
+        (rc = dmalloc(&h->d_elbo, 1)) || (rc = dmalloc(&h->d_iters, 1)))
+        return rc;
+    std::vector<int32_t> order((size_t)h->M);
+    std::iota(order.begin(), order.end(), 0);
+    const std::vector<int64_t>& len = corp->h_doc_len;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return len[x] > len[y]; });
+    {   // LDS tile buckets with this kernel's per-row footprint (6 floats of per-token scratch): cap the tile at 32 KB
+        std::vector<tmvb_bucket> bk;
+        tmvb_build_lds_buckets(len, order, h->M, h->KP + 3, -1, 3, bk, 32 * 1024);
+        h->buckets = bk;
+    }
+    if (h->M) TMVB_HIP(hipMemcpyAsync(h->d_doc_order, order.data(), (size_t)h->M * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    TMVB_HIP(hipMemsetAsync(h->d_stats, 0, (size_t)h->stats_len() * sizeof(float), ctx->stream));
+    TMVB_HIP(hipMemsetAsync(h->d_sweeps, 0, std::max<size_t>((size_t)h->M, 1), ctx->stream));
+    TMVB_HIP(hipMemsetAsync(h->d_beta[0], 0, KPV * sizeof(float), ctx->stream));
+    TMVB_HIP(hipMemsetAsync(h->d_beta[1], 0, KPV * sizeof(float), ctx->stream));
+    TMVB_HIP(hipMemsetAsync(h->d_lse, 0, std::max<size_t>(NZ, 1) * sizeof(float), ctx->stream));
+    TMVB_HIP(hipMemsetAsync(h->d_ksum, 0, sizeof(double), ctx->stream));
+    TMVB_HIP(hipEventCreate(&h->ev0));
+    TMVB_HIP(hipEventCreate(&h->ev1));
+    TMVB_HIP(hipStreamSynchronize(ctx->stream));
+    // constructor state, src/fLDA.jl:38-52: eta = 0.5, alpha = 1, gamma = 1, Elogtheta = psi(1) - psi(K), tau = eta;
+    // kappa and beta are drawn from Dirichlet(V, 1) with Julia's RNG in the reference: uniform until tmvb_flda_set_state
+    const double eta0 = 0.5;
+    std::vector<double> alpha(K, 1.0), kap((size_t)h->V, h->V ? 1.0 / (double)h->V : 0.0), beta((size_t)K * h->V, h->V ? 1.0 / (double)h->V : 0.0);
+    std::vector<double> gamma(KM, 1.0), elog(KM, -0.5772156649015329 - tmvb_digamma_host((double)K)), tau(NZ, eta0);
+    rc = tmvb_flda_set_state(h, &eta0, alpha.data(), kap.data(), nullptr, beta.data(), nullptr, gamma.data(), elog.data(), nullptr, tau.data(), nullptr, nullptr);
+    if (rc) return rc;
+    guard.release();
+    *out = h;
+    return TMVB_OK;
+}
+
+// update_buffer!-style state upload (the reference has no device model for fLDA; the fields are those of src/fLDA.jl:6-29).
+// NULL = unchanged; *_old default to the current values.  tau / tau_old: [nnz] in CSR token order.
+extern "C" int tmvb_flda_set_state(tmvb_flda* h, const double* eta, const double* alpha, const double* kappa, const double* kappa_old,
+                                   const double* beta, const double* beta_old, const double* gamma, const double* Elogtheta,
+                                   const double* Elogtheta_old, const double* tau, const double* tau_old, const double* elbo)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_flda_set_state: handle is NULL");
+    tmvb_ctx* ctx = h->ctx;
+    TMVB_HIP(hipSetDevice(ctx->device));
+    const size_t K = h->K, KM = K * (size_t)h->M, V = (size_t)h->V, NZ = (size_t)h->nnz;
+    int rc;
+    if (eta) {
+        TMVB_REQUIRE(*eta >= 0.0 && *eta <= 1.0, TMVB_ESHAPE, "eta must belong to the interval [0,1].");     // src/modelutils.jl:75
+        TMVB_HIP(hipMemcpyAsync(h->d_eta, eta, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        TMVB_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    if (alpha) {
+        for (size_t i = 0; i < K; ++i) TMVB_REQUIRE(std::isfinite(alpha[i]) && alpha[i] > 0.0, TMVB_ENONFINITE, "alpha must be finite and positive.");
+        TMVB_HIP(hipMemcpyAsync(h->d_alpha_d, alpha, K * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        if ((rc = upload_f32(ctx, h->d_alpha_f, alpha, K))) return rc;
+    }
+    if (kappa) {
+        if ((rc = upload_f32(ctx, h->d_kappa, kappa, V))) return rc;
+        if (!kappa_old && (rc = upload_f32(ctx, h->d_kappa_old, kappa, V))) return rc;
+    }
+    if (kappa_old && (rc = upload_f32(ctx, h->d_kappa_old, kappa_old, V))) return rc;
+    if (beta) {
+        if ((rc = flda_upload_beta(h, h->d_beta[h->cur], beta))) return rc;
+        if (!beta_old && (rc = flda_upload_beta(h, h->d_beta[h->cur ^ 1], beta))) return rc;
+        if ((rc = flda_refresh_L(h))) return rc;
+    }
+    if (beta_old && (rc = flda_upload_beta(h, h->d_beta[h->cur ^ 1], beta_old))) return rc;
+    if (gamma && (rc = upload_f32(ctx, h->d_gamma, gamma, KM))) return rc;
+    if (Elogtheta) {
+        if ((rc = upload_f32(ctx, h->d_elog, Elogtheta, KM))) return rc;
+        if (!Elogtheta_old && (rc = upload_f32(ctx, h->d_elog_old, Elogtheta, KM))) return rc;
+    }
+    if (Elogtheta_old && (rc = upload_f32(ctx, h->d_elog_old, Elogtheta_old, KM))) return rc;
+    if (tau) {
+        for (size_t q = 0; q < NZ; ++q) TMVB_REQUIRE(tau[q] >= 0.0 && tau[q] <= 1.0, TMVB_ESHAPE, "tau must belong to the interval [0,1].");
+        if ((rc = upload_f32(ctx, h->d_tau, tau, NZ))) return rc;
+        if (!tau_old && (rc = upload_f32(ctx, h->d_tau_old, tau, NZ))) return rc;
+    }
+    if (tau_old && (rc = upload_f32(ctx, h->d_tau_old, tau_old, NZ))) return rc;
+    if (elbo) h->elbo = *elbo;
+    TMVB_HIP(hipStreamSynchronize(ctx->stream));
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_flda_get_state(tmvb_flda* h, double* eta, double* alpha, double* kappa, double* kappa_old, double* beta, double* beta_old,
+                                   double* gamma, double* Elogtheta, double* Elogtheta_old, double* tau, double* tau_old, double* elbo)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_flda_get_state: handle is NULL");
+    tmvb_ctx* ctx = h->ctx;
+    TMVB_HIP(hipSetDevice(ctx->device));
+    const size_t K = h->K, KM = K * (size_t)h->M, V = (size_t)h->V, NZ = (size_t)h->nnz;
+    int rc;
+    if (eta) TMVB_HIP(hipMemcpyAsync(eta, h->d_eta, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (alpha) TMVB_HIP(hipMemcpyAsync(alpha, h->d_alpha_d, K * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    TMVB_HIP(hipStreamSynchronize(ctx->stream));
+    if (kappa && (rc = download_f32(ctx, kappa, h->d_kappa, V))) return rc;
+    if (kappa_old && (rc = download_f32(ctx, kappa_old, h->d_kappa_old, V))) return rc;
+    if (beta && (rc = flda_download_beta(h, beta, h->d_beta[h->cur]))) return rc;
+    if (beta_old && (rc = flda_download_beta(h, beta_old, h->d_beta[h->cur ^ 1]))) return rc;
+    if (gamma && (rc = download_f32(ctx, gamma, h->d_gamma, KM))) return rc;
+    if (Elogtheta && (rc = download_f32(ctx, Elogtheta, h->d_elog, KM))) return rc;
+    if (Elogtheta_old && (rc = download_f32(ctx, Elogtheta_old, h->d_elog_old, KM))) return rc;
+    if (tau && (rc = download_f32(ctx, tau, h->d_tau, NZ))) return rc;
+    if (tau_old && (rc = download_f32(ctx, tau_old, h->d_tau_old, NZ))) return rc;
+    if (elbo) *elbo = h->elbo;
+    return TMVB_OK;
+}
+
+// update_phi! / update_tau! / update_gamma! / update_Elogtheta! sweeps + update_beta!(model, d) + update_kappa!(model, d) for
+// every document (src/fLDA.jl:222-236).  Asynchronous on the context's stream.
+extern "C" int tmvb_flda_estep(tmvb_flda* h, int32_t viter, double vtol)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_flda_estep: handle is NULL");
+    TMVB_REQUIRE(viter >= 0, TMVB_EINVAL, "iteration parameters must be nonnegative.");     // src/fLDA.jl:216
+    TMVB_REQUIRE(vtol >= 0, TMVB_EINVAL, "tolerance parameters must be nonnegative.");      // :215
+    tmvb_ctx* ctx = h->ctx;
+    TMVB_HIP(hipSetDevice(ctx->device));
+    FldaParams p;
+    p.K = h->K; p.KP = h->KP; p.LPR = h->KP / 4; p.lpr_magic = (unsigned)(0x100000000ull / (unsigned)p.LPR) + 1u;
+    p.doc_ptr = h->corp->d_doc_ptr; p.terms = h->corp->d_terms; p.counts = h->corp->d_counts; p.doc_order = h->d_doc_order;
+    p.L = h->d_L; p.kappa = h->d_kappa; p.eta = h->d_eta; p.alpha = h->d_alpha_f;
+    p.gamma = h->d_gamma; p.elog = h->d_elog; p.elog_old = h->d_elog_old; p.tau = h->d_tau; p.tau_old = h->d_tau_old; p.lse = h->d_lse;
+    p.sweeps = h->d_sweeps; p.viter = viter; p.vtol = (float)vtol;
+    TMVB_HIP(hipEventRecord(h->ev0, ctx->stream));
+    for (const tmvb_bucket& b : h->buckets) {
+        const size_t lds = flda_tile_bytes(b.tile_rows, h->KP);
+        const dim3 grid((unsigned)b.count), block(64);
+        if (h->nslot == 1) hipLaunchKernelGGL((flda_estep_kernel<1>), grid, block, lds, ctx->stream, p, b.first, b.tile_rows);
+        else hipLaunchKernelGGL((flda_estep_kernel<2>), grid, block, lds, ctx->stream, p, b.first, b.tile_rows);
+        TMVB_HIP(hipGetLastError());
+    }
+    const tmvb_inv_index& ix = h->corp->term_index;
+    if (ix.n_chunks > 0) {
+        FldaStatsParams sp;
+        sp.K = h->K; sp.KP = h->KP; sp.tok_doc = ix.d_doc; sp.tok_pos = ix.d_pos; sp.tok_val = ix.d_val;
+        sp.chunk_id = ix.d_chunk_id; sp.chunk_begin = ix.d_chunk_begin; sp.chunk_end = ix.d_chunk_end; sp.chunk_out = ix.d_chunk_out;
+        sp.n_chunks = (int)ix.n_chunks; sp.L = h->d_L; sp.elog_old = h->d_elog_old; sp.tau = h->d_tau; sp.tau_old = h->d_tau_old; sp.lse = h->d_lse;
+        sp.S = h->d_stats; sp.kstat = h->kstat(); sp.partial = h->d_ts_partial;
+        const dim3 grid((unsigned)((ix.n_chunks + 3) / 4)), block(256);
+        if (h->nslot == 1) hipLaunchKernelGGL((flda_stats_kernel<1>), grid, block, 0, ctx->stream, sp);
+        else hipLaunchKernelGGL((flda_stats_kernel<2>), grid, block, 0, ctx->stream, sp);
+        TMVB_HIP(hipGetLastError());
+        if (ix.n_multi > 0) {
+            if (h->nslot == 1) hipLaunchKernelGGL((flda_stats_multi_kernel<1>), dim3((unsigned)ix.n_multi), dim3(64), 0, ctx->stream, sp, ix.d_multi_id, ix.d_multi_first, ix.d_multi_count, (int)ix.n_multi);
+            else hipLaunchKernelGGL((flda_stats_multi_kernel<2>), dim3((unsigned)ix.n_multi), dim3(64), 0, ctx->stream, sp, ix.d_multi_id, ix.d_multi_first, ix.d_multi_count, (int)ix.n_multi);
+            TMVB_HIP(hipGetLastError());
+        }
+    }
+    TMVB_HIP(hipEventRecord(h->ev1, ctx->stream));
+    h->timed = true;
+    return TMVB_OK;
+}
+
+// Elogtheta_sum (update_alpha!'s input, src/fLDA.jl:129) into the statistics tail
+extern "C" int tmvb_flda_reduce_docs(tmvb_flda* h)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_flda_reduce_docs: handle is NULL");
+    TMVB_HIP(hipSetDevice(h->ctx->device));
+    return tmvb_colsum(h->ctx, h->nslot, h->K, h->d_elog, h->M, h->d_partial, h->d_esum, h->esum_f());
+}
+
+extern "C" int tmvb_flda_stats(tmvb_flda* h, void** dev_ptr, int64_t* n_f32)
+{
+    TMVB_REQUIRE(h && dev_ptr && n_f32, TMVB_EINVAL, "tmvb_flda_stats: NULL argument");
+    *dev_ptr = h->d_stats;
+    *n_f32 = h->stats_len();
+    return TMVB_OK;
+}
+
+// Attach / detach a communicator: this handle holds one document shard of a corpus of M_total documents and C_total tokens.
+extern "C" int tmvb_flda_set_comm(tmvb_flda* h, tmvb_comm* comm, int64_t M_total, int64_t C_total)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_flda_set_comm: handle is NULL");
+    if (comm) {
+        TMVB_REQUIRE(M_total >= h->M && C_total >= h->corp->info.sum_counts, TMVB_ESHAPE, "tmvb_flda_set_comm: totals smaller than the local shard");
+        h->M_total = M_total; h->C_total = (double)C_total;
+    } else {
+        h->M_total = h->M; h->C_total = (double)h->corp->info.sum_counts;
+    }
+    h->distributed = comm != nullptr;
+    h->comm = comm;
+    return TMVB_OK;
+}
+
+// update_beta!(model) (src/fLDA.jl:152-156) and update_kappa!(model) (:138-142), which train! runs back to back (:237-238);
+// refreshes the log table.
+extern "C" int tmvb_flda_update_beta(tmvb_flda* h)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_flda_update_beta: handle is NULL");
+    tmvb_ctx* ctx = h->ctx;
+    TMVB_HIP(hipSetDevice(ctx->device));
+    int rc = tmvb_colsum(ctx, h->nslot, h->K, h->d_stats, h->V, h->d_partial, h->d_rowsum, nullptr);
+    if (rc) return rc;
+    const int64_t total = (int64_t)h->KP * h->V;
+    const int nb = (int)std::min<int64_t>(2048, std::max<int64_t>(1, (total + 255) / 256));
+    hipLaunchKernelGGL(beta_norm_kernel, dim3(nb), dim3(256), (size_t)h->K * sizeof(double), ctx->stream,
+                       h->d_stats, h->d_rowsum, h->d_beta[h->cur ^ 1], h->K, h->KP, h->V, (double*)nullptr, 0.0f);
+    TMVB_HIP(hipGetLastError());
+    h->cur ^= 1;                                            // beta_old <- beta, beta <- new
+    if ((rc = flda_refresh_L(h))) return rc;
+    hipLaunchKernelGGL(flda_kappa_eta_kernel, dim3(1), dim3(1024), 0, ctx->stream, h->kstat(), h->d_kappa, h->d_kappa_old, h->V, h->C_total,
+                       h->d_eta, 1, 0, h->d_ksum);
+    TMVB_HIP(hipGetLastError());
+    return TMVB_OK;
+}
+
+// update_alpha! (src/fLDA.jl:128-150): the LDA Newton iteration
+extern "C" int tmvb_flda_update_alpha(tmvb_flda* h, int32_t niter, double ntol)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_flda_update_alpha: handle is NULL");
+    TMVB_REQUIRE(niter >= 0, TMVB_EINVAL, "iteration parameters must be nonnegative.");
+    TMVB_REQUIRE(ntol >= 0, TMVB_EINVAL, "tolerance parameters must be nonnegative.");
+    tmvb_ctx* ctx = h->ctx;
+    TMVB_HIP(hipSetDevice(ctx->device));
+    const float* ef = h->distributed ? h->esum_f() : nullptr;      // sharded: the all-reduced fp32 tail
+    if (h->nslot == 1) hipLaunchKernelGGL((lda_alpha_kernel<1>), dim3(1), dim3(64), 0, ctx->stream, h->K, (double)h->M_total, h->d_esum, ef, h->d_alpha_d, h->d_alpha_f, niter, ntol, h->d_iters);
+    else hipLaunchKernelGGL((lda_alpha_kernel<2>), dim3(1), dim3(64), 0, ctx->stream, h->K, (double)h->M_total, h->d_esum, ef, h->d_alpha_d, h->d_alpha_f, niter, ntol, h->d_iters);
+    TMVB_HIP(hipGetLastError());
+    return TMVB_OK;
+}
+
+// update_eta! (src/fLDA.jl:122-124), from the background mass that update_kappa! summed
+extern "C" int tmvb_flda_update_eta(tmvb_flda* h)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_flda_update_eta: handle is NULL");
+    TMVB_HIP(hipSetDevice(h->ctx->device));
+    hipLaunchKernelGGL(flda_kappa_eta_kernel, dim3(1), dim3(1024), 0, h->ctx->stream, h->kstat(), h->d_kappa, h->d_kappa_old, h->V, h->C_total,
+                       h->d_eta, 0, 1, h->d_ksum);
+    TMVB_HIP(hipGetLastError());
+    return TMVB_OK;
+}
+
+// update_elbo! (src/fLDA.jl:108-118) on the device; the sum over this context's documents
+extern "C" int tmvb_flda_update_elbo(tmvb_flda* h, double* elbo)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_flda_update_elbo: handle is NULL");
+    tmvb_ctx* ctx = h->ctx;
+    TMVB_HIP(hipSetDevice(ctx->device));
+    if (h->M > 0) {
+        const dim3 grid((unsigned)h->M), block(64);
+        if (h->nslot == 1)
+            hipLaunchKernelGGL((flda_elbo_kernel<1>), grid, block, 0, ctx->stream, h->K, h->KP, h->corp->d_doc_ptr, h->corp->d_terms, h->corp->d_counts,
+                               h->d_alpha_d, h->d_eta, h->d_kappa, h->d_beta[h->cur], h->d_beta[h->cur ^ 1], h->d_gamma, h->d_elog, h->d_elog_old,
+                               h->d_tau, h->d_tau_old, h->d_doc_val);
+        else
+            hipLaunchKernelGGL((flda_elbo_kernel<2>), grid, block, 0, ctx->stream, h->K, h->KP, h->corp->d_doc_ptr, h->corp->d_terms, h->corp->d_counts,
+                               h->d_alpha_d, h->d_eta, h->d_kappa, h->d_beta[h->cur], h->d_beta[h->cur ^ 1], h->d_gamma, h->d_elog, h->d_elog_old,
+                               h->d_tau, h->d_tau_old, h->d_doc_val);
+        TMVB_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(lda_elbo_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, h->d_doc_val, h->M, h->K, h->d_alpha_d, h->d_elbo,
+                       (const double*)nullptr, 0, 1.0);
+    TMVB_HIP(hipGetLastError());
+    double v = 0.0;
+    TMVB_HIP(hipMemcpyAsync(&v, h->d_elbo, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    TMVB_HIP(hipStreamSynchronize(ctx->stream));
+    h->elbo = v;
+    if (elbo) *elbo = v;
+    return TMVB_OK;
+}
+
+namespace {
+struct FldaTrainOps {
+    int niter, viter; double ntol, vtol;
+    int estep(tmvb_flda* h) { return tmvb_flda_estep(h, viter, vtol); }                  // src/fLDA.jl:222-236
+    int reduce(tmvb_flda* h) { return tmvb_flda_reduce_docs(h); }
+    int before_allreduce(tmvb_flda*) { return TMVB_OK; }
+    float* stats(tmvb_flda* h) { return h->d_stats; }
+    int64_t stats_len(tmvb_flda* h) { return h->stats_len(); }
+    int mstep(tmvb_flda* h)
+    {
+        int rc = tmvb_flda_update_beta(h);                                               // :237-238 (beta, kappa)
+        if (!rc) rc = tmvb_flda_update_alpha(h, niter, ntol);                            // :239
+        if (!rc) rc = tmvb_flda_update_eta(h);                                           // :240
+        return rc;
+    }
+    int elbo_local(tmvb_flda* h, double* s, double* once) { *once = 0.0; return tmvb_flda_update_elbo(h, s); }
+    double* elbo_dev(tmvb_flda* h) { return h->d_elbo; }
+    tmvb_comm* comm(tmvb_flda* h) { return h->comm; }
+    bool distributed(tmvb_flda* h) { return h->distributed; }
+    tmvb_ctx* ctx(tmvb_flda* h) { return h->ctx; }
+    int64_t nnz(tmvb_flda* h) { return h->corp->info.nnz; }
+    void set_elbo(tmvb_flda* h, double v) { h->elbo = v; }
+    double get_elbo(tmvb_flda* h) { return h->elbo; }
+    int finish(tmvb_flda* h)
+    {
+        TMVB_HIP(hipSetDevice(h->ctx->device));
+        TMVB_HIP(hipStreamSynchronize(h->ctx->stream));
+        return TMVB_OK;
+    }
+};
+}  // namespace
+
+// NOTE on the sharded ELBO: lda_elbo_final_kernel adds M (lgamma(sum alpha) - sum lgamma(alpha)) with the LOCAL M, so the
+// ranks' values add up to the corpus ELBO.
+extern "C" int tmvb_flda_train_group(tmvb_flda* const* hs, int32_t n, int32_t iter, double tol, int32_t niter, double ntol, int32_t viter,
+                                     double vtol, int32_t checkelbo, double* elbo_traj, int32_t* iters_done, double* elbo_baseline)
+{
+    TMVB_REQUIRE(tol >= 0 && ntol >= 0 && vtol >= 0, TMVB_EINVAL, "tolerance parameters must be nonnegative.");   // src/fLDA.jl:215
+    TMVB_REQUIRE(iter >= 0 && niter >= 0 && viter >= 0, TMVB_EINVAL, "iteration parameters must be nonnegative."); // :216
+    FldaTrainOps ops{niter, viter, ntol, vtol};
+    return tmvb_train_group_loop("tmvb_flda_train", hs, n, iter, tol, checkelbo, elbo_traj, iters_done, elbo_baseline, ops);
+}
+
+// train! (src/fLDA.jl:213-247)
+extern "C" int tmvb_flda_train(tmvb_flda* h, int32_t iter, double tol, int32_t niter, double ntol, int32_t viter, double vtol,
+                               int32_t checkelbo, double* elbo_traj, int32_t* iters_done, double* elbo_baseline)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_flda_train: handle is NULL");
+    return tmvb_flda_train_group(&h, 1, iter, tol, niter, ntol, viter, vtol, checkelbo, elbo_traj, iters_done, elbo_baseline);
+}
+
+extern "C" int tmvb_flda_doc_sweeps(tmvb_flda* h, uint8_t* out)
+{
+    TMVB_REQUIRE(h && (out || h->M == 0), TMVB_EINVAL, "tmvb_flda_doc_sweeps: NULL argument");
+    TMVB_HIP(hipSetDevice(h->ctx->device));
+    if (h->M) TMVB_HIP(hipMemcpyAsync(out, h->d_sweeps, (size_t)h->M, hipMemcpyDeviceToHost, h->ctx->stream));
+    TMVB_HIP(hipStreamSynchronize(h->ctx->stream));
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_flda_last_estep_ms(tmvb_flda* h, float* ms)
+{
+    TMVB_REQUIRE(h && ms, TMVB_EINVAL, "tmvb_flda_last_estep_ms: NULL argument");
+    TMVB_REQUIRE(h->timed, TMVB_EINVAL, "tmvb_flda_last_estep_ms: no E-step has run");
+    TMVB_HIP(hipSetDevice(h->ctx->device));
+    TMVB_HIP(hipEventSynchronize(h->ev1));
+    TMVB_HIP(hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return TMVB_OK;
+}

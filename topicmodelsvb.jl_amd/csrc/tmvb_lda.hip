@@ -29,6 +29,7 @@
 // bytes per outer iteration: nnz*(8 + 4K + 4K) + 12*M*K + 12*K*V + 4*(M+1).
 #include "tmvb_common_kernels.h"
 #include "tmvb_train.h"
+#include "tmvb_dirichlet.h"
 #include "tmvb_regtile.h"
 
 // e_q of the first TMVB_LDA_E_LDS topics reach the lanes through LDS (one ds_write, broadcast ds_read_b128) instead of
@@ -497,74 +498,6 @@ __global__ __launch_bounds__(64) void lda_estep_reg_any_kernel(LdaParams p, int6
     else lda_estep_reg_body<LPR, 1>(p, d, off, N, topic_of_lane);
 }
 
-// update_alpha!  src/LDA.jl:97-118, fp64, one wave (lane = topic).
-template <int NSLOT>
-__global__ __launch_bounds__(64) void lda_alpha_kernel(int K, double Md, const double* __restrict__ esum_d,
-                                                       const float* __restrict__ esum_f, double* __restrict__ alpha_d,
-                                                       float* __restrict__ alpha_f, int niter, double ntol,
-                                                       int* __restrict__ iters_out)
-{
-    const int lane = threadIdx.x;
-    double a[NSLOT], es[NSLOT], grad[NSLOT], hinv[NSLOT], pp[NSLOT];
-#pragma unroll
-    for (int s = 0; s < NSLOT; ++s) {
-        int i = lane + 64 * s;
-        a[s] = (i < K) ? alpha_d[i] : 1.0;
-        es[s] = (i < K) ? (esum_f ? (double)esum_f[i] : esum_d[i]) : 0.0;
-    }
-    double nu = (double)K;
-    int it = 0;
-    for (int t = 0; t < niter; ++t) {
-        ++it;
-        double rho = 1.0;
-        double l = 0.0;
-#pragma unroll
-        for (int s = 0; s < NSLOT; ++s) if (lane + 64 * s < K) l += a[s];
-        const double asum = wave_sum_d(l);
-        const double dgs = digamma_d(asum);
-        double gh = 0.0, hs = 0.0, gn2 = 0.0;
-#pragma unroll
-        for (int s = 0; s < NSLOT; ++s) {
-            if (lane + 64 * s < K) {
-                grad[s] = nu / a[s] + Md * (dgs - digamma_d(a[s])) + es[s];          // :103
-                hinv[s] = -1.0 / (Md * trigamma_d(a[s]) + nu / (a[s] * a[s]));       // :104
-                gh += grad[s] * hinv[s]; hs += hinv[s]; gn2 += grad[s] * grad[s];
-            } else { grad[s] = 0.0; hinv[s] = 0.0; }
-        }
-        gh = wave_sum_d(gh); hs = wave_sum_d(hs); gn2 = wave_sum_d(gn2);
-        const double c = gh / (1.0 / (Md * trigamma_d(asum)) + hs);                  // :105
-#pragma unroll
-        for (int s = 0; s < NSLOT; ++s) pp[s] = (grad[s] - c) * hinv[s];
-        for (int guard = 0; guard < 1200; ++guard) {                                 // :107-109
-            double mn = INFINITY;
-#pragma unroll
-            for (int s = 0; s < NSLOT; ++s) if (lane + 64 * s < K) mn = fmin(mn, a[s] - rho * pp[s]);
-            mn = wave_min_d(mn);
-            if (mn < 0.0) rho *= 0.5; else break;
-        }
-#pragma unroll
-        for (int s = 0; s < NSLOT; ++s) {                                            // :110 @finite
-            if (lane + 64 * s < K) {
-                double na = fabs(a[s] - rho * pp[s]);
-                na = fmin(na, 1.7976931348623157e308);
-                a[s] = (a[s] > 0.0) ? na : ((a[s] < 0.0) ? -na : 0.0);
-            }
-        }
-        if ((rho * sqrt(gn2) < ntol) && (nu / (double)K < ntol)) break;              // :112
-        nu *= 0.5;                                                                   // :115
-    }
-#pragma unroll
-    for (int s = 0; s < NSLOT; ++s) {
-        int i = lane + 64 * s;
-        if (i < K) {
-            double v = a[s] + TMVB_EPS_D;                                            // :117
-            alpha_d[i] = v;
-            alpha_f[i] = (float)v;
-        }
-    }
-    if (lane == 0 && iters_out) *iters_out = it;
-}
-
 // ------------------------------------------------------------------------------ ELBO
 // update_elbo!  src/LDA.jl:83-93 per document (terms :50-80 without the corpus-level constant of
 // Elogptheta, added by lda_elbo_final_kernel).  One wave per document, lane = topic.
@@ -713,39 +646,6 @@ __global__ __launch_bounds__(64) void lda_elbo_reg_kernel(int K, const int32_t* 
     double tot = wave_sum_d(acc);
     if (K > 1 && !TMVB_ELBO_SKIP_TAIL) tot += -lgamma(g0) + (g0 - (double)K) * digamma_d(g0);
     if (lane == 0) doc_val[d] = tot;
-}
-
-// elbo = sum_d doc_val[d] + M * (lgamma(sum alpha) - sum lgamma(alpha))   (src/LDA.jl:51, finite())
-__global__ __launch_bounds__(1024) void lda_elbo_final_kernel(const double* __restrict__ doc_val, int64_t M, int K,
-                                                              const double* __restrict__ alpha_d, double* __restrict__ out,
-                                                              const double* __restrict__ pw_partial, int pw_blocks, double pw_share)
-{
-    __shared__ double red[1024];
-    double s8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};      // 8 independent chains: the loads overlap (fixed order)
-    for (int64_t d0 = threadIdx.x; d0 < M; d0 += 8 * 1024) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { const int64_t d = d0 + (int64_t)u * 1024; if (d < M) s8[u] += doc_val[d]; }
-    }
-    double pwl = 0.0;                                             // E_q[log p(w)] partials of update_beta!, if in use
-    if (pw_partial) for (int b = threadIdx.x; b < pw_blocks; b += 1024) pwl += pw_share * pw_partial[b];
-    red[threadIdx.x] = (((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]))) + pwl;
-    __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-        __syncthreads();
-    }
-    // lgamma(alpha_i) in parallel (K <= 1024 = blockDim), summed in index order by thread 0
-    __shared__ double lga[1024];
-    if ((int)threadIdx.x < K) lga[threadIdx.x] = lgamma(alpha_d[threadIdx.x]);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double asum = 0.0, lg = 0.0;
-        for (int i = 0; i < K; ++i) { asum += alpha_d[i]; lg += lga[i]; }
-        double a = lgamma(asum);
-        a = fmin(fmax(a, -1.7976931348623157e308), 1.7976931348623157e308);
-        lg = fmin(fmax(lg, -1.7976931348623157e308), 1.7976931348623157e308);
-        out[0] = red[0] + (double)M * (a - lg);
-    }
 }
 
 #define TMVB_REG_ANY_TILES 99   // bucket of register-tile documents with mixed tile counts (lda_estep_reg_any_kernel)
