@@ -33,7 +33,7 @@ class Hyper(C.Structure):
 
 
 def build(force: bool = False) -> str:
-    srcs = [os.path.join(_HERE, f) for f in ("oracle_special.c", "oracle_lda.c", "oracle_ctm.c", "oracle_ctpf.c", "oracle_flda.c", "tmvb_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("oracle_special.c", "oracle_lda.c", "oracle_ctm.c", "oracle_ctpf.c", "oracle_flda.c", "oracle_fctm.c", "tmvb_oracle.h")]
     if not force and os.path.exists(_LIB_PATH):
         try:
             if all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in srcs):
@@ -58,6 +58,7 @@ def lib():
         _lib.orc_ctpf_update_elbo.restype = c_dbl
         _lib.orc_flda_update_elbo.restype = c_dbl
         _lib.orc_flda_update_eta.restype = c_dbl
+        _lib.orc_fctm_update_elbo.restype = c_dbl
     return _lib
 
 
@@ -345,6 +346,72 @@ class CTM:
                                    c_dbl(vtol), C.c_int(ce), _pd(traj))
         self.elbo = elbo.value
         return traj[:done]
+
+
+# ------------------------------------------------------------------------------------- fCTM
+class fCTM(CTM):
+    """State + operators of src/fCTM.jl (filtered CTM), backed by the C oracle.  tau / tau_old: flat [nnz], CSR order."""
+
+    def __init__(self, corp: CSR, K: int, beta0, kappa0):
+        super().__init__(corp, K, beta0)
+        self.eta = 0.5                                                    # :37
+        self.kappa = np.ascontiguousarray(kappa0, dtype=np.float64).copy()
+        self.kappa_old = self.kappa.copy()
+        self.kappa_temp = np.zeros(self.V)
+        nnz = len(corp.terms)
+        self.tau = np.full(nnz, self.eta)
+        self.tau_old = self.tau.copy()
+
+    def estep(self, niter=1000, ntol=None, viter=10, vtol=None, d0=0, d1=None):
+        ntol = 1.0 / self.K ** 2 if ntol is None else ntol
+        vtol = 1.0 / self.K ** 2 if vtol is None else vtol
+        d1 = self.M if d1 is None else d1
+        sw = np.zeros(max(d1 - d0, 1), dtype=np.int32)
+        nst = c_i64(0)
+        rc = lib().orc_fctm_estep(*self._corp_args(), c_i64(d0), c_i64(d1), c_dbl(self.eta), _pd(self.kappa), _pd(self.mu),
+                                  _pd(self.invsigma), _pd(self.beta), _pd(self.beta_temp), _pd(self.kappa_temp), _pd(self.lam),
+                                  _pd(self.lam_old), _pd(self.vsq), _pd(self.logzeta), _pd(self.tau), _pd(self.tau_old),
+                                  C.c_int(niter), c_dbl(ntol), C.c_int(viter), c_dbl(vtol), _pi32(sw), C.byref(nst))
+        assert rc == 0
+        self.newton_steps = nst.value
+        return sw[: d1 - d0]
+
+    def update_kappa(self):
+        lib().orc_flda_update_kappa(c_i64(self.V), _pd(self.kappa), _pd(self.kappa_old), _pd(self.kappa_temp))
+
+    def mstep(self):
+        """update_beta!, update_kappa!, update_sigma!, update_mu! (src/fCTM.jl:249-252; update_eta! is commented out, :253)"""
+        self.update_beta(); self.update_kappa(); self.update_sigma_mu()
+
+    def update_elbo(self, d0=0, d1=None, store=True):
+        d1 = self.M if d1 is None else d1
+        e = lib().orc_fctm_update_elbo(*self._corp_args(), c_i64(d0), c_i64(d1), c_dbl(self.eta), _pd(self.kappa), _pd(self.mu),
+                                       _pd(self.invsigma), _pd(self.beta), _pd(self.beta_old), _pd(self.lam), _pd(self.lam_old),
+                                       _pd(self.vsq), _pd(self.logzeta), _pd(self.tau), _pd(self.tau_old))
+        if store:
+            self.elbo = e
+        return e
+
+    def train(self, iter=150, tol=1.0, niter=1000, ntol=None, viter=10, vtol=None, checkelbo=1):
+        """train!  src/fCTM.jl:226-262 incl. check_elbo! (signed stop rule)."""
+        ce = 0 if checkelbo in (None, float("inf")) else int(checkelbo)
+        if len(self.corp.terms) == 0:
+            iter = 0
+        if ce and ce <= iter:
+            self.update_elbo()
+        traj = []
+        for k in range(1, iter + 1):
+            self.estep(niter, ntol, viter, vtol)
+            self.mstep()
+            if ce and k % ce == 0:
+                old = self.elbo
+                new = self.update_elbo()
+                traj.append(new)
+                if new - old < tol:
+                    break
+            else:
+                traj.append(float("nan"))
+        return np.array(traj)
 
 
 # ------------------------------------------------------------------------------------ CTPF

@@ -19,7 +19,7 @@
 static const double EPS = ORC_EPSILON;
 
 /* In-place lower Cholesky of column-major n x n A (uses lower triangle). Returns 0 if SPD. */
-static int chol_lower(double* A, int64_t n)
+int orc_chol_lower(double* A, int64_t n)
 {
     for (int64_t j = 0; j < n; ++j) {
         double d = A[j * n + j];
@@ -37,7 +37,7 @@ static int chol_lower(double* A, int64_t n)
 }
 
 /* Solve L L^T x = b in place (b -> x). L lower, column-major. */
-static void chol_solve(const double* L, int64_t n, double* b)
+void orc_chol_solve(const double* L, int64_t n, double* b)
 {
     for (int64_t i = 0; i < n; ++i) {
         double s = b[i];
@@ -52,7 +52,7 @@ static void chol_solve(const double* L, int64_t n, double* b)
 }
 
 /* Gaussian elimination with partial pivoting fallback (A overwritten). */
-static int lu_solve(double* A, int64_t n, double* b)
+int orc_lu_solve(double* A, int64_t n, double* b)
 {
     for (int64_t c = 0; c < n; ++c) {
         int64_t piv = c;
@@ -172,8 +172,8 @@ static int ctm_doc(int64_t K, int64_t Nd, const int32_t* terms, const int32_t* c
             for (int64_t i = 0; i < K; ++i) w->H[i * K + i] += Cd * w->ex[i];
             memcpy(w->rhs, w->g, sizeof(double) * (size_t)K);
             memcpy(w->H2, w->H, sizeof(double) * (size_t)(K * K));
-            if (chol_lower(w->H2, K) == 0) chol_solve(w->H2, K, w->rhs);
-            else { memcpy(w->rhs, w->g, sizeof(double) * (size_t)K); lu_solve(w->H, K, w->rhs); }
+            if (orc_chol_lower(w->H2, K) == 0) orc_chol_solve(w->H2, K, w->rhs);
+            else { memcpy(w->rhs, w->g, sizeof(double) * (size_t)K); orc_lu_solve(w->H, K, w->rhs); }
             for (int64_t i = 0; i < K; ++i) lam[i] += w->rhs[i];                            /* :136 */
             if (sqrt(gn2) < ntol) break;                                                    /* :138 */
         }
@@ -291,11 +291,11 @@ int orc_ctm_update_sigma_mu(int64_t M, int64_t K, const double* lambda, const do
     double* L = (double*)malloc(sizeof(double) * (size_t)(K * K));
     double* col = (double*)malloc(sizeof(double) * (size_t)K);
     memcpy(L, sigma, sizeof(double) * (size_t)(K * K));
-    int bad = chol_lower(L, K);
+    int bad = orc_chol_lower(L, K);
     if (!bad) {
         for (int64_t j = 0; j < K; ++j) {
             for (int64_t i = 0; i < K; ++i) col[i] = (i == j) ? 1.0 : 0.0;
-            chol_solve(L, K, col);
+            orc_chol_solve(L, K, col);
             for (int64_t i = 0; i < K; ++i) invsigma[j * K + i] = col[i];
         }
         /* symmetrise (inv(::Symmetric) returns Symmetric) */
@@ -330,7 +330,7 @@ double orc_ctm_update_elbo(int64_t M, int64_t V, int64_t K,
     double* df = (double*)malloc(sizeof(double) * (size_t)K);
     memcpy(L, invsigma, sizeof(double) * (size_t)(K * K));
     double logdet = NAN;
-    if (chol_lower(L, K) == 0) {
+    if (orc_chol_lower(L, K) == 0) {
         logdet = 0.0;
         for (int64_t i = 0; i < K; ++i) logdet += 2.0 * log(L[i * K + i]);
     }

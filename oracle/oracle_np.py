@@ -400,6 +400,105 @@ class CTM:
         return traj
 
 
+class fCTM(CTM):
+    """src/fCTM.jl:6-64: filtered CTM.  beta0 and kappa0 must be supplied (Julia RNG in the reference, :40-43)."""
+
+    def __init__(self, docs, V, K, beta0, kappa0):
+        super().__init__(docs, V, K, beta0)
+        self.eta = 0.5                                                  # :37
+        self.kappa = np.array(kappa0, dtype=np.float64).copy()
+        self.kappa_old = self.kappa.copy()
+        self.kappa_temp = np.zeros(V)
+        self.tau = [np.full(len(t), self.eta) for t, _ in self.docs]    # :57
+        self.tau_old = [x.copy() for x in self.tau]
+        self.sweeps = []
+
+    def update_phi(self, d):          # :216-219
+        terms, _ = self.docs[d]
+        self.phi = additive_logistic_cols(self.tau[d][None, :] * np.log(self.beta[:, terms] + EPSILON) + self.lam[d][:, None])
+
+    def update_tau(self, d):          # :208-213
+        self.tau_old[d] = self.tau[d]
+        terms, _ = self.docs[d]
+        with np.errstate(divide="ignore", over="ignore"):
+            prod = np.prod(self.beta[:, terms] ** (-self.phi), axis=0) if len(terms) else np.zeros(0)
+        self.tau[d] = self.eta / (EPSILON + (self.eta + (1.0 - self.eta) * (self.kappa[terms] * prod)))
+
+    def update_beta_doc(self, d):     # :155-158
+        terms, counts = self.docs[d]
+        self.beta_temp[:, terms] = self.beta_temp[:, terms] + self.phi * (self.tau[d] * counts)[None, :]
+
+    def update_kappa_doc(self, d):    # :141-144
+        terms, counts = self.docs[d]
+        self.kappa_temp[terms] = self.kappa_temp[terms] + (1.0 - self.tau[d]) * counts
+
+    def update_kappa(self):           # :134-138
+        self.kappa_old = self.kappa
+        self.kappa = self.kappa_temp / self.kappa_temp.sum()
+        self.kappa_temp = np.zeros(self.V)
+
+    def update_elbo(self):            # :105-115, :68-102
+        elbo = 0.0
+        _, logdet = np.linalg.slogdet(self.invsigma)
+        K = self.K
+        for d in range(self.M):
+            terms, counts = self.docs[d]
+            phi = additive_logistic_cols(self.tau_old[d][None, :] * np.log(self.beta_old[:, terms] + EPSILON) + self.lam_old[d][:, None])
+            l, v, lz, C, tau = self.lam[d], self.vsq[d], self.logzeta[d], self.C[d], self.tau[d]
+            df = l - self.mu
+            e_peta = 0.5 * (logdet - K * math.log(2 * math.pi) - np.dot(np.diag(self.invsigma), v) - df @ self.invsigma @ df)
+            tc = float(np.dot(tau, counts))
+            e_pc = math.log(EPSILON + self.eta ** tc * (1.0 - self.eta) ** (C - tc))
+            e_pz = (np.dot(phi.T @ l, counts) if len(terms) else 0.0) - C * (np.exp(l + 0.5 * v - lz).sum() + lz - 1.0)
+            e_pw = (float(np.sum((phi * np.log(self.beta[:, terms] + EPSILON)) @ (counts * tau))) if len(terms) else 0.0) \
+                + float(np.dot(counts * (1.0 - tau), np.log(self.kappa[terms] + EPSILON)))
+            e_qeta = -0.5 * (K * (1 + math.log(2 * math.pi)) + np.log(v).sum())
+            e_qc = -sum(c * _xlogx_entropy(np.array([t, 1.0 - t])) for t, c in zip(tau, counts))
+            e_qz = -sum(c * _xlogx_entropy(phi[:, n]) for n, c in enumerate(counts))
+            elbo += e_peta + e_pc + e_pz + e_pw - e_qeta - e_qc - e_qz
+        self.elbo = float(elbo)
+        return self.elbo
+
+    def train(self, iter=150, tol=1.0, niter=1000, ntol=None, viter=10, vtol=None, checkelbo=1):   # :226-262
+        ntol = 1.0 / self.K ** 2 if ntol is None else ntol
+        vtol = 1.0 / self.K ** 2 if vtol is None else vtol
+        traj = []
+        if all(len(t) == 0 for t, _ in self.docs):
+            iter = 0
+        if checkelbo <= iter:
+            self.update_elbo()
+        for k in range(1, iter + 1):
+            sw = []
+            for d in range(self.M):
+                s = 0
+                for _ in range(viter):
+                    s += 1
+                    self.update_phi(d)
+                    self.update_tau(d)
+                    self.update_logzeta(d)
+                    self.update_lambda(d, niter, ntol)
+                    self.update_vsq(d, niter, ntol)
+                    if np.linalg.norm(self.lam[d] - self.lam_old[d]) < vtol:
+                        break
+                sw.append(s)
+                self.update_beta_doc(d)
+                self.update_kappa_doc(d)
+            self.sweeps.append(sw)
+            self.update_beta()
+            self.update_kappa()
+            self.update_sigma()
+            self.update_mu()                    # update_eta! is commented out in the reference (:253)
+            if checkelbo != math.inf and k % checkelbo == 0:
+                old = self.elbo
+                new = self.update_elbo()
+                traj.append(new)
+                if (new - old) < tol:
+                    break
+            else:
+                traj.append(float("nan"))
+        return traj
+
+
 def _binom_lgamma_sum(n, p):
     """sum_{y=0}^{n} pdf(Binomial(n,p), y) * lgamma(y+1)   (src/CTPF.jl:116)"""
     n = int(n)

@@ -211,6 +211,20 @@ double orc_flda_update_elbo(int64_t M, int64_t V, int64_t K,
                             const double* beta, const double* beta_old, const double* gamma, const double* Elogtheta,
                             const double* Elogtheta_old, const double* tau, const double* tau_old);   /* :108-118 */
 
+
+/* ---- filtered CTM (src/fCTM.jl) ---- */
+int orc_fctm_estep(int64_t M, int64_t V, int64_t K,
+                   const int64_t* doc_ptr, const int32_t* terms, const int32_t* counts,
+                   int64_t d0, int64_t d1, double eta, const double* kappa, const double* mu, const double* invsigma,
+                   const double* beta, double* beta_temp, double* kappa_temp, double* lambda, double* lambda_old,
+                   double* vsq, double* logzeta, double* tau, double* tau_old,
+                   int niter, double ntol, int viter, double vtol, int32_t* sweeps_out, int64_t* newton_out);
+double orc_fctm_update_elbo(int64_t M, int64_t V, int64_t K,
+                            const int64_t* doc_ptr, const int32_t* terms, const int32_t* counts,
+                            int64_t d0, int64_t d1, double eta, const double* kappa, const double* mu, const double* invsigma,
+                            const double* beta, const double* beta_old, const double* lambda, const double* lambda_old,
+                            const double* vsq, const double* logzeta, const double* tau, const double* tau_old);
+
 #ifdef __cplusplus
 }
 #endif

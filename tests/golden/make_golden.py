@@ -100,11 +100,25 @@ def flda_case(name, seed, M, V, K, iters, empty_every=0):
                         elbo_traj=np.array(traj), sweeps=np.array(m.sweeps, np.int32))
 
 
+def fctm_case(name, seed, M, V, K, iters):
+    rng = np.random.default_rng(seed)
+    docs = mkcorp(rng, M, V)
+    beta0 = beta_init(rng, K, V)
+    kappa0 = beta_init(rng, 1, V)[0]
+    m = onp.fCTM(docs, V, K, beta0, kappa0)
+    traj = m.train(iter=iters, tol=-1e300)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), M=M, V=V, K=K, iters=iters, beta0=beta0, kappa0=kappa0, **pack(docs),
+                        eta=m.eta, kappa=m.kappa, mu=m.mu, sigma=m.sigma, invsigma=m.invsigma, beta=m.beta, lam=np.stack(m.lam, 1),
+                        vsq=np.stack(m.vsq, 1), logzeta=m.logzeta, tau=np.concatenate(m.tau), tau_old=np.concatenate(m.tau_old),
+                        elbo_traj=np.array(traj), sweeps=np.array(m.sweeps, np.int32))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "flda":          # only the filtered-model fixtures (added in round 2)
+    if len(sys.argv) > 1 and sys.argv[1] == "filtered":      # only the filtered-model fixtures (added in round 2)
         flda_case("flda_m40_v60_k5", 41, 40, 60, 5, 4)
         flda_case("flda_m30_v50_k9_empty", 42, 30, 50, 9, 3, empty_every=7)
-        print("fLDA golden fixtures written to", HERE)
+        fctm_case("fctm_m30_v50_k4", 51, 30, 50, 4, 3)
+        print("filtered-model golden fixtures written to", HERE)
         sys.exit(0)
     lda_case("lda_m40_v60_k3", 11, 40, 60, 3, 5)
     lda_case("lda_m40_v60_k7", 12, 40, 60, 7, 5)
@@ -114,4 +128,5 @@ if __name__ == "__main__":
     ctpf_case("ctpf_m30_v40_u12_k6_r1", 32, 30, 40, 12, 6, 3, maxRat=1)
     flda_case("flda_m40_v60_k5", 41, 40, 60, 5, 4)
     flda_case("flda_m30_v50_k9_empty", 42, 30, 50, 9, 3, empty_every=7)
+    fctm_case("fctm_m30_v50_k4", 51, 30, 50, 4, 3)
     print("golden fixtures written to", HERE)

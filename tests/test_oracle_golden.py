@@ -48,6 +48,22 @@ def test_flda_golden(oracle, name):
     assert np.array_equal(np.bincount(g["sweeps"][-1].ravel(), minlength=11), m.sweep_hist)
 
 
+def test_fctm_golden(oracle):
+    """filtered CTM (src/fCTM.jl): the C oracle against the fixture of the independent NumPy restatement"""
+    g = load("fctm_m30_v50_k4")
+    m = oracle.fCTM(oracle.CSR(g["doc_ptr"], g["terms"], g["counts"], int(g["V"])), int(g["K"]), g["beta0"], g["kappa0"])
+    traj = m.train(iter=int(g["iters"]), tol=-1e300)
+    np.testing.assert_allclose(traj, g["elbo_traj"], rtol=1e-10)
+    np.testing.assert_allclose(m.lam, g["lam"], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(m.vsq, g["vsq"], rtol=1e-9)
+    np.testing.assert_allclose(m.tau, g["tau"], rtol=1e-9)
+    np.testing.assert_allclose(m.kappa, g["kappa"], rtol=1e-9, atol=1e-300)
+    np.testing.assert_allclose(m.beta, g["beta"], rtol=1e-9, atol=1e-300)
+    np.testing.assert_allclose(m.mu, g["mu"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(m.sigma, g["sigma"], rtol=1e-9, atol=1e-12)
+    assert m.eta == 0.5                                   # update_eta! is commented out in the reference's train!
+
+
 def test_ctm_golden(oracle):
     g = load("ctm_m40_v60_k5")
     m = oracle.CTM(csr(oracle, g), int(g["K"]), g["beta0"])
