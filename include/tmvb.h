@@ -54,6 +54,7 @@ typedef struct tmvb_ctm    tmvb_ctm;
 typedef struct tmvb_ctpf   tmvb_ctpf;
 typedef struct tmvb_comm   tmvb_comm;
 typedef struct tmvb_flda   tmvb_flda;
+typedef struct tmvb_fctm   tmvb_fctm;
 
 int         tmvb_abi_version(void);
 const char* tmvb_last_error(void);
@@ -307,6 +308,39 @@ int tmvb_ctm_train_group(tmvb_ctm* const* hs, int32_t n, int32_t iter, double to
 int tmvb_ctm_sweep_hist(tmvb_ctm* h, int64_t* hist, int32_t nbins, int64_t* newton_steps);
 int tmvb_ctm_doc_sweeps(tmvb_ctm* h, uint8_t* out);
 int tmvb_ctm_last_estep_ms(tmvb_ctm* h, float* ms);
+
+/* ============================== fCTM (new device path; oracle src/fCTM.jl) ==============================
+ * Filtered CTM: CTM plus the per-token switch tau_n (prior eta) and the background distribution kappa of fLDA.  No accelerator
+ * path in the reference (src/macros.jl:274-278).  Same Newton machinery and K limits as CTM; the per-document chain is
+ * update_phi! / update_tau! / update_logzeta! / update_lambda! / update_vsq! (src/fCTM.jl:236-241 -- lambda BEFORE vsq, unlike CTM).
+ * eta is a fixed parameter (update_eta! is commented out of train!, src/fCTM.jl:253). */
+int tmvb_fctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb_fctm** out);           /* fCTM(corp, K), src/fCTM.jl:32-65 */
+int tmvb_fctm_destroy(tmvb_fctm* h);
+/* eta[1], mu[K], sigma/invsigma[K*K], kappa[V], beta[K*V], lambda/vsq[K*M], logzeta[M], tau[nnz] (CSR token order); NULL = unchanged;
+ * the *_old arguments default to the current values. */
+int tmvb_fctm_set_state(tmvb_fctm* h, const double* eta, const double* mu, const double* sigma, const double* invsigma,
+                        const double* kappa, const double* kappa_old, const double* beta, const double* beta_old,
+                        const double* lambda, const double* lambda_old, const double* vsq, const double* logzeta,
+                        const double* tau, const double* tau_old, const double* elbo);
+int tmvb_fctm_get_state(tmvb_fctm* h, double* eta, double* mu, double* sigma, double* invsigma, double* kappa, double* kappa_old,
+                        double* beta, double* beta_old, double* lambda, double* lambda_old, double* vsq, double* logzeta,
+                        double* tau, double* tau_old, double* elbo);
+/* sweeps of src/fCTM.jl:233-248 + update_beta!(model, d) (:155) + update_kappa!(model, d) (:141) for every document.
+ * Packed statistics: float32 [ S (K*V) | sum_lambda (K) | sum_vsq (K) | scatter (K*K) | kappa_stats (V) ]. */
+int tmvb_fctm_estep(tmvb_fctm* h, int32_t niter, double ntol, int32_t viter, double vtol);
+int tmvb_fctm_reduce_docs(tmvb_fctm* h);
+int tmvb_fctm_update_beta(tmvb_fctm* h);                                /* update_beta! (:148) and update_kappa! (:134) */
+int tmvb_fctm_update_sigma(tmvb_fctm* h);                               /* update_sigma! (:128-131), previous mu */
+int tmvb_fctm_update_mu(tmvb_fctm* h);                                  /* update_mu! (:122-124) */
+int tmvb_fctm_update_elbo(tmvb_fctm* h, double* elbo);                  /* update_elbo! (:105-115) */
+/* train! (src/fCTM.jl:226-262); arguments as tmvb_ctm_train. */
+int tmvb_fctm_train(tmvb_fctm* h, int32_t iter, double tol, int32_t niter, double ntol, int32_t viter, double vtol,
+                    int32_t checkelbo, double* elbo_traj, int32_t* iters_done, double* elbo_baseline);
+int tmvb_fctm_set_comm(tmvb_fctm* h, tmvb_comm* comm, int64_t M_total);
+int tmvb_fctm_train_group(tmvb_fctm* const* hs, int32_t n, int32_t iter, double tol, int32_t niter, double ntol, int32_t viter,
+                          double vtol, int32_t checkelbo, double* elbo_traj, int32_t* iters_done, double* elbo_baseline);
+int tmvb_fctm_sweep_hist(tmvb_fctm* h, int64_t* hist, int32_t nbins, int64_t* newton_steps);
+int tmvb_fctm_doc_sweeps(tmvb_fctm* h, uint8_t* out);
 
 /* ============================== CTPF (src/gpuCTPF.jl, oracle src/CTPF.jl) ============================== */
 

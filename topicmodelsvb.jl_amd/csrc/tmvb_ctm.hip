@@ -26,6 +26,7 @@
 // workgroup.
 #include "tmvb_common_kernels.h"
 #include "tmvb_train.h"
+#include "tmvb_filtered.h"
 
 #include <utility>
 
@@ -56,6 +57,11 @@ struct CtmParams {
     double vtol;
     int debug;                // TMVB_DEBUG_FLAGS (profiling experiments only): 1 = skip vsq Newton, 2 = diagonal solve instead of GJ
     int store_w;              // KP > 128: the statistics pass reads stored per-token weights instead of recomputing them
+    // filtered CTM only (src/fCTM.jl)
+    const float* L = nullptr;         // [V][KP] log(beta + eps), pads 0
+    const float* kappa = nullptr;     // [V]
+    float eta = 0.5f;
+    float* tau = nullptr; float* tau_old = nullptr; float* lse = nullptr;     // [nnz], CSR order
 };
 
 __device__ __forceinline__ float readlane_f(float v, int l)
@@ -158,7 +164,14 @@ __device__ __forceinline__ float gj_solve_rows(float (&H)[R], float diag, float 
 }
 
 // ------------------------------------------------------------------------------ E-step kernel
-template <int R>
+// FILT = true is the filtered CTM (src/fCTM.jl, new device path -- the reference has none): phi carries the per-token
+// switch as an exponent, phi[i,n] = softmax_i(tau_n log(beta[i,t_n] + eps) + lambda_i) (:216-219), so the tile holds rows
+// of L = log(beta + eps) and the token phase is the two-pass column softmax of tmvb_flda.hip with update_tau! (:208-213)
+// fused in; the sweep order is phi, tau, logzeta, LAMBDA, VSQ (:236-241) instead of CTM's phi, logzeta, vsq, lambda.
+// The Newton machinery is shared.
+static size_t ctm_tile_bytes(int rows, int KP, bool filt) { return tmvb_tile_bytes(rows, KP) + (filt ? 3 * (size_t)rows * sizeof(float) : 0); }
+
+template <int R, bool FILT>
 __global__ __launch_bounds__(64) void ctm_estep_kernel(CtmParams p, int64_t first, int tile_rows)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -166,10 +179,13 @@ __global__ __launch_bounds__(64) void ctm_estep_kernel(CtmParams p, int64_t firs
     const int lane = threadIdx.x;
     const int K = p.K;
     float* Bt = lds;
-    float* e_l = Bt + (size_t)tile_rows * KP;
+    float* e_l = Bt + (size_t)tile_rows * KP;     // CTM: exp(lambda - max); fCTM: lambda itself (pads -inf)
     float* w_l = e_l + KP;
     float* c_l = w_l + tile_rows;
     int* t_l = (int*)(c_l + tile_rows);
+    float* tp_l = (float*)(t_l + tile_rows);      // FILT only: tau entering the sweep, tau after update_tau!, column maximum
+    float* tn_l = tp_l + tile_rows;
+    float* m_l = tn_l + tile_rows;
 
     const int d = p.doc_order[first + blockIdx.x];
     const int64_t off = p.doc_ptr[d];
@@ -197,8 +213,10 @@ __global__ __launch_bounds__(64) void ctm_estep_kernel(CtmParams p, int64_t firs
         for (int n = lane; n < rows; n += 64) {
             t_l[n] = p.terms[off + c0 + n];
             c_l[n] = (float)p.counts[off + c0 + n];
+            if constexpr (FILT) tn_l[n] = p.tau[off + c0 + n];
         }
         WAVE_LDS_FENCE();
+        const float* table = FILT ? p.L : p.beta;
         const int nch = rows * LPR;
 #pragma unroll 4
         for (int f0 = 0; f0 < nch; f0 += 64) {
@@ -206,7 +224,7 @@ __global__ __launch_bounds__(64) void ctm_estep_kernel(CtmParams p, int64_t firs
             if (f < nch) {
                 const int n = (LPR == 1) ? f : (int)__umulhi((unsigned)f, p.lpr_magic);
                 const int c = f - n * LPR;
-                const float* src = p.beta + ((int64_t)t_l[n] * KP + 4 * c);
+                const float* src = table + ((int64_t)t_l[n] * KP + 4 * c);
                 __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(Bt + (size_t)f0 * 4), 16, 0, 0);
             }
         }
@@ -227,9 +245,6 @@ __global__ __launch_bounds__(64) void ctm_estep_kernel(CtmParams p, int64_t firs
             w_l[n] = c_l[n] / ((s0 + s1) + (s2 + s3));
         }
         WAVE_LDS_FENCE();
-    };
-    auto store_w = [&](int c0, int rows) {
-        (void)c0; (void)rows;     // K <= 64: the statistics pass recomputes w_n = c_n / s_n from (beta row, E row, count)
     };
     const int r4 = lane & 3, ql = lane >> 2;
     auto phase2 = [&](int rows, float4& acc) {
@@ -252,36 +267,51 @@ __global__ __launch_bounds__(64) void ctm_estep_kernel(CtmParams p, int64_t firs
             }
         }
     };
-
-    int sweeps = 0;
-    unsigned nsteps = 0;
-    for (int v = 0; v < p.viter; ++v) {
-        ++sweeps;
-        // update_phi!  src/CTM.jl:175-178 (additive_logistic, src/utils.jl:114-122), linear space
-        const float lmax = wave_max(on ? (float)lam : -INFINITY);
-        e = on ? expf((float)lam - lmax) : 0.0f;
-        if (lane < KP) e_l[lane] = e;
+    // fCTM: column softmax normalisers (update_phi!, src/fCTM.jl:216-219) and update_tau! (:208-213), lane = token
+    auto filt_a = [&](int c0, int rows, bool store) {
+        const float4* er = (const float4*)e_l;
+        for (int n = lane; n < rows; n += 64) {
+            const float4* br = (const float4*)(Bt + (size_t)n * KP);
+            const float tp = tn_l[n];
+            float m = -INFINITY;
+#pragma unroll
+            for (int q = 0; q < LPR; ++q) {
+                const float4 b = br[q], ev = er[q];
+                m = fmaxf(m, fmaxf(fmaxf(fmaf(tp, b.x, ev.x), fmaf(tp, b.y, ev.y)), fmaxf(fmaf(tp, b.z, ev.z), fmaf(tp, b.w, ev.w))));
+            }
+            float s = 0.0f, a = 0.0f;
+#pragma unroll
+            for (int q = 0; q < LPR; ++q) {
+                const float4 b = br[q], ev = er[q];
+                const float p0 = __expf(fmaf(tp, b.x, ev.x) - m), p1 = __expf(fmaf(tp, b.y, ev.y) - m);
+                const float p2 = __expf(fmaf(tp, b.z, ev.z) - m), p3 = __expf(fmaf(tp, b.w, ev.w) - m);
+                s += (p0 + p1) + (p2 + p3);
+                a = fmaf(p0, b.x, a); a = fmaf(p1, b.y, a); a = fmaf(p2, b.z, a); a = fmaf(p3, b.w, a);
+            }
+            const float prod = __expf(fminf(-(a / s), 87.0f));           // prod_i beta^-phi  (:212)
+            const float tnew = p.eta / (TMVB_EPS_F + (p.eta + (1.0f - p.eta) * (p.kappa[t_l[n]] * prod)));
+            tp_l[n] = tp; tn_l[n] = tnew; m_l[n] = m; w_l[n] = c_l[n] / s;
+            if (store) { p.tau_old[off + c0 + n] = tp; p.tau[off + c0 + n] = tnew; p.lse[off + c0 + n] = m + __logf(s); }
+        }
         WAVE_LDS_FENCE();
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int c0 = 0; c0 < N; c0 += tile_rows) {
-            const int rows = min(tile_rows, N - c0);
-            if (!(single && v > 0)) load_chunk(c0, rows);
-            phase1(rows);
-            if (!single) store_w(c0, rows);
-            phase2(rows, acc);
-            if (!single) WAVE_LDS_FENCE();
+    };
+    // fCTM: (phi * counts)_i, lane = (topic quad, token residue), one v_exp_f32 per (token, topic)
+    auto filt_b = [&](int rows, float4& acc) {
+        if (ql >= LPR) return;
+        const float4 ev = *(const float4*)(e_l + 4 * ql);
+        for (int n = r4; n < rows; n += 4) {
+            const float tp = tp_l[n], m = m_l[n], w = w_l[n];
+            const float4 b = *(const float4*)(Bt + (size_t)n * KP + 4 * ql);
+            acc.x = fmaf(w, __expf(fmaf(tp, b.x, ev.x) - m), acc.x);
+            acc.y = fmaf(w, __expf(fmaf(tp, b.y, ev.y) - m), acc.y);
+            acc.z = fmaf(w, __expf(fmaf(tp, b.z, ev.z) - m), acc.z);
+            acc.w = fmaf(w, __expf(fmaf(tp, b.w, ev.w) - m), acc.w);
         }
-        acc = dpp_add4<0xB1>(acc);
-        acc = dpp_add4<0x4E>(acc);
-        const float gsel = (r4 == 0) ? acc.x : (r4 == 1) ? acc.y : (r4 == 2) ? acc.z : acc.w;
-        const double phic = on ? (double)(e * gsel) : 0.0;                  // (phi * counts)_i
-        // update_logzeta!  :169-171
-        {
-            const double x = on ? lam + 0.5 * vs : -INFINITY;
-            const double m = wave_max_d(x);
-            lz = m + log(wave_sum_d(on ? exp(x - m) : 0.0));
-        }
-        // update_vsq!  :146-165  (one scalar Newton iteration per topic = per lane)
+    };
+
+    unsigned nsteps = 0;
+    // update_vsq!  src/CTM.jl:146-165 = src/fCTM.jl:180-198  (one scalar Newton iteration per topic = per lane)
+    auto run_vsq = [&]() {
         if (on && !(p.debug & 1)) {
             for (int t = 0; t < p.niter; ++t) {
                 double rho = 1.0;
@@ -295,7 +325,9 @@ __global__ __launch_bounds__(64) void ctm_estep_kernel(CtmParams p, int64_t firs
             }
             vs += TMVB_EPS_D;                                                              // :164
         }
-        // update_lambda!  :129-142
+    };
+    // update_lambda!  src/CTM.jl:129-142 = src/fCTM.jl:162-176
+    auto run_lambda = [&](const double phic) {
         lam_old = lam;
         for (int t = 0; t < p.niter; ++t) {
             ++nsteps;
@@ -326,9 +358,56 @@ __global__ __launch_bounds__(64) void ctm_estep_kernel(CtmParams p, int64_t firs
             if (on) lam += (double)delta;                                                  // :136
             if (sqrt(gn2) < p.ntol) break;                                                 // :138
         }
+    };
+
+    int sweeps = 0;
+    for (int v = 0; v < p.viter; ++v) {
+        ++sweeps;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        double phic;
+        if constexpr (FILT) {
+            if (lane < KP) e_l[lane] = on ? (float)lam : -INFINITY;
+            WAVE_LDS_FENCE();
+            for (int c0 = 0; c0 < N; c0 += tile_rows) {
+                const int rows = min(tile_rows, N - c0);
+                if (!(single && v > 0)) load_chunk(c0, rows);
+                filt_a(c0, rows, !single);
+                filt_b(rows, acc);
+                if (!single) WAVE_LDS_FENCE();
+            }
+            acc = dpp_add4<0xB1>(acc);
+            acc = dpp_add4<0x4E>(acc);
+            const float gsel = (r4 == 0) ? acc.x : (r4 == 1) ? acc.y : (r4 == 2) ? acc.z : acc.w;
+            phic = on ? (double)gsel : 0.0;                                     // (phi * counts)_i
+        } else {
+            // update_phi!  src/CTM.jl:175-178 (additive_logistic, src/utils.jl:114-122), linear space
+            const float lmax = wave_max(on ? (float)lam : -INFINITY);
+            e = on ? expf((float)lam - lmax) : 0.0f;
+            if (lane < KP) e_l[lane] = e;
+            WAVE_LDS_FENCE();
+            for (int c0 = 0; c0 < N; c0 += tile_rows) {
+                const int rows = min(tile_rows, N - c0);
+                if (!(single && v > 0)) load_chunk(c0, rows);
+                phase1(rows);
+                phase2(rows, acc);
+                if (!single) WAVE_LDS_FENCE();
+            }
+            acc = dpp_add4<0xB1>(acc);
+            acc = dpp_add4<0x4E>(acc);
+            const float gsel = (r4 == 0) ? acc.x : (r4 == 1) ? acc.y : (r4 == 2) ? acc.z : acc.w;
+            phic = on ? (double)(e * gsel) : 0.0;                               // (phi * counts)_i
+        }
+        // update_logzeta!  src/CTM.jl:169-171 = src/fCTM.jl:202-204
+        {
+            const double x = on ? lam + 0.5 * vs : -INFINITY;
+            const double m = wave_max_d(x);
+            lz = m + log(wave_sum_d(on ? exp(x - m) : 0.0));
+        }
+        if constexpr (FILT) { run_lambda(phic); run_vsq(); }                    // src/fCTM.jl:239-240
+        else { run_vsq(); run_lambda(phic); }                                   // src/CTM.jl:198-199
         const double df = on ? lam - lam_old : 0.0;
         const double dist2 = wave_sum_d(df * df);
-        if (sqrt(dist2) < p.vtol) break;                                                   // :200
+        if (sqrt(dist2) < p.vtol) break;                                        // :200 / :242
     }
 
     if (sweeps > 0) {
@@ -338,10 +417,18 @@ __global__ __launch_bounds__(64) void ctm_estep_kernel(CtmParams p, int64_t firs
             p.vsq[(int64_t)d * K + lane] = (float)vs;
         }
         if (lane == 0) p.logzeta[d] = (float)lz;
-        if (lane < KP) p.E[(int64_t)d * KP + lane] = e;       // e = exp(lambda_old - max): last-sweep phi factor
-        if (single) store_w(0, N);
+        if constexpr (FILT) {
+            if (single)
+                for (int n = lane; n < N; n += 64) {
+                    p.tau_old[off + n] = tp_l[n]; p.tau[off + n] = tn_l[n];
+                    p.lse[off + n] = m_l[n] + __logf(c_l[n] / w_l[n]);          // m + log s
+                }
+        } else {
+            if (lane < KP) p.E[(int64_t)d * KP + lane] = e;   // e = exp(lambda_old - max): last-sweep phi factor
+        }
     } else {
-        if (lane < KP) p.E[(int64_t)d * KP + lane] = 0.0f;    // viter = 0: no responsibilities
+        if constexpr (FILT) { for (int n = lane; n < N; n += 64) p.lse[off + n] = INFINITY; }   // viter = 0: phi = 0 in the statistics
+        else if (lane < KP) p.E[(int64_t)d * KP + lane] = 0.0f;                                 // viter = 0: no responsibilities
     }
     if (lane == 0) {
         p.sweeps[d] = (uint8_t)min(sweeps, 255);
@@ -360,10 +447,10 @@ __global__ __launch_bounds__(64) void ctm_estep_kernel(CtmParams p, int64_t firs
 #define CTM_GENERIC_TILE_ROWS 32
 static size_t ctm_generic_lds_bytes(int KP)
 {
-    return ((size_t)KP * KP + (size_t)CTM_GENERIC_TILE_ROWS * KP + 2 * (size_t)KP + 3 * CTM_GENERIC_TILE_ROWS) * sizeof(float) + (size_t)KP * sizeof(double);
+    return ((size_t)KP * KP + (size_t)CTM_GENERIC_TILE_ROWS * KP + 2 * (size_t)KP + 6 * CTM_GENERIC_TILE_ROWS) * sizeof(float) + (size_t)KP * sizeof(double);
 }
 
-template <int NS>
+template <int NS, bool FILT>
 __global__ __launch_bounds__(64) void ctm_estep_generic_kernel(CtmParams p, int64_t first)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -377,7 +464,10 @@ __global__ __launch_bounds__(64) void ctm_estep_generic_kernel(CtmParams p, int6
     float* w_l = g_l + KP;                              // [tile_rows]
     float* c_l = w_l + tile_rows;
     int* t_l = (int*)(c_l + tile_rows);
-    double* dm_l = (double*)(t_l + tile_rows);          // [KP] mu - lambda (8-byte aligned: KP is a multiple of 4, so the float blocks above total a multiple of 8 floats)
+    float* tp_l = (float*)(t_l + tile_rows);            // FILT: tau entering the sweep / after update_tau! / column maximum
+    float* tn_l = tp_l + tile_rows;
+    float* m_l = tn_l + tile_rows;
+    double* dm_l = (double*)(m_l + tile_rows);          // [KP] mu - lambda (8-byte aligned: KP is a multiple of 4, so the float blocks above total a multiple of 8 floats)
 
     const int d = p.doc_order[first + blockIdx.x];
     const int64_t off = p.doc_ptr[d];
@@ -406,15 +496,17 @@ __global__ __launch_bounds__(64) void ctm_estep_generic_kernel(CtmParams p, int6
         for (int n = lane; n < rows; n += 64) {
             t_l[n] = p.terms[off + c0 + n];
             c_l[n] = (float)p.counts[off + c0 + n];
+            if constexpr (FILT) tn_l[n] = p.tau[off + c0 + n];
         }
         WAVE_LDS_FENCE();
+        const float* table = FILT ? p.L : p.beta;
         const int nch = rows * LPR;
         for (int f0 = 0; f0 < nch; f0 += 64) {
             const int f = f0 + lane;
             if (f < nch) {
                 const int n = (LPR == 1) ? f : (int)__umulhi((unsigned)f, p.lpr_magic);
                 const int c = f - n * LPR;
-                const float* src = p.beta + ((int64_t)t_l[n] * KP + 4 * c);
+                const float* src = table + ((int64_t)t_l[n] * KP + 4 * c);
                 __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(Bt + (size_t)f0 * 4), 16, 0, 0);
             }
         }
@@ -450,40 +542,97 @@ __global__ __launch_bounds__(64) void ctm_estep_generic_kernel(CtmParams p, int6
         }
     };
 
+    // filtered CTM (src/fCTM.jl:216-219, :208-213): see ctm_estep_kernel
+    auto filt_a = [&](int c0, int rows) {
+        const float4* er = (const float4*)e_l;
+        for (int n = lane; n < rows; n += 64) {
+            const float4* br = (const float4*)(Bt + (size_t)n * KP);
+            const float tp = tn_l[n];
+            float m = -INFINITY;
+            for (int q = 0; q < LPR; ++q) {
+                const float4 b = br[q], ev = er[q];
+                m = fmaxf(m, fmaxf(fmaxf(fmaf(tp, b.x, ev.x), fmaf(tp, b.y, ev.y)), fmaxf(fmaf(tp, b.z, ev.z), fmaf(tp, b.w, ev.w))));
+            }
+            float s = 0.0f, a = 0.0f;
+            for (int q = 0; q < LPR; ++q) {
+                const float4 b = br[q], ev = er[q];
+                const float p0 = __expf(fmaf(tp, b.x, ev.x) - m), p1 = __expf(fmaf(tp, b.y, ev.y) - m);
+                const float p2 = __expf(fmaf(tp, b.z, ev.z) - m), p3 = __expf(fmaf(tp, b.w, ev.w) - m);
+                s += (p0 + p1) + (p2 + p3);
+                a = fmaf(p0, b.x, a); a = fmaf(p1, b.y, a); a = fmaf(p2, b.z, a); a = fmaf(p3, b.w, a);
+            }
+            const float prod = __expf(fminf(-(a / s), 87.0f));
+            const float tnew = p.eta / (TMVB_EPS_F + (p.eta + (1.0f - p.eta) * (p.kappa[t_l[n]] * prod)));
+            tp_l[n] = tp; m_l[n] = m; w_l[n] = c_l[n] / s;
+            p.tau_old[off + c0 + n] = tp; p.tau[off + c0 + n] = tnew; p.lse[off + c0 + n] = m + __logf(s);   // streamed window: always stored
+        }
+        WAVE_LDS_FENCE();
+    };
+    auto filt_b = [&](int rows, float4 (&acc)[NS]) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int q = ql + 16 * s;
+            if (q >= LPR) continue;
+            const float4 ev = *(const float4*)(e_l + 4 * q);
+            for (int n = r4; n < rows; n += 4) {
+                const float tp = tp_l[n], m = m_l[n], w = w_l[n];
+                const float4 b = *(const float4*)(Bt + (size_t)n * KP + 4 * q);
+                acc[s].x = fmaf(w, __expf(fmaf(tp, b.x, ev.x) - m), acc[s].x);
+                acc[s].y = fmaf(w, __expf(fmaf(tp, b.y, ev.y) - m), acc[s].y);
+                acc[s].z = fmaf(w, __expf(fmaf(tp, b.z, ev.z) - m), acc[s].z);
+                acc[s].w = fmaf(w, __expf(fmaf(tp, b.w, ev.w) - m), acc[s].w);
+            }
+        }
+    };
+
     int sweeps = 0;
     unsigned nsteps = 0;
     for (int v = 0; v < p.viter; ++v) {
         ++sweeps;
         // update_phi!  src/CTM.jl:175-178, linear space (no epsilon)
-        float lml = -INFINITY;
-#pragma unroll
-        for (int s = 0; s < NS; ++s) if (on[s]) lml = fmaxf(lml, (float)lam[s]);
-        const float lmax = wave_max(lml);
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            e[s] = on[s] ? expf((float)lam[s] - lmax) : 0.0f;
-            if (on[s]) e_l[lane + 64 * s] = e[s];
-        }
-        for (int i = K + lane; i < KP; i += 64) e_l[i] = 0.0f;                          // pads
-        WAVE_LDS_FENCE();
         float4 acc[NS];
 #pragma unroll
         for (int s = 0; s < NS; ++s) acc[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int c0 = 0; c0 < N; c0 += tile_rows) {
-            const int rows = min(tile_rows, N - c0);
-            load_chunk(c0, rows);
-            phase1(rows);
-            if (p.store_w)                       // last executed sweep wins (the exit sweep is not known in advance)
-                for (int n = lane; n < rows; n += 64) p.wtok[p.tok_inv[off + c0 + n]] = w_l[n];
-            phase2(rows, acc);
+        if constexpr (FILT) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) if (on[s]) e_l[lane + 64 * s] = (float)lam[s];
+            for (int i = K + lane; i < KP; i += 64) e_l[i] = -INFINITY;                 // pads: exp(-inf) = 0
             WAVE_LDS_FENCE();
+            for (int c0 = 0; c0 < N; c0 += tile_rows) {
+                const int rows = min(tile_rows, N - c0);
+                load_chunk(c0, rows);
+                filt_a(c0, rows);
+                filt_b(rows, acc);
+                WAVE_LDS_FENCE();
+            }
+        } else {
+            float lml = -INFINITY;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) if (on[s]) lml = fmaxf(lml, (float)lam[s]);
+            const float lmax = wave_max(lml);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                e[s] = on[s] ? expf((float)lam[s] - lmax) : 0.0f;
+                if (on[s]) e_l[lane + 64 * s] = e[s];
+            }
+            for (int i = K + lane; i < KP; i += 64) e_l[i] = 0.0f;                      // pads
+            WAVE_LDS_FENCE();
+            for (int c0 = 0; c0 < N; c0 += tile_rows) {
+                const int rows = min(tile_rows, N - c0);
+                load_chunk(c0, rows);
+                phase1(rows);
+                if (p.store_w)                       // last executed sweep wins (the exit sweep is not known in advance)
+                    for (int n = lane; n < rows; n += 64) p.wtok[p.tok_inv[off + c0 + n]] = w_l[n];
+                phase2(rows, acc);
+                WAVE_LDS_FENCE();
+            }
         }
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             float4 a = dpp_add4<0xB1>(acc[s]);
             a = dpp_add4<0x4E>(a);
             const float gsel = (r4 == 0) ? a.x : (r4 == 1) ? a.y : (r4 == 2) ? a.z : a.w;
-            phic[s] = on[s] ? (double)(e[s] * gsel) : 0.0;                          // (phi * counts)_i
+            phic[s] = on[s] ? (double)((FILT ? 1.0f : e[s]) * gsel) : 0.0;             // (phi * counts)_i
         }
         // update_logzeta!  :169-171
         {
@@ -496,7 +645,8 @@ __global__ __launch_bounds__(64) void ctm_estep_generic_kernel(CtmParams p, int6
             for (int s = 0; s < NS; ++s) if (on[s]) sl += exp(lam[s] + 0.5 * vs[s] - m);
             lz = m + log(wave_sum_d(sl));
         }
-        // update_vsq!  :146-165
+        // update_vsq!  src/CTM.jl:146-165 = src/fCTM.jl:180-198 (before update_lambda! in CTM, after it in fCTM)
+        auto run_vsq = [&]() {
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             if (!on[s]) continue;
@@ -512,6 +662,8 @@ __global__ __launch_bounds__(64) void ctm_estep_generic_kernel(CtmParams p, int6
             }
             vs[s] += TMVB_EPS_D;
         }
+        };
+        if constexpr (!FILT) run_vsq();                                                     // src/CTM.jl:198
         // update_lambda!  :129-142
 #pragma unroll
         for (int s = 0; s < NS; ++s) lam_old[s] = lam[s];
@@ -578,6 +730,7 @@ __global__ __launch_bounds__(64) void ctm_estep_generic_kernel(CtmParams p, int6
             WAVE_LDS_FENCE();
             if (sqrt(gn2) < p.ntol) break;                                                  // :138
         }
+        if constexpr (FILT) run_vsq();                                                      // src/fCTM.jl:240
         double d2l = 0.0;
 #pragma unroll
         for (int s = 0; s < NS; ++s) if (on[s]) { const double df = lam[s] - lam_old[s]; d2l += df * df; }
@@ -587,20 +740,20 @@ __global__ __launch_bounds__(64) void ctm_estep_generic_kernel(CtmParams p, int6
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const int i = lane + 64 * s;
-        if (sweeps > 0) {
-            if (on[s]) {
-                p.lambda[(int64_t)d * K + i] = (float)lam[s];
-                p.lambda_old[(int64_t)d * K + i] = (float)lam_old[s];
-                p.vsq[(int64_t)d * K + i] = (float)vs[s];
-            }
-            if (on[s]) p.E[(int64_t)d * KP + i] = e[s];
-        } else if (on[s]) {
-            p.E[(int64_t)d * KP + i] = 0.0f;
+        if (sweeps > 0 && on[s]) {
+            p.lambda[(int64_t)d * K + i] = (float)lam[s];
+            p.lambda_old[(int64_t)d * K + i] = (float)lam_old[s];
+            p.vsq[(int64_t)d * K + i] = (float)vs[s];
         }
+        if constexpr (!FILT) { if (on[s]) p.E[(int64_t)d * KP + i] = (sweeps > 0) ? e[s] : 0.0f; }
     }
-    for (int i = K + lane; i < KP; i += 64) p.E[(int64_t)d * KP + i] = 0.0f;              // pads
-    if (sweeps == 0 && p.store_w)
-        for (int n = lane; n < N; n += 64) p.wtok[p.tok_inv[off + n]] = 0.0f;             // viter = 0: no responsibilities
+    if constexpr (FILT) {
+        if (sweeps == 0) for (int n = lane; n < N; n += 64) p.lse[off + n] = INFINITY;     // viter = 0: phi = 0 in the statistics
+    } else {
+        for (int i = K + lane; i < KP; i += 64) p.E[(int64_t)d * KP + i] = 0.0f;          // pads
+        if (sweeps == 0 && p.store_w)
+            for (int n = lane; n < N; n += 64) p.wtok[p.tok_inv[off + n]] = 0.0f;         // viter = 0: no responsibilities
+    }
     if (lane == 0) {
         if (sweeps > 0) p.logzeta[d] = (float)lz;
         p.sweeps[d] = (uint8_t)min(sweeps, 255);
@@ -1099,7 +1252,7 @@ extern "C" int tmvb_ctm_estep(tmvb_ctm* h, int32_t niter, double ntol, int32_t v
             hipLaunchKernelGGL(kern, dim3((unsigned)h->M), dim3(64), lds, ctx->stream, p, (int64_t)0);
             return TMVB_OK;
         };
-        int lrc = (h->KP > 64) ? launch(ctm_estep_generic_kernel<2>) : launch(ctm_estep_generic_kernel<1>);
+        int lrc = (h->KP > 64) ? launch(ctm_estep_generic_kernel<2, false>) : launch(ctm_estep_generic_kernel<1, false>);
         if (lrc) return lrc;
         TMVB_HIP(hipGetLastError());
     }
@@ -1114,10 +1267,10 @@ extern "C" int tmvb_ctm_estep(tmvb_ctm* h, int32_t niter, double ntol, int32_t v
         hipStream_t st = (naux > 1) ? h->aux[bi % naux] : ctx->stream;
         const size_t lds = tmvb_tile_bytes(b.tile_rows, h->KP);
         const dim3 grid((unsigned)b.count), block(64);
-#define CTM_CASE(KPV) case KPV: hipLaunchKernelGGL((ctm_estep_kernel<KPV>), grid, block, lds, st, p, b.first, b.tile_rows); break;
+#define CTM_CASE(KPV) case KPV: hipLaunchKernelGGL((ctm_estep_kernel<KPV, false>), grid, block, lds, st, p, b.first, b.tile_rows); break;
         // (measured: compiling for 4 waves per SIMD -- 128 VGPRs, 17 spilled -- changes nothing: 5.98 vs 5.97 ms)
         switch (h->KP) { CTM_CASE(4) CTM_CASE(12) CTM_CASE(20) CTM_CASE(28) CTM_CASE(36) CTM_CASE(44) CTM_CASE(60)
-                         default: hipLaunchKernelGGL((ctm_estep_kernel<52>), grid, block, lds, st, p, b.first, b.tile_rows); break; }
+                         default: hipLaunchKernelGGL((ctm_estep_kernel<52, false>), grid, block, lds, st, p, b.first, b.tile_rows); break; }
 #undef CTM_CASE
         TMVB_HIP(hipGetLastError());
     }
@@ -1351,4 +1504,385 @@ extern "C" int tmvb_ctm_last_estep_ms(tmvb_ctm* h, float* ms)
     TMVB_HIP(hipEventSynchronize(h->ev1));
     TMVB_HIP(hipEventElapsedTime(ms, h->ev0, h->ev1));
     return TMVB_OK;
+}
+
+// ====================================================================================================================
+// filtered CTM (src/fCTM.jl) -- new device path; the reference's `@gpu train!` does nothing for an fCTM (src/macros.jl:277).
+// The handle wraps a CTM handle (same Newton machinery, M-step for sigma / mu, MFMA scatter) and adds the per-token switch
+// tau, the background distribution kappa, the log table L = log(beta + eps) and the rebuilt-phi statistics pass shared
+// with fLDA (tmvb_filtered.h).  Statistics buffer: [ S (K*V) | sum lambda (K) | sum vsq (K) | scatter (K*K) | kappa_stats (V) ].
+// ====================================================================================================================
+
+// update_elbo!  src/fCTM.jl:105-115 per document (terms :68-102); phi rebuilt from tau_old, beta_old, lambda_old (:109)
+template <int NS>
+__global__ __launch_bounds__(64) void fctm_elbo_kernel(int K, int KP, const int64_t* __restrict__ doc_ptr,
+                                                       const int32_t* __restrict__ terms, const int32_t* __restrict__ counts,
+                                                       const double* __restrict__ mu_d, const double* __restrict__ invsigma_d,
+                                                       const double* __restrict__ logdet_inv, double eta, const float* __restrict__ kappa,
+                                                       const float* __restrict__ beta, const float* __restrict__ beta_old,
+                                                       const float* __restrict__ lambda, const float* __restrict__ lambda_old,
+                                                       const float* __restrict__ vsq, const float* __restrict__ logzeta,
+                                                       const float* __restrict__ tau, const float* __restrict__ tau_old,
+                                                       double* __restrict__ doc_val)
+{
+    const int lane = threadIdx.x;
+    const int d = blockIdx.x;
+    const int64_t off = doc_ptr[d];
+    const int N = (int)(doc_ptr[d + 1] - off);
+    bool on[NS]; int ix[NS];
+    float lo[NS];
+    double l[NS], v[NS], df[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        on[s] = lane + 64 * s < K;
+        ix[s] = on[s] ? lane + 64 * s : 0;
+        lo[s] = on[s] ? lambda_old[(int64_t)d * K + ix[s]] : -INFINITY;
+        l[s] = on[s] ? (double)lambda[(int64_t)d * K + ix[s]] : 0.0;
+        v[s] = on[s] ? (double)vsq[(int64_t)d * K + ix[s]] : 1.0;
+        df[s] = on[s] ? l[s] - mu_d[ix[s]] : 0.0;
+    }
+    const double lz = (double)logzeta[d];
+    double acc = 0.0, Cd = 0.0, ta = 0.0;
+    for (int n = 0; n < N; ++n) {
+        const int t = terms[off + n];
+        const float c = (float)counts[off + n];
+        const float tn = tau[off + n], to = tau_old[off + n];
+        Cd += (double)c; ta += (double)tn * (double)c;
+        float x[NS], ml = -INFINITY;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            x[s] = on[s] ? fmaf(to, logf(beta_old[(int64_t)t * KP + ix[s]] + TMVB_EPS_F), lo[s]) : -INFINITY;   // :109
+            ml = fmaxf(ml, x[s]);
+        }
+        const float mx = wave_max(ml);
+        float ex[NS], sl = 0.0f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { ex[s] = on[s] ? expf(x[s] - mx) : 0.0f; sl += ex[s]; }
+        const float inv = 1.0f / wave_sum(sl);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (!on[s]) continue;
+            const float ph = ex[s] * inv;
+            const double cp = (double)(c * ph);
+            acc += cp * l[s];                                                                  // Elogpz :82 (first part)
+            acc += cp * (double)tn * (double)logf(beta[(int64_t)t * KP + ix[s]] + TMVB_EPS_F);  // Elogpw :89, topical part
+            if (ph > 0.0f) acc -= cp * (double)logf(ph);                                       // -Elogqz :108-111
+        }
+        if (lane == 0) {
+            acc += (double)c * (1.0 - (double)tn) * (double)logf(kappa[t] + TMVB_EPS_F);       // Elogpw :89, background part
+            if (tn > 0.0f && tn < 1.0f) acc -= (double)c * ((double)tn * log((double)tn) + (1.0 - (double)tn) * log(1.0 - (double)tn));   // -Elogqc :101-104
+        }
+    }
+    // Elogpeta :69
+    double mv[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) mv[s] = 0.0;
+    for (int j = 0; j < K; ++j) {
+        const double dj = (j < 64) ? readlane_d(df[0], j & 63) : readlane_d(df[NS - 1], j & 63);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) mv[s] = fma(on[s] ? invsigma_d[(int64_t)j * K + ix[s]] : 0.0, dj, mv[s]);
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        if (!on[s]) continue;
+        acc += -0.5 * (invsigma_d[(int64_t)ix[s] * K + ix[s]] * v[s] + df[s] * mv[s]);
+        acc -= Cd * exp(l[s] + 0.5 * v[s] - lz);                                               // Elogpz :82 (second part)
+        acc += 0.5 * log(v[s]);                                                                // -Elogqeta :95-97
+    }
+    double tot = wave_sum_d(acc);
+    const double TWO_PI_LOG = 1.8378770664093453;
+    tot += 0.5 * (*logdet_inv - (double)K * TWO_PI_LOG);
+    tot -= Cd * (lz - 1.0);
+    tot += 0.5 * (double)K * (1.0 + TWO_PI_LOG);
+    tot += log(TMVB_EPS_D + pow(eta, ta) * pow(1.0 - eta, Cd - ta));                           // Elogpc :74-77
+    if (lane == 0) doc_val[d] = tot;
+}
+
+struct tmvb_fctm {
+    tmvb_ctm* base = nullptr;
+    int64_t nnz = 0;
+    double eta = 0.5;                     // update_eta! is commented out in the reference's train! (src/fCTM.jl:253): a parameter
+    float* d_L = nullptr; float* d_kappa = nullptr; float* d_kappa_old = nullptr;
+    float* d_tau = nullptr; float* d_tau_old = nullptr; float* d_lse = nullptr;
+    float* d_stats = nullptr;             // the base handle is bound to this buffer
+    double* d_eta_scratch = nullptr; double* d_ksum = nullptr;
+    int64_t stats_len() const { return base->stats_len() + base->V; }
+    float* kstat() const { return d_stats + (size_t)base->stats_len(); }
+};
+
+extern "C" int tmvb_fctm_destroy(tmvb_fctm* h)
+{
+    if (!h) return TMVB_OK;
+    if (h->base && h->base->ctx) { (void)hipSetDevice(h->base->ctx->device); (void)hipStreamSynchronize(h->base->ctx->stream); }
+    (void)tmvb_ctm_destroy(h->base);      // does not free the bound statistics buffer
+    (void)hipFree(h->d_L); (void)hipFree(h->d_kappa); (void)hipFree(h->d_kappa_old); (void)hipFree(h->d_tau); (void)hipFree(h->d_tau_old);
+    (void)hipFree(h->d_lse); (void)hipFree(h->d_stats); (void)hipFree(h->d_eta_scratch); (void)hipFree(h->d_ksum);
+    delete h;
+    return TMVB_OK;
+}
+
+static int fctm_refresh_L(tmvb_fctm* h)
+{
+    tmvb_ctm* b = h->base;
+    const int64_t total = (int64_t)b->KP * b->V;
+    const int nb = (int)std::min<int64_t>(2048, std::max<int64_t>(1, (total + 255) / 256));
+    hipLaunchKernelGGL(flda_logbeta_kernel, dim3(nb), dim3(256), 0, b->ctx->stream, b->d_beta[b->cur], h->d_L, b->K, b->KP, b->V);
+    TMVB_HIP(hipGetLastError());
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_fctm_set_state(tmvb_fctm* h, const double* eta, const double* mu, const double* sigma, const double* invsigma,
+                                   const double* kappa, const double* kappa_old, const double* beta, const double* beta_old,
+                                   const double* lambda, const double* lambda_old, const double* vsq, const double* logzeta,
+                                   const double* tau, const double* tau_old, const double* elbo);
+
+extern "C" int tmvb_fctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb_fctm** out)
+{
+    TMVB_REQUIRE(out != nullptr, TMVB_EINVAL, "tmvb_fctm_create: out is NULL");
+    *out = nullptr;
+    tmvb_fctm* h = new tmvb_fctm();
+    tmvb_create_guard<tmvb_fctm, tmvb_fctm_destroy> guard{h};
+    int rc = tmvb_ctm_create(ctx, corp, K, &h->base);                     // fCTM(corp, K), src/fCTM.jl:32-65: same constructor state
+    if (rc) return rc;
+    tmvb_ctm* b = h->base;
+    h->nnz = corp->info.nnz;
+    const size_t V = (size_t)b->V, NZ = (size_t)h->nnz, KPV = (size_t)b->KP * b->V + 4;
+    if ((rc = dmalloc(&h->d_L, KPV)) || (rc = dmalloc(&h->d_kappa, V)) || (rc = dmalloc(&h->d_kappa_old, V)) || (rc = dmalloc(&h->d_tau, NZ)) ||
+        (rc = dmalloc(&h->d_tau_old, NZ)) || (rc = dmalloc(&h->d_lse, NZ)) || (rc = dmalloc(&h->d_stats, (size_t)h->stats_len())) ||
+        (rc = dmalloc(&h->d_eta_scratch, 1)) || (rc = dmalloc(&h->d_ksum, 1)))
+        return rc;
+    TMVB_HIP(hipMemsetAsync(h->d_stats, 0, (size_t)h->stats_len() * sizeof(float), ctx->stream));
+    TMVB_HIP(hipMemsetAsync(h->d_lse, 0, std::max<size_t>(NZ, 1) * sizeof(float), ctx->stream));
+    TMVB_HIP(hipStreamSynchronize(ctx->stream));
+    if ((rc = tmvb_ctm_bind_stats(b, h->d_stats, h->stats_len()))) return rc;
+    const double eta0 = 0.5;                                              // :37
+    std::vector<double> kap(V, V ? 1.0 / (double)V : 0.0), tau(NZ, eta0);
+    if ((rc = tmvb_fctm_set_state(h, &eta0, nullptr, nullptr, nullptr, kap.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                  tau.data(), nullptr, nullptr)))
+        return rc;
+    if ((rc = fctm_refresh_L(h))) return rc;
+    guard.release();
+    *out = h;
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_fctm_set_state(tmvb_fctm* h, const double* eta, const double* mu, const double* sigma, const double* invsigma,
+                                   const double* kappa, const double* kappa_old, const double* beta, const double* beta_old,
+                                   const double* lambda, const double* lambda_old, const double* vsq, const double* logzeta,
+                                   const double* tau, const double* tau_old, const double* elbo)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_fctm_set_state: handle is NULL");
+    tmvb_ctm* b = h->base;
+    tmvb_ctx* ctx = b->ctx;
+    int rc = tmvb_ctm_set_state(b, mu, sigma, invsigma, beta, beta_old, lambda, lambda_old, vsq, logzeta, elbo);
+    if (rc) return rc;
+    const size_t V = (size_t)b->V, NZ = (size_t)h->nnz;
+    if (eta) {
+        TMVB_REQUIRE(*eta >= 0.0 && *eta <= 1.0, TMVB_ESHAPE, "eta must belong to the interval [0,1].");    // src/modelutils.jl:145
+        h->eta = *eta;
+    }
+    if (kappa) {
+        if ((rc = upload_f32(ctx, h->d_kappa, kappa, V))) return rc;
+        if (!kappa_old && (rc = upload_f32(ctx, h->d_kappa_old, kappa, V))) return rc;
+    }
+    if (kappa_old && (rc = upload_f32(ctx, h->d_kappa_old, kappa_old, V))) return rc;
+    if (tau) {
+        for (size_t q = 0; q < NZ; ++q) TMVB_REQUIRE(tau[q] >= 0.0 && tau[q] <= 1.0, TMVB_ESHAPE, "tau must belong to the interval [0,1].");
+        if ((rc = upload_f32(ctx, h->d_tau, tau, NZ))) return rc;
+        if (!tau_old && (rc = upload_f32(ctx, h->d_tau_old, tau, NZ))) return rc;
+    }
+    if (tau_old && (rc = upload_f32(ctx, h->d_tau_old, tau_old, NZ))) return rc;
+    if (beta && (rc = fctm_refresh_L(h))) return rc;
+    TMVB_HIP(hipStreamSynchronize(ctx->stream));
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_fctm_get_state(tmvb_fctm* h, double* eta, double* mu, double* sigma, double* invsigma, double* kappa, double* kappa_old,
+                                   double* beta, double* beta_old, double* lambda, double* lambda_old, double* vsq, double* logzeta,
+                                   double* tau, double* tau_old, double* elbo)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_fctm_get_state: handle is NULL");
+    tmvb_ctm* b = h->base;
+    int rc = tmvb_ctm_get_state(b, mu, sigma, invsigma, beta, beta_old, lambda, lambda_old, vsq, logzeta, elbo);
+    if (rc) return rc;
+    const size_t V = (size_t)b->V, NZ = (size_t)h->nnz;
+    if (eta) *eta = h->eta;
+    if (kappa && (rc = download_f32(b->ctx, kappa, h->d_kappa, V))) return rc;
+    if (kappa_old && (rc = download_f32(b->ctx, kappa_old, h->d_kappa_old, V))) return rc;
+    if (tau && (rc = download_f32(b->ctx, tau, h->d_tau, NZ))) return rc;
+    if (tau_old && (rc = download_f32(b->ctx, tau_old, h->d_tau_old, NZ))) return rc;
+    return TMVB_OK;
+}
+
+// update_phi! / update_tau! / update_logzeta! / update_lambda! / update_vsq! sweeps + update_beta!(model, d) + update_kappa!(model, d)
+// for every document (src/fCTM.jl:233-248).  Asynchronous on the context's stream.
+extern "C" int tmvb_fctm_estep(tmvb_fctm* h, int32_t niter, double ntol, int32_t viter, double vtol)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_fctm_estep: handle is NULL");
+    TMVB_REQUIRE(viter >= 0 && niter >= 0, TMVB_EINVAL, "iteration parameters must be nonnegative.");   // src/fCTM.jl:229
+    TMVB_REQUIRE(vtol >= 0 && ntol >= 0, TMVB_EINVAL, "tolerance parameters must be nonnegative.");     // :228
+    tmvb_ctm* b = h->base;
+    tmvb_ctx* ctx = b->ctx;
+    TMVB_HIP(hipSetDevice(ctx->device));
+    CtmParams p;
+    p.K = b->K; p.KP = b->KP; p.LPR = b->KP / 4; p.lpr_magic = (unsigned)(0x100000000ull / (unsigned)p.LPR) + 1u;
+    p.doc_ptr = b->corp->d_doc_ptr; p.terms = b->corp->d_terms; p.counts = b->corp->d_counts;
+    p.doc_order = b->d_doc_order; p.tok_inv = b->corp->term_index.d_inv;
+    p.beta = b->d_beta[b->cur]; p.invsigma = b->d_invsigma_f; p.mu = b->d_mu_f;
+    p.lambda = b->d_lambda; p.lambda_old = b->d_lambda_old; p.vsq = b->d_vsq; p.logzeta = b->d_logzeta;
+    p.wtok = b->d_wtok; p.E = b->d_E; p.sweeps = b->d_sweeps; p.newton_steps = b->d_newton;
+    p.niter = niter; p.ntol = ntol; p.viter = viter; p.vtol = vtol; p.debug = 0; p.store_w = 0;
+    p.L = h->d_L; p.kappa = h->d_kappa; p.eta = (float)h->eta; p.tau = h->d_tau; p.tau_old = h->d_tau_old; p.lse = h->d_lse;
+    TMVB_HIP(hipEventRecord(b->ev0, ctx->stream));
+    TMVB_HIP(hipMemsetAsync(b->d_newton, 0, sizeof(unsigned long long), ctx->stream));
+    if (b->generic && b->M > 0) {
+        const size_t lds = ctm_generic_lds_bytes(b->KP);
+        auto launch = [&](auto kern) -> int {
+            TMVB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3((unsigned)b->M), dim3(64), lds, ctx->stream, p, (int64_t)0);
+            return TMVB_OK;
+        };
+        int lrc = (b->KP > 64) ? launch(ctm_estep_generic_kernel<2, true>) : launch(ctm_estep_generic_kernel<1, true>);
+        if (lrc) return lrc;
+        TMVB_HIP(hipGetLastError());
+    } else {
+        for (const tmvb_bucket& bk : b->buckets) {
+            const size_t lds = ctm_tile_bytes(bk.tile_rows, b->KP, true);
+            const dim3 grid((unsigned)bk.count), block(64);
+#define FCTM_CASE(KPV) case KPV: hipLaunchKernelGGL((ctm_estep_kernel<KPV, true>), grid, block, lds, ctx->stream, p, bk.first, bk.tile_rows); break;
+            switch (b->KP) { FCTM_CASE(4) FCTM_CASE(12) FCTM_CASE(20) FCTM_CASE(28) FCTM_CASE(36) FCTM_CASE(44) FCTM_CASE(60)
+                             default: hipLaunchKernelGGL((ctm_estep_kernel<52, true>), grid, block, lds, ctx->stream, p, bk.first, bk.tile_rows); break; }
+#undef FCTM_CASE
+            TMVB_HIP(hipGetLastError());
+        }
+    }
+    FldaStatsParams sp;
+    sp.K = b->K; sp.KP = b->KP; sp.L = h->d_L; sp.elog_old = b->d_lambda_old; sp.tau = h->d_tau; sp.tau_old = h->d_tau_old; sp.lse = h->d_lse;
+    sp.S = h->d_stats; sp.kstat = h->kstat(); sp.partial = b->d_ts_partial;
+    int rc = tmvb_launch_filtered_stats(ctx, b->nslot, b->corp->term_index, sp);
+    if (rc) return rc;
+    TMVB_HIP(hipEventRecord(b->ev1, ctx->stream));
+    b->timed = true;
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_fctm_reduce_docs(tmvb_fctm* h)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_fctm_reduce_docs: handle is NULL");
+    return tmvb_ctm_reduce_docs(h->base);
+}
+
+// update_beta!(model) (src/fCTM.jl:148-152) and update_kappa!(model) (:134-138), run back to back by train! (:249-250)
+extern "C" int tmvb_fctm_update_beta(tmvb_fctm* h)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_fctm_update_beta: handle is NULL");
+    tmvb_ctm* b = h->base;
+    int rc = tmvb_ctm_update_beta(b);
+    if (!rc) rc = fctm_refresh_L(h);
+    if (rc) return rc;
+    hipLaunchKernelGGL(flda_kappa_eta_kernel, dim3(1), dim3(1024), 0, b->ctx->stream, h->kstat(), h->d_kappa, h->d_kappa_old, b->V, 1.0,
+                       h->d_eta_scratch, 1, 0, h->d_ksum);
+    TMVB_HIP(hipGetLastError());
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_fctm_update_sigma(tmvb_fctm* h) { TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_fctm_update_sigma: handle is NULL"); return tmvb_ctm_update_sigma(h->base); }
+extern "C" int tmvb_fctm_update_mu(tmvb_fctm* h) { TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_fctm_update_mu: handle is NULL"); return tmvb_ctm_update_mu(h->base); }
+
+extern "C" int tmvb_fctm_update_elbo(tmvb_fctm* h, double* elbo)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_fctm_update_elbo: handle is NULL");
+    tmvb_ctm* b = h->base;
+    tmvb_ctx* ctx = b->ctx;
+    TMVB_HIP(hipSetDevice(ctx->device));
+    if (b->M > 0) {
+        const dim3 grid((unsigned)b->M), block(64);
+        if (b->nslot == 1)
+            hipLaunchKernelGGL((fctm_elbo_kernel<1>), grid, block, 0, ctx->stream, b->K, b->KP, b->corp->d_doc_ptr, b->corp->d_terms, b->corp->d_counts,
+                               b->d_mu, b->d_invsigma, b->d_logdet, h->eta, h->d_kappa, b->d_beta[b->cur], b->d_beta[b->cur ^ 1], b->d_lambda,
+                               b->d_lambda_old, b->d_vsq, b->d_logzeta, h->d_tau, h->d_tau_old, b->d_doc_val);
+        else
+            hipLaunchKernelGGL((fctm_elbo_kernel<2>), grid, block, 0, ctx->stream, b->K, b->KP, b->corp->d_doc_ptr, b->corp->d_terms, b->corp->d_counts,
+                               b->d_mu, b->d_invsigma, b->d_logdet, h->eta, h->d_kappa, b->d_beta[b->cur], b->d_beta[b->cur ^ 1], b->d_lambda,
+                               b->d_lambda_old, b->d_vsq, b->d_logzeta, h->d_tau, h->d_tau_old, b->d_doc_val);
+        TMVB_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(sum_docs_kernel, dim3(1), dim3(1024), 0, ctx->stream, b->d_doc_val, b->M, b->d_elbo);
+    TMVB_HIP(hipGetLastError());
+    double v = 0.0;
+    int st = 0;
+    TMVB_HIP(hipMemcpyAsync(&v, b->d_elbo, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    TMVB_HIP(hipMemcpyAsync(&st, b->d_status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    TMVB_HIP(hipStreamSynchronize(ctx->stream));
+    TMVB_REQUIRE(st == 0, TMVB_ENONFINITE, "sigma must be positive-definite.");
+    b->elbo = v;
+    if (elbo) *elbo = v;
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_fctm_set_comm(tmvb_fctm* h, tmvb_comm* comm, int64_t M_total)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_fctm_set_comm: handle is NULL");
+    return tmvb_ctm_set_comm(h->base, comm, M_total);
+}
+
+namespace {
+struct FctmTrainOps {
+    int niter, viter; double ntol, vtol;
+    int estep(tmvb_fctm* h) { return tmvb_fctm_estep(h, niter, ntol, viter, vtol); }   // src/fCTM.jl:233-248
+    int reduce(tmvb_fctm* h) { return tmvb_fctm_reduce_docs(h); }
+    int before_allreduce(tmvb_fctm*) { return TMVB_OK; }
+    float* stats(tmvb_fctm* h) { return h->d_stats; }
+    int64_t stats_len(tmvb_fctm* h) { return h->stats_len(); }
+    int mstep(tmvb_fctm* h)
+    {
+        int rc = tmvb_fctm_update_beta(h);                                             // :249-250 (beta, kappa)
+        if (!rc) rc = tmvb_fctm_update_sigma(h);                                       // :251 (previous mu)
+        if (!rc) rc = tmvb_fctm_update_mu(h);                                          // :252;  update_eta! is commented out (:253)
+        return rc;
+    }
+    int elbo_local(tmvb_fctm* h, double* s, double* once) { *once = 0.0; return tmvb_fctm_update_elbo(h, s); }
+    double* elbo_dev(tmvb_fctm* h) { return h->base->d_elbo; }
+    tmvb_comm* comm(tmvb_fctm* h) { return h->base->comm; }
+    bool distributed(tmvb_fctm* h) { return h->base->distributed; }
+    tmvb_ctx* ctx(tmvb_fctm* h) { return h->base->ctx; }
+    int64_t nnz(tmvb_fctm* h) { return h->nnz; }
+    void set_elbo(tmvb_fctm* h, double v) { h->base->elbo = v; }
+    double get_elbo(tmvb_fctm* h) { return h->base->elbo; }
+    int finish(tmvb_fctm* h)
+    {
+        TMVB_HIP(hipSetDevice(h->base->ctx->device));
+        TMVB_HIP(hipStreamSynchronize(h->base->ctx->stream));
+        return TMVB_OK;
+    }
+};
+}  // namespace
+
+extern "C" int tmvb_fctm_train_group(tmvb_fctm* const* hs, int32_t n, int32_t iter, double tol, int32_t niter, double ntol, int32_t viter,
+                                     double vtol, int32_t checkelbo, double* elbo_traj, int32_t* iters_done, double* elbo_baseline)
+{
+    TMVB_REQUIRE(tol >= 0 && ntol >= 0 && vtol >= 0, TMVB_EINVAL, "tolerance parameters must be nonnegative.");   // src/fCTM.jl:228
+    TMVB_REQUIRE(iter >= 0 && niter >= 0 && viter >= 0, TMVB_EINVAL, "iteration parameters must be nonnegative."); // :229
+    FctmTrainOps ops{niter, viter, ntol, vtol};
+    return tmvb_train_group_loop("tmvb_fctm_train", hs, n, iter, tol, checkelbo, elbo_traj, iters_done, elbo_baseline, ops);
+}
+
+// train! (src/fCTM.jl:226-262)
+extern "C" int tmvb_fctm_train(tmvb_fctm* h, int32_t iter, double tol, int32_t niter, double ntol, int32_t viter, double vtol,
+                               int32_t checkelbo, double* elbo_traj, int32_t* iters_done, double* elbo_baseline)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_fctm_train: handle is NULL");
+    return tmvb_fctm_train_group(&h, 1, iter, tol, niter, ntol, viter, vtol, checkelbo, elbo_traj, iters_done, elbo_baseline);
+}
+
+extern "C" int tmvb_fctm_doc_sweeps(tmvb_fctm* h, uint8_t* out)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_fctm_doc_sweeps: handle is NULL");
+    return tmvb_ctm_doc_sweeps(h->base, out);
+}
+
+extern "C" int tmvb_fctm_sweep_hist(tmvb_fctm* h, int64_t* hist, int32_t nbins, int64_t* newton_steps)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_fctm_sweep_hist: handle is NULL");
+    return tmvb_ctm_sweep_hist(h->base, hist, nbins, newton_steps);
 }
