@@ -140,7 +140,10 @@ def test_every_ccall_matches_the_header():
     for must in ("tmvb_lda_train", "tmvb_ctm_train", "tmvb_ctpf_train", "tmvb_lda_train_group", "tmvb_ctm_train_group", "tmvb_comm_create_rccl",
                  "tmvb_comm_create_rccl_all", "tmvb_comm_create_host", "tmvb_comm_unique_id", "tmvb_lda_set_comm", "tmvb_ctm_set_comm",
                  "tmvb_ctpf_set_comm", "tmvb_ctpf_set_state_old", "tmvb_ctpf_recommend", "tmvb_ctm_update_sigma", "tmvb_ctm_update_mu",
-                 "tmvb_ctpf_mstep", "tmvb_lda_estep", "tmvb_ctm_estep", "tmvb_ctpf_estep"):
+                 "tmvb_ctpf_mstep", "tmvb_lda_estep", "tmvb_ctm_estep", "tmvb_ctpf_estep", "tmvb_flda_train", "tmvb_fctm_train",
+                 "tmvb_flda_set_state", "tmvb_fctm_set_state", "tmvb_flda_get_state", "tmvb_fctm_get_state", "tmvb_flda_estep", "tmvb_fctm_estep",
+                 "tmvb_flda_update_eta", "tmvb_fctm_update_sigma", "tmvb_flda_train_group", "tmvb_fctm_train_group", "tmvb_flda_set_comm",
+                 "tmvb_fctm_set_comm"):
         assert must in seen, f"the Julia shim does not bind {must}"
 
 
@@ -151,8 +154,8 @@ def test_header_parser_sees_the_whole_abi(tmvb):
     assert protos["tmvb_corpus_create"][1][1] == ("i64", None)
 
 
-def test_gpu_macro_file_covers_the_three_models():
+def test_gpu_macro_file_covers_the_models():
     src = open(os.path.join(ROOT, "topicmodelsvb.jl_amd", "julia", "gpu_macro.jl")).read()
-    for t in ("LDA", "CTM", "CTPF"):
+    for t in ("LDA", "CTM", "CTPF", "fLDA", "fCTM"):
         assert f"copyback!(model::{t}, dev::hip{t})" in src and f"hipmodel(model::{t}) = hip{t}(model)" in src
     assert "macro gpu(expr::Expr)" in src

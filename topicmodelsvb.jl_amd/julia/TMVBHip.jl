@@ -534,3 +534,268 @@ function topicdist(model::hipCTPF, d::Integer)      # src/modelutils.jl:960-965
 	(d <= length(model.corp)) || throw(CorpusError("document index outside corpus range."))
 	return model.gimel[d] / sum(model.gimel[d])
 end
+
+# ---------------------------------------------------------------------------------------------- fLDA / fCTM
+# Filtered models (src/fLDA.jl, src/fCTM.jl).  The reference has no device types for them: `@gpu train!` on an fLDA / fCTM
+# does nothing (src/macros.jl:274-278).  hipfLDA / hipfCTM follow the gpuLDA / gpuCTM pattern on the engine's filtered
+# kernels.  tau / tau_old travel as flat vectors in corpus token order (vcat(model.tau...)).
+
+splitdocs(flat::Vector{Float64}, N::Vector{Int}) = (o = cumsum([0; N]); [flat[o[d]+1:o[d+1]] for d in 1:length(N)])
+flatdocs(v::VectorList{Float64}) = isempty(v) ? Float64[] : vcat(v...)
+
+mutable struct hipfLDA <: TopicModel
+	K::Int; M::Int; V::Int; N::Vector{Int}; C::Vector{Int}
+	corp::Corpus; topics::VectorList{Int}
+	eta::Float64; alpha::Vector{Float64}
+	kappa::Vector{Float64}; kappa_old::Vector{Float64}
+	beta::Matrix{Float64}; beta_old::Matrix{Float64}
+	Elogtheta::VectorList{Float64}; Elogtheta_old::VectorList{Float64}; gamma::VectorList{Float64}
+	tau::VectorList{Float64}; tau_old::VectorList{Float64}
+	elbo::Float64
+	ctx::Ptr{Cvoid}; dcorp::Ptr{Cvoid}; handle::Ptr{Cvoid}
+	comm::Union{hipComm, Nothing}
+end
+
+function hipfLDA(model::fLDA; device::Integer=0)
+	ctx = tmvb_context(device)
+	dcorp = tmvb_upload_corpus(ctx, model.corp)
+	h = Ref{Ptr{Cvoid}}(C_NULL)
+	tmvb_check(ccall((:tmvb_flda_create, LIBTMVB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Ref{Ptr{Cvoid}}), ctx, dcorp, model.K, h))
+	m = hipfLDA(model.K, model.M, model.V, model.N, model.C, model.corp, model.topics, model.eta, model.alpha, model.kappa, model.kappa_old,
+		model.beta, model.beta_old, model.Elogtheta, model.Elogtheta_old, model.gamma, model.tau, model.tau_old, model.elbo, ctx, dcorp, h[], nothing)
+	finalizer(m) do x
+		ccall((:tmvb_flda_destroy, LIBTMVB), Cint, (Ptr{Cvoid},), x.handle)
+		tmvb_destroy_corpus(x.dcorp)
+		tmvb_destroy_context(x.ctx)
+	end
+	return m
+end
+
+function update_buffer!(model::hipfLDA)
+	beta, beta_old = Matrix{Float64}(model.beta), Matrix{Float64}(model.beta_old)
+	gamma, El, Elo = hcat(model.gamma...), hcat(model.Elogtheta...), hcat(model.Elogtheta_old...)
+	tau, tau_old = flatdocs(model.tau), flatdocs(model.tau_old)
+	eta = Ref{Float64}(model.eta); elbo = Ref{Float64}(model.elbo)
+	GC.@preserve beta beta_old gamma El Elo tau tau_old begin
+		tmvb_check(ccall((:tmvb_flda_set_state, LIBTMVB), Cint,
+			(Ptr{Cvoid}, Ref{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Float64}),
+			model.handle, eta, model.alpha, model.kappa, model.kappa_old, beta, beta_old, gamma, El, Elo, tau, tau_old, elbo))
+	end
+end
+
+function update_host!(model::hipfLDA)
+	K, M, V, nnz = model.K, model.M, model.V, sum(model.N)
+	alpha = zeros(K); kappa = zeros(V); kappa_old = zeros(V); beta = zeros(K, V); beta_old = zeros(K, V)
+	gamma = zeros(K, M); El = zeros(K, M); Elo = zeros(K, M); tau = zeros(nnz); tau_old = zeros(nnz)
+	eta = Ref{Float64}(0.0); elbo = Ref{Float64}(0.0)
+	tmvb_check(ccall((:tmvb_flda_get_state, LIBTMVB), Cint,
+		(Ptr{Cvoid}, Ref{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Float64}),
+		model.handle, eta, alpha, kappa, kappa_old, beta, beta_old, gamma, El, Elo, tau, tau_old, elbo))
+	model.eta, model.alpha, model.kappa, model.kappa_old, model.beta, model.beta_old = eta[], alpha, kappa, kappa_old, beta, beta_old
+	model.gamma, model.Elogtheta, model.Elogtheta_old = cols(gamma), cols(El), cols(Elo)
+	model.tau, model.tau_old = splitdocs(tau, model.N), splitdocs(tau_old, model.N)
+	model.elbo = elbo[]
+end
+
+"update_phi! / update_tau! / update_gamma! / update_Elogtheta! sweeps + update_beta!(model, d) + update_kappa!(model, d) (src/fLDA.jl:222-236)."
+update_estep!(model::hipfLDA, viter::Integer, vtol::Real) = tmvb_check(ccall((:tmvb_flda_estep, LIBTMVB), Cint, (Ptr{Cvoid}, Int32, Float64), model.handle, viter, vtol))
+update_Elogtheta_sum!(model::hipfLDA) = tmvb_check(ccall((:tmvb_flda_reduce_docs, LIBTMVB), Cint, (Ptr{Cvoid},), model.handle))
+"update_beta! and update_kappa! (src/fLDA.jl:152, :138)."
+update_beta!(model::hipfLDA) = tmvb_check(ccall((:tmvb_flda_update_beta, LIBTMVB), Cint, (Ptr{Cvoid},), model.handle))
+update_alpha!(model::hipfLDA, niter::Integer, ntol::Real) = tmvb_check(ccall((:tmvb_flda_update_alpha, LIBTMVB), Cint, (Ptr{Cvoid}, Int32, Float64), model.handle, niter, ntol))
+update_eta!(model::hipfLDA) = tmvb_check(ccall((:tmvb_flda_update_eta, LIBTMVB), Cint, (Ptr{Cvoid},), model.handle))      # src/fLDA.jl:122
+function update_elbo!(model::hipfLDA)
+	e = Ref{Float64}(0.0)
+	tmvb_check(ccall((:tmvb_flda_update_elbo, LIBTMVB), Cint, (Ptr{Cvoid}, Ref{Float64}), model.handle, e))
+	model.elbo = e[]
+end
+
+"Document shard of a corpus of M_total documents and C_total tokens (sum of all counts; eta's denominator, src/fLDA.jl:123)."
+function set_comm!(model::hipfLDA, comm::Union{hipComm, Nothing}, M_total::Integer, C_total::Integer)
+	tmvb_check(ccall((:tmvb_flda_set_comm, LIBTMVB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64), model.handle, comm === nothing ? C_NULL : comm.handle, M_total, C_total))
+	model.comm = comm
+	nothing
+end
+
+"train!(model::fLDA; ...) (src/fLDA.jl:213-247) on the device."
+function train!(model::hipfLDA; iter::Integer=150, tol::Real=1.0, niter::Integer=1000, ntol::Real=1/model.K^2, viter::Integer=10, vtol::Real=1/model.K^2, checkelbo::Real=1, printelbo::Bool=true)
+	check_train_args([tol, ntol, vtol], [iter, niter, viter], checkelbo)
+	update_buffer!(model)
+	traj = fill(NaN, max(iter, 1)); done = Ref{Int32}(0); base = Ref{Float64}(model.elbo)
+	tmvb_check(ccall((:tmvb_flda_train, LIBTMVB), Cint,
+		(Ptr{Cvoid}, Int32, Float64, Int32, Float64, Int32, Float64, Int32, Ptr{Float64}, Ref{Int32}, Ref{Float64}),
+		model.handle, iter, tol, niter, ntol, viter, vtol, checkelbo_arg(checkelbo), traj, done, base))
+	printelbo && print_delbo(traj, done[], base[])
+	(iter > 0) && update_host!(model)
+	model.topics = [reverse(sortperm(vec(model.beta[i,:]))) for i in 1:model.K]
+	nothing
+end
+
+function train!(models::Vector{hipfLDA}; iter::Integer=150, tol::Real=1.0, niter::Integer=1000, ntol::Real=1/models[1].K^2, viter::Integer=10, vtol::Real=1/models[1].K^2, checkelbo::Real=1, printelbo::Bool=true)
+	check_train_args([tol, ntol, vtol], [iter, niter, viter], checkelbo)
+	foreach(update_buffer!, models)
+	hs = Ptr{Cvoid}[m.handle for m in models]
+	traj = fill(NaN, max(iter, 1)); done = Ref{Int32}(0); base = Ref{Float64}(models[1].elbo)
+	tmvb_check(ccall((:tmvb_flda_train_group, LIBTMVB), Cint,
+		(Ptr{Ptr{Cvoid}}, Int32, Int32, Float64, Int32, Float64, Int32, Float64, Int32, Ptr{Float64}, Ref{Int32}, Ref{Float64}),
+		hs, length(hs), iter, tol, niter, ntol, viter, vtol, checkelbo_arg(checkelbo), traj, done, base))
+	printelbo && print_delbo(traj, done[], base[])
+	for m in models
+		(iter > 0) && update_host!(m)
+		m.topics = [reverse(sortperm(vec(m.beta[i,:]))) for i in 1:m.K]
+	end
+	nothing
+end
+
+"""
+predict (src/modelutils.jl:857-883) on the device.  As in the reference only alpha, beta and topics come from the trained model
+(:866-868): kappa and eta are those of the fresh fLDA(corp, K).  The reference's loop tests `vtol`, which that function never
+defines (:877); `tol` is used here.
+"""
+function predict(corp::Corpus, train_model::hipfLDA; iter::Integer=10, tol::Real=1/train_model.K^2)
+	check_corp(corp)
+	(corp.vocab == train_model.corp.vocab)	|| throw(CorpusError("predict corpus and train_model corpus must have identical vocabularies."))
+	(tol >= 0)								|| throw(ArgumentError("tolerance parameter must be nonnegative."))
+	(iter >= 0)								|| throw(ArgumentError("iteration parameter must be nonnegative."))
+	host = fLDA(corp, train_model.K)
+	host.alpha, host.beta, host.beta_old, host.topics = train_model.alpha, train_model.beta, copy(train_model.beta), train_model.topics
+	dev = hipfLDA(host)
+	update_buffer!(dev)
+	update_estep!(dev, iter, tol)
+	update_host!(dev)
+	host.gamma, host.Elogtheta, host.Elogtheta_old, host.tau, host.tau_old = dev.gamma, dev.Elogtheta, dev.Elogtheta_old, dev.tau, dev.tau_old
+	return host
+end
+
+function topicdist(model::hipfLDA, d::Integer)      # src/modelutils.jl:946-951
+	(d <= length(model.corp)) || throw(CorpusError("document index outside corpus range."))
+	return model.gamma[d] / sum(model.gamma[d])
+end
+
+mutable struct hipfCTM <: TopicModel
+	K::Int; M::Int; V::Int; N::Vector{Int}; C::Vector{Int}
+	corp::Corpus; topics::VectorList{Int}
+	eta::Float64
+	mu::Vector{Float64}; sigma::Matrix{Float64}; invsigma::Matrix{Float64}
+	kappa::Vector{Float64}; kappa_old::Vector{Float64}
+	beta::Matrix{Float64}; beta_old::Matrix{Float64}
+	lambda::VectorList{Float64}; lambda_old::VectorList{Float64}; vsq::VectorList{Float64}; logzeta::Vector{Float64}
+	tau::VectorList{Float64}; tau_old::VectorList{Float64}
+	elbo::Float64
+	ctx::Ptr{Cvoid}; dcorp::Ptr{Cvoid}; handle::Ptr{Cvoid}
+	comm::Union{hipComm, Nothing}
+end
+
+function hipfCTM(model::fCTM; device::Integer=0)
+	ctx = tmvb_context(device)
+	dcorp = tmvb_upload_corpus(ctx, model.corp)
+	h = Ref{Ptr{Cvoid}}(C_NULL)
+	tmvb_check(ccall((:tmvb_fctm_create, LIBTMVB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Ref{Ptr{Cvoid}}), ctx, dcorp, model.K, h))
+	m = hipfCTM(model.K, model.M, model.V, model.N, model.C, model.corp, model.topics, model.eta, model.mu, Matrix(model.sigma),
+		Matrix(model.invsigma), model.kappa, model.kappa_old, model.beta, model.beta_old, model.lambda, model.lambda_old, model.vsq,
+		model.logzeta, model.tau, model.tau_old, model.elbo, ctx, dcorp, h[], nothing)
+	finalizer(m) do x
+		ccall((:tmvb_fctm_destroy, LIBTMVB), Cint, (Ptr{Cvoid},), x.handle)
+		tmvb_destroy_corpus(x.dcorp)
+		tmvb_destroy_context(x.ctx)
+	end
+	return m
+end
+
+function update_buffer!(model::hipfCTM)
+	beta, beta_old = Matrix{Float64}(model.beta), Matrix{Float64}(model.beta_old)
+	lam, lam_old, vsq = hcat(model.lambda...), hcat(model.lambda_old...), hcat(model.vsq...)
+	tau, tau_old = flatdocs(model.tau), flatdocs(model.tau_old)
+	eta = Ref{Float64}(model.eta); elbo = Ref{Float64}(model.elbo)
+	GC.@preserve beta beta_old lam lam_old vsq tau tau_old begin
+		tmvb_check(ccall((:tmvb_fctm_set_state, LIBTMVB), Cint,
+			(Ptr{Cvoid}, Ref{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Float64}),
+			model.handle, eta, model.mu, model.sigma, model.invsigma, model.kappa, model.kappa_old, beta, beta_old, lam, lam_old, vsq, model.logzeta, tau, tau_old, elbo))
+	end
+end
+
+function update_host!(model::hipfCTM)
+	K, M, V, nnz = model.K, model.M, model.V, sum(model.N)
+	mu = zeros(K); sg = zeros(K, K); isg = zeros(K, K); kappa = zeros(V); kappa_old = zeros(V); beta = zeros(K, V); beta_old = zeros(K, V)
+	lam = zeros(K, M); lam_old = zeros(K, M); vsq = zeros(K, M); lz = zeros(M); tau = zeros(nnz); tau_old = zeros(nnz)
+	eta = Ref{Float64}(0.0); elbo = Ref{Float64}(0.0)
+	tmvb_check(ccall((:tmvb_fctm_get_state, LIBTMVB), Cint,
+		(Ptr{Cvoid}, Ref{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Float64}),
+		model.handle, eta, mu, sg, isg, kappa, kappa_old, beta, beta_old, lam, lam_old, vsq, lz, tau, tau_old, elbo))
+	model.eta, model.mu, model.sigma, model.invsigma = eta[], mu, sg, isg
+	model.kappa, model.kappa_old, model.beta, model.beta_old = kappa, kappa_old, beta, beta_old
+	model.lambda, model.lambda_old, model.vsq, model.logzeta = cols(lam), cols(lam_old), cols(vsq), lz
+	model.tau, model.tau_old = splitdocs(tau, model.N), splitdocs(tau_old, model.N)
+	model.elbo = elbo[]
+end
+
+"update_phi! / update_tau! / update_logzeta! / update_lambda! / update_vsq! sweeps + update_beta!(model, d) + update_kappa!(model, d) (src/fCTM.jl:233-248)."
+update_estep!(model::hipfCTM, niter::Integer, ntol::Real, viter::Integer, vtol::Real) = tmvb_check(ccall((:tmvb_fctm_estep, LIBTMVB), Cint, (Ptr{Cvoid}, Int32, Float64, Int32, Float64), model.handle, niter, ntol, viter, vtol))
+update_doc_sums!(model::hipfCTM) = tmvb_check(ccall((:tmvb_fctm_reduce_docs, LIBTMVB), Cint, (Ptr{Cvoid},), model.handle))
+"update_beta! and update_kappa! (src/fCTM.jl:148, :134)."
+update_beta!(model::hipfCTM) = tmvb_check(ccall((:tmvb_fctm_update_beta, LIBTMVB), Cint, (Ptr{Cvoid},), model.handle))
+update_sigma!(model::hipfCTM) = tmvb_check(ccall((:tmvb_fctm_update_sigma, LIBTMVB), Cint, (Ptr{Cvoid},), model.handle))  # src/fCTM.jl:128 -- before update_mu!
+update_mu!(model::hipfCTM) = tmvb_check(ccall((:tmvb_fctm_update_mu, LIBTMVB), Cint, (Ptr{Cvoid},), model.handle))        # :122
+function update_elbo!(model::hipfCTM)
+	e = Ref{Float64}(0.0)
+	tmvb_check(ccall((:tmvb_fctm_update_elbo, LIBTMVB), Cint, (Ptr{Cvoid}, Ref{Float64}), model.handle, e))
+	model.elbo = e[]
+end
+
+function set_comm!(model::hipfCTM, comm::Union{hipComm, Nothing}, M_total::Integer)
+	tmvb_check(ccall((:tmvb_fctm_set_comm, LIBTMVB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64), model.handle, comm === nothing ? C_NULL : comm.handle, M_total))
+	model.comm = comm
+	nothing
+end
+
+"train!(model::fCTM; ...) (src/fCTM.jl:226-262) on the device; eta stays fixed (update_eta! is commented out, :253)."
+function train!(model::hipfCTM; iter::Integer=150, tol::Real=1.0, niter::Integer=1000, ntol::Real=1/model.K^2, viter::Integer=10, vtol::Real=1/model.K^2, checkelbo::Real=1, printelbo::Bool=true)
+	check_train_args([tol, ntol, vtol], [iter, niter, viter], checkelbo)
+	update_buffer!(model)
+	traj = fill(NaN, max(iter, 1)); done = Ref{Int32}(0); base = Ref{Float64}(model.elbo)
+	tmvb_check(ccall((:tmvb_fctm_train, LIBTMVB), Cint,
+		(Ptr{Cvoid}, Int32, Float64, Int32, Float64, Int32, Float64, Int32, Ptr{Float64}, Ref{Int32}, Ref{Float64}),
+		model.handle, iter, tol, niter, ntol, viter, vtol, checkelbo_arg(checkelbo), traj, done, base))
+	printelbo && print_delbo(traj, done[], base[])
+	(iter > 0) && update_host!(model)
+	model.topics = [reverse(sortperm(vec(model.beta[i,:]))) for i in 1:model.K]
+	nothing
+end
+
+function train!(models::Vector{hipfCTM}; iter::Integer=150, tol::Real=1.0, niter::Integer=1000, ntol::Real=1/models[1].K^2, viter::Integer=10, vtol::Real=1/models[1].K^2, checkelbo::Real=1, printelbo::Bool=true)
+	check_train_args([tol, ntol, vtol], [iter, niter, viter], checkelbo)
+	foreach(update_buffer!, models)
+	hs = Ptr{Cvoid}[m.handle for m in models]
+	traj = fill(NaN, max(iter, 1)); done = Ref{Int32}(0); base = Ref{Float64}(models[1].elbo)
+	tmvb_check(ccall((:tmvb_fctm_train_group, LIBTMVB), Cint,
+		(Ptr{Ptr{Cvoid}}, Int32, Int32, Float64, Int32, Float64, Int32, Float64, Int32, Ptr{Float64}, Ref{Int32}, Ref{Float64}),
+		hs, length(hs), iter, tol, niter, ntol, viter, vtol, checkelbo_arg(checkelbo), traj, done, base))
+	printelbo && print_delbo(traj, done[], base[])
+	for m in models
+		(iter > 0) && update_host!(m)
+		m.topics = [reverse(sortperm(vec(m.beta[i,:]))) for i in 1:m.K]
+	end
+	nothing
+end
+
+"predict (src/modelutils.jl:915-943) on the device; mu / sigma / invsigma / beta / topics from the trained model (:924-928), `tol` for the reference's undefined `vtol` (:937)."
+function predict(corp::Corpus, train_model::hipfCTM; iter::Integer=10, tol::Real=1/train_model.K^2, niter::Integer=1000, ntol::Real=1/train_model.K^2)
+	check_corp(corp)
+	(corp.vocab == train_model.corp.vocab)	|| throw(CorpusError("predict corpus and train_model corpus must have identical vocabularies."))
+	all([tol, ntol] .>= 0)					|| throw(ArgumentError("tolerance parameters must be nonnegative."))
+	all([iter, niter] .>= 0)				|| throw(ArgumentError("iteration parameters must be nonnegative."))
+	host = fCTM(corp, train_model.K)
+	host.mu, host.sigma, host.invsigma = train_model.mu, Symmetric(train_model.sigma), Symmetric(train_model.invsigma)
+	host.beta, host.beta_old, host.topics = train_model.beta, copy(train_model.beta), train_model.topics
+	dev = hipfCTM(host)
+	update_buffer!(dev)
+	update_estep!(dev, niter, ntol, iter, tol)
+	update_host!(dev)
+	host.lambda, host.lambda_old, host.vsq, host.logzeta, host.tau, host.tau_old = dev.lambda, dev.lambda_old, dev.vsq, dev.logzeta, dev.tau, dev.tau_old
+	return host
+end
+
+function topicdist(model::hipfCTM, d::Integer)      # src/modelutils.jl:953-958
+	(d <= length(model.corp)) || throw(CorpusError("document index outside corpus range."))
+	return additive_logistic(model.lambda[d] + 0.5 * model.vsq[d])
+end

@@ -47,9 +47,46 @@ function copyback!(model::CTPF, dev::hipCTPF)
 	nothing
 end
 
+"Last-sweep phi of the first document of a filtered model (src/fLDA.jl:204-207, src/fCTM.jl:230-233)."
+function host_phi1(model::fLDA)
+	model.M == 0 && return Matrix{Float64}[]
+	terms = model.corp[1].terms
+	return [additive_logistic(model.tau_old[1]' .* log.(@boink model.beta_old[:,terms]) .+ model.Elogtheta_old[1], dims=1)]
+end
+
+function host_phi1(model::fCTM)
+	model.M == 0 && return Matrix{Float64}[]
+	terms = model.corp[1].terms
+	return [additive_logistic(model.tau_old[1]' .* log.(@boink model.beta_old[:,terms]) .+ model.lambda_old[1], dims=1)]
+end
+
+function copyback!(model::fLDA, dev::hipfLDA)
+	model.topics, model.eta, model.alpha, model.kappa, model.beta = dev.topics, dev.eta, dev.alpha, dev.kappa, dev.beta
+	model.Elogtheta, model.gamma, model.tau, model.elbo = dev.Elogtheta, dev.gamma, dev.tau, dev.elbo
+	model.phi = host_phi1(model)                                   # from the pre-copy *_old state
+	model.Elogtheta_old, model.tau_old = deepcopy(model.Elogtheta), deepcopy(model.tau)
+	model.beta ./= sum(model.beta, dims=2); model.beta_old = copy(model.beta)          # Float64 re-normalisation as :147-148
+	model.kappa ./= sum(model.kappa); model.kappa_old = copy(model.kappa)
+	nothing
+end
+
+function copyback!(model::fCTM, dev::hipfCTM)
+	model.topics, model.eta, model.mu = dev.topics, dev.eta, dev.mu
+	model.sigma, model.invsigma = Symmetric(dev.sigma), Symmetric(dev.invsigma)
+	model.kappa, model.beta, model.lambda, model.vsq, model.logzeta = dev.kappa, dev.beta, dev.lambda, dev.vsq, dev.logzeta
+	model.tau, model.elbo = dev.tau, dev.elbo
+	model.phi = host_phi1(model)
+	model.lambda_old, model.tau_old = deepcopy(model.lambda), deepcopy(model.tau)
+	model.beta ./= sum(model.beta, dims=2); model.beta_old = copy(model.beta)
+	model.kappa ./= sum(model.kappa); model.kappa_old = copy(model.kappa)
+	nothing
+end
+
 hipmodel(model::LDA) = hipLDA(model)
 hipmodel(model::CTM) = hipCTM(model)
 hipmodel(model::CTPF) = hipCTPF(model)
+hipmodel(model::fLDA) = hipfLDA(model)
+hipmodel(model::fCTM) = hipfCTM(model)
 
 """
     @gpu train!(model; kwargs...)
@@ -63,13 +100,11 @@ macro gpu(expr::Expr)
 		local model = $(esc(expr.args[2]))
 		local kwargs = [(kw.args[1], eval(kw.args[2])) for kw in $(esc(expr.args[3:end]))]
 
-		if isa(model, Union{LDA, CTM, CTPF})
+		if isa(model, Union{LDA, CTM, CTPF, fLDA, fCTM})       # the reference does nothing for fLDA / fCTM (src/macros.jl:274-278)
 			local dev = hipmodel(model)
 			train!(dev; kwargs...)
 			copyback!(model, dev)
 			finalize(dev)                        # release the device state now, not at the next GC
-			nothing
-		elseif isa(model, Union{fLDA, fCTM})      # no accelerated path in the reference either (src/macros.jl:274-278)
 			nothing
 		else
 			train!(model; kwargs...)
