@@ -7,7 +7,7 @@ knows `train` gets the document-sharded run -- the all-reduce of the packed stat
     ncclAllReduce between reduce_docs and update_beta, and the group path of *_train_group;
   * the world-size-2 flow (two processes, both shards on cuda:0) runs through the host transport
     (tmvb_comm_create_host) with gloo carrying the sums: same library loop, same all-reduce call sites, only the
-    transport differs.  LDA K=50, LDA K=100 (config 3 of BASELINE.json, sharded), CTM, CTPF.
+    transport differs.  LDA K=50, LDA K=100 (config 3 of BASELINE.json, sharded), CTM, CTPF, fLDA, fCTM.
 """
 import os
 import sys
@@ -140,6 +140,20 @@ def _worker(rank, world, initfile, out_dir, model, K, iters):
         gm.set_comm(comm, corpus.M)
         traj = gm.train(iter=iters, tol=0.0, checkelbo=1, printelbo=False)
         out = dict(mu=gm.mu, sigma=gm.sigma, beta=gm.beta, lam=gm.lam, base=gm.elbo_baseline)
+    elif model in ("flda", "fctm"):
+        corpus = tm.syn_nsf(M=1500, V=600, seed=14)
+        d0, d1 = corpus.shard_bounds(world)[rank]
+        gm = (tm.gpufLDA if model == "flda" else tm.gpufCTM)(corpus.shard(d0, d1), K, ctx=ctx)
+        gm.beta = np.asfortranarray(tm.dirichlet_rows(K, corpus.V, seed=3)); gm.beta_old = gm.beta.copy(order="F")
+        gm.kappa = tm.dirichlet_rows(1, corpus.V, seed=5)[0].copy(); gm.kappa_old = gm.kappa.copy()
+        gm.update_buffer()
+        if model == "flda":
+            gm.set_comm(comm, corpus.M, int(np.sum(corpus.C)))
+        else:
+            gm.set_comm(comm, corpus.M)
+        traj = gm.train(iter=iters, tol=0.0, checkelbo=1, printelbo=False)
+        out = dict(eta=gm.eta, kappa=gm.kappa, beta=gm.beta, tau=gm.tau, base=gm.elbo_baseline)
+        out.update(dict(alpha=gm.alpha, gamma=gm.gamma) if model == "flda" else dict(mu=gm.mu, sigma=gm.sigma, lam=gm.lam))
     else:
         corpus = tm.syn_citeu(M=900, V=700, U=120, seed=13)
         d0, d1 = corpus.shard_bounds(world)[rank]
@@ -219,6 +233,37 @@ def test_in_library_sharded_ctpf_world2(tmvb):
             np.testing.assert_allclose(r[n], getattr(gm, n), rtol=2e-4)
         g = gm.gimel[:, int(r["d0"]):int(r["d1"])]
         assert np.quantile(np.abs(r["gimel"] - g) / np.abs(g), 0.999) < 5e-3
+
+
+@pytest.mark.parametrize("model", ["flda", "fctm"])
+def test_in_library_sharded_filtered_world2(tmvb, model):
+    """The filtered models shard like their parents; the kappa statistics ride in the same packed all-reduce and fLDA's
+    eta divides by the GLOBAL token count (tmvb_flda_set_comm's C_total)."""
+    K, iters = 10, 4
+    res = _run(model, K, iters)
+    corpus = tmvb.syn_nsf(M=1500, V=600, seed=14)
+    gm = (tmvb.gpufLDA if model == "flda" else tmvb.gpufCTM)(corpus, K)
+    gm.beta = np.asfortranarray(tmvb.dirichlet_rows(K, corpus.V, seed=3)); gm.beta_old = gm.beta.copy(order="F")
+    gm.kappa = tmvb.dirichlet_rows(1, corpus.V, seed=5)[0].copy(); gm.kappa_old = gm.kappa.copy()
+    gm.update_buffer()
+    traj = gm.train(iter=iters, tol=0.0, checkelbo=1, printelbo=False)
+    nnz0 = int(corpus.doc_ptr[int(res[0]["d1"])])
+    for n in ("kappa", "beta", "eta"):
+        assert np.array_equal(res[0][n], res[1][n]), n
+    for r in res:
+        np.testing.assert_allclose(r["traj"], np.array(traj), rtol=1e-5)
+        np.testing.assert_allclose(float(r["eta"]), gm.eta, rtol=1e-5)
+        np.testing.assert_allclose(r["kappa"], gm.kappa, rtol=5e-3, atol=1e-9)
+        big = gm.beta > 1e-6
+        np.testing.assert_allclose(r["beta"][big], gm.beta[big], rtol=5e-3)
+    tau = np.concatenate([res[0]["tau"], res[1]["tau"]])
+    assert len(res[0]["tau"]) == nnz0 and tau.shape == gm.tau.shape
+    assert np.quantile(np.abs(tau - gm.tau), 0.999) < 5e-3
+    if model == "flda":
+        np.testing.assert_allclose(res[0]["alpha"], gm.alpha, rtol=5e-4)
+    else:
+        np.testing.assert_allclose(res[0]["mu"], gm.mu, atol=5e-4)
+        np.testing.assert_allclose(res[0]["sigma"], gm.sigma, atol=1e-3 * max(1.0, np.abs(gm.sigma).max()))
 
 
 def test_ctpf_train_twice_equals_one_run(tmvb):

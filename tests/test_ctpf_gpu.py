@@ -1,7 +1,8 @@
 """
 GPU parity tests for the CTPF path: HIP engine (C ABI) vs the fp64 oracle and the golden fixtures.
 Tolerances (fp64 -> fp32): teacher-forced single step: gimel, zayin rel <= 5e-4; alef, he rel <= 5e-4;
-rates (bet, vav, dalet, het) rel <= 1e-4.  Free running 4 iterations: state rel <= 2e-2 (no ELBO on device).
+rates (bet, vav, dalet, het) rel <= 1e-4.  Free running (measured deviations: profiles/r2_ctpf_free_running_deviations.txt, bounds = 3-5x those):
+  golden K=4/6: ELBO rel <= 5e-6, state rel <= 1e-3;  K=100: ELBO rel <= 1e-5, rates rel <= 2e-3, scores rel <= 3e-4.
 """
 import os
 
@@ -107,9 +108,9 @@ def test_free_running_train_vs_golden(tmvb, name):
     traj = tmvb.gpu_train_ctpf(m, iter=int(g["iters"]), tol=0.0, checkelbo=1, printelbo=False)
     tmvb.check_model_ctpf(m)
     gold = g["elbo_traj"]
-    assert len(traj) == len(gold) and np.all(np.abs(traj - gold) <= 2e-3 * np.abs(gold)), (traj, gold)
+    assert len(traj) == len(gold) and np.all(np.abs(traj - gold) <= 5e-6 * np.abs(gold)), (traj, gold)
     for n in ("alef", "he", "bet", "vav", "dalet", "het", "gimel", "zayin"):
-        assert rel(getattr(m, n), g[n]) <= 2e-2, n
+        assert rel(getattr(m, n), g[n]) <= 1e-3, n
 
 
 def test_k100_train_and_recommend(tmvb, oracle):
@@ -121,11 +122,11 @@ def test_k100_train_and_recommend(tmvb, oracle):
     for it in range(4):
         om.estep(); om.mstep()
     e_o = om.update_elbo()
-    assert abs(traj[-1] - e_o) <= 2e-3 * abs(e_o)
+    assert abs(traj[-1] - e_o) <= 1e-5 * abs(e_o)
     for n in ("bet", "vav", "dalet", "het"):
-        assert rel(getattr(gm, n), getattr(om, n)) <= 2e-2, n
+        assert rel(getattr(gm, n), getattr(om, n)) <= 2e-3, n
     sc = (om.gimel / om.dalet[:, None] + om.zayin / om.het[:, None]).T @ (om.he / om.vav[:, None])
-    assert np.abs(gm.scores - sc).max() <= 2e-2 * np.abs(sc).max()
+    assert np.abs(gm.scores - sc).max() <= 3e-4 * np.abs(sc).max()
     assert len(gm.drecs) == gm.M and len(gm.urecs) == gm.U
 
 

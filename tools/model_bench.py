@@ -3,7 +3,8 @@
 config 3 LDA K=100 on SYN-NSF (one GPU's view), config 4 CTM K=50 on SYN-NSF, config 5 CTPF K=50 on SYN-CITEU.
 One JSON line per configuration with the same roofline vocabulary as bench.py (algorithmic bytes of SURVEY.md
 section 8d / DESIGN.md section 3; CTM additionally the flop count of its Newton solves against the fp32 peak).
-Usage: python tools/model_bench.py [lda100] [ctm] [ctpf]   (default: all)"""
+and the filtered models fLDA / fCTM K=50 on SYN-NSF.
+Usage: python tools/model_bench.py [lda100] [ctm] [ctpf] [flda] [fctm]   (default: all)"""
 import json
 import os
 import sys
@@ -125,7 +126,70 @@ def ctpf():
             "recommend": {"ms_scores": ms_s, "ms_rank": ms_r, "pairs": pc.M * pc.U}}
 
 
+def cpu_line_1t(kind, make, step, frac, sample_note):
+    """Single-thread cpu_baseline (the filtered-model oracles have no OpenMP E-step)."""
+    m = make()
+    t0 = time.perf_counter(); step(m); one = 1.0 / (time.perf_counter() - t0)
+    return {"value": one * frac, "unit": "VB iters/sec", "cores": 1, "kind": "port",
+            "sample": f"fp64 C oracle ({kind}), {sample_note}; 1 single-thread iteration; value = sample iters/s x work fraction {frac:.4f}"}
+
+
+def flda():
+    K = 50
+    pc = tm.syn_nsf()
+    gm = tm.gpufLDA(pc, K)
+    gm.beta = np.asfortranarray(tm.dirichlet_rows(K, pc.V, seed=7)); gm.beta_old = gm.beta.copy(order="F")
+    gm.kappa = tm.dirichlet_rows(1, pc.V, seed=9)[0].copy(); gm.kappa_old = gm.kappa.copy(); gm.update_buffer()
+    def it():
+        gm.estep(10, 1.0 / K ** 2); gm.reduce_docs(); gm.update_beta(); gm.update_alpha(1000, 1.0 / K ** 2); gm.update_eta()
+    sec = timed(it, 20, 3, gm.synchronize)
+    es = gm.last_estep_ms()
+    # LDA's bytes + tau / tau_old / lse (read + write per token entry) + the kappa statistics
+    B = pc.nnz * (8 + 8 * K + 24) + 12 * pc.M * K + 12 * K * pc.V + 8 * pc.V + 4 * (pc.M + 1)
+    from oracle import oracle as oc
+    sh = pc.shard(0, 4000)
+    beta0 = tm.dirichlet_rows(K, pc.V, seed=7); kappa0 = tm.dirichlet_rows(1, pc.V, seed=9)[0]
+    def ostep(m):
+        m.estep(); m.mstep()
+    cpu = cpu_line_1t("port of src/fLDA.jl train!", lambda: oc.fLDA(oc.CSR(sh.doc_ptr, sh.terms, sh.counts, sh.V), K, beta0, kappa0), ostep,
+                      sh.nnz / pc.nnz, f"first {sh.M} documents of SYN-NSF ({sh.nnz} of {pc.nnz} nnz), K=50, cold start")
+    return {"cpu_baseline": cpu, "metric": "VB iters/sec, fLDA K=50 on NSF-shaped corpus (section 8 row f4)", "value": 1.0 / sec, "unit": "VB iters/sec",
+            "ms_per_step": 1e3 * sec, "estep_ms": es, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "fLDA K=50, SYN-NSF, train! defaults, cold start, 3 warm-up + 20 timed iterations", "M": pc.M, "V": pc.V, "nnz": pc.nnz},
+            "roofline": {"bound": "hbm", "achieved": B / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": B / sec / 1e9 / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_iteration": B, "traffic": None}}
+
+
+def fctm():
+    K = 50
+    pc = tm.syn_nsf()
+    gm = tm.gpufCTM(pc, K)
+    gm.beta = np.asfortranarray(tm.dirichlet_rows(K, pc.V, seed=7)); gm.beta_old = gm.beta.copy(order="F")
+    gm.kappa = tm.dirichlet_rows(1, pc.V, seed=9)[0].copy(); gm.kappa_old = gm.kappa.copy(); gm.update_buffer()
+    def it():
+        gm.estep(); gm.reduce_docs(); gm.mstep()
+    sec = timed(it, 6, 2, gm.synchronize)
+    hist, newton = gm.sweep_hist()
+    sweeps = int(sum(i * int(h) for i, h in enumerate(hist)))
+    B = pc.nnz * (8 + 8 * K + 24) + 16 * pc.M * K + 8 * pc.M + 12 * K * pc.V + 8 * pc.V + 8 * K * K
+    F = newton * (K ** 3 / 3.0 + 4 * K * K) + 8.0 * K * pc.nnz * (sweeps / pc.M)
+    from oracle import oracle as oc
+    sh = pc.shard(0, 400)
+    beta0 = tm.dirichlet_rows(K, pc.V, seed=7); kappa0 = tm.dirichlet_rows(1, pc.V, seed=9)[0]
+    def ostep(m):
+        m.estep(); m.mstep()
+    cpu = cpu_line_1t("port of src/fCTM.jl train!", lambda: oc.fCTM(oc.CSR(sh.doc_ptr, sh.terms, sh.counts, sh.V), K, beta0, kappa0), ostep,
+                      sh.M / pc.M, f"first {sh.M} documents of SYN-NSF (the Newton solves scale with the document count), K=50, cold start")
+    return {"cpu_baseline": cpu, "metric": "VB iters/sec, fCTM K=50 on NSF-shaped corpus (section 8 row f4)", "value": 1.0 / sec, "unit": "VB iters/sec",
+            "ms_per_step": 1e3 * sec, "dtype": "f32 (fp64 gradients / logzeta / vsq)", "data": "synthetic",
+            "config": {"workload": "fCTM K=50, SYN-NSF, train! defaults, cold start, 2 warm-up + 6 timed iterations",
+                       "M": pc.M, "V": pc.V, "nnz": pc.nnz, "lambda_newton_steps_last_iteration": int(newton), "sweeps_last_iteration": sweeps},
+            "roofline": {"bound": "valu (register Gauss-Jordan)", "achieved": F / sec / 1e12, "peak": F32_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": F / sec / 1e12 / F32_PEAK_TFLOPS, "flops_per_iteration": F,
+                         "hbm_GBs": B / sec / 1e9, "hbm_frac": B / sec / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_iteration": B, "traffic": None}}
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["lda100", "ctm", "ctpf"]
+    which = sys.argv[1:] or ["lda100", "ctm", "ctpf", "flda", "fctm"]
     for w in which:
-        print(json.dumps({"lda100": lda100, "ctm": ctm, "ctpf": ctpf}[w]()), flush=True)
+        print(json.dumps({"lda100": lda100, "ctm": ctm, "ctpf": ctpf, "flda": flda, "fctm": fctm}[w]()), flush=True)
