@@ -1,0 +1,41 @@
+#!/usr/bin/env python
+"""Scan gfx950 assembly (hipcc -save-temps .s) for reads of SGPRs that are the destination of a scalar load still in
+flight (between the s_load and the next s_waitcnt lgkmcnt(0)).  The batched CTM kernel streams invsigma through SGPRs with
+hand-placed loads and waits (csrc/tmvb_ctm_batch.h); a compiler-inserted copy of an in-flight group would read garbage.
+Usage: check_smem_inflight.py file.s [kernel-name-substring]    exit code 1 when a hazard is found."""
+import re
+import sys
+
+
+def main():
+    path = sys.argv[1]
+    want = sys.argv[2] if len(sys.argv) > 2 else None
+    inflight, bad, kern, on = set(), 0, None, want is None
+    for ln, line in enumerate(open(path), 1):
+        t = line.strip()
+        if t.endswith(":") and not t.startswith(".") and not t.startswith(";"):
+            kern = t[:-1]; on = want is None or want in kern; inflight = set()
+        if not on or not t or t.startswith(";") or t.startswith("."):
+            continue
+        if "s_waitcnt" in t and ("lgkmcnt(0)" in t or re.search(r"s_waitcnt\s+0x?0*\b", t)):
+            inflight = set(); continue
+        m = re.match(r"s_(?:buffer_)?load_dword(?:x\d+)?\s+s\[?(\d+)(?::(\d+))?\]?", t)
+        if m:
+            a = int(m.group(1)); b = int(m.group(2)) if m.group(2) else a
+            inflight |= set(range(a, b + 1)); continue
+        if inflight:
+            regs = set()
+            for mm in re.finditer(r"s\[(\d+):(\d+)\]", t):
+                regs |= set(range(int(mm.group(1)), int(mm.group(2)) + 1))
+            for mm in re.finditer(r"\bs(\d+)\b", t):
+                regs.add(int(mm.group(1)))
+            if regs & inflight:
+                bad += 1
+                if bad <= 10:
+                    print(f"{path}:{ln}: [{kern}] reads in-flight SGPR(s) {sorted(regs & inflight)[:4]}: {t[:90]}")
+    print(f"{bad} in-flight SGPR reads")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -436,6 +436,20 @@ __global__ __launch_bounds__(64) void ctm_estep_kernel(CtmParams p, int64_t firs
     }
 }
 
+#include "tmvb_ctm_batch.h"
+
+// padded fp64 copies of the tables the batched kernel streams through SGPRs (fp32-rounded invsigma, so that the fp64
+// gradient and the fp32 Newton matrix describe the same matrix, as in ctm_estep_kernel)
+__global__ __launch_bounds__(256) void ctm_batch_tabs_kernel(int K, int KP, const float* __restrict__ invsigma_f, const float* __restrict__ mu_f,
+                                                             double* __restrict__ Sd, double* __restrict__ sdiag, double* __restrict__ mud)
+{
+    for (int q = threadIdx.x; q < KP * KP; q += blockDim.x) Sd[q] = (double)invsigma_f[q];
+    for (int i = threadIdx.x; i < KP + 8; i += blockDim.x) {
+        sdiag[i] = (i < KP) ? (double)invsigma_f[i * KP + i] : 0.0;
+        mud[i] = (i < K) ? (double)mu_f[i] : 0.0;
+    }
+}
+
 // ------------------------------------------------------------------------------ E-step kernel, any K <= 128
 // The register Gauss-Jordan above needs one lane per matrix row and KP VGPRs per row (K <= 60).  Larger models keep
 // the Newton matrix in LDS instead: lane l owns the topics / matrix rows l and l + 64 (NS = 2 slots), the K x K matrix
@@ -997,6 +1011,9 @@ struct tmvb_ctm {
     float* d_lambda = nullptr; float* d_lambda_old = nullptr; float* d_vsq = nullptr; float* d_logzeta = nullptr;
     float* d_wtok = nullptr; float* d_E = nullptr; float* d_ts_partial = nullptr;
     float* d_invsigma_f = nullptr; float* d_mu_f = nullptr;
+    bool batch = false;                // lane-per-document kernel (tmvb_ctm_batch.h), KP <= 52
+    double* d_bt_Sd = nullptr; double* d_bt_sdiag = nullptr; double* d_bt_mud = nullptr; unsigned long long* d_cg_iters = nullptr;
+    float cg_tol = 1e-5f;
     double* d_sigma = nullptr; double* d_invsigma = nullptr; double* d_mu = nullptr; double* d_logdet = nullptr;
     float* d_scatter_partial = nullptr; int n_scatter_waves = 0; int64_t docs_per_wave = 0;
     uint8_t* d_sweeps = nullptr; int32_t* d_doc_order = nullptr;
@@ -1023,6 +1040,7 @@ extern "C" int tmvb_ctm_destroy(tmvb_ctm* h)
     if (h->own_stats) (void)hipFree(h->d_stats);
     (void)hipFree(h->d_lambda); (void)hipFree(h->d_lambda_old); (void)hipFree(h->d_vsq); (void)hipFree(h->d_logzeta);
     (void)hipFree(h->d_wtok); (void)hipFree(h->d_E); (void)hipFree(h->d_ts_partial); (void)hipFree(h->d_invsigma_f);
+    (void)hipFree(h->d_bt_Sd); (void)hipFree(h->d_bt_sdiag); (void)hipFree(h->d_bt_mud); (void)hipFree(h->d_cg_iters);
     (void)hipFree(h->d_mu_f); (void)hipFree(h->d_sigma); (void)hipFree(h->d_invsigma); (void)hipFree(h->d_mu);
     (void)hipFree(h->d_logdet); (void)hipFree(h->d_scatter_partial); (void)hipFree(h->d_sweeps); (void)hipFree(h->d_doc_order);
     (void)hipFree(h->d_partial); (void)hipFree(h->d_rowsum); (void)hipFree(h->d_doc_val); (void)hipFree(h->d_elbo);
@@ -1095,6 +1113,15 @@ extern "C" int tmvb_ctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
         (rc = dmalloc(&h->d_doc_val, (size_t)h->M)) || (rc = dmalloc(&h->d_elbo, 1)) || (rc = dmalloc(&h->d_newton, 1)) ||
         (rc = dmalloc(&h->d_status, 1))) {
         return rc;
+    }
+    {
+        // lane-per-document kernel: the default for KP <= 52 (K <= 50); TMVB_CTM_BATCH=0 selects the wave-per-document kernels
+        const char* e = getenv("TMVB_CTM_BATCH");
+        h->batch = !h->generic && h->KP <= 52 && !(e && atoi(e) == 0);
+        if (const char* t = getenv("TMVB_CTM_CG_TOL")) h->cg_tol = std::max(1e-7f, (float)atof(t));
+        if ((rc = dmalloc(&h->d_bt_Sd, (size_t)h->KP * h->KP + 8)) || (rc = dmalloc(&h->d_bt_sdiag, (size_t)h->KP + 8)) ||
+            (rc = dmalloc(&h->d_bt_mud, (size_t)h->KP + 8)) || (rc = dmalloc(&h->d_cg_iters, 1)))
+            return rc;
     }
     std::vector<int32_t> order((size_t)h->M);
     std::iota(order.begin(), order.end(), 0);
@@ -1256,7 +1283,23 @@ extern "C" int tmvb_ctm_estep(tmvb_ctm* h, int32_t niter, double ntol, int32_t v
         if (lrc) return lrc;
         TMVB_HIP(hipGetLastError());
     }
-    const int nb = h->generic ? 0 : (int)h->buckets.size();
+    if (h->batch && h->M > 0) {
+        hipLaunchKernelGGL(ctm_batch_tabs_kernel, dim3(1), dim3(256), 0, ctx->stream, h->K, h->KP, h->d_invsigma_f, h->d_mu_f, h->d_bt_Sd,
+                           h->d_bt_sdiag, h->d_bt_mud);
+        TMVB_HIP(hipGetLastError());
+        TMVB_HIP(hipMemsetAsync(h->d_cg_iters, 0, sizeof(unsigned long long), ctx->stream));
+        CtmBatchTabs tb;
+        tb.S = h->d_invsigma_f; tb.Sd = h->d_bt_Sd; tb.sdiag = h->d_bt_sdiag; tb.mud = h->d_bt_mud;
+        tb.cg_tol2 = h->cg_tol * h->cg_tol; tb.cg_maxit = 4 * h->KP; tb.cg_iters = h->d_cg_iters;
+        const dim3 grid((unsigned)((h->M + 63) / 64)), block(64);
+        const size_t lds = (size_t)h->KP * 64 * (sizeof(double) + sizeof(float));
+#define CTM_BCASE(KPV) case KPV: hipLaunchKernelGGL((ctm_estep_batch_kernel<KPV>), grid, block, lds, ctx->stream, p, tb, (int64_t)h->M); break;
+        switch (h->KP) { CTM_BCASE(4) CTM_BCASE(12) CTM_BCASE(20) CTM_BCASE(28) CTM_BCASE(36) CTM_BCASE(44)
+                         default: hipLaunchKernelGGL((ctm_estep_batch_kernel<52>), grid, block, lds, ctx->stream, p, tb, (int64_t)h->M); break; }
+#undef CTM_BCASE
+        TMVB_HIP(hipGetLastError());
+    }
+    const int nb = (h->generic || h->batch) ? 0 : (int)h->buckets.size();
     const int naux = std::min(nb, (int)tmvb_ctm::NAUX);
     if (naux > 1) {
         TMVB_HIP(hipEventRecord(h->ev_fork, ctx->stream));
