@@ -13,8 +13,9 @@ def main():
     inflight, bad, kern, on = set(), 0, None, want is None
     for ln, line in enumerate(open(path), 1):
         t = line.strip()
-        if t.endswith(":") and not t.startswith(".") and not t.startswith(";"):
-            kern = t[:-1]; on = want is None or want in kern; inflight = set()
+        lab = re.match(r"^([A-Za-z_][\w$.]*):", t)
+        if lab and not t.startswith("."):
+            kern = lab.group(1); on = want is None or want in kern; inflight = set()
         if not on or not t or t.startswith(";") or t.startswith("."):
             continue
         if "s_waitcnt" in t and ("lgkmcnt(0)" in t or re.search(r"s_waitcnt\s+0x?0*\b", t)):

@@ -438,16 +438,13 @@ __global__ __launch_bounds__(64) void ctm_estep_kernel(CtmParams p, int64_t firs
 
 #include "tmvb_ctm_batch.h"
 
-// padded fp64 copies of the tables the batched kernel streams through SGPRs (fp32-rounded invsigma, so that the fp64
-// gradient and the fp32 Newton matrix describe the same matrix, as in ctm_estep_kernel)
-__global__ __launch_bounds__(256) void ctm_batch_tabs_kernel(int K, int KP, const float* __restrict__ invsigma_f, const float* __restrict__ mu_f,
-                                                             double* __restrict__ Sd, double* __restrict__ sdiag, double* __restrict__ mud)
+// 64-float padded copies of mu and of invsigma's diagonal for the batched kernel's block scalar loads
+__global__ __launch_bounds__(64) void ctm_batch_tabs_kernel(int K, int KP, const float* __restrict__ invsigma_f, const float* __restrict__ mu_f,
+                                                            float* __restrict__ sdiag, float* __restrict__ muf)
 {
-    for (int q = threadIdx.x; q < KP * KP; q += blockDim.x) Sd[q] = (double)invsigma_f[q];
-    for (int i = threadIdx.x; i < KP + 8; i += blockDim.x) {
-        sdiag[i] = (i < KP) ? (double)invsigma_f[i * KP + i] : 0.0;
-        mud[i] = (i < K) ? (double)mu_f[i] : 0.0;
-    }
+    const int i = threadIdx.x;
+    sdiag[i] = (i < KP) ? invsigma_f[i * KP + i] : 0.0f;
+    muf[i] = (i < K) ? mu_f[i] : 0.0f;
 }
 
 // ------------------------------------------------------------------------------ E-step kernel, any K <= 128
@@ -1012,7 +1009,7 @@ struct tmvb_ctm {
     float* d_wtok = nullptr; float* d_E = nullptr; float* d_ts_partial = nullptr;
     float* d_invsigma_f = nullptr; float* d_mu_f = nullptr;
     bool batch = false;                // lane-per-document kernel (tmvb_ctm_batch.h), KP <= 52
-    double* d_bt_Sd = nullptr; double* d_bt_sdiag = nullptr; double* d_bt_mud = nullptr; unsigned long long* d_cg_iters = nullptr;
+    float* d_bt_sdiag = nullptr; float* d_bt_muf = nullptr; unsigned long long* d_cg_iters = nullptr;
     float cg_tol = 1e-5f;
     double* d_sigma = nullptr; double* d_invsigma = nullptr; double* d_mu = nullptr; double* d_logdet = nullptr;
     float* d_scatter_partial = nullptr; int n_scatter_waves = 0; int64_t docs_per_wave = 0;
@@ -1040,7 +1037,7 @@ extern "C" int tmvb_ctm_destroy(tmvb_ctm* h)
     if (h->own_stats) (void)hipFree(h->d_stats);
     (void)hipFree(h->d_lambda); (void)hipFree(h->d_lambda_old); (void)hipFree(h->d_vsq); (void)hipFree(h->d_logzeta);
     (void)hipFree(h->d_wtok); (void)hipFree(h->d_E); (void)hipFree(h->d_ts_partial); (void)hipFree(h->d_invsigma_f);
-    (void)hipFree(h->d_bt_Sd); (void)hipFree(h->d_bt_sdiag); (void)hipFree(h->d_bt_mud); (void)hipFree(h->d_cg_iters);
+    (void)hipFree(h->d_bt_sdiag); (void)hipFree(h->d_bt_muf); (void)hipFree(h->d_cg_iters);
     (void)hipFree(h->d_mu_f); (void)hipFree(h->d_sigma); (void)hipFree(h->d_invsigma); (void)hipFree(h->d_mu);
     (void)hipFree(h->d_logdet); (void)hipFree(h->d_scatter_partial); (void)hipFree(h->d_sweeps); (void)hipFree(h->d_doc_order);
     (void)hipFree(h->d_partial); (void)hipFree(h->d_rowsum); (void)hipFree(h->d_doc_val); (void)hipFree(h->d_elbo);
@@ -1105,7 +1102,7 @@ extern "C" int tmvb_ctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
         (rc = dmalloc(&h->d_logzeta, (size_t)h->M)) || (rc = dmalloc(&h->d_wtok, (size_t)corp->info.nnz)) ||
         (rc = dmalloc(&h->d_E, (size_t)h->KP * h->M + 4)) || (rc = tmvb_corpus_term_index(corp)) ||
         (rc = dmalloc(&h->d_ts_partial, (size_t)corp->term_index.n_slots * (K + 1))) ||
-        (rc = dmalloc(&h->d_invsigma_f, (size_t)h->KP * h->KP)) || (rc = dmalloc(&h->d_mu_f, K)) ||
+        (rc = dmalloc(&h->d_invsigma_f, (size_t)h->KP * h->KP + 64)) || (rc = dmalloc(&h->d_mu_f, K)) ||
         (rc = dmalloc(&h->d_sigma, (size_t)K * K)) || (rc = dmalloc(&h->d_invsigma, (size_t)K * K)) || (rc = dmalloc(&h->d_mu, K)) ||
         (rc = dmalloc(&h->d_logdet, 1)) || (rc = dmalloc(&h->d_scatter_partial, (size_t)h->n_scatter_waves * h->NB * h->NB * 1024)) ||
         (rc = dmalloc(&h->d_sweeps, (size_t)h->M)) || (rc = dmalloc(&h->d_doc_order, (size_t)h->M)) ||
@@ -1119,8 +1116,7 @@ extern "C" int tmvb_ctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
         const char* e = getenv("TMVB_CTM_BATCH");
         h->batch = !h->generic && h->KP <= 52 && !(e && atoi(e) == 0);
         if (const char* t = getenv("TMVB_CTM_CG_TOL")) h->cg_tol = std::max(1e-7f, (float)atof(t));
-        if ((rc = dmalloc(&h->d_bt_Sd, (size_t)h->KP * h->KP + 8)) || (rc = dmalloc(&h->d_bt_sdiag, (size_t)h->KP + 8)) ||
-            (rc = dmalloc(&h->d_bt_mud, (size_t)h->KP + 8)) || (rc = dmalloc(&h->d_cg_iters, 1)))
+        if ((rc = dmalloc(&h->d_bt_sdiag, 64)) || (rc = dmalloc(&h->d_bt_muf, 64)) || (rc = dmalloc(&h->d_cg_iters, 16)))
             return rc;
     }
     std::vector<int32_t> order((size_t)h->M);
@@ -1284,18 +1280,19 @@ extern "C" int tmvb_ctm_estep(tmvb_ctm* h, int32_t niter, double ntol, int32_t v
         TMVB_HIP(hipGetLastError());
     }
     if (h->batch && h->M > 0) {
-        hipLaunchKernelGGL(ctm_batch_tabs_kernel, dim3(1), dim3(256), 0, ctx->stream, h->K, h->KP, h->d_invsigma_f, h->d_mu_f, h->d_bt_Sd,
-                           h->d_bt_sdiag, h->d_bt_mud);
+        hipLaunchKernelGGL(ctm_batch_tabs_kernel, dim3(1), dim3(64), 0, ctx->stream, h->K, h->KP, h->d_invsigma_f, h->d_mu_f, h->d_bt_sdiag, h->d_bt_muf);
         TMVB_HIP(hipGetLastError());
-        TMVB_HIP(hipMemsetAsync(h->d_cg_iters, 0, sizeof(unsigned long long), ctx->stream));
+        TMVB_HIP(hipMemsetAsync(h->d_cg_iters, 0, 16 * sizeof(unsigned long long), ctx->stream));
         CtmBatchTabs tb;
-        tb.S = h->d_invsigma_f; tb.Sd = h->d_bt_Sd; tb.sdiag = h->d_bt_sdiag; tb.mud = h->d_bt_mud;
+        tb.S = h->d_invsigma_f; tb.sdiag = h->d_bt_sdiag; tb.muf = h->d_bt_muf;
         tb.cg_tol2 = h->cg_tol * h->cg_tol; tb.cg_maxit = 4 * h->KP; tb.cg_iters = h->d_cg_iters;
         const dim3 grid((unsigned)((h->M + 63) / 64)), block(64);
         const size_t lds = (size_t)h->KP * 64 * (sizeof(double) + sizeof(float));
-#define CTM_BCASE(KPV) case KPV: hipLaunchKernelGGL((ctm_estep_batch_kernel<KPV>), grid, block, lds, ctx->stream, p, tb, (int64_t)h->M); break;
+        CtmBatchArgs ba;
+        ba.p = p; ba.tb = tb; ba.M = (int64_t)h->M;
+#define CTM_BCASE(KPV) case KPV: hipLaunchKernelGGL((ctm_estep_batch_kernel<KPV>), grid, block, lds, ctx->stream, ba); break;
         switch (h->KP) { CTM_BCASE(4) CTM_BCASE(12) CTM_BCASE(20) CTM_BCASE(28) CTM_BCASE(36) CTM_BCASE(44)
-                         default: hipLaunchKernelGGL((ctm_estep_batch_kernel<52>), grid, block, lds, ctx->stream, p, tb, (int64_t)h->M); break; }
+                         default: hipLaunchKernelGGL((ctm_estep_batch_kernel<52>), grid, block, lds, ctx->stream, ba); break; }
 #undef CTM_BCASE
         TMVB_HIP(hipGetLastError());
     }
@@ -1515,6 +1512,22 @@ extern "C" int tmvb_ctm_train(tmvb_ctm* h, int32_t iter, double tol, int32_t nit
 
 // per-document sweep counts of the last E-step (document order of the corpus), for parity tests that compare the
 // state of exactly those documents whose exit sweep agrees with the oracle's
+// Diagnostics of the last E-step of the lane-per-document kernel: out[0] CG trips, [1] Newton trips, [2] waves (all summed
+// over waves), [3..7] shader cycles in the token / logzeta / vsq / gradient / CG phases, [8] whole-kernel cycles (summed
+// over waves).  All zero when the wave-per-document kernels ran.
+extern "C" int tmvb_ctm_solver_stats(tmvb_ctm* h, int64_t* out9)
+{
+    TMVB_REQUIRE(h != nullptr && out9 != nullptr, TMVB_EINVAL, "tmvb_ctm_solver_stats: NULL argument");
+    TMVB_HIP(hipSetDevice(h->ctx->device));
+    unsigned long long v[9] = {0};
+    if (h->batch) {
+        TMVB_HIP(hipMemcpyAsync(v, h->d_cg_iters, sizeof(v), hipMemcpyDeviceToHost, h->ctx->stream));
+        TMVB_HIP(hipStreamSynchronize(h->ctx->stream));
+    }
+    for (int q = 0; q < 9; ++q) out9[q] = (int64_t)v[q];
+    return TMVB_OK;
+}
+
 extern "C" int tmvb_ctm_doc_sweeps(tmvb_ctm* h, uint8_t* out)
 {
     TMVB_REQUIRE(h && (out || h->M == 0), TMVB_EINVAL, "tmvb_ctm_doc_sweeps: NULL argument");

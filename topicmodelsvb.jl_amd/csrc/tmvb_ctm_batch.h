@@ -23,16 +23,16 @@
 
 typedef float cb_v2f __attribute__((ext_vector_type(2)));
 typedef float cb_v16f __attribute__((ext_vector_type(16)));
-typedef double cb_v8d __attribute__((ext_vector_type(8)));
+typedef float cb_v4f __attribute__((ext_vector_type(4)));
 
 struct CtmBatchTabs {
     const float* S = nullptr;        // [R * R] fp32 invsigma (pads 0), + 64 B readable slack
-    const double* Sd = nullptr;      // [R * R] the same values as doubles, + 64 B slack
-    const double* sdiag = nullptr;   // [R] diagonal of S as doubles (pads 0)
-    const double* mud = nullptr;     // [R] mu as doubles (pads 0)
+    const float* sdiag = nullptr;    // [64] diagonal of S (pads 0)
+    const float* muf = nullptr;      // [64] mu (pads 0)
     float cg_tol2 = 1e-10f;          // squared relative residual at which a lane's CG stops
     int cg_maxit = 200;
-    unsigned long long* cg_iters = nullptr;   // diagnostics: total CG iterations (wave trips x 64)
+    unsigned long long* cg_iters = nullptr;   // diagnostics: [0] CG trips summed over waves, [1] Newton trips summed over waves, [2] waves,
+                                              // [3..8] shader cycles per phase summed over waves: token, logzeta, vsq, gradient, CG, whole kernel
 };
 
 template <typename F, int... I>
@@ -128,53 +128,95 @@ __device__ __forceinline__ void cb_matvec_f32(const float* S, const cb_v2f (&p)[
     cb_pipe_f32<R, 0, NG>(a, b, S, p, y);
 }
 
-// mv[i] += Sd[j][i] dm[j] in fp64 (the Newton gradient's invsigma (mu - lambda), src/CTM.jl:134)
-template <int R, int GI>
-__device__ __forceinline__ void cb_consume_f64(const CbGroup& g, const double (&dm)[R], double (&mv)[R])
+// exp(a) in fp64, ~1e-14 relative: n = rint(a / ln 2), degree-11 Taylor polynomial on |r| <= ln 2 / 2, ldexp.  19 instructions
+// (the library exp is ~3x that, and the kernel has 3 x K inlined call sites).
+__device__ __forceinline__ double cb_exp(double a)
 {
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const cb_v8d blk = __builtin_bit_cast(cb_v8d, g.b[k]);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int f = (2 * GI + k) * 8 + e;
-            if (f < R * R) {
-                const int j = f / R, i = f % R;
-                asm volatile("v_fmac_f64 %0, %1, %2" : "+v"(mv[i]) : "s"(blk[e]), "v"(dm[j]));
-            }
-        }
-    }
+    a = fmax(a, -745.0);
+    const double n = __builtin_rint(a * 1.4426950408889634074);
+    double r = fma(n, -6.93147180369123816490e-01, a);
+    r = fma(n, -1.90821492927058770002e-10, r);
+    double q = 2.50521083854417187751e-08;                 // 1 / 11!
+    q = fma(q, r, 2.75573192239858906526e-07);             // 1 / 10!
+    q = fma(q, r, 2.75573192239858906526e-06);
+    q = fma(q, r, 2.48015873015873015873e-05);
+    q = fma(q, r, 1.98412698412698412698e-04);
+    q = fma(q, r, 1.38888888888888888889e-03);
+    q = fma(q, r, 8.33333333333333333333e-03);
+    q = fma(q, r, 4.16666666666666666667e-02);
+    q = fma(q, r, 1.66666666666666666667e-01);
+    q = fma(q, r, 0.5);
+    q = fma(q, r, 1.0);
+    q = fma(q, r, 1.0);
+    return __builtin_ldexp(q, (int)n);
 }
-template <int R, int GI, int NG>
-__device__ __forceinline__ void cb_pipe_f64(CbGroup& cur, CbGroup& nxt, const double* Sd, const double (&dm)[R], double (&mv)[R])
+// the same on N independent arguments, stage by stage: N-fold instruction-level parallelism for the single resident wave
+template <int N>
+__device__ __forceinline__ void cb_exp_n(double (&a)[N])
 {
-    constexpr int NB = (R * R + 7) / 8;
-    if constexpr (GI < NG) {
-        if constexpr (GI + 1 < NG) cb_issue<NB, GI + 1>(nxt, Sd);
-        cb_consume_f64<R, GI>(cur, dm, mv);
-        if constexpr (GI + 1 < NG) cb_wait();
-        cb_pipe_f64<R, GI + 1, NG>(nxt, cur, Sd, dm, mv);
-    }
-}
-template <int R>
-__device__ __forceinline__ void cb_matvec_f64(const double* Sd, const double (&dm)[R], double (&mv)[R])
-{
-    constexpr int NB = (R * R + 7) / 8, NG = (NB + 1) / 2;
+    double n[N], q[N];
 #pragma unroll
-    for (int i = 0; i < R; ++i) mv[i] = 0.0;
-    CbGroup a, b;
-    cb_issue<NB, 0>(a, Sd);
-    cb_wait();
-    cb_pipe_f64<R, 0, NG>(a, b, Sd, dm, mv);
+    for (int u = 0; u < N; ++u) { a[u] = fmax(a[u], -745.0); n[u] = __builtin_rint(a[u] * 1.4426950408889634074); }
+#pragma unroll
+    for (int u = 0; u < N; ++u) a[u] = fma(n[u], -6.93147180369123816490e-01, a[u]);
+#pragma unroll
+    for (int u = 0; u < N; ++u) { a[u] = fma(n[u], -1.90821492927058770002e-10, a[u]); q[u] = fma(2.50521083854417187751e-08, a[u], 2.75573192239858906526e-07); }
+    const double c[9] = {2.75573192239858906526e-06, 2.48015873015873015873e-05, 1.98412698412698412698e-04, 1.38888888888888888889e-03,
+                         8.33333333333333333333e-03, 4.16666666666666666667e-02, 1.66666666666666666667e-01, 0.5, 1.0};
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+#pragma unroll
+        for (int u = 0; u < N; ++u) q[u] = fma(q[u], a[u], c[k]);
+    }
+#pragma unroll
+    for (int u = 0; u < N; ++u) a[u] = __builtin_ldexp(fma(q[u], a[u], 1.0), (int)n[u]);
+}
+template <int N>
+__device__ __forceinline__ void cb_rcp_n(const double (&a)[N], double (&y)[N])
+{
+#pragma unroll
+    for (int u = 0; u < N; ++u) y[u] = __builtin_amdgcn_rcp(a[u]);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        double e[N];
+#pragma unroll
+        for (int u = 0; u < N; ++u) e[u] = fma(-a[u], y[u], 1.0);
+#pragma unroll
+        for (int u = 0; u < N; ++u) y[u] = fma(e[u], y[u], y[u]);
+    }
 }
 
-// a uniform double table entry as an SGPR pair (one s_load per use: a C++ load would be hoisted and spilled)
-template <int I>
-__device__ __forceinline__ double cb_sdouble(const double* tab)
+// 1 / a in fp64 for a > 0: v_rcp_f64 seed and two Newton refinements
+__device__ __forceinline__ double cb_rcp(double a)
 {
-    double v;
-    asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(tab), "n"(I * 8));
+    double y = __builtin_amdgcn_rcp(a);
+    y = fma(fma(-a, y, 1.0), y, y);
+    y = fma(fma(-a, y, 1.0), y, y);
+    return y;
+}
+
+// Small uniform tables (mu, the diagonal of S) as SGPRs: load and wait in ONE asm statement.  Their consumers are ordinary
+// compiler-generated instructions, which -- unlike the volatile asm FMAs of the mat-vecs -- the scheduler is free to move
+// above a separate wait statement (it did: v_cvt_f64_f32 of an SGPR right behind its s_load).
+template <int OFF>
+__device__ __forceinline__ cb_v4f cb_sload4_sync(const float* tab)
+{
+    cb_v4f v;
+    asm volatile("s_load_dwordx4 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(tab), "n"(OFF * 4));
     return v;
+}
+template <int NBLK>
+__device__ __forceinline__ void cb_sload64_sync(const float* tab, cb_v16f (&b)[4])
+{
+    if constexpr (NBLK == 1) asm volatile("s_load_dwordx16 %0, %1, 0\n\ts_waitcnt lgkmcnt(0)" : "=s"(b[0]) : "s"(tab));
+    else if constexpr (NBLK == 2)
+        asm volatile("s_load_dwordx16 %0, %2, 0\n\ts_load_dwordx16 %1, %2, 64\n\ts_waitcnt lgkmcnt(0)" : "=&s"(b[0]), "=&s"(b[1]) : "s"(tab));
+    else if constexpr (NBLK == 3)
+        asm volatile("s_load_dwordx16 %0, %3, 0\n\ts_load_dwordx16 %1, %3, 64\n\ts_load_dwordx16 %2, %3, 128\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(b[0]), "=&s"(b[1]), "=&s"(b[2]) : "s"(tab));
+    else
+        asm volatile("s_load_dwordx16 %0, %4, 0\n\ts_load_dwordx16 %1, %4, 64\n\ts_load_dwordx16 %2, %4, 128\n\ts_load_dwordx16 %3, %4, 192\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(b[0]), "=&s"(b[1]), "=&s"(b[2]), "=&s"(b[3]) : "s"(tab));
 }
 
 template <int R>
@@ -192,8 +234,8 @@ __device__ __forceinline__ float cb_dot(const cb_v2f (&a)[R / 2], const cb_v2f (
 
 // Jacobi-preconditioned CG for (S + Diag(D)) x = g, one system per lane.  x is left in x_l[(i / 2) * 64 + lane] (pairs).
 // `live` lanes iterate until |r|^2 <= tol2 |g|^2; the wave stops when no lane is live.  Returns the wave's trip count.
-template <int R>
-__device__ __forceinline__ int cb_cg_solve(const CtmBatchTabs& tb, const cb_v2f (&D)[R / 2], const cb_v2f (&dinv)[R / 2],
+template <int R, typename TB>
+__device__ __forceinline__ int cb_cg_solve(const TB& tb, const cb_v2f (&D)[R / 2], const cb_v2f (&dinv)[R / 2],
                                            const cb_v2f (&g)[R / 2], bool live, cb_v2f* __restrict__ x_l, int lane)
 {
     cb_v2f r[R / 2], pv[R / 2], y[R / 2];
@@ -230,10 +272,33 @@ __device__ __forceinline__ int cb_cg_solve(const CtmBatchTabs& tb, const cb_v2f 
     return trips;
 }
 
+// One kernel argument, so that field offsets in the kernarg segment are plain offsetof()s.
+struct CtmBatchArgs { CtmParams p; CtmBatchTabs tb; int64_t M; };
+
+// A pointer-sized kernel argument read from the kernarg segment AT THE POINT OF USE.  Referencing `a.p.lambda` the normal way
+// makes the compiler load every pointer at kernel entry and keep it in SGPRs for the whole kernel; with ~20 pointers live,
+// the two in-flight SMEM groups of the mat-vecs (64 SGPRs) no longer fit the 102-SGPR file and the register allocator
+// spilled an IN-FLIGHT group to VGPR lanes (tools/check_smem_inflight.py caught it in the KP = 44 instantiation).
+template <typename T, int OFF>
+__device__ __forceinline__ T cb_karg()
+{
+    static_assert(sizeof(T) == 8, "pointer-sized fields only");
+    T v;
+    asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "n"(OFF));
+    return v;
+}
+#define CB_KARG(type, field) cb_karg<type, (int)offsetof(CtmBatchArgs, field)>()
+
 // ---- the kernel: wave w owns documents doc_order[64 w .. 64 w + 63] (sorted by length, so a wave's documents are alike)
 template <int R>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void ctm_estep_batch_kernel(CtmParams p, CtmBatchTabs tb, int64_t M)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void ctm_estep_batch_kernel(CtmBatchArgs a)
 {
+    // hot scalars through the normal path; every pointer through CB_KARG where it is used
+    const int p_K = a.p.K, p_viter = a.p.viter, p_niter = a.p.niter, p_debug = a.p.debug;
+    const double p_ntol = a.p.ntol, p_vtol = a.p.vtol;
+    struct { int K, viter, niter, debug; double ntol, vtol; } p = {p_K, p_viter, p_niter, p_debug, p_ntol, p_vtol};
+    struct { const float* S; const float* sdiag; const float* muf; float cg_tol2; int cg_maxit; } tb = {a.tb.S, a.tb.sdiag, a.tb.muf, a.tb.cg_tol2, a.tb.cg_maxit};
+    const int64_t M = a.M;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     double* vs_l = (double*)lds;                         // [R][64] vsq, fp64
     cb_v2f* x_l = (cb_v2f*)(lds + 2 * R * 64);           // [R / 2][64] CG solution pairs
@@ -242,29 +307,39 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const int K = p.K;
     const int64_t slot = (int64_t)blockIdx.x * 64 + lane;
     const bool valid = slot < M;
-    const int d = p.doc_order[valid ? slot : M - 1];
-    const int64_t off = p.doc_ptr[d];
-    const int N = valid ? (int)(p.doc_ptr[d + 1] - off) : 0;
+    const int d = CB_KARG(const int32_t*, p.doc_order)[valid ? slot : M - 1];
+    int64_t off;
+    int N;
+    { const int64_t* doc_ptr = CB_KARG(const int64_t*, p.doc_ptr); off = doc_ptr[d]; N = valid ? (int)(doc_ptr[d + 1] - off) : 0; }
     const int Nmax = wave_max_i(N);
 
     // C_d = sum of counts (src/CTM.jl:33)
     float cl = 0.0f;
-    for (int n = 0; n < Nmax; ++n) cl += (n < N) ? (float)p.counts[off + n] : 0.0f;
+    { const int32_t* counts = CB_KARG(const int32_t*, p.counts); for (int n = 0; n < Nmax; ++n) cl += (n < N) ? (float)counts[off + n] : 0.0f; }
     const double Cd = (double)cl;
 
     double lam[R];
     float dsum[R];                               // lambda - lambda_old of the current sweep (sum of its Newton steps)
+    double lz;
+    {
+        const float* lam_in = CB_KARG(const float*, p.lambda);
+        const float* vsq_in = CB_KARG(const float*, p.vsq);
 #pragma unroll
-    for (int i = 0; i < R; ++i) {
-        const bool on = i < K;
-        lam[i] = on ? (double)p.lambda[(int64_t)d * K + i] : 0.0;
-        vs_l[i * 64 + lane] = on ? (double)p.vsq[(int64_t)d * K + i] : 1.0;
-        dsum[i] = 0.0f;
+        for (int i = 0; i < R; ++i) {
+            const bool on = i < K;
+            lam[i] = on ? (double)lam_in[(int64_t)d * K + i] : 0.0;
+            vs_l[i * 64 + lane] = on ? (double)vsq_in[(int64_t)d * K + i] : 1.0;
+            dsum[i] = 0.0f;
+        }
+        lz = (double)CB_KARG(const float*, p.logzeta)[d];
     }
-    double lz = (double)p.logzeta[d];
     bool active = valid && p.viter > 0;
     int sweeps = 0;
-    unsigned nsteps = 0, ncg = 0;
+    unsigned nsteps = 0, ncg = 0, ntrip = 0;
+    long long cyc[5] = {0, 0, 0, 0, 0};
+    const long long t_start = __builtin_readcyclecounter();
+    long long t_mark = t_start;
+    auto lap = [&](int which) { const long long now = __builtin_readcyclecounter(); cyc[which] += now - t_mark; t_mark = now; };
 
     for (int v = 0; v < p.viter; ++v) {
         if (!__any(active)) break;
@@ -283,81 +358,134 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             }
             // E keeps the LAST executed sweep's factor e = exp(lambda_old - max) for the statistics pass
             if (active) {
+                float* E = CB_KARG(float*, p.E);
 #pragma unroll
-                for (int i = 0; i < R / 2; ++i) *(cb_v2f*)(p.E + (int64_t)d * R + 2 * i) = e2[i];
+                for (int i = 0; i < R / 2; ++i) *(cb_v2f*)(E + (int64_t)d * R + 2 * i) = e2[i];
             }
-            float4 cur[LPR], nxt[LPR];
-            int t0 = (0 < N) ? p.terms[off] : 0;
-            float c_cur = (0 < N) ? (float)p.counts[off] : 0.0f;
-            {
-                const float4* row = (const float4*)(p.beta + (int64_t)t0 * R);
+            const float* beta = CB_KARG(const float*, p.beta);
+            const int32_t* terms = CB_KARG(const int32_t*, p.terms);
+            const int32_t* counts = CB_KARG(const int32_t*, p.counts);
+            // One wave per SIMD hides no latency by itself: the rows of CH steps are in flight together (CH * KP VGPRs) and the
+            // term ids / counts of the next CH steps are fetched alongside, so a step never waits for a dependent load chain
+            // (ids -> row addresses -> rows), only for the first row of its chunk.
+            constexpr int CH = 4;
+            int tq[CH], tn[CH];
+            float cq[CH], cn[CH];
+            auto load_ids = [&](int n0, int (&t)[CH], float (&c)[CH]) {
 #pragma unroll
-                for (int q = 0; q < LPR; ++q) cur[q] = row[q];
-            }
-            for (int n = 0; n < Nmax; ++n) {
-                const bool more = n + 1 < N;
-                const int t1 = more ? p.terms[off + n + 1] : 0;
-                const float c_nxt = more ? (float)p.counts[off + n + 1] : 0.0f;
-                const float4* row = (const float4*)(p.beta + (int64_t)t1 * R);
-#pragma unroll
-                for (int q = 0; q < LPR; ++q) nxt[q] = row[q];
-                cb_v2f s0 = cb_v2f{0.f, 0.f}, s1 = cb_v2f{0.f, 0.f};
-#pragma unroll
-                for (int q = 0; q < LPR; ++q) {
-                    s0 = __builtin_elementwise_fma(cb_v2f{cur[q].x, cur[q].y}, e2[2 * q], s0);
-                    s1 = __builtin_elementwise_fma(cb_v2f{cur[q].z, cur[q].w}, e2[2 * q + 1], s1);
+                for (int u = 0; u < CH; ++u) {
+                    const bool in = n0 + u < N;
+                    t[u] = in ? terms[off + n0 + u] : 0;
+                    c[u] = in ? (float)counts[off + n0 + u] : 0.0f;
                 }
-                const cb_v2f ss = s0 + s1;
-                // a lane past its document's end reads term 0 with count 0; beta[:, 0] may be all zero (a term the corpus never
-                // uses: CTM's phi has no epsilon), so its weight is forced to 0 instead of 0 / 0
-                const float w = (c_cur > 0.0f) ? c_cur / (ss.x + ss.y) : 0.0f;
-                const cb_v2f w2 = cb_v2f{w, w};
+            };
+            load_ids(0, tq, cq);
+            for (int n0 = 0; n0 < Nmax; n0 += CH) {
+                float4 rows[CH][LPR];
 #pragma unroll
-                for (int q = 0; q < LPR; ++q) {
-                    acc[2 * q] = __builtin_elementwise_fma(w2, cb_v2f{cur[q].x, cur[q].y}, acc[2 * q]);
-                    acc[2 * q + 1] = __builtin_elementwise_fma(w2, cb_v2f{cur[q].z, cur[q].w}, acc[2 * q + 1]);
+                for (int u = 0; u < CH; ++u) {
+                    const float4* row = (const float4*)(beta + (int64_t)tq[u] * R);
+#pragma unroll
+                    for (int q = 0; q < LPR; ++q) rows[u][q] = row[q];
+                }
+                load_ids(n0 + CH, tn, cn);
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    cb_v2f s0 = cb_v2f{0.f, 0.f}, s1 = cb_v2f{0.f, 0.f};
+#pragma unroll
+                    for (int q = 0; q < LPR; ++q) {
+                        s0 = __builtin_elementwise_fma(cb_v2f{rows[u][q].x, rows[u][q].y}, e2[2 * q], s0);
+                        s1 = __builtin_elementwise_fma(cb_v2f{rows[u][q].z, rows[u][q].w}, e2[2 * q + 1], s1);
+                    }
+                    const cb_v2f ss = s0 + s1;
+                    // a lane past its document's end reads term 0 with count 0; beta[:, 0] may be all zero (a term the corpus
+                    // never uses: CTM's phi has no epsilon), so its weight is forced to 0 instead of 0 / 0
+                    const float w = (cq[u] > 0.0f) ? cq[u] / (ss.x + ss.y) : 0.0f;
+                    const cb_v2f w2 = cb_v2f{w, w};
+#pragma unroll
+                    for (int q = 0; q < LPR; ++q) {
+                        acc[2 * q] = __builtin_elementwise_fma(w2, cb_v2f{rows[u][q].x, rows[u][q].y}, acc[2 * q]);
+                        acc[2 * q + 1] = __builtin_elementwise_fma(w2, cb_v2f{rows[u][q].z, rows[u][q].w}, acc[2 * q + 1]);
+                    }
                 }
 #pragma unroll
-                for (int q = 0; q < LPR; ++q) cur[q] = nxt[q];
-                c_cur = c_nxt;
+                for (int u = 0; u < CH; ++u) { tq[u] = tn[u]; cq[u] = cn[u]; }
             }
 #pragma unroll
             for (int i = 0; i < R / 2; ++i) { phic[2 * i] = e2[i].x * acc[i].x; phic[2 * i + 1] = e2[i].y * acc[i].y; }
         }
+        lap(0);
         // ---- update_logzeta!  src/CTM.jl:169-171
         {
             double m = -INFINITY;
 #pragma unroll
             for (int i = 0; i < R; ++i) if (i < K) m = fmax(m, lam[i] + 0.5 * vs_l[i * 64 + lane]);
             double s = 0.0;
+            auto lz_chunk = [&](auto tag) {
+                constexpr int i0 = 4 * decltype(tag)::value;
+                double a[4];
 #pragma unroll
-            for (int i = 0; i < R; ++i) if (i < K) s += exp(lam[i] + 0.5 * vs_l[i * 64 + lane] - m);
+                for (int u = 0; u < 4; ++u) a[u] = lam[i0 + u] + 0.5 * vs_l[(i0 + u) * 64 + lane] - m;
+                cb_exp_n<4>(a);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (i0 + u < K) s += a[u];
+            };
+            tmvb_static_for<LPR>(lz_chunk);
             if (active) lz = m + log(s);
         }
+        lap(1);
         // ---- update_vsq!  src/CTM.jl:146-165 (one scalar Newton iteration per topic)
         if (!(p.debug & 1)) {
-            auto vsq_topic = [&](auto tag) {
-                constexpr int i = decltype(tag)::value;
-                if (i >= K) return;
-                const double isdiag = cb_sdouble<i>(tb.sdiag);
-                double vs = vs_l[i * 64 + lane];
-                bool act = active;
+            // four topics per loop: four independent fp64 dependency chains for the single resident wave
+            auto vsq_group = [&](auto tag) {
+                constexpr int i0 = 4 * decltype(tag)::value;
+                if (i0 >= K) return;
+                double vs[4], isd[4];
+                bool act[4];
+                const cb_v4f sd4 = cb_sload4_sync<i0>(tb.sdiag);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { vs[u] = vs_l[(i0 + u) * 64 + lane]; act[u] = active && (i0 + u < K); }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) isd[u] = (double)sd4[u];
                 for (int t = 0; t < p.niter; ++t) {
-                    if (!__any(act)) break;
-                    double rho = 1.0;
-                    const double ex = exp(lam[i] + 0.5 * vs - lz);
-                    const double grad = -0.5 * (isdiag + Cd * ex - 1.0 / vs);                  // :150
-                    const double ihd = -1.0 / (0.25 * Cd * ex + 0.5 / (vs * vs));             // :151
-                    const double pp = ihd * grad;
-                    while (__any(act && vs - rho * pp <= 0.0)) rho = (vs - rho * pp <= 0.0) ? rho * 0.5 : rho;   // :154
-                    if (act) vs -= rho * pp;
-                    if (rho * fabs(grad) < p.ntol) act = false;                                // :159
+                    if (!__any(act[0] || act[1] || act[2] || act[3])) break;
+                    double ex[4], rv[4], den[4], ihd[4], grad[4], pp[4], rho[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) ex[u] = lam[i0 + u] + 0.5 * vs[u] - lz;
+                    cb_exp_n<4>(ex);
+                    cb_rcp_n<4>(vs, rv);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        grad[u] = -0.5 * (isd[u] + Cd * ex[u] - rv[u]);                        // :150
+                        den[u] = 0.25 * Cd * ex[u] + 0.5 * rv[u] * rv[u];
+                    }
+                    cb_rcp_n<4>(den, ihd);                                                      // -1 / den = inverse Hessian, :151
+                    bool shrink = false;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { pp[u] = -ihd[u] * grad[u]; rho[u] = 1.0; shrink = shrink || (act[u] && vs[u] - pp[u] <= 0.0); }
+                    while (__any(shrink)) {                                                    // :154
+                        shrink = false;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            if (act[u] && vs[u] - rho[u] * pp[u] <= 0.0) rho[u] *= 0.5;
+                            shrink = shrink || (act[u] && vs[u] - rho[u] * pp[u] <= 0.0);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (act[u]) vs[u] -= rho[u] * pp[u];
+                        if (rho[u] * fabs(grad[u]) < p.ntol) act[u] = false;                    // :159
+                    }
                 }
-                if (active) vs += TMVB_EPS_D;                                                  // :164
-                vs_l[i * 64 + lane] = vs;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (active && i0 + u < K) vs[u] += TMVB_EPS_D;                              // :164
+                    vs_l[(i0 + u) * 64 + lane] = vs[u];
+                }
             };
-            tmvb_static_for<R>(vsq_topic);
+            tmvb_static_for<LPR>(vsq_group);
         }
+        lap(2);
         // ---- update_lambda!  src/CTM.jl:129-142
         {
 #pragma unroll
@@ -365,30 +493,55 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             bool newt = active;
             for (int t = 0; t < p.niter; ++t) {
                 if (!__any(newt)) break;
+                ++ntrip;
                 if (newt) ++nsteps;
                 cb_v2f g[R / 2], D[R / 2], dinv[R / 2];
                 double gn2 = 0.0;
                 {
-                    double dm[R], mv[R];
+                    // invsigma (mu - lambda), :134, with the fp32 mat-vec of the CG: fp64 FMAs issue at half rate and a fp64 mat-vec
+                    // (2704 of them + 2704 widenings of the table, or a second 21.6 KB table that evicts the first from the 16 KB
+                    // scalar cache) measured 100 000+ cycles per Newton step against 9 000 for this one.  Rounding mu - lambda to
+                    // fp32 and accumulating in fp32 perturbs each gradient component by ~eps sqrt(K) |S_ij dm_j| ~ 1e-6 - 1e-5,
+                    // 40 - 400 times below the exit threshold ntol = 1 / K^2; the terms that cancel at the optimum (phi counts,
+                    // C_d e^{...}) stay in fp64 below.
+                    cb_v2f dmf[R / 2], mvf[R / 2];
+                    {
+                        cb_v16f mb[4];
+                        cb_sload64_sync<(R + 15) / 16>(tb.muf, mb);
 #pragma unroll
-                    for (int i = 0; i < R; ++i) dm[i] = 0.0;
-                    auto set_dm = [&](auto tag) { constexpr int i = decltype(tag)::value; dm[i] = cb_sdouble<i>(tb.mud) - lam[i]; };
-                    tmvb_static_for<R>(set_dm);
-                    cb_matvec_f64<R>(tb.Sd, dm, mv);
-                    auto grad_i = [&](auto tag) {
-                        constexpr int i = decltype(tag)::value;
-                        const bool on = i < K;
-                        const double ex = on ? exp(lam[i] + 0.5 * vs_l[i * 64 + lane] - lz) : 0.0;
-                        const double gd = on ? (mv[i] + (double)phic[i] - Cd * ex) : 0.0;         // :134
-                        gn2 = fma(gd, gd, gn2);
-                        const float dval = on ? (float)(Cd * ex) : 1.0f;                        // pad rows: unit rows
-                        const float hd = (float)cb_sdouble<i>(tb.sdiag) + dval;                  // -H_ii
-                        if (i & 1) { g[i / 2].y = (float)gd; D[i / 2].y = dval; dinv[i / 2].y = 1.0f / hd; }
-                        else { g[i / 2].x = (float)gd; D[i / 2].x = dval; dinv[i / 2].x = 1.0f / hd; }
+                        for (int i = 0; i < R; ++i) {
+                            const float v = (float)((double)mb[i / 16][i % 16] - lam[i]);
+                            if (i & 1) dmf[i / 2].y = v; else dmf[i / 2].x = v;
+                        }
+                    }
+                    cb_matvec_f32<R>(tb.S, dmf, mvf);
+                    double mv[R];
+#pragma unroll
+                    for (int i = 0; i < R / 2; ++i) { mv[2 * i] = (double)mvf[i].x; mv[2 * i + 1] = (double)mvf[i].y; }
+                    auto grad_chunk = [&](auto tag) {
+                        constexpr int i0 = 4 * decltype(tag)::value;
+                        double ex[4];
+                        const cb_v4f sdg = cb_sload4_sync<i0>(tb.sdiag);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) ex[u] = lam[i0 + u] + 0.5 * vs_l[(i0 + u) * 64 + lane] - lz;
+                        cb_exp_n<4>(ex);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int i = i0 + u;
+                            const bool on = i < K;
+                            const double gd = on ? (mv[i] + (double)phic[i] - Cd * ex[u]) : 0.0;     // :134
+                            gn2 = fma(gd, gd, gn2);
+                            const float dval = on ? (float)(Cd * ex[u]) : 1.0f;                     // pad rows: unit rows
+                            const float hd = sdg[u] + dval;                                         // -H_ii
+                            if (i & 1) { g[i / 2].y = (float)gd; D[i / 2].y = dval; dinv[i / 2].y = 1.0f / hd; }
+                            else { g[i / 2].x = (float)gd; D[i / 2].x = dval; dinv[i / 2].x = 1.0f / hd; }
+                        }
                     };
-                    tmvb_static_for<R>(grad_i);
+                    tmvb_static_for<LPR>(grad_chunk);
                 }
+                lap(3);
                 ncg += (unsigned)cb_cg_solve<R>(tb, D, dinv, g, newt, x_l, lane);
+                lap(4);
                 if (newt) {
 #pragma unroll
                     for (int i = 0; i < R / 2; ++i) {
@@ -408,24 +561,36 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 
     if (valid) {
         if (sweeps > 0) {
+            float* lam_out = CB_KARG(float*, p.lambda);
+            float* lam_old_out = CB_KARG(float*, p.lambda_old);
+            float* vsq_out = CB_KARG(float*, p.vsq);
 #pragma unroll
             for (int i = 0; i < R; ++i) {
                 if (i < K) {
-                    p.lambda[(int64_t)d * K + i] = (float)lam[i];
-                    p.lambda_old[(int64_t)d * K + i] = (float)(lam[i] - (double)dsum[i]);
-                    p.vsq[(int64_t)d * K + i] = (float)vs_l[i * 64 + lane];
+                    lam_out[(int64_t)d * K + i] = (float)lam[i];
+                    lam_old_out[(int64_t)d * K + i] = (float)(lam[i] - (double)dsum[i]);
+                    vsq_out[(int64_t)d * K + i] = (float)vs_l[i * 64 + lane];
                 }
             }
-            p.logzeta[d] = (float)lz;
+            CB_KARG(float*, p.logzeta)[d] = (float)lz;
         } else {
+            float* E = CB_KARG(float*, p.E);
 #pragma unroll
-            for (int i = 0; i < R; ++i) p.E[(int64_t)d * R + i] = 0.0f;                         // viter = 0: no responsibilities
+            for (int i = 0; i < R; ++i) E[(int64_t)d * R + i] = 0.0f;                           // viter = 0: no responsibilities
         }
-        p.sweeps[d] = (uint8_t)min(sweeps, 255);
+        CB_KARG(uint8_t*, p.sweeps)[d] = (uint8_t)min(sweeps, 255);
     }
     const unsigned tot = wave_sum_u(valid ? nsteps : 0u);
     if (lane == 0) {
-        if (p.newton_steps) atomicAdd(p.newton_steps, (unsigned long long)tot);
-        if (tb.cg_iters) atomicAdd(tb.cg_iters, (unsigned long long)ncg);
+        unsigned long long* newton_steps = CB_KARG(unsigned long long*, p.newton_steps);
+        unsigned long long* diag = CB_KARG(unsigned long long*, tb.cg_iters);
+        if (newton_steps) atomicAdd(newton_steps, (unsigned long long)tot);
+        if (diag) {
+            atomicAdd(diag, (unsigned long long)ncg);
+            atomicAdd(diag + 1, (unsigned long long)ntrip);
+            atomicAdd(diag + 2, 1ull);
+            for (int q = 0; q < 5; ++q) atomicAdd(diag + 3 + q, (unsigned long long)cyc[q]);
+            atomicAdd(diag + 8, (unsigned long long)(__builtin_readcyclecounter() - t_start));
+        }
     }
 }

@@ -150,6 +150,13 @@ class gpuCTM:
         check(lib().tmvb_ctm_sweep_hist(self.handle, h.ctypes.data_as(P_i64), C.c_int32(nbins), C.byref(ns)))
         return h, ns.value
 
+    def solver_stats(self):
+        """Lane-per-document kernel diagnostics of the last E-step (tmvb_ctm_solver_stats)."""
+        out = np.zeros(9, dtype=np.int64)
+        check(lib().tmvb_ctm_solver_stats(self.handle, out.ctypes.data_as(P_i64)))
+        names = ("cg_trips", "newton_trips", "waves", "cyc_token", "cyc_logzeta", "cyc_vsq", "cyc_gradient", "cyc_cg", "cyc_kernel")
+        return dict(zip(names, out.tolist()))
+
     def doc_sweeps(self):
         """Sweeps each document ran in the last E-step (uint8 per document, corpus order)."""
         out = np.zeros(max(self.M, 1), dtype=np.uint8)
