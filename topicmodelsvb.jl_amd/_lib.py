@@ -10,6 +10,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import subprocess
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
@@ -71,12 +72,28 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if not force and os.path.exists(obj) and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in [src] + hdrs):
             continue
         cmd = [hipcc] + flags + ["-c", src, "-o", obj]
+        if os.path.basename(src) == "tmvb_ctm.hip":
+            cmd.insert(-4, "-save-temps=obj")      # keeps build/tmvb_ctm-hip-amdgcn-amd-amdhsa-gfx950.s for the ISA check below
         if verbose:
             print(" ".join(cmd))
         procs.append((cmd, subprocess.Popen(cmd)))
     for cmd, pr in procs:
         if pr.wait() != 0:
             raise subprocess.CalledProcessError(pr.returncode, cmd)
+    # The batched CTM kernel streams invsigma through SGPRs with hand-placed scalar loads and waits (csrc/tmvb_ctm_batch.h).
+    # A compiler-inserted read of a destination that is still in flight, or a write to the reserved registers, would be a
+    # silent wrong-answer bug, so the generated ISA is checked at build time and the build fails on a finding.
+    isa = os.path.join(objdir, "tmvb_ctm-hip-amdgcn-amd-amdhsa-gfx950.s")
+    checker = os.path.join(_ROOT, "tools", "check_smem_inflight.py")
+    if os.path.exists(isa) and os.path.exists(checker):
+        res = subprocess.run([sys.executable, checker, isa, "ctm_estep_batch"], capture_output=True, text=True)
+        if res.returncode != 0:
+            for o in objs:
+                if os.path.basename(o).startswith("tmvb_ctm.hip") and os.path.exists(o):
+                    os.remove(o)
+            raise EngineError("ISA check of the batched CTM kernel failed:\n" + res.stdout[-2000:])
+        if verbose:
+            print(res.stdout.strip().splitlines()[-1])
     rocm_lib = os.path.join(os.path.dirname(os.path.dirname(hipcc)), "lib")
     # RCCL carries the document-sharded all-reduce (tmvb_comm.hip)
     cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH] + objs + ["-L" + rocm_lib, "-lrccl", "-Wl,-rpath," + rocm_lib]

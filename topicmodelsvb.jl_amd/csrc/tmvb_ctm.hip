@@ -1290,9 +1290,11 @@ extern "C" int tmvb_ctm_estep(tmvb_ctm* h, int32_t niter, double ntol, int32_t v
         const size_t lds = (size_t)h->KP * 64 * (sizeof(double) + sizeof(float));
         CtmBatchArgs ba;
         ba.p = p; ba.tb = tb; ba.M = (int64_t)h->M;
-#define CTM_BCASE(KPV) case KPV: hipLaunchKernelGGL((ctm_estep_batch_kernel<KPV>), grid, block, lds, ctx->stream, ba); break;
-        switch (h->KP) { CTM_BCASE(4) CTM_BCASE(12) CTM_BCASE(20) CTM_BCASE(28) CTM_BCASE(36) CTM_BCASE(44)
-                         default: hipLaunchKernelGGL((ctm_estep_batch_kernel<52>), grid, block, lds, ctx->stream, ba); break; }
+        static const bool prof = [] { const char* e = getenv("TMVB_CTM_PROF"); return e && atoi(e) != 0; }();
+#define CTM_BCASE(KPV) case KPV: hipLaunchKernelGGL((ctm_estep_batch_kernel<KPV, false>), grid, block, lds, ctx->stream, ba); break;
+        if (prof && h->KP == 52) hipLaunchKernelGGL((ctm_estep_batch_kernel<52, true>), grid, block, lds, ctx->stream, ba);
+        else switch (h->KP) { CTM_BCASE(4) CTM_BCASE(12) CTM_BCASE(20) CTM_BCASE(28) CTM_BCASE(36) CTM_BCASE(44)
+                              default: hipLaunchKernelGGL((ctm_estep_batch_kernel<52, false>), grid, block, lds, ctx->stream, ba); break; }
 #undef CTM_BCASE
         TMVB_HIP(hipGetLastError());
     }

@@ -54,65 +54,104 @@ __device__ __forceinline__ unsigned wave_sum_u(unsigned v)
     return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
 }
 
-// ---- SMEM streaming: a flat table goes through SGPRs in groups of two s_load_dwordx16; group g + 1 is in flight while
-// group g is consumed.  Inline asm because a plain C++ load of a loop-invariant table is hoisted out of the solver loops
-// and spilled to VGPR lanes (10 000 v_readlane / v_writelane in the probe), and because SMEM returns out of order: every
-// wait is lgkmcnt(0), placed explicitly.
-template <int OFF>
-__device__ __forceinline__ cb_v16f cb_sload16(const void* base)
+// ---- SMEM streaming of the K x K table through FIXED scalar registers.
+// s[34:35] = table base, s[36:67] = group A (two s_load_dwordx16), s[68:99] = group B.  Group g + 1 is in flight while the
+// packed FMAs of group g execute (SMEM returns out of order: every wait is lgkmcnt(0), placed by hand).  All of it is
+// volatile inline asm naming the registers literally, every statement clobbering s34 - s99:
+//  * a plain C++ load of the loop-invariant table is hoisted out of the solver loops and spilled to VGPR lanes
+//    (10 000 v_readlane / v_writelane in the probe);
+//  * compiler-allocated destination registers ("=s" operands) worked in the probe, but in the full kernel the register
+//    allocator, short of SGPRs, spilled or copied a group that was still IN FLIGHT (v_writelane / s_mov of garbage) -- in a
+//    different instantiation after every unrelated edit.  Registers the compiler never sees cannot be spilled; the clobber
+//    list keeps its own values out of them for the duration, and between the statements it has only VGPR operands to set up.
+// The FMA statements themselves carry no clobber list (a statement that "writes" SGPRs gets an s_nop behind it from the hazard
+// recognizer: +45 % on the mat-vec): the loads and waits, spread through the whole mat-vec, keep the compiler's values out.
+// tools/check_smem_inflight.py scans the generated ISA for any read of an in-flight destination and, between the
+// CBFX_BEGIN / CBFX_END markers, for any compiler-generated write to s34 - s99.
+#define CB_CLOB "s34", "s35", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99"
+
+__device__ __forceinline__ void cb_fx_base(const float* S) { asm volatile("s_mov_b64 s[34:35], %0" : : "s"(S) : CB_CLOB); }
+__device__ __forceinline__ void cb_fx_wait() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 0" : : : CB_CLOB, "memory"); }
+template <int BUF, int OFF>
+__device__ __forceinline__ void cb_fx_load()
 {
-    cb_v16f v;
-    asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(v) : "s"(base), "n"(OFF));
-    return v;
+    if constexpr (BUF == 0) asm volatile("s_load_dwordx16 s[36:51], s[34:35], %0" : : "n"(OFF) : CB_CLOB);
+    else if constexpr (BUF == 1) asm volatile("s_load_dwordx16 s[52:67], s[34:35], %0" : : "n"(OFF) : CB_CLOB);
+    else if constexpr (BUF == 2) asm volatile("s_load_dwordx16 s[68:83], s[34:35], %0" : : "n"(OFF) : CB_CLOB);
+    else asm volatile("s_load_dwordx16 s[84:99], s[34:35], %0" : : "n"(OFF) : CB_CLOB);
 }
-struct CbGroup { cb_v16f b[2]; };
-// No register operands on the wait: a tied ("+s") operand made the register allocator copy a group that was still in
-// flight (s_mov of the destination SGPRs BEFORE the wait = garbage).  Every consumer of a group is a volatile asm FMA that
-// follows the wait in program order, so volatile ordering alone is the dependence.  tools/check_smem_inflight.py scans the
-// generated ISA for any read of an in-flight destination.
-__device__ __forceinline__ void cb_wait() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 0" ::: "memory"); }
+// y += {s[lo], s[hi]} * p.x (ODD = 0) or p.y (ODD = 1); PAIR = which of the 32 SGPR pairs of the two groups
+#define CB_FX_CASE(P, LO, HI)                                                                                                              \
+    if constexpr (PAIR == P) {                                                                                                             \
+        if constexpr (ODD) asm volatile("v_pk_fma_f32 %0, s[" #LO ":" #HI "], %1, %0 op_sel:[0,1,0]" : "+v"(y) : "v"(p));                  \
+        else asm volatile("v_pk_fma_f32 %0, s[" #LO ":" #HI "], %1, %0 op_sel_hi:[1,0,1]" : "+v"(y) : "v"(p));                             \
+    }
+template <int PAIR, int ODD>
+__device__ __forceinline__ void cb_fx_fma(cb_v2f& y, const cb_v2f p)
+{
+    CB_FX_CASE(0, 36, 37)
+    CB_FX_CASE(1, 38, 39)
+    CB_FX_CASE(2, 40, 41)
+    CB_FX_CASE(3, 42, 43)
+    CB_FX_CASE(4, 44, 45)
+    CB_FX_CASE(5, 46, 47)
+    CB_FX_CASE(6, 48, 49)
+    CB_FX_CASE(7, 50, 51)
+    CB_FX_CASE(8, 52, 53)
+    CB_FX_CASE(9, 54, 55)
+    CB_FX_CASE(10, 56, 57)
+    CB_FX_CASE(11, 58, 59)
+    CB_FX_CASE(12, 60, 61)
+    CB_FX_CASE(13, 62, 63)
+    CB_FX_CASE(14, 64, 65)
+    CB_FX_CASE(15, 66, 67)
+    CB_FX_CASE(16, 68, 69)
+    CB_FX_CASE(17, 70, 71)
+    CB_FX_CASE(18, 72, 73)
+    CB_FX_CASE(19, 74, 75)
+    CB_FX_CASE(20, 76, 77)
+    CB_FX_CASE(21, 78, 79)
+    CB_FX_CASE(22, 80, 81)
+    CB_FX_CASE(23, 82, 83)
+    CB_FX_CASE(24, 84, 85)
+    CB_FX_CASE(25, 86, 87)
+    CB_FX_CASE(26, 88, 89)
+    CB_FX_CASE(27, 90, 91)
+    CB_FX_CASE(28, 92, 93)
+    CB_FX_CASE(29, 94, 95)
+    CB_FX_CASE(30, 96, 97)
+    CB_FX_CASE(31, 98, 99)
+}
+#undef CB_FX_CASE
 
 template <int NB, int GI>
-__device__ __forceinline__ void cb_issue(CbGroup& g, const void* base)
+__device__ __forceinline__ void cb_fx_issue()
 {
-    if constexpr (2 * GI < NB) g.b[0] = cb_sload16<(2 * GI) * 64>(base);
-    if constexpr (2 * GI + 1 < NB) g.b[1] = cb_sload16<(2 * GI + 1 < NB ? (2 * GI + 1) * 64 : 0)>(base);
+    if constexpr (2 * GI < NB) cb_fx_load<(GI & 1) * 2, (2 * GI) * 64>();
+    if constexpr (2 * GI + 1 < NB) cb_fx_load<(GI & 1) * 2 + 1, (2 * GI + 1 < NB ? (2 * GI + 1) * 64 : 0)>();
 }
-
-// y[i] += S[j][i] p[j], two columns i per packed FMA.  The FMAs are volatile asm statements: in the full kernel (unlike in
-// the probe) the DAG scheduler, under register pressure, moved every FMA of the mat-vec behind ALL its loads and spilled
-// the 2704 loaded values to VGPR lanes; volatile asm keeps load group / FMAs / wait in program order.
-template <int ODD>
-__device__ __forceinline__ void cb_pk_fma_s(cb_v2f& y, const cb_v2f s, const cb_v2f p)
-{
-    if constexpr (ODD) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(y) : "s"(s), "v"(p));
-    else asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(y) : "s"(s), "v"(p));
-}
+// y[i] += S[j][i] p[j] for the 32 table entries of group GI, two columns i per packed FMA
 template <int R, int GI>
-__device__ __forceinline__ void cb_consume_f32(const CbGroup& g, const cb_v2f (&p)[R / 2], cb_v2f (&y)[R / 2])
+__device__ __forceinline__ void cb_fx_consume(const cb_v2f (&p)[R / 2], cb_v2f (&y)[R / 2])
 {
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int f = (2 * GI + k) * 16 + 2 * e;
-            if (f < R * R) {
-                const int j = f / R, i = f % R;
-                if (j & 1) cb_pk_fma_s<1>(y[i / 2], cb_v2f{g.b[k][2 * e], g.b[k][2 * e + 1]}, p[j / 2]);
-                else cb_pk_fma_s<0>(y[i / 2], cb_v2f{g.b[k][2 * e], g.b[k][2 * e + 1]}, p[j / 2]);
-            }
+    tmvb_static_for<16>([&](auto tag) {
+        constexpr int q = decltype(tag)::value;                 // pair q of the group: block q / 8, element pair q % 8
+        constexpr int f = (2 * GI + q / 8) * 16 + 2 * (q % 8);
+        if constexpr (f < R * R) {
+            constexpr int j = f / R, i = f % R;
+            cb_fx_fma<(GI & 1) * 16 + q, (j & 1)>(y[i / 2], p[j / 2]);
         }
-    }
+    });
 }
 template <int R, int GI, int NG>
-__device__ __forceinline__ void cb_pipe_f32(CbGroup& cur, CbGroup& nxt, const float* S, const cb_v2f (&p)[R / 2], cb_v2f (&y)[R / 2])
+__device__ __forceinline__ void cb_fx_pipe(const cb_v2f (&p)[R / 2], cb_v2f (&y)[R / 2])
 {
     constexpr int NB = (R * R + 15) / 16;
     if constexpr (GI < NG) {
-        if constexpr (GI + 1 < NG) cb_issue<NB, GI + 1>(nxt, S);
-        cb_consume_f32<R, GI>(cur, p, y);
-        if constexpr (GI + 1 < NG) cb_wait();
-        cb_pipe_f32<R, GI + 1, NG>(nxt, cur, S, p, y);
+        if constexpr (GI + 1 < NG) cb_fx_issue<NB, GI + 1>();
+        cb_fx_consume<R, GI>(p, y);
+        if constexpr (GI + 1 < NG) cb_fx_wait();
+        cb_fx_pipe<R, GI + 1, NG>(p, y);
     }
 }
 // y = S p  (S symmetric, [R][R] flat)
@@ -122,10 +161,12 @@ __device__ __forceinline__ void cb_matvec_f32(const float* S, const cb_v2f (&p)[
     constexpr int NB = (R * R + 15) / 16, NG = (NB + 1) / 2;
 #pragma unroll
     for (int i = 0; i < R / 2; ++i) y[i] = cb_v2f{0.f, 0.f};
-    CbGroup a, b;
-    cb_issue<NB, 0>(a, S);
-    cb_wait();
-    cb_pipe_f32<R, 0, NG>(a, b, S, p, y);
+    asm volatile("; CBFX_BEGIN");
+    cb_fx_base(S);
+    cb_fx_issue<NB, 0>();
+    cb_fx_wait();
+    cb_fx_pipe<R, 0, NG>(p, y);
+    asm volatile("; CBFX_END" : : : CB_CLOB);
 }
 
 // exp(a) in fp64, ~1e-14 relative: n = rint(a / ln 2), degree-11 Taylor polynomial on |r| <= ln 2 / 2, ldexp.  19 instructions
@@ -290,7 +331,9 @@ __device__ __forceinline__ T cb_karg()
 #define CB_KARG(type, field) cb_karg<type, (int)offsetof(CtmBatchArgs, field)>()
 
 // ---- the kernel: wave w owns documents doc_order[64 w .. 64 w + 63] (sorted by length, so a wave's documents are alike)
-template <int R>
+// PROF = true adds the per-phase cycle counters of tmvb_ctm_solver_stats (TMVB_CTM_PROF=1): twelve more live SGPRs, which is
+// what the production instantiation cannot afford next to the two in-flight SMEM groups (the allocator then spills a group).
+template <int R, bool PROF>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void ctm_estep_batch_kernel(CtmBatchArgs a)
 {
     // hot scalars through the normal path; every pointer through CB_KARG where it is used
@@ -337,9 +380,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     int sweeps = 0;
     unsigned nsteps = 0, ncg = 0, ntrip = 0;
     long long cyc[5] = {0, 0, 0, 0, 0};
-    const long long t_start = __builtin_readcyclecounter();
+    const long long t_start = PROF ? __builtin_readcyclecounter() : 0;
     long long t_mark = t_start;
-    auto lap = [&](int which) { const long long now = __builtin_readcyclecounter(); cyc[which] += now - t_mark; t_mark = now; };
+    auto lap = [&](int which) {
+        if constexpr (PROF) { const long long now = __builtin_readcyclecounter(); cyc[which] += now - t_mark; t_mark = now; }
+    };
 
     for (int v = 0; v < p.viter; ++v) {
         if (!__any(active)) break;
@@ -589,8 +634,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             atomicAdd(diag, (unsigned long long)ncg);
             atomicAdd(diag + 1, (unsigned long long)ntrip);
             atomicAdd(diag + 2, 1ull);
-            for (int q = 0; q < 5; ++q) atomicAdd(diag + 3 + q, (unsigned long long)cyc[q]);
-            atomicAdd(diag + 8, (unsigned long long)(__builtin_readcyclecounter() - t_start));
+            if constexpr (PROF) {
+                for (int q = 0; q < 5; ++q) atomicAdd(diag + 3 + q, (unsigned long long)cyc[q]);
+                atomicAdd(diag + 8, (unsigned long long)(__builtin_readcyclecounter() - t_start));
+            }
         }
     }
 }
