@@ -308,10 +308,11 @@ int tmvb_ctm_train_group(tmvb_ctm* const* hs, int32_t n, int32_t iter, double to
 int tmvb_ctm_sweep_hist(tmvb_ctm* h, int64_t* hist, int32_t nbins, int64_t* newton_steps);
 int tmvb_ctm_doc_sweeps(tmvb_ctm* h, uint8_t* out);
 int tmvb_ctm_last_estep_ms(tmvb_ctm* h, float* ms);
-/* Diagnostics of the last E-step when the lane-per-document kernel ran (K <= 50, csrc/tmvb_ctm_batch.h): out9[0] conjugate-gradient
- * trips, [1] Newton trips, [2] waves (summed over waves), [3..7] shader cycles in the token / logzeta / vsq / gradient / CG
- * phases, [8] whole-kernel cycles.  Zeros otherwise. */
-int tmvb_ctm_solver_stats(tmvb_ctm* h, int64_t* out9);
+/* Diagnostics of the last E-step when the lane-per-document kernel ran (K <= 50, csrc/tmvb_ctm_batch.h), 12 values: out[0]
+ * conjugate-gradient trips, [1] Newton trips, [2] waves (summed over waves); with TMVB_CTM_PROF=1 in the environment also
+ * [3..10] shader cycles per phase (token, logzeta, vsq, gradient assembly, CG, gradient mat-vec, lambda update, spare) and
+ * [11] whole-kernel cycles.  Zeros otherwise. */
+int tmvb_ctm_solver_stats(tmvb_ctm* h, int64_t* out12);
 
 /* ============================== fCTM (new device path; oracle src/fCTM.jl) ==============================
  * Filtered CTM: CTM plus the per-token switch tau_n (prior eta) and the background distribution kappa of fLDA.  No accelerator

@@ -8,5 +8,5 @@ python /root/repo/tools/check_smem_inflight.py /tmp/ctmb/tmvb_ctm-hip-amdgcn-amd
 cd /root/repo || exit 1
 rm -rf topicmodelsvb.jl_amd/csrc/gpurun_out
 python -c "import __graft_entry__ as g; g.build()" 2>&1 | tail -1
-timeout 3000 /usr/local/graft/bin/gpurun --timeout 1800 -- "ITERS=${ITERS:-3} $EXTRA_ENV python tools/ctm_probe.py > gpurun_out/ctm_probe_batch.txt 2>&1; TMVB_CTM_PROF=1 ITERS=${ITERS:-3} $EXTRA_ENV python tools/ctm_probe.py >> gpurun_out/ctm_probe_batch.txt 2>&1; timeout 900 python -m pytest tests/test_ctm_gpu.py -q -m gpu -x > gpurun_out/t_ctm_batch.txt 2>&1" > /tmp/gpurun10.log 2>&1
+timeout 3000 /usr/local/graft/bin/gpurun --timeout 1800 -- "ITERS=2 $EXTRA_ENV python tools/ctm_probe.py > gpurun_out/ctm_probe_batch.txt 2>&1; TMVB_CTM_PROF=1 ITERS=${ITERS:-3} $EXTRA_ENV python tools/ctm_probe.py >> gpurun_out/ctm_probe_batch.txt 2>&1; timeout 900 python -m pytest tests/test_ctm_gpu.py -q -m gpu -x > gpurun_out/t_ctm_batch.txt 2>&1" > /tmp/gpurun10.log 2>&1
 tail -1 /tmp/gpurun10.log; cat gpurun_out/ctm_probe_batch.txt; tail -3 gpurun_out/t_ctm_batch.txt

@@ -93,7 +93,7 @@ template <typename T>
 static int upload(tmvb_ctx* ctx, T** dptr, const T* h, size_t n)
 {
     *dptr = nullptr;
-    size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    size_t bytes = std::max<size_t>(n, 1) * sizeof(T) + 64;      // slack: kernels read token ids four at a time (tmvb_ctm_batch.h)
     hipError_t e = hipMalloc((void**)dptr, bytes);
     if (e != hipSuccess) {
         tmvb_set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));

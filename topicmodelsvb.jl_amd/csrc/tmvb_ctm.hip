@@ -1010,7 +1010,7 @@ struct tmvb_ctm {
     float* d_invsigma_f = nullptr; float* d_mu_f = nullptr;
     bool batch = false;                // lane-per-document kernel (tmvb_ctm_batch.h), KP <= 52
     float* d_bt_sdiag = nullptr; float* d_bt_muf = nullptr; unsigned long long* d_cg_iters = nullptr;
-    float cg_tol = 1e-5f;
+    float cg_tol = 1e-4f, cg_abs = 0.05f;   // CG exit: relative residual, and the fraction of ntol it may stop at (TMVB_CTM_CG_TOL / _ABS)
     double* d_sigma = nullptr; double* d_invsigma = nullptr; double* d_mu = nullptr; double* d_logdet = nullptr;
     float* d_scatter_partial = nullptr; int n_scatter_waves = 0; int64_t docs_per_wave = 0;
     uint8_t* d_sweeps = nullptr; int32_t* d_doc_order = nullptr;
@@ -1116,6 +1116,7 @@ extern "C" int tmvb_ctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
         const char* e = getenv("TMVB_CTM_BATCH");
         h->batch = !h->generic && h->KP <= 52 && !(e && atoi(e) == 0);
         if (const char* t = getenv("TMVB_CTM_CG_TOL")) h->cg_tol = std::max(1e-7f, (float)atof(t));
+        if (const char* t = getenv("TMVB_CTM_CG_ABS")) h->cg_abs = std::max(0.0f, (float)atof(t));
         if ((rc = dmalloc(&h->d_bt_sdiag, 64)) || (rc = dmalloc(&h->d_bt_muf, 64)) || (rc = dmalloc(&h->d_cg_iters, 16)))
             return rc;
     }
@@ -1285,7 +1286,7 @@ extern "C" int tmvb_ctm_estep(tmvb_ctm* h, int32_t niter, double ntol, int32_t v
         TMVB_HIP(hipMemsetAsync(h->d_cg_iters, 0, 16 * sizeof(unsigned long long), ctx->stream));
         CtmBatchTabs tb;
         tb.S = h->d_invsigma_f; tb.sdiag = h->d_bt_sdiag; tb.muf = h->d_bt_muf;
-        tb.cg_tol2 = h->cg_tol * h->cg_tol; tb.cg_maxit = 4 * h->KP; tb.cg_iters = h->d_cg_iters;
+        tb.cg_tol2 = h->cg_tol * h->cg_tol; { const double fl = h->cg_abs * std::min(ntol, 4e-4); tb.cg_abs2 = (float)(fl * fl); }   // never looser than at the reference K = 50 (ntol = 1/K^2) tb.cg_maxit = 4 * h->KP; tb.cg_iters = h->d_cg_iters;
         const dim3 grid((unsigned)((h->M + 63) / 64)), block(64);
         const size_t lds = (size_t)h->KP * 64 * (sizeof(double) + sizeof(float));
         CtmBatchArgs ba;
@@ -1514,19 +1515,19 @@ extern "C" int tmvb_ctm_train(tmvb_ctm* h, int32_t iter, double tol, int32_t nit
 
 // per-document sweep counts of the last E-step (document order of the corpus), for parity tests that compare the
 // state of exactly those documents whose exit sweep agrees with the oracle's
-// Diagnostics of the last E-step of the lane-per-document kernel: out[0] CG trips, [1] Newton trips, [2] waves (all summed
-// over waves), [3..7] shader cycles in the token / logzeta / vsq / gradient / CG phases, [8] whole-kernel cycles (summed
-// over waves).  All zero when the wave-per-document kernels ran.
+// Diagnostics of the last E-step of the lane-per-document kernel (12 values): [0] CG trips, [1] Newton trips, [2] waves (all
+// summed over waves); with TMVB_CTM_PROF=1 also [3..10] shader cycles per phase (token, logzeta, vsq, gradient assembly, CG,
+// gradient mat-vec, lambda update, spare) and [11] whole-kernel cycles.  All zero when the wave-per-document kernels ran.
 extern "C" int tmvb_ctm_solver_stats(tmvb_ctm* h, int64_t* out9)
 {
     TMVB_REQUIRE(h != nullptr && out9 != nullptr, TMVB_EINVAL, "tmvb_ctm_solver_stats: NULL argument");
     TMVB_HIP(hipSetDevice(h->ctx->device));
-    unsigned long long v[9] = {0};
+    unsigned long long v[12] = {0};
     if (h->batch) {
         TMVB_HIP(hipMemcpyAsync(v, h->d_cg_iters, sizeof(v), hipMemcpyDeviceToHost, h->ctx->stream));
         TMVB_HIP(hipStreamSynchronize(h->ctx->stream));
     }
-    for (int q = 0; q < 9; ++q) out9[q] = (int64_t)v[q];
+    for (int q = 0; q < 12; ++q) out9[q] = (int64_t)v[q];
     return TMVB_OK;
 }
 

@@ -29,10 +29,12 @@ struct CtmBatchTabs {
     const float* S = nullptr;        // [R * R] fp32 invsigma (pads 0), + 64 B readable slack
     const float* sdiag = nullptr;    // [64] diagonal of S (pads 0)
     const float* muf = nullptr;      // [64] mu (pads 0)
-    float cg_tol2 = 1e-10f;          // squared relative residual at which a lane's CG stops
+    float cg_tol2 = 1e-8f;           // a lane's CG stops at |r|^2 <= max(cg_tol2 |g|^2, cg_abs2):  relative 1e-4 ...
+    float cg_abs2 = 0.0f;            // ... or 5 % of the Newton exit threshold ntol, whichever is looser
     int cg_maxit = 200;
     unsigned long long* cg_iters = nullptr;   // diagnostics: [0] CG trips summed over waves, [1] Newton trips summed over waves, [2] waves,
-                                              // [3..8] shader cycles per phase summed over waves: token, logzeta, vsq, gradient, CG, whole kernel
+                                              // [3..10] shader cycles per phase summed over waves: token, logzeta, vsq, gradient assembly, CG, gradient mat-vec,
+                                              // lambda update, spare; [11] whole kernel
 };
 
 template <typename F, int... I>
@@ -284,8 +286,8 @@ __device__ __forceinline__ int cb_cg_solve(const TB& tb, const cb_v2f (&D)[R / 2
     for (int i = 0; i < R / 2; ++i) { r[i] = g[i]; pv[i] = g[i] * dinv[i]; x_l[i * 64 + lane] = cb_v2f{0.f, 0.f}; }
     const float gg = cb_dot<R>(g, g);
     float rz = cb_dot<R>(r, pv);
-    const float thr = tb.cg_tol2 * gg;
-    live = live && gg > 0.0f;
+    const float thr = fmaxf(tb.cg_tol2 * gg, tb.cg_abs2);
+    live = live && gg > thr;
     int trips = 0;
     while (trips < tb.cg_maxit && __any(live)) {
         ++trips;
@@ -340,7 +342,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const int p_K = a.p.K, p_viter = a.p.viter, p_niter = a.p.niter, p_debug = a.p.debug;
     const double p_ntol = a.p.ntol, p_vtol = a.p.vtol;
     struct { int K, viter, niter, debug; double ntol, vtol; } p = {p_K, p_viter, p_niter, p_debug, p_ntol, p_vtol};
-    struct { const float* S; const float* sdiag; const float* muf; float cg_tol2; int cg_maxit; } tb = {a.tb.S, a.tb.sdiag, a.tb.muf, a.tb.cg_tol2, a.tb.cg_maxit};
+    struct { const float* S; const float* sdiag; const float* muf; float cg_tol2, cg_abs2; int cg_maxit; } tb = {a.tb.S, a.tb.sdiag, a.tb.muf, a.tb.cg_tol2, a.tb.cg_abs2, a.tb.cg_maxit};
     const int64_t M = a.M;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     double* vs_l = (double*)lds;                         // [R][64] vsq, fp64
@@ -362,7 +364,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const double Cd = (double)cl;
 
     double lam[R];
-    float dsum[R];                               // lambda - lambda_old of the current sweep (sum of its Newton steps)
     double lz;
     {
         const float* lam_in = CB_KARG(const float*, p.lambda);
@@ -372,14 +373,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             const bool on = i < K;
             lam[i] = on ? (double)lam_in[(int64_t)d * K + i] : 0.0;
             vs_l[i * 64 + lane] = on ? (double)vsq_in[(int64_t)d * K + i] : 1.0;
-            dsum[i] = 0.0f;
         }
         lz = (double)CB_KARG(const float*, p.logzeta)[d];
     }
     bool active = valid && p.viter > 0;
     int sweeps = 0;
     unsigned nsteps = 0, ncg = 0, ntrip = 0;
-    long long cyc[5] = {0, 0, 0, 0, 0};
+    long long cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const long long t_start = PROF ? __builtin_readcyclecounter() : 0;
     long long t_mark = t_start;
     auto lap = [&](int which) {
@@ -389,6 +389,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     for (int v = 0; v < p.viter; ++v) {
         if (!__any(active)) break;
         if (active) ++sweeps;
+        // lambda_old of this sweep goes straight to its output array (and is read back for the exit test): 52 more live
+        // registers per lane would push the kernel past the 512-entry file, and spills to scratch cost far more than these
+        // two strided passes per sweep (measured: 35 000 cycles per Newton step for reloading lambda from scratch)
+        if (active) {
+            float* lam_old_out = CB_KARG(float*, p.lambda_old);
+#pragma unroll
+            for (int i = 0; i < R; ++i) if (i < K) lam_old_out[(int64_t)d * K + i] = (float)lam[i];
+        }
         // ---- update_phi!  src/CTM.jl:175-178 in linear space, (phi * counts)_i = e_i sum_n w_n beta[i, t_n]
         float phic[R];
         {
@@ -410,9 +418,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             const float* beta = CB_KARG(const float*, p.beta);
             const int32_t* terms = CB_KARG(const int32_t*, p.terms);
             const int32_t* counts = CB_KARG(const int32_t*, p.counts);
+            // Token step n = token n of each of the wave's 64 documents; every lane gathers "its" row of beta (KP floats).
             // One wave per SIMD hides no latency by itself: the rows of CH steps are in flight together (CH * KP VGPRs) and the
             // term ids / counts of the next CH steps are fetched alongside, so a step never waits for a dependent load chain
-            // (ids -> row addresses -> rows), only for the first row of its chunk.
+            // (ids -> row addresses -> rows).  The phase is bound by the gather traffic itself: lane = document cannot keep
+            // 64 documents' tiles on chip (1.1 MB), so every sweep re-reads nnz * KP * 4 bytes -- 22.7 GB per E-step on
+            // SYN-NSF at 10 sweeps, served mostly by L2 / Infinity Cache (beta is 5.3 MB) at ~7 TB/s.  Staging the rows
+            // through LDS with coalesced DMA (three 64-row buffers, vsq parked in registers) was built and measured: same
+            // bytes, 3.3 M instead of 2.9 M cycles per wave, more registers; dropped.
             constexpr int CH = 4;
             int tq[CH], tn[CH];
             float cq[CH], cn[CH];
@@ -533,8 +546,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         lap(2);
         // ---- update_lambda!  src/CTM.jl:129-142
         {
-#pragma unroll
-            for (int i = 0; i < R; ++i) if (active) dsum[i] = 0.0f;
             bool newt = active;
             for (int t = 0; t < p.niter; ++t) {
                 if (!__any(newt)) break;
@@ -560,6 +571,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                         }
                     }
                     cb_matvec_f32<R>(tb.S, dmf, mvf);
+                    lap(5);
                     double mv[R];
 #pragma unroll
                     for (int i = 0; i < R / 2; ++i) { mv[2 * i] = (double)mvf[i].x; mv[2 * i + 1] = (double)mvf[i].y; }
@@ -592,28 +604,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                     for (int i = 0; i < R / 2; ++i) {
                         const cb_v2f x = x_l[i * 64 + lane];
                         lam[2 * i] += (double)x.x; lam[2 * i + 1] += (double)x.y;             // :136
-                        dsum[2 * i] += x.x; dsum[2 * i + 1] += x.y;
                     }
                 }
                 if (sqrt(gn2) < p.ntol) newt = false;                                           // :138
+                lap(6);
             }
         }
-        float dist2 = 0.0f;
+        if (active) {
+            const float* lam_old_in = CB_KARG(const float*, p.lambda_old);
+            float dist2 = 0.0f;
 #pragma unroll
-        for (int i = 0; i < R; ++i) dist2 = fmaf(dsum[i], dsum[i], dist2);
-        if (sqrtf(dist2) < (float)p.vtol) active = false;                                       // :200
+            for (int i = 0; i < R; ++i) {
+                if (i < K) { const float df = (float)(lam[i] - (double)lam_old_in[(int64_t)d * K + i]); dist2 = fmaf(df, df, dist2); }
+            }
+            if (sqrtf(dist2) < (float)p.vtol) active = false;                                   // :200
+        }
     }
 
     if (valid) {
         if (sweeps > 0) {
             float* lam_out = CB_KARG(float*, p.lambda);
-            float* lam_old_out = CB_KARG(float*, p.lambda_old);
             float* vsq_out = CB_KARG(float*, p.vsq);
 #pragma unroll
             for (int i = 0; i < R; ++i) {
                 if (i < K) {
                     lam_out[(int64_t)d * K + i] = (float)lam[i];
-                    lam_old_out[(int64_t)d * K + i] = (float)(lam[i] - (double)dsum[i]);
                     vsq_out[(int64_t)d * K + i] = (float)vs_l[i * 64 + lane];
                 }
             }
@@ -635,8 +650,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             atomicAdd(diag + 1, (unsigned long long)ntrip);
             atomicAdd(diag + 2, 1ull);
             if constexpr (PROF) {
-                for (int q = 0; q < 5; ++q) atomicAdd(diag + 3 + q, (unsigned long long)cyc[q]);
-                atomicAdd(diag + 8, (unsigned long long)(__builtin_readcyclecounter() - t_start));
+                for (int q = 0; q < 8; ++q) atomicAdd(diag + 3 + q, (unsigned long long)cyc[q]);
+                atomicAdd(diag + 11, (unsigned long long)(__builtin_readcyclecounter() - t_start));
             }
         }
     }

@@ -152,9 +152,10 @@ class gpuCTM:
 
     def solver_stats(self):
         """Lane-per-document kernel diagnostics of the last E-step (tmvb_ctm_solver_stats)."""
-        out = np.zeros(9, dtype=np.int64)
+        out = np.zeros(12, dtype=np.int64)
         check(lib().tmvb_ctm_solver_stats(self.handle, out.ctypes.data_as(P_i64)))
-        names = ("cg_trips", "newton_trips", "waves", "cyc_token", "cyc_logzeta", "cyc_vsq", "cyc_gradient", "cyc_cg", "cyc_kernel")
+        names = ("cg_trips", "newton_trips", "waves", "cyc_token", "cyc_logzeta", "cyc_vsq", "cyc_gradient", "cyc_cg", "cyc_gradmv",
+                 "cyc_update", "cyc_spare", "cyc_kernel")
         return dict(zip(names, out.tolist()))
 
     def doc_sweeps(self):
