@@ -1286,7 +1286,8 @@ extern "C" int tmvb_ctm_estep(tmvb_ctm* h, int32_t niter, double ntol, int32_t v
         TMVB_HIP(hipMemsetAsync(h->d_cg_iters, 0, 16 * sizeof(unsigned long long), ctx->stream));
         CtmBatchTabs tb;
         tb.S = h->d_invsigma_f; tb.sdiag = h->d_bt_sdiag; tb.muf = h->d_bt_muf;
-        tb.cg_tol2 = h->cg_tol * h->cg_tol; { const double fl = h->cg_abs * std::min(ntol, 4e-4); tb.cg_abs2 = (float)(fl * fl); }   // never looser than at the reference K = 50 (ntol = 1/K^2) tb.cg_maxit = 4 * h->KP; tb.cg_iters = h->d_cg_iters;
+        tb.cg_tol2 = h->cg_tol * h->cg_tol; tb.cg_maxit = 4 * h->KP; tb.cg_iters = h->d_cg_iters;
+        { const double fl = h->cg_abs * std::min(ntol, 4e-4); tb.cg_abs2 = (float)(fl * fl); }   // never looser than at the reference K = 50 (ntol = 1/K^2)
         const dim3 grid((unsigned)((h->M + 63) / 64)), block(64);
         const size_t lds = (size_t)h->KP * 64 * (sizeof(double) + sizeof(float));
         CtmBatchArgs ba;
