@@ -146,12 +146,10 @@ extern "C" int tmvb_corpus_create(tmvb_ctx* ctx, int64_t M, int64_t V, int64_t U
         bool dup = false;
         for (int64_t q = a; q < b; ++q) {
             if (terms[q] < 0 || terms[q] >= V) {
-                delete c;
                 tmvb_set_error("document %lld failed check: term id %d outside the vocabulary [0,%lld)", (long long)(d + 1), terms[q], (long long)V);
                 return TMVB_ECORPUS;
             }
             if (counts[q] <= 0) {
-                delete c;
                 tmvb_set_error("document %lld failed check: all counts must be positive integers", (long long)(d + 1));
                 return TMVB_ECORPUS;
             }
@@ -167,12 +165,10 @@ extern "C" int tmvb_corpus_create(tmvb_ctx* ctx, int64_t M, int64_t V, int64_t U
             bool dupr = false;
             for (int64_t q = ra; q < rb; ++q) {
                 if (readers[q] < 0 || readers[q] >= U) {
-                    delete c;
                     tmvb_set_error("document %lld failed check: reader id %d outside the users [0,%lld)", (long long)(d + 1), readers[q], (long long)U);
                     return TMVB_ECORPUS;
                 }
                 if (ratings[q] <= 0) {
-                    delete c;
                     tmvb_set_error("document %lld failed check: all ratings must be positive integers", (long long)(d + 1));
                     return TMVB_ECORPUS;
                 }
