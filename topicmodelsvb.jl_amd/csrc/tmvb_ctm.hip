@@ -1250,6 +1250,32 @@ extern "C" int tmvb_ctm_get_state(tmvb_ctm* h, double* mu, double* sigma, double
     return TMVB_OK;
 }
 
+// launch of the lane-per-document kernel (tmvb_ctm_batch.h) for CTM (FILT = false) and fCTM (FILT = true)
+template <bool FILT>
+static int ctm_launch_batch(tmvb_ctm* h, const CtmParams& p, double ntol)
+{
+    tmvb_ctx* ctx = h->ctx;
+    hipLaunchKernelGGL(ctm_batch_tabs_kernel, dim3(1), dim3(64), 0, ctx->stream, h->K, h->KP, h->d_invsigma_f, h->d_mu_f, h->d_bt_sdiag, h->d_bt_muf);
+    TMVB_HIP(hipGetLastError());
+    TMVB_HIP(hipMemsetAsync(h->d_cg_iters, 0, 16 * sizeof(unsigned long long), ctx->stream));
+    CtmBatchTabs tb;
+    tb.S = h->d_invsigma_f; tb.sdiag = h->d_bt_sdiag; tb.muf = h->d_bt_muf;
+    tb.cg_tol2 = h->cg_tol * h->cg_tol; tb.cg_maxit = 4 * h->KP; tb.cg_iters = h->d_cg_iters;
+    { const double fl = h->cg_abs * std::min(ntol, 4e-4); tb.cg_abs2 = (float)(fl * fl); }   // never looser than at the reference K = 50 (ntol = 1/K^2)
+    const dim3 grid((unsigned)((h->M + 63) / 64)), block(64);
+    const size_t lds = (size_t)h->KP * 64 * (sizeof(double) + sizeof(float));
+    CtmBatchArgs ba;
+    ba.p = p; ba.tb = tb; ba.M = (int64_t)h->M;
+    static const bool prof = [] { const char* e = getenv("TMVB_CTM_PROF"); return e && atoi(e) != 0; }();
+#define CTM_BCASE(KPV) case KPV: hipLaunchKernelGGL((ctm_estep_batch_kernel<KPV, false, FILT>), grid, block, lds, ctx->stream, ba); break;
+    if (prof && h->KP == 52) hipLaunchKernelGGL((ctm_estep_batch_kernel<52, true, FILT>), grid, block, lds, ctx->stream, ba);
+    else switch (h->KP) { CTM_BCASE(4) CTM_BCASE(12) CTM_BCASE(20) CTM_BCASE(28) CTM_BCASE(36) CTM_BCASE(44)
+                          default: hipLaunchKernelGGL((ctm_estep_batch_kernel<52, false, FILT>), grid, block, lds, ctx->stream, ba); break; }
+#undef CTM_BCASE
+    TMVB_HIP(hipGetLastError());
+    return TMVB_OK;
+}
+
 extern "C" int tmvb_ctm_estep(tmvb_ctm* h, int32_t niter, double ntol, int32_t viter, double vtol)
 {
     TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_ctm_estep: handle is NULL");
@@ -1281,24 +1307,8 @@ extern "C" int tmvb_ctm_estep(tmvb_ctm* h, int32_t niter, double ntol, int32_t v
         TMVB_HIP(hipGetLastError());
     }
     if (h->batch && h->M > 0) {
-        hipLaunchKernelGGL(ctm_batch_tabs_kernel, dim3(1), dim3(64), 0, ctx->stream, h->K, h->KP, h->d_invsigma_f, h->d_mu_f, h->d_bt_sdiag, h->d_bt_muf);
-        TMVB_HIP(hipGetLastError());
-        TMVB_HIP(hipMemsetAsync(h->d_cg_iters, 0, 16 * sizeof(unsigned long long), ctx->stream));
-        CtmBatchTabs tb;
-        tb.S = h->d_invsigma_f; tb.sdiag = h->d_bt_sdiag; tb.muf = h->d_bt_muf;
-        tb.cg_tol2 = h->cg_tol * h->cg_tol; tb.cg_maxit = 4 * h->KP; tb.cg_iters = h->d_cg_iters;
-        { const double fl = h->cg_abs * std::min(ntol, 4e-4); tb.cg_abs2 = (float)(fl * fl); }   // never looser than at the reference K = 50 (ntol = 1/K^2)
-        const dim3 grid((unsigned)((h->M + 63) / 64)), block(64);
-        const size_t lds = (size_t)h->KP * 64 * (sizeof(double) + sizeof(float));
-        CtmBatchArgs ba;
-        ba.p = p; ba.tb = tb; ba.M = (int64_t)h->M;
-        static const bool prof = [] { const char* e = getenv("TMVB_CTM_PROF"); return e && atoi(e) != 0; }();
-#define CTM_BCASE(KPV) case KPV: hipLaunchKernelGGL((ctm_estep_batch_kernel<KPV, false>), grid, block, lds, ctx->stream, ba); break;
-        if (prof && h->KP == 52) hipLaunchKernelGGL((ctm_estep_batch_kernel<52, true>), grid, block, lds, ctx->stream, ba);
-        else switch (h->KP) { CTM_BCASE(4) CTM_BCASE(12) CTM_BCASE(20) CTM_BCASE(28) CTM_BCASE(36) CTM_BCASE(44)
-                              default: hipLaunchKernelGGL((ctm_estep_batch_kernel<52, false>), grid, block, lds, ctx->stream, ba); break; }
-#undef CTM_BCASE
-        TMVB_HIP(hipGetLastError());
+        int brc = ctm_launch_batch<false>(h, p, ntol);
+        if (brc) return brc;
     }
     const int nb = (h->generic || h->batch) ? 0 : (int)h->buckets.size();
     const int naux = std::min(nb, (int)tmvb_ctm::NAUX);
@@ -1805,6 +1815,8 @@ extern "C" int tmvb_fctm_estep(tmvb_fctm* h, int32_t niter, double ntol, int32_t
         int lrc = (b->KP > 64) ? launch(ctm_estep_generic_kernel<2, true>) : launch(ctm_estep_generic_kernel<1, true>);
         if (lrc) return lrc;
         TMVB_HIP(hipGetLastError());
+    } else if (b->batch) {
+        if (b->M > 0) { int brc = ctm_launch_batch<true>(b, p, ntol); if (brc) return brc; }
     } else {
         for (const tmvb_bucket& bk : b->buckets) {
             const size_t lds = ctm_tile_bytes(bk.tile_rows, b->KP, true);

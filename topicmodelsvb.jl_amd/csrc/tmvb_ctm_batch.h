@@ -335,7 +335,12 @@ __device__ __forceinline__ T cb_karg()
 // ---- the kernel: wave w owns documents doc_order[64 w .. 64 w + 63] (sorted by length, so a wave's documents are alike)
 // PROF = true adds the per-phase cycle counters of tmvb_ctm_solver_stats (TMVB_CTM_PROF=1): twelve more live SGPRs, which is
 // what the production instantiation cannot afford next to the two in-flight SMEM groups (the allocator then spills a group).
-template <int R, bool PROF>
+// FILT = true: the filtered CTM (src/fCTM.jl).  phi carries the per-token switch as an exponent,
+// phi[i,n] = softmax_i(tau_n log(beta[i,t_n] + eps) + lambda_i) (:216-219), so the token phase gathers rows of L = log(beta + eps),
+// runs the two-pass column softmax per lane with update_tau! (:208-213) fused in, and writes tau / tau_old / the log-sum-exp per
+// token every sweep (the statistics pass rebuilds the last sweep's phi from them); the sweep order is phi, tau, logzeta, LAMBDA,
+// VSQ (:236-241).
+template <int R, bool PROF, bool FILT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void ctm_estep_batch_kernel(CtmBatchArgs a)
 {
     // hot scalars through the normal path; every pointer through CB_KARG where it is used
@@ -399,6 +404,85 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         }
         // ---- update_phi!  src/CTM.jl:175-178 in linear space, (phi * counts)_i = e_i sum_n w_n beta[i, t_n]
         float phic[R];
+        if constexpr (FILT) {
+            const float* Ltab = CB_KARG(const float*, p.L);
+            const float* kappa = CB_KARG(const float*, p.kappa);
+            const int32_t* terms = CB_KARG(const int32_t*, p.terms);
+            const int32_t* counts = CB_KARG(const int32_t*, p.counts);
+            float* tau = CB_KARG(float*, p.tau);
+            float* tau_old = CB_KARG(float*, p.tau_old);
+            float* lse = CB_KARG(float*, p.lse);
+            const float eta = a.p.eta;
+            cb_v2f lf[R / 2], acc[R / 2];
+#pragma unroll
+            for (int i = 0; i < R / 2; ++i) {
+                lf[i] = cb_v2f{(2 * i < K) ? (float)lam[2 * i] : -INFINITY, (2 * i + 1 < K) ? (float)lam[2 * i + 1] : -INFINITY};
+                acc[i] = cb_v2f{0.f, 0.f};
+            }
+            // CH steps' rows (and kappa entries) in flight together, the ids / counts / tau of the next CH steps fetched alongside:
+            // no step waits for the dependent chain ids -> addresses -> rows.  K exps per token (v_exp_f32 issues at quarter
+            // rate) make this phase compute-heavier than CTM's.
+            constexpr int CH = 2;
+            int tq[CH], tn[CH];
+            float cq[CH], cn[CH], uq[CH], un[CH];
+            auto load_ids = [&](int n0, int (&t)[CH], float (&c)[CH], float (&u)[CH]) {
+#pragma unroll
+                for (int k = 0; k < CH; ++k) {
+                    const bool in = n0 + k < N;
+                    t[k] = in ? terms[off + n0 + k] : 0;
+                    c[k] = in ? (float)counts[off + n0 + k] : 0.0f;
+                    u[k] = in ? tau[off + n0 + k] : 0.5f;
+                }
+            };
+            load_ids(0, tq, cq, uq);
+            for (int n0 = 0; n0 < Nmax; n0 += CH) {
+                float4 rows[CH][LPR];
+                float kp[CH];
+#pragma unroll
+                for (int k = 0; k < CH; ++k) {
+                    const float4* row = (const float4*)(Ltab + (int64_t)tq[k] * R);
+#pragma unroll
+                    for (int q = 0; q < LPR; ++q) rows[k][q] = row[q];
+                    kp[k] = kappa[tq[k]];
+                }
+                load_ids(n0 + CH, tn, cn, un);
+#pragma unroll
+                for (int k = 0; k < CH; ++k) {
+                    const cb_v2f tp2 = cb_v2f{uq[k], uq[k]};
+                    cb_v2f x[R / 2];
+                    float m = -INFINITY;
+#pragma unroll
+                    for (int q = 0; q < LPR; ++q) {
+                        x[2 * q] = __builtin_elementwise_fma(tp2, cb_v2f{rows[k][q].x, rows[k][q].y}, lf[2 * q]);          // pads: -inf
+                        x[2 * q + 1] = __builtin_elementwise_fma(tp2, cb_v2f{rows[k][q].z, rows[k][q].w}, lf[2 * q + 1]);
+                        m = fmaxf(m, fmaxf(fmaxf(x[2 * q].x, x[2 * q].y), fmaxf(x[2 * q + 1].x, x[2 * q + 1].y)));
+                    }
+                    cb_v2f s2 = cb_v2f{0.f, 0.f}, a2 = cb_v2f{0.f, 0.f};
+#pragma unroll
+                    for (int q = 0; q < LPR; ++q) {
+                        x[2 * q] = cb_v2f{__expf(x[2 * q].x - m), __expf(x[2 * q].y - m)};                                 // un-normalised phi
+                        x[2 * q + 1] = cb_v2f{__expf(x[2 * q + 1].x - m), __expf(x[2 * q + 1].y - m)};
+                        s2 += x[2 * q] + x[2 * q + 1];
+                        a2 = __builtin_elementwise_fma(x[2 * q], cb_v2f{rows[k][q].x, rows[k][q].y}, a2);                   // pads: 0 * L(= 0)
+                        a2 = __builtin_elementwise_fma(x[2 * q + 1], cb_v2f{rows[k][q].z, rows[k][q].w}, a2);
+                    }
+                    const float sn = s2.x + s2.y, an = a2.x + a2.y;
+                    const float prod = __expf(fminf(-(an / sn), 87.0f));                                                   // prod_i beta^-phi  (:212)
+                    const float tnew = eta / (TMVB_EPS_F + (eta + (1.0f - eta) * (kp[k] * prod)));
+                    const float w = (cq[k] > 0.0f) ? cq[k] / sn : 0.0f;
+                    const cb_v2f w2 = cb_v2f{w, w};
+#pragma unroll
+                    for (int i = 0; i < R / 2; ++i) acc[i] = __builtin_elementwise_fma(w2, x[i], acc[i]);
+                    if (active && n0 + k < N) {
+                        tau_old[off + n0 + k] = uq[k]; tau[off + n0 + k] = tnew; lse[off + n0 + k] = m + __logf(sn);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < CH; ++k) { tq[k] = tn[k]; cq[k] = cn[k]; uq[k] = un[k]; }
+            }
+#pragma unroll
+            for (int i = 0; i < R / 2; ++i) { phic[2 * i] = acc[i].x; phic[2 * i + 1] = acc[i].y; }                // (phi * counts)_i
+        } else
         {
             float lmax = -INFINITY;
 #pragma unroll
@@ -491,7 +575,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             tmvb_static_for<LPR>(lz_chunk);
             if (active) lz = m + log(s);
         }
-        lap(1);
+        auto run_vsq = [&]() {
         // ---- update_vsq!  src/CTM.jl:146-165 (one scalar Newton iteration per topic)
         if (!(p.debug & 1)) {
             // four topics per loop: four independent fp64 dependency chains for the single resident wave
@@ -543,7 +627,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             };
             tmvb_static_for<LPR>(vsq_group);
         }
-        lap(2);
+        };
+        auto run_lambda = [&]() {
         // ---- update_lambda!  src/CTM.jl:129-142
         {
             bool newt = active;
@@ -610,6 +695,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 lap(6);
             }
         }
+        };
+        lap(1);
+        if constexpr (FILT) { run_lambda(); lap(2); run_vsq(); }                    // src/fCTM.jl:239-240
+        else { run_vsq(); lap(2); run_lambda(); }                                   // src/CTM.jl:198-199
         if (active) {
             const float* lam_old_in = CB_KARG(const float*, p.lambda_old);
             float dist2 = 0.0f;
@@ -633,6 +722,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 }
             }
             CB_KARG(float*, p.logzeta)[d] = (float)lz;
+        } else if constexpr (FILT) {
+            float* lse = CB_KARG(float*, p.lse);
+            for (int n = 0; n < N; ++n) lse[off + n] = INFINITY;                                // viter = 0: phi = 0 in the statistics
         } else {
             float* E = CB_KARG(float*, p.E);
 #pragma unroll
