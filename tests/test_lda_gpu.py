@@ -289,3 +289,28 @@ def test_every_kernel_path_by_k(tmvb, oracle, K, merged, monkeypatch):
         assert rel(gm.beta[big], om.beta[big]).max() <= RTOL_BETA, (it, "beta")
         assert rel(gm.alpha, om.alpha).max() <= RTOL_ALPHA
         assert abs(e_g - e_o) <= RTOL_ELBO_STEP * abs(e_o)
+
+
+def test_train_equals_stepwise_pipelined(tmvb):
+    """train! enqueues its iterations without host synchronisation; the stepwise loop below synchronises after every
+    operator.  Both must give the same state bit for bit: every stream that carries document kernels has to wait for the
+    previous iteration's M-step (a missing wait on the chain stream of the pipelined plan once let the next E-step start
+    under the running M-step -- invisible to tests that synchronise between steps)."""
+    pc = tmvb.syn_nsf(M=30000, V=8000, seed=17)
+    K = 50
+
+    def fresh():
+        g = tmvb.gpuLDA(pc, K)
+        g.beta = np.asfortranarray(tmvb.dirichlet_rows(K, pc.V, seed=3)); g.beta_old = g.beta.copy(order="F"); g.update_buffer()
+        return g
+    a = fresh()
+    a.train(iter=8, tol=0.0, checkelbo=np.inf, printelbo=False)
+    b = fresh()
+    for it in range(8):
+        b.estep(10, 1.0 / K ** 2); b.synchronize()
+        b.reduce_docs(); b.synchronize()
+        b.update_beta(); b.synchronize()
+        b.update_alpha(1000, 1.0 / K ** 2); b.synchronize()
+    b.update_host()
+    assert np.array_equal(a.beta, b.beta) and np.array_equal(a.alpha, b.alpha)
+    assert np.array_equal(a.gamma, b.gamma) and np.array_equal(a.Elogtheta, b.Elogtheta)

@@ -794,10 +794,11 @@ static int lda_piece_count(const tmvb_lda* h)
 {
     if (!tmvb_termstats_recomputes(h->KP, h->e_padded) || !h->reg_path) return 1;
     if (const char* e = getenv("TMVB_LDA_PIECES")) return std::max(1, std::min(16, atoi(e)));
-    // measured on SYN-NSF shards (tools/probes/pieces_sweep.sh): 2.7 M and 5.5 M tokens are fastest with 2 pieces,
-    // 10.9 M with 4; below ~2 M the extra launches cost more than the overlap returns
+    // measured on SYN-NSF and its shards in the steady state (tools/run_pieces.sh, it/s): 10.9 M tokens 1 / 2 / 3 / 4 / 6 pieces
+    // = 717 / 806 / 813 / 803 / ~790; 5.5 M tokens 1354 / 1413 / 1426; 2.7 M tokens 2416 / 2229; 1.4 M tokens 3926 / 3303.
+    // Below ~4 M tokens the one-pass plan (critical chain on the context's stream, no cross-stream hops) wins.
     const int64_t nnz = h->corp->info.nnz;
-    return nnz >= (int64_t)(1 << 23) ? 4 : nnz >= (int64_t)(1 << 21) ? 2 : 1;
+    return nnz >= (int64_t)(1 << 22) ? 3 : 1;
 }
 
 // Cut the register-tile buckets where the running token count crosses a multiple of nnz / P.  The LDS-tile
@@ -1108,8 +1109,11 @@ static int lda_estep_impl(tmvb_lda* h, int32_t viter, double vtol)
     if (chain_st == ctx->stream) { int jrc = lda_join_side(h); if (jrc) return jrc; }   // update_alpha! of the last iteration
     TMVB_HIP(hipEventRecord(h->ev_fork, ctx->stream));
     for (int a = 0; a < 2; ++a) {
-        if (h->aux[a] == chain_st) continue;
-        if (a == 0 && chain_st == ctx->stream) continue;                                 // aux[0] is unused in this plan
+        // every stream that carries document kernels waits for the fork event, i.e. for the previous iteration's M-step on
+        // the context's stream -- INCLUDING the chain stream aux[0] of the pipelined plan (a `continue` for "the chain stream"
+        // once skipped it: the next iteration's first piece then started under the current M-step, reading beta while
+        // beta_norm was still to run; caught in the kernel timeline, now covered by test_train_equals_stepwise_pipelined)
+        if (a == 0 && chain_st == ctx->stream) continue;                                 // aux[0] is unused in the one-pass plan
         TMVB_HIP(hipStreamWaitEvent(h->aux[a], h->ev_fork, 0));
         if (h->side_pending) TMVB_HIP(hipStreamWaitEvent(h->aux[a], h->ev_side, 0));   // update_alpha! of the last iteration
     }
