@@ -218,3 +218,26 @@ def test_lane_per_document_kernel_viter_zero_and_fixed_sweeps(tmvb, monkeypatch)
         g.estep(viter=3, vtol=0.0); g.update_host()
         assert np.all(g.doc_sweeps() == 3)
     assert np.abs(gw.lam - gb.lam).max() <= 1e-4 and np.abs(gw.lam_old - gb.lam_old).max() <= 1e-4
+
+
+@pytest.mark.parametrize("batch", ["1", "0"])
+def test_train_equals_stepwise(tmvb, monkeypatch, batch):
+    """train! runs its iterations without host synchronisation; synchronising after every operator must give the same
+    state bit for bit (every stream carrying document kernels waits for the previous M-step)."""
+    monkeypatch.setenv("TMVB_CTM_BATCH", batch)
+    pc = tmvb.syn_nsf(M=6000, V=3000, seed=19)
+    K = 20
+
+    def fresh():
+        g = tmvb.gpuCTM(pc, K)
+        g.beta = np.asfortranarray(tmvb.dirichlet_rows(K, pc.V, seed=3)); g.beta_old = g.beta.copy(order="F"); g.update_buffer()
+        return g
+    a = fresh()
+    a.train(iter=4, tol=0.0, checkelbo=np.inf, printelbo=False)
+    b = fresh()
+    for it in range(4):
+        b.estep(); b.synchronize(); b.reduce_docs(); b.synchronize(); b.update_beta(); b.synchronize()
+        b.update_sigma(); b.synchronize(); b.update_mu(); b.synchronize()
+    b.update_host()
+    for n in ("beta", "mu", "sigma", "lam", "vsq", "logzeta"):
+        assert np.array_equal(getattr(a, n), getattr(b, n)), n

@@ -151,3 +151,23 @@ def test_citeu_shaped_invariants_k50(tmvb):
     np.testing.assert_allclose(gm.alef.sum(), 0.1 * 50 * pc.V + pc.counts.sum(), rtol=2e-5)
     np.testing.assert_allclose(gm.he.sum(), 0.1 * 50 * pc.U + pc.ratings.sum(), rtol=2e-5)
     assert np.all(gm.bet > 0) and np.all(gm.vav > 0) and np.all(np.isfinite(gm.gimel))
+
+
+def test_train_equals_stepwise(tmvb):
+    """train! without host synchronisation == the same operators with a synchronisation after each, bit for bit."""
+    pc = tmvb.syn_citeu(M=6000, V=3000, U=800, seed=23)
+    K = 20
+    alef0 = np.asfortranarray(np.exp(tmvb.dirichlet_rows(K, pc.V, seed=4) - 0.5))
+
+    def fresh():
+        m = tmvb.gpuCTPF(pc, K)
+        m.alef = alef0.copy(order="F"); m.alef_old = alef0.copy(order="F"); m.update_buffer()
+        return m
+    a = fresh()
+    a.train(iter=5, tol=0.0, checkelbo=np.inf, printelbo=False, recs=False)
+    b = fresh()
+    for it in range(5):
+        b.estep(); b.synchronize(); b.reduce_docs(); b.synchronize(); b.mstep(); b.synchronize()
+    b.update_host()
+    for n in ("alef", "he", "bet", "vav", "dalet", "het", "gimel", "zayin"):
+        assert np.array_equal(getattr(a, n), getattr(b, n)), n
