@@ -3,7 +3,7 @@
 cd /root/repo/topicmodelsvb.jl_amd/csrc || exit 1
 mkdir -p /tmp/ctmb
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wno-pass-failed -I../../include -save-temps=obj -c tmvb_ctm.hip -o /tmp/ctmb/tmvb_ctm.o 2>&1 | grep -E "error" -A5 | head -20
-bash /tmp/ctmb/stats.sh
+bash /tmp/ctmb/stats.sh 2>/dev/null
 python /root/repo/tools/check_smem_inflight.py /tmp/ctmb/tmvb_ctm-hip-amdgcn-amd-amdhsa-gfx950.s ctm_estep_batch || exit 1
 cd /root/repo || exit 1
 rm -rf topicmodelsvb.jl_amd/csrc/gpurun_out
