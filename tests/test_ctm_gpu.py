@@ -241,3 +241,22 @@ def test_train_equals_stepwise(tmvb, monkeypatch, batch):
     b.update_host()
     for n in ("beta", "mu", "sigma", "lam", "vsq", "logzeta"):
         assert np.array_equal(getattr(a, n), getattr(b, n)), n
+
+
+def test_regrouping_documents_changes_nothing(tmvb, monkeypatch):
+    """The lane-per-document kernel regroups documents by last E-step's Newton step counts (ctm_reorder_kernel) so that the
+    lanes of a wave finish together.  Documents are independent: per-document results must be BIT-identical with and
+    without the regrouping."""
+    pc = tmvb.syn_nsf(M=9000, V=4000, seed=29)
+    K = 20
+
+    def run(flag):
+        monkeypatch.setenv("TMVB_CTM_REORDER", flag)
+        g = tmvb.gpuCTM(pc, K)
+        g.beta = np.asfortranarray(tmvb.dirichlet_rows(K, pc.V, seed=3)); g.beta_old = g.beta.copy(order="F"); g.update_buffer()
+        g.train(iter=4, tol=0.0, checkelbo=np.inf, printelbo=False)
+        return g
+    a, b = run("1"), run("0")
+    for n in ("beta", "mu", "sigma", "lam", "lam_old", "vsq", "logzeta"):
+        assert np.array_equal(getattr(a, n), getattr(b, n)), n
+    assert np.array_equal(a.doc_sweeps(), b.doc_sweeps())

@@ -62,6 +62,7 @@ struct CtmParams {
     const float* kappa = nullptr;     // [V]
     float eta = 0.5f;
     float* tau = nullptr; float* tau_old = nullptr; float* lse = nullptr;     // [nnz], CSR order
+    uint16_t* doc_newton = nullptr;   // [M] lambda-Newton steps of each document in this E-step (lane-per-document kernel: next E-step's grouping key)
 };
 
 __device__ __forceinline__ float readlane_f(float v, int l)
@@ -445,6 +446,44 @@ __global__ __launch_bounds__(64) void ctm_batch_tabs_kernel(int K, int KP, const
     const int i = threadIdx.x;
     sdiag[i] = (i < KP) ? invsigma_f[i * KP + i] : 0.0f;
     muf[i] = (i < K) ? mu_f[i] : 0.0f;
+}
+
+// Regroup the documents of the lane-per-document kernel.  A wave runs every loop until its slowest lane is done: on SYN-NSF
+// a wave makes 29 Newton trips per E-step while its documents need 21 on average (iterations 30 - 60).  Documents are
+// independent, so any grouping gives bit-identical per-document results (a finished lane only idles); grouping documents that
+// needed similar numbers of Newton steps LAST iteration cuts the idling.  The static order is by length (the token phase runs
+// to the longest document of the wave); inside chunks of CTM_REORDER_CHUNK consecutive documents of that order -- similar
+// lengths -- the documents are sorted by last iteration's step count, descending, stable (bitonic sort of key << 16 | rank
+// in LDS, one workgroup per chunk).
+#define CTM_REORDER_CHUNK 2048
+__global__ __launch_bounds__(1024) void ctm_reorder_kernel(const int32_t* __restrict__ order0, const uint16_t* __restrict__ key,
+                                                           int32_t* __restrict__ order, int64_t M)
+{
+    __shared__ unsigned v[CTM_REORDER_CHUNK];
+    const int64_t base = (int64_t)blockIdx.x * CTM_REORDER_CHUNK;
+    for (int i = threadIdx.x; i < CTM_REORDER_CHUNK; i += 1024) {
+        const int64_t q = base + i;
+        // composite: larger key first; equal keys keep the static order (smaller i first -> larger CHUNK - 1 - i first)
+        v[i] = (q < M) ? (((unsigned)key[order0[q]] << 16) | (unsigned)(CTM_REORDER_CHUNK - 1 - i)) : 0u;
+    }
+    __syncthreads();
+    for (int k = 2; k <= CTM_REORDER_CHUNK; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < CTM_REORDER_CHUNK; i += 1024) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const unsigned a = v[i], b = v[l];
+                    const bool desc = (i & k) == 0;            // descending overall
+                    if (desc ? (a < b) : (a > b)) { v[i] = b; v[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = threadIdx.x; i < CTM_REORDER_CHUNK; i += 1024) {
+        const int64_t q = base + i;
+        if (q < M) order[q] = order0[base + (CTM_REORDER_CHUNK - 1 - (int)(v[i] & 0xffffu))];
+    }
 }
 
 // ------------------------------------------------------------------------------ E-step kernel, any K <= 128
@@ -1009,6 +1048,8 @@ struct tmvb_ctm {
     float* d_wtok = nullptr; float* d_E = nullptr; float* d_ts_partial = nullptr;
     float* d_invsigma_f = nullptr; float* d_mu_f = nullptr;
     bool batch = false;                // lane-per-document kernel (tmvb_ctm_batch.h), KP <= 52
+    bool reorder = false, keys_valid = false;      // regroup its documents by last E-step's Newton step counts (ctm_reorder_kernel)
+    uint16_t* d_doc_newton = nullptr; int32_t* d_doc_order0 = nullptr;
     float* d_bt_sdiag = nullptr; float* d_bt_muf = nullptr; unsigned long long* d_cg_iters = nullptr;
     float cg_tol = 1e-4f, cg_abs = 0.05f;   // CG exit: relative residual, and the fraction of ntol it may stop at (TMVB_CTM_CG_TOL / _ABS)
     double* d_sigma = nullptr; double* d_invsigma = nullptr; double* d_mu = nullptr; double* d_logdet = nullptr;
@@ -1037,7 +1078,7 @@ extern "C" int tmvb_ctm_destroy(tmvb_ctm* h)
     if (h->own_stats) (void)hipFree(h->d_stats);
     (void)hipFree(h->d_lambda); (void)hipFree(h->d_lambda_old); (void)hipFree(h->d_vsq); (void)hipFree(h->d_logzeta);
     (void)hipFree(h->d_wtok); (void)hipFree(h->d_E); (void)hipFree(h->d_ts_partial); (void)hipFree(h->d_invsigma_f);
-    (void)hipFree(h->d_bt_sdiag); (void)hipFree(h->d_bt_muf); (void)hipFree(h->d_cg_iters);
+    (void)hipFree(h->d_bt_sdiag); (void)hipFree(h->d_bt_muf); (void)hipFree(h->d_cg_iters); (void)hipFree(h->d_doc_newton); (void)hipFree(h->d_doc_order0);
     (void)hipFree(h->d_mu_f); (void)hipFree(h->d_sigma); (void)hipFree(h->d_invsigma); (void)hipFree(h->d_mu);
     (void)hipFree(h->d_logdet); (void)hipFree(h->d_scatter_partial); (void)hipFree(h->d_sweeps); (void)hipFree(h->d_doc_order);
     (void)hipFree(h->d_partial); (void)hipFree(h->d_rowsum); (void)hipFree(h->d_doc_val); (void)hipFree(h->d_elbo);
@@ -1117,8 +1158,12 @@ extern "C" int tmvb_ctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
         h->batch = !h->generic && h->KP <= 52 && !(e && atoi(e) == 0);
         if (const char* t = getenv("TMVB_CTM_CG_TOL")) h->cg_tol = std::max(1e-7f, (float)atof(t));
         if (const char* t = getenv("TMVB_CTM_CG_ABS")) h->cg_abs = std::max(0.0f, (float)atof(t));
-        if ((rc = dmalloc(&h->d_bt_sdiag, 64)) || (rc = dmalloc(&h->d_bt_muf, 64)) || (rc = dmalloc(&h->d_cg_iters, 16)))
+        if ((rc = dmalloc(&h->d_bt_sdiag, 64)) || (rc = dmalloc(&h->d_bt_muf, 64)) || (rc = dmalloc(&h->d_cg_iters, 16)) ||
+            (rc = dmalloc(&h->d_doc_newton, (size_t)std::max<int64_t>(h->M, 1))) || (rc = dmalloc(&h->d_doc_order0, (size_t)std::max<int64_t>(h->M, 1))))
             return rc;
+        // regrouping pays when a chunk of the length-sorted order is still homogeneous in length: corpora of >= 4 chunks
+        const char* r = getenv("TMVB_CTM_REORDER");
+        h->reorder = h->batch && h->M >= 4 * CTM_REORDER_CHUNK && !(r && atoi(r) == 0);
     }
     std::vector<int32_t> order((size_t)h->M);
     std::iota(order.begin(), order.end(), 0);
@@ -1135,6 +1180,8 @@ extern "C" int tmvb_ctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
         tmvb_build_lds_buckets(len, order, h->M, h->KP, -1, 3, h->buckets, cap);
     }
     if (h->M) TMVB_HIP(hipMemcpyAsync(h->d_doc_order, order.data(), (size_t)h->M * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    if (h->M) TMVB_HIP(hipMemcpyAsync(h->d_doc_order0, order.data(), (size_t)h->M * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    TMVB_HIP(hipMemsetAsync(h->d_doc_newton, 0, std::max<size_t>((size_t)h->M, 1) * sizeof(uint16_t), ctx->stream));
     TMVB_HIP(hipMemsetAsync(h->d_stats, 0, (size_t)h->stats_len() * sizeof(float), ctx->stream));
     TMVB_HIP(hipMemsetAsync(h->d_sweeps, 0, std::max<size_t>((size_t)h->M, 1), ctx->stream));
     TMVB_HIP(hipMemsetAsync(h->d_newton, 0, sizeof(unsigned long long), ctx->stream));
@@ -1264,8 +1311,14 @@ static int ctm_launch_batch(tmvb_ctm* h, const CtmParams& p, double ntol)
     { const double fl = h->cg_abs * std::min(ntol, 4e-4); tb.cg_abs2 = (float)(fl * fl); }   // never looser than at the reference K = 50 (ntol = 1/K^2)
     const dim3 grid((unsigned)((h->M + 63) / 64)), block(64);
     const size_t lds = (size_t)h->KP * 64 * (sizeof(double) + sizeof(float));
+    if (h->reorder && h->keys_valid) {
+        hipLaunchKernelGGL(ctm_reorder_kernel, dim3((unsigned)((h->M + CTM_REORDER_CHUNK - 1) / CTM_REORDER_CHUNK)), dim3(1024), 0, ctx->stream,
+                           h->d_doc_order0, h->d_doc_newton, h->d_doc_order, (int64_t)h->M);
+        TMVB_HIP(hipGetLastError());
+    }
+    h->keys_valid = true;
     CtmBatchArgs ba;
-    ba.p = p; ba.tb = tb; ba.M = (int64_t)h->M;
+    ba.p = p; ba.p.doc_newton = h->d_doc_newton; ba.tb = tb; ba.M = (int64_t)h->M;
     static const bool prof = [] { const char* e = getenv("TMVB_CTM_PROF"); return e && atoi(e) != 0; }();
 #define CTM_BCASE(KPV) case KPV: hipLaunchKernelGGL((ctm_estep_batch_kernel<KPV, false, FILT>), grid, block, lds, ctx->stream, ba); break;
     if (prof && h->KP == 52) hipLaunchKernelGGL((ctm_estep_batch_kernel<52, true, FILT>), grid, block, lds, ctx->stream, ba);

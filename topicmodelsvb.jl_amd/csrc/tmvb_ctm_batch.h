@@ -731,6 +731,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             for (int i = 0; i < R; ++i) E[(int64_t)d * R + i] = 0.0f;                           // viter = 0: no responsibilities
         }
         CB_KARG(uint8_t*, p.sweeps)[d] = (uint8_t)min(sweeps, 255);
+        CB_KARG(uint16_t*, p.doc_newton)[d] = (uint16_t)min(nsteps, 65535u);       // next E-step's grouping key (ctm_reorder_kernel)
     }
     const unsigned tot = wave_sum_u(valid ? nsteps : 0u);
     if (lane == 0) {
