@@ -1155,7 +1155,9 @@ extern "C" int tmvb_ctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
     {
         // lane-per-document kernel: the default for KP <= 52 (K <= 50); TMVB_CTM_BATCH=0 selects the wave-per-document kernels
         const char* e = getenv("TMVB_CTM_BATCH");
-        h->batch = !h->generic && h->KP <= 52 && !(e && atoi(e) == 0);
+        // (a lane walks its document's tokens one after the other: corpora with documents of thousands of unique terms would
+        // serialise on them, so those keep the wave-per-document kernel, which spreads a document's tokens over the lanes)
+        h->batch = !h->generic && h->KP <= 52 && corp->info.max_doc_len <= 2048 && !(e && atoi(e) == 0);
         if (const char* t = getenv("TMVB_CTM_CG_TOL")) h->cg_tol = std::max(1e-7f, (float)atof(t));
         if (const char* t = getenv("TMVB_CTM_CG_ABS")) h->cg_abs = std::max(0.0f, (float)atof(t));
         if ((rc = dmalloc(&h->d_bt_sdiag, 64)) || (rc = dmalloc(&h->d_bt_muf, 64)) || (rc = dmalloc(&h->d_cg_iters, 16)) ||
