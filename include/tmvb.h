@@ -261,8 +261,11 @@ int tmvb_flda_last_estep_ms(tmvb_flda* h, float* ms);
 
 /* gpuCTM(corp, K) (src/gpuCTM.jl:45-98).  Constructor state as src/CTM.jl:37-48 (mu=0, sigma=invsigma=I,
  * lambda=0, vsq=1, logzeta=0.5); beta is uniform until tmvb_ctm_set_state (the reference draws it with
- * Julia's RNG).  K <= 128.  For K <= 60 the lambda Newton systems are solved in registers (lane = matrix row); for
- * 60 < K <= 128 the Newton matrix lives in LDS (two topic slots per lane) -- same arithmetic, slower per flop. */
+ * Julia's RNG).  K <= 128.  Three E-step kernels behind tmvb_ctm_estep: K <= 50 -- one LANE per
+ * document, invsigma streamed through scalar registers, the lambda Newton systems solved by Jacobi-preconditioned CG to
+ * max(1e-4 |g|, 5 % of ntol) (corpora with documents of more than 2048 unique terms use the next kernel); K <= 60 -- one wave
+ * per document, Gauss-Jordan in registers (lane = matrix row); 60 < K <= 128 -- the Newton matrix in LDS (two topic slots
+ * per lane), same arithmetic, slower per flop. */
 int tmvb_ctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb_ctm** out);
 int tmvb_ctm_destroy(tmvb_ctm* h);
 
