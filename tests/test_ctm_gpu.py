@@ -5,7 +5,8 @@ Tolerances (fp64 -> fp32 state; fp64 Newton gradients on device):
                                vsq rel <= 2e-3, logzeta abs <= 1e-3, beta rel <= 5e-4 on entries > 1e-6,
                                mu abs <= 1e-4, sigma abs <= 2e-4 * max|sigma|, ELBO rel <= 2e-6
   free running               : ELBO rel <= 2e-4 per iteration
-K <= 60 runs the register Gauss-Jordan kernel, 60 < K <= 128 the LDS Newton solve (ctm_estep_generic_kernel).
+K <= 50 runs the lane-per-document kernel (ctm_estep_batch_kernel: CG Newton solves), 50 < K <= 60 the register Gauss-Jordan kernel,
+60 < K <= 128 the LDS Newton solve (ctm_estep_generic_kernel); the two K <= 50 kernels are also compared with each other below.
 """
 import os
 

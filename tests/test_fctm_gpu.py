@@ -5,7 +5,8 @@ oracle and the committed golden fixture.  Tolerances (fp64 -> fp32 state; fp64 N
                                beta rel <= 1e-3 on entries > 1e-6, kappa rel <= 2e-3, mu abs <= 2e-4,
                                sigma abs <= 5e-4 * max|sigma|, ELBO rel <= 5e-6
   free running               : ELBO rel <= 3e-4 per iteration
-K <= 60 runs the register Gauss-Jordan kernel (FILT instantiation), 60 < K <= 128 the LDS Newton solve.
+K <= 50 runs the lane-per-document kernel (FILT instantiation, CG Newton solves), 50 < K <= 60 the register Gauss-Jordan kernel,
+60 < K <= 128 the LDS Newton solve.
 """
 import os
 
