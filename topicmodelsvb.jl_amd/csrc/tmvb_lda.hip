@@ -33,10 +33,12 @@
 #include "tmvb_regtile.h"
 
 // e_q of the first TMVB_LDA_E_LDS topics reach the lanes through LDS (one ds_write, broadcast ds_read_b128) instead of
-// v_readlane: moves a quarter of phase 1's issue slots from the saturated VALU to the idle LDS pipe (+2 % measured at
-// 32 and at 52 of 52 topics; 0 = all v_readlane)
+// v_readlane: moves phase 1's broadcast issue slots from the saturated VALU to the idle LDS pipe.  Must be a multiple of 32
+// (the v_readlane blocks cover topics in blocks of 32 from the first one the LDS path does not) or 0 = all v_readlane.
+// Round 2, steady state: 64 (all topics for K <= 60, the first 64 for K = 100) against 32: K = 50 +1 %, cold start +2 %,
+// K = 100 +3 %, a 16 100-document shard +4 %.
 #ifndef TMVB_LDA_E_LDS
-#define TMVB_LDA_E_LDS 32
+#define TMVB_LDA_E_LDS 64
 #endif
 
 #include <algorithm>
