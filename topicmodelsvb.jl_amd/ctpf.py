@@ -239,3 +239,15 @@ def gpu_train_ctpf(model: CTPF, device_id: int = 0, **kwargs):
         setattr(model, n + "_old", np.array(getattr(g, n), copy=True, order="F"))
     g.close()
     return traj
+
+
+def topicdist_ctpf(model, d):
+    """topicdist(model::Union{CTPF, gpuCTPF}, d)  src/modelutils.jl:960-965: gimel[d] / sum(gimel[d]) (d is 1-based like the
+    reference; a list / range of indices returns a list, :972-983)."""
+    if not isinstance(d, (int, np.integer)):
+        return [topicdist_ctpf(model, int(x)) for x in d]
+    if not (1 <= d <= model.M):
+        from ._lib import CorpusError
+        raise CorpusError("document index outside corpus range.")
+    g = model.gimel[:, d - 1]
+    return g / g.sum()

@@ -187,3 +187,34 @@ def gpu_train_fctm(model: fCTM, device_id: int = 0, **kwargs):
     model.lam_old = model.lam.copy(order="F"); model.tau_old = model.tau.copy()
     g.close()
     return traj
+
+
+def predict_fctm(corp, train_model, iter: int = 10, tol: float | None = None, niter: int = 1000, ntol: float | None = None,
+                 device_id: int = 0, seed: int = 7) -> fCTM:
+    """predict(corp, train_model::fCTM; iter, tol, niter, ntol)  src/modelutils.jl:916-943 on the device: one pass of the
+    fused filtered CTM E-step (phi, tau, logzeta, lambda, vsq sweeps) with mu / sigma / invsigma / beta frozen (:924-928);
+    kappa and eta are those of the fresh fCTM(corp, K), as in the reference.  `tol` stands for the reference's undefined
+    `vtol` (:937)."""
+    K = train_model.K
+    tol = 1.0 / K ** 2 if tol is None else tol
+    ntol = 1.0 / K ** 2 if ntol is None else ntol
+    from .lda import _packed
+    pc = _packed(corp)
+    if pc.V != train_model.V:
+        from ._lib import CorpusError
+        raise CorpusError("predict corpus and train_model corpus must have identical vocabularies.")
+    if tol < 0 or ntol < 0:
+        raise ValueError("tolerance parameters must be nonnegative.")
+    if iter < 0 or niter < 0:
+        raise ValueError("iteration parameters must be nonnegative.")
+    host = fCTM(pc, K, seed)
+    host.mu, host.sigma, host.invsigma = np.array(train_model.mu), np.asfortranarray(train_model.sigma), np.asfortranarray(train_model.invsigma)
+    host.beta = np.asfortranarray(train_model.beta); host.beta_old = host.beta.copy(order="F")
+    host.topics = train_model.topics
+    g = gpufCTM(None, K, device_id=device_id, _from=host)
+    g.estep(niter, ntol, iter, tol)
+    g.update_host()
+    for n in ("lam", "lam_old", "vsq", "logzeta", "tau", "tau_old"):
+        setattr(host, n, getattr(g, n))
+    g.close()
+    return host

@@ -181,3 +181,32 @@ def gpu_train_flda(model: fLDA, device_id: int = 0, **kwargs):
     model.Elogtheta_old = model.Elogtheta.copy(order="F"); model.tau_old = model.tau.copy()
     g.close()
     return traj
+
+
+def predict_flda(corp, train_model, iter: int = 10, tol: float | None = None, device_id: int = 0, seed: int = 7) -> fLDA:
+    """predict(corp, train_model::fLDA; iter=10, tol=1/K^2)  src/modelutils.jl:858-883 on the device: one pass of the fused
+    filtered E-step (phi, tau, gamma, Elogtheta sweeps), no M-step.  As in the reference only alpha, beta and topics come
+    from the trained model (:866-868): kappa and eta are those of the fresh fLDA(corp, K) (`seed` stands in for Julia's
+    RNG).  The reference's loop tests `vtol`, a name that function never defines (:877); `tol` is used here."""
+    K = train_model.K
+    tol = 1.0 / K ** 2 if tol is None else tol
+    from .lda import _packed
+    pc = _packed(corp)
+    if pc.V != train_model.V:
+        from ._lib import CorpusError
+        raise CorpusError("predict corpus and train_model corpus must have identical vocabularies.")
+    if tol < 0:
+        raise ValueError("tolerance parameter must be nonnegative.")
+    if iter < 0:
+        raise ValueError("iteration parameter must be nonnegative.")
+    host = fLDA(pc, K, seed)
+    host.alpha = np.array(train_model.alpha, dtype=np.float64)
+    host.beta = np.asfortranarray(train_model.beta); host.beta_old = host.beta.copy(order="F")
+    host.topics = train_model.topics
+    g = gpufLDA(None, K, device_id=device_id, _from=host)
+    g.estep(iter, tol)
+    g.update_host()
+    for n in ("gamma", "Elogtheta", "Elogtheta_old", "tau", "tau_old"):
+        setattr(host, n, getattr(g, n))
+    g.close()
+    return host
