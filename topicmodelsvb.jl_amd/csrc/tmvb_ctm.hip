@@ -1157,7 +1157,9 @@ extern "C" int tmvb_ctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
         const char* e = getenv("TMVB_CTM_BATCH");
         // (a lane walks its document's tokens one after the other: corpora with documents of thousands of unique terms would
         // serialise on them, so those keep the wave-per-document kernel, which spreads a document's tokens over the lanes)
-        h->batch = !h->generic && h->KP <= 52 && corp->info.max_doc_len <= 2048 && !(e && atoi(e) == 0);
+        // (its token phase addresses the token arrays and the topic table with unsigned 32-bit byte offsets)
+        h->batch = !h->generic && h->KP <= 52 && corp->info.max_doc_len <= 2048 && corp->info.nnz < (1ll << 30) && (int64_t)h->KP * h->V < (1ll << 30) &&
+                   !(e && atoi(e) == 0);
         if (const char* t = getenv("TMVB_CTM_CG_TOL")) h->cg_tol = std::max(1e-7f, (float)atof(t));
         if (const char* t = getenv("TMVB_CTM_CG_ABS")) h->cg_abs = std::max(0.0f, (float)atof(t));
         if ((rc = dmalloc(&h->d_bt_sdiag, 64)) || (rc = dmalloc(&h->d_bt_muf, 64)) || (rc = dmalloc(&h->d_cg_iters, 16)) ||
@@ -1312,7 +1314,7 @@ static int ctm_launch_batch(tmvb_ctm* h, const CtmParams& p, double ntol)
     tb.cg_tol2 = h->cg_tol * h->cg_tol; tb.cg_maxit = 4 * h->KP; tb.cg_iters = h->d_cg_iters;
     { const double fl = h->cg_abs * std::min(ntol, 4e-4); tb.cg_abs2 = (float)(fl * fl); }   // never looser than at the reference K = 50 (ntol = 1/K^2)
     const dim3 grid((unsigned)((h->M + 63) / 64)), block(64);
-    const size_t lds = (size_t)h->KP * 64 * (sizeof(double) + sizeof(float));
+    const size_t lds = (size_t)h->KP * 64 * (sizeof(double) + sizeof(float)) + 64 * sizeof(int32_t);   // vsq, CG solution / row staging, row ids
     if (h->reorder && h->keys_valid) {
         hipLaunchKernelGGL(ctm_reorder_kernel, dim3((unsigned)((h->M + CTM_REORDER_CHUNK - 1) / CTM_REORDER_CHUNK)), dim3(1024), 0, ctx->stream,
                            h->d_doc_order0, h->d_doc_newton, h->d_doc_order, (int64_t)h->M);

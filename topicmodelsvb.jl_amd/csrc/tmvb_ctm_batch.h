@@ -332,6 +332,25 @@ __device__ __forceinline__ T cb_karg()
 }
 #define CB_KARG(type, field) cb_karg<type, (int)offsetof(CtmBatchArgs, field)>()
 
+// One token step of the cooperative row gather (see the token phase of the kernel): every lane publishes the row id of its own
+// document, reads back the ids of the LPR rows it fetches chunks of, and issues its LPR 16-byte loads.
+template <int R>
+__device__ __forceinline__ void cb_token_issue(const __attribute__((address_space(1))) float* tab, int* tl, int lane, const int (&rmap)[R / 4],
+                                               const unsigned (&cbyte)[R / 4], int t, cb_v4f (&b)[R / 4])
+{
+    __builtin_amdgcn_wave_barrier();
+    tl[lane] = t;
+    __builtin_amdgcn_wave_barrier();
+    int tt[R / 4];
+#pragma unroll
+    for (int i = 0; i < R / 4; ++i) tt[i] = tl[rmap[i]];
+    // uniform base + unsigned 32-bit byte offset: the SGPR-base form of global_load, one VGPR of address per load (64-bit per-lane
+    // addresses were hoisted out of the token loop as 26 registers, spilled to scratch and reloaded behind s_waitcnt vmcnt(0))
+    const __attribute__((address_space(1))) char* base = (const __attribute__((address_space(1))) char*)tab;
+#pragma unroll
+    for (int i = 0; i < R / 4; ++i) b[i] = *(const __attribute__((address_space(1))) cb_v4f*)(base + ((unsigned)tt[i] * (unsigned)(R * 4) + cbyte[i]));
+}
+
 // ---- the kernel: wave w owns documents doc_order[64 w .. 64 w + 63] (sorted by length, so a wave's documents are alike)
 // PROF = true adds the per-phase cycle counters of tmvb_ctm_solver_stats (TMVB_CTM_PROF=1): twelve more live SGPRs, which is
 // what the production instantiation cannot afford next to the two in-flight SMEM groups (the allocator then spills a group).
@@ -499,45 +518,71 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
                 for (int i = 0; i < R / 2; ++i) *(cb_v2f*)(E + (int64_t)d * R + 2 * i) = e2[i];
             }
-            const float* beta = CB_KARG(const float*, p.beta);
-            const int32_t* terms = CB_KARG(const int32_t*, p.terms);
-            const int32_t* counts = CB_KARG(const int32_t*, p.counts);
-            // Token step n = token n of each of the wave's 64 documents; every lane gathers "its" row of beta (KP floats).
-            // One wave per SIMD hides no latency by itself: the rows of CH steps are in flight together (CH * KP VGPRs) and the
-            // term ids / counts of the next CH steps are fetched alongside, so a step never waits for a dependent load chain
-            // (ids -> row addresses -> rows).  The phase is bound by the gather traffic itself: lane = document cannot keep
-            // 64 documents' tiles on chip (1.1 MB), so every sweep re-reads nnz * KP * 4 bytes -- 22.7 GB per E-step on
-            // SYN-NSF at 10 sweeps, served mostly by L2 / Infinity Cache (beta is 5.3 MB) at ~7 TB/s.  Staging the rows
-            // through LDS with coalesced DMA (three 64-row buffers, vsq parked in registers) was built and measured: same
-            // bytes, 3.3 M instead of 2.9 M cycles per wave, more registers; dropped.
-            constexpr int CH = 4;
-            int tq[CH], tn[CH];
-            float cq[CH], cn[CH];
+            typedef const __attribute__((address_space(1))) float* gfloat_p;          // global_load, not flat_load: a flat load ties up
+            typedef const __attribute__((address_space(1))) int32_t* gint_p;          // lgkmcnt as well and every LDS wait would drain them
+            gfloat_p beta = (gfloat_p)CB_KARG(const float*, p.beta);
+            gint_p terms = (gint_p)CB_KARG(const int32_t*, p.terms);
+            gint_p counts = (gint_p)CB_KARG(const int32_t*, p.counts);
+            // Token step n = token n of each of the wave's 64 documents: lane l needs row terms[off_l + n] of beta (KP floats, 208 B at
+            // K = 50).  Lane = document cannot keep 64 documents' tiles on chip (1.1 MB), so every sweep re-reads nnz * KP * 4 bytes
+            // (22.7 GB per E-step on SYN-NSF, from L2 / Infinity Cache).  How the rows are fetched decides the phase
+            // (tools/probes/rowgather_probe.hip, profiles/r2_rowgather_probe.txt): when every lane loads its own row, a
+            // global_load_dwordx4 touches 64 different lines and the CU's vector L1 looks up one line per cycle -- 832 cycles of L1
+            // per step per wave, shared by the four waves of the CU (TCP busy 87 % of the kernel, TCP_PENDING_STALL 58 %;
+            // profiles/r2_ctm_k50_mem_pmc.txt).  Here the 64 x LPR 16-byte chunks of a step are loaded COOPERATIVELY: chunk
+            // q = 64 i + lane of instruction i belongs to row q / LPR (13 consecutive lanes read one row: ~13 lines per instruction,
+            // 5x fewer L1 look-ups), CH steps stay in flight in registers, and each step is transposed through the 13 KB LDS region of
+            // the CG solution (idle in this phase): ds_write_b128 in chunk order, ds_read_b128 of the lane's own row (stride 208 B:
+            // conflict free).  The row ids travel the other way through a 64-entry LDS table.  VMEM returns in order, so a lane's own
+            // ids / counts are fetched two rounds ahead (waiting for a load younger than the rows in flight would drain them).
+            constexpr int CH = (R == 52) ? 2 : 4;
+            cb_v4f* xl4 = (cb_v4f*)(lds + 2 * R * 64);               // [64 rows][LPR chunks]
+            int* tl = (int*)(lds + 3 * R * 64);                        // [64] row ids of one step
+            int rmap[LPR];
+            unsigned cbyte[LPR];
+#pragma unroll
+            for (int i = 0; i < LPR; ++i) { const int q = 64 * i + lane; rmap[i] = q / LPR; cbyte[i] = (unsigned)(q % LPR) * 16u; }
+            int tq[CH], tn[CH], t2[CH];
+            float cq[CH], cn[CH], c2[CH];
+            // branch-free, 32-bit offsets from the uniform array bases (the host checks nnz and KP * V against 2^30 elements); an index
+            // past the document's end is clamped into it (an empty document reads its neighbour's first token or the upload slack)
+            // (the document's offset is read again every sweep: kept live through the Newton phases it was spilled to scratch and its
+            // reload at the top of the token loop -- VMEM returns in order -- drained the rows in flight every round)
+            const unsigned off4 = (unsigned)CB_KARG(const int64_t*, p.doc_ptr)[d] * 4u;
+            typedef const __attribute__((address_space(1))) char* gchar_p;
             auto load_ids = [&](int n0, int (&t)[CH], float (&c)[CH]) {
 #pragma unroll
                 for (int u = 0; u < CH; ++u) {
                     const bool in = n0 + u < N;
-                    t[u] = in ? terms[off + n0 + u] : 0;
-                    c[u] = in ? (float)counts[off + n0 + u] : 0.0f;
+                    const unsigned ix = off4 + 4u * (unsigned)max(min(n0 + u, N - 1), 0);
+                    const int tv = *(gint_p)((gchar_p)terms + ix), cv = *(gint_p)((gchar_p)counts + ix);
+                    t[u] = in ? tv : 0;
+                    c[u] = in ? (float)cv : 0.0f;
                 }
             };
+            cb_v4f buf[CH][LPR];
             load_ids(0, tq, cq);
+            tmvb_static_for<CH>([&](auto tag) {
+                constexpr int u = decltype(tag)::value;
+                cb_token_issue<R>(beta, tl, lane, rmap, cbyte, tq[u], buf[u]);
+            });
+            load_ids(CH, tn, cn);
             for (int n0 = 0; n0 < Nmax; n0 += CH) {
-                float4 rows[CH][LPR];
+                load_ids(n0 + 2 * CH, t2, c2);
+                tmvb_static_for<CH>([&](auto tag) {
+                    constexpr int u = decltype(tag)::value;
 #pragma unroll
-                for (int u = 0; u < CH; ++u) {
-                    const float4* row = (const float4*)(beta + (int64_t)tq[u] * R);
+                    for (int i = 0; i < LPR; ++i) xl4[64 * i + lane] = buf[u][i];
+                    __builtin_amdgcn_wave_barrier();
+                    cb_v4f row[LPR];
 #pragma unroll
-                    for (int q = 0; q < LPR; ++q) rows[u][q] = row[q];
-                }
-                load_ids(n0 + CH, tn, cn);
-#pragma unroll
-                for (int u = 0; u < CH; ++u) {
+                    for (int q = 0; q < LPR; ++q) row[q] = xl4[lane * LPR + q];
+                    cb_token_issue<R>(beta, tl, lane, rmap, cbyte, tn[u], buf[u]);      // step n0 + CH + u (row 0 past the longest document)
                     cb_v2f s0 = cb_v2f{0.f, 0.f}, s1 = cb_v2f{0.f, 0.f};
 #pragma unroll
                     for (int q = 0; q < LPR; ++q) {
-                        s0 = __builtin_elementwise_fma(cb_v2f{rows[u][q].x, rows[u][q].y}, e2[2 * q], s0);
-                        s1 = __builtin_elementwise_fma(cb_v2f{rows[u][q].z, rows[u][q].w}, e2[2 * q + 1], s1);
+                        s0 = __builtin_elementwise_fma(cb_v2f{row[q].x, row[q].y}, e2[2 * q], s0);
+                        s1 = __builtin_elementwise_fma(cb_v2f{row[q].z, row[q].w}, e2[2 * q + 1], s1);
                     }
                     const cb_v2f ss = s0 + s1;
                     // a lane past its document's end reads term 0 with count 0; beta[:, 0] may be all zero (a term the corpus
@@ -546,13 +591,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                     const cb_v2f w2 = cb_v2f{w, w};
 #pragma unroll
                     for (int q = 0; q < LPR; ++q) {
-                        acc[2 * q] = __builtin_elementwise_fma(w2, cb_v2f{rows[u][q].x, rows[u][q].y}, acc[2 * q]);
-                        acc[2 * q + 1] = __builtin_elementwise_fma(w2, cb_v2f{rows[u][q].z, rows[u][q].w}, acc[2 * q + 1]);
+                        acc[2 * q] = __builtin_elementwise_fma(w2, cb_v2f{row[q].x, row[q].y}, acc[2 * q]);
+                        acc[2 * q + 1] = __builtin_elementwise_fma(w2, cb_v2f{row[q].z, row[q].w}, acc[2 * q + 1]);
                     }
-                }
+                });
 #pragma unroll
-                for (int u = 0; u < CH; ++u) { tq[u] = tn[u]; cq[u] = cn[u]; }
+                for (int u = 0; u < CH; ++u) { tq[u] = tn[u]; cq[u] = cn[u]; tn[u] = t2[u]; cn[u] = c2[u]; }
             }
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int i = 0; i < R / 2; ++i) { phic[2 * i] = e2[i].x * acc[i].x; phic[2 * i + 1] = e2[i].y * acc[i].y; }
         }
