@@ -57,12 +57,35 @@ def test_partial_wait_does_not_clear_in_flight_state(tmp_path):
 def test_compiler_write_inside_streaming_region_is_flagged(tmp_path):
     rc, out = run(tmp_path, """
 	; CBFX_BEGIN
-	s_mov_b64 s[34:35], s[4:5]
-	s_load_dwordx16 s[36:51], s[34:35], 0
+	s_load_dwordx16 s[36:51], s[4:5], 0
 	s_waitcnt lgkmcnt(0)
 	s_or_saveexec_b64 s[40:41], -1
+	v_pk_fma_f32 v[2:3], s[42:43], v[10:11], v[2:3] op_sel_hi:[1,0,1]
 	; CBFX_END""")
     assert rc == 1 and "writes a reserved SGPR" in out
+    rc, out = run(tmp_path, """
+	; CBFX_BEGIN
+	s_load_dwordx16 s[68:83], s[4:5], 0
+	s_waitcnt lgkmcnt(0)
+	v_readlane_b32 s70, v254, 3
+	v_pk_fma_f32 v[2:3], s[68:69], v[10:11], v[2:3] op_sel_hi:[1,0,1]
+	; CBFX_END""")
+    assert rc == 1                                   # a spill reload into the block between its load and its last FMA
+
+
+def test_block_is_free_after_its_last_fma_and_before_its_load(tmp_path):
+    rc, out = run(tmp_path, """
+	; CBFX_BEGIN
+	s_mov_b64 s[36:37], s[4:5]
+	s_load_dwordx16 s[36:51], s[4:5], 0
+	s_waitcnt lgkmcnt(0)
+	v_pk_fma_f32 v[2:3], s[50:51], v[10:11], v[2:3] op_sel_hi:[1,0,1]
+	s_mov_b64 s[40:41], vcc
+	s_load_dwordx16 s[36:51], s[4:5], 0x100
+	s_waitcnt lgkmcnt(0)
+	v_pk_fma_f32 v[2:3], s[36:37], v[10:11], v[2:3] op_sel_hi:[1,0,1]
+	; CBFX_END""")
+    assert rc == 0, out
 
 
 def test_other_kernels_are_ignored(tmp_path):

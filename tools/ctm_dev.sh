@@ -3,7 +3,7 @@
 # statistics of the KP = 52 instantiation from the saved ISA, then GPU probe (plain and with TMVB_CTM_PROF=1) + the CTM tests.
 # Usage (from anywhere): tools/ctm_dev.sh        env: ITERS (probe iterations, default 3), EXTRA_ENV ("NAME=value ..." for the probe)
 cd /root/repo || exit 1
-python -c "import __graft_entry__ as g; g.build()" 2>&1 | tail -3
+python -c "import __graft_entry__ as g; g.build()" > /tmp/ctm_dev_build.log 2>&1 || { grep -A6 "error" /tmp/ctm_dev_build.log | head -40; echo BUILD FAILED; exit 1; }; tail -1 /tmp/ctm_dev_build.log
 S=topicmodelsvb.jl_amd/build/tmvb_ctm-hip-amdgcn-amd-amdhsa-gfx950.s
 if [ -f $S ]; then
   awk '/^_Z22ctm_estep_batch_kernelILi52ELb0ELb0E/{on=1} on&&/s_endpgm/{on=0} on' $S > /tmp/ctm_b52.s

@@ -57,103 +57,117 @@ __device__ __forceinline__ unsigned wave_sum_u(unsigned v)
 }
 
 // ---- SMEM streaming of the K x K table through FIXED scalar registers.
-// s[34:35] = table base, s[36:67] = group A (two s_load_dwordx16), s[68:99] = group B.  Group g + 1 is in flight while the
-// packed FMAs of group g execute (SMEM returns out of order: every wait is lgkmcnt(0), placed by hand).  All of it is
-// volatile inline asm naming the registers literally, every statement clobbering s34 - s99:
+// s[36:67] = group A (two s_load_dwordx16), s[68:99] = group B.  Group g + 1 is in flight while the packed FMAs of group g
+// execute (SMEM returns out of order: every wait is lgkmcnt(0), placed by hand).  All of it is volatile inline asm, and every
+// statement names its 16-register block as a PHYSICAL-register operand ("{s[36:51]}"): output of the load, read-write of the wait
+// behind it, input of the FMAs.  What was tried before, and why it is like this:
 //  * a plain C++ load of the loop-invariant table is hoisted out of the solver loops and spilled to VGPR lanes
 //    (10 000 v_readlane / v_writelane in the probe);
-//  * compiler-allocated destination registers ("=s" operands) worked in the probe, but in the full kernel the register
-//    allocator, short of SGPRs, spilled or copied a group that was still IN FLIGHT (v_writelane / s_mov of garbage) -- in a
-//    different instantiation after every unrelated edit.  Registers the compiler never sees cannot be spilled; the clobber
-//    list keeps its own values out of them for the duration, and between the statements it has only VGPR operands to set up.
-// The FMA statements themselves carry no clobber list (a statement that "writes" SGPRs gets an s_nop behind it from the hazard
-// recognizer: +45 % on the mat-vec): the loads and waits, spread through the whole mat-vec, keep the compiler's values out.
-// tools/check_smem_inflight.py scans the generated ISA for any read of an in-flight destination and, between the
-// CBFX_BEGIN / CBFX_END markers, for any compiler-generated write to s34 - s99.
-#define CB_CLOB "s34", "s35", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99"
+//  * compiler-allocated destination registers ("=s" operands): in the full kernel the register allocator, short of SGPRs,
+//    spilled or copied a group that was still IN FLIGHT (v_writelane / s_mov of garbage), in a different instantiation after
+//    every unrelated edit;
+//  * registers named only in the asm text and in clobber lists: nothing tells the compiler that they are live BETWEEN the
+//    statements, and after a change of register pressure elsewhere it put short-lived temporaries (a spill reload, the zero
+//    for the accumulators) into s36 - s39 between a load and the FMAs that read them.
+// With the blocks as operands the compiler knows they are live from the load to the last FMA and has no reason to move a value
+// that must sit in the same physical registers at both ends.  The loads and waits also clobber nothing else; a statement that
+// defines SGPRs gets an s_nop behind it from the hazard recognizer, the FMAs (inputs only) do not.
+// tools/check_smem_inflight.py still scans the generated ISA for any read of an in-flight destination and, between the
+// CBFX_BEGIN / CBFX_END markers, for any compiler-generated write to s36 - s99; build() fails on a finding.
+struct cb_fx_regs { cb_v16f a0, a1, b0, b1; };          // s[36:51], s[52:67], s[68:83], s[84:99]
 
-__device__ __forceinline__ void cb_fx_base(const float* S) { asm volatile("s_mov_b64 s[34:35], %0" : : "s"(S) : CB_CLOB); }
-__device__ __forceinline__ void cb_fx_wait() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 0" : : : CB_CLOB, "memory"); }
 template <int BUF, int OFF>
-__device__ __forceinline__ void cb_fx_load()
+__device__ __forceinline__ void cb_fx_load(cb_fx_regs& g, const float* S)
 {
-    if constexpr (BUF == 0) asm volatile("s_load_dwordx16 s[36:51], s[34:35], %0" : : "n"(OFF) : CB_CLOB);
-    else if constexpr (BUF == 1) asm volatile("s_load_dwordx16 s[52:67], s[34:35], %0" : : "n"(OFF) : CB_CLOB);
-    else if constexpr (BUF == 2) asm volatile("s_load_dwordx16 s[68:83], s[34:35], %0" : : "n"(OFF) : CB_CLOB);
-    else asm volatile("s_load_dwordx16 s[84:99], s[34:35], %0" : : "n"(OFF) : CB_CLOB);
+    if constexpr (BUF == 0) asm volatile("s_load_dwordx16 %0, %1, %2" : "={s[36:51]}"(g.a0) : "s"(S), "n"(OFF));
+    else if constexpr (BUF == 1) asm volatile("s_load_dwordx16 %0, %1, %2" : "={s[52:67]}"(g.a1) : "s"(S), "n"(OFF));
+    else if constexpr (BUF == 2) asm volatile("s_load_dwordx16 %0, %1, %2" : "={s[68:83]}"(g.b0) : "s"(S), "n"(OFF));
+    else asm volatile("s_load_dwordx16 %0, %1, %2" : "={s[84:99]}"(g.b1) : "s"(S), "n"(OFF));
+}
+// completion point of the group in buffers 2 GRP, 2 GRP + 1 (N of them loaded)
+template <int GRP, int N>
+__device__ __forceinline__ void cb_fx_wait(cb_fx_regs& g)
+{
+    if constexpr (GRP == 0 && N == 2) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 0" : "+{s[36:51]}"(g.a0), "+{s[52:67]}"(g.a1) : : "memory");
+    else if constexpr (GRP == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 0" : "+{s[36:51]}"(g.a0) : : "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 0" : "+{s[68:83]}"(g.b0), "+{s[84:99]}"(g.b1) : : "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 0" : "+{s[68:83]}"(g.b0) : : "memory");
 }
 // y += {s[lo], s[hi]} * p.x (ODD = 0) or p.y (ODD = 1); PAIR = which of the 32 SGPR pairs of the two groups
-#define CB_FX_CASE(P, LO, HI)                                                                                                              \
+#define CB_FX_CASE(P, LO, HI, BLK, FIELD)                                                                                                  \
     if constexpr (PAIR == P) {                                                                                                             \
-        if constexpr (ODD) asm volatile("v_pk_fma_f32 %0, s[" #LO ":" #HI "], %1, %0 op_sel:[0,1,0]" : "+v"(y) : "v"(p));                  \
-        else asm volatile("v_pk_fma_f32 %0, s[" #LO ":" #HI "], %1, %0 op_sel_hi:[1,0,1]" : "+v"(y) : "v"(p));                             \
+        if constexpr (ODD) asm volatile("v_pk_fma_f32 %0, s[" #LO ":" #HI "], %1, %0 op_sel:[0,1,0]" : "+v"(y) : "v"(p), "{s[" BLK "]}"(g.FIELD)); \
+        else asm volatile("v_pk_fma_f32 %0, s[" #LO ":" #HI "], %1, %0 op_sel_hi:[1,0,1]" : "+v"(y) : "v"(p), "{s[" BLK "]}"(g.FIELD));    \
     }
 template <int PAIR, int ODD>
-__device__ __forceinline__ void cb_fx_fma(cb_v2f& y, const cb_v2f p)
+__device__ __forceinline__ void cb_fx_fma(const cb_fx_regs& g, cb_v2f& y, const cb_v2f p)
 {
-    CB_FX_CASE(0, 36, 37)
-    CB_FX_CASE(1, 38, 39)
-    CB_FX_CASE(2, 40, 41)
-    CB_FX_CASE(3, 42, 43)
-    CB_FX_CASE(4, 44, 45)
-    CB_FX_CASE(5, 46, 47)
-    CB_FX_CASE(6, 48, 49)
-    CB_FX_CASE(7, 50, 51)
-    CB_FX_CASE(8, 52, 53)
-    CB_FX_CASE(9, 54, 55)
-    CB_FX_CASE(10, 56, 57)
-    CB_FX_CASE(11, 58, 59)
-    CB_FX_CASE(12, 60, 61)
-    CB_FX_CASE(13, 62, 63)
-    CB_FX_CASE(14, 64, 65)
-    CB_FX_CASE(15, 66, 67)
-    CB_FX_CASE(16, 68, 69)
-    CB_FX_CASE(17, 70, 71)
-    CB_FX_CASE(18, 72, 73)
-    CB_FX_CASE(19, 74, 75)
-    CB_FX_CASE(20, 76, 77)
-    CB_FX_CASE(21, 78, 79)
-    CB_FX_CASE(22, 80, 81)
-    CB_FX_CASE(23, 82, 83)
-    CB_FX_CASE(24, 84, 85)
-    CB_FX_CASE(25, 86, 87)
-    CB_FX_CASE(26, 88, 89)
-    CB_FX_CASE(27, 90, 91)
-    CB_FX_CASE(28, 92, 93)
-    CB_FX_CASE(29, 94, 95)
-    CB_FX_CASE(30, 96, 97)
-    CB_FX_CASE(31, 98, 99)
+    CB_FX_CASE(0, 36, 37, "36:51", a0)
+    CB_FX_CASE(1, 38, 39, "36:51", a0)
+    CB_FX_CASE(2, 40, 41, "36:51", a0)
+    CB_FX_CASE(3, 42, 43, "36:51", a0)
+    CB_FX_CASE(4, 44, 45, "36:51", a0)
+    CB_FX_CASE(5, 46, 47, "36:51", a0)
+    CB_FX_CASE(6, 48, 49, "36:51", a0)
+    CB_FX_CASE(7, 50, 51, "36:51", a0)
+    CB_FX_CASE(8, 52, 53, "52:67", a1)
+    CB_FX_CASE(9, 54, 55, "52:67", a1)
+    CB_FX_CASE(10, 56, 57, "52:67", a1)
+    CB_FX_CASE(11, 58, 59, "52:67", a1)
+    CB_FX_CASE(12, 60, 61, "52:67", a1)
+    CB_FX_CASE(13, 62, 63, "52:67", a1)
+    CB_FX_CASE(14, 64, 65, "52:67", a1)
+    CB_FX_CASE(15, 66, 67, "52:67", a1)
+    CB_FX_CASE(16, 68, 69, "68:83", b0)
+    CB_FX_CASE(17, 70, 71, "68:83", b0)
+    CB_FX_CASE(18, 72, 73, "68:83", b0)
+    CB_FX_CASE(19, 74, 75, "68:83", b0)
+    CB_FX_CASE(20, 76, 77, "68:83", b0)
+    CB_FX_CASE(21, 78, 79, "68:83", b0)
+    CB_FX_CASE(22, 80, 81, "68:83", b0)
+    CB_FX_CASE(23, 82, 83, "68:83", b0)
+    CB_FX_CASE(24, 84, 85, "84:99", b1)
+    CB_FX_CASE(25, 86, 87, "84:99", b1)
+    CB_FX_CASE(26, 88, 89, "84:99", b1)
+    CB_FX_CASE(27, 90, 91, "84:99", b1)
+    CB_FX_CASE(28, 92, 93, "84:99", b1)
+    CB_FX_CASE(29, 94, 95, "84:99", b1)
+    CB_FX_CASE(30, 96, 97, "84:99", b1)
+    CB_FX_CASE(31, 98, 99, "84:99", b1)
 }
 #undef CB_FX_CASE
 
+// blocks of 16 floats of group GI that exist (the table has NB of them)
+template <int NB, int GI> constexpr int cb_fx_nblk = (2 * GI + 1 < NB) ? 2 : ((2 * GI < NB) ? 1 : 0);
+
 template <int NB, int GI>
-__device__ __forceinline__ void cb_fx_issue()
+__device__ __forceinline__ void cb_fx_issue(cb_fx_regs& g, const float* S)
 {
-    if constexpr (2 * GI < NB) cb_fx_load<(GI & 1) * 2, (2 * GI) * 64>();
-    if constexpr (2 * GI + 1 < NB) cb_fx_load<(GI & 1) * 2 + 1, (2 * GI + 1 < NB ? (2 * GI + 1) * 64 : 0)>();
+    if constexpr (2 * GI < NB) cb_fx_load<(GI & 1) * 2, (2 * GI) * 64>(g, S);
+    if constexpr (2 * GI + 1 < NB) cb_fx_load<(GI & 1) * 2 + 1, (2 * GI + 1 < NB ? (2 * GI + 1) * 64 : 0)>(g, S);
 }
 // y[i] += S[j][i] p[j] for the 32 table entries of group GI, two columns i per packed FMA
 template <int R, int GI>
-__device__ __forceinline__ void cb_fx_consume(const cb_v2f (&p)[R / 2], cb_v2f (&y)[R / 2])
+__device__ __forceinline__ void cb_fx_consume(const cb_fx_regs& g, const cb_v2f (&p)[R / 2], cb_v2f (&y)[R / 2])
 {
     tmvb_static_for<16>([&](auto tag) {
         constexpr int q = decltype(tag)::value;                 // pair q of the group: block q / 8, element pair q % 8
         constexpr int f = (2 * GI + q / 8) * 16 + 2 * (q % 8);
         if constexpr (f < R * R) {
             constexpr int j = f / R, i = f % R;
-            cb_fx_fma<(GI & 1) * 16 + q, (j & 1)>(y[i / 2], p[j / 2]);
+            cb_fx_fma<(GI & 1) * 16 + q, (j & 1)>(g, y[i / 2], p[j / 2]);
         }
     });
 }
 template <int R, int GI, int NG>
-__device__ __forceinline__ void cb_fx_pipe(const cb_v2f (&p)[R / 2], cb_v2f (&y)[R / 2])
+__device__ __forceinline__ void cb_fx_pipe(cb_fx_regs& g, const float* S, const cb_v2f (&p)[R / 2], cb_v2f (&y)[R / 2])
 {
     constexpr int NB = (R * R + 15) / 16;
     if constexpr (GI < NG) {
-        if constexpr (GI + 1 < NG) cb_fx_issue<NB, GI + 1>();
-        cb_fx_consume<R, GI>(p, y);
-        if constexpr (GI + 1 < NG) cb_fx_wait();
-        cb_fx_pipe<R, GI + 1, NG>(p, y);
+        if constexpr (GI + 1 < NG) cb_fx_issue<NB, GI + 1>(g, S);
+        cb_fx_consume<R, GI>(g, p, y);
+        if constexpr (GI + 1 < NG) cb_fx_wait<(GI + 1) & 1, cb_fx_nblk<NB, GI + 1>>(g);
+        cb_fx_pipe<R, GI + 1, NG>(g, S, p, y);
     }
 }
 // y = S p  (S symmetric, [R][R] flat)
@@ -163,12 +177,12 @@ __device__ __forceinline__ void cb_matvec_f32(const float* S, const cb_v2f (&p)[
     constexpr int NB = (R * R + 15) / 16, NG = (NB + 1) / 2;
 #pragma unroll
     for (int i = 0; i < R / 2; ++i) y[i] = cb_v2f{0.f, 0.f};
+    cb_fx_regs g;
     asm volatile("; CBFX_BEGIN");
-    cb_fx_base(S);
-    cb_fx_issue<NB, 0>();
-    cb_fx_wait();
-    cb_fx_pipe<R, 0, NG>(p, y);
-    asm volatile("; CBFX_END" : : : CB_CLOB);
+    cb_fx_issue<NB, 0>(g, S);
+    cb_fx_wait<0, cb_fx_nblk<NB, 0>>(g);
+    cb_fx_pipe<R, 0, NG>(g, S, p, y);
+    asm volatile("; CBFX_END");
 }
 
 // exp(a) in fp64, ~1e-14 relative: n = rint(a / ln 2), degree-11 Taylor polynomial on |r| <= ln 2 / 2, ldexp.  19 instructions
@@ -275,15 +289,15 @@ __device__ __forceinline__ float cb_dot(const cb_v2f (&a)[R / 2], const cb_v2f (
     return s.x + s.y;
 }
 
-// Jacobi-preconditioned CG for (S + Diag(D)) x = g, one system per lane.  x is left in x_l[(i / 2) * 64 + lane] (pairs).
+// Jacobi-preconditioned CG for (S + Diag(D)) x = g, one system per lane; x (pairs) stays in registers.
 // `live` lanes iterate until |r|^2 <= tol2 |g|^2; the wave stops when no lane is live.  Returns the wave's trip count.
 template <int R, typename TB>
 __device__ __forceinline__ int cb_cg_solve(const TB& tb, const cb_v2f (&D)[R / 2], const cb_v2f (&dinv)[R / 2],
-                                           const cb_v2f (&g)[R / 2], bool live, cb_v2f* __restrict__ x_l, int lane)
+                                           const cb_v2f (&g)[R / 2], bool live, cb_v2f (&x)[R / 2])
 {
     cb_v2f r[R / 2], pv[R / 2], y[R / 2];
 #pragma unroll
-    for (int i = 0; i < R / 2; ++i) { r[i] = g[i]; pv[i] = g[i] * dinv[i]; x_l[i * 64 + lane] = cb_v2f{0.f, 0.f}; }
+    for (int i = 0; i < R / 2; ++i) { r[i] = g[i]; pv[i] = g[i] * dinv[i]; x[i] = cb_v2f{0.f, 0.f}; }
     const float gg = cb_dot<R>(g, g);
     float rz = cb_dot<R>(r, pv);
     const float thr = fmaxf(tb.cg_tol2 * gg, tb.cg_abs2);
@@ -299,7 +313,7 @@ __device__ __forceinline__ int cb_cg_solve(const TB& tb, const cb_v2f (&D)[R / 2
         const cb_v2f a2 = cb_v2f{alpha, alpha}, na2 = cb_v2f{-alpha, -alpha};
 #pragma unroll
         for (int i = 0; i < R / 2; ++i) {
-            x_l[i * 64 + lane] = __builtin_elementwise_fma(a2, pv[i], x_l[i * 64 + lane]);
+            x[i] = __builtin_elementwise_fma(a2, pv[i], x[i]);
             r[i] = __builtin_elementwise_fma(na2, y[i], r[i]);
             y[i] = r[i] * dinv[i];                                   // z
         }
@@ -369,8 +383,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     struct { const float* S; const float* sdiag; const float* muf; float cg_tol2, cg_abs2; int cg_maxit; } tb = {a.tb.S, a.tb.sdiag, a.tb.muf, a.tb.cg_tol2, a.tb.cg_abs2, a.tb.cg_maxit};
     const int64_t M = a.M;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    double* vs_l = (double*)lds;                         // [R][64] vsq, fp64
-    cb_v2f* x_l = (cb_v2f*)(lds + 2 * R * 64);           // [R / 2][64] CG solution pairs
+    // LDS per wave: lambda in fp64 [R][64], vsq in fp32 [R][64] (the same 13 KB stage the token rows in the token phase, vsq parked in
+    // registers meanwhile), 64 row ids.  Lambda used to live in 104 registers per lane next to five CG vectors and the token rows:
+    // past the 512-entry file, and what the allocator then spilled to scratch was reloaded behind s_waitcnt vmcnt(0) in every phase.
+    double* lam_l = (double*)lds;                        // [R][64] lambda, fp64
+    float* vsf_l = lds + 2 * R * 64;                     // [R][64] vsq, fp32 between the phases (every phase computes on it in fp64)
+    // One base register + an immediate offset per access.  The bases are re-derived from an opaque copy of the lane id at the top
+    // of every phase (CB_VIEW): addresses computed from `lane` itself are sweep-loop invariants, and the compiler hoisted one
+    // address register PER ELEMENT out of the loop (~150 of them) and reloaded them from scratch before every LDS access.
+    double* lamp = lam_l + threadIdx.x;
+    float* vsp = vsf_l + threadIdx.x;
+#define CB_VIEW() do { int ln_ = lane; asm volatile("" : "+v"(ln_)); lamp = lam_l + ln_; vsp = vsf_l + ln_; } while (0)
+#define LAM(i) lamp[(i) * 64]
+#define VSF(i) vsp[(i) * 64]
+#define VSQ(i) ((double)vsp[(i) * 64])
     constexpr int LPR = R / 4;
     const int lane = threadIdx.x;
     const int K = p.K;
@@ -387,7 +413,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     { const int32_t* counts = CB_KARG(const int32_t*, p.counts); for (int n = 0; n < Nmax; ++n) cl += (n < N) ? (float)counts[off + n] : 0.0f; }
     const double Cd = (double)cl;
 
-    double lam[R];
     double lz;
     {
         const float* lam_in = CB_KARG(const float*, p.lambda);
@@ -395,8 +420,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
         for (int i = 0; i < R; ++i) {
             const bool on = i < K;
-            lam[i] = on ? (double)lam_in[(int64_t)d * K + i] : 0.0;
-            vs_l[i * 64 + lane] = on ? (double)vsq_in[(int64_t)d * K + i] : 1.0;
+            LAM(i) = on ? (double)lam_in[(int64_t)d * K + i] : 0.0;
+            VSF(i) = on ? vsq_in[(int64_t)d * K + i] : 1.0f;
         }
         lz = (double)CB_KARG(const float*, p.logzeta)[d];
     }
@@ -416,10 +441,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         // lambda_old of this sweep goes straight to its output array (and is read back for the exit test): 52 more live
         // registers per lane would push the kernel past the 512-entry file, and spills to scratch cost far more than these
         // two strided passes per sweep (measured: 35 000 cycles per Newton step for reloading lambda from scratch)
+        CB_VIEW();
         if (active) {
             float* lam_old_out = CB_KARG(float*, p.lambda_old);
 #pragma unroll
-            for (int i = 0; i < R; ++i) if (i < K) lam_old_out[(int64_t)d * K + i] = (float)lam[i];
+            for (int i = 0; i < R; ++i) if (i < K) lam_old_out[(int64_t)d * K + i] = (float)LAM(i);
         }
         // ---- update_phi!  src/CTM.jl:175-178 in linear space, (phi * counts)_i = e_i sum_n w_n beta[i, t_n]
         float phic[R];
@@ -435,7 +461,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             cb_v2f lf[R / 2], acc[R / 2];
 #pragma unroll
             for (int i = 0; i < R / 2; ++i) {
-                lf[i] = cb_v2f{(2 * i < K) ? (float)lam[2 * i] : -INFINITY, (2 * i + 1 < K) ? (float)lam[2 * i + 1] : -INFINITY};
+                lf[i] = cb_v2f{(2 * i < K) ? (float)LAM(2 * i) : -INFINITY, (2 * i + 1 < K) ? (float)LAM(2 * i + 1) : -INFINITY};
                 acc[i] = cb_v2f{0.f, 0.f};
             }
             // CH steps' rows (and kappa entries) in flight together, the ids / counts / tau of the next CH steps fetched alongside:
@@ -505,11 +531,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         {
             float lmax = -INFINITY;
 #pragma unroll
-            for (int i = 0; i < R; ++i) if (i < K) lmax = fmaxf(lmax, (float)lam[i]);
+            for (int i = 0; i < R; ++i) if (i < K) lmax = fmaxf(lmax, (float)LAM(i));
             cb_v2f e2[R / 2], acc[R / 2];
 #pragma unroll
             for (int i = 0; i < R / 2; ++i) {
-                e2[i] = cb_v2f{(2 * i < K) ? expf((float)lam[2 * i] - lmax) : 0.0f, (2 * i + 1 < K) ? expf((float)lam[2 * i + 1] - lmax) : 0.0f};
+                e2[i] = cb_v2f{(2 * i < K) ? expf((float)LAM(2 * i) - lmax) : 0.0f, (2 * i + 1 < K) ? expf((float)LAM(2 * i + 1) - lmax) : 0.0f};
                 acc[i] = cb_v2f{0.f, 0.f};
             }
             // E keeps the LAST executed sweep's factor e = exp(lambda_old - max) for the statistics pass
@@ -536,8 +562,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             // conflict free).  The row ids travel the other way through a 64-entry LDS table.  VMEM returns in order, so a lane's own
             // ids / counts are fetched two rounds ahead (waiting for a load younger than the rows in flight would drain them).
             constexpr int CH = (R == 52) ? 2 : 4;
-            cb_v4f* xl4 = (cb_v4f*)(lds + 2 * R * 64);               // [64 rows][LPR chunks]
+            cb_v4f* xl4 = (cb_v4f*)vsf_l;                              // [64 rows][LPR chunks]: the vsq region, vsq parked in registers
             int* tl = (int*)(lds + 3 * R * 64);                        // [64] row ids of one step
+            float vpark[R];
+#pragma unroll
+            for (int i = 0; i < R; ++i) vpark[i] = VSF(i);
+            __builtin_amdgcn_wave_barrier();
             int rmap[LPR];
             unsigned cbyte[LPR];
 #pragma unroll
@@ -599,21 +629,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 for (int u = 0; u < CH; ++u) { tq[u] = tn[u]; cq[u] = cn[u]; tn[u] = t2[u]; cn[u] = c2[u]; }
             }
             __builtin_amdgcn_wave_barrier();
+            CB_VIEW();
+#pragma unroll
+            for (int i = 0; i < R; ++i) VSF(i) = vpark[i];
 #pragma unroll
             for (int i = 0; i < R / 2; ++i) { phic[2 * i] = e2[i].x * acc[i].x; phic[2 * i + 1] = e2[i].y * acc[i].y; }
         }
         lap(0);
         // ---- update_logzeta!  src/CTM.jl:169-171
         {
+            CB_VIEW();
             double m = -INFINITY;
 #pragma unroll
-            for (int i = 0; i < R; ++i) if (i < K) m = fmax(m, lam[i] + 0.5 * vs_l[i * 64 + lane]);
+            for (int i = 0; i < R; ++i) if (i < K) m = fmax(m, LAM(i) + 0.5 * VSQ(i));
             double s = 0.0;
             auto lz_chunk = [&](auto tag) {
                 constexpr int i0 = 4 * decltype(tag)::value;
                 double a[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) a[u] = lam[i0 + u] + 0.5 * vs_l[(i0 + u) * 64 + lane] - m;
+                for (int u = 0; u < 4; ++u) a[u] = LAM(i0 + u) + 0.5 * VSQ(i0 + u) - m;
                 cb_exp_n<4>(a);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) if (i0 + u < K) s += a[u];
@@ -628,18 +662,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             auto vsq_group = [&](auto tag) {
                 constexpr int i0 = 4 * decltype(tag)::value;
                 if (i0 >= K) return;
+                CB_VIEW();
                 double vs[4], isd[4];
                 bool act[4];
                 const cb_v4f sd4 = cb_sload4_sync<i0>(tb.sdiag);
+                double lm[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { vs[u] = vs_l[(i0 + u) * 64 + lane]; act[u] = active && (i0 + u < K); }
+                for (int u = 0; u < 4; ++u) { vs[u] = VSQ(i0 + u); lm[u] = LAM(i0 + u); act[u] = active && (i0 + u < K); }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) isd[u] = (double)sd4[u];
                 for (int t = 0; t < p.niter; ++t) {
                     if (!__any(act[0] || act[1] || act[2] || act[3])) break;
                     double ex[4], rv[4], den[4], ihd[4], grad[4], pp[4], rho[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) ex[u] = lam[i0 + u] + 0.5 * vs[u] - lz;
+                    for (int u = 0; u < 4; ++u) ex[u] = lm[u] + 0.5 * vs[u] - lz;
                     cb_exp_n<4>(ex);
                     cb_rcp_n<4>(vs, rv);
 #pragma unroll
@@ -668,7 +704,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     if (active && i0 + u < K) vs[u] += TMVB_EPS_D;                              // :164
-                    vs_l[(i0 + u) * 64 + lane] = vs[u];
+                    VSF(i0 + u) = (float)vs[u];
                 }
             };
             tmvb_static_for<LPR>(vsq_group);
@@ -682,6 +718,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 if (!__any(newt)) break;
                 ++ntrip;
                 if (newt) ++nsteps;
+                CB_VIEW();
                 cb_v2f g[R / 2], D[R / 2], dinv[R / 2];
                 double gn2 = 0.0;
                 {
@@ -697,7 +734,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                         cb_sload64_sync<(R + 15) / 16>(tb.muf, mb);
 #pragma unroll
                         for (int i = 0; i < R; ++i) {
-                            const float v = (float)((double)mb[i / 16][i % 16] - lam[i]);
+                            const float v = (float)((double)mb[i / 16][i % 16] - LAM(i));
                             if (i & 1) dmf[i / 2].y = v; else dmf[i / 2].x = v;
                         }
                     }
@@ -711,7 +748,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                         double ex[4];
                         const cb_v4f sdg = cb_sload4_sync<i0>(tb.sdiag);
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) ex[u] = lam[i0 + u] + 0.5 * vs_l[(i0 + u) * 64 + lane] - lz;
+                        for (int u = 0; u < 4; ++u) ex[u] = LAM(i0 + u) + 0.5 * VSQ(i0 + u) - lz;
                         cb_exp_n<4>(ex);
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
@@ -728,14 +765,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                     tmvb_static_for<LPR>(grad_chunk);
                 }
                 lap(3);
-                ncg += (unsigned)cb_cg_solve<R>(tb, D, dinv, g, newt, x_l, lane);
+                cb_v2f x[R / 2];
+                ncg += (unsigned)cb_cg_solve<R>(tb, D, dinv, g, newt, x);
                 lap(4);
+                CB_VIEW();
                 if (newt) {
 #pragma unroll
-                    for (int i = 0; i < R / 2; ++i) {
-                        const cb_v2f x = x_l[i * 64 + lane];
-                        lam[2 * i] += (double)x.x; lam[2 * i + 1] += (double)x.y;             // :136
-                    }
+                    for (int i = 0; i < R / 2; ++i) { LAM(2 * i) += (double)x[i].x; LAM(2 * i + 1) += (double)x[i].y; }     // :136
                 }
                 if (sqrt(gn2) < p.ntol) newt = false;                                           // :138
                 lap(6);
@@ -745,17 +781,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         lap(1);
         if constexpr (FILT) { run_lambda(); lap(2); run_vsq(); }                    // src/fCTM.jl:239-240
         else { run_vsq(); lap(2); run_lambda(); }                                   // src/CTM.jl:198-199
+        CB_VIEW();
         if (active) {
             const float* lam_old_in = CB_KARG(const float*, p.lambda_old);
             float dist2 = 0.0f;
 #pragma unroll
             for (int i = 0; i < R; ++i) {
-                if (i < K) { const float df = (float)(lam[i] - (double)lam_old_in[(int64_t)d * K + i]); dist2 = fmaf(df, df, dist2); }
+                if (i < K) { const float df = (float)(LAM(i) - (double)lam_old_in[(int64_t)d * K + i]); dist2 = fmaf(df, df, dist2); }
             }
             if (sqrtf(dist2) < (float)p.vtol) active = false;                                   // :200
         }
     }
 
+    CB_VIEW();
     if (valid) {
         if (sweeps > 0) {
             float* lam_out = CB_KARG(float*, p.lambda);
@@ -763,8 +801,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
             for (int i = 0; i < R; ++i) {
                 if (i < K) {
-                    lam_out[(int64_t)d * K + i] = (float)lam[i];
-                    vsq_out[(int64_t)d * K + i] = (float)vs_l[i * 64 + lane];
+                    lam_out[(int64_t)d * K + i] = (float)LAM(i);
+                    vsq_out[(int64_t)d * K + i] = VSF(i);
                 }
             }
             CB_KARG(float*, p.logzeta)[d] = (float)lz;
@@ -795,3 +833,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         }
     }
 }
+#undef LAM
+#undef VSQ
+#undef VSF
+#undef CB_VIEW
