@@ -1158,7 +1158,7 @@ extern "C" int tmvb_ctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
         // (a lane walks its document's tokens one after the other: corpora with documents of thousands of unique terms would
         // serialise on them, so those keep the wave-per-document kernel, which spreads a document's tokens over the lanes)
         // (its token phase addresses the token arrays and the topic table with unsigned 32-bit byte offsets)
-        h->batch = !h->generic && h->KP <= 52 && corp->info.max_doc_len <= 2048 && corp->info.nnz < (1ll << 30) && (int64_t)h->KP * h->V < (1ll << 30) &&
+        h->batch = !h->generic && h->KP <= 52 && corp->info.max_doc_len <= 2048 && corp->info.nnz < (1ll << 30) && (int64_t)h->KP * h->V < (1ll << 30) && h->V < (1 << 24) &&
                    !(e && atoi(e) == 0);
         if (const char* t = getenv("TMVB_CTM_CG_TOL")) h->cg_tol = std::max(1e-7f, (float)atof(t));
         if (const char* t = getenv("TMVB_CTM_CG_ABS")) h->cg_abs = std::max(0.0f, (float)atof(t));

@@ -352,17 +352,17 @@ template <int R>
 __device__ __forceinline__ void cb_token_issue(const __attribute__((address_space(1))) float* tab, int* tl, int lane, const int (&rmap)[R / 4],
                                                const unsigned (&cbyte)[R / 4], int t, cb_v4f (&b)[R / 4])
 {
-    __builtin_amdgcn_wave_barrier();
+    // (LDS operations of one wave execute in program order, and the compiler keeps may-aliasing LDS accesses in order: no barrier)
     tl[lane] = t;
-    __builtin_amdgcn_wave_barrier();
     int tt[R / 4];
 #pragma unroll
     for (int i = 0; i < R / 4; ++i) tt[i] = tl[rmap[i]];
-    // uniform base + unsigned 32-bit byte offset: the SGPR-base form of global_load, one VGPR of address per load (64-bit per-lane
-    // addresses were hoisted out of the token loop as 26 registers, spilled to scratch and reloaded behind s_waitcnt vmcnt(0))
+    // uniform base + unsigned 32-bit byte offset (24-bit multiply: row ids are < 2^24): the SGPR-base form of global_load, one
+    // VGPR of address per load (64-bit per-lane addresses were hoisted out of the token loop as 26 registers, spilled to scratch
+    // and reloaded behind s_waitcnt vmcnt(0))
     const __attribute__((address_space(1))) char* base = (const __attribute__((address_space(1))) char*)tab;
 #pragma unroll
-    for (int i = 0; i < R / 4; ++i) b[i] = *(const __attribute__((address_space(1))) cb_v4f*)(base + ((unsigned)tt[i] * (unsigned)(R * 4) + cbyte[i]));
+    for (int i = 0; i < R / 4; ++i) b[i] = *(const __attribute__((address_space(1))) cb_v4f*)(base + (__umul24((unsigned)tt[i], (unsigned)(R * 4)) + cbyte[i]));
 }
 
 // ---- the kernel: wave w owns documents doc_order[64 w .. 64 w + 63] (sorted by length, so a wave's documents are alike)
@@ -603,7 +603,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                     constexpr int u = decltype(tag)::value;
 #pragma unroll
                     for (int i = 0; i < LPR; ++i) xl4[64 * i + lane] = buf[u][i];
-                    __builtin_amdgcn_wave_barrier();
                     cb_v4f row[LPR];
 #pragma unroll
                     for (int q = 0; q < LPR; ++q) row[q] = xl4[lane * LPR + q];
