@@ -15,8 +15,8 @@
 //
 // Everything else of the per-document chain (update_phi!, update_logzeta!, update_vsq!, the exit tests) is the same
 // arithmetic as ctm_estep_kernel, per lane instead of per wave; loops run until no lane of the wave needs another trip.
-// One wave per SIMD (the 512-entry register file holds the lane's vectors: lambda in fp64, the five CG vectors, the
-// gradient accumulators); vsq (fp64) and the CG solution live in LDS ([topic][lane], conflict free).
+// One wave per SIMD: the 512-entry register file holds the five CG vectors, the CG solution and the gradient accumulators (token
+// phase: the rows in flight); lambda (fp64) and vsq (fp32) live in LDS ([topic][lane], conflict free), see the kernel.
 #pragma once
 
 #include <utility>
