@@ -44,20 +44,24 @@ __device__ __forceinline__ void swap_add16(float& a, float b)
 }
 typedef float v2f_t __attribute__((ext_vector_type(2)));
 
-// two independent swaps under one pair of hazard nops
+// two independent swaps under one pair of hazard nops.  PK: the two sums as one v_pk_add_f32 -- which costs a v_mov_b32 detour per swap
+// pair (the tied asm operand of the pair's second half is not coalesced): worth it for R > 64 (K = 100: 451 vs 437 it/s), two
+// v_add_f32 are better for R <= 64 (K = 50: 851 vs 837 it/s).
+template <bool PK>
 __device__ __forceinline__ void swap_add32_x2(float& a0, float b0, float& a1, float b1)
 {
     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\ts_nop 1"
                  : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1));
-    const v2f_t s = v2f_t{a0, a1} + v2f_t{b0, b1};       // one v_pk_add_f32
-    a0 = s.x; a1 = s.y;
+    if constexpr (PK) { const v2f_t s = v2f_t{a0, a1} + v2f_t{b0, b1}; a0 = s.x; a1 = s.y; }
+    else { a0 += b0; a1 += b1; }
 }
+template <bool PK>
 __device__ __forceinline__ void swap_add16_x2(float& a0, float b0, float& a1, float b1)
 {
     asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 1"
                  : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1));
-    const v2f_t s = v2f_t{a0, a1} + v2f_t{b0, b1};
-    a0 = s.x; a1 = s.y;
+    if constexpr (PK) { const v2f_t s = v2f_t{a0, a1} + v2f_t{b0, b1}; a0 = s.x; a1 = s.y; }
+    else { a0 += b0; a1 += b1; }
 }
 template <int CTRL>
 __device__ __forceinline__ void dpp_stage(float& a, float b, bool hi)
@@ -80,14 +84,14 @@ __device__ __forceinline__ void lane_reduce_scatter(F&& prod2, float (&res)[(R +
     auto stage32 = [&](int j, float& x, float& y) {
         const v2f_t a = prod2(j), b = prod2(j + R / 4);
         x = a.x; y = a.y;
-        swap_add32_x2(x, b.x, y, b.y);
+        swap_add32_x2<(R > 64)>(x, b.x, y, b.y);
     };
 #pragma unroll
     for (int u = 0; u < U / 2; ++u) {
         float ax, ay, bx, by;
         stage32(u, ax, ay);
         stage32(u + H, bx, by);
-        swap_add16_x2(ax, bx, ay, by);
+        swap_add16_x2<(R > 64)>(ax, bx, ay, by);
         p[2 * u] = ax; p[2 * u + 1] = ay;
         if ((u & 1) == 1) __builtin_amdgcn_sched_barrier(0);     // keep later products from being hoisted (register pressure)
     }
