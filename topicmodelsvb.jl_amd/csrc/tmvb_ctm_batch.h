@@ -394,6 +394,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     double* lamp = lam_l + threadIdx.x;
     float* vsp = vsf_l + threadIdx.x;
 #define CB_VIEW() do { int ln_ = lane; asm volatile("" : "+v"(ln_)); lamp = lam_l + ln_; vsp = vsf_l + ln_; } while (0)
+#define CB_LAM_PAD (-1.0e30)
 #define LAM(i) lamp[(i) * 64]
 #define VSF(i) vsp[(i) * 64]
 #define VSQ(i) ((double)vsp[(i) * 64])
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
         for (int i = 0; i < R; ++i) {
             const bool on = i < K;
-            LAM(i) = on ? (double)lam_in[(int64_t)d * K + i] : 0.0;
+            LAM(i) = on ? (double)lam_in[(int64_t)d * K + i] : CB_LAM_PAD;    // pads: exp(pad + ...) == 0 exactly, no i < K tests downstream
             VSF(i) = on ? vsq_in[(int64_t)d * K + i] : 1.0f;
         }
         lz = (double)CB_KARG(const float*, p.logzeta)[d];
@@ -531,11 +532,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         {
             float lmax = -INFINITY;
 #pragma unroll
-            for (int i = 0; i < R; ++i) if (i < K) lmax = fmaxf(lmax, (float)LAM(i));
+            for (int i = 0; i < R; ++i) lmax = fmaxf(lmax, (float)LAM(i));
             cb_v2f e2[R / 2], acc[R / 2];
 #pragma unroll
             for (int i = 0; i < R / 2; ++i) {
-                e2[i] = cb_v2f{(2 * i < K) ? expf((float)LAM(2 * i) - lmax) : 0.0f, (2 * i + 1 < K) ? expf((float)LAM(2 * i + 1) - lmax) : 0.0f};
+                e2[i] = cb_v2f{expf((float)LAM(2 * i) - lmax), expf((float)LAM(2 * i + 1) - lmax)};          // pads: expf(-1e30) = 0
                 acc[i] = cb_v2f{0.f, 0.f};
             }
             // E keeps the LAST executed sweep's factor e = exp(lambda_old - max) for the statistics pass
@@ -640,7 +641,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             CB_VIEW();
             double m = -INFINITY;
 #pragma unroll
-            for (int i = 0; i < R; ++i) if (i < K) m = fmax(m, LAM(i) + 0.5 * VSQ(i));
+            for (int i = 0; i < R; ++i) m = fmax(m, LAM(i) + 0.5 * VSQ(i));
             double s = 0.0;
             auto lz_chunk = [&](auto tag) {
                 constexpr int i0 = 4 * decltype(tag)::value;
@@ -649,7 +650,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 for (int u = 0; u < 4; ++u) a[u] = LAM(i0 + u) + 0.5 * VSQ(i0 + u) - m;
                 cb_exp_n<4>(a);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) if (i0 + u < K) s += a[u];
+                for (int u = 0; u < 4; ++u) s += a[u];                                          // pads add exp(-1e30 - m) = +0
             };
             tmvb_static_for<LPR>(lz_chunk);
             if (active) lz = m + log(s);
@@ -833,6 +834,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     }
 }
 #undef LAM
+#undef CB_LAM_PAD
 #undef VSQ
 #undef VSF
 #undef CB_VIEW
