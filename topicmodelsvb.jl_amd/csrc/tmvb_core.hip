@@ -242,20 +242,74 @@ int tmvb_build_inv_index(tmvb_ctx* ctx, int64_t M, int64_t n_ids, const int64_t*
             }
         }
     }
-    std::vector<int32_t> cid, cb, ce, co, mid, mfirst, mcount;
+    // Chunks (one wave each, 4 per workgroup) and their ORDER.  The statistics pass gathers one row of per-document factors per
+    // posting: 33 MB of rows on SYN-NSF against 4 MB of L2 per XCD, 20 % L2 hits (TCC_HIT / TCC_REQ), the rest from the Infinity
+    // Cache at ~700 cycles.  Postings of an id are sorted by document, so a frequent id's list is cut at the boundaries of NC
+    // document-id CLASSES (<= TMVB_CLASS_DOCS documents each: their rows fit an L2) and the chunks of class x go to workgroups
+    // b = x (mod 8) -- workgroups are handed to the 8 XCDs round robin, so an XCD's L2 sees one class at a time (speed only: any
+    // placement gives the same sums).  Rare ids (< TMVB_CLASS_MIN_POSTINGS postings) stay whole: cutting them would multiply the
+    // waves and the partial-sum slots for a few postings each; they fill the classes' last workgroups and the tail of the launch.
+    struct Chunk { int32_t id, b, e, out; };
+    std::vector<int32_t> mid, mfirst, mcount;
     int64_t slots = 0;
+    int64_t ndocs = 0;
+    for (int64_t d = 0; d < M; ++d) if (in_piece(d)) ++ndocs;
+    static const int class_env = [] { const char* e = getenv("TMVB_STATS_CLASSES"); return e ? atoi(e) : -1; }();
+    static const int64_t class_docs = [] { const char* e = getenv("TMVB_CLASS_DOCS"); return e ? (int64_t)atoi(e) : (int64_t)TMVB_CLASS_DOCS; }();
+    static const int64_t class_min = [] { const char* e = getenv("TMVB_CLASS_MIN_POSTINGS"); return e ? (int64_t)atoi(e) : (int64_t)TMVB_CLASS_MIN_POSTINGS; }();
+    int NC = 8 * (int)((ndocs + 8 * class_docs - 1) / (8 * class_docs));
+    if (class_env >= 0) NC = class_env;
+    if (ndocs < 4 * class_docs && class_env < 0) NC = 0;               // everything fits a couple of L2s anyway
+    std::vector<std::vector<Chunk>> cls((size_t)std::max(NC, 1));
+    std::vector<Chunk> rare;
+    auto doc_class = [&](int64_t d) { return (int)(d * NC / M); };
     for (int64_t j = 0; j < n_ids; ++j) {
-        int64_t a = cnt[j], b = cnt[j + 1];
+        const int64_t a = cnt[j], b = cnt[j + 1];
         if (b == a) continue;
-        int64_t nch = (b - a + TMVB_CHUNK - 1) / TMVB_CHUNK;
+        // segments: the id's postings cut at class boundaries (one segment if the id is rare or classes are off)
+        std::vector<std::pair<int64_t, int>> seg;                             // (begin, class)
+        if (NC > 0 && b - a >= class_min) {
+            int prev = -1;
+            for (int64_t q = a; q < b; ++q) {
+                const int c = doc_class(doc[q]);
+                if (c != prev) { seg.emplace_back(q, c); prev = c; }
+            }
+        } else {
+            seg.emplace_back(a, -1);
+        }
+        int64_t nch = 0;
+        for (size_t g = 0; g < seg.size(); ++g) {
+            const int64_t sa = seg[g].first, sb = g + 1 < seg.size() ? seg[g + 1].first : b;
+            nch += (sb - sa + TMVB_CHUNK - 1) / TMVB_CHUNK;
+        }
         if (nch > 1) { mid.push_back((int32_t)j); mfirst.push_back((int32_t)slots); mcount.push_back((int32_t)nch); }
-        for (int64_t k = 0; k < nch; ++k) {
-            cid.push_back((int32_t)j);
-            cb.push_back((int32_t)(a + k * TMVB_CHUNK));
-            ce.push_back((int32_t)std::min<int64_t>(b, a + (k + 1) * TMVB_CHUNK));
-            co.push_back(nch > 1 ? (int32_t)(slots++) : -1);
+        for (size_t g = 0; g < seg.size(); ++g) {
+            const int64_t sa = seg[g].first, sb = g + 1 < seg.size() ? seg[g + 1].first : b;
+            for (int64_t q = sa; q < sb; q += TMVB_CHUNK) {
+                const Chunk ch{(int32_t)j, (int32_t)q, (int32_t)std::min<int64_t>(sb, q + TMVB_CHUNK), nch > 1 ? (int32_t)(slots++) : -1};
+                if (seg[g].second >= 0) cls[(size_t)seg[g].second].push_back(ch); else rare.push_back(ch);
+            }
         }
     }
+    std::vector<Chunk> order;
+    order.reserve(rare.size() + 64);
+    size_t rare_used = 0;
+    if (NC > 0) {
+        for (auto& L : cls)                                                   // whole workgroups per class: top up with rare chunks
+            while (L.size() % 4 != 0 && rare_used < rare.size()) L.push_back(rare[rare_used++]);
+        for (int r = 0; r < NC / 8; ++r) {
+            size_t maxb = 0;
+            for (int x = 0; x < 8; ++x) maxb = std::max(maxb, (cls[(size_t)(8 * r + x)].size() + 3) / 4);
+            for (size_t k = 0; k < maxb; ++k)
+                for (int x = 0; x < 8; ++x) {
+                    const auto& L = cls[(size_t)(8 * r + x)];
+                    for (size_t u = 4 * k; u < std::min(L.size(), 4 * k + 4); ++u) order.push_back(L[u]);
+                }
+        }
+    }
+    for (; rare_used < rare.size(); ++rare_used) order.push_back(rare[rare_used]);
+    std::vector<int32_t> cid(order.size()), cb(order.size()), ce(order.size()), co(order.size());
+    for (size_t q = 0; q < order.size(); ++q) { cid[q] = order[q].id; cb[q] = order[q].b; ce[q] = order[q].e; co[q] = order[q].out; }
     ix->n_chunks = (int64_t)cid.size(); ix->n_multi = (int64_t)mid.size(); ix->n_slots = slots;
     int rc;
     if ((rc = upload(ctx, &ix->d_doc, doc.data(), doc.size())) || (rc = upload(ctx, &ix->d_pos, pos.data(), pos.size())) ||

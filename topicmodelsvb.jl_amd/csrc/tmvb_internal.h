@@ -65,6 +65,8 @@ struct tmvb_bucket {
 // readers_sortperm / Y_cumsum (:443-472); used by the gather-side statistics kernels, which rebuild
 // phi .* counts' from (w_token, E_doc) instead of reading a materialised phi buffer.
 #define TMVB_CHUNK 256
+#define TMVB_CLASS_DOCS 8192            // documents per class of the statistics pass (tmvb_build_inv_index): 2 MB of 256-byte rows
+#define TMVB_CLASS_MIN_POSTINGS 1024    // ids with fewer postings are not cut at class boundaries
 struct tmvb_inv_index {
     bool built = false;
     int64_t n_ids = 0, nnz = 0;
