@@ -851,16 +851,27 @@ __global__ __launch_bounds__(64) void ctm_scatter_mfma_kernel(const float* __res
 }
 
 // scatter[i*K + j] = sum_w partial[w][tile(i,j)][(i % 32) * 32 + j % 32]  (fixed order)
+// 16 elements x 16 interleaved wave groups per workgroup (one thread per element summed 500 partials in a row on ten CUs: 136 us)
 __global__ __launch_bounds__(256) void ctm_scatter_reduce_kernel(const float* __restrict__ partial, int nwaves, int K, int NB,
                                                                  float* __restrict__ scatter)
 {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= K * K) return;
-    const int i = q / K, j = q - i * K;
-    const size_t tile = (size_t)(i >> 5) * NB + (j >> 5), in = (size_t)(i & 31) * 32 + (j & 31);
+    __shared__ double red[16][17];
+    const int e = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int q = blockIdx.x * 16 + e;
     double s = 0.0;
-    for (int w = 0; w < nwaves; ++w) s += (double)partial[((size_t)w * NB * NB + tile) * 1024 + in];
-    scatter[q] = (float)s;
+    if (q < K * K) {
+        const int i = q / K, j = q - i * K;
+        const size_t tile = (size_t)(i >> 5) * NB + (j >> 5), in = (size_t)(i & 31) * 32 + (j & 31);
+        for (int w = g; w < nwaves; w += 16) s += (double)partial[((size_t)w * NB * NB + tile) * 1024 + in];
+    }
+    red[g][e] = s;
+    __syncthreads();
+    if (g == 0 && q < K * K) {
+        double t = 0.0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t += red[u][e];
+        scatter[q] = (float)t;
+    }
 }
 
 // update_sigma! (src/CTM.jl:108-111) then update_mu! (:102-104), one workgroup, fp64:
@@ -1055,12 +1066,13 @@ struct tmvb_ctm {
     double* d_sigma = nullptr; double* d_invsigma = nullptr; double* d_mu = nullptr; double* d_logdet = nullptr;
     float* d_scatter_partial = nullptr; int n_scatter_waves = 0; int64_t docs_per_wave = 0;
     uint8_t* d_sweeps = nullptr; int32_t* d_doc_order = nullptr;
-    double* d_partial = nullptr; double* d_rowsum = nullptr; double* d_doc_val = nullptr; double* d_elbo = nullptr;
+    double* d_partial = nullptr; double* d_partial_docs = nullptr; double* d_rowsum = nullptr; double* d_doc_val = nullptr; double* d_elbo = nullptr;
     unsigned long long* d_newton = nullptr; int* d_status = nullptr;
     double elbo = 0.0;
     std::vector<tmvb_bucket> buckets;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    bool tail_fresh = false;           // the statistics tail (sum lambda | sum vsq | scatter) was computed by the last tmvb_ctm_estep
     static constexpr int NAUX = 4;
     hipStream_t aux[NAUX] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[NAUX] = {nullptr, nullptr, nullptr, nullptr};
@@ -1081,7 +1093,7 @@ extern "C" int tmvb_ctm_destroy(tmvb_ctm* h)
     (void)hipFree(h->d_bt_sdiag); (void)hipFree(h->d_bt_muf); (void)hipFree(h->d_cg_iters); (void)hipFree(h->d_doc_newton); (void)hipFree(h->d_doc_order0);
     (void)hipFree(h->d_mu_f); (void)hipFree(h->d_sigma); (void)hipFree(h->d_invsigma); (void)hipFree(h->d_mu);
     (void)hipFree(h->d_logdet); (void)hipFree(h->d_scatter_partial); (void)hipFree(h->d_sweeps); (void)hipFree(h->d_doc_order);
-    (void)hipFree(h->d_partial); (void)hipFree(h->d_rowsum); (void)hipFree(h->d_doc_val); (void)hipFree(h->d_elbo);
+    (void)hipFree(h->d_partial); (void)hipFree(h->d_partial_docs); (void)hipFree(h->d_rowsum); (void)hipFree(h->d_doc_val); (void)hipFree(h->d_elbo);
     (void)hipFree(h->d_newton); (void)hipFree(h->d_status);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -1120,6 +1132,8 @@ extern "C" int tmvb_ctm_set_state(tmvb_ctm* h, const double* mu, const double* s
                                   const double* beta, const double* beta_old, const double* lambda,
                                   const double* lambda_old, const double* vsq, const double* logzeta, const double* elbo);
 
+static int ctm_reduce_docs_on(tmvb_ctm* h, hipStream_t st);
+
 extern "C" int tmvb_ctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb_ctm** out)
 {
     TMVB_REQUIRE(out != nullptr, TMVB_EINVAL, "tmvb_ctm_create: out is NULL");
@@ -1147,7 +1161,8 @@ extern "C" int tmvb_ctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
         (rc = dmalloc(&h->d_sigma, (size_t)K * K)) || (rc = dmalloc(&h->d_invsigma, (size_t)K * K)) || (rc = dmalloc(&h->d_mu, K)) ||
         (rc = dmalloc(&h->d_logdet, 1)) || (rc = dmalloc(&h->d_scatter_partial, (size_t)h->n_scatter_waves * h->NB * h->NB * 1024)) ||
         (rc = dmalloc(&h->d_sweeps, (size_t)h->M)) || (rc = dmalloc(&h->d_doc_order, (size_t)h->M)) ||
-        (rc = dmalloc(&h->d_partial, (size_t)TMVB_REDUCE_BLOCKS * K)) || (rc = dmalloc(&h->d_rowsum, K)) ||
+        (rc = dmalloc(&h->d_partial, (size_t)TMVB_REDUCE_BLOCKS * K)) || (rc = dmalloc(&h->d_partial_docs, (size_t)TMVB_REDUCE_BLOCKS * K)) ||
+        (rc = dmalloc(&h->d_rowsum, K)) ||
         (rc = dmalloc(&h->d_doc_val, (size_t)h->M)) || (rc = dmalloc(&h->d_elbo, 1)) || (rc = dmalloc(&h->d_newton, 1)) ||
         (rc = dmalloc(&h->d_status, 1))) {
         return rc;
@@ -1237,6 +1252,7 @@ extern "C" int tmvb_ctm_set_state(tmvb_ctm* h, const double* mu, const double* s
                                   const double* lambda_old, const double* vsq, const double* logzeta, const double* elbo)
 {
     TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_ctm_set_state: handle is NULL");
+    h->tail_fresh = false;
     tmvb_ctx* ctx = h->ctx;
     TMVB_HIP(hipSetDevice(ctx->device));
     const size_t K = h->K, KP = h->KP, KM = K * (size_t)h->M;
@@ -1391,12 +1407,25 @@ extern "C" int tmvb_ctm_estep(tmvb_ctm* h, int32_t niter, double ntol, int32_t v
             TMVB_HIP(hipStreamWaitEvent(ctx->stream, h->ev_join[a], 0));
         }
     }
+    // The document reductions of tmvb_ctm_reduce_docs (sum lambda, sum vsq, the scatter matrix with the current mu: 0.15 ms of small
+    // kernels) depend only on what the document kernels just wrote: they run here on a side stream under the statistics pass, and
+    // tmvb_ctm_reduce_docs finds them done (tail_fresh; any change of lambda / vsq / mu through the API clears the flag).
+    static const bool fold = [] { const char* e = getenv("TMVB_CTM_FOLD_REDUCE"); return !(e && atoi(e) == 0); }();
+    const bool folded = fold && h->M > 0 && h->aux[0] != nullptr;
+    if (folded) {
+        TMVB_HIP(hipEventRecord(h->ev_fork, ctx->stream));
+        TMVB_HIP(hipStreamWaitEvent(h->aux[0], h->ev_fork, 0));
+        int frc = ctm_reduce_docs_on(h, h->aux[0]);
+        if (frc) return frc;
+        TMVB_HIP(hipEventRecord(h->ev_join[0], h->aux[0]));
+    }
     // update_beta!(model, d)  src/CTM.jl:122-125 as the gather-side statistics pass (no epsilon in CTM's phi)
     TermStatsParams tp;
     tp.K = h->K; tp.tstride = h->KP; tp.ostride = h->K;
     tp.w = h->d_wtok; tp.E = h->d_E; tp.T = h->d_beta[h->cur]; tp.eps = 0.0f; tp.base = 0.0f; tp.keps = 0.0f;
     tp.out = h->d_stats; tp.partial = h->d_ts_partial;
     int rc = tmvb_launch_termstats(ctx, h->nslot, h->KP, true, h->corp->term_index, tp);
+    if (folded) { TMVB_HIP(hipStreamWaitEvent(ctx->stream, h->ev_join[0], 0)); h->tail_fresh = (rc == TMVB_OK); }
     if (rc) return rc;
     TMVB_HIP(hipEventRecord(h->ev1, ctx->stream));
     h->timed = true;
@@ -1404,25 +1433,32 @@ extern "C" int tmvb_ctm_estep(tmvb_ctm* h, int32_t niter, double ntol, int32_t v
 }
 
 // sum_d lambda_d, sum_d vsq_d and the scatter matrix (with the CURRENT = previous-iteration mu) into the statistics tail
-extern "C" int tmvb_ctm_reduce_docs(tmvb_ctm* h)
+static int ctm_reduce_docs_on(tmvb_ctm* h, hipStream_t st)
 {
-    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_ctm_reduce_docs: handle is NULL");
     tmvb_ctx* ctx = h->ctx;
-    TMVB_HIP(hipSetDevice(ctx->device));
     int rc;
-    if ((rc = tmvb_colsum(ctx, h->nslot, h->K, h->d_lambda, h->M, h->d_partial, nullptr, h->tail()))) return rc;
-    if ((rc = tmvb_colsum(ctx, h->nslot, h->K, h->d_vsq, h->M, h->d_partial, nullptr, h->tail() + h->K))) return rc;
+    if ((rc = tmvb_colsum(ctx, h->nslot, h->K, h->d_lambda, h->M, h->d_partial_docs, nullptr, h->tail(), st))) return rc;
+    if ((rc = tmvb_colsum(ctx, h->nslot, h->K, h->d_vsq, h->M, h->d_partial_docs, nullptr, h->tail() + h->K, st))) return rc;
     if (h->M > 0) {
-        hipLaunchKernelGGL(ctm_scatter_mfma_kernel, dim3(h->n_scatter_waves, h->NB * h->NB), dim3(64), 0, ctx->stream, h->d_lambda, h->d_mu_f,
+        hipLaunchKernelGGL(ctm_scatter_mfma_kernel, dim3(h->n_scatter_waves, h->NB * h->NB), dim3(64), 0, st, h->d_lambda, h->d_mu_f,
                            h->K, h->NB, h->M, h->docs_per_wave, h->d_scatter_partial);
         TMVB_HIP(hipGetLastError());
-        hipLaunchKernelGGL(ctm_scatter_reduce_kernel, dim3((h->K * h->K + 255) / 256), dim3(256), 0, ctx->stream, h->d_scatter_partial,
+        hipLaunchKernelGGL(ctm_scatter_reduce_kernel, dim3((h->K * h->K + 15) / 16), dim3(256), 0, st, h->d_scatter_partial,
                            h->n_scatter_waves, h->K, h->NB, h->tail() + 2 * h->K);
         TMVB_HIP(hipGetLastError());
     } else {
-        TMVB_HIP(hipMemsetAsync(h->tail() + 2 * h->K, 0, (size_t)h->K * h->K * sizeof(float), ctx->stream));
+        TMVB_HIP(hipMemsetAsync(h->tail() + 2 * h->K, 0, (size_t)h->K * h->K * sizeof(float), st));
     }
     return TMVB_OK;
+}
+
+extern "C" int tmvb_ctm_reduce_docs(tmvb_ctm* h)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_ctm_reduce_docs: handle is NULL");
+    TMVB_HIP(hipSetDevice(h->ctx->device));
+    // tmvb_ctm_estep already computed the tail (on a side stream, under its statistics pass) from the state it left behind
+    if (h->tail_fresh) { h->tail_fresh = false; return TMVB_OK; }
+    return ctm_reduce_docs_on(h, h->ctx->stream);
 }
 
 extern "C" int tmvb_ctm_stats(tmvb_ctm* h, void** dev_ptr, int64_t* n_f32)
@@ -1492,6 +1528,7 @@ extern "C" int tmvb_ctm_update_sigma(tmvb_ctm* h)
 extern "C" int tmvb_ctm_update_mu(tmvb_ctm* h)
 {
     TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_ctm_update_mu: handle is NULL");
+    h->tail_fresh = false;                 // the scatter matrix of the tail was taken about the mu that changes now
     return ctm_sigma_mu(h, 0, 1);
 }
 
