@@ -284,7 +284,9 @@ int tmvb_ctm_get_state(tmvb_ctm* h, double* mu, double* sigma, double* invsigma,
  * src/gpuCTM.jl:478-479, :425, :390, :342, :254).  Asynchronous on the context's stream. */
 int tmvb_ctm_estep(tmvb_ctm* h, int32_t niter, double ntol, int32_t viter, double vtol);
 /* sum_d lambda_d, sum_d vsq_d and the scatter matrix sum_d (lambda_d - mu)(lambda_d - mu)^T (f32 MFMA) with
- * the current (= previous-iteration) mu, into the statistics tail. */
+ * the current (= previous-iteration) mu, into the statistics tail.  tmvb_ctm_estep already computes them on a side
+ * stream under its statistics pass; the call then only acknowledges that result (it recomputes on the context's stream
+ * when lambda / vsq / mu were changed through the API since, or when no E-step came before). */
 int tmvb_ctm_reduce_docs(tmvb_ctm* h);
 /* Packed statistics for the host's all-reduce: float32 [ S (K*V) | sum_lambda (K) | sum_vsq (K) | scatter (K*K) ]. */
 int tmvb_ctm_stats(tmvb_ctm* h, void** dev_ptr, int64_t* n_f32);
