@@ -303,6 +303,7 @@ __global__ __launch_bounds__(64) void ctpf_estep_reg_kernel(CtpfParams p, int64_
     float gim_old = gim, zay_old = zay;
     float e[1] = {0.f}, f[1] = {0.f}, ea = 0.f, eb = 0.f;
 
+    __shared__ __attribute__((aligned(16))) float ef_lds[2][R];
     int sweeps = 0;
     for (int v = 0; v < p.viter; ++v) {
         ++sweeps;
@@ -315,12 +316,25 @@ __global__ __launch_bounds__(64) void ctpf_estep_reg_kernel(CtpfParams p, int64_
         ea = on ? fast_exp(a - mab) : 0.f;
         eb = on ? fast_exp(b - mab) : 0.f;
         f[0] = ea + eb;
+        // The factors e, f = ea + eb reach all lanes through LDS (one ds_write each, uniform-address ds_read_b128) instead of two
+        // v_readlane per topic: the broadcast leaves the saturated VALU (113 of the sweep's 844 instructions) for the idle LDS pipe,
+        // as in lda_estep_reg_body.  Pad topics carry 0.
+        if (mytopic >= 0 && mytopic < R) { ef_lds[0][mytopic] = e[0]; ef_lds[1][mytopic] = f[0]; }
+        WAVE_LDS_FENCE();
         // terms
         v2f sacc[T][2];
 #pragma unroll
         for (int t = 0; t < T; ++t) { sacc[t][0] = v2f{0.f, 0.f}; sacc[t][1] = v2f{0.f, 0.f}; }
-        regtile_phase1_block<R, T, 0>(A2, e, sacc);
-        if constexpr (R > 32) regtile_phase1_block<R, T, 32>(A2, e, sacc);
+#pragma unroll
+        for (int j = 0; j < LPR; ++j) {
+            const float4 ev = ((const float4*)ef_lds[0])[j];
+            const v2f e0 = v2f{ev.x, ev.y}, e1 = v2f{ev.z, ev.w};
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                sacc[t][0] = __builtin_elementwise_fma(A2[t][2 * j], e0, sacc[t][0]);
+                sacc[t][1] = __builtin_elementwise_fma(A2[t][2 * j + 1], e1, sacc[t][1]);
+            }
+        }
         float w[T];
 #pragma unroll
         for (int t = 0; t < T; ++t) {
@@ -336,8 +350,12 @@ __global__ __launch_bounds__(64) void ctpf_estep_reg_kernel(CtpfParams p, int64_
         }, G, lane);
         // readers
         v2f hacc[1][2] = {{v2f{0.f, 0.f}, v2f{0.f, 0.f}}};
-        regtile_phase1_block<R, 1, 0>(H2, f, hacc);
-        if constexpr (R > 32) regtile_phase1_block<R, 1, 32>(H2, f, hacc);
+#pragma unroll
+        for (int j = 0; j < LPR; ++j) {
+            const float4 fv = ((const float4*)ef_lds[1])[j];
+            hacc[0][0] = __builtin_elementwise_fma(H2[0][2 * j], v2f{fv.x, fv.y}, hacc[0][0]);
+            hacc[0][1] = __builtin_elementwise_fma(H2[0][2 * j + 1], v2f{fv.z, fv.w}, hacc[0][1]);
+        }
         const v2f hs = hacc[0][0] + hacc[0][1];
         const float wr = fast_div(rr, hs.x + hs.y);
         float Hh[1];
