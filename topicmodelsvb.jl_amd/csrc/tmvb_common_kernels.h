@@ -432,6 +432,40 @@ static inline int tmvb_launch_termstats(tmvb_ctx* ctx, int nslot, int KP, bool e
     return TMVB_OK;
 }
 
+// Two statistics passes over two inverted indices in one pair of launches (recompute variant only; returns TMVB_EINVAL otherwise so
+// that the caller can fall back to two launches): see termstats_recompute2_kernel.
+static inline int tmvb_launch_termstats2(tmvb_ctx* ctx, int nslot, int KP, const tmvb_inv_index& ix0, TermStatsParams tp0,
+                                         const tmvb_inv_index& ix1, TermStatsParams tp1)
+{
+    const int lpr = KP / 4;
+    if (!(lpr <= 32) || ix0.n_chunks <= 0 || ix1.n_chunks <= 0) return TMVB_EINVAL;
+    hipStream_t st = ctx->stream;
+    auto fill = [](TermStatsParams& tp, const tmvb_inv_index& ix) {
+        tp.tok_doc = ix.d_doc; tp.tok_pos = ix.d_pos; tp.chunk_id = ix.d_chunk_id; tp.chunk_begin = ix.d_chunk_begin;
+        tp.chunk_end = ix.d_chunk_end; tp.chunk_out = ix.d_chunk_out; tp.n_chunks = (int)ix.n_chunks; tp.tok_val = ix.d_val;
+    };
+    fill(tp0, ix0); fill(tp1, ix1);
+    const dim3 grid((unsigned)((std::max(ix0.n_chunks, ix1.n_chunks) + 3) / 4), 2), block(256);
+    if (lpr == 13) hipLaunchKernelGGL((termstats_recompute2_kernel<13, 16>), grid, block, 0, st, tp0, tp1, lpr);
+    else if (lpr == 25) hipLaunchKernelGGL((termstats_recompute2_kernel<25, 32>), grid, block, 0, st, tp0, tp1, lpr);
+    else if (lpr <= 16) hipLaunchKernelGGL((termstats_recompute2_kernel<0, 16>), grid, block, 0, st, tp0, tp1, lpr);
+    else hipLaunchKernelGGL((termstats_recompute2_kernel<0, 32>), grid, block, 0, st, tp0, tp1, lpr);
+    TMVB_HIP(hipGetLastError());
+    const int64_t nm = std::max(ix0.n_multi, ix1.n_multi);
+    if (nm > 0) {
+        const TermStatsMulti m0{ix0.d_multi_id, ix0.d_multi_first, ix0.d_multi_count, (int)ix0.n_multi};
+        const TermStatsMulti m1{ix1.d_multi_id, ix1.d_multi_first, ix1.d_multi_count, (int)ix1.n_multi};
+        int rc = dispatch_nslot(nslot, [&](auto ns) -> int {
+            constexpr int NS = decltype(ns)::value;
+            hipLaunchKernelGGL((termstats_multi2_kernel<NS>), dim3((unsigned)nm, 2), dim3(256), 0, st, tp0, m0, tp1, m1);
+            return TMVB_OK;
+        });
+        if (rc) return rc;
+        TMVB_HIP(hipGetLastError());
+    }
+    return TMVB_OK;
+}
+
 // LDS-tile buckets for the documents of `order` (sorted by descending length) that are longer than
 // `min_len_exclusive`; `extra_rows` = per-row side arrays (floats) next to the KP-float tile row.
 // Returns the number of documents bucketed (a prefix of `order`).

@@ -927,16 +927,26 @@ extern "C" int tmvb_ctpf_estep(tmvb_ctpf* h, int32_t viter, double vtol)
     TermStatsParams tp;
     tp.K = h->K; tp.tstride = h->KP; tp.ostride = h->K; tp.eps = 0.0f; tp.base = 0.0f; tp.keps = 0.0f; tp.partial = h->d_ts_partial;
     tp.w = h->d_wtok; tp.E = h->d_E1; tp.T = h->d_TA; tp.out = h->d_stats;
-    // the two passes are independent (alef / he statistics): the reader pass runs on aux[0] under the term pass
-    TMVB_HIP(hipEventRecord(h->ev_fork, ctx->stream));
-    int rc = tmvb_launch_termstats(ctx, h->nslot, h->KP, true, h->corp->term_index, tp);
-    if (rc) return rc;
-    if (h->U > 0) {
-        tp.w = h->d_wrdr; tp.E = h->d_E2; tp.T = h->d_TH; tp.out = h->he_stats(); tp.partial = h->d_ts_partial2;
-        TMVB_HIP(hipStreamWaitEvent(h->aux[0], h->ev_fork, 0));
-        if ((rc = tmvb_launch_termstats(ctx, h->nslot, h->KP, true, h->corp->reader_index, tp, h->aux[0]))) return rc;
-        TMVB_HIP(hipEventRecord(h->ev_join[0], h->aux[0]));
-        TMVB_HIP(hipStreamWaitEvent(ctx->stream, h->ev_join[0], 0));
+    // the two passes are independent (alef / he statistics): one launch with the pass as blockIdx.y (recompute variant), else the
+    // reader pass on aux[0] under the term pass
+    TermStatsParams tr = tp;
+    tr.w = h->d_wrdr; tr.E = h->d_E2; tr.T = h->d_TH; tr.out = h->he_stats(); tr.partial = h->d_ts_partial2;
+    static const bool fuse_env = [] { const char* e = getenv("TMVB_CTPF_FUSE_STATS"); return !(e && atoi(e) == 0); }();
+    int rc = TMVB_EINVAL;
+    if (fuse_env && h->U > 0 && tmvb_termstats_recomputes(h->KP, true))
+        rc = tmvb_launch_termstats2(ctx, h->nslot, h->KP, h->corp->term_index, tp, h->corp->reader_index, tr);
+    if (rc == TMVB_EINVAL) {
+        TMVB_HIP(hipEventRecord(h->ev_fork, ctx->stream));
+        rc = tmvb_launch_termstats(ctx, h->nslot, h->KP, true, h->corp->term_index, tp);
+        if (rc) return rc;
+        if (h->U > 0) {
+            TMVB_HIP(hipStreamWaitEvent(h->aux[0], h->ev_fork, 0));
+            if ((rc = tmvb_launch_termstats(ctx, h->nslot, h->KP, true, h->corp->reader_index, tr, h->aux[0]))) return rc;
+            TMVB_HIP(hipEventRecord(h->ev_join[0], h->aux[0]));
+            TMVB_HIP(hipStreamWaitEvent(ctx->stream, h->ev_join[0], 0));
+        }
+    } else if (rc) {
+        return rc;
     }
     TMVB_HIP(hipEventRecord(h->ev1, ctx->stream));
     h->timed = true;

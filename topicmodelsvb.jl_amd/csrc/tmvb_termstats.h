@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void termstats_chunk4_kernel(TermStatsParams p
 // slot (LPR active), 64 / LANES row slots per wave instruction; the dot product is a 4-step DPP row reduction
 // (+ one v_permlane16_swap step joining the two 16-lane rows of a 32-lane slot).
 template <int LPR_T, int LANES>
-__global__ __launch_bounds__(256) void termstats_recompute_kernel(TermStatsParams p, int LPR_rt)
+__device__ __forceinline__ void termstats_recompute_body(const TermStatsParams& p, int LPR_rt)
 {
     static_assert(LANES == 16 || LANES == 32, "termstats_recompute_kernel: 16 or 32 lanes per row slot");
     constexpr int SLOTS = 64 / LANES;
@@ -262,14 +262,27 @@ __global__ __launch_bounds__(256) void termstats_recompute_kernel(TermStatsParam
     }
 }
 
+template <int LPR_T, int LANES>
+__global__ __launch_bounds__(256) void termstats_recompute_kernel(TermStatsParams p, int LPR_rt)
+{
+    termstats_recompute_body<LPR_T, LANES>(p, LPR_rt);
+}
+// Two independent passes (CTPF: the term index and the reader index) in ONE launch, blockIdx.y selects the pass: run on two streams
+// they cost a ~19 us cross-stream join in a 0.3 ms iteration.
+template <int LPR_T, int LANES>
+__global__ __launch_bounds__(256) void termstats_recompute2_kernel(TermStatsParams p0, TermStatsParams p1, int LPR_rt)
+{
+    if (blockIdx.y == 0) termstats_recompute_body<LPR_T, LANES>(p0, LPR_rt);
+    else termstats_recompute_body<LPR_T, LANES>(p1, LPR_rt);
+}
+
 // ids whose tokens span several chunks: one workgroup per id, its 4 waves sum interleaved partial
 // slots, then wave 0 combines the 4 sums in a fixed order (deterministic)
 template <int NSLOT>
-__global__ __launch_bounds__(256) void termstats_multi_kernel(TermStatsParams p, const int32_t* __restrict__ multi_id,
-                                                              const int32_t* __restrict__ multi_first,
-                                                              const int32_t* __restrict__ multi_count, int n_multi)
+__device__ __forceinline__ void termstats_multi_body(const TermStatsParams& p, const int32_t* __restrict__ multi_id,
+                                                     const int32_t* __restrict__ multi_first,
+                                                     const int32_t* __restrict__ multi_count, int n_multi, float (&red)[4][64 * NSLOT + 1])
 {
-    __shared__ float red[4][64 * NSLOT + 1];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int m = blockIdx.x;
     if (m >= n_multi) return;
@@ -303,4 +316,21 @@ __global__ __launch_bounds__(256) void termstats_multi_kernel(TermStatsParams p,
             p.out[(int64_t)j * p.ostride + i] += p.base + fmaf(p.T[(int64_t)j * p.tstride + i], a, p.eps * ws);
         }
     }
+}
+
+template <int NSLOT>
+__global__ __launch_bounds__(256) void termstats_multi_kernel(TermStatsParams p, const int32_t* __restrict__ multi_id,
+                                                              const int32_t* __restrict__ multi_first,
+                                                              const int32_t* __restrict__ multi_count, int n_multi)
+{
+    __shared__ float red[4][64 * NSLOT + 1];
+    termstats_multi_body<NSLOT>(p, multi_id, multi_first, multi_count, n_multi, red);
+}
+struct TermStatsMulti { const int32_t* id; const int32_t* first; const int32_t* count; int n; };
+template <int NSLOT>
+__global__ __launch_bounds__(256) void termstats_multi2_kernel(TermStatsParams p0, TermStatsMulti m0, TermStatsParams p1, TermStatsMulti m1)
+{
+    __shared__ float red[4][64 * NSLOT + 1];
+    if (blockIdx.y == 0) termstats_multi_body<NSLOT>(p0, m0.id, m0.first, m0.count, m0.n, red);
+    else termstats_multi_body<NSLOT>(p1, m1.id, m1.first, m1.count, m1.n, red);
 }
