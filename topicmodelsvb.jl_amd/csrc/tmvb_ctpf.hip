@@ -252,13 +252,13 @@ __global__ __launch_bounds__(64) void ctpf_estep_kernel(CtpfParams p, int64_t fi
 // with e, ea, eb = exp(psi(.) - log rates - max) as in ctpf_estep_kernel.  A lane past the last term / reader
 // carries count 0 (its weight is exactly 0), so the tiles are loaded without branches.
 template <int LPR, int T>
-__global__ __launch_bounds__(64) void ctpf_estep_reg_kernel(CtpfParams p, int64_t first, const int* __restrict__ topic_of_lane)
+__device__ __forceinline__ void ctpf_estep_reg_body(const CtpfParams& p, const int d, const int* __restrict__ topic_of_lane,
+                                                    float (&ef_lds)[2][4 * LPR])
 {
     constexpr int R = 4 * LPR;
     static_assert(R <= 64, "ctpf_estep_reg_kernel: one result slot per lane");
     const int lane = threadIdx.x;
     const int K = p.K;
-    const int d = p.doc_order[first + blockIdx.x];
     const int64_t off = p.doc_ptr[d], roff = p.rdr_ptr[d];
     const int N = (int)(p.doc_ptr[d + 1] - off), Rd = (int)(p.rdr_ptr[d + 1] - roff);
 
@@ -303,7 +303,6 @@ __global__ __launch_bounds__(64) void ctpf_estep_reg_kernel(CtpfParams p, int64_
     float gim_old = gim, zay_old = zay;
     float e[1] = {0.f}, f[1] = {0.f}, ea = 0.f, eb = 0.f;
 
-    __shared__ __attribute__((aligned(16))) float ef_lds[2][R];
     int sweeps = 0;
     for (int v = 0; v < p.viter; ++v) {
         ++sweeps;
@@ -383,10 +382,29 @@ __global__ __launch_bounds__(64) void ctpf_estep_reg_kernel(CtpfParams p, int64_
     if (lane == 0) p.sweeps[d] = (uint8_t)min(sweeps, 255);
 }
 
+template <int LPR, int T>
+__global__ __launch_bounds__(64) void ctpf_estep_reg_kernel(CtpfParams p, int64_t first, const int* __restrict__ topic_of_lane)
+{
+    __shared__ __attribute__((aligned(16))) float ef_lds[2][4 * LPR];
+    ctpf_estep_reg_body<LPR, T>(p, p.doc_order[first + blockIdx.x], topic_of_lane, ef_lds);
+}
+// Both register-tile buckets in one launch, the tile count read per document (wave-uniform): one kernel tail and one kernel
+// boundary fewer in a 0.3 ms iteration; both bodies run two waves per SIMD, so the wider allocation costs nothing.
+template <int LPR>
+__global__ __launch_bounds__(64) void ctpf_estep_reg_any_kernel(CtpfParams p, int64_t first, const int* __restrict__ topic_of_lane)
+{
+    __shared__ __attribute__((aligned(16))) float ef_lds[2][4 * LPR];
+    const int d = p.doc_order[first + blockIdx.x];
+    const int N = __builtin_amdgcn_readfirstlane((int)(p.doc_ptr[d + 1] - p.doc_ptr[d]));
+    if (N > 64) ctpf_estep_reg_body<LPR, 2>(p, d, topic_of_lane, ef_lds);
+    else ctpf_estep_reg_body<LPR, 1>(p, d, topic_of_lane, ef_lds);
+}
+
 template <int LPR>
 static void ctpf_launch_reg(int tiles, dim3 grid, hipStream_t st, const CtpfParams& p, int64_t first, const int* tol)
 {
-    if (tiles <= 1) hipLaunchKernelGGL((ctpf_estep_reg_kernel<LPR, 1>), grid, dim3(64), 0, st, p, first, tol);
+    if (tiles == 99) hipLaunchKernelGGL((ctpf_estep_reg_any_kernel<LPR>), grid, dim3(64), 0, st, p, first, tol);
+    else if (tiles <= 1) hipLaunchKernelGGL((ctpf_estep_reg_kernel<LPR, 1>), grid, dim3(64), 0, st, p, first, tol);
     else hipLaunchKernelGGL((ctpf_estep_reg_kernel<LPR, 2>), grid, dim3(64), 0, st, p, first, tol);
 }
 
@@ -892,11 +910,19 @@ extern "C" int tmvb_ctpf_estep(tmvb_ctpf* h, int32_t viter, double vtol)
     for (int a = h->reg_path ? 1 : 0; a < 2; ++a) TMVB_HIP(hipStreamWaitEvent(h->aux[a], h->ev_fork, 0));
     for (int bi = 0; bi < nb; ++bi) {
         const tmvb_bucket& b = h->buckets[bi];
-        const dim3 grid((unsigned)b.count), block(64);
+        dim3 grid((unsigned)b.count), block(64);
         if (b.reg_tiles > 0) {
             hipStream_t st = chain_st;
+            // two adjacent register-tile buckets (T = 2 then T = 1 in processing order): one mixed-tile launch
+            static const bool any_env = [] { const char* e = getenv("TMVB_CTPF_REG_ANY"); return !(e && atoi(e) == 0); }();
+            int tiles = b.reg_tiles;
+            if (any_env && bi + 1 < nb && h->buckets[bi + 1].reg_tiles > 0 && h->buckets[bi + 1].first == b.first + b.count) {
+                grid = dim3((unsigned)(b.count + h->buckets[bi + 1].count));
+                tiles = 99;
+                ++bi;
+            }
             switch (p.LPR) {
-#define CTPF_REG_CASE(LPRV) case LPRV: ctpf_launch_reg<LPRV>(b.reg_tiles, grid, st, p, b.first, h->d_topic_of_lane); break;
+#define CTPF_REG_CASE(LPRV) case LPRV: ctpf_launch_reg<LPRV>(tiles, grid, st, p, b.first, h->d_topic_of_lane); break;
                 CTPF_REG_CASE(1) CTPF_REG_CASE(3) CTPF_REG_CASE(5) CTPF_REG_CASE(7) CTPF_REG_CASE(9) CTPF_REG_CASE(11) CTPF_REG_CASE(13)
                 CTPF_REG_CASE(15)
 #undef CTPF_REG_CASE
