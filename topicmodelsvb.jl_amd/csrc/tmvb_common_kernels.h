@@ -383,13 +383,14 @@ static __global__ __launch_bounds__(256) void colsum2_final_kernel(tmvb_colsum_j
 
 // same partition of the columns over TMVB_REDUCE_BLOCKS blocks for both jobs (a job with fewer columns just has idle blocks),
 // hence the same summation order as tmvb_colsum with that block count
-static inline int tmvb_colsum2(tmvb_ctx* ctx, int K, tmvb_colsum_job j0, tmvb_colsum_job j1)
+static inline int tmvb_colsum2(tmvb_ctx* ctx, int K, tmvb_colsum_job j0, tmvb_colsum_job j1, hipStream_t on_stream = nullptr)
 {
     TMVB_REQUIRE(K <= 64, TMVB_EINVAL, "tmvb_colsum2: K <= 64");
+    hipStream_t st = on_stream ? on_stream : ctx->stream;
     const int64_t nmax = std::max(j0.ncols, j1.ncols);
     const int nb = (int)std::min<int64_t>(TMVB_REDUCE_BLOCKS, std::max<int64_t>(1, (nmax + 3) / 4));
-    hipLaunchKernelGGL(colsum2_partial_kernel, dim3(nb, 2), dim3(256), 0, ctx->stream, j0, j1, K);
-    hipLaunchKernelGGL(colsum2_final_kernel, dim3((K + 3) / 4, 2), dim3(256), 0, ctx->stream, j0, j1, nb, K);
+    hipLaunchKernelGGL(colsum2_partial_kernel, dim3(nb, 2), dim3(256), 0, st, j0, j1, K);
+    hipLaunchKernelGGL(colsum2_final_kernel, dim3((K + 3) / 4, 2), dim3(256), 0, st, j0, j1, nb, K);
     TMVB_HIP(hipGetLastError());
     return TMVB_OK;
 }
