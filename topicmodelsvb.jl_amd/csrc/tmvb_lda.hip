@@ -724,7 +724,7 @@ struct tmvb_lda {
     // alpha / Elogtheta_sum on it, and before a document-sharded caller all-reduces the statistics buffer;
     // the next E-step's document kernels wait for the side chain directly.
     static constexpr int SIDE = 2;
-    hipEvent_t ev_docs = nullptr, ev_side = nullptr, ev_mark = nullptr;
+    hipEvent_t ev_docs = nullptr, ev_side = nullptr, ev_mark = nullptr, ev_chain = nullptr;
     double* d_partial_side = nullptr;
     bool esum_fresh = false;           // d_esum / statistics tail hold the sums of the current Elogtheta
     bool esum_side = false;            // ... and they were produced on the side stream by the last E-step
@@ -879,6 +879,7 @@ extern "C" int tmvb_lda_destroy(tmvb_lda* h)
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_docs) (void)hipEventDestroy(h->ev_docs);
     if (h->ev_side) (void)hipEventDestroy(h->ev_side);
+    if (h->ev_chain) (void)hipEventDestroy(h->ev_chain);
     if (h->ev_mark) (void)hipEventDestroy(h->ev_mark);
     (void)hipFree(h->d_partial_side); (void)hipFree(h->d_pw_partial);
     for (tmvb_inv_index& ix : h->pieces) tmvb_free_inv_index(&ix);
@@ -983,6 +984,7 @@ extern "C" int tmvb_lda_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
     TMVB_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     TMVB_HIP(hipEventCreateWithFlags(&h->ev_docs, hipEventDisableTiming));
     TMVB_HIP(hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming));
+    TMVB_HIP(hipEventCreateWithFlags(&h->ev_chain, hipEventDisableTiming));
     TMVB_HIP(hipEventCreateWithFlags(&h->ev_mark, hipEventDisableTiming));
     if ((rc = dmalloc(&h->d_partial_side, (size_t)TMVB_REDUCE_BLOCKS * K)) || (rc = dmalloc(&h->d_pw_partial, 2048))) return rc;
     for (int a = 0; a < tmvb_lda::NAUX; ++a) {
@@ -1133,6 +1135,7 @@ static int lda_estep_impl(tmvb_lda* h, int32_t viter, double vtol)
     auto close_pieces = [&](int upto) -> int {          // document kernels of pieces < upto are all issued
         for (; piece_open < upto; ++piece_open) {
             if (piece_open == P - 1) {                  // the last piece also holds the long documents (aux[1])
+                TMVB_HIP(hipEventRecord(h->ev_chain, chain_st));          // the chain's own document kernels, before the join below
                 TMVB_HIP(hipEventRecord(h->ev_join[1], h->aux[1]));
                 TMVB_HIP(hipStreamWaitEvent(chain_st, h->ev_join[1], 0));
             }
@@ -1186,7 +1189,11 @@ static int lda_estep_impl(tmvb_lda* h, int32_t viter, double vtol)
     {
         int rc = close_pieces(P);
         if (rc) return rc;
-        TMVB_HIP(hipStreamWaitEvent(side, h->ev_piece[P - 1], 0));       // recorded after the last document kernel
+        // the side chain needs every document kernel: the chain's (ev_chain) and the long documents' (ev_join[1]) -- waited for
+        // directly, not through ev_piece[P - 1], which the chain stream records only after ITS join with aux[1]: one cross-stream
+        // hop (~20 us) less in front of update_alpha!, which on a small shard is what the next iteration waits for
+        TMVB_HIP(hipStreamWaitEvent(side, h->ev_chain, 0));
+        TMVB_HIP(hipStreamWaitEvent(side, h->ev_join[1], 0));
     }
     // Elogtheta_sum (update_alpha!'s input, src/LDA.jl:98) under the statistics pass
     {
