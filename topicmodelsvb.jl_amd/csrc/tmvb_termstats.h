@@ -203,30 +203,50 @@ __device__ __forceinline__ void termstats_recompute_body(const TermStatsParams& 
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const int cnt = min(64, e - t0);
-#pragma unroll 8
-        for (int k = 0; k < cnt; k += SLOTS) {
-            const int kk = k + rs;
-            const bool row_on = kk < cnt;
-            const int2 dw = dw_l[wv][min(kk, 63)];
-            float4 ev = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row_on && lane_on) ev = *(const float4*)(p.E + (int64_t)dw.x * ES + 4 * cc);
-            const v2f elo = v2f{ev.x, ev.y}, ehi = v2f{ev.z, ev.w};
-            const v2f d2 = __builtin_elementwise_fma(tlo, elo, thi * ehi);
-            float part = d2.x + d2.y;
-            part += dpp_f<0xB1>(part);
-            part += dpp_f<0x4E>(part);
-            part += dpp_f<0x141>(part);
-            part += dpp_f<0x140>(part);                       // all 16 lanes of a row hold the row's sum
-            if (LANES == 32) {                                // rows 2r and 2r+1 form one slot: add the sibling row
-                float sib = part;
-                asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(part), "+v"(sib));
-                part += sib;                                  // every lane of the slot holds s_n - keps
+        // U row gathers in flight per wave: the loads are UNCONDITIONAL (a row slot past the end reads document 0's row and gets
+        // weight 0; a lane past the last column chunk reads the row's zero padding when the rows are padded to 16 bytes x LANES),
+        // so the block is straight-line code and the compiler issues all U loads before the first wait.  With the loads under
+        // `if (row_on && lane_on)` it kept ONE gather in flight per wave (s_waitcnt vmcnt(0) right behind every load).
+        constexpr int U = 4;
+        const bool pad_ok = ES >= 4 * LANES;            // uniform
+        for (int k0 = 0; k0 < cnt; k0 += U * SLOTS) {
+            int2 dw[U];
+            bool ron[U];
+            float4 ev[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int kk = k0 + u * SLOTS + rs;
+                ron[u] = kk < cnt;
+                dw[u] = dw_l[wv][min(kk, 63)];
             }
-            const float wz = row_on ? fast_div(__builtin_bit_cast(float, dw.y), part + p.keps) : 0.0f;
-            const v2f w2 = v2f{wz, wz};
-            alo = __builtin_elementwise_fma(w2, elo, alo);
-            ahi = __builtin_elementwise_fma(w2, ehi, ahi);
-            wl += wz;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float* src = p.E + (int64_t)(ron[u] ? dw[u].x : 0) * ES + 4 * cc;
+                if (pad_ok) ev[u] = *(const float4*)src;
+                else { ev[u] = make_float4(0.f, 0.f, 0.f, 0.f); if (lane_on) ev[u] = *(const float4*)src; }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (k0 + u * SLOTS >= cnt) break;                 // uniform: whole row-slot group past the end
+                const bool row_on = ron[u];
+                const v2f elo = lane_on ? v2f{ev[u].x, ev[u].y} : v2f{0.f, 0.f}, ehi = lane_on ? v2f{ev[u].z, ev[u].w} : v2f{0.f, 0.f};
+                const v2f d2 = __builtin_elementwise_fma(tlo, elo, thi * ehi);
+                float part = d2.x + d2.y;
+                part += dpp_f<0xB1>(part);
+                part += dpp_f<0x4E>(part);
+                part += dpp_f<0x141>(part);
+                part += dpp_f<0x140>(part);                       // all 16 lanes of a row hold the row's sum
+                if (LANES == 32) {                                // rows 2r and 2r+1 form one slot: add the sibling row
+                    float sib = part;
+                    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(part), "+v"(sib));
+                    part += sib;                                  // every lane of the slot holds s_n - keps
+                }
+                const float wz = row_on ? fast_div(__builtin_bit_cast(float, dw[u].y), part + p.keps) : 0.0f;
+                const v2f w2 = v2f{wz, wz};
+                alo = __builtin_elementwise_fma(w2, elo, alo);
+                ahi = __builtin_elementwise_fma(w2, ehi, ahi);
+                wl += wz;
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
