@@ -49,16 +49,31 @@ static __global__ __launch_bounds__(256) void flda_stats_kernel(FldaStatsParams 
         const float vn = tn * cn;
         kl += cn - vn;                                                  // (1 - tau_n) c_n
         const int cnt = min(64, e - t0);
-        for (int k = 0; k < cnt; ++k) {
-            const int dk = __builtin_amdgcn_readlane(dd, k);
-            const float vk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vn), k));
-            const float tk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tp), k));
-            const float lk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ls), k));
-            const float* erow = p.elog_old + (int64_t)dk * K;
+        // four postings per trip, their row loads unconditional (a lane past K re-reads element 0, a posting past the end is lane
+        // data of an invalid token: document 0, weight 0, lse = inf -> contributes exactly 0): straight-line code, four gathers
+        // in flight per wave instead of one
+        constexpr int U = 4;
+        for (int k0 = 0; k0 < cnt; k0 += U) {
+            float ev[U][NS], vk[U], tk[U], lk[U];
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const int i = lane + 64 * s;
-                if (i < K) acc[s] = fmaf(vk, __expf(fmaf(tk, Lj[s], erow[i]) - lk), acc[s]);
+            for (int u = 0; u < U; ++u) {
+                const int k = min(k0 + u, 63);
+                const int dk = __builtin_amdgcn_readlane(dd, k);
+                vk[u] = (k0 + u < 64) ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vn), k)) : 0.0f;
+                tk[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tp), k));
+                lk[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ls), k));
+                const float* erow = p.elog_old + (int64_t)dk * K;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) { const int i = lane + 64 * s; ev[u][s] = erow[i < K ? i : 0]; }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (k0 + u >= cnt) break;                                   // uniform
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const int i = lane + 64 * s;
+                    if (i < K) acc[s] = fmaf(vk[u], __expf(fmaf(tk[u], Lj[s], ev[u][s]) - lk[u]), acc[s]);
+                }
             }
         }
     }
@@ -96,14 +111,23 @@ static __global__ __launch_bounds__(64) void flda_stats_multi_kernel(FldaStatsPa
     float acc[NS], ks = 0.0f;
 #pragma unroll
     for (int s = 0; s < NS; ++s) acc[s] = 0.0f;
-    for (int c = 0; c < cnt; ++c) {
-        const float* pr = p.partial + (int64_t)(first + c) * (K + 1);
+    // four partial rows in flight per trip (fixed order of summation; a row past the end is the last row again, not added)
+    for (int c0 = 0; c0 < cnt; c0 += 4) {
+        float v[4][NS], kv[4];
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const int i = lane + 64 * s;
-            if (i < K) acc[s] += pr[i];
+        for (int u = 0; u < 4; ++u) {
+            const float* pr = p.partial + (int64_t)(first + min(c0 + u, cnt - 1)) * (K + 1);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) { const int i = lane + 64 * s; v[u][s] = pr[i < K ? i : K]; }
+            kv[u] = pr[K];
         }
-        ks += pr[K];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (c0 + u >= cnt) break;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) { const int i = lane + 64 * s; if (i < K) acc[s] += v[u][s]; }
+            ks += kv[u];
+        }
     }
 #pragma unroll
     for (int s = 0; s < NS; ++s) {

@@ -312,15 +312,25 @@ __device__ __forceinline__ void termstats_multi_body(const TermStatsParams& p, c
 #pragma unroll
     for (int s = 0; s < NSLOT; ++s) acc[s] = 0.0f;
     float wsum = 0.0f;
-#pragma unroll 8
-    for (int c = wv; c < cnt; c += 4) {
-        const float* pr = p.partial + (int64_t)(first + c) * (K + 1);
+    // four partial rows of this wave in flight per trip, loaded unconditionally (a row past the end: the last row again, not
+    // added; a lane past K: element K): with the loads under `if (i < K)` in a loop of unknown length the wave waited for each
+    // row before asking for the next.  Same order of summation.
+    for (int c0 = wv; c0 < cnt; c0 += 16) {
+        float v[4][NSLOT], wk[4];
 #pragma unroll
-        for (int s = 0; s < NSLOT; ++s) {
-            const int i = lane + 64 * s;
-            if (i < K) acc[s] += pr[i];
+        for (int u = 0; u < 4; ++u) {
+            const float* pr = p.partial + (int64_t)(first + min(c0 + 4 * u, cnt - 1)) * (K + 1);
+#pragma unroll
+            for (int s = 0; s < NSLOT; ++s) { const int i = lane + 64 * s; v[u][s] = pr[i < K ? i : K]; }
+            wk[u] = pr[K];
         }
-        wsum += pr[K];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (c0 + 4 * u >= cnt) break;                    // wave-uniform
+#pragma unroll
+            for (int s = 0; s < NSLOT; ++s) { const int i = lane + 64 * s; if (i < K) acc[s] += v[u][s]; }
+            wsum += wk[u];
+        }
     }
 #pragma unroll
     for (int s = 0; s < NSLOT; ++s) red[wv][lane + 64 * s] = acc[s];
