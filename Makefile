@@ -18,7 +18,7 @@ topicmodelsvb.jl_amd/build/%.hip.o: $(CSRC)/%.hip $(HDRS)
 	$(HIPCC) $(FLAGS) -c $< -o $@
 
 $(LIB): $(OBJS)
-	$(HIPCC) --offload-arch=$(ARCH) -fPIC -shared -o $@ $(OBJS) -L$(ROCM)/lib -lrccl -Wl,-rpath,$(ROCM)/lib
+	$(HIPCC) --offload-arch=$(ARCH) -fPIC -shared -o $@ $(OBJS) -ldl -Wl,-rpath,$(ROCM)/lib
 
 oracle:
 	$(MAKE) -C oracle

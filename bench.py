@@ -191,6 +191,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-plateau", action="store_true")
     ap.add_argument("--no-cold", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the lines of BASELINE.json's configs 3-5 (LDA K=100, CTM K=50, CTPF K=50) carried under other_configs at N=1")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -410,9 +412,25 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(tm, corpus, K, beta0)
-        print(json.dumps(result), flush=True)
     if comm is not None:
-        eng.model.set_comm(None, shard.M); comm.close()
+        eng.model.set_comm(None, shard.M); comm.close(); comm = None
+    eng.model.close(); del eng
+    if rank == 0:
+        # BASELINE.json configs 3-5 (N = 1 only; default sizes only): one measured line each, steady-state window, roofline and a
+        # full-corpus OpenMP cpu_baseline -- tools/model_bench.py; the headline fields above stay config 2's
+        if world == 1 and not args.no_other_configs and (args.K, args.docs, args.vocab) == (50, 128804, 25319):
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import model_bench
+            others = {}
+            for name in ("lda100", "ctm", "ctpf"):
+                t_c = time.perf_counter()
+                try:
+                    others[name] = model_bench.ALL[name](cpu=not args.no_cpu_baseline)
+                except Exception as e:                       # a failing side line must not cost the headline
+                    others[name] = {"error": f"{type(e).__name__}: {e}"}
+                log(f"other_configs[{name}] done in {time.perf_counter() - t_c:.1f}s")
+            result["other_configs"] = others
+        print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -221,9 +221,14 @@ class fLDA(LDA):
         self.tau = np.full(nnz, self.eta)                                 # :49
         self.tau_old = self.tau.copy()
 
-    def estep(self, viter=10, vtol=None, d0=0, d1=None):
+    def estep(self, viter=10, vtol=None, d0=0, d1=None, omp_threads=0):
         vtol = 1.0 / self.K ** 2 if vtol is None else vtol
         d1 = self.M if d1 is None else d1
+        if omp_threads:
+            return lib().orc_flda_estep_omp(*self._corp_args(), c_i64(d0), c_i64(d1), c_dbl(self.eta), _pd(self.alpha), _pd(self.kappa),
+                                            _pd(self.beta), _pd(self.beta_temp), _pd(self.kappa_temp), _pd(self.gamma), _pd(self.Elogtheta),
+                                            _pd(self.Elogtheta_old), _pd(self.tau), _pd(self.tau_old), C.c_int(viter), c_dbl(vtol),
+                                            C.c_int(omp_threads))
         sw = np.zeros(max(d1 - d0, 1), dtype=np.int32)
         rc = lib().orc_flda_estep(*self._corp_args(), c_i64(d0), c_i64(d1), c_dbl(self.eta), _pd(self.alpha), _pd(self.kappa),
                                   _pd(self.beta), _pd(self.beta_temp), _pd(self.kappa_temp), _pd(self.gamma), _pd(self.Elogtheta),
@@ -362,10 +367,15 @@ class fCTM(CTM):
         self.tau = np.full(nnz, self.eta)
         self.tau_old = self.tau.copy()
 
-    def estep(self, niter=1000, ntol=None, viter=10, vtol=None, d0=0, d1=None):
+    def estep(self, niter=1000, ntol=None, viter=10, vtol=None, d0=0, d1=None, omp_threads=0):
         ntol = 1.0 / self.K ** 2 if ntol is None else ntol
         vtol = 1.0 / self.K ** 2 if vtol is None else vtol
         d1 = self.M if d1 is None else d1
+        if omp_threads:
+            return lib().orc_fctm_estep_omp(*self._corp_args(), c_i64(d0), c_i64(d1), c_dbl(self.eta), _pd(self.kappa), _pd(self.mu),
+                                            _pd(self.invsigma), _pd(self.beta), _pd(self.beta_temp), _pd(self.kappa_temp), _pd(self.lam),
+                                            _pd(self.lam_old), _pd(self.vsq), _pd(self.logzeta), _pd(self.tau), _pd(self.tau_old),
+                                            C.c_int(niter), c_dbl(ntol), C.c_int(viter), c_dbl(vtol), C.c_int(omp_threads))
         sw = np.zeros(max(d1 - d0, 1), dtype=np.int32)
         nst = c_i64(0)
         rc = lib().orc_fctm_estep(*self._corp_args(), c_i64(d0), c_i64(d1), c_dbl(self.eta), _pd(self.kappa), _pd(self.mu),

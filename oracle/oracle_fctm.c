@@ -11,6 +11,9 @@
  * tau / tau_old: flat [nnz] arrays in CSR token order.
  */
 #include "tmvb_oracle.h"
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -155,6 +158,57 @@ int orc_fctm_estep(int64_t M, int64_t V, int64_t K,
     if (newton_out) *newton_out = newton;
     free(phi); free(stage); free(ws);
     return 0;
+}
+
+/* The same E-step, document-parallel with OpenMP (cpu_baseline only; private statistics ADD duplicate ids: condensed corpora) */
+int orc_fctm_estep_omp(int64_t M, int64_t V, int64_t K,
+                       const int64_t* doc_ptr, const int32_t* terms, const int32_t* counts,
+                       int64_t d0, int64_t d1, double eta, const double* kappa, const double* mu, const double* invsigma,
+                       const double* beta, double* beta_temp, double* kappa_temp, double* lambda, double* lambda_old,
+                       double* vsq, double* logzeta, double* tau, double* tau_old,
+                       int niter, double ntol, int viter, double vtol, int nthreads)
+{
+    int used = 1;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+    int64_t mx = fctm_max_len(doc_ptr, d0, d1);
+#pragma omp parallel
+    {
+#pragma omp single
+        used = omp_get_num_threads();
+        double* phi = (double*)malloc(sizeof(double) * (size_t)(K * mx));
+        double* ws = (double*)malloc(sizeof(double) * (size_t)(2 * K * K + 4 * K));
+        double* bt = (double*)calloc((size_t)(K * V), sizeof(double));
+        double* kt = (double*)calloc((size_t)V, sizeof(double));
+        for (int64_t q = 0; q < K * mx; ++q) phi[q] = 1.0 / (double)K;
+        int64_t newton = 0;
+#pragma omp for schedule(dynamic, 16)
+        for (int64_t d = d0; d < d1; ++d) {
+            int64_t off = doc_ptr[d], Nd = doc_ptr[d + 1] - off;
+            const int32_t* tm = terms + off; const int32_t* ct = counts + off;
+            fctm_doc(K, Nd, tm, ct, eta, kappa, mu, invsigma, beta, lambda + d * K, lambda_old + d * K, vsq + d * K,
+                     logzeta + d, tau + off, tau_old + off, phi, ws, niter, ntol, viter, vtol, &newton);
+            for (int64_t n = 0; n < Nd; ++n) {
+                double* col = bt + (int64_t)tm[n] * K;
+                const double wn = tau[off + n] * (double)ct[n];
+                for (int64_t i = 0; i < K; ++i) col[i] += phi[n * K + i] * wn;
+                kt[tm[n]] += (1.0 - tau[off + n]) * (double)ct[n];
+            }
+        }
+#pragma omp critical
+        {
+            for (int64_t q = 0; q < K * V; ++q) beta_temp[q] += bt[q];
+            for (int64_t j = 0; j < V; ++j) kappa_temp[j] += kt[j];
+        }
+        free(phi); free(ws); free(bt); free(kt);
+    }
+#else
+    (void)nthreads;
+    orc_fctm_estep(M, V, K, doc_ptr, terms, counts, d0, d1, eta, kappa, mu, invsigma, beta, beta_temp, kappa_temp, lambda,
+                   lambda_old, vsq, logzeta, tau, tau_old, niter, ntol, viter, vtol, NULL, NULL);
+#endif
+    (void)M;
+    return used;
 }
 
 /* update_elbo!  :105-115 with the seven terms of :68-102 */

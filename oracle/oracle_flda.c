@@ -8,6 +8,9 @@
  * Storage: tau / tau_old are flat [nnz] arrays in CSR token order (the reference's Vector{Vector} tau[d][n]).
  */
 #include "tmvb_oracle.h"
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -115,6 +118,57 @@ int orc_flda_estep(int64_t M, int64_t V, int64_t K,
     }
     free(phi); free(stage);
     return 0;
+}
+
+/* The same E-step, document-parallel with OpenMP (bench.py / tools/model_bench.py cpu_baseline only): every thread runs whole
+ * documents and accumulates private statistics, reduced at the end.  Private accumulation ADDS duplicate term ids of one
+ * document (quirk Q1 overwrites them), so this variant is for condensed corpora -- which every corpus the engine accepts is. */
+int orc_flda_estep_omp(int64_t M, int64_t V, int64_t K,
+                       const int64_t* doc_ptr, const int32_t* terms, const int32_t* counts,
+                       int64_t d0, int64_t d1, double eta, const double* alpha, const double* kappa, const double* beta,
+                       double* beta_temp, double* kappa_temp, double* gamma, double* Elogtheta, double* Elogtheta_old,
+                       double* tau, double* tau_old, int viter, double vtol, int nthreads)
+{
+    int used = 1;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+    int64_t mx = flda_max_len(doc_ptr, d0, d1);
+#pragma omp parallel
+    {
+#pragma omp single
+        used = omp_get_num_threads();
+        double* phi = (double*)malloc(sizeof(double) * (size_t)(K * mx));
+        double* bt = (double*)calloc((size_t)(K * V), sizeof(double));
+        double* kt = (double*)calloc((size_t)V, sizeof(double));
+        for (int64_t q = 0; q < K * mx; ++q) phi[q] = 1.0 / (double)K;
+#pragma omp for schedule(dynamic, 16)
+        for (int64_t d = d0; d < d1; ++d) {
+            int64_t off = doc_ptr[d], Nd = doc_ptr[d + 1] - off;
+            const int32_t* tm = terms + off;
+            const int32_t* ct = counts + off;
+            orc_flda_doc_sweeps(K, Nd, tm, ct, eta, alpha, kappa, beta, gamma + d * K, Elogtheta + d * K,
+                                Elogtheta_old + d * K, tau + off, tau_old + off, phi, viter, vtol);
+            for (int64_t n = 0; n < Nd; ++n) {
+                double* col = bt + (int64_t)tm[n] * K;
+                const double wn = tau[off + n] * (double)ct[n];
+                for (int64_t i = 0; i < K; ++i) col[i] += phi[n * K + i] * wn;
+                kt[tm[n]] += (1.0 - tau[off + n]) * (double)ct[n];
+            }
+        }
+#pragma omp critical
+        {
+            for (int64_t q = 0; q < K * V; ++q) beta_temp[q] += bt[q];
+            for (int64_t j = 0; j < V; ++j) kappa_temp[j] += kt[j];
+        }
+        free(phi); free(bt); free(kt);
+    }
+#else
+    (void)nthreads;
+    orc_flda_estep(M, V, K, doc_ptr, terms, counts, d0, d1, eta, alpha, kappa, beta, beta_temp, kappa_temp, gamma, Elogtheta,
+                   Elogtheta_old, tau, tau_old, viter, vtol, NULL);
+#endif
+    (void)M;
+    return used;
 }
 
 /* update_kappa!(model)  :138-142 */

@@ -203,6 +203,12 @@ int orc_flda_estep(int64_t M, int64_t V, int64_t K,
                    int64_t d0, int64_t d1, double eta, const double* alpha, const double* kappa, const double* beta,
                    double* beta_temp, double* kappa_temp, double* gamma, double* Elogtheta, double* Elogtheta_old,
                    double* tau, double* tau_old, int viter, double vtol, int32_t* sweeps_out);
+/* the same, OpenMP document-parallel (cpu_baseline only; condensed corpora); returns the team size */
+int orc_flda_estep_omp(int64_t M, int64_t V, int64_t K,
+                       const int64_t* doc_ptr, const int32_t* terms, const int32_t* counts,
+                       int64_t d0, int64_t d1, double eta, const double* alpha, const double* kappa, const double* beta,
+                       double* beta_temp, double* kappa_temp, double* gamma, double* Elogtheta, double* Elogtheta_old,
+                       double* tau, double* tau_old, int viter, double vtol, int nthreads);
 void orc_flda_update_kappa(int64_t V, double* kappa, double* kappa_old, double* kappa_temp);       /* :138-142 */
 double orc_flda_update_eta(int64_t M, const int64_t* doc_ptr, const int32_t* counts, const double* tau);   /* :122-124 */
 double orc_flda_update_elbo(int64_t M, int64_t V, int64_t K,
@@ -219,6 +225,12 @@ int orc_fctm_estep(int64_t M, int64_t V, int64_t K,
                    const double* beta, double* beta_temp, double* kappa_temp, double* lambda, double* lambda_old,
                    double* vsq, double* logzeta, double* tau, double* tau_old,
                    int niter, double ntol, int viter, double vtol, int32_t* sweeps_out, int64_t* newton_out);
+int orc_fctm_estep_omp(int64_t M, int64_t V, int64_t K,
+                       const int64_t* doc_ptr, const int32_t* terms, const int32_t* counts,
+                       int64_t d0, int64_t d1, double eta, const double* kappa, const double* mu, const double* invsigma,
+                       const double* beta, double* beta_temp, double* kappa_temp, double* lambda, double* lambda_old,
+                       double* vsq, double* logzeta, double* tau, double* tau_old,
+                       int niter, double ntol, int viter, double vtol, int nthreads);
 double orc_fctm_update_elbo(int64_t M, int64_t V, int64_t K,
                             const int64_t* doc_ptr, const int32_t* terms, const int32_t* counts,
                             int64_t d0, int64_t d1, double eta, const double* kappa, const double* mu, const double* invsigma,

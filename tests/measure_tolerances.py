@@ -43,3 +43,43 @@ e_o = om.update_elbo()
 sc = (om.gimel / om.dalet[:, None] + om.zayin / om.het[:, None]).T @ (om.he / om.vav[:, None])
 print("k100 elbo rel", abs(traj[-1] - e_o) / abs(e_o), {n: rel(getattr(gm, n), getattr(om, n)) for n in ("bet", "vav", "dalet", "het")},
       "scores", float(np.abs(gm.scores - sc).max() / np.abs(sc).max()))
+
+# ---- CTM: teacher-forced single-step deviations per K (the bounds of tests/test_ctm_gpu.py::test_teacher_forced_step) and the
+# free-running K = 50 run on the CG kernel (test_free_running_k50_cg_kernel_tracks_the_oracle)
+import test_ctm_gpu as TC            # noqa: E402
+print("CTM teacher-forced (max over 3 iterations): K, |dlam|, |dlam|/(2e-3+2e-3|lam|), vsq rel, logzeta abs, beta rel (>1e-6), mu abs, sigma abs/max, elbo rel")
+for K in (3, 12, 25, 41, 50, 57, 64, 100, 128):
+    g = TC.synth_case(tmvb, K)
+    gm, om = TC.make_pair(tmvb, oracle, g)
+    worst = np.zeros(8)
+    for it in range(3):
+        TC.force(gm, om); TC.step(gm); TC.step(om)
+        e_g = gm.update_elbo(); e_o = om.update_elbo(); gm.update_host()
+        dl = np.abs(gm.lam - om.lam)
+        big = om.beta > 1e-6
+        cur = np.array([dl.max(), (dl / (2e-3 + 2e-3 * np.abs(om.lam))).max(), (np.abs(gm.vsq - om.vsq) / om.vsq).max(),
+                        np.abs(gm.logzeta - om.logzeta).max(), (np.abs(gm.beta[big] - om.beta[big]) / om.beta[big]).max(),
+                        np.abs(gm.mu - om.mu).max(), np.abs(gm.sigma - om.sigma).max() / np.abs(om.sigma).max(), abs(e_g - e_o) / abs(e_o)])
+        worst = np.maximum(worst, cur)
+    print("  K=%d " % K + " ".join("%.3g" % x for x in worst))
+
+pc = tmvb.syn_nsf(M=1500, V=25319, seed=2)
+K = 50
+beta0 = tmvb.dirichlet_rows(K, pc.V, seed=7)
+gm = tmvb.gpuCTM(pc, K)
+gm.beta = np.asfortranarray(beta0); gm.beta_old = gm.beta.copy(order="F")
+om = oracle.CTM(oracle.CSR(pc.doc_ptr, pc.terms, pc.counts, pc.V), K, beta0)
+t_g = gm.train(iter=20, tol=1.0, checkelbo=1, printelbo=False)
+e_prev, t_o = om.update_elbo(), []
+for k in range(20):
+    om.estep(omp_threads=os.cpu_count() or 1); om.update_beta(); om.update_sigma_mu()
+    e_new = om.update_elbo(); t_o.append(e_new)
+    stop = (e_new - e_prev) < 1.0; e_prev = e_new
+    if stop:
+        break
+t_o = np.asarray(t_o); n = min(len(t_g), len(t_o))
+print("CTM K=50 free-running (CG kernel), 1500 docs: iterations device/oracle", len(t_g), len(t_o), "elbo rel per iteration",
+      " ".join("%.2e" % x for x in np.abs(t_g[:n] - t_o[:n]) / np.abs(t_o[:n])))
+if len(t_g) == len(t_o):
+    print("  final |dmu|", np.abs(gm.mu - om.mu).max(), "|dsigma|/max", np.abs(gm.sigma - om.sigma).max() / np.abs(om.sigma).max(),
+          "|dlam| max", np.abs(gm.lam - om.lam).max(), "99.9 pct", np.quantile(np.abs(gm.lam - om.lam), 0.999))

@@ -50,23 +50,39 @@ def test_teacher_forced_step(tmvb, oracle, case):
     # K = 100 is the reference's own published CTPF size (plots.R:4,17); K > 64 runs two topic slots per lane
     g = load(case) if case.startswith("ctpf_") else synth_case(tmvb, int(case.split("_k")[1]))
     gm, om = make_pair(tmvb, oracle, g)
+    probe = oracle.CTPF(om.corp, int(g["K"]), g["alef0"])      # a second oracle that only reports its own exit sweeps
     for it in range(3):
         force(gm, om)
         gm.estep(); gm.reduce_docs(); gm.mstep()
-        sw = om.estep(); om.mstep()
+        for n in ("alef", "he", "bet", "vav", "dalet", "het", "gimel", "zayin"):
+            setattr(probe, n, np.array(getattr(om, n), copy=True, order="F"))
+        sw = np.asarray(probe.estep())
         gm.update_host()
         sw_g = gm.doc_sweeps()
-        same = sw_g == np.asarray(sw)
+        same = sw_g == sw
         assert np.array_equal(gm.sweep_hist(), np.bincount(sw_g, minlength=11))
-        # documents whose exit sweep agrees with the oracle's are compared one by one; the others are counted
+        # a document whose exit test (norm of the gimel change against vtol) straddles the threshold in fp32 leaves one sweep
+        # earlier or later than in fp64: such documents are counted, and the oracle is then run with the DEVICE's sweep count
+        # for them (viter = that count, vtol = 0), so that every document and every global is compared on every pass
         assert (~same).sum() <= 0.05 * gm.M, (it, int((~same).sum()))
-        assert rel(gm.gimel[:, same], om.gimel[:, same]) <= 5e-4, (it, "gimel")
-        assert rel(gm.zayin[:, same], om.zayin[:, same]) <= 5e-4, (it, "zayin")
-        if same.all():                                         # the globals see every document
-            assert rel(gm.alef, om.alef) <= 5e-4, (it, "alef")
-            assert rel(gm.he, om.he) <= 5e-4, (it, "he")
-            for n in ("bet", "vav", "dalet", "het"):
-                assert rel(getattr(gm, n), getattr(om, n)) <= 1e-4, (it, n)
+        assert np.all(np.abs(sw_g[~same].astype(int) - sw[~same]) <= 1)
+        d = 0
+        while d < gm.M:                                        # runs of documents with one treatment -> one oracle call
+            e = d
+            while e < gm.M and (same[e] == same[d]) and (same[d] or sw_g[e] == sw_g[d]):
+                e += 1
+            if same[d]:
+                om.estep(d0=d, d1=e)
+            else:
+                om.estep(viter=int(sw_g[d]), vtol=0.0, d0=d, d1=e)
+            d = e
+        om.mstep()
+        assert rel(gm.gimel, om.gimel) <= 5e-4, (it, "gimel")
+        assert rel(gm.zayin, om.zayin) <= 5e-4, (it, "zayin")
+        assert rel(gm.alef, om.alef) <= 5e-4, (it, "alef")
+        assert rel(gm.he, om.he) <= 5e-4, (it, "he")
+        for n in ("bet", "vav", "dalet", "het"):
+            assert rel(getattr(gm, n), getattr(om, n)) <= 1e-4, (it, n)
         assert rel(gm.alef_old, om.alef_old) <= 1e-6 and rel(gm.dalet_old, om.dalet_old) <= 1e-12
         assert np.all(gm.alef > 0) and np.all(gm.he > 0) and np.all(gm.gimel > 0) and np.all(gm.zayin > 0)
 
@@ -151,6 +167,42 @@ def test_citeu_shaped_invariants_k50(tmvb):
     np.testing.assert_allclose(gm.alef.sum(), 0.1 * 50 * pc.V + pc.counts.sum(), rtol=2e-5)
     np.testing.assert_allclose(gm.he.sum(), 0.1 * 50 * pc.U + pc.ratings.sum(), rtol=2e-5)
     assert np.all(gm.bet > 0) and np.all(gm.vav > 0) and np.all(np.isfinite(gm.gimel))
+
+
+def test_full_size_citeu_properties_k50(tmvb):
+    """BASELINE.json config 5 at its full size (CTPF K = 50 on SYN-CITEU: M = 16 980, V = 8 000, U = 5 551 with readers)
+    through size-independent properties: shape-parameter mass conservation (sum alef = a K V + total counts, sum he = e K U
+    + total ratings, per-document sum gimel = c K + C_d + R_d-part), positive rates, increasing ELBO, run-to-run bitwise
+    reproducibility of the atomics-free statistics."""
+    pc = tmvb.syn_citeu()
+    K = 50
+
+    def run():
+        g = tmvb.gpuCTPF(pc, K)
+        es = []
+        for it in range(3):
+            g.estep(); g.reduce_docs(); g.mstep()
+            es.append(g.update_elbo())
+        g.update_host()
+        return g, es
+    a, ea = run()
+    np.testing.assert_allclose(a.alef.sum(), 0.1 * K * pc.V + pc.counts.sum(), rtol=2e-5)
+    np.testing.assert_allclose(a.he.sum(), 0.1 * K * pc.U + pc.ratings.sum(), rtol=2e-5)
+    # per document: sum_k gimel = c K + sum counts + (top half of xi) . ratings, sum_k zayin = g K + (bottom half) . ratings;
+    # the two halves of xi sum to one per reader (src/CTPF.jl:309-323), so gimel + zayin conserves counts + ratings
+    Cd = np.add.reduceat(pc.counts, pc.doc_ptr[:-1]) * (np.diff(pc.doc_ptr) > 0)
+    Rd = np.zeros(pc.M); nz = np.diff(pc.rdr_ptr) > 0
+    Rd[nz] = np.add.reduceat(pc.ratings, pc.rdr_ptr[:-1][nz])
+    np.testing.assert_allclose((a.gimel + a.zayin).sum(axis=0), 0.2 * K + Cd + Rd, rtol=3e-5)
+    for n in ("bet", "vav", "dalet", "het"):
+        assert np.all(getattr(a, n) > 0) and np.all(np.isfinite(getattr(a, n))), n
+    assert np.all(a.alef > 0) and np.all(a.he > 0) and np.all(a.gimel > 0) and np.all(a.zayin > 0)
+    assert np.all(np.isfinite(ea)) and ea[1] > ea[0] and ea[2] > ea[1]
+    assert a.sweep_hist().sum() == pc.M
+    b, eb = run()
+    for n in ("alef", "he", "bet", "vav", "dalet", "het", "gimel", "zayin"):
+        assert np.array_equal(getattr(a, n), getattr(b, n)), n
+    assert ea == eb
 
 
 def test_train_equals_stepwise(tmvb):

@@ -159,3 +159,50 @@ def test_gpu_macro_file_covers_the_models():
     for t in ("LDA", "CTM", "CTPF", "fLDA", "fCTM"):
         assert f"copyback!(model::{t}, dev::hip{t})" in src and f"hipmodel(model::{t}) = hip{t}(model)" in src
     assert "macro gpu(expr::Expr)" in src
+
+
+def _ref_assignments(lo, hi):
+    """`model.<field> = ...` statements of the reference's @gpu copy-back (src/macros.jl lines lo..hi), as written there.
+    The list is data about the reference's interface, spelled out here because /root/reference does not travel."""
+    return {
+        (136, 149): ["topics", "alpha", "beta", "Elogtheta", "Elogtheta_old", "gamma", "phi", "elbo", "beta_old"],
+        (177, 192): ["topics", "mu", "sigma", "invsigma", "beta", "lambda", "lambda_old", "vsq", "logzeta", "phi", "elbo", "beta_old"],
+        (239, 265): ["topics", "scores", "drecs", "urecs", "alef", "alef_old", "he", "he_old", "bet", "bet_old", "vav", "vav_old", "gimel",
+                     "gimel_old", "zayin", "zayin_old", "dalet", "dalet_old", "het", "het_old", "phi", "xi", "elbo"],
+    }[(lo, hi)]
+
+
+def _function_body(src, signature):
+    i = src.index(signature)
+    j = src.index("\nend\n", i)
+    return src[i:j]
+
+
+def test_copyback_assigns_every_field_the_reference_assigns_from_the_device():
+    """Every field the reference's `@gpu` assigns back to the host model (src/macros.jl:136-149 LDA, :177-192 CTM, :239-265
+    CTPF) is assigned in the matching copyback!; state fields come straight from `dev.`, `*_old` fields are copies of the
+    freshly assigned host field (as in the reference), and phi / xi are rebuilt by dev_phi1 / dev_xi1, whose bodies read the
+    device's *_old state only (the shim once rebuilt phi from the HOST model's pre-training beta_old)."""
+    src = open(os.path.join(ROOT, "topicmodelsvb.jl_amd", "julia", "gpu_macro.jl")).read()
+    for T, span in (("LDA", (136, 149)), ("CTM", (177, 192)), ("CTPF", (239, 265))):
+        body = _function_body(src, f"function copyback!(model::{T}, dev::hip{T})")
+        assigns = dict(re.findall(r"^\s*model\.(\w+)\s*=\s*([^#\n]+)", body, flags=re.M))
+        for field in _ref_assignments(*span):
+            assert field in assigns, f"copyback!(::{T}) does not assign model.{field} (src/macros.jl:{span[0]}-{span[1]})"
+            rhs = assigns[field].strip()
+            if field in ("phi", "xi"):
+                assert rhs == f"dev_{field}1(dev)", (T, field, rhs)
+            elif field.endswith("_old"):
+                base = field[:-4]
+                assert re.fullmatch(rf"(copy|deepcopy)\(model\.{base}\)", rhs), (T, field, rhs)
+                # ... and the copy is taken after the field itself was assigned from the device
+                assert body.index(f"model.{base} =") < body.index(f"model.{field} ="), (T, field)
+            else:
+                assert re.fullmatch(rf"(Symmetric\()?dev\.{field}\)?", rhs), (T, field, rhs)
+    # phi / xi for CTPF are taken from dev.*_old BEFORE any host *_old is overwritten, and the builders never touch `model`
+    for fn in ("dev_phi1(dev::hipLDA)", "dev_phi1(dev::hipCTM)", "dev_phi1(dev::hipCTPF)", "dev_xi1(dev::hipCTPF)", "dev_phi1(dev::hipfLDA)",
+               "dev_phi1(dev::hipfCTM)"):
+        body = _function_body(src, "function " + fn)
+        assert "model." not in body, fn
+        assert "_old" in body, fn
+    assert "host_phi1" not in src

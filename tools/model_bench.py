@@ -1,9 +1,14 @@
 #!/usr/bin/env python
 """Measured lines for the configurations of BASELINE.json other than the headline one (which bench.py owns):
-config 3 LDA K=100 on SYN-NSF (one GPU's view), config 4 CTM K=50 on SYN-NSF, config 5 CTPF K=50 on SYN-CITEU.
-One JSON line per configuration with the same roofline vocabulary as bench.py (algorithmic bytes of SURVEY.md
-section 8d / DESIGN.md section 3; CTM additionally the flop count of its Newton solves against the fp32 peak).
-and the filtered models fLDA / fCTM K=50 on SYN-NSF.
+config 3 LDA K=100 on SYN-NSF (one GPU's view), config 4 CTM K=50 on SYN-NSF, config 5 CTPF K=50 on SYN-CITEU, and the
+filtered models fLDA / fCTM K=50 on SYN-NSF.  One JSON object per configuration with the
+same vocabulary as bench.py: STEADY-STATE window (untimed burn-in iterations from the cold start first, then warm-up +
+timed iterations), roofline on the algorithmic bytes of SURVEY.md section 8d / DESIGN.md section 3 (CTM additionally
+the flop counts of its Newton solves against the fp32 peak: nominal = the formula of section 8d, executed = what the
+CG kernel really issues), and a cpu_baseline (the fp64 C oracle with its OpenMP document-parallel E-step).
+
+bench.py imports lda100 / ctm / ctpf from here and carries their lines under "other_configs" of its one JSON line, so
+that the driver's BENCH record holds them.
 Usage: python tools/model_bench.py [lda100] [ctm] [ctpf] [flda] [fctm]   (default: all)"""
 import json
 import os
@@ -19,28 +24,34 @@ HBM_PEAK_GBS = 8000.0
 F32_PEAK_TFLOPS = 157.3
 
 
-def cpu_line(kind, make, step, frac, sample_note, budget_s=12.0):
-    """cpu_baseline of a configuration: the fp64 C oracle (port of the reference's CPU path) on a bounded document sample
-    of the same workload, OpenMP document-parallel E-step on the CPUs this process may use (cgroup quota / affinity),
-    scaled to full-corpus iterations/s by the sample's share of the work (`frac`); one single-thread iteration beside it."""
-    from bench import usable_cpus
+def usable_cpus():
+    from bench import usable_cpus as u
+    return u()
+
+
+def cpu_line(kind, make, step, frac, sample_note, warm=1, timed=2, budget_s=12.0, full=False):
+    """cpu_baseline of a configuration: the fp64 C oracle (port of the reference's CPU path; the reference is Julia and
+    cannot run here) with the OpenMP document-parallel E-step on the CPUs this process may use (cgroup quota / affinity).
+    full=True: the whole corpus (frac = 1); otherwise a bounded document sample, scaled to full-corpus iterations/s by
+    the sample's share of the work (`frac`) and labelled "sample"."""
     threads, info = usable_cpus()
     m = make()
-    step(m, threads)                                    # warm-up: OpenMP start-up, first touch
+    for _ in range(warm):
+        step(m, threads)                                # OpenMP start-up, first touch
     t0 = time.perf_counter(); n = 0
-    while n < 4 and time.perf_counter() - t0 < budget_s / 2:
+    while n < timed and (n == 0 or time.perf_counter() - t0 < budget_s):
         step(m, threads); n += 1
     omp = n / (time.perf_counter() - t0)
-    m1 = make()
-    t1 = time.perf_counter(); step(m1, 0); one = 1.0 / (time.perf_counter() - t1)
-    return {"value": omp * frac, "unit": "VB iters/sec", "cores": threads, "host_cpus": info, "kind": "port",
-            "single_thread_value": one * frac,
-            "sample": f"fp64 C oracle ({kind}), {sample_note}; 1 warm-up + {n} timed iterations on {threads} OpenMP threads, "
-                      f"1 single-thread iteration; value = sample iters/s x work fraction {frac:.4f}"}
+    name = "value" if full else "value (sample, scaled)"
+    return {"value": omp * frac, "value_is": "full corpus" if full else "sample scaled by work fraction", "unit": "VB iters/sec",
+            "cores": threads, "host_cpus": info, "kind": "port",
+            "sample": f"fp64 C oracle ({kind}), {sample_note}; {warm} warm-up + {n} timed iterations from the cold start on {threads} OpenMP "
+                      f"threads" + ("" if full else f"; {name} = sample iters/s x work fraction {frac:.4f}")}
 
 
-def timed(fn, steps, warmup, sync):
-    for _ in range(warmup):
+def window(fn, sync, burnin, warmup, steps):
+    """burn-in (state preparation) + warm-up untimed, then `steps` timed iterations between synchronisations."""
+    for _ in range(burnin + warmup):
         fn()
     sync()
     t0 = time.perf_counter()
@@ -50,146 +61,201 @@ def timed(fn, steps, warmup, sync):
     return (time.perf_counter() - t0) / steps
 
 
-def lda100():
+def lda100(burnin=60, warmup=3, steps=20, cpu=True):
     K = 100
     pc = tm.syn_nsf()
     gm = tm.gpuLDA(pc, K)
-    gm.beta = np.asfortranarray(tm.dirichlet_rows(K, pc.V, seed=7)); gm.beta_old = gm.beta.copy(order="F"); gm.update_buffer()
+    beta0 = tm.dirichlet_rows(K, pc.V, seed=7)
+    gm.beta = np.asfortranarray(beta0); gm.beta_old = gm.beta.copy(order="F"); gm.update_buffer()
+
     def it():
         gm.estep(10, 1.0 / K ** 2); gm.reduce_docs(); gm.update_beta(); gm.update_alpha(1000, 1.0 / K ** 2)
-    sec = timed(it, 20, 3, gm.synchronize)
+    cold = window(it, gm.synchronize, 0, warmup, steps)
+    sec = window(it, gm.synchronize, max(burnin - warmup - steps, 0), warmup, steps)
+    hist = gm.sweep_hist(11).tolist()
     B = pc.nnz * (8 + 8 * K) + 12 * pc.M * K + 12 * K * pc.V + 4 * (pc.M + 1)
-    from oracle import oracle as oc
-    sh = pc.shard(0, 24000)
-    beta0 = tm.dirichlet_rows(K, pc.V, seed=7)
-    def ostep(m, nt):
-        m.estep(omp_threads=nt); m.update_beta(); m.update_alpha()
-    cpu = cpu_line("port of src/LDA.jl train!", lambda: oc.LDA(oc.CSR(sh.doc_ptr, sh.terms, sh.counts, sh.V), K, beta0), ostep,
-                   sh.nnz / pc.nnz, f"first {sh.M} documents of SYN-NSF ({sh.nnz} of {pc.nnz} nnz), K=100, cold start")
-    return {"cpu_baseline": cpu, "metric": "VB iters/sec, LDA K=100 on NSF-shaped corpus (config 3, one GPU)", "value": 1.0 / sec, "unit": "VB iters/sec",
+    line = {"metric": "VB iters/sec, LDA K=100 on NSF-shaped corpus (config 3's model, one GPU)", "value": 1.0 / sec, "unit": "VB iters/sec",
             "ms_per_step": 1e3 * sec, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "LDA K=100, SYN-NSF, train! defaults, cold start, 3 warm-up + 20 timed iterations", "M": pc.M, "V": pc.V, "nnz": pc.nnz},
+            "config": {"workload": f"LDA K=100, SYN-NSF, train! defaults, steady state: {burnin} untimed iterations from the cold start, then "
+                                   f"{warmup} warm-up + {steps} timed", "M": pc.M, "V": pc.V, "nnz": pc.nnz, "sweep_hist_last_step": hist},
+            "cold_start": {"value": 1.0 / cold, "ms_per_step": 1e3 * cold, "window": f"iterations {warmup + 1}..{warmup + steps} from the cold start"},
             "roofline": {"bound": "hbm", "achieved": B / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": B / sec / 1e9 / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_iteration": B, "traffic": None}}
+    gm.close()
+    if cpu:
+        from oracle import oracle as oc
+
+        def ostep(m, nt):
+            m.estep(omp_threads=nt); m.update_beta(); m.update_alpha()
+        line["cpu_baseline"] = cpu_line("port of src/LDA.jl train!", lambda: oc.LDA(oc.CSR(pc.doc_ptr, pc.terms, pc.counts, pc.V), K, beta0), ostep,
+                                        1.0, f"FULL SYN-NSF ({pc.M} documents, {pc.nnz} nnz), K=100", warm=1, timed=1, full=True)
+        oc.lib().orc_omp_pool_free()
+    return line
 
 
-def ctm():
+def ctm(burnin=30, warmup=2, steps=8, cpu=True):
     K = 50
     pc = tm.syn_nsf()
     gm = tm.gpuCTM(pc, K)
-    gm.beta = np.asfortranarray(tm.dirichlet_rows(K, pc.V, seed=7)); gm.beta_old = gm.beta.copy(order="F"); gm.update_buffer()
+    beta0 = tm.dirichlet_rows(K, pc.V, seed=7)
+    gm.beta = np.asfortranarray(beta0); gm.beta_old = gm.beta.copy(order="F"); gm.update_buffer()
+
     def it():
         gm.estep(); gm.reduce_docs(); gm.update_beta(); gm.update_sigma(); gm.update_mu()
-    sec = timed(it, 6, 2, gm.synchronize)
+    cold = window(it, gm.synchronize, 0, warmup, steps)
+    sec = window(it, gm.synchronize, max(burnin - warmup - steps, 0), warmup, steps)
+    es_ms = gm.last_estep_ms()
     hist, newton = gm.sweep_hist()
+    st = gm.solver_stats()
     sweeps = int(sum(i * int(h) for i, h in enumerate(hist)))
+    KP = 52
     B = pc.nnz * (8 + 8 * K) + 16 * pc.M * K + 8 * pc.M + 12 * K * pc.V + 8 * K * K
-    F = newton * (K ** 3 / 3.0 + 4 * K * K) + 6.0 * K * pc.nnz * (sweeps / pc.M)
-    from oracle import oracle as oc
-    sh = pc.shard(0, 1500)
-    beta0 = tm.dirichlet_rows(K, pc.V, seed=7)
-    def ostep(m, nt):
-        m.estep(omp_threads=nt); m.update_beta(); m.update_sigma_mu()
-    cpu = cpu_line("port of src/CTM.jl train!", lambda: oc.CTM(oc.CSR(sh.doc_ptr, sh.terms, sh.counts, sh.V), K, beta0), ostep,
-                   sh.M / pc.M, f"first {sh.M} documents of SYN-NSF (the Newton solves scale with the document count), K=50, cold start")
-    return {"cpu_baseline": cpu, "metric": "VB iters/sec, CTM K=50 on NSF-shaped corpus (config 4)", "value": 1.0 / sec, "unit": "VB iters/sec",
-            "ms_per_step": 1e3 * sec, "dtype": "f32 (fp64 gradients / logzeta / vsq)", "data": "synthetic",
-            "config": {"workload": "CTM K=50, SYN-NSF, train! defaults (niter=1000 ntol=1/K^2 viter=10 vtol=1/K^2), cold start, 2 warm-up + 6 timed iterations",
-                       "M": pc.M, "V": pc.V, "nnz": pc.nnz, "lambda_newton_steps_last_iteration": int(newton), "sweeps_last_iteration": sweeps},
-            "roofline": {"bound": "valu (register Gauss-Jordan; f32 MFMA has the same peak)", "achieved": F / sec / 1e12, "peak": F32_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": F / sec / 1e12 / F32_PEAK_TFLOPS, "flops_per_iteration": F,
+    tok = 6.0 * K * pc.nnz * (sweeps / pc.M)
+    F_nom = newton * (K ** 3 / 3.0 + 4 * K * K) + tok
+    # what the lane-per-document kernel issues: a wave runs every loop until its slowest lane is done (64 lanes per trip);
+    # one CG trip = one K x K mat-vec + 5 vector updates, one Newton trip = the gradient's mat-vec + exp / assembly
+    F_exec = 64.0 * (st["cg_trips"] * (2 * KP * KP + 12 * KP) + st["newton_trips"] * (2 * KP * KP + 24 * KP)) + tok if st["waves"] else None
+    line = {"metric": "VB iters/sec, CTM K=50 on NSF-shaped corpus (config 4)", "value": 1.0 / sec, "unit": "VB iters/sec",
+            "ms_per_step": 1e3 * sec, "estep_ms": es_ms, "dtype": "f32 (fp64 gradients / logzeta / vsq)", "data": "synthetic",
+            "config": {"workload": f"CTM K=50, SYN-NSF, train! defaults (niter=1000 ntol=1/K^2 viter=10 vtol=1/K^2), steady state: {burnin} untimed "
+                                   f"iterations from the cold start, then {warmup} warm-up + {steps} timed",
+                       "M": pc.M, "V": pc.V, "nnz": pc.nnz, "lambda_newton_steps_last_iteration": int(newton), "sweeps_last_iteration": sweeps,
+                       "sweep_hist_last_step": [int(h) for h in hist],
+                       "kernel": "ctm_estep_batch_kernel (lane per document, Jacobi-preconditioned CG Newton solves)" if st["waves"] else "wave per document",
+                       "cg_wave_trips": st["cg_trips"], "newton_wave_trips": st["newton_trips"]},
+            "cold_start": {"value": 1.0 / cold, "ms_per_step": 1e3 * cold, "window": f"iterations {warmup + 1}..{warmup + steps} from the cold start"},
+            "roofline": {"bound": "valu (packed fp32 CG mat-vecs with invsigma streamed through SGPRs; f32 MFMA has the same peak and is not used in the solve)",
+                         "achieved": F_nom / sec / 1e12, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": F_nom / sec / 1e12 / F32_PEAK_TFLOPS,
+                         "flops_per_iteration_nominal": F_nom,
+                         "nominal_is": "SURVEY.md 8d: newton steps x (K^3/3 + 4K^2) + 6 K N_d per sweep -- the flops a direct factorisation per Newton step would execute",
+                         "flops_per_iteration_executed": F_exec, "executed_TFLOPs": (F_exec / sec / 1e12) if F_exec else None,
+                         "executed_frac": (F_exec / sec / 1e12 / F32_PEAK_TFLOPS) if F_exec else None,
+                         "executed_is": "64 lanes x (CG wave trips x (2 KP^2 + 12 KP) + Newton wave trips x (2 KP^2 + 24 KP)) + token phase; idle lanes of a trip included",
                          "hbm_GBs": B / sec / 1e9, "hbm_frac": B / sec / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_iteration": B, "traffic": None}}
+    gm.close()
+    if cpu:
+        from oracle import oracle as oc
+
+        def ostep(m, nt):
+            m.estep(omp_threads=nt); m.update_beta(); m.update_sigma_mu()
+        line["cpu_baseline"] = cpu_line("port of src/CTM.jl train!", lambda: oc.CTM(oc.CSR(pc.doc_ptr, pc.terms, pc.counts, pc.V), K, beta0), ostep,
+                                        1.0, f"FULL SYN-NSF ({pc.M} documents), K=50; one iteration takes ~10 s, so no warm-up iteration", warm=0, timed=1, full=True)
+    return line
 
 
-def ctpf():
+def ctpf(burnin=60, warmup=5, steps=50, cpu=True):
     K = 50
     pc = tm.syn_citeu()
     gm = tm.gpuCTPF(pc, K)
+
     def it():
         gm.estep(); gm.reduce_docs(); gm.mstep()
-    sec = timed(it, 50, 5, gm.synchronize)
+    cold = window(it, gm.synchronize, 0, warmup, steps)
+    sec = window(it, gm.synchronize, max(burnin - warmup - steps, 0), warmup, steps)
+    es_ms = gm.last_estep_ms()
+    hist = gm.sweep_hist().tolist()
+    # a checked iteration (update_elbo! on the device after every M-step)
+    gm.synchronize(); t0 = time.perf_counter()
+    for _ in range(10):
+        it(); gm.update_elbo()
+    gm.synchronize(); checked = (time.perf_counter() - t0) / 10
     B = pc.nnz * (8 + 8 * K) + pc.nR * (8 + 8 * K) + 16 * pc.M * K + 12 * K * (pc.V + pc.U)
     ms_s, ms_r = gm.recommend(scores=False)
-    from oracle import oracle as oc
-    sh = pc.shard(0, 3000)
-    alef0 = np.exp(tm.dirichlet_rows(K, pc.V, seed=7) - 0.5)
-    def ostep(m, nt):
-        m.estep(omp_threads=nt); m.mstep()
-    cpu = cpu_line("port of src/CTPF.jl train!", lambda: oc.CTPF(oc.CSR(sh.doc_ptr, sh.terms, sh.counts, sh.V, sh.rdr_ptr, sh.readers, sh.ratings, sh.U), K, alef0),
-                   ostep, (sh.nnz + sh.nR) / (pc.nnz + pc.nR), f"first {sh.M} documents of SYN-CITEU ({sh.nnz}+{sh.nR} of {pc.nnz}+{pc.nR} term+reader entries), K=50, cold start")
-    return {"cpu_baseline": cpu, "metric": "VB iters/sec, CTPF K=50 on CiteULike-shaped corpus (config 5)", "value": 1.0 / sec, "unit": "VB iters/sec",
-            "ms_per_step": 1e3 * sec, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "CTPF K=50, SYN-CITEU with readers, train! defaults (viter=10 vtol=1/K^2 checkelbo=Inf), cold start, 5 warm-up + 50 timed iterations",
-                       "M": pc.M, "V": pc.V, "U": pc.U, "nnz": pc.nnz, "nR": pc.nR},
+    line = {"metric": "VB iters/sec, CTPF K=50 on CiteULike-shaped corpus (config 5)", "value": 1.0 / sec, "unit": "VB iters/sec",
+            "ms_per_step": 1e3 * sec, "estep_ms": es_ms, "ms_per_checked_step": 1e3 * checked, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"CTPF K=50, SYN-CITEU with readers, train! defaults (viter=10 vtol=1/K^2 checkelbo=Inf), steady state: {burnin} untimed "
+                                   f"iterations from the cold start, then {warmup} warm-up + {steps} timed",
+                       "M": pc.M, "V": pc.V, "U": pc.U, "nnz": pc.nnz, "nR": pc.nR, "sweep_hist_last_step": hist},
+            "cold_start": {"value": 1.0 / cold, "ms_per_step": 1e3 * cold, "window": f"iterations {warmup + 1}..{warmup + steps} from the cold start"},
             "roofline": {"bound": "hbm", "achieved": B / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": B / sec / 1e9 / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_iteration": B, "traffic": None},
             "recommend": {"ms_scores": ms_s, "ms_rank": ms_r, "pairs": pc.M * pc.U}}
+    gm.close()
+    if cpu:
+        from oracle import oracle as oc
+        alef0 = np.exp(tm.dirichlet_rows(K, pc.V, seed=7) - 0.5)
+
+        def ostep(m, nt):
+            m.estep(omp_threads=nt); m.mstep()
+        line["cpu_baseline"] = cpu_line("port of src/CTPF.jl train!",
+                                        lambda: oc.CTPF(oc.CSR(pc.doc_ptr, pc.terms, pc.counts, pc.V, pc.rdr_ptr, pc.readers, pc.ratings, pc.U), K, alef0),
+                                        ostep, 1.0, f"FULL SYN-CITEU ({pc.M} documents, {pc.nnz} term + {pc.nR} reader entries), K=50", warm=1, timed=2, full=True)
+    return line
 
 
-def cpu_line_1t(kind, make, step, frac, sample_note):
-    """Single-thread cpu_baseline (the filtered-model oracles have no OpenMP E-step)."""
-    m = make()
-    t0 = time.perf_counter(); step(m); one = 1.0 / (time.perf_counter() - t0)
-    return {"value": one * frac, "unit": "VB iters/sec", "cores": 1, "kind": "port",
-            "sample": f"fp64 C oracle ({kind}), {sample_note}; 1 single-thread iteration; value = sample iters/s x work fraction {frac:.4f}"}
-
-
-def flda():
+def flda(burnin=60, warmup=3, steps=20, cpu=True):
     K = 50
     pc = tm.syn_nsf()
     gm = tm.gpufLDA(pc, K)
     gm.beta = np.asfortranarray(tm.dirichlet_rows(K, pc.V, seed=7)); gm.beta_old = gm.beta.copy(order="F")
     gm.kappa = tm.dirichlet_rows(1, pc.V, seed=9)[0].copy(); gm.kappa_old = gm.kappa.copy(); gm.update_buffer()
+
     def it():
         gm.estep(10, 1.0 / K ** 2); gm.reduce_docs(); gm.update_beta(); gm.update_alpha(1000, 1.0 / K ** 2); gm.update_eta()
-    sec = timed(it, 20, 3, gm.synchronize)
+    cold = window(it, gm.synchronize, 0, warmup, steps)
+    sec = window(it, gm.synchronize, max(burnin - warmup - steps, 0), warmup, steps)
     es = gm.last_estep_ms()
     # LDA's bytes + tau / tau_old / lse (read + write per token entry) + the kappa statistics
     B = pc.nnz * (8 + 8 * K + 24) + 12 * pc.M * K + 12 * K * pc.V + 8 * pc.V + 4 * (pc.M + 1)
-    from oracle import oracle as oc
-    sh = pc.shard(0, 4000)
-    beta0 = tm.dirichlet_rows(K, pc.V, seed=7); kappa0 = tm.dirichlet_rows(1, pc.V, seed=9)[0]
-    def ostep(m):
-        m.estep(); m.mstep()
-    cpu = cpu_line_1t("port of src/fLDA.jl train!", lambda: oc.fLDA(oc.CSR(sh.doc_ptr, sh.terms, sh.counts, sh.V), K, beta0, kappa0), ostep,
-                      sh.nnz / pc.nnz, f"first {sh.M} documents of SYN-NSF ({sh.nnz} of {pc.nnz} nnz), K=50, cold start")
-    return {"cpu_baseline": cpu, "metric": "VB iters/sec, fLDA K=50 on NSF-shaped corpus (section 8 row f4)", "value": 1.0 / sec, "unit": "VB iters/sec",
+    line = {"metric": "VB iters/sec, fLDA K=50 on NSF-shaped corpus (section 8 row f4)", "value": 1.0 / sec, "unit": "VB iters/sec",
             "ms_per_step": 1e3 * sec, "estep_ms": es, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "fLDA K=50, SYN-NSF, train! defaults, cold start, 3 warm-up + 20 timed iterations", "M": pc.M, "V": pc.V, "nnz": pc.nnz},
+            "config": {"workload": f"fLDA K=50, SYN-NSF, train! defaults, steady state: {burnin} untimed iterations, then {warmup} warm-up + {steps} timed",
+                       "M": pc.M, "V": pc.V, "nnz": pc.nnz},
+            "cold_start": {"value": 1.0 / cold, "ms_per_step": 1e3 * cold},
             "roofline": {"bound": "hbm", "achieved": B / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": B / sec / 1e9 / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_iteration": B, "traffic": None}}
+    gm.close()
+    if cpu:
+        from oracle import oracle as oc
+        sh = pc.shard(0, 16000)
+        beta0 = tm.dirichlet_rows(K, pc.V, seed=7); kappa0 = tm.dirichlet_rows(1, pc.V, seed=9)[0]
+
+        def ostep(m, nt):
+            m.estep(omp_threads=nt); m.mstep()
+        line["cpu_baseline"] = cpu_line("port of src/fLDA.jl train!", lambda: oc.fLDA(oc.CSR(sh.doc_ptr, sh.terms, sh.counts, sh.V), K, beta0, kappa0), ostep,
+                                        sh.nnz / pc.nnz, f"first {sh.M} documents of SYN-NSF ({sh.nnz} of {pc.nnz} nnz), K=50")
+    return line
 
 
-def fctm():
+def fctm(burnin=30, warmup=2, steps=6, cpu=True):
     K = 50
     pc = tm.syn_nsf()
     gm = tm.gpufCTM(pc, K)
     gm.beta = np.asfortranarray(tm.dirichlet_rows(K, pc.V, seed=7)); gm.beta_old = gm.beta.copy(order="F")
     gm.kappa = tm.dirichlet_rows(1, pc.V, seed=9)[0].copy(); gm.kappa_old = gm.kappa.copy(); gm.update_buffer()
+
     def it():
         gm.estep(); gm.reduce_docs(); gm.mstep()
-    sec = timed(it, 6, 2, gm.synchronize)
+    cold = window(it, gm.synchronize, 0, warmup, steps)
+    sec = window(it, gm.synchronize, max(burnin - warmup - steps, 0), warmup, steps)
     hist, newton = gm.sweep_hist()
     sweeps = int(sum(i * int(h) for i, h in enumerate(hist)))
     B = pc.nnz * (8 + 8 * K + 24) + 16 * pc.M * K + 8 * pc.M + 12 * K * pc.V + 8 * pc.V + 8 * K * K
     F = newton * (K ** 3 / 3.0 + 4 * K * K) + 8.0 * K * pc.nnz * (sweeps / pc.M)
-    from oracle import oracle as oc
-    sh = pc.shard(0, 400)
-    beta0 = tm.dirichlet_rows(K, pc.V, seed=7); kappa0 = tm.dirichlet_rows(1, pc.V, seed=9)[0]
-    def ostep(m):
-        m.estep(); m.mstep()
-    cpu = cpu_line_1t("port of src/fCTM.jl train!", lambda: oc.fCTM(oc.CSR(sh.doc_ptr, sh.terms, sh.counts, sh.V), K, beta0, kappa0), ostep,
-                      sh.M / pc.M, f"first {sh.M} documents of SYN-NSF (the Newton solves scale with the document count), K=50, cold start")
-    return {"cpu_baseline": cpu, "metric": "VB iters/sec, fCTM K=50 on NSF-shaped corpus (section 8 row f4)", "value": 1.0 / sec, "unit": "VB iters/sec",
+    line = {"metric": "VB iters/sec, fCTM K=50 on NSF-shaped corpus (section 8 row f4)", "value": 1.0 / sec, "unit": "VB iters/sec",
             "ms_per_step": 1e3 * sec, "dtype": "f32 (fp64 gradients / logzeta / vsq)", "data": "synthetic",
-            "config": {"workload": "fCTM K=50, SYN-NSF, train! defaults, cold start, 2 warm-up + 6 timed iterations",
+            "config": {"workload": f"fCTM K=50, SYN-NSF, train! defaults, steady state: {burnin} untimed iterations, then {warmup} warm-up + {steps} timed",
                        "M": pc.M, "V": pc.V, "nnz": pc.nnz, "lambda_newton_steps_last_iteration": int(newton), "sweeps_last_iteration": sweeps},
-            "roofline": {"bound": "valu (register Gauss-Jordan)", "achieved": F / sec / 1e12, "peak": F32_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": F / sec / 1e12 / F32_PEAK_TFLOPS, "flops_per_iteration": F,
+            "cold_start": {"value": 1.0 / cold, "ms_per_step": 1e3 * cold},
+            "roofline": {"bound": "valu (packed fp32 CG mat-vecs, K v_exp_f32 per token per sweep)", "achieved": F / sec / 1e12, "peak": F32_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": F / sec / 1e12 / F32_PEAK_TFLOPS, "flops_per_iteration_nominal": F,
                          "hbm_GBs": B / sec / 1e9, "hbm_frac": B / sec / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_iteration": B, "traffic": None}}
+    gm.close()
+    if cpu:
+        from oracle import oracle as oc
+        sh = pc.shard(0, 4000)
+        beta0 = tm.dirichlet_rows(K, pc.V, seed=7); kappa0 = tm.dirichlet_rows(1, pc.V, seed=9)[0]
 
+        def ostep(m, nt):
+            m.estep(omp_threads=nt); m.mstep()
+        line["cpu_baseline"] = cpu_line("port of src/fCTM.jl train!", lambda: oc.fCTM(oc.CSR(sh.doc_ptr, sh.terms, sh.counts, sh.V), K, beta0, kappa0), ostep,
+                                        sh.M / pc.M, f"first {sh.M} documents of SYN-NSF (the Newton solves scale with the document count), K=50")
+    return line
+
+
+ALL = {"lda100": lda100, "ctm": ctm, "ctpf": ctpf, "flda": flda, "fctm": fctm}
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["lda100", "ctm", "ctpf", "flda", "fctm"]
+    which = sys.argv[1:] or list(ALL)
     for w in which:
-        print(json.dumps({"lda100": lda100, "ctm": ctm, "ctpf": ctpf, "flda": flda, "fctm": fctm}[w]()), flush=True)
+        print(json.dumps(ALL[w]()), flush=True)

@@ -51,20 +51,26 @@ def _sources():
     return out
 
 
+LAST_BUILD = {"mode": "not run", "compiled": [], "linked": False}
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
-    """hipcc --offload-arch=gfx950 build of libtmvb_hip.so (in-tree)."""
+    """hipcc --offload-arch=gfx950 build of libtmvb_hip.so (in-tree).  LAST_BUILD records what this call did: "reused" (the
+    library is newer than every source), or "compiled" with the translation units that went through hipcc."""
+    global LAST_BUILD
     srcs = _sources()
     deps = srcs + [os.path.join(_HERE, "csrc", h) for h in sorted(os.listdir(os.path.join(_HERE, "csrc"))) if h.endswith(".h")] \
         + [os.path.join(_ROOT, "include", "tmvb.h")]
     if not force and os.path.exists(LIB_PATH):
         if all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps if os.path.exists(d)):
+            LAST_BUILD = {"mode": "reused", "compiled": [], "linked": False}
             return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     flags = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wno-pass-failed",
              "-I", os.path.join(_ROOT, "include"), "-I", os.path.join(_HERE, "csrc")]
     objdir = os.path.join(_HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    procs, objs = [], []
+    procs, objs, compiled = [], [], []
     for src in srcs:                      # one hipcc per translation unit, in parallel
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         objs.append(obj)
@@ -76,6 +82,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             cmd.insert(-4, "-save-temps=obj")      # keeps build/tmvb_ctm-hip-amdgcn-amd-amdhsa-gfx950.s for the ISA check below
         if verbose:
             print(" ".join(cmd))
+        compiled.append(os.path.basename(src))
         procs.append((cmd, subprocess.Popen(cmd)))
     for cmd, pr in procs:
         if pr.wait() != 0:
@@ -95,11 +102,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if verbose:
             print(res.stdout.strip().splitlines()[-1])
     rocm_lib = os.path.join(os.path.dirname(os.path.dirname(hipcc)), "lib")
-    # RCCL carries the document-sharded all-reduce (tmvb_comm.hip)
-    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH] + objs + ["-L" + rocm_lib, "-lrccl", "-Wl,-rpath," + rocm_lib]
+    # RCCL carries the document-sharded all-reduce (tmvb_comm.hip); it is bound with dlopen at the first communicator call
+    # (the rpath lets that dlopen find /opt/rocm/lib/librccl.so.1), so single-GPU use needs no RCCL on the machine
+    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH] + objs + ["-ldl", "-Wl,-rpath," + rocm_lib]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    LAST_BUILD = {"mode": "compiled", "compiled": compiled, "linked": True}
     return LIB_PATH
 
 

@@ -3,14 +3,17 @@
 // The reference is single-device (one OpenCL queue, src/gpuLDA.jl:64); its only multi-batch precedent is the v0.6
 // `newbeta +=` accumulation (v0.6/src/gpuLDA.jl:200-225).  Here documents shard across the GPUs of one node and the one
 // exchange per outer iteration is a sum-all-reduce of the packed sufficient statistics.
-// Backends: RCCL (ncclCommInitRank with a host-broadcast unique id for one process per GPU, ncclCommInitAll for one host
+// Backends: RCCL (bound with dlopen at the first communicator call; ncclCommInitRank with a host-broadcast unique id for one process per GPU, ncclCommInitAll for one host
 // thread driving n GPUs) and a host-callback transport that stages the buffer through pinned memory (MPI / gloo hosts,
 // single-GPU tests).  Host code only; no kernels.
 #include "tmvb_internal.h"
 
-#include <rccl/rccl.h>
+#include <rccl/rccl.h>          // types and NCCL_VERSION_CODE only: the library itself is loaded on first use (below)
+
+#include <dlfcn.h>
 
 #include <cstring>
+#include <mutex>
 
 struct tmvb_comm {
     tmvb_ctx* ctx = nullptr;
@@ -23,29 +26,86 @@ struct tmvb_comm {
     size_t pinned_bytes = 0;
 };
 
+// RCCL is bound at the first communicator call, not at load time: single-GPU use of libtmvb_hip.so needs no RCCL at all, and a
+// process that already holds an RCCL (PyTorch ships its own librccl with the same SONAME) keeps exactly one copy -- the one
+// already mapped is taken (RTLD_NOLOAD) before the loader's search path and /opt/rocm/lib are tried.  The header this file
+// was compiled against and the runtime must agree in their major version (struct layouts, enum values); checked once.
+namespace {
+struct RcclApi {
+    void* so = nullptr;
+    int version = 0;
+    decltype(&ncclGetVersion) GetVersion = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string error;
+};
+RcclApi g_rccl;
+std::once_flag g_rccl_once;
+
+void rccl_bind()
+{
+    RcclApi& a = g_rccl;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    if (const char* e = getenv("TMVB_RCCL_LIB")) a.so = dlopen(e, RTLD_NOW | RTLD_LOCAL);
+    for (int pass = 0; pass < 2 && !a.so; ++pass)
+        for (const char* n : names) {
+            a.so = dlopen(n, (pass == 0 ? RTLD_NOLOAD : 0) | RTLD_NOW | RTLD_LOCAL);
+            if (a.so) break;
+        }
+    if (!a.so) { a.error = std::string("RCCL is not available: ") + (dlerror() ? dlerror() : "librccl.so.1 not found") + " (set TMVB_RCCL_LIB)"; return; }
+#define TMVB_RCCL_SYM(field, sym)                                                         \
+    a.field = reinterpret_cast<decltype(a.field)>(dlsym(a.so, #sym));                     \
+    if (!a.field) { a.error = "librccl has no symbol " #sym; return; }
+    TMVB_RCCL_SYM(GetVersion, ncclGetVersion) TMVB_RCCL_SYM(GetUniqueId, ncclGetUniqueId) TMVB_RCCL_SYM(CommInitRank, ncclCommInitRank)
+    TMVB_RCCL_SYM(CommInitAll, ncclCommInitAll) TMVB_RCCL_SYM(CommDestroy, ncclCommDestroy) TMVB_RCCL_SYM(AllReduce, ncclAllReduce)
+    TMVB_RCCL_SYM(GroupStart, ncclGroupStart) TMVB_RCCL_SYM(GroupEnd, ncclGroupEnd) TMVB_RCCL_SYM(GetErrorString, ncclGetErrorString)
+#undef TMVB_RCCL_SYM
+    if (a.GetVersion(&a.version) != ncclSuccess) { a.error = "ncclGetVersion failed"; return; }
+    // version code: major * 10000 + minor * 100 + patch (NCCL >= 2.9)
+    if (a.version / 10000 != NCCL_VERSION_CODE / 10000) {
+        char buf[160];
+        snprintf(buf, sizeof buf, "RCCL runtime version %d does not match the header libtmvb_hip.so was built against (%d): major versions differ",
+                 a.version, (int)NCCL_VERSION_CODE);
+        a.error = buf;
+    }
+}
+
+// TMVB_OK when RCCL is bound and version-compatible, otherwise TMVB_ERCCL with the reason
+int rccl_ready()
+{
+    std::call_once(g_rccl_once, rccl_bind);
+    if (!g_rccl.error.empty()) { tmvb_set_error("%s", g_rccl.error.c_str()); return TMVB_ERCCL; }
+    return TMVB_OK;
+}
+}  // namespace
+
 #define TMVB_NCCL(call)                                                                         \
     do {                                                                                        \
-        ncclResult_t r_ = (call);                                                               \
+        ncclResult_t r_ = (g_rccl.call);                                                        \
         if (r_ != ncclSuccess) {                                                                \
-            tmvb_set_error("%s failed: %s (%s:%d)", #call, ncclGetErrorString(r_), __FILE__,    \
-                           __LINE__);                                                           \
+            tmvb_set_error("nccl%s failed: %s (%s:%d)", #call, g_rccl.GetErrorString(r_), __FILE__, __LINE__);    \
             return TMVB_ERCCL;                                                                  \
         }                                                                                       \
     } while (0)
 
 extern "C" int tmvb_rccl_version(void)
 {
-    int v = 0;
-    if (ncclGetVersion(&v) != ncclSuccess) return 0;
-    return v;
+    return rccl_ready() == TMVB_OK ? g_rccl.version : 0;
 }
 
 extern "C" int tmvb_comm_unique_id(void* id_out)
 {
     TMVB_REQUIRE(id_out != nullptr, TMVB_EINVAL, "tmvb_comm_unique_id: id_out is NULL");
     static_assert(sizeof(ncclUniqueId) == TMVB_UNIQUE_ID_BYTES, "ncclUniqueId size");
+    if (int rc = rccl_ready()) return rc;
     ncclUniqueId id;
-    TMVB_NCCL(ncclGetUniqueId(&id));
+    TMVB_NCCL(GetUniqueId(&id));
     memcpy(id_out, &id, sizeof(id));
     return TMVB_OK;
 }
@@ -56,11 +116,12 @@ extern "C" int tmvb_comm_create_rccl(tmvb_ctx* ctx, const void* unique_id, int32
     *out = nullptr;
     TMVB_REQUIRE(ctx && unique_id, TMVB_EINVAL, "tmvb_comm_create_rccl: NULL context or unique id");
     TMVB_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, TMVB_EINVAL, "tmvb_comm_create_rccl: rank %d not in [0,%d)", rank, nranks);
+    if (int rc = rccl_ready()) return rc;
     TMVB_HIP(hipSetDevice(ctx->device));
     ncclUniqueId id;
     memcpy(&id, unique_id, sizeof(id));
     ncclComm_t c = nullptr;
-    TMVB_NCCL(ncclCommInitRank(&c, nranks, id, rank));
+    TMVB_NCCL(CommInitRank(&c, nranks, id, rank));
     tmvb_comm* h = new tmvb_comm();
     h->ctx = ctx; h->nranks = nranks; h->rank = rank; h->backend = 0; h->nccl = c;
     *out = h;
@@ -78,8 +139,9 @@ extern "C" int tmvb_comm_create_rccl_all(tmvb_ctx* const* ctxs, int32_t n, tmvb_
             TMVB_REQUIRE(devs[j] != devs[i], TMVB_EINVAL, "tmvb_comm_create_rccl_all: device %d appears twice (one rank per GPU)", devs[i]);
         out[i] = nullptr;
     }
+    if (int rc = rccl_ready()) return rc;
     std::vector<ncclComm_t> comms(n, nullptr);
-    TMVB_NCCL(ncclCommInitAll(comms.data(), n, devs.data()));
+    TMVB_NCCL(CommInitAll(comms.data(), n, devs.data()));
     for (int i = 0; i < n; ++i) {
         tmvb_comm* h = new tmvb_comm();
         h->ctx = ctxs[i]; h->nranks = n; h->rank = i; h->backend = 0; h->nccl = comms[i];
@@ -104,7 +166,7 @@ extern "C" int tmvb_comm_destroy(tmvb_comm* c)
 {
     if (!c) return TMVB_OK;
     if (c->ctx) (void)hipSetDevice(c->ctx->device);
-    if (c->nccl) (void)ncclCommDestroy(c->nccl);
+    if (c->nccl && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->nccl);
     if (c->pinned) (void)hipHostFree(c->pinned);
     delete c;
     return TMVB_OK;
@@ -127,7 +189,7 @@ static int comm_allreduce_one(tmvb_comm* c, void* dev_ptr, int64_t count, int32_
     tmvb_ctx* ctx = c->ctx;
     TMVB_HIP(hipSetDevice(ctx->device));
     if (c->backend == 0) {
-        TMVB_NCCL(ncclAllReduce(dev_ptr, dev_ptr, (size_t)count, dtype == TMVB_F32 ? ncclFloat32 : ncclFloat64, ncclSum, c->nccl, ctx->stream));
+        TMVB_NCCL(AllReduce(dev_ptr, dev_ptr, (size_t)count, dtype == TMVB_F32 ? ncclFloat32 : ncclFloat64, ncclSum, c->nccl, ctx->stream));
         return TMVB_OK;
     }
     const size_t bytes = (size_t)count * (dtype == TMVB_F32 ? 4 : 8);
@@ -163,11 +225,11 @@ int tmvb_comm_allreduce_group(tmvb_comm* const* comms, void* const* dev_ptrs, co
         all_rccl = all_rccl && comms[i]->backend == 0;
     }
     TMVB_REQUIRE(all_rccl, TMVB_EINVAL, "grouped all-reduce over several local handles needs RCCL communicators (tmvb_comm_create_rccl_all)");
-    TMVB_NCCL(ncclGroupStart());
+    TMVB_NCCL(GroupStart());
     int rc = TMVB_OK;
     for (int i = 0; i < n && rc == TMVB_OK; ++i) rc = comm_allreduce_one(comms[i], dev_ptrs[i], counts[i], dtype);
-    ncclResult_t r = ncclGroupEnd();
+    ncclResult_t r = g_rccl.GroupEnd();
     if (rc) return rc;
-    if (r != ncclSuccess) { tmvb_set_error("ncclGroupEnd failed: %s", ncclGetErrorString(r)); return TMVB_ERCCL; }
+    if (r != ncclSuccess) { tmvb_set_error("ncclGroupEnd failed: %s", g_rccl.GetErrorString(r)); return TMVB_ERCCL; }
     return TMVB_OK;
 }

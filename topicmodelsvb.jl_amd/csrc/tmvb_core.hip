@@ -258,7 +258,7 @@ int tmvb_build_inv_index(tmvb_ctx* ctx, int64_t M, int64_t n_ids, const int64_t*
     static const int64_t class_docs = [] { const char* e = getenv("TMVB_CLASS_DOCS"); return e ? (int64_t)atoi(e) : (int64_t)TMVB_CLASS_DOCS; }();
     static const int64_t class_min = [] { const char* e = getenv("TMVB_CLASS_MIN_POSTINGS"); return e ? (int64_t)atoi(e) : (int64_t)TMVB_CLASS_MIN_POSTINGS; }();
     int NC = 8 * (int)((ndocs + 8 * class_docs - 1) / (8 * class_docs));
-    if (class_env >= 0) NC = class_env;
+    if (class_env >= 0) NC = 8 * ((class_env + 7) / 8);               // classes are emitted in rounds of 8 (one per XCD): round up
     if (ndocs < 4 * class_docs && class_env < 0) NC = 0;               // everything fits a couple of L2s anyway
     std::vector<std::vector<Chunk>> cls((size_t)std::max(NC, 1));
     std::vector<Chunk> rare;
@@ -291,6 +291,8 @@ int tmvb_build_inv_index(tmvb_ctx* ctx, int64_t M, int64_t n_ids, const int64_t*
             }
         }
     }
+    size_t total_chunks = rare.size();
+    for (const auto& L : cls) total_chunks += L.size();
     std::vector<Chunk> order;
     order.reserve(rare.size() + 64);
     size_t rare_used = 0;
@@ -308,6 +310,8 @@ int tmvb_build_inv_index(tmvb_ctx* ctx, int64_t M, int64_t n_ids, const int64_t*
         }
     }
     for (; rare_used < rare.size(); ++rare_used) order.push_back(rare[rare_used]);
+    // every chunk holds postings (and multi-chunk ids a partial-sum slot): one left out of the launch order would drop them silently
+    TMVB_REQUIRE(order.size() == total_chunks, TMVB_EINVAL, "statistics chunk order holds %zu of %zu chunks (NC = %d)", order.size(), total_chunks, NC);
     std::vector<int32_t> cid(order.size()), cb(order.size()), ce(order.size()), co(order.size());
     for (size_t q = 0; q < order.size(); ++q) { cid[q] = order[q].id; cb[q] = order[q].b; ce[q] = order[q].e; co[q] = order[q].out; }
     ix->n_chunks = (int64_t)cid.size(); ix->n_multi = (int64_t)mid.size(); ix->n_slots = slots;
