@@ -1,10 +1,11 @@
 """
 GPU parity tests for the CTM path: HIP engine (C ABI) vs the fp64 oracle and the committed golden fixture.
-Tolerances (fp64 -> fp32 state; fp64 Newton gradients on device):
-  teacher-forced single step : lambda abs <= 2e-3 + rel 2e-3 (fp32 Gauss-Jordan steps, exit at ||g|| < ntol),
-                               vsq rel <= 2e-3, logzeta abs <= 1e-3, beta rel <= 5e-4 on entries > 1e-6,
-                               mu abs <= 1e-4, sigma abs <= 2e-4 * max|sigma|, ELBO rel <= 2e-6
-  free running               : ELBO rel <= 2e-4 per iteration
+Tolerances (fp64 -> fp32 state; fp64 Newton gradients on device) = 5x the deviations measured on MI355X with
+tests/measure_tolerances.py (profiles/r3_ctm_deviations.txt: worst case K = 50 on the CG kernel, |dlambda| 3.0e-5, vsq 1.7e-5,
+logzeta 1.5e-6, beta 2.0e-5, mu 1.1e-6, sigma 1.5e-6, ELBO 3.6e-8; the direct-solve kernels sit at 1e-6):
+  teacher-forced single step : lambda abs <= 1.5e-4 + rel 1.5e-4, vsq rel <= 1e-4, logzeta abs <= 1e-5,
+                               beta rel <= 1e-4 on entries > 1e-6, mu abs <= 1e-5, sigma abs <= 1e-5 * max|sigma|, ELBO rel <= 2e-7
+  free running K = 50 (CG)   : ELBO rel <= 1e-6 per iteration (measured <= 1.1e-7; SURVEY.md section 8c asks 1e-4)
 K <= 50 runs the lane-per-document kernel (ctm_estep_batch_kernel: CG Newton solves), 50 < K <= 60 the register Gauss-Jordan kernel,
 60 < K <= 128 the LDS Newton solve (ctm_estep_generic_kernel); the two K <= 50 kernels are also compared with each other below.
 """
@@ -64,15 +65,15 @@ def test_teacher_forced_step(tmvb, oracle, case):
         step(gm); step(om)
         e_g = gm.update_elbo(); e_o = om.update_elbo()
         gm.update_host()
-        assert np.all(np.abs(gm.lam - om.lam) <= 2e-3 + 2e-3 * np.abs(om.lam)), (it, np.abs(gm.lam - om.lam).max())
-        assert np.all(np.abs(gm.vsq - om.vsq) <= 2e-3 * om.vsq), (it, "vsq")
-        assert np.abs(gm.logzeta - om.logzeta).max() <= 1e-3, (it, "logzeta")
+        assert np.all(np.abs(gm.lam - om.lam) <= 1.5e-4 + 1.5e-4 * np.abs(om.lam)), (it, np.abs(gm.lam - om.lam).max())
+        assert np.all(np.abs(gm.vsq - om.vsq) <= 1e-4 * om.vsq), (it, "vsq")
+        assert np.abs(gm.logzeta - om.logzeta).max() <= 1e-5, (it, "logzeta")
         big = om.beta > 1e-6
-        assert (np.abs(gm.beta[big] - om.beta[big]) / om.beta[big]).max() <= 5e-4, (it, "beta")
-        assert np.abs(gm.mu - om.mu).max() <= 1e-4, (it, "mu")
-        assert np.abs(gm.sigma - om.sigma).max() <= 2e-4 * np.abs(om.sigma).max(), (it, "sigma")
+        assert (np.abs(gm.beta[big] - om.beta[big]) / om.beta[big]).max() <= 1e-4, (it, "beta")
+        assert np.abs(gm.mu - om.mu).max() <= 1e-5, (it, "mu")
+        assert np.abs(gm.sigma - om.sigma).max() <= 1e-5 * np.abs(om.sigma).max(), (it, "sigma")
         assert np.abs(gm.invsigma - om.invsigma).max() <= 1e-3 * np.abs(om.invsigma).max(), (it, "invsigma")
-        assert abs(e_g - e_o) <= 2e-6 * abs(e_o), (it, e_g, e_o)
+        assert abs(e_g - e_o) <= 2e-7 * abs(e_o), (it, e_g, e_o)
         np.testing.assert_allclose(gm.beta.sum(axis=1), 1.0, rtol=1e-5)
         assert np.all(gm.vsq > 0)
         np.linalg.cholesky(gm.sigma)                     # check_model: sigma positive-definite
@@ -209,13 +210,13 @@ def test_full_size_nsf_properties_k50(tmvb, monkeypatch):
 
 # deviations of the free-running K = 50 run below, measured with tests/measure_tolerances.py on MI355X (profiles/r3_ctm_deviations.txt);
 # the bounds are 3-5x those figures
-FREE_K50_ELBO_RTOL = 1e-4
+FREE_K50_ELBO_RTOL = 1e-6
 
 
 def test_free_running_k50_cg_kernel_tracks_the_oracle(tmvb, oracle):
     """20 free-running iterations of CTM K = 50 on a 1 500-document NSF-shaped corpus with the DEFAULT kernel (lane per
     document, Newton systems solved inexactly by preconditioned CG) against the fp64 oracle (exact solves): the inexact
-    Newton must not drift -- ELBO rel <= 1e-4 at every iteration, same stop decision +-1 under the
+    Newton must not drift -- ELBO rel <= 1e-6 at every iteration (SURVEY.md section 8c asks 1e-4), same stop decision +-1 under the
     signed rule (Q4)."""
     pc = tmvb.syn_nsf(M=1500, V=25319, seed=2)
     K = 50
@@ -240,8 +241,9 @@ def test_free_running_k50_cg_kernel_tracks_the_oracle(tmvb, oracle):
     assert n >= 5
     assert np.all(np.abs(t_g[:n] - t_o[:n]) <= FREE_K50_ELBO_RTOL * np.abs(t_o[:n])), (t_g, t_o)
     if len(t_g) == len(t_o):
-        assert np.abs(gm.mu - om.mu).max() <= 5e-3
-        assert np.abs(gm.sigma - om.sigma).max() <= 5e-3 * np.abs(om.sigma).max()
+        assert np.abs(gm.mu - om.mu).max() <= 2e-4                              # measured 3.1e-5
+        assert np.abs(gm.sigma - om.sigma).max() <= 1e-4 * np.abs(om.sigma).max()     # measured 1.9e-5
+        assert np.quantile(np.abs(gm.lam - om.lam), 0.999) <= 1.5e-3             # measured 2.3e-4 (max 2.2e-2: a document one sweep apart)
 
 
 # ------------------------------------------------------------------ the two E-step kernels against each other
