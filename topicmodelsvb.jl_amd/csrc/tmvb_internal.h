@@ -58,6 +58,7 @@ struct tmvb_bucket {
     int32_t reg_tiles = 0;     // > 0: register-tile kernel with this many 64-token tiles (no LDS tile)
     int32_t piece = 0;         // pipelined E-step: which statistics pass consumes this bucket's documents
     int32_t waves = 1;         // > 1: register-tile kernel with one workgroup of `waves` waves per (long) document
+    int32_t grid_np = 0;       // > 0: grid-tile kernel (tmvb_gridtile.h) with this many token PAIRS per lane (<= 32 grid_np tokens)
 };
 
 // Inverted (id-major) index over a CSR token stream, cut into chunks of at most TMVB_CHUNK tokens.

@@ -31,6 +31,7 @@
 #include "tmvb_train.h"
 #include "tmvb_dirichlet.h"
 #include "tmvb_regtile.h"
+#include "tmvb_gridtile.h"
 
 // e_q of the first TMVB_LDA_E_LDS topics reach the lanes through LDS (one ds_write, broadcast ds_read_b128) instead of
 // v_readlane: moves phase 1's broadcast issue slots from the saturated VALU to the idle LDS pipe.  Must be a multiple of 32
@@ -500,6 +501,162 @@ __global__ __launch_bounds__(64) void lda_estep_reg_any_kernel(LdaParams p, int6
     else lda_estep_reg_body<LPR, 1>(p, d, off, N, topic_of_lane);
 }
 
+// ------------------------------------------------------------------------------ grid-tile E-step (tmvb_gridtile.h)
+// One wave = one document of at most 32 NP unique terms; lane l = (token group a = l >> 2, topic class b = l & 3) holds the
+// sub-tile {tokens 16 s + a, s < 2 NP} x {topics 4 j + b, j < LPR} as NP x LPR register pairs (pair = two token slots).
+// Same arithmetic per sweep as lda_estep_reg_body (src/LDA.jl:172-175); what differs is where the sums run:
+//   s_n   = K eps + sum_i B[n][i] e_i      LPR packed fmas per token pair + a 4-lane all-reduce (2 DPP adds per token slot)
+//   g_i   = sum_n w_n B[n][i]              LPR packed fmas per token pair, one add per topic to fold the pair, then the
+//                                          16-lane reduce-scatter of LPR + 1 values (sum_n w_n rides along as value LPR)
+//   psi(sum gamma): sum_i gamma_i = K eps + sum alpha + C_d in exact arithmetic (sum_i phi_in = 1), a per-document constant --
+//                   evaluated once per document, not once per sweep (the fp64 reference's own sum agrees with it to 1e-16).
+template <int LPR, int NP>
+__device__ __forceinline__ void lda_estep_grid_body(const LdaParams& p, const int d, const int64_t off, const int N,
+                                                    const int* __restrict__ topic_of_lane)
+{
+    constexpr int M = LPR + 1;                       // values of the reduce-scatter: LPR topics of the class + sum w
+    constexpr int NS = (M + 15) / 16;
+    const int lane = threadIdx.x & 63;
+    const int a = lane >> 2, b = lane & 3;
+    const int K = p.K;
+
+    gv2f B[NP][LPR];
+    gv2f c[NP];
+    {
+        const float* __restrict__ beta_b = p.beta + b;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            // branch-free: a slot past the document's last token reads term 0's row with count 0 -> weight exactly 0
+            const int n0 = 32 * q + a, n1 = n0 + 16;
+            const bool in0 = n0 < N, in1 = n1 < N;
+            const int t0 = in0 ? p.terms[off + n0] : 0, t1 = in1 ? p.terms[off + n1] : 0;
+            c[q] = gv2f{in0 ? (float)p.counts[off + n0] : 0.0f, in1 ? (float)p.counts[off + n1] : 0.0f};
+            const float* r0 = beta_b + (int64_t)t0 * (4 * LPR);
+            const float* r1 = beta_b + (int64_t)t1 * (4 * LPR);
+#pragma unroll
+            for (int j = 0; j < LPR; ++j) B[q][j] = gv2f{r0[4 * j], r1[4 * j]};
+        }
+    }
+    // topic role: result slot r of this lane owns topic mytopic[r] (4 j + b for the primary owner of value j; -1 otherwise)
+    int mytopic[NS];
+    bool on[NS];
+    float alpha[NS], elog[NS], elog_old[NS], gam[NS], e[NS];
+    float asum_l = 0.0f, csum_l = 0.0f;
+#pragma unroll
+    for (int r = 0; r < NS; ++r) {
+        mytopic[r] = topic_of_lane[r * 64 + lane];
+        on[r] = mytopic[r] >= 0 && mytopic[r] < K;
+        alpha[r] = on[r] ? p.alpha[mytopic[r]] : 0.0f;
+        elog[r] = on[r] ? p.elog[(int64_t)d * K + mytopic[r]] : 0.0f;
+        elog_old[r] = elog[r]; gam[r] = 0.0f; e[r] = 0.0f;
+        asum_l += alpha[r];
+    }
+#pragma unroll
+    for (int q = 0; q < NP; ++q) csum_l += (b == 0) ? c[q].x + c[q].y : 0.0f;       // each token once (class 0 of its group)
+    // psi(sum_i gamma_i) with sum_i gamma_i = K eps + sum alpha + C_d
+    const float gsum = (float)K * TMVB_EPS_F + wave_sum(asum_l) + wave_sum(csum_l);
+    const float dgs = digamma_f(gsum);
+    constexpr int WS_A = kGridMap<M>.a_of[LPR], WS_R = kGridMap<M>.r_of[LPR];      // owner of sum_n w_n in class 0
+
+    __shared__ __attribute__((aligned(16))) float e_lds[4][4 * ((LPR + 3) / 4)];      // e by class: [b][j]
+    int sweeps = 0;
+    for (int v = 0; v < p.viter; ++v) {
+        ++sweeps;
+#pragma unroll
+        for (int r = 0; r < NS; ++r) {
+            e[r] = on[r] ? fast_exp(elog[r]) : 0.0f;                                  // update_phi!, src/LDA.jl:152
+            if (mytopic[r] >= 0) e_lds[mytopic[r] & 3][mytopic[r] >> 2] = e[r];
+        }
+        WAVE_LDS_FENCE();
+        // ---- phase 1: s_n over this lane's LPR topics, then over the quad
+        gv2f sacc[NP][2];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) { sacc[q][0] = gv2f{0.f, 0.f}; sacc[q][1] = gv2f{0.f, 0.f}; }
+#pragma unroll
+        for (int jq = 0; jq < (LPR + 3) / 4; ++jq) {
+            const float4 ev = ((const float4*)e_lds[b])[jq];
+            const float ej[4] = {ev.x, ev.y, ev.z, ev.w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = 4 * jq + u;
+                if (j < LPR) {
+#pragma unroll
+                    for (int q = 0; q < NP; ++q)
+                        sacc[q][j & 1] = __builtin_elementwise_fma(B[q][j], gv2f{ej[u], ej[u]}, sacc[q][j & 1]);
+                }
+            }
+        }
+        gv2f w[NP];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            gv2f s2 = sacc[q][0] + sacc[q][1];
+            s2.x += dpp_f<0xB1>(s2.x); s2.y += dpp_f<0xB1>(s2.y);                     // quad_perm [1,0,3,2]
+            s2.x += dpp_f<0x4E>(s2.x); s2.y += dpp_f<0x4E>(s2.y);                     // quad_perm [2,3,0,1]
+            const float keps = (float)K * TMVB_EPS_F;
+            w[q] = gv2f{c[q].x * __builtin_amdgcn_rcpf(s2.x + keps), c[q].y * __builtin_amdgcn_rcpf(s2.y + keps)};
+        }
+        // ---- phase 2: g_i over this lane's tokens, then over the 16 token groups
+        float gv[M];
+        {
+            gv2f g2[LPR];
+#pragma unroll
+            for (int j = 0; j < LPR; ++j) g2[j] = B[0][j] * w[0];
+#pragma unroll
+            for (int q = 1; q < NP; ++q)
+#pragma unroll
+                for (int j = 0; j < LPR; ++j) g2[j] = __builtin_elementwise_fma(B[q][j], w[q], g2[j]);
+#pragma unroll
+            for (int j = 0; j < LPR; ++j) gv[j] = g2[j].x + g2[j].y;
+            float wl = w[0].x + w[0].y;
+#pragma unroll
+            for (int q = 1; q < NP; ++q) wl += w[q].x + w[q].y;
+            gv[LPR] = wl;
+        }
+        float pr[NS];
+        grid_reduce_scatter<M>(gv, pr);
+        const float wtot = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pr[WS_R]), 4 * WS_A));
+        // ---- tail: one topic per lane
+        float dl = 0.0f;
+#pragma unroll
+        for (int r = 0; r < NS; ++r) {
+            gam[r] = TMVB_EPS_F + (alpha[r] + fmaf(e[r], pr[r], TMVB_EPS_F * wtot));   // update_gamma!, src/LDA.jl:145
+            const float dg = digamma_f(gam[r]);
+            elog_old[r] = elog[r];                                                    // update_Elogtheta!, :137-138
+            if (on[r]) {
+                elog[r] = dg - dgs;
+                const float df = elog[r] - elog_old[r];
+                dl = fmaf(df, df, dl);
+            }
+        }
+        const float dist2 = wave_sum(dl);
+        if (__builtin_amdgcn_sqrtf(dist2) < p.vtol) break;                            // :175
+    }
+    if (sweeps > 0) {
+#pragma unroll
+        for (int r = 0; r < NS; ++r) {
+            if (on[r]) {
+                p.gamma[(int64_t)d * K + mytopic[r]] = gam[r];
+                p.elog[(int64_t)d * K + mytopic[r]] = elog[r];
+                p.elog_old[(int64_t)d * K + mytopic[r]] = elog_old[r];
+            }
+            if (mytopic[r] >= 0 && mytopic[r] < p.estride) p.E[(int64_t)d * p.estride + mytopic[r]] = e[r];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < NS; ++r)
+            if (mytopic[r] >= 0 && mytopic[r] < p.estride) p.E[(int64_t)d * p.estride + mytopic[r]] = 0.0f;
+    }
+    if (lane == 0) p.sweeps[d] = (uint8_t)min(sweeps, 255);
+}
+
+template <int LPR, int NP>
+__global__ __launch_bounds__(64) void lda_estep_grid_kernel(LdaParams p, int64_t first, const int* __restrict__ topic_of_lane)
+{
+    const int d = p.doc_order[first + blockIdx.x];
+    const int64_t off = p.doc_ptr[d];
+    lda_estep_grid_body<LPR, NP>(p, d, off, (int)(p.doc_ptr[d + 1] - off), topic_of_lane);
+}
+
 // ------------------------------------------------------------------------------ ELBO
 // update_elbo!  src/LDA.jl:83-93 per document (terms :50-80 without the corpus-level constant of
 // Elogptheta, added by lda_elbo_final_kernel).  One wave per document, lane = topic.
@@ -651,6 +808,35 @@ __global__ __launch_bounds__(64) void lda_elbo_reg_kernel(int K, const int32_t* 
 }
 
 #define TMVB_REG_ANY_TILES 99   // bucket of register-tile documents with mixed tile counts (lda_estep_reg_any_kernel)
+#define TMVB_GRID_ANY_NP 99     // bucket of grid-tile documents with mixed lengths (lda_estep_grid_any_kernel)
+#define TMVB_GRID_NP_MAX 6      // token pairs per lane of the widest grid-tile instantiation: documents of <= 192 unique terms
+
+// token-pair classes of the grid-tile kernel: a document runs the smallest instantiated NP that holds it
+static inline int lda_grid_np_class(int64_t n) { const int64_t np = (n + 31) / 32; return np <= 2 ? 2 : np <= 3 ? 3 : np <= 4 ? 4 : 6; }
+
+// All grid-tile documents of a SMALL corpus / shard in one launch (the pair count is read per document, wave-uniform)
+template <int LPR>
+__global__ __launch_bounds__(64) void lda_estep_grid_any_kernel(LdaParams p, int64_t first, const int* __restrict__ topic_of_lane)
+{
+    const int d = p.doc_order[first + blockIdx.x];
+    const int64_t off = p.doc_ptr[d];
+    const int N = (int)(p.doc_ptr[d + 1] - off);
+    const int np = __builtin_amdgcn_readfirstlane((N + 31) >> 5);
+    if (np > 4) lda_estep_grid_body<LPR, 6>(p, d, off, N, topic_of_lane);
+    else if (np == 4) lda_estep_grid_body<LPR, 4>(p, d, off, N, topic_of_lane);
+    else if (np == 3) lda_estep_grid_body<LPR, 3>(p, d, off, N, topic_of_lane);
+    else lda_estep_grid_body<LPR, 2>(p, d, off, N, topic_of_lane);
+}
+
+template <int LPR>
+static void lda_launch_grid(int np, dim3 grid, dim3 block, hipStream_t st, const LdaParams& p, int64_t first, const int* tol)
+{
+    if (np == TMVB_GRID_ANY_NP) hipLaunchKernelGGL((lda_estep_grid_any_kernel<LPR>), grid, block, 0, st, p, first, tol);
+    else if (np <= 2) hipLaunchKernelGGL((lda_estep_grid_kernel<LPR, 2>), grid, block, 0, st, p, first, tol);
+    else if (np == 3) hipLaunchKernelGGL((lda_estep_grid_kernel<LPR, 3>), grid, block, 0, st, p, first, tol);
+    else if (np == 4) hipLaunchKernelGGL((lda_estep_grid_kernel<LPR, 4>), grid, block, 0, st, p, first, tol);
+    else hipLaunchKernelGGL((lda_estep_grid_kernel<LPR, 6>), grid, block, 0, st, p, first, tol);
+}
 
 // register-tile launch for a bucket of `tiles`-tile documents (instantiates T = 1..TMAX only)
 template <int LPR, int TMAX>
@@ -696,6 +882,8 @@ struct tmvb_lda {
     bool e_padded = false;             // E rows are zero padded to >= KP floats (float4 statistics kernels)
     float* d_ts_partial = nullptr;     // [n_slots][K+1]
     int* d_topic_of_lane = nullptr;    // register-tile kernel lane maps
+    int* d_grid_topic_of_lane = nullptr;   // grid-tile kernel lane map (tmvb_gridtile.h)
+    bool grid_path = false;            // KP <= 60 with recomputed statistics weights: documents of <= 192 terms use lda_estep_grid_kernel
     bool reg_path = false;             // K <= 64 with a specialised LPR: short documents use lda_estep_reg_kernel
     int32_t* d_doc_order = nullptr;
     double* d_partial = nullptr;       // [TMVB_REDUCE_BLOCKS][K]
@@ -757,14 +945,14 @@ static void lda_build_buckets(tmvb_lda* h, std::vector<int32_t>& order)
     std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return len[x] > len[y]; });
     h->buckets.clear();
     const int max_tiles = lda_reg_max_tiles(h->KP / 4);
-    const int64_t reg_max = h->reg_path ? 64 * max_tiles : -1;
+    const int64_t reg_max = h->grid_path ? 32 * TMVB_GRID_NP_MAX : h->reg_path ? 64 * max_tiles : -1;
     // documents longer than reg_max: LDS-tile kernel
     // long documents get up to 156 KiB of LDS (one workgroup per CU): a tile that holds the whole document is
     // gathered once per E-step, a streamed one once per sweep
     // Documents between 64 T and 64 T W unique terms keep the register-tile arithmetic with one workgroup of
     // W = TMVB_LONG_WAVES waves each (lda_estep_reg_long_kernel); only what is longer still goes through LDS.
     const bool long_reg = h->reg_path && getenv("TMVB_LDA_NO_LONG") == nullptr;
-    const int64_t long_max = long_reg ? reg_max * TMVB_LONG_WAVES : reg_max;
+    const int64_t long_max = long_reg ? (int64_t)64 * max_tiles * TMVB_LONG_WAVES : reg_max;
     int64_t pos = tmvb_build_lds_buckets(len, order, h->M, h->KP, long_max, 3, h->buckets, TMVB_BIG_TILE_BYTES);
     if (long_reg) {
         for (int T = max_tiles; T >= 1 && pos < h->M; --T) {   // (KP = 100, T = 3 spills to AGPRs and is still 2.8x the LDS kernel)
@@ -779,7 +967,22 @@ static void lda_build_buckets(tmvb_lda* h, std::vector<int32_t>& order)
     // (KP <= 60 only: with two result slots per lane the widest body costs the short documents a wave per SIMD --
     //  measured at KP = 100, 16 k documents: 2.14 k it/s merged, 2.26 k separate)
     if (h->reg_path && h->KP <= 60 && pos < h->M && lda_piece_count(h) == 1 && getenv("TMVB_LDA_NO_MERGE") == nullptr) {
-        h->buckets.push_back({pos, h->M - pos, 0, TMVB_REG_ANY_TILES});
+        tmvb_bucket b{pos, h->M - pos, 0, TMVB_REG_ANY_TILES};
+        if (h->grid_path) b.grid_np = TMVB_GRID_ANY_NP;
+        h->buckets.push_back(b);
+        return;
+    }
+    if (h->grid_path) {
+        // grid-tile buckets, longest first: one launch per instantiated pair count
+        while (pos < h->M) {
+            const int np = lda_grid_np_class(len[order[pos]]);
+            int64_t cnt = 0;
+            while (pos + cnt < h->M && lda_grid_np_class(len[order[pos + cnt]]) == np) ++cnt;
+            tmvb_bucket b{pos, cnt, 0, (np + 1) / 2};        // reg_tiles > 0 marks a register bucket (chain stream, piece cuts)
+            b.grid_np = np;
+            h->buckets.push_back(b);
+            pos += cnt;
+        }
         return;
     }
     // register-tile buckets: T = ceil(N / 64) tiles of 64 tokens
@@ -870,7 +1073,7 @@ extern "C" int tmvb_lda_destroy(tmvb_lda* h)
     (void)hipFree(h->d_alpha_d); (void)hipFree(h->d_alpha_f); (void)hipFree(h->d_beta[0]); (void)hipFree(h->d_beta[1]);
     if (h->own_stats) (void)hipFree(h->d_stats);
     (void)hipFree(h->d_wtok); (void)hipFree(h->d_E); (void)hipFree(h->d_ts_partial);
-    (void)hipFree(h->d_topic_of_lane);
+    (void)hipFree(h->d_topic_of_lane); (void)hipFree(h->d_grid_topic_of_lane);
     (void)hipFree(h->d_gamma); (void)hipFree(h->d_elog); (void)hipFree(h->d_elog_old); (void)hipFree(h->d_sweeps);
     (void)hipFree(h->d_doc_order); (void)hipFree(h->d_partial); (void)hipFree(h->d_rowsum); (void)hipFree(h->d_esum);
     (void)hipFree(h->d_doc_val); (void)hipFree(h->d_elbo); (void)hipFree(h->d_iters);
@@ -949,6 +1152,24 @@ extern "C" int tmvb_lda_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
         tmvb_reg_lane_maps(h->KP, tol, lot);
         if ((rc = dmalloc(&h->d_topic_of_lane, tol.size()))) return rc;
         TMVB_HIP(hipMemcpy(h->d_topic_of_lane, tol.data(), tol.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+    // grid-tile kernel (tmvb_gridtile.h): KP <= 60 (LPR <= 15: the widest instantiation stays within 256 VGPRs), statistics pass
+    // recomputes the token weights (nothing per token is stored); TMVB_LDA_GRID=0 keeps the lane = token register tile
+    h->grid_path = h->reg_path && h->KP <= 60 && tmvb_termstats_recomputes(h->KP, h->e_padded) &&
+                   !(getenv("TMVB_LDA_GRID") && atoi(getenv("TMVB_LDA_GRID")) == 0);
+    if (h->grid_path) {
+        std::vector<int> tol;
+        switch (h->KP / 4) {
+#define LDA_GRID_MAP_CASE(LPRV) case LPRV: tmvb_grid_lane_map_fill<LPRV>(tol); break;
+            LDA_GRID_MAP_CASE(1) LDA_GRID_MAP_CASE(3) LDA_GRID_MAP_CASE(5) LDA_GRID_MAP_CASE(7) LDA_GRID_MAP_CASE(9) LDA_GRID_MAP_CASE(11)
+            LDA_GRID_MAP_CASE(13) LDA_GRID_MAP_CASE(15)
+#undef LDA_GRID_MAP_CASE
+            default: h->grid_path = false;
+        }
+        if (h->grid_path) {
+            if ((rc = dmalloc(&h->d_grid_topic_of_lane, tol.size()))) return rc;
+            TMVB_HIP(hipMemcpy(h->d_grid_topic_of_lane, tol.data(), tol.size() * sizeof(int), hipMemcpyHostToDevice));
+        }
     }
     std::vector<int32_t> order;
     lda_build_buckets(h, order);
@@ -1152,6 +1373,19 @@ static int lda_estep_impl(tmvb_lda* h, int32_t viter, double vtol)
         hipStream_t st = chain ? chain_st : h->aux[1];
         if (!h->reg_path) st = h->aux[(bi & 1) ^ 1];          // LDS-tile buckets only: alternate the two streams
         if (chain) { int rc = close_pieces(b.piece); if (rc) return rc; }
+        if (b.grid_np > 0) {
+            const dim3 grid((unsigned)b.count), block(64);
+            const int* tol = h->d_grid_topic_of_lane;
+            switch (p.LPR) {
+#define LDA_GRID_CASE(LPRV) case LPRV: lda_launch_grid<LPRV>(b.grid_np, grid, block, st, p, b.first, tol); break;
+                LDA_GRID_CASE(1) LDA_GRID_CASE(3) LDA_GRID_CASE(5) LDA_GRID_CASE(7) LDA_GRID_CASE(9) LDA_GRID_CASE(11) LDA_GRID_CASE(13)
+                LDA_GRID_CASE(15)
+#undef LDA_GRID_CASE
+                default: TMVB_REQUIRE(false, TMVB_EINVAL, "tmvb_lda_estep: no grid-tile kernel for KP=%d", h->KP);
+            }
+            TMVB_HIP(hipGetLastError());
+            continue;
+        }
         if (b.reg_tiles > 0) {
             const dim3 grid((unsigned)b.count), block(64 * (unsigned)b.waves);
             const int* tol = h->d_topic_of_lane;
