@@ -60,45 +60,46 @@ struct GridMap {
 };
 template <int M> constexpr GridMap<M> kGridMap{};
 
-// one swap stage (lane bit 5 or 4): pairs (i, i + h) exchange halves / rows and add; all swaps of the stage share ONE pair of
+// one swap stage (lane bit 5 or 4): pairs (i, i + h) exchange halves / rows and add; up to four swaps share ONE pair of
 // hazard wait states (VALU write -> v_permlane*_swap read needs 2 states, and so does the swap's result -> VALU read;
-// hipcc pads nothing inside an asm statement)
-#define GRID_SWAP2(OP)                                                                                                     \
-    asm volatile("s_nop 1\n\t" OP " %0, %1\n\t" OP " %2, %3\n\ts_nop 1" : "+v"(x0), "+v"(y0), "+v"(x1), "+v"(y1))
-#define GRID_SWAP1(OP) asm volatile("s_nop 1\n\t" OP " %0, %1\n\ts_nop 1" : "+v"(x0), "+v"(y0))
-
-template <bool B32>
-__device__ __forceinline__ void grid_swap_add2(float& x0, float y0, float& x1, float y1)
+// hipcc pads nothing inside an asm statement).  A value without a partner value (odd count) is swapped with a copy of itself.
+template <bool B32, int NPAIR>
+__device__ __forceinline__ void grid_swap_block(float* x, float* y)          // x[q] <-> y[q], q < NPAIR; x[q] += y[q]
 {
-    if constexpr (B32) GRID_SWAP2("v_permlane32_swap_b32"); else GRID_SWAP2("v_permlane16_swap_b32");
-    x0 += y0; x1 += y1;
-}
-template <bool B32>
-__device__ __forceinline__ void grid_swap_add1(float& x0, float y0)
-{
-    if constexpr (B32) GRID_SWAP1("v_permlane32_swap_b32"); else GRID_SWAP1("v_permlane16_swap_b32");
-    x0 += y0;
-}
-// x += (x of the partner lane): swap with a copy
-template <bool B32>
-__device__ __forceinline__ void grid_swap_self(float& x0)
-{
-    float y0 = x0;
-    if constexpr (B32) asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x0), "+v"(y0));
-    else asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x0), "+v"(y0));
-    x0 += y0;
+    static_assert(NPAIR >= 1 && NPAIR <= 4, "grid_swap_block");
+#define GRID_SW(OP)                                                                                                                  \
+    if constexpr (NPAIR == 1) asm volatile("s_nop 1\n\t" OP " %0, %1\n\ts_nop 1" : "+v"(x[0]), "+v"(y[0]));                           \
+    else if constexpr (NPAIR == 2) asm volatile("s_nop 1\n\t" OP " %0, %1\n\t" OP " %2, %3\n\ts_nop 1"                               \
+                                                : "+v"(x[0]), "+v"(y[0]), "+v"(x[1]), "+v"(y[1]));                                   \
+    else if constexpr (NPAIR == 3) asm volatile("s_nop 1\n\t" OP " %0, %1\n\t" OP " %2, %3\n\t" OP " %4, %5\n\ts_nop 1"             \
+                                                : "+v"(x[0]), "+v"(y[0]), "+v"(x[1]), "+v"(y[1]), "+v"(x[2]), "+v"(y[2]));           \
+    else asm volatile("s_nop 1\n\t" OP " %0, %1\n\t" OP " %2, %3\n\t" OP " %4, %5\n\t" OP " %6, %7\n\ts_nop 1"                     \
+                      : "+v"(x[0]), "+v"(y[0]), "+v"(x[1]), "+v"(y[1]), "+v"(x[2]), "+v"(y[2]), "+v"(x[3]), "+v"(y[3]))
+    if constexpr (B32) { GRID_SW("v_permlane32_swap_b32"); } else { GRID_SW("v_permlane16_swap_b32"); }
+#undef GRID_SW
+#pragma unroll
+    for (int q = 0; q < NPAIR; ++q) x[q] += y[q];
 }
 
 // stage on the first m of the MF values of v (compile-time indices only: the array stays in registers)
 template <int MF, int m, bool B32>
 __device__ __forceinline__ void grid_swap_stage(float (&v)[MF])
 {
-    constexpr int h = (m + 1) / 2, P = m - h;        // P pairs (i, i + h); for odd m the value h - 1 has no partner value
+    constexpr int h = (m + 1) / 2;                   // pairs (i, i + h), i < m - h; for odd m the value h - 1 pairs with a copy
+    float x[h], y[h];
 #pragma unroll
-    for (int i = 0; i + 1 < P; i += 2) grid_swap_add2<B32>(v[i], v[i + h], v[i + 1], v[i + 1 + h]);
-    if constexpr ((P & 1) != 0) grid_swap_add1<B32>(v[P - 1], v[P - 1 + h]);
-    if constexpr ((m & 1) != 0 && m > 1) grid_swap_self<B32>(v[h - 1]);
-    if constexpr (m == 1) grid_swap_self<B32>(v[0]);
+    for (int i = 0; i < h; ++i) { x[i] = v[i]; y[i] = (i + h < m) ? v[i + h] : v[i]; }
+#pragma unroll
+    for (int i0 = 0; i0 < h; i0 += 4) {
+        constexpr int dummy = 0; (void)dummy;
+        const int n = (h - i0 < 4) ? h - i0 : 4;
+        if (n == 4) grid_swap_block<B32, 4>(x + i0, y + i0);
+        else if (n == 3) grid_swap_block<B32, 3>(x + i0, y + i0);
+        else if (n == 2) grid_swap_block<B32, 2>(x + i0, y + i0);
+        else grid_swap_block<B32, 1>(x + i0, y + i0);
+    }
+#pragma unroll
+    for (int i = 0; i < h; ++i) v[i] = x[i];
 }
 
 // one DPP stage inside a row of 16 lanes.  BIT8: partner = lane ^ 8 (row_ror:8, low side = banks 0,1); otherwise partner =

@@ -255,6 +255,39 @@ __device__ __forceinline__ float digamma_f(float x)
     return psi - rec;
 }
 
+// digamma for the sweep loops, x > 0, fp32, 19 VALU + 3 transcendental instructions (digamma_f: ~45): the recurrence is a fixed
+// 3-step shift written as ONE rational, psi(x) = psi(y) - (3x^2 + 6x + 2) / (x (x+1) (x+2)), y = x + 3, merged with the series'
+// 1/(2y); six series terms (the seventh is 1.7e-8 at y = 3); raw v_log_f32 (y >= 3 is never denormal).  Max error against
+// fp64 over [1e-6, 1e5]: 8.8e-7 (absolute where |psi| <= 1, relative elsewhere); digamma_f: 4.9e-7.
+__device__ __forceinline__ float digamma_sweep_f(float x)
+{
+    const float y = x + 3.0f, x1 = x + 1.0f, x2 = x + 2.0f;
+    const float D = (x * x1) * x2;
+    const float A = fmaf(fmaf(6.0f, x, 12.0f), x, 4.0f);            // 2 (3x^2 + 6x + 2)
+    const float num = fmaf(y, A, D);                                 // (1/x + 1/(x+1) + 1/(x+2) + 1/(2y)) * 2 y D
+    const float r = __builtin_amdgcn_rcpf(y * D);
+    const float t2 = __builtin_amdgcn_rcpf(y * y);
+    float p = -0.021092796092796094f;                                // B_12 / 12
+    p = fmaf(p, t2, 0.007575757575757576f);
+    p = fmaf(p, t2, -0.004166666666666667f);
+    p = fmaf(p, t2, 0.003968253968253968f);
+    p = fmaf(p, t2, -0.008333333333333333f);
+    p = fmaf(p, t2, 0.08333333333333333f);
+    float psi = fmaf(__builtin_amdgcn_logf(y), 0.6931471805599453f, -0.5f * num * r);
+    return fmaf(-t2, p, psi);
+}
+
+// exp(x), x <= 0 finite: 2^t (v_exp_f32) with t = fl(x log2 e) and the rounding of t put back to first order,
+// e = 2^t (1 + ln2 (x log2 e - t)); 5 VALU + 1 transcendental (fast_exp: 9 + 1), relative error 1.2e-7.
+__device__ __forceinline__ float sweep_exp(float x)
+{
+    const float t = x * 1.44269502162933349609375f;
+    float r = fmaf(x, 1.44269502162933349609375f, -t);
+    r = fmaf(x, 1.925963033500011e-08f, r);
+    const float e = __builtin_amdgcn_exp2f(t);
+    return fmaf(e, r * 0.6931471805599453f, e);
+}
+
 // fp64 digamma / trigamma: the published SpecialFunctions.jl algorithm (recurrence to x>=7 / 8,
 // then 8-term asymptotic series), used by the alpha Newton step and the ELBO kernels.
 __device__ __forceinline__ double digamma_d(double x)

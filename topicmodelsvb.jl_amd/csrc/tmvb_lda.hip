@@ -236,6 +236,8 @@ __global__ __launch_bounds__(64) void lda_estep_kernel(LdaParams p, int64_t firs
         }
         const float gsum = wave_sum(gl);
         const float dgs = digamma_f(gsum);
+    const float vtol2 = p.vtol * p.vtol;
+    const float keps4 = 0.25f * (float)K * TMVB_EPS_F;                            // K eps, a quarter per lane of the quad
         // update_Elogtheta!  src/LDA.jl:137-138 and the exit test :175
         float dl = 0.0f;
 #pragma unroll
@@ -523,16 +525,24 @@ __device__ __forceinline__ void lda_estep_grid_body(const LdaParams& p, const in
     gv2f B[NP][LPR];
     gv2f c[NP];
     {
+        // branch-free and in two waves of loads: every id / count of the lane first (a slot past the document's last token
+        // reads element 0 and gets count 0 -> weight exactly 0), then every row -- no load sits behind a wait for another
+        int tm[2 * NP], cn[2 * NP];
+#pragma unroll
+        for (int s = 0; s < 2 * NP; ++s) {
+            const int n = 16 * s + a;
+            const int64_t at = n < N ? off + n : 0;
+            tm[s] = p.terms[at];
+            cn[s] = p.counts[at];                           // unconditional load, masked below
+        }
+#pragma unroll
+        for (int s = 0; s < 2 * NP; ++s) cn[s] = (16 * s + a < N) ? cn[s] : 0;
         const float* __restrict__ beta_b = p.beta + b;
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
-            // branch-free: a slot past the document's last token reads term 0's row with count 0 -> weight exactly 0
-            const int n0 = 32 * q + a, n1 = n0 + 16;
-            const bool in0 = n0 < N, in1 = n1 < N;
-            const int t0 = in0 ? p.terms[off + n0] : 0, t1 = in1 ? p.terms[off + n1] : 0;
-            c[q] = gv2f{in0 ? (float)p.counts[off + n0] : 0.0f, in1 ? (float)p.counts[off + n1] : 0.0f};
-            const float* r0 = beta_b + (int64_t)t0 * (4 * LPR);
-            const float* r1 = beta_b + (int64_t)t1 * (4 * LPR);
+            c[q] = gv2f{(float)cn[2 * q], (float)cn[2 * q + 1]};
+            const float* r0 = beta_b + (int64_t)tm[2 * q] * (4 * LPR);
+            const float* r1 = beta_b + (int64_t)tm[2 * q + 1] * (4 * LPR);
 #pragma unroll
             for (int j = 0; j < LPR; ++j) B[q][j] = gv2f{r0[4 * j], r1[4 * j]};
         }
@@ -540,22 +550,27 @@ __device__ __forceinline__ void lda_estep_grid_body(const LdaParams& p, const in
     // topic role: result slot r of this lane owns topic mytopic[r] (4 j + b for the primary owner of value j; -1 otherwise)
     int mytopic[NS];
     bool on[NS];
-    float alpha[NS], elog[NS], elog_old[NS], gam[NS], e[NS];
+    float alpha_eps[NS], elog[NS], elog_old[NS], gam[NS], e[NS];
     float asum_l = 0.0f, csum_l = 0.0f;
 #pragma unroll
     for (int r = 0; r < NS; ++r) {
         mytopic[r] = topic_of_lane[r * 64 + lane];
         on[r] = mytopic[r] >= 0 && mytopic[r] < K;
-        alpha[r] = on[r] ? p.alpha[mytopic[r]] : 0.0f;
-        elog[r] = on[r] ? p.elog[(int64_t)d * K + mytopic[r]] : 0.0f;
+        const int tp = on[r] ? mytopic[r] : 0;                   // unconditional loads (no branch, no early wait), masked after
+        const float al_ld = p.alpha[tp], el_ld = p.elog[(int64_t)d * K + tp];
+        const float al = on[r] ? al_ld : 0.0f;
+        alpha_eps[r] = al + TMVB_EPS_F;
+        elog[r] = on[r] ? el_ld : 0.0f;
         elog_old[r] = elog[r]; gam[r] = 0.0f; e[r] = 0.0f;
-        asum_l += alpha[r];
+        asum_l += al;
     }
 #pragma unroll
     for (int q = 0; q < NP; ++q) csum_l += (b == 0) ? c[q].x + c[q].y : 0.0f;       // each token once (class 0 of its group)
     // psi(sum_i gamma_i) with sum_i gamma_i = K eps + sum alpha + C_d
     const float gsum = (float)K * TMVB_EPS_F + wave_sum(asum_l) + wave_sum(csum_l);
     const float dgs = digamma_f(gsum);
+    const float vtol2 = p.vtol * p.vtol;
+    const float keps4 = 0.25f * (float)K * TMVB_EPS_F;                            // K eps, a quarter per lane of the quad
     constexpr int WS_A = kGridMap<M>.a_of[LPR], WS_R = kGridMap<M>.r_of[LPR];      // owner of sum_n w_n in class 0
 
     __shared__ __attribute__((aligned(16))) float e_lds[4][4 * ((LPR + 3) / 4)];      // e by class: [b][j]
@@ -564,14 +579,14 @@ __device__ __forceinline__ void lda_estep_grid_body(const LdaParams& p, const in
         ++sweeps;
 #pragma unroll
         for (int r = 0; r < NS; ++r) {
-            e[r] = on[r] ? fast_exp(elog[r]) : 0.0f;                                  // update_phi!, src/LDA.jl:152
+            e[r] = on[r] ? sweep_exp(elog[r]) : 0.0f;                                 // update_phi!, src/LDA.jl:152
             if (mytopic[r] >= 0) e_lds[mytopic[r] & 3][mytopic[r] >> 2] = e[r];
         }
         WAVE_LDS_FENCE();
         // ---- phase 1: s_n over this lane's LPR topics, then over the quad
         gv2f sacc[NP][2];
 #pragma unroll
-        for (int q = 0; q < NP; ++q) { sacc[q][0] = gv2f{0.f, 0.f}; sacc[q][1] = gv2f{0.f, 0.f}; }
+        for (int q = 0; q < NP; ++q) { sacc[q][0] = gv2f{keps4, keps4}; sacc[q][1] = gv2f{0.f, 0.f}; }
 #pragma unroll
         for (int jq = 0; jq < (LPR + 3) / 4; ++jq) {
             const float4 ev = ((const float4*)e_lds[b])[jq];
@@ -592,8 +607,7 @@ __device__ __forceinline__ void lda_estep_grid_body(const LdaParams& p, const in
             gv2f s2 = sacc[q][0] + sacc[q][1];
             s2.x += dpp_f<0xB1>(s2.x); s2.y += dpp_f<0xB1>(s2.y);                     // quad_perm [1,0,3,2]
             s2.x += dpp_f<0x4E>(s2.x); s2.y += dpp_f<0x4E>(s2.y);                     // quad_perm [2,3,0,1]
-            const float keps = (float)K * TMVB_EPS_F;
-            w[q] = gv2f{c[q].x * __builtin_amdgcn_rcpf(s2.x + keps), c[q].y * __builtin_amdgcn_rcpf(s2.y + keps)};
+            w[q] = c[q] * gv2f{__builtin_amdgcn_rcpf(s2.x), __builtin_amdgcn_rcpf(s2.y)};   // s_n includes K eps (sacc's start value)
         }
         // ---- phase 2: g_i over this lane's tokens, then over the 16 token groups
         float gv[M];
@@ -607,10 +621,10 @@ __device__ __forceinline__ void lda_estep_grid_body(const LdaParams& p, const in
                 for (int j = 0; j < LPR; ++j) g2[j] = __builtin_elementwise_fma(B[q][j], w[q], g2[j]);
 #pragma unroll
             for (int j = 0; j < LPR; ++j) gv[j] = g2[j].x + g2[j].y;
-            float wl = w[0].x + w[0].y;
+            gv2f ws = w[0];
 #pragma unroll
-            for (int q = 1; q < NP; ++q) wl += w[q].x + w[q].y;
-            gv[LPR] = wl;
+            for (int q = 1; q < NP; ++q) ws += w[q];
+            gv[LPR] = ws.x + ws.y;
         }
         float pr[NS];
         grid_reduce_scatter<M>(gv, pr);
@@ -619,8 +633,8 @@ __device__ __forceinline__ void lda_estep_grid_body(const LdaParams& p, const in
         float dl = 0.0f;
 #pragma unroll
         for (int r = 0; r < NS; ++r) {
-            gam[r] = TMVB_EPS_F + (alpha[r] + fmaf(e[r], pr[r], TMVB_EPS_F * wtot));   // update_gamma!, src/LDA.jl:145
-            const float dg = digamma_f(gam[r]);
+            gam[r] = fmaf(wtot, TMVB_EPS_F, fmaf(e[r], pr[r], alpha_eps[r]));         // update_gamma!, src/LDA.jl:145
+            const float dg = digamma_sweep_f(gam[r]);
             elog_old[r] = elog[r];                                                    // update_Elogtheta!, :137-138
             if (on[r]) {
                 elog[r] = dg - dgs;
@@ -629,7 +643,7 @@ __device__ __forceinline__ void lda_estep_grid_body(const LdaParams& p, const in
             }
         }
         const float dist2 = wave_sum(dl);
-        if (__builtin_amdgcn_sqrtf(dist2) < p.vtol) break;                            // :175
+        if (dist2 < vtol2) break;                                                     // :175, norm < vtol on the squares
     }
     if (sweeps > 0) {
 #pragma unroll
