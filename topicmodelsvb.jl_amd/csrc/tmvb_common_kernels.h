@@ -13,7 +13,7 @@
 #define TMVB_MAX_NSLOT 16                      // K <= 1024
 #define TMVB_MAX_TILE_BYTES (64 * 1024)
 #define TMVB_BIG_TILE_BYTES (156 * 1024)         // of the 160 KiB per CU: needs hipFuncAttributeMaxDynamicSharedMemorySize
-#define TMVB_REDUCE_BLOCKS 256
+#define TMVB_REDUCE_BLOCKS 1024                 // 4 waves each: the column sums are latency-bound, 256 blocks left a CU with 4 waves (54 us for the 26 MB of Elogtheta next to a statistics pass)
 
 // one wave per workgroup: __syncthreads() lowers to an LDS fence (the s_barrier is elided)
 #define WAVE_LDS_FENCE() __syncthreads()
@@ -228,7 +228,13 @@ static __global__ __launch_bounds__(256) void colsum_final_kernel(const double* 
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= K) return;
     double s = 0.0;
-    for (int b = lane; b < nblocks; b += 64) s += partial[(int64_t)b * K + i];
+    for (int b0 = 0; b0 < nblocks; b0 += 64 * 16) {          // 16 independent loads in flight per lane, added in a fixed order
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int b = b0 + lane + 64 * u; v[u] = b < nblocks ? partial[(int64_t)b * K + i] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += v[u];
+    }
     s = wave_sum_d(s);
     if (lane == 0) {
         if (out_d) out_d[i] = s;

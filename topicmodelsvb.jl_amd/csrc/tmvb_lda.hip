@@ -512,15 +512,21 @@ __global__ __launch_bounds__(64) void lda_estep_reg_any_kernel(LdaParams p, int6
 //                                          16-lane reduce-scatter of LPR + 1 values (sum_n w_n rides along as value LPR)
 //   psi(sum gamma): sum_i gamma_i = K eps + sum alpha + C_d in exact arithmetic (sum_i phi_in = 1), a per-document constant --
 //                   evaluated once per document, not once per sweep (the fp64 reference's own sum agrees with it to 1e-16).
-template <int LPR, int NP>
+// W > 1: W waves (one workgroup) share a LONG document of up to 32 NP W unique terms -- wave w holds the tokens
+// 32 NP w + 16 s + a in its own register tile, the per-wave partial sums (g_i, sum w) meet in LDS once per sweep (one
+// __syncthreads, double-buffered by sweep parity) and every wave then runs the tail redundantly and bit-identically, so the
+// exit test stays uniform across the workgroup.
+template <int LPR, int NP, int W = 1>
 __device__ __forceinline__ void lda_estep_grid_body(const LdaParams& p, const int d, const int64_t off, const int N,
                                                     const int* __restrict__ topic_of_lane)
 {
     constexpr int M = LPR + 1;                       // values of the reduce-scatter: LPR topics of the class + sum w
     constexpr int NS = (M + 15) / 16;
     const int lane = threadIdx.x & 63;
+    const int wave = (W > 1) ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
     const int a = lane >> 2, b = lane & 3;
     const int K = p.K;
+    __shared__ float xch[2][W > 1 ? W : 1][W > 1 ? NS * 64 : 1];      // W > 1: per-wave partial result slots, by sweep parity
 
     gv2f B[NP][LPR];
     gv2f c[NP];
@@ -528,23 +534,29 @@ __device__ __forceinline__ void lda_estep_grid_body(const LdaParams& p, const in
         // branch-free and in two waves of loads: every id / count of the lane first (a slot past the document's last token
         // reads element 0 and gets count 0 -> weight exactly 0), then every row -- no load sits behind a wait for another
         int tm[2 * NP], cn[2 * NP];
+        const int64_t off0 = N > 0 ? off : 0;               // uniform base + 32-bit lane offset
+        const int* __restrict__ tp = p.terms + off0;
+        const int* __restrict__ cp = p.counts + off0;
 #pragma unroll
         for (int s = 0; s < 2 * NP; ++s) {
-            const int n = 16 * s + a;
-            const int64_t at = n < N ? off + n : 0;
-            tm[s] = p.terms[at];
-            cn[s] = p.counts[at];                           // unconditional load, masked below
+            const int n = 32 * NP * wave + 16 * s + a;
+            const unsigned nc = n < N ? (unsigned)n : 0u;
+            tm[s] = tp[nc];
+            cn[s] = cp[nc];                                 // unconditional load, masked below
         }
 #pragma unroll
-        for (int s = 0; s < 2 * NP; ++s) cn[s] = (16 * s + a < N) ? cn[s] : 0;
-        const float* __restrict__ beta_b = p.beta + b;
+        for (int s = 0; s < 2 * NP; ++s) cn[s] = (32 * NP * wave + 16 * s + a < N) ? cn[s] : 0;
+        // rows through a uniform base + 32-bit byte offset (the table is V * KP * 4 < 4 GiB bytes, checked at create): one
+        // multiply per row, the 16 j bytes ride in the instruction's immediate offset
+        const char* __restrict__ beta_c = (const char*)p.beta;
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
             c[q] = gv2f{(float)cn[2 * q], (float)cn[2 * q + 1]};
-            const float* r0 = beta_b + (int64_t)tm[2 * q] * (4 * LPR);
-            const float* r1 = beta_b + (int64_t)tm[2 * q + 1] * (4 * LPR);
+            const uint32_t o0 = (uint32_t)tm[2 * q] * (uint32_t)(16 * LPR) + 4u * (uint32_t)b;
+            const uint32_t o1 = (uint32_t)tm[2 * q + 1] * (uint32_t)(16 * LPR) + 4u * (uint32_t)b;
 #pragma unroll
-            for (int j = 0; j < LPR; ++j) B[q][j] = gv2f{r0[4 * j], r1[4 * j]};
+            for (int j = 0; j < LPR; ++j)
+                B[q][j] = gv2f{*(const float*)(beta_c + o0 + 16u * j), *(const float*)(beta_c + o1 + 16u * j)};
         }
     }
     // topic role: result slot r of this lane owns topic mytopic[r] (4 j + b for the primary owner of value j; -1 otherwise)
@@ -567,13 +579,22 @@ __device__ __forceinline__ void lda_estep_grid_body(const LdaParams& p, const in
 #pragma unroll
     for (int q = 0; q < NP; ++q) csum_l += (b == 0) ? c[q].x + c[q].y : 0.0f;       // each token once (class 0 of its group)
     // psi(sum_i gamma_i) with sum_i gamma_i = K eps + sum alpha + C_d
-    const float gsum = (float)K * TMVB_EPS_F + wave_sum(asum_l) + wave_sum(csum_l);
+    float csum = wave_sum(csum_l);
+    if constexpr (W > 1) {                                     // C_d over the waves of the document
+        if (lane == 0) xch[1][wave][0] = csum;
+        __syncthreads();
+        csum = 0.0f;
+#pragma unroll
+        for (int ww = 0; ww < W; ++ww) csum += xch[1][ww][0];  // (sweep 0 writes buffer 0; buffer 1 is written again only in
+    }                                                          //  sweep 1, behind sweep 0's barrier)
+    const float gsum = (float)K * TMVB_EPS_F + wave_sum(asum_l) + csum;
     const float dgs = digamma_f(gsum);
     const float vtol2 = p.vtol * p.vtol;
     const float keps4 = 0.25f * (float)K * TMVB_EPS_F;                            // K eps, a quarter per lane of the quad
     constexpr int WS_A = kGridMap<M>.a_of[LPR], WS_R = kGridMap<M>.r_of[LPR];      // owner of sum_n w_n in class 0
 
-    __shared__ __attribute__((aligned(16))) float e_lds[4][4 * ((LPR + 3) / 4)];      // e by class: [b][j]
+    __shared__ __attribute__((aligned(16))) float e_lds_all[W][4][4 * ((LPR + 3) / 4)];   // e by class: [b][j], one copy per wave
+    float (*e_lds)[4 * ((LPR + 3) / 4)] = e_lds_all[wave];
     int sweeps = 0;
     for (int v = 0; v < p.viter; ++v) {
         ++sweeps;
@@ -582,7 +603,7 @@ __device__ __forceinline__ void lda_estep_grid_body(const LdaParams& p, const in
             e[r] = on[r] ? sweep_exp(elog[r]) : 0.0f;                                 // update_phi!, src/LDA.jl:152
             if (mytopic[r] >= 0) e_lds[mytopic[r] & 3][mytopic[r] >> 2] = e[r];
         }
-        WAVE_LDS_FENCE();
+        if constexpr (W > 1) WAVE_PRIVATE_LDS_FENCE(); else WAVE_LDS_FENCE();
         // ---- phase 1: s_n over this lane's LPR topics, then over the quad
         gv2f sacc[NP][2];
 #pragma unroll
@@ -628,6 +649,19 @@ __device__ __forceinline__ void lda_estep_grid_body(const LdaParams& p, const in
         }
         float pr[NS];
         grid_reduce_scatter<M>(gv, pr);
+        if constexpr (W > 1) {
+            float (*xb)[NS * 64] = xch[v & 1];
+#pragma unroll
+            for (int r = 0; r < NS; ++r) xb[wave][r * 64 + lane] = pr[r];
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < NS; ++r) {
+                float t = 0.0f;
+#pragma unroll
+                for (int ww = 0; ww < W; ++ww) t += xb[ww][r * 64 + lane];      // fixed order: identical totals in every wave
+                pr[r] = t;
+            }
+        }
         const float wtot = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pr[WS_R]), 4 * WS_A));
         // ---- tail: one topic per lane
         float dl = 0.0f;
@@ -645,22 +679,24 @@ __device__ __forceinline__ void lda_estep_grid_body(const LdaParams& p, const in
         const float dist2 = wave_sum(dl);
         if (dist2 < vtol2) break;                                                     // :175, norm < vtol on the squares
     }
-    if (sweeps > 0) {
+    if (wave == 0) {                                                                  // every wave holds the same state
+        if (sweeps > 0) {
 #pragma unroll
-        for (int r = 0; r < NS; ++r) {
-            if (on[r]) {
-                p.gamma[(int64_t)d * K + mytopic[r]] = gam[r];
-                p.elog[(int64_t)d * K + mytopic[r]] = elog[r];
-                p.elog_old[(int64_t)d * K + mytopic[r]] = elog_old[r];
+            for (int r = 0; r < NS; ++r) {
+                if (on[r]) {
+                    p.gamma[(int64_t)d * K + mytopic[r]] = gam[r];
+                    p.elog[(int64_t)d * K + mytopic[r]] = elog[r];
+                    p.elog_old[(int64_t)d * K + mytopic[r]] = elog_old[r];
+                }
+                if (mytopic[r] >= 0 && mytopic[r] < p.estride) p.E[(int64_t)d * p.estride + mytopic[r]] = e[r];
             }
-            if (mytopic[r] >= 0 && mytopic[r] < p.estride) p.E[(int64_t)d * p.estride + mytopic[r]] = e[r];
-        }
-    } else {
+        } else {
 #pragma unroll
-        for (int r = 0; r < NS; ++r)
-            if (mytopic[r] >= 0 && mytopic[r] < p.estride) p.E[(int64_t)d * p.estride + mytopic[r]] = 0.0f;
+            for (int r = 0; r < NS; ++r)
+                if (mytopic[r] >= 0 && mytopic[r] < p.estride) p.E[(int64_t)d * p.estride + mytopic[r]] = 0.0f;
+        }
+        if (lane == 0) p.sweeps[d] = (uint8_t)min(sweeps, 255);
     }
-    if (lane == 0) p.sweeps[d] = (uint8_t)min(sweeps, 255);
 }
 
 template <int LPR, int NP>
@@ -669,6 +705,15 @@ __global__ __launch_bounds__(64) void lda_estep_grid_kernel(LdaParams p, int64_t
     const int d = p.doc_order[first + blockIdx.x];
     const int64_t off = p.doc_ptr[d];
     lda_estep_grid_body<LPR, NP>(p, d, off, (int)(p.doc_ptr[d + 1] - off), topic_of_lane);
+}
+
+// long documents: one workgroup of W waves per document (lda_estep_grid_body, W > 1)
+template <int LPR, int NP, int W>
+__global__ __launch_bounds__(64 * W) void lda_estep_grid_long_kernel(LdaParams p, int64_t first, const int* __restrict__ topic_of_lane)
+{
+    const int d = p.doc_order[first + blockIdx.x];
+    const int64_t off = p.doc_ptr[d];
+    lda_estep_grid_body<LPR, NP, W>(p, d, off, (int)(p.doc_ptr[d + 1] - off), topic_of_lane);
 }
 
 // ------------------------------------------------------------------------------ ELBO
@@ -845,6 +890,8 @@ __global__ __launch_bounds__(64) void lda_estep_grid_any_kernel(LdaParams p, int
 template <int LPR>
 static void lda_launch_grid(int np, dim3 grid, dim3 block, hipStream_t st, const LdaParams& p, int64_t first, const int* tol)
 {
+    if (block.x == 128) { hipLaunchKernelGGL((lda_estep_grid_long_kernel<LPR, TMVB_GRID_NP_MAX, 2>), grid, block, 0, st, p, first, tol); return; }
+    if (block.x == 256) { hipLaunchKernelGGL((lda_estep_grid_long_kernel<LPR, TMVB_GRID_NP_MAX, 4>), grid, block, 0, st, p, first, tol); return; }
     if (np == TMVB_GRID_ANY_NP) hipLaunchKernelGGL((lda_estep_grid_any_kernel<LPR>), grid, block, 0, st, p, first, tol);
     else if (np <= 2) hipLaunchKernelGGL((lda_estep_grid_kernel<LPR, 2>), grid, block, 0, st, p, first, tol);
     else if (np == 3) hipLaunchKernelGGL((lda_estep_grid_kernel<LPR, 3>), grid, block, 0, st, p, first, tol);
@@ -968,12 +1015,21 @@ static void lda_build_buckets(tmvb_lda* h, std::vector<int32_t>& order)
     const bool long_reg = h->reg_path && getenv("TMVB_LDA_NO_LONG") == nullptr;
     const int64_t long_max = long_reg ? (int64_t)64 * max_tiles * TMVB_LONG_WAVES : reg_max;
     int64_t pos = tmvb_build_lds_buckets(len, order, h->M, h->KP, long_max, 3, h->buckets, TMVB_BIG_TILE_BYTES);
+    // grid-tile kernel with 4 / 2 waves per document: up to 768 / 384 unique terms
+    const int64_t grid_long_max = (h->grid_path && long_reg) ? (int64_t)32 * TMVB_GRID_NP_MAX * 4 : 0;
     if (long_reg) {
         for (int T = max_tiles; T >= 1 && pos < h->M; --T) {   // (KP = 100, T = 3 spills to AGPRs and is still 2.8x the LDS kernel)
-            const int64_t lo = std::max<int64_t>(64 * TMVB_LONG_WAVES * (int64_t)(T - 1), reg_max);
+            const int64_t lo = std::max<int64_t>(std::max<int64_t>(64 * TMVB_LONG_WAVES * (int64_t)(T - 1), reg_max), grid_long_max);
             int64_t cnt = 0;
             while (pos + cnt < h->M && len[order[pos + cnt]] > lo) ++cnt;
             if (cnt) { tmvb_bucket b{pos, cnt, 0, T}; b.waves = TMVB_LONG_WAVES; h->buckets.push_back(b); }
+            pos += cnt;
+        }
+        for (int Wv = 4; Wv >= 2 && grid_long_max > 0 && pos < h->M; Wv >>= 1) {
+            const int64_t lo = (int64_t)32 * TMVB_GRID_NP_MAX * (Wv / 2);
+            int64_t cnt = 0;
+            while (pos + cnt < h->M && len[order[pos + cnt]] > lo) ++cnt;
+            if (cnt) { tmvb_bucket b{pos, cnt, 0, 1}; b.waves = Wv; b.grid_np = TMVB_GRID_NP_MAX; h->buckets.push_back(b); }
             pos += cnt;
         }
     }
@@ -1170,6 +1226,7 @@ extern "C" int tmvb_lda_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
     // grid-tile kernel (tmvb_gridtile.h): KP <= 60 (LPR <= 15: the widest instantiation stays within 256 VGPRs), statistics pass
     // recomputes the token weights (nothing per token is stored); TMVB_LDA_GRID=0 keeps the lane = token register tile
     h->grid_path = h->reg_path && h->KP <= 60 && tmvb_termstats_recomputes(h->KP, h->e_padded) &&
+                   (uint64_t)h->V * (uint64_t)h->KP * 4u < (1ull << 32) &&            // rows are addressed by 32-bit byte offsets
                    !(getenv("TMVB_LDA_GRID") && atoi(getenv("TMVB_LDA_GRID")) == 0);
     if (h->grid_path) {
         std::vector<int> tol;
@@ -1344,7 +1401,14 @@ static int lda_estep_impl(tmvb_lda* h, int32_t viter, double vtol)
     // statistics -> M-step stays on the context's stream, so that it pays kernel boundaries (~2 us) instead of
     // cross-stream event hops (~30 us each way, a quarter of a 0.3 ms iteration); only the latency-bound long
     // documents fork to aux[1].  Pipelined pieces need the two chains on two streams.
-    hipStream_t chain_st = (P == 1 && h->reg_path) ? ctx->stream : h->aux[0];
+    // Pipelined pieces (round 3): the document chain ALSO stays on the context's stream; the statistics passes of the pieces
+    // before the last run on aux[0] in the chain's shadow (where an event hop costs nothing), and the last pass -- the one
+    // nothing hides -- follows the last document kernel on the context's stream, as do the M-step and the next E-step: no
+    // cross-stream hop is left on the critical path of an iteration (there were two, ~20 us each, around the last pass).
+    // TMVB_LDA_CHAIN_AUX=1 restores the round-2 plan (chain on aux[0], every pass on the context's stream).
+    static const bool chain_aux = [] { const char* e = getenv("TMVB_LDA_CHAIN_AUX"); return e && atoi(e) != 0; }();
+    hipStream_t chain_st = (h->reg_path && (P == 1 || !chain_aux)) ? ctx->stream : h->aux[0];
+    const bool shadow_stats = P > 1 && chain_st == ctx->stream;       // passes 0 .. P-2 on aux[0]
     if (chain_st == ctx->stream) { int jrc = lda_join_side(h); if (jrc) return jrc; }   // update_alpha! of the last iteration
     TMVB_HIP(hipEventRecord(h->ev_fork, ctx->stream));
     for (int a = 0; a < 2; ++a) {
@@ -1362,9 +1426,9 @@ static int lda_estep_impl(tmvb_lda* h, int32_t viter, double vtol)
     tp.out = h->d_stats; tp.partial = h->d_ts_partial; tp.estride = h->e_padded ? h->estride : 0;
     // gather-side statistics of the documents whose kernels precede `after` on its stream:
     //   S[:, j] += beta[:, j] .* sum_tokens w E[:, doc] + eps sum w     (update_beta!(model, d))
-    auto stats_pass = [&](const tmvb_inv_index& ix) -> int {
+    auto stats_pass = [&](const tmvb_inv_index& ix, hipStream_t on) -> int {
         if ((p.debug & 1) || ix.n_chunks <= 0) return TMVB_OK;
-        return tmvb_launch_termstats(ctx, h->nslot, h->KP, h->e_padded, ix, tp);
+        return tmvb_launch_termstats(ctx, h->nslot, h->KP, h->e_padded, ix, tp, on);
     };
     int piece_open = 0;                                 // pieces [0, piece_open) have their statistics pass issued
     auto close_pieces = [&](int upto) -> int {          // document kernels of pieces < upto are all issued
@@ -1374,9 +1438,21 @@ static int lda_estep_impl(tmvb_lda* h, int32_t viter, double vtol)
                 TMVB_HIP(hipEventRecord(h->ev_join[1], h->aux[1]));
                 TMVB_HIP(hipStreamWaitEvent(chain_st, h->ev_join[1], 0));
             }
-            TMVB_HIP(hipEventRecord(h->ev_piece[piece_open], chain_st));
-            if (chain_st != ctx->stream) TMVB_HIP(hipStreamWaitEvent(ctx->stream, h->ev_piece[piece_open], 0));
-            int rc = stats_pass(piece_index(piece_open));
+            hipStream_t pass_st = ctx->stream;
+            if (shadow_stats) {
+                if (piece_open < P - 1) {                // in the chain's shadow: aux[0] waits for this piece's document kernels
+                    pass_st = h->aux[0];
+                    TMVB_HIP(hipEventRecord(h->ev_piece[piece_open], chain_st));
+                    TMVB_HIP(hipStreamWaitEvent(pass_st, h->ev_piece[piece_open], 0));
+                } else {                                 // the passes accumulate in order: the last one waits for aux[0]'s
+                    TMVB_HIP(hipEventRecord(h->ev_join[0], h->aux[0]));
+                    TMVB_HIP(hipStreamWaitEvent(ctx->stream, h->ev_join[0], 0));
+                }
+            } else {
+                TMVB_HIP(hipEventRecord(h->ev_piece[piece_open], chain_st));
+                if (chain_st != ctx->stream) TMVB_HIP(hipStreamWaitEvent(ctx->stream, h->ev_piece[piece_open], 0));
+            }
+            int rc = stats_pass(piece_index(piece_open), pass_st);
             if (rc) return rc;
         }
         return TMVB_OK;
@@ -1388,7 +1464,7 @@ static int lda_estep_impl(tmvb_lda* h, int32_t viter, double vtol)
         if (!h->reg_path) st = h->aux[(bi & 1) ^ 1];          // LDS-tile buckets only: alternate the two streams
         if (chain) { int rc = close_pieces(b.piece); if (rc) return rc; }
         if (b.grid_np > 0) {
-            const dim3 grid((unsigned)b.count), block(64);
+            const dim3 grid((unsigned)b.count), block(64 * (unsigned)b.waves);
             const int* tol = h->d_grid_topic_of_lane;
             switch (p.LPR) {
 #define LDA_GRID_CASE(LPRV) case LPRV: lda_launch_grid<LPRV>(b.grid_np, grid, block, st, p, b.first, tol); break;
