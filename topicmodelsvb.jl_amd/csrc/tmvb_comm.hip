@@ -27,9 +27,9 @@ struct tmvb_comm {
 };
 
 // RCCL is bound at the first communicator call, not at load time: single-GPU use of libtmvb_hip.so needs no RCCL at all, and a
-// process that already holds an RCCL (PyTorch ships its own librccl with the same SONAME) keeps exactly one copy -- the one
-// already mapped is taken (RTLD_NOLOAD) before the loader's search path and /opt/rocm/lib are tried.  The header this file
-// was compiled against and the runtime must agree in their major version (struct layouts, enum values); checked once.
+// process may hold another RCCL already (PyTorch ships its own librccl with the same SONAME): the copy next to the HIP runtime
+// in use is taken, privately (RTLD_LOCAL).  The header this file was compiled against and the runtime must agree in their
+// major version (struct layouts, enum values); checked once.
 namespace {
 struct RcclApi {
     void* so = nullptr;
@@ -51,13 +51,26 @@ std::once_flag g_rccl_once;
 void rccl_bind()
 {
     RcclApi& a = g_rccl;
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     if (const char* e = getenv("TMVB_RCCL_LIB")) a.so = dlopen(e, RTLD_NOW | RTLD_LOCAL);
-    for (int pass = 0; pass < 2 && !a.so; ++pass)
-        for (const char* n : names) {
-            a.so = dlopen(n, (pass == 0 ? RTLD_NOLOAD : 0) | RTLD_NOW | RTLD_LOCAL);
-            if (a.so) break;
+    // first choice: the RCCL that sits next to the HIP runtime this process really runs on (found through dladdr) -- an RCCL
+    // built for another HIP release fails in ncclCommInitRank with "unhandled cuda error" (seen with PyTorch's bundled copy
+    // under /opt/rocm's runtime); RTLD_LOCAL + dlsym on our own handle keep a second copy in the process from interfering
+    if (!a.so) {
+        Dl_info info;
+        if (dladdr(reinterpret_cast<const void*>(&hipGetDeviceCount), &info) && info.dli_fname) {
+            std::string path(info.dli_fname);
+            const size_t slash = path.find_last_of('/');
+            if (slash != std::string::npos) {
+                path = path.substr(0, slash + 1) + "librccl.so.1";
+                a.so = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+            }
         }
+    }
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};      // then the loader's search path (our rpath)
+    for (const char* n : names) {
+        if (a.so) break;
+        a.so = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    }
     if (!a.so) { a.error = std::string("RCCL is not available: ") + (dlerror() ? dlerror() : "librccl.so.1 not found") + " (set TMVB_RCCL_LIB)"; return; }
 #define TMVB_RCCL_SYM(field, sym)                                                         \
     a.field = reinterpret_cast<decltype(a.field)>(dlsym(a.so, #sym));                     \

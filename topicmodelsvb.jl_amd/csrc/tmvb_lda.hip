@@ -868,21 +868,30 @@ __global__ __launch_bounds__(64) void lda_elbo_reg_kernel(int K, const int32_t* 
 
 #define TMVB_REG_ANY_TILES 99   // bucket of register-tile documents with mixed tile counts (lda_estep_reg_any_kernel)
 #define TMVB_GRID_ANY_NP 99     // bucket of grid-tile documents with mixed lengths (lda_estep_grid_any_kernel)
-#define TMVB_GRID_NP_MAX 6      // token pairs per lane of the widest grid-tile instantiation: documents of <= 192 unique terms
 
-// token-pair classes of the grid-tile kernel: a document runs the smallest instantiated NP that holds it
-static inline int lda_grid_np_class(int64_t n) { const int64_t np = (n + 31) / 32; return np <= 2 ? 2 : np <= 3 ? 3 : np <= 4 ? 4 : 6; }
+// token pairs per lane of the widest grid-tile instantiation: 2 NP LPR tile registers + 2 LPR accumulators + ~40 must stay
+// within the 256 architectural VGPRs.  KP <= 60: 6 pairs (documents of <= 192 unique terms per wave), KP <= 76: 4, KP <= 100: 3.
+constexpr int lda_grid_np_max(int lpr) { return lpr <= 15 ? 6 : lpr <= 19 ? 4 : 3; }
+
+// token-pair classes of the grid-tile kernel: a document runs the smallest instantiated NP (2, 3, 4, 6 up to the maximum) that holds it
+static inline int lda_grid_np_class(int64_t n, int np_max)
+{
+    const int64_t np = (n + 31) / 32;
+    const int c = np <= 2 ? 2 : np <= 3 ? 3 : np <= 4 ? 4 : 6;
+    return c <= np_max ? c : np_max;
+}
 
 // All grid-tile documents of a SMALL corpus / shard in one launch (the pair count is read per document, wave-uniform)
 template <int LPR>
 __global__ __launch_bounds__(64) void lda_estep_grid_any_kernel(LdaParams p, int64_t first, const int* __restrict__ topic_of_lane)
 {
+    constexpr int NPM = lda_grid_np_max(LPR);
     const int d = p.doc_order[first + blockIdx.x];
     const int64_t off = p.doc_ptr[d];
     const int N = (int)(p.doc_ptr[d + 1] - off);
     const int np = __builtin_amdgcn_readfirstlane((N + 31) >> 5);
-    if (np > 4) lda_estep_grid_body<LPR, 6>(p, d, off, N, topic_of_lane);
-    else if (np == 4) lda_estep_grid_body<LPR, 4>(p, d, off, N, topic_of_lane);
+    if (NPM >= 6 && np > 4) lda_estep_grid_body<LPR, (NPM >= 6 ? 6 : 2)>(p, d, off, N, topic_of_lane);
+    else if (NPM >= 4 && np == 4) lda_estep_grid_body<LPR, (NPM >= 4 ? 4 : 2)>(p, d, off, N, topic_of_lane);
     else if (np == 3) lda_estep_grid_body<LPR, 3>(p, d, off, N, topic_of_lane);
     else lda_estep_grid_body<LPR, 2>(p, d, off, N, topic_of_lane);
 }
@@ -890,13 +899,14 @@ __global__ __launch_bounds__(64) void lda_estep_grid_any_kernel(LdaParams p, int
 template <int LPR>
 static void lda_launch_grid(int np, dim3 grid, dim3 block, hipStream_t st, const LdaParams& p, int64_t first, const int* tol)
 {
-    if (block.x == 128) { hipLaunchKernelGGL((lda_estep_grid_long_kernel<LPR, TMVB_GRID_NP_MAX, 2>), grid, block, 0, st, p, first, tol); return; }
-    if (block.x == 256) { hipLaunchKernelGGL((lda_estep_grid_long_kernel<LPR, TMVB_GRID_NP_MAX, 4>), grid, block, 0, st, p, first, tol); return; }
+    constexpr int NPM = lda_grid_np_max(LPR);
+    if (block.x == 128) { hipLaunchKernelGGL((lda_estep_grid_long_kernel<LPR, NPM, 2>), grid, block, 0, st, p, first, tol); return; }
+    if (block.x == 256) { hipLaunchKernelGGL((lda_estep_grid_long_kernel<LPR, NPM, 4>), grid, block, 0, st, p, first, tol); return; }
     if (np == TMVB_GRID_ANY_NP) hipLaunchKernelGGL((lda_estep_grid_any_kernel<LPR>), grid, block, 0, st, p, first, tol);
     else if (np <= 2) hipLaunchKernelGGL((lda_estep_grid_kernel<LPR, 2>), grid, block, 0, st, p, first, tol);
     else if (np == 3) hipLaunchKernelGGL((lda_estep_grid_kernel<LPR, 3>), grid, block, 0, st, p, first, tol);
-    else if (np == 4) hipLaunchKernelGGL((lda_estep_grid_kernel<LPR, 4>), grid, block, 0, st, p, first, tol);
-    else hipLaunchKernelGGL((lda_estep_grid_kernel<LPR, 6>), grid, block, 0, st, p, first, tol);
+    else if (np == 4) hipLaunchKernelGGL((lda_estep_grid_kernel<LPR, (NPM >= 4 ? 4 : 3)>), grid, block, 0, st, p, first, tol);
+    else hipLaunchKernelGGL((lda_estep_grid_kernel<LPR, (NPM >= 6 ? 6 : NPM)>), grid, block, 0, st, p, first, tol);
 }
 
 // register-tile launch for a bucket of `tiles`-tile documents (instantiates T = 1..TMAX only)
@@ -944,7 +954,8 @@ struct tmvb_lda {
     float* d_ts_partial = nullptr;     // [n_slots][K+1]
     int* d_topic_of_lane = nullptr;    // register-tile kernel lane maps
     int* d_grid_topic_of_lane = nullptr;   // grid-tile kernel lane map (tmvb_gridtile.h)
-    bool grid_path = false;            // KP <= 60 with recomputed statistics weights: documents of <= 192 terms use lda_estep_grid_kernel
+    bool grid_path = false;            // KP <= 100 with recomputed statistics weights: documents of <= 32 grid_np_max terms use lda_estep_grid_kernel
+    int grid_np_max = 0;               // lda_grid_np_max(KP / 4)
     bool reg_path = false;             // K <= 64 with a specialised LPR: short documents use lda_estep_reg_kernel
     int32_t* d_doc_order = nullptr;
     double* d_partial = nullptr;       // [TMVB_REDUCE_BLOCKS][K]
@@ -1006,7 +1017,7 @@ static void lda_build_buckets(tmvb_lda* h, std::vector<int32_t>& order)
     std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return len[x] > len[y]; });
     h->buckets.clear();
     const int max_tiles = lda_reg_max_tiles(h->KP / 4);
-    const int64_t reg_max = h->grid_path ? 32 * TMVB_GRID_NP_MAX : h->reg_path ? 64 * max_tiles : -1;
+    const int64_t reg_max = h->grid_path ? 32 * h->grid_np_max : h->reg_path ? 64 * max_tiles : -1;
     // documents longer than reg_max: LDS-tile kernel
     // long documents get up to 156 KiB of LDS (one workgroup per CU): a tile that holds the whole document is
     // gathered once per E-step, a streamed one once per sweep
@@ -1016,7 +1027,7 @@ static void lda_build_buckets(tmvb_lda* h, std::vector<int32_t>& order)
     const int64_t long_max = long_reg ? (int64_t)64 * max_tiles * TMVB_LONG_WAVES : reg_max;
     int64_t pos = tmvb_build_lds_buckets(len, order, h->M, h->KP, long_max, 3, h->buckets, TMVB_BIG_TILE_BYTES);
     // grid-tile kernel with 4 / 2 waves per document: up to 768 / 384 unique terms
-    const int64_t grid_long_max = (h->grid_path && long_reg) ? (int64_t)32 * TMVB_GRID_NP_MAX * 4 : 0;
+    const int64_t grid_long_max = (h->grid_path && long_reg) ? (int64_t)32 * h->grid_np_max * 4 : 0;
     if (long_reg) {
         for (int T = max_tiles; T >= 1 && pos < h->M; --T) {   // (KP = 100, T = 3 spills to AGPRs and is still 2.8x the LDS kernel)
             const int64_t lo = std::max<int64_t>(std::max<int64_t>(64 * TMVB_LONG_WAVES * (int64_t)(T - 1), reg_max), grid_long_max);
@@ -1026,10 +1037,10 @@ static void lda_build_buckets(tmvb_lda* h, std::vector<int32_t>& order)
             pos += cnt;
         }
         for (int Wv = 4; Wv >= 2 && grid_long_max > 0 && pos < h->M; Wv >>= 1) {
-            const int64_t lo = (int64_t)32 * TMVB_GRID_NP_MAX * (Wv / 2);
+            const int64_t lo = (int64_t)32 * h->grid_np_max * (Wv / 2);
             int64_t cnt = 0;
             while (pos + cnt < h->M && len[order[pos + cnt]] > lo) ++cnt;
-            if (cnt) { tmvb_bucket b{pos, cnt, 0, 1}; b.waves = Wv; b.grid_np = TMVB_GRID_NP_MAX; h->buckets.push_back(b); }
+            if (cnt) { tmvb_bucket b{pos, cnt, 0, 1}; b.waves = Wv; b.grid_np = h->grid_np_max; h->buckets.push_back(b); }
             pos += cnt;
         }
     }
@@ -1045,9 +1056,9 @@ static void lda_build_buckets(tmvb_lda* h, std::vector<int32_t>& order)
     if (h->grid_path) {
         // grid-tile buckets, longest first: one launch per instantiated pair count
         while (pos < h->M) {
-            const int np = lda_grid_np_class(len[order[pos]]);
+            const int np = lda_grid_np_class(len[order[pos]], h->grid_np_max);
             int64_t cnt = 0;
-            while (pos + cnt < h->M && lda_grid_np_class(len[order[pos + cnt]]) == np) ++cnt;
+            while (pos + cnt < h->M && lda_grid_np_class(len[order[pos + cnt]], h->grid_np_max) == np) ++cnt;
             tmvb_bucket b{pos, cnt, 0, (np + 1) / 2};        // reg_tiles > 0 marks a register bucket (chain stream, piece cuts)
             b.grid_np = np;
             h->buckets.push_back(b);
@@ -1225,7 +1236,8 @@ extern "C" int tmvb_lda_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
     }
     // grid-tile kernel (tmvb_gridtile.h): KP <= 60 (LPR <= 15: the widest instantiation stays within 256 VGPRs), statistics pass
     // recomputes the token weights (nothing per token is stored); TMVB_LDA_GRID=0 keeps the lane = token register tile
-    h->grid_path = h->reg_path && h->KP <= 60 && tmvb_termstats_recomputes(h->KP, h->e_padded) &&
+    h->grid_np_max = lda_grid_np_max(h->KP / 4);
+    h->grid_path = h->reg_path && h->KP <= 100 && tmvb_termstats_recomputes(h->KP, h->e_padded) &&
                    (uint64_t)h->V * (uint64_t)h->KP * 4u < (1ull << 32) &&            // rows are addressed by 32-bit byte offsets
                    !(getenv("TMVB_LDA_GRID") && atoi(getenv("TMVB_LDA_GRID")) == 0);
     if (h->grid_path) {
@@ -1233,7 +1245,8 @@ extern "C" int tmvb_lda_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
         switch (h->KP / 4) {
 #define LDA_GRID_MAP_CASE(LPRV) case LPRV: tmvb_grid_lane_map_fill<LPRV>(tol); break;
             LDA_GRID_MAP_CASE(1) LDA_GRID_MAP_CASE(3) LDA_GRID_MAP_CASE(5) LDA_GRID_MAP_CASE(7) LDA_GRID_MAP_CASE(9) LDA_GRID_MAP_CASE(11)
-            LDA_GRID_MAP_CASE(13) LDA_GRID_MAP_CASE(15)
+            LDA_GRID_MAP_CASE(13) LDA_GRID_MAP_CASE(15) LDA_GRID_MAP_CASE(17) LDA_GRID_MAP_CASE(19) LDA_GRID_MAP_CASE(21) LDA_GRID_MAP_CASE(23)
+            LDA_GRID_MAP_CASE(25)
 #undef LDA_GRID_MAP_CASE
             default: h->grid_path = false;
         }
@@ -1469,7 +1482,7 @@ static int lda_estep_impl(tmvb_lda* h, int32_t viter, double vtol)
             switch (p.LPR) {
 #define LDA_GRID_CASE(LPRV) case LPRV: lda_launch_grid<LPRV>(b.grid_np, grid, block, st, p, b.first, tol); break;
                 LDA_GRID_CASE(1) LDA_GRID_CASE(3) LDA_GRID_CASE(5) LDA_GRID_CASE(7) LDA_GRID_CASE(9) LDA_GRID_CASE(11) LDA_GRID_CASE(13)
-                LDA_GRID_CASE(15)
+                LDA_GRID_CASE(15) LDA_GRID_CASE(17) LDA_GRID_CASE(19) LDA_GRID_CASE(21) LDA_GRID_CASE(23) LDA_GRID_CASE(25)
 #undef LDA_GRID_CASE
                 default: TMVB_REQUIRE(false, TMVB_EINVAL, "tmvb_lda_estep: no grid-tile kernel for KP=%d", h->KP);
             }
