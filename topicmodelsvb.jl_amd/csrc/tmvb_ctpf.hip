@@ -20,6 +20,7 @@
 #include "tmvb_common_kernels.h"
 #include "tmvb_train.h"
 #include "tmvb_regtile.h"
+#include "tmvb_gridtile.h"
 
 struct CtpfParams {
     int K, KP, LPR;
@@ -408,6 +409,176 @@ static void ctpf_launch_reg(int tiles, dim3 grid, hipStream_t st, const CtpfPara
     else hipLaunchKernelGGL((ctpf_estep_reg_kernel<LPR, 2>), grid, dim3(64), 0, st, p, first, tol);
 }
 
+// ------------------------------------------------------------------------------ grid-tile E-step (tmvb_gridtile.h)
+// The register-tile arithmetic above on the 16 x 4 lane grid of tmvb_gridtile.h: lane (a, b) holds {terms 16 s + a} x {topics
+// 4 j + b} of the TA rows (NPT pairs of term slots) and the same of the TH rows of the readers (NPR pairs); per sweep four
+// matrix-vector products on packed fmas, two 4-lane all-reduces and two 16-lane reduce-scatters of LPR values instead of two
+// 64-lane reduce-scatters of KP values.  The softmax shifts (the maxima of x and of (a, b), src/CTPF.jl:329, :336) cancel in
+// phi / xi, so they are taken once, in the document's first sweep, and kept (the factors move by a few units per sweep; fp32
+// exp has 80 to spare).  W > 1: W waves share a long document (terms 32 NPT w + ..., readers 32 NPR w + ...), partial sums
+// through LDS once per sweep, every wave runs the identical tail.
+template <int LPR, int NPT, int NPR, int W = 1>
+__device__ __forceinline__ void ctpf_estep_grid_body(const CtpfParams& p, const int d, const int* __restrict__ topic_of_lane)
+{
+    constexpr int R = 4 * LPR;
+    static_assert(LPR <= 16, "ctpf_estep_grid_body: one result slot per lane");
+    const int lane = threadIdx.x & 63;
+    const int wave = (W > 1) ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+    const int a = lane >> 2, b = lane & 3;
+    const int K = p.K;
+    const int64_t off = p.doc_ptr[d], roff = p.rdr_ptr[d];
+    const int N = (int)(p.doc_ptr[d + 1] - off), Rd = (int)(p.rdr_ptr[d + 1] - roff);
+    __shared__ float xch[2][W > 1 ? W : 1][W > 1 ? 128 : 1];         // W > 1: per-wave partial (G | H), by sweep parity
+    __shared__ __attribute__((aligned(16))) float ef_all[W][2][4][16];   // e / f by class: [b][j], one copy per wave
+    float (*ef)[4][16] = ef_all[wave];
+
+    gv2f A[NPT][LPR], ct[NPT], H[NPR][LPR], rr[NPR];
+    {
+        const int64_t off0 = N > 0 ? off : 0;
+        grid_load_tile<LPR, NPT>(A, ct, p.TA, p.terms + off0, p.counts + off0, N, 32 * NPT * wave, a, b);
+    }
+    if (Rd > 0) {                                       // uniform: a corpus without readers has no TH table
+        grid_load_tile<LPR, NPR>(H, rr, p.TH, p.readers + roff, p.ratings + roff, Rd, 32 * NPR * wave, a, b);
+    } else {
+#pragma unroll
+        for (int q = 0; q < NPR; ++q) {
+            rr[q] = gv2f{0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < LPR; ++j) H[q][j] = gv2f{1.0f, 1.0f};
+        }
+    }
+    // topic role: this lane owns topic mytopic after the reduce-scatters (-1: not a primary owner)
+    const int mytopic = topic_of_lane[lane];
+    const bool on = mytopic >= 0 && mytopic < K;
+    const int mt = on ? mytopic : 0;
+    const float lb_l = p.lrates[mt], lv_l = p.lrates[K + mt], ld_l = p.lrates[2 * K + mt], lh_l = p.lrates[3 * K + mt];
+    const float g_l = p.gimel[(int64_t)d * K + mt], z_l = p.zayin[(int64_t)d * K + mt];
+    const float lb = on ? lb_l : 0.f, lv = on ? lv_l : 0.f, ld = on ? ld_l : 0.f, lh = on ? lh_l : 0.f;
+    float gim = on ? g_l : 1.0f, zay = on ? z_l : 1.0f;
+    float gim_old = gim, zay_old = zay;
+    float e = 0.f, f = 0.f, ea = 0.f, eb = 0.f, mx = 0.f, mab = 0.f;
+    const float vtol2 = p.vtol * p.vtol;
+
+    int sweeps = 0;
+    for (int v = 0; v < p.viter; ++v) {
+        ++sweeps;
+        const float dg = digamma_sweep_f(gim), dz = digamma_sweep_f(zay);
+        const float x = dg - ld - lb;                     // update_phi!  src/CTPF.jl:329
+        const float xa = dg - ld - lv, xb = dz - lh - lv; // update_xi!  :336
+        if (v == 0) {
+            mx = wave_max(on ? x : -INFINITY);
+            mab = wave_max(on ? fmaxf(xa, xb) : -INFINITY);
+        }
+        e = on ? sweep_exp(x - mx) : 0.f;
+        ea = on ? sweep_exp(xa - mab) : 0.f;
+        eb = on ? sweep_exp(xb - mab) : 0.f;
+        f = ea + eb;
+        if (mytopic >= 0) { ef[0][mytopic & 3][mytopic >> 2] = e; ef[1][mytopic & 3][mytopic >> 2] = f; }
+        if constexpr (W > 1) WAVE_PRIVATE_LDS_FENCE(); else WAVE_LDS_FENCE();
+        float G[1], Hh[1];
+        {   // terms: s_n = sum_i TA[n][i] e_i, w_n = c_n / s_n, G_i = sum_n w_n TA[n][i]
+            gv2f w[NPT];
+            grid_phase1<LPR, NPT>(A, ef[0][b], 0.0f, w);
+#pragma unroll
+            for (int q = 0; q < NPT; ++q) w[q] = ct[q] * gv2f{__builtin_amdgcn_rcpf(w[q].x), __builtin_amdgcn_rcpf(w[q].y)};
+            float gG[LPR];
+            grid_phase2<LPR, NPT>(A, w, gG);
+            grid_reduce_scatter<LPR>(gG, G);
+        }
+        {   // readers: s_u = sum_i TH[u][i] f_i, w_u = r_u / s_u, H_i = sum_u w_u TH[u][i]
+            gv2f w[NPR];
+            grid_phase1<LPR, NPR>(H, ef[1][b], 0.0f, w);
+#pragma unroll
+            for (int q = 0; q < NPR; ++q) w[q] = rr[q] * gv2f{__builtin_amdgcn_rcpf(w[q].x), __builtin_amdgcn_rcpf(w[q].y)};
+            float gH[LPR];
+            grid_phase2<LPR, NPR>(H, w, gH);
+            grid_reduce_scatter<LPR>(gH, Hh);
+        }
+        if constexpr (W > 1) {
+            float (*xb2)[128] = xch[v & 1];
+            xb2[wave][lane] = G[0]; xb2[wave][64 + lane] = Hh[0];
+            __syncthreads();
+            float tg = 0.0f, th = 0.0f;
+#pragma unroll
+            for (int ww = 0; ww < W; ++ww) { tg += xb2[ww][lane]; th += xb2[ww][64 + lane]; }   // fixed order: identical in every wave
+            G[0] = tg; Hh[0] = th;
+        }
+        zay_old = zay; gim_old = gim;
+        float dl = 0.f;
+        if (on) {
+            zay = fmaf(eb, Hh[0], p.hg);                  // update_zayin!  :322
+            gim = fmaf(ea, Hh[0], fmaf(e, G[0], p.hc));   // update_gimel!  :313
+            const float df = gim - gim_old;
+            dl = df * df;
+        }
+        if (wave_sum(dl) < vtol2) break;                  // :359, norm < vtol on the squares
+    }
+    if (wave == 0) {
+        const bool mine = mytopic >= 0 && mytopic < R;
+        if (sweeps > 0) {
+            if (on) {
+                p.gimel[(int64_t)d * K + mt] = gim; p.gimel_old[(int64_t)d * K + mt] = gim_old;
+                p.zayin[(int64_t)d * K + mt] = zay; p.zayin_old[(int64_t)d * K + mt] = zay_old;
+            }
+            if (mine) { p.E1[(int64_t)d * R + mytopic] = e; p.E2[(int64_t)d * R + mytopic] = f; }
+        } else {
+            if (mine) { p.E1[(int64_t)d * R + mytopic] = 0.f; p.E2[(int64_t)d * R + mytopic] = 0.f; }   // viter = 0
+        }
+        if (lane == 0) p.sweeps[d] = (uint8_t)min(sweeps, 255);
+    }
+}
+
+// length classes of the grid-tile kernel (term pairs, reader pairs per lane): documents of <= 32 readers by their terms
+// (<= 64 / 96 / 128 / 192), <= 128 terms with <= 64 readers, and -- four waves per document -- <= 256 terms with <= 512 readers
+#define CTPF_GRID_CLASSES(X) X(2, 1) X(3, 1) X(4, 1) X(6, 1) X(4, 2)
+#define CTPF_GRID_LONG_NPT 2
+#define CTPF_GRID_LONG_NPR 4
+#define CTPF_GRID_LONG_W 4
+static inline bool ctpf_grid_class(int64_t n, int64_t r, int* npt, int* npr, int* waves)
+{
+    *waves = 1;
+    if (r <= 32 && n <= 192) { *npr = 1; *npt = n <= 64 ? 2 : n <= 96 ? 3 : n <= 128 ? 4 : 6; return true; }
+    if (r <= 64 && n <= 128) { *npt = 4; *npr = 2; return true; }
+    if (n <= 32 * CTPF_GRID_LONG_NPT * CTPF_GRID_LONG_W && r <= 32 * CTPF_GRID_LONG_NPR * CTPF_GRID_LONG_W) {
+        *npt = CTPF_GRID_LONG_NPT; *npr = CTPF_GRID_LONG_NPR; *waves = CTPF_GRID_LONG_W; return true;
+    }
+    return false;
+}
+
+template <int LPR, int NPT, int NPR>
+__global__ __launch_bounds__(64) void ctpf_estep_grid_kernel(CtpfParams p, int64_t first, const int* __restrict__ topic_of_lane)
+{
+    ctpf_estep_grid_body<LPR, NPT, NPR>(p, p.doc_order[first + blockIdx.x], topic_of_lane);
+}
+template <int LPR>
+__global__ __launch_bounds__(64 * CTPF_GRID_LONG_W) void ctpf_estep_grid_long_kernel(CtpfParams p, int64_t first, const int* __restrict__ topic_of_lane)
+{
+    ctpf_estep_grid_body<LPR, CTPF_GRID_LONG_NPT, CTPF_GRID_LONG_NPR, CTPF_GRID_LONG_W>(p, p.doc_order[first + blockIdx.x], topic_of_lane);
+}
+// every single-wave class in one launch, the class read per document (wave-uniform): one kernel tail per iteration
+template <int LPR>
+__global__ __launch_bounds__(64) void ctpf_estep_grid_any_kernel(CtpfParams p, int64_t first, const int* __restrict__ topic_of_lane)
+{
+    const int d = p.doc_order[first + blockIdx.x];
+    const int N = __builtin_amdgcn_readfirstlane((int)(p.doc_ptr[d + 1] - p.doc_ptr[d]));
+    const int Rd = __builtin_amdgcn_readfirstlane((int)(p.rdr_ptr[d + 1] - p.rdr_ptr[d]));
+    if (Rd > 32) ctpf_estep_grid_body<LPR, 4, 2>(p, d, topic_of_lane);
+    else if (N > 128) ctpf_estep_grid_body<LPR, 6, 1>(p, d, topic_of_lane);
+    else if (N > 96) ctpf_estep_grid_body<LPR, 4, 1>(p, d, topic_of_lane);
+    else if (N > 64) ctpf_estep_grid_body<LPR, 3, 1>(p, d, topic_of_lane);
+    else ctpf_estep_grid_body<LPR, 2, 1>(p, d, topic_of_lane);
+}
+
+template <int LPR>
+static void ctpf_launch_grid(const tmvb_bucket& b, dim3 grid, hipStream_t st, const CtpfParams& p, int64_t first, const int* tol)
+{
+    if (b.waves > 1) { hipLaunchKernelGGL((ctpf_estep_grid_long_kernel<LPR>), grid, dim3(64 * CTPF_GRID_LONG_W), 0, st, p, first, tol); return; }
+    if (b.grid_np == 99) { hipLaunchKernelGGL((ctpf_estep_grid_any_kernel<LPR>), grid, dim3(64), 0, st, p, first, tol); return; }
+#define CTPF_GRID_LAUNCH(T_, R_) if (b.grid_np == T_ && b.grid_np2 == R_) { hipLaunchKernelGGL((ctpf_estep_grid_kernel<LPR, T_, R_>), grid, dim3(64), 0, st, p, first, tol); return; }
+    CTPF_GRID_CLASSES(CTPF_GRID_LAUNCH)
+#undef CTPF_GRID_LAUNCH
+}
+
 // shape update + table refresh:  X[id][i] = prior + stats[id][i];  T[id][i] = exp(psi(X));  stats <- 0
 // (update_alef!/update_he! src/CTPF.jl:251-255, :266-270: X <- X_temp, X_temp <- prior)
 __global__ __launch_bounds__(256) void ctpf_shape_kernel(float* __restrict__ stats, float prior, float* __restrict__ X,
@@ -658,6 +829,8 @@ struct tmvb_ctpf {
     double* d_partial = nullptr; double* d_partial2 = nullptr; double* d_rs_alef = nullptr; double* d_rs_he = nullptr; double* d_sum_g = nullptr; double* d_sum_z = nullptr;
     double elbo = 0.0;
     int* d_topic_of_lane = nullptr;     // register-tile kernel: topic owned by each lane after the reduce-scatter
+    int* d_grid_topic_of_lane = nullptr;   // grid-tile kernel (tmvb_gridtile.h): the same for its 16-lane reduce-scatter
+    bool grid_path = false;             // KP <= 60: documents of <= 256 terms and <= 512 readers use ctpf_estep_grid_kernel
     bool reg_path = false;              // KP = 4 * odd <= 60: short documents (<= 128 terms, <= 64 readers) use ctpf_estep_reg_kernel
     std::vector<tmvb_bucket> buckets;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -677,7 +850,7 @@ extern "C" int tmvb_ctpf_destroy(tmvb_ctpf* h)
     if (!h) return TMVB_OK;
     if (h->ctx) (void)hipSetDevice(h->ctx->device);
     (void)hipFree(h->d_alef); (void)hipFree(h->d_alef_old); (void)hipFree(h->d_he); (void)hipFree(h->d_he_old);
-    (void)hipFree(h->d_TA); (void)hipFree(h->d_TH); (void)hipFree(h->d_topic_of_lane);
+    (void)hipFree(h->d_TA); (void)hipFree(h->d_TH); (void)hipFree(h->d_topic_of_lane); (void)hipFree(h->d_grid_topic_of_lane);
     if (h->own_stats) (void)hipFree(h->d_stats);
     (void)hipFree(h->d_rates); (void)hipFree(h->d_lrates); (void)hipFree(h->d_gimel); (void)hipFree(h->d_gimel_old);
     (void)hipFree(h->d_zayin); (void)hipFree(h->d_zayin_old); (void)hipFree(h->d_wtok); (void)hipFree(h->d_wrdr);
@@ -750,11 +923,35 @@ extern "C" int tmvb_ctpf_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmv
         if ((rc = dmalloc(&h->d_topic_of_lane, tol.size()))) return rc;
         TMVB_HIP(hipMemcpy(h->d_topic_of_lane, tol.data(), tol.size() * sizeof(int), hipMemcpyHostToDevice));
     }
+    // grid-tile kernel: KP <= 60, both tables addressable by 32-bit byte offsets; TMVB_CTPF_GRID=0 keeps the lane = token tiles
+    h->grid_path = h->reg_path && (uint64_t)std::max(h->V, h->U) * (uint64_t)h->KP * 4u < (1ull << 32) &&
+                   !(getenv("TMVB_CTPF_GRID") && atoi(getenv("TMVB_CTPF_GRID")) == 0);
+    if (h->grid_path) {
+        std::vector<int> tol;
+        switch (h->KP / 4) {
+#define CTPF_GRID_MAP_CASE(LPRV) case LPRV: tmvb_grid_lane_map_fill<LPRV, 0>(tol); break;
+            CTPF_GRID_MAP_CASE(1) CTPF_GRID_MAP_CASE(3) CTPF_GRID_MAP_CASE(5) CTPF_GRID_MAP_CASE(7) CTPF_GRID_MAP_CASE(9) CTPF_GRID_MAP_CASE(11)
+            CTPF_GRID_MAP_CASE(13) CTPF_GRID_MAP_CASE(15)
+#undef CTPF_GRID_MAP_CASE
+            default: h->grid_path = false;
+        }
+        if (h->grid_path) {
+            if ((rc = dmalloc(&h->d_grid_topic_of_lane, tol.size()))) return rc;
+            TMVB_HIP(hipMemcpy(h->d_grid_topic_of_lane, tol.data(), tol.size() * sizeof(int), hipMemcpyHostToDevice));
+        }
+    }
     std::vector<int64_t> len((size_t)h->M);
     std::vector<int32_t> order, reg2, reg1;
+    // grid-tile classes (ctpf_grid_class): key = waves * 10000 + npt * 100 + npr, longest class first
+    std::vector<std::pair<int, int32_t>> gdocs;
     for (int64_t d = 0; d < h->M; ++d) {
         len[d] = corp->h_doc_len[d] + corp->h_rdr_len[d];
-        const bool reg = h->reg_path && corp->h_doc_len[d] <= 128 && corp->h_rdr_len[d] <= 64;
+        int npt = 0, npr = 0, wv = 1;
+        if (h->grid_path && ctpf_grid_class(corp->h_doc_len[d], corp->h_rdr_len[d], &npt, &npr, &wv)) {
+            gdocs.emplace_back(wv * 10000 + npt * 100 + npr, (int32_t)d);
+            continue;
+        }
+        const bool reg = h->reg_path && !h->grid_path && corp->h_doc_len[d] <= 128 && corp->h_rdr_len[d] <= 64;
         if (!reg) order.push_back((int32_t)d);
         else if (corp->h_doc_len[d] > 64) reg2.push_back((int32_t)d);
         else reg1.push_back((int32_t)d);
@@ -769,6 +966,20 @@ extern "C" int tmvb_ctpf_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmv
     order.insert(order.end(), reg2.begin(), reg2.end());
     if (!reg1.empty()) h->buckets.push_back({(int64_t)order.size(), (int64_t)reg1.size(), 0, 1});
     order.insert(order.end(), reg1.begin(), reg1.end());
+    if (!gdocs.empty()) {
+        std::stable_sort(gdocs.begin(), gdocs.end(), [&](const std::pair<int, int32_t>& x, const std::pair<int, int32_t>& y) {
+            return x.first != y.first ? x.first > y.first : len[x.second] > len[y.second]; });
+        size_t q = 0;
+        while (q < gdocs.size()) {
+            size_t e = q;
+            while (e < gdocs.size() && gdocs[e].first == gdocs[q].first) ++e;
+            tmvb_bucket b{(int64_t)order.size(), (int64_t)(e - q), 0, 1};
+            b.waves = gdocs[q].first / 10000; b.grid_np = (gdocs[q].first / 100) % 100; b.grid_np2 = gdocs[q].first % 100;
+            h->buckets.push_back(b);
+            for (size_t u = q; u < e; ++u) order.push_back(gdocs[u].second);
+            q = e;
+        }
+    }
     if (h->M) TMVB_HIP(hipMemcpyAsync(h->d_doc_order, order.data(), (size_t)h->M * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     TMVB_HIP(hipMemsetAsync(h->d_stats, 0, (size_t)h->stats_len() * sizeof(float), ctx->stream));
     TMVB_HIP(hipMemsetAsync(h->d_sweeps, 0, std::max<size_t>((size_t)h->M, 1), ctx->stream));
@@ -932,6 +1143,28 @@ extern "C" int tmvb_ctpf_estep(tmvb_ctpf* h, int32_t viter, double vtol)
     for (int bi = 0; bi < nb; ++bi) {
         const tmvb_bucket& b = h->buckets[bi];
         dim3 grid((unsigned)b.count), block(64);
+        if (b.grid_np > 0) {
+            // four-wave documents on aux[1] next to the chain; the single-wave classes back to back on the context's stream -- as ONE
+            // mixed-class launch unless TMVB_CTPF_GRID_ANY=0 (one kernel tail per iteration; the price is the widest body's registers)
+            static const bool gany = [] { const char* e = getenv("TMVB_CTPF_GRID_ANY"); return !(e && atoi(e) == 0); }();
+            hipStream_t st = b.waves > 1 ? h->aux[1] : chain_st;
+            tmvb_bucket bb = b;
+            if (gany && b.waves == 1) {
+                int64_t cnt = b.count;
+                while (bi + 1 < nb && h->buckets[bi + 1].grid_np > 0 && h->buckets[bi + 1].waves == 1 &&
+                       h->buckets[bi + 1].first == b.first + cnt) { cnt += h->buckets[bi + 1].count; ++bi; }
+                if (cnt > b.count) { bb.count = cnt; bb.grid_np = 99; grid = dim3((unsigned)cnt); }
+            }
+            switch (p.LPR) {
+#define CTPF_GRID_CASE(LPRV) case LPRV: ctpf_launch_grid<LPRV>(bb, grid, st, p, b.first, h->d_grid_topic_of_lane); break;
+                CTPF_GRID_CASE(1) CTPF_GRID_CASE(3) CTPF_GRID_CASE(5) CTPF_GRID_CASE(7) CTPF_GRID_CASE(9) CTPF_GRID_CASE(11) CTPF_GRID_CASE(13)
+                CTPF_GRID_CASE(15)
+#undef CTPF_GRID_CASE
+                default: TMVB_REQUIRE(false, TMVB_EINVAL, "tmvb_ctpf_estep: no grid-tile kernel for KP=%d", h->KP);
+            }
+            TMVB_HIP(hipGetLastError());
+            continue;
+        }
         if (b.reg_tiles > 0) {
             hipStream_t st = chain_st;
             // two adjacent register-tile buckets (T = 2 then T = 1 in processing order): one mixed-tile launch

@@ -151,12 +151,90 @@ __device__ __forceinline__ void grid_reduce_scatter(float (&v)[M], float (&res)[
     for (int r = 0; r < (M + 15) / 16; ++r) res[r] = v[r];
 }
 
-// host copy of the map for LPR topics per class + the sum-of-weights value (M = LPR + 1 values): topic_of_lane[r * 64 + l] =
-// the topic lane l owns in result slot r (4 j + b for the primary owner of index j < LPR), -1 otherwise.
-template <int LPR>
+// ---- the tile and its two matrix-vector products ---------------------------------------------------------------------------
+// Tile of the rows ids[nbase + 16 s + a], s < 2 NP, of a [.][4 LPR] fp32 table (uniform base + 32-bit byte offsets: the table
+// must be smaller than 4 GiB), topics 4 j + b; vals -> c (as float).  Branch-free and in two waves of loads: every id / value of
+// the lane first (a slot past the slice's last entry reads entry 0 and gets value 0 -> weight exactly 0), then every row.
+template <int LPR, int NP>
+__device__ __forceinline__ void grid_load_tile(gv2f (&B)[NP][LPR], gv2f (&c)[NP], const float* __restrict__ table,
+                                               const int* __restrict__ ids, const int* __restrict__ vals, const int N,
+                                               const int nbase, const int a, const int b)
+{
+    int tm[2 * NP], cn[2 * NP];
+#pragma unroll
+    for (int s = 0; s < 2 * NP; ++s) {
+        const int n = nbase + 16 * s + a;
+        const unsigned nc = n < N ? (unsigned)n : 0u;
+        tm[s] = ids[nc];
+        cn[s] = vals[nc];                                   // unconditional load, masked below
+    }
+#pragma unroll
+    for (int s = 0; s < 2 * NP; ++s) cn[s] = (nbase + 16 * s + a < N) ? cn[s] : 0;
+    const char* __restrict__ tb = (const char*)table;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        c[q] = gv2f{(float)cn[2 * q], (float)cn[2 * q + 1]};
+        const uint32_t o0 = (uint32_t)tm[2 * q] * (uint32_t)(16 * LPR) + 4u * (uint32_t)b;
+        const uint32_t o1 = (uint32_t)tm[2 * q + 1] * (uint32_t)(16 * LPR) + 4u * (uint32_t)b;
+#pragma unroll
+        for (int j = 0; j < LPR; ++j)
+            B[q][j] = gv2f{*(const float*)(tb + o0 + 16u * j), *(const float*)(tb + o1 + 16u * j)};
+    }
+}
+
+// s_n = 4 init4 + sum_i B[n][i] e_i for the lane's 2 NP tokens, complete in every lane of the quad: LPR packed fmas per token
+// pair with e_j (the class's row in LDS, [j]) broadcast inside the pair by op_sel, then two DPP adds per token.
+template <int LPR, int NP>
+__device__ __forceinline__ void grid_phase1(const gv2f (&B)[NP][LPR], const float* __restrict__ e_row, const float init4, gv2f (&s)[NP])
+{
+    gv2f sacc[NP][2];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) { sacc[q][0] = gv2f{init4, init4}; sacc[q][1] = gv2f{0.f, 0.f}; }
+#pragma unroll
+    for (int jq = 0; jq < (LPR + 3) / 4; ++jq) {
+        const float4 ev = ((const float4*)e_row)[jq];
+        const float ej[4] = {ev.x, ev.y, ev.z, ev.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = 4 * jq + u;
+            if (j < LPR) {
+#pragma unroll
+                for (int q = 0; q < NP; ++q)
+                    sacc[q][j & 1] = __builtin_elementwise_fma(B[q][j], gv2f{ej[u], ej[u]}, sacc[q][j & 1]);
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        gv2f s2 = sacc[q][0] + sacc[q][1];
+        s2.x += dpp_f<0xB1>(s2.x); s2.y += dpp_f<0xB1>(s2.y);                     // quad_perm [1,0,3,2]
+        s2.x += dpp_f<0x4E>(s2.x); s2.y += dpp_f<0x4E>(s2.y);                     // quad_perm [2,3,0,1]
+        s[q] = s2;
+    }
+}
+
+// gv[j] = sum over the lane's tokens of w_n B[n][j], j < LPR (the 16-lane reduce-scatter follows)
+template <int LPR, int NP, int MV>
+__device__ __forceinline__ void grid_phase2(const gv2f (&B)[NP][LPR], const gv2f (&w)[NP], float (&gv)[MV])
+{
+    static_assert(MV >= LPR, "grid_phase2");
+    gv2f g2[LPR];
+#pragma unroll
+    for (int j = 0; j < LPR; ++j) g2[j] = B[0][j] * w[0];
+#pragma unroll
+    for (int q = 1; q < NP; ++q)
+#pragma unroll
+        for (int j = 0; j < LPR; ++j) g2[j] = __builtin_elementwise_fma(B[q][j], w[q], g2[j]);
+#pragma unroll
+    for (int j = 0; j < LPR; ++j) gv[j] = g2[j].x + g2[j].y;
+}
+
+// host copy of the map for LPR topics per class + EXTRA more values riding in the reduce-scatter (LDA: sum_n w_n, M = LPR + 1):
+// topic_of_lane[r * 64 + l] = the topic lane l owns in result slot r (4 j + b for the primary owner of index j < LPR), -1 otherwise.
+template <int LPR, int EXTRA = 1>
 static void tmvb_grid_lane_map_fill(std::vector<int>& topic_of_lane)
 {
-    constexpr int M = LPR + 1;
+    constexpr int M = LPR + EXTRA;
     const GridMap<M>& g = kGridMap<M>;
     topic_of_lane.assign((size_t)GridMap<M>::NS * 64, -1);
     for (int r = 0; r < GridMap<M>::NS; ++r)

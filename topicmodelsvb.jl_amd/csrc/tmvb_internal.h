@@ -59,6 +59,7 @@ struct tmvb_bucket {
     int32_t piece = 0;         // pipelined E-step: which statistics pass consumes this bucket's documents
     int32_t waves = 1;         // > 1: register-tile kernel with one workgroup of `waves` waves per (long) document
     int32_t grid_np = 0;       // > 0: grid-tile kernel (tmvb_gridtile.h) with this many token PAIRS per lane (<= 32 grid_np tokens)
+    int32_t grid_np2 = 0;      // CTPF: reader pairs per lane of the grid-tile kernel
 };
 
 // Inverted (id-major) index over a CSR token stream, cut into chunks of at most TMVB_CHUNK tokens.

@@ -531,33 +531,8 @@ __device__ __forceinline__ void lda_estep_grid_body(const LdaParams& p, const in
     gv2f B[NP][LPR];
     gv2f c[NP];
     {
-        // branch-free and in two waves of loads: every id / count of the lane first (a slot past the document's last token
-        // reads element 0 and gets count 0 -> weight exactly 0), then every row -- no load sits behind a wait for another
-        int tm[2 * NP], cn[2 * NP];
-        const int64_t off0 = N > 0 ? off : 0;               // uniform base + 32-bit lane offset
-        const int* __restrict__ tp = p.terms + off0;
-        const int* __restrict__ cp = p.counts + off0;
-#pragma unroll
-        for (int s = 0; s < 2 * NP; ++s) {
-            const int n = 32 * NP * wave + 16 * s + a;
-            const unsigned nc = n < N ? (unsigned)n : 0u;
-            tm[s] = tp[nc];
-            cn[s] = cp[nc];                                 // unconditional load, masked below
-        }
-#pragma unroll
-        for (int s = 0; s < 2 * NP; ++s) cn[s] = (32 * NP * wave + 16 * s + a < N) ? cn[s] : 0;
-        // rows through a uniform base + 32-bit byte offset (the table is V * KP * 4 < 4 GiB bytes, checked at create): one
-        // multiply per row, the 16 j bytes ride in the instruction's immediate offset
-        const char* __restrict__ beta_c = (const char*)p.beta;
-#pragma unroll
-        for (int q = 0; q < NP; ++q) {
-            c[q] = gv2f{(float)cn[2 * q], (float)cn[2 * q + 1]};
-            const uint32_t o0 = (uint32_t)tm[2 * q] * (uint32_t)(16 * LPR) + 4u * (uint32_t)b;
-            const uint32_t o1 = (uint32_t)tm[2 * q + 1] * (uint32_t)(16 * LPR) + 4u * (uint32_t)b;
-#pragma unroll
-            for (int j = 0; j < LPR; ++j)
-                B[q][j] = gv2f{*(const float*)(beta_c + o0 + 16u * j), *(const float*)(beta_c + o1 + 16u * j)};
-        }
+        const int64_t off0 = N > 0 ? off : 0;               // uniform base + 32-bit lane offsets
+        grid_load_tile<LPR, NP>(B, c, p.beta, p.terms + off0, p.counts + off0, N, 32 * NP * wave, a, b);
     }
     // topic role: result slot r of this lane owns topic mytopic[r] (4 j + b for the primary owner of value j; -1 otherwise)
     int mytopic[NS];
@@ -604,44 +579,15 @@ __device__ __forceinline__ void lda_estep_grid_body(const LdaParams& p, const in
             if (mytopic[r] >= 0) e_lds[mytopic[r] & 3][mytopic[r] >> 2] = e[r];
         }
         if constexpr (W > 1) WAVE_PRIVATE_LDS_FENCE(); else WAVE_LDS_FENCE();
-        // ---- phase 1: s_n over this lane's LPR topics, then over the quad
-        gv2f sacc[NP][2];
-#pragma unroll
-        for (int q = 0; q < NP; ++q) { sacc[q][0] = gv2f{keps4, keps4}; sacc[q][1] = gv2f{0.f, 0.f}; }
-#pragma unroll
-        for (int jq = 0; jq < (LPR + 3) / 4; ++jq) {
-            const float4 ev = ((const float4*)e_lds[b])[jq];
-            const float ej[4] = {ev.x, ev.y, ev.z, ev.w};
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = 4 * jq + u;
-                if (j < LPR) {
-#pragma unroll
-                    for (int q = 0; q < NP; ++q)
-                        sacc[q][j & 1] = __builtin_elementwise_fma(B[q][j], gv2f{ej[u], ej[u]}, sacc[q][j & 1]);
-                }
-            }
-        }
+        // ---- phase 1: s_n over this lane's LPR topics, then over the quad (K eps rides in as the start value)
         gv2f w[NP];
+        grid_phase1<LPR, NP>(B, e_lds[b], keps4, w);
 #pragma unroll
-        for (int q = 0; q < NP; ++q) {
-            gv2f s2 = sacc[q][0] + sacc[q][1];
-            s2.x += dpp_f<0xB1>(s2.x); s2.y += dpp_f<0xB1>(s2.y);                     // quad_perm [1,0,3,2]
-            s2.x += dpp_f<0x4E>(s2.x); s2.y += dpp_f<0x4E>(s2.y);                     // quad_perm [2,3,0,1]
-            w[q] = c[q] * gv2f{__builtin_amdgcn_rcpf(s2.x), __builtin_amdgcn_rcpf(s2.y)};   // s_n includes K eps (sacc's start value)
-        }
+        for (int q = 0; q < NP; ++q) w[q] = c[q] * gv2f{__builtin_amdgcn_rcpf(w[q].x), __builtin_amdgcn_rcpf(w[q].y)};
         // ---- phase 2: g_i over this lane's tokens, then over the 16 token groups
         float gv[M];
+        grid_phase2<LPR, NP>(B, w, gv);
         {
-            gv2f g2[LPR];
-#pragma unroll
-            for (int j = 0; j < LPR; ++j) g2[j] = B[0][j] * w[0];
-#pragma unroll
-            for (int q = 1; q < NP; ++q)
-#pragma unroll
-                for (int j = 0; j < LPR; ++j) g2[j] = __builtin_elementwise_fma(B[q][j], w[q], g2[j]);
-#pragma unroll
-            for (int j = 0; j < LPR; ++j) gv[j] = g2[j].x + g2[j].y;
             gv2f ws = w[0];
 #pragma unroll
             for (int q = 1; q < NP; ++q) ws += w[q];
