@@ -101,6 +101,33 @@ def test_device_elbo_matches_oracle(tmvb, oracle, case):
         assert np.isfinite(e_g) and abs(e_g - e_o) <= 2e-5 * abs(e_o), (it, e_g, e_o)
 
 
+def test_fast_elbo_equals_the_entry_by_entry_kernel(tmvb):
+    """update_elbo!'s per-document part in its table form (two row reads and 3 K fmas per term / reader entry) against the
+    entry-by-entry kernel (2 K digammas per entry; TMVB_CTPF_ELBO_LEGACY=1), which the oracle tests pinned in round 2: same
+    state, relative difference <= 2e-7; K = 12, 50 (one topic slot per lane), 100 (two), ratings > 1, documents without
+    readers, and a state no E-step produced (the constructor's)."""
+    import subprocess, sys, json
+    code = (
+        "import sys, json, numpy as np; sys.path.insert(0, %r); import tmvb_amd; tm = tmvb_amd.pkg\n"
+        "out = []\n"
+        "for K in (12, 50, 100):\n"
+        "    pc = tm.syn_citeu(M=300, V=500, U=90, seed=K)\n"
+        "    rng = np.random.default_rng(K); pc.ratings[:] = rng.integers(1, 4, size=pc.nR)\n"
+        "    g = tm.gpuCTPF(pc, K)\n"
+        "    out.append(g.update_elbo())\n"
+        "    for it in range(3):\n"
+        "        g.estep(); g.reduce_docs(); g.mstep(); out.append(g.update_elbo())\n"
+        "print(json.dumps(out))\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for legacy in ("0", "1"):
+        env = dict(os.environ, TMVB_CTPF_ELBO_LEGACY=legacy)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[legacy] = np.array(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert np.all(np.isfinite(res["0"]))
+    assert np.all(np.abs(res["0"] - res["1"]) <= 2e-7 * np.abs(res["1"])), (res["0"], res["1"])
+
+
 def test_fixed_sweeps_exact_arithmetic(tmvb, oracle):
     g = synth_case(tmvb, 50, M=60, V=200, U=40, seed=9)
     gm, om = make_pair(tmvb, oracle, g)

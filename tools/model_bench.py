@@ -154,7 +154,8 @@ def ctpf(burnin=60, warmup=5, steps=50, cpu=True):
     sec = window(it, gm.synchronize, max(burnin - warmup - steps, 0), warmup, steps)
     es_ms = gm.last_estep_ms()
     hist = gm.sweep_hist().tolist()
-    # a checked iteration (update_elbo! on the device after every M-step)
+    # a checked iteration (update_elbo! on the device after every M-step); the first call builds the per-document constants
+    gm.update_elbo()
     gm.synchronize(); t0 = time.perf_counter()
     for _ in range(10):
         it(); gm.update_elbo()

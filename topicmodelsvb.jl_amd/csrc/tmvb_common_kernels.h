@@ -334,12 +334,16 @@ static int download_f32(tmvb_ctx* ctx, double* dst, const float* src, size_t n)
 
 
 
+// blocks of a column sum: at least 128 columns per block (32 per wave) -- a function of the column count only, so the summation
+// order is the same on every rank and in every run
+static inline int tmvb_colsum_blocks(int64_t ncols) { return (int)std::min<int64_t>(TMVB_REDUCE_BLOCKS, std::max<int64_t>(1, (ncols + 127) / 128)); }
+
 // deterministic column sums of a K x ncols fp32 matrix into out_d (fp64) and/or out_f (fp32)
 static inline int tmvb_colsum(tmvb_ctx* ctx, int nslot, int K, const float* X, int64_t ncols, double* d_partial,
                               double* out_d, float* out_f, hipStream_t on_stream = nullptr)
 {
     hipStream_t st = on_stream ? on_stream : ctx->stream;
-    int nb = (int)std::min<int64_t>(TMVB_REDUCE_BLOCKS, std::max<int64_t>(1, (ncols + 3) / 4));
+    int nb = tmvb_colsum_blocks(ncols);
     int rc = dispatch_nslot(nslot, [&](auto ns) -> int {
         constexpr int NS = decltype(ns)::value;
         hipLaunchKernelGGL((colsum_partial_kernel<NS>), dim3(nb), dim3(256), 0, st, X, ncols, K, d_partial);
@@ -379,7 +383,13 @@ static __global__ __launch_bounds__(256) void colsum2_final_kernel(tmvb_colsum_j
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= K) return;
     double s = 0.0;
-    for (int b = lane; b < nblocks; b += 64) s += j.partial[(int64_t)b * K + i];
+    for (int b0 = 0; b0 < nblocks; b0 += 64 * 16) {          // 16 independent loads in flight per lane, added in a fixed order
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int b = b0 + lane + 64 * u; v[u] = b < nblocks ? j.partial[(int64_t)b * K + i] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += v[u];
+    }
     s = wave_sum_d(s);
     if (lane == 0) {
         if (j.out_d) j.out_d[i] = s;
@@ -394,7 +404,7 @@ static inline int tmvb_colsum2(tmvb_ctx* ctx, int K, tmvb_colsum_job j0, tmvb_co
     TMVB_REQUIRE(K <= 64, TMVB_EINVAL, "tmvb_colsum2: K <= 64");
     hipStream_t st = on_stream ? on_stream : ctx->stream;
     const int64_t nmax = std::max(j0.ncols, j1.ncols);
-    const int nb = (int)std::min<int64_t>(TMVB_REDUCE_BLOCKS, std::max<int64_t>(1, (nmax + 3) / 4));
+    const int nb = tmvb_colsum_blocks(nmax);
     hipLaunchKernelGGL(colsum2_partial_kernel, dim3(nb, 2), dim3(256), 0, st, j0, j1, K);
     hipLaunchKernelGGL(colsum2_final_kernel, dim3((K + 3) / 4, 2), dim3(256), 0, st, j0, j1, nb, K);
     TMVB_HIP(hipGetLastError());

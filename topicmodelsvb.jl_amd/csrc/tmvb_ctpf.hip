@@ -417,20 +417,25 @@ static void ctpf_launch_reg(int tiles, dim3 grid, hipStream_t st, const CtpfPara
 // phi / xi, so they are taken once, in the document's first sweep, and kept (the factors move by a few units per sweep; fp32
 // exp has 80 to spare).  W > 1: W waves share a long document (terms 32 NPT w + ..., readers 32 NPR w + ...), partial sums
 // through LDS once per sweep, every wave runs the identical tail.
-template <int LPR, int NPT, int NPR, int W = 1>
-__device__ __forceinline__ void ctpf_estep_grid_body(const CtpfParams& p, const int d, const int* __restrict__ topic_of_lane)
+// BW = waves per workgroup: W (the W waves of one long document); with W = 1 and BW > 1 the waves of a workgroup would be
+// independent single-wave documents sharing nothing but the LDS array, sliced by wave (tried as one launch for the whole corpus:
+// slower, see tmvb_ctpf_estep).
+template <int LPR, int NPT, int NPR, int W = 1, int BW = W>
+__device__ __forceinline__ void ctpf_estep_grid_body(const CtpfParams& p, const int d, const int* __restrict__ topic_of_lane,
+                                                    float (*ef_all)[2][4][16], float (*xch)[4][128])
 {
     constexpr int R = 4 * LPR;
     static_assert(LPR <= 16, "ctpf_estep_grid_body: one result slot per lane");
+    static_assert(W == 1 || W == BW, "ctpf_estep_grid_body: a multi-wave document owns its workgroup");
+    static_assert(W <= 4, "ctpf_estep_grid_body: the exchange buffer holds four waves");
     const int lane = threadIdx.x & 63;
-    const int wave = (W > 1) ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+    const int bwave = (BW > 1) ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;   // LDS slice
+    const int wave = (W > 1) ? bwave : 0;                                                       // share of the document
     const int a = lane >> 2, b = lane & 3;
     const int K = p.K;
     const int64_t off = p.doc_ptr[d], roff = p.rdr_ptr[d];
     const int N = (int)(p.doc_ptr[d + 1] - off), Rd = (int)(p.rdr_ptr[d + 1] - roff);
-    __shared__ float xch[2][W > 1 ? W : 1][W > 1 ? 128 : 1];         // W > 1: per-wave partial (G | H), by sweep parity
-    __shared__ __attribute__((aligned(16))) float ef_all[W][2][4][16];   // e / f by class: [b][j], one copy per wave
-    float (*ef)[4][16] = ef_all[wave];
+    float (*ef)[4][16] = ef_all[bwave];                 // e / f by class: [b][j], one copy per wave
 
     gv2f A[NPT][LPR], ct[NPT], H[NPR][LPR], rr[NPR];
     {
@@ -474,7 +479,7 @@ __device__ __forceinline__ void ctpf_estep_grid_body(const CtpfParams& p, const 
         eb = on ? sweep_exp(xb - mab) : 0.f;
         f = ea + eb;
         if (mytopic >= 0) { ef[0][mytopic & 3][mytopic >> 2] = e; ef[1][mytopic & 3][mytopic >> 2] = f; }
-        if constexpr (W > 1) WAVE_PRIVATE_LDS_FENCE(); else WAVE_LDS_FENCE();
+        if constexpr (BW > 1) WAVE_PRIVATE_LDS_FENCE(); else WAVE_LDS_FENCE();
         float G[1], Hh[1];
         {   // terms: s_n = sum_i TA[n][i] e_i, w_n = c_n / s_n, G_i = sum_n w_n TA[n][i]
             gv2f w[NPT];
@@ -529,56 +534,65 @@ __device__ __forceinline__ void ctpf_estep_grid_body(const CtpfParams& p, const 
 }
 
 // length classes of the grid-tile kernel (term pairs, reader pairs per lane): documents of <= 32 readers by their terms
-// (<= 64 / 96 / 128 / 192), <= 128 terms with <= 64 readers, and -- four waves per document -- <= 256 terms with <= 512 readers
+// (<= 64 / 96 / 128 / 192), <= 128 terms with <= 64 readers, and -- eight waves per document -- <= 512 terms with <= 512 readers
 #define CTPF_GRID_CLASSES(X) X(2, 1) X(3, 1) X(4, 1) X(6, 1) X(4, 2)
-#define CTPF_GRID_LONG_NPT 2
-#define CTPF_GRID_LONG_NPR 4
-#define CTPF_GRID_LONG_W 4
+// multi-wave classes, four waves per document: (2 term pairs, 4 reader pairs) = <= 256 terms, <= 512 readers, and (3, 3) = <= 384, <= 384
 static inline bool ctpf_grid_class(int64_t n, int64_t r, int* npt, int* npr, int* waves)
 {
     *waves = 1;
     if (r <= 32 && n <= 192) { *npr = 1; *npt = n <= 64 ? 2 : n <= 96 ? 3 : n <= 128 ? 4 : 6; return true; }
     if (r <= 64 && n <= 128) { *npt = 4; *npr = 2; return true; }
-    if (n <= 32 * CTPF_GRID_LONG_NPT * CTPF_GRID_LONG_W && r <= 32 * CTPF_GRID_LONG_NPR * CTPF_GRID_LONG_W) {
-        *npt = CTPF_GRID_LONG_NPT; *npr = CTPF_GRID_LONG_NPR; *waves = CTPF_GRID_LONG_W; return true;
-    }
+    if (n <= 256 && r <= 512) { *npt = 2; *npr = 4; *waves = 4; return true; }
+    if (n <= 384 && r <= 384) { *npt = 3; *npr = 3; *waves = 4; return true; }
     return false;
 }
+
+#define CTPF_GRID_LDS(BWV)                                                                                              \
+    __shared__ float xch[2][4][128];                    /* multi-wave documents: per-wave partial (G | H), by sweep parity */ \
+    __shared__ __attribute__((aligned(16))) float ef_all[BWV][2][4][16]
 
 template <int LPR, int NPT, int NPR>
 __global__ __launch_bounds__(64) void ctpf_estep_grid_kernel(CtpfParams p, int64_t first, const int* __restrict__ topic_of_lane)
 {
-    ctpf_estep_grid_body<LPR, NPT, NPR>(p, p.doc_order[first + blockIdx.x], topic_of_lane);
+    CTPF_GRID_LDS(1);
+    ctpf_estep_grid_body<LPR, NPT, NPR>(p, p.doc_order[first + blockIdx.x], topic_of_lane, ef_all, xch);
 }
-template <int LPR>
-__global__ __launch_bounds__(64 * CTPF_GRID_LONG_W) void ctpf_estep_grid_long_kernel(CtpfParams p, int64_t first, const int* __restrict__ topic_of_lane)
+template <int LPR, int NPT, int NPR, int W>
+__global__ __launch_bounds__(64 * W) void ctpf_estep_grid_long_kernel(CtpfParams p, int64_t first, const int* __restrict__ topic_of_lane)
 {
-    ctpf_estep_grid_body<LPR, CTPF_GRID_LONG_NPT, CTPF_GRID_LONG_NPR, CTPF_GRID_LONG_W>(p, p.doc_order[first + blockIdx.x], topic_of_lane);
+    CTPF_GRID_LDS(W);
+    ctpf_estep_grid_body<LPR, NPT, NPR, W>(p, p.doc_order[first + blockIdx.x], topic_of_lane, ef_all, xch);
+}
+// single-wave class of a document (wave-uniform)
+template <int LPR, int BW>
+__device__ __forceinline__ void ctpf_estep_grid_any(const CtpfParams& p, const int d, const int* __restrict__ topic_of_lane,
+                                                   float (*ef_all)[2][4][16], float (*xch)[4][128])
+{
+    const int N = __builtin_amdgcn_readfirstlane((int)(p.doc_ptr[d + 1] - p.doc_ptr[d]));
+    const int Rd = __builtin_amdgcn_readfirstlane((int)(p.rdr_ptr[d + 1] - p.rdr_ptr[d]));
+    if (Rd > 32) ctpf_estep_grid_body<LPR, 4, 2, 1, BW>(p, d, topic_of_lane, ef_all, xch);
+    else if (N > 128) ctpf_estep_grid_body<LPR, 6, 1, 1, BW>(p, d, topic_of_lane, ef_all, xch);
+    else if (N > 96) ctpf_estep_grid_body<LPR, 4, 1, 1, BW>(p, d, topic_of_lane, ef_all, xch);
+    else if (N > 64) ctpf_estep_grid_body<LPR, 3, 1, 1, BW>(p, d, topic_of_lane, ef_all, xch);
+    else ctpf_estep_grid_body<LPR, 2, 1, 1, BW>(p, d, topic_of_lane, ef_all, xch);
 }
 // every single-wave class in one launch, the class read per document (wave-uniform): one kernel tail per iteration
 template <int LPR>
 __global__ __launch_bounds__(64) void ctpf_estep_grid_any_kernel(CtpfParams p, int64_t first, const int* __restrict__ topic_of_lane)
 {
-    const int d = p.doc_order[first + blockIdx.x];
-    const int N = __builtin_amdgcn_readfirstlane((int)(p.doc_ptr[d + 1] - p.doc_ptr[d]));
-    const int Rd = __builtin_amdgcn_readfirstlane((int)(p.rdr_ptr[d + 1] - p.rdr_ptr[d]));
-    if (Rd > 32) ctpf_estep_grid_body<LPR, 4, 2>(p, d, topic_of_lane);
-    else if (N > 128) ctpf_estep_grid_body<LPR, 6, 1>(p, d, topic_of_lane);
-    else if (N > 96) ctpf_estep_grid_body<LPR, 4, 1>(p, d, topic_of_lane);
-    else if (N > 64) ctpf_estep_grid_body<LPR, 3, 1>(p, d, topic_of_lane);
-    else ctpf_estep_grid_body<LPR, 2, 1>(p, d, topic_of_lane);
+    CTPF_GRID_LDS(1);
+    ctpf_estep_grid_any<LPR, 1>(p, p.doc_order[first + blockIdx.x], topic_of_lane, ef_all, xch);
 }
-
 template <int LPR>
 static void ctpf_launch_grid(const tmvb_bucket& b, dim3 grid, hipStream_t st, const CtpfParams& p, int64_t first, const int* tol)
 {
-    if (b.waves > 1) { hipLaunchKernelGGL((ctpf_estep_grid_long_kernel<LPR>), grid, dim3(64 * CTPF_GRID_LONG_W), 0, st, p, first, tol); return; }
+    if (b.waves == 4 && b.grid_np == 2) { hipLaunchKernelGGL((ctpf_estep_grid_long_kernel<LPR, 2, 4, 4>), grid, dim3(256), 0, st, p, first, tol); return; }
+    if (b.waves == 4) { hipLaunchKernelGGL((ctpf_estep_grid_long_kernel<LPR, 3, 3, 4>), grid, dim3(256), 0, st, p, first, tol); return; }
     if (b.grid_np == 99) { hipLaunchKernelGGL((ctpf_estep_grid_any_kernel<LPR>), grid, dim3(64), 0, st, p, first, tol); return; }
 #define CTPF_GRID_LAUNCH(T_, R_) if (b.grid_np == T_ && b.grid_np2 == R_) { hipLaunchKernelGGL((ctpf_estep_grid_kernel<LPR, T_, R_>), grid, dim3(64), 0, st, p, first, tol); return; }
     CTPF_GRID_CLASSES(CTPF_GRID_LAUNCH)
 #undef CTPF_GRID_LAUNCH
 }
-
 // shape update + table refresh:  X[id][i] = prior + stats[id][i];  T[id][i] = exp(psi(X));  stats <- 0
 // (update_alef!/update_he! src/CTPF.jl:251-255, :266-270: X <- X_temp, X_temp <- prior)
 __global__ __launch_bounds__(256) void ctpf_shape_kernel(float* __restrict__ stats, float prior, float* __restrict__ X,
@@ -768,6 +782,130 @@ __global__ __launch_bounds__(64) void ctpf_elbo_doc_kernel(int K, const int64_t*
     if (lane == 0) doc_val[d] = tot;
 }
 
+// ---- update_elbo!'s per-document part, fast form (round 3) ------------------------------------------------------------------
+// The kernel above spends its time on 2 K digammas per token and per reader (psi(alef_old), psi(alef) of the entry's row) and on
+// three wave reductions per entry.  Both go away with two per-call tables per shape matrix,
+//     To[id][i] = exp(psi(X_old[id][i])),    D[id][i] = psi(X[id][i]) - psi(X_old[id][i])       (ctpf_elbo_tables_kernel),
+// because an entry's contribution factors through per-document vectors Q (the softmax factors) and P:
+//     phi_in = To[t_n][i] e_i / s_n,  s_n = sum_i To[t_n][i] e_i,  e_i = exp(x_i - max x)
+//     c_n sum_i phi_in (lt_i + psi(alef[i,t_n]) - log bet_i - log phi_in) = c_n [ (sum_i To_i P_i + sum_i To_i D_i Q_i) / s_n + log s_n ]
+//     with Q_i = e_i, P_i = e_i (lt_i - log bet_i - x_i + max x); the readers the same with Q_i = ea_i + eb_i and
+//     P_i = ea_i (lt_i - log vav_i - a_i + m) + eb_i (le_i - log vav_i - b_i + m), m = max(a, b).
+// One wave per document: lane = topic for the per-document vectors (fp64, as above), then lane = token / reader for the entries:
+// two row reads, 3 K fmas, one reciprocal and one logarithm per entry.  sum_n lgamma(c_n + 1) + sum_u lgamma(r_u + 1) is a
+// per-document constant of the corpus (lg_doc, computed once on the host).
+__global__ __launch_bounds__(256) void ctpf_elbo_tables_kernel(const float* __restrict__ X, const float* __restrict__ X_old,
+                                                               float* __restrict__ To, float* __restrict__ D, int K, int KP, int64_t n_ids)
+{
+    const int64_t total = n_ids * KP;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t id = q / KP;
+        const int i = (int)(q - id * KP);
+        float to = 0.0f, dd = 0.0f;
+        if (i < K) {
+            const float po = digamma_f(X_old[id * K + i]);
+            to = expf(po);
+            dd = digamma_f(X[id * K + i]) - po;
+        }
+        To[q] = to; D[q] = dd;
+    }
+}
+
+// sum over the entries [0, n_ent) of one document of val[entry] * ((sum_i To_i P_i + sum_i To_i D_i Q_i) / s + log s), lane = entry
+__device__ __forceinline__ float ctpf_elbo_entries(const int* __restrict__ ids, const int* __restrict__ vals, const int n_ent,
+                                                   const float* __restrict__ To, const float* __restrict__ D, const int KP,
+                                                   const float* __restrict__ Ql, const float* __restrict__ Pl, const int lane)
+{
+    float acc = 0.0f;
+    const int lpr = KP >> 2;
+    for (int n0 = 0; n0 < n_ent; n0 += 64) {
+        const int n = n0 + lane;
+        const bool in = n < n_ent;
+        const int id = ids[in ? n : 0];
+        const float cv = in ? (float)vals[in ? n : 0] : 0.0f;
+        const float4* __restrict__ rt = (const float4*)(To + (int64_t)id * KP);
+        const float4* __restrict__ rd = (const float4*)(D + (int64_t)id * KP);
+        float s = 0.0f, u = 0.0f, w = 0.0f;
+#pragma unroll 4
+        for (int q = 0; q < lpr; ++q) {
+            const float4 t = rt[q], dd = rd[q];
+            const float4 qq = ((const float4*)Ql)[q], pp = ((const float4*)Pl)[q];
+            s = fmaf(t.x, qq.x, fmaf(t.y, qq.y, fmaf(t.z, qq.z, fmaf(t.w, qq.w, s))));
+            u = fmaf(t.x, pp.x, fmaf(t.y, pp.y, fmaf(t.z, pp.z, fmaf(t.w, pp.w, u))));
+            w = fmaf(t.x * dd.x, qq.x, fmaf(t.y * dd.y, qq.y, fmaf(t.z * dd.z, qq.z, fmaf(t.w * dd.w, qq.w, w))));
+        }
+        acc = fmaf(cv, (u + w) / s + logf(s), acc);       // s > 0: To > 0 and the largest factor of Q is 1
+    }
+    return acc;
+}
+
+template <int NS>
+__global__ __launch_bounds__(64) void ctpf_elbo_doc_fast_kernel(int K, int KP, const int64_t* __restrict__ doc_ptr, const int32_t* __restrict__ terms,
+                                                                const int32_t* __restrict__ counts, const int64_t* __restrict__ rdr_ptr,
+                                                                const int32_t* __restrict__ readers, const int32_t* __restrict__ ratings,
+                                                                const float* __restrict__ TAo, const float* __restrict__ DA,
+                                                                const float* __restrict__ THo, const float* __restrict__ DH,
+                                                                const double* __restrict__ rates /* [8][K] */, const double* __restrict__ rs_alef,
+                                                                const double* __restrict__ rs_he, const float* __restrict__ gimel,
+                                                                const float* __restrict__ gimel_old, const float* __restrict__ zayin,
+                                                                const float* __restrict__ zayin_old, const double* __restrict__ lg_doc,
+                                                                double hc, double hd, double hg, double hh, double* __restrict__ doc_val)
+{
+    __shared__ __attribute__((aligned(16))) float PQ[4][64 * NS + 8];  // Q1 | P1 | Q2 | P2, pads zero (KP = 4 * odd can exceed 64 NS by 4)
+    const int lane = threadIdx.x;
+    const int d = blockIdx.x;
+    double acc = 0.0;
+    double xo[NS], ao[NS], bo[NS], lt[NS], le[NS], lbet[NS], lvav[NS];
+    bool on[NS];
+    double mx = -INFINITY, mab = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        on[s] = lane + 64 * s < K;
+        const int i = on[s] ? lane + 64 * s : 0;
+        const double bet = rates[i], vav = rates[K + i], dalet = rates[2 * K + i], het = rates[3 * K + i];
+        const double bet_o = rates[4 * K + i], vav_o = rates[5 * K + i], dalet_o = rates[6 * K + i], het_o = rates[7 * K + i];
+        const double gi = on[s] ? (double)gimel[(int64_t)d * K + i] : 1.0, za = on[s] ? (double)zayin[(int64_t)d * K + i] : 1.0;
+        const double gio = on[s] ? (double)gimel_old[(int64_t)d * K + i] : 1.0, zao = on[s] ? (double)zayin_old[(int64_t)d * K + i] : 1.0;
+        const double dgo = digamma_d(gio);
+        xo[s] = dgo - log(dalet_o) - log(bet_o);           // softmax arguments rebuilt from the *_old variables (:240-241)
+        ao[s] = dgo - log(dalet_o) - log(vav_o);
+        bo[s] = digamma_d(zao) - log(het_o) - log(vav_o);
+        lt[s] = digamma_d(gi) - log(dalet);               // E[log theta]
+        le[s] = digamma_d(za) - log(het);                 // E[log epsilon]
+        lbet[s] = log(bet); lvav[s] = log(vav);
+        if (on[s]) {
+            mx = fmax(mx, xo[s]); mab = fmax(mab, fmax(ao[s], bo[s]));
+            acc -= gi / (dalet * vav) * rs_he[i] + za / (het * vav) * rs_he[i] + gi / (dalet * bet) * rs_alef[i];   // :112,:123,:134
+            acc += (hc - 1.0) * lt[s] - hd * gi / dalet;                          // Elogptheta :156
+            acc += (hg - 1.0) * le[s] - hh * za / het;                            // Elogpepsilon :174
+            acc += gamma_entropy_d(gi, dalet) + gamma_entropy_d(za, het);         // -Elogqtheta, -Elogqepsilon
+        }
+    }
+    mx = -wave_min_d(-mx); mab = -wave_min_d(-mab);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        float q1 = 0.f, p1 = 0.f, q2 = 0.f, p2 = 0.f;
+        if (on[s]) {
+            const double e = exp(xo[s] - mx), ea = exp(ao[s] - mab), eb = exp(bo[s] - mab);
+            q1 = (float)e; p1 = (float)(e * (lt[s] - lbet[s] - xo[s] + mx));
+            q2 = (float)(ea + eb);
+            p2 = (float)(ea * (lt[s] - lvav[s] - ao[s] + mab) + eb * (le[s] - lvav[s] - bo[s] + mab));
+        }
+        PQ[0][lane + 64 * s] = q1; PQ[1][lane + 64 * s] = p1; PQ[2][lane + 64 * s] = q2; PQ[3][lane + 64 * s] = p2;
+    }
+    if (lane < 8) { PQ[0][64 * NS + lane] = 0.f; PQ[1][64 * NS + lane] = 0.f; PQ[2][64 * NS + lane] = 0.f; PQ[3][64 * NS + lane] = 0.f; }
+    WAVE_LDS_FENCE();
+    const int64_t off = doc_ptr[d], roff = rdr_ptr[d];
+    const int N = (int)(doc_ptr[d + 1] - off), Rd = (int)(rdr_ptr[d + 1] - roff);
+    float ent = 0.0f;
+    if (N > 0) ent += ctpf_elbo_entries(terms + off, counts + off, N, TAo, DA, KP, PQ[0], PQ[1], lane);
+    if (Rd > 0) ent += ctpf_elbo_entries(readers + roff, ratings + roff, Rd, THo, DH, KP, PQ[2], PQ[3], lane);
+    acc += (double)ent;
+    double tot = wave_sum_d(acc);
+    tot += (double)K * (hc * log(hd) - lgamma(hc)) + (double)K * (hg * log(hh) - lgamma(hg)) - lg_doc[d];
+    if (lane == 0) doc_val[d] = tot;
+}
+
 // global part over the entries of a K x n shape matrix X with rate vector `rate`:
 //   sum [ (prior_shape - 1)(psi(x) - log rate_i) - prior_rate x / rate_i + entropy(Gamma(x, 1/rate_i)) ]
 // (Elogpbeta - Elogqbeta :144-150,:198-204 with (a, b, alef, bet); Elogpeta - Elogqeta :162-168,:216-222 with (e, f, he, vav))
@@ -826,11 +964,14 @@ struct tmvb_ctpf {
     float* d_ts_partial = nullptr; float* d_ts_partial2 = nullptr;   // multi-chunk partials of the term / reader statistics passes
     uint8_t* d_sweeps = nullptr; int32_t* d_doc_order = nullptr;
     double* d_doc_val = nullptr; double* d_elbo_partial = nullptr; double* d_elbo = nullptr;
+    // fast update_elbo!: per-call tables exp(psi(X_old)) / psi(X) - psi(X_old) of both shape matrices (allocated at the first call)
+    // and the per-document constants sum lgamma(count + 1) + sum lgamma(rating + 1)
+    float* d_TAo = nullptr; float* d_DA = nullptr; float* d_THo = nullptr; float* d_DH = nullptr; double* d_lg_doc = nullptr;
     double* d_partial = nullptr; double* d_partial2 = nullptr; double* d_rs_alef = nullptr; double* d_rs_he = nullptr; double* d_sum_g = nullptr; double* d_sum_z = nullptr;
     double elbo = 0.0;
     int* d_topic_of_lane = nullptr;     // register-tile kernel: topic owned by each lane after the reduce-scatter
     int* d_grid_topic_of_lane = nullptr;   // grid-tile kernel (tmvb_gridtile.h): the same for its 16-lane reduce-scatter
-    bool grid_path = false;             // KP <= 60: documents of <= 256 terms and <= 512 readers use ctpf_estep_grid_kernel
+    bool grid_path = false;             // KP <= 60: documents of <= 512 terms and <= 512 readers use ctpf_estep_grid_kernel
     bool reg_path = false;              // KP = 4 * odd <= 60: short documents (<= 128 terms, <= 64 readers) use ctpf_estep_reg_kernel
     std::vector<tmvb_bucket> buckets;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -857,6 +998,7 @@ extern "C" int tmvb_ctpf_destroy(tmvb_ctpf* h)
     (void)hipFree(h->d_E1); (void)hipFree(h->d_E2); (void)hipFree(h->d_ts_partial); (void)hipFree(h->d_ts_partial2); (void)hipFree(h->d_sweeps);
     (void)hipFree(h->d_doc_order); (void)hipFree(h->d_partial); (void)hipFree(h->d_partial2); (void)hipFree(h->d_rs_alef); (void)hipFree(h->d_rs_he);
     (void)hipFree(h->d_sum_g); (void)hipFree(h->d_sum_z); (void)hipFree(h->d_doc_val); (void)hipFree(h->d_elbo_partial); (void)hipFree(h->d_elbo);
+    (void)hipFree(h->d_TAo); (void)hipFree(h->d_DA); (void)hipFree(h->d_THo); (void)hipFree(h->d_DH); (void)hipFree(h->d_lg_doc);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -987,7 +1129,14 @@ extern "C" int tmvb_ctpf_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmv
     TMVB_HIP(hipEventCreate(&h->ev1));
     TMVB_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     for (int a = 0; a < tmvb_ctpf::NAUX; ++a) {
-        TMVB_HIP(hipStreamCreateWithFlags(&h->aux[a], hipStreamNonBlocking));
+        // aux[1] carries the few multi-wave (long) documents next to the chain's one big launch: at the default priority its 512-thread
+        // workgroups find no CU with eight free wave slots until the chain's launch drains and then add their whole run time to the
+        // E-step; on a high-priority queue they are placed first (TMVB_CTPF_LONG_PRIO=0: default priority)
+        static const bool long_prio = [] { const char* e = getenv("TMVB_CTPF_LONG_PRIO"); return !(e && atoi(e) == 0); }();
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        if (a == 1 && long_prio) TMVB_HIP(hipStreamCreateWithPriority(&h->aux[a], hipStreamNonBlocking, prio_hi));
+        else TMVB_HIP(hipStreamCreateWithFlags(&h->aux[a], hipStreamNonBlocking));
         TMVB_HIP(hipEventCreateWithFlags(&h->ev_join[a], hipEventDisableTiming));
     }
     TMVB_HIP(hipStreamSynchronize(ctx->stream));
@@ -1144,8 +1293,10 @@ extern "C" int tmvb_ctpf_estep(tmvb_ctpf* h, int32_t viter, double vtol)
         const tmvb_bucket& b = h->buckets[bi];
         dim3 grid((unsigned)b.count), block(64);
         if (b.grid_np > 0) {
-            // four-wave documents on aux[1] next to the chain; the single-wave classes back to back on the context's stream -- as ONE
-            // mixed-class launch unless TMVB_CTPF_GRID_ANY=0 (one kernel tail per iteration; the price is the widest body's registers)
+            // the multi-wave (long) documents on aux[1] next to the chain, the single-wave classes on the context's stream -- as ONE
+            // mixed-class launch unless TMVB_CTPF_GRID_ANY=0 (one kernel tail per iteration; the price is the widest body's registers).
+            // (Measured and dropped: everything in one launch of four-wave workgroups, long documents first and four single-wave
+            //  documents per later workgroup: 0.256 ms per iteration against 0.193 ms.)
             static const bool gany = [] { const char* e = getenv("TMVB_CTPF_GRID_ANY"); return !(e && atoi(e) == 0); }();
             hipStream_t st = b.waves > 1 ? h->aux[1] : chain_st;
             tmvb_bucket bb = b;
@@ -1344,7 +1495,42 @@ extern "C" int tmvb_ctpf_update_elbo_parts(tmvb_ctpf* h, double* doc_part, doubl
     TMVB_HIP(hipMemcpyAsync(&res[1], h->d_elbo, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     TMVB_HIP(hipStreamSynchronize(ctx->stream));
     // per-document part
-    if (h->M > 0) {
+    static const bool legacy_elbo = [] { const char* e = getenv("TMVB_CTPF_ELBO_LEGACY"); return e && atoi(e) != 0; }();
+    if (h->M > 0 && !legacy_elbo) {
+        if (!h->d_lg_doc) {                               // first call: tables and the corpus constants
+            const size_t na = (size_t)h->V * h->KP + 4, nh = (size_t)std::max<int64_t>(h->U, 1) * h->KP + 4;
+            if ((rc = dmalloc(&h->d_TAo, na)) || (rc = dmalloc(&h->d_DA, na)) || (rc = dmalloc(&h->d_THo, nh)) || (rc = dmalloc(&h->d_DH, nh)) ||
+                (rc = dmalloc(&h->d_lg_doc, (size_t)h->M))) return rc;
+            std::vector<double> lg((size_t)h->M, 0.0);
+            const tmvb_corpus* c = h->corp;
+            for (int64_t d = 0; d < h->M; ++d) {
+                double v = 0.0;
+                for (int64_t q = c->h_doc_ptr[d]; q < c->h_doc_ptr[d + 1]; ++q) v += std::lgamma((double)c->h_counts[q] + 1.0);
+                for (int64_t q = c->h_rdr_ptr[d]; q < c->h_rdr_ptr[d + 1]; ++q) v += std::lgamma((double)c->h_ratings[q] + 1.0);
+                lg[(size_t)d] = v;
+            }
+            TMVB_HIP(hipMemcpyAsync(h->d_lg_doc, lg.data(), lg.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+            TMVB_HIP(hipStreamSynchronize(ctx->stream));
+        }
+        int nbt = (int)std::min<int64_t>(2048, std::max<int64_t>(1, ((int64_t)h->KP * h->V + 255) / 256));
+        hipLaunchKernelGGL(ctpf_elbo_tables_kernel, dim3(nbt), dim3(256), 0, ctx->stream, h->d_alef, h->d_alef_old, h->d_TAo, h->d_DA, h->K, h->KP, h->V);
+        if (h->U > 0) {
+            nbt = (int)std::min<int64_t>(2048, std::max<int64_t>(1, ((int64_t)h->KP * h->U + 255) / 256));
+            hipLaunchKernelGGL(ctpf_elbo_tables_kernel, dim3(nbt), dim3(256), 0, ctx->stream, h->d_he, h->d_he_old, h->d_THo, h->d_DH, h->K, h->KP, h->U);
+        }
+        TMVB_HIP(hipGetLastError());
+        if (h->nslot == 1)
+            hipLaunchKernelGGL((ctpf_elbo_doc_fast_kernel<1>), dim3((unsigned)h->M), dim3(64), 0, ctx->stream, h->K, h->KP, h->corp->d_doc_ptr, h->corp->d_terms,
+                               h->corp->d_counts, h->corp->d_rdr_ptr, h->corp->d_readers, h->corp->d_ratings, h->d_TAo, h->d_DA, h->d_THo, h->d_DH,
+                               h->d_rates, h->d_rs_alef, h->d_rs_he, h->d_gimel, h->d_gimel_old, h->d_zayin, h->d_zayin_old, h->d_lg_doc,
+                               hy[2], hy[3], hy[6], hy[7], h->d_doc_val);
+        else
+            hipLaunchKernelGGL((ctpf_elbo_doc_fast_kernel<2>), dim3((unsigned)h->M), dim3(64), 0, ctx->stream, h->K, h->KP, h->corp->d_doc_ptr, h->corp->d_terms,
+                               h->corp->d_counts, h->corp->d_rdr_ptr, h->corp->d_readers, h->corp->d_ratings, h->d_TAo, h->d_DA, h->d_THo, h->d_DH,
+                               h->d_rates, h->d_rs_alef, h->d_rs_he, h->d_gimel, h->d_gimel_old, h->d_zayin, h->d_zayin_old, h->d_lg_doc,
+                               hy[2], hy[3], hy[6], hy[7], h->d_doc_val);
+        TMVB_HIP(hipGetLastError());
+    } else if (h->M > 0) {
         if (h->nslot == 1)
             hipLaunchKernelGGL((ctpf_elbo_doc_kernel<1>), dim3((unsigned)h->M), dim3(64), 0, ctx->stream, h->K, h->corp->d_doc_ptr, h->corp->d_terms,
                                h->corp->d_counts, h->corp->d_rdr_ptr, h->corp->d_readers, h->corp->d_ratings, h->d_alef, h->d_alef_old, h->d_he,
