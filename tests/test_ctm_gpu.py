@@ -298,6 +298,39 @@ def test_lane_per_document_kernel_matches_wave_per_document_kernel(tmvb, monkeyp
         gb.update_buffer()
 
 
+def test_one_long_document_does_not_evict_the_corpus_from_the_lane_kernel(tmvb, monkeypatch):
+    """A lane of the lane-per-document kernel walks its document's tokens one after the other, so documents of more than 2048
+    unique terms keep the wave-per-document kernel -- those documents only (round 2 sent the whole corpus there: a 4.5x cliff
+    for one outlier).  Corpus: 640 ordinary documents + one of 3000 and one of 2500 unique terms.  The lane kernel must have run
+    on the 640 (solver_stats), and every document -- the two long ones included -- must agree with the all-wave-kernel run."""
+    rng = np.random.default_rng(5)
+    V, K = 4000, 20
+    docs = [(np.sort(rng.choice(V, size=int(rng.integers(5, 120)), replace=False)), None) for _ in range(640)]
+    docs.insert(100, (np.sort(rng.choice(V, size=3000, replace=False)), None))
+    docs.insert(400, (np.sort(rng.choice(V, size=2500, replace=False)), None))
+    docs = [(t, rng.integers(1, 4, size=len(t))) for t, _ in docs]
+    doc_ptr = np.concatenate([[0], np.cumsum([len(t) for t, _ in docs])]).astype(np.int64)
+    terms = np.concatenate([t for t, _ in docs]).astype(np.int32); counts = np.concatenate([c for _, c in docs]).astype(np.int32)
+    pc = tmvb.PackedCorpus(doc_ptr, terms, counts, V)
+    gw, gb = _pair(tmvb, pc, K, monkeypatch)
+    for it in range(2):
+        gw.estep(); gb.estep()
+        st = gb.solver_stats()
+        assert st["waves"] == (640 + 63) // 64 and st["cg_trips"] > 0, st          # the lane kernel ran, on the 640 documents
+        assert gw.solver_stats()["waves"] == 0
+        for g in (gw, gb):
+            g.reduce_docs(); g.update_beta(); g.update_sigma(); g.update_mu(); g.update_host()
+        assert np.all(gb.doc_sweeps() > 0)
+        assert (gw.doc_sweeps() != gb.doc_sweeps()).mean() <= 0.02
+        # the long documents ran the same kernel on the same state (another LDS window per bucket: not the same summation order)
+        assert np.abs(gw.lam[:, [100, 401]] - gb.lam[:, [100, 401]]).max() <= 2e-5
+        assert np.abs(gw.lam - gb.lam).max() <= 1e-3
+        assert np.abs(gw.mu - gb.mu).max() <= 1e-4 and np.abs(gw.sigma - gb.sigma).max() <= 1e-4 * np.abs(gw.sigma).max()
+        for n in ("mu", "sigma", "invsigma", "beta", "beta_old", "lam", "lam_old", "vsq", "logzeta"):
+            v = getattr(gw, n); setattr(gb, n, v.copy(order="F") if v.ndim > 1 else v.copy())
+        gb.update_buffer()
+
+
 def test_lane_per_document_kernel_viter_zero_and_fixed_sweeps(tmvb, monkeypatch):
     pc = tmvb.syn_nsf(M=300, V=400, seed=9)
     gw, gb = _pair(tmvb, pc, 12, monkeypatch)

@@ -456,6 +456,7 @@ __global__ __launch_bounds__(64) void ctm_batch_tabs_kernel(int K, int KP, const
 // lengths -- the documents are sorted by last iteration's step count, descending, stable (bitonic sort of key << 16 | rank
 // in LDS, one workgroup per chunk).
 #define CTM_REORDER_CHUNK 2048
+#define CTM_BATCH_MAX_LEN 2048     // unique terms per document the lane-per-document kernel takes
 __global__ __launch_bounds__(1024) void ctm_reorder_kernel(const int32_t* __restrict__ order0, const uint16_t* __restrict__ key,
                                                            int32_t* __restrict__ order, int64_t M)
 {
@@ -1059,6 +1060,8 @@ struct tmvb_ctm {
     float* d_wtok = nullptr; float* d_E = nullptr; float* d_ts_partial = nullptr;
     float* d_invsigma_f = nullptr; float* d_mu_f = nullptr;
     bool batch = false;                // lane-per-document kernel (tmvb_ctm_batch.h), KP <= 52
+    int64_t n_long = 0;                // ... except the first n_long documents of the processing order (> CTM_BATCH_MAX_LEN unique terms each):
+                                       // a lane walks its document's tokens one after the other, so those keep the wave-per-document kernel
     bool reorder = false, keys_valid = false;      // regroup its documents by last E-step's Newton step counts (ctm_reorder_kernel)
     uint16_t* d_doc_newton = nullptr; int32_t* d_doc_order0 = nullptr;
     float* d_bt_sdiag = nullptr; float* d_bt_muf = nullptr; unsigned long long* d_cg_iters = nullptr;
@@ -1170,10 +1173,11 @@ extern "C" int tmvb_ctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
     {
         // lane-per-document kernel: the default for KP <= 52 (K <= 50); TMVB_CTM_BATCH=0 selects the wave-per-document kernels
         const char* e = getenv("TMVB_CTM_BATCH");
-        // (a lane walks its document's tokens one after the other: corpora with documents of thousands of unique terms would
-        // serialise on them, so those keep the wave-per-document kernel, which spreads a document's tokens over the lanes)
+        // (a lane walks its document's tokens one after the other: documents of thousands of unique terms would serialise their wave
+        // on them, so THOSE documents -- not the corpus: round 2 sent every document of a corpus with one such document there -- keep
+        // the wave-per-document kernel, which spreads a document's tokens over the lanes; h->n_long below)
         // (its token phase addresses the token arrays and the topic table with unsigned 32-bit byte offsets)
-        h->batch = !h->generic && h->KP <= 52 && corp->info.max_doc_len <= 2048 && corp->info.nnz < (1ll << 30) && (int64_t)h->KP * h->V < (1ll << 30) && h->V < (1 << 24) &&
+        h->batch = !h->generic && h->KP <= 52 && corp->info.nnz < (1ll << 30) && (int64_t)h->KP * h->V < (1ll << 30) && h->V < (1 << 24) &&
                    !(e && atoi(e) == 0);
         if (const char* t = getenv("TMVB_CTM_CG_TOL")) h->cg_tol = std::max(1e-7f, (float)atof(t));
         if (const char* t = getenv("TMVB_CTM_CG_ABS")) h->cg_abs = std::max(0.0f, (float)atof(t));
@@ -1188,6 +1192,8 @@ extern "C" int tmvb_ctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
     std::iota(order.begin(), order.end(), 0);
     const std::vector<int64_t>& len = corp->h_doc_len;
     std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return len[x] > len[y]; });
+    h->n_long = 0;
+    if (h->batch) while (h->n_long < h->M && len[order[(size_t)h->n_long]] > CTM_BATCH_MAX_LEN) ++h->n_long;
     {
         // The resident topic tile decides the waves per CU of the Newton-bound kernel (K = 50: a 96-row tile is 21 KB,
         // 7 waves per CU), and the Newton steps -- 97 % of the kernel -- never touch it.  A 32-row window (8 KB) that
@@ -1196,7 +1202,7 @@ extern "C" int tmvb_ctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
         // 6.03 / 5.94 ms).  TMVB_CTM_MAX_TILE_KB overrides.
         size_t cap = 8 * 1024;
         if (const char* e = getenv("TMVB_CTM_MAX_TILE_KB")) cap = std::max<size_t>(4, (size_t)atoi(e)) * 1024;
-        tmvb_build_lds_buckets(len, order, h->M, h->KP, -1, 3, h->buckets, cap);
+        tmvb_build_lds_buckets(len, order, h->batch ? h->n_long : h->M, h->KP, -1, 3, h->buckets, cap);   // batch: the long documents only
     }
     if (h->M) TMVB_HIP(hipMemcpyAsync(h->d_doc_order, order.data(), (size_t)h->M * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     if (h->M) TMVB_HIP(hipMemcpyAsync(h->d_doc_order0, order.data(), (size_t)h->M * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
@@ -1329,16 +1335,18 @@ static int ctm_launch_batch(tmvb_ctm* h, const CtmParams& p, double ntol)
     tb.S = h->d_invsigma_f; tb.sdiag = h->d_bt_sdiag; tb.muf = h->d_bt_muf;
     tb.cg_tol2 = h->cg_tol * h->cg_tol; tb.cg_maxit = 4 * h->KP; tb.cg_iters = h->d_cg_iters;
     { const double fl = h->cg_abs * std::min(ntol, 4e-4); tb.cg_abs2 = (float)(fl * fl); }   // never looser than at the reference K = 50 (ntol = 1/K^2)
-    const dim3 grid((unsigned)((h->M + 63) / 64)), block(64);
+    const int64_t Mb = h->M - h->n_long;                 // the documents behind the long ones in the processing order
+    if (Mb <= 0) return TMVB_OK;
+    const dim3 grid((unsigned)((Mb + 63) / 64)), block(64);
     const size_t lds = (size_t)h->KP * 64 * (sizeof(double) + sizeof(float)) + 64 * sizeof(int32_t);   // vsq, CG solution / row staging, row ids
     if (h->reorder && h->keys_valid) {
-        hipLaunchKernelGGL(ctm_reorder_kernel, dim3((unsigned)((h->M + CTM_REORDER_CHUNK - 1) / CTM_REORDER_CHUNK)), dim3(1024), 0, ctx->stream,
-                           h->d_doc_order0, h->d_doc_newton, h->d_doc_order, (int64_t)h->M);
+        hipLaunchKernelGGL(ctm_reorder_kernel, dim3((unsigned)((Mb + CTM_REORDER_CHUNK - 1) / CTM_REORDER_CHUNK)), dim3(1024), 0, ctx->stream,
+                           h->d_doc_order0 + h->n_long, h->d_doc_newton, h->d_doc_order + h->n_long, Mb);
         TMVB_HIP(hipGetLastError());
     }
     h->keys_valid = true;
     CtmBatchArgs ba;
-    ba.p = p; ba.p.doc_newton = h->d_doc_newton; ba.tb = tb; ba.M = (int64_t)h->M;
+    ba.p = p; ba.p.doc_order = p.doc_order + h->n_long; ba.p.doc_newton = h->d_doc_newton; ba.tb = tb; ba.M = Mb;
     static const bool prof = [] { const char* e = getenv("TMVB_CTM_PROF"); return e && atoi(e) != 0; }();
 #define CTM_BCASE(KPV) case KPV: hipLaunchKernelGGL((ctm_estep_batch_kernel<KPV, false, FILT>), grid, block, lds, ctx->stream, ba); break;
     if (prof && h->KP == 52) hipLaunchKernelGGL((ctm_estep_batch_kernel<52, true, FILT>), grid, block, lds, ctx->stream, ba);
@@ -1379,19 +1387,17 @@ extern "C" int tmvb_ctm_estep(tmvb_ctm* h, int32_t niter, double ntol, int32_t v
         if (lrc) return lrc;
         TMVB_HIP(hipGetLastError());
     }
-    if (h->batch && h->M > 0) {
-        int brc = ctm_launch_batch<false>(h, p, ntol);
-        if (brc) return brc;
-    }
-    const int nb = (h->generic || h->batch) ? 0 : (int)h->buckets.size();
-    const int naux = std::min(nb, (int)tmvb_ctm::NAUX);
-    if (naux > 1) {
+    // buckets of the wave-per-document kernel: every document (no lane-per-document kernel for this K) or the long ones next to the
+    // lane-per-document launch; on auxiliary streams whenever something else runs beside them
+    const int nb = h->generic ? 0 : (int)h->buckets.size();
+    const int naux = (nb > 1 || (nb > 0 && h->batch)) ? std::min(std::max(nb, 1), (int)tmvb_ctm::NAUX) : 0;
+    if (naux > 0) {
         TMVB_HIP(hipEventRecord(h->ev_fork, ctx->stream));
         for (int a = 0; a < naux; ++a) TMVB_HIP(hipStreamWaitEvent(h->aux[a], h->ev_fork, 0));
     }
     for (int bi = 0; bi < nb; ++bi) {
         const tmvb_bucket& b = h->buckets[bi];
-        hipStream_t st = (naux > 1) ? h->aux[bi % naux] : ctx->stream;
+        hipStream_t st = (naux > 0) ? h->aux[bi % naux] : ctx->stream;
         const size_t lds = tmvb_tile_bytes(b.tile_rows, h->KP);
         const dim3 grid((unsigned)b.count), block(64);
 #define CTM_CASE(KPV) case KPV: hipLaunchKernelGGL((ctm_estep_kernel<KPV, false>), grid, block, lds, st, p, b.first, b.tile_rows); break;
@@ -1401,7 +1407,11 @@ extern "C" int tmvb_ctm_estep(tmvb_ctm* h, int32_t niter, double ntol, int32_t v
 #undef CTM_CASE
         TMVB_HIP(hipGetLastError());
     }
-    if (naux > 1) {
+    if (h->batch && h->M > 0) {
+        int brc = ctm_launch_batch<false>(h, p, ntol);
+        if (brc) return brc;
+    }
+    if (naux > 0) {
         for (int a = 0; a < naux; ++a) {
             TMVB_HIP(hipEventRecord(h->ev_join[a], h->aux[a]));
             TMVB_HIP(hipStreamWaitEvent(ctx->stream, h->ev_join[a], 0));
@@ -1909,9 +1919,9 @@ extern "C" int tmvb_fctm_estep(tmvb_fctm* h, int32_t niter, double ntol, int32_t
         int lrc = (b->KP > 64) ? launch(ctm_estep_generic_kernel<2, true>) : launch(ctm_estep_generic_kernel<1, true>);
         if (lrc) return lrc;
         TMVB_HIP(hipGetLastError());
-    } else if (b->batch) {
-        if (b->M > 0) { int brc = ctm_launch_batch<true>(b, p, ntol); if (brc) return brc; }
     } else {
+        // lane-per-document kernel for all but the long documents (b->n_long; the buckets then hold only those), else every bucket
+        if (b->batch && b->M > 0) { int brc = ctm_launch_batch<true>(b, p, ntol); if (brc) return brc; }
         for (const tmvb_bucket& bk : b->buckets) {
             const size_t lds = ctm_tile_bytes(bk.tile_rows, b->KP, true);
             const dim3 grid((unsigned)bk.count), block(64);
