@@ -1602,9 +1602,10 @@ extern "C" int tmvb_lda_update_alpha(tmvb_lda* h, int32_t niter, double ntol)
     return TMVB_OK;
 }
 
-extern "C" int tmvb_lda_update_elbo(tmvb_lda* h, double* elbo)
+// update_elbo! enqueued on the context's stream: the value (this shard's share, for a sharded handle) is left in h->d_elbo, no host
+// synchronisation -- the sharded train loop all-reduces it where it lies (tmvb_train.h)
+static int lda_elbo_enqueue(tmvb_lda* h)
 {
-    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_lda_update_elbo: handle is NULL");
     h->mark_valid = false;
     tmvb_ctx* ctx = h->ctx;
     TMVB_HIP(hipSetDevice(ctx->device));
@@ -1643,6 +1644,15 @@ extern "C" int tmvb_lda_update_elbo(tmvb_lda* h, double* elbo)
                        use_pw ? h->d_pw_partial : (const double*)nullptr, h->pw_blocks,
                        h->distributed && h->M_total > 0 ? (double)h->M / (double)h->M_total : 1.0);
     TMVB_HIP(hipGetLastError());
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_lda_update_elbo(tmvb_lda* h, double* elbo)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_lda_update_elbo: handle is NULL");
+    int rc = lda_elbo_enqueue(h);
+    if (rc) return rc;
+    tmvb_ctx* ctx = h->ctx;
     double v = 0.0;
     TMVB_HIP(hipMemcpyAsync(&v, h->d_elbo, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     TMVB_HIP(hipStreamSynchronize(ctx->stream));
@@ -1670,6 +1680,7 @@ struct LdaTrainOps {
     int64_t stats_len(tmvb_lda* h) { return (int64_t)h->K * h->V + h->K; }
     int mstep(tmvb_lda* h) { int rc = tmvb_lda_update_beta(h); return rc ? rc : tmvb_lda_update_alpha(h, niter, ntol); }   // :181-182
     int elbo_local(tmvb_lda* h, double* s, double* once) { *once = 0.0; return tmvb_lda_update_elbo(h, s); }
+    int elbo_enqueue(tmvb_lda* h, double* once) { *once = 0.0; TMVB_HIP(hipSetDevice(h->ctx->device)); return lda_elbo_enqueue(h); }   // -> elbo_dev(h), no sync
     double* elbo_dev(tmvb_lda* h) { return h->d_elbo; }
     tmvb_comm* comm(tmvb_lda* h) { return h->comm; }
     bool distributed(tmvb_lda* h) { return h->distributed; }

@@ -10,6 +10,9 @@
 #pragma once
 #include "tmvb_internal.h"
 
+#include <type_traits>
+#include <utility>
+
 // Ops (per model):
 //   int      estep(H*)                      E-step sweeps + per-document statistics, asynchronous
 //   int      reduce(H*)                     per-document sums into the statistics tail
@@ -52,9 +55,45 @@ static int tmvb_group_sum_f64(H* const* hs, int n, Ops& ops, double local_sum, d
     return TMVB_OK;
 }
 
+// Ops may also offer  int elbo_enqueue(H*, double* once): update_elbo! enqueued on the context's stream, the summable part left in
+// elbo_dev(h), no host synchronisation.  A sharded check then costs one collective on the stream and ONE synchronisation (the
+// 8-byte read-back) instead of three (read-back of the local value, upload of it, read-back of the sum).
+template <class Ops, class H, class = void> struct tmvb_has_elbo_enqueue : std::false_type {};
+template <class Ops, class H>
+struct tmvb_has_elbo_enqueue<Ops, H, std::void_t<decltype(std::declval<Ops&>().elbo_enqueue((H*)nullptr, (double*)nullptr))>> : std::true_type {};
+
 template <class H, class Ops>
 static int tmvb_group_elbo(H* const* hs, int n, Ops& ops, double* out)
 {
+    if constexpr (tmvb_has_elbo_enqueue<Ops, H>::value) {
+        if (ops.comm(hs[0])) {
+            double once = 0.0;
+            std::vector<tmvb_comm*> comms(n);
+            std::vector<void*> ptrs(n);
+            std::vector<int64_t> counts(n, 1);
+            for (int i = 0; i < n; ++i) {
+                double g = 0.0;
+                int rc = ops.elbo_enqueue(hs[i], &g);
+                if (rc) return rc;
+                once = g;
+                comms[i] = ops.comm(hs[i]); ptrs[i] = ops.elbo_dev(hs[i]);
+            }
+            int rc = tmvb_comm_allreduce_group(comms.data(), ptrs.data(), counts.data(), n, TMVB_F64);   // every handle carries its own share
+            if (rc) return rc;
+            tmvb_ctx* c0 = ops.ctx(hs[0]);
+            TMVB_HIP(hipSetDevice(c0->device));
+            double v = 0.0;
+            TMVB_HIP(hipMemcpyAsync(&v, ops.elbo_dev(hs[0]), sizeof(double), hipMemcpyDeviceToHost, c0->stream));
+            TMVB_HIP(hipStreamSynchronize(c0->stream));
+            for (int i = 1; i < n; ++i) {
+                TMVB_HIP(hipSetDevice(ops.ctx(hs[i])->device));
+                TMVB_HIP(hipStreamSynchronize(ops.ctx(hs[i])->stream));
+            }
+            *out = v + once;
+            for (int i = 0; i < n; ++i) ops.set_elbo(hs[i], *out);
+            return TMVB_OK;
+        }
+    }
     double sum = 0.0, once = 0.0;
     for (int i = 0; i < n; ++i) {
         double s = 0.0, g = 0.0;
