@@ -55,7 +55,7 @@ def mstep_bytes(K, V):
     return 12 * K * V
 
 
-LDA_KERNEL_SOURCES = ("tmvb_lda.hip", "tmvb_termstats.h", "tmvb_common_kernels.h", "tmvb_internal.h", "tmvb_regtile.h")
+LDA_KERNEL_SOURCES = ("tmvb_lda.hip", "tmvb_gridtile.h", "tmvb_termstats.h", "tmvb_common_kernels.h", "tmvb_internal.h", "tmvb_regtile.h")
 
 
 def kernel_source_hash():
@@ -73,7 +73,7 @@ def pmc_traffic(K, M, nnz):
     passes of this same command, tools/pmc_summary.py), corrected as MI355X_MICROARCH.md's HBM section prescribes for
     gfx950 (2 x FETCH_SIZE; KB units).  Returned only when the summary was collected on this workload AND on the kernel
     sources this run is built from (source hash stamped into the summary); otherwise null with the reason."""
-    for name in ("r2_lda_k50_pmc.json", "r1_lda_k50_pmc.json"):
+    for name in ("r3_lda_k50_pmc.json", "r2_lda_k50_pmc.json", "r1_lda_k50_pmc.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             break
@@ -351,7 +351,7 @@ def main():
                        "parallelism": f"doc-shard x{world}, 1 all-reduce of {K * V + K} f32 per iteration" if world > 1 else "single GPU",
                        "collective": collective,
                        "sweep_hist_last_step": sweep_hist},
-            "roofline": {"bound": "hbm", "kernel": "LDA E-step = the per-document register-tile / LDS-tile sweep kernels (lda_estep_reg*_kernel, lda_estep_kernel) over the document pieces + the gather-side statistics passes (termstats_recompute_kernel, termstats_multi_kernel) of every piece; one 'launch' = one E-step, timed start-to-end with HIP events on the context stream",
+            "roofline": {"bound": "hbm", "kernel": "LDA E-step = the per-document grid-tile sweep kernels (lda_estep_grid_kernel<LPR, NP>, lda_estep_grid_long_kernel; lda_estep_reg_long_kernel / lda_estep_kernel for documents of more than 768 unique terms) over the document pieces + the gather-side statistics passes (termstats_recompute_kernel, termstats_multi_kernel) of every piece; one 'launch' = one E-step, timed start-to-end with HIP events on the context stream",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel_source_hash": kernel_source_hash(),
                          "algorithmic_bytes_per_estep": b_e, "estep_ms": ms,
@@ -422,13 +422,22 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import model_bench
             others = {}
-            for name in ("lda100", "ctm", "ctpf"):
+            for name in ("lda100", "ctm", "ctpf"):             # the GPU windows first, back to back (the clocks stay up) ...
                 t_c = time.perf_counter()
                 try:
-                    others[name] = model_bench.ALL[name](cpu=not args.no_cpu_baseline)
+                    others[name] = model_bench.ALL[name](cpu=False)
                 except Exception as e:                       # a failing side line must not cost the headline
                     others[name] = {"error": f"{type(e).__name__}: {e}"}
-                log(f"other_configs[{name}] done in {time.perf_counter() - t_c:.1f}s")
+                log(f"other_configs[{name}] GPU window done in {time.perf_counter() - t_c:.1f}s")
+            for name in ("lda100", "ctm", "ctpf"):             # ... then their CPU baselines
+                if args.no_cpu_baseline or "error" in others[name]:
+                    continue
+                t_c = time.perf_counter()
+                try:
+                    others[name]["cpu_baseline"] = model_bench.CPU[name]()
+                except Exception as e:
+                    others[name]["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+                log(f"other_configs[{name}] cpu_baseline done in {time.perf_counter() - t_c:.1f}s")
             result["other_configs"] = others
         print(json.dumps(result), flush=True)
     if world > 1:

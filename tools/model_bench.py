@@ -83,14 +83,22 @@ def lda100(burnin=60, warmup=3, steps=20, cpu=True):
                          "algorithmic_bytes_per_iteration": B, "traffic": None}}
     gm.close()
     if cpu:
-        from oracle import oracle as oc
-
-        def ostep(m, nt):
-            m.estep(omp_threads=nt); m.update_beta(); m.update_alpha()
-        line["cpu_baseline"] = cpu_line("port of src/LDA.jl train!", lambda: oc.LDA(oc.CSR(pc.doc_ptr, pc.terms, pc.counts, pc.V), K, beta0), ostep,
-                                        1.0, f"FULL SYN-NSF ({pc.M} documents, {pc.nnz} nnz), K=100", warm=1, timed=1, full=True)
-        oc.lib().orc_omp_pool_free()
+        line["cpu_baseline"] = lda100_cpu(pc)
     return line
+
+
+def lda100_cpu(pc=None):
+    from oracle import oracle as oc
+    K = 100
+    pc = pc or tm.syn_nsf()
+    beta0 = tm.dirichlet_rows(K, pc.V, seed=7)
+
+    def ostep(m, nt):
+        m.estep(omp_threads=nt); m.update_beta(); m.update_alpha()
+    out = cpu_line("port of src/LDA.jl train!", lambda: oc.LDA(oc.CSR(pc.doc_ptr, pc.terms, pc.counts, pc.V), K, beta0), ostep,
+                   1.0, f"FULL SYN-NSF ({pc.M} documents, {pc.nnz} nnz), K=100", warm=1, timed=1, full=True)
+    oc.lib().orc_omp_pool_free()
+    return out
 
 
 def ctm(burnin=30, warmup=2, steps=8, cpu=True):
@@ -134,24 +142,31 @@ def ctm(burnin=30, warmup=2, steps=8, cpu=True):
                          "hbm_GBs": B / sec / 1e9, "hbm_frac": B / sec / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_iteration": B, "traffic": None}}
     gm.close()
     if cpu:
-        from oracle import oracle as oc
-
-        def ostep(m, nt):
-            m.estep(omp_threads=nt); m.update_beta(); m.update_sigma_mu()
-        line["cpu_baseline"] = cpu_line("port of src/CTM.jl train!", lambda: oc.CTM(oc.CSR(pc.doc_ptr, pc.terms, pc.counts, pc.V), K, beta0), ostep,
-                                        1.0, f"FULL SYN-NSF ({pc.M} documents), K=50; one iteration takes ~10 s, so no warm-up iteration", warm=0, timed=1, full=True)
+        line["cpu_baseline"] = ctm_cpu(pc)
     return line
 
 
-def ctpf(burnin=60, warmup=5, steps=50, cpu=True):
+def ctm_cpu(pc=None):
+    from oracle import oracle as oc
+    K = 50
+    pc = pc or tm.syn_nsf()
+    beta0 = tm.dirichlet_rows(K, pc.V, seed=7)
+
+    def ostep(m, nt):
+        m.estep(omp_threads=nt); m.update_beta(); m.update_sigma_mu()
+    return cpu_line("port of src/CTM.jl train!", lambda: oc.CTM(oc.CSR(pc.doc_ptr, pc.terms, pc.counts, pc.V), K, beta0), ostep,
+                    1.0, f"FULL SYN-NSF ({pc.M} documents), K=50; one iteration takes ~10 s, so no warm-up iteration", warm=0, timed=1, full=True)
+
+
+def ctpf(burnin=300, warmup=10, steps=200, cpu=True):
     K = 50
     pc = tm.syn_citeu()
     gm = tm.gpuCTPF(pc, K)
 
     def it():
         gm.estep(); gm.reduce_docs(); gm.mstep()
-    cold = window(it, gm.synchronize, 0, warmup, steps)
-    sec = window(it, gm.synchronize, max(burnin - warmup - steps, 0), warmup, steps)
+    cold = window(it, gm.synchronize, 0, 5, 50)
+    sec = window(it, gm.synchronize, max(burnin - 55 - warmup - steps, 0), warmup, steps)
     es_ms = gm.last_estep_ms()
     hist = gm.sweep_hist().tolist()
     # a checked iteration (update_elbo! on the device after every M-step); the first call builds the per-document constants
@@ -167,21 +182,27 @@ def ctpf(burnin=60, warmup=5, steps=50, cpu=True):
             "config": {"workload": f"CTPF K=50, SYN-CITEU with readers, train! defaults (viter=10 vtol=1/K^2 checkelbo=Inf), steady state: {burnin} untimed "
                                    f"iterations from the cold start, then {warmup} warm-up + {steps} timed",
                        "M": pc.M, "V": pc.V, "U": pc.U, "nnz": pc.nnz, "nR": pc.nR, "sweep_hist_last_step": hist},
-            "cold_start": {"value": 1.0 / cold, "ms_per_step": 1e3 * cold, "window": f"iterations {warmup + 1}..{warmup + steps} from the cold start"},
+            "cold_start": {"value": 1.0 / cold, "ms_per_step": 1e3 * cold, "window": "iterations 6..55 from the cold start"},
             "roofline": {"bound": "hbm", "achieved": B / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": B / sec / 1e9 / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_iteration": B, "traffic": None},
             "recommend": {"ms_scores": ms_s, "ms_rank": ms_r, "pairs": pc.M * pc.U}}
     gm.close()
     if cpu:
-        from oracle import oracle as oc
-        alef0 = np.exp(tm.dirichlet_rows(K, pc.V, seed=7) - 0.5)
-
-        def ostep(m, nt):
-            m.estep(omp_threads=nt); m.mstep()
-        line["cpu_baseline"] = cpu_line("port of src/CTPF.jl train!",
-                                        lambda: oc.CTPF(oc.CSR(pc.doc_ptr, pc.terms, pc.counts, pc.V, pc.rdr_ptr, pc.readers, pc.ratings, pc.U), K, alef0),
-                                        ostep, 1.0, f"FULL SYN-CITEU ({pc.M} documents, {pc.nnz} term + {pc.nR} reader entries), K=50", warm=1, timed=2, full=True)
+        line["cpu_baseline"] = ctpf_cpu(pc)
     return line
+
+
+def ctpf_cpu(pc=None):
+    from oracle import oracle as oc
+    K = 50
+    pc = pc or tm.syn_citeu()
+    alef0 = np.exp(tm.dirichlet_rows(K, pc.V, seed=7) - 0.5)
+
+    def ostep(m, nt):
+        m.estep(omp_threads=nt); m.mstep()
+    return cpu_line("port of src/CTPF.jl train!",
+                    lambda: oc.CTPF(oc.CSR(pc.doc_ptr, pc.terms, pc.counts, pc.V, pc.rdr_ptr, pc.readers, pc.ratings, pc.U), K, alef0),
+                    ostep, 1.0, f"FULL SYN-CITEU ({pc.M} documents, {pc.nnz} term + {pc.nR} reader entries), K=50", warm=1, timed=2, full=True)
 
 
 def flda(burnin=60, warmup=3, steps=20, cpu=True):
@@ -255,6 +276,7 @@ def fctm(burnin=30, warmup=2, steps=6, cpu=True):
 
 
 ALL = {"lda100": lda100, "ctm": ctm, "ctpf": ctpf, "flda": flda, "fctm": fctm}
+CPU = {"lda100": lda100_cpu, "ctm": ctm_cpu, "ctpf": ctpf_cpu}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(ALL)

@@ -157,6 +157,12 @@ function copyback!(model::fCTM, dev::hipfCTM)
 	nothing
 end
 
+# Topic counts the engine takes (tmvb_*_create returns TMVB_EINVAL beyond them, which tmvb_check turns into the ArgumentError the
+# reference throws for bad arguments): LDA 1024, CTM / fCTM / CTPF / fLDA 128.  `@gpu train!` on a larger model trains on the CPU
+# path with a warning instead of failing -- the macro stays a drop-in for every model the package can build.
+hip_max_topics(::LDA) = 1024
+hip_max_topics(::Union{CTM, CTPF, fLDA, fCTM}) = 128
+
 hipmodel(model::LDA) = hipLDA(model)
 hipmodel(model::CTM) = hipCTM(model)
 hipmodel(model::CTPF) = hipCTPF(model)
@@ -175,7 +181,10 @@ macro gpu(expr::Expr)
 		local model = $(esc(expr.args[2]))
 		local kwargs = [(kw.args[1], eval(kw.args[2])) for kw in $(esc(expr.args[3:end]))]
 
-		if isa(model, Union{LDA, CTM, CTPF, fLDA, fCTM})       # the reference does nothing for fLDA / fCTM (src/macros.jl:274-278)
+		if isa(model, Union{LDA, CTM, CTPF, fLDA, fCTM}) && model.K > hip_max_topics(model)
+			@warn "libtmvb_hip takes K <= $(hip_max_topics(model)) for this model; training on the CPU path."
+			train!(model; kwargs...)
+		elseif isa(model, Union{LDA, CTM, CTPF, fLDA, fCTM})   # the reference does nothing for fLDA / fCTM (src/macros.jl:274-278)
 			local dev = hipmodel(model)
 			train!(dev; kwargs...)
 			copyback!(model, dev)
