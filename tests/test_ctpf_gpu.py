@@ -101,6 +101,39 @@ def test_device_elbo_matches_oracle(tmvb, oracle, case):
         assert np.isfinite(e_g) and abs(e_g - e_o) <= 2e-5 * abs(e_o), (it, e_g, e_o)
 
 
+@pytest.mark.parametrize("grid", ["0", "1"])
+def test_long_documents_and_the_lane_per_token_path(tmvb, oracle, monkeypatch, grid):
+    """The grid-tile kernel's classes on one corpus -- documents of up to 192 terms with few readers, 33 .. 64 readers, and the
+    four-wave classes (up to 256 terms x 512 readers, 384 x 384), plus one document beyond them (LDS kernel) -- and, with
+    TMVB_CTPF_GRID=0, the lane = token register-tile path of rounds 1-2 on the same corpus; pinned sweeps, against the oracle."""
+    monkeypatch.setenv("TMVB_CTPF_GRID", grid)
+    rng = np.random.default_rng(11)
+    V, U, K = 1500, 700, 50
+    shapes = [(30, 3), (64, 1), (90, 20), (128, 32), (129, 5), (192, 30), (100, 40), (128, 64), (60, 100), (250, 10), (200, 300), (20, 500),
+              (300, 200), (380, 380), (600, 50), (10, 0), (5, 600)]
+    tl, rl = [], []
+    for n, r in shapes:
+        tl.append((np.sort(rng.choice(V, size=n, replace=False)), rng.integers(1, 4, size=n)))
+        rl.append((np.sort(rng.choice(U, size=r, replace=False)), rng.integers(1, 3, size=r)))
+    g = dict(K=K, V=V, U=U, doc_ptr=np.concatenate([[0], np.cumsum([len(t) for t, _ in tl])]).astype(np.int64),
+             terms=np.concatenate([t for t, _ in tl]).astype(np.int32), counts=np.concatenate([c for _, c in tl]).astype(np.int32),
+             rdr_ptr=np.concatenate([[0], np.cumsum([len(t) for t, _ in rl])]).astype(np.int64),
+             readers=np.concatenate([t for t, _ in rl]).astype(np.int32), ratings=np.concatenate([c for _, c in rl]).astype(np.int32),
+             alef0=np.exp(tmvb.dirichlet_rows(K, V, seed=6) - 0.5))
+    gm, om = make_pair(tmvb, oracle, g)
+    for it in range(2):
+        force(gm, om)
+        gm.estep(viter=4, vtol=0.0); gm.reduce_docs(); gm.mstep()
+        om.estep(viter=4, vtol=0.0); om.mstep()
+        e_g = gm.update_elbo(); e_o = om.update_elbo()
+        gm.update_host()
+        assert np.all(gm.doc_sweeps() == 4)
+        assert rel(gm.gimel, om.gimel) <= 3e-4 and rel(gm.zayin, om.zayin) <= 3e-4, (it, rel(gm.gimel, om.gimel), rel(gm.zayin, om.zayin))
+        assert rel(gm.alef, om.alef) <= 3e-4 and rel(gm.he, om.he) <= 3e-4
+        assert rel(gm.vav, om.vav) <= 2e-5 and rel(gm.bet, om.bet) <= 2e-5
+        assert abs(e_g - e_o) <= 2e-5 * abs(e_o), (it, e_g, e_o)
+
+
 def test_fast_elbo_equals_the_entry_by_entry_kernel(tmvb):
     """update_elbo!'s per-document part in its table form (two row reads and 3 K fmas per term / reader entry) against the
     entry-by-entry kernel (2 K digammas per entry; TMVB_CTPF_ELBO_LEGACY=1), which the oracle tests pinned in round 2: same

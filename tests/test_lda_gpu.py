@@ -291,6 +291,53 @@ def test_every_kernel_path_by_k(tmvb, oracle, K, merged, monkeypatch):
         assert abs(e_g - e_o) <= RTOL_ELBO_STEP * abs(e_o)
 
 
+@pytest.mark.parametrize("K", [10, 50, 100])
+def test_lane_per_token_register_tile_path_still_matches_the_oracle(tmvb, oracle, K, monkeypatch):
+    """Round 3 made the grid-tile kernel (tmvb_gridtile.h) the default for KP <= 100; the lane = token register-tile kernels of
+    rounds 1-2 stay in the library behind TMVB_LDA_GRID=0 (and, multi-wave, for documents beyond the grid kernel's reach): they
+    must keep matching the oracle."""
+    monkeypatch.setenv("TMVB_LDA_GRID", "0")
+    pc = tmvb.syn_nsf(M=120, V=900, seed=17)
+    g = dict(K=K, V=pc.V, doc_ptr=pc.doc_ptr, terms=pc.terms, counts=pc.counts, beta0=tmvb.dirichlet_rows(K, pc.V, seed=3))
+    gm, om = make_pair(tmvb, oracle, g)
+    for it in range(2):
+        force(gm, om)
+        gm.estep(viter=4, vtol=0.0); gm.reduce_docs(); om.estep(viter=4, vtol=0.0)
+        gm.update_beta(); om.update_beta(); gm.update_alpha(); om.update_alpha()
+        e_g = gm.update_elbo(); e_o = om.update_elbo()
+        gm.update_host()
+        assert rel(gm.gamma, om.gamma).max() <= RTOL_STATE, (it, "gamma")
+        big = om.beta > 1e-6
+        assert rel(gm.beta[big], om.beta[big]).max() <= RTOL_BETA, (it, "beta")
+        assert rel(gm.alpha, om.alpha).max() <= RTOL_ALPHA
+        assert abs(e_g - e_o) <= RTOL_ELBO_STEP * abs(e_o)
+
+
+def test_grid_tile_long_documents_two_and_four_waves(tmvb, oracle):
+    """Documents of 193 .. 768 unique terms run the grid-tile kernel with two / four waves per document (partial sums through
+    LDS, identical tails in every wave); beyond that the four-wave lane = token kernel and the LDS kernel.  One corpus with all
+    of them, K = 50 (six pairs per lane) and K = 100 (three), teacher-forced against the oracle with pinned sweeps."""
+    rng = np.random.default_rng(3)
+    V = 3000
+    lens = [40, 150, 200, 300, 380, 390, 500, 760, 800, 1100, 1500, 90, 64, 65, 96, 97, 128, 129, 192, 193]
+    docs = [(np.sort(rng.choice(V, size=n, replace=False)), rng.integers(1, 5, size=n)) for n in lens]
+    doc_ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    terms = np.concatenate([t for t, _ in docs]).astype(np.int32); counts = np.concatenate([c for _, c in docs]).astype(np.int32)
+    for K in (50, 100):
+        g = dict(K=K, V=V, doc_ptr=doc_ptr, terms=terms, counts=counts, beta0=tmvb.dirichlet_rows(K, V, seed=3))
+        gm, om = make_pair(tmvb, oracle, g)
+        for it in range(2):
+            force(gm, om)
+            gm.estep(viter=5, vtol=0.0); gm.reduce_docs(); om.estep(viter=5, vtol=0.0)
+            gm.update_beta(); om.update_beta(); gm.update_alpha(); om.update_alpha()
+            gm.update_host()
+            assert np.all(gm.doc_sweeps() == 5)
+            assert rel(gm.gamma, om.gamma).max() <= RTOL_STATE, (K, it, "gamma")
+            assert rel(gm.Elogtheta, om.Elogtheta).max() <= RTOL_STATE, (K, it, "Elogtheta")
+            big = om.beta > 1e-6
+            assert rel(gm.beta[big], om.beta[big]).max() <= RTOL_BETA, (K, it, "beta")
+
+
 def test_train_equals_stepwise_pipelined(tmvb):
     """train! enqueues its iterations without host synchronisation; the stepwise loop below synchronises after every
     operator.  Both must give the same state bit for bit: every stream that carries document kernels has to wait for the
