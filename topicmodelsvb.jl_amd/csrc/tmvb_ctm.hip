@@ -457,6 +457,21 @@ __global__ __launch_bounds__(64) void ctm_batch_tabs_kernel(int K, int KP, const
 // in LDS, one workgroup per chunk).
 #define CTM_REORDER_CHUNK 2048
 #define CTM_BATCH_MAX_LEN 2048     // unique terms per document the lane-per-document kernel takes
+// Length limit of the lane-per-document kernel for THIS corpus.  A wave of that kernel walks max-length-of-its-64-documents token
+// steps per sweep, and a launch of ~2 waves per SIMD slot ends with its slowest slot: on SYN-NSF (mean 85 terms, longest 419) the wave
+// of the 64 longest documents alone ran 13.4 M cycles against a mean of 11.3 M per SLOT -- the E-step waited 0.8 ms for one wave.
+// Documents beyond ~3x the mean length go to the wave-per-document kernel instead (a few hundred documents, beside the lane kernel on
+// the auxiliary streams), bounded to at most 1/64 of the corpus.  TMVB_CTM_BATCH_MAX_LEN overrides.
+static int64_t ctm_batch_len_limit(const std::vector<int64_t>& len, const std::vector<int32_t>& order, int64_t M)
+{
+    if (const char* e = getenv("TMVB_CTM_BATCH_MAX_LEN")) return std::min<int64_t>(std::max(atoi(e), 1), CTM_BATCH_MAX_LEN);
+    if (M < 4096) return CTM_BATCH_MAX_LEN;                           // small corpora: one kernel (with fewer waves than SIMD slots the longest wave IS the E-step, so the rule holds from here on)
+    double sum = 0.0;
+    for (int64_t d = 0; d < M; ++d) sum += (double)len[(size_t)d];
+    int64_t lim = std::max<int64_t>(128, (int64_t)(3.0 * sum / (double)M));
+    lim = std::max(lim, len[(size_t)order[(size_t)(M / 64)]]);          // order is by descending length: at most M / 64 documents beyond it
+    return std::min<int64_t>(lim, CTM_BATCH_MAX_LEN);
+}
 __global__ __launch_bounds__(1024) void ctm_reorder_kernel(const int32_t* __restrict__ order0, const uint16_t* __restrict__ key,
                                                            int32_t* __restrict__ order, int64_t M)
 {
@@ -1193,7 +1208,10 @@ extern "C" int tmvb_ctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
     const std::vector<int64_t>& len = corp->h_doc_len;
     std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return len[x] > len[y]; });
     h->n_long = 0;
-    if (h->batch) while (h->n_long < h->M && len[order[(size_t)h->n_long]] > CTM_BATCH_MAX_LEN) ++h->n_long;
+    if (h->batch) {
+        const int64_t lim = ctm_batch_len_limit(len, order, h->M);
+        while (h->n_long < h->M && len[order[(size_t)h->n_long]] > lim) ++h->n_long;
+    }
     {
         // The resident topic tile decides the waves per CU of the Newton-bound kernel (K = 50: a 96-row tile is 21 KB,
         // 7 waves per CU), and the Newton steps -- 97 % of the kernel -- never touch it.  A 32-row window (8 KB) that
