@@ -457,21 +457,6 @@ __global__ __launch_bounds__(64) void ctm_batch_tabs_kernel(int K, int KP, const
 // in LDS, one workgroup per chunk).
 #define CTM_REORDER_CHUNK 2048
 #define CTM_BATCH_MAX_LEN 2048     // unique terms per document the lane-per-document kernel takes
-// Length limit of the lane-per-document kernel for THIS corpus.  A wave of that kernel walks max-length-of-its-64-documents token
-// steps per sweep, and a launch of ~2 waves per SIMD slot ends with its slowest slot: on SYN-NSF (mean 85 terms, longest 419) the wave
-// of the 64 longest documents alone ran 13.4 M cycles against a mean of 11.3 M per SLOT -- the E-step waited 0.8 ms for one wave.
-// Documents beyond ~3x the mean length go to the wave-per-document kernel instead (a few hundred documents, beside the lane kernel on
-// the auxiliary streams), bounded to at most 1/64 of the corpus.  TMVB_CTM_BATCH_MAX_LEN overrides.
-static int64_t ctm_batch_len_limit(const std::vector<int64_t>& len, const std::vector<int32_t>& order, int64_t M)
-{
-    if (const char* e = getenv("TMVB_CTM_BATCH_MAX_LEN")) return std::min<int64_t>(std::max(atoi(e), 1), CTM_BATCH_MAX_LEN);
-    if (M < 4096) return CTM_BATCH_MAX_LEN;                           // small corpora: one kernel (with fewer waves than SIMD slots the longest wave IS the E-step, so the rule holds from here on)
-    double sum = 0.0;
-    for (int64_t d = 0; d < M; ++d) sum += (double)len[(size_t)d];
-    int64_t lim = std::max<int64_t>(128, (int64_t)(3.0 * sum / (double)M));
-    lim = std::max(lim, len[(size_t)order[(size_t)(M / 64)]]);          // order is by descending length: at most M / 64 documents beyond it
-    return std::min<int64_t>(lim, CTM_BATCH_MAX_LEN);
-}
 __global__ __launch_bounds__(1024) void ctm_reorder_kernel(const int32_t* __restrict__ order0, const uint16_t* __restrict__ key,
                                                            int32_t* __restrict__ order, int64_t M)
 {
@@ -1209,8 +1194,7 @@ extern "C" int tmvb_ctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
     std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return len[x] > len[y]; });
     h->n_long = 0;
     if (h->batch) {
-        const int64_t lim = ctm_batch_len_limit(len, order, h->M);
-        while (h->n_long < h->M && len[order[(size_t)h->n_long]] > lim) ++h->n_long;
+        while (h->n_long < h->M && len[order[(size_t)h->n_long]] > CTM_BATCH_MAX_LEN) ++h->n_long;
     }
     {
         // The resident topic tile decides the waves per CU of the Newton-bound kernel (K = 50: a 96-row tile is 21 KB,
@@ -1355,7 +1339,13 @@ static int ctm_launch_batch(tmvb_ctm* h, const CtmParams& p, double ntol)
     { const double fl = h->cg_abs * std::min(ntol, 4e-4); tb.cg_abs2 = (float)(fl * fl); }   // never looser than at the reference K = 50 (ntol = 1/K^2)
     const int64_t Mb = h->M - h->n_long;                 // the documents behind the long ones in the processing order
     if (Mb <= 0) return TMVB_OK;
-    const dim3 grid((unsigned)((Mb + 63) / 64)), block(64);
+    // persistent launch: one 64-lane workgroup per SIMD of the device (the kernel takes a whole SIMD's register file), each pulling
+    // waves-of-documents from the queue at d_cg_iters[12] (zeroed above); the order of the queue is the processing order, longest
+    // documents first.  TMVB_CTM_PERSISTENT=0: one workgroup per wave-of-documents, placed by the hardware dispatcher.
+    const int n_items = (int)((Mb + 63) / 64);
+    static const bool persistent = [] { const char* e = getenv("TMVB_CTM_PERSISTENT"); return !(e && atoi(e) == 0); }();
+    const dim3 grid((unsigned)(persistent ? std::min(n_items, 4 * ctx->num_cu) : n_items)), block(64);
+    tb.next_item = (unsigned*)(h->d_cg_iters + 12); tb.n_items = n_items;
     const size_t lds = (size_t)h->KP * 64 * (sizeof(double) + sizeof(float)) + 64 * sizeof(int32_t);   // vsq, CG solution / row staging, row ids
     if (h->reorder && h->keys_valid) {
         hipLaunchKernelGGL(ctm_reorder_kernel, dim3((unsigned)((Mb + CTM_REORDER_CHUNK - 1) / CTM_REORDER_CHUNK)), dim3(1024), 0, ctx->stream,
@@ -1366,12 +1356,26 @@ static int ctm_launch_batch(tmvb_ctm* h, const CtmParams& p, double ntol)
     CtmBatchArgs ba;
     ba.p = p; ba.p.doc_order = p.doc_order + h->n_long; ba.p.doc_newton = h->d_doc_newton; ba.tb = tb; ba.M = Mb;
     static const bool prof = [] { const char* e = getenv("TMVB_CTM_PROF"); return e && atoi(e) != 0; }();
+    // TMVB_CTM_WAVE_LOG=<file> (with TMVB_CTM_PROF=1): per-item start / end / placement of this launch, written after a synchronisation (diagnostics only)
+    static const char* wave_log = getenv("TMVB_CTM_WAVE_LOG");
+    static unsigned long long* d_wl = nullptr; static size_t wl_cap = 0;
+    const bool logging = prof && h->KP == 52 && wave_log;
+    if (logging) {
+        if (wl_cap < (size_t)n_items * 4) { (void)hipFree(d_wl); wl_cap = (size_t)n_items * 4; TMVB_HIP(hipMalloc((void**)&d_wl, wl_cap * sizeof(unsigned long long))); }
+        ba.tb.wave_log = d_wl;
+    }
 #define CTM_BCASE(KPV) case KPV: hipLaunchKernelGGL((ctm_estep_batch_kernel<KPV, false, FILT>), grid, block, lds, ctx->stream, ba); break;
     if (prof && h->KP == 52) hipLaunchKernelGGL((ctm_estep_batch_kernel<52, true, FILT>), grid, block, lds, ctx->stream, ba);
     else switch (h->KP) { CTM_BCASE(4) CTM_BCASE(12) CTM_BCASE(20) CTM_BCASE(28) CTM_BCASE(36) CTM_BCASE(44)
                           default: hipLaunchKernelGGL((ctm_estep_batch_kernel<52, false, FILT>), grid, block, lds, ctx->stream, ba); break; }
 #undef CTM_BCASE
     TMVB_HIP(hipGetLastError());
+    if (logging) {
+        std::vector<unsigned long long> wl((size_t)n_items * 4);
+        TMVB_HIP(hipMemcpyAsync(wl.data(), d_wl, wl.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+        TMVB_HIP(hipStreamSynchronize(ctx->stream));
+        if (FILE* f = fopen(wave_log, "wb")) { fwrite(wl.data(), sizeof(unsigned long long), wl.size(), f); fclose(f); }
+    }
     return TMVB_OK;
 }
 

@@ -35,6 +35,9 @@ struct CtmBatchTabs {
     unsigned long long* cg_iters = nullptr;   // diagnostics: [0] CG trips summed over waves, [1] Newton trips summed over waves, [2] waves,
                                               // [3..10] shader cycles per phase summed over waves: token, logzeta, vsq, gradient assembly, CG, gradient mat-vec,
                                               // lambda update, spare; [11] whole kernel
+    unsigned* next_item = nullptr;            // work queue of the persistent launch: the next wave-of-documents to take (zeroed before the launch)
+    int n_items = 0;                          // waves-of-documents in the queue (64 documents each)
+    unsigned long long* wave_log = nullptr;   // PROF only (TMVB_CTM_WAVE_LOG): per wave [start, end] of the 100 MHz wall clock, HW_ID, longest document
 };
 
 template <typename F, int... I>
@@ -345,6 +348,14 @@ __device__ __forceinline__ T cb_karg()
     return v;
 }
 #define CB_KARG(type, field) cb_karg<type, (int)offsetof(CtmBatchArgs, field)>()
+template <int OFF>
+__device__ __forceinline__ int cb_karg32()
+{
+    int v;
+    asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "n"(OFF));
+    return v;
+}
+#define CB_KARG32(field) cb_karg32<(int)offsetof(CtmBatchArgs, field)>()
 
 // One token step of the cooperative row gather (see the token phase of the kernel): every lane publishes the row id of its own
 // document, reads back the ids of the LPR rows it fetches chunks of, and issues its LPR 16-byte loads.
@@ -401,13 +412,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     constexpr int LPR = R / 4;
     const int lane = threadIdx.x;
     const int K = p.K;
-    const int64_t slot = (int64_t)blockIdx.x * 64 + lane;
+    // Persistent launch: one workgroup per SIMD slot of the device, each takes the next wave-of-documents from a queue until none is
+    // left.  (With one 64-document workgroup per wave-of-documents the hardware dispatcher placed wave 1024 + k a median 130 us after
+    // the k-th slot had become free -- profiles/r3_ctm_wave_log.txt -- and the launch ended with its slowest slot.)
+    for (;;) {
+    int item;
+    { unsigned* q = CB_KARG(unsigned*, tb.next_item); unsigned v = 0; if (lane == 0) v = atomicAdd(q, 1u); item = __builtin_amdgcn_readfirstlane((int)v); }
+    if (item >= CB_KARG32(tb.n_items)) break;
+    const int64_t slot = (int64_t)item * 64 + lane;
     const bool valid = slot < M;
     const int d = CB_KARG(const int32_t*, p.doc_order)[valid ? slot : M - 1];
     int64_t off;
     int N;
     { const int64_t* doc_ptr = CB_KARG(const int64_t*, p.doc_ptr); off = doc_ptr[d]; N = valid ? (int)(doc_ptr[d + 1] - off) : 0; }
     const int Nmax = wave_max_i(N);
+    if constexpr (PROF) {
+        unsigned long long* wl = CB_KARG(unsigned long long*, tb.wave_log);
+        if (wl && lane == 0) wl[4 * (int64_t)item] = wall_clock64();
+    }
 
     // C_d = sum of counts (src/CTM.jl:33)
     float cl = 0.0f;
@@ -829,9 +851,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             if constexpr (PROF) {
                 for (int q = 0; q < 8; ++q) atomicAdd(diag + 3 + q, (unsigned long long)cyc[q]);
                 atomicAdd(diag + 11, (unsigned long long)(__builtin_readcyclecounter() - t_start));
+                unsigned long long* wl = CB_KARG(unsigned long long*, tb.wave_log);
+                if (wl) {
+                    unsigned hw;
+                    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+                    wl[4 * (int64_t)item + 1] = wall_clock64();
+                    wl[4 * (int64_t)item + 2] = hw;
+                    wl[4 * (int64_t)item + 3] = (unsigned long long)Nmax | ((unsigned long long)ntrip << 32);
+                }
             }
         }
     }
+    }   // next item
 }
 #undef LAM
 #undef CB_LAM_PAD
