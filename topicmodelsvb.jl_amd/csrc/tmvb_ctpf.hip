@@ -795,8 +795,12 @@ __global__ __launch_bounds__(64) void ctpf_elbo_doc_kernel(int K, const int64_t*
 // two row reads, 3 K fmas, one reciprocal and one logarithm per entry.  sum_n lgamma(c_n + 1) + sum_u lgamma(r_u + 1) is a
 // per-document constant of the corpus (lg_doc, computed once on the host).
 __global__ __launch_bounds__(256) void ctpf_elbo_tables_kernel(const float* __restrict__ X, const float* __restrict__ X_old,
-                                                               float* __restrict__ To, float* __restrict__ D, int K, int KP, int64_t n_ids)
+                                                               float* __restrict__ To, float* __restrict__ D, int K, int KP, int64_t n_ids,
+                                                               const double* __restrict__ rates, double* __restrict__ lrates_d)
 {
+    // log of the eight rate vectors (bet, vav, dalet, het and their *_old) in fp64, once per call instead of per document and lane
+    if (lrates_d != nullptr && blockIdx.x == 0)
+        for (int q = threadIdx.x; q < 8 * K; q += blockDim.x) lrates_d[q] = log(rates[q]);
     const int64_t total = n_ids * KP;
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
         const int64_t id = q / KP;
@@ -845,7 +849,8 @@ __global__ __launch_bounds__(64) void ctpf_elbo_doc_fast_kernel(int K, int KP, c
                                                                 const int32_t* __restrict__ readers, const int32_t* __restrict__ ratings,
                                                                 const float* __restrict__ TAo, const float* __restrict__ DA,
                                                                 const float* __restrict__ THo, const float* __restrict__ DH,
-                                                                const double* __restrict__ rates /* [8][K] */, const double* __restrict__ rs_alef,
+                                                                const double* __restrict__ rates /* [8][K] */, const double* __restrict__ lrates_d /* their logs */,
+                                                                const double* __restrict__ rs_alef,
                                                                 const double* __restrict__ rs_he, const float* __restrict__ gimel,
                                                                 const float* __restrict__ gimel_old, const float* __restrict__ zayin,
                                                                 const float* __restrict__ zayin_old, const double* __restrict__ lg_doc,
@@ -858,27 +863,34 @@ __global__ __launch_bounds__(64) void ctpf_elbo_doc_fast_kernel(int K, int KP, c
     double xo[NS], ao[NS], bo[NS], lt[NS], le[NS], lbet[NS], lvav[NS];
     bool on[NS];
     double mx = -INFINITY, mab = -INFINITY;
+    // (the logs of the rates come from lrates_d, psi and lgamma of a shape from one evaluation -- digamma_lgamma_d: this prelude was
+    //  ~4000 fp64 instructions per document with the library's lgamma / log and the loop form of digamma, and the kernel's whole time)
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         on[s] = lane + 64 * s < K;
         const int i = on[s] ? lane + 64 * s : 0;
         const double bet = rates[i], vav = rates[K + i], dalet = rates[2 * K + i], het = rates[3 * K + i];
-        const double bet_o = rates[4 * K + i], vav_o = rates[5 * K + i], dalet_o = rates[6 * K + i], het_o = rates[7 * K + i];
+        const double l_bet = lrates_d[i], l_vav = lrates_d[K + i], l_dalet = lrates_d[2 * K + i], l_het = lrates_d[3 * K + i];
+        const double l_bet_o = lrates_d[4 * K + i], l_vav_o = lrates_d[5 * K + i], l_dalet_o = lrates_d[6 * K + i], l_het_o = lrates_d[7 * K + i];
         const double gi = on[s] ? (double)gimel[(int64_t)d * K + i] : 1.0, za = on[s] ? (double)zayin[(int64_t)d * K + i] : 1.0;
         const double gio = on[s] ? (double)gimel_old[(int64_t)d * K + i] : 1.0, zao = on[s] ? (double)zayin_old[(int64_t)d * K + i] : 1.0;
-        const double dgo = digamma_d(gio);
-        xo[s] = dgo - log(dalet_o) - log(bet_o);           // softmax arguments rebuilt from the *_old variables (:240-241)
-        ao[s] = dgo - log(dalet_o) - log(vav_o);
-        bo[s] = digamma_d(zao) - log(het_o) - log(vav_o);
-        lt[s] = digamma_d(gi) - log(dalet);               // E[log theta]
-        le[s] = digamma_d(za) - log(het);                 // E[log epsilon]
-        lbet[s] = log(bet); lvav[s] = log(vav);
+        const double dgo = digamma_shift8_d(gio);
+        xo[s] = dgo - l_dalet_o - l_bet_o;                 // softmax arguments rebuilt from the *_old variables (:240-241)
+        ao[s] = dgo - l_dalet_o - l_vav_o;
+        bo[s] = digamma_shift8_d(zao) - l_het_o - l_vav_o;
+        double psi_g, lg_g, psi_z, lg_z;
+        digamma_lgamma_d(gi, psi_g, lg_g);
+        digamma_lgamma_d(za, psi_z, lg_z);
+        lt[s] = psi_g - l_dalet;                          // E[log theta]
+        le[s] = psi_z - l_het;                            // E[log epsilon]
+        lbet[s] = l_bet; lvav[s] = l_vav;
         if (on[s]) {
+            const double r_dalet = tmvb_rcp_d(dalet), r_het = tmvb_rcp_d(het), r_vav = tmvb_rcp_d(vav), r_bet = tmvb_rcp_d(bet);
             mx = fmax(mx, xo[s]); mab = fmax(mab, fmax(ao[s], bo[s]));
-            acc -= gi / (dalet * vav) * rs_he[i] + za / (het * vav) * rs_he[i] + gi / (dalet * bet) * rs_alef[i];   // :112,:123,:134
-            acc += (hc - 1.0) * lt[s] - hd * gi / dalet;                          // Elogptheta :156
-            acc += (hg - 1.0) * le[s] - hh * za / het;                            // Elogpepsilon :174
-            acc += gamma_entropy_d(gi, dalet) + gamma_entropy_d(za, het);         // -Elogqtheta, -Elogqepsilon
+            acc -= (gi * r_dalet * r_vav + za * r_het * r_vav) * rs_he[i] + gi * r_dalet * r_bet * rs_alef[i];   // :112,:123,:134
+            acc += (hc - 1.0) * lt[s] - hd * gi * r_dalet;                        // Elogptheta :156
+            acc += (hg - 1.0) * le[s] - hh * za * r_het;                          // Elogpepsilon :174
+            acc += (gi - l_dalet + lg_g + (1.0 - gi) * psi_g) + (za - l_het + lg_z + (1.0 - za) * psi_z);   // -Elogqtheta, -Elogqepsilon: Gamma entropies
         }
     }
     mx = -wave_min_d(-mx); mab = -wave_min_d(-mab);
@@ -917,8 +929,10 @@ __global__ __launch_bounds__(256) void ctpf_elbo_global_kernel(const float* __re
     const int64_t total = n_ids * K;
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
         const int i = (int)(q % K);
-        const double x = (double)X[q], r = rate[i];
-        s += (ps - 1.0) * (digamma_d(x) - log(r)) - pr * x / r + gamma_entropy_d(x, r);
+        const double x = (double)X[q], r = rate[i], lr = log(r);
+        double psi, lg;
+        digamma_lgamma_d(x, psi, lg);
+        s += (ps - 1.0) * (psi - lr) - pr * x * tmvb_rcp_d(r) + (x - lr + lg + (1.0 - x) * psi);
     }
     red[threadIdx.x] = s;
     __syncthreads();
@@ -945,6 +959,23 @@ __global__ __launch_bounds__(1024) void ctpf_elbo_final_kernel(const double* __r
     if (threadIdx.x == 0) out[0] = red[0] + constant;
 }
 
+// out[0] = sum of doc_val[0, M), out[1] = sum of partial[0, npartial) + constant: both parts of update_elbo! behind one launch
+__global__ __launch_bounds__(1024) void ctpf_elbo_final2_kernel(const double* __restrict__ doc_val, int64_t M, const double* __restrict__ partial,
+                                                                int npartial, double constant, double* __restrict__ out)
+{
+    __shared__ double red[2][1024];
+    double s = 0.0, g = 0.0;
+    for (int64_t d = threadIdx.x; d < M; d += 1024) s += doc_val[d];
+    for (int q = threadIdx.x; q < npartial; q += 1024) g += partial[q];
+    red[0][threadIdx.x] = s; red[1][threadIdx.x] = g;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = red[0][0]; out[1] = red[1][0] + constant; }
+}
+
 // ------------------------------------------------------------------------------ host side
 struct tmvb_ctpf {
     tmvb_ctx* ctx = nullptr;
@@ -959,6 +990,8 @@ struct tmvb_ctpf {
     float* d_TA = nullptr; float* d_TH = nullptr;                  // padded tables
     float* d_stats = nullptr; bool own_stats = true;               // alef_stats (K*V) | he_stats (K*U) | sum_gimel (K) | sum_zayin (K)
     double* d_rates = nullptr; float* d_lrates = nullptr;          // [8][K], [4][K]
+    double* d_lrates_d = nullptr;                                  // [8][K] log(rates) in fp64 for update_elbo! (filled per call)
+    bool rs_fresh = false;                                         // d_rs_alef / d_rs_he are the row sums of the current alef / he
     float* d_gimel = nullptr; float* d_gimel_old = nullptr; float* d_zayin = nullptr; float* d_zayin_old = nullptr;
     float* d_wtok = nullptr; float* d_wrdr = nullptr; float* d_E1 = nullptr; float* d_E2 = nullptr;
     float* d_ts_partial = nullptr; float* d_ts_partial2 = nullptr;   // multi-chunk partials of the term / reader statistics passes
@@ -993,7 +1026,7 @@ extern "C" int tmvb_ctpf_destroy(tmvb_ctpf* h)
     (void)hipFree(h->d_alef); (void)hipFree(h->d_alef_old); (void)hipFree(h->d_he); (void)hipFree(h->d_he_old);
     (void)hipFree(h->d_TA); (void)hipFree(h->d_TH); (void)hipFree(h->d_topic_of_lane); (void)hipFree(h->d_grid_topic_of_lane);
     if (h->own_stats) (void)hipFree(h->d_stats);
-    (void)hipFree(h->d_rates); (void)hipFree(h->d_lrates); (void)hipFree(h->d_gimel); (void)hipFree(h->d_gimel_old);
+    (void)hipFree(h->d_rates); (void)hipFree(h->d_lrates); (void)hipFree(h->d_lrates_d); (void)hipFree(h->d_gimel); (void)hipFree(h->d_gimel_old);
     (void)hipFree(h->d_zayin); (void)hipFree(h->d_zayin_old); (void)hipFree(h->d_wtok); (void)hipFree(h->d_wrdr);
     (void)hipFree(h->d_E1); (void)hipFree(h->d_E2); (void)hipFree(h->d_ts_partial); (void)hipFree(h->d_ts_partial2); (void)hipFree(h->d_sweeps);
     (void)hipFree(h->d_doc_order); (void)hipFree(h->d_partial); (void)hipFree(h->d_partial2); (void)hipFree(h->d_rs_alef); (void)hipFree(h->d_rs_he);
@@ -1053,7 +1086,7 @@ extern "C" int tmvb_ctpf_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmv
         (rc = dmalloc(&h->d_ts_partial, slots * (K + 1))) || (rc = dmalloc(&h->d_ts_partial2, slots * (K + 1))) || (rc = dmalloc(&h->d_sweeps, (size_t)h->M)) || (rc = dmalloc(&h->d_doc_order, (size_t)h->M)) ||
         (rc = dmalloc(&h->d_partial, (size_t)TMVB_REDUCE_BLOCKS * K)) || (rc = dmalloc(&h->d_partial2, (size_t)TMVB_REDUCE_BLOCKS * K)) || (rc = dmalloc(&h->d_rs_alef, K)) || (rc = dmalloc(&h->d_rs_he, K)) ||
         (rc = dmalloc(&h->d_sum_g, K)) || (rc = dmalloc(&h->d_sum_z, K)) || (rc = dmalloc(&h->d_doc_val, (size_t)h->M)) ||
-        (rc = dmalloc(&h->d_elbo_partial, 1024)) || (rc = dmalloc(&h->d_elbo, 1))) {
+        (rc = dmalloc(&h->d_elbo_partial, 1024)) || (rc = dmalloc(&h->d_elbo, 2))) {
         return rc;
     }
     // processing order: first the documents of the LDS-tile kernel by rows (terms + readers), longest first, in LDS
@@ -1165,6 +1198,7 @@ extern "C" int tmvb_ctpf_set_state(tmvb_ctpf* h, const double* hyper, const doub
         for (int q = 0; q < 8; ++q) TMVB_REQUIRE(hyper[q] > 0.0, TMVB_ESHAPE, "%c must be positive.", nm[q]);   // src/modelutils.jl:188-195
         memcpy(h->hyper, hyper, sizeof(h->hyper));
     }
+    if (alef || he) h->rs_fresh = false;
     if (alef) {
         TMVB_REQUIRE(positive_finite(alef, KV), TMVB_ENONFINITE, "alef must be positive.");
         if ((rc = upload_f32(ctx, h->d_alef, alef, KV)) || (rc = upload_f32(ctx, h->d_alef_old, alef, KV))) return rc;
@@ -1467,6 +1501,7 @@ extern "C" int tmvb_ctpf_mstep(tmvb_ctpf* h)
     hipLaunchKernelGGL((ctpf_rates_kernel<1>), dim3(1), dim3(64), 0, ctx->stream, h->K, h->hyper[1], h->hyper[3], h->hyper[5], h->hyper[7],
                        h->d_rs_alef, h->d_rs_he, h->d_sum_g, h->d_sum_z, h->d_rates, h->d_lrates);
     TMVB_HIP(hipGetLastError());
+    h->rs_fresh = true;                                   // d_rs_alef / d_rs_he = row sums of the alef / he just written
     return TMVB_OK;
 }
 
@@ -1479,28 +1514,29 @@ extern "C" int tmvb_ctpf_update_elbo_parts(tmvb_ctpf* h, double* doc_part, doubl
     tmvb_ctx* ctx = h->ctx;
     TMVB_HIP(hipSetDevice(ctx->device));
     int rc;
-    // rowsums of the CURRENT shapes (Elogpya/Elogpyb/Elogpz use sum(he, dims=2), sum(alef, dims=2))
-    if ((rc = tmvb_colsum(ctx, h->nslot, h->K, h->d_alef, h->V, h->d_partial, h->d_rs_alef, nullptr))) return rc;
-    if (h->U > 0) { if ((rc = tmvb_colsum(ctx, h->nslot, h->K, h->d_he, h->U, h->d_partial, h->d_rs_he, nullptr))) return rc; }
-    else TMVB_HIP(hipMemsetAsync(h->d_rs_he, 0, (size_t)h->K * sizeof(double), ctx->stream));
+    // rowsums of the CURRENT shapes (Elogpya/Elogpyb/Elogpz use sum(he, dims=2), sum(alef, dims=2)): the M-step has just left them in
+    // d_rs_alef / d_rs_he unless the state was set through the API since (rs_fresh)
+    if (!h->rs_fresh) {
+        if ((rc = tmvb_colsum(ctx, h->nslot, h->K, h->d_alef, h->V, h->d_partial, h->d_rs_alef, nullptr))) return rc;
+        if (h->U > 0) { if ((rc = tmvb_colsum(ctx, h->nslot, h->K, h->d_he, h->U, h->d_partial, h->d_rs_he, nullptr))) return rc; }
+        else TMVB_HIP(hipMemsetAsync(h->d_rs_he, 0, (size_t)h->K * sizeof(double), ctx->stream));
+        h->rs_fresh = true;
+    }
     const double* hy = h->hyper;
     double res[2] = {0.0, 0.0};
-    // global part
+    // global part: partial sums now, added up by the one final kernel behind the per-document part (one copy, one synchronisation)
     const int nb = 256;
     hipLaunchKernelGGL(ctpf_elbo_global_kernel, dim3(nb), dim3(256), 0, ctx->stream, h->d_alef, h->V, h->K, h->d_rates, hy[0], hy[1], h->d_elbo_partial);
     hipLaunchKernelGGL(ctpf_elbo_global_kernel, dim3(nb), dim3(256), 0, ctx->stream, h->d_he, h->U, h->K, h->d_rates + h->K, hy[4], hy[5], h->d_elbo_partial + nb);
     TMVB_HIP(hipGetLastError());
     const double cst = (double)h->V * h->K * (hy[0] * std::log(hy[1]) - std::lgamma(hy[0])) + (double)h->U * h->K * (hy[4] * std::log(hy[5]) - std::lgamma(hy[4]));
-    hipLaunchKernelGGL(ctpf_elbo_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, h->d_doc_val, (int64_t)0, h->d_elbo_partial, 2 * nb, cst, h->d_elbo);
-    TMVB_HIP(hipMemcpyAsync(&res[1], h->d_elbo, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    TMVB_HIP(hipStreamSynchronize(ctx->stream));
     // per-document part
     static const bool legacy_elbo = [] { const char* e = getenv("TMVB_CTPF_ELBO_LEGACY"); return e && atoi(e) != 0; }();
     if (h->M > 0 && !legacy_elbo) {
         if (!h->d_lg_doc) {                               // first call: tables and the corpus constants
             const size_t na = (size_t)h->V * h->KP + 4, nh = (size_t)std::max<int64_t>(h->U, 1) * h->KP + 4;
             if ((rc = dmalloc(&h->d_TAo, na)) || (rc = dmalloc(&h->d_DA, na)) || (rc = dmalloc(&h->d_THo, nh)) || (rc = dmalloc(&h->d_DH, nh)) ||
-                (rc = dmalloc(&h->d_lg_doc, (size_t)h->M))) return rc;
+                (rc = dmalloc(&h->d_lrates_d, 8 * (size_t)h->K)) || (rc = dmalloc(&h->d_lg_doc, (size_t)h->M))) return rc;
             std::vector<double> lg((size_t)h->M, 0.0);
             const tmvb_corpus* c = h->corp;
             for (int64_t d = 0; d < h->M; ++d) {
@@ -1513,21 +1549,23 @@ extern "C" int tmvb_ctpf_update_elbo_parts(tmvb_ctpf* h, double* doc_part, doubl
             TMVB_HIP(hipStreamSynchronize(ctx->stream));
         }
         int nbt = (int)std::min<int64_t>(2048, std::max<int64_t>(1, ((int64_t)h->KP * h->V + 255) / 256));
-        hipLaunchKernelGGL(ctpf_elbo_tables_kernel, dim3(nbt), dim3(256), 0, ctx->stream, h->d_alef, h->d_alef_old, h->d_TAo, h->d_DA, h->K, h->KP, h->V);
+        hipLaunchKernelGGL(ctpf_elbo_tables_kernel, dim3(nbt), dim3(256), 0, ctx->stream, h->d_alef, h->d_alef_old, h->d_TAo, h->d_DA, h->K, h->KP, h->V,
+                           (const double*)h->d_rates, h->d_lrates_d);
         if (h->U > 0) {
             nbt = (int)std::min<int64_t>(2048, std::max<int64_t>(1, ((int64_t)h->KP * h->U + 255) / 256));
-            hipLaunchKernelGGL(ctpf_elbo_tables_kernel, dim3(nbt), dim3(256), 0, ctx->stream, h->d_he, h->d_he_old, h->d_THo, h->d_DH, h->K, h->KP, h->U);
+            hipLaunchKernelGGL(ctpf_elbo_tables_kernel, dim3(nbt), dim3(256), 0, ctx->stream, h->d_he, h->d_he_old, h->d_THo, h->d_DH, h->K, h->KP, h->U,
+                               (const double*)nullptr, (double*)nullptr);
         }
         TMVB_HIP(hipGetLastError());
         if (h->nslot == 1)
             hipLaunchKernelGGL((ctpf_elbo_doc_fast_kernel<1>), dim3((unsigned)h->M), dim3(64), 0, ctx->stream, h->K, h->KP, h->corp->d_doc_ptr, h->corp->d_terms,
                                h->corp->d_counts, h->corp->d_rdr_ptr, h->corp->d_readers, h->corp->d_ratings, h->d_TAo, h->d_DA, h->d_THo, h->d_DH,
-                               h->d_rates, h->d_rs_alef, h->d_rs_he, h->d_gimel, h->d_gimel_old, h->d_zayin, h->d_zayin_old, h->d_lg_doc,
+                               h->d_rates, h->d_lrates_d, h->d_rs_alef, h->d_rs_he, h->d_gimel, h->d_gimel_old, h->d_zayin, h->d_zayin_old, h->d_lg_doc,
                                hy[2], hy[3], hy[6], hy[7], h->d_doc_val);
         else
             hipLaunchKernelGGL((ctpf_elbo_doc_fast_kernel<2>), dim3((unsigned)h->M), dim3(64), 0, ctx->stream, h->K, h->KP, h->corp->d_doc_ptr, h->corp->d_terms,
                                h->corp->d_counts, h->corp->d_rdr_ptr, h->corp->d_readers, h->corp->d_ratings, h->d_TAo, h->d_DA, h->d_THo, h->d_DH,
-                               h->d_rates, h->d_rs_alef, h->d_rs_he, h->d_gimel, h->d_gimel_old, h->d_zayin, h->d_zayin_old, h->d_lg_doc,
+                               h->d_rates, h->d_lrates_d, h->d_rs_alef, h->d_rs_he, h->d_gimel, h->d_gimel_old, h->d_zayin, h->d_zayin_old, h->d_lg_doc,
                                hy[2], hy[3], hy[6], hy[7], h->d_doc_val);
         TMVB_HIP(hipGetLastError());
     } else if (h->M > 0) {
@@ -1543,8 +1581,10 @@ extern "C" int tmvb_ctpf_update_elbo_parts(tmvb_ctpf* h, double* doc_part, doubl
                                hy[2], hy[3], hy[6], hy[7], h->d_doc_val);
         TMVB_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(ctpf_elbo_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, h->d_doc_val, h->M, h->d_elbo_partial, 0, 0.0, h->d_elbo);
-    TMVB_HIP(hipMemcpyAsync(&res[0], h->d_elbo, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    // d_elbo[0] = sum over the documents (the part that adds up over shards), d_elbo[1] = the global part
+    hipLaunchKernelGGL(ctpf_elbo_final2_kernel, dim3(1), dim3(1024), 0, ctx->stream, h->d_doc_val, h->M, h->d_elbo_partial, 2 * nb, cst, h->d_elbo);
+    TMVB_HIP(hipGetLastError());
+    TMVB_HIP(hipMemcpyAsync(res, h->d_elbo, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     TMVB_HIP(hipStreamSynchronize(ctx->stream));
     if (doc_part) *doc_part = res[0];
     if (global_part) *global_part = res[1];

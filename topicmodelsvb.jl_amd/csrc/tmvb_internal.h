@@ -339,4 +339,110 @@ __device__ __forceinline__ double trigamma_d(double x)
     return psi + t * w * p;
 }
 
+// fp64 reciprocal: v_rcp_f64 (about 27 bits) + two Newton steps; 1 ulp-class (not correctly rounded, which nothing here needs).
+__device__ __forceinline__ double tmvb_rcp_d(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
+// digamma and trigamma of the same argument for the alpha Newton step, fp64, x > 0.  The published algorithm (recurrence to
+// x >= 7 / 8, then the asymptotic series; Appendix A of SURVEY.md) with the recurrence written for the GPU: instead of a loop of
+// 7 - floor(x) IEEE divisions per lane (the lanes of a wave run the longest loop: ~2 x 8 divisions of ~40 instructions each per
+// call), a FIXED shift by 8 for x < 8 with both recurrence sums from ONE reciprocal: with P(x) = prod_{v=0}^{7} (x + v),
+//   sum 1/(x+v) = P'/P,   sum 1/(x+v)^2 = (P'/P)^2 - P''/P
+// (P, P', P'' by Horner on the expanded coefficients: 21 fmas).  The series then runs at y = x + 8 >= 8.  Agreement with the loop
+// form: <= 4e-15 relative on (1e-6, 1e4) (host check in tests/test_oracle_special.py style; the alpha tolerance is 1e-4).
+__device__ __forceinline__ void digamma_trigamma_d(double x, double& psi, double& psi1)
+{
+    const bool small = x < 8.0;
+    double y = x, rec0 = 0.0, rec1 = 0.0;
+    if (small) {
+        // P(x) = x (x+1) ... (x+7) = x^8 + 28 x^7 + 322 x^6 + 1960 x^5 + 6769 x^4 + 13132 x^3 + 13068 x^2 + 5040 x
+        double P = x + 28.0; P = fma(P, x, 322.0); P = fma(P, x, 1960.0); P = fma(P, x, 6769.0); P = fma(P, x, 13132.0);
+        P = fma(P, x, 13068.0); P = fma(P, x, 5040.0); P *= x;
+        double P1 = fma(8.0, x, 196.0); P1 = fma(P1, x, 1932.0); P1 = fma(P1, x, 9800.0); P1 = fma(P1, x, 27076.0);
+        P1 = fma(P1, x, 39396.0); P1 = fma(P1, x, 26136.0); P1 = fma(P1, x, 5040.0);
+        double P2 = fma(56.0, x, 1176.0); P2 = fma(P2, x, 9660.0); P2 = fma(P2, x, 39200.0); P2 = fma(P2, x, 81228.0);
+        P2 = fma(P2, x, 78792.0); P2 = fma(P2, x, 26136.0);
+        const double rP = tmvb_rcp_d(P);
+        rec0 = P1 * rP;                                   // sum_{v=0}^{7} 1/(x+v)
+        rec1 = fma(rec0, rec0, -P2 * rP);                 // sum_{v=0}^{7} 1/(x+v)^2
+        y = x + 8.0;
+    }
+    const double t = tmvb_rcp_d(y), w = t * t;
+    double p = -0.4432598039215686;
+    p = fma(p, w, 0.08333333333333333);
+    p = fma(p, w, -0.021092796092796094);
+    p = fma(p, w, 0.007575757575757576);
+    p = fma(p, w, -0.004166666666666667);
+    p = fma(p, w, 0.003968253968253968);
+    p = fma(p, w, -0.008333333333333333);
+    p = fma(p, w, 0.08333333333333333);
+    psi = (log(y) - 0.5 * t) - w * p - rec0;
+    double q = -7.092156862745098;
+    q = fma(q, w, 1.1666666666666667);
+    q = fma(q, w, -0.2531135531135531);
+    q = fma(q, w, 0.07575757575757576);
+    q = fma(q, w, -0.03333333333333333);
+    q = fma(q, w, 0.023809523809523808);
+    q = fma(q, w, -0.03333333333333333);
+    q = fma(q, w, 0.16666666666666666);
+    psi1 = (t + 0.5 * w) + t * w * q + rec1;
+}
+
+// digamma and log-gamma of the same argument x > 0 in fp64 with ONE pass of the same fixed shift (no branch: the identities hold
+// for every x > 0):  psi(x) = psi(x + 8) - P'/P,  lgamma(x) = lgamma(x + 8) - log P(x),  P(x) = x (x+1) ... (x+7); psi and
+// lgamma at y = x + 8 >= 8 by their asymptotic series (psi as above; Stirling's series to the y^-13 term, next term 8e-16 at y = 8)
+// sharing log y and 1 / y.  Two logarithms and two reciprocals per call where lgamma() + digamma_d() of the library cost several
+// hundred instructions and a loop of divisions.  <= 2e-15 relative against mpmath on (1e-6, 1e5) (formula check on the host).
+__device__ __forceinline__ void digamma_lgamma_d(double x, double& psi, double& lg)
+{
+    double P = x + 28.0; P = fma(P, x, 322.0); P = fma(P, x, 1960.0); P = fma(P, x, 6769.0); P = fma(P, x, 13132.0);
+    P = fma(P, x, 13068.0); P = fma(P, x, 5040.0); P *= x;
+    double P1 = fma(8.0, x, 196.0); P1 = fma(P1, x, 1932.0); P1 = fma(P1, x, 9800.0); P1 = fma(P1, x, 27076.0);
+    P1 = fma(P1, x, 39396.0); P1 = fma(P1, x, 26136.0); P1 = fma(P1, x, 5040.0);
+    const double rec0 = P1 * tmvb_rcp_d(P);               // sum_{v=0}^{7} 1/(x+v)
+    const double y = x + 8.0, t = tmvb_rcp_d(y), w = t * t, ly = log(y);
+    double p = -0.4432598039215686;
+    p = fma(p, w, 0.08333333333333333);
+    p = fma(p, w, -0.021092796092796094);
+    p = fma(p, w, 0.007575757575757576);
+    p = fma(p, w, -0.004166666666666667);
+    p = fma(p, w, 0.003968253968253968);
+    p = fma(p, w, -0.008333333333333333);
+    p = fma(p, w, 0.08333333333333333);
+    psi = (ly - 0.5 * t) - w * p - rec0;
+    double s = 1.0 / 156.0;
+    s = fma(s, w, -691.0 / 360360.0);
+    s = fma(s, w, 1.0 / 1188.0);
+    s = fma(s, w, -1.0 / 1680.0);
+    s = fma(s, w, 1.0 / 1260.0);
+    s = fma(s, w, -1.0 / 360.0);
+    s = fma(s, w, 1.0 / 12.0);
+    lg = ((y - 0.5) * ly - y + 0.91893853320467274178) + t * s - log(P);
+}
+// psi alone, same shift (one logarithm)
+__device__ __forceinline__ double digamma_shift8_d(double x)
+{
+    double P = x + 28.0; P = fma(P, x, 322.0); P = fma(P, x, 1960.0); P = fma(P, x, 6769.0); P = fma(P, x, 13132.0);
+    P = fma(P, x, 13068.0); P = fma(P, x, 5040.0); P *= x;
+    double P1 = fma(8.0, x, 196.0); P1 = fma(P1, x, 1932.0); P1 = fma(P1, x, 9800.0); P1 = fma(P1, x, 27076.0);
+    P1 = fma(P1, x, 39396.0); P1 = fma(P1, x, 26136.0); P1 = fma(P1, x, 5040.0);
+    const double rec0 = P1 * tmvb_rcp_d(P);
+    const double y = x + 8.0, t = tmvb_rcp_d(y), w = t * t;
+    double p = -0.4432598039215686;
+    p = fma(p, w, 0.08333333333333333);
+    p = fma(p, w, -0.021092796092796094);
+    p = fma(p, w, 0.007575757575757576);
+    p = fma(p, w, -0.004166666666666667);
+    p = fma(p, w, 0.003968253968253968);
+    p = fma(p, w, -0.008333333333333333);
+    p = fma(p, w, 0.08333333333333333);
+    return (log(y) - 0.5 * t) - w * p - rec0;
+}
+
+
 #endif  // __HIPCC__
