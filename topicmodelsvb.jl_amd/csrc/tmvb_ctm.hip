@@ -1137,6 +1137,9 @@ extern "C" int tmvb_ctm_set_state(tmvb_ctm* h, const double* mu, const double* s
 
 static int ctm_reduce_docs_on(tmvb_ctm* h, hipStream_t st);
 
+// set by tmvb_fctm_create around its call of tmvb_ctm_create: the filtered model has the lane-per-document kernel for KP <= 52 only
+static thread_local bool tls_ctm_create_filtered = false;
+
 extern "C" int tmvb_ctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb_ctm** out)
 {
     TMVB_REQUIRE(out != nullptr, TMVB_EINVAL, "tmvb_ctm_create: out is NULL");
@@ -1177,7 +1180,11 @@ extern "C" int tmvb_ctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
         // on them, so THOSE documents -- not the corpus: round 2 sent every document of a corpus with one such document there -- keep
         // the wave-per-document kernel, which spreads a document's tokens over the lanes; h->n_long below)
         // (its token phase addresses the token arrays and the topic table with unsigned 32-bit byte offsets)
-        h->batch = !h->generic && h->KP <= 52 && corp->info.nnz < (1ll << 30) && (int64_t)h->KP * h->V < (1ll << 30) && h->V < (1 << 24) &&
+        // (KP = 60, K = 51 ... 60: three waves per CU by LDS instead of four, the plain CTM only; TMVB_CTM_BATCH60=0 keeps the
+        //  wave-per-document kernel there)
+        const char* e60 = getenv("TMVB_CTM_BATCH60");
+        const int kp_max = ((e60 && atoi(e60) == 0) || tls_ctm_create_filtered) ? 52 : 60;
+        h->batch = !h->generic && h->KP <= kp_max && corp->info.nnz < (1ll << 30) && (int64_t)h->KP * h->V < (1ll << 30) && h->V < (1 << 24) &&
                    !(e && atoi(e) == 0);
         if (const char* t = getenv("TMVB_CTM_CG_TOL")) h->cg_tol = std::max(1e-7f, (float)atof(t));
         if (const char* t = getenv("TMVB_CTM_CG_ABS")) h->cg_abs = std::max(0.0f, (float)atof(t));
@@ -1344,9 +1351,10 @@ static int ctm_launch_batch(tmvb_ctm* h, const CtmParams& p, double ntol)
     // documents first.  TMVB_CTM_PERSISTENT=0: one workgroup per wave-of-documents, placed by the hardware dispatcher.
     const int n_items = (int)((Mb + 63) / 64);
     static const bool persistent = [] { const char* e = getenv("TMVB_CTM_PERSISTENT"); return !(e && atoi(e) == 0); }();
-    const dim3 grid((unsigned)(persistent ? std::min(n_items, 4 * ctx->num_cu) : n_items)), block(64);
-    tb.next_item = (unsigned*)(h->d_cg_iters + 12); tb.n_items = n_items;
     const size_t lds = (size_t)h->KP * 64 * (sizeof(double) + sizeof(float)) + 64 * sizeof(int32_t);   // vsq, CG solution / row staging, row ids
+    const int per_cu = (int)std::min<size_t>(4, (160 * 1024) / lds);      // one wave per SIMD, and what the CU's LDS holds
+    const dim3 grid((unsigned)(persistent ? std::min(n_items, per_cu * ctx->num_cu) : n_items)), block(64);
+    tb.next_item = (unsigned*)(h->d_cg_iters + 12); tb.n_items = n_items;
     if (h->reorder && h->keys_valid) {
         hipLaunchKernelGGL(ctm_reorder_kernel, dim3((unsigned)((Mb + CTM_REORDER_CHUNK - 1) / CTM_REORDER_CHUNK)), dim3(1024), 0, ctx->stream,
                            h->d_doc_order0 + h->n_long, h->d_doc_newton, h->d_doc_order + h->n_long, Mb);
@@ -1366,6 +1374,9 @@ static int ctm_launch_batch(tmvb_ctm* h, const CtmParams& p, double ntol)
     }
 #define CTM_BCASE(KPV) case KPV: hipLaunchKernelGGL((ctm_estep_batch_kernel<KPV, false, FILT>), grid, block, lds, ctx->stream, ba); break;
     if (prof && h->KP == 52) hipLaunchKernelGGL((ctm_estep_batch_kernel<52, true, FILT>), grid, block, lds, ctx->stream, ba);
+    else if (h->KP == 60) {
+        if constexpr (!FILT) hipLaunchKernelGGL((ctm_estep_batch_kernel<60, false, false>), grid, block, lds, ctx->stream, ba);
+    }
     else switch (h->KP) { CTM_BCASE(4) CTM_BCASE(12) CTM_BCASE(20) CTM_BCASE(28) CTM_BCASE(36) CTM_BCASE(44)
                           default: hipLaunchKernelGGL((ctm_estep_batch_kernel<52, false, FILT>), grid, block, lds, ctx->stream, ba); break; }
 #undef CTM_BCASE
@@ -1838,7 +1849,9 @@ extern "C" int tmvb_fctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmv
     *out = nullptr;
     tmvb_fctm* h = new tmvb_fctm();
     tmvb_create_guard<tmvb_fctm, tmvb_fctm_destroy> guard{h};
+    tls_ctm_create_filtered = true;
     int rc = tmvb_ctm_create(ctx, corp, K, &h->base);                     // fCTM(corp, K), src/fCTM.jl:32-65: same constructor state
+    tls_ctm_create_filtered = false;
     if (rc) return rc;
     tmvb_ctm* b = h->base;
     h->nnz = corp->info.nnz;

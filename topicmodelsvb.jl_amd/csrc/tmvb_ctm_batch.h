@@ -584,7 +584,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             // the CG solution (idle in this phase): ds_write_b128 in chunk order, ds_read_b128 of the lane's own row (stride 208 B:
             // conflict free).  The row ids travel the other way through a 64-entry LDS table.  VMEM returns in order, so a lane's own
             // ids / counts are fetched two rounds ahead (waiting for a load younger than the rows in flight would drain them).
-            constexpr int CH = (R == 52) ? 2 : 4;
+            constexpr int CH = (R >= 52) ? 2 : 4;
             cb_v4f* xl4 = (cb_v4f*)vsf_l;                              // [64 rows][LPR chunks]: the vsq region, vsq parked in registers
             int* tl = (int*)(lds + 3 * R * 64);                        // [64] row ids of one step
             float vpark[R];
