@@ -63,6 +63,12 @@ struct CtmParams {
     float eta = 0.5f;
     float* tau = nullptr; float* tau_old = nullptr; float* lse = nullptr;     // [nnz], CSR order
     uint16_t* doc_newton = nullptr;   // [M] lambda-Newton steps of each document in this E-step (lane-per-document kernel: next E-step's grouping key)
+    // ctm_estep_generic_kernel<.., CG = true> only: the document queue of the persistent launch and the CG stopping rule
+    unsigned* queue = nullptr;        // next position of doc_order to take (zeroed before the launch)
+    int64_t n_docs = 0;
+    float cg_tol2 = 1e-8f, cg_abs2 = 0.0f;
+    int cg_maxit = 200;
+    unsigned long long* cg_diag = nullptr;   // [0] CG trips, [1] Newton trips, [2] documents
 };
 
 __device__ __forceinline__ float readlane_f(float v, int l)
@@ -494,22 +500,41 @@ __global__ __launch_bounds__(1024) void ctm_reorder_kernel(const int32_t* __rest
 // the lanes' ds_read_b128 of their own rows are conflict free, the pivot row is a uniform-address broadcast read) and
 // eliminated in place, one wave per document.  The topic tile is streamed through a fixed 32-row LDS window (gathered
 // again every sweep).  Same arithmetic, exit tests and fp64 gradients as ctm_estep_kernel; ~K^3 LDS traffic per solve
-// makes it several times slower per flop -- it is the K > 60 path, not the tuned one.
+// makes it several times slower per flop (K = 64: 170 ms per E-step on SYN-NSF, K = 100: 1.48 s) -- round 1's K > 60 path, now CG = false.
+//
+// CG = true (round 3, the default for K > 60): the Newton matrix is never formed.  invsigma is the same for every document, so ONE
+// copy sits in LDS for a workgroup of several waves (one document per wave at a time, each wave pulling documents from a queue for
+// the lifetime of the launch: the copy is loaded once), and (invsigma + C_d Diag(e^{...})) x = g is solved by the Jacobi-
+// preconditioned conjugate gradients of the lane-per-document kernel (tmvb_ctm_batch.h; same stopping rule) with lane = matrix row:
+// a mat-vec is LPR ds_read_b128 of the lane's own row (stride KP = 4 * odd: conflict free) against LPR broadcast reads of the
+// direction, ~5 mat-vecs per Newton step instead of K^3 / 3 eliminations through LDS.  The gradient's invsigma (mu - lambda) uses
+// the same fp32 mat-vec (as in the lane-per-document kernel: the rounding is 10 - 100 times below ntol).
 #define CTM_GENERIC_TILE_ROWS 32
-static size_t ctm_generic_lds_bytes(int KP)
+static size_t ctm_generic_wave_floats(int KP) { return (size_t)CTM_GENERIC_TILE_ROWS * KP + 2 * (size_t)KP + 6 * CTM_GENERIC_TILE_ROWS + 2 * (size_t)KP; }
+static size_t ctm_generic_lds_bytes(int KP, int waves = 1)
 {
-    return ((size_t)KP * KP + (size_t)CTM_GENERIC_TILE_ROWS * KP + 2 * (size_t)KP + 6 * CTM_GENERIC_TILE_ROWS) * sizeof(float) + (size_t)KP * sizeof(double);
+    return ((size_t)KP * KP + (size_t)waves * ctm_generic_wave_floats(KP)) * sizeof(float);
+}
+// waves per workgroup of the CG form: what the CU's LDS holds next to the one copy of invsigma, at most two per SIMD
+static int ctm_generic_cg_waves(int KP)
+{
+    const size_t room = 160 * 1024 - (size_t)KP * KP * sizeof(float);
+    return (int)std::max<size_t>(1, std::min<size_t>(8, room / (ctm_generic_wave_floats(KP) * sizeof(float))));
 }
 
-template <int NS, bool FILT>
-__global__ __launch_bounds__(64) void ctm_estep_generic_kernel(CtmParams p, int64_t first)
+template <int NS, bool FILT, bool CG = false>
+__global__ __launch_bounds__(CG ? 512 : 64) void ctm_estep_generic_kernel(CtmParams p, int64_t first)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int K = p.K, KP = p.KP, LPR = p.LPR;
     constexpr int tile_rows = CTM_GENERIC_TILE_ROWS;
-    float* A = lds;                                     // [KP][KP] Newton matrix
-    float* Bt = A + (size_t)KP * KP;                    // [tile_rows][KP] topic tile window
+    // CG: waves of a workgroup run different documents with different trip counts -- a wave-level fence (LDS operations of one wave
+    // complete in program order) where the one-wave form uses the workgroup barrier
+#define GEN_FENCE() do { if constexpr (CG) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } else { __syncthreads(); } } while (0)
+    float* A = lds;                                     // [KP][KP] Newton matrix; CG: invsigma, read-only, shared by the workgroup's waves
+    const size_t wave_floats = (size_t)tile_rows * KP + 2 * (size_t)KP + 6 * tile_rows + 2 * (size_t)KP;
+    float* Bt = A + (size_t)KP * KP + (CG ? (size_t)(threadIdx.x >> 6) * wave_floats : 0);   // [tile_rows][KP] topic tile window
     float* e_l = Bt + (size_t)tile_rows * KP;           // [KP]
     float* g_l = e_l + KP;                              // [KP] right-hand side of the solve
     float* w_l = g_l + KP;                              // [tile_rows]
@@ -520,7 +545,13 @@ __global__ __launch_bounds__(64) void ctm_estep_generic_kernel(CtmParams p, int6
     float* m_l = tn_l + tile_rows;
     double* dm_l = (double*)(m_l + tile_rows);          // [KP] mu - lambda (8-byte aligned: KP is a multiple of 4, so the float blocks above total a multiple of 8 floats)
 
-    const int d = p.doc_order[first + blockIdx.x];
+    if constexpr (CG) {
+        for (int q = threadIdx.x; q < KP * KP / 4; q += blockDim.x) ((float4*)A)[q] = ((const float4*)p.invsigma)[q];
+        __syncthreads();
+    }
+    float* p_l = g_l;                                   // CG: the vector of the mat-vec in flight (the direction, or mu - lambda)
+    unsigned ncg_w = 0, nnewt_w = 0, ndocs_w = 0;
+    auto run_doc = [&](const int d) {
     const int64_t off = p.doc_ptr[d];
     const int N = (int)(p.doc_ptr[d + 1] - off);
 
@@ -549,7 +580,7 @@ __global__ __launch_bounds__(64) void ctm_estep_generic_kernel(CtmParams p, int6
             c_l[n] = (float)p.counts[off + c0 + n];
             if constexpr (FILT) tn_l[n] = p.tau[off + c0 + n];
         }
-        WAVE_LDS_FENCE();
+        GEN_FENCE();
         const float* table = FILT ? p.L : p.beta;
         const int nch = rows * LPR;
         for (int f0 = 0; f0 < nch; f0 += 64) {
@@ -562,7 +593,7 @@ __global__ __launch_bounds__(64) void ctm_estep_generic_kernel(CtmParams p, int6
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        WAVE_LDS_FENCE();
+        GEN_FENCE();
     };
     auto phase1 = [&](int rows) {
         const float4* er = (const float4*)e_l;
@@ -576,7 +607,7 @@ __global__ __launch_bounds__(64) void ctm_estep_generic_kernel(CtmParams p, int6
             }
             w_l[n] = c_l[n] / ((s0 + s1) + (s2 + s3));
         }
-        WAVE_LDS_FENCE();
+        GEN_FENCE();
     };
     const int r4 = lane & 3, ql = lane >> 2;
     auto phase2 = [&](int rows, float4 (&acc)[NS]) {
@@ -617,7 +648,7 @@ __global__ __launch_bounds__(64) void ctm_estep_generic_kernel(CtmParams p, int6
             tp_l[n] = tp; m_l[n] = m; w_l[n] = c_l[n] / s;
             p.tau_old[off + c0 + n] = tp; p.tau[off + c0 + n] = tnew; p.lse[off + c0 + n] = m + __logf(s);   // streamed window: always stored
         }
-        WAVE_LDS_FENCE();
+        GEN_FENCE();
     };
     auto filt_b = [&](int rows, float4 (&acc)[NS]) {
 #pragma unroll
@@ -648,13 +679,13 @@ __global__ __launch_bounds__(64) void ctm_estep_generic_kernel(CtmParams p, int6
 #pragma unroll
             for (int s = 0; s < NS; ++s) if (on[s]) e_l[lane + 64 * s] = (float)lam[s];
             for (int i = K + lane; i < KP; i += 64) e_l[i] = -INFINITY;                 // pads: exp(-inf) = 0
-            WAVE_LDS_FENCE();
+            GEN_FENCE();
             for (int c0 = 0; c0 < N; c0 += tile_rows) {
                 const int rows = min(tile_rows, N - c0);
                 load_chunk(c0, rows);
                 filt_a(c0, rows);
                 filt_b(rows, acc);
-                WAVE_LDS_FENCE();
+                GEN_FENCE();
             }
         } else {
             float lml = -INFINITY;
@@ -667,7 +698,7 @@ __global__ __launch_bounds__(64) void ctm_estep_generic_kernel(CtmParams p, int6
                 if (on[s]) e_l[lane + 64 * s] = e[s];
             }
             for (int i = K + lane; i < KP; i += 64) e_l[i] = 0.0f;                      // pads
-            WAVE_LDS_FENCE();
+            GEN_FENCE();
             for (int c0 = 0; c0 < N; c0 += tile_rows) {
                 const int rows = min(tile_rows, N - c0);
                 load_chunk(c0, rows);
@@ -675,7 +706,7 @@ __global__ __launch_bounds__(64) void ctm_estep_generic_kernel(CtmParams p, int6
                 if (p.store_w)                       // last executed sweep wins (the exit sweep is not known in advance)
                     for (int n = lane; n < rows; n += 64) p.wtok[p.tok_inv[off + c0 + n]] = w_l[n];
                 phase2(rows, acc);
-                WAVE_LDS_FENCE();
+                GEN_FENCE();
             }
         }
 #pragma unroll
@@ -724,8 +755,83 @@ __global__ __launch_bounds__(64) void ctm_estep_generic_kernel(CtmParams p, int6
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 ex[s] = on[s] ? exp(lam[s] + 0.5 * vs[s] - lz) : 0.0;
-                if (on[s]) dm_l[lane + 64 * s] = mu[s] - lam[s];
+                if constexpr (!CG) { if (on[s]) dm_l[lane + 64 * s] = mu[s] - lam[s]; }
             }
+            double gn2;
+            if constexpr (CG) {
+                // y = invsigma v for the vector in p_l (pads zero), lane = row
+                auto matvec = [&](float (&y)[NS]) {
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) {
+                        y[s] = 0.0f;
+                        if (!row[s]) continue;
+                        const float4* sr = (const float4*)(A + (size_t)(lane + 64 * s) * KP);
+                        const float4* pr = (const float4*)p_l;
+                        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                        for (int q = 0; q < LPR; ++q) {
+                            const float4 a = sr[q], b = pr[q];
+                            a0 = fmaf(a.x, b.x, a0); a1 = fmaf(a.y, b.y, a1); a2 = fmaf(a.z, b.z, a2); a3 = fmaf(a.w, b.w, a3);
+                        }
+                        y[s] = (a0 + a1) + (a2 + a3);
+                    }
+                };
+                float g[NS], Dg[NS], dinv[NS], x[NS], r[NS], pv[NS], y[NS];
+#pragma unroll
+                for (int s = 0; s < NS; ++s) if (row[s]) p_l[lane + 64 * s] = (float)(mu[s] - lam[s]);
+                for (int i = K + lane; i < KP; i += 64) p_l[i] = 0.0f;
+                GEN_FENCE();
+                matvec(y);                                                                  // invsigma (mu - lambda)
+                GEN_FENCE();
+                double gn2l = 0.0;
+                float ggl = 0.0f, rzl = 0.0f;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const double gd = on[s] ? ((double)y[s] + phic[s] - Cd * ex[s]) : 0.0;  // :134
+                    gn2l += gd * gd;
+                    g[s] = (float)gd;
+                    Dg[s] = on[s] ? (float)(Cd * ex[s]) : 1.0f;                             // -H = invsigma + C_d Diag(.)  :135
+                    dinv[s] = 1.0f / ((float)isdiag[s] + Dg[s]);
+                    r[s] = g[s]; pv[s] = on[s] ? g[s] * dinv[s] : 0.0f; x[s] = 0.0f;
+                    ggl = fmaf(g[s], g[s], ggl); rzl = fmaf(r[s], pv[s], rzl);
+                }
+                gn2 = wave_sum_d(gn2l);
+                const float gg = wave_sum(ggl);
+                float rz = wave_sum(rzl);
+                const float thr = fmaxf(p.cg_tol2 * gg, p.cg_abs2);
+                int trips = 0;
+                if (gg > thr) {
+                    while (trips < p.cg_maxit) {
+                        ++trips;
+#pragma unroll
+                        for (int s = 0; s < NS; ++s) if (row[s]) p_l[lane + 64 * s] = pv[s];
+                        GEN_FENCE();
+                        matvec(y);
+                        GEN_FENCE();
+                        float pHpl = 0.0f;
+#pragma unroll
+                        for (int s = 0; s < NS; ++s) { y[s] = fmaf(Dg[s], pv[s], y[s]); pHpl = fmaf(pv[s], y[s], pHpl); }
+                        const float pHp = wave_sum(pHpl);
+                        const float alpha = (pHp > 0.0f) ? rz / pHp : 0.0f;
+                        float rrl = 0.0f, rznl = 0.0f;
+#pragma unroll
+                        for (int s = 0; s < NS; ++s) {
+                            x[s] = fmaf(alpha, pv[s], x[s]);
+                            r[s] = fmaf(-alpha, y[s], r[s]);
+                            y[s] = r[s] * dinv[s];                                           // z
+                            rrl = fmaf(r[s], r[s], rrl); rznl = fmaf(r[s], y[s], rznl);
+                        }
+                        const float rr = wave_sum(rrl), rzn = wave_sum(rznl);
+                        if (rr <= thr) break;
+                        const float beta = (rz > 0.0f) ? rzn / rz : 0.0f;
+                        rz = rzn;
+#pragma unroll
+                        for (int s = 0; s < NS; ++s) pv[s] = on[s] ? fmaf(beta, pv[s], y[s]) : 0.0f;
+                    }
+                }
+                ncg_w += (unsigned)trips; ++nnewt_w;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) if (on[s]) lam[s] += (double)x[s];             // :136
+            } else {
             for (int i = K + lane; i < KP; i += 64) dm_l[i] = 0.0;
             // A <- invsigma (pads zero), row by row
 #pragma unroll
@@ -735,7 +841,7 @@ __global__ __launch_bounds__(64) void ctm_estep_generic_kernel(CtmParams p, int6
                 float4* dst = (float4*)(A + (size_t)(lane + 64 * s) * KP);
                 for (int q = 0; q < LPR; ++q) dst[q] = src[q];
             }
-            WAVE_LDS_FENCE();
+            GEN_FENCE();
             double gn2l = 0.0;
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
@@ -749,8 +855,8 @@ __global__ __launch_bounds__(64) void ctm_estep_generic_kernel(CtmParams p, int6
                 g_l[i] = (float)gd;
                 A[(size_t)i * KP + i] += (float)(Cd * ex[s]);                           // -H = invsigma + C_d Diag(.)  :135
             }
-            const double gn2 = wave_sum_d(gn2l);
-            WAVE_LDS_FENCE();
+            gn2 = wave_sum_d(gn2l);
+            GEN_FENCE();
             // Gauss-Jordan in LDS, no pivoting (SPD)
             for (int j = 0; j < K; ++j) {
                 const float rp = fast_rcp(A[(size_t)j * KP + j]);
@@ -771,14 +877,15 @@ __global__ __launch_bounds__(64) void ctm_estep_generic_kernel(CtmParams p, int6
                     for (int c = j + 1; c < c0; ++c) ar[c] = fmaf(nf, A[(size_t)j * KP + c], ar[c]);   // head of the row up to the aligned part
                     g_l[i] = fmaf(nf, gj, g_l[i]);
                 }
-                WAVE_LDS_FENCE();
+                GEN_FENCE();
             }
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const int i = lane + 64 * s;
                 if (on[s]) lam[s] += (double)(g_l[i] * fast_rcp(A[(size_t)i * KP + i]));   // :136
             }
-            WAVE_LDS_FENCE();
+            GEN_FENCE();
+            }
             if (sqrt(gn2) < p.ntol) break;                                                  // :138
         }
         if constexpr (FILT) run_vsq();                                                      // src/fCTM.jl:240
@@ -810,6 +917,22 @@ __global__ __launch_bounds__(64) void ctm_estep_generic_kernel(CtmParams p, int6
         p.sweeps[d] = (uint8_t)min(sweeps, 255);
         if (p.newton_steps) atomicAdd(p.newton_steps, (unsigned long long)nsteps);
     }
+    ++ndocs_w;
+    };   // run_doc
+    if constexpr (CG) {
+        for (;;) {
+            unsigned v = 0;
+            if (lane == 0) v = atomicAdd(p.queue, 1u);
+            const int64_t q = (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)v);
+            if (q >= p.n_docs) break;
+            run_doc(p.doc_order[first + q]);
+            GEN_FENCE();
+        }
+        if (lane == 0 && p.cg_diag) {
+            atomicAdd(p.cg_diag, (unsigned long long)ncg_w); atomicAdd(p.cg_diag + 1, (unsigned long long)nnewt_w); atomicAdd(p.cg_diag + 2, (unsigned long long)ndocs_w);
+        }
+    } else run_doc(p.doc_order[first + blockIdx.x]);
+#undef GEN_FENCE
 }
 
 // ------------------------------------------------------------------------------ M-step: sigma
@@ -1051,7 +1174,8 @@ struct tmvb_ctm {
     tmvb_comm* comm = nullptr;         // document-sharded train!: the all-reduce of the packed statistics (not owned)
     int nslot = 1;                     // topic slots per lane of the lane = topic kernels ((K + 63) / 64)
     int NB = 2;                        // 32 x 32 tiles per side of the MFMA scatter product
-    bool generic = false;              // K > 60: LDS Newton solve (ctm_estep_generic_kernel)
+    bool generic = false;              // K > 60: ctm_estep_generic_kernel
+    bool generic_cg = false;           // ... in its conjugate-gradient form (d_cg_iters then carries its trip counts)
     float* d_beta[2] = {nullptr, nullptr};
     int cur = 0;
     float* d_stats = nullptr;          // S (K*V) | sum_lambda (K) | sum_vsq (K) | scatter (K*K)
@@ -1332,6 +1456,43 @@ extern "C" int tmvb_ctm_get_state(tmvb_ctm* h, double* mu, double* sigma, double
     return TMVB_OK;
 }
 
+// launch of the K > 60 kernel for CTM (FILT = false) and fCTM (FILT = true): the conjugate-gradient form as one persistent workgroup
+// of several waves per CU (TMVB_CTM_GENERIC_CG=0: round 1's Gauss-Jordan form, one wave per document)
+template <bool FILT>
+static int ctm_launch_generic(tmvb_ctm* h, CtmParams p, double ntol)
+{
+    tmvb_ctx* ctx = h->ctx;
+    static const bool use_cg = [] { const char* e = getenv("TMVB_CTM_GENERIC_CG"); return !(e && atoi(e) == 0); }();
+    h->generic_cg = use_cg;
+    if (use_cg) {
+        const int waves = ctm_generic_cg_waves(h->KP);
+        const size_t lds = ctm_generic_lds_bytes(h->KP, waves);
+        TMVB_HIP(hipMemsetAsync(h->d_cg_iters, 0, 16 * sizeof(unsigned long long), ctx->stream));
+        p.queue = (unsigned*)(h->d_cg_iters + 12); p.n_docs = h->M; p.cg_diag = h->d_cg_iters;
+        p.cg_tol2 = h->cg_tol * h->cg_tol; p.cg_maxit = 4 * h->KP;
+        { const double fl = h->cg_abs * std::min(ntol, 4e-4); p.cg_abs2 = (float)(fl * fl); }
+        const unsigned nwg = (unsigned)std::min<int64_t>(ctx->num_cu, (h->M + waves - 1) / waves);
+        auto launch = [&](auto kern) -> int {
+            TMVB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3(nwg), dim3(64 * waves), lds, ctx->stream, p, (int64_t)0);
+            return TMVB_OK;
+        };
+        int lrc = (h->KP > 64) ? launch(ctm_estep_generic_kernel<2, FILT, true>) : launch(ctm_estep_generic_kernel<1, FILT, true>);
+        if (lrc) return lrc;
+    } else {
+        const size_t lds = ctm_generic_lds_bytes(h->KP);
+        auto launch = [&](auto kern) -> int {
+            TMVB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3((unsigned)h->M), dim3(64), lds, ctx->stream, p, (int64_t)0);
+            return TMVB_OK;
+        };
+        int lrc = (h->KP > 64) ? launch(ctm_estep_generic_kernel<2, FILT, false>) : launch(ctm_estep_generic_kernel<1, FILT, false>);
+        if (lrc) return lrc;
+    }
+    TMVB_HIP(hipGetLastError());
+    return TMVB_OK;
+}
+
 // launch of the lane-per-document kernel (tmvb_ctm_batch.h) for CTM (FILT = false) and fCTM (FILT = true)
 template <bool FILT>
 static int ctm_launch_batch(tmvb_ctm* h, const CtmParams& p, double ntol)
@@ -1410,15 +1571,8 @@ extern "C" int tmvb_ctm_estep(tmvb_ctm* h, int32_t niter, double ntol, int32_t v
     TMVB_HIP(hipEventRecord(h->ev0, ctx->stream));
     TMVB_HIP(hipMemsetAsync(h->d_newton, 0, sizeof(unsigned long long), ctx->stream));
     if (h->generic && h->M > 0) {
-        const size_t lds = ctm_generic_lds_bytes(h->KP);
-        auto launch = [&](auto kern) -> int {
-            TMVB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(kern, dim3((unsigned)h->M), dim3(64), lds, ctx->stream, p, (int64_t)0);
-            return TMVB_OK;
-        };
-        int lrc = (h->KP > 64) ? launch(ctm_estep_generic_kernel<2, false>) : launch(ctm_estep_generic_kernel<1, false>);
+        int lrc = ctm_launch_generic<false>(h, p, ntol);
         if (lrc) return lrc;
-        TMVB_HIP(hipGetLastError());
     }
     // buckets of the wave-per-document kernel: every document (no lane-per-document kernel for this K) or the long ones next to the
     // lane-per-document launch; on auxiliary streams whenever something else runs beside them
@@ -1671,7 +1825,7 @@ extern "C" int tmvb_ctm_solver_stats(tmvb_ctm* h, int64_t* out9)
     TMVB_REQUIRE(h != nullptr && out9 != nullptr, TMVB_EINVAL, "tmvb_ctm_solver_stats: NULL argument");
     TMVB_HIP(hipSetDevice(h->ctx->device));
     unsigned long long v[12] = {0};
-    if (h->batch) {
+    if (h->batch || (h->generic && h->generic_cg)) {
         TMVB_HIP(hipMemcpyAsync(v, h->d_cg_iters, sizeof(v), hipMemcpyDeviceToHost, h->ctx->stream));
         TMVB_HIP(hipStreamSynchronize(h->ctx->stream));
     }
@@ -1945,15 +2099,8 @@ extern "C" int tmvb_fctm_estep(tmvb_fctm* h, int32_t niter, double ntol, int32_t
     TMVB_HIP(hipEventRecord(b->ev0, ctx->stream));
     TMVB_HIP(hipMemsetAsync(b->d_newton, 0, sizeof(unsigned long long), ctx->stream));
     if (b->generic && b->M > 0) {
-        const size_t lds = ctm_generic_lds_bytes(b->KP);
-        auto launch = [&](auto kern) -> int {
-            TMVB_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(kern, dim3((unsigned)b->M), dim3(64), lds, ctx->stream, p, (int64_t)0);
-            return TMVB_OK;
-        };
-        int lrc = (b->KP > 64) ? launch(ctm_estep_generic_kernel<2, true>) : launch(ctm_estep_generic_kernel<1, true>);
+        int lrc = ctm_launch_generic<true>(b, p, ntol);
         if (lrc) return lrc;
-        TMVB_HIP(hipGetLastError());
     } else {
         // lane-per-document kernel for all but the long documents (b->n_long; the buckets then hold only those), else every bucket
         if (b->batch && b->M > 0) { int brc = ctm_launch_batch<true>(b, p, ntol); if (brc) return brc; }
