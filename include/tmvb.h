@@ -263,9 +263,10 @@ int tmvb_flda_last_estep_ms(tmvb_flda* h, float* ms);
  * lambda=0, vsq=1, logzeta=0.5); beta is uniform until tmvb_ctm_set_state (the reference draws it with
  * Julia's RNG).  K <= 128.  Three E-step kernels behind tmvb_ctm_estep: K <= 50 -- one LANE per
  * document, invsigma streamed through scalar registers, the lambda Newton systems solved by Jacobi-preconditioned CG to
- * max(1e-4 |g|, 5 % of ntol) (corpora with documents of more than 2048 unique terms use the next kernel); K <= 60 -- one wave
- * per document, Gauss-Jordan in registers (lane = matrix row); 60 < K <= 128 -- the Newton matrix in LDS (two topic slots
- * per lane), same arithmetic, slower per flop. */
+ * max(1e-4 |g|, 5 % of ntol); its documents of more than 2048 unique terms (and everything under TMVB_CTM_BATCH=0) -- one wave
+ * per document, Gauss-Jordan in registers (lane = matrix row); 50 < K <= 128 -- one wave per document, lane = matrix row (two
+ * topic slots per lane beyond 64), the same CG against one copy of invsigma in LDS per workgroup (TMVB_CTM_GENERIC_CG=0: round 1's
+ * Gauss-Jordan through LDS, 30 times slower at K = 100). */
 int tmvb_ctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb_ctm** out);
 int tmvb_ctm_destroy(tmvb_ctm* h);
 

@@ -1207,7 +1207,11 @@ struct tmvb_ctm {
     float* tail() const { return d_stats + (size_t)K * V; }
 };
 
-static bool ctm_kp_supported(int kp) { return kp >= 4 && kp <= 60 && kp % 8 == 4; }   // KP = 4 * odd, lane = matrix row
+// KP = 4 * odd <= 52 (K <= 50): the lane-per-document kernel and, for its long documents / TMVB_CTM_BATCH=0, the register Gauss-Jordan
+// kernel.  Beyond (round 3): ctm_estep_generic_kernel in its conjugate-gradient form -- at K = 51 ... 60 it measured 11.9 ms per E-step
+// on SYN-NSF against 16.5 ms for a KP = 60 instantiation of the lane-per-document kernel (three waves per CU by LDS, 330 scratch
+// reloads) and 40.7 ms for the register Gauss-Jordan kernel that round 2 ran there.
+static bool ctm_kp_supported(int kp) { return kp >= 4 && kp <= 52 && kp % 8 == 4; }
 
 extern "C" int tmvb_ctm_destroy(tmvb_ctm* h)
 {
@@ -1261,9 +1265,6 @@ extern "C" int tmvb_ctm_set_state(tmvb_ctm* h, const double* mu, const double* s
 
 static int ctm_reduce_docs_on(tmvb_ctm* h, hipStream_t st);
 
-// set by tmvb_fctm_create around its call of tmvb_ctm_create: the filtered model has the lane-per-document kernel for KP <= 52 only
-static thread_local bool tls_ctm_create_filtered = false;
-
 extern "C" int tmvb_ctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb_ctm** out)
 {
     TMVB_REQUIRE(out != nullptr, TMVB_EINVAL, "tmvb_ctm_create: out is NULL");
@@ -1276,7 +1277,7 @@ extern "C" int tmvb_ctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
     tmvb_create_guard<tmvb_ctm, tmvb_ctm_destroy> guard{h};      // every early return below destroys h
     h->ctx = ctx; h->corp = corp; h->K = K; h->KP = tmvb_kpad(K);
     h->nslot = (K + 63) / 64; h->NB = (K + 31) / 32;
-    h->generic = !ctm_kp_supported(h->KP);          // the register Gauss-Jordan kernel holds one matrix row per lane: K <= 60
+    h->generic = !ctm_kp_supported(h->KP) || [] { const char* e = getenv("TMVB_CTM_FORCE_GENERIC"); return e && atoi(e) != 0; }();   // (the env: measurements)
     h->M = corp->info.M; h->V = corp->info.V; h->M_total = h->M;
     const size_t KM = (size_t)K * h->M, KPV = (size_t)h->KP * h->V + 4;
     h->docs_per_wave = 256;
@@ -1304,11 +1305,7 @@ extern "C" int tmvb_ctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
         // on them, so THOSE documents -- not the corpus: round 2 sent every document of a corpus with one such document there -- keep
         // the wave-per-document kernel, which spreads a document's tokens over the lanes; h->n_long below)
         // (its token phase addresses the token arrays and the topic table with unsigned 32-bit byte offsets)
-        // (KP = 60, K = 51 ... 60: three waves per CU by LDS instead of four, the plain CTM only; TMVB_CTM_BATCH60=0 keeps the
-        //  wave-per-document kernel there)
-        const char* e60 = getenv("TMVB_CTM_BATCH60");
-        const int kp_max = ((e60 && atoi(e60) == 0) || tls_ctm_create_filtered) ? 52 : 60;
-        h->batch = !h->generic && h->KP <= kp_max && corp->info.nnz < (1ll << 30) && (int64_t)h->KP * h->V < (1ll << 30) && h->V < (1 << 24) &&
+        h->batch = !h->generic && h->KP <= 52 && corp->info.nnz < (1ll << 30) && (int64_t)h->KP * h->V < (1ll << 30) && h->V < (1 << 24) &&
                    !(e && atoi(e) == 0);
         if (const char* t = getenv("TMVB_CTM_CG_TOL")) h->cg_tol = std::max(1e-7f, (float)atof(t));
         if (const char* t = getenv("TMVB_CTM_CG_ABS")) h->cg_abs = std::max(0.0f, (float)atof(t));
@@ -1535,9 +1532,6 @@ static int ctm_launch_batch(tmvb_ctm* h, const CtmParams& p, double ntol)
     }
 #define CTM_BCASE(KPV) case KPV: hipLaunchKernelGGL((ctm_estep_batch_kernel<KPV, false, FILT>), grid, block, lds, ctx->stream, ba); break;
     if (prof && h->KP == 52) hipLaunchKernelGGL((ctm_estep_batch_kernel<52, true, FILT>), grid, block, lds, ctx->stream, ba);
-    else if (h->KP == 60) {
-        if constexpr (!FILT) hipLaunchKernelGGL((ctm_estep_batch_kernel<60, false, false>), grid, block, lds, ctx->stream, ba);
-    }
     else switch (h->KP) { CTM_BCASE(4) CTM_BCASE(12) CTM_BCASE(20) CTM_BCASE(28) CTM_BCASE(36) CTM_BCASE(44)
                           default: hipLaunchKernelGGL((ctm_estep_batch_kernel<52, false, FILT>), grid, block, lds, ctx->stream, ba); break; }
 #undef CTM_BCASE
@@ -1589,7 +1583,7 @@ extern "C" int tmvb_ctm_estep(tmvb_ctm* h, int32_t niter, double ntol, int32_t v
         const dim3 grid((unsigned)b.count), block(64);
 #define CTM_CASE(KPV) case KPV: hipLaunchKernelGGL((ctm_estep_kernel<KPV, false>), grid, block, lds, st, p, b.first, b.tile_rows); break;
         // (measured: compiling for 4 waves per SIMD -- 128 VGPRs, 17 spilled -- changes nothing: 5.98 vs 5.97 ms)
-        switch (h->KP) { CTM_CASE(4) CTM_CASE(12) CTM_CASE(20) CTM_CASE(28) CTM_CASE(36) CTM_CASE(44) CTM_CASE(60)
+        switch (h->KP) { CTM_CASE(4) CTM_CASE(12) CTM_CASE(20) CTM_CASE(28) CTM_CASE(36) CTM_CASE(44)
                          default: hipLaunchKernelGGL((ctm_estep_kernel<52, false>), grid, block, lds, st, p, b.first, b.tile_rows); break; }
 #undef CTM_CASE
         TMVB_HIP(hipGetLastError());
@@ -2003,9 +1997,7 @@ extern "C" int tmvb_fctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmv
     *out = nullptr;
     tmvb_fctm* h = new tmvb_fctm();
     tmvb_create_guard<tmvb_fctm, tmvb_fctm_destroy> guard{h};
-    tls_ctm_create_filtered = true;
     int rc = tmvb_ctm_create(ctx, corp, K, &h->base);                     // fCTM(corp, K), src/fCTM.jl:32-65: same constructor state
-    tls_ctm_create_filtered = false;
     if (rc) return rc;
     tmvb_ctm* b = h->base;
     h->nnz = corp->info.nnz;
@@ -2108,7 +2100,7 @@ extern "C" int tmvb_fctm_estep(tmvb_fctm* h, int32_t niter, double ntol, int32_t
             const size_t lds = ctm_tile_bytes(bk.tile_rows, b->KP, true);
             const dim3 grid((unsigned)bk.count), block(64);
 #define FCTM_CASE(KPV) case KPV: hipLaunchKernelGGL((ctm_estep_kernel<KPV, true>), grid, block, lds, ctx->stream, p, bk.first, bk.tile_rows); break;
-            switch (b->KP) { FCTM_CASE(4) FCTM_CASE(12) FCTM_CASE(20) FCTM_CASE(28) FCTM_CASE(36) FCTM_CASE(44) FCTM_CASE(60)
+            switch (b->KP) { FCTM_CASE(4) FCTM_CASE(12) FCTM_CASE(20) FCTM_CASE(28) FCTM_CASE(36) FCTM_CASE(44)
                              default: hipLaunchKernelGGL((ctm_estep_kernel<52, true>), grid, block, lds, ctx->stream, p, bk.first, bk.tile_rows); break; }
 #undef FCTM_CASE
             TMVB_HIP(hipGetLastError());
