@@ -258,6 +258,54 @@ def _pair(tmvb, pc, K, monkeypatch):
     return gw, gb
 
 
+@pytest.mark.parametrize("K", [53, 60, 64, 100, 128])
+def test_k_gt_50_conjugate_gradient_form_matches_the_gauss_jordan_form(tmvb, monkeypatch, K):
+    """K > 52 (KP > 52) runs ctm_estep_generic_kernel: round 3's form solves the Newton systems by preconditioned CG against one copy of
+    invsigma in LDS (persistent multi-wave workgroups, documents from a queue), round 1's form (TMVB_CTM_GENERIC_CG=0) eliminates
+    the Newton matrix in LDS.  Same state in, three outer iterations whose sigma / mu come from data, on a ragged corpus with empty
+    documents, documents longer than the 32-row tile window and unused terms: lambda to 1e-3, Newton step totals to 0.1 %, ELBO
+    to 1e-6; the solver statistics show which form ran."""
+    rng = np.random.default_rng(100 + K)
+    V, M = 700, 300
+    docs = []
+    for d in range(M):
+        n = 0 if d % 83 == 7 else int(rng.integers(1, 50 if d % 9 else 150))
+        t = np.sort(rng.choice(V - 60, size=n, replace=False)); c = rng.integers(1, 5, size=n)
+        docs.append((t, c))
+    doc_ptr = np.concatenate([[0], np.cumsum([len(t) for t, _ in docs])]).astype(np.int64)
+    terms = np.concatenate([t for t, _ in docs]).astype(np.int32); counts = np.concatenate([c for _, c in docs]).astype(np.int32)
+    pc = tmvb.PackedCorpus(doc_ptr, terms, counts, V)
+    gj, cg = tmvb.gpuCTM(pc, K), tmvb.gpuCTM(pc, K)
+    for g in (gj, cg):
+        g.beta = np.asfortranarray(tmvb.dirichlet_rows(K, pc.V, seed=5)); g.beta_old = g.beta.copy(order="F"); g.update_buffer()
+    for it in range(3):
+        monkeypatch.setenv("TMVB_CTM_GENERIC_CG", "0"); gj.estep()
+        monkeypatch.setenv("TMVB_CTM_GENERIC_CG", "1"); cg.estep()
+        st = cg.solver_stats()
+        assert st["waves"] == M and st["cg_trips"] > 0 and st["newton_trips"] > 0, st       # (here: documents, CG and Newton trips)
+        assert gj.solver_stats()["cg_trips"] == 0
+        hj, nj = gj.sweep_hist(); hc, nc = cg.sweep_hist()
+        assert abs(nj - nc) <= max(2, 1e-3 * nj), (it, nj, nc)
+        for g in (gj, cg):
+            g.reduce_docs(); g.update_beta(); g.update_sigma(); g.update_mu(); g.update_host()
+        assert np.array_equal(gj.doc_sweeps() > 0, cg.doc_sweeps() > 0)
+        assert (gj.doc_sweeps() != cg.doc_sweeps()).mean() <= 0.02
+        assert np.abs(gj.lam - cg.lam).max() <= 1e-3, (it, np.abs(gj.lam - cg.lam).max())
+        assert np.abs(gj.vsq - cg.vsq).max() <= 1e-3 * gj.vsq.max()
+        assert np.abs(gj.mu - cg.mu).max() <= 1e-4 and np.abs(gj.sigma - cg.sigma).max() <= 1e-4 * np.abs(gj.sigma).max()
+        ej, ec = gj.update_elbo(), cg.update_elbo()
+        assert abs(ej - ec) <= 1e-6 * abs(ej), (it, ej, ec)
+        for n in ("mu", "sigma", "invsigma", "beta", "beta_old", "lam", "lam_old", "vsq", "logzeta"):
+            v = getattr(gj, n); setattr(cg, n, v.copy(order="F") if v.ndim > 1 else v.copy())
+        cg.update_buffer()
+    # the queue-driven launch is deterministic per document: a second run from the same state gives the same bits
+    g1, g2 = tmvb.gpuCTM(pc, K), tmvb.gpuCTM(pc, K)
+    for g in (g1, g2):
+        g.beta = np.asfortranarray(tmvb.dirichlet_rows(K, pc.V, seed=5)); g.beta_old = g.beta.copy(order="F"); g.update_buffer()
+        g.estep(); g.update_host()
+    assert np.array_equal(g1.lam, g2.lam) and np.array_equal(g1.vsq, g2.vsq) and np.array_equal(g1.logzeta, g2.logzeta)
+
+
 @pytest.mark.parametrize("K", [7, 20, 34, 50])
 def test_lane_per_document_kernel_matches_wave_per_document_kernel(tmvb, monkeypatch, K):
     """Same state in, both kernels run the reference's per-document chain: the lane-per-document kernel solves the Newton

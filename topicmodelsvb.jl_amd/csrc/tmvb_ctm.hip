@@ -1207,8 +1207,8 @@ struct tmvb_ctm {
     float* tail() const { return d_stats + (size_t)K * V; }
 };
 
-// KP = 4 * odd <= 52 (K <= 50): the lane-per-document kernel and, for its long documents / TMVB_CTM_BATCH=0, the register Gauss-Jordan
-// kernel.  Beyond (round 3): ctm_estep_generic_kernel in its conjugate-gradient form -- at K = 51 ... 60 it measured 11.9 ms per E-step
+// KP = 4 * odd <= 52 (K <= 52): the lane-per-document kernel and, for its long documents / TMVB_CTM_BATCH=0, the register Gauss-Jordan
+// kernel.  Beyond (round 3): ctm_estep_generic_kernel in its conjugate-gradient form -- at K = 53 ... 60 it measured 11.9 ms per E-step
 // on SYN-NSF against 16.5 ms for a KP = 60 instantiation of the lane-per-document kernel (three waves per CU by LDS, 330 scratch
 // reloads) and 40.7 ms for the register Gauss-Jordan kernel that round 2 ran there.
 static bool ctm_kp_supported(int kp) { return kp >= 4 && kp <= 52 && kp % 8 == 4; }
@@ -1459,7 +1459,8 @@ template <bool FILT>
 static int ctm_launch_generic(tmvb_ctm* h, CtmParams p, double ntol)
 {
     tmvb_ctx* ctx = h->ctx;
-    static const bool use_cg = [] { const char* e = getenv("TMVB_CTM_GENERIC_CG"); return !(e && atoi(e) == 0); }();
+    const char* ecg = getenv("TMVB_CTM_GENERIC_CG");          // (read per launch: the tests run both forms in one process)
+    const bool use_cg = !(ecg && atoi(ecg) == 0);
     h->generic_cg = use_cg;
     if (use_cg) {
         const int waves = ctm_generic_cg_waves(h->KP);
