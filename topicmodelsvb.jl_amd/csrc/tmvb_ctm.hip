@@ -729,6 +729,41 @@ __global__ __launch_bounds__(CG ? 512 : 64) void ctm_estep_generic_kernel(CtmPar
         }
         // update_vsq!  src/CTM.jl:146-165 = src/fCTM.jl:180-198 (before update_lambda! in CTM, after it in fCTM)
         auto run_vsq = [&]() {
+        if constexpr (CG) {
+            // the slots' Newton iterations side by side (two independent fp64 chains per lane), exp and reciprocals as in the
+            // lane-per-document kernel (cb_exp_n, cb_rcp_n); a lane's slot stops where the one-slot-at-a-time loop below would
+            bool act[NS];
+            double vv[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) { act[s] = on[s]; vv[s] = vs[s]; }
+            for (int t = 0; t < p.niter; ++t) {
+                bool any_act = false;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) any_act = any_act || act[s];
+                if (!__any(any_act)) break;
+                double ex[NS], rv[NS], den[NS], ihd[NS];
+#pragma unroll
+                for (int s = 0; s < NS; ++s) ex[s] = lam[s] + 0.5 * vv[s] - lz;
+                cb_exp_n<NS>(ex);
+                cb_rcp_n<NS>(vv, rv);
+#pragma unroll
+                for (int s = 0; s < NS; ++s) den[s] = 0.25 * Cd * ex[s] + 0.5 * rv[s] * rv[s];
+                cb_rcp_n<NS>(den, ihd);
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const double grad = -0.5 * (isdiag[s] + Cd * ex[s] - rv[s]);
+                    const double pp = -ihd[s] * grad;
+                    double rho = 1.0;
+                    if (act[s]) {
+                        while (vv[s] - rho * pp <= 0.0) rho *= 0.5;
+                        vv[s] -= rho * pp;
+                        if (rho * fabs(grad) < p.ntol) act[s] = false;
+                    }
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < NS; ++s) if (on[s]) vs[s] = vv[s] + TMVB_EPS_D;
+        } else {
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             if (!on[s]) continue;
@@ -743,6 +778,7 @@ __global__ __launch_bounds__(CG ? 512 : 64) void ctm_estep_generic_kernel(CtmPar
                 if (rho * fabs(grad) < p.ntol) break;
             }
             vs[s] += TMVB_EPS_D;
+        }
         }
         };
         if constexpr (!FILT) run_vsq();                                                     // src/CTM.jl:198
@@ -760,20 +796,28 @@ __global__ __launch_bounds__(CG ? 512 : 64) void ctm_estep_generic_kernel(CtmPar
             double gn2;
             if constexpr (CG) {
                 // y = invsigma v for the vector in p_l (pads zero), lane = row
+                // (one broadcast read of the vector per four columns for both slots, packed FMAs)
                 auto matvec = [&](float (&y)[NS]) {
+                    const float4* pr = (const float4*)p_l;
+                    const float4* sr[NS];
+                    cb_v2f a01[NS], a23[NS];
 #pragma unroll
                     for (int s = 0; s < NS; ++s) {
-                        y[s] = 0.0f;
-                        if (!row[s]) continue;
-                        const float4* sr = (const float4*)(A + (size_t)(lane + 64 * s) * KP);
-                        const float4* pr = (const float4*)p_l;
-                        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-                        for (int q = 0; q < LPR; ++q) {
-                            const float4 a = sr[q], b = pr[q];
-                            a0 = fmaf(a.x, b.x, a0); a1 = fmaf(a.y, b.y, a1); a2 = fmaf(a.z, b.z, a2); a3 = fmaf(a.w, b.w, a3);
-                        }
-                        y[s] = (a0 + a1) + (a2 + a3);
+                        sr[s] = (const float4*)(A + (size_t)(row[s] ? lane + 64 * s : 0) * KP);
+                        a01[s] = cb_v2f{0.f, 0.f}; a23[s] = cb_v2f{0.f, 0.f};
                     }
+#pragma unroll 2
+                    for (int q = 0; q < LPR; ++q) {
+                        const float4 b = pr[q];
+#pragma unroll
+                        for (int s = 0; s < NS; ++s) {
+                            const float4 a = sr[s][q];
+                            a01[s] = __builtin_elementwise_fma(cb_v2f{a.x, a.y}, cb_v2f{b.x, b.y}, a01[s]);
+                            a23[s] = __builtin_elementwise_fma(cb_v2f{a.z, a.w}, cb_v2f{b.z, b.w}, a23[s]);
+                        }
+                    }
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) { const cb_v2f t = a01[s] + a23[s]; y[s] = row[s] ? t.x + t.y : 0.0f; }
                 };
                 float g[NS], Dg[NS], dinv[NS], x[NS], r[NS], pv[NS], y[NS];
 #pragma unroll
@@ -1475,7 +1519,7 @@ static int ctm_launch_generic(tmvb_ctm* h, CtmParams p, double ntol)
             hipLaunchKernelGGL(kern, dim3(nwg), dim3(64 * waves), lds, ctx->stream, p, (int64_t)0);
             return TMVB_OK;
         };
-        int lrc = (h->KP > 64) ? launch(ctm_estep_generic_kernel<2, FILT, true>) : launch(ctm_estep_generic_kernel<1, FILT, true>);
+        int lrc = (h->K > 64) ? launch(ctm_estep_generic_kernel<2, FILT, true>) : launch(ctm_estep_generic_kernel<1, FILT, true>);   // (K = 61 ... 64: KP = 68, but one topic slot per lane)
         if (lrc) return lrc;
     } else {
         const size_t lds = ctm_generic_lds_bytes(h->KP);
