@@ -68,6 +68,7 @@ struct CtmParams {
     int64_t n_docs = 0;
     float cg_tol2 = 1e-8f, cg_abs2 = 0.0f;
     int cg_maxit = 200;
+    int tile_rows = 32;               // rows of a wave's topic tile window
     unsigned long long* cg_diag = nullptr;   // [0] CG trips, [1] Newton trips, [2] documents
 };
 
@@ -510,25 +511,36 @@ __global__ __launch_bounds__(1024) void ctm_reorder_kernel(const int32_t* __rest
 // direction, ~5 mat-vecs per Newton step instead of K^3 / 3 eliminations through LDS.  The gradient's invsigma (mu - lambda) uses
 // the same fp32 mat-vec (as in the lane-per-document kernel: the rounding is 10 - 100 times below ntol).
 #define CTM_GENERIC_TILE_ROWS 32
-static size_t ctm_generic_wave_floats(int KP) { return (size_t)CTM_GENERIC_TILE_ROWS * KP + 2 * (size_t)KP + 6 * CTM_GENERIC_TILE_ROWS + 2 * (size_t)KP; }
-static size_t ctm_generic_lds_bytes(int KP, int waves = 1)
+// waves per workgroup of the CG form (= per CU): the latency of the token gathers and of the CG's reduction chains is hidden by other
+// waves only, so as many as registers and LDS allow -- K <= 64 (one topic slot): 12 (168 VGPRs); K > 64: 12, or 8 (256 VGPRs) for KP > 108
+static size_t ctm_generic_wave_floats(int KP, int tile_rows = CTM_GENERIC_TILE_ROWS) { return (size_t)tile_rows * KP + 2 * (size_t)KP + 6 * (size_t)tile_rows + 2 * (size_t)KP; }
+static size_t ctm_generic_lds_bytes(int KP, int waves = 1, int tile_rows = CTM_GENERIC_TILE_ROWS)
 {
-    return ((size_t)KP * KP + (size_t)waves * ctm_generic_wave_floats(KP)) * sizeof(float);
+    return ((size_t)KP * KP + (size_t)waves * ctm_generic_wave_floats(KP, tile_rows)) * sizeof(float);
 }
-// waves per workgroup of the CG form: what the CU's LDS holds next to the one copy of invsigma, at most two per SIMD
-static int ctm_generic_cg_waves(int KP)
+// Shape of the CG form's workgroup: waves (at most two per SIMD) and the rows of each wave's tile window, from what the CU's LDS holds
+// next to the one copy of invsigma.  max_waves (the instantiation's bound) while that leaves a window of 24 rows or more, else fewer
+// (never below four);
+// the window is capped at 128 rows.  TMVB_CTM_CG_WAVES / TMVB_CTM_CG_TILE override.
+static void ctm_generic_cg_shape(int KP, int max_waves, int* waves, int* tile_rows)
 {
-    const size_t room = 160 * 1024 - (size_t)KP * KP * sizeof(float);
-    return (int)std::max<size_t>(1, std::min<size_t>(8, room / (ctm_generic_wave_floats(KP) * sizeof(float))));
+    const size_t room = (160 * 1024 - (size_t)KP * KP * sizeof(float)) / sizeof(float);
+    auto rows_for = [&](int w) { const int64_t f = (int64_t)(room / (size_t)w) - 4 * KP; return (int)std::max<int64_t>(0, f / (KP + 6)); };
+    int w = max_waves;
+    while (w > 4 && rows_for(w) < 24) --w;
+    if (const char* e = getenv("TMVB_CTM_CG_WAVES")) w = std::min(max_waves, std::max(1, atoi(e)));
+    int t = std::min(128, rows_for(w)) & ~3;
+    if (const char* e = getenv("TMVB_CTM_CG_TILE")) t = std::min(t, std::max(4, atoi(e) & ~3));
+    *waves = w; *tile_rows = std::max(4, t);
 }
 
-template <int NS, bool FILT, bool CG = false>
-__global__ __launch_bounds__(CG ? 512 : 64) void ctm_estep_generic_kernel(CtmParams p, int64_t first)
+template <int NS, bool FILT, bool CG = false, int MAXW = 1>
+__global__ __launch_bounds__(64 * MAXW) void ctm_estep_generic_kernel(CtmParams p, int64_t first)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
     const int K = p.K, KP = p.KP, LPR = p.LPR;
-    constexpr int tile_rows = CTM_GENERIC_TILE_ROWS;
+    const int tile_rows = CG ? p.tile_rows : CTM_GENERIC_TILE_ROWS;   // CG: as many rows as the CU's LDS gives each wave (a document that fits stays resident over its sweeps)
     // CG: waves of a workgroup run different documents with different trip counts -- a wave-level fence (LDS operations of one wave
     // complete in program order) where the one-wave form uses the workgroup barrier
 #define GEN_FENCE() do { if constexpr (CG) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } else { __syncthreads(); } } while (0)
@@ -554,6 +566,7 @@ __global__ __launch_bounds__(CG ? 512 : 64) void ctm_estep_generic_kernel(CtmPar
     auto run_doc = [&](const int d) {
     const int64_t off = p.doc_ptr[d];
     const int N = (int)(p.doc_ptr[d + 1] - off);
+    const bool resident = CG && N <= tile_rows;         // the document's rows are gathered once, in its first sweep
 
     float cl = 0.0f;
     for (int n = lane; n < N; n += 64) cl += (float)p.counts[off + n];
@@ -646,6 +659,7 @@ __global__ __launch_bounds__(CG ? 512 : 64) void ctm_estep_generic_kernel(CtmPar
             const float prod = __expf(fminf(-(a / s), 87.0f));
             const float tnew = p.eta / (TMVB_EPS_F + (p.eta + (1.0f - p.eta) * (p.kappa[t_l[n]] * prod)));
             tp_l[n] = tp; m_l[n] = m; w_l[n] = c_l[n] / s;
+            tn_l[n] = tnew;                                                                                 // (a resident tile is not loaded again)
             p.tau_old[off + c0 + n] = tp; p.tau[off + c0 + n] = tnew; p.lse[off + c0 + n] = m + __logf(s);   // streamed window: always stored
         }
         GEN_FENCE();
@@ -682,7 +696,7 @@ __global__ __launch_bounds__(CG ? 512 : 64) void ctm_estep_generic_kernel(CtmPar
             GEN_FENCE();
             for (int c0 = 0; c0 < N; c0 += tile_rows) {
                 const int rows = min(tile_rows, N - c0);
-                load_chunk(c0, rows);
+                if (!(resident && v > 0)) load_chunk(c0, rows);
                 filt_a(c0, rows);
                 filt_b(rows, acc);
                 GEN_FENCE();
@@ -701,7 +715,7 @@ __global__ __launch_bounds__(CG ? 512 : 64) void ctm_estep_generic_kernel(CtmPar
             GEN_FENCE();
             for (int c0 = 0; c0 < N; c0 += tile_rows) {
                 const int rows = min(tile_rows, N - c0);
-                load_chunk(c0, rows);
+                if (!(resident && v > 0)) load_chunk(c0, rows);
                 phase1(rows);
                 if (p.store_w)                       // last executed sweep wins (the exit sweep is not known in advance)
                     for (int n = lane; n < rows; n += 64) p.wtok[p.tok_inv[off + c0 + n]] = w_l[n];
@@ -1507,8 +1521,15 @@ static int ctm_launch_generic(tmvb_ctm* h, CtmParams p, double ntol)
     const bool use_cg = !(ecg && atoi(ecg) == 0);
     h->generic_cg = use_cg;
     if (use_cg) {
-        const int waves = ctm_generic_cg_waves(h->KP);
-        const size_t lds = ctm_generic_lds_bytes(h->KP, waves);
+        // instantiation by register budget: TMVB_CTM_CG_MAXW = 8 / 12 / 16 overrides the choice (measurements)
+        // (measured on SYN-NSF, ms per E-step at iteration 30: K = 53: 16 waves / 128 VGPRs 7.9, 12 / 168 8.1, 8 / 256 9.8;  K = 64: 9.0, 9.1, 11.3;
+        //  K = 80: 12 waves 15.4, 8 waves 18.0;  K = 100: 10 waves / 168 VGPRs 20.9, 8 / 256 22.3;  K = 128: 6 waves / 168 VGPRs 39.1, 6 / 256 37.1)
+        int maxw = (h->K <= 64 || h->KP <= 108) ? 12 : 8;
+        if (const char* e = getenv("TMVB_CTM_CG_MAXW")) { if (h->K > 64) maxw = (atoi(e) >= 12) ? 12 : 8; }
+        int waves, tile_rows;
+        ctm_generic_cg_shape(h->KP, maxw, &waves, &tile_rows);
+        p.tile_rows = tile_rows;
+        const size_t lds = ctm_generic_lds_bytes(h->KP, waves, tile_rows);
         TMVB_HIP(hipMemsetAsync(h->d_cg_iters, 0, 16 * sizeof(unsigned long long), ctx->stream));
         p.queue = (unsigned*)(h->d_cg_iters + 12); p.n_docs = h->M; p.cg_diag = h->d_cg_iters;
         p.cg_tol2 = h->cg_tol * h->cg_tol; p.cg_maxit = 4 * h->KP;
@@ -1519,7 +1540,9 @@ static int ctm_launch_generic(tmvb_ctm* h, CtmParams p, double ntol)
             hipLaunchKernelGGL(kern, dim3(nwg), dim3(64 * waves), lds, ctx->stream, p, (int64_t)0);
             return TMVB_OK;
         };
-        int lrc = (h->K > 64) ? launch(ctm_estep_generic_kernel<2, FILT, true>) : launch(ctm_estep_generic_kernel<1, FILT, true>);   // (K = 61 ... 64: KP = 68, but one topic slot per lane)
+        int lrc;
+        if (h->K <= 64) lrc = launch(ctm_estep_generic_kernel<1, FILT, true, 12>);   // (K = 61 ... 64: KP = 68, but one topic slot per lane)
+        else lrc = (maxw == 12) ? launch(ctm_estep_generic_kernel<2, FILT, true, 12>) : launch(ctm_estep_generic_kernel<2, FILT, true, 8>);
         if (lrc) return lrc;
     } else {
         const size_t lds = ctm_generic_lds_bytes(h->KP);
@@ -1528,7 +1551,7 @@ static int ctm_launch_generic(tmvb_ctm* h, CtmParams p, double ntol)
             hipLaunchKernelGGL(kern, dim3((unsigned)h->M), dim3(64), lds, ctx->stream, p, (int64_t)0);
             return TMVB_OK;
         };
-        int lrc = (h->KP > 64) ? launch(ctm_estep_generic_kernel<2, FILT, false>) : launch(ctm_estep_generic_kernel<1, FILT, false>);
+        int lrc = (h->KP > 64) ? launch(ctm_estep_generic_kernel<2, FILT, false, 1>) : launch(ctm_estep_generic_kernel<1, FILT, false, 1>);
         if (lrc) return lrc;
     }
     TMVB_HIP(hipGetLastError());
