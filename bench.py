@@ -191,6 +191,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-plateau", action="store_true")
     ap.add_argument("--no-cold", action="store_true")
+    ap.add_argument("--other-configs-inline", action="store_true", help="measure the side configurations in this process instead of fresh ones")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the lines of BASELINE.json's configs 3-5 (LDA K=100, CTM K=50, CTPF K=50) carried under other_configs at N=1")
     args = ap.parse_args()
@@ -422,10 +423,24 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import model_bench
             others = {}
-            for name in ("lda100", "ctm", "ctpf"):             # the GPU windows first, back to back (the clocks stay up) ...
+            # The GPU windows first, back to back (the clocks stay up), each in a FRESH process: the iteration time of a model depends
+            # on how many hardware queues the process's streams, past and present, have been mapped onto (LDA K = 100: 835 it/s as the
+            # first model of a process, 750 behind the models this process has already closed -- DESIGN.md section 4c), and these lines
+            # report the configuration, not this process's history.  --other-configs-inline runs them here instead.
+            import subprocess
+            for name in ("lda100", "ctm", "ctpf"):
                 t_c = time.perf_counter()
                 try:
-                    others[name] = model_bench.ALL[name](cpu=False)
+                    if args.other_configs_inline:
+                        others[name] = model_bench.ALL[name](cpu=False)
+                    else:
+                        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "model_bench.py"), "--gpu-only", name], capture_output=True,
+                                             text=True, timeout=900, cwd=ROOT)
+                        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+                        if out.returncode != 0 or not lines:
+                            raise RuntimeError(f"model_bench.py {name} failed (rc {out.returncode}): {out.stderr[-300:]}")
+                        others[name] = json.loads(lines[-1])
+                        others[name]["process"] = "fresh process (python tools/model_bench.py --gpu-only " + name + ")"
                 except Exception as e:                       # a failing side line must not cost the headline
                     others[name] = {"error": f"{type(e).__name__}: {e}"}
                 log(f"other_configs[{name}] GPU window done in {time.perf_counter() - t_c:.1f}s")

@@ -101,8 +101,7 @@ def lda100_cpu(pc=None):
     return out
 
 
-def ctm(burnin=30, warmup=2, steps=8, cpu=True):
-    K = 50
+def ctm(burnin=30, warmup=2, steps=8, cpu=True, K=50):
     pc = tm.syn_nsf()
     gm = tm.gpuCTM(pc, K)
     beta0 = tm.dirichlet_rows(K, pc.V, seed=7)
@@ -116,20 +115,24 @@ def ctm(burnin=30, warmup=2, steps=8, cpu=True):
     hist, newton = gm.sweep_hist()
     st = gm.solver_stats()
     sweeps = int(sum(i * int(h) for i, h in enumerate(hist)))
-    KP = 52
+    KP = 4 * ((K + 3) // 4); KP += 4 * (1 - (KP // 4) % 2)          # 4 * odd
+    lane_kernel = KP <= 52
     B = pc.nnz * (8 + 8 * K) + 16 * pc.M * K + 8 * pc.M + 12 * K * pc.V + 8 * K * K
     tok = 6.0 * K * pc.nnz * (sweeps / pc.M)
     F_nom = newton * (K ** 3 / 3.0 + 4 * K * K) + tok
     # what the lane-per-document kernel issues: a wave runs every loop until its slowest lane is done (64 lanes per trip);
     # one CG trip = one K x K mat-vec + 5 vector updates, one Newton trip = the gradient's mat-vec + exp / assembly
-    F_exec = 64.0 * (st["cg_trips"] * (2 * KP * KP + 12 * KP) + st["newton_trips"] * (2 * KP * KP + 24 * KP)) + tok if st["waves"] else None
-    line = {"metric": "VB iters/sec, CTM K=50 on NSF-shaped corpus (config 4)", "value": 1.0 / sec, "unit": "VB iters/sec",
+    # (the K > 52 kernel runs one wave per document: its trip counts are per document)
+    per_trip = 64.0 if lane_kernel else 1.0
+    F_exec = per_trip * (st["cg_trips"] * (2 * KP * KP + 12 * KP) + st["newton_trips"] * (2 * KP * KP + 24 * KP)) + tok if st["waves"] else None
+    line = {"metric": f"VB iters/sec, CTM K={K} on NSF-shaped corpus" + (" (config 4)" if K == 50 else ""), "value": 1.0 / sec, "unit": "VB iters/sec",
             "ms_per_step": 1e3 * sec, "estep_ms": es_ms, "dtype": "f32 (fp64 gradients / logzeta / vsq)", "data": "synthetic",
-            "config": {"workload": f"CTM K=50, SYN-NSF, train! defaults (niter=1000 ntol=1/K^2 viter=10 vtol=1/K^2), steady state: {burnin} untimed "
+            "config": {"workload": f"CTM K={K}, SYN-NSF, train! defaults (niter=1000 ntol=1/K^2 viter=10 vtol=1/K^2), steady state: {burnin} untimed "
                                    f"iterations from the cold start, then {warmup} warm-up + {steps} timed",
                        "M": pc.M, "V": pc.V, "nnz": pc.nnz, "lambda_newton_steps_last_iteration": int(newton), "sweeps_last_iteration": sweeps,
                        "sweep_hist_last_step": [int(h) for h in hist],
-                       "kernel": "ctm_estep_batch_kernel (lane per document, Jacobi-preconditioned CG Newton solves)" if st["waves"] else "wave per document",
+                       "kernel": ("ctm_estep_batch_kernel (lane per document, Jacobi-preconditioned CG Newton solves)" if lane_kernel else
+                                  "ctm_estep_generic_kernel<.., CG> (wave per document, lane = matrix row, CG against invsigma in LDS)") if st["waves"] else "wave per document",
                        "cg_wave_trips": st["cg_trips"], "newton_wave_trips": st["newton_trips"]},
             "cold_start": {"value": 1.0 / cold, "ms_per_step": 1e3 * cold, "window": f"iterations {warmup + 1}..{warmup + steps} from the cold start"},
             "roofline": {"bound": "valu (packed fp32 CG mat-vecs with invsigma streamed through SGPRs; f32 MFMA has the same peak and is not used in the solve)",
@@ -141,9 +144,14 @@ def ctm(burnin=30, warmup=2, steps=8, cpu=True):
                          "executed_is": "64 lanes x (CG wave trips x (2 KP^2 + 12 KP) + Newton wave trips x (2 KP^2 + 24 KP)) + token phase; idle lanes of a trip included",
                          "hbm_GBs": B / sec / 1e9, "hbm_frac": B / sec / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_iteration": B, "traffic": None}}
     gm.close()
-    if cpu:
+    if cpu and K == 50:
         line["cpu_baseline"] = ctm_cpu(pc)
     return line
+
+
+def ctm100(cpu=False):
+    """CTM K = 100 on SYN-NSF (not a BASELINE.json configuration: the K > 52 kernel's line, no CPU baseline)."""
+    return ctm(burnin=20, warmup=2, steps=6, cpu=False, K=100)
 
 
 def ctm_cpu(pc=None):
@@ -275,10 +283,12 @@ def fctm(burnin=30, warmup=2, steps=6, cpu=True):
     return line
 
 
-ALL = {"lda100": lda100, "ctm": ctm, "ctpf": ctpf, "flda": flda, "fctm": fctm}
+ALL = {"lda100": lda100, "ctm": ctm, "ctpf": ctpf, "flda": flda, "fctm": fctm, "ctm100": ctm100}
 CPU = {"lda100": lda100_cpu, "ctm": ctm_cpu, "ctpf": ctpf_cpu}
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or list(ALL)
+    argv = sys.argv[1:]
+    gpu_only = "--gpu-only" in argv                       # no cpu_baseline (bench.py adds it from its own process)
+    which = [a for a in argv if not a.startswith("--")] or list(ALL)
     for w in which:
-        print(json.dumps(ALL[w]()), flush=True)
+        print(json.dumps(ALL[w](cpu=False) if gpu_only else ALL[w]()), flush=True)

@@ -15,6 +15,8 @@
 #include <algorithm>
 #include <cstring>
 #include <numeric>
+#include <map>
+#include <mutex>
 
 static thread_local std::string g_last_error;
 
@@ -41,6 +43,50 @@ extern "C" int tmvb_device_count(void)
     return n;
 }
 
+// see tmvb_internal.h
+bool tmvb_streams_pooled()
+{
+    static const bool on = [] { const char* e = getenv("TMVB_STREAM_POOL"); return e && atoi(e) != 0; }();   // opt-in, see tmvb_internal.h
+    return on;
+}
+
+void tmvb_release_stream(hipStream_t st)
+{
+    if (st && !tmvb_streams_pooled()) (void)hipStreamDestroy(st);
+}
+
+hipStream_t tmvb_pool_stream(int device, int slot, bool high_priority)
+{
+    if (!tmvb_streams_pooled()) {                         // TMVB_STREAM_POOL=0: a stream of the caller's own (tmvb_release_stream destroys it)
+        hipStream_t st = nullptr;
+        hipError_t e;
+        if (high_priority) { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi); e = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi); }
+        else e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        if (e != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        return st;
+    }
+    static std::mutex mu;
+    static std::map<std::pair<int, int>, hipStream_t> pool;
+    std::lock_guard<std::mutex> lk(mu);
+    const std::pair<int, int> key{device, high_priority ? 1000 + slot : slot};
+    auto it = pool.find(key);
+    if (it != pool.end()) return it->second;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    (void)hipSetDevice(device);
+    hipStream_t st = nullptr;
+    hipError_t e;
+    if (high_priority) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        e = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi);
+    } else e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    (void)hipSetDevice(cur);
+    if (e != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    pool[key] = st;
+    return st;
+}
+
 extern "C" int tmvb_ctx_create(int32_t device_id, void* hip_stream, tmvb_ctx** out)
 {
     TMVB_REQUIRE(out != nullptr, TMVB_EINVAL, "tmvb_ctx_create: out is NULL");
@@ -60,13 +106,13 @@ extern "C" int tmvb_ctx_create(int32_t device_id, void* hip_stream, tmvb_ctx** o
         c->stream = (hipStream_t)hip_stream;
         c->own_stream = false;
     } else {
-        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-        if (e != hipSuccess) {
+        c->stream = tmvb_pool_stream(device_id, 0);
+        if (!c->stream) {
             delete c;
-            tmvb_set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+            tmvb_set_error("hipStreamCreate failed");
             return TMVB_EHIP;
         }
-        c->own_stream = true;
+        c->own_stream = !tmvb_streams_pooled();           // pooled: lives as long as the process
     }
     *out = c;
     return TMVB_OK;

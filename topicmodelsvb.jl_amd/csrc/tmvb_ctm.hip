@@ -1289,7 +1289,7 @@ extern "C" int tmvb_ctm_destroy(tmvb_ctm* h)
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     for (int a = 0; a < tmvb_ctm::NAUX; ++a) {
         if (h->ev_join[a]) (void)hipEventDestroy(h->ev_join[a]);
-        if (h->aux[a]) (void)hipStreamDestroy(h->aux[a]);
+        tmvb_release_stream(h->aux[a]); h->aux[a] = nullptr;        // pooled streams stay (tmvb_pool_stream)
     }
     delete h;
     return TMVB_OK;
@@ -1395,6 +1395,7 @@ extern "C" int tmvb_ctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
     if (h->M) TMVB_HIP(hipMemcpyAsync(h->d_doc_order, order.data(), (size_t)h->M * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     if (h->M) TMVB_HIP(hipMemcpyAsync(h->d_doc_order0, order.data(), (size_t)h->M * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     TMVB_HIP(hipMemsetAsync(h->d_doc_newton, 0, std::max<size_t>((size_t)h->M, 1) * sizeof(uint16_t), ctx->stream));
+    TMVB_HIP(hipMemsetAsync(h->d_cg_iters, 0, 16 * sizeof(unsigned long long), ctx->stream));      // tmvb_ctm_solver_stats before the first E-step
     TMVB_HIP(hipMemsetAsync(h->d_stats, 0, (size_t)h->stats_len() * sizeof(float), ctx->stream));
     TMVB_HIP(hipMemsetAsync(h->d_sweeps, 0, std::max<size_t>((size_t)h->M, 1), ctx->stream));
     TMVB_HIP(hipMemsetAsync(h->d_newton, 0, sizeof(unsigned long long), ctx->stream));
@@ -1405,7 +1406,8 @@ extern "C" int tmvb_ctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
     TMVB_HIP(hipEventCreate(&h->ev1));
     TMVB_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     for (int a = 0; a < tmvb_ctm::NAUX; ++a) {
-        TMVB_HIP(hipStreamCreateWithFlags(&h->aux[a], hipStreamNonBlocking));
+        h->aux[a] = tmvb_pool_stream(ctx->device, 1 + a);
+        TMVB_REQUIRE(h->aux[a] != nullptr, TMVB_EHIP, "hipStreamCreate failed");
         TMVB_HIP(hipEventCreateWithFlags(&h->ev_join[a], hipEventDisableTiming));
     }
     TMVB_HIP(hipStreamSynchronize(ctx->stream));

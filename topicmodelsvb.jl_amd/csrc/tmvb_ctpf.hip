@@ -1037,7 +1037,7 @@ extern "C" int tmvb_ctpf_destroy(tmvb_ctpf* h)
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     for (int a = 0; a < tmvb_ctpf::NAUX; ++a) {
         if (h->ev_join[a]) (void)hipEventDestroy(h->ev_join[a]);
-        if (h->aux[a]) (void)hipStreamDestroy(h->aux[a]);
+        tmvb_release_stream(h->aux[a]); h->aux[a] = nullptr;        // pooled streams stay (tmvb_pool_stream)
     }
     delete h;
     return TMVB_OK;
@@ -1166,10 +1166,8 @@ extern "C" int tmvb_ctpf_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmv
         // workgroups find no CU with eight free wave slots until the chain's launch drains and then add their whole run time to the
         // E-step; on a high-priority queue they are placed first (TMVB_CTPF_LONG_PRIO=0: default priority)
         static const bool long_prio = [] { const char* e = getenv("TMVB_CTPF_LONG_PRIO"); return !(e && atoi(e) == 0); }();
-        int prio_lo = 0, prio_hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-        if (a == 1 && long_prio) TMVB_HIP(hipStreamCreateWithPriority(&h->aux[a], hipStreamNonBlocking, prio_hi));
-        else TMVB_HIP(hipStreamCreateWithFlags(&h->aux[a], hipStreamNonBlocking));
+        h->aux[a] = tmvb_pool_stream(ctx->device, 1 + a, a == 1 && long_prio);
+        TMVB_REQUIRE(h->aux[a] != nullptr, TMVB_EHIP, "hipStreamCreate failed");
         TMVB_HIP(hipEventCreateWithFlags(&h->ev_join[a], hipEventDisableTiming));
     }
     TMVB_HIP(hipStreamSynchronize(ctx->stream));

@@ -13,6 +13,19 @@
 
 // ------------------------------------------------------------------------------------ errors
 void tmvb_set_error(const char* fmt, ...);
+// The library's HIP streams (tmvb_core.hip): slot 0 = a context's stream, slots 1 .. = the models' auxiliary streams.
+// Default: every context / model creates its own and destroys them with it.  TMVB_STREAM_POOL=1: one set per device for the life of
+// the process, shared by every context / model on that device (models alive at the same time then serialise).
+// Why the switch exists (profiles/r3_stream_pool.txt): the runtime maps streams onto a few hardware queues, and how many queues are
+// alive / which streams share one changes the iteration time by 6 - 10 % -- LDA K = 100 on SYN-NSF runs 835 it/s as the first model
+// of a process (or next to a live one) and 750 as a model built after another one was closed; with GPU_MAX_HW_QUEUES=8 the FIRST
+// model is the slow one (688), with 2 every model is (755).  The pool makes a sequence of models in a plain process all run at the
+// first model's rate (833 / 832 / ...), but inside a process that also drives torch streams (bench.py) its effect depended on what
+// had run before (LDA K = 100 712 ... 834, CTPF 1660 ... 5400 it/s), so it is not the default; bench.py measures each of its side
+// configurations in a fresh process instead.  An open item.
+hipStream_t tmvb_pool_stream(int device, int slot, bool high_priority = false);
+void tmvb_release_stream(hipStream_t st);            // no-op for pooled streams (TMVB_STREAM_POOL=0: destroys the caller's own stream)
+bool tmvb_streams_pooled();
 
 #define TMVB_HIP(call)                                                                         \
     do {                                                                                       \

@@ -1116,7 +1116,7 @@ extern "C" int tmvb_lda_destroy(tmvb_lda* h)
     for (hipEvent_t e : h->ev_piece) if (e) (void)hipEventDestroy(e);
     for (int a = 0; a < tmvb_lda::NAUX; ++a) {
         if (h->ev_join[a]) (void)hipEventDestroy(h->ev_join[a]);
-        if (h->aux[a]) (void)hipStreamDestroy(h->aux[a]);
+        tmvb_release_stream(h->aux[a]); h->aux[a] = nullptr;        // pooled streams stay (tmvb_pool_stream)
     }
     delete h;
     return TMVB_OK;
@@ -1239,7 +1239,8 @@ extern "C" int tmvb_lda_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
     TMVB_HIP(hipEventCreateWithFlags(&h->ev_mark, hipEventDisableTiming));
     if ((rc = dmalloc(&h->d_partial_side, (size_t)TMVB_REDUCE_BLOCKS * K)) || (rc = dmalloc(&h->d_pw_partial, 2048))) return rc;
     for (int a = 0; a < tmvb_lda::NAUX; ++a) {
-        TMVB_HIP(hipStreamCreateWithFlags(&h->aux[a], hipStreamNonBlocking));
+        h->aux[a] = tmvb_pool_stream(ctx->device, 1 + a);
+        TMVB_REQUIRE(h->aux[a] != nullptr, TMVB_EHIP, "hipStreamCreate failed");
         TMVB_HIP(hipEventCreateWithFlags(&h->ev_join[a], hipEventDisableTiming));
     }
     TMVB_HIP(hipMemsetAsync(h->d_beta[0], 0, KPV * sizeof(float), ctx->stream));
