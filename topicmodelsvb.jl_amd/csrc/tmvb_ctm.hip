@@ -447,12 +447,27 @@ __global__ __launch_bounds__(64) void ctm_estep_kernel(CtmParams p, int64_t firs
 #include "tmvb_ctm_batch.h"
 
 // 64-float padded copies of mu and of invsigma's diagonal for the batched kernel's block scalar loads
+// (and the launch's counters / work queue zeroed: one launch instead of a memset beside it)
 __global__ __launch_bounds__(64) void ctm_batch_tabs_kernel(int K, int KP, const float* __restrict__ invsigma_f, const float* __restrict__ mu_f,
-                                                            float* __restrict__ sdiag, float* __restrict__ muf)
+                                                            float* __restrict__ sdiag, float* __restrict__ muf, unsigned long long* __restrict__ counters16)
 {
     const int i = threadIdx.x;
     sdiag[i] = (i < KP) ? invsigma_f[i * KP + i] : 0.0f;
     muf[i] = (i < K) ? mu_f[i] : 0.0f;
+    if (i < 16) counters16[i] = 0ull;
+}
+
+// tmvb_ctm_update_sigma with a staged result: the staging buffers over sigma / invsigma (fp64), invsigma (fp32, padded), its log-determinant
+// and the status flag in one launch (five device-to-device copies were 30 us of launches)
+__global__ __launch_bounds__(256) void ctm_commit_sigma_kernel(int KK, int KPKP, const double* __restrict__ sigma_s, const double* __restrict__ invsigma_s,
+                                                               const float* __restrict__ invsigma_f_s, const double* __restrict__ logdet_s,
+                                                               const int* __restrict__ status_s, double* __restrict__ sigma, double* __restrict__ invsigma,
+                                                               float* __restrict__ invsigma_f, double* __restrict__ logdet, int* __restrict__ status)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < KK) { sigma[q] = sigma_s[q]; invsigma[q] = invsigma_s[q]; }
+    if (q < KPKP) invsigma_f[q] = invsigma_f_s[q];
+    if (q == 0) { *logdet = *logdet_s; *status = *status_s; }
 }
 
 // Regroup the documents of the lane-per-document kernel.  A wave runs every loop until its slowest lane is done: on SYN-NSF
@@ -1014,14 +1029,24 @@ __global__ __launch_bounds__(64) void ctm_scatter_mfma_kernel(const float* __res
     const float mui = (ri < K) ? mu[ri] : 0.0f;
     const float muj = (rj < K) ? mu[rj] : 0.0f;
     f32x16 c = {0};
-    for (int64_t d = d0; d < d1; d += 2) {
-        const int64_t dd = d + kk;
-        float a = 0.0f, bq = 0.0f;
-        if (dd < d1) {
-            if (ri < K) a = lambda[dd * K + ri] - mui;
-            if (rj < K) bq = lambda[dd * K + rj] - muj;
+    // eight document pairs per round, their 16 loads in flight together (one pair per round left the wave waiting a memory latency
+    // per MFMA: 179 us for the 128 804 x 50 lambda of SYN-NSF); rows past the slab / topics past K read a valid address and are zeroed
+    const bool oi = ri < K, oj = rj < K;
+    const int ci = oi ? ri : 0, cj = oj ? rj : 0;
+    for (int64_t d = d0; d < d1; d += 16) {
+        float a[8], bq[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t dd = d + 2 * u + kk;
+            const int64_t dc = dd < d1 ? dd : d0;
+            a[u] = lambda[dc * K + ci]; bq[u] = lambda[dc * K + cj];
         }
-        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, c, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool in = d + 2 * u + kk < d1;
+            const float av = (in && oi) ? a[u] - mui : 0.0f, bv = (in && oj) ? bq[u] - muj : 0.0f;
+            c = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, c, 0, 0, 0);
+        }
     }
     // C/D layout of 32x32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     float* out = partial + ((size_t)blockIdx.x * NB * NB + blockIdx.y) * 1024;
@@ -1251,13 +1276,19 @@ struct tmvb_ctm {
     double* d_sigma = nullptr; double* d_invsigma = nullptr; double* d_mu = nullptr; double* d_logdet = nullptr;
     float* d_scatter_partial = nullptr; int n_scatter_waves = 0; int64_t docs_per_wave = 0;
     uint8_t* d_sweeps = nullptr; int32_t* d_doc_order = nullptr;
-    double* d_partial = nullptr; double* d_partial_docs = nullptr; double* d_rowsum = nullptr; double* d_doc_val = nullptr; double* d_elbo = nullptr;
+    double* d_partial = nullptr; double* d_partial_docs = nullptr; double* d_partial_docs2 = nullptr; double* d_rowsum = nullptr; double* d_doc_val = nullptr; double* d_elbo = nullptr;
     unsigned long long* d_newton = nullptr; int* d_status = nullptr;
     double elbo = 0.0;
     std::vector<tmvb_bucket> buckets;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     bool tail_fresh = false;           // the statistics tail (sum lambda | sum vsq | scatter) was computed by the last tmvb_ctm_estep
+    // ... and, one process, behind it on the same side stream: update_sigma!'s result into staging buffers (tmvb_ctm_update_sigma then
+    // only copies them over -- the 115 us fp64 inversion leaves the iteration's critical path) and the regrouping of the documents for
+    // the NEXT E-step (ctm_reorder_kernel; it used to run in front of that E-step).  ev_spec marks their end.
+    bool sigma_staged = false, reorder_staged = false, spec_pending = false;
+    double* d_sigma_s = nullptr; double* d_invsigma_s = nullptr; float* d_invsigma_f_s = nullptr; double* d_logdet_s = nullptr; int* d_status_s = nullptr;
+    hipEvent_t ev_spec = nullptr;
     static constexpr int NAUX = 4;
     hipStream_t aux[NAUX] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[NAUX] = {nullptr, nullptr, nullptr, nullptr};
@@ -1282,11 +1313,13 @@ extern "C" int tmvb_ctm_destroy(tmvb_ctm* h)
     (void)hipFree(h->d_bt_sdiag); (void)hipFree(h->d_bt_muf); (void)hipFree(h->d_cg_iters); (void)hipFree(h->d_doc_newton); (void)hipFree(h->d_doc_order0);
     (void)hipFree(h->d_mu_f); (void)hipFree(h->d_sigma); (void)hipFree(h->d_invsigma); (void)hipFree(h->d_mu);
     (void)hipFree(h->d_logdet); (void)hipFree(h->d_scatter_partial); (void)hipFree(h->d_sweeps); (void)hipFree(h->d_doc_order);
-    (void)hipFree(h->d_partial); (void)hipFree(h->d_partial_docs); (void)hipFree(h->d_rowsum); (void)hipFree(h->d_doc_val); (void)hipFree(h->d_elbo);
+    (void)hipFree(h->d_partial); (void)hipFree(h->d_partial_docs); (void)hipFree(h->d_partial_docs2); (void)hipFree(h->d_rowsum); (void)hipFree(h->d_doc_val); (void)hipFree(h->d_elbo);
     (void)hipFree(h->d_newton); (void)hipFree(h->d_status);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_spec) (void)hipEventDestroy(h->ev_spec);
+    (void)hipFree(h->d_sigma_s); (void)hipFree(h->d_invsigma_s); (void)hipFree(h->d_invsigma_f_s); (void)hipFree(h->d_logdet_s); (void)hipFree(h->d_status_s);
     for (int a = 0; a < tmvb_ctm::NAUX; ++a) {
         if (h->ev_join[a]) (void)hipEventDestroy(h->ev_join[a]);
         tmvb_release_stream(h->aux[a]); h->aux[a] = nullptr;        // pooled streams stay (tmvb_pool_stream)
@@ -1322,6 +1355,8 @@ extern "C" int tmvb_ctm_set_state(tmvb_ctm* h, const double* mu, const double* s
                                   const double* lambda_old, const double* vsq, const double* logzeta, const double* elbo);
 
 static int ctm_reduce_docs_on(tmvb_ctm* h, hipStream_t st);
+static int ctm_join_spec(tmvb_ctm* h);
+static int ctm_sigma_mu(tmvb_ctm* h, int do_sigma, int do_mu, bool staged, hipStream_t st);
 
 extern "C" int tmvb_ctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb_ctm** out)
 {
@@ -1348,9 +1383,11 @@ extern "C" int tmvb_ctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
         (rc = dmalloc(&h->d_ts_partial, (size_t)corp->term_index.n_slots * (K + 1))) ||
         (rc = dmalloc(&h->d_invsigma_f, (size_t)h->KP * h->KP + 64)) || (rc = dmalloc(&h->d_mu_f, K)) ||
         (rc = dmalloc(&h->d_sigma, (size_t)K * K)) || (rc = dmalloc(&h->d_invsigma, (size_t)K * K)) || (rc = dmalloc(&h->d_mu, K)) ||
+        (rc = dmalloc(&h->d_sigma_s, (size_t)K * K)) || (rc = dmalloc(&h->d_invsigma_s, (size_t)K * K)) || (rc = dmalloc(&h->d_invsigma_f_s, (size_t)h->KP * h->KP + 64)) ||
+        (rc = dmalloc(&h->d_logdet_s, 1)) || (rc = dmalloc(&h->d_status_s, 1)) ||
         (rc = dmalloc(&h->d_logdet, 1)) || (rc = dmalloc(&h->d_scatter_partial, (size_t)h->n_scatter_waves * h->NB * h->NB * 1024)) ||
         (rc = dmalloc(&h->d_sweeps, (size_t)h->M)) || (rc = dmalloc(&h->d_doc_order, (size_t)h->M)) ||
-        (rc = dmalloc(&h->d_partial, (size_t)TMVB_REDUCE_BLOCKS * K)) || (rc = dmalloc(&h->d_partial_docs, (size_t)TMVB_REDUCE_BLOCKS * K)) ||
+        (rc = dmalloc(&h->d_partial, (size_t)TMVB_REDUCE_BLOCKS * K)) || (rc = dmalloc(&h->d_partial_docs, (size_t)TMVB_REDUCE_BLOCKS * K)) || (rc = dmalloc(&h->d_partial_docs2, (size_t)TMVB_REDUCE_BLOCKS * K)) ||
         (rc = dmalloc(&h->d_rowsum, K)) ||
         (rc = dmalloc(&h->d_doc_val, (size_t)h->M)) || (rc = dmalloc(&h->d_elbo, 1)) || (rc = dmalloc(&h->d_newton, 1)) ||
         (rc = dmalloc(&h->d_status, 1))) {
@@ -1405,6 +1442,7 @@ extern "C" int tmvb_ctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
     TMVB_HIP(hipEventCreate(&h->ev0));
     TMVB_HIP(hipEventCreate(&h->ev1));
     TMVB_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    TMVB_HIP(hipEventCreateWithFlags(&h->ev_spec, hipEventDisableTiming));
     for (int a = 0; a < tmvb_ctm::NAUX; ++a) {
         h->aux[a] = tmvb_pool_stream(ctx->device, 1 + a);
         TMVB_REQUIRE(h->aux[a] != nullptr, TMVB_EHIP, "hipStreamCreate failed");
@@ -1448,7 +1486,7 @@ extern "C" int tmvb_ctm_set_state(tmvb_ctm* h, const double* mu, const double* s
                                   const double* lambda_old, const double* vsq, const double* logzeta, const double* elbo)
 {
     TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_ctm_set_state: handle is NULL");
-    h->tail_fresh = false;
+    h->tail_fresh = false; h->sigma_staged = false;
     tmvb_ctx* ctx = h->ctx;
     TMVB_HIP(hipSetDevice(ctx->device));
     const size_t K = h->K, KP = h->KP, KM = K * (size_t)h->M;
@@ -1565,9 +1603,8 @@ template <bool FILT>
 static int ctm_launch_batch(tmvb_ctm* h, const CtmParams& p, double ntol)
 {
     tmvb_ctx* ctx = h->ctx;
-    hipLaunchKernelGGL(ctm_batch_tabs_kernel, dim3(1), dim3(64), 0, ctx->stream, h->K, h->KP, h->d_invsigma_f, h->d_mu_f, h->d_bt_sdiag, h->d_bt_muf);
+    hipLaunchKernelGGL(ctm_batch_tabs_kernel, dim3(1), dim3(64), 0, ctx->stream, h->K, h->KP, h->d_invsigma_f, h->d_mu_f, h->d_bt_sdiag, h->d_bt_muf, h->d_cg_iters);
     TMVB_HIP(hipGetLastError());
-    TMVB_HIP(hipMemsetAsync(h->d_cg_iters, 0, 16 * sizeof(unsigned long long), ctx->stream));
     CtmBatchTabs tb;
     tb.S = h->d_invsigma_f; tb.sdiag = h->d_bt_sdiag; tb.muf = h->d_bt_muf;
     tb.cg_tol2 = h->cg_tol * h->cg_tol; tb.cg_maxit = 4 * h->KP; tb.cg_iters = h->d_cg_iters;
@@ -1575,7 +1612,7 @@ static int ctm_launch_batch(tmvb_ctm* h, const CtmParams& p, double ntol)
     const int64_t Mb = h->M - h->n_long;                 // the documents behind the long ones in the processing order
     if (Mb <= 0) return TMVB_OK;
     // persistent launch: one 64-lane workgroup per SIMD of the device (the kernel takes a whole SIMD's register file), each pulling
-    // waves-of-documents from the queue at d_cg_iters[12] (zeroed above); the order of the queue is the processing order, longest
+    // waves-of-documents from the queue at d_cg_iters[12] (zeroed by ctm_batch_tabs_kernel); the order of the queue is the processing order, longest
     // documents first.  TMVB_CTM_PERSISTENT=0: one workgroup per wave-of-documents, placed by the hardware dispatcher.
     const int n_items = (int)((Mb + 63) / 64);
     static const bool persistent = [] { const char* e = getenv("TMVB_CTM_PERSISTENT"); return !(e && atoi(e) == 0); }();
@@ -1583,11 +1620,12 @@ static int ctm_launch_batch(tmvb_ctm* h, const CtmParams& p, double ntol)
     const int per_cu = (int)std::min<size_t>(4, (160 * 1024) / lds);      // one wave per SIMD, and what the CU's LDS holds
     const dim3 grid((unsigned)(persistent ? std::min(n_items, per_cu * ctx->num_cu) : n_items)), block(64);
     tb.next_item = (unsigned*)(h->d_cg_iters + 12); tb.n_items = n_items;
-    if (h->reorder && h->keys_valid) {
+    if (h->reorder && h->keys_valid && !h->reorder_staged) {      // (staged: the last tmvb_ctm_estep already regrouped behind its statistics tail)
         hipLaunchKernelGGL(ctm_reorder_kernel, dim3((unsigned)((Mb + CTM_REORDER_CHUNK - 1) / CTM_REORDER_CHUNK)), dim3(1024), 0, ctx->stream,
                            h->d_doc_order0 + h->n_long, h->d_doc_newton, h->d_doc_order + h->n_long, Mb);
         TMVB_HIP(hipGetLastError());
     }
+    h->reorder_staged = false;
     h->keys_valid = true;
     CtmBatchArgs ba;
     ba.p = p; ba.p.doc_order = p.doc_order + h->n_long; ba.p.doc_newton = h->d_doc_newton; ba.tb = tb; ba.M = Mb;
@@ -1632,6 +1670,7 @@ extern "C" int tmvb_ctm_estep(tmvb_ctm* h, int32_t niter, double ntol, int32_t v
     p.niter = niter; p.ntol = ntol; p.viter = viter; p.vtol = vtol;
     { const char* dbg = getenv("TMVB_DEBUG_FLAGS"); p.debug = dbg ? atoi(dbg) : 0; }
     p.store_w = tmvb_termstats_recomputes(h->KP, true) ? 0 : 1;
+    { int jrc = ctm_join_spec(h); if (jrc) return jrc; }        // the regrouped document order of the last E-step's side stream
     TMVB_HIP(hipEventRecord(h->ev0, ctx->stream));
     TMVB_HIP(hipMemsetAsync(h->d_newton, 0, sizeof(unsigned long long), ctx->stream));
     if (h->generic && h->M > 0) {
@@ -1679,6 +1718,23 @@ extern "C" int tmvb_ctm_estep(tmvb_ctm* h, int32_t niter, double ntol, int32_t v
         int frc = ctm_reduce_docs_on(h, h->aux[0]);
         if (frc) return frc;
         TMVB_HIP(hipEventRecord(h->ev_join[0], h->aux[0]));
+        // behind the tail, still under the statistics pass: update_sigma! staged (single process only: a sharded run all-reduces the
+        // tail first) and the documents regrouped for the next E-step
+        static const bool spec = [] { const char* e = getenv("TMVB_CTM_SPECULATE"); return !(e && atoi(e) == 0); }();
+        if (spec) {
+            if (!h->distributed) { frc = ctm_sigma_mu(h, 1, 0, true, h->aux[0]); if (frc) return frc; h->sigma_staged = true; }
+            if (h->batch && h->reorder && h->keys_valid) {
+                const int64_t Mb = h->M - h->n_long;
+                if (Mb > 0) {
+                    hipLaunchKernelGGL(ctm_reorder_kernel, dim3((unsigned)((Mb + CTM_REORDER_CHUNK - 1) / CTM_REORDER_CHUNK)), dim3(1024), 0, h->aux[0],
+                                       h->d_doc_order0 + h->n_long, h->d_doc_newton, h->d_doc_order + h->n_long, Mb);
+                    TMVB_HIP(hipGetLastError());
+                    h->reorder_staged = true;
+                }
+            }
+            TMVB_HIP(hipEventRecord(h->ev_spec, h->aux[0]));
+            h->spec_pending = true;
+        }
     }
     // update_beta!(model, d)  src/CTM.jl:122-125 as the gather-side statistics pass (no epsilon in CTM's phi)
     TermStatsParams tp;
@@ -1698,8 +1754,13 @@ static int ctm_reduce_docs_on(tmvb_ctm* h, hipStream_t st)
 {
     tmvb_ctx* ctx = h->ctx;
     int rc;
-    if ((rc = tmvb_colsum(ctx, h->nslot, h->K, h->d_lambda, h->M, h->d_partial_docs, nullptr, h->tail(), st))) return rc;
-    if ((rc = tmvb_colsum(ctx, h->nslot, h->K, h->d_vsq, h->M, h->d_partial_docs, nullptr, h->tail() + h->K, st))) return rc;
+    if (h->K <= 64) {       // sum lambda and sum vsq in one pair of launches (same blocks, same summation order as tmvb_colsum)
+        if ((rc = tmvb_colsum2(ctx, h->K, {h->d_lambda, h->M, h->d_partial_docs, nullptr, h->tail()},
+                               {h->d_vsq, h->M, h->d_partial_docs2, nullptr, h->tail() + h->K}, st))) return rc;
+    } else {
+        if ((rc = tmvb_colsum(ctx, h->nslot, h->K, h->d_lambda, h->M, h->d_partial_docs, nullptr, h->tail(), st))) return rc;
+        if ((rc = tmvb_colsum(ctx, h->nslot, h->K, h->d_vsq, h->M, h->d_partial_docs, nullptr, h->tail() + h->K, st))) return rc;
+    }
     if (h->M > 0) {
         hipLaunchKernelGGL(ctm_scatter_mfma_kernel, dim3(h->n_scatter_waves, h->NB * h->NB), dim3(64), 0, st, h->d_lambda, h->d_mu_f,
                            h->K, h->NB, h->M, h->docs_per_wave, h->d_scatter_partial);
@@ -1768,29 +1829,55 @@ extern "C" int tmvb_ctm_update_beta(tmvb_ctm* h)
     return TMVB_OK;
 }
 
-static int ctm_sigma_mu(tmvb_ctm* h, int do_sigma, int do_mu)
+// staged = true: update_sigma! into the staging buffers on stream st (tmvb_ctm_estep's side stream)
+static int ctm_sigma_mu(tmvb_ctm* h, int do_sigma, int do_mu, bool staged, hipStream_t st)
 {
     tmvb_ctx* ctx = h->ctx;
     TMVB_HIP(hipSetDevice(ctx->device));
     const size_t lds = (size_t)h->K * h->K * sizeof(double);
     if (lds > 48 * 1024) TMVB_HIP(hipFuncSetAttribute((const void*)ctm_sigma_mu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(ctm_sigma_mu_kernel, dim3(1), dim3(256), lds, ctx->stream, h->K, h->KP, (double)h->M_total, h->tail(),
-                       h->d_sigma, h->d_invsigma, h->d_invsigma_f, h->d_mu, h->d_mu_f, h->d_logdet, h->d_status, do_sigma, do_mu);
+    if (staged)
+        hipLaunchKernelGGL(ctm_sigma_mu_kernel, dim3(1), dim3(256), lds, st, h->K, h->KP, (double)h->M_total, h->tail(),
+                           h->d_sigma_s, h->d_invsigma_s, h->d_invsigma_f_s, h->d_mu, h->d_mu_f, h->d_logdet_s, h->d_status_s, 1, 0);
+    else
+        hipLaunchKernelGGL(ctm_sigma_mu_kernel, dim3(1), dim3(256), lds, ctx->stream, h->K, h->KP, (double)h->M_total, h->tail(),
+                           h->d_sigma, h->d_invsigma, h->d_invsigma_f, h->d_mu, h->d_mu_f, h->d_logdet, h->d_status, do_sigma, do_mu);
     TMVB_HIP(hipGetLastError());
+    return TMVB_OK;
+}
+
+// the context's stream waits for what tmvb_ctm_estep left running on its side stream behind the statistics tail
+static int ctm_join_spec(tmvb_ctm* h)
+{
+    if (h->spec_pending) { TMVB_HIP(hipStreamWaitEvent(h->ctx->stream, h->ev_spec, 0)); h->spec_pending = false; }
     return TMVB_OK;
 }
 
 extern "C" int tmvb_ctm_update_sigma(tmvb_ctm* h)
 {
     TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_ctm_update_sigma: handle is NULL");
-    return ctm_sigma_mu(h, 1, 0);
+    if (h->sigma_staged) {
+        // tmvb_ctm_estep already inverted: sigma of exactly this statistics tail (any change of lambda / vsq / mu / the tail through the
+        // API clears the flag) sits in the staging buffers
+        tmvb_ctx* ctx = h->ctx;
+        TMVB_HIP(hipSetDevice(ctx->device));
+        int jrc = ctm_join_spec(h);
+        if (jrc) return jrc;
+        const int KK = h->K * h->K, KPKP = h->KP * h->KP;
+        hipLaunchKernelGGL(ctm_commit_sigma_kernel, dim3((unsigned)((KPKP + 255) / 256)), dim3(256), 0, ctx->stream, KK, KPKP, h->d_sigma_s, h->d_invsigma_s,
+                           h->d_invsigma_f_s, h->d_logdet_s, h->d_status_s, h->d_sigma, h->d_invsigma, h->d_invsigma_f, h->d_logdet, h->d_status);
+        TMVB_HIP(hipGetLastError());
+        h->sigma_staged = false;
+        return TMVB_OK;
+    }
+    return ctm_sigma_mu(h, 1, 0, false, nullptr);
 }
 
 extern "C" int tmvb_ctm_update_mu(tmvb_ctm* h)
 {
     TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_ctm_update_mu: handle is NULL");
-    h->tail_fresh = false;                 // the scatter matrix of the tail was taken about the mu that changes now
-    return ctm_sigma_mu(h, 0, 1);
+    h->tail_fresh = false; h->sigma_staged = false;     // the scatter matrix of the tail was taken about the mu that changes now
+    return ctm_sigma_mu(h, 0, 1, false, nullptr);
 }
 
 extern "C" int tmvb_ctm_update_elbo(tmvb_ctm* h, double* elbo)
