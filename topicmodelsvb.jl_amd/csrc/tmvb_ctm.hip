@@ -509,6 +509,54 @@ __global__ __launch_bounds__(1024) void ctm_reorder_kernel(const int32_t* __rest
     }
 }
 
+// Queue order of the lane-per-document launch: whole waves-of-documents (64 consecutive entries of the regrouped order) sorted by
+// predicted time, longest first -- item time = 8.4 us x longest document + 37 us x Newton trips + const on SYN-NSF
+// (profiles/r3_ctm_wave_log.txt), the trips taken from last E-step's per-document step counts.  List scheduling wants the longest
+// items first; the length order alone leaves the Newton counts out (measured item times in queue order: 4456 us, longest first: 4382).
+// Per-document results do not depend on the grouping, and waves move whole.  Up to CTM_WAVESORT_MAX waves.
+#define CTM_WAVESORT_MAX 8192
+// key of one wave-of-documents (one wave of the launch per wave-of-documents, lane = document)
+__global__ __launch_bounds__(64) void ctm_wave_key_kernel(const int32_t* __restrict__ order, const int64_t* __restrict__ doc_ptr,
+                                                          const uint16_t* __restrict__ newton, unsigned* __restrict__ keys)
+{
+    const int w = blockIdx.x, lane = threadIdx.x;
+    const int d = order[(int64_t)w * 64 + lane];
+    const int len = wave_max_i((int)(doc_ptr[d + 1] - doc_ptr[d])), nt = wave_max_i((int)newton[d]);
+    const float t = 8.4f * (float)len + 37.0f * (float)nt;
+    if (lane == 0) keys[w] = (min((unsigned)t, (1u << 19) - 1u) << 13) | (unsigned)(CTM_WAVESORT_MAX - 1 - w);     // ties keep the given order
+}
+// keys[0, n) sorted descending in place (bitonic, one workgroup; P = power of two >= n)
+__global__ __launch_bounds__(1024) void ctm_wave_sort_kernel(unsigned* __restrict__ keys, int n, int P)
+{
+    __shared__ unsigned v[CTM_WAVESORT_MAX];
+    for (int w = threadIdx.x; w < P; w += 1024) v[w] = w < n ? keys[w] : 0u;
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < P; i += 1024) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const unsigned a = v[i], b = v[l];
+                    const bool desc = (i & k) == 0;
+                    if (desc ? (a < b) : (a > b)) { v[i] = b; v[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int w = threadIdx.x; w < n; w += 1024) keys[w] = v[w];
+}
+// out = the waves-of-documents of `order` in the sorted order; a trailing partial wave stays last
+__global__ __launch_bounds__(256) void ctm_wave_permute_kernel(const int32_t* __restrict__ order, const unsigned* __restrict__ keys, int n, int64_t Mb,
+                                                               int32_t* __restrict__ out)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= Mb) return;
+    const int q = (int)(idx >> 6);
+    const int src = q < n ? (CTM_WAVESORT_MAX - 1 - (int)(keys[q] & (CTM_WAVESORT_MAX - 1))) : q;
+    out[idx] = order[(int64_t)src * 64 + (idx & 63)];
+}
+
 // ------------------------------------------------------------------------------ E-step kernel, any K <= 128
 // The register Gauss-Jordan above needs one lane per matrix row and KP VGPRs per row (K <= 60).  Larger models keep
 // the Newton matrix in LDS instead: lane l owns the topics / matrix rows l and l + 64 (NS = 2 slots), the K x K matrix
@@ -1271,6 +1319,7 @@ struct tmvb_ctm {
                                        // a lane walks its document's tokens one after the other, so those keep the wave-per-document kernel
     bool reorder = false, keys_valid = false;      // regroup its documents by last E-step's Newton step counts (ctm_reorder_kernel)
     uint16_t* d_doc_newton = nullptr; int32_t* d_doc_order0 = nullptr;
+    int32_t* d_doc_order_q = nullptr; unsigned* d_wave_keys = nullptr; bool queue_sorted = false; hipEvent_t ev_spec2 = nullptr; bool spec2_pending = false;      // the lane-per-document launch's queue order (ctm_wave_sort_kernel), valid for the next E-step
     float* d_bt_sdiag = nullptr; float* d_bt_muf = nullptr; unsigned long long* d_cg_iters = nullptr;
     float cg_tol = 1e-4f, cg_abs = 0.05f;   // CG exit: relative residual, and the fraction of ntol it may stop at (TMVB_CTM_CG_TOL / _ABS)
     double* d_sigma = nullptr; double* d_invsigma = nullptr; double* d_mu = nullptr; double* d_logdet = nullptr;
@@ -1310,7 +1359,7 @@ extern "C" int tmvb_ctm_destroy(tmvb_ctm* h)
     if (h->own_stats) (void)hipFree(h->d_stats);
     (void)hipFree(h->d_lambda); (void)hipFree(h->d_lambda_old); (void)hipFree(h->d_vsq); (void)hipFree(h->d_logzeta);
     (void)hipFree(h->d_wtok); (void)hipFree(h->d_E); (void)hipFree(h->d_ts_partial); (void)hipFree(h->d_invsigma_f);
-    (void)hipFree(h->d_bt_sdiag); (void)hipFree(h->d_bt_muf); (void)hipFree(h->d_cg_iters); (void)hipFree(h->d_doc_newton); (void)hipFree(h->d_doc_order0);
+    (void)hipFree(h->d_bt_sdiag); (void)hipFree(h->d_bt_muf); (void)hipFree(h->d_cg_iters); (void)hipFree(h->d_doc_newton); (void)hipFree(h->d_doc_order0); (void)hipFree(h->d_doc_order_q); (void)hipFree(h->d_wave_keys);
     (void)hipFree(h->d_mu_f); (void)hipFree(h->d_sigma); (void)hipFree(h->d_invsigma); (void)hipFree(h->d_mu);
     (void)hipFree(h->d_logdet); (void)hipFree(h->d_scatter_partial); (void)hipFree(h->d_sweeps); (void)hipFree(h->d_doc_order);
     (void)hipFree(h->d_partial); (void)hipFree(h->d_partial_docs); (void)hipFree(h->d_partial_docs2); (void)hipFree(h->d_rowsum); (void)hipFree(h->d_doc_val); (void)hipFree(h->d_elbo);
@@ -1319,6 +1368,7 @@ extern "C" int tmvb_ctm_destroy(tmvb_ctm* h)
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_spec) (void)hipEventDestroy(h->ev_spec);
+    if (h->ev_spec2) (void)hipEventDestroy(h->ev_spec2);
     (void)hipFree(h->d_sigma_s); (void)hipFree(h->d_invsigma_s); (void)hipFree(h->d_invsigma_f_s); (void)hipFree(h->d_logdet_s); (void)hipFree(h->d_status_s);
     for (int a = 0; a < tmvb_ctm::NAUX; ++a) {
         if (h->ev_join[a]) (void)hipEventDestroy(h->ev_join[a]);
@@ -1405,7 +1455,7 @@ extern "C" int tmvb_ctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
         if (const char* t = getenv("TMVB_CTM_CG_TOL")) h->cg_tol = std::max(1e-7f, (float)atof(t));
         if (const char* t = getenv("TMVB_CTM_CG_ABS")) h->cg_abs = std::max(0.0f, (float)atof(t));
         if ((rc = dmalloc(&h->d_bt_sdiag, 64)) || (rc = dmalloc(&h->d_bt_muf, 64)) || (rc = dmalloc(&h->d_cg_iters, 16)) ||
-            (rc = dmalloc(&h->d_doc_newton, (size_t)std::max<int64_t>(h->M, 1))) || (rc = dmalloc(&h->d_doc_order0, (size_t)std::max<int64_t>(h->M, 1))))
+            (rc = dmalloc(&h->d_doc_newton, (size_t)std::max<int64_t>(h->M, 1))) || (rc = dmalloc(&h->d_doc_order0, (size_t)std::max<int64_t>(h->M, 1))) || (rc = dmalloc(&h->d_doc_order_q, (size_t)std::max<int64_t>(h->M, 1))) || (rc = dmalloc(&h->d_wave_keys, CTM_WAVESORT_MAX)))
             return rc;
         // regrouping pays when a chunk of the length-sorted order is still homogeneous in length: corpora of >= 4 chunks
         const char* r = getenv("TMVB_CTM_REORDER");
@@ -1443,6 +1493,7 @@ extern "C" int tmvb_ctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
     TMVB_HIP(hipEventCreate(&h->ev1));
     TMVB_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     TMVB_HIP(hipEventCreateWithFlags(&h->ev_spec, hipEventDisableTiming));
+    TMVB_HIP(hipEventCreateWithFlags(&h->ev_spec2, hipEventDisableTiming));
     for (int a = 0; a < tmvb_ctm::NAUX; ++a) {
         h->aux[a] = tmvb_pool_stream(ctx->device, 1 + a);
         TMVB_REQUIRE(h->aux[a] != nullptr, TMVB_EHIP, "hipStreamCreate failed");
@@ -1628,7 +1679,8 @@ static int ctm_launch_batch(tmvb_ctm* h, const CtmParams& p, double ntol)
     h->reorder_staged = false;
     h->keys_valid = true;
     CtmBatchArgs ba;
-    ba.p = p; ba.p.doc_order = p.doc_order + h->n_long; ba.p.doc_newton = h->d_doc_newton; ba.tb = tb; ba.M = Mb;
+    ba.p = p; ba.p.doc_order = (h->queue_sorted && !FILT) ? h->d_doc_order_q : p.doc_order + h->n_long; ba.p.doc_newton = h->d_doc_newton; ba.tb = tb; ba.M = Mb;
+    h->queue_sorted = false;
     static const bool prof = [] { const char* e = getenv("TMVB_CTM_PROF"); return e && atoi(e) != 0; }();
     // TMVB_CTM_WAVE_LOG=<file> (with TMVB_CTM_PROF=1): per-item start / end / placement of this launch, written after a synchronisation (diagnostics only)
     static const char* wave_log = getenv("TMVB_CTM_WAVE_LOG");
@@ -1724,12 +1776,29 @@ extern "C" int tmvb_ctm_estep(tmvb_ctm* h, int32_t niter, double ntol, int32_t v
         if (spec) {
             if (!h->distributed) { frc = ctm_sigma_mu(h, 1, 0, true, h->aux[0]); if (frc) return frc; h->sigma_staged = true; }
             if (h->batch && h->reorder && h->keys_valid) {
+                // on a second side stream (nothing but the E-step kernels to wait for): regroup, then the queue order of the launch
                 const int64_t Mb = h->M - h->n_long;
                 if (Mb > 0) {
-                    hipLaunchKernelGGL(ctm_reorder_kernel, dim3((unsigned)((Mb + CTM_REORDER_CHUNK - 1) / CTM_REORDER_CHUNK)), dim3(1024), 0, h->aux[0],
+                    hipStream_t s2 = h->aux[1];
+                    TMVB_HIP(hipStreamWaitEvent(s2, h->ev_fork, 0));
+                    hipLaunchKernelGGL(ctm_reorder_kernel, dim3((unsigned)((Mb + CTM_REORDER_CHUNK - 1) / CTM_REORDER_CHUNK)), dim3(1024), 0, s2,
                                        h->d_doc_order0 + h->n_long, h->d_doc_newton, h->d_doc_order + h->n_long, Mb);
                     TMVB_HIP(hipGetLastError());
                     h->reorder_staged = true;
+                    static const bool wsort = [] { const char* e = getenv("TMVB_CTM_WAVESORT"); return !(e && atoi(e) == 0); }();
+                    const int64_t nfull = Mb / 64;
+                    if (wsort && nfull >= 2 && nfull <= CTM_WAVESORT_MAX) {
+                        int P = 2; while (P < nfull) P <<= 1;
+                        hipLaunchKernelGGL(ctm_wave_key_kernel, dim3((unsigned)nfull), dim3(64), 0, s2, h->d_doc_order + h->n_long, h->corp->d_doc_ptr,
+                                           h->d_doc_newton, h->d_wave_keys);
+                        hipLaunchKernelGGL(ctm_wave_sort_kernel, dim3(1), dim3(1024), 0, s2, h->d_wave_keys, (int)nfull, P);
+                        hipLaunchKernelGGL(ctm_wave_permute_kernel, dim3((unsigned)((Mb + 255) / 256)), dim3(256), 0, s2, h->d_doc_order + h->n_long,
+                                           h->d_wave_keys, (int)nfull, Mb, h->d_doc_order_q);
+                        TMVB_HIP(hipGetLastError());
+                        h->queue_sorted = true;
+                    }
+                    TMVB_HIP(hipEventRecord(h->ev_spec2, s2));
+                    h->spec2_pending = true;
                 }
             }
             TMVB_HIP(hipEventRecord(h->ev_spec, h->aux[0]));
@@ -1850,6 +1919,7 @@ static int ctm_sigma_mu(tmvb_ctm* h, int do_sigma, int do_mu, bool staged, hipSt
 static int ctm_join_spec(tmvb_ctm* h)
 {
     if (h->spec_pending) { TMVB_HIP(hipStreamWaitEvent(h->ctx->stream, h->ev_spec, 0)); h->spec_pending = false; }
+    if (h->spec2_pending) { TMVB_HIP(hipStreamWaitEvent(h->ctx->stream, h->ev_spec2, 0)); h->spec2_pending = false; }
     return TMVB_OK;
 }
 
