@@ -431,3 +431,52 @@ def test_regrouping_documents_changes_nothing(tmvb, monkeypatch):
     for n in ("beta", "mu", "sigma", "lam", "lam_old", "vsq", "logzeta"):
         assert np.array_equal(getattr(a, n), getattr(b, n)), n
     assert np.array_equal(a.doc_sweeps(), b.doc_sweeps())
+
+
+@pytest.mark.parametrize("spec,wsort", [("0", "0"), ("1", "0"), ("0", "1")])
+def test_staged_sigma_and_queue_order_change_nothing(tmvb, monkeypatch, spec, wsort):
+    """tmvb_ctm_estep stages update_sigma! on a side stream under its statistics pass and computes the next E-step's document
+    regrouping and queue order (waves-of-documents by predicted time) there as well.  None of it may change a bit: the staged
+    sigma is the same kernel on the same statistics tail, and documents are independent of their grouping.  Stepwise calls (the
+    staged result is consumed by update_sigma) and train() (the C loop), K = 50 (the KP = 52 instantiation), enough documents
+    for several regrouping chunks; against the default (both on)."""
+    pc = tmvb.syn_nsf(M=9000, V=4000, seed=31)
+    K = 50
+
+    def run(s, w, stepwise):
+        monkeypatch.setenv("TMVB_CTM_SPECULATE", s); monkeypatch.setenv("TMVB_CTM_WAVESORT", w)
+        g = tmvb.gpuCTM(pc, K)
+        g.beta = np.asfortranarray(tmvb.dirichlet_rows(K, pc.V, seed=3)); g.beta_old = g.beta.copy(order="F"); g.update_buffer()
+        if stepwise:
+            for it in range(4):
+                g.estep(); g.reduce_docs(); g.update_beta(); g.update_sigma(); g.update_mu()
+            g.update_elbo(); g.update_host()
+        else:
+            g.train(iter=4, tol=0.0, checkelbo=np.inf, printelbo=False)
+        return g
+    for stepwise in (True, False):
+        a, b = run("1", "1", stepwise), run(spec, wsort, stepwise)
+        for n in ("beta", "mu", "sigma", "invsigma", "lam", "lam_old", "vsq", "logzeta"):
+            assert np.array_equal(getattr(a, n), getattr(b, n)), (n, stepwise)
+        assert np.array_equal(a.doc_sweeps(), b.doc_sweeps())
+        assert a.elbo == b.elbo
+
+
+def test_staged_sigma_is_dropped_when_the_state_changes(tmvb):
+    """The sigma staged by tmvb_ctm_estep belongs to the statistics tail of that E-step: setting lambda through the API afterwards
+    (update_buffer) must make update_sigma invert the tail it is given by the next reduce_docs, not the staged one."""
+    pc = tmvb.syn_nsf(M=1200, V=2000, seed=33)
+    K = 20
+    a, b = tmvb.gpuCTM(pc, K), tmvb.gpuCTM(pc, K)
+    for g in (a, b):
+        g.beta = np.asfortranarray(tmvb.dirichlet_rows(K, pc.V, seed=3)); g.beta_old = g.beta.copy(order="F"); g.update_buffer()
+        g.estep(); g.update_host()
+    lam2 = a.lam + 0.25 * np.sin(np.arange(a.lam.size, dtype=np.float64)).reshape(a.lam.shape, order="F")
+    # a: state changed after the E-step (the staged sigma is stale); b: the same lambda set BEFORE anything was staged, via a fresh model
+    a.lam = np.asfortranarray(lam2); a.update_buffer(); a.reduce_docs(); a.update_sigma(); a.update_mu(); a.update_host()
+    c = tmvb.gpuCTM(pc, K)
+    for n in ("mu", "sigma", "invsigma", "beta", "beta_old", "lam_old", "vsq", "logzeta"):
+        v = getattr(b, n); setattr(c, n, v.copy(order="F") if v.ndim > 1 else v.copy())
+    c.lam = np.asfortranarray(lam2); c.update_buffer(); c.reduce_docs(); c.update_sigma(); c.update_mu(); c.update_host()
+    assert np.array_equal(a.sigma, c.sigma) and np.array_equal(a.mu, c.mu)
+    assert np.abs(a.sigma - b.sigma).max() > 0          # and it is not the sigma of the unchanged state

@@ -1772,7 +1772,8 @@ extern "C" int tmvb_ctm_estep(tmvb_ctm* h, int32_t niter, double ntol, int32_t v
         TMVB_HIP(hipEventRecord(h->ev_join[0], h->aux[0]));
         // behind the tail, still under the statistics pass: update_sigma! staged (single process only: a sharded run all-reduces the
         // tail first) and the documents regrouped for the next E-step
-        static const bool spec = [] { const char* e = getenv("TMVB_CTM_SPECULATE"); return !(e && atoi(e) == 0); }();
+        const char* espec = getenv("TMVB_CTM_SPECULATE");     // (read per call: the tests run both ways in one process)
+        const bool spec = !(espec && atoi(espec) == 0);
         if (spec) {
             if (!h->distributed) { frc = ctm_sigma_mu(h, 1, 0, true, h->aux[0]); if (frc) return frc; h->sigma_staged = true; }
             if (h->batch && h->reorder && h->keys_valid) {
@@ -1785,7 +1786,8 @@ extern "C" int tmvb_ctm_estep(tmvb_ctm* h, int32_t niter, double ntol, int32_t v
                                        h->d_doc_order0 + h->n_long, h->d_doc_newton, h->d_doc_order + h->n_long, Mb);
                     TMVB_HIP(hipGetLastError());
                     h->reorder_staged = true;
-                    static const bool wsort = [] { const char* e = getenv("TMVB_CTM_WAVESORT"); return !(e && atoi(e) == 0); }();
+                    const char* ews = getenv("TMVB_CTM_WAVESORT");
+                    const bool wsort = !(ews && atoi(ews) == 0);
                     const int64_t nfull = Mb / 64;
                     if (wsort && nfull >= 2 && nfull <= CTM_WAVESORT_MAX) {
                         int P = 2; while (P < nfull) P <<= 1;
