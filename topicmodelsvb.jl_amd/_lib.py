@@ -134,6 +134,8 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise EngineError(f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc, gfx950). "
                               "The HIP engine has no CPU fallback.")
+        # eight hardware queues for the process's HIP streams (tmvb_core.hip: tmvb_env_defaults); only effective before HIP initialises
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
         L = C.CDLL(LIB_PATH)
         L.tmvb_last_error.restype = C.c_char_p
         L.tmvb_abi_version.restype = C.c_int

@@ -87,6 +87,14 @@ hipStream_t tmvb_pool_stream(int device, int slot, bool high_priority)
     return st;
 }
 
+// Eight hardware queues for the process's HIP streams unless the user says otherwise (the runtime's default is four).  The models run
+// two to four streams each; with four queues a model built after others had been closed shared queues in ways that cost up to a third
+// of its speed (one process, ctpf / lda100 / ctm / ctpf / lda100 / ...: LDA K = 100 531 it/s and CTM 185 against 838 and 202 in fresh
+// processes), with eight every model of such a sequence runs at its fresh-process rate (832 - 843, 201 - 203; profiles/r3_stream_pool.txt).
+// The runtime reads the variable when it initialises, so this only helps when the library is loaded before the first HIP call
+// (python: _lib.py sets it too; bench.py before importing torch; Julia: TMVBHip.__init__).
+__attribute__((constructor)) static void tmvb_env_defaults() { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 extern "C" int tmvb_ctx_create(int32_t device_id, void* hip_stream, tmvb_ctx** out)
 {
     TMVB_REQUIRE(out != nullptr, TMVB_EINVAL, "tmvb_ctx_create: out is NULL");

@@ -22,7 +22,8 @@ void tmvb_set_error(const char* fmt, ...);
 // model is the slow one (688), with 2 every model is (755).  The pool makes a sequence of models in a plain process all run at the
 // first model's rate (833 / 832 / ...), but inside a process that also drives torch streams (bench.py) its effect depended on what
 // had run before (LDA K = 100 712 ... 834, CTPF 1660 ... 5400 it/s), so it is not the default; bench.py measures each of its side
-// configurations in a fresh process instead.  An open item.
+// configurations in a fresh process instead.  What fixed the sequences measured is in tmvb_core.hip (tmvb_env_defaults: eight hardware
+// queues) and tmvb_lda.hip (the side chain on aux[1]); the pool stays as a switch.
 hipStream_t tmvb_pool_stream(int device, int slot, bool high_priority = false);
 void tmvb_release_stream(hipStream_t st);            // no-op for pooled streams (TMVB_STREAM_POOL=0: destroys the caller's own stream)
 bool tmvb_streams_pooled();

@@ -929,7 +929,7 @@ struct tmvb_lda {
     // The context's stream joins the side chain lazily (lda_join_side): before anything that reads or rewrites
     // alpha / Elogtheta_sum on it, and before a document-sharded caller all-reduces the statistics buffer;
     // the next E-step's document kernels wait for the side chain directly.
-    static constexpr int SIDE = 2;
+    static constexpr int SIDE = 1;     // aux[1]: the long documents' stream, idle by the time the side chain starts (round 3: was a stream of its own, aux[2])
     hipEvent_t ev_docs = nullptr, ev_side = nullptr, ev_mark = nullptr, ev_chain = nullptr;
     double* d_partial_side = nullptr;
     bool esum_fresh = false;           // d_esum / statistics tail hold the sums of the current Elogtheta
@@ -1316,6 +1316,13 @@ extern "C" int tmvb_lda_get_state(tmvb_lda* h, double* alpha, double* beta, doub
 
 static int lda_estep_impl(tmvb_lda* h, int32_t viter, double vtol);
 
+// stream of the side chain (TMVB_LDA_SIDE_STREAM: experiment with the stream -> hardware-queue mapping)
+static int lda_side_index()
+{
+    static const int ix = [] { const char* e = getenv("TMVB_LDA_SIDE_STREAM"); const int v = e ? atoi(e) : (int)tmvb_lda::SIDE; return (v >= 0 && v < (int)tmvb_lda::NAUX) ? v : (int)tmvb_lda::SIDE; }();
+    return ix;
+}
+
 extern "C" int tmvb_lda_estep(tmvb_lda* h, int32_t viter, double vtol)
 {
     TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_lda_estep: handle is NULL");
@@ -1469,7 +1476,7 @@ static int lda_estep_impl(tmvb_lda* h, int32_t viter, double vtol)
         if (rc) return rc;
         TMVB_HIP(hipGetLastError());
     }
-    hipStream_t side = h->aux[tmvb_lda::SIDE];
+    hipStream_t side = h->aux[lda_side_index()];
     {
         int rc = close_pieces(P);
         if (rc) return rc;
@@ -1581,7 +1588,7 @@ extern "C" int tmvb_lda_update_alpha(tmvb_lda* h, int32_t niter, double ntol)
     tmvb_ctx* ctx = h->ctx;
     TMVB_HIP(hipSetDevice(ctx->device));
     const float* ef = h->distributed ? h->d_stats + (size_t)h->K * h->V : nullptr;
-    hipStream_t side = h->aux[tmvb_lda::SIDE];
+    hipStream_t side = h->aux[lda_side_index()];
     // One context: the Newton step needs nothing but Elogtheta_sum, which the E-step left on this very
     // stream, so it starts under the statistics pass.  Document-sharded: it needs the all-reduced sums, i.e.
     // the context's stream as of the preceding update_beta call (or as of now).

@@ -20,6 +20,8 @@
 # the same C ABI.
 
 const LIBTMVB = get(ENV, "TMVB_HIP_LIB", "libtmvb_hip.so")
+# eight hardware queues for the process's HIP streams, before the runtime initialises (the library's constructor does the same: tmvb_core.hip)
+haskey(ENV, "GPU_MAX_HW_QUEUES") || (ENV["GPU_MAX_HW_QUEUES"] = "8")
 
 const TMVB_OK, TMVB_EINVAL, TMVB_ESHAPE, TMVB_ECORPUS, TMVB_ENOMEM, TMVB_EHIP, TMVB_ENONFINITE, TMVB_ENODEVICE, TMVB_ERCCL = 0, 1, 2, 3, 4, 5, 6, 7, 8
 const TMVB_UNIQUE_ID_BYTES = 128
