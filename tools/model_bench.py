@@ -101,7 +101,7 @@ def lda100_cpu(pc=None):
     return out
 
 
-def ctm(burnin=30, warmup=2, steps=8, cpu=True, K=50):
+def ctm(burnin=60, warmup=2, steps=8, cpu=True, K=50):        # 60 burn-in iterations: the same steady-state definition as bench.py's LDA window (30 -> 202, 60 -> 206, 100 -> 214 it/s)
     pc = tm.syn_nsf()
     gm = tm.gpuCTM(pc, K)
     beta0 = tm.dirichlet_rows(K, pc.V, seed=7)
