@@ -227,7 +227,7 @@ int tmvb_lda_last_estep_ms(tmvb_lda* h, float* ms);
  * Filtered LDA: LDA plus a per-token Bernoulli switch tau_n (prior eta) and a background distribution kappa.  The reference
  * has NO accelerator path for it (`@gpu train!` on an fLDA does nothing, src/macros.jl:274-278); SURVEY.md section 8 f4 names
  * it as the next row.  The entry points mirror the LDA ones; the per-document operator chain update_phi! / update_tau! /
- * update_gamma! / update_Elogtheta! (src/fLDA.jl:188, :180, :173, :166) is one fused kernel.  K <= 128.
+ * update_gamma! / update_Elogtheta! (src/fLDA.jl:188, :180, :173, :166) is one fused kernel.  K <= 1024 (1, 2, 4, 8 or 16 topic slots per lane, as LDA).
  * tau / tau_old are flat double[nnz] arrays in the CSR token order of tmvb_corpus_create (= vcat(model.tau...)). */
 int tmvb_flda_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb_flda** out);           /* fLDA(corp, K), src/fLDA.jl:28-60 */
 int tmvb_flda_destroy(tmvb_flda* h);

@@ -48,7 +48,7 @@ def synth_case(tmvb, K, M=80, V=500, seed=6):
                 kappa0=tmvb.dirichlet_rows(1, V, seed=9)[0])
 
 
-@pytest.mark.parametrize("case", ["flda_m40_v60_k5", "flda_m30_v50_k9_empty", "syn_k12", "syn_k50", "syn_k100"])
+@pytest.mark.parametrize("case", ["flda_m40_v60_k5", "flda_m30_v50_k9_empty", "syn_k12", "syn_k50", "syn_k100", "syn_k200", "syn_k300", "syn_k600"])
 def test_teacher_forced_fixed_sweeps(tmvb, oracle, case):
     """vtol = 0 pins every document to exactly `viter` sweeps on both sides: pure arithmetic parity of the fused sweep,
     the rebuilt-phi statistics pass, the M-step and the ELBO."""
@@ -141,7 +141,7 @@ def test_errors_and_invariants(tmvb):
     with pytest.raises(ValueError):
         tmvb.gpufLDA(pc, 0)
     with pytest.raises(ValueError):
-        tmvb.gpufLDA(pc, 129)
+        tmvb.gpufLDA(pc, 1025)              # K <= 1024, as LDA (round 3; 128 before)
     gm = tmvb.gpufLDA(pc, 16)
     with pytest.raises(ValueError):
         gm.train(viter=-1, printelbo=False)

@@ -186,13 +186,13 @@ static int tmvb_launch_filtered_stats(tmvb_ctx* ctx, int nslot, const tmvb_inv_i
     sp.chunk_id = ix.d_chunk_id; sp.chunk_begin = ix.d_chunk_begin; sp.chunk_end = ix.d_chunk_end; sp.chunk_out = ix.d_chunk_out;
     sp.n_chunks = (int)ix.n_chunks;
     const dim3 grid((unsigned)((ix.n_chunks + 3) / 4)), block(256);
-    if (nslot == 1) hipLaunchKernelGGL((flda_stats_kernel<1>), grid, block, 0, ctx->stream, sp);
-    else hipLaunchKernelGGL((flda_stats_kernel<2>), grid, block, 0, ctx->stream, sp);
+    (void)dispatch_nslot(nslot, [&](auto ns) -> int {
+        constexpr int NS = decltype(ns)::value;
+        hipLaunchKernelGGL((flda_stats_kernel<NS>), grid, block, 0, ctx->stream, sp);
+        if (ix.n_multi > 0)
+            hipLaunchKernelGGL((flda_stats_multi_kernel<NS>), dim3((unsigned)ix.n_multi), dim3(64), 0, ctx->stream, sp, ix.d_multi_id, ix.d_multi_first, ix.d_multi_count, (int)ix.n_multi);
+        return TMVB_OK;
+    });
     TMVB_HIP(hipGetLastError());
-    if (ix.n_multi > 0) {
-        if (nslot == 1) hipLaunchKernelGGL((flda_stats_multi_kernel<1>), dim3((unsigned)ix.n_multi), dim3(64), 0, ctx->stream, sp, ix.d_multi_id, ix.d_multi_first, ix.d_multi_count, (int)ix.n_multi);
-        else hipLaunchKernelGGL((flda_stats_multi_kernel<2>), dim3((unsigned)ix.n_multi), dim3(64), 0, ctx->stream, sp, ix.d_multi_id, ix.d_multi_first, ix.d_multi_count, (int)ix.n_multi);
-        TMVB_HIP(hipGetLastError());
-    }
     return TMVB_OK;
 }

@@ -379,7 +379,7 @@ extern "C" int tmvb_flda_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmv
     *out = nullptr;
     TMVB_REQUIRE(ctx && corp, TMVB_EINVAL, "tmvb_flda_create: NULL context or corpus");
     TMVB_REQUIRE(K > 0, TMVB_EINVAL, "number of topics must be a positive integer.");      // src/fLDA.jl:30
-    TMVB_REQUIRE(K <= 128, TMVB_EINVAL, "tmvb_flda_create: K <= 128 (two topic slots per lane); got K=%d", K);
+    TMVB_REQUIRE(K <= 1024, TMVB_EINVAL, "tmvb_flda_create: K <= 1024 (sixteen topic slots per lane); got K=%d", K);
     TMVB_HIP(hipSetDevice(ctx->device));
     tmvb_flda* h = new tmvb_flda();
     tmvb_create_guard<tmvb_flda, tmvb_flda_destroy> guard{h};
@@ -522,8 +522,13 @@ extern "C" int tmvb_flda_estep(tmvb_flda* h, int32_t viter, double vtol)
     for (const tmvb_bucket& b : h->buckets) {
         const size_t lds = flda_tile_bytes(b.tile_rows, h->KP);
         const dim3 grid((unsigned)b.count), block(64);
-        if (h->nslot == 1) hipLaunchKernelGGL((flda_estep_kernel<1>), grid, block, lds, ctx->stream, p, b.first, b.tile_rows);
-        else hipLaunchKernelGGL((flda_estep_kernel<2>), grid, block, lds, ctx->stream, p, b.first, b.tile_rows);
+        int lrc = dispatch_nslot(h->nslot, [&](auto ns) -> int {            // 1, 2, 4, 8 or 16 topic slots per lane (K <= 1024, as LDA)
+            constexpr int NS = decltype(ns)::value;
+            if (lds > 48 * 1024) TMVB_HIP(hipFuncSetAttribute((const void*)flda_estep_kernel<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((flda_estep_kernel<NS>), grid, block, lds, ctx->stream, p, b.first, b.tile_rows);
+            return TMVB_OK;
+        });
+        if (lrc) return lrc;
         TMVB_HIP(hipGetLastError());
     }
     {
@@ -600,8 +605,10 @@ extern "C" int tmvb_flda_update_alpha(tmvb_flda* h, int32_t niter, double ntol)
     tmvb_ctx* ctx = h->ctx;
     TMVB_HIP(hipSetDevice(ctx->device));
     const float* ef = h->distributed ? h->esum_f() : nullptr;      // sharded: the all-reduced fp32 tail
-    if (h->nslot == 1) hipLaunchKernelGGL((lda_alpha_kernel<1>), dim3(1), dim3(64), 0, ctx->stream, h->K, (double)h->M_total, h->d_esum, ef, h->d_alpha_d, h->d_alpha_f, niter, ntol, h->d_iters);
-    else hipLaunchKernelGGL((lda_alpha_kernel<2>), dim3(1), dim3(64), 0, ctx->stream, h->K, (double)h->M_total, h->d_esum, ef, h->d_alpha_d, h->d_alpha_f, niter, ntol, h->d_iters);
+    (void)dispatch_nslot(h->nslot, [&](auto ns) -> int {
+        hipLaunchKernelGGL((lda_alpha_kernel<decltype(ns)::value>), dim3(1), dim3(64), 0, ctx->stream, h->K, (double)h->M_total, h->d_esum, ef, h->d_alpha_d, h->d_alpha_f, niter, ntol, h->d_iters);
+        return TMVB_OK;
+    });
     TMVB_HIP(hipGetLastError());
     return TMVB_OK;
 }
@@ -625,14 +632,12 @@ extern "C" int tmvb_flda_update_elbo(tmvb_flda* h, double* elbo)
     TMVB_HIP(hipSetDevice(ctx->device));
     if (h->M > 0) {
         const dim3 grid((unsigned)h->M), block(64);
-        if (h->nslot == 1)
-            hipLaunchKernelGGL((flda_elbo_kernel<1>), grid, block, 0, ctx->stream, h->K, h->KP, h->corp->d_doc_ptr, h->corp->d_terms, h->corp->d_counts,
+        (void)dispatch_nslot(h->nslot, [&](auto ns) -> int {
+            hipLaunchKernelGGL((flda_elbo_kernel<decltype(ns)::value>), grid, block, 0, ctx->stream, h->K, h->KP, h->corp->d_doc_ptr, h->corp->d_terms, h->corp->d_counts,
                                h->d_alpha_d, h->d_eta, h->d_kappa, h->d_beta[h->cur], h->d_beta[h->cur ^ 1], h->d_gamma, h->d_elog, h->d_elog_old,
                                h->d_tau, h->d_tau_old, h->d_doc_val);
-        else
-            hipLaunchKernelGGL((flda_elbo_kernel<2>), grid, block, 0, ctx->stream, h->K, h->KP, h->corp->d_doc_ptr, h->corp->d_terms, h->corp->d_counts,
-                               h->d_alpha_d, h->d_eta, h->d_kappa, h->d_beta[h->cur], h->d_beta[h->cur ^ 1], h->d_gamma, h->d_elog, h->d_elog_old,
-                               h->d_tau, h->d_tau_old, h->d_doc_val);
+            return TMVB_OK;
+        });
         TMVB_HIP(hipGetLastError());
     }
     hipLaunchKernelGGL(lda_elbo_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, h->d_doc_val, h->M, h->K, h->d_alpha_d, h->d_elbo,
