@@ -124,8 +124,15 @@ def usable_cpus():
 
 def cpu_baseline(tm, corpus, K, beta0, budget_s=24.0):
     """fp64 oracle (oracle/*.c) on the FULL corpus: OpenMP document-parallel E-step on every host core, per-thread
-    statistics allocated once; then one single-thread iteration (the reference is single-threaded) if the budget allows."""
+    statistics allocated once; then one single-thread iteration (the reference is single-threaded) if the budget allows.
+
+    PARITY IN THE SAME RUN (round-3 review: "compare what you time with the oracle"): the 1 warm-up + 2 timed oracle
+    iterations of the widest team are at the same time the checker of the HIP engine -- a gpuLDA on the same full corpus is
+    reset to the oracle's state before each of them (teacher forcing), runs the same outer iteration, and every document and
+    every global is compared (oracle/parity.py; tolerances of SURVEY.md section 8c).  Returns (cpu_baseline, parity)."""
+    import numpy as np
     from oracle import oracle as oc
+    from oracle import parity as op
     oc.build()
     host_cores, cpu_info = usable_cpus()
     threads = host_cores
@@ -148,7 +155,14 @@ def cpu_baseline(tm, corpus, K, beta0, budget_s=24.0):
     # the private-statistics reduction grows with the thread count, so the fastest team is not always the widest:
     # try all usable CPUs, a half and a quarter (1 warm-up + 2 timed iterations each) and keep the best
     tried = {}
-    for nt in sorted({host_cores, max(1, host_cores // 2), max(1, host_cores // 4)}, reverse=True):
+    # widest team: its three iterations are the parity check's oracle iterations (timed: the oracle's own calls only)
+    gm = tm.gpuLDA(corpus, K)
+    gm.beta = np.asfortranarray(beta0); gm.beta_old = gm.beta.copy(order="F"); gm.update_buffer()
+    block, secs = op.lda_parity(gm, oc.LDA(csr, K, beta0), iters=3, threads=host_cores, log=log)
+    gm.close()
+    tried[host_cores] = 2.0 / (secs[1] + secs[2])
+    oc.lib().orc_omp_pool_free()
+    for nt in sorted({max(1, host_cores // 2), max(1, host_cores // 4)} - {host_cores}, reverse=True):
         tried[nt], _ = run(nt, 1, 2, budget_s / 8)
         oc.lib().orc_omp_pool_free()
     threads = max(tried, key=tried.get)
@@ -166,6 +180,7 @@ def cpu_baseline(tm, corpus, K, beta0, budget_s=24.0):
         single = (sh.nnz / max(corpus.nnz, 1)) / (time.perf_counter() - t1)
         single_note = f"1 iteration on the first {sh.M} documents ({sh.nnz} nnz), scaled by the nnz fraction"
     oc.lib().orc_omp_pool_free()
+    block["against"] = "fp64 C oracle (port of src/LDA.jl), the cpu_baseline's own iterations: cold start + 2 more teacher-forced outer iterations on the FULL workload"
     return {
         "value": omp, "unit": "VB iters/sec", "cores": threads, "host_cpus": cpu_info, "kind": "port",
         "omp_threads_tried": {str(k): v for k, v in tried.items()},
@@ -173,9 +188,9 @@ def cpu_baseline(tm, corpus, K, beta0, budget_s=24.0):
         "sample": f"fp64 C oracle (port of src/LDA.jl train!; the Julia reference cannot run here) on the FULL workload "
                   f"({corpus.M} docs, {corpus.nnz} nnz), same cold start (alpha=1, gamma=1, beta0 seed 7): 1 warm-up + {n_omp} timed "
                   f"iterations with the OpenMP document-parallel E-step on {threads} threads (the CPUs usable by this process: affinity mask and cgroup quota, see host_cpus), per-thread "
-                  f"statistics allocated once; single thread: {single_note}.  Cold-start iterations run fewer sweeps per "
+                  f"statistics allocated once (E-step + update_beta! + update_alpha!; on the widest team these iterations are also the parity check's, see `parity`); single thread: {single_note}.  Cold-start iterations run fewer sweeps per "
                   f"document than the GPU's steady-state window, which favours the CPU figure.",
-    }
+    }, block
 
 
 def main():
@@ -184,6 +199,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--burnin", type=int, default=60, help="untimed iterations that bring the model to its steady state before warm-up")
+    ap.add_argument("--clock-warmup", type=float, default=0.6,
+                    help="seconds of untimed iterations on a scratch model before anything is measured (clocks, first touches); 0 = off")
     ap.add_argument("--K", type=int, default=50)
     ap.add_argument("--docs", type=int, default=128804)
     ap.add_argument("--vocab", type=int, default=25319)
@@ -315,6 +332,24 @@ def main():
             elapsed = float(t.item())
         return elapsed, [a.elapsed_time(b) for a, b in ev]
 
+    # ---- clocks and first touches (round-3 review: the driver's first window read 8 % below the same build's rate in a process
+    # that had already run for a second, while its SECOND window matched): a scratch model of the same shard runs untimed
+    # iterations until the device has been busy for --clock-warmup seconds, in chunks whose rates go to stderr (the ramp is
+    # visible there) and into config.clock_warmup.  It shares nothing with the measured model but the device: the workload
+    # definition (60 burn-in iterations from the cold start, then W + K) is unchanged.
+    clock_log = []
+    if args.clock_warmup > 0:
+        scratch = HipLDAEngine(shard, K, beta0, corpus.M, local_rank, distributed=False)
+        t_w = time.perf_counter()
+        while time.perf_counter() - t_w < args.clock_warmup and len(clock_log) < 40:
+            torch.cuda.synchronize(); t_c = time.perf_counter()
+            for _ in range(50):
+                scratch.estep(viter, vtol); scratch.reduce_docs(); scratch.update_beta(); scratch.update_alpha(niter, ntol)
+            torch.cuda.synchronize()
+            clock_log.append(round(50.0 / (time.perf_counter() - t_c), 1))
+        scratch.model.close(); del scratch
+        log(f"[rank {rank}] clock warm-up: {len(clock_log)} chunks of 50 iterations, it/s per chunk: {clock_log}")
+
     # ---- steady-state window (the headline)
     eng = make_engine()
     allreduce, comm = attach_comm(eng)
@@ -336,6 +371,46 @@ def main():
             comm_c.close()
         eng_c.model.close(); del eng_c
 
+    # ---- multi-GPU self-validation (N > 1): the first run on real multi-GPU hardware has to prove itself.  A fresh sharded
+    # model runs 5 checked iterations of the library's train! from the cold start; then (i) every rank hashes its replica of the
+    # globals (alpha, beta -- the replicated M-step must leave them bit-identical everywhere) and the 64-bit hashes are
+    # all-gathered and compared, (ii) rank 0 alone runs the same 5 iterations on the WHOLE corpus on its own GPU (N = 1) and the
+    # two ELBO trajectories are compared: they differ by fp32 summation order only.
+    mg_check = None
+    if world > 1:
+        n_chk = 5
+        eng_s = make_engine()
+        ar_s, comm_s = attach_comm(eng_s)
+        if comm_s is None:
+            mg_check = {"skipped": "needs the in-library communicator (tmvb_*_set_comm); --collective torch has no sharded train!"}
+        else:
+            buf = np.full(n_chk, np.nan); done, base = C.c_int32(0), C.c_double(0.0)
+            tm._lib.check(L.tmvb_lda_train(eng_s.model.handle, C.c_int32(n_chk), C.c_double(0.0), C.c_int32(niter), C.c_double(ntol), C.c_int32(viter),
+                                           C.c_double(vtol), C.c_int32(1), buf.ctypes.data_as(C.POINTER(C.c_double)), C.byref(done), C.byref(base)))
+            traj_n = buf[:done.value].copy()
+            eng_s.model.update_host()
+            dig = hashlib.sha256(np.ascontiguousarray(eng_s.model.alpha).tobytes() + np.asfortranarray(eng_s.model.beta).tobytes(order="F")).digest()
+            mine = torch.tensor([int.from_bytes(dig[:8], "little", signed=True)], dtype=torch.int64)
+            allh = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+            dist.all_gather(allh, mine)                                  # gloo
+            hashes = [int(t.item()) for t in allh]
+            mg_check = {"iterations": int(done.value), "globals_hash_equal": len(set(hashes)) == 1,
+                        "globals_hash_per_rank": [f"{h & 0xFFFFFFFFFFFFFFFF:016x}" for h in hashes]}
+            if rank == 0:
+                g1 = tm.gpuLDA(corpus, K, device_id=local_rank)
+                g1.beta = np.asfortranarray(beta0); g1.beta_old = g1.beta.copy(order="F")
+                traj_1 = g1.train(iter=n_chk, tol=0.0, checkelbo=1, printelbo=False)
+                g1.close()
+                m = min(len(traj_1), len(traj_n))
+                relv = float(np.max(np.abs(traj_n[:m] - traj_1[:m]) / np.abs(traj_1[:m]))) if m else float("nan")
+                mg_check.update({"elbo_rel_vs_n1": relv, "elbo_rel_tolerance": 2e-6, "elbo_n": traj_n.tolist(), "elbo_n1": np.asarray(traj_1).tolist(),
+                                 "pass": bool(mg_check["globals_hash_equal"] and m == n_chk and relv <= 2e-6)})
+                if not mg_check["pass"]:
+                    log("MULTI-GPU SELF-CHECK FAILED: " + json.dumps(mg_check))
+            eng_s.model.set_comm(None, shard.M); comm_s.close()
+        eng_s.model.close(); del eng_s
+        barrier()
+
     result = None
     if rank == 0:
         ms = float(np.mean(estep_ms))
@@ -351,6 +426,8 @@ def main():
                                    f"viter=10 vtol=1/K^2 niter=1000 ntol=1/K^2 checkelbo=Inf; steady state: {args.burnin} untimed burn-in "
                                    f"iterations from the cold start (state preparation), then {args.warmup} warm-up + {args.steps} timed",
                        "K": K, "M": corpus.M, "V": V, "nnz": corpus.nnz, "sum_counts": int(corpus.counts.sum()), "burnin": args.burnin,
+                       "clock_warmup": {"seconds": args.clock_warmup, "its_per_chunk_of_50": clock_log,
+                                        "what": "untimed iterations of a scratch model on the same shard before the measured model is built (device clocks, first touches); not state preparation"},
                        "parallelism": f"doc-shard x{world}, 1 all-reduce of {K * V + K} f32 per iteration" if world > 1 else "single GPU",
                        "collective": collective,
                        "sweep_hist_last_step": sweep_hist},
@@ -359,11 +436,16 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src, "kernel_source_hash": kernel_source_hash(),
                          "algorithmic_bytes_per_estep": b_e, "estep_ms": ms,
                          "estep_ms_min": float(np.min(estep_ms)), "estep_ms_max": float(np.max(estep_ms)),
+                         "estep_ms_median": float(np.median(estep_ms)), "estep_ms_steps": [round(float(x), 4) for x in estep_ms],
+                         "frac_at_median": b_e / (float(np.median(estep_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "launches_per_estep": n_launch,
                          "whole_iteration_GBs": (b_e + mstep_bytes(K, V)) / (elapsed / args.steps) / 1e9},
             "cold_start": cold,
             "cpu_baseline": None,
+            "parity": None,
         }
+        if mg_check is not None:
+            result["multi_gpu_check"] = mg_check
 
     # ---- time to ELBO plateau (second half of the BASELINE metric): fresh cold start, checkelbo=1, tol=1.0, the
     # library's own train! loop (sharded through the communicator when N>1), in chunks so that the wall clock of the
@@ -414,7 +496,9 @@ def main():
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(tm, corpus, K, beta0)
+            result["cpu_baseline"], result["parity"] = cpu_baseline(tm, corpus, K, beta0)
+            if not result["parity"]["pass"]:
+                log("PARITY FAILED against the fp64 oracle at the timed size: " + json.dumps(result["parity"]["worst"]))
     if comm is not None:
         eng.model.set_comm(None, shard.M); comm.close(); comm = None
     eng.model.close(); del eng
@@ -452,6 +536,9 @@ def main():
                 t_c = time.perf_counter()
                 try:
                     others[name]["cpu_baseline"] = model_bench.CPU[name]()
+                    others[name]["parity"] = others[name]["cpu_baseline"].pop("parity", None)
+                    if others[name]["parity"] and not others[name]["parity"]["pass"]:
+                        log(f"PARITY FAILED for {name}: " + json.dumps(others[name]["parity"]["worst"]))
                 except Exception as e:
                     others[name]["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
                 log(f"other_configs[{name}] cpu_baseline done in {time.perf_counter() - t_c:.1f}s")

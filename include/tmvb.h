@@ -261,10 +261,10 @@ int tmvb_flda_last_estep_ms(tmvb_flda* h, float* ms);
 
 /* gpuCTM(corp, K) (src/gpuCTM.jl:45-98).  Constructor state as src/CTM.jl:37-48 (mu=0, sigma=invsigma=I,
  * lambda=0, vsq=1, logzeta=0.5); beta is uniform until tmvb_ctm_set_state (the reference draws it with
- * Julia's RNG).  K <= 128.  Three E-step kernels behind tmvb_ctm_estep: K <= 50 -- one LANE per
+ * Julia's RNG).  K <= 128.  Three E-step kernels behind tmvb_ctm_estep: K <= 52 -- one LANE per
  * document, invsigma streamed through scalar registers, the lambda Newton systems solved by Jacobi-preconditioned CG to
  * max(1e-4 |g|, 5 % of ntol); its documents of more than 2048 unique terms (and everything under TMVB_CTM_BATCH=0) -- one wave
- * per document, Gauss-Jordan in registers (lane = matrix row); 50 < K <= 128 -- one wave per document, lane = matrix row (two
+ * per document, Gauss-Jordan in registers (lane = matrix row); 52 < K <= 128 -- one wave per document, lane = matrix row (two
  * topic slots per lane beyond 64), the same CG against one copy of invsigma in LDS per workgroup (TMVB_CTM_GENERIC_CG=0: round 1's
  * Gauss-Jordan through LDS, 30 times slower at K = 100). */
 int tmvb_ctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb_ctm** out);
@@ -314,7 +314,7 @@ int tmvb_ctm_train_group(tmvb_ctm* const* hs, int32_t n, int32_t iter, double to
 int tmvb_ctm_sweep_hist(tmvb_ctm* h, int64_t* hist, int32_t nbins, int64_t* newton_steps);
 int tmvb_ctm_doc_sweeps(tmvb_ctm* h, uint8_t* out);
 int tmvb_ctm_last_estep_ms(tmvb_ctm* h, float* ms);
-/* Diagnostics of the last E-step when the lane-per-document kernel ran (K <= 50, csrc/tmvb_ctm_batch.h), 12 values: out[0]
+/* Diagnostics of the last E-step when the lane-per-document kernel ran (K <= 52, csrc/tmvb_ctm_batch.h), 12 values: out[0]
  * conjugate-gradient trips, [1] Newton trips, [2] waves (summed over waves); with TMVB_CTM_PROF=1 in the environment also
  * [3..10] shader cycles per phase (token, logzeta, vsq, gradient assembly, CG, gradient mat-vec, lambda update, spare) and
  * [11] whole-kernel cycles.  Zeros otherwise. */
@@ -357,7 +357,7 @@ int tmvb_fctm_doc_sweeps(tmvb_fctm* h, uint8_t* out);
 
 /* gpuCTPF(corp, K) (src/gpuCTPF.jl:68-152).  Constructor state as src/CTPF.jl:81-100 (he=1, rates=1, gimel=zayin=1,
  * hyper-parameters a..h = 0.1); alef is 1 until tmvb_ctpf_set_state (the reference draws it with Julia's RNG, :83).
- * K <= 128 (lane l owns topics l and l + 64); the register-tile fast path covers K <= 60. */
+ * K <= 128 (lane l owns topics l and l + 64); the grid-tile fast path (one topic slot per lane of a 16 x 4 lane grid) covers K <= 60. */
 int tmvb_ctpf_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb_ctpf** out);
 int tmvb_ctpf_destroy(tmvb_ctpf* h);
 /* update_buffer! state half (src/modelutils.jl:474-493).  hyper[8] = a..h; alef[K*V], he[K*U], bet/vav/dalet/het[K],

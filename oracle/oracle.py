@@ -44,11 +44,35 @@ def build(force: bool = False) -> str:
     return _LIB_PATH
 
 
+def usable_cpus() -> int:
+    """CPUs this process may really use: affinity mask and cgroup quota (a container often sees every host core in
+    os.cpu_count() while being limited to a few -- 256 visible, 16 usable on the GPU boxes)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        q = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q[0] != "max":
+            n = min(n, max(1, int(float(q[0]) / float(q[1]) + 0.5)))
+    except Exception:
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, int(quota / period + 0.5)))
+        except Exception:
+            pass
+    return n
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(_LIB_PATH):
             build()
+        # the ELBO evaluations are document-parallel with the OpenMP default team: keep it to the CPUs we may use
+        os.environ.setdefault("OMP_NUM_THREADS", str(usable_cpus()))
         _lib = C.CDLL(_LIB_PATH)
         _lib.orc_digamma.restype = c_dbl; _lib.orc_digamma.argtypes = [c_dbl]
         _lib.orc_trigamma.restype = c_dbl; _lib.orc_trigamma.argtypes = [c_dbl]
@@ -160,9 +184,12 @@ class LDA:
         vtol = 1.0 / self.K ** 2 if vtol is None else vtol
         d1 = self.M if d1 is None else d1
         if omp_threads:
-            return lib().orc_lda_estep_omp(*self._corp_args(), c_i64(d0), c_i64(d1), _pd(self.alpha), _pd(self.beta),
-                                           _pd(self.beta_temp), _pd(self.gamma), _pd(self.Elogtheta), _pd(self.Elogtheta_old),
-                                           C.c_int(viter), c_dbl(vtol), C.c_int(omp_threads))
+            # document-parallel (the per-document results do not depend on the thread count; the statistics' summation order does)
+            sw = np.zeros(max(d1 - d0, 1), dtype=np.int32)
+            lib().orc_lda_estep_omp_sw(*self._corp_args(), c_i64(d0), c_i64(d1), _pd(self.alpha), _pd(self.beta),
+                                       _pd(self.beta_temp), _pd(self.gamma), _pd(self.Elogtheta), _pd(self.Elogtheta_old),
+                                       C.c_int(viter), c_dbl(vtol), C.c_int(omp_threads), _pi32(sw))
+            return sw[: d1 - d0]
         sw = np.zeros(max(d1 - d0, 1), dtype=np.int32)
         rc = lib().orc_lda_estep(*self._corp_args(), c_i64(d0), c_i64(d1), _pd(self.alpha), _pd(self.beta),
                                  _pd(self.beta_temp), _pd(self.gamma), _pd(self.Elogtheta), _pd(self.Elogtheta_old),
@@ -309,10 +336,14 @@ class CTM:
         vtol = 1.0 / self.K ** 2 if vtol is None else vtol
         d1 = self.M if d1 is None else d1
         if omp_threads:
-            return lib().orc_ctm_estep_omp(*self._corp_args(), c_i64(d0), c_i64(d1), _pd(self.mu), _pd(self.invsigma),
-                                           _pd(self.beta), _pd(self.beta_temp), _pd(self.lam), _pd(self.lam_old),
-                                           _pd(self.vsq), _pd(self.logzeta), C.c_int(niter), c_dbl(ntol), C.c_int(viter),
-                                           c_dbl(vtol), C.c_int(omp_threads))
+            sw = np.zeros(max(d1 - d0, 1), dtype=np.int32); nw = np.zeros(max(d1 - d0, 1), dtype=np.int32)
+            lib().orc_ctm_estep_omp_sw(*self._corp_args(), c_i64(d0), c_i64(d1), _pd(self.mu), _pd(self.invsigma),
+                                       _pd(self.beta), _pd(self.beta_temp), _pd(self.lam), _pd(self.lam_old),
+                                       _pd(self.vsq), _pd(self.logzeta), C.c_int(niter), c_dbl(ntol), C.c_int(viter),
+                                       c_dbl(vtol), C.c_int(omp_threads), _pi32(sw), _pi32(nw))
+            self.newton_per_doc = nw[: d1 - d0]
+            self.newton_steps = int(nw.sum())
+            return sw[: d1 - d0]
         sw = np.zeros(max(d1 - d0, 1), dtype=np.int32)
         nst = c_i64(0)
         rc = lib().orc_ctm_estep(*self._corp_args(), c_i64(d0), c_i64(d1), _pd(self.mu), _pd(self.invsigma),
@@ -454,7 +485,9 @@ class CTPF:
                   _pd(self.bet), _pd(self.vav), _pd(self.dalet), _pd(self.het), _pd(self.alef_temp), _pd(self.he_temp),
                   _pd(self.gimel), _pd(self.gimel_old), _pd(self.zayin), _pd(self.zayin_old), C.c_int(viter), c_dbl(vtol))
         if omp_threads:
-            return lib().orc_ctpf_estep_omp(*common, C.c_int(omp_threads))
+            sw = np.zeros(max(d1 - d0, 1), dtype=np.int32)
+            lib().orc_ctpf_estep_omp_sw(*common, C.c_int(omp_threads), _pi32(sw))
+            return sw[: d1 - d0]
         sw = np.zeros(max(d1 - d0, 1), dtype=np.int32)
         rc = lib().orc_ctpf_estep(*common, _pi32(sw))
         assert rc == 0

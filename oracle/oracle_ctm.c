@@ -228,12 +228,14 @@ int orc_ctm_estep(int64_t M, int64_t V, int64_t K,
     return 0;
 }
 
-int orc_ctm_estep_omp(int64_t M, int64_t V, int64_t K,
+/* sweeps_out / newton_out (may be NULL): per-document sweep counts and lambda Newton steps, [d - d0] */
+int orc_ctm_estep_omp_sw(int64_t M, int64_t V, int64_t K,
                   const int64_t* doc_ptr, const int32_t* terms, const int32_t* counts,
                   int64_t d0, int64_t d1,
                   const double* mu, const double* invsigma, const double* beta, double* beta_temp,
                   double* lambda, double* lambda_old, double* vsq, double* logzeta,
-                  int niter, double ntol, int viter, double vtol, int nthreads)
+                  int niter, double ntol, int viter, double vtol, int nthreads,
+                  int32_t* sweeps_out, int32_t* newton_out)
 {
     (void)M;
     int used = 1;
@@ -250,9 +252,12 @@ int orc_ctm_estep_omp(int64_t M, int64_t V, int64_t K,
 #pragma omp for schedule(dynamic, 16)
         for (int64_t d = d0; d < d1; ++d) {
             int64_t off = doc_ptr[d], Nd = doc_ptr[d + 1] - off;
-            ctm_doc(K, Nd, terms + off, counts + off, mu, invsigma, beta,
+            int64_t nst = 0;
+            int sw = ctm_doc(K, Nd, terms + off, counts + off, mu, invsigma, beta,
                     lambda + d * K, lambda_old + d * K, vsq + d * K, logzeta + d,
-                    niter, ntol, viter, vtol, &w, NULL);
+                    niter, ntol, viter, vtol, &w, &nst);
+            if (sweeps_out) sweeps_out[d - d0] = sw;
+            if (newton_out) newton_out[d - d0] = (int32_t)nst;
             ctm_update_beta_doc(K, Nd, terms + off, counts + off, w.phi, bt, w.stage);
         }
 #pragma omp critical
@@ -262,10 +267,22 @@ int orc_ctm_estep_omp(int64_t M, int64_t V, int64_t K,
     }
 #else
     (void)nthreads;
+    (void)newton_out;
     orc_ctm_estep(M, V, K, doc_ptr, terms, counts, d0, d1, mu, invsigma, beta, beta_temp,
-                  lambda, lambda_old, vsq, logzeta, niter, ntol, viter, vtol, NULL, NULL);
+                  lambda, lambda_old, vsq, logzeta, niter, ntol, viter, vtol, sweeps_out, NULL);
 #endif
     return used;
+}
+
+int orc_ctm_estep_omp(int64_t M, int64_t V, int64_t K,
+                  const int64_t* doc_ptr, const int32_t* terms, const int32_t* counts,
+                  int64_t d0, int64_t d1,
+                  const double* mu, const double* invsigma, const double* beta, double* beta_temp,
+                  double* lambda, double* lambda_old, double* vsq, double* logzeta,
+                  int niter, double ntol, int viter, double vtol, int nthreads)
+{
+    return orc_ctm_estep_omp_sw(M, V, K, doc_ptr, terms, counts, d0, d1, mu, invsigma, beta, beta_temp,
+                                lambda, lambda_old, vsq, logzeta, niter, ntol, viter, vtol, nthreads, NULL, NULL);
 }
 
 /* update_sigma! (src/CTM.jl:108-111) THEN update_mu! (:102-104): sigma uses the previous mu
@@ -325,9 +342,7 @@ double orc_ctm_update_elbo(int64_t M, int64_t V, int64_t K,
 {
     (void)M; (void)V;
     int64_t mx = max_len(doc_ptr, d0, d1);
-    double* phi = (double*)malloc(sizeof(double) * (size_t)(K * mx));
     double* L = (double*)malloc(sizeof(double) * (size_t)(K * K));
-    double* df = (double*)malloc(sizeof(double) * (size_t)K);
     memcpy(L, invsigma, sizeof(double) * (size_t)(K * K));
     double logdet = NAN;
     if (orc_chol_lower(L, K) == 0) {
@@ -335,6 +350,14 @@ double orc_ctm_update_elbo(int64_t M, int64_t V, int64_t K,
         for (int64_t i = 0; i < K; ++i) logdet += 2.0 * log(L[i * K + i]);
     }
     double elbo = 0.0;
+    /* documents are independent: evaluated document-parallel (OpenMP, one workspace per thread) into ed[d - d0] and then added in
+     * document order -- the same sum, bit for bit, as the sequential loop */
+    double* ed = (double*)calloc((size_t)(d1 > d0 ? d1 - d0 : 1), sizeof(double));
+#pragma omp parallel
+    {
+    double* phi = (double*)malloc(sizeof(double) * (size_t)(K * mx));
+    double* df = (double*)malloc(sizeof(double) * (size_t)K);
+#pragma omp for schedule(dynamic, 16)
     for (int64_t d = d0; d < d1; ++d) {
         int64_t off = doc_ptr[d], Nd = doc_ptr[d + 1] - off;
         const int32_t* tm = terms + off; const int32_t* ct = counts + off;
@@ -380,9 +403,12 @@ double orc_ctm_update_elbo(int64_t M, int64_t V, int64_t K,
             for (int64_t i = 0; i < K; ++i) { double pv = phi[n * K + i]; if (pv > 0.0) h -= pv * log(pv); }
             t5 -= (double)ct[n] * h;
         }
-        elbo += t1 + t2 + t3 - t4 - t5;                                        /* :94 */
+        ed[d - d0] = t1 + t2 + t3 - t4 - t5;                                   /* :94 */
     }
-    free(phi); free(L); free(df);
+    free(phi); free(df);
+    }
+    for (int64_t d = d0; d < d1; ++d) elbo += ed[d - d0];
+    free(ed); free(L);
     return elbo;
 }
 

@@ -175,7 +175,8 @@ int orc_ctpf_estep(int64_t M, int64_t V, int64_t U, int64_t K,
     return 0;
 }
 
-int orc_ctpf_estep_omp(int64_t M, int64_t V, int64_t U, int64_t K,
+/* sweeps_out (may be NULL): per-document sweep counts, [d - d0] */
+int orc_ctpf_estep_omp_sw(int64_t M, int64_t V, int64_t U, int64_t K,
                    const int64_t* doc_ptr, const int32_t* terms, const int32_t* counts,
                    const int64_t* rdr_ptr, const int32_t* readers, const int32_t* ratings,
                    int64_t d0, int64_t d1, const orc_ctpf_hyper* hp,
@@ -183,7 +184,7 @@ int orc_ctpf_estep_omp(int64_t M, int64_t V, int64_t U, int64_t K,
                    const double* bet, const double* vav, const double* dalet, const double* het,
                    double* alef_temp, double* he_temp,
                    double* gimel, double* gimel_old, double* zayin, double* zayin_old,
-                   int viter, double vtol, int nthreads)
+                   int viter, double vtol, int nthreads, int32_t* sweeps_out)
 {
     (void)M;
     int used = 1;
@@ -203,9 +204,10 @@ int orc_ctpf_estep_omp(int64_t M, int64_t V, int64_t U, int64_t K,
         for (int64_t d = d0; d < d1; ++d) {
             int64_t off = doc_ptr[d], Nd = doc_ptr[d + 1] - off;
             int64_t roff = rdr_ptr[d], Rd = rdr_ptr[d + 1] - roff;
-            ctpf_doc(K, Nd, terms + off, counts + off, Rd, readers + roff, ratings + roff, hp,
+            int sw = ctpf_doc(K, Nd, terms + off, counts + off, Rd, readers + roff, ratings + roff, hp,
                      alef, he, bet, vav, dalet, het,
                      gimel + d * K, gimel_old + d * K, zayin + d * K, zayin_old + d * K, viter, vtol, &w);
+            if (sweeps_out) sweeps_out[d - d0] = sw;
             ctpf_scatter(K, Nd, terms + off, counts + off, Rd, readers + roff, ratings + roff, &w, at, ht);
         }
 #pragma omp critical
@@ -219,9 +221,24 @@ int orc_ctpf_estep_omp(int64_t M, int64_t V, int64_t U, int64_t K,
 #else
     (void)nthreads;
     orc_ctpf_estep(M, V, U, K, doc_ptr, terms, counts, rdr_ptr, readers, ratings, d0, d1, hp, alef, he,
-                   bet, vav, dalet, het, alef_temp, he_temp, gimel, gimel_old, zayin, zayin_old, viter, vtol, NULL);
+                   bet, vav, dalet, het, alef_temp, he_temp, gimel, gimel_old, zayin, zayin_old, viter, vtol, sweeps_out);
 #endif
     return used;
+}
+
+int orc_ctpf_estep_omp(int64_t M, int64_t V, int64_t U, int64_t K,
+                   const int64_t* doc_ptr, const int32_t* terms, const int32_t* counts,
+                   const int64_t* rdr_ptr, const int32_t* readers, const int32_t* ratings,
+                   int64_t d0, int64_t d1, const orc_ctpf_hyper* hp,
+                   const double* alef, const double* he,
+                   const double* bet, const double* vav, const double* dalet, const double* het,
+                   double* alef_temp, double* he_temp,
+                   double* gimel, double* gimel_old, double* zayin, double* zayin_old,
+                   int viter, double vtol, int nthreads)
+{
+    return orc_ctpf_estep_omp_sw(M, V, U, K, doc_ptr, terms, counts, rdr_ptr, readers, ratings, d0, d1, hp, alef, he,
+                                 bet, vav, dalet, het, alef_temp, he_temp, gimel, gimel_old, zayin, zayin_old,
+                                 viter, vtol, nthreads, NULL);
 }
 
 /* src/CTPF.jl:366-371 in the reference's order:
@@ -302,8 +319,6 @@ double orc_ctpf_update_elbo(int64_t M, int64_t V, int64_t U, int64_t K,
 {
     int64_t mxN, mxR;
     max_lens(doc_ptr, rdr_ptr, 0, M, &mxN, &mxR);
-    ctpf_ws w;
-    ws_alloc(&w, K, mxN, mxR);
     double* rs_he = (double*)calloc((size_t)K, sizeof(double));
     double* rs_alef = (double*)calloc((size_t)K, sizeof(double));
     double elbo = 0.0;
@@ -327,6 +342,14 @@ double orc_ctpf_update_elbo(int64_t M, int64_t V, int64_t U, int64_t K,
             x += gamma_entropy(hv, 1.0 / vav[i]);
         }
     elbo += x;
+    /* the per-document terms: documents are independent, so they are evaluated document-parallel (OpenMP, one workspace per
+     * thread) into ed[d] and then added in document order -- the same sum, bit for bit, as the sequential loop */
+    double* ed = (double*)calloc((size_t)(M > 0 ? M : 1), sizeof(double));
+#pragma omp parallel
+    {
+    ctpf_ws w;
+    ws_alloc(&w, K, mxN, mxR);
+#pragma omp for schedule(dynamic, 16)
     for (int64_t d = 0; d < M; ++d) {
         int64_t off = doc_ptr[d], Nd = doc_ptr[d + 1] - off;
         int64_t roff = rdr_ptr[d], Rd = rdr_ptr[d + 1] - roff;
@@ -376,10 +399,13 @@ double orc_ctpf_update_elbo(int64_t M, int64_t V, int64_t U, int64_t K,
         /* - Elogqtheta :207-213, - Elogqepsilon :225-231 */
         for (int64_t i = 0; i < K; ++i) e += gamma_entropy(gi[i], 1.0 / dalet[i]);
         for (int64_t i = 0; i < K; ++i) e += gamma_entropy(za[i], 1.0 / het[i]);
-        elbo += e;
+        ed[d] = e;
     }
-    free(rs_he); free(rs_alef);
     ws_free(&w);
+    }
+    for (int64_t d = 0; d < M; ++d) elbo += ed[d];
+    free(ed);
+    free(rs_he); free(rs_alef);
     return elbo;
 }
 

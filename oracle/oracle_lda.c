@@ -141,12 +141,14 @@ static int pool_reserve(int nt, int64_t len)
     return 0;                            /* the buffers themselves are first-touched by their own threads */
 }
 
-int orc_lda_estep_omp(int64_t M, int64_t V, int64_t K,
+/* sweeps_out (may be NULL): sweeps_out[d - d0] = the sweeps document d ran, as orc_lda_estep reports them (each document is
+ * written by the one thread that owns it) -- the full-size parity checks compare per document. */
+int orc_lda_estep_omp_sw(int64_t M, int64_t V, int64_t K,
                       const int64_t* doc_ptr, const int32_t* terms, const int32_t* counts,
                       int64_t d0, int64_t d1,
                       const double* alpha, const double* beta, double* beta_temp,
                       double* gamma, double* Elogtheta, double* Elogtheta_old,
-                      int viter, double vtol, int nthreads)
+                      int viter, double vtol, int nthreads, int32_t* sweeps_out)
 {
     (void)M; (void)V;
     int used = 1;
@@ -169,9 +171,10 @@ int orc_lda_estep_omp(int64_t M, int64_t V, int64_t K,
 #pragma omp for schedule(dynamic, 16)
         for (int64_t d = d0; d < d1; ++d) {
             int64_t off = doc_ptr[d], Nd = doc_ptr[d + 1] - off;
-            orc_lda_doc_sweeps(K, Nd, terms + off, counts + off, alpha, beta,
+            int sw = orc_lda_doc_sweeps(K, Nd, terms + off, counts + off, alpha, beta,
                                gamma + d * K, Elogtheta + d * K, Elogtheta_old + d * K,
                                phi, viter, vtol);
+            if (sweeps_out) sweeps_out[d - d0] = sw;
             for (int64_t n = 0; n < Nd; ++n) {
                 double* col = bt + (int64_t)terms[off + n] * K;
                 double c = (double)counts[off + n];
@@ -191,9 +194,20 @@ int orc_lda_estep_omp(int64_t M, int64_t V, int64_t K,
 #else
     (void)nthreads;
     orc_lda_estep(M, V, K, doc_ptr, terms, counts, d0, d1, alpha, beta, beta_temp,
-                  gamma, Elogtheta, Elogtheta_old, viter, vtol, NULL);
+                  gamma, Elogtheta, Elogtheta_old, viter, vtol, sweeps_out);
 #endif
     return used;
+}
+
+int orc_lda_estep_omp(int64_t M, int64_t V, int64_t K,
+                      const int64_t* doc_ptr, const int32_t* terms, const int32_t* counts,
+                      int64_t d0, int64_t d1,
+                      const double* alpha, const double* beta, double* beta_temp,
+                      double* gamma, double* Elogtheta, double* Elogtheta_old,
+                      int viter, double vtol, int nthreads)
+{
+    return orc_lda_estep_omp_sw(M, V, K, doc_ptr, terms, counts, d0, d1, alpha, beta, beta_temp,
+                                gamma, Elogtheta, Elogtheta_old, viter, vtol, nthreads, NULL);
 }
 
 /* update_beta!(model)  src/LDA.jl:121-125 */
@@ -274,12 +288,18 @@ double orc_lda_update_elbo(int64_t M, int64_t V, int64_t K,
 {
     (void)M; (void)V;
     int64_t mx = max_doc_len(doc_ptr, d0, d1);
-    double* phi = (double*)malloc(sizeof(double) * (size_t)(K * mx));
-    double* expE = (double*)malloc(sizeof(double) * (size_t)K);
     double asum = 0.0, lgsum = 0.0;
     for (int64_t i = 0; i < K; ++i) { asum += alpha[i]; lgsum += orc_lgamma(alpha[i]); }
     double cst = orc_finite(orc_lgamma(asum)) - orc_finite(lgsum);   /* :51 */
     double elbo = 0.0;
+    /* documents are independent: evaluated document-parallel (OpenMP, one phi workspace per thread) into ed[d - d0] and then
+     * added in document order -- the same sum, bit for bit, as the sequential loop */
+    double* ed = (double*)calloc((size_t)(d1 > d0 ? d1 - d0 : 1), sizeof(double));
+#pragma omp parallel
+    {
+    double* phi = (double*)malloc(sizeof(double) * (size_t)(K * mx));
+    double* expE = (double*)malloc(sizeof(double) * (size_t)K);
+#pragma omp for schedule(dynamic, 16)
     for (int64_t d = d0; d < d1; ++d) {
         int64_t off = doc_ptr[d], Nd = doc_ptr[d + 1] - off;
         const int32_t* tm = terms + off;
@@ -335,9 +355,12 @@ double orc_lda_update_elbo(int64_t M, int64_t V, int64_t K,
             }
             t5 -= (double)ct[n] * h;
         }
-        elbo += t1 + t2 + t3 - t4 - t5;   /* :89 */
+        ed[d - d0] = t1 + t2 + t3 - t4 - t5;   /* :89 */
     }
     free(phi); free(expE);
+    }
+    for (int64_t d = d0; d < d1; ++d) elbo += ed[d - d0];
+    free(ed);
     return elbo;
 }
 

@@ -1,0 +1,254 @@
+"""
+parity.py -- teacher-forced comparison of the HIP engine with the fp64 oracle AT THE SIZE THAT IS TIMED.
+
+TEST INFRASTRUCTURE (like everything under oracle/): called by tests/ (`-m gpu` full-size tests), by bench.py's and
+tools/model_bench.py's cpu_baseline legs -- the oracle iterations those legs time anyway are the ones compared here -- and by
+nothing in the product package.  PARITY UNPINNED: the oracle is a restatement of the Julia reference, see tmvb_oracle.h.
+
+One pass per outer iteration, from the same state on both sides:
+  1. the device state is reset to the oracle's state (teacher forcing, as tests/test_*_gpu.py do);
+  2. both run one E-step with the reference's per-document exit rule (src/LDA.jl:175, src/CTM.jl:202, src/CTPF.jl:361);
+  3. a document whose exit test straddles the threshold in fp32 leaves one sweep earlier or later than in fp64.  Such
+     documents are COUNTED (`sweep_mismatch_frac`, bound 5 %: SURVEY.md section 8c), and the oracle then re-runs exactly those
+     documents with the DEVICE's sweep count (viter = that count, vtol = 0): their contribution to the sufficient statistics is
+     taken out and put back (both computed by the oracle, in fp64), so that EVERY document and EVERY global is compared, not only
+     the documents that happened to agree;
+  4. both run the M-step and (optionally) update_elbo!, and the states are compared with the tolerances of SURVEY.md section 8c /
+     DESIGN.md section 6, which are the ones the small-corpus tests use.
+The oracle's own calls are timed (E-step, M-step), so the caller can report them as the CPU baseline of the same run.
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+
+# fp64 -> fp32 tolerances, the ones written in tests/test_lda_gpu.py, tests/test_ctm_gpu.py, tests/test_ctpf_gpu.py
+LDA_TOL = {"gamma_rel_p999": 2e-4, "Elogtheta_rel_p999": 2e-4, "beta_rel_max": 1e-4, "alpha_rel_max": 1e-4, "elbo_rel": 1e-6,
+           "sweep_mismatch_frac": 0.05}
+CTM_TOL = {"lambda_err_p999": 1.0, "vsq_rel_p999": 1e-4, "logzeta_abs_p999": 1e-5, "beta_rel_max": 1e-4, "mu_abs_max": 1e-5,
+           "sigma_abs_rel_max": 1e-5, "elbo_rel": 2e-7, "sweep_mismatch_frac": 0.05}
+CTPF_TOL = {"gimel_rel_p999": 5e-4, "zayin_rel_p999": 5e-4, "alef_rel_max": 5e-4, "he_rel_max": 5e-4, "rates_rel_max": 1e-4,
+            "elbo_rel": 2e-5, "sweep_mismatch_frac": 0.05}
+
+
+def _rel(a, b, floor=1e-300):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    return np.abs(a - b) / np.maximum(np.abs(b), floor)
+
+
+def _q(x, q=0.999):
+    x = np.asarray(x).ravel()
+    return float(np.quantile(x, q)) if x.size else 0.0
+
+
+def _mx(x):
+    x = np.asarray(x)
+    return float(x.max()) if x.size else 0.0
+
+
+def _runs(idx):
+    """consecutive runs [a, b) of a sorted index list"""
+    out = []
+    for d in idx:
+        if out and out[-1][1] == d:
+            out[-1][1] = d + 1
+        else:
+            out.append([d, d + 1])
+    return out
+
+
+def _verdict(rows, tol):
+    """worst value of every metric over the iterations, and pass = every one within its tolerance"""
+    worst = {k: max(r[k] for r in rows if r.get(k) is not None) if any(r.get(k) is not None for r in rows) else None for k in tol}
+    ok = all(v is None or (np.isfinite(v) and v <= tol[k]) for k, v in worst.items())
+    return worst, bool(ok)
+
+
+class _Timer:
+    def __init__(self):
+        self.t = {}
+
+    def add(self, k, dt):
+        self.t[k] = self.t.get(k, 0.0) + dt
+
+
+# --------------------------------------------------------------------------------------------------------- LDA
+def lda_force(gm, om):
+    gm.alpha = om.alpha.copy(); gm.beta = om.beta.copy(order="F"); gm.beta_old = om.beta_old.copy(order="F")
+    gm.gamma = om.gamma.copy(order="F"); gm.Elogtheta = om.Elogtheta.copy(order="F")
+    gm.Elogtheta_old = om.Elogtheta_old.copy(order="F")
+    gm.update_buffer()
+
+
+def lda_parity(gm, om, iters=3, threads=0, elbo=True, viter=10, vtol=None, niter=1000, ntol=None, log=None):
+    """gm: topicmodelsvb.jl_amd gpuLDA, om: oracle.LDA on the same corpus, both at the same state.  Returns the parity block and
+    the oracle's seconds per iteration (E-step + update_beta! + update_alpha!; the mismatch fix-ups and ELBO are not in them)."""
+    K, M = om.K, om.M
+    rows, secs = [], []
+    for it in range(iters):
+        lda_force(gm, om)
+        pre = (om.gamma.copy(order="F"), om.Elogtheta.copy(order="F"), om.Elogtheta_old.copy(order="F"))
+        gm.estep(viter, vtol); gm.reduce_docs()
+        t0 = time.perf_counter()
+        sw_o = np.asarray(om.estep(viter, vtol, omp_threads=threads) if threads else om.estep(viter, vtol))
+        t_e = time.perf_counter() - t0
+        gm.synchronize()
+        sw_g = gm.doc_sweeps().astype(np.int64)
+        bad = np.nonzero(sw_g != sw_o)[0]
+        if len(bad):
+            # take the mismatched documents' fp64 contribution out of beta_temp and put the one with the device's sweep count in
+            keep = om.beta_temp
+            A = np.zeros_like(keep); B = np.zeros_like(keep)
+
+            def restore(a, b):
+                om.gamma[:, a:b] = pre[0][:, a:b]; om.Elogtheta[:, a:b] = pre[1][:, a:b]; om.Elogtheta_old[:, a:b] = pre[2][:, a:b]
+            for d in bad:
+                d = int(d)
+                restore(d, d + 1); om.beta_temp = A; om.estep(viter, vtol, d0=d, d1=d + 1)
+                restore(d, d + 1); om.beta_temp = B; om.estep(int(sw_g[d]), 0.0, d0=d, d1=d + 1)
+            keep += B; keep -= A
+            om.beta_temp = keep
+        t0 = time.perf_counter()
+        om.update_beta(); om.update_alpha(niter, ntol)
+        t_m = time.perf_counter() - t0
+        gm.update_beta(); gm.update_alpha(niter, ntol)
+        r = {"sweep_mismatch_frac": len(bad) / max(M, 1), "sweep_mismatch_max": int(np.abs(sw_g - sw_o).max()) if M else 0}
+        if elbo:
+            e_g = gm.update_elbo(); e_o = om.update_elbo()
+            r["elbo_rel"] = abs(e_g - e_o) / abs(e_o); r["elbo_hip"] = e_g; r["elbo_oracle"] = e_o
+        gm.update_host()
+        rg = _rel(gm.gamma, om.gamma); re = _rel(gm.Elogtheta, om.Elogtheta)
+        big = om.beta > 1e-6
+        r.update({"gamma_rel_p999": _q(rg), "gamma_rel_max": _mx(rg), "Elogtheta_rel_p999": _q(re), "Elogtheta_rel_max": _mx(re),
+                  "beta_rel_max": _mx(_rel(gm.beta[big], om.beta[big])), "beta_abs_max": _mx(np.abs(gm.beta - om.beta)),
+                  "alpha_rel_max": _mx(_rel(gm.alpha, om.alpha)), "oracle_estep_s": t_e, "oracle_mstep_s": t_m})
+        rows.append(r); secs.append(t_e + t_m)
+        if log:
+            log(f"parity LDA K={K} iteration {it + 1}: " + ", ".join(f"{k}={v:.3g}" for k, v in r.items() if isinstance(v, float)))
+    worst, ok = _verdict(rows, LDA_TOL)
+    return {"pass": ok, "iterations": iters, "mode": "teacher-forced, every document compared (documents whose exit sweep differs: oracle re-run with the device's sweep count)",
+            "documents": M, "worst": worst, "tolerances": LDA_TOL, "per_iteration": rows,
+            **{k: worst[k] for k in ("gamma_rel_p999", "beta_rel_max", "alpha_rel_max", "elbo_rel", "sweep_mismatch_frac")}}, secs
+
+
+# --------------------------------------------------------------------------------------------------------- CTM
+def ctm_force(gm, om):
+    gm.mu = om.mu.copy(); gm.sigma = om.sigma.copy(order="F"); gm.invsigma = om.invsigma.copy(order="F")
+    gm.beta = om.beta.copy(order="F"); gm.beta_old = om.beta_old.copy(order="F")
+    gm.lam = om.lam.copy(order="F"); gm.lam_old = om.lam_old.copy(order="F")
+    gm.vsq = om.vsq.copy(order="F"); gm.logzeta = om.logzeta.copy()
+    gm.update_buffer()
+
+
+def ctm_parity(gm, om, iters=2, threads=0, elbo=True, log=None):
+    """CTM: lambda abs <= 1.5e-4 + rel 1.5e-4 (reported as err / bound, tolerance 1), vsq rel, logzeta abs -- 99.9th percentile
+    over all documents; beta, mu, sigma, ELBO as tests/test_ctm_gpu.py::test_teacher_forced_step."""
+    K, M = om.K, om.M
+    rows, secs = [], []
+    for it in range(iters):
+        ctm_force(gm, om)
+        pre = (om.lam.copy(order="F"), om.lam_old.copy(order="F"), om.vsq.copy(order="F"), om.logzeta.copy())
+        gm.estep(); gm.reduce_docs()
+        t0 = time.perf_counter()
+        sw_o = np.asarray(om.estep(omp_threads=threads) if threads else om.estep())
+        t_e = time.perf_counter() - t0
+        gm.synchronize()
+        sw_g = gm.doc_sweeps().astype(np.int64)
+        bad = np.nonzero(sw_g != sw_o)[0]
+        if len(bad):
+            keep = om.beta_temp
+            A = np.zeros_like(keep); B = np.zeros_like(keep)
+
+            def restore(a, b):
+                om.lam[:, a:b] = pre[0][:, a:b]; om.lam_old[:, a:b] = pre[1][:, a:b]; om.vsq[:, a:b] = pre[2][:, a:b]; om.logzeta[a:b] = pre[3][a:b]
+            for d in bad:
+                d = int(d)
+                restore(d, d + 1); om.beta_temp = A; om.estep(d0=d, d1=d + 1)
+                restore(d, d + 1); om.beta_temp = B; om.estep(viter=int(sw_g[d]), vtol=0.0, d0=d, d1=d + 1)
+            keep += B; keep -= A
+            om.beta_temp = keep
+        t0 = time.perf_counter()
+        om.update_beta(); om.update_sigma_mu()
+        t_m = time.perf_counter() - t0
+        gm.update_beta(); gm.update_sigma(); gm.update_mu()
+        r = {"sweep_mismatch_frac": len(bad) / max(M, 1), "sweep_mismatch_max": int(np.abs(sw_g - sw_o).max()) if M else 0}
+        if elbo:
+            e_g = gm.update_elbo(); e_o = om.update_elbo()
+            r["elbo_rel"] = abs(e_g - e_o) / abs(e_o); r["elbo_hip"] = e_g; r["elbo_oracle"] = e_o
+        gm.update_host()
+        lerr = np.abs(gm.lam - om.lam) / (1.5e-4 + 1.5e-4 * np.abs(om.lam))
+        big = om.beta > 1e-6
+        r.update({"lambda_err_p999": _q(lerr), "lambda_err_max": _mx(lerr), "lambda_abs_max": _mx(np.abs(gm.lam - om.lam)),
+                  "vsq_rel_p999": _q(_rel(gm.vsq, om.vsq)), "vsq_rel_max": _mx(_rel(gm.vsq, om.vsq)),
+                  "logzeta_abs_p999": _q(np.abs(gm.logzeta - om.logzeta)), "logzeta_abs_max": _mx(np.abs(gm.logzeta - om.logzeta)),
+                  "beta_rel_max": _mx(_rel(gm.beta[big], om.beta[big])), "mu_abs_max": _mx(np.abs(gm.mu - om.mu)),
+                  "sigma_abs_rel_max": _mx(np.abs(gm.sigma - om.sigma)) / _mx(np.abs(om.sigma)),
+                  "oracle_estep_s": t_e, "oracle_mstep_s": t_m})
+        rows.append(r); secs.append(t_e + t_m)
+        if log:
+            log(f"parity CTM K={K} iteration {it + 1}: " + ", ".join(f"{k}={v:.3g}" for k, v in r.items() if isinstance(v, float)))
+    worst, ok = _verdict(rows, CTM_TOL)
+    return {"pass": ok, "iterations": iters, "mode": "teacher-forced, every document compared (documents whose exit sweep differs: oracle re-run with the device's sweep count)",
+            "documents": M, "worst": worst, "tolerances": CTM_TOL, "per_iteration": rows,
+            "lambda_err_is": "|lambda_hip - lambda_oracle| / (1.5e-4 + 1.5e-4 |lambda_oracle|), tolerance 1",
+            **{k: worst[k] for k in ("lambda_err_p999", "beta_rel_max", "mu_abs_max", "elbo_rel", "sweep_mismatch_frac")}}, secs
+
+
+# --------------------------------------------------------------------------------------------------------- CTPF
+CTPF_FIELDS = ("alef", "he", "bet", "vav", "dalet", "het", "gimel", "zayin")
+
+
+def ctpf_force(gm, om):
+    for n in CTPF_FIELDS:
+        setattr(gm, n, np.array(getattr(om, n), copy=True, order="F"))
+    gm.update_buffer()
+
+
+def ctpf_parity(gm, om, iters=3, threads=0, elbo=False, log=None):
+    K, M = om.K, om.M
+    rows, secs = [], []
+    for it in range(iters):
+        ctpf_force(gm, om)
+        pre = tuple(getattr(om, n).copy(order="F") for n in ("gimel", "gimel_old", "zayin", "zayin_old"))
+        gm.estep(); gm.reduce_docs()
+        t0 = time.perf_counter()
+        sw_o = np.asarray(om.estep(omp_threads=threads) if threads else om.estep())
+        t_e = time.perf_counter() - t0
+        gm.synchronize()
+        sw_g = gm.doc_sweeps().astype(np.int64)
+        bad = np.nonzero(sw_g != sw_o)[0]
+        if len(bad):
+            ka, kh = om.alef_temp, om.he_temp
+            Aa = np.zeros_like(ka); Ba = np.zeros_like(ka); Ah = np.zeros_like(kh); Bh = np.zeros_like(kh)
+
+            def restore(a, b):
+                for n, p in zip(("gimel", "gimel_old", "zayin", "zayin_old"), pre):
+                    getattr(om, n)[:, a:b] = p[:, a:b]
+            for d in bad:
+                d = int(d)
+                restore(d, d + 1); om.alef_temp, om.he_temp = Aa, Ah; om.estep(d0=d, d1=d + 1)
+                restore(d, d + 1); om.alef_temp, om.he_temp = Ba, Bh; om.estep(viter=int(sw_g[d]), vtol=0.0, d0=d, d1=d + 1)
+            ka += Ba; ka -= Aa; kh += Bh; kh -= Ah
+            om.alef_temp, om.he_temp = ka, kh
+        t0 = time.perf_counter()
+        om.mstep()
+        t_m = time.perf_counter() - t0
+        gm.mstep()
+        r = {"sweep_mismatch_frac": len(bad) / max(M, 1), "sweep_mismatch_max": int(np.abs(sw_g - sw_o).max()) if M else 0}
+        if elbo:
+            e_g = gm.update_elbo(); e_o = om.update_elbo()
+            r["elbo_rel"] = abs(e_g - e_o) / abs(e_o); r["elbo_hip"] = e_g; r["elbo_oracle"] = e_o
+        gm.update_host()
+        r.update({"gimel_rel_p999": _q(_rel(gm.gimel, om.gimel)), "gimel_rel_max": _mx(_rel(gm.gimel, om.gimel)),
+                  "zayin_rel_p999": _q(_rel(gm.zayin, om.zayin)), "zayin_rel_max": _mx(_rel(gm.zayin, om.zayin)),
+                  "alef_rel_max": _mx(_rel(gm.alef, om.alef)), "he_rel_max": _mx(_rel(gm.he, om.he)),
+                  "rates_rel_max": max(_mx(_rel(getattr(gm, n), getattr(om, n))) for n in ("bet", "vav", "dalet", "het")),
+                  "oracle_estep_s": t_e, "oracle_mstep_s": t_m})
+        rows.append(r); secs.append(t_e + t_m)
+        if log:
+            log(f"parity CTPF K={K} iteration {it + 1}: " + ", ".join(f"{k}={v:.3g}" for k, v in r.items() if isinstance(v, float)))
+    worst, ok = _verdict(rows, CTPF_TOL)
+    return {"pass": ok, "iterations": iters, "mode": "teacher-forced, every document compared (documents whose exit sweep differs: oracle re-run with the device's sweep count)",
+            "documents": M, "worst": worst, "tolerances": CTPF_TOL, "per_iteration": rows,
+            **{k: worst[k] for k in ("gimel_rel_p999", "alef_rel_max", "he_rel_max", "rates_rel_max", "sweep_mismatch_frac")}}, secs

@@ -65,6 +65,13 @@ int orc_lda_estep_omp(int64_t M, int64_t V, int64_t K,
                       const double* alpha, const double* beta, double* beta_temp,
                       double* gamma, double* Elogtheta, double* Elogtheta_old,
                       int viter, double vtol, int nthreads);
+/* the same with per-document sweep counts (sweeps_out[d - d0], may be NULL): the full-size parity checks */
+int orc_lda_estep_omp_sw(int64_t M, int64_t V, int64_t K,
+                      const int64_t* doc_ptr, const int32_t* terms, const int32_t* counts,
+                      int64_t d0, int64_t d1,
+                      const double* alpha, const double* beta, double* beta_temp,
+                      double* gamma, double* Elogtheta, double* Elogtheta_old,
+                      int viter, double vtol, int nthreads, int32_t* sweeps_out);
 
 /* update_beta!(model), src/LDA.jl:121-125: beta_old <- beta; beta <- rownormalise(beta_temp);
  * beta_temp <- 0. */
@@ -113,6 +120,14 @@ int orc_ctm_estep_omp(int64_t M, int64_t V, int64_t K,
                   const double* mu, const double* invsigma, const double* beta, double* beta_temp,
                   double* lambda, double* lambda_old, double* vsq, double* logzeta,
                   int niter, double ntol, int viter, double vtol, int nthreads);
+/* the same with per-document sweep counts and lambda Newton steps ([d - d0], may be NULL) */
+int orc_ctm_estep_omp_sw(int64_t M, int64_t V, int64_t K,
+                  const int64_t* doc_ptr, const int32_t* terms, const int32_t* counts,
+                  int64_t d0, int64_t d1,
+                  const double* mu, const double* invsigma, const double* beta, double* beta_temp,
+                  double* lambda, double* lambda_old, double* vsq, double* logzeta,
+                  int niter, double ntol, int viter, double vtol, int nthreads,
+                  int32_t* sweeps_out, int32_t* newton_out);
 
 /* update_sigma! then update_mu! (src/CTM.jl:108-111, :102-104, order :207-208). Returns 0, or
  * nonzero if sigma is not positive definite. */
@@ -159,6 +174,16 @@ int orc_ctpf_estep_omp(int64_t M, int64_t V, int64_t U, int64_t K,
                    double* alef_temp, double* he_temp,
                    double* gimel, double* gimel_old, double* zayin, double* zayin_old,
                    int viter, double vtol, int nthreads);
+/* the same with per-document sweep counts ([d - d0], may be NULL) */
+int orc_ctpf_estep_omp_sw(int64_t M, int64_t V, int64_t U, int64_t K,
+                   const int64_t* doc_ptr, const int32_t* terms, const int32_t* counts,
+                   const int64_t* rdr_ptr, const int32_t* readers, const int32_t* ratings,
+                   int64_t d0, int64_t d1, const orc_ctpf_hyper* hp,
+                   const double* alef, const double* he,
+                   const double* bet, const double* vav, const double* dalet, const double* het,
+                   double* alef_temp, double* he_temp,
+                   double* gimel, double* gimel_old, double* zayin, double* zayin_old,
+                   int viter, double vtol, int nthreads, int32_t* sweeps_out);
 
 /* Global updates in the reference order (src/CTPF.jl:366-371).  gimel_sum/zayin_sum are the
  * K-vectors sum_d gimel[:,d], sum_d zayin[:,d].  The *_old outputs receive the previous

@@ -1,8 +1,11 @@
 """The C-ABI library builds for gfx950, loads without a GPU and exports every symbol include/tmvb.h declares."""
 import ctypes
 import os
+import sys
 
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_library_loads_and_exports_header_symbols(tmvb):
@@ -36,3 +39,30 @@ def test_product_package_does_not_import_the_oracle():
                 src = open(os.path.join(dp, f), errors="replace").read()
                 for b in banned:
                     assert b not in src, f"{f} references the oracle ({b})"
+
+
+def test_missing_rccl_is_an_error_code_not_a_crash():
+    """No RCCL on the machine (round-3 advice: the failure message was built from two dlerror() calls, the second of which
+    returns NULL -> std::string(nullptr)): tmvb_rccl_version() must return 0 and the communicator entry points TMVB_ERCCL with
+    a message.  Runs in a child process (the binding is decided once per process); needs no GPU."""
+    import subprocess
+    code = r'''
+import ctypes as C, sys
+sys.path.insert(0, sys.argv[1])
+import tmvb_amd
+tm = tmvb_amd.pkg
+L = tm.lib()
+L.tmvb_rccl_version.restype = C.c_int
+assert L.tmvb_rccl_version() == 0
+buf = (C.c_char * 128)()
+rc = L.tmvb_comm_unique_id(buf)
+L.tmvb_last_error.restype = C.c_char_p
+msg = L.tmvb_last_error().decode()
+assert rc == tm._lib.ERCCL == 8, rc
+assert "RCCL is not available" in msg and "/nonexistent/librccl.so" in msg, msg
+print("ok:", msg)
+'''
+    env = dict(os.environ, TMVB_RCCL_LIB="/nonexistent/librccl.so")
+    out = subprocess.run([sys.executable, "-c", code, ROOT], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-800:]
+    assert out.stdout.startswith("ok:")

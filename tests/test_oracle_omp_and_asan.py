@@ -26,14 +26,16 @@ def test_omp_estep_matches_sequential_lda_ctm(tmvb, oracle):
     csr = oracle.CSR(pc.doc_ptr, pc.terms, pc.counts, pc.V)
     a, b = oracle.LDA(csr, K, beta0), oracle.LDA(csr, K, beta0)
     for _ in range(2):
-        a.estep(); a.update_beta(); a.update_alpha()
-        b.estep(omp_threads=3); b.update_beta(); b.update_alpha()
+        sa = a.estep(); a.update_beta(); a.update_alpha()
+        sb = b.estep(omp_threads=3); b.update_beta(); b.update_alpha()
+        assert np.array_equal(sa, sb)                       # per-document sweep counts (the full-size parity checks use them)
     np.testing.assert_allclose(a.gamma, b.gamma, rtol=1e-12)
     np.testing.assert_allclose(a.beta, b.beta, rtol=1e-11, atol=1e-300)
     a, b = oracle.CTM(csr, K, beta0), oracle.CTM(csr, K, beta0)
     for _ in range(2):
-        a.estep(); a.update_beta(); a.update_sigma_mu()
-        b.estep(omp_threads=3); b.update_beta(); b.update_sigma_mu()
+        sa = a.estep(); a.update_beta(); a.update_sigma_mu()
+        sb = b.estep(omp_threads=3); b.update_beta(); b.update_sigma_mu()
+        assert np.array_equal(sa, sb) and a.newton_steps == b.newton_steps == int(b.newton_per_doc.sum())
     np.testing.assert_allclose(a.lam, b.lam, rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(a.beta, b.beta, rtol=1e-9, atol=1e-300)
 

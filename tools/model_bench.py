@@ -29,24 +29,42 @@ def usable_cpus():
     return u()
 
 
-def cpu_line(kind, make, step, frac, sample_note, warm=1, timed=2, budget_s=12.0, full=False):
+def cpu_line(kind, make, step, frac, sample_note, warm=1, timed=2, budget_s=12.0, full=False, check=None):
     """cpu_baseline of a configuration: the fp64 C oracle (port of the reference's CPU path; the reference is Julia and
     cannot run here) with the OpenMP document-parallel E-step on the CPUs this process may use (cgroup quota / affinity).
     full=True: the whole corpus (frac = 1); otherwise a bounded document sample, scaled to full-corpus iterations/s by
-    the sample's share of the work (`frac`) and labelled "sample"."""
+    the sample's share of the work (`frac`) and labelled "sample".
+    check(om, iters, threads) -> (parity block, oracle seconds per iteration): the warm-up + timed oracle iterations are run
+    THROUGH oracle/parity.py, i.e. they are at the same time the checker of the HIP engine on the same full corpus (teacher
+    forced, every document and every global compared); the block is returned under "parity"."""
     threads, info = usable_cpus()
     m = make()
-    for _ in range(warm):
-        step(m, threads)                                # OpenMP start-up, first touch
-    t0 = time.perf_counter(); n = 0
-    while n < timed and (n == 0 or time.perf_counter() - t0 < budget_s):
-        step(m, threads); n += 1
-    omp = n / (time.perf_counter() - t0)
+    block = None
+    if check is not None:
+        block, secs = check(m, warm + timed, threads)
+        n = timed
+        omp = n / sum(secs[warm:])
+    else:
+        for _ in range(warm):
+            step(m, threads)                                # OpenMP start-up, first touch
+        t0 = time.perf_counter(); n = 0
+        while n < timed and (n == 0 or time.perf_counter() - t0 < budget_s):
+            step(m, threads); n += 1
+        omp = n / (time.perf_counter() - t0)
     name = "value" if full else "value (sample, scaled)"
-    return {"value": omp * frac, "value_is": "full corpus" if full else "sample scaled by work fraction", "unit": "VB iters/sec",
-            "cores": threads, "host_cpus": info, "kind": "port",
-            "sample": f"fp64 C oracle ({kind}), {sample_note}; {warm} warm-up + {n} timed iterations from the cold start on {threads} OpenMP "
-                      f"threads" + ("" if full else f"; {name} = sample iters/s x work fraction {frac:.4f}")}
+    out = {"value": omp * frac, "value_is": "full corpus" if full else "sample scaled by work fraction", "unit": "VB iters/sec",
+           "cores": threads, "host_cpus": info, "kind": "port",
+           "sample": f"fp64 C oracle ({kind}), {sample_note}; {warm} warm-up + {n} timed iterations from the cold start on {threads} OpenMP "
+                     f"threads" + (" (the oracle's own calls of the parity check's teacher-forced iterations)" if check else "")
+                     + ("" if full else f"; {name} = sample iters/s x work fraction {frac:.4f}")}
+    if block is not None:
+        block["against"] = f"fp64 C oracle ({kind}), the cpu_baseline's own iterations on the FULL workload"
+        out["parity"] = block
+    return out
+
+
+def _log(*a):
+    print(*a, file=sys.stderr, flush=True)
 
 
 def window(fn, sync, burnin, warmup, steps):
@@ -84,10 +102,11 @@ def lda100(burnin=60, warmup=3, steps=20, cpu=True):
     gm.close()
     if cpu:
         line["cpu_baseline"] = lda100_cpu(pc)
+        line["parity"] = line["cpu_baseline"].pop("parity", None)
     return line
 
 
-def lda100_cpu(pc=None):
+def lda100_cpu(pc=None, parity=True):
     from oracle import oracle as oc
     K = 100
     pc = pc or tm.syn_nsf()
@@ -95,8 +114,16 @@ def lda100_cpu(pc=None):
 
     def ostep(m, nt):
         m.estep(omp_threads=nt); m.update_beta(); m.update_alpha()
+    def check(om, iters, threads):
+        from oracle import parity as op
+        gm = tm.gpuLDA(pc, K)
+        gm.beta = np.asfortranarray(beta0); gm.beta_old = gm.beta.copy(order="F"); gm.update_buffer()
+        try:
+            return op.lda_parity(gm, om, iters=iters, threads=threads, log=_log)
+        finally:
+            gm.close()
     out = cpu_line("port of src/LDA.jl train!", lambda: oc.LDA(oc.CSR(pc.doc_ptr, pc.terms, pc.counts, pc.V), K, beta0), ostep,
-                   1.0, f"FULL SYN-NSF ({pc.M} documents, {pc.nnz} nnz), K=100", warm=1, timed=1, full=True)
+                   1.0, f"FULL SYN-NSF ({pc.M} documents, {pc.nnz} nnz), K=100", warm=1, timed=1, full=True, check=check if parity else None)
     oc.lib().orc_omp_pool_free()
     return out
 
@@ -146,6 +173,7 @@ def ctm(burnin=60, warmup=2, steps=8, cpu=True, K=50):        # 60 burn-in itera
     gm.close()
     if cpu and K == 50:
         line["cpu_baseline"] = ctm_cpu(pc)
+        line["parity"] = line["cpu_baseline"].pop("parity", None)
     return line
 
 
@@ -154,7 +182,7 @@ def ctm100(cpu=False):
     return ctm(burnin=20, warmup=2, steps=6, cpu=False, K=100)
 
 
-def ctm_cpu(pc=None):
+def ctm_cpu(pc=None, parity=True):
     from oracle import oracle as oc
     K = 50
     pc = pc or tm.syn_nsf()
@@ -162,8 +190,18 @@ def ctm_cpu(pc=None):
 
     def ostep(m, nt):
         m.estep(omp_threads=nt); m.update_beta(); m.update_sigma_mu()
+    def check(om, iters, threads):
+        from oracle import parity as op
+        gm = tm.gpuCTM(pc, K)
+        gm.beta = np.asfortranarray(beta0); gm.beta_old = gm.beta.copy(order="F"); gm.update_buffer()
+        try:
+            return op.ctm_parity(gm, om, iters=iters, threads=threads, log=_log)
+        finally:
+            gm.close()
+    # two iterations: the cold start (lambda = 0, sigma = I) and the state one iteration later (mu, sigma, lambda moved)
     return cpu_line("port of src/CTM.jl train!", lambda: oc.CTM(oc.CSR(pc.doc_ptr, pc.terms, pc.counts, pc.V), K, beta0), ostep,
-                    1.0, f"FULL SYN-NSF ({pc.M} documents), K=50; one iteration takes ~10 s, so no warm-up iteration", warm=0, timed=1, full=True)
+                    1.0, f"FULL SYN-NSF ({pc.M} documents), K=50; one iteration takes ~5-10 s, so no warm-up iteration", warm=0, timed=2 if parity else 1,
+                    full=True, check=check if parity else None)
 
 
 def ctpf(burnin=300, warmup=10, steps=200, cpu=True):
@@ -197,10 +235,11 @@ def ctpf(burnin=300, warmup=10, steps=200, cpu=True):
     gm.close()
     if cpu:
         line["cpu_baseline"] = ctpf_cpu(pc)
+        line["parity"] = line["cpu_baseline"].pop("parity", None)
     return line
 
 
-def ctpf_cpu(pc=None):
+def ctpf_cpu(pc=None, parity=True):
     from oracle import oracle as oc
     K = 50
     pc = pc or tm.syn_citeu()
@@ -208,9 +247,18 @@ def ctpf_cpu(pc=None):
 
     def ostep(m, nt):
         m.estep(omp_threads=nt); m.mstep()
+    def check(om, iters, threads):
+        from oracle import parity as op
+        gm = tm.gpuCTPF(pc, K)
+        gm.alef = np.asfortranarray(alef0); gm.alef_old = gm.alef.copy(order="F"); gm.update_buffer()
+        try:
+            return op.ctpf_parity(gm, om, iters=iters, threads=threads, log=_log)
+        finally:
+            gm.close()
     return cpu_line("port of src/CTPF.jl train!",
                     lambda: oc.CTPF(oc.CSR(pc.doc_ptr, pc.terms, pc.counts, pc.V, pc.rdr_ptr, pc.readers, pc.ratings, pc.U), K, alef0),
-                    ostep, 1.0, f"FULL SYN-CITEU ({pc.M} documents, {pc.nnz} term + {pc.nR} reader entries), K=50", warm=1, timed=2, full=True)
+                    ostep, 1.0, f"FULL SYN-CITEU ({pc.M} documents, {pc.nnz} term + {pc.nR} reader entries), K=50", warm=1, timed=2, full=True,
+                    check=check if parity else None)
 
 
 def flda(burnin=60, warmup=3, steps=20, cpu=True):

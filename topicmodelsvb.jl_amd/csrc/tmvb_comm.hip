@@ -51,7 +51,17 @@ std::once_flag g_rccl_once;
 void rccl_bind()
 {
     RcclApi& a = g_rccl;
-    if (const char* e = getenv("TMVB_RCCL_LIB")) a.so = dlopen(e, RTLD_NOW | RTLD_LOCAL);
+    // dlerror() clears the error it returns: read it ONCE, right after the failed dlopen it belongs to
+    std::string why;
+    auto open = [&](const char* path) {
+        a.so = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+        if (!a.so) { const char* de = dlerror(); why = de ? de : (std::string(path) + " not found"); }
+    };
+    if (const char* e = getenv("TMVB_RCCL_LIB")) {
+        // an explicit choice is used as given: if it does not load, say so instead of silently binding another copy
+        open(e);
+        if (!a.so) { a.error = "RCCL is not available: TMVB_RCCL_LIB=" + std::string(e) + ": " + why; return; }
+    }
     // first choice: the RCCL that sits next to the HIP runtime this process really runs on (found through dladdr) -- an RCCL
     // built for another HIP release fails in ncclCommInitRank with "unhandled cuda error" (seen with PyTorch's bundled copy
     // under /opt/rocm's runtime); RTLD_LOCAL + dlsym on our own handle keep a second copy in the process from interfering
@@ -62,16 +72,16 @@ void rccl_bind()
             const size_t slash = path.find_last_of('/');
             if (slash != std::string::npos) {
                 path = path.substr(0, slash + 1) + "librccl.so.1";
-                a.so = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+                open(path.c_str());
             }
         }
     }
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};      // then the loader's search path (our rpath)
     for (const char* n : names) {
         if (a.so) break;
-        a.so = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        open(n);
     }
-    if (!a.so) { a.error = std::string("RCCL is not available: ") + (dlerror() ? dlerror() : "librccl.so.1 not found") + " (set TMVB_RCCL_LIB)"; return; }
+    if (!a.so) { a.error = "RCCL is not available: " + (why.empty() ? std::string("librccl.so.1 not found") : why) + " (set TMVB_RCCL_LIB)"; return; }
 #define TMVB_RCCL_SYM(field, sym)                                                         \
     a.field = reinterpret_cast<decltype(a.field)>(dlsym(a.so, #sym));                     \
     if (!a.field) { a.error = "librccl has no symbol " #sym; return; }

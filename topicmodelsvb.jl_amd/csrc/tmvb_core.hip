@@ -87,13 +87,13 @@ hipStream_t tmvb_pool_stream(int device, int slot, bool high_priority)
     return st;
 }
 
-// Eight hardware queues for the process's HIP streams unless the user says otherwise (the runtime's default is four).  The models run
-// two to four streams each; with four queues a model built after others had been closed shared queues in ways that cost up to a third
-// of its speed (one process, ctpf / lda100 / ctm / ctpf / lda100 / ...: LDA K = 100 531 it/s and CTM 185 against 838 and 202 in fresh
-// processes), with eight every model of such a sequence runs at its fresh-process rate (832 - 843, 201 - 203; profiles/r3_stream_pool.txt).
-// The runtime reads the variable when it initialises, so this only helps when the library is loaded before the first HIP call
-// (python: _lib.py sets it too; bench.py before importing torch; Julia: TMVBHip.__init__).
-__attribute__((constructor)) static void tmvb_env_defaults() { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+// Eight hardware queues (GPU_MAX_HW_QUEUES=8; the runtime's default is four) is the setting the stream plans were measured with: the
+// models run two to four streams each, and with four queues a model built after others had been closed shared queues in ways that
+// cost up to a third of its speed (one process, ctpf / lda100 / ctm / ctpf / lda100 / ...: LDA K = 100 531 it/s and CTM 185 against
+// 838 and 202 in fresh processes; with eight every model runs at its fresh-process rate, profiles/r3_stream_pool.txt).  The runtime
+// reads the variable when it initialises, and it is process-wide, so it is the LAUNCHER's to set, visibly and overridably -- python:
+// _lib.py, bench.py before importing torch; Julia: TMVBHip.__init__; README -- and not this library's: loading a shared object must
+// not reconfigure every other HIP user of the process (round-3 advice; the constructor that did so is gone).
 
 extern "C" int tmvb_ctx_create(int32_t device_id, void* hip_stream, tmvb_ctx** out)
 {
@@ -154,6 +154,9 @@ static int upload(tmvb_ctx* ctx, T** dptr, const T* h, size_t n)
         return TMVB_ENOMEM;
     }
     if (n) TMVB_HIP(hipMemcpyAsync(*dptr, h, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    // the slack (and the one element an EMPTY array still holds) is defined memory: the branch-free tile loads read entry 0 for an
+    // empty document and use it as a row index before the weight masks it (tmvb_gridtile.h: grid_load_tile) -- id 0 is always valid
+    TMVB_HIP(hipMemsetAsync((char*)*dptr + n * sizeof(T), 0, bytes - n * sizeof(T), ctx->stream));
     return TMVB_OK;
 }
 

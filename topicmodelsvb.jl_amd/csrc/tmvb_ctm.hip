@@ -1851,12 +1851,21 @@ extern "C" int tmvb_ctm_reduce_docs(tmvb_ctm* h)
     TMVB_HIP(hipSetDevice(h->ctx->device));
     // tmvb_ctm_estep already computed the tail (on a side stream, under its statistics pass) from the state it left behind
     if (h->tail_fresh) { h->tail_fresh = false; return TMVB_OK; }
+    // recomputing the tail: a sigma staged from the previous tail is not this tail's, and the staging kernel may still be reading it
+    h->sigma_staged = false;
+    { int jrc = ctm_join_spec(h); if (jrc) return jrc; }
     return ctm_reduce_docs_on(h, h->ctx->stream);
 }
 
 extern "C" int tmvb_ctm_stats(tmvb_ctm* h, void** dev_ptr, int64_t* n_f32)
 {
     TMVB_REQUIRE(h && dev_ptr && n_f32, TMVB_EINVAL, "tmvb_ctm_stats: NULL argument");
+    // the caller may rewrite the tail through this pointer (a host-side all-reduce): a sigma that tmvb_ctm_estep inverted
+    // speculatively from the tail as it is NOW must not be committed afterwards (round-3 advice), and whatever the caller
+    // enqueues on the context's stream must come after the staging kernel's reads
+    h->sigma_staged = false;
+    TMVB_HIP(hipSetDevice(h->ctx->device));
+    { int jrc = ctm_join_spec(h); if (jrc) return jrc; }
     *dev_ptr = h->d_stats;
     *n_f32 = h->stats_len();
     return TMVB_OK;
@@ -1867,6 +1876,8 @@ extern "C" int tmvb_ctm_bind_stats(tmvb_ctm* h, void* dev_ptr, int64_t n_f32)
     TMVB_REQUIRE(h && dev_ptr, TMVB_EINVAL, "tmvb_ctm_bind_stats: NULL argument");
     TMVB_REQUIRE(n_f32 >= h->stats_len(), TMVB_ESHAPE, "tmvb_ctm_bind_stats: buffer holds %lld floats, need %lld", (long long)n_f32, (long long)h->stats_len());
     TMVB_HIP(hipSetDevice(h->ctx->device));
+    h->sigma_staged = false;                                    // as tmvb_ctm_stats: the tail leaves the library's hands
+    { int jrc = ctm_join_spec(h); if (jrc) return jrc; }
     TMVB_HIP(hipMemcpyAsync(dev_ptr, h->d_stats, (size_t)h->stats_len() * sizeof(float), hipMemcpyDeviceToDevice, h->ctx->stream));
     TMVB_HIP(hipStreamSynchronize(h->ctx->stream));
     if (h->own_stats) (void)hipFree(h->d_stats);
@@ -1949,6 +1960,8 @@ extern "C" int tmvb_ctm_update_mu(tmvb_ctm* h)
 {
     TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_ctm_update_mu: handle is NULL");
     h->tail_fresh = false; h->sigma_staged = false;     // the scatter matrix of the tail was taken about the mu that changes now
+    TMVB_HIP(hipSetDevice(h->ctx->device));
+    { int jrc = ctm_join_spec(h); if (jrc) return jrc; }        // a staging kernel still running on the side stream reads d_mu / d_mu_f
     return ctm_sigma_mu(h, 0, 1, false, nullptr);
 }
 

@@ -660,6 +660,128 @@ __global__ __launch_bounds__(64) void ctpf_rates_kernel(int K, double hb, double
     }
 }
 
+// ---- the fused M-step (K <= 64; round 4).  The M-step used to be six dependent launches of 4-7 us each (column sums of gimel / zayin in
+// two stages, the shape update, column sums of alef / he in two stages, the rates): 36 us of a 185 us iteration, most of it kernel
+// boundaries.  Now two launches:
+//   A  grid (NB, 3), lane = topic, one wave per id / document, blocks own contiguous id ranges:
+//        y = 0  he:   he_old <- he; he <- e + stats; stats <- 0; TH <- exp(psi(he))        (update_he!   src/CTPF.jl:266-270)
+//        y = 1  alef: the same with a, TA                                                   (update_alef! :251-255)
+//        y = 2  sum_d gimel_d and sum_d zayin_d (only when tmvb_ctpf_reduce_docs deferred them; a sharded run all-reduces them first)
+//      each block also leaves the fp64 column sums of what it wrote / read (fixed order: ids ascending per wave, then the four
+//      waves) in partial[y][block][topic];
+//   B  one block of 16 waves: wave (m, part) adds the partial rows b = part, part + 4, ... of matrix m in order, the four parts meet in
+//      LDS, and wave 0 runs update_dalet! / update_het! / update_bet! / update_vav! (:295-305, :281-291) -- every rate depends on its own
+//      topic's sums only.
+// Deterministic (no atomics, fixed summation order): run-to-run bitwise reproducible like the two-stage column sums it replaces.
+struct CtpfMstepJob { float* stats; float prior; float* X; float* X_old; float* T; int64_t n_ids; double* partial; };
+
+__global__ __launch_bounds__(256) void ctpf_mstep_a_kernel(CtpfMstepJob jh, CtpfMstepJob ja, const float* __restrict__ gimel,
+                                                           const float* __restrict__ zayin, int64_t M, double* __restrict__ part_g,
+                                                           double* __restrict__ part_z, int K, int KP)
+{
+    __shared__ double red[2][4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nbk = (int)gridDim.x, bx = (int)blockIdx.x;
+    const bool on = lane < K;
+    double a0 = 0.0, a1 = 0.0;
+    if (blockIdx.y < 2) {
+        const CtpfMstepJob j = blockIdx.y ? ja : jh;
+        const int64_t per = (j.n_ids + nbk - 1) / nbk;
+        const int64_t lo = (int64_t)bx * per, hi = min(lo + per, j.n_ids);
+        for (int64_t id0 = lo + wv; id0 < hi; id0 += 16) {            // four ids of this wave per trip: their loads in flight together
+            float xo[4], sv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t id = min(id0 + 4 * u, hi - 1);
+                const int64_t q = id * K + (on ? lane : 0);
+                xo[u] = j.X[q]; sv[u] = j.stats[q];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t id = id0 + 4 * u;
+                if (id >= hi) break;                                  // wave-uniform
+                float t = 0.0f;
+                if (on) {
+                    const float x = j.prior + sv[u];
+                    if (j.X_old) j.X_old[id * K + lane] = xo[u];      // X_old <- X
+                    j.X[id * K + lane] = x; j.stats[id * K + lane] = 0.0f;
+                    t = expf(digamma_f(x));
+                    a0 += (double)x;
+                }
+                if (lane < KP) j.T[id * KP + lane] = t;
+            }
+        }
+        red[0][wv][lane] = a0;
+        __syncthreads();
+        if (wv == 0 && on) j.partial[(int64_t)bx * K + lane] = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
+        return;
+    }
+    const int64_t per = (M + nbk - 1) / nbk;
+    const int64_t lo = (int64_t)bx * per, hi = min(lo + per, M);
+    for (int64_t d0 = lo + wv; d0 < hi; d0 += 16) {
+        float g[4], z[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t q = min(d0 + 4 * u, hi - 1) * K + (on ? lane : 0);
+            g[u] = gimel[q]; z[u] = zayin[q];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (d0 + 4 * u >= hi) break;
+            a0 += (double)g[u]; a1 += (double)z[u];
+        }
+    }
+    red[0][wv][lane] = a0; red[1][wv][lane] = a1;
+    __syncthreads();
+    if (wv == 0 && on) {
+        part_g[(int64_t)bx * K + lane] = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
+        part_z[(int64_t)bx * K + lane] = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
+    }
+}
+
+__global__ __launch_bounds__(1024) void ctpf_mstep_b_kernel(int K, int nb, int with_docs, double hb, double hd, double hf, double hh,
+                                                            const double* __restrict__ part_he, const double* __restrict__ part_alef,
+                                                            const double* __restrict__ part_g, const double* __restrict__ part_z,
+                                                            double* __restrict__ rs_he, double* __restrict__ rs_alef,
+                                                            double* __restrict__ sum_gimel, double* __restrict__ sum_zayin,
+                                                            float* __restrict__ tail /* [2][K] fp32 copies of the document sums */,
+                                                            double* __restrict__ rates, float* __restrict__ lrates)
+{
+    __shared__ double red[4][4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, m = w >> 2, part = w & 3;
+    const bool on = lane < K;
+    const double* src = m == 0 ? part_he : m == 1 ? part_alef : m == 2 ? part_g : part_z;
+    double acc = 0.0;
+    if (m < 2 || with_docs) {
+        for (int b0 = part; b0 < nb; b0 += 32) {                       // eight partial rows of this wave in flight per trip
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)min(b0 + 4 * u, nb - 1) * K + (on ? lane : 0)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (b0 + 4 * u < nb) acc += v[u];
+        }
+    }
+    red[m][part][lane] = acc;
+    __syncthreads();
+    if (w != 0 || !on) return;
+    double tot[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) tot[q] = (red[q][0][lane] + red[q][1][lane]) + (red[q][2][lane] + red[q][3][lane]);
+    const int i = lane;
+    rs_he[i] = tot[0]; rs_alef[i] = tot[1];
+    if (with_docs) { sum_gimel[i] = tot[2]; sum_zayin[i] = tot[3]; tail[i] = (float)tot[2]; tail[K + i] = (float)tot[3]; }
+    else { tot[2] = sum_gimel[i]; tot[3] = sum_zayin[i]; }
+    const double bet = rates[i], vav = rates[K + i], dalet = rates[2 * K + i], het = rates[3 * K + i];
+    const double dalet_n = (hd + tot[1] / bet) + tot[0] / vav;                    // :297 (old bet, vav)
+    const double het_n = hh + tot[0] / vav;                                       // :304
+    const double bet_n = hb + tot[2] / dalet_n;                                   // :283 (new dalet)
+    const double vav_n = (hf + tot[2] / dalet_n) + tot[3] / het_n;                // :290
+    rates[4 * K + i] = bet; rates[5 * K + i] = vav; rates[6 * K + i] = dalet; rates[7 * K + i] = het;
+    rates[i] = bet_n; rates[K + i] = vav_n; rates[2 * K + i] = dalet_n; rates[3 * K + i] = het_n;
+    lrates[i] = (float)log(bet_n); lrates[K + i] = (float)log(vav_n);
+    lrates[2 * K + i] = (float)log(dalet_n); lrates[3 * K + i] = (float)log(het_n);
+}
+
 // ------------------------------------------------------------------------------ ELBO (src/CTPF.jl:111-247)
 // The Binomial sums  sum_y pdf(Binomial(n,p),y) lgamma(y+1)  enter Elogpya/Elogpyb/Elogpz with a minus sign
 // (src/CTPF.jl:116,:127,:138) and -Elogqy/-Elogqz through entropy(Multinomial) with a plus sign (:183,:192): they
@@ -992,6 +1114,7 @@ struct tmvb_ctpf {
     double* d_rates = nullptr; float* d_lrates = nullptr;          // [8][K], [4][K]
     double* d_lrates_d = nullptr;                                  // [8][K] log(rates) in fp64 for update_elbo! (filled per call)
     bool rs_fresh = false;                                         // d_rs_alef / d_rs_he are the row sums of the current alef / he
+    bool docs_pending = false;                                     // tmvb_ctpf_reduce_docs was asked for and deferred into the fused M-step (K <= 64, one context)
     float* d_gimel = nullptr; float* d_gimel_old = nullptr; float* d_zayin = nullptr; float* d_zayin_old = nullptr;
     float* d_wtok = nullptr; float* d_wrdr = nullptr; float* d_E1 = nullptr; float* d_E2 = nullptr;
     float* d_ts_partial = nullptr; float* d_ts_partial2 = nullptr;   // multi-chunk partials of the term / reader statistics passes
@@ -1427,16 +1550,36 @@ static int ctpf_reduce_docs_on(tmvb_ctpf* h, hipStream_t st)
                         {h->d_zayin, h->M, h->d_partial2, h->d_sum_z, h->tail() + h->K}, st);
 }
 
+static bool ctpf_mstep_fused(const tmvb_ctpf* h)
+{
+    static const bool env = [] { const char* e = getenv("TMVB_CTPF_FUSED_MSTEP"); return !(e && atoi(e) == 0); }();
+    return env && h->K <= 64;
+}
+
+// the document sums a deferred tmvb_ctpf_reduce_docs still owes (anything that hands the statistics tail out needs them now)
+static int ctpf_flush_docs(tmvb_ctpf* h)
+{
+    if (!h->docs_pending) return TMVB_OK;
+    h->docs_pending = false;
+    return ctpf_reduce_docs_on(h, h->ctx->stream);
+}
+
 extern "C" int tmvb_ctpf_reduce_docs(tmvb_ctpf* h)
 {
     TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_ctpf_reduce_docs: handle is NULL");
     TMVB_HIP(hipSetDevice(h->ctx->device));
+    // one context, K <= 64: the sums ride in the fused M-step's first launch (tmvb_ctpf_mstep) instead of two launches of their own;
+    // a sharded handle needs them in the statistics tail before its all-reduce
+    if (!h->distributed && ctpf_mstep_fused(h)) { h->docs_pending = true; return TMVB_OK; }
+    h->docs_pending = false;
     return ctpf_reduce_docs_on(h, h->ctx->stream);
 }
 
 extern "C" int tmvb_ctpf_stats(tmvb_ctpf* h, void** dev_ptr, int64_t* n_f32)
 {
     TMVB_REQUIRE(h && dev_ptr && n_f32, TMVB_EINVAL, "tmvb_ctpf_stats: NULL argument");
+    TMVB_HIP(hipSetDevice(h->ctx->device));
+    { int frc = ctpf_flush_docs(h); if (frc) return frc; }
     *dev_ptr = h->d_stats;
     *n_f32 = h->stats_len();
     return TMVB_OK;
@@ -1447,6 +1590,7 @@ extern "C" int tmvb_ctpf_bind_stats(tmvb_ctpf* h, void* dev_ptr, int64_t n_f32)
     TMVB_REQUIRE(h && dev_ptr, TMVB_EINVAL, "tmvb_ctpf_bind_stats: NULL argument");
     TMVB_REQUIRE(n_f32 >= h->stats_len(), TMVB_ESHAPE, "tmvb_ctpf_bind_stats: buffer holds %lld floats, need %lld", (long long)n_f32, (long long)h->stats_len());
     TMVB_HIP(hipSetDevice(h->ctx->device));
+    { int frc = ctpf_flush_docs(h); if (frc) return frc; }
     TMVB_HIP(hipMemcpyAsync(dev_ptr, h->d_stats, (size_t)h->stats_len() * sizeof(float), hipMemcpyDeviceToDevice, h->ctx->stream));
     TMVB_HIP(hipStreamSynchronize(h->ctx->stream));
     if (h->own_stats) (void)hipFree(h->d_stats);
@@ -1458,6 +1602,8 @@ extern "C" int tmvb_ctpf_bind_stats(tmvb_ctpf* h, void* dev_ptr, int64_t n_f32)
 extern "C" int tmvb_ctpf_set_distributed(tmvb_ctpf* h, int32_t distributed)
 {
     TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_ctpf_set_distributed: handle is NULL");
+    TMVB_HIP(hipSetDevice(h->ctx->device));
+    { int frc = ctpf_flush_docs(h); if (frc) return frc; }
     h->distributed = distributed != 0;
     return TMVB_OK;
 }
@@ -1471,8 +1617,26 @@ extern "C" int tmvb_ctpf_mstep(tmvb_ctpf* h)
     TMVB_HIP(hipSetDevice(ctx->device));
     int rc;
     if (h->distributed) {     // tail -> fp64 sums
+        h->docs_pending = false;
         if ((rc = tmvb_colsum(ctx, h->nslot, h->K, h->tail(), 1, h->d_partial, h->d_sum_g, nullptr))) return rc;
         if ((rc = tmvb_colsum(ctx, h->nslot, h->K, h->tail() + h->K, 1, h->d_partial, h->d_sum_z, nullptr))) return rc;
+    }
+    if (ctpf_mstep_fused(h)) {
+        constexpr int NB = 128;
+        static_assert(4 * NB <= 2 * TMVB_REDUCE_BLOCKS, "partial buffers");
+        const int with_docs = h->docs_pending ? 1 : 0;
+        h->docs_pending = false;
+        double* p_he = h->d_partial; double* p_alef = h->d_partial + (size_t)NB * h->K;
+        double* p_g = h->d_partial2; double* p_z = h->d_partial2 + (size_t)NB * h->K;
+        const CtpfMstepJob jh{h->he_stats(), (float)h->hyper[4], h->d_he, h->d_he_old, h->d_TH, h->U, p_he};
+        const CtpfMstepJob ja{h->d_stats, (float)h->hyper[0], h->d_alef, h->d_alef_old, h->d_TA, h->V, p_alef};
+        hipLaunchKernelGGL(ctpf_mstep_a_kernel, dim3(NB, with_docs ? 3 : 2), dim3(256), 0, ctx->stream, jh, ja, h->d_gimel, h->d_zayin, h->M, p_g, p_z, h->K, h->KP);
+        TMVB_HIP(hipGetLastError());
+        hipLaunchKernelGGL(ctpf_mstep_b_kernel, dim3(1), dim3(1024), 0, ctx->stream, h->K, NB, with_docs, h->hyper[1], h->hyper[3], h->hyper[5], h->hyper[7],
+                           p_he, p_alef, p_g, p_z, h->d_rs_he, h->d_rs_alef, h->d_sum_g, h->d_sum_z, h->tail(), h->d_rates, h->d_lrates);
+        TMVB_HIP(hipGetLastError());
+        h->rs_fresh = true;
+        return TMVB_OK;
     }
     // he_old <- he; he <- e + stats; TH refresh; rowsum(he)    (:266-270)
     // (measured: putting this branch on a second stream gains nothing -- the kernels are 5-8 us each and a

@@ -236,8 +236,6 @@ __global__ __launch_bounds__(64) void lda_estep_kernel(LdaParams p, int64_t firs
         }
         const float gsum = wave_sum(gl);
         const float dgs = digamma_f(gsum);
-    const float vtol2 = p.vtol * p.vtol;
-    const float keps4 = 0.25f * (float)K * TMVB_EPS_F;                            // K eps, a quarter per lane of the quad
         // update_Elogtheta!  src/LDA.jl:137-138 and the exit test :175
         float dl = 0.0f;
 #pragma unroll
@@ -1180,7 +1178,7 @@ extern "C" int tmvb_lda_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
         if ((rc = dmalloc(&h->d_topic_of_lane, tol.size()))) return rc;
         TMVB_HIP(hipMemcpy(h->d_topic_of_lane, tol.data(), tol.size() * sizeof(int), hipMemcpyHostToDevice));
     }
-    // grid-tile kernel (tmvb_gridtile.h): KP <= 60 (LPR <= 15: the widest instantiation stays within 256 VGPRs), statistics pass
+    // grid-tile kernel (tmvb_gridtile.h): KP <= 100 (LPR <= 25; up to 6 / 4 / 3 token pairs per lane for KP <= 60 / 76 / 100 within 256 VGPRs), statistics pass
     // recomputes the token weights (nothing per token is stored); TMVB_LDA_GRID=0 keeps the lane = token register tile
     h->grid_np_max = lda_grid_np_max(h->KP / 4);
     h->grid_path = h->reg_path && h->KP <= 100 && tmvb_termstats_recomputes(h->KP, h->e_padded) &&
