@@ -16,6 +16,7 @@
 #   pmc:<name>:<counters>:<cmd>   rocprofv3 --pmc <counters> --kernel-trace -- python <cmd> (counters in their OWN pass, never with
 #                            --stats / other trace domains)  -> pmc_<name>.txt (tools/counter_summary.py); env:PMC_KEEP_DB=1 keeps the db
 #   py:<script>[,args]       python <script> args            -> py_<n>.txt
+#   exe:<binary>[,args]      a prebuilt probe binary (tools/probes/...)  -> exe_<n>.txt
 #   env:<VAR=VALUE>  export for the steps that follow
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd "$R" || exit 1
 TAG=$1; shift
@@ -47,6 +48,7 @@ for step in "$@"; do
             db=$(find "$O/pmc_$name" -name "*.db" | head -1)
             python tools/counter_summary.py "$db" > "$O/pmc_$name.txt" 2>&1; head -30 "$O/pmc_$name.txt"
             [ -z "$KEEP_DB" ] && [ -z "$PMC_KEEP_DB" ] && find "$O/pmc_$name" -name "*.db" -delete ;;
+    exe)    ( time timeout 900 ${arg//,/ } ) > "$O/exe_$n.txt" 2>&1; echo "rc=$?" >> "$O/exe_$n.txt"; tail -40 "$O/exe_$n.txt" ;;
     py)     ( time timeout 1500 python ${arg//,/ } ) > "$O/py_$n.txt" 2>&1; echo "rc=$?" >> "$O/py_$n.txt"; tail -40 "$O/py_$n.txt" ;;
     *)      echo "unknown step $step" ;;
   esac
