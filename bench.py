@@ -57,16 +57,14 @@ def mstep_bytes(K, V):
     return 12 * K * V
 
 
-LDA_KERNEL_SOURCES = ("tmvb_lda.hip", "tmvb_gridtile.h", "tmvb_termstats.h", "tmvb_common_kernels.h", "tmvb_internal.h", "tmvb_regtile.h")
-
-
 def kernel_source_hash():
-    """sha256 over the sources of the LDA E-step kernels (the ones roofline.traffic is collected on): PMC numbers
-    collected on other kernels are stale."""
+    """sha256 over every kernel source under csrc/ (the statistics pass, the reductions and the headers are shared by the
+    models, so one stamp serves all PMC summaries): numbers collected on other kernels are stale."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "topicmodelsvb.jl_amd", "csrc")
-    for f in LDA_KERNEL_SOURCES:
-        h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 
@@ -75,7 +73,7 @@ def pmc_traffic(K, M, nnz):
     passes of this same command, tools/pmc_summary.py), corrected as MI355X_MICROARCH.md's HBM section prescribes for
     gfx950 (2 x FETCH_SIZE; KB units).  Returned only when the summary was collected on this workload AND on the kernel
     sources this run is built from (source hash stamped into the summary); otherwise null with the reason."""
-    for name in ("r3_lda_k50_pmc.json", "r2_lda_k50_pmc.json", "r1_lda_k50_pmc.json"):
+    for name in ("r4_lda50_pmc.json", "r3_lda_k50_pmc.json", "r2_lda_k50_pmc.json", "r1_lda_k50_pmc.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             break

@@ -15,6 +15,7 @@
 #                            env:TRACE_MARKER=<kernel substring>, + _timeline.txt with env:TRACE_TIMELINE=1)
 #   pmc:<name>:<counters>:<cmd>   rocprofv3 --pmc <counters> --kernel-trace -- python <cmd> (counters in their OWN pass, never with
 #                            --stats / other trace domains)  -> pmc_<name>.txt (tools/counter_summary.py); env:PMC_KEEP_DB=1 keeps the db
+#   pmcbytes:<model>         HBM bytes per iteration of lda50 | lda100 | ctm | ctpf (two --pmc passes) -> <model>_pmc.json / .txt
 #   py:<script>[,args]       python <script> args            -> py_<n>.txt
 #   exe:<binary>[,args]      a prebuilt probe binary (tools/probes/...)  -> exe_<n>.txt
 #   env:<VAR=VALUE>  export for the steps that follow
@@ -48,6 +49,13 @@ for step in "$@"; do
             db=$(find "$O/pmc_$name" -name "*.db" | head -1)
             python tools/counter_summary.py "$db" > "$O/pmc_$name.txt" 2>&1; head -30 "$O/pmc_$name.txt"
             [ -z "$KEEP_DB" ] && [ -z "$PMC_KEEP_DB" ] && find "$O/pmc_$name" -name "*.db" -delete ;;
+    pmcbytes) # pmcbytes:<lda50|lda100|ctm|ctpf>: FETCH_SIZE and WRITE_SIZE in separate passes over tools/pmc_window.py <model> 20 6,
+            # summarised per kernel and per iteration with the kernel-source hash stamped in -> <model>_pmc.json / .txt (copy to profiles/r4_<model>_pmc.*)
+            for c in FETCH_SIZE WRITE_SIZE; do
+              ( cd /tmp && timeout 900 rocprofv3 --pmc $c --kernel-trace -d "$O/pmcb_${arg}_$c" -- python $R/tools/pmc_window.py $arg 20 6 ) > "$O/pmcb_${arg}_$c.log" 2>&1; echo "rc=$?" >> "$O/pmcb_${arg}_$c.log"
+            done
+            python tools/pmc_summary.py $(find "$O/pmcb_${arg}_FETCH_SIZE" -name "*.db" | head -1) $(find "$O/pmcb_${arg}_WRITE_SIZE" -name "*.db" | head -1) --iters 26 --json "$O/${arg}_pmc.json" > "$O/${arg}_pmc.txt" 2>&1
+            head -12 "$O/${arg}_pmc.txt"; find "$O" -path "*pmcb_${arg}_*" -name "*.db" -delete ;;
     exe)    ( time timeout 900 ${arg//,/ } ) > "$O/exe_$n.txt" 2>&1; echo "rc=$?" >> "$O/exe_$n.txt"; tail -40 "$O/exe_$n.txt" ;;
     py)     ( time timeout 1500 python ${arg//,/ } ) > "$O/py_$n.txt" 2>&1; echo "rc=$?" >> "$O/py_$n.txt"; tail -40 "$O/py_$n.txt" ;;
     *)      echo "unknown step $step" ;;

@@ -67,6 +67,28 @@ def _log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def pmc_traffic(name):
+    """HBM bytes per outer iteration from the committed rocprofv3 PMC summary of this configuration (separate --pmc FETCH_SIZE /
+    --pmc WRITE_SIZE passes of tools/pmc_window.py <name>, summarised by tools/pmc_summary.py; 2 x FETCH_SIZE + WRITE_SIZE in KB as
+    MI355X_MICROARCH.md's HBM section prescribes for gfx950), summed over every kernel of an iteration.  Only when the summary was
+    collected on the kernel sources this build is made of (hash stamped into the summary); otherwise (None, reason)."""
+    from bench import kernel_source_hash
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", f"r4_{name}_pmc.json")
+    if not os.path.exists(path):
+        return None, f"no profiles/r4_{name}_pmc.json"
+    rows = json.load(open(path))
+    meta = rows.get("_meta", {})
+    if meta.get("kernel_source_hash") != kernel_source_hash():
+        return None, f"profiles/r4_{name}_pmc.json was collected on kernel sources {meta.get('kernel_source_hash')}, this build is {kernel_source_hash()} (stale)"
+    tot = sum((2.0 * r["fetch_kb_per_iteration"] + r["write_kb_per_iteration"]) * 1024.0 for k, r in rows.items() if k != "_meta")
+    return tot, f"profiles/r4_{name}_pmc.json (rocprofv3 --pmc, separate passes; 2*FETCH_SIZE+WRITE_SIZE over every dispatch of {meta.get('iterations')} iterations / that count)"
+
+
+def _traffic_fields(name, B):
+    t, src = pmc_traffic(name)
+    return {"traffic": t, "traffic_source": src, "traffic_over_algorithmic": (t / B) if t else None}
+
+
 def window(fn, sync, burnin, warmup, steps):
     """burn-in (state preparation) + warm-up untimed, then `steps` timed iterations between synchronisations."""
     for _ in range(burnin + warmup):
@@ -98,7 +120,7 @@ def lda100(burnin=60, warmup=3, steps=20, cpu=True):
                                    f"{warmup} warm-up + {steps} timed", "M": pc.M, "V": pc.V, "nnz": pc.nnz, "sweep_hist_last_step": hist},
             "cold_start": {"value": 1.0 / cold, "ms_per_step": 1e3 * cold, "window": f"iterations {warmup + 1}..{warmup + steps} from the cold start"},
             "roofline": {"bound": "hbm", "achieved": B / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": B / sec / 1e9 / HBM_PEAK_GBS,
-                         "algorithmic_bytes_per_iteration": B, "traffic": None}}
+                         "algorithmic_bytes_per_iteration": B, **_traffic_fields("lda100", B)}}
     gm.close()
     if cpu:
         line["cpu_baseline"] = lda100_cpu(pc)
@@ -169,7 +191,8 @@ def ctm(burnin=60, warmup=2, steps=8, cpu=True, K=50):        # 60 burn-in itera
                          "flops_per_iteration_executed": F_exec, "executed_TFLOPs": (F_exec / sec / 1e12) if F_exec else None,
                          "executed_frac": (F_exec / sec / 1e12 / F32_PEAK_TFLOPS) if F_exec else None,
                          "executed_is": "64 lanes x (CG wave trips x (2 KP^2 + 12 KP) + Newton wave trips x (2 KP^2 + 24 KP)) + token phase; idle lanes of a trip included",
-                         "hbm_GBs": B / sec / 1e9, "hbm_frac": B / sec / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_iteration": B, "traffic": None}}
+                         "hbm_GBs": B / sec / 1e9, "hbm_frac": B / sec / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_iteration": B,
+                         **(_traffic_fields("ctm", B) if K == 50 else {"traffic": None})}}
     gm.close()
     if cpu and K == 50:
         line["cpu_baseline"] = ctm_cpu(pc)
@@ -230,7 +253,7 @@ def ctpf(burnin=300, warmup=10, steps=200, cpu=True):
                        "M": pc.M, "V": pc.V, "U": pc.U, "nnz": pc.nnz, "nR": pc.nR, "sweep_hist_last_step": hist},
             "cold_start": {"value": 1.0 / cold, "ms_per_step": 1e3 * cold, "window": "iterations 6..55 from the cold start"},
             "roofline": {"bound": "hbm", "achieved": B / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": B / sec / 1e9 / HBM_PEAK_GBS,
-                         "algorithmic_bytes_per_iteration": B, "traffic": None},
+                         "algorithmic_bytes_per_iteration": B, **_traffic_fields("ctpf", B)},
             "recommend": {"ms_scores": ms_s, "ms_rank": ms_r, "pairs": pc.M * pc.U}}
     gm.close()
     if cpu:

@@ -98,21 +98,26 @@ template <bool SWAP_AB>
 __device__ __forceinline__ void matvec_v1(const float* __restrict__ SA, const float (&p)[R], float (&yo)[R], const int lane)
 {
     const v4f* base = (const v4f*)(SA + (lane & 3) * R);
+    v4f acc[R / 4];                                    // thirteen independent accumulator chains (k outer, row group inner):
+#pragma unroll                                         // a 4x4x1 MFMA that waits for its own previous result costs ~90 cycles
+    for (int g = 0; g < R / 4; ++g) acc[g] = v4f{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int g = 0; g < R / 4; ++g) {
-        v4f acc = v4f{0.f, 0.f, 0.f, 0.f};
+    for (int k4 = 0; k4 < R / 4; ++k4) {
+        v4f a[R / 4];
 #pragma unroll
-        for (int k4 = 0; k4 < R / 4; ++k4) {
-            const v4f a = base[(g * 4 * R) / 4 + k4];
+        for (int g = 0; g < R / 4; ++g) a[g] = base[(g * 4 * R) / 4 + k4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if constexpr (SWAP_AB) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(p[4 * k4 + u], a[u], acc, 0, 0, 0);
-                else acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[u], p[4 * k4 + u], acc, 0, 0, 0);
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int g = 0; g < R / 4; ++g) {
+                if constexpr (SWAP_AB) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(p[4 * k4 + u], a[g][u], acc[g], 0, 0, 0);
+                else acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[g][u], p[4 * k4 + u], acc[g], 0, 0, 0);
             }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) yo[4 * g + i] = acc[i];
     }
+#pragma unroll
+    for (int g = 0; g < R / 4; ++g)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) yo[4 * g + i] = acc[g][i];
 }
 
 // ------------------------------------------------------------------------------------------------ V2: 32x32x2, A from LDS

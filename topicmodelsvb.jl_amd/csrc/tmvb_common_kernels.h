@@ -428,7 +428,13 @@ static inline int tmvb_launch_termstats(tmvb_ctx* ctx, int nslot, int KP, bool e
         const dim3 grid((unsigned)((ix.n_chunks + 3) / 4)), block(256);
         const int lpr = KP / 4;
         if (e_padded && lpr <= 32) {       // recompute w from (T row, E row, count): no per-token weights in memory
-            if (lpr == 13) hipLaunchKernelGGL((termstats_recompute_kernel<13, 16>), grid, block, 0, st, tp, lpr);
+            // PAD form: rows zero-padded to 4 * LANES floats, 32-bit byte offsets into E, 24-bit document ids (tmvb_termstats.h)
+            const int lanes = lpr <= 16 ? 16 : 32;
+            const bool pad = tp.estride >= 4 * lanes && ix.n_docs < (1 << 24) && (uint64_t)ix.n_docs * (uint64_t)tp.estride * 4u < (1ull << 32) &&
+                             !(getenv("TMVB_STATS_PAD") && atoi(getenv("TMVB_STATS_PAD")) == 0);
+            if (lpr == 13 && pad) hipLaunchKernelGGL((termstats_recompute_kernel<13, 16, true>), grid, block, 0, st, tp, lpr);
+            else if (lpr == 25 && pad) hipLaunchKernelGGL((termstats_recompute_kernel<25, 32, true>), grid, block, 0, st, tp, lpr);
+            else if (lpr == 13) hipLaunchKernelGGL((termstats_recompute_kernel<13, 16>), grid, block, 0, st, tp, lpr);
             else if (lpr == 25) hipLaunchKernelGGL((termstats_recompute_kernel<25, 32>), grid, block, 0, st, tp, lpr);
             else if (lpr <= 16) hipLaunchKernelGGL((termstats_recompute_kernel<0, 16>), grid, block, 0, st, tp, lpr);
             else hipLaunchKernelGGL((termstats_recompute_kernel<0, 32>), grid, block, 0, st, tp, lpr);

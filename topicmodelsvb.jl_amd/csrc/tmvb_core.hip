@@ -285,7 +285,7 @@ int tmvb_build_inv_index(tmvb_ctx* ctx, int64_t M, int64_t n_ids, const int64_t*
             for (int64_t q = h_ptr[d]; q < h_ptr[d + 1]; ++q) cnt[h_ids[q] + 1]++;
     for (int64_t j = 0; j < n_ids; ++j) cnt[j + 1] += cnt[j];
     const int64_t nnz = cnt[n_ids];
-    ix->n_ids = n_ids; ix->nnz = nnz;
+    ix->n_ids = n_ids; ix->nnz = nnz; ix->n_docs = M;
     std::vector<int32_t> doc(nnz), pos(nnz), inv(doc_piece ? 0 : nnz_all);
     std::vector<float> val(nnz);
     {

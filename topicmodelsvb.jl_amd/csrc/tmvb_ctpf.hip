@@ -661,121 +661,138 @@ __global__ __launch_bounds__(64) void ctpf_rates_kernel(int K, double hb, double
 }
 
 // ---- the fused M-step (K <= 64; round 4).  The M-step used to be six dependent launches of 4-7 us each (column sums of gimel / zayin in
-// two stages, the shape update, column sums of alef / he in two stages, the rates): 36 us of a 185 us iteration, most of it kernel
-// boundaries.  Now two launches:
-//   A  grid (NB, 3), lane = topic, one wave per id / document, blocks own contiguous id ranges:
-//        y = 0  he:   he_old <- he; he <- e + stats; stats <- 0; TH <- exp(psi(he))        (update_he!   src/CTPF.jl:266-270)
-//        y = 1  alef: the same with a, TA                                                   (update_alef! :251-255)
-//        y = 2  sum_d gimel_d and sum_d zayin_d (only when tmvb_ctpf_reduce_docs deferred them; a sharded run all-reduces them first)
-//      each block also leaves the fp64 column sums of what it wrote / read (fixed order: ids ascending per wave, then the four
-//      waves) in partial[y][block][topic];
-//   B  one block of 16 waves: wave (m, part) adds the partial rows b = part, part + 4, ... of matrix m in order, the four parts meet in
-//      LDS, and wave 0 runs update_dalet! / update_het! / update_bet! / update_vav! (:295-305, :281-291) -- every rate depends on its own
-//      topic's sums only.
-// Deterministic (no atomics, fixed summation order): run-to-run bitwise reproducible like the two-stage column sums it replaces.
-struct CtpfMstepJob { float* stats; float prior; float* X; float* X_old; float* T; int64_t n_ids; double* partial; };
+// two stages, the shape update, column sums of alef / he in two stages, the rates): 36 us of a 185 us iteration, nearly all of it
+// kernel boundaries and single-trip latencies.  Now ONE launch, grid (NB, 4) x 16 waves, lane = topic, a wave per id / document:
+//     y = 0  he:   he_old <- he; he <- e + stats; stats <- 0; TH <- exp(psi(he))        (update_he!   src/CTPF.jl:266-270)
+//     y = 1  alef: the same with a, TA                                                   (update_alef! :251-255)
+//     y = 2  sum_d gimel_d      y = 3  sum_d zayin_d      (only when tmvb_ctpf_reduce_docs deferred them to here; a sharded run
+//                                                          all-reduces them first and launches y = 0, 1 only)
+// Blocks own contiguous id ranges, every wave has all its (<= 8 / <= 16) rows in flight at once; each block leaves the fp64 column
+// sums of what it wrote / read in partial[y][block][topic] (ids ascending per wave, then the sixteen waves in order), and the block
+// that finishes LAST (a device-scope counter; no block ever waits for another) adds the partial rows in a fixed order and runs
+// update_dalet! / update_het! / update_bet! / update_vav! (:295-305, :281-291) -- every rate depends on its own topic's sums only.
+// Deterministic: which block happens to be last changes who adds, never the order of the additions; run-to-run bitwise reproducible
+// like the two-stage column sums it replaces.
+struct CtpfMstepJob { float* stats; float prior; float* X; float* X_old; float* T; int64_t n_ids; };
+struct CtpfMstepTail {
+    int with_docs;                     // 1: y = 2, 3 are part of this launch
+    double hb, hd, hf, hh;
+    double* partial;                   // [4][NB][K]
+    unsigned int* counter;             // zero between launches (the last block resets it)
+    double* rs_he; double* rs_alef; double* sum_gimel; double* sum_zayin;
+    float* tail;                       // [2][K] fp32 copies of the document sums (statistics tail)
+    double* rates; float* lrates;
+};
 
-__global__ __launch_bounds__(256) void ctpf_mstep_a_kernel(CtpfMstepJob jh, CtpfMstepJob ja, const float* __restrict__ gimel,
-                                                           const float* __restrict__ zayin, int64_t M, double* __restrict__ part_g,
-                                                           double* __restrict__ part_z, int K, int KP)
+__device__ __forceinline__ double ctpf_coherent_load(const double* p)
 {
-    __shared__ double red[2][4][64];
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(1024) void ctpf_mstep_kernel(CtpfMstepJob jh, CtpfMstepJob ja, const float* __restrict__ gimel,
+                                                          const float* __restrict__ zayin, int64_t M, CtpfMstepTail t, int K, int KP)
+{
+    __shared__ double red[16][64];
+    __shared__ unsigned int last_flag;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int nbk = (int)gridDim.x, bx = (int)blockIdx.x;
+    const int nbk = (int)gridDim.x, bx = (int)blockIdx.x, y = (int)blockIdx.y;
     const bool on = lane < K;
-    double a0 = 0.0, a1 = 0.0;
-    if (blockIdx.y < 2) {
-        const CtpfMstepJob j = blockIdx.y ? ja : jh;
+    double a0 = 0.0;
+    if (y < 2) {
+        const CtpfMstepJob j = y ? ja : jh;
         const int64_t per = (j.n_ids + nbk - 1) / nbk;
         const int64_t lo = (int64_t)bx * per, hi = min(lo + per, j.n_ids);
-        for (int64_t id0 = lo + wv; id0 < hi; id0 += 16) {            // four ids of this wave per trip: their loads in flight together
-            float xo[4], sv[4];
+        for (int64_t id0 = lo + wv; id0 < hi; id0 += 16 * 8) {        // eight ids of this wave per trip, their loads in flight together
+            float xo[8], sv[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int64_t id = min(id0 + 4 * u, hi - 1);
-                const int64_t q = id * K + (on ? lane : 0);
+            for (int u = 0; u < 8; ++u) {
+                const int64_t q = min(id0 + 16 * u, hi - 1) * K + (on ? lane : 0);
                 xo[u] = j.X[q]; sv[u] = j.stats[q];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int64_t id = id0 + 4 * u;
+            for (int u = 0; u < 8; ++u) {
+                const int64_t id = id0 + 16 * u;
                 if (id >= hi) break;                                  // wave-uniform
-                float t = 0.0f;
+                float tv = 0.0f;
                 if (on) {
                     const float x = j.prior + sv[u];
                     if (j.X_old) j.X_old[id * K + lane] = xo[u];      // X_old <- X
                     j.X[id * K + lane] = x; j.stats[id * K + lane] = 0.0f;
-                    t = expf(digamma_f(x));
+                    tv = expf(digamma_f(x));
                     a0 += (double)x;
                 }
-                if (lane < KP) j.T[id * KP + lane] = t;
+                if (lane < KP) j.T[id * KP + lane] = tv;
             }
         }
-        red[0][wv][lane] = a0;
-        __syncthreads();
-        if (wv == 0 && on) j.partial[(int64_t)bx * K + lane] = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
-        return;
-    }
-    const int64_t per = (M + nbk - 1) / nbk;
-    const int64_t lo = (int64_t)bx * per, hi = min(lo + per, M);
-    for (int64_t d0 = lo + wv; d0 < hi; d0 += 16) {
-        float g[4], z[4];
+    } else {
+        const float* __restrict__ X = y == 2 ? gimel : zayin;
+        const int64_t per = (M + nbk - 1) / nbk;
+        const int64_t lo = (int64_t)bx * per, hi = min(lo + per, M);
+        for (int64_t d0 = lo + wv; d0 < hi; d0 += 16 * 16) {
+            float g[16];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int64_t q = min(d0 + 4 * u, hi - 1) * K + (on ? lane : 0);
-            g[u] = gimel[q]; z[u] = zayin[q];
-        }
+            for (int u = 0; u < 16; ++u) g[u] = X[min(d0 + 16 * u, hi - 1) * K + (on ? lane : 0)];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (d0 + 4 * u >= hi) break;
-            a0 += (double)g[u]; a1 += (double)z[u];
+            for (int u = 0; u < 16; ++u) {
+                if (d0 + 16 * u >= hi) break;
+                a0 += (double)g[u];
+            }
         }
     }
-    red[0][wv][lane] = a0; red[1][wv][lane] = a1;
+    red[wv][lane] = a0;
     __syncthreads();
-    if (wv == 0 && on) {
-        part_g[(int64_t)bx * K + lane] = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
-        part_z[(int64_t)bx * K + lane] = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
+    // ---- last block done: every block publishes its partial row, then counts itself.  ONE wave writes the row, fences (release at
+    // device scope: a wave-level L2 write-back -- with all sixteen waves of all 256 blocks fencing, the kernel took 82 us) and counts;
+    // the last block reads the rows with device-coherent loads.
+    if (wv == 0) {
+        if (on) {
+            double s = 0.0;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) s += red[w][lane];
+            __hip_atomic_store(&t.partial[((int64_t)y * nbk + bx) * K + lane], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __threadfence();
+        if (lane == 0) {
+            const unsigned int total = gridDim.x * gridDim.y;
+            const unsigned int prev = atomicAdd(t.counter, 1u);
+            last_flag = (prev == total - 1u) ? 1u : 0u;
+        }
     }
-}
-
-__global__ __launch_bounds__(1024) void ctpf_mstep_b_kernel(int K, int nb, int with_docs, double hb, double hd, double hf, double hh,
-                                                            const double* __restrict__ part_he, const double* __restrict__ part_alef,
-                                                            const double* __restrict__ part_g, const double* __restrict__ part_z,
-                                                            double* __restrict__ rs_he, double* __restrict__ rs_alef,
-                                                            double* __restrict__ sum_gimel, double* __restrict__ sum_zayin,
-                                                            float* __restrict__ tail /* [2][K] fp32 copies of the document sums */,
-                                                            double* __restrict__ rates, float* __restrict__ lrates)
-{
-    __shared__ double red[4][4][64];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, m = w >> 2, part = w & 3;
-    const bool on = lane < K;
-    const double* src = m == 0 ? part_he : m == 1 ? part_alef : m == 2 ? part_g : part_z;
+    __syncthreads();
+    if (!last_flag) return;
+    if (wv == 0) __threadfence();
+    __syncthreads();
+    // wave (m, part): rows b = part, part + 4, ... of matrix m, all in flight
+    const int m = wv >> 2, part = wv & 3;
     double acc = 0.0;
-    if (m < 2 || with_docs) {
-        for (int b0 = part; b0 < nb; b0 += 32) {                       // eight partial rows of this wave in flight per trip
-            double v[8];
+    if (m < 2 || t.with_docs) {
+        const double* src = t.partial + (int64_t)m * nbk * K + (on ? lane : 0);
+        for (int b0 = part; b0 < nbk; b0 += 64) {
+            double v[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)min(b0 + 4 * u, nb - 1) * K + (on ? lane : 0)];
+            for (int u = 0; u < 16; ++u) v[u] = ctpf_coherent_load(src + (int64_t)min(b0 + 4 * u, nbk - 1) * K);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) if (b0 + 4 * u < nb) acc += v[u];
+            for (int u = 0; u < 16; ++u) if (b0 + 4 * u < nbk) acc += v[u];
         }
     }
-    red[m][part][lane] = acc;
+    __syncthreads();                                                  // red[] is reused
+    red[wv][lane] = acc;
     __syncthreads();
-    if (w != 0 || !on) return;
+    if (threadIdx.x == 0) *t.counter = 0u;                            // ready for the next launch (stream order)
+    if (wv != 0 || !on) return;
     double tot[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) tot[q] = (red[q][0][lane] + red[q][1][lane]) + (red[q][2][lane] + red[q][3][lane]);
+    for (int q = 0; q < 4; ++q) tot[q] = (red[4 * q][lane] + red[4 * q + 1][lane]) + (red[4 * q + 2][lane] + red[4 * q + 3][lane]);
     const int i = lane;
-    rs_he[i] = tot[0]; rs_alef[i] = tot[1];
-    if (with_docs) { sum_gimel[i] = tot[2]; sum_zayin[i] = tot[3]; tail[i] = (float)tot[2]; tail[K + i] = (float)tot[3]; }
-    else { tot[2] = sum_gimel[i]; tot[3] = sum_zayin[i]; }
+    t.rs_he[i] = tot[0]; t.rs_alef[i] = tot[1];
+    if (t.with_docs) { t.sum_gimel[i] = tot[2]; t.sum_zayin[i] = tot[3]; t.tail[i] = (float)tot[2]; t.tail[K + i] = (float)tot[3]; }
+    else { tot[2] = t.sum_gimel[i]; tot[3] = t.sum_zayin[i]; }
+    double* rates = t.rates; float* lrates = t.lrates;
     const double bet = rates[i], vav = rates[K + i], dalet = rates[2 * K + i], het = rates[3 * K + i];
-    const double dalet_n = (hd + tot[1] / bet) + tot[0] / vav;                    // :297 (old bet, vav)
-    const double het_n = hh + tot[0] / vav;                                       // :304
-    const double bet_n = hb + tot[2] / dalet_n;                                   // :283 (new dalet)
-    const double vav_n = (hf + tot[2] / dalet_n) + tot[3] / het_n;                // :290
+    const double dalet_n = (t.hd + tot[1] / bet) + tot[0] / vav;                  // :297 (old bet, vav)
+    const double het_n = t.hh + tot[0] / vav;                                     // :304
+    const double bet_n = t.hb + tot[2] / dalet_n;                                 // :283 (new dalet)
+    const double vav_n = (t.hf + tot[2] / dalet_n) + tot[3] / het_n;              // :290
     rates[4 * K + i] = bet; rates[5 * K + i] = vav; rates[6 * K + i] = dalet; rates[7 * K + i] = het;
     rates[i] = bet_n; rates[K + i] = vav_n; rates[2 * K + i] = dalet_n; rates[3 * K + i] = het_n;
     lrates[i] = (float)log(bet_n); lrates[K + i] = (float)log(vav_n);
@@ -1114,6 +1131,7 @@ struct tmvb_ctpf {
     double* d_rates = nullptr; float* d_lrates = nullptr;          // [8][K], [4][K]
     double* d_lrates_d = nullptr;                                  // [8][K] log(rates) in fp64 for update_elbo! (filled per call)
     bool rs_fresh = false;                                         // d_rs_alef / d_rs_he are the row sums of the current alef / he
+    unsigned int* d_mstep_counter = nullptr;                        // last-block-done counter of the fused M-step (zero between launches)
     bool docs_pending = false;                                     // tmvb_ctpf_reduce_docs was asked for and deferred into the fused M-step (K <= 64, one context)
     float* d_gimel = nullptr; float* d_gimel_old = nullptr; float* d_zayin = nullptr; float* d_zayin_old = nullptr;
     float* d_wtok = nullptr; float* d_wrdr = nullptr; float* d_E1 = nullptr; float* d_E2 = nullptr;
@@ -1153,6 +1171,7 @@ extern "C" int tmvb_ctpf_destroy(tmvb_ctpf* h)
     (void)hipFree(h->d_zayin); (void)hipFree(h->d_zayin_old); (void)hipFree(h->d_wtok); (void)hipFree(h->d_wrdr);
     (void)hipFree(h->d_E1); (void)hipFree(h->d_E2); (void)hipFree(h->d_ts_partial); (void)hipFree(h->d_ts_partial2); (void)hipFree(h->d_sweeps);
     (void)hipFree(h->d_doc_order); (void)hipFree(h->d_partial); (void)hipFree(h->d_partial2); (void)hipFree(h->d_rs_alef); (void)hipFree(h->d_rs_he);
+    (void)hipFree(h->d_mstep_counter);
     (void)hipFree(h->d_sum_g); (void)hipFree(h->d_sum_z); (void)hipFree(h->d_doc_val); (void)hipFree(h->d_elbo_partial); (void)hipFree(h->d_elbo);
     (void)hipFree(h->d_TAo); (void)hipFree(h->d_DA); (void)hipFree(h->d_THo); (void)hipFree(h->d_DH); (void)hipFree(h->d_lg_doc);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -1208,10 +1227,12 @@ extern "C" int tmvb_ctpf_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmv
         (rc = dmalloc(&h->d_E1, (size_t)h->KP * h->M + 4)) || (rc = dmalloc(&h->d_E2, (size_t)h->KP * h->M + 4)) ||
         (rc = dmalloc(&h->d_ts_partial, slots * (K + 1))) || (rc = dmalloc(&h->d_ts_partial2, slots * (K + 1))) || (rc = dmalloc(&h->d_sweeps, (size_t)h->M)) || (rc = dmalloc(&h->d_doc_order, (size_t)h->M)) ||
         (rc = dmalloc(&h->d_partial, (size_t)TMVB_REDUCE_BLOCKS * K)) || (rc = dmalloc(&h->d_partial2, (size_t)TMVB_REDUCE_BLOCKS * K)) || (rc = dmalloc(&h->d_rs_alef, K)) || (rc = dmalloc(&h->d_rs_he, K)) ||
+        (rc = dmalloc(&h->d_mstep_counter, 1)) ||
         (rc = dmalloc(&h->d_sum_g, K)) || (rc = dmalloc(&h->d_sum_z, K)) || (rc = dmalloc(&h->d_doc_val, (size_t)h->M)) ||
         (rc = dmalloc(&h->d_elbo_partial, 1024)) || (rc = dmalloc(&h->d_elbo, 2))) {
         return rc;
     }
+    TMVB_HIP(hipMemset(h->d_mstep_counter, 0, sizeof(unsigned int)));
     // processing order: first the documents of the LDS-tile kernel by rows (terms + readers), longest first, in LDS
     // buckets on the combined row count; then the register-tile documents (<= 128 terms and <= 64 readers) by tiles
     h->reg_path = (h->KP / 4) <= 15 && ((h->KP / 4) & 1);
@@ -1622,18 +1643,15 @@ extern "C" int tmvb_ctpf_mstep(tmvb_ctpf* h)
         if ((rc = tmvb_colsum(ctx, h->nslot, h->K, h->tail() + h->K, 1, h->d_partial, h->d_sum_z, nullptr))) return rc;
     }
     if (ctpf_mstep_fused(h)) {
-        constexpr int NB = 128;
-        static_assert(4 * NB <= 2 * TMVB_REDUCE_BLOCKS, "partial buffers");
+        constexpr int NB = 64;
+        static_assert(4 * NB <= TMVB_REDUCE_BLOCKS, "partial buffer");
         const int with_docs = h->docs_pending ? 1 : 0;
         h->docs_pending = false;
-        double* p_he = h->d_partial; double* p_alef = h->d_partial + (size_t)NB * h->K;
-        double* p_g = h->d_partial2; double* p_z = h->d_partial2 + (size_t)NB * h->K;
-        const CtpfMstepJob jh{h->he_stats(), (float)h->hyper[4], h->d_he, h->d_he_old, h->d_TH, h->U, p_he};
-        const CtpfMstepJob ja{h->d_stats, (float)h->hyper[0], h->d_alef, h->d_alef_old, h->d_TA, h->V, p_alef};
-        hipLaunchKernelGGL(ctpf_mstep_a_kernel, dim3(NB, with_docs ? 3 : 2), dim3(256), 0, ctx->stream, jh, ja, h->d_gimel, h->d_zayin, h->M, p_g, p_z, h->K, h->KP);
-        TMVB_HIP(hipGetLastError());
-        hipLaunchKernelGGL(ctpf_mstep_b_kernel, dim3(1), dim3(1024), 0, ctx->stream, h->K, NB, with_docs, h->hyper[1], h->hyper[3], h->hyper[5], h->hyper[7],
-                           p_he, p_alef, p_g, p_z, h->d_rs_he, h->d_rs_alef, h->d_sum_g, h->d_sum_z, h->tail(), h->d_rates, h->d_lrates);
+        const CtpfMstepJob jh{h->he_stats(), (float)h->hyper[4], h->d_he, h->d_he_old, h->d_TH, h->U};
+        const CtpfMstepJob ja{h->d_stats, (float)h->hyper[0], h->d_alef, h->d_alef_old, h->d_TA, h->V};
+        const CtpfMstepTail tl{with_docs, h->hyper[1], h->hyper[3], h->hyper[5], h->hyper[7], h->d_partial, h->d_mstep_counter,
+                               h->d_rs_he, h->d_rs_alef, h->d_sum_g, h->d_sum_z, h->tail(), h->d_rates, h->d_lrates};
+        hipLaunchKernelGGL(ctpf_mstep_kernel, dim3(NB, with_docs ? 4 : 2), dim3(1024), 0, ctx->stream, jh, ja, h->d_gimel, h->d_zayin, h->M, tl, h->K, h->KP);
         TMVB_HIP(hipGetLastError());
         h->rs_fresh = true;
         return TMVB_OK;

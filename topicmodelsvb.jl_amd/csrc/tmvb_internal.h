@@ -86,6 +86,7 @@ struct tmvb_bucket {
 struct tmvb_inv_index {
     bool built = false;
     int64_t n_ids = 0, nnz = 0;
+    int64_t n_docs = 0;                // documents of the corpus the index was built on (tok_doc values are < n_docs)
     int32_t* d_doc = nullptr;          // [nnz] document of each token, id-major order
     int32_t* d_pos = nullptr;          // [nnz] CSR position of each token, id-major order
     int32_t* d_inv = nullptr;          // [nnz] id-major position of each CSR token (inverse of d_pos)

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void termstats_chunk4_kernel(TermStatsParams p
 // registers) and the document's E row, which this kernel fetches anyway.  LANES = 16 or 32 lanes per row
 // slot (LPR active), 64 / LANES row slots per wave instruction; the dot product is a 4-step DPP row reduction
 // (+ one v_permlane16_swap step joining the two 16-lane rows of a 32-lane slot).
-template <int LPR_T, int LANES>
+template <int LPR_T, int LANES, bool PAD = false>
 __device__ __forceinline__ void termstats_recompute_body(const TermStatsParams& p, int LPR_rt)
 {
     static_assert(LANES == 16 || LANES == 32, "termstats_recompute_kernel: 16 or 32 lanes per row slot");
@@ -209,6 +209,48 @@ __device__ __forceinline__ void termstats_recompute_body(const TermStatsParams& 
         // `if (row_on && lane_on)` it kept ONE gather in flight per wave (s_waitcnt vmcnt(0) right behind every load).
         constexpr int U = 4;
         const bool pad_ok = ES >= 4 * LANES;            // uniform
+        // Fast form (round 4) when every row is padded with zeros to 4 * LANES floats and E is addressable by 32-bit byte offsets
+        // (PAD: decided by the launcher).  The pass is VALU-issue bound next to the document kernels, and of
+        // the ~27 VALU instructions it spent per row slot 9 were bookkeeping: four v_cndmask zeroing the pad lanes' E values (their T
+        // values are zero and the pad of E is zero: the products vanish by themselves), a v_cndmask + v_mad_i64_i32 + v_lshl_add_u64
+        // for a 64-bit row address (now one v_mad_u32_u24: uniform base + 32-bit offset, as the document kernels' tile loads), and a
+        // Newton step behind v_rcp_f32 (the document kernels' own w_n is c_n * v_rcp_f32(s_n)).  A slot past the chunk's end reads the
+        // staged entry (document 0, value 0): weight exactly 0 as long as its s is not 0, which keps > 0 guarantees for LDA; the
+        // select on the row stays for the models with keps = 0.
+        if constexpr (PAD) {
+            const char* __restrict__ Eb = (const char*)p.E;
+            const uint32_t esb = (uint32_t)ES * 4u, lane_off = 16u * (uint32_t)cc;
+            for (int k0 = 0; k0 < cnt; k0 += U * SLOTS) {
+                int2 dw[U];
+                float4 ev[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) dw[u] = dw_l[wv][k0 + u * SLOTS + rs];          // k0 + 3 SLOTS + rs <= 63
+#pragma unroll
+                for (int u = 0; u < U; ++u) ev[u] = *(const float4*)(Eb + (__umul24((uint32_t)dw[u].x, esb) + lane_off));
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (k0 + u * SLOTS >= cnt) break;                 // uniform: whole row-slot group past the end
+                    const v2f elo = v2f{ev[u].x, ev[u].y}, ehi = v2f{ev[u].z, ev[u].w};
+                    const v2f d2 = __builtin_elementwise_fma(tlo, elo, thi * ehi);
+                    float part = d2.x + d2.y;
+                    part += dpp_f<0xB1>(part);
+                    part += dpp_f<0x4E>(part);
+                    part += dpp_f<0x141>(part);
+                    part += dpp_f<0x140>(part);                       // all 16 lanes of a row hold the row's sum
+                    if (LANES == 32) {
+                        float sib = part;
+                        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(part), "+v"(sib));
+                        part += sib;
+                    }
+                    float wz = __builtin_bit_cast(float, dw[u].y) * __builtin_amdgcn_rcpf(part + p.keps);
+                    wz = (k0 + u * SLOTS + rs < cnt) ? wz : 0.0f;
+                    const v2f w2 = v2f{wz, wz};
+                    alo = __builtin_elementwise_fma(w2, elo, alo);
+                    ahi = __builtin_elementwise_fma(w2, ehi, ahi);
+                    wl += wz;
+                }
+            }
+        } else
         for (int k0 = 0; k0 < cnt; k0 += U * SLOTS) {
             int2 dw[U];
             bool ron[U];
@@ -282,10 +324,10 @@ __device__ __forceinline__ void termstats_recompute_body(const TermStatsParams& 
     }
 }
 
-template <int LPR_T, int LANES>
+template <int LPR_T, int LANES, bool PAD = false>
 __global__ __launch_bounds__(256) void termstats_recompute_kernel(TermStatsParams p, int LPR_rt)
 {
-    termstats_recompute_body<LPR_T, LANES>(p, LPR_rt);
+    termstats_recompute_body<LPR_T, LANES, PAD>(p, LPR_rt);
 }
 // Two independent passes (CTPF: the term index and the reader index) in ONE launch, blockIdx.y selects the pass: run on two streams
 // they cost a ~19 us cross-stream join in a 0.3 ms iteration.
