@@ -57,14 +57,22 @@ def mstep_bytes(K, V):
     return 12 * K * V
 
 
-def kernel_source_hash():
-    """sha256 over every kernel source under csrc/ (the statistics pass, the reductions and the headers are shared by the
-    models, so one stamp serves all PMC summaries): numbers collected on other kernels are stale."""
+KERNEL_SOURCES = {
+    # the sources the kernels of one configuration are compiled from (the statistics pass, the reductions and the shared headers
+    # belong to every model); a PMC summary is valid for a build whose files of ITS model are unchanged
+    "lda": ("tmvb_lda.hip", "tmvb_gridtile.h", "tmvb_regtile.h", "tmvb_termstats.h", "tmvb_common_kernels.h", "tmvb_internal.h"),
+    "ctm": ("tmvb_ctm.hip", "tmvb_ctm_batch.h", "tmvb_filtered.h", "tmvb_termstats.h", "tmvb_common_kernels.h", "tmvb_internal.h"),
+    "ctpf": ("tmvb_ctpf.hip", "tmvb_gridtile.h", "tmvb_regtile.h", "tmvb_termstats.h", "tmvb_common_kernels.h", "tmvb_internal.h"),
+}
+
+
+def kernel_source_hash(model="lda"):
+    """sha256 over the kernel sources of one model family (lda: LDA K=50 / K=100; ctm; ctpf): PMC numbers collected on other
+    kernels are stale."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "topicmodelsvb.jl_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h")):
-            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    for f in KERNEL_SOURCES[model]:
+        h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 

@@ -45,9 +45,12 @@ def synth_case(tmvb, K, M=80, V=300, U=60, seed=4):
                 ratings=ratings, alef0=np.exp(tmvb.dirichlet_rows(K, V, seed=6) - 0.5))
 
 
-@pytest.mark.parametrize("case", ["ctpf_m40_v60_u15_k4", "ctpf_m30_v40_u12_k6_r1", "syn_k12", "syn_k50", "syn_k64", "syn_k77", "syn_k100", "syn_k128"])
+@pytest.mark.parametrize("case", ["ctpf_m40_v60_u15_k4", "ctpf_m30_v40_u12_k6_r1", "syn_k12", "syn_k50", "syn_k64", "syn_k77", "syn_k100", "syn_k128",
+                                  "syn_k150", "syn_k256", "syn_k300", "syn_k512"])
 def test_teacher_forced_step(tmvb, oracle, case):
-    # K = 100 is the reference's own published CTPF size (plots.R:4,17); K > 64 runs two topic slots per lane
+    # K = 100 is the reference's own published CTPF size (plots.R:4,17); K > 64 runs two topic slots per lane; round 4: K <= 512 (four /
+    # eight slots per lane; K = 150: rows of 156 floats, stored-weight float4 statistics kernel; K = 256 (KP = 260), 300, 512: dense E
+    # rows and the scalar statistics kernel) -- the reference's CPU path has no cap (src/CTPF.jl:327-337)
     g = load(case) if case.startswith("ctpf_") else synth_case(tmvb, int(case.split("_k")[1]))
     gm, om = make_pair(tmvb, oracle, g)
     probe = oracle.CTPF(om.corp, int(g["K"]), g["alef0"])      # a second oracle that only reports its own exit sweeps
@@ -87,7 +90,7 @@ def test_teacher_forced_step(tmvb, oracle, case):
         assert np.all(gm.alef > 0) and np.all(gm.he > 0) and np.all(gm.gimel > 0) and np.all(gm.zayin > 0)
 
 
-@pytest.mark.parametrize("case", ["ctpf_m40_v60_u15_k4", "syn_k12", "syn_k50", "syn_k100"])
+@pytest.mark.parametrize("case", ["ctpf_m40_v60_u15_k4", "syn_k12", "syn_k50", "syn_k100", "syn_k150", "syn_k300"])
 def test_device_elbo_matches_oracle(tmvb, oracle, case):
     """update_elbo! (src/CTPF.jl:234-247) on the device (Binomial sums cancelled analytically) vs the oracle's
     term-by-term evaluation, after one teacher-forced step with pinned sweep counts; rel <= 2e-5."""
@@ -211,7 +214,7 @@ def test_errors(tmvb):
     with pytest.raises(ValueError):
         tmvb.gpuCTPF(pc, 0)
     with pytest.raises(ValueError):
-        tmvb.gpuCTPF(pc, 129)                    # two topic slots per lane: K <= 128
+        tmvb.gpuCTPF(pc, 513)                    # eight topic slots per lane: K <= 512
     gm = tmvb.gpuCTPF(pc, 4)
     with pytest.raises(ValueError):
         gm.train(iter=2, checkelbo=0, printelbo=False)      # src/gpuCTPF.jl:681

@@ -72,7 +72,9 @@ def pmc_traffic(name):
     --pmc WRITE_SIZE passes of tools/pmc_window.py <name>, summarised by tools/pmc_summary.py; 2 x FETCH_SIZE + WRITE_SIZE in KB as
     MI355X_MICROARCH.md's HBM section prescribes for gfx950), summed over every kernel of an iteration.  Only when the summary was
     collected on the kernel sources this build is made of (hash stamped into the summary); otherwise (None, reason)."""
-    from bench import kernel_source_hash
+    from bench import kernel_source_hash as _ksh
+    fam = "lda" if name.startswith("lda") else name
+    kernel_source_hash = lambda: _ksh(fam)
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", f"r4_{name}_pmc.json")
     if not os.path.exists(path):
         return None, f"no profiles/r4_{name}_pmc.json"

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs (rocpd databases) per kernel.
-Usage: pmc_summary.py fetch.db write.db --iters N [--json PATH]
+Usage: pmc_summary.py fetch.db write.db --iters N [--json PATH] [--model lda|ctm|ctpf]
 N = outer iterations the profiled command ran (warm-up + timed): the E-step issues several dispatches of
 the same kernel per iteration (document pieces), so the figure that matters is KB per ITERATION."""
 import json
@@ -38,7 +38,8 @@ def main():
         import os
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         from bench import kernel_source_hash
-        rows["_meta"] = {"kernel_source_hash": kernel_source_hash(), "iterations": iters}
+        fam = sys.argv[sys.argv.index("--model") + 1] if "--model" in sys.argv else "lda"      # lda | ctm | ctpf: whose sources to stamp
+        rows["_meta"] = {"kernel_source_hash": kernel_source_hash(fam), "model_family": fam, "iterations": iters}
         json.dump(rows, open(js, "w"), indent=1)
 
 

@@ -469,7 +469,12 @@ static inline int tmvb_launch_termstats2(tmvb_ctx* ctx, int nslot, int KP, const
     };
     fill(tp0, ix0); fill(tp1, ix1);
     const dim3 grid((unsigned)((std::max(ix0.n_chunks, ix1.n_chunks) + 3) / 4), 2), block(256);
-    if (lpr == 13) hipLaunchKernelGGL((termstats_recompute2_kernel<13, 16>), grid, block, 0, st, tp0, tp1, lpr);
+    const int lanes = lpr <= 16 ? 16 : 32;
+    const int64_t nd = std::max(ix0.n_docs, ix1.n_docs);
+    const bool pad = tp0.estride >= 4 * lanes && tp1.estride == tp0.estride && nd < (1 << 24) && (uint64_t)nd * (uint64_t)tp0.estride * 4u < (1ull << 32) &&
+                     !(getenv("TMVB_STATS_PAD") && atoi(getenv("TMVB_STATS_PAD")) == 0);
+    if (lpr == 13 && pad) hipLaunchKernelGGL((termstats_recompute2_kernel<13, 16, true>), grid, block, 0, st, tp0, tp1, lpr);
+    else if (lpr == 13) hipLaunchKernelGGL((termstats_recompute2_kernel<13, 16>), grid, block, 0, st, tp0, tp1, lpr);
     else if (lpr == 25) hipLaunchKernelGGL((termstats_recompute2_kernel<25, 32>), grid, block, 0, st, tp0, tp1, lpr);
     else if (lpr <= 16) hipLaunchKernelGGL((termstats_recompute2_kernel<0, 16>), grid, block, 0, st, tp0, tp1, lpr);
     else hipLaunchKernelGGL((termstats_recompute2_kernel<0, 32>), grid, block, 0, st, tp0, tp1, lpr);

@@ -41,8 +41,10 @@ struct CtpfParams {
     float* gimel; float* gimel_old; float* zayin; float* zayin_old;   // [M][K]
     float* wtok;                // [nnz] term-major   c_n / s_n
     float* wrdr;                // [nR]  reader-major rating_u / s'_u
-    float* E1;                  // [M][KP] e      (phi factor)
-    float* E2;                  // [M][KP] ea+eb  (xi_top + xi_bot factor)
+    float* E1;                  // [M][estride] e      (phi factor)
+    float* E2;                  // [M][estride] ea+eb  (xi_top + xi_bot factor)
+    int estride;                // row stride of E1 / E2: KP rounded up to 64 floats for 32 < KP <= 64 (zero padded: the statistics pass's
+                                // fast form, tmvb_termstats.h), KP otherwise
     uint8_t* sweeps;
     int viter;
     float vtol;
@@ -227,12 +229,12 @@ __global__ __launch_bounds__(64) void ctpf_estep_kernel(CtpfParams p, int64_t fi
                 p.gimel[(int64_t)d * K + i] = gim[s]; p.gimel_old[(int64_t)d * K + i] = gim_old[s];
                 p.zayin[(int64_t)d * K + i] = zay[s]; p.zayin_old[(int64_t)d * K + i] = zay_old[s];
             }
-            if (on[s]) { p.E1[(int64_t)d * KP + i] = e[s]; p.E2[(int64_t)d * KP + i] = ea[s] + eb[s]; }
+            if (on[s]) { p.E1[(int64_t)d * p.estride + i] = e[s]; p.E2[(int64_t)d * p.estride + i] = ea[s] + eb[s]; }
         } else {
-            if (on[s]) { p.E1[(int64_t)d * KP + i] = 0.f; p.E2[(int64_t)d * KP + i] = 0.f; }   // viter = 0
+            if (on[s]) { p.E1[(int64_t)d * p.estride + i] = 0.f; p.E2[(int64_t)d * p.estride + i] = 0.f; }   // viter = 0
         }
     }
-    for (int i = K + lane; i < KP; i += 64) { p.E1[(int64_t)d * KP + i] = 0.f; p.E2[(int64_t)d * KP + i] = 0.f; }   // pads
+    for (int i = K + lane; i < KP; i += 64) { p.E1[(int64_t)d * p.estride + i] = 0.f; p.E2[(int64_t)d * p.estride + i] = 0.f; }   // pads
     if (sweeps > 0 && single) {
         store_w(p.wtok, p.tok_inv, off, 0, N, 0);
         store_w(p.wrdr, p.rdr_inv, roff, 0, Rd, N);
@@ -376,9 +378,9 @@ __device__ __forceinline__ void ctpf_estep_reg_body(const CtpfParams& p, const i
             p.gimel[(int64_t)d * K + mt] = gim; p.gimel_old[(int64_t)d * K + mt] = gim_old;
             p.zayin[(int64_t)d * K + mt] = zay; p.zayin_old[(int64_t)d * K + mt] = zay_old;
         }
-        if (mine) { p.E1[(int64_t)d * R + mytopic] = e[0]; p.E2[(int64_t)d * R + mytopic] = f[0]; }
+        if (mine) { p.E1[(int64_t)d * p.estride + mytopic] = e[0]; p.E2[(int64_t)d * p.estride + mytopic] = f[0]; }
     } else {
-        if (mine) { p.E1[(int64_t)d * R + mytopic] = 0.f; p.E2[(int64_t)d * R + mytopic] = 0.f; }   // viter = 0
+        if (mine) { p.E1[(int64_t)d * p.estride + mytopic] = 0.f; p.E2[(int64_t)d * p.estride + mytopic] = 0.f; }   // viter = 0
     }
     if (lane == 0) p.sweeps[d] = (uint8_t)min(sweeps, 255);
 }
@@ -525,9 +527,9 @@ __device__ __forceinline__ void ctpf_estep_grid_body(const CtpfParams& p, const 
                 p.gimel[(int64_t)d * K + mt] = gim; p.gimel_old[(int64_t)d * K + mt] = gim_old;
                 p.zayin[(int64_t)d * K + mt] = zay; p.zayin_old[(int64_t)d * K + mt] = zay_old;
             }
-            if (mine) { p.E1[(int64_t)d * R + mytopic] = e; p.E2[(int64_t)d * R + mytopic] = f; }
+            if (mine) { p.E1[(int64_t)d * p.estride + mytopic] = e; p.E2[(int64_t)d * p.estride + mytopic] = f; }
         } else {
-            if (mine) { p.E1[(int64_t)d * R + mytopic] = 0.f; p.E2[(int64_t)d * R + mytopic] = 0.f; }   // viter = 0
+            if (mine) { p.E1[(int64_t)d * p.estride + mytopic] = 0.f; p.E2[(int64_t)d * p.estride + mytopic] = 0.f; }   // viter = 0
         }
         if (lane == 0) p.sweeps[d] = (uint8_t)min(sweeps, 255);
     }
@@ -1135,6 +1137,8 @@ struct tmvb_ctpf {
     bool docs_pending = false;                                     // tmvb_ctpf_reduce_docs was asked for and deferred into the fused M-step (K <= 64, one context)
     float* d_gimel = nullptr; float* d_gimel_old = nullptr; float* d_zayin = nullptr; float* d_zayin_old = nullptr;
     float* d_wtok = nullptr; float* d_wrdr = nullptr; float* d_E1 = nullptr; float* d_E2 = nullptr;
+    int estride = 0;                                                // row stride of d_E1 / d_E2 (CtpfParams::estride)
+    bool e_padded = true;                                           // rows of KP (or 64) floats with zero pads; false: dense K floats (KP / 4 > 64)
     float* d_ts_partial = nullptr; float* d_ts_partial2 = nullptr;   // multi-chunk partials of the term / reader statistics passes
     uint8_t* d_sweeps = nullptr; int32_t* d_doc_order = nullptr;
     double* d_doc_val = nullptr; double* d_elbo_partial = nullptr; double* d_elbo = nullptr;
@@ -1209,11 +1213,15 @@ extern "C" int tmvb_ctpf_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmv
     *out = nullptr;
     TMVB_REQUIRE(ctx && corp, TMVB_EINVAL, "tmvb_ctpf_create: NULL context or corpus");
     TMVB_REQUIRE(K > 0, TMVB_EINVAL, "number of topics must be a positive integer.");
-    TMVB_REQUIRE(K <= 128, TMVB_EINVAL, "tmvb_ctpf_create: K <= 128 (two topic slots per lane); got K=%d", K);
+    TMVB_REQUIRE(K <= 512, TMVB_EINVAL, "tmvb_ctpf_create: K <= 512 (eight topic slots per lane); got K=%d", K);
     TMVB_HIP(hipSetDevice(ctx->device));
     tmvb_ctpf* h = new tmvb_ctpf();
     tmvb_create_guard<tmvb_ctpf, tmvb_ctpf_destroy> guard{h};      // every early return below destroys h
     h->ctx = ctx; h->corp = corp; h->K = K; h->KP = tmvb_kpad(K); h->nslot = (K + 63) / 64;
+    // E rows: padded to KP floats (64 for 32 < KP <= 64: the statistics pass's fast form) while a row fits 64 sixteen-byte chunks,
+    // dense K floats beyond (the scalar statistics kernel; round 4: K <= 512)
+    h->e_padded = h->KP / 4 <= 64;
+    h->estride = !h->e_padded ? K : (h->KP > 32 && h->KP <= 64) ? 64 : h->KP;
     h->M = corp->info.M; h->V = corp->info.V; h->U = corp->info.U;
     const size_t KM = (size_t)K * h->M, KV = (size_t)K * h->V, KU = (size_t)K * h->U;
     int rc;
@@ -1224,7 +1232,7 @@ extern "C" int tmvb_ctpf_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmv
         (rc = dmalloc(&h->d_stats, (size_t)h->stats_len())) || (rc = dmalloc(&h->d_rates, 8 * (size_t)K)) || (rc = dmalloc(&h->d_lrates, 4 * (size_t)K)) ||
         (rc = dmalloc(&h->d_gimel, KM)) || (rc = dmalloc(&h->d_gimel_old, KM)) || (rc = dmalloc(&h->d_zayin, KM)) || (rc = dmalloc(&h->d_zayin_old, KM)) ||
         (rc = dmalloc(&h->d_wtok, (size_t)corp->info.nnz)) || (rc = dmalloc(&h->d_wrdr, (size_t)corp->info.nR)) ||
-        (rc = dmalloc(&h->d_E1, (size_t)h->KP * h->M + 4)) || (rc = dmalloc(&h->d_E2, (size_t)h->KP * h->M + 4)) ||
+        (rc = dmalloc(&h->d_E1, (size_t)h->estride * h->M + 4)) || (rc = dmalloc(&h->d_E2, (size_t)h->estride * h->M + 4)) ||
         (rc = dmalloc(&h->d_ts_partial, slots * (K + 1))) || (rc = dmalloc(&h->d_ts_partial2, slots * (K + 1))) || (rc = dmalloc(&h->d_sweeps, (size_t)h->M)) || (rc = dmalloc(&h->d_doc_order, (size_t)h->M)) ||
         (rc = dmalloc(&h->d_partial, (size_t)TMVB_REDUCE_BLOCKS * K)) || (rc = dmalloc(&h->d_partial2, (size_t)TMVB_REDUCE_BLOCKS * K)) || (rc = dmalloc(&h->d_rs_alef, K)) || (rc = dmalloc(&h->d_rs_he, K)) ||
         (rc = dmalloc(&h->d_mstep_counter, 1)) ||
@@ -1233,6 +1241,8 @@ extern "C" int tmvb_ctpf_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmv
         return rc;
     }
     TMVB_HIP(hipMemset(h->d_mstep_counter, 0, sizeof(unsigned int)));
+    TMVB_HIP(hipMemset(h->d_E1, 0, ((size_t)h->estride * h->M + 4) * sizeof(float)));      // the pad columns stay zero for good
+    TMVB_HIP(hipMemset(h->d_E2, 0, ((size_t)h->estride * h->M + 4) * sizeof(float)));
     // processing order: first the documents of the LDS-tile kernel by rows (terms + readers), longest first, in LDS
     // buckets on the combined row count; then the register-tile documents (<= 128 terms and <= 64 readers) by tiles
     h->reg_path = (h->KP / 4) <= 15 && ((h->KP / 4) & 1);
@@ -1454,9 +1464,9 @@ extern "C" int tmvb_ctpf_estep(tmvb_ctpf* h, int32_t viter, double vtol)
     p.doc_order = h->d_doc_order; p.tok_inv = h->corp->term_index.d_inv; p.rdr_inv = h->corp->reader_index.d_inv;
     p.TA = h->d_TA; p.TH = h->d_TH; p.lrates = h->d_lrates; p.hc = (float)h->hyper[2]; p.hg = (float)h->hyper[6];
     p.gimel = h->d_gimel; p.gimel_old = h->d_gimel_old; p.zayin = h->d_zayin; p.zayin_old = h->d_zayin_old;
-    p.wtok = h->d_wtok; p.wrdr = h->d_wrdr; p.E1 = h->d_E1; p.E2 = h->d_E2; p.sweeps = h->d_sweeps;
+    p.wtok = h->d_wtok; p.wrdr = h->d_wrdr; p.E1 = h->d_E1; p.E2 = h->d_E2; p.estride = h->estride; p.sweeps = h->d_sweeps;
     p.viter = viter; p.vtol = (float)vtol;
-    p.store_w = tmvb_termstats_recomputes(h->KP, true) ? 0 : 1;
+    p.store_w = tmvb_termstats_recomputes(h->KP, h->e_padded) ? 0 : 1;
     TMVB_HIP(hipEventRecord(h->ev0, ctx->stream));
     // stream plan as in tmvb_lda_estep for one statistics pass: the register-tile buckets run back to back on the
     // context's stream (the critical chain document kernels -> statistics -> M-step pays kernel boundaries, not ~20 us
@@ -1520,7 +1530,8 @@ extern "C" int tmvb_ctpf_estep(tmvb_ctpf* h, int32_t viter, double vtol)
             hipLaunchKernelGGL(kern, grid, block, lds, st, p, b.first, b.tile_rows);
             return TMVB_OK;
         };
-        int lrc = (h->nslot == 2) ? ((p.LPR == 25) ? launch(ctpf_estep_kernel<25, 2>) : launch(ctpf_estep_kernel<0, 2>))
+        int lrc = (h->nslot > 4) ? launch(ctpf_estep_kernel<0, 8>) : (h->nslot > 2) ? launch(ctpf_estep_kernel<0, 4>)
+                  : (h->nslot == 2) ? ((p.LPR == 25) ? launch(ctpf_estep_kernel<25, 2>) : launch(ctpf_estep_kernel<0, 2>))
                   : (p.LPR == 13) ? launch(ctpf_estep_kernel<13, 1>) : (p.LPR == 3) ? launch(ctpf_estep_kernel<3, 1>) : launch(ctpf_estep_kernel<0, 1>);
         if (lrc) return lrc;
         TMVB_HIP(hipGetLastError());
@@ -1533,22 +1544,22 @@ extern "C" int tmvb_ctpf_estep(tmvb_ctpf* h, int32_t viter, double vtol)
     // update_alef!(model, d) / update_he!(model, d) (src/CTPF.jl:259-262, :274-277) as gather-side statistics
     TermStatsParams tp;
     tp.K = h->K; tp.tstride = h->KP; tp.ostride = h->K; tp.eps = 0.0f; tp.base = 0.0f; tp.keps = 0.0f; tp.partial = h->d_ts_partial;
-    tp.w = h->d_wtok; tp.E = h->d_E1; tp.T = h->d_TA; tp.out = h->d_stats;
+    tp.w = h->d_wtok; tp.E = h->d_E1; tp.T = h->d_TA; tp.out = h->d_stats; tp.estride = h->estride;
     // the two passes are independent (alef / he statistics): one launch with the pass as blockIdx.y (recompute variant), else the
     // reader pass on aux[0] under the term pass
     TermStatsParams tr = tp;
     tr.w = h->d_wrdr; tr.E = h->d_E2; tr.T = h->d_TH; tr.out = h->he_stats(); tr.partial = h->d_ts_partial2;
     static const bool fuse_env = [] { const char* e = getenv("TMVB_CTPF_FUSE_STATS"); return !(e && atoi(e) == 0); }();
     int rc = TMVB_EINVAL;
-    if (fuse_env && h->U > 0 && tmvb_termstats_recomputes(h->KP, true))
+    if (fuse_env && h->U > 0 && tmvb_termstats_recomputes(h->KP, h->e_padded))
         rc = tmvb_launch_termstats2(ctx, h->nslot, h->KP, h->corp->term_index, tp, h->corp->reader_index, tr);
     if (rc == TMVB_EINVAL) {
         TMVB_HIP(hipEventRecord(h->ev_fork, ctx->stream));
-        rc = tmvb_launch_termstats(ctx, h->nslot, h->KP, true, h->corp->term_index, tp);
+        rc = tmvb_launch_termstats(ctx, h->nslot, h->KP, h->e_padded, h->corp->term_index, tp);
         if (rc) return rc;
         if (h->U > 0) {
             TMVB_HIP(hipStreamWaitEvent(h->aux[0], h->ev_fork, 0));
-            if ((rc = tmvb_launch_termstats(ctx, h->nslot, h->KP, true, h->corp->reader_index, tr, h->aux[0]))) return rc;
+            if ((rc = tmvb_launch_termstats(ctx, h->nslot, h->KP, h->e_padded, h->corp->reader_index, tr, h->aux[0]))) return rc;
             TMVB_HIP(hipEventRecord(h->ev_join[0], h->aux[0]));
             TMVB_HIP(hipStreamWaitEvent(ctx->stream, h->ev_join[0], 0));
         }
@@ -1737,28 +1748,26 @@ extern "C" int tmvb_ctpf_update_elbo_parts(tmvb_ctpf* h, double* doc_part, doubl
                                (const double*)nullptr, (double*)nullptr);
         }
         TMVB_HIP(hipGetLastError());
-        if (h->nslot == 1)
-            hipLaunchKernelGGL((ctpf_elbo_doc_fast_kernel<1>), dim3((unsigned)h->M), dim3(64), 0, ctx->stream, h->K, h->KP, h->corp->d_doc_ptr, h->corp->d_terms,
+        auto fast = [&](auto ns) {
+            constexpr int NS = decltype(ns)::value;
+            hipLaunchKernelGGL((ctpf_elbo_doc_fast_kernel<NS>), dim3((unsigned)h->M), dim3(64), 0, ctx->stream, h->K, h->KP, h->corp->d_doc_ptr, h->corp->d_terms,
                                h->corp->d_counts, h->corp->d_rdr_ptr, h->corp->d_readers, h->corp->d_ratings, h->d_TAo, h->d_DA, h->d_THo, h->d_DH,
                                h->d_rates, h->d_lrates_d, h->d_rs_alef, h->d_rs_he, h->d_gimel, h->d_gimel_old, h->d_zayin, h->d_zayin_old, h->d_lg_doc,
                                hy[2], hy[3], hy[6], hy[7], h->d_doc_val);
-        else
-            hipLaunchKernelGGL((ctpf_elbo_doc_fast_kernel<2>), dim3((unsigned)h->M), dim3(64), 0, ctx->stream, h->K, h->KP, h->corp->d_doc_ptr, h->corp->d_terms,
-                               h->corp->d_counts, h->corp->d_rdr_ptr, h->corp->d_readers, h->corp->d_ratings, h->d_TAo, h->d_DA, h->d_THo, h->d_DH,
-                               h->d_rates, h->d_lrates_d, h->d_rs_alef, h->d_rs_he, h->d_gimel, h->d_gimel_old, h->d_zayin, h->d_zayin_old, h->d_lg_doc,
-                               hy[2], hy[3], hy[6], hy[7], h->d_doc_val);
+        };
+        if (h->nslot == 1) fast(std::integral_constant<int, 1>()); else if (h->nslot == 2) fast(std::integral_constant<int, 2>());
+        else if (h->nslot <= 4) fast(std::integral_constant<int, 4>()); else fast(std::integral_constant<int, 8>());
         TMVB_HIP(hipGetLastError());
     } else if (h->M > 0) {
-        if (h->nslot == 1)
-            hipLaunchKernelGGL((ctpf_elbo_doc_kernel<1>), dim3((unsigned)h->M), dim3(64), 0, ctx->stream, h->K, h->corp->d_doc_ptr, h->corp->d_terms,
+        auto slow = [&](auto ns) {
+            constexpr int NS = decltype(ns)::value;
+            hipLaunchKernelGGL((ctpf_elbo_doc_kernel<NS>), dim3((unsigned)h->M), dim3(64), 0, ctx->stream, h->K, h->corp->d_doc_ptr, h->corp->d_terms,
                                h->corp->d_counts, h->corp->d_rdr_ptr, h->corp->d_readers, h->corp->d_ratings, h->d_alef, h->d_alef_old, h->d_he,
                                h->d_he_old, h->d_rates, h->d_rs_alef, h->d_rs_he, h->d_gimel, h->d_gimel_old, h->d_zayin, h->d_zayin_old,
                                hy[2], hy[3], hy[6], hy[7], h->d_doc_val);
-        else
-            hipLaunchKernelGGL((ctpf_elbo_doc_kernel<2>), dim3((unsigned)h->M), dim3(64), 0, ctx->stream, h->K, h->corp->d_doc_ptr, h->corp->d_terms,
-                               h->corp->d_counts, h->corp->d_rdr_ptr, h->corp->d_readers, h->corp->d_ratings, h->d_alef, h->d_alef_old, h->d_he,
-                               h->d_he_old, h->d_rates, h->d_rs_alef, h->d_rs_he, h->d_gimel, h->d_gimel_old, h->d_zayin, h->d_zayin_old,
-                               hy[2], hy[3], hy[6], hy[7], h->d_doc_val);
+        };
+        if (h->nslot == 1) slow(std::integral_constant<int, 1>()); else if (h->nslot == 2) slow(std::integral_constant<int, 2>());
+        else if (h->nslot <= 4) slow(std::integral_constant<int, 4>()); else slow(std::integral_constant<int, 8>());
         TMVB_HIP(hipGetLastError());
     }
     // d_elbo[0] = sum over the documents (the part that adds up over shards), d_elbo[1] = the global part

@@ -227,9 +227,10 @@ __device__ __forceinline__ void termstats_recompute_body(const TermStatsParams& 
                 for (int u = 0; u < U; ++u) dw[u] = dw_l[wv][k0 + u * SLOTS + rs];          // k0 + 3 SLOTS + rs <= 63
 #pragma unroll
                 for (int u = 0; u < U; ++u) ev[u] = *(const float4*)(Eb + (__umul24((uint32_t)dw[u].x, esb) + lane_off));
+                // no early exit for a row-slot group past the end (its weights are 0): with a uniform `break` between the groups the
+                // compiler sank every load next to its use -- ONE gather in flight per wave again, 8 % slower than the form it replaces
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    if (k0 + u * SLOTS >= cnt) break;                 // uniform: whole row-slot group past the end
                     const v2f elo = v2f{ev[u].x, ev[u].y}, ehi = v2f{ev[u].z, ev[u].w};
                     const v2f d2 = __builtin_elementwise_fma(tlo, elo, thi * ehi);
                     float part = d2.x + d2.y;
@@ -331,11 +332,11 @@ __global__ __launch_bounds__(256) void termstats_recompute_kernel(TermStatsParam
 }
 // Two independent passes (CTPF: the term index and the reader index) in ONE launch, blockIdx.y selects the pass: run on two streams
 // they cost a ~19 us cross-stream join in a 0.3 ms iteration.
-template <int LPR_T, int LANES>
+template <int LPR_T, int LANES, bool PAD = false>
 __global__ __launch_bounds__(256) void termstats_recompute2_kernel(TermStatsParams p0, TermStatsParams p1, int LPR_rt)
 {
-    if (blockIdx.y == 0) termstats_recompute_body<LPR_T, LANES>(p0, LPR_rt);
-    else termstats_recompute_body<LPR_T, LANES>(p1, LPR_rt);
+    if (blockIdx.y == 0) termstats_recompute_body<LPR_T, LANES, PAD>(p0, LPR_rt);
+    else termstats_recompute_body<LPR_T, LANES, PAD>(p1, LPR_rt);
 }
 
 // ids whose tokens span several chunks: one workgroup per id, its 4 waves sum interleaved partial
