@@ -93,12 +93,14 @@ def pmc_traffic(K, M, nnz):
     meta = rows.get("_meta", {})
     if meta.get("kernel_source_hash") != kernel_source_hash():
         return None, f"{name} was collected on kernel sources {meta.get('kernel_source_hash')}, this build is {kernel_source_hash()} (stale)"
-    tot = 0.0
+    tot, issue = 0.0, 0.0
     for kname, r in rows.items():
         if "lda_estep" in kname or "termstats" in kname:
             if "fetch_kb_per_iteration" not in r:
                 return None, "incomplete PMC summary"
             tot += (2.0 * r["fetch_kb_per_iteration"] + r["write_kb_per_iteration"]) * 1024.0
+            issue += r.get("valu_issue_cycles_per_simd_per_iteration", float("nan"))
+    pmc_traffic.valu_issue_cycles = issue if issue == issue else None      # VALU-issue cycles per SIMD of one E-step's kernels (third pass)
     return tot, f"profiles/{name} (rocprofv3 --pmc, separate passes; 2*FETCH_SIZE+WRITE_SIZE summed over the E-step's dispatches of one iteration)"
 
 
@@ -444,6 +446,9 @@ def main():
                          "estep_ms_min": float(np.min(estep_ms)), "estep_ms_max": float(np.max(estep_ms)),
                          "estep_ms_median": float(np.median(estep_ms)), "estep_ms_steps": [round(float(x), 4) for x in estep_ms],
                          "frac_at_median": b_e / (float(np.median(estep_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "valu_issue_frac": (getattr(pmc_traffic, "valu_issue_cycles", None) / (ms * 1e-3 * 2.4e9)) if getattr(pmc_traffic, "valu_issue_cycles", None) else None,
+                         "valu_issue_frac_is": "VALU-issue cycles per SIMD of the E-step's kernels (4 x SQ_ACTIVE_INST_VALU / 1024 SIMDs, rocprofv3 --pmc, kernels serialised) / (this run's estep_ms x 2.4 GHz): "
+                                               "the share of the E-step during which an average SIMD issues a vector instruction -- the limit the byte-count frac saturates against (the byte model overstates what reaches HBM: traffic / algorithmic)",
                          "launches_per_estep": n_launch,
                          "whole_iteration_GBs": (b_e + mstep_bytes(K, V)) / (elapsed / args.steps) / 1e9},
             "cold_start": cold,

@@ -54,10 +54,12 @@ def synth_case(tmvb, K, M=60, V=300, seed=3):
 
 
 @pytest.mark.parametrize("case", ["golden_k5", "syn_k3", "syn_k12", "syn_k17", "syn_k25", "syn_k33", "syn_k41", "syn_k50", "syn_k57",
-                                  "syn_k61", "syn_k64", "syn_k100", "syn_k128"])
+                                  "syn_k61", "syn_k64", "syn_k100", "syn_k128", "syn_k150", "syn_k200", "syn_k256"])
 def test_teacher_forced_step(tmvb, oracle, case):
     # one case per register Gauss-Jordan instantiation (KP = 4, 12, 20, 28, 36, 44, 52, 60), then the LDS Newton solve
-    # of the K > 60 path with one (KP = 68 rows need two slots already) and two topic slots per lane
+    # of the K > 60 path with one (KP = 68 rows need two slots already) and two topic slots per lane; round 4: K = 150 / 200 / 256 -- four
+    # slots per lane, invsigma read from global memory by columns (GA), the sigma inversion in a global workspace, stored-weight
+    # statistics (K = 256: KP = 260, dense E rows and the scalar statistics kernel).  The reference's CPU path has no cap (src/CTM.jl:129-142)
     g = load("ctm_m40_v60_k5") if case == "golden_k5" else synth_case(tmvb, int(case.split("_k")[1]))
     gm, om = make_pair(tmvb, oracle, g)
     for it in range(3):
@@ -135,7 +137,7 @@ def test_gpu_macro_round_trip_and_errors(tmvb):
     with pytest.raises(ValueError):
         tmvb.gpuCTM(pc, 0)
     with pytest.raises(ValueError):
-        tmvb.gpuCTM(pc, 129)                     # two topic slots per lane: K <= 128
+        tmvb.gpuCTM(pc, 257)                     # four topic slots per lane: K <= 256
     gm = tmvb.gpuCTM(pc, K)
     with pytest.raises(ValueError):
         gm.train(niter=-1, printelbo=False)

@@ -70,7 +70,7 @@ def compare(gm, om, it):
     np.linalg.cholesky(gm.sigma)
 
 
-@pytest.mark.parametrize("case", ["golden_k4", "syn_k3", "syn_k12", "syn_k25", "syn_k41", "syn_k50", "syn_k57", "syn_k64", "syn_k100"])
+@pytest.mark.parametrize("case", ["golden_k4", "syn_k3", "syn_k12", "syn_k25", "syn_k41", "syn_k50", "syn_k57", "syn_k64", "syn_k100", "syn_k150", "syn_k256"])
 def test_teacher_forced_step(tmvb, oracle, case):
     g = load("fctm_m30_v50_k4") if case == "golden_k4" else synth_case(tmvb, int(case.split("_k")[1]))
     gm, om = make_pair(tmvb, oracle, g)
@@ -146,7 +146,7 @@ def test_errors_and_invariants(tmvb):
     with pytest.raises(ValueError):
         tmvb.gpufCTM(pc, 0)
     with pytest.raises(ValueError):
-        tmvb.gpufCTM(pc, 129)
+        tmvb.gpufCTM(pc, 257)
     gm = tmvb.gpufCTM(pc, 16)
     with pytest.raises(ValueError):
         gm.train(niter=-1, printelbo=False)

@@ -54,8 +54,9 @@ for step in "$@"; do
             for c in FETCH_SIZE WRITE_SIZE; do
               ( cd /tmp && timeout 900 rocprofv3 --pmc $c --kernel-trace -d "$O/pmcb_${arg}_$c" -- python $R/tools/pmc_window.py $arg 20 6 ) > "$O/pmcb_${arg}_$c.log" 2>&1; echo "rc=$?" >> "$O/pmcb_${arg}_$c.log"
             done
-            python tools/pmc_summary.py $(find "$O/pmcb_${arg}_FETCH_SIZE" -name "*.db" | head -1) $(find "$O/pmcb_${arg}_WRITE_SIZE" -name "*.db" | head -1) --iters 26 --model $(echo $arg | sed "s/lda.*/lda/") --json "$O/${arg}_pmc.json" > "$O/${arg}_pmc.txt" 2>&1
-            head -12 "$O/${arg}_pmc.txt"; find "$O" -path "*pmcb_${arg}_*" -name "*.db" -delete ;;
+            ( cd /tmp && timeout 900 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace -d "$O/pmcb_${arg}_VALU" -- python $R/tools/pmc_window.py $arg 20 6 ) > "$O/pmcb_${arg}_VALU.log" 2>&1; echo "rc=$?" >> "$O/pmcb_${arg}_VALU.log"
+            python tools/pmc_summary.py $(find "$O/pmcb_${arg}_FETCH_SIZE" -name "*.db" | head -1) $(find "$O/pmcb_${arg}_WRITE_SIZE" -name "*.db" | head -1) --valu $(find "$O/pmcb_${arg}_VALU" -name "*.db" | head -1) --iters 26 --model $(echo $arg | sed "s/lda.*/lda/") --json "$O/${arg}_pmc.json" > "$O/${arg}_pmc.txt" 2>&1
+            head -12 "$O/${arg}_pmc.txt"; grep -A8 "VALU pass" "$O/${arg}_pmc.txt"; find "$O" -path "*pmcb_${arg}_*" -name "*.db" -delete ;;
     exe)    ( time timeout 900 ${arg//,/ } ) > "$O/exe_$n.txt" 2>&1; echo "rc=$?" >> "$O/exe_$n.txt"; tail -40 "$O/exe_$n.txt" ;;
     py)     ( time timeout 1500 python ${arg//,/ } ) > "$O/py_$n.txt" 2>&1; echo "rc=$?" >> "$O/py_$n.txt"; tail -40 "$O/py_$n.txt" ;;
     *)      echo "unknown step $step" ;;

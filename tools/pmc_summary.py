@@ -17,8 +17,18 @@ def load(path):
     return out
 
 
+def load_all(path):
+    c = sqlite3.connect(path)
+    out = {}
+    for name, cnt, n, tot in c.execute("select kernel_name, counter_name, count(*), sum(value) from counters_collection "
+                                       "group by kernel_name, counter_name"):
+        out.setdefault(name, {})[cnt] = (n, tot)
+    return out
+
+
 def main():
     fetch, write = load(sys.argv[1]), load(sys.argv[2])
+    valu = load_all(sys.argv[sys.argv.index("--valu") + 1]) if "--valu" in sys.argv else {}
     js = sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else None
     iters = int(sys.argv[sys.argv.index("--iters") + 1])
     print("# rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes), KB per outer iteration")
@@ -32,6 +42,19 @@ def main():
         print(f"{max(f[1], w[1]):6d} {f[2] / iters:12.1f} {w[2] / iters:12.1f}  {k[:100]}")
         rows[k] = {"calls": max(f[1], w[1]), "iterations": iters, "fetch_kb_per_iteration": f[2] / iters,
                    "write_kb_per_iteration": w[2] / iters}
+    if valu:
+        # third pass (SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES GRBM_GUI_ACTIVE): VALU instructions issued and the cycles a SIMD's VALU was
+        # issuing (4 cycles per wave64 instruction; SQ_ACTIVE_INST_VALU is summed over the 1024 SIMDs), per kernel and iteration
+        print("# VALU pass: instructions per iteration / per wave, and VALU-issue cycles per SIMD per iteration = 4 * SQ_ACTIVE_INST_VALU / 1024")
+        print(f"{'insts/it':>14} {'insts/wave':>11} {'issue_cyc/SIMD/it':>18} {'busy%':>6}  kernel")
+        for k, r in sorted(valu.items(), key=lambda kv: -kv[1].get("SQ_ACTIVE_INST_VALU", (0, 0))[1]):
+            iv = r.get("SQ_INSTS_VALU", (0, 0.0))[1]; av = r.get("SQ_ACTIVE_INST_VALU", (0, 0.0))[1]
+            wv = r.get("SQ_WAVES", (0, 0.0))[1]; ga = r.get("GRBM_GUI_ACTIVE", (0, 0.0))[1]
+            busy = 100.0 * 4.0 * av / (ga * 128.0) if ga else float("nan")
+            print(f"{iv / iters:14.0f} {iv / wv if wv else float('nan'):11.1f} {4.0 * av / 1024.0 / iters:18.0f} {busy:6.1f}  {k[:100]}")
+            rows.setdefault(k, {"iterations": iters})
+            rows[k].update({"insts_valu_per_iteration": iv / iters, "waves_per_iteration": wv / iters,
+                            "valu_issue_cycles_per_simd_per_iteration": 4.0 * av / 1024.0 / iters, "valu_busy_frac_alone": busy / 100.0})
     if js:
         # stamp the kernel sources the counters were collected on: bench.py reports roofline.traffic only when
         # the stamp matches the sources of the running build (a stale summary yields null)

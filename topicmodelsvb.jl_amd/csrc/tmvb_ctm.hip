@@ -30,7 +30,7 @@
 
 #include <utility>
 
-#define CTM_MAX_K 128
+#define CTM_MAX_K 256
 
 struct CtmParams {
     int K, KP, LPR;
@@ -48,7 +48,9 @@ struct CtmParams {
     float* vsq;               // [M][K]
     float* logzeta;           // [M]
     float* wtok;              // [nnz] term-major
-    float* E;                 // [M][KP]
+    float* E;                 // [M][estride]
+    int estride;              // KP (zero pads) while a row has at most 64 sixteen-byte chunks, K beyond (ctm_estep_generic_kernel honours it; the
+                              // K <= 60 kernels write KP-strided rows, which is the same thing there)
     uint8_t* sweeps;
     unsigned long long* newton_steps;
     int niter;
@@ -585,9 +587,9 @@ static size_t ctm_generic_lds_bytes(int KP, int waves = 1, int tile_rows = CTM_G
 // next to the one copy of invsigma.  max_waves (the instantiation's bound) while that leaves a window of 24 rows or more, else fewer
 // (never below four);
 // the window is capped at 128 rows.  TMVB_CTM_CG_WAVES / TMVB_CTM_CG_TILE override.
-static void ctm_generic_cg_shape(int KP, int max_waves, int* waves, int* tile_rows)
+static void ctm_generic_cg_shape(int KP, int max_waves, int* waves, int* tile_rows, bool global_a = false)
 {
-    const size_t room = (160 * 1024 - (size_t)KP * KP * sizeof(float)) / sizeof(float);
+    const size_t room = (160 * 1024 - (global_a ? 0 : (size_t)KP * KP * sizeof(float))) / sizeof(float);
     auto rows_for = [&](int w) { const int64_t f = (int64_t)(room / (size_t)w) - 4 * KP; return (int)std::max<int64_t>(0, f / (KP + 6)); };
     int w = max_waves;
     while (w > 4 && rows_for(w) < 24) --w;
@@ -597,9 +599,13 @@ static void ctm_generic_cg_shape(int KP, int max_waves, int* waves, int* tile_ro
     *waves = w; *tile_rows = std::max(4, t);
 }
 
-template <int NS, bool FILT, bool CG = false, int MAXW = 1>
+// GA = true (round 4, K > 128: four topic slots per lane): a 256 x 256 invsigma does not fit the LDS, so it STAYS IN GLOBAL MEMORY (L2-resident,
+// 260 KB at K = 256) and the mat-vec reads it by columns -- invsigma is symmetric, y_i = sum_c S[c][i] v_c, and row c is one coalesced read
+// of the lanes (the lane's own row would be 64 cache lines per load instruction).  The whole LDS goes to the waves' tile windows.
+template <int NS, bool FILT, bool CG = false, int MAXW = 1, bool GA = false>
 __global__ __launch_bounds__(64 * MAXW) void ctm_estep_generic_kernel(CtmParams p, int64_t first)
 {
+    static_assert(!GA || CG, "the global-memory invsigma exists for the conjugate-gradient form only");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
     const int K = p.K, KP = p.KP, LPR = p.LPR;
@@ -609,7 +615,7 @@ __global__ __launch_bounds__(64 * MAXW) void ctm_estep_generic_kernel(CtmParams 
 #define GEN_FENCE() do { if constexpr (CG) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } else { __syncthreads(); } } while (0)
     float* A = lds;                                     // [KP][KP] Newton matrix; CG: invsigma, read-only, shared by the workgroup's waves
     const size_t wave_floats = (size_t)tile_rows * KP + 2 * (size_t)KP + 6 * tile_rows + 2 * (size_t)KP;
-    float* Bt = A + (size_t)KP * KP + (CG ? (size_t)(threadIdx.x >> 6) * wave_floats : 0);   // [tile_rows][KP] topic tile window
+    float* Bt = A + (GA ? 0 : (size_t)KP * KP) + (CG ? (size_t)(threadIdx.x >> 6) * wave_floats : 0);   // [tile_rows][KP] topic tile window
     float* e_l = Bt + (size_t)tile_rows * KP;           // [KP]
     float* g_l = e_l + KP;                              // [KP] right-hand side of the solve
     float* w_l = g_l + KP;                              // [tile_rows]
@@ -620,7 +626,7 @@ __global__ __launch_bounds__(64 * MAXW) void ctm_estep_generic_kernel(CtmParams 
     float* m_l = tn_l + tile_rows;
     double* dm_l = (double*)(m_l + tile_rows);          // [KP] mu - lambda (8-byte aligned: KP is a multiple of 4, so the float blocks above total a multiple of 8 floats)
 
-    if constexpr (CG) {
+    if constexpr (CG && !GA) {
         for (int q = threadIdx.x; q < KP * KP / 4; q += blockDim.x) ((float4*)A)[q] = ((const float4*)p.invsigma)[q];
         __syncthreads();
     }
@@ -875,6 +881,31 @@ __global__ __launch_bounds__(64 * MAXW) void ctm_estep_generic_kernel(CtmParams 
                 // y = invsigma v for the vector in p_l (pads zero), lane = row
                 // (one broadcast read of the vector per four columns for both slots, packed FMAs)
                 auto matvec = [&](float (&y)[NS]) {
+                    if constexpr (GA) {
+                        const float* __restrict__ S = p.invsigma;
+                        int col[NS];
+                        float a0[NS], a1[NS];
+#pragma unroll
+                        for (int s = 0; s < NS; ++s) { col[s] = row[s] ? lane + 64 * s : 0; a0[s] = 0.0f; a1[s] = 0.0f; }
+#pragma unroll 2
+                        for (int c = 0; c < KP; c += 4) {                    // rows c .. c + 3 (rows past K are zero)
+                            const float4 b = *(const float4*)(p_l + c);
+                            float v0[NS], v1[NS], v2[NS], v3[NS];
+#pragma unroll
+                            for (int s = 0; s < NS; ++s) {
+                                const float* sc = S + (size_t)c * KP + col[s];
+                                v0[s] = sc[0]; v1[s] = sc[KP]; v2[s] = sc[2 * KP]; v3[s] = sc[3 * KP];
+                            }
+#pragma unroll
+                            for (int s = 0; s < NS; ++s) {
+                                a0[s] = fmaf(v0[s], b.x, a0[s]); a1[s] = fmaf(v1[s], b.y, a1[s]);
+                                a0[s] = fmaf(v2[s], b.z, a0[s]); a1[s] = fmaf(v3[s], b.w, a1[s]);
+                            }
+                        }
+#pragma unroll
+                        for (int s = 0; s < NS; ++s) y[s] = row[s] ? a0[s] + a1[s] : 0.0f;
+                        return;
+                    }
                     const float4* pr = (const float4*)p_l;
                     const float4* sr[NS];
                     cb_v2f a01[NS], a23[NS];
@@ -1024,12 +1055,13 @@ __global__ __launch_bounds__(64 * MAXW) void ctm_estep_generic_kernel(CtmParams 
             p.lambda_old[(int64_t)d * K + i] = (float)lam_old[s];
             p.vsq[(int64_t)d * K + i] = (float)vs[s];
         }
-        if constexpr (!FILT) { if (on[s]) p.E[(int64_t)d * KP + i] = (sweeps > 0) ? e[s] : 0.0f; }
+        if constexpr (!FILT) { if (on[s]) p.E[(int64_t)d * p.estride + i] = (sweeps > 0) ? e[s] : 0.0f; }
     }
     if constexpr (FILT) {
         if (sweeps == 0) for (int n = lane; n < N; n += 64) p.lse[off + n] = INFINITY;     // viter = 0: phi = 0 in the statistics
     } else {
-        for (int i = K + lane; i < KP; i += 64) p.E[(int64_t)d * KP + i] = 0.0f;          // pads
+        if (p.estride >= KP)                                                               // dense rows (KP / 4 > 64) have no pads
+            for (int i = K + lane; i < KP; i += 64) p.E[(int64_t)d * p.estride + i] = 0.0f;   // pads
         if (sweeps == 0 && p.store_w)
             for (int n = lane; n < N; n += 64) p.wtok[p.tok_inv[off + n]] = 0.0f;         // viter = 0: no responsibilities
     }
@@ -1137,9 +1169,13 @@ __global__ __launch_bounds__(256) void ctm_sigma_mu_kernel(int K, int KP, double
                                                            double* __restrict__ sigma_d, double* __restrict__ invsigma_d,
                                                            float* __restrict__ invsigma_f, double* __restrict__ mu_d,
                                                            float* __restrict__ mu_f, double* __restrict__ logdet_inv,
-                                                           int* __restrict__ status, int do_sigma, int do_mu)
+                                                           int* __restrict__ status, int do_sigma, int do_mu, double* __restrict__ work)
 {
-    extern __shared__ double sm[];       // [K][K]
+    // [K][K]: LDS up to K = 128 (128 KiB); beyond (round 4, K <= 256) a global-memory workspace -- the one workgroup's __syncthreads
+    // order its global reads and writes as they order the LDS ones; an inversion then runs at L2 speed (milliseconds at K = 256,
+    // next to an E-step of hundreds)
+    extern __shared__ double sm_lds[];
+    double* __restrict__ sm = work ? work : sm_lds;
     const float* sum_lambda = stats_tail;
     const float* sum_vsq = stats_tail + K;
     const float* scatter = stats_tail + 2 * K;
@@ -1262,7 +1298,9 @@ __global__ __launch_bounds__(64) void ctm_elbo_kernel(int K, int KP, const int64
 #pragma unroll
     for (int s = 0; s < NS; ++s) mv[s] = 0.0;
     for (int j = 0; j < K; ++j) {
-        const double dj = (j < 64) ? readlane_d(df[0], j & 63) : readlane_d(df[NS - 1], j & 63);
+        double dj = 0.0;                                                      // df of topic j: slot j / 64 (uniform), lane j % 64
+#pragma unroll
+        for (int s = 0; s < NS; ++s) if ((j >> 6) == s) dj = readlane_d(df[s], j & 63);
 #pragma unroll
         for (int s = 0; s < NS; ++s) mv[s] = fma(on[s] ? invsigma_d[(int64_t)j * K + ix[s]] : 0.0, dj, mv[s]);
     }
@@ -1313,6 +1351,7 @@ struct tmvb_ctm {
     bool own_stats = true;
     float* d_lambda = nullptr; float* d_lambda_old = nullptr; float* d_vsq = nullptr; float* d_logzeta = nullptr;
     float* d_wtok = nullptr; float* d_E = nullptr; float* d_ts_partial = nullptr;
+    double* d_sigma_work = nullptr; double* d_sigma_work_s = nullptr;   // K > 128: [K][K] workspaces of the sigma inversion (and of the staged one)
     float* d_invsigma_f = nullptr; float* d_mu_f = nullptr;
     bool batch = false;                // lane-per-document kernel (tmvb_ctm_batch.h), KP <= 52
     int64_t n_long = 0;                // ... except the first n_long documents of the processing order (> CTM_BATCH_MAX_LEN unique terms each):
@@ -1358,6 +1397,7 @@ extern "C" int tmvb_ctm_destroy(tmvb_ctm* h)
     (void)hipFree(h->d_beta[0]); (void)hipFree(h->d_beta[1]);
     if (h->own_stats) (void)hipFree(h->d_stats);
     (void)hipFree(h->d_lambda); (void)hipFree(h->d_lambda_old); (void)hipFree(h->d_vsq); (void)hipFree(h->d_logzeta);
+    (void)hipFree(h->d_sigma_work); (void)hipFree(h->d_sigma_work_s);
     (void)hipFree(h->d_wtok); (void)hipFree(h->d_E); (void)hipFree(h->d_ts_partial); (void)hipFree(h->d_invsigma_f);
     (void)hipFree(h->d_bt_sdiag); (void)hipFree(h->d_bt_muf); (void)hipFree(h->d_cg_iters); (void)hipFree(h->d_doc_newton); (void)hipFree(h->d_doc_order0); (void)hipFree(h->d_doc_order_q); (void)hipFree(h->d_wave_keys);
     (void)hipFree(h->d_mu_f); (void)hipFree(h->d_sigma); (void)hipFree(h->d_invsigma); (void)hipFree(h->d_mu);
@@ -1414,7 +1454,7 @@ extern "C" int tmvb_ctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
     *out = nullptr;
     TMVB_REQUIRE(ctx && corp, TMVB_EINVAL, "tmvb_ctm_create: NULL context or corpus");
     TMVB_REQUIRE(K > 0, TMVB_EINVAL, "number of topics must be a positive integer.");       // src/gpuCTM.jl constructor
-    TMVB_REQUIRE(K <= CTM_MAX_K, TMVB_EINVAL, "tmvb_ctm_create: K <= %d (two topic slots per lane); got K=%d", CTM_MAX_K, K);
+    TMVB_REQUIRE(K <= CTM_MAX_K, TMVB_EINVAL, "tmvb_ctm_create: K <= %d (four topic slots per lane); got K=%d", CTM_MAX_K, K);
     TMVB_HIP(hipSetDevice(ctx->device));
     tmvb_ctm* h = new tmvb_ctm();
     tmvb_create_guard<tmvb_ctm, tmvb_ctm_destroy> guard{h};      // every early return below destroys h
@@ -1440,7 +1480,8 @@ extern "C" int tmvb_ctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
         (rc = dmalloc(&h->d_partial, (size_t)TMVB_REDUCE_BLOCKS * K)) || (rc = dmalloc(&h->d_partial_docs, (size_t)TMVB_REDUCE_BLOCKS * K)) || (rc = dmalloc(&h->d_partial_docs2, (size_t)TMVB_REDUCE_BLOCKS * K)) ||
         (rc = dmalloc(&h->d_rowsum, K)) ||
         (rc = dmalloc(&h->d_doc_val, (size_t)h->M)) || (rc = dmalloc(&h->d_elbo, 1)) || (rc = dmalloc(&h->d_newton, 1)) ||
-        (rc = dmalloc(&h->d_status, 1))) {
+        (rc = dmalloc(&h->d_status, 1)) ||
+        (K > 128 && ((rc = dmalloc(&h->d_sigma_work, (size_t)K * K)) || (rc = dmalloc(&h->d_sigma_work_s, (size_t)K * K))))) {
         return rc;
     }
     {
@@ -1617,10 +1658,12 @@ static int ctm_launch_generic(tmvb_ctm* h, CtmParams p, double ntol)
         //  K = 80: 12 waves 15.4, 8 waves 18.0;  K = 100: 10 waves / 168 VGPRs 20.9, 8 / 256 22.3;  K = 128: 6 waves / 168 VGPRs 39.1, 6 / 256 37.1)
         int maxw = (h->K <= 64 || h->KP <= 108) ? 12 : 8;
         if (const char* e = getenv("TMVB_CTM_CG_MAXW")) { if (h->K > 64) maxw = (atoi(e) >= 12) ? 12 : 8; }
+        const bool ga = h->K > 128;                            // four topic slots per lane, invsigma read from global memory (L2)
+        if (ga) maxw = 8;
         int waves, tile_rows;
-        ctm_generic_cg_shape(h->KP, maxw, &waves, &tile_rows);
+        ctm_generic_cg_shape(h->KP, maxw, &waves, &tile_rows, ga);
         p.tile_rows = tile_rows;
-        const size_t lds = ctm_generic_lds_bytes(h->KP, waves, tile_rows);
+        const size_t lds = ctm_generic_lds_bytes(h->KP, waves, tile_rows) - (ga ? (size_t)h->KP * h->KP * sizeof(float) : 0);
         TMVB_HIP(hipMemsetAsync(h->d_cg_iters, 0, 16 * sizeof(unsigned long long), ctx->stream));
         p.queue = (unsigned*)(h->d_cg_iters + 12); p.n_docs = h->M; p.cg_diag = h->d_cg_iters;
         p.cg_tol2 = h->cg_tol * h->cg_tol; p.cg_maxit = 4 * h->KP;
@@ -1632,7 +1675,8 @@ static int ctm_launch_generic(tmvb_ctm* h, CtmParams p, double ntol)
             return TMVB_OK;
         };
         int lrc;
-        if (h->K <= 64) lrc = launch(ctm_estep_generic_kernel<1, FILT, true, 12>);   // (K = 61 ... 64: KP = 68, but one topic slot per lane)
+        if (ga) lrc = launch(ctm_estep_generic_kernel<4, FILT, true, 8, true>);
+        else if (h->K <= 64) lrc = launch(ctm_estep_generic_kernel<1, FILT, true, 12>);   // (K = 61 ... 64: KP = 68, but one topic slot per lane)
         else lrc = (maxw == 12) ? launch(ctm_estep_generic_kernel<2, FILT, true, 12>) : launch(ctm_estep_generic_kernel<2, FILT, true, 8>);
         if (lrc) return lrc;
     } else {
@@ -1642,6 +1686,7 @@ static int ctm_launch_generic(tmvb_ctm* h, CtmParams p, double ntol)
             hipLaunchKernelGGL(kern, dim3((unsigned)h->M), dim3(64), lds, ctx->stream, p, (int64_t)0);
             return TMVB_OK;
         };
+        TMVB_REQUIRE(h->K <= 128, TMVB_EINVAL, "TMVB_CTM_GENERIC_CG=0 (the Gauss-Jordan form through LDS) exists for K <= 128 only");
         int lrc = (h->KP > 64) ? launch(ctm_estep_generic_kernel<2, FILT, false, 1>) : launch(ctm_estep_generic_kernel<1, FILT, false, 1>);
         if (lrc) return lrc;
     }
@@ -1718,10 +1763,10 @@ extern "C" int tmvb_ctm_estep(tmvb_ctm* h, int32_t niter, double ntol, int32_t v
     p.doc_order = h->d_doc_order; p.tok_inv = h->corp->term_index.d_inv;
     p.beta = h->d_beta[h->cur]; p.invsigma = h->d_invsigma_f; p.mu = h->d_mu_f;
     p.lambda = h->d_lambda; p.lambda_old = h->d_lambda_old; p.vsq = h->d_vsq; p.logzeta = h->d_logzeta;
-    p.wtok = h->d_wtok; p.E = h->d_E; p.sweeps = h->d_sweeps; p.newton_steps = h->d_newton;
+    p.wtok = h->d_wtok; p.E = h->d_E; p.estride = (h->KP / 4 <= 64) ? h->KP : h->K; p.sweeps = h->d_sweeps; p.newton_steps = h->d_newton;
     p.niter = niter; p.ntol = ntol; p.viter = viter; p.vtol = vtol;
     { const char* dbg = getenv("TMVB_DEBUG_FLAGS"); p.debug = dbg ? atoi(dbg) : 0; }
-    p.store_w = tmvb_termstats_recomputes(h->KP, true) ? 0 : 1;
+    p.store_w = tmvb_termstats_recomputes(h->KP, h->KP / 4 <= 64) ? 0 : 1;
     { int jrc = ctm_join_spec(h); if (jrc) return jrc; }        // the regrouped document order of the last E-step's side stream
     TMVB_HIP(hipEventRecord(h->ev0, ctx->stream));
     TMVB_HIP(hipMemsetAsync(h->d_newton, 0, sizeof(unsigned long long), ctx->stream));
@@ -1812,7 +1857,7 @@ extern "C" int tmvb_ctm_estep(tmvb_ctm* h, int32_t niter, double ntol, int32_t v
     tp.K = h->K; tp.tstride = h->KP; tp.ostride = h->K;
     tp.w = h->d_wtok; tp.E = h->d_E; tp.T = h->d_beta[h->cur]; tp.eps = 0.0f; tp.base = 0.0f; tp.keps = 0.0f;
     tp.out = h->d_stats; tp.partial = h->d_ts_partial;
-    int rc = tmvb_launch_termstats(ctx, h->nslot, h->KP, true, h->corp->term_index, tp);
+    int rc = tmvb_launch_termstats(ctx, h->nslot, h->KP, h->KP / 4 <= 64, h->corp->term_index, tp);
     if (folded) { TMVB_HIP(hipStreamWaitEvent(ctx->stream, h->ev_join[0], 0)); h->tail_fresh = (rc == TMVB_OK); }
     if (rc) return rc;
     TMVB_HIP(hipEventRecord(h->ev1, ctx->stream));
@@ -1916,14 +1961,17 @@ static int ctm_sigma_mu(tmvb_ctm* h, int do_sigma, int do_mu, bool staged, hipSt
 {
     tmvb_ctx* ctx = h->ctx;
     TMVB_HIP(hipSetDevice(ctx->device));
-    const size_t lds = (size_t)h->K * h->K * sizeof(double);
+    const bool in_lds = h->K <= 128;
+    const size_t lds = in_lds ? (size_t)h->K * h->K * sizeof(double) : 0;
     if (lds > 48 * 1024) TMVB_HIP(hipFuncSetAttribute((const void*)ctm_sigma_mu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (staged)
         hipLaunchKernelGGL(ctm_sigma_mu_kernel, dim3(1), dim3(256), lds, st, h->K, h->KP, (double)h->M_total, h->tail(),
-                           h->d_sigma_s, h->d_invsigma_s, h->d_invsigma_f_s, h->d_mu, h->d_mu_f, h->d_logdet_s, h->d_status_s, 1, 0);
+                           h->d_sigma_s, h->d_invsigma_s, h->d_invsigma_f_s, h->d_mu, h->d_mu_f, h->d_logdet_s, h->d_status_s, 1, 0,
+                           in_lds ? (double*)nullptr : h->d_sigma_work_s);
     else
         hipLaunchKernelGGL(ctm_sigma_mu_kernel, dim3(1), dim3(256), lds, ctx->stream, h->K, h->KP, (double)h->M_total, h->tail(),
-                           h->d_sigma, h->d_invsigma, h->d_invsigma_f, h->d_mu, h->d_mu_f, h->d_logdet, h->d_status, do_sigma, do_mu);
+                           h->d_sigma, h->d_invsigma, h->d_invsigma_f, h->d_mu, h->d_mu_f, h->d_logdet, h->d_status, do_sigma, do_mu,
+                           in_lds ? (double*)nullptr : h->d_sigma_work);
     TMVB_HIP(hipGetLastError());
     return TMVB_OK;
 }
@@ -1975,8 +2023,12 @@ extern "C" int tmvb_ctm_update_elbo(tmvb_ctm* h, double* elbo)
             hipLaunchKernelGGL((ctm_elbo_kernel<1>), dim3((unsigned)h->M), dim3(64), 0, ctx->stream, h->K, h->KP, h->corp->d_doc_ptr,
                                h->corp->d_terms, h->corp->d_counts, h->d_mu, h->d_invsigma, h->d_logdet, h->d_beta[h->cur],
                                h->d_beta[h->cur ^ 1], h->d_lambda, h->d_lambda_old, h->d_vsq, h->d_logzeta, h->d_doc_val);
-        else
+        else if (h->nslot == 2)
             hipLaunchKernelGGL((ctm_elbo_kernel<2>), dim3((unsigned)h->M), dim3(64), 0, ctx->stream, h->K, h->KP, h->corp->d_doc_ptr,
+                               h->corp->d_terms, h->corp->d_counts, h->d_mu, h->d_invsigma, h->d_logdet, h->d_beta[h->cur],
+                               h->d_beta[h->cur ^ 1], h->d_lambda, h->d_lambda_old, h->d_vsq, h->d_logzeta, h->d_doc_val);
+        else
+            hipLaunchKernelGGL((ctm_elbo_kernel<4>), dim3((unsigned)h->M), dim3(64), 0, ctx->stream, h->K, h->KP, h->corp->d_doc_ptr,
                                h->corp->d_terms, h->corp->d_counts, h->d_mu, h->d_invsigma, h->d_logdet, h->d_beta[h->cur],
                                h->d_beta[h->cur ^ 1], h->d_lambda, h->d_lambda_old, h->d_vsq, h->d_logzeta, h->d_doc_val);
         TMVB_HIP(hipGetLastError());
@@ -2175,7 +2227,9 @@ __global__ __launch_bounds__(64) void fctm_elbo_kernel(int K, int KP, const int6
 #pragma unroll
     for (int s = 0; s < NS; ++s) mv[s] = 0.0;
     for (int j = 0; j < K; ++j) {
-        const double dj = (j < 64) ? readlane_d(df[0], j & 63) : readlane_d(df[NS - 1], j & 63);
+        double dj = 0.0;                                                      // df of topic j: slot j / 64 (uniform), lane j % 64
+#pragma unroll
+        for (int s = 0; s < NS; ++s) if ((j >> 6) == s) dj = readlane_d(df[s], j & 63);
 #pragma unroll
         for (int s = 0; s < NS; ++s) mv[s] = fma(on[s] ? invsigma_d[(int64_t)j * K + ix[s]] : 0.0, dj, mv[s]);
     }
@@ -2327,7 +2381,7 @@ extern "C" int tmvb_fctm_estep(tmvb_fctm* h, int32_t niter, double ntol, int32_t
     p.doc_order = b->d_doc_order; p.tok_inv = b->corp->term_index.d_inv;
     p.beta = b->d_beta[b->cur]; p.invsigma = b->d_invsigma_f; p.mu = b->d_mu_f;
     p.lambda = b->d_lambda; p.lambda_old = b->d_lambda_old; p.vsq = b->d_vsq; p.logzeta = b->d_logzeta;
-    p.wtok = b->d_wtok; p.E = b->d_E; p.sweeps = b->d_sweeps; p.newton_steps = b->d_newton;
+    p.wtok = b->d_wtok; p.E = b->d_E; p.estride = (b->KP / 4 <= 64) ? b->KP : b->K; p.sweeps = b->d_sweeps; p.newton_steps = b->d_newton;
     p.niter = niter; p.ntol = ntol; p.viter = viter; p.vtol = vtol; p.debug = 0; p.store_w = 0;
     p.L = h->d_L; p.kappa = h->d_kappa; p.eta = (float)h->eta; p.tau = h->d_tau; p.tau_old = h->d_tau_old; p.lse = h->d_lse;
     TMVB_HIP(hipEventRecord(b->ev0, ctx->stream));
@@ -2393,8 +2447,12 @@ extern "C" int tmvb_fctm_update_elbo(tmvb_fctm* h, double* elbo)
             hipLaunchKernelGGL((fctm_elbo_kernel<1>), grid, block, 0, ctx->stream, b->K, b->KP, b->corp->d_doc_ptr, b->corp->d_terms, b->corp->d_counts,
                                b->d_mu, b->d_invsigma, b->d_logdet, h->eta, h->d_kappa, b->d_beta[b->cur], b->d_beta[b->cur ^ 1], b->d_lambda,
                                b->d_lambda_old, b->d_vsq, b->d_logzeta, h->d_tau, h->d_tau_old, b->d_doc_val);
-        else
+        else if (b->nslot == 2)
             hipLaunchKernelGGL((fctm_elbo_kernel<2>), grid, block, 0, ctx->stream, b->K, b->KP, b->corp->d_doc_ptr, b->corp->d_terms, b->corp->d_counts,
+                               b->d_mu, b->d_invsigma, b->d_logdet, h->eta, h->d_kappa, b->d_beta[b->cur], b->d_beta[b->cur ^ 1], b->d_lambda,
+                               b->d_lambda_old, b->d_vsq, b->d_logzeta, h->d_tau, h->d_tau_old, b->d_doc_val);
+        else
+            hipLaunchKernelGGL((fctm_elbo_kernel<4>), grid, block, 0, ctx->stream, b->K, b->KP, b->corp->d_doc_ptr, b->corp->d_terms, b->corp->d_counts,
                                b->d_mu, b->d_invsigma, b->d_logdet, h->eta, h->d_kappa, b->d_beta[b->cur], b->d_beta[b->cur ^ 1], b->d_lambda,
                                b->d_lambda_old, b->d_vsq, b->d_logzeta, h->d_tau, h->d_tau_old, b->d_doc_val);
         TMVB_HIP(hipGetLastError());

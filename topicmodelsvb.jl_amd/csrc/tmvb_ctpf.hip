@@ -234,7 +234,8 @@ __global__ __launch_bounds__(64) void ctpf_estep_kernel(CtpfParams p, int64_t fi
             if (on[s]) { p.E1[(int64_t)d * p.estride + i] = 0.f; p.E2[(int64_t)d * p.estride + i] = 0.f; }   // viter = 0
         }
     }
-    for (int i = K + lane; i < KP; i += 64) { p.E1[(int64_t)d * p.estride + i] = 0.f; p.E2[(int64_t)d * p.estride + i] = 0.f; }   // pads
+    if (p.estride >= KP)                                                                        // dense rows (KP / 4 > 64) have no pads
+        for (int i = K + lane; i < KP; i += 64) { p.E1[(int64_t)d * p.estride + i] = 0.f; p.E2[(int64_t)d * p.estride + i] = 0.f; }   // pads
     if (sweeps > 0 && single) {
         store_w(p.wtok, p.tok_inv, off, 0, N, 0);
         store_w(p.wrdr, p.rdr_inv, roff, 0, Rd, N);

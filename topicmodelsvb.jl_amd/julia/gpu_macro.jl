@@ -158,10 +158,11 @@ function copyback!(model::fCTM, dev::hipfCTM)
 end
 
 # Topic counts the engine takes (tmvb_*_create returns TMVB_EINVAL beyond them, which tmvb_check turns into the ArgumentError the
-# reference throws for bad arguments): LDA / fLDA 1024, CTM / fCTM / CTPF 128.  `@gpu train!` on a larger model trains on the CPU
+# reference throws for bad arguments): LDA / fLDA 1024, CTPF 512, CTM / fCTM 256 (round 4; 128 before).  `@gpu train!` on a larger model trains on the CPU
 # path with a warning instead of failing -- the macro stays a drop-in for every model the package can build.
 hip_max_topics(::Union{LDA, fLDA}) = 1024
-hip_max_topics(::Union{CTM, CTPF, fCTM}) = 128
+hip_max_topics(::Union{CTM, fCTM}) = 256
+hip_max_topics(::CTPF) = 512
 
 hipmodel(model::LDA) = hipLDA(model)
 hipmodel(model::CTM) = hipCTM(model)
