@@ -361,3 +361,27 @@ def test_train_equals_stepwise_pipelined(tmvb):
     b.update_host()
     assert np.array_equal(a.beta, b.beta) and np.array_equal(a.alpha, b.alpha)
     assert np.array_equal(a.gamma, b.gamma) and np.array_equal(a.Elogtheta, b.Elogtheta)
+
+
+def test_two_copy_kernel_for_short_documents(tmvb, oracle, monkeypatch):
+    """lda_estep_tt_kernel (TMVB_LDA_TT=1; off by default: measured 2 % slower than the NP = 2 grid tile): documents of
+    <= 64 unique terms with the tile held twice (lane = token for s = B e, lane = topic for g = B' w).  Same parity bar as every other path."""
+    monkeypatch.setenv("TMVB_LDA_TT", "1")
+    monkeypatch.setenv("TMVB_LDA_NO_MERGE", "1")          # one launch per class, as large corpora run
+    pc = tmvb.syn_nsf(M=200, V=900, seed=21)
+    K = 50
+    assert (np.diff(pc.doc_ptr) <= 64).sum() >= 30 and (np.diff(pc.doc_ptr) > 64).sum() >= 30
+    g = dict(K=K, V=pc.V, doc_ptr=pc.doc_ptr, terms=pc.terms, counts=pc.counts, beta0=tmvb.dirichlet_rows(K, pc.V, seed=3))
+    gm, om = make_pair(tmvb, oracle, g)
+    for it in range(3):
+        force(gm, om)
+        gm.estep(viter=5, vtol=0.0); gm.reduce_docs(); om.estep(viter=5, vtol=0.0)
+        gm.update_beta(); om.update_beta()
+        gm.update_alpha(); om.update_alpha()
+        e_g = gm.update_elbo(); e_o = om.update_elbo()
+        gm.update_host()
+        assert rel(gm.gamma, om.gamma).max() <= RTOL_STATE, (it, "gamma")
+        assert rel(gm.Elogtheta, om.Elogtheta).max() <= RTOL_STATE, (it, "Elogtheta")
+        big = om.beta > 1e-6
+        assert rel(gm.beta[big], om.beta[big]).max() <= RTOL_BETA, (it, "beta")
+        assert abs(e_g - e_o) <= RTOL_ELBO_STEP * abs(e_o), (it, e_g, e_o)

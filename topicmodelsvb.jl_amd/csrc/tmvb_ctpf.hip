@@ -586,12 +586,40 @@ __global__ __launch_bounds__(64) void ctpf_estep_grid_any_kernel(CtpfParams p, i
     CTPF_GRID_LDS(1);
     ctpf_estep_grid_any<LPR, 1>(p, p.doc_order[first + blockIdx.x], topic_of_lane, ef_all, xch);
 }
+// Round 4: that one launch ran EVERY document at ONE wave per SIMD -- the (6, 1) body needs 258 registers, and a kernel's allocation is
+// its widest path's (the ISA said so; the kernel issued a vector instruction 42 % of the time).  Two launches by register need instead:
+//   NARROW  (2, 1) and (3, 1): documents of <= 96 terms and <= 32 readers (most of a CiteULike-shaped corpus), 168 VGPRs = three waves per SIMD,
+//           on the context's stream;
+//   WIDE    (4, 1), (6, 1), (4, 2): the rest of the single-wave classes, on aux[0] beside it (the multi-wave long documents keep aux[1]).
+template <int LPR>
+__global__ __launch_bounds__(64, 3) void ctpf_estep_grid_narrow_kernel(CtpfParams p, int64_t first, const int* __restrict__ topic_of_lane)
+{
+    CTPF_GRID_LDS(1);
+    const int d = p.doc_order[first + blockIdx.x];
+    const int N = __builtin_amdgcn_readfirstlane((int)(p.doc_ptr[d + 1] - p.doc_ptr[d]));
+    if (N > 64) ctpf_estep_grid_body<LPR, 3, 1, 1, 1>(p, d, topic_of_lane, ef_all, xch);
+    else ctpf_estep_grid_body<LPR, 2, 1, 1, 1>(p, d, topic_of_lane, ef_all, xch);
+}
+template <int LPR>
+__global__ __launch_bounds__(64) void ctpf_estep_grid_wide_kernel(CtpfParams p, int64_t first, const int* __restrict__ topic_of_lane)
+{
+    CTPF_GRID_LDS(1);
+    const int d = p.doc_order[first + blockIdx.x];
+    const int N = __builtin_amdgcn_readfirstlane((int)(p.doc_ptr[d + 1] - p.doc_ptr[d]));
+    const int Rd = __builtin_amdgcn_readfirstlane((int)(p.rdr_ptr[d + 1] - p.rdr_ptr[d]));
+    if (Rd > 32) ctpf_estep_grid_body<LPR, 4, 2, 1, 1>(p, d, topic_of_lane, ef_all, xch);
+    else if (N > 128) ctpf_estep_grid_body<LPR, 6, 1, 1, 1>(p, d, topic_of_lane, ef_all, xch);
+    else ctpf_estep_grid_body<LPR, 4, 1, 1, 1>(p, d, topic_of_lane, ef_all, xch);
+}
 template <int LPR>
 static void ctpf_launch_grid(const tmvb_bucket& b, dim3 grid, hipStream_t st, const CtpfParams& p, int64_t first, const int* tol)
 {
+
     if (b.waves == 4 && b.grid_np == 2) { hipLaunchKernelGGL((ctpf_estep_grid_long_kernel<LPR, 2, 4, 4>), grid, dim3(256), 0, st, p, first, tol); return; }
     if (b.waves == 4) { hipLaunchKernelGGL((ctpf_estep_grid_long_kernel<LPR, 3, 3, 4>), grid, dim3(256), 0, st, p, first, tol); return; }
     if (b.grid_np == 99) { hipLaunchKernelGGL((ctpf_estep_grid_any_kernel<LPR>), grid, dim3(64), 0, st, p, first, tol); return; }
+    if (b.grid_np == 98) { hipLaunchKernelGGL((ctpf_estep_grid_wide_kernel<LPR>), grid, dim3(64), 0, st, p, first, tol); return; }
+    if (b.grid_np == 97) { hipLaunchKernelGGL((ctpf_estep_grid_narrow_kernel<LPR>), grid, dim3(64), 0, st, p, first, tol); return; }
 #define CTPF_GRID_LAUNCH(T_, R_) if (b.grid_np == T_ && b.grid_np2 == R_) { hipLaunchKernelGGL((ctpf_estep_grid_kernel<LPR, T_, R_>), grid, dim3(64), 0, st, p, first, tol); return; }
     CTPF_GRID_CLASSES(CTPF_GRID_LAUNCH)
 #undef CTPF_GRID_LAUNCH
@@ -1475,7 +1503,8 @@ extern "C" int tmvb_ctpf_estep(tmvb_ctpf* h, int32_t viter, double vtol)
     const int nb = (int)h->buckets.size();
     hipStream_t chain_st = ctx->stream;                          // only used when h->reg_path
     TMVB_HIP(hipEventRecord(h->ev_fork, ctx->stream));
-    for (int a = h->reg_path ? 1 : 0; a < 2; ++a) TMVB_HIP(hipStreamWaitEvent(h->aux[a], h->ev_fork, 0));
+    for (int a = 0; a < 2; ++a) TMVB_HIP(hipStreamWaitEvent(h->aux[a], h->ev_fork, 0));
+    bool aux0_used = !h->reg_path;
     for (int bi = 0; bi < nb; ++bi) {
         const tmvb_bucket& b = h->buckets[bi];
         dim3 grid((unsigned)b.count), block(64);
@@ -1487,11 +1516,17 @@ extern "C" int tmvb_ctpf_estep(tmvb_ctpf* h, int32_t viter, double vtol)
             static const bool gany = [] { const char* e = getenv("TMVB_CTPF_GRID_ANY"); return !(e && atoi(e) == 0); }();
             hipStream_t st = b.waves > 1 ? h->aux[1] : chain_st;
             tmvb_bucket bb = b;
+            // (round 4) the single-wave classes as TWO launches by register need (ctpf_estep_grid_narrow_kernel / _wide_kernel) unless
+            // TMVB_CTPF_SPLIT=0 (read per call: the tests run both)
+            const char* es = getenv("TMVB_CTPF_SPLIT");
+            const bool split = !(es && atoi(es) == 0);
             if (gany && b.waves == 1) {
+                const bool wide = b.grid_np >= 4;
                 int64_t cnt = b.count;
                 while (bi + 1 < nb && h->buckets[bi + 1].grid_np > 0 && h->buckets[bi + 1].waves == 1 &&
-                       h->buckets[bi + 1].first == b.first + cnt) { cnt += h->buckets[bi + 1].count; ++bi; }
-                if (cnt > b.count) { bb.count = cnt; bb.grid_np = 99; grid = dim3((unsigned)cnt); }
+                       h->buckets[bi + 1].first == b.first + cnt && (!split || (h->buckets[bi + 1].grid_np >= 4) == wide)) { cnt += h->buckets[bi + 1].count; ++bi; }
+                if (split) { bb.count = cnt; bb.grid_np = wide ? 98 : 97; grid = dim3((unsigned)cnt); if (wide) { st = h->aux[0]; aux0_used = true; } }
+                else if (cnt > b.count) { bb.count = cnt; bb.grid_np = 99; grid = dim3((unsigned)cnt); }
             }
             switch (p.LPR) {
 #define CTPF_GRID_CASE(LPRV) case LPRV: ctpf_launch_grid<LPRV>(bb, grid, st, p, b.first, h->d_grid_topic_of_lane); break;
@@ -1538,7 +1573,7 @@ extern "C" int tmvb_ctpf_estep(tmvb_ctpf* h, int32_t viter, double vtol)
         TMVB_HIP(hipGetLastError());
     }
     for (int a = 0; a < 2; ++a) {
-        if (a == 0 && h->reg_path) continue;                  // aux[0] carried nothing in this plan
+        if (a == 0 && !aux0_used) continue;                   // aux[0] carried nothing in this plan
         TMVB_HIP(hipEventRecord(h->ev_join[a], h->aux[a]));
         TMVB_HIP(hipStreamWaitEvent(ctx->stream, h->ev_join[a], 0));
     }

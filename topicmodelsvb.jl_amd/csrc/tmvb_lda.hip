@@ -651,6 +651,10 @@ __global__ __launch_bounds__(64) void lda_estep_grid_kernel(LdaParams p, int64_t
     lda_estep_grid_body<LPR, NP>(p, d, off, (int)(p.doc_ptr[d + 1] - off), topic_of_lane);
 }
 
+// (Round 4, measured and dropped: the same body compiled for one wave per SIMD more than the allocator takes by itself --
+// __launch_bounds__(64, 5) for NP = 2: 96 VGPRs instead of 102, (64, 4) for NP = 3: 128 instead of 134, five spilled dwords, one reload
+// per sweep.  The counters had said the kernels issue a vector instruction only 63 - 81 % of the time when alone; A/B on one box,
+// alternating: 1192 / 1201 it/s against 1270 / 1280 without.  The scratch reload sits in the sweep's dependency chain.)
 // long documents: one workgroup of W waves per document (lda_estep_grid_body, W > 1)
 template <int LPR, int NP, int W>
 __global__ __launch_bounds__(64 * W) void lda_estep_grid_long_kernel(LdaParams p, int64_t first, const int* __restrict__ topic_of_lane)
@@ -658,6 +662,122 @@ __global__ __launch_bounds__(64 * W) void lda_estep_grid_long_kernel(LdaParams p
     const int d = p.doc_order[first + blockIdx.x];
     const int64_t off = p.doc_ptr[d];
     lda_estep_grid_body<LPR, NP, W>(p, d, off, (int)(p.doc_ptr[d + 1] - off), topic_of_lane);
+}
+
+// ------------------------------------------------------------------------------ two-copy E-step for documents of <= 64 unique terms (round 4)
+// A document of at most 64 terms (30 % of SYN-NSF) spends half of its grid-tile sweep on what does NOT shrink with the document: the fold and the
+// 16-lane reduce-scatter behind phase 2 (~50 issue slots) and the one-topic-per-lane tail (~60) of a 200-slot sweep.  Here the N x KP tile is held
+// TWICE, once per matrix-vector product, each copy in the layout that needs no cross-lane sum at all:
+//   copy A  lane = token n, registers = the KP topics of its row        s_n = K eps + sum_i A[i] e_i         (update_phi!'s normaliser, src/LDA.jl:152-153)
+//   copy B  lane = topic i, registers = the 64 tokens' values B[n]      g_i = sum_n w_n B[n]                 (update_gamma!, :145)
+// e (one value per topic lane) reaches the token lanes and w = c ./ s (one value per token lane) reaches the topic lanes through 256 bytes of
+// LDS each: one ds_write_b32 and broadcast ds_read_b128 (all lanes read the same address), so both products are plain packed fmas against
+// wave-uniform operands -- 26 + 32 v_pk_fma_f32 at KP = 52 -- and the tail finds g_i already in the lane that owns topic i.  sum_n w_n (the eps term
+// of gamma) rides in lane 63 of copy B as a row of ones.  ~130 issue slots per sweep against 200; 116 tile registers + ~40 (three waves per SIMD
+// where the NP = 2 grid tile runs four).  Same arithmetic and exit rule as lda_estep_grid_body; the sums run in a different order (fp32: 1e-7).
+// Requires KP <= 60 (one topic per lane, lane 63 free).
+template <int LPR>
+__global__ __launch_bounds__(64) void lda_estep_tt_kernel(LdaParams p, int64_t first)
+{
+    constexpr int KP = 4 * LPR;
+    static_assert(KP <= 60, "lda_estep_tt_kernel: one topic per lane and a free lane 63");
+    __shared__ __attribute__((aligned(16))) float e_l[64];
+    __shared__ __attribute__((aligned(16))) float w_l[64];
+    const int lane = threadIdx.x;
+    const int K = p.K;
+    const int d = p.doc_order[first + blockIdx.x];
+    const int64_t off = p.doc_ptr[d];
+    const int N = (int)(p.doc_ptr[d + 1] - off);                 // <= 64
+    // ---- copy A: this lane's token (a lane past the last token reads token 0 and carries count 0 -> weight exactly 0)
+    const bool tok_on = lane < N;
+    const int64_t off0 = N > 0 ? off : 0;
+    const int tm = p.terms[off0 + (tok_on ? lane : 0)];
+    const float c = tok_on ? (float)p.counts[off0 + lane] : 0.0f;
+    gv2f A[2 * LPR];
+    {
+        const float4* __restrict__ row = (const float4*)((const char*)p.beta + (uint32_t)tm * (uint32_t)(4 * KP));
+#pragma unroll
+        for (int q = 0; q < LPR; ++q) { const float4 v = row[q]; A[2 * q] = gv2f{v.x, v.y}; A[2 * q + 1] = gv2f{v.z, v.w}; }
+    }
+    // ---- copy B: this lane's topic over the 64 token slots (ids broadcast from the token lanes; rows are coalesced 4 KP-byte reads)
+    gv2f B[32];
+    {
+        const uint32_t lo = 4u * (uint32_t)(lane < KP ? lane : 0);
+        const char* __restrict__ tb = (const char*)p.beta;
+#pragma unroll
+        for (int m = 0; m < 32; ++m) {
+            const uint32_t i0 = (uint32_t)__builtin_amdgcn_readlane(tm, 2 * m), i1 = (uint32_t)__builtin_amdgcn_readlane(tm, 2 * m + 1);
+            B[m] = gv2f{*(const float*)(tb + (i0 * (uint32_t)(4 * KP) + lo)), *(const float*)(tb + (i1 * (uint32_t)(4 * KP) + lo))};
+        }
+        if (lane >= KP) {
+#pragma unroll
+            for (int m = 0; m < 32; ++m) B[m] = (lane == 63) ? gv2f{1.0f, 1.0f} : gv2f{0.0f, 0.0f};      // lane 63: sum_n w_n
+        }
+    }
+    // ---- topic role: lane i < K owns topic i
+    const bool on = lane < K;
+    const int tp = on ? lane : 0;
+    const float al_ld = p.alpha[tp], el_ld = p.elog[(int64_t)d * K + tp];
+    const float al = on ? al_ld : 0.0f;
+    const float alpha_eps = al + TMVB_EPS_F;
+    float elog = on ? el_ld : 0.0f, elog_old = elog, gam = 0.0f, e = 0.0f;
+    // psi(sum_i gamma_i) with sum_i gamma_i = K eps + sum alpha + C_d (exact arithmetic: sum_i phi_in = 1)
+    const float gsum = (float)K * TMVB_EPS_F + wave_sum(al) + wave_sum(c);
+    const float dgs = digamma_f(gsum);
+    const float vtol2 = p.vtol * p.vtol;
+    const float keps = (float)K * TMVB_EPS_F;
+    int sweeps = 0;
+    for (int v = 0; v < p.viter; ++v) {
+        ++sweeps;
+        e = on ? sweep_exp(elog) : 0.0f;                                                  // update_phi!, src/LDA.jl:152
+        e_l[lane] = e;
+        WAVE_LDS_FENCE();
+        // ---- phase 1 (lane = token): s_n = K eps + sum_i A[i] e_i
+        gv2f s0 = gv2f{keps, 0.0f}, s1 = gv2f{0.0f, 0.0f};
+#pragma unroll
+        for (int q = 0; q < LPR; ++q) {
+            const float4 ev = ((const float4*)e_l)[q];
+            s0 = __builtin_elementwise_fma(A[2 * q], gv2f{ev.x, ev.y}, s0);
+            s1 = __builtin_elementwise_fma(A[2 * q + 1], gv2f{ev.z, ev.w}, s1);
+        }
+        const gv2f st = s0 + s1;
+        const float w = c * __builtin_amdgcn_rcpf(st.x + st.y);                           // w_n = c_n / s_n
+        w_l[lane] = w;
+        WAVE_LDS_FENCE();
+        // ---- phase 2 (lane = topic): g_i = sum_n w_n B[n]
+        gv2f g0 = gv2f{0.0f, 0.0f}, g1 = gv2f{0.0f, 0.0f};
+#pragma unroll
+        for (int m4 = 0; m4 < 16; ++m4) {
+            const float4 wv = ((const float4*)w_l)[m4];
+            g0 = __builtin_elementwise_fma(B[2 * m4], gv2f{wv.x, wv.y}, g0);
+            g1 = __builtin_elementwise_fma(B[2 * m4 + 1], gv2f{wv.z, wv.w}, g1);
+        }
+        const gv2f gt = g0 + g1;
+        const float g = gt.x + gt.y;
+        const float wtot = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, g), 63));
+        // ---- tail: one topic per lane
+        gam = fmaf(wtot, TMVB_EPS_F, fmaf(e, g, alpha_eps));                              // update_gamma!, src/LDA.jl:145
+        const float dg = digamma_sweep_f(gam);
+        elog_old = elog;                                                                  // update_Elogtheta!, :137-138
+        float dl = 0.0f;
+        if (on) {
+            elog = dg - dgs;
+            const float df = elog - elog_old;
+            dl = df * df;
+        }
+        if (wave_sum(dl) < vtol2) break;                                                  // :175, norm < vtol on the squares
+    }
+    if (sweeps > 0) {
+        if (on) {
+            p.gamma[(int64_t)d * K + lane] = gam;
+            p.elog[(int64_t)d * K + lane] = elog;
+            p.elog_old[(int64_t)d * K + lane] = elog_old;
+        }
+        if (lane < p.estride) p.E[(int64_t)d * p.estride + lane] = (lane < KP) ? e : 0.0f;
+    } else if (lane < p.estride) {
+        p.E[(int64_t)d * p.estride + lane] = 0.0f;
+    }
+    if (lane == 0) p.sweeps[d] = (uint8_t)min(sweeps, 255);
 }
 
 // ------------------------------------------------------------------------------ ELBO
@@ -812,6 +932,7 @@ __global__ __launch_bounds__(64) void lda_elbo_reg_kernel(int K, const int32_t* 
 
 #define TMVB_REG_ANY_TILES 99   // bucket of register-tile documents with mixed tile counts (lda_estep_reg_any_kernel)
 #define TMVB_GRID_ANY_NP 99     // bucket of grid-tile documents with mixed lengths (lda_estep_grid_any_kernel)
+#define TMVB_GRID_TT_NP 1       // bucket of documents of <= 64 unique terms on the two-copy kernel (lda_estep_tt_kernel; KP <= 60)
 
 // token pairs per lane of the widest grid-tile instantiation: 2 NP LPR tile registers + 2 LPR accumulators + ~40 must stay
 // within the 256 architectural VGPRs.  KP <= 60: 6 pairs (documents of <= 192 unique terms per wave), KP <= 76: 4, KP <= 100: 3.
@@ -840,6 +961,11 @@ __global__ __launch_bounds__(64) void lda_estep_grid_any_kernel(LdaParams p, int
     else lda_estep_grid_body<LPR, 2>(p, d, off, N, topic_of_lane);
 }
 
+// (Round 4, measured and dropped: the one mixed launch of a small shard runs every document at the widest body's registers (NP = 6: 230 VGPRs,
+// two waves per SIMD).  Splitting it by register need -- NP = 2, 3 on the chain at three waves per SIMD, NP = 4, 6 beside it on aux[0], what
+// gained CTPF 7 % (tmvb_ctpf.hip) -- LOSES here: 16 100 documents 0.185 ms per iteration against 0.173, 32 200 documents 0.277 against 0.271
+// (A/B on one box, alternating).  LDA's sweeps keep a SIMD busier than CTPF's one- or two-sweep documents do, and the second launch costs a
+// cross-stream join in a 0.17 ms iteration.)
 template <int LPR>
 static void lda_launch_grid(int np, dim3 grid, dim3 block, hipStream_t st, const LdaParams& p, int64_t first, const int* tol)
 {
@@ -847,6 +973,9 @@ static void lda_launch_grid(int np, dim3 grid, dim3 block, hipStream_t st, const
     if (block.x == 128) { hipLaunchKernelGGL((lda_estep_grid_long_kernel<LPR, NPM, 2>), grid, block, 0, st, p, first, tol); return; }
     if (block.x == 256) { hipLaunchKernelGGL((lda_estep_grid_long_kernel<LPR, NPM, 4>), grid, block, 0, st, p, first, tol); return; }
     if (np == TMVB_GRID_ANY_NP) hipLaunchKernelGGL((lda_estep_grid_any_kernel<LPR>), grid, block, 0, st, p, first, tol);
+    else if (np == TMVB_GRID_TT_NP) {
+        if constexpr (LPR <= 15) hipLaunchKernelGGL((lda_estep_tt_kernel<LPR>), grid, block, 0, st, p, first);
+    }
     else if (np <= 2) hipLaunchKernelGGL((lda_estep_grid_kernel<LPR, 2>), grid, block, 0, st, p, first, tol);
     else if (np == 3) hipLaunchKernelGGL((lda_estep_grid_kernel<LPR, 3>), grid, block, 0, st, p, first, tol);
     else if (np == 4) hipLaunchKernelGGL((lda_estep_grid_kernel<LPR, (NPM >= 4 ? 4 : 3)>), grid, block, 0, st, p, first, tol);
@@ -999,10 +1128,17 @@ static void lda_build_buckets(tmvb_lda* h, std::vector<int32_t>& order)
     }
     if (h->grid_path) {
         // grid-tile buckets, longest first: one launch per instantiated pair count
+        // (round 4) documents of <= 64 unique terms on the two-copy kernel (lda_estep_tt_kernel, KP <= 60): OFF by default -- measured A/B on
+        // SYN-NSF K = 50, alternating on one box: 1256 / 1267 it/s with it against 1287 / 1288 without (its ~125 VALU instructions per sweep
+        // against 200 are paid for with 29 dependent LDS broadcast reads per sweep and three waves per SIMD instead of four).  TMVB_LDA_TT=1
+        // selects it (read per model: tests/test_lda_gpu.py runs it against the oracle).
+        const char* tt_e = getenv("TMVB_LDA_TT");
+        const bool tt = tt_e && atoi(tt_e) != 0 && h->KP <= 60 && h->estride <= 64;
+        auto cls = [&](int64_t n) { return (tt && n <= 64) ? TMVB_GRID_TT_NP : lda_grid_np_class(n, h->grid_np_max); };
         while (pos < h->M) {
-            const int np = lda_grid_np_class(len[order[pos]], h->grid_np_max);
+            const int np = cls(len[order[pos]]);
             int64_t cnt = 0;
-            while (pos + cnt < h->M && lda_grid_np_class(len[order[pos + cnt]], h->grid_np_max) == np) ++cnt;
+            while (pos + cnt < h->M && cls(len[order[pos + cnt]]) == np) ++cnt;
             tmvb_bucket b{pos, cnt, 0, (np + 1) / 2};        // reg_tiles > 0 marks a register bucket (chain stream, piece cuts)
             b.grid_np = np;
             h->buckets.push_back(b);
