@@ -82,10 +82,15 @@ static __global__ __launch_bounds__(1024) void lda_elbo_final_kernel(const doubl
                                                               const double* __restrict__ pw_partial, int pw_blocks, double pw_share)
 {
     __shared__ double red[1024];
-    double s8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};      // 8 independent chains: the loads overlap (fixed order)
-    for (int64_t d0 = threadIdx.x; d0 < M; d0 += 8 * 1024) {
+    // 16 loads in flight per thread, unconditional (a slot past the end reads element 0 and adds 0): the one block's 126 dependent
+    // trips of one load each were most of this kernel's 40 us at M = 128 804 (round 4; fixed order: run-to-run bitwise)
+    double s8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int64_t d0 = threadIdx.x; d0 < M; d0 += 16 * 1024) {
+        double v[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int64_t d = d0 + (int64_t)u * 1024; if (d < M) s8[u] += doc_val[d]; }
+        for (int u = 0; u < 16; ++u) { const int64_t d = d0 + (int64_t)u * 1024; v[u] = doc_val[d < M ? d : 0]; }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int64_t d = d0 + (int64_t)u * 1024; s8[u & 7] += (d < M) ? v[u] : 0.0; }
     }
     double pwl = 0.0;                                             // E_q[log p(w)] partials of update_beta!, if in use
     if (pw_partial) for (int b = threadIdx.x; b < pw_blocks; b += 1024) pwl += pw_share * pw_partial[b];

@@ -281,12 +281,12 @@ __global__ __launch_bounds__(64) void flda_elbo_kernel(int K, int KP, const int6
         const double g = (double)gamma[(int64_t)d * K + ix[s]];
         acc += (alpha_d[ix[s]] - 1.0) * el;                                                        // Elogptheta :63 (dot part)
         acc += pc[s] * el;                                                                         // Elogpz :77
-        if (K > 1) acc += lgamma(g) - (g - 1.0) * digamma_d(g);                                    // -Elogqtheta :89 (utils.jl:172-176)
+        if (K > 1) { double ps, lg; digamma_lgamma_d(g, ps, lg); acc += lg - (g - 1.0) * ps; }                                    // -Elogqtheta :89 (utils.jl:172-176)
         gl += g;
     }
     const double g0 = wave_sum_d(gl);
     double tot = wave_sum_d(acc);
-    if (K > 1) tot += -lgamma(g0) + (g0 - (double)K) * digamma_d(g0);
+    if (K > 1) { double ps0, lg0; digamma_lgamma_d(g0, ps0, lg0); tot += -lg0 + (g0 - (double)K) * ps0; }
     // Elogpc :69-71: the powers are formed first, so the term saturates at log(eps) for documents of more than ~100 tokens
     const double eta = eta_d[0];
     tot += log(TMVB_EPS_D + pow(eta, ta) * pow(1.0 - eta, Cd - ta));

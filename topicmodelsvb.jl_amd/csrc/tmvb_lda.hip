@@ -835,13 +835,13 @@ __global__ __launch_bounds__(64) void lda_elbo_kernel(int K, int KP, const int64
             double g = (double)gamma[(int64_t)d * K + i];
             acc += (alpha_d[i] - 1.0) * el;                                                  // Elogptheta :51 (dot part)
             acc += pc[s] * el;                                                               // Elogpz :58
-            if (K > 1) acc += lgamma(g) - (g - 1.0) * digamma_d(g);                          // -Elogqtheta :72 (utils.jl:172-176)
+            if (K > 1) { double ps, lg; digamma_lgamma_d(g, ps, lg); acc += lg - (g - 1.0) * ps; }                          // -Elogqtheta :72 (utils.jl:172-176)
             gl += g;
         }
     }
     const double g0 = wave_sum_d(gl);
     double tot = wave_sum_d(acc);
-    if (K > 1) tot += -lgamma(g0) + (g0 - (double)K) * digamma_d(g0);
+    if (K > 1) { double ps0, lg0; digamma_lgamma_d(g0, ps0, lg0); tot += -lg0 + (g0 - (double)K) * ps0; }
     if (lane == 0) doc_val[d] = tot;
 }
 
@@ -920,15 +920,32 @@ __global__ __launch_bounds__(64) void lda_elbo_reg_kernel(int K, const int32_t* 
         if (i < K) {
             const double g = (double)gamma[(int64_t)d * K + i];
             acc += (alpha_d[i] - 1.0) * (double)el[s];                               // Elogptheta :51 (dot part)
-            if (K > 1 && !TMVB_ELBO_SKIP_TAIL) acc += lgamma(g) - (g - 1.0) * digamma_d(g);                  // -Elogqtheta :72 (utils.jl:172-176)
+            if (K > 1 && !TMVB_ELBO_SKIP_TAIL) {                                     // -Elogqtheta :72 (utils.jl:172-176)
+                // psi and lgamma of gamma from ONE evaluation (digamma_lgamma_d, <= 2e-15 against mpmath): the library's lgamma() +
+                // the loop form of digamma_d were ~45 % of this kernel (round 4: 438 -> see DESIGN.md section 2.4)
+                double ps, lg;
+                digamma_lgamma_d(g, ps, lg);
+                acc += lg - (g - 1.0) * ps;
+            }
             gl += g;
         }
     }
     const double g0 = wave_sum_d(gl);
     double tot = wave_sum_d(acc);
-    if (K > 1 && !TMVB_ELBO_SKIP_TAIL) tot += -lgamma(g0) + (g0 - (double)K) * digamma_d(g0);
+    if (K > 1 && !TMVB_ELBO_SKIP_TAIL) {
+        double ps0, lg0;
+        digamma_lgamma_d(g0, ps0, lg0);
+        tot += -lg0 + (g0 - (double)K) * ps0;
+    }
     if (lane == 0) doc_val[d] = tot;
 }
+
+// (Round 4, measured and dropped, both against this kernel at 366 us per call on SYN-NSF K = 50: (i) a table form -- log(beta_old + eps) once per table
+// entry and call plus Elogtheta_old per document instead of a v_log_f32 per (token, topic): 1 logarithm instead of 53 in the loop body, four VALU
+// instructions per (token, topic) instead of eight -- took 1.58 ms per checked iteration against 1.07: the second gathered row per token costs more
+// than the logarithms; (ii) the same sums on the E-step's 16 x 4 lane grid (16 rows per load instruction instead of 64, e_old / Elogtheta as LDS
+// broadcast rows instead of 104 v_readlane per tile, packed arithmetic): 1.051 against 1.060 ms, i.e. nothing.  Neither the logarithms nor the
+// gather's shape bound it; one wave per document with two dependent global loads in front of the rows and an fp64 tail behind them does.)
 
 #define TMVB_REG_ANY_TILES 99   // bucket of register-tile documents with mixed tile counts (lda_estep_reg_any_kernel)
 #define TMVB_GRID_ANY_NP 99     // bucket of grid-tile documents with mixed lengths (lda_estep_grid_any_kernel)
