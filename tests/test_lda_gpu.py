@@ -386,29 +386,3 @@ def test_two_copy_kernel_for_short_documents(tmvb, oracle, monkeypatch):
         assert rel(gm.beta[big], om.beta[big]).max() <= RTOL_BETA, (it, "beta")
         assert abs(e_g - e_o) <= RTOL_ELBO_STEP * abs(e_o), (it, e_g, e_o)
 
-
-@pytest.mark.parametrize("K", [3, 18, 50, 57])
-def test_elbo_grid_form_equals_the_lane_per_token_form(tmvb, oracle, K, monkeypatch):
-    """update_elbo! on the 16 x 4 lane grid (lda_elbo_grid_kernel, round 4; default for KP <= 60) against the lane = token kernel
-    (TMVB_LDA_ELBO_GRID=0) and the oracle, on a trained state with documents of 20 ... 400 unique terms (several 96-token trips)."""
-    rng = np.random.default_rng(9)
-    V = 1200
-    docs = []
-    for n in list(rng.integers(20, 130, size=150)) + [200, 288, 289, 400, 96, 97, 1]:
-        t = np.sort(rng.choice(V, size=int(n), replace=False)); c = rng.integers(1, 5, size=int(n))
-        docs.append((t, c))
-    doc_ptr = np.concatenate([[0], np.cumsum([len(t) for t, _ in docs])])
-    g = dict(K=K, V=V, doc_ptr=doc_ptr, terms=np.concatenate([t for t, _ in docs]).astype(np.int32),
-             counts=np.concatenate([c for _, c in docs]).astype(np.int32), beta0=tmvb.dirichlet_rows(K, V, seed=3))
-    gm, om = make_pair(tmvb, oracle, g)
-    for it in range(6):
-        gm.estep(); gm.reduce_docs(); gm.update_beta(); gm.update_alpha()
-    e_grid = gm.update_elbo()
-    monkeypatch.setenv("TMVB_LDA_ELBO_GRID", "0")
-    e_tok = gm.update_elbo()
-    assert abs(e_grid - e_tok) <= 2e-7 * abs(e_tok), (e_grid, e_tok)
-    gm.update_host()
-    for n in ("alpha", "beta", "beta_old", "gamma", "Elogtheta", "Elogtheta_old"):
-        setattr(om, n, np.array(getattr(gm, n), dtype=np.float64, copy=True, order="F"))
-    e_o = om.update_elbo()
-    assert abs(e_grid - e_o) <= RTOL_ELBO_STEP * abs(e_o), (e_grid, e_o)
