@@ -155,21 +155,38 @@ __device__ __forceinline__ void grid_reduce_scatter(float (&v)[M], float (&res)[
 // Tile of the rows ids[nbase + 16 s + a], s < 2 NP, of a [.][4 LPR] fp32 table (uniform base + 32-bit byte offsets: the table
 // must be smaller than 4 GiB), topics 4 j + b; vals -> c (as float).  Branch-free and in two waves of loads: every id / value of
 // the lane first (a slot past the slice's last entry reads entry 0 and gets value 0 -> weight exactly 0), then every row.
-template <int LPR, int NP>
-__device__ __forceinline__ void grid_load_tile(gv2f (&B)[NP][LPR], gv2f (&c)[NP], const float* __restrict__ table,
-                                               const int* __restrict__ ids, const int* __restrict__ vals, const int N,
-                                               const int nbase, const int a, const int b)
+// first wave of loads: the ids and (masked) values of the lane's 2 NP token slots
+// (the raw form leaves the values unmasked: a caller that prefetches must not touch what it loaded before it needs it)
+template <int NP>
+__device__ __forceinline__ void grid_load_ids_raw(int (&tm)[2 * NP], int (&cn)[2 * NP], const int* __restrict__ ids, const int* __restrict__ vals,
+                                                  const int N, const int nbase, const int a)
 {
-    int tm[2 * NP], cn[2 * NP];
 #pragma unroll
     for (int s = 0; s < 2 * NP; ++s) {
         const int n = nbase + 16 * s + a;
         const unsigned nc = n < N ? (unsigned)n : 0u;
         tm[s] = ids[nc];
-        cn[s] = vals[nc];                                   // unconditional load, masked below
+        cn[s] = vals[nc];                                   // unconditional load, masked by grid_mask_vals
     }
+}
+template <int NP>
+__device__ __forceinline__ void grid_mask_vals(int (&cn)[2 * NP], const int N, const int nbase, const int a)
+{
 #pragma unroll
     for (int s = 0; s < 2 * NP; ++s) cn[s] = (nbase + 16 * s + a < N) ? cn[s] : 0;
+}
+template <int NP>
+__device__ __forceinline__ void grid_load_ids(int (&tm)[2 * NP], int (&cn)[2 * NP], const int* __restrict__ ids, const int* __restrict__ vals,
+                                              const int N, const int nbase, const int a)
+{
+    grid_load_ids_raw<NP>(tm, cn, ids, vals, N, nbase, a);
+    grid_mask_vals<NP>(cn, N, nbase, a);
+}
+// second wave: the rows
+template <int LPR, int NP>
+__device__ __forceinline__ void grid_load_rows(gv2f (&B)[NP][LPR], gv2f (&c)[NP], const float* __restrict__ table, const int (&tm)[2 * NP],
+                                               const int (&cn)[2 * NP], const int b)
+{
     const char* __restrict__ tb = (const char*)table;
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
@@ -180,6 +197,15 @@ __device__ __forceinline__ void grid_load_tile(gv2f (&B)[NP][LPR], gv2f (&c)[NP]
         for (int j = 0; j < LPR; ++j)
             B[q][j] = gv2f{*(const float*)(tb + o0 + 16u * j), *(const float*)(tb + o1 + 16u * j)};
     }
+}
+template <int LPR, int NP>
+__device__ __forceinline__ void grid_load_tile(gv2f (&B)[NP][LPR], gv2f (&c)[NP], const float* __restrict__ table,
+                                               const int* __restrict__ ids, const int* __restrict__ vals, const int N,
+                                               const int nbase, const int a, const int b)
+{
+    int tm[2 * NP], cn[2 * NP];
+    grid_load_ids<NP>(tm, cn, ids, vals, N, nbase, a);
+    grid_load_rows<LPR, NP>(B, c, table, tm, cn, b);
 }
 
 // s_n = 4 init4 + sum_i B[n][i] e_i for the lane's 2 NP tokens, complete in every lane of the quad: LPR packed fmas per token
