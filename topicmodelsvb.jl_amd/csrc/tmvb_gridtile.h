@@ -156,31 +156,19 @@ __device__ __forceinline__ void grid_reduce_scatter(float (&v)[M], float (&res)[
 // must be smaller than 4 GiB), topics 4 j + b; vals -> c (as float).  Branch-free and in two waves of loads: every id / value of
 // the lane first (a slot past the slice's last entry reads entry 0 and gets value 0 -> weight exactly 0), then every row.
 // first wave of loads: the ids and (masked) values of the lane's 2 NP token slots
-// (the raw form leaves the values unmasked: a caller that prefetches must not touch what it loaded before it needs it)
 template <int NP>
-__device__ __forceinline__ void grid_load_ids_raw(int (&tm)[2 * NP], int (&cn)[2 * NP], const int* __restrict__ ids, const int* __restrict__ vals,
-                                                  const int N, const int nbase, const int a)
+__device__ __forceinline__ void grid_load_ids(int (&tm)[2 * NP], int (&cn)[2 * NP], const int* __restrict__ ids, const int* __restrict__ vals,
+                                              const int N, const int nbase, const int a)
 {
 #pragma unroll
     for (int s = 0; s < 2 * NP; ++s) {
         const int n = nbase + 16 * s + a;
         const unsigned nc = n < N ? (unsigned)n : 0u;
         tm[s] = ids[nc];
-        cn[s] = vals[nc];                                   // unconditional load, masked by grid_mask_vals
+        cn[s] = vals[nc];                                   // unconditional load, masked below
     }
-}
-template <int NP>
-__device__ __forceinline__ void grid_mask_vals(int (&cn)[2 * NP], const int N, const int nbase, const int a)
-{
 #pragma unroll
     for (int s = 0; s < 2 * NP; ++s) cn[s] = (nbase + 16 * s + a < N) ? cn[s] : 0;
-}
-template <int NP>
-__device__ __forceinline__ void grid_load_ids(int (&tm)[2 * NP], int (&cn)[2 * NP], const int* __restrict__ ids, const int* __restrict__ vals,
-                                              const int N, const int nbase, const int a)
-{
-    grid_load_ids_raw<NP>(tm, cn, ids, vals, N, nbase, a);
-    grid_mask_vals<NP>(cn, N, nbase, a);
 }
 // second wave: the rows
 template <int LPR, int NP>

@@ -514,11 +514,9 @@ __global__ __launch_bounds__(64) void lda_estep_reg_any_kernel(LdaParams p, int6
 // 32 NP w + 16 s + a in its own register tile, the per-wave partial sums (g_i, sum w) meet in LDS once per sweep (one
 // __syncthreads, double-buffered by sweep parity) and every wave then runs the tail redundantly and bit-identically, so the
 // exit test stays uniform across the workgroup.
-// ids_pre / vals_pre (W = 1 only): the lane's token ids and masked counts, loaded by the caller ahead of time (lda_estep_grid_pf_kernel)
 template <int LPR, int NP, int W = 1>
 __device__ __forceinline__ void lda_estep_grid_body(const LdaParams& p, const int d, const int64_t off, const int N,
-                                                    const int* __restrict__ topic_of_lane, const int (*ids_pre)[2 * NP] = nullptr,
-                                                    const int (*vals_pre)[2 * NP] = nullptr)
+                                                    const int* __restrict__ topic_of_lane)
 {
     constexpr int M = LPR + 1;                       // values of the reduce-scatter: LPR topics of the class + sum w
     constexpr int NS = (M + 15) / 16;
@@ -532,14 +530,7 @@ __device__ __forceinline__ void lda_estep_grid_body(const LdaParams& p, const in
     gv2f c[NP];
     {
         const int64_t off0 = N > 0 ? off : 0;               // uniform base + 32-bit lane offsets
-        if (ids_pre) {                                       // prefetched raw: mask the counts of the slots past the document's end now
-            int cnm[2 * NP];
-#pragma unroll
-            for (int s = 0; s < 2 * NP; ++s) cnm[s] = (*vals_pre)[s];
-            grid_mask_vals<NP>(cnm, N, 0, a);
-            grid_load_rows<LPR, NP>(B, c, p.beta, *ids_pre, cnm, b);
-        }
-        else grid_load_tile<LPR, NP>(B, c, p.beta, p.terms + off0, p.counts + off0, N, 32 * NP * wave, a, b);
+        grid_load_tile<LPR, NP>(B, c, p.beta, p.terms + off0, p.counts + off0, N, 32 * NP * wave, a, b);
     }
     // topic role: result slot r of this lane owns topic mytopic[r] (4 j + b for the primary owner of value j; -1 otherwise)
     int mytopic[NS];
@@ -664,52 +655,12 @@ __global__ __launch_bounds__(64) void lda_estep_grid_kernel(LdaParams p, int64_t
 // __launch_bounds__(64, 5) for NP = 2: 96 VGPRs instead of 102, (64, 4) for NP = 3: 128 instead of 134, five spilled dwords, one reload
 // per sweep.  The counters had said the kernels issue a vector instruction only 63 - 81 % of the time when alone; A/B on one box,
 // alternating: 1192 / 1201 it/s against 1270 / 1280 without.  The scratch reload sits in the sweep's dependency chain.)
-// Round 4: D documents per wave with the NEXT document's loads in flight under the current document's sweeps.  A document's wave starts with
-// four dependent memory round trips -- doc_order -> doc_ptr -> ids / counts -> rows -- before its first fma (about 3 us of a 10 - 13 us
-// residency), which only the SIMD's other two or three waves hide.  Here wave w of G takes the documents first + w, first + w + G, ... (D of them:
-// a short, strided chain, so that the launch still balances itself as waves finish) as a two-stage pipeline: at the top of document j the
-// scalars (d, off, N) of document j + 2 and the ids / counts of document j + 1 are requested, and document j's own rows -- its ids arrived
-// during document j - 1 -- are one round trip away.
-template <int LPR, int NP, int D>
-__global__ __launch_bounds__(64) void lda_estep_grid_pf_kernel(LdaParams p, int64_t first, int64_t count, const int* __restrict__ topic_of_lane)
-{
-    const int lane = threadIdx.x & 63, a = lane >> 2;
-    const int64_t G = gridDim.x;
-    const int64_t i0 = blockIdx.x;
-    if (i0 >= count) return;
-    const int64_t left = (count - i0 + G - 1) / G;
-    const int nd = left < D ? (int)left : D;                    // this wave's documents: i0, i0 + G, ...
-    // three stages, one memory round trip each, all requested at the top of a trip and none consumed before the end of it:
-    //   stage 1  d      = doc_order[.]          of the document three trips ahead
-    //   stage 2  off, N = doc_ptr[d], [d + 1]   of the document two trips ahead (its d arrived last trip)
-    //   stage 3  ids / counts                   of the next document (its off, N arrived last trip)
-    // (past the wave's last document the stages re-request that document: no branches, nothing out of range; the values
-    // stay in vector registers until the trip's end -- the asm below -- or the compiler would wait for each at once to
-    // move it to a scalar register)
-    auto order_at = [&](int j) -> int { const int jj = j < nd ? j : nd - 1; return p.doc_order[first + i0 + (int64_t)jj * G]; };
-    int dA = order_at(0), dB = order_at(1), dC = order_at(2);
-    int64_t offA = p.doc_ptr[dA]; int NA = (int)(p.doc_ptr[dA + 1] - offA);
-    int64_t offB = p.doc_ptr[dB]; int NB = (int)(p.doc_ptr[dB + 1] - offB);
-    int tmA[2 * NP], cnA[2 * NP];
-    { const int64_t o = NA > 0 ? offA : 0; grid_load_ids_raw<NP>(tmA, cnA, p.terms + o, p.counts + o, NA, 0, a); }
-#pragma unroll 1
-    for (int j = 0; j < nd; ++j) {
-        int dD = order_at(j + 3);
-        int64_t lo = p.doc_ptr[dC], hi = p.doc_ptr[dC + 1];
-        int tmB[2 * NP], cnB[2 * NP];
-        { const int64_t o = NB > 0 ? offB : 0; grid_load_ids_raw<NP>(tmB, cnB, p.terms + o, p.counts + o, NB, 0, a); }
-        lda_estep_grid_body<LPR, NP>(p, dA, offA, NA, topic_of_lane, &tmA, &cnA);
-        WAVE_LDS_FENCE();                                       // the next document reuses the wave's LDS rows
-        asm volatile("" : "+v"(dD), "+v"(lo), "+v"(hi));
-        dA = dB; offA = offB; NA = NB;
-        dB = dC;
-        offB = ((int64_t)__builtin_amdgcn_readfirstlane((int)(lo >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
-        NB = __builtin_amdgcn_readfirstlane((int)(hi - lo));
-        dC = __builtin_amdgcn_readfirstlane(dD);
-#pragma unroll
-        for (int s = 0; s < 2 * NP; ++s) { tmA[s] = tmB[s]; cnA[s] = cnB[s]; }
-    }
-}
+// (Round 4, measured and dropped too: D = 4 documents per wave with the NEXT document's loads in flight under the current one's sweeps -- a
+// three-stage pipeline, doc_order three trips ahead, doc_ptr two, the ids and counts one, all held in vector registers until the trip's end so
+// that the compiler does not wait for each to move it to a scalar register.  The twelve extra registers cost NP = 4 and 6 a wave per SIMD
+// (210 / 280 VGPRs): E-step 0.856 ms against 0.751; restricted to NP <= 3 (168 VGPRs, occupancy unchanged) 0.763 / 0.769 against 0.750 / 0.751;
+// NP = 2 alone 0.750.  Three or four resident waves per SIMD already cover the load chain of a starting document; a quarter as many waves, each
+// four times as long, only lengthen the launch's tail.  A/B on one box, alternating, run r4x.)
 
 // long documents: one workgroup of W waves per document (lda_estep_grid_body, W > 1)
 template <int LPR, int NP, int W>
@@ -1039,12 +990,6 @@ __global__ __launch_bounds__(64) void lda_estep_grid_any_kernel(LdaParams p, int
 // gained CTPF 7 % (tmvb_ctpf.hip) -- LOSES here: 16 100 documents 0.185 ms per iteration against 0.173, 32 200 documents 0.277 against 0.271
 // (A/B on one box, alternating).  LDA's sweeps keep a SIMD busier than CTPF's one- or two-sweep documents do, and the second launch costs a
 // cross-stream join in a 0.17 ms iteration.)
-static inline int lda_grid_pf_docs()
-{
-    const char* e = getenv("TMVB_LDA_PF");
-    return e ? atoi(e) : 0;
-}
-
 template <int LPR>
 static void lda_launch_grid(int np, dim3 grid, dim3 block, hipStream_t st, const LdaParams& p, int64_t first, const int* tol)
 {
@@ -1054,16 +999,6 @@ static void lda_launch_grid(int np, dim3 grid, dim3 block, hipStream_t st, const
     if (np == TMVB_GRID_ANY_NP) hipLaunchKernelGGL((lda_estep_grid_any_kernel<LPR>), grid, block, 0, st, p, first, tol);
     else if (np == TMVB_GRID_TT_NP) {
         if constexpr (LPR <= 15) hipLaunchKernelGGL((lda_estep_tt_kernel<LPR>), grid, block, 0, st, p, first);
-    }
-    else if (lda_grid_pf_docs() > 1 && LPR == 13) {
-        // D documents per wave, the next document's loads under the current one's sweeps (lda_estep_grid_pf_kernel; TMVB_LDA_PF=<D>, 0 / 1 = off)
-        constexpr int D = 4;
-        const int64_t count = grid.x;
-        const dim3 g2((unsigned)((count + D - 1) / D));
-        if (np <= 2) hipLaunchKernelGGL((lda_estep_grid_pf_kernel<LPR, 2, D>), g2, block, 0, st, p, first, count, tol);
-        else if (np == 3) hipLaunchKernelGGL((lda_estep_grid_pf_kernel<LPR, 3, D>), g2, block, 0, st, p, first, count, tol);
-        else if (np == 4) hipLaunchKernelGGL((lda_estep_grid_pf_kernel<LPR, (NPM >= 4 ? 4 : 3), D>), g2, block, 0, st, p, first, count, tol);
-        else hipLaunchKernelGGL((lda_estep_grid_pf_kernel<LPR, (NPM >= 6 ? 6 : NPM), D>), g2, block, 0, st, p, first, count, tol);
     }
     else if (np <= 2) hipLaunchKernelGGL((lda_estep_grid_kernel<LPR, 2>), grid, block, 0, st, p, first, tol);
     else if (np == 3) hipLaunchKernelGGL((lda_estep_grid_kernel<LPR, 3>), grid, block, 0, st, p, first, tol);
