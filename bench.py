@@ -212,6 +212,9 @@ def main():
     ap.add_argument("--K", type=int, default=50)
     ap.add_argument("--docs", type=int, default=128804)
     ap.add_argument("--vocab", type=int, default=25319)
+    ap.add_argument("--ar-slices", type=int, default=None,
+                    help="N > 1, in-library communicator: vocabulary slabs the statistics all-reduce is issued in under the last statistics "
+                         "pass (tmvb_lda_estep_allreduce; default: the library's, 4; 1 = one collective after the E-step, round 3's form)")
     ap.add_argument("--collective", choices=["lib", "torch"], default="lib",
                     help="lib: RCCL inside libtmvb_hip.so (tmvb_comm_allreduce); torch: torch.distributed all_reduce on the bound buffer")
     ap.add_argument("--plateau-cap", type=int, default=4000)
@@ -222,6 +225,8 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the lines of BASELINE.json's configs 3-5 (LDA K=100, CTM K=50, CTPF K=50) carried under other_configs at N=1")
     args = ap.parse_args()
+    if args.ar_slices is not None:
+        os.environ["TMVB_AR_SLICES"] = str(args.ar_slices)       # read by the library when the first plan is agreed on
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -296,10 +301,11 @@ def main():
                     comm.close()
                 comm, use_lib = None, False
         if use_lib:
-            collective = f"RCCL {tm.rccl_version()} inside libtmvb_hip.so (tmvb_comm_allreduce on the context stream)"
+            collective = (f"RCCL {tm.rccl_version()} inside libtmvb_hip.so (tmvb_lda_estep_allreduce: the statistics all-reduce in "
+                          f"{os.environ.get('TMVB_AR_SLICES', '4')} vocabulary slabs on a side stream under the last statistics pass)")
             eng.model.set_comm(comm, corpus.M)
-            ptr, n = eng.model.stats()
-            return (lambda: comm.allreduce(ptr, n)), comm
+            eng.fused_allreduce = True
+            return (lambda: None), comm
         if one_gpu_debug:
             collective = "host transport + gloo (one-GPU plumbing check, not a measurement)"
             import numpy as _np
@@ -308,8 +314,8 @@ def main():
                 t = torch.from_numpy(a); dist.all_reduce(t, op=dist.ReduceOp.SUM)
             comm = tm.Communicator.host(eng.ctx, world, rank, gsum)
             eng.model.set_comm(comm, corpus.M)
-            ptr, n = eng.model.stats()
-            return (lambda: comm.allreduce(ptr, n)), comm
+            eng.fused_allreduce = True                           # the same call sequence as the RCCL run
+            return (lambda: None), comm
         collective = "torch.distributed all_reduce (nccl = RCCL) on the bound statistics buffer"
         if "nccl" not in comm_holder:
             comm_holder["nccl"] = dist.new_group(backend="nccl")
@@ -317,8 +323,14 @@ def main():
         return tr.allreduce_stats, None
 
     def run_window(eng, allreduce, burnin, warmup, steps):
+        fused = getattr(eng, "fused_allreduce", False)
+
         def one():
-            eng.estep(viter, vtol); eng.reduce_docs(); allreduce(); eng.update_beta(); eng.update_alpha(niter, ntol)
+            if fused:
+                eng.model.estep_allreduce(viter, vtol)
+            else:
+                eng.estep(viter, vtol); eng.reduce_docs(); allreduce()
+            eng.update_beta(); eng.update_alpha(niter, ntol)
         for _ in range(burnin + warmup):
             one()
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
@@ -326,10 +338,14 @@ def main():
         t_start = time.perf_counter()
         for s in range(steps):
             ev[s][0].record(eng.stream)           # HIP events on the stream the kernels are launched on
-            eng.estep(viter, vtol)
-            ev[s][1].record(eng.stream)
-            eng.reduce_docs()
-            allreduce()
+            if fused:                             # N > 1: the bracket then holds the E-step AND its (overlapped) collective
+                eng.model.estep_allreduce(viter, vtol)
+                ev[s][1].record(eng.stream)
+            else:
+                eng.estep(viter, vtol)
+                ev[s][1].record(eng.stream)
+                eng.reduce_docs()
+                allreduce()
             eng.update_beta()
             eng.update_alpha(niter, ntol)
         barrier()
@@ -436,13 +452,16 @@ def main():
                        "K": K, "M": corpus.M, "V": V, "nnz": corpus.nnz, "sum_counts": int(corpus.counts.sum()), "burnin": args.burnin,
                        "clock_warmup": {"seconds": args.clock_warmup, "its_per_chunk_of_50": clock_log,
                                         "what": "untimed iterations of a scratch model on the same shard before the measured model is built (device clocks, first touches); not state preparation"},
-                       "parallelism": f"doc-shard x{world}, 1 all-reduce of {K * V + K} f32 per iteration" if world > 1 else "single GPU",
+                       "parallelism": f"doc-shard x{world}, all-reduce of {K * V + K} f32 per iteration" if world > 1 else "single GPU",
                        "collective": collective,
                        "sweep_hist_last_step": sweep_hist},
             "roofline": {"bound": "hbm", "kernel": "LDA E-step = the per-document grid-tile sweep kernels (lda_estep_grid_kernel<LPR, NP>, lda_estep_grid_long_kernel; lda_estep_reg_long_kernel / lda_estep_kernel for documents of more than 768 unique terms) over the document pieces + the gather-side statistics passes (termstats_recompute_kernel, termstats_multi_kernel) of every piece; one 'launch' = one E-step, timed start-to-end with HIP events on the context stream",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel_source_hash": kernel_source_hash(),
                          "algorithmic_bytes_per_estep": b_e, "estep_ms": ms,
+                         "estep_ms_includes": ("the statistics all-reduce, overlapped slab by slab with the last statistics pass (tmvb_lda_estep_allreduce is one "
+                                               "asynchronous call: the events bracket E-step + collective, so frac understates the E-step alone at N > 1)")
+                                              if getattr(eng, "fused_allreduce", False) else "the E-step only",
                          "estep_ms_min": float(np.min(estep_ms)), "estep_ms_max": float(np.max(estep_ms)),
                          "estep_ms_median": float(np.median(estep_ms)), "estep_ms_steps": [round(float(x), 4) for x in estep_ms],
                          "frac_at_median": b_e / (float(np.median(estep_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -208,6 +208,17 @@ int tmvb_lda_train(tmvb_lda* h, int32_t iter, double tol, int32_t niter, double 
 /* Attach (comm != NULL) or detach a communicator: the handle's corpus is this rank's document shard of a corpus of
  * M_total documents.  Implies tmvb_lda_set_distributed.  The communicator is not owned by the handle. */
 int tmvb_lda_set_comm(tmvb_lda* h, tmvb_comm* comm, int64_t M_total);
+
+/* One rank's E-step, per-document sums and the sum-all-reduce of the packed statistics over the handle's communicator, in one
+ * asynchronous call (the sharded train! uses it when the process drives one handle; a host that composes the iteration itself calls
+ * it INSTEAD of tmvb_lda_estep + tmvb_lda_reduce_docs + tmvb_comm_allreduce, then tmvb_lda_update_beta / _alpha as before).  The
+ * last statistics pass is issued in TMVB_AR_SLICES (default 4; 1 = one collective) vocabulary slices and the slab of S a slice
+ * completes is all-reduced on a side stream while the next slice's pass runs: the collective of src/gpuLDA.jl's multi-device
+ * precedent (v0.6/src/gpuLDA.jl:200-225: host gathers every device's buffer after the E-step) overlapped with the pass that feeds it.
+ * The first call on a communicator is collective beyond that: the ranks sum their postings per term (V doubles) to agree on the
+ * cuts.  Every rank must call it the same number of times; results equal the three-call form's up to the fp32 summation order of
+ * the collective.  TMVB_EINVAL without a communicator. */
+int tmvb_lda_estep_allreduce(tmvb_lda* h, int32_t viter, double vtol);
 /* One host thread, n GPUs: hs[i] carries the i-th communicator of tmvb_comm_create_rccl_all (n = 1: same as
  * tmvb_lda_train).  The n all-reduces of an iteration are issued as one RCCL group. */
 int tmvb_lda_train_group(tmvb_lda* const* hs, int32_t n, int32_t iter, double tol, int32_t niter, double ntol,

@@ -35,7 +35,7 @@ def test_torchrun_two_ranks_on_one_gpu():
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["steps"] == 4 and r["scaling"] == "strong" and r["value"] > 0
     assert "host transport" in r["config"]["collective"]
-    assert r["config"]["parallelism"].startswith("doc-shard x2")
+    assert r["config"]["parallelism"].startswith("doc-shard x2") and "all-reduce" in r["roofline"]["estep_ms_includes"]
     chk = r["multi_gpu_check"]
     assert chk["globals_hash_equal"] and len(set(chk["globals_hash_per_rank"])) == 1, chk
     assert chk["iterations"] == 5 and chk["elbo_rel_vs_n1"] <= chk["elbo_rel_tolerance"], chk

@@ -15,6 +15,9 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "libtmvb_hip.so")
+# experiments only (tools/build_variant.sh): TMVB_LIB_VARIANT=<name> loads libtmvb_hip_<name>.so, the same sources built with extra -D
+# flags, so that a compile-time variant can be timed against the shipped library inside ONE gpurun call (boxes differ by up to 8 %)
+_VARIANT = os.environ.get("TMVB_LIB_VARIANT", "")
 SOURCES = ["tmvb_core.hip", "tmvb_comm.hip", "tmvb_lda.hip", "tmvb_flda.hip", "tmvb_ctm.hip", "tmvb_ctpf.hip", "tmvb_ctpf_recs.hip"]
 
 OK, EINVAL, ESHAPE, ECORPUS, ENOMEM, EHIP, ENONFINITE, ENODEVICE, ERCCL = range(9)
@@ -136,7 +139,12 @@ def lib():
                               "The HIP engine has no CPU fallback.")
         # eight hardware queues for the process's HIP streams (tmvb_core.hip: tmvb_env_defaults); only effective before HIP initialises
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-        L = C.CDLL(LIB_PATH)
+        path = LIB_PATH
+        if _VARIANT:
+            path = os.path.join(_HERE, f"libtmvb_hip_{_VARIANT}.so")
+            if not os.path.exists(path):
+                raise EngineError(f"TMVB_LIB_VARIANT={_VARIANT}: {path} is missing (tools/build_variant.sh)")
+        L = C.CDLL(path)
         L.tmvb_last_error.restype = C.c_char_p
         L.tmvb_abi_version.restype = C.c_int
         L.tmvb_device_count.restype = C.c_int

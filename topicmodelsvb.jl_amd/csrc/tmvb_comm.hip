@@ -204,15 +204,16 @@ extern "C" int tmvb_comm_info(const tmvb_comm* c, int32_t* nranks, int32_t* rank
     return TMVB_OK;
 }
 
-static int comm_allreduce_one(tmvb_comm* c, void* dev_ptr, int64_t count, int32_t dtype)
+static int comm_allreduce_one(tmvb_comm* c, void* dev_ptr, int64_t count, int32_t dtype, hipStream_t on = nullptr)
 {
     TMVB_REQUIRE(c && dev_ptr, TMVB_EINVAL, "tmvb_comm_allreduce: NULL argument");
     TMVB_REQUIRE(count >= 0 && (dtype == TMVB_F32 || dtype == TMVB_F64), TMVB_EINVAL, "tmvb_comm_allreduce: bad count or dtype");
     if (count == 0) return TMVB_OK;
     tmvb_ctx* ctx = c->ctx;
     TMVB_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = on ? on : ctx->stream;
     if (c->backend == 0) {
-        TMVB_NCCL(AllReduce(dev_ptr, dev_ptr, (size_t)count, dtype == TMVB_F32 ? ncclFloat32 : ncclFloat64, ncclSum, c->nccl, ctx->stream));
+        TMVB_NCCL(AllReduce(dev_ptr, dev_ptr, (size_t)count, dtype == TMVB_F32 ? ncclFloat32 : ncclFloat64, ncclSum, c->nccl, st));
         return TMVB_OK;
     }
     const size_t bytes = (size_t)count * (dtype == TMVB_F32 ? 4 : 8);
@@ -223,18 +224,25 @@ static int comm_allreduce_one(tmvb_comm* c, void* dev_ptr, int64_t count, int32_
         if (e != hipSuccess) { tmvb_set_error("hipHostMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e)); return TMVB_ENOMEM; }
         c->pinned_bytes = bytes;
     }
-    TMVB_HIP(hipMemcpyAsync(c->pinned, dev_ptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    TMVB_HIP(hipStreamSynchronize(ctx->stream));
+    TMVB_HIP(hipMemcpyAsync(c->pinned, dev_ptr, bytes, hipMemcpyDeviceToHost, st));
+    TMVB_HIP(hipStreamSynchronize(st));
     const int rc = c->fn(c->user, c->pinned, count, dtype);
     TMVB_REQUIRE(rc == 0, TMVB_ERCCL, "tmvb_comm_allreduce: the host all-reduce callback returned %d", rc);
-    TMVB_HIP(hipMemcpyAsync(dev_ptr, c->pinned, bytes, hipMemcpyHostToDevice, ctx->stream));
-    TMVB_HIP(hipStreamSynchronize(ctx->stream));     // the staging buffer is reused by the next call
+    TMVB_HIP(hipMemcpyAsync(dev_ptr, c->pinned, bytes, hipMemcpyHostToDevice, st));
+    TMVB_HIP(hipStreamSynchronize(st));              // the staging buffer is reused by the next call
     return TMVB_OK;
 }
 
 extern "C" int tmvb_comm_allreduce(tmvb_comm* c, void* dev_ptr, int64_t count, int32_t dtype)
 {
     return comm_allreduce_one(c, dev_ptr, count, dtype);
+}
+
+// the same collective on a stream of the caller's (the context's device): the vocabulary slabs of tmvb_lda_estep_allreduce go through
+// a side stream while the statistics pass still runs on the context's
+int tmvb_comm_allreduce_on(tmvb_comm* c, void* dev_ptr, int64_t count, int32_t dtype, hipStream_t on)
+{
+    return comm_allreduce_one(c, dev_ptr, count, dtype, on);
 }
 
 // n collectives issued by ONE host thread (ncclCommInitAll communicators): they must sit inside one RCCL group,

@@ -415,17 +415,26 @@ static inline int tmvb_colsum2(tmvb_ctx* ctx, int K, tmvb_colsum_job j0, tmvb_co
 // true when the statistics pass recomputes the per-token weights (no wtok stores needed in the document kernels)
 static inline bool tmvb_termstats_recomputes(int KP, bool e_padded) { return e_padded && KP / 4 <= 32; }
 
+// slice >= 0: only the ids of vocabulary slice `slice` of an index built with id cuts (tmvb_inv_index::slice_*)
 static inline int tmvb_launch_termstats(tmvb_ctx* ctx, int nslot, int KP, bool e_padded, const tmvb_inv_index& ix,
-                                        TermStatsParams tp, hipStream_t on_stream = nullptr)
+                                        TermStatsParams tp, hipStream_t on_stream = nullptr, int slice = -1)
 {
     if (ix.n_chunks <= 0) return TMVB_OK;
     hipStream_t st = on_stream ? on_stream : ctx->stream;
-    tp.tok_doc = ix.d_doc; tp.tok_pos = ix.d_pos; tp.chunk_id = ix.d_chunk_id; tp.chunk_begin = ix.d_chunk_begin;
-    tp.chunk_end = ix.d_chunk_end; tp.chunk_out = ix.d_chunk_out; tp.n_chunks = (int)ix.n_chunks;
+    int64_t c0 = 0, c1 = ix.n_chunks, m0 = 0, m1 = ix.n_multi;
+    if (slice >= 0) {
+        TMVB_REQUIRE((size_t)slice + 1 < ix.slice_chunk.size(), TMVB_EINVAL, "statistics pass: the index has no vocabulary slice %d", slice);
+        c0 = ix.slice_chunk[(size_t)slice]; c1 = ix.slice_chunk[(size_t)slice + 1];
+        m0 = ix.slice_multi[(size_t)slice]; m1 = ix.slice_multi[(size_t)slice + 1];
+        if (c1 <= c0) return TMVB_OK;
+    }
+    const int64_t n_chunks = c1 - c0, n_multi = m1 - m0;
+    tp.tok_doc = ix.d_doc; tp.tok_pos = ix.d_pos; tp.chunk_id = ix.d_chunk_id + c0; tp.chunk_begin = ix.d_chunk_begin + c0;
+    tp.chunk_end = ix.d_chunk_end + c0; tp.chunk_out = ix.d_chunk_out + c0; tp.n_chunks = (int)n_chunks;
     tp.tok_val = ix.d_val;
     int rc = dispatch_nslot(nslot, [&](auto ns) -> int {
         constexpr int NS = decltype(ns)::value;
-        const dim3 grid((unsigned)((ix.n_chunks + 3) / 4)), block(256);
+        const dim3 grid((unsigned)((n_chunks + 3) / 4)), block(256);
         const int lpr = KP / 4;
         if (e_padded && lpr <= 32) {       // recompute w from (T row, E row, count): no per-token weights in memory
             // PAD form: rows zero-padded to 4 * LANES floats, 32-bit byte offsets into E, 24-bit document ids (tmvb_termstats.h)
@@ -445,9 +454,9 @@ static inline int tmvb_launch_termstats(tmvb_ctx* ctx, int nslot, int KP, bool e
         } else {
             hipLaunchKernelGGL((termstats_chunk_kernel<NS>), grid, block, 0, st, tp);
         }
-        if (ix.n_multi > 0)
-            hipLaunchKernelGGL((termstats_multi_kernel<NS>), dim3((unsigned)ix.n_multi), dim3(256), 0, st, tp,
-                               ix.d_multi_id, ix.d_multi_first, ix.d_multi_count, (int)ix.n_multi);
+        if (n_multi > 0)
+            hipLaunchKernelGGL((termstats_multi_kernel<NS>), dim3((unsigned)n_multi), dim3(256), 0, st, tp,
+                               ix.d_multi_id + m0, ix.d_multi_first + m0, ix.d_multi_count + m0, (int)n_multi);
         return TMVB_OK;
     });
     if (rc) return rc;

@@ -274,7 +274,7 @@ extern "C" int tmvb_corpus_create(tmvb_ctx* ctx, int64_t M, int64_t V, int64_t U
 }
 
 int tmvb_build_inv_index(tmvb_ctx* ctx, int64_t M, int64_t n_ids, const int64_t* h_ptr, const int32_t* h_ids,
-                         const int32_t* h_vals, tmvb_inv_index* ix, const int32_t* doc_piece, int piece)
+                         const int32_t* h_vals, tmvb_inv_index* ix, const int32_t* doc_piece, int piece, const std::vector<int64_t>* id_cuts)
 {
     const int64_t nnz_all = h_ptr[M];
     TMVB_REQUIRE(nnz_all < (int64_t)INT32_MAX, TMVB_EINVAL, "inverted index: token count must fit int32");
@@ -317,56 +317,71 @@ int tmvb_build_inv_index(tmvb_ctx* ctx, int64_t M, int64_t n_ids, const int64_t*
     int NC = 8 * (int)((ndocs + 8 * class_docs - 1) / (8 * class_docs));
     if (class_env >= 0) NC = 8 * ((class_env + 7) / 8);               // classes are emitted in rounds of 8 (one per XCD): round up
     if (ndocs < 4 * class_docs && class_env < 0) NC = 0;               // everything fits a couple of L2s anyway
-    std::vector<std::vector<Chunk>> cls((size_t)std::max(NC, 1));
-    std::vector<Chunk> rare;
+    // id_cuts: the same order built slice by slice of the id range, so that a slice is a contiguous run of chunks (and of multi-chunk ids)
+    std::vector<int64_t> cuts;
+    if (id_cuts) {
+        cuts = *id_cuts;
+        TMVB_REQUIRE(cuts.size() >= 2 && cuts.front() == 0 && cuts.back() == n_ids, TMVB_EINVAL, "inverted index: id cuts must run from 0 to the id count");
+        for (size_t s = 0; s + 1 < cuts.size(); ++s) TMVB_REQUIRE(cuts[s] <= cuts[s + 1], TMVB_EINVAL, "inverted index: id cuts must ascend");
+    } else {
+        cuts = {0, n_ids};
+    }
     auto doc_class = [&](int64_t d) { return (int)(d * NC / M); };
-    for (int64_t j = 0; j < n_ids; ++j) {
-        const int64_t a = cnt[j], b = cnt[j + 1];
-        if (b == a) continue;
-        // segments: the id's postings cut at class boundaries (one segment if the id is rare or classes are off)
-        std::vector<std::pair<int64_t, int>> seg;                             // (begin, class)
-        if (NC > 0 && b - a >= class_min) {
-            int prev = -1;
-            for (int64_t q = a; q < b; ++q) {
-                const int c = doc_class(doc[q]);
-                if (c != prev) { seg.emplace_back(q, c); prev = c; }
-            }
-        } else {
-            seg.emplace_back(a, -1);
-        }
-        int64_t nch = 0;
-        for (size_t g = 0; g < seg.size(); ++g) {
-            const int64_t sa = seg[g].first, sb = g + 1 < seg.size() ? seg[g + 1].first : b;
-            nch += (sb - sa + TMVB_CHUNK - 1) / TMVB_CHUNK;
-        }
-        if (nch > 1) { mid.push_back((int32_t)j); mfirst.push_back((int32_t)slots); mcount.push_back((int32_t)nch); }
-        for (size_t g = 0; g < seg.size(); ++g) {
-            const int64_t sa = seg[g].first, sb = g + 1 < seg.size() ? seg[g + 1].first : b;
-            for (int64_t q = sa; q < sb; q += TMVB_CHUNK) {
-                const Chunk ch{(int32_t)j, (int32_t)q, (int32_t)std::min<int64_t>(sb, q + TMVB_CHUNK), nch > 1 ? (int32_t)(slots++) : -1};
-                if (seg[g].second >= 0) cls[(size_t)seg[g].second].push_back(ch); else rare.push_back(ch);
-            }
-        }
-    }
-    size_t total_chunks = rare.size();
-    for (const auto& L : cls) total_chunks += L.size();
     std::vector<Chunk> order;
-    order.reserve(rare.size() + 64);
-    size_t rare_used = 0;
-    if (NC > 0) {
-        for (auto& L : cls)                                                   // whole workgroups per class: top up with rare chunks
-            while (L.size() % 4 != 0 && rare_used < rare.size()) L.push_back(rare[rare_used++]);
-        for (int r = 0; r < NC / 8; ++r) {
-            size_t maxb = 0;
-            for (int x = 0; x < 8; ++x) maxb = std::max(maxb, (cls[(size_t)(8 * r + x)].size() + 3) / 4);
-            for (size_t k = 0; k < maxb; ++k)
-                for (int x = 0; x < 8; ++x) {
-                    const auto& L = cls[(size_t)(8 * r + x)];
-                    for (size_t u = 4 * k; u < std::min(L.size(), 4 * k + 4); ++u) order.push_back(L[u]);
+    size_t total_chunks = 0;
+    std::vector<int64_t> slice_chunk{0}, slice_multi{0};
+    for (size_t sl = 0; sl + 1 < cuts.size(); ++sl) {
+        std::vector<std::vector<Chunk>> cls((size_t)std::max(NC, 1));
+        std::vector<Chunk> rare;
+        for (int64_t j = cuts[sl]; j < cuts[sl + 1]; ++j) {
+            const int64_t a = cnt[j], b = cnt[j + 1];
+            if (b == a) continue;
+            // segments: the id's postings cut at class boundaries (one segment if the id is rare or classes are off)
+            std::vector<std::pair<int64_t, int>> seg;                             // (begin, class)
+            if (NC > 0 && b - a >= class_min) {
+                int prev = -1;
+                for (int64_t q = a; q < b; ++q) {
+                    const int c = doc_class(doc[q]);
+                    if (c != prev) { seg.emplace_back(q, c); prev = c; }
                 }
+            } else {
+                seg.emplace_back(a, -1);
+            }
+            int64_t nch = 0;
+            for (size_t g = 0; g < seg.size(); ++g) {
+                const int64_t sa = seg[g].first, sb = g + 1 < seg.size() ? seg[g + 1].first : b;
+                nch += (sb - sa + TMVB_CHUNK - 1) / TMVB_CHUNK;
+            }
+            if (nch > 1) { mid.push_back((int32_t)j); mfirst.push_back((int32_t)slots); mcount.push_back((int32_t)nch); }
+            for (size_t g = 0; g < seg.size(); ++g) {
+                const int64_t sa = seg[g].first, sb = g + 1 < seg.size() ? seg[g + 1].first : b;
+                for (int64_t q = sa; q < sb; q += TMVB_CHUNK) {
+                    const Chunk ch{(int32_t)j, (int32_t)q, (int32_t)std::min<int64_t>(sb, q + TMVB_CHUNK), nch > 1 ? (int32_t)(slots++) : -1};
+                    if (seg[g].second >= 0) cls[(size_t)seg[g].second].push_back(ch); else rare.push_back(ch);
+                }
+            }
         }
+        total_chunks += rare.size();
+        for (const auto& L : cls) total_chunks += L.size();
+        size_t rare_used = 0;
+        if (NC > 0) {
+            for (auto& L : cls)                                                   // whole workgroups per class: top up with rare chunks
+                while (L.size() % 4 != 0 && rare_used < rare.size()) L.push_back(rare[rare_used++]);
+            for (int r = 0; r < NC / 8; ++r) {
+                size_t maxb = 0;
+                for (int x = 0; x < 8; ++x) maxb = std::max(maxb, (cls[(size_t)(8 * r + x)].size() + 3) / 4);
+                for (size_t k = 0; k < maxb; ++k)
+                    for (int x = 0; x < 8; ++x) {
+                        const auto& L = cls[(size_t)(8 * r + x)];
+                        for (size_t u = 4 * k; u < std::min(L.size(), 4 * k + 4); ++u) order.push_back(L[u]);
+                    }
+            }
+        }
+        for (; rare_used < rare.size(); ++rare_used) order.push_back(rare[rare_used]);
+        slice_chunk.push_back((int64_t)order.size()); slice_multi.push_back((int64_t)mid.size());
     }
-    for (; rare_used < rare.size(); ++rare_used) order.push_back(rare[rare_used]);
+    if (id_cuts) { ix->slice_id = cuts; ix->slice_chunk = slice_chunk; ix->slice_multi = slice_multi; }
+    else { ix->slice_id.clear(); ix->slice_chunk.clear(); ix->slice_multi.clear(); }
     // every chunk holds postings (and multi-chunk ids a partial-sum slot): one left out of the launch order would drop them silently
     TMVB_REQUIRE(order.size() == total_chunks, TMVB_EINVAL, "statistics chunk order holds %zu of %zu chunks (NC = %d)", order.size(), total_chunks, NC);
     std::vector<int32_t> cid(order.size()), cb(order.size()), ce(order.size()), co(order.size());

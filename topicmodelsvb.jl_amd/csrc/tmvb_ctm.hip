@@ -1346,6 +1346,7 @@ struct tmvb_ctm {
     bool generic = false;              // K > 60: ctm_estep_generic_kernel
     bool generic_cg = false;           // ... in its conjugate-gradient form (d_cg_iters then carries its trip counts)
     float* d_beta[2] = {nullptr, nullptr};
+    float* d_beta_pad = nullptr;       // TMVB_CTM_ROWPAD: [V][64] copy of beta (KP = 52) for the lane-per-document kernel's row gather
     int cur = 0;
     float* d_stats = nullptr;          // S (K*V) | sum_lambda (K) | sum_vsq (K) | scatter (K*K)
     bool own_stats = true;
@@ -1394,7 +1395,7 @@ extern "C" int tmvb_ctm_destroy(tmvb_ctm* h)
 {
     if (!h) return TMVB_OK;
     if (h->ctx) (void)hipSetDevice(h->ctx->device);
-    (void)hipFree(h->d_beta[0]); (void)hipFree(h->d_beta[1]);
+    (void)hipFree(h->d_beta[0]); (void)hipFree(h->d_beta[1]); (void)hipFree(h->d_beta_pad);
     if (h->own_stats) (void)hipFree(h->d_stats);
     (void)hipFree(h->d_lambda); (void)hipFree(h->d_lambda_old); (void)hipFree(h->d_vsq); (void)hipFree(h->d_logzeta);
     (void)hipFree(h->d_sigma_work); (void)hipFree(h->d_sigma_work_s);
@@ -1694,6 +1695,15 @@ static int ctm_launch_generic(tmvb_ctm* h, CtmParams p, double ntol)
     return TMVB_OK;
 }
 
+// TMVB_CTM_ROWPAD: rows of 52 floats (208 B) straddle two or three 128-byte lines, rows at a 256-byte stride exactly two
+__global__ __launch_bounds__(256) void ctm_rowpad_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int64_t V)
+{
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;            // one 16-byte chunk of the padded table
+    if (q >= V * 16) return;
+    const int64_t v = q >> 4; const int c = (int)(q & 15);
+    dst[q] = c < 13 ? src[v * 13 + c] : float4{0.f, 0.f, 0.f, 0.f};
+}
+
 // launch of the lane-per-document kernel (tmvb_ctm_batch.h) for CTM (FILT = false) and fCTM (FILT = true)
 template <bool FILT>
 static int ctm_launch_batch(tmvb_ctm* h, const CtmParams& p, double ntol)
@@ -1725,6 +1735,12 @@ static int ctm_launch_batch(tmvb_ctm* h, const CtmParams& p, double ntol)
     h->keys_valid = true;
     CtmBatchArgs ba;
     ba.p = p; ba.p.doc_order = (h->queue_sorted && !FILT) ? h->d_doc_order_q : p.doc_order + h->n_long; ba.p.doc_newton = h->d_doc_newton; ba.tb = tb; ba.M = Mb;
+    if (cb_rowb<52, FILT>::value == 256u && h->KP == 52) {
+        if (!h->d_beta_pad) { int prc = dmalloc(&h->d_beta_pad, (size_t)h->V * 64); if (prc) return prc; }
+        hipLaunchKernelGGL(ctm_rowpad_kernel, dim3((unsigned)((h->V * 16 + 255) / 256)), dim3(256), 0, ctx->stream, (const float4*)p.beta, (float4*)h->d_beta_pad, h->V);
+        TMVB_HIP(hipGetLastError());
+        ba.p.beta = h->d_beta_pad;
+    }
     h->queue_sorted = false;
     static const bool prof = [] { const char* e = getenv("TMVB_CTM_PROF"); return e && atoi(e) != 0; }();
     // TMVB_CTM_WAVE_LOG=<file> (with TMVB_CTM_PROF=1): per-item start / end / placement of this launch, written after a synchronisation (diagnostics only)

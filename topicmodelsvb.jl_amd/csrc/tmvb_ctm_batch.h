@@ -359,7 +359,18 @@ __device__ __forceinline__ int cb_karg32()
 
 // One token step of the cooperative row gather (see the token phase of the kernel): every lane publishes the row id of its own
 // document, reads back the ids of the LPR rows it fetches chunks of, and issues its LPR 16-byte loads.
-template <int R>
+// ROWB: bytes between rows of the gathered table: R * 4, or 256 for the copy of a 52-float table that ctm_launch_batch makes per
+// E-step (ctm_rowpad_kernel, 4 us) -- a 208-byte row at a 208-byte stride straddles two or three 128-byte lines (2.5 on average),
+// at a 256-byte stride exactly two.  A/B in one process tree (tools/ctm_ab.py, three alternating rounds): 205.6 / 205.8 / 202.9 it/s
+// without, 208.8 / 208.1 / 203.8 with (+1 %).  -DTMVB_CTM_ROWPAD=0 builds the unpadded gather.
+#ifndef TMVB_CTM_ROWPAD
+#define TMVB_CTM_ROWPAD 1
+#endif
+#ifndef TMVB_CTM_VSQ32
+#define TMVB_CTM_VSQ32 0
+#endif
+template <int R, bool FILT> struct cb_rowb { static constexpr unsigned value = (TMVB_CTM_ROWPAD && !FILT && R == 52) ? 256u : (unsigned)(R * 4); };
+template <int R, unsigned ROWB>
 __device__ __forceinline__ void cb_token_issue(const __attribute__((address_space(1))) float* tab, int* tl, int lane, const int (&rmap)[R / 4],
                                                const unsigned (&cbyte)[R / 4], int t, cb_v4f (&b)[R / 4])
 {
@@ -373,7 +384,7 @@ __device__ __forceinline__ void cb_token_issue(const __attribute__((address_spac
     // and reloaded behind s_waitcnt vmcnt(0))
     const __attribute__((address_space(1))) char* base = (const __attribute__((address_space(1))) char*)tab;
 #pragma unroll
-    for (int i = 0; i < R / 4; ++i) b[i] = *(const __attribute__((address_space(1))) cb_v4f*)(base + (__umul24((unsigned)tt[i], (unsigned)(R * 4)) + cbyte[i]));
+    for (int i = 0; i < R / 4; ++i) b[i] = *(const __attribute__((address_space(1))) cb_v4f*)(base + (__umul24((unsigned)tt[i], ROWB) + cbyte[i]));
 }
 
 // ---- the kernel: wave w owns documents doc_order[64 w .. 64 w + 63] (sorted by length, so a wave's documents are alike)
@@ -584,7 +595,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             // the CG solution (idle in this phase): ds_write_b128 in chunk order, ds_read_b128 of the lane's own row (stride 208 B:
             // conflict free).  The row ids travel the other way through a 64-entry LDS table.  VMEM returns in order, so a lane's own
             // ids / counts are fetched two rounds ahead (waiting for a load younger than the rows in flight would drain them).
-            constexpr int CH = (R >= 52) ? 2 : 4;
+#ifndef TMVB_CTM_CH52
+#define TMVB_CTM_CH52 2
+#endif
+            constexpr int CH = (R >= 52) ? TMVB_CTM_CH52 : 4;
             cb_v4f* xl4 = (cb_v4f*)vsf_l;                              // [64 rows][LPR chunks]: the vsq region, vsq parked in registers
             int* tl = (int*)(lds + 3 * R * 64);                        // [64] row ids of one step
             float vpark[R];
@@ -617,7 +631,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             load_ids(0, tq, cq);
             tmvb_static_for<CH>([&](auto tag) {
                 constexpr int u = decltype(tag)::value;
-                cb_token_issue<R>(beta, tl, lane, rmap, cbyte, tq[u], buf[u]);
+                cb_token_issue<R, cb_rowb<R, FILT>::value>(beta, tl, lane, rmap, cbyte, tq[u], buf[u]);
             });
             load_ids(CH, tn, cn);
             for (int n0 = 0; n0 < Nmax; n0 += CH) {
@@ -629,7 +643,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                     cb_v4f row[LPR];
 #pragma unroll
                     for (int q = 0; q < LPR; ++q) row[q] = xl4[lane * LPR + q];
-                    cb_token_issue<R>(beta, tl, lane, rmap, cbyte, tn[u], buf[u]);      // step n0 + CH + u (row 0 past the longest document)
+                    cb_token_issue<R, cb_rowb<R, FILT>::value>(beta, tl, lane, rmap, cbyte, tn[u], buf[u]);      // step n0 + CH + u (row 0 past the longest document)
                     cb_v2f s0 = cb_v2f{0.f, 0.f}, s1 = cb_v2f{0.f, 0.f};
 #pragma unroll
                     for (int q = 0; q < LPR; ++q) {
@@ -693,6 +707,32 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 for (int u = 0; u < 4; ++u) { vs[u] = VSQ(i0 + u); lm[u] = LAM(i0 + u); act[u] = active && (i0 + u < K); }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) isd[u] = (double)sd4[u];
+#if TMVB_CTM_VSQ32
+                {   // the Newton iterations far from the exit threshold in fp32 (an fp64 exp + two reciprocals are ~400 cycles per
+                    // topic and iteration for the one resident wave, the fp32 forms ~60); a lane leaves this loop, WITHOUT taking the
+                    // step, as soon as its gradient is within 16 ntol, so every exit test and the last steps stay in fp64 below
+                    float vf[4], af[4], isf[4];
+                    bool pa[4];
+                    const float cdf = (float)Cd, thr = 16.0f * (float)p.ntol;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { vf[u] = (float)vs[u]; af[u] = (float)(lm[u] - lz); isf[u] = sd4[u]; pa[u] = act[u]; }
+                    for (int t = 0; t < p.niter; ++t) {
+                        if (!__any(pa[0] || pa[1] || pa[2] || pa[3])) break;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const float ex = __expf(af[u] + 0.5f * vf[u]);
+                            const float rv = __builtin_amdgcn_rcpf(vf[u]);
+                            const float gr = -0.5f * (isf[u] + cdf * ex - rv);
+                            const float pp = -gr * __builtin_amdgcn_rcpf(0.25f * cdf * ex + 0.5f * rv * rv);
+                            float rho = 1.0f;
+                            while (pa[u] && vf[u] - rho * pp <= 0.0f) rho *= 0.5f;
+                            if (pa[u]) { if (rho * fabsf(gr) < thr) pa[u] = false; else vf[u] -= rho * pp; }
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) if (act[u]) vs[u] = (double)vf[u];
+                }
+#endif
                 for (int t = 0; t < p.niter; ++t) {
                     if (!__any(act[0] || act[1] || act[2] || act[3])) break;
                     double ex[4], rv[4], den[4], ihd[4], grad[4], pp[4], rho[4];

@@ -101,10 +101,14 @@ struct tmvb_inv_index {
     int32_t* d_multi_first = nullptr;  // [n_multi] first partial slot
     int32_t* d_multi_count = nullptr;  // [n_multi] number of partial slots
     int64_t n_slots = 0;
+    // id_cuts given to the builder: the chunk order is slice-major -- slice s = ids [slice_id[s], slice_id[s + 1]) = chunks
+    // [slice_chunk[s], slice_chunk[s + 1]) and multi-chunk ids [slice_multi[s], slice_multi[s + 1]); empty = one slice
+    std::vector<int64_t> slice_id, slice_chunk, slice_multi;
 };
 // doc_piece != NULL restricts the index to the documents d with doc_piece[d] == piece (pipelined E-step)
 int tmvb_build_inv_index(tmvb_ctx* ctx, int64_t M, int64_t n_ids, const int64_t* h_ptr, const int32_t* h_ids,
-                         const int32_t* h_vals, tmvb_inv_index* out, const int32_t* doc_piece = nullptr, int piece = 0);
+                         const int32_t* h_vals, tmvb_inv_index* out, const int32_t* doc_piece = nullptr, int piece = 0,
+                         const std::vector<int64_t>* id_cuts = nullptr);
 void tmvb_free_inv_index(tmvb_inv_index* ix);
 
 struct tmvb_corpus {
@@ -139,6 +143,7 @@ int tmvb_ctpf_view_of(tmvb_ctpf* h, tmvb_ctpf_view* v);
 int tmvb_corpus_term_index(tmvb_corpus* c);
 // n sum-all-reduces issued by one host thread inside one RCCL group (tmvb_comm.hip)
 int tmvb_comm_allreduce_group(tmvb_comm* const* comms, void* const* dev_ptrs, const int64_t* counts, int n, int32_t dtype);
+int tmvb_comm_allreduce_on(tmvb_comm* c, void* dev_ptr, int64_t count, int32_t dtype, hipStream_t on);
 int tmvb_corpus_reader_index(tmvb_corpus* c);
 
 // EPSILON of the reference (src/utils.jl:3) = 2^-99, exactly representable in fp32.

@@ -1096,6 +1096,19 @@ struct tmvb_lda {
     bool stats_fresh = false;          // S holds the statistics of an E-step that update_beta! has not consumed yet
     bool pw_valid = false;             // d_pw_partial belongs to the current (beta, beta_old, Elogtheta_old) state
     bool side_pending = false;         // ev_side marks side-stream work the context's stream has not waited for yet
+    // tmvb_lda_estep_allreduce (document-sharded run): the LAST statistics pass is issued in vocabulary slices, and the slab of S
+    // a slice completes is all-reduced on aux[AR] while the next slice's pass runs on the context's stream.  Cuts and order are
+    // agreed over the communicator once (lda_ar_prepare) -- every rank issues the same collectives in the same order.
+    static constexpr int AR = 3;
+    tmvb_comm* ar_comm = nullptr;      // the communicator the plan below was agreed on (nullptr: none yet)
+    int ar_slices = 0;                 // <= 1: one all-reduce of the whole buffer
+    std::vector<int64_t> ar_cuts;      // slice s = term ids [ar_cuts[s], ar_cuts[s + 1])
+    std::vector<int> ar_order;         // the slices in processing order
+    tmvb_inv_index ar_index;           // pieces.empty(): the shard's index, slice-major (else pieces.back() is rebuilt in place)
+    std::vector<int32_t> doc_piece;    // kept from lda_cut_pieces for that rebuild
+    std::vector<hipEvent_t> ev_slice;
+    hipEvent_t ev_comm = nullptr, ev_tail = nullptr;
+    bool ar_live = false;              // set for the E-step inside tmvb_lda_estep_allreduce
 };
 
 static bool lda_reg_lpr_supported(int lpr) { return lpr >= 1 && lpr <= 25 && (lpr & 1); }   // every KP = 4 * odd <= 100
@@ -1271,6 +1284,10 @@ extern "C" int tmvb_lda_destroy(tmvb_lda* h)
     if (h->ev_mark) (void)hipEventDestroy(h->ev_mark);
     (void)hipFree(h->d_partial_side); (void)hipFree(h->d_pw_partial);
     for (tmvb_inv_index& ix : h->pieces) tmvb_free_inv_index(&ix);
+    if (h->ar_index.built) tmvb_free_inv_index(&h->ar_index);
+    for (hipEvent_t e : h->ev_slice) if (e) (void)hipEventDestroy(e);
+    if (h->ev_comm) (void)hipEventDestroy(h->ev_comm);
+    if (h->ev_tail) (void)hipEventDestroy(h->ev_tail);
     for (hipEvent_t e : h->ev_piece) if (e) (void)hipEventDestroy(e);
     for (int a = 0; a < tmvb_lda::NAUX; ++a) {
         if (h->ev_join[a]) (void)hipEventDestroy(h->ev_join[a]);
@@ -1365,7 +1382,7 @@ extern "C" int tmvb_lda_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
         const int P = lda_piece_count(h);
         size_t slots = 0;
         if (P > 1) {
-            std::vector<int32_t> doc_piece;
+            std::vector<int32_t>& doc_piece = h->doc_piece;
             lda_cut_pieces(h, order, P, doc_piece);
             h->pieces.resize(P);
             h->ev_piece.assign(P, nullptr);
@@ -1577,6 +1594,14 @@ static int lda_estep_impl(tmvb_lda* h, int32_t viter, double vtol)
                 TMVB_HIP(hipEventRecord(h->ev_piece[piece_open], chain_st));
                 if (chain_st != ctx->stream) TMVB_HIP(hipStreamWaitEvent(ctx->stream, h->ev_piece[piece_open], 0));
             }
+            if (piece_open == P - 1 && h->ar_live) {     // tmvb_lda_estep_allreduce: slice by slice, an event behind each
+                const tmvb_inv_index& ix = h->pieces.empty() ? h->ar_index : h->pieces.back();
+                for (int k = 0; k < h->ar_slices; ++k) {
+                    if (!(p.debug & 1)) { int rc = tmvb_launch_termstats(ctx, h->nslot, h->KP, h->e_padded, ix, tp, pass_st, h->ar_order[(size_t)k]); if (rc) return rc; }
+                    TMVB_HIP(hipEventRecord(h->ev_slice[(size_t)k], pass_st));
+                }
+                continue;
+            }
             int rc = stats_pass(piece_index(piece_open), pass_st);
             if (rc) return rc;
         }
@@ -1675,6 +1700,120 @@ extern "C" int tmvb_lda_reduce_docs(tmvb_lda* h)
     h->esum_side = false;
     { int jrc = lda_join_side(h); if (jrc) return jrc; }
     return colsum(h, h->d_elog, h->M, h->d_esum, h->d_stats + (size_t)h->K * h->V);
+}
+
+// ---- the sharded E-step with its collective: see the fields of tmvb_lda.
+// The plan.  Every rank needs the same slabs in the same order, so the postings per term of the WHOLE corpus are summed over the
+// communicator once (fp64: exact).  Cuts: equal shares of  postings(v) / nnz + 1 / V  -- half a slice's weight is pass time, half is
+// bytes on the wire.  Order: the two-machine flow shop (pass, then collective) has Johnson's rule -- slices with less pass than wire
+// first, cheapest pass first; then the others, most wire first -- so a vocabulary sorted by frequency (few heavy ids in front, a long
+// tail of light ones) sends its long tail first and hides it under the heavy ids' pass, and a shuffled one gets S alike slices.
+static int lda_ar_prepare(tmvb_lda* h)
+{
+    if (h->ar_comm == h->comm) return TMVB_OK;
+    tmvb_ctx* ctx = h->ctx;
+    static const int want = [] { const char* e = getenv("TMVB_AR_SLICES"); return e ? atoi(e) : 4; }();
+    const int64_t V = h->V;
+    int S = (int)std::min<int64_t>(std::max(want, 1), std::max<int64_t>(V, 1));
+    if (!(tmvb_termstats_recomputes(h->KP, h->e_padded) && h->reg_path)) S = 1;      // the stored-weight passes keep one collective
+    std::vector<double> cnt((size_t)V, 0.0);
+    for (int32_t t : h->corp->h_terms) cnt[(size_t)t] += 1.0;
+    {   // the collective every rank takes part in, sliced or not (a rank must not decide alone)
+        double* d = nullptr;
+        int rc = dmalloc(&d, (size_t)V);
+        if (rc) return rc;
+        hipError_t e = hipMemcpyAsync(d, cnt.data(), (size_t)V * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) rc = tmvb_comm_allreduce(h->comm, d, V, TMVB_F64);
+        if (e == hipSuccess && !rc) e = hipMemcpyAsync(cnt.data(), d, (size_t)V * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && !rc) e = hipStreamSynchronize(ctx->stream);
+        (void)hipFree(d);
+        if (rc) return rc;
+        TMVB_HIP(e);
+    }
+    double tot = 0.0;
+    for (double c : cnt) tot += c;
+    if (tot <= 0.0) S = 1;
+    h->ar_cuts.assign(1, 0);
+    if (S > 1) {
+        double run = 0.0;
+        for (int64_t v = 0; v < V; ++v) {
+            run += 0.5 * cnt[(size_t)v] / tot + 0.5 / (double)V;
+            while ((int)h->ar_cuts.size() < S && run >= (double)h->ar_cuts.size() / (double)S) h->ar_cuts.push_back(v + 1);
+        }
+        while ((int)h->ar_cuts.size() < S) h->ar_cuts.push_back(V);
+    }
+    h->ar_cuts.push_back(V);
+    h->ar_order.clear();
+    if (S > 1) {
+        std::vector<double> pass((size_t)S, 0.0), wire((size_t)S, 0.0);
+        for (int sl = 0; sl < S; ++sl) {
+            for (int64_t v = h->ar_cuts[(size_t)sl]; v < h->ar_cuts[(size_t)sl + 1]; ++v) pass[(size_t)sl] += cnt[(size_t)v] / tot;
+            wire[(size_t)sl] = (double)(h->ar_cuts[(size_t)sl + 1] - h->ar_cuts[(size_t)sl]) / (double)V;
+        }
+        std::vector<int> first, second;
+        for (int sl = 0; sl < S; ++sl) (pass[(size_t)sl] < wire[(size_t)sl] ? first : second).push_back(sl);
+        std::stable_sort(first.begin(), first.end(), [&](int a, int b) { return pass[(size_t)a] < pass[(size_t)b]; });
+        std::stable_sort(second.begin(), second.end(), [&](int a, int b) { return wire[(size_t)a] > wire[(size_t)b]; });
+        h->ar_order = first;
+        h->ar_order.insert(h->ar_order.end(), second.begin(), second.end());
+        // the last piece's index again, slice-major
+        tmvb_inv_index fresh;
+        const bool whole = h->pieces.empty();
+        int rc = tmvb_build_inv_index(ctx, h->M, V, h->corp->h_doc_ptr.data(), h->corp->h_terms.data(), h->corp->h_counts.data(), &fresh,
+                                      whole ? nullptr : h->doc_piece.data(), whole ? 0 : (int)h->pieces.size() - 1, &h->ar_cuts);
+        if (rc) { tmvb_free_inv_index(&fresh); return rc; }
+        tmvb_inv_index& slot = whole ? h->ar_index : h->pieces.back();
+        const int64_t old_slots = whole ? h->corp->term_index.n_slots : slot.n_slots;
+        if (slot.built) { TMVB_HIP(hipStreamSynchronize(ctx->stream)); tmvb_free_inv_index(&slot); }
+        slot = fresh;
+        TMVB_REQUIRE(slot.n_slots <= old_slots, TMVB_EINVAL, "tmvb_lda_estep_allreduce: the sliced index needs %lld partial-sum slots, %lld are allocated",
+                     (long long)slot.n_slots, (long long)old_slots);
+        while ((int)h->ev_slice.size() < S) {
+            hipEvent_t ev = nullptr;
+            TMVB_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            h->ev_slice.push_back(ev);
+        }
+        if (!h->ev_comm) TMVB_HIP(hipEventCreateWithFlags(&h->ev_comm, hipEventDisableTiming));
+        if (!h->ev_tail) TMVB_HIP(hipEventCreateWithFlags(&h->ev_tail, hipEventDisableTiming));
+    }
+    h->ar_slices = S;
+    h->ar_comm = h->comm;
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_lda_estep_allreduce(tmvb_lda* h, int32_t viter, double vtol)
+{
+    TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_lda_estep_allreduce: handle is NULL");
+    TMVB_REQUIRE(h->comm != nullptr && h->distributed, TMVB_EINVAL, "tmvb_lda_estep_allreduce: the handle has no communicator (tmvb_lda_set_comm)");
+    TMVB_HIP(hipSetDevice(h->ctx->device));
+    int rc = lda_ar_prepare(h);
+    if (rc) return rc;
+    const int S = h->ar_slices;
+    h->ar_live = S > 1;
+    rc = tmvb_lda_estep(h, viter, vtol);
+    h->ar_live = false;
+    if (rc) return rc;
+    if ((rc = tmvb_lda_reduce_docs(h))) return rc;                       // the tail (Elogtheta_sum): joins the side chain
+    const int64_t K = h->K, V = h->V;
+    if (S <= 1) return tmvb_comm_allreduce(h->comm, h->d_stats, K * V + K, TMVB_F32);
+    tmvb_ctx* ctx = h->ctx;
+    hipStream_t cs = h->aux[tmvb_lda::AR];
+    hipEvent_t ev_tail = h->ev_tail;
+    TMVB_HIP(hipEventRecord(ev_tail, ctx->stream));                       // behind the join above: the tail is complete here
+    for (int k = 0; k < S; ++k) {
+        const int sl = h->ar_order[(size_t)k];
+        TMVB_HIP(hipStreamWaitEvent(cs, h->ev_slice[(size_t)k], 0));
+        int64_t count = (h->ar_cuts[(size_t)sl + 1] - h->ar_cuts[(size_t)sl]) * K;
+        if (sl == S - 1) { TMVB_HIP(hipStreamWaitEvent(cs, ev_tail, 0)); count += K; }   // the tail rides with the slab it follows in memory
+        if ((rc = tmvb_comm_allreduce_on(h->comm, h->d_stats + h->ar_cuts[(size_t)sl] * K, count, TMVB_F32, cs))) {
+            (void)hipStreamSynchronize(cs); (void)hipStreamSynchronize(ctx->stream);
+            return rc;
+        }
+    }
+    TMVB_HIP(hipEventRecord(h->ev_comm, cs));
+    TMVB_HIP(hipStreamWaitEvent(ctx->stream, h->ev_comm, 0));
+    return TMVB_OK;
 }
 
 extern "C" int tmvb_lda_stats(tmvb_lda* h, void** dev_ptr, int64_t* n_f32)
@@ -1833,6 +1972,7 @@ extern "C" int tmvb_lda_set_comm(tmvb_lda* h, tmvb_comm* comm, int64_t M_total)
     int rc = tmvb_lda_set_distributed(h, comm ? M_total : h->M, comm != nullptr);
     if (rc) return rc;
     h->comm = comm;
+    if (h->ar_comm != comm) h->ar_comm = nullptr;       // the slicing plan was agreed on another communicator: agree again
     return TMVB_OK;
 }
 
@@ -1841,6 +1981,7 @@ struct LdaTrainOps {
     int niter, viter; double ntol, vtol;
     int estep(tmvb_lda* h) { return tmvb_lda_estep(h, viter, vtol); }                 // src/LDA.jl:170-180
     int reduce(tmvb_lda* h) { return tmvb_lda_reduce_docs(h); }                       // :98
+    int estep_allreduce(tmvb_lda* h) { return tmvb_lda_estep_allreduce(h, viter, vtol); }   // one process per GPU: the three steps with the collective sliced
     int before_allreduce(tmvb_lda* h) { TMVB_HIP(hipSetDevice(h->ctx->device)); return lda_join_side(h); }
     float* stats(tmvb_lda* h) { return h->d_stats; }
     int64_t stats_len(tmvb_lda* h) { return (int64_t)h->K * h->V + h->K; }

@@ -62,6 +62,13 @@ template <class Ops, class H, class = void> struct tmvb_has_elbo_enqueue : std::
 template <class Ops, class H>
 struct tmvb_has_elbo_enqueue<Ops, H, std::void_t<decltype(std::declval<Ops&>().elbo_enqueue((H*)nullptr, (double*)nullptr))>> : std::true_type {};
 
+// Ops may offer  int estep_allreduce(H*): estep + reduce + the statistics all-reduce in one call that overlaps the collective with the
+// last statistics pass (LDA).  Used when this process drives ONE handle (one process per GPU); several local handles keep the
+// grouped collective below.
+template <class Ops, class H, class = void> struct tmvb_has_estep_allreduce : std::false_type {};
+template <class Ops, class H>
+struct tmvb_has_estep_allreduce<Ops, H, std::void_t<decltype(std::declval<Ops&>().estep_allreduce((H*)nullptr))>> : std::true_type {};
+
 template <class H, class Ops>
 static int tmvb_group_elbo(H* const* hs, int n, Ops& ops, double* out)
 {
@@ -141,9 +148,13 @@ static int tmvb_train_group_loop(const char* who, H* const* hs, int n, int iter,
     int done = 0;
     for (int k = 1; k <= iter; ++k) {
         ++done;
-        for (int i = 0; i < n; ++i) if ((rc = ops.estep(hs[i]))) return rc;
-        for (int i = 0; i < n; ++i) if ((rc = ops.reduce(hs[i]))) return rc;
-        if (sharded) {
+        bool fused = false;
+        if constexpr (tmvb_has_estep_allreduce<Ops, H>::value) {
+            if (sharded && n == 1) { if ((rc = ops.estep_allreduce(hs[0]))) return rc; fused = true; }
+        }
+        if (!fused) for (int i = 0; i < n; ++i) if ((rc = ops.estep(hs[i]))) return rc;
+        if (!fused) for (int i = 0; i < n; ++i) if ((rc = ops.reduce(hs[i]))) return rc;
+        if (sharded && !fused) {
             for (int i = 0; i < n; ++i) {
                 if ((rc = ops.before_allreduce(hs[i]))) return rc;
                 comms[i] = ops.comm(hs[i]); ptrs[i] = ops.stats(hs[i]); counts[i] = ops.stats_len(hs[i]);

@@ -206,6 +206,8 @@ end
 "update_phi! / update_gamma! / update_Elogtheta! sweeps + update_beta!(model, d) of every document (src/LDA.jl:170-180)."
 update_estep!(model::hipLDA, viter::Integer, vtol::Real) = tmvb_check(ccall((:tmvb_lda_estep, LIBTMVB), Cint, (Ptr{Cvoid}, Int32, Float64), model.handle, viter, vtol))
 update_Elogtheta_sum!(model::hipLDA) = tmvb_check(ccall((:tmvb_lda_reduce_docs, LIBTMVB), Cint, (Ptr{Cvoid},), model.handle))
+"Sharded run (set_comm!): update_estep! + update_Elogtheta_sum! + the statistics all-reduce, issued in vocabulary slabs under the last statistics pass."
+update_estep_allreduce!(model::hipLDA, viter::Integer, vtol::Real) = tmvb_check(ccall((:tmvb_lda_estep_allreduce, LIBTMVB), Cint, (Ptr{Cvoid}, Int32, Float64), model.handle, viter, vtol))
 update_beta!(model::hipLDA) = tmvb_check(ccall((:tmvb_lda_update_beta, LIBTMVB), Cint, (Ptr{Cvoid},), model.handle))
 update_alpha!(model::hipLDA, niter::Integer, ntol::Real) = tmvb_check(ccall((:tmvb_lda_update_alpha, LIBTMVB), Cint, (Ptr{Cvoid}, Int32, Float64), model.handle, niter, ntol))
 function update_elbo!(model::hipLDA)

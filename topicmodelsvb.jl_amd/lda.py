@@ -227,6 +227,12 @@ class gpuLDA:
     def reduce_docs(self):
         check(lib().tmvb_lda_reduce_docs(self.handle))
 
+    def estep_allreduce(self, viter: int = 10, vtol: float | None = None):
+        """estep + reduce_docs + the statistics all-reduce over the attached communicator, the collective issued in vocabulary
+        slabs under the last statistics pass (tmvb_lda_estep_allreduce, include/tmvb.h)."""
+        vtol = 1.0 / self.K ** 2 if vtol is None else vtol
+        check(lib().tmvb_lda_estep_allreduce(self.handle, C.c_int32(viter), C.c_double(vtol)))
+
     def update_beta(self):
         check(lib().tmvb_lda_update_beta(self.handle))
 
