@@ -214,7 +214,8 @@ def main():
     ap.add_argument("--vocab", type=int, default=25319)
     ap.add_argument("--ar-slices", type=int, default=None,
                     help="N > 1, in-library communicator: vocabulary slabs the statistics all-reduce is issued in under the last statistics "
-                         "pass (tmvb_lda_estep_allreduce; default: the library's, 4; 1 = one collective after the E-step, round 3's form)")
+                         "pass (tmvb_lda_estep_allreduce; default: the library's, 1 = the statistics in one collective after the pass, the Elogtheta_sum tail in "
+                         "an early one of its own)")
     ap.add_argument("--collective", choices=["lib", "torch"], default="lib",
                     help="lib: RCCL inside libtmvb_hip.so (tmvb_comm_allreduce); torch: torch.distributed all_reduce on the bound buffer")
     ap.add_argument("--plateau-cap", type=int, default=4000)
@@ -301,8 +302,8 @@ def main():
                     comm.close()
                 comm, use_lib = None, False
         if use_lib:
-            collective = (f"RCCL {tm.rccl_version()} inside libtmvb_hip.so (tmvb_lda_estep_allreduce: the statistics all-reduce in "
-                          f"{os.environ.get('TMVB_AR_SLICES', '4')} vocabulary slabs on a side stream under the last statistics pass)")
+            collective = (f"RCCL {tm.rccl_version()} inside libtmvb_hip.so (tmvb_lda_estep_allreduce: the Elogtheta_sum tail all-reduced on a side stream "
+                          f"under the statistics pass, the statistics in {os.environ.get('TMVB_AR_SLICES', '1')} vocabulary slab(s))")
             eng.model.set_comm(comm, corpus.M)
             eng.fused_allreduce = True
             return (lambda: None), comm

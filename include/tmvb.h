@@ -211,13 +211,15 @@ int tmvb_lda_set_comm(tmvb_lda* h, tmvb_comm* comm, int64_t M_total);
 
 /* One rank's E-step, per-document sums and the sum-all-reduce of the packed statistics over the handle's communicator, in one
  * asynchronous call (the sharded train! uses it when the process drives one handle; a host that composes the iteration itself calls
- * it INSTEAD of tmvb_lda_estep + tmvb_lda_reduce_docs + tmvb_comm_allreduce, then tmvb_lda_update_beta / _alpha as before).  The
- * last statistics pass is issued in TMVB_AR_SLICES (default 4; 1 = one collective) vocabulary slices and the slab of S a slice
- * completes is all-reduced on a side stream while the next slice's pass runs: the collective of src/gpuLDA.jl's multi-device
- * precedent (v0.6/src/gpuLDA.jl:200-225: host gathers every device's buffer after the E-step) overlapped with the pass that feeds it.
- * The first call on a communicator is collective beyond that: the ranks sum their postings per term (V doubles) to agree on the
- * cuts.  Every rank must call it the same number of times; results equal the three-call form's up to the fp32 summation order of
- * the collective.  TMVB_EINVAL without a communicator. */
+ * it INSTEAD of tmvb_lda_estep + tmvb_lda_reduce_docs + tmvb_comm_allreduce, then tmvb_lda_update_beta / _alpha as before).
+ * The collective of the multi-device precedent (v0.6/src/gpuLDA.jl:200-225: the host gathers every device's buffer after the
+ * E-step) is issued in pieces, in the same order on every rank: (1) the Elogtheta_sum tail (K floats) on a side stream as soon as
+ * the document kernels' column sums exist, i.e. under the statistics pass -- tmvb_lda_update_alpha then starts from that event
+ * instead of after the whole buffer; (2) with TMVB_AR_SLICES = S > 1 (default 1) the last statistics pass runs in S vocabulary
+ * slices and the slab of S a slice completes is all-reduced on the side stream while the next slice's pass runs; (3) the last
+ * (or only) slab on the context's stream.  The first call on a communicator is collective beyond that: the ranks sum their
+ * postings per term (V doubles) to agree on the cuts and the order.  Every rank must call it the same number of times; results
+ * are bit-identical to the three-call form's.  TMVB_EINVAL without a communicator. */
 int tmvb_lda_estep_allreduce(tmvb_lda* h, int32_t viter, double vtol);
 /* One host thread, n GPUs: hs[i] carries the i-th communicator of tmvb_comm_create_rccl_all (n = 1: same as
  * tmvb_lda_train).  The n all-reduces of an iteration are issued as one RCCL group. */

@@ -6,7 +6,7 @@ fused call must leave EXACTLY the state of estep + reduce_docs + allreduce:
 
   * RCCL with nranks = 1 (the call sequence and the event plumbing of the side stream; RCCL short-cuts a one-rank in-place
     all-reduce -- 0.7 us per call, tools/ar_slices_probe.py -- so no collective kernel runs; one-, two- and three-piece plans);
-  * two ranks on one GPU through the host transport with gloo carrying the sums: TMVB_AR_SLICES = 4 and 7 against 1, bit for bit,
+  * two ranks on one GPU through the host transport with gloo carrying the sums: TMVB_AR_SLICES = 4 and 7 against 1 (the default), bit for bit,
     and both against the whole corpus on one context.
 """
 import os
@@ -27,9 +27,10 @@ def _lda(tm, corpus, K, ctx=None):
     return gm
 
 
-@pytest.mark.parametrize("pieces,K", [(1, 50), (3, 50), (1, 100), (2, 20)])
-def test_fused_call_equals_the_three_calls_single_rank(tmvb, monkeypatch, pieces, K):
+@pytest.mark.parametrize("pieces,K,slices", [(1, 50, 4), (3, 50, 4), (1, 100, 3), (2, 20, 4), (1, 50, 1), (3, 50, 1)])
+def test_fused_call_equals_the_three_calls_single_rank(tmvb, monkeypatch, pieces, K, slices):
     monkeypatch.setenv("TMVB_LDA_PIECES", str(pieces))
+    monkeypatch.setenv("TMVB_AR_SLICES", str(slices))          # read when the plan is agreed on, at the first fused call
     corpus = tmvb.syn_nsf(M=4000, V=2500, seed=31)
     a, b = _lda(tmvb, corpus, K), _lda(tmvb, corpus, K)
     ca = tmvb.Communicator.rccl(a.ctx, tmvb.Communicator.unique_id(), 1, 0)

@@ -366,9 +366,7 @@ __device__ __forceinline__ int cb_karg32()
 #ifndef TMVB_CTM_ROWPAD
 #define TMVB_CTM_ROWPAD 1
 #endif
-#ifndef TMVB_CTM_VSQ32
-#define TMVB_CTM_VSQ32 0
-#endif
+
 template <int R, bool FILT> struct cb_rowb { static constexpr unsigned value = (TMVB_CTM_ROWPAD && !FILT && R == 52) ? 256u : (unsigned)(R * 4); };
 template <int R, unsigned ROWB>
 __device__ __forceinline__ void cb_token_issue(const __attribute__((address_space(1))) float* tab, int* tl, int lane, const int (&rmap)[R / 4],
@@ -707,32 +705,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 for (int u = 0; u < 4; ++u) { vs[u] = VSQ(i0 + u); lm[u] = LAM(i0 + u); act[u] = active && (i0 + u < K); }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) isd[u] = (double)sd4[u];
-#if TMVB_CTM_VSQ32
-                {   // the Newton iterations far from the exit threshold in fp32 (an fp64 exp + two reciprocals are ~400 cycles per
-                    // topic and iteration for the one resident wave, the fp32 forms ~60); a lane leaves this loop, WITHOUT taking the
-                    // step, as soon as its gradient is within 16 ntol, so every exit test and the last steps stay in fp64 below
-                    float vf[4], af[4], isf[4];
-                    bool pa[4];
-                    const float cdf = (float)Cd, thr = 16.0f * (float)p.ntol;
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) { vf[u] = (float)vs[u]; af[u] = (float)(lm[u] - lz); isf[u] = sd4[u]; pa[u] = act[u]; }
-                    for (int t = 0; t < p.niter; ++t) {
-                        if (!__any(pa[0] || pa[1] || pa[2] || pa[3])) break;
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const float ex = __expf(af[u] + 0.5f * vf[u]);
-                            const float rv = __builtin_amdgcn_rcpf(vf[u]);
-                            const float gr = -0.5f * (isf[u] + cdf * ex - rv);
-                            const float pp = -gr * __builtin_amdgcn_rcpf(0.25f * cdf * ex + 0.5f * rv * rv);
-                            float rho = 1.0f;
-                            while (pa[u] && vf[u] - rho * pp <= 0.0f) rho *= 0.5f;
-                            if (pa[u]) { if (rho * fabsf(gr) < thr) pa[u] = false; else vf[u] -= rho * pp; }
-                        }
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) if (act[u]) vs[u] = (double)vf[u];
-                }
-#endif
+                // (round 4, measured and dropped: the iterations far from the exit threshold in fp32 -- __expf, v_rcp_f32, a lane leaving the fp32
+                //  loop without taking the step once its gradient is within 16 ntol, so that every exit test and the last steps stay in fp64.
+                //  tools/ctm_ab.py, three alternating rounds: 199.8 / 202.7 / 203.2 it/s against 207.6 / 208.6 / 205.0 -- the extra loop's
+                //  registers and divergence cost more than ~2 of ~4 fp64 iterations save.  CH = 1 / 3 / 4 token steps in flight instead of
+                //  2 at KP = 52: 76 / 185 / 44 it/s against 207 -- scratch.)
                 for (int t = 0; t < p.niter; ++t) {
                     if (!__any(act[0] || act[1] || act[2] || act[3])) break;
                     double ex[4], rv[4], den[4], ihd[4], grad[4], pp[4], rho[4];

@@ -1013,6 +1013,42 @@ __device__ __forceinline__ float ctpf_elbo_entries(const int* __restrict__ ids, 
     return acc;
 }
 
+// The same sum with FOUR lanes per entry (lane = 4 a + b: entry n0 + a, chunks b, b + 4, b + 8, b + 12 of the entry's two rows): a load
+// instruction then touches 16 rows, one 64-byte run each, where lane = entry touches 64 rows in 64 different cache lines -- the CU's vector
+// L1 looks up one line per cycle (the CTM token phase's lesson).  The partial sums meet inside the quad (two DPP adds each).
+#ifndef TMVB_CTPF_ELBO_QUAD
+#define TMVB_CTPF_ELBO_QUAD 1
+#endif
+__device__ __forceinline__ float ctpf_elbo_entries_quad(const int* __restrict__ ids, const int* __restrict__ vals, const int n_ent,
+                                                        const float* __restrict__ To, const float* __restrict__ D, const int KP,
+                                                        const float* __restrict__ Ql, const float* __restrict__ Pl, const int lane)
+{
+    float acc = 0.0f;
+    const int lpr = KP >> 2;
+    const int a = lane >> 2, b = lane & 3;
+    for (int n0 = 0; n0 < n_ent; n0 += 16) {
+        const int n = n0 + a;
+        const bool in = n < n_ent;
+        const int id = ids[in ? n : 0];
+        const float cv = in ? (float)vals[in ? n : 0] : 0.0f;
+        const float4* __restrict__ rt = (const float4*)(To + (int64_t)id * KP);
+        const float4* __restrict__ rd = (const float4*)(D + (int64_t)id * KP);
+        float s = 0.0f, u = 0.0f, w = 0.0f;
+        for (int q = b; q < lpr; q += 4) {
+            const float4 t = rt[q], dd = rd[q];
+            const float4 qq = ((const float4*)Ql)[q], pp = ((const float4*)Pl)[q];
+            s = fmaf(t.x, qq.x, fmaf(t.y, qq.y, fmaf(t.z, qq.z, fmaf(t.w, qq.w, s))));
+            u = fmaf(t.x, pp.x, fmaf(t.y, pp.y, fmaf(t.z, pp.z, fmaf(t.w, pp.w, u))));
+            w = fmaf(t.x * dd.x, qq.x, fmaf(t.y * dd.y, qq.y, fmaf(t.z * dd.z, qq.z, fmaf(t.w * dd.w, qq.w, w))));
+        }
+        float uw = u + w;
+        s += dpp_f<0xB1>(s); uw += dpp_f<0xB1>(uw);
+        s += dpp_f<0x4E>(s); uw += dpp_f<0x4E>(uw);
+        if (b == 0) acc = fmaf(cv, uw / s + logf(s), acc);   // s > 0: To > 0 and the largest factor of Q is 1
+    }
+    return acc;
+}
+
 template <int NS>
 __global__ __launch_bounds__(64) void ctpf_elbo_doc_fast_kernel(int K, int KP, const int64_t* __restrict__ doc_ptr, const int32_t* __restrict__ terms,
                                                                 const int32_t* __restrict__ counts, const int64_t* __restrict__ rdr_ptr,
@@ -1024,8 +1060,10 @@ __global__ __launch_bounds__(64) void ctpf_elbo_doc_fast_kernel(int K, int KP, c
                                                                 const double* __restrict__ rs_he, const float* __restrict__ gimel,
                                                                 const float* __restrict__ gimel_old, const float* __restrict__ zayin,
                                                                 const float* __restrict__ zayin_old, const double* __restrict__ lg_doc,
-                                                                double hc, double hd, double hg, double hh, double* __restrict__ doc_val)
+                                                                double hc, double hd, double hg, double hh, double doc_const, double* __restrict__ doc_val)
 {
+    // doc_const = K (c log d - lgamma(c)) + K (g log h - lgamma(g)), from the host: the library's fp64 lgamma / log of four hyperparameters
+    // were evaluated here by every wave (round 4: ~2 us of a document's ~7)
     __shared__ __attribute__((aligned(16))) float PQ[4][64 * NS + 8];  // Q1 | P1 | Q2 | P2, pads zero (KP = 4 * odd can exceed 64 NS by 4)
     const int lane = threadIdx.x;
     const int d = blockIdx.x;
@@ -1080,11 +1118,22 @@ __global__ __launch_bounds__(64) void ctpf_elbo_doc_fast_kernel(int K, int KP, c
     const int64_t off = doc_ptr[d], roff = rdr_ptr[d];
     const int N = (int)(doc_ptr[d + 1] - off), Rd = (int)(rdr_ptr[d + 1] - roff);
     float ent = 0.0f;
-    if (N > 0) ent += ctpf_elbo_entries(terms + off, counts + off, N, TAo, DA, KP, PQ[0], PQ[1], lane);
-    if (Rd > 0) ent += ctpf_elbo_entries(readers + roff, ratings + roff, Rd, THo, DH, KP, PQ[2], PQ[3], lane);
+    // (TMVB_CTPF_ELBO_SKIP: timing by elimination, tools/build_variant.sh -- 1 = no entry sums, 2 = no term entries, 3 = no reader entries;
+    //  wrong results, never the shipped build)
+#ifndef TMVB_CTPF_ELBO_SKIP
+#define TMVB_CTPF_ELBO_SKIP 0
+#endif
+#if TMVB_CTPF_ELBO_QUAD
+#define CTPF_ELBO_ENTRIES ctpf_elbo_entries_quad
+#else
+#define CTPF_ELBO_ENTRIES ctpf_elbo_entries
+#endif
+    if (N > 0 && TMVB_CTPF_ELBO_SKIP != 1 && TMVB_CTPF_ELBO_SKIP != 2) ent += CTPF_ELBO_ENTRIES(terms + off, counts + off, N, TAo, DA, KP, PQ[0], PQ[1], lane);
+    if (Rd > 0 && TMVB_CTPF_ELBO_SKIP != 1 && TMVB_CTPF_ELBO_SKIP != 3) ent += CTPF_ELBO_ENTRIES(readers + roff, ratings + roff, Rd, THo, DH, KP, PQ[2], PQ[3], lane);
+#undef CTPF_ELBO_ENTRIES
     acc += (double)ent;
     double tot = wave_sum_d(acc);
-    tot += (double)K * (hc * log(hd) - lgamma(hc)) + (double)K * (hg * log(hh) - lgamma(hg)) - lg_doc[d];
+    tot += doc_const - lg_doc[d];
     if (lane == 0) doc_val[d] = tot;
 }
 
@@ -1789,7 +1838,8 @@ extern "C" int tmvb_ctpf_update_elbo_parts(tmvb_ctpf* h, double* doc_part, doubl
             hipLaunchKernelGGL((ctpf_elbo_doc_fast_kernel<NS>), dim3((unsigned)h->M), dim3(64), 0, ctx->stream, h->K, h->KP, h->corp->d_doc_ptr, h->corp->d_terms,
                                h->corp->d_counts, h->corp->d_rdr_ptr, h->corp->d_readers, h->corp->d_ratings, h->d_TAo, h->d_DA, h->d_THo, h->d_DH,
                                h->d_rates, h->d_lrates_d, h->d_rs_alef, h->d_rs_he, h->d_gimel, h->d_gimel_old, h->d_zayin, h->d_zayin_old, h->d_lg_doc,
-                               hy[2], hy[3], hy[6], hy[7], h->d_doc_val);
+                               hy[2], hy[3], hy[6], hy[7],
+                               (double)h->K * (hy[2] * std::log(hy[3]) - std::lgamma(hy[2])) + (double)h->K * (hy[6] * std::log(hy[7]) - std::lgamma(hy[6])), h->d_doc_val);
         };
         if (h->nslot == 1) fast(std::integral_constant<int, 1>()); else if (h->nslot == 2) fast(std::integral_constant<int, 2>());
         else if (h->nslot <= 4) fast(std::integral_constant<int, 4>()); else fast(std::integral_constant<int, 8>());

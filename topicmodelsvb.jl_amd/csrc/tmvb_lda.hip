@@ -1109,6 +1109,7 @@ struct tmvb_lda {
     std::vector<hipEvent_t> ev_slice;
     hipEvent_t ev_comm = nullptr, ev_tail = nullptr;
     bool ar_live = false;              // set for the E-step inside tmvb_lda_estep_allreduce
+    bool tail_early = false;           // ev_tail (on aux[AR]) marks the all-reduced Elogtheta_sum tail: update_alpha! starts from it
 };
 
 static bool lda_reg_lpr_supported(int lpr) { return lpr >= 1 && lpr <= 25 && (lpr & 1); }   // every KP = 4 * odd <= 100
@@ -1520,7 +1521,7 @@ extern "C" int tmvb_lda_estep(tmvb_lda* h, int32_t viter, double vtol)
 static int lda_estep_impl(tmvb_lda* h, int32_t viter, double vtol)
 {
     tmvb_ctx* ctx = h->ctx;
-    h->mark_valid = false; h->esum_fresh = false; h->esum_side = false;
+    h->mark_valid = false; h->esum_fresh = false; h->esum_side = false; h->tail_early = false;
     TMVB_HIP(hipSetDevice(ctx->device));
     LdaParams p;
     p.K = h->K; p.KP = h->KP; p.LPR = h->KP / 4; p.lpr_magic = (unsigned)(0x100000000ull / (unsigned)p.LPR) + 1u; p.V = h->V;
@@ -1712,7 +1713,10 @@ static int lda_ar_prepare(tmvb_lda* h)
 {
     if (h->ar_comm == h->comm) return TMVB_OK;
     tmvb_ctx* ctx = h->ctx;
-    static const int want = [] { const char* e = getenv("TMVB_AR_SLICES"); return e ? atoi(e) : 4; }();
+// (default ONE slab: on the 16 100-document shard of an 8-GPU run every further slice costs ~20 us of launches and kernel tails -- fused
+    // iteration 0.166 / 0.184 / 0.205 / 0.224 ms with 1 / 2 / 3 / 4 slabs at nranks = 1, tools/ar_slices_probe.py -- against a last pass of
+    // ~50 us to hide wire under; what pays at that size is the early collective of the tail, below, which every setting has)
+    const int want = [] { const char* e = getenv("TMVB_AR_SLICES"); return e ? atoi(e) : 1; }();      // read per plan (per communicator)
     const int64_t V = h->V;
     int S = (int)std::min<int64_t>(std::max(want, 1), std::max<int64_t>(V, 1));
     if (!(tmvb_termstats_recomputes(h->KP, h->e_padded) && h->reg_path)) S = 1;      // the stored-weight passes keep one collective
@@ -1794,26 +1798,41 @@ extern "C" int tmvb_lda_estep_allreduce(tmvb_lda* h, int32_t viter, double vtol)
     rc = tmvb_lda_estep(h, viter, vtol);
     h->ar_live = false;
     if (rc) return rc;
-    if ((rc = tmvb_lda_reduce_docs(h))) return rc;                       // the tail (Elogtheta_sum): joins the side chain
+    const bool tail_on_side = h->esum_fresh && h->esum_side;             // the E-step's side chain made the tail (ev_side marks it)
+    if ((rc = tmvb_lda_reduce_docs(h))) return rc;                       // ... or this call does, on the context's stream
+    // The collectives, in the order every rank issues them:
+    //   1. the Elogtheta_sum tail (K floats) on aux[AR], as soon as the side chain has it -- the statistics pass is still running; update_alpha!
+    //      then starts from THAT event on the side stream instead of waiting for the whole buffer (a one-wave fp64 Newton kernel, ~45 us, that the
+    //      next E-step waits for: in the three-call form it only starts after the last collective);
+    //   2. slabs 0 .. S-2 on aux[AR], each behind its slice's event, under the following slices' passes;
+    //   3. the last slab on the context's stream itself, behind aux[AR]'s collectives: no cross-stream hop (~25 us each way) is left on the
+    //      critical path -- with the last slab on aux[AR] as well, four slabs cost 0.107 ms more than they could hide (tools/ar_slices_probe.py).
     const int64_t K = h->K, V = h->V;
-    if (S <= 1) return tmvb_comm_allreduce(h->comm, h->d_stats, K * V + K, TMVB_F32);
     tmvb_ctx* ctx = h->ctx;
     hipStream_t cs = h->aux[tmvb_lda::AR];
-    hipEvent_t ev_tail = h->ev_tail;
-    TMVB_HIP(hipEventRecord(ev_tail, ctx->stream));                       // behind the join above: the tail is complete here
-    for (int k = 0; k < S; ++k) {
+    if (!h->ev_comm) TMVB_HIP(hipEventCreateWithFlags(&h->ev_comm, hipEventDisableTiming));
+    if (!h->ev_tail) TMVB_HIP(hipEventCreateWithFlags(&h->ev_tail, hipEventDisableTiming));
+    if (tail_on_side) {
+        TMVB_HIP(hipStreamWaitEvent(cs, h->ev_side, 0));                  // NOT the context's stream: the statistics pass is queued on it
+    } else {
+        TMVB_HIP(hipEventRecord(h->ev_tail, ctx->stream));
+        TMVB_HIP(hipStreamWaitEvent(cs, h->ev_tail, 0));
+    }
+    auto fail = [&](int code) { (void)hipStreamSynchronize(cs); (void)hipStreamSynchronize(ctx->stream); return code; };
+    if ((rc = tmvb_comm_allreduce_on(h->comm, h->d_stats + K * V, K, TMVB_F32, cs))) return fail(rc);
+    TMVB_HIP(hipEventRecord(h->ev_tail, cs));
+    h->tail_early = true;
+    for (int k = 0; k + 1 < S; ++k) {
         const int sl = h->ar_order[(size_t)k];
         TMVB_HIP(hipStreamWaitEvent(cs, h->ev_slice[(size_t)k], 0));
-        int64_t count = (h->ar_cuts[(size_t)sl + 1] - h->ar_cuts[(size_t)sl]) * K;
-        if (sl == S - 1) { TMVB_HIP(hipStreamWaitEvent(cs, ev_tail, 0)); count += K; }   // the tail rides with the slab it follows in memory
-        if ((rc = tmvb_comm_allreduce_on(h->comm, h->d_stats + h->ar_cuts[(size_t)sl] * K, count, TMVB_F32, cs))) {
-            (void)hipStreamSynchronize(cs); (void)hipStreamSynchronize(ctx->stream);
-            return rc;
-        }
+        const int64_t count = (h->ar_cuts[(size_t)sl + 1] - h->ar_cuts[(size_t)sl]) * K;
+        if ((rc = tmvb_comm_allreduce_on(h->comm, h->d_stats + h->ar_cuts[(size_t)sl] * K, count, TMVB_F32, cs))) return fail(rc);
     }
     TMVB_HIP(hipEventRecord(h->ev_comm, cs));
-    TMVB_HIP(hipStreamWaitEvent(ctx->stream, h->ev_comm, 0));
-    return TMVB_OK;
+    TMVB_HIP(hipStreamWaitEvent(ctx->stream, h->ev_comm, 0));             // collectives of one communicator run in issue order anyway
+    if (S <= 1) return tmvb_comm_allreduce(h->comm, h->d_stats, K * V, TMVB_F32);
+    const int last = h->ar_order[(size_t)S - 1];
+    return tmvb_comm_allreduce(h->comm, h->d_stats + h->ar_cuts[(size_t)last] * K, (h->ar_cuts[(size_t)last + 1] - h->ar_cuts[(size_t)last]) * K, TMVB_F32);
 }
 
 extern "C" int tmvb_lda_stats(tmvb_lda* h, void** dev_ptr, int64_t* n_f32)
@@ -1889,7 +1908,10 @@ extern "C" int tmvb_lda_update_alpha(tmvb_lda* h, int32_t niter, double ntol)
     // One context: the Newton step needs nothing but Elogtheta_sum, which the E-step left on this very
     // stream, so it starts under the statistics pass.  Document-sharded: it needs the all-reduced sums, i.e.
     // the context's stream as of the preceding update_beta call (or as of now).
-    if (h->distributed || !h->esum_side) {
+    if (h->tail_early) {                                    // tmvb_lda_estep_allreduce: the tail's own collective, long done
+        TMVB_HIP(hipStreamWaitEvent(side, h->ev_tail, 0));
+        h->tail_early = false;
+    } else if (h->distributed || !h->esum_side) {
         if (!h->mark_valid) TMVB_HIP(hipEventRecord(h->ev_mark, ctx->stream));
         TMVB_HIP(hipStreamWaitEvent(side, h->ev_mark, 0));
     }
