@@ -1057,9 +1057,6 @@ struct tmvb_lda {
     int32_t* d_doc_order = nullptr;
     double* d_partial = nullptr;       // [TMVB_REDUCE_BLOCKS][K]
     double* d_rowsum = nullptr;        // [K]
-    double* d_gsum = nullptr;          // [K] column sums of gamma (side chain) and its partials
-    double* d_partial_g = nullptr;
-    bool rowsum_fresh = false;         // d_rowsum = sum_d (gamma_d - alpha) of the last E-step = the row sums of its statistics (update_beta!)
     double* d_esum = nullptr;          // [K]
     double* d_doc_val = nullptr;       // [M]
     double* d_elbo = nullptr;          // [1]
@@ -1277,7 +1274,7 @@ extern "C" int tmvb_lda_destroy(tmvb_lda* h)
     (void)hipFree(h->d_wtok); (void)hipFree(h->d_E); (void)hipFree(h->d_ts_partial);
     (void)hipFree(h->d_topic_of_lane); (void)hipFree(h->d_grid_topic_of_lane);
     (void)hipFree(h->d_gamma); (void)hipFree(h->d_elog); (void)hipFree(h->d_elog_old); (void)hipFree(h->d_sweeps);
-    (void)hipFree(h->d_doc_order); (void)hipFree(h->d_partial); (void)hipFree(h->d_rowsum); (void)hipFree(h->d_esum); (void)hipFree(h->d_gsum); (void)hipFree(h->d_partial_g);
+    (void)hipFree(h->d_doc_order); (void)hipFree(h->d_partial); (void)hipFree(h->d_rowsum); (void)hipFree(h->d_esum);
     (void)hipFree(h->d_doc_val); (void)hipFree(h->d_elbo); (void)hipFree(h->d_iters);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -1346,7 +1343,7 @@ extern "C" int tmvb_lda_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
         (rc = dmalloc(&h->d_beta[1], KPV)) || (rc = dmalloc(&h->d_stats, KV + K)) || (rc = dmalloc(&h->d_gamma, KM)) ||
         (rc = dmalloc(&h->d_elog, KM)) || (rc = dmalloc(&h->d_elog_old, KM)) || (rc = dmalloc(&h->d_sweeps, (size_t)h->M)) ||
         (rc = dmalloc(&h->d_doc_order, (size_t)h->M)) || (rc = dmalloc(&h->d_partial, (size_t)TMVB_REDUCE_BLOCKS * K)) ||
-        (rc = dmalloc(&h->d_rowsum, K)) || (rc = dmalloc(&h->d_esum, K)) || (rc = dmalloc(&h->d_gsum, K)) || (rc = dmalloc(&h->d_partial_g, (size_t)TMVB_REDUCE_BLOCKS * K)) || (rc = dmalloc(&h->d_doc_val, (size_t)h->M)) ||
+        (rc = dmalloc(&h->d_rowsum, K)) || (rc = dmalloc(&h->d_esum, K)) ||  (rc = dmalloc(&h->d_doc_val, (size_t)h->M)) ||
         (rc = dmalloc(&h->d_elbo, 1)) || (rc = dmalloc(&h->d_iters, 1)) || (rc = dmalloc(&h->d_wtok, tmvb_termstats_recomputes(h->KP, h->KP / 4 <= 64) ? (size_t)1 : (size_t)corp->info.nnz)) ||   // stored weights: K > 128 only
        
         (rc = dmalloc(&h->d_E, (size_t)((h->KP + 31) / 32 * 32) * h->M + 4))) {
@@ -1496,13 +1493,6 @@ extern "C" int tmvb_lda_get_state(tmvb_lda* h, double* alpha, double* beta, doub
 static int lda_estep_impl(tmvb_lda* h, int32_t viter, double vtol);
 
 // stream of the side chain (TMVB_LDA_SIDE_STREAM: experiment with the stream -> hardware-queue mapping)
-// row sums of the statistics from the column sums of gamma (see the side chain of lda_estep_impl)
-__global__ void lda_rowsum_gamma_kernel(const double* __restrict__ gsum, const double* __restrict__ alpha, double M, int K, double* __restrict__ rowsum)
-{
-    const int i = threadIdx.x;
-    if (i < K) rowsum[i] = gsum[i] - M * alpha[i];
-}
-
 static int lda_side_index()
 {
     static const int ix = [] { const char* e = getenv("TMVB_LDA_SIDE_STREAM"); const int v = e ? atoi(e) : (int)tmvb_lda::SIDE; return (v >= 0 && v < (int)tmvb_lda::NAUX) ? v : (int)tmvb_lda::SIDE; }();
@@ -1682,26 +1672,13 @@ static int lda_estep_impl(tmvb_lda* h, int32_t viter, double vtol)
     }
     // Elogtheta_sum (update_alpha!'s input, src/LDA.jl:98) under the statistics pass
     {
-        // ... and, in the same pair of launches, the column sums of gamma: the row sums update_beta! normalises by are
-        //   sum_v S[v][k] = sum_d sum_n c_n phi_nk = sum_d (gamma_dk - alpha_k)
-        // (the statistics pass recomputes exactly the phi of the sweep that produced gamma), so update_beta! need not read the
-        // K x V statistics a second time for them: two launches (17 + 5.5 us) off the tail of every iteration (round 4).  One
-        // context only -- a sharded handle needs the row sums of the all-reduced statistics.
-        static const bool gsum_on = [] { const char* e = getenv("TMVB_LDA_ROWSUM_GAMMA"); return !(e && atoi(e) == 0); }();
-        int rc;
-        h->rowsum_fresh = false;
-        if (gsum_on && h->K <= 64 && !h->distributed && !(p.debug & 1) && p.viter > 0) {   // (no sweep: gamma is not this pass's phi)
-            rc = tmvb_colsum2(ctx, h->K, tmvb_colsum_job{h->d_elog, h->M, h->d_partial_side, h->d_esum, h->d_stats + (size_t)h->K * h->V},
-                              tmvb_colsum_job{h->d_gamma, h->M, h->d_partial_g, h->d_gsum, nullptr}, side);
-            if (rc) return rc;
-            // (before update_alpha!'s kernel, which is launched on this stream later and rewrites alpha)
-            hipLaunchKernelGGL(lda_rowsum_gamma_kernel, dim3(1), dim3(64), 0, side, h->d_gsum, h->d_alpha_d, (double)h->M, h->K, h->d_rowsum);
-            TMVB_HIP(hipGetLastError());
-            h->rowsum_fresh = true;
-        } else {
-            rc = tmvb_colsum(ctx, h->nslot, h->K, h->d_elog, h->M, h->d_partial_side, h->d_esum, h->d_stats + (size_t)h->K * h->V, side);
-            if (rc) return rc;
-        }
+        // (Round 4, measured and dropped: the row sums update_beta! normalises by are sum_v S[v][k] = sum_d (gamma_dk - alpha_k), so the column
+        // sums of gamma -- one more job of this launch pair -- would take colsum(S) (17 + 5.5 us) off the tail of every iteration.  On the whole
+        // corpus the tail is not what the next iteration waits for (1297.5 / 1302.4 it/s with, 1299.0 / 1274.0 without); on a 16 100-document
+        // shard THIS side chain is -- document kernels -> column sums -> update_alpha! (42 us on one wave) -> next E-step -- and the extra job
+        // lengthens it: period 186.8 us against 178.9 (timelines of run r4ag).  Stream priorities for the chain changed nothing either.)
+        int rc = tmvb_colsum(ctx, h->nslot, h->K, h->d_elog, h->M, h->d_partial_side, h->d_esum, h->d_stats + (size_t)h->K * h->V, side);
+        if (rc) return rc;
         TMVB_HIP(hipEventRecord(h->ev_side, side));
         h->side_pending = true;
         h->esum_fresh = true; h->esum_side = true;
@@ -1910,13 +1887,7 @@ extern "C" int tmvb_lda_update_beta(tmvb_lda* h)
         TMVB_HIP(hipEventRecord(h->ev_mark, ctx->stream));
         h->mark_valid = true;
     }
-    int rc = TMVB_OK;
-    if (h->rowsum_fresh && h->stats_fresh && !h->distributed) {     // the side chain of the E-step left them (lda_rowsum_gamma_kernel)
-        rc = lda_join_side(h);
-        h->rowsum_fresh = false;
-    } else {
-        rc = colsum(h, h->d_stats, h->V, h->d_rowsum, nullptr);
-    }
+    int rc = colsum(h, h->d_stats, h->V, h->d_rowsum, nullptr);
     if (rc) return rc;
     const int64_t total = (int64_t)h->KP * h->V;
     int nb = (int)std::min<int64_t>(2048, std::max<int64_t>(1, (total + 255) / 256));
