@@ -55,6 +55,20 @@ void tmvb_release_stream(hipStream_t st)
     if (st && !tmvb_streams_pooled()) (void)hipStreamDestroy(st);
 }
 
+unsigned tmvb_event_flags()
+{
+    static const unsigned f = [] {
+        // default 1: the events order streams of ONE device, and every host read goes through a stream synchronisation or a copy, so the
+        // system-scope fence of a default event buys nothing -- and costs: a 16 100-document LDA shard, whose iteration crosses streams four
+        // times, runs 0.172 / 0.173 ms per iteration without it against 0.187 / 0.182 with (run r4ai, alternating); whole corpus and CTPF
+        // inside the noise
+        const char* e = getenv("TMVB_EVENT_FLAGS");
+        const int v = e ? atoi(e) : 1;
+        return (unsigned)hipEventDisableTiming | (v == 1 ? (unsigned)hipEventDisableSystemFence : v == 2 ? (unsigned)hipEventReleaseToDevice : 0u);
+    }();
+    return f;
+}
+
 hipStream_t tmvb_pool_stream(int device, int slot, bool high_priority)
 {
     if (!tmvb_streams_pooled()) {                         // TMVB_STREAM_POOL=0: a stream of the caller's own (tmvb_release_stream destroys it)

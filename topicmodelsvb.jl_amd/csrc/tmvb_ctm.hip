@@ -1533,13 +1533,13 @@ extern "C" int tmvb_ctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
     TMVB_HIP(hipMemsetAsync(h->d_beta[1], 0, KPV * sizeof(float), ctx->stream));
     TMVB_HIP(hipEventCreate(&h->ev0));
     TMVB_HIP(hipEventCreate(&h->ev1));
-    TMVB_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-    TMVB_HIP(hipEventCreateWithFlags(&h->ev_spec, hipEventDisableTiming));
-    TMVB_HIP(hipEventCreateWithFlags(&h->ev_spec2, hipEventDisableTiming));
+    TMVB_HIP(hipEventCreateWithFlags(&h->ev_fork, tmvb_event_flags()));
+    TMVB_HIP(hipEventCreateWithFlags(&h->ev_spec, tmvb_event_flags()));
+    TMVB_HIP(hipEventCreateWithFlags(&h->ev_spec2, tmvb_event_flags()));
     for (int a = 0; a < tmvb_ctm::NAUX; ++a) {
         h->aux[a] = tmvb_pool_stream(ctx->device, 1 + a);
         TMVB_REQUIRE(h->aux[a] != nullptr, TMVB_EHIP, "hipStreamCreate failed");
-        TMVB_HIP(hipEventCreateWithFlags(&h->ev_join[a], hipEventDisableTiming));
+        TMVB_HIP(hipEventCreateWithFlags(&h->ev_join[a], tmvb_event_flags()));
     }
     TMVB_HIP(hipStreamSynchronize(ctx->stream));
     // constructor state, src/CTM.jl:37-48: mu = 0, sigma = invsigma = I, lambda = 0, vsq = 1, logzeta = 0.5; beta uniform

@@ -1392,7 +1392,7 @@ extern "C" int tmvb_ctpf_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmv
     TMVB_HIP(hipMemsetAsync(h->d_sweeps, 0, std::max<size_t>((size_t)h->M, 1), ctx->stream));
     TMVB_HIP(hipEventCreate(&h->ev0));
     TMVB_HIP(hipEventCreate(&h->ev1));
-    TMVB_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    TMVB_HIP(hipEventCreateWithFlags(&h->ev_fork, tmvb_event_flags()));
     for (int a = 0; a < tmvb_ctpf::NAUX; ++a) {
         // aux[1] carries the few multi-wave (long) documents next to the chain's one big launch: at the default priority its 512-thread
         // workgroups find no CU with eight free wave slots until the chain's launch drains and then add their whole run time to the
@@ -1400,7 +1400,7 @@ extern "C" int tmvb_ctpf_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmv
         static const bool long_prio = [] { const char* e = getenv("TMVB_CTPF_LONG_PRIO"); return !(e && atoi(e) == 0); }();
         h->aux[a] = tmvb_pool_stream(ctx->device, 1 + a, a == 1 && long_prio);
         TMVB_REQUIRE(h->aux[a] != nullptr, TMVB_EHIP, "hipStreamCreate failed");
-        TMVB_HIP(hipEventCreateWithFlags(&h->ev_join[a], hipEventDisableTiming));
+        TMVB_HIP(hipEventCreateWithFlags(&h->ev_join[a], tmvb_event_flags()));
     }
     TMVB_HIP(hipStreamSynchronize(ctx->stream));
     // constructor state src/CTPF.jl:81-100: he = 1, rates = 1, gimel = zayin = 1; alef is drawn with Julia's RNG (:83): 1 here

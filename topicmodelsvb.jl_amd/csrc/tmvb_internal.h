@@ -25,6 +25,9 @@ void tmvb_set_error(const char* fmt, ...);
 // configurations in a fresh process instead.  What fixed the sequences measured is in tmvb_core.hip (tmvb_env_defaults: eight hardware
 // queues) and tmvb_lda.hip (the side chain on aux[1]); the pool stays as a switch.
 hipStream_t tmvb_pool_stream(int device, int slot, bool high_priority = false);
+// Flags of the library's ordering events (stream forks and joins on ONE device).  TMVB_EVENT_FLAGS: 0 = hipEventDisableTiming,
+// 1 (default) = | hipEventDisableSystemFence, 2 = | hipEventReleaseToDevice (tmvb_core.hip)
+unsigned tmvb_event_flags();
 void tmvb_release_stream(hipStream_t st);            // no-op for pooled streams (TMVB_STREAM_POOL=0: destroys the caller's own stream)
 bool tmvb_streams_pooled();
 

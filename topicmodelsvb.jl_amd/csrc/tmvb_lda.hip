@@ -1391,13 +1391,13 @@ extern "C" int tmvb_lda_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
                 rc = tmvb_build_inv_index(ctx, h->M, h->V, corp->h_doc_ptr.data(), corp->h_terms.data(), corp->h_counts.data(),
                                           &h->pieces[q], doc_piece.data(), q);
                 slots = std::max(slots, (size_t)h->pieces[q].n_slots);
-                if (!rc && hipEventCreateWithFlags(&h->ev_piece[q], hipEventDisableTiming) != hipSuccess) rc = TMVB_EHIP;
+                if (!rc && hipEventCreateWithFlags(&h->ev_piece[q], tmvb_event_flags()) != hipSuccess) rc = TMVB_EHIP;
             }
         } else {
             rc = tmvb_corpus_term_index(corp);
             slots = (size_t)corp->term_index.n_slots;
             h->ev_piece.assign(1, nullptr);
-            if (!rc && hipEventCreateWithFlags(&h->ev_piece[0], hipEventDisableTiming) != hipSuccess) rc = TMVB_EHIP;
+            if (!rc && hipEventCreateWithFlags(&h->ev_piece[0], tmvb_event_flags()) != hipSuccess) rc = TMVB_EHIP;
         }
         if (!rc) rc = dmalloc(&h->d_ts_partial, slots * (K + 1));
         if (rc) return rc;
@@ -1408,16 +1408,16 @@ extern "C" int tmvb_lda_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
     { const char* t = getenv("TMVB_ESTEP_TIMING"); h->timing = t && atoi(t) != 0; }
     TMVB_HIP(hipEventCreate(&h->ev0));
     TMVB_HIP(hipEventCreate(&h->ev1));
-    TMVB_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-    TMVB_HIP(hipEventCreateWithFlags(&h->ev_docs, hipEventDisableTiming));
-    TMVB_HIP(hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming));
-    TMVB_HIP(hipEventCreateWithFlags(&h->ev_chain, hipEventDisableTiming));
-    TMVB_HIP(hipEventCreateWithFlags(&h->ev_mark, hipEventDisableTiming));
+    TMVB_HIP(hipEventCreateWithFlags(&h->ev_fork, tmvb_event_flags()));
+    TMVB_HIP(hipEventCreateWithFlags(&h->ev_docs, tmvb_event_flags()));
+    TMVB_HIP(hipEventCreateWithFlags(&h->ev_side, tmvb_event_flags()));
+    TMVB_HIP(hipEventCreateWithFlags(&h->ev_chain, tmvb_event_flags()));
+    TMVB_HIP(hipEventCreateWithFlags(&h->ev_mark, tmvb_event_flags()));
     if ((rc = dmalloc(&h->d_partial_side, (size_t)TMVB_REDUCE_BLOCKS * K)) || (rc = dmalloc(&h->d_pw_partial, 2048))) return rc;
     for (int a = 0; a < tmvb_lda::NAUX; ++a) {
         h->aux[a] = tmvb_pool_stream(ctx->device, 1 + a);
         TMVB_REQUIRE(h->aux[a] != nullptr, TMVB_EHIP, "hipStreamCreate failed");
-        TMVB_HIP(hipEventCreateWithFlags(&h->ev_join[a], hipEventDisableTiming));
+        TMVB_HIP(hipEventCreateWithFlags(&h->ev_join[a], tmvb_event_flags()));
     }
     TMVB_HIP(hipMemsetAsync(h->d_beta[0], 0, KPV * sizeof(float), ctx->stream));
     TMVB_HIP(hipMemsetAsync(h->d_beta[1], 0, KPV * sizeof(float), ctx->stream));
@@ -1780,11 +1780,11 @@ static int lda_ar_prepare(tmvb_lda* h)
                      (long long)slot.n_slots, (long long)old_slots);
         while ((int)h->ev_slice.size() < S) {
             hipEvent_t ev = nullptr;
-            TMVB_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            TMVB_HIP(hipEventCreateWithFlags(&ev, tmvb_event_flags()));
             h->ev_slice.push_back(ev);
         }
-        if (!h->ev_comm) TMVB_HIP(hipEventCreateWithFlags(&h->ev_comm, hipEventDisableTiming));
-        if (!h->ev_tail) TMVB_HIP(hipEventCreateWithFlags(&h->ev_tail, hipEventDisableTiming));
+        if (!h->ev_comm) TMVB_HIP(hipEventCreateWithFlags(&h->ev_comm, tmvb_event_flags()));
+        if (!h->ev_tail) TMVB_HIP(hipEventCreateWithFlags(&h->ev_tail, tmvb_event_flags()));
     }
     h->ar_slices = S;
     h->ar_comm = h->comm;
@@ -1815,8 +1815,8 @@ extern "C" int tmvb_lda_estep_allreduce(tmvb_lda* h, int32_t viter, double vtol)
     const int64_t K = h->K, V = h->V;
     tmvb_ctx* ctx = h->ctx;
     hipStream_t cs = h->aux[tmvb_lda::AR];
-    if (!h->ev_comm) TMVB_HIP(hipEventCreateWithFlags(&h->ev_comm, hipEventDisableTiming));
-    if (!h->ev_tail) TMVB_HIP(hipEventCreateWithFlags(&h->ev_tail, hipEventDisableTiming));
+    if (!h->ev_comm) TMVB_HIP(hipEventCreateWithFlags(&h->ev_comm, tmvb_event_flags()));
+    if (!h->ev_tail) TMVB_HIP(hipEventCreateWithFlags(&h->ev_tail, tmvb_event_flags()));
     if (tail_on_side) {
         TMVB_HIP(hipStreamWaitEvent(cs, h->ev_side, 0));                  // NOT the context's stream: the statistics pass is queued on it
     } else {
