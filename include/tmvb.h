@@ -221,6 +221,13 @@ int tmvb_lda_set_comm(tmvb_lda* h, tmvb_comm* comm, int64_t M_total);
  * postings per term (V doubles) to agree on the cuts and the order.  Every rank must call it the same number of times; results
  * are bit-identical to the three-call form's.  TMVB_EINVAL without a communicator. */
 int tmvb_lda_estep_allreduce(tmvb_lda* h, int32_t viter, double vtol);
+
+/* The slab plan tmvb_lda_estep_allreduce derives from the GLOBAL postings per term (host arithmetic only, no device: every rank
+ * computes the same plan from the same all-reduced counts).  counts[V] >= 0; want >= 1 slabs asked for.  Out: *slices = S (<= want,
+ * <= V, 1 if every count is zero), cuts[0..S] (slab s = term ids [cuts[s], cuts[s + 1]), cuts[0] = 0, cuts[S] = V; equal shares of
+ * postings(v) / nnz + 1 / V), order[0..S) (the slabs in issue order: Johnson's rule for pass-then-wire).  The caller provides
+ * want + 1 and want entries. */
+int tmvb_allreduce_plan(const double* counts, int64_t V, int32_t want, int64_t* cuts, int32_t* order, int32_t* slices);
 /* One host thread, n GPUs: hs[i] carries the i-th communicator of tmvb_comm_create_rccl_all (n = 1: same as
  * tmvb_lda_train).  The n all-reduces of an iteration are issued as one RCCL group. */
 int tmvb_lda_train_group(tmvb_lda* const* hs, int32_t n, int32_t iter, double tol, int32_t niter, double ntol,

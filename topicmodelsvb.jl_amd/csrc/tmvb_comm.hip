@@ -12,6 +12,7 @@
 
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 
@@ -262,5 +263,48 @@ int tmvb_comm_allreduce_group(tmvb_comm* const* comms, void* const* dev_ptrs, co
     ncclResult_t r = g_rccl.GroupEnd();
     if (rc) return rc;
     if (r != ncclSuccess) { tmvb_set_error("ncclGroupEnd failed: %s", g_rccl.GetErrorString(r)); return TMVB_ERCCL; }
+    return TMVB_OK;
+}
+
+// ---- the plan of a sliced all-reduce (tmvb_lda_estep_allreduce): pure host arithmetic on the GLOBAL postings per term, so that every
+// rank derives the same slabs in the same order.  Cuts: equal shares of  postings(v) / nnz + 1 / V  (half a slice's weight is pass
+// time, half is bytes on the wire).  Order: Johnson's rule for the two-machine flow shop (statistics pass, then collective) -- slices
+// with less pass than wire first, cheapest pass first; then the others, most wire first.
+extern "C" int tmvb_allreduce_plan(const double* counts, int64_t V, int32_t want, int64_t* cuts, int32_t* order, int32_t* slices)
+{
+    TMVB_REQUIRE(counts && cuts && order && slices && V >= 0 && want >= 1, TMVB_EINVAL, "tmvb_allreduce_plan: bad argument");
+    int S = (int)std::min<int64_t>((int64_t)want, std::max<int64_t>(V, 1));
+    double tot = 0.0;
+    for (int64_t v = 0; v < V; ++v) { TMVB_REQUIRE(counts[v] >= 0.0, TMVB_EINVAL, "tmvb_allreduce_plan: negative count"); tot += counts[v]; }
+    if (tot <= 0.0) S = 1;
+    std::vector<int64_t> c(1, 0);
+    if (S > 1) {
+        double run = 0.0;
+        for (int64_t v = 0; v < V; ++v) {
+            run += 0.5 * counts[v] / tot + 0.5 / (double)V;
+            while ((int)c.size() < S && run >= (double)c.size() / (double)S) c.push_back(v + 1);
+        }
+        while ((int)c.size() < S) c.push_back(V);
+    }
+    c.push_back(V);
+    std::vector<int> ord;
+    if (S > 1) {
+        std::vector<double> pass((size_t)S, 0.0), wire((size_t)S, 0.0);
+        for (int sl = 0; sl < S; ++sl) {
+            for (int64_t v = c[(size_t)sl]; v < c[(size_t)sl + 1]; ++v) pass[(size_t)sl] += counts[v] / tot;
+            wire[(size_t)sl] = (double)(c[(size_t)sl + 1] - c[(size_t)sl]) / (double)V;
+        }
+        std::vector<int> first, second;
+        for (int sl = 0; sl < S; ++sl) (pass[(size_t)sl] < wire[(size_t)sl] ? first : second).push_back(sl);
+        std::stable_sort(first.begin(), first.end(), [&](int a, int b) { return pass[(size_t)a] < pass[(size_t)b]; });
+        std::stable_sort(second.begin(), second.end(), [&](int a, int b) { return wire[(size_t)a] > wire[(size_t)b]; });
+        ord = first;
+        ord.insert(ord.end(), second.begin(), second.end());
+    } else {
+        ord.assign(1, 0);
+    }
+    for (int sl = 0; sl <= S; ++sl) cuts[sl] = c[(size_t)sl];
+    for (int sl = 0; sl < S; ++sl) order[sl] = ord[(size_t)sl];
+    *slices = S;
     return TMVB_OK;
 }

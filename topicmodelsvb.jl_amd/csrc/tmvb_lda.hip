@@ -1740,32 +1740,17 @@ static int lda_ar_prepare(tmvb_lda* h)
         if (rc) return rc;
         TMVB_HIP(e);
     }
-    double tot = 0.0;
-    for (double c : cnt) tot += c;
-    if (tot <= 0.0) S = 1;
-    h->ar_cuts.assign(1, 0);
-    if (S > 1) {
-        double run = 0.0;
-        for (int64_t v = 0; v < V; ++v) {
-            run += 0.5 * cnt[(size_t)v] / tot + 0.5 / (double)V;
-            while ((int)h->ar_cuts.size() < S && run >= (double)h->ar_cuts.size() / (double)S) h->ar_cuts.push_back(v + 1);
-        }
-        while ((int)h->ar_cuts.size() < S) h->ar_cuts.push_back(V);
+    {   // cuts and order from the GLOBAL counts: a host function of its own (tmvb_allreduce_plan, tmvb_comm.hip), tested on the CPU
+        std::vector<int64_t> cuts((size_t)S + 1);
+        std::vector<int32_t> order((size_t)S);
+        int32_t s_out = 1;
+        int prc = tmvb_allreduce_plan(cnt.data(), V, S, cuts.data(), order.data(), &s_out);
+        if (prc) return prc;
+        S = s_out;
+        h->ar_cuts.assign(cuts.begin(), cuts.begin() + S + 1);
+        h->ar_order.assign(order.begin(), order.begin() + S);
     }
-    h->ar_cuts.push_back(V);
-    h->ar_order.clear();
     if (S > 1) {
-        std::vector<double> pass((size_t)S, 0.0), wire((size_t)S, 0.0);
-        for (int sl = 0; sl < S; ++sl) {
-            for (int64_t v = h->ar_cuts[(size_t)sl]; v < h->ar_cuts[(size_t)sl + 1]; ++v) pass[(size_t)sl] += cnt[(size_t)v] / tot;
-            wire[(size_t)sl] = (double)(h->ar_cuts[(size_t)sl + 1] - h->ar_cuts[(size_t)sl]) / (double)V;
-        }
-        std::vector<int> first, second;
-        for (int sl = 0; sl < S; ++sl) (pass[(size_t)sl] < wire[(size_t)sl] ? first : second).push_back(sl);
-        std::stable_sort(first.begin(), first.end(), [&](int a, int b) { return pass[(size_t)a] < pass[(size_t)b]; });
-        std::stable_sort(second.begin(), second.end(), [&](int a, int b) { return wire[(size_t)a] > wire[(size_t)b]; });
-        h->ar_order = first;
-        h->ar_order.insert(h->ar_order.end(), second.begin(), second.end());
         // the last piece's index again, slice-major
         tmvb_inv_index fresh;
         const bool whole = h->pieces.empty();
