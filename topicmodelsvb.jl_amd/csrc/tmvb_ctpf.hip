@@ -566,6 +566,19 @@ __global__ __launch_bounds__(64 * W) void ctpf_estep_grid_long_kernel(CtpfParams
     CTPF_GRID_LDS(W);
     ctpf_estep_grid_body<LPR, NPT, NPR, W>(p, p.doc_order[first + blockIdx.x], topic_of_lane, ef_all, xch);
 }
+// The two four-wave classes in ONE launch (round 4): the first `count_a` workgroups run the (3, 3) body, the others the (2, 4) body -- the
+// host's own assignment, so every document's arithmetic is what the two launches did.  SYN-CITEU has 3 documents of the first class and
+// 436 of the second; as two launches on one stream the three ran 39 us of pure latency IN FRONT of the 436 (E-step 74 us where the widest
+// single-wave launch ends at 55), and a stream of their own cost more than it brought (a fifth active stream: 0.204 -> 0.235 / 0.255 ms
+// per iteration).  Both bodies need 116 VGPRs, so the mixed launch costs no occupancy.
+template <int LPR>
+__global__ __launch_bounds__(256) void ctpf_estep_grid_long2_kernel(CtpfParams p, int64_t first, const int* __restrict__ topic_of_lane, int count_a)
+{
+    CTPF_GRID_LDS(4);
+    const int d = p.doc_order[first + blockIdx.x];
+    if ((int)blockIdx.x < count_a) ctpf_estep_grid_body<LPR, 3, 3, 4>(p, d, topic_of_lane, ef_all, xch);
+    else ctpf_estep_grid_body<LPR, 2, 4, 4>(p, d, topic_of_lane, ef_all, xch);
+}
 // single-wave class of a document (wave-uniform)
 template <int LPR, int BW>
 __device__ __forceinline__ void ctpf_estep_grid_any(const CtpfParams& p, const int d, const int* __restrict__ topic_of_lane,
@@ -615,6 +628,7 @@ template <int LPR>
 static void ctpf_launch_grid(const tmvb_bucket& b, dim3 grid, hipStream_t st, const CtpfParams& p, int64_t first, const int* tol)
 {
 
+    if (b.waves == 4 && b.grid_np == 96) { hipLaunchKernelGGL((ctpf_estep_grid_long2_kernel<LPR>), grid, dim3(256), 0, st, p, first, tol, (int)b.grid_np2); return; }
     if (b.waves == 4 && b.grid_np == 2) { hipLaunchKernelGGL((ctpf_estep_grid_long_kernel<LPR, 2, 4, 4>), grid, dim3(256), 0, st, p, first, tol); return; }
     if (b.waves == 4) { hipLaunchKernelGGL((ctpf_estep_grid_long_kernel<LPR, 3, 3, 4>), grid, dim3(256), 0, st, p, first, tol); return; }
     if (b.grid_np == 99) { hipLaunchKernelGGL((ctpf_estep_grid_any_kernel<LPR>), grid, dim3(64), 0, st, p, first, tol); return; }
@@ -1565,6 +1579,14 @@ extern "C" int tmvb_ctpf_estep(tmvb_ctpf* h, int32_t viter, double vtol)
             static const bool gany = [] { const char* e = getenv("TMVB_CTPF_GRID_ANY"); return !(e && atoi(e) == 0); }();
             hipStream_t st = b.waves > 1 ? h->aux[1] : chain_st;
             tmvb_bucket bb = b;
+            // the (3, 3) four-wave bucket and the (2, 4) one behind it as one launch (ctpf_estep_grid_long2_kernel); TMVB_CTPF_LONG_MERGE=0: two
+            const char* elm = getenv("TMVB_CTPF_LONG_MERGE");
+            if (b.waves == 4 && b.grid_np == 3 && b.grid_np2 == 3 && bi + 1 < nb && h->buckets[bi + 1].waves == 4 && h->buckets[bi + 1].grid_np == 2 &&
+                h->buckets[bi + 1].grid_np2 == 4 && h->buckets[bi + 1].first == b.first + b.count && b.count < (1 << 30) && !(elm && atoi(elm) == 0)) {
+                bb.grid_np = 96; bb.grid_np2 = (int)b.count; bb.count = b.count + h->buckets[bi + 1].count;
+                grid = dim3((unsigned)bb.count);
+                ++bi;
+            }
             // (round 4) the single-wave classes as TWO launches by register need (ctpf_estep_grid_narrow_kernel / _wide_kernel) unless
             // TMVB_CTPF_SPLIT=0 (read per call: the tests run both)
             const char* es = getenv("TMVB_CTPF_SPLIT");
