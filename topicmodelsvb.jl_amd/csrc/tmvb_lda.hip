@@ -1412,7 +1412,7 @@ extern "C" int tmvb_lda_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
     TMVB_HIP(hipEventCreateWithFlags(&h->ev_docs, tmvb_event_flags()));
     TMVB_HIP(hipEventCreateWithFlags(&h->ev_side, tmvb_event_flags()));
     TMVB_HIP(hipEventCreateWithFlags(&h->ev_chain, tmvb_event_flags()));
-    TMVB_HIP(hipEventCreateWithFlags(&h->ev_mark, tmvb_event_flags()));
+    TMVB_HIP(hipEventCreateWithFlags(&h->ev_mark, hipEventDisableTiming /* may sit behind a collective: keeps the system-scope fence */));
     if ((rc = dmalloc(&h->d_partial_side, (size_t)TMVB_REDUCE_BLOCKS * K)) || (rc = dmalloc(&h->d_pw_partial, 2048))) return rc;
     for (int a = 0; a < tmvb_lda::NAUX; ++a) {
         h->aux[a] = tmvb_pool_stream(ctx->device, 1 + a);
@@ -1768,8 +1768,6 @@ static int lda_ar_prepare(tmvb_lda* h)
             TMVB_HIP(hipEventCreateWithFlags(&ev, tmvb_event_flags()));
             h->ev_slice.push_back(ev);
         }
-        if (!h->ev_comm) TMVB_HIP(hipEventCreateWithFlags(&h->ev_comm, tmvb_event_flags()));
-        if (!h->ev_tail) TMVB_HIP(hipEventCreateWithFlags(&h->ev_tail, tmvb_event_flags()));
     }
     h->ar_slices = S;
     h->ar_comm = h->comm;
@@ -1800,8 +1798,10 @@ extern "C" int tmvb_lda_estep_allreduce(tmvb_lda* h, int32_t viter, double vtol)
     const int64_t K = h->K, V = h->V;
     tmvb_ctx* ctx = h->ctx;
     hipStream_t cs = h->aux[tmvb_lda::AR];
-    if (!h->ev_comm) TMVB_HIP(hipEventCreateWithFlags(&h->ev_comm, tmvb_event_flags()));
-    if (!h->ev_tail) TMVB_HIP(hipEventCreateWithFlags(&h->ev_tail, tmvb_event_flags()));
+    // the two events recorded BEHIND collectives keep the default system-scope fence: what they order was written with the help of other
+    // devices (the ordering events of the single-device plans do without it, tmvb_event_flags)
+    if (!h->ev_comm) TMVB_HIP(hipEventCreateWithFlags(&h->ev_comm, hipEventDisableTiming));
+    if (!h->ev_tail) TMVB_HIP(hipEventCreateWithFlags(&h->ev_tail, hipEventDisableTiming));
     if (tail_on_side) {
         TMVB_HIP(hipStreamWaitEvent(cs, h->ev_side, 0));                  // NOT the context's stream: the statistics pass is queued on it
     } else {
