@@ -1984,7 +1984,7 @@ extern "C" int tmvb_lda_set_comm(tmvb_lda* h, tmvb_comm* comm, int64_t M_total)
     int rc = tmvb_lda_set_distributed(h, comm ? M_total : h->M, comm != nullptr);
     if (rc) return rc;
     h->comm = comm;
-    if (h->ar_comm != comm) h->ar_comm = nullptr;       // the slicing plan was agreed on another communicator: agree again
+    h->ar_comm = nullptr;                               // the plan is agreed anew on every attach (a new communicator may live at an old address)
     return TMVB_OK;
 }
 
