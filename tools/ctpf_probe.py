@@ -3,6 +3,7 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+os.environ.setdefault("TMVB_ESTEP_TIMING", "1")      # last_estep_ms needs the library's timing events
 import tmvb_amd
 tm = tmvb_amd.pkg
 K = int(os.environ.get("K", 50))

@@ -238,8 +238,20 @@ def ctpf(burnin=300, warmup=10, steps=200, cpu=True):
         gm.estep(); gm.reduce_docs(); gm.mstep()
     cold = window(it, gm.synchronize, 0, 5, 50)
     sec = window(it, gm.synchronize, max(burnin - 55 - warmup - steps, 0), warmup, steps)
-    es_ms = gm.last_estep_ms()
     hist = gm.sweep_hist().tolist()
+    # the E-step's own time: from a second model created with TMVB_ESTEP_TIMING=1 (the library records its two timing events -- default
+    # events, a system-scope release each, on the stream the whole iteration runs on -- only then; the timed model runs without them)
+    os.environ["TMVB_ESTEP_TIMING"] = "1"
+    gt = tm.gpuCTPF(pc, K)
+    del os.environ["TMVB_ESTEP_TIMING"]
+    es = []
+    for i in range(burnin + 10):
+        gt.estep()
+        if i >= burnin:
+            es.append(gt.last_estep_ms())
+        gt.reduce_docs(); gt.mstep()
+    es_ms = float(np.mean(es))
+    gt.close()
     # a checked iteration (update_elbo! on the device after every M-step); the first call builds the per-document constants
     gm.update_elbo()
     gm.synchronize(); t0 = time.perf_counter()

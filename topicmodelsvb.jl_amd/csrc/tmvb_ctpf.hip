@@ -1246,6 +1246,7 @@ struct tmvb_ctpf {
     std::vector<tmvb_bucket> buckets;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    bool timing = false;               // TMVB_ESTEP_TIMING=1 (read at creation): record the events behind tmvb_ctpf_last_estep_ms
     static constexpr int NAUX = 4;
     hipStream_t aux[NAUX] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[NAUX] = {nullptr, nullptr, nullptr, nullptr};
@@ -1404,6 +1405,9 @@ extern "C" int tmvb_ctpf_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmv
     if (h->M) TMVB_HIP(hipMemcpyAsync(h->d_doc_order, order.data(), (size_t)h->M * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     TMVB_HIP(hipMemsetAsync(h->d_stats, 0, (size_t)h->stats_len() * sizeof(float), ctx->stream));
     TMVB_HIP(hipMemsetAsync(h->d_sweeps, 0, std::max<size_t>((size_t)h->M, 1), ctx->stream));
+    // (the two timing events are default events -- time stamps and a system-scope release each -- on the stream the whole iteration runs on:
+    //  recorded unconditionally they cost every 0.15 ms iteration two barrier packets; round 4, as LDA has it)
+    { const char* t = getenv("TMVB_ESTEP_TIMING"); h->timing = t && atoi(t) != 0; }
     TMVB_HIP(hipEventCreate(&h->ev0));
     TMVB_HIP(hipEventCreate(&h->ev1));
     TMVB_HIP(hipEventCreateWithFlags(&h->ev_fork, tmvb_event_flags()));
@@ -1559,7 +1563,7 @@ extern "C" int tmvb_ctpf_estep(tmvb_ctpf* h, int32_t viter, double vtol)
     p.wtok = h->d_wtok; p.wrdr = h->d_wrdr; p.E1 = h->d_E1; p.E2 = h->d_E2; p.estride = h->estride; p.sweeps = h->d_sweeps;
     p.viter = viter; p.vtol = (float)vtol;
     p.store_w = tmvb_termstats_recomputes(h->KP, h->e_padded) ? 0 : 1;
-    TMVB_HIP(hipEventRecord(h->ev0, ctx->stream));
+    if (h->timing) TMVB_HIP(hipEventRecord(h->ev0, ctx->stream));
     // stream plan as in tmvb_lda_estep for one statistics pass: the register-tile buckets run back to back on the
     // context's stream (the critical chain document kernels -> statistics -> M-step pays kernel boundaries, not ~20 us
     // cross-stream hops: the whole iteration is 0.3 ms), the LDS-tile buckets (long documents) on aux[1]
@@ -1673,7 +1677,7 @@ extern "C" int tmvb_ctpf_estep(tmvb_ctpf* h, int32_t viter, double vtol)
     } else if (rc) {
         return rc;
     }
-    TMVB_HIP(hipEventRecord(h->ev1, ctx->stream));
+    if (h->timing) TMVB_HIP(hipEventRecord(h->ev1, ctx->stream));
     h->timed = true;
     return TMVB_OK;
 }
@@ -1985,6 +1989,7 @@ extern "C" int tmvb_ctpf_sweep_hist(tmvb_ctpf* h, int64_t* hist, int32_t nbins)
 extern "C" int tmvb_ctpf_last_estep_ms(tmvb_ctpf* h, float* ms)
 {
     TMVB_REQUIRE(h && ms, TMVB_EINVAL, "tmvb_ctpf_last_estep_ms: NULL argument");
+    TMVB_REQUIRE(h->timing, TMVB_EINVAL, "tmvb_ctpf_last_estep_ms: E-step timing is off (set TMVB_ESTEP_TIMING=1 before creating the model)");
     TMVB_REQUIRE(h->timed, TMVB_EINVAL, "tmvb_ctpf_last_estep_ms: no E-step has run");
     TMVB_HIP(hipSetDevice(h->ctx->device));
     TMVB_HIP(hipEventSynchronize(h->ev1));
