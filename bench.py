@@ -222,6 +222,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-plateau", action="store_true")
     ap.add_argument("--no-cold", action="store_true")
+    ap.add_argument("--torch-events", action="store_true", help="diagnostics: torch.cuda.Event (default HIP events) around the E-step instead of the library's")
+    ap.add_argument("--no-step-events", action="store_true",
+                    help="diagnostics: no HIP events around the E-step inside the timed window (the line then has no valid roofline block); "
+                         "what the two events per step cost")
     ap.add_argument("--other-configs-inline", action="store_true", help="measure the side configurations in this process instead of fresh ones")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the lines of BASELINE.json's configs 3-5 (LDA K=100, CTM K=50, CTPF K=50) carried under other_configs at N=1")
@@ -334,17 +338,30 @@ def main():
             eng.update_beta(); eng.update_alpha(niter, ntol)
         for _ in range(burnin + warmup):
             one()
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        # HIP events on the stream the kernels are launched on.  The library's (tmvb_event_create: hipEventDisableSystemFence, the flag HIP
+        # documents for timing); torch.cuda.Event's default events perform a system-scope fence each -- two per step cost the timed
+        # window 1.4 % (--torch-events: 1292 / 1295 / 1298 it/s with them, 1321 / 1302 / 1319 with no events at all, run r4bd)
+        if args.torch_events:
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+            rec = lambda e: e.record(eng.stream)
+            ela = lambda a, b2: a.elapsed_time(b2)
+        else:
+            ev = [(eng.ctx.timing_event(), eng.ctx.timing_event()) for _ in range(steps)]
+            rec = lambda e: e.record()
+            ela = lambda a, b2: a.elapsed_ms(b2)
         barrier()
         t_start = time.perf_counter()
         for s in range(steps):
-            ev[s][0].record(eng.stream)           # HIP events on the stream the kernels are launched on
+            if not args.no_step_events:
+                rec(ev[s][0])
             if fused:                             # N > 1: the bracket then holds the E-step AND its (overlapped) collective
                 eng.model.estep_allreduce(viter, vtol)
-                ev[s][1].record(eng.stream)
+                if not args.no_step_events:
+                    rec(ev[s][1])
             else:
                 eng.estep(viter, vtol)
-                ev[s][1].record(eng.stream)
+                if not args.no_step_events:
+                    rec(ev[s][1])
                 eng.reduce_docs()
                 allreduce()
             eng.update_beta()
@@ -355,7 +372,7 @@ def main():
             t = torch.tensor([elapsed], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)          # gloo (CPU tensor)
             elapsed = float(t.item())
-        return elapsed, [a.elapsed_time(b) for a, b in ev]
+        return elapsed, ([ela(a, b2) for a, b2 in ev] if not args.no_step_events else [float('nan')] * steps)
 
     # ---- clocks and first touches (round-3 review: the driver's first window read 8 % below the same build's rate in a process
     # that had already run for a second, while its SECOND window matched): a scratch model of the same shard runs untimed

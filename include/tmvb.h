@@ -69,6 +69,16 @@ int tmvb_device_count(void);
 int tmvb_ctx_create(int32_t device_id, void* hip_stream, tmvb_ctx** out);
 int tmvb_ctx_destroy(tmvb_ctx* ctx);
 int tmvb_ctx_synchronize(tmvb_ctx* ctx);
+
+/* Timing events on the context's stream for a host that measures the library's asynchronous calls (bench.py's HIP-event bracket around
+ * the E-step): HIP events WITH time stamps and WITHOUT the system-scope fence a default event performs when it completes
+ * (hipEventDisableSystemFence -- the flag HIP documents for timing; two default events per 0.77 ms LDA iteration cost it 1.4 %).
+ * tmvb_event_elapsed_ms waits for `stop`.  Events belong to the device of the context that created them. */
+typedef struct tmvb_event tmvb_event;
+int tmvb_event_create(tmvb_ctx* ctx, tmvb_event** out);
+int tmvb_event_record(tmvb_event* ev);                                  /* on the creating context's stream */
+int tmvb_event_elapsed_ms(tmvb_event* start, tmvb_event* stop, float* ms);
+int tmvb_event_destroy(tmvb_event* ev);
 /* Diagnostics: evaluate the engine's fp32 device special functions on host data (the accuracy pins of the tests).
  * which: 0 = digamma (x > 0; src/utils.jl:21-53's algorithm), 1 = exp as used for exp(Elogtheta) (x <= 0 in exact
  * arithmetic), 2 = the rcp-based reciprocal 1/x. */

@@ -149,6 +149,45 @@ extern "C" int tmvb_ctx_destroy(tmvb_ctx* ctx)
     return TMVB_OK;
 }
 
+struct tmvb_event { tmvb_ctx* ctx; hipEvent_t ev; };
+
+extern "C" int tmvb_event_create(tmvb_ctx* ctx, tmvb_event** out)
+{
+    TMVB_REQUIRE(ctx != nullptr && out != nullptr, TMVB_EINVAL, "tmvb_event_create: NULL argument");
+    *out = nullptr;
+    TMVB_HIP(hipSetDevice(ctx->device));
+    hipEvent_t e = nullptr;
+    TMVB_HIP(hipEventCreateWithFlags(&e, hipEventDisableSystemFence));        // time stamps on, system-scope fence off
+    *out = new tmvb_event{ctx, e};
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_event_record(tmvb_event* ev)
+{
+    TMVB_REQUIRE(ev != nullptr, TMVB_EINVAL, "tmvb_event_record: NULL argument");
+    TMVB_HIP(hipSetDevice(ev->ctx->device));
+    TMVB_HIP(hipEventRecord(ev->ev, ev->ctx->stream));
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_event_elapsed_ms(tmvb_event* start, tmvb_event* stop, float* ms)
+{
+    TMVB_REQUIRE(start && stop && ms, TMVB_EINVAL, "tmvb_event_elapsed_ms: NULL argument");
+    TMVB_HIP(hipSetDevice(stop->ctx->device));
+    TMVB_HIP(hipEventSynchronize(stop->ev));
+    TMVB_HIP(hipEventElapsedTime(ms, start->ev, stop->ev));
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_event_destroy(tmvb_event* ev)
+{
+    if (!ev) return TMVB_OK;
+    (void)hipSetDevice(ev->ctx->device);
+    (void)hipEventDestroy(ev->ev);
+    delete ev;
+    return TMVB_OK;
+}
+
 extern "C" int tmvb_ctx_synchronize(tmvb_ctx* ctx)
 {
     TMVB_REQUIRE(ctx != nullptr, TMVB_EINVAL, "tmvb_ctx_synchronize: ctx is NULL");

@@ -115,9 +115,40 @@ class DeviceContext:
     def synchronize(self):
         check(lib().tmvb_ctx_synchronize(self.handle))
 
+    def timing_event(self):
+        """A HIP timing event on this context's stream without the system-scope fence of a default event (tmvb_event_create)."""
+        return TimingEvent(self)
+
     def close(self):
         if self.handle:
             lib().tmvb_ctx_destroy(self.handle)
+            self.handle = VP()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class TimingEvent:
+    """tmvb_event_*: record() on the context's stream; a.elapsed_ms(b) waits for b."""
+
+    def __init__(self, ctx):
+        self.handle = VP()
+        check(lib().tmvb_event_create(ctx.handle, C.byref(self.handle)))
+
+    def record(self):
+        check(lib().tmvb_event_record(self.handle))
+
+    def elapsed_ms(self, stop) -> float:
+        ms = C.c_float(0.0)
+        check(lib().tmvb_event_elapsed_ms(self.handle, stop.handle, C.byref(ms)))
+        return float(ms.value)
+
+    def close(self):
+        if self.handle:
+            lib().tmvb_event_destroy(self.handle)
             self.handle = VP()
 
     def __del__(self):
