@@ -1201,8 +1201,10 @@ static int lda_piece_count(const tmvb_lda* h)
     // measured on SYN-NSF and its shards in the steady state (tools/run_pieces.sh, it/s): 10.9 M tokens 1 / 2 / 3 / 4 / 6 pieces
     // = 717 / 806 / 813 / 803 / ~790; 5.5 M tokens 1354 / 1413 / 1426; 2.7 M tokens 2416 / 2229; 1.4 M tokens 3926 / 3303.
     // Below ~4 M tokens the one-pass plan (critical chain on the context's stream, no cross-stream hops) wins.
+    // K = 100 (LPR = 25; round 4, alternating in one call, SYN-NSF): 2 pieces 871 / 874 it/s, 3 pieces 850 / 852, 4 pieces 867 / 865, 5 pieces 829
     const int64_t nnz = h->corp->info.nnz;
-    return nnz >= (int64_t)(1 << 22) ? 3 : 1;
+    if (nnz < (int64_t)(1 << 22)) return 1;
+    return h->KP / 4 >= 25 ? 2 : 3;
 }
 
 // Cut the register-tile buckets where the running token count crosses a multiple of nnz / P.  The LDS-tile
