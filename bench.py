@@ -309,6 +309,10 @@ def main():
             collective = (f"RCCL {tm.rccl_version()} inside libtmvb_hip.so (tmvb_lda_estep_allreduce: the Elogtheta_sum tail all-reduced on a side stream "
                           f"under the statistics pass, the statistics in {os.environ.get('TMVB_AR_SLICES', '1')} vocabulary slab(s))")
             eng.model.set_comm(comm, corpus.M)
+            if os.environ.get("TMVB_FUSED_ALLREDUCE", "1") == "0":       # the three-call form of rounds 2-3 (escape hatch, also read by the library's train!)
+                collective = f"RCCL {tm.rccl_version()} inside libtmvb_hip.so (tmvb_comm_allreduce on the context stream; TMVB_FUSED_ALLREDUCE=0)"
+                ptr, n = eng.model.stats()
+                return (lambda: comm.allreduce(ptr, n)), comm
             eng.fused_allreduce = True
             return (lambda: None), comm
         if one_gpu_debug:

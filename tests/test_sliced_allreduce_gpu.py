@@ -70,6 +70,8 @@ def _gloo_sum(dist):
 
 
 def _worker(rank, world, initfile, out_dir, slices, M, V, K, iters):
+    if slices == 0:                                        # the three-call form inside train! (TMVB_FUSED_ALLREDUCE=0)
+        os.environ["TMVB_FUSED_ALLREDUCE"] = "0"; slices = 1
     os.environ["TMVB_AR_SLICES"] = str(slices)
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
@@ -114,6 +116,14 @@ def test_world2_sliced_equals_one_collective_bit_for_bit(tmvb):
     gm = _lda(tmvb, corpus, 50)
     traj = gm.train(iter=4, tol=0.0, checkelbo=1, printelbo=False)
     np.testing.assert_allclose(four[0]["traj"], np.array(traj), rtol=2e-6)
+
+
+def test_world2_three_call_escape_hatch_equals_the_fused_train(tmvb):
+    """TMVB_FUSED_ALLREDUCE=0 makes the sharded train! run estep + reduce_docs + ONE all-reduce on the context's stream (rounds 2-3)."""
+    fused, three = _run(1, iters=3), _run(0, iters=3)
+    for r in range(2):
+        for k in ("traj", "alpha", "beta", "gamma"):
+            assert np.array_equal(fused[r][k], three[r][k]), (r, k)
 
 
 def test_world2_more_slices_than_terms_and_an_empty_shard(tmvb):

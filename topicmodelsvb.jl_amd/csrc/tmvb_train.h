@@ -150,7 +150,10 @@ static int tmvb_train_group_loop(const char* who, H* const* hs, int n, int iter,
         ++done;
         bool fused = false;
         if constexpr (tmvb_has_estep_allreduce<Ops, H>::value) {
-            if (sharded && n == 1) { if ((rc = ops.estep_allreduce(hs[0]))) return rc; fused = true; }
+            // (TMVB_FUSED_ALLREDUCE=0: the three-call form of rounds 2-3 -- one collective of the whole buffer on the context's stream -- for a
+            //  first run on hardware where the fused form's two streams of collectives would have to be ruled out as a suspect)
+            static const bool fuse = [] { const char* e = getenv("TMVB_FUSED_ALLREDUCE"); return !(e && atoi(e) == 0); }();
+            if (sharded && n == 1 && fuse) { if ((rc = ops.estep_allreduce(hs[0]))) return rc; fused = true; }
         }
         if (!fused) for (int i = 0; i < n; ++i) if ((rc = ops.estep(hs[i]))) return rc;
         if (!fused) for (int i = 0; i < n; ++i) if ((rc = ops.reduce(hs[i]))) return rc;
