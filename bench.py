@@ -104,6 +104,130 @@ def pmc_traffic(K, M, nnz):
     return tot, f"profiles/{name} (rocprofv3 --pmc, separate passes; 2*FETCH_SIZE+WRITE_SIZE summed over the E-step's dispatches of one iteration)"
 
 
+# ---------------------------------------------------------------------------------------------------------------- the ONE line
+# Round-4 review: the line had grown to 20 KB (per-iteration parity dumps, clock log, paragraphs) and the driver could not parse
+# it.  The contract line on stdout is now SLIM (< 6000 bytes, tests/test_bench_line.py bounds it): the contract fields, and per
+# configuration only the numbers a reader checks.  Everything else -- per-iteration parity rows, per-step E-step times, the clock
+# log, the ELBO-vs-wall-clock curve, tolerances, the explanatory strings, multi_gpu_check's arrays -- goes to bench_detail.json
+# next to this script (and to gpurun_out/ when that directory exists) and to stderr.
+LINE_LIMIT = 6000
+ROOFLINE_KEEP = ("bound", "achieved", "peak", "unit", "frac", "algorithmic_bytes", "traffic", "traffic_over_algorithmic", "valu_issue_frac",
+                 "issue_model_frac", "estep_ms", "estep_ms_median", "kernel_source_hash", "executed_frac", "hbm_frac")
+CPU_KEEP = ("value", "unit", "cores", "kind", "single_thread_value", "sample")
+PARITY_KEEP = ("pass", "worst", "documents", "iterations")
+
+
+def _r(x, sig=7):
+    """floats to `sig` significant digits (the detail file keeps them all)"""
+    if isinstance(x, bool) or x is None:
+        return x
+    if isinstance(x, float):
+        return float(f"{x:.{sig}g}") if x == x and abs(x) != float("inf") else None
+    if isinstance(x, dict):
+        return {k: _r(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, sig) for v in x]
+    return x
+
+
+def _slim_roofline(rf):
+    if not rf:
+        return rf
+    rf = dict(rf)
+    for a in ("algorithmic_bytes_per_estep", "algorithmic_bytes_per_iteration"):
+        if a in rf:
+            rf["algorithmic_bytes"] = rf[a]
+    if rf.get("traffic") and rf.get("algorithmic_bytes") and "traffic_over_algorithmic" not in rf:
+        rf["traffic_over_algorithmic"] = rf["traffic"] / rf["algorithmic_bytes"]
+    out = {k: rf[k] for k in ROOFLINE_KEEP if k in rf}
+    if isinstance(out.get("bound"), str):
+        out["bound"] = out["bound"].split(" ")[0]                # "valu (packed fp32 ...)" -> "valu"
+    return out
+
+
+def _slim_cpu(cb):
+    if not cb or "error" in cb:
+        return cb
+    out = {k: cb[k] for k in CPU_KEEP if k in cb}
+    if "sample" in out:
+        out["sample"] = cb.get("sample_short") or str(out["sample"])[:90]
+    return out
+
+
+def _slim_parity(p):
+    if not p:
+        return p
+    return {k: p[k] for k in PARITY_KEEP if k in p}
+
+
+def _slim_config(line):
+    c = line.get("config") or {}
+    out = {"workload": str(c.get("workload", "")).split(";")[0].split(", steady state")[0][:120]}
+    for k in ("K", "M", "V", "U", "nnz", "nR", "burnin", "parallelism", "collective"):
+        if k in c:
+            out[k] = c[k] if not isinstance(c[k], str) else c[k][:70]
+    return out
+
+
+def slim_line(result):
+    """The contract line from the full result dict (pure function: tests/test_bench_line.py feeds it a canned result)."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    out = {k: result.get(k) for k in keep}
+    out["config"] = _slim_config(result)
+    out["roofline"] = _slim_roofline(result.get("roofline"))
+    out["cpu_baseline"] = _slim_cpu(result.get("cpu_baseline"))
+    out["parity"] = _slim_parity(result.get("parity"))
+    if result.get("cold_start"):
+        out["cold_start"] = {k: result["cold_start"].get(k) for k in ("value", "ms_per_step")}
+    pl = result.get("elbo_plateau")
+    if pl:
+        out["elbo_plateau"] = {k: pl.get(k) for k in ("reached", "seconds", "iterations", "elbo_first", "elbo_last", "last_delta")}
+    mg = result.get("multi_gpu_check")
+    if mg:
+        out["multi_gpu_check"] = {k: mg[k] for k in ("pass", "iterations", "globals_hash_equal", "elbo_rel_vs_n1", "elbo_rel_tolerance", "form", "fallback", "skipped",
+                                                     "shard_nnz_max_over_min") if k in mg}
+    if result.get("other_configs"):
+        oc = {}
+        for name, ln in result["other_configs"].items():
+            if "error" in ln:
+                oc[name] = {"error": str(ln["error"])[:200]}
+                continue
+            o = {k: ln.get(k) for k in ("metric", "value", "unit", "ms_per_step", "estep_ms", "dtype") if k in ln}
+            o["dtype"] = str(o.get("dtype", "f32")).split(" ")[0]
+            o["config"] = _slim_config(ln)
+            o["roofline"] = _slim_roofline(ln.get("roofline"))
+            o["cpu_baseline"] = _slim_cpu(ln.get("cpu_baseline"))
+            o["parity"] = _slim_parity(ln.get("parity"))
+            oc[name] = o
+        out["other_configs"] = oc
+    out["detail"] = "bench_detail.json"
+    out = _r(out)
+    line = json.dumps(out, separators=(",", ":"))
+    if len(line) >= LINE_LIMIT:                                  # never print a line the driver cannot take: shed the side configurations' extras
+        for o in out.get("other_configs", {}).values():
+            for k in ("parity", "cpu_baseline", "config"):
+                if isinstance(o.get(k), dict):
+                    o[k] = {kk: vv for kk, vv in o[k].items() if kk in ("pass", "value", "cores", "workload")}
+        line = json.dumps(out, separators=(",", ":"))
+    if len(line) >= LINE_LIMIT:
+        out.pop("other_configs", None)
+        line = json.dumps(out, separators=(",", ":"))
+    return line
+
+
+def write_detail(result):
+    """The full record (everything the slim line leaves out) -> bench_detail.json next to the script, gpurun_out/ when present, stderr."""
+    text = json.dumps(result, indent=1, default=str)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, "bench_detail.json"), "w") as f:
+                    f.write(text)
+            except OSError as e:
+                log(f"bench_detail.json not written under {d}: {e}")
+    log("bench detail: " + json.dumps(result, default=str))
+
+
 def usable_cpus():
     """CPUs this process may really use: the affinity mask and the cgroup CPU quota (containers often see every host
     core in os.cpu_count() while being limited to a few)."""
@@ -193,6 +317,7 @@ def cpu_baseline(tm, corpus, K, beta0, budget_s=24.0):
         "value": omp, "unit": "VB iters/sec", "cores": threads, "host_cpus": cpu_info, "kind": "port",
         "omp_threads_tried": {str(k): v for k, v in tried.items()},
         "single_thread_value": single,
+        "sample_short": f"fp64 C oracle, FULL corpus, 1 warm-up + {n_omp} timed iterations, OpenMP x{threads}",
         "sample": f"fp64 C oracle (port of src/LDA.jl train!; the Julia reference cannot run here) on the FULL workload "
                   f"({corpus.M} docs, {corpus.nnz} nnz), same cold start (alpha=1, gamma=1, beta0 seed 7): 1 warm-up + {n_omp} timed "
                   f"iterations with the OpenMP document-parallel E-step on {threads} threads (the CPUs usable by this process: affinity mask and cgroup quota, see host_cpus), per-thread "
@@ -305,26 +430,23 @@ def main():
                 if comm is not None:
                     comm.close()
                 comm, use_lib = None, False
-        if use_lib:
-            collective = (f"RCCL {tm.rccl_version()} inside libtmvb_hip.so (tmvb_lda_estep_allreduce: the Elogtheta_sum tail all-reduced on a side stream "
-                          f"under the statistics pass, the statistics in {os.environ.get('TMVB_AR_SLICES', '1')} vocabulary slab(s))")
-            eng.model.set_comm(comm, corpus.M)
-            if os.environ.get("TMVB_FUSED_ALLREDUCE", "1") == "0":       # the three-call form of rounds 2-3 (escape hatch, also read by the library's train!)
-                collective = f"RCCL {tm.rccl_version()} inside libtmvb_hip.so (tmvb_comm_allreduce on the context stream; TMVB_FUSED_ALLREDUCE=0)"
-                ptr, n = eng.model.stats()
-                return (lambda: comm.allreduce(ptr, n)), comm
-            eng.fused_allreduce = True
-            return (lambda: None), comm
-        if one_gpu_debug:
-            collective = "host transport + gloo (one-GPU plumbing check, not a measurement)"
-            import numpy as _np
-
+        fused_form = os.environ.get("TMVB_FUSED_ALLREDUCE", "0") != "0"   # opt-in; DEFAULT = the three-call form, ONE collective per iteration (the library's train! default too)
+        if one_gpu_debug and not use_lib:
             def gsum(a):
                 t = torch.from_numpy(a); dist.all_reduce(t, op=dist.ReduceOp.SUM)
             comm = tm.Communicator.host(eng.ctx, world, rank, gsum)
+            transport = "host transport + gloo (one-GPU plumbing check, not a measurement)"
+        elif use_lib:
+            transport = f"RCCL {tm.rccl_version()} inside libtmvb_hip.so"
+        if comm is not None:
             eng.model.set_comm(comm, corpus.M)
-            eng.fused_allreduce = True                           # the same call sequence as the RCCL run
-            return (lambda: None), comm
+            if fused_form:
+                collective = f"{transport}: tmvb_lda_estep_allreduce (TMVB_FUSED_ALLREDUCE=1: Elogtheta_sum tail early on a side stream, statistics in {os.environ.get('TMVB_AR_SLICES', '1')} slab(s))"
+                eng.fused_allreduce = True
+                return (lambda: None), comm
+            collective = f"{transport}: ONE all-reduce of K*V+K f32 per iteration on the context stream (tmvb_comm_allreduce)"
+            ptr, n = eng.model.stats()
+            return (lambda: comm.allreduce(ptr, n)), comm
         collective = "torch.distributed all_reduce (nccl = RCCL) on the bound statistics buffer"
         if "nccl" not in comm_holder:
             comm_holder["nccl"] = dist.new_group(backend="nccl")
@@ -440,7 +562,10 @@ def main():
             allh = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
             dist.all_gather(allh, mine)                                  # gloo
             hashes = [int(t.item()) for t in allh]
+            shard_nnz = [int(corpus.doc_ptr[b] - corpus.doc_ptr[a]) for a, b in bounds]
             mg_check = {"iterations": int(done.value), "globals_hash_equal": len(set(hashes)) == 1,
+                        "form": "fused" if getattr(eng_s, "fused_allreduce", False) else "single", "shard_nnz": shard_nnz,
+                        "shard_nnz_max_over_min": max(shard_nnz) / max(min(shard_nnz), 1),
                         "globals_hash_per_rank": [f"{h & 0xFFFFFFFFFFFFFFFF:016x}" for h in hashes]}
             if rank == 0:
                 g1 = tm.gpuLDA(corpus, K, device_id=local_rank)
@@ -595,7 +720,8 @@ def main():
                     others[name]["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
                 log(f"other_configs[{name}] cpu_baseline done in {time.perf_counter() - t_c:.1f}s")
             result["other_configs"] = others
-        print(json.dumps(result), flush=True)
+        write_detail(result)
+        print(slim_line(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

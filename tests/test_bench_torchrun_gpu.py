@@ -23,23 +23,55 @@ def _free_port():
     return p
 
 
-def test_torchrun_two_ranks_on_one_gpu():
-    env = dict(os.environ, TMVB_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
-           "--burnin", "3", "--docs", "6000", "--clock-warmup", "0", "--plateau-cap", "100"]
-    out = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
+def _launch(world, extra_env=None, docs="6000"):
+    env = dict(os.environ, TMVB_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "4", "--warmup", "1",
+           "--burnin", "3", "--docs", docs, "--clock-warmup", "0", "--plateau-cap", "100"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=1500)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]                      # rank 0 prints ONE JSON line
+    assert len(lines[0]) < 6000                                     # ... that the driver can take (round 4: 20 KB, "parsed": null)
     r = json.loads(lines[0])
-    assert r["n_gpus"] == 2 and r["steps"] == 4 and r["scaling"] == "strong" and r["value"] > 0
-    assert "host transport" in r["config"]["collective"]
-    assert r["config"]["parallelism"].startswith("doc-shard x2") and "all-reduce" in r["roofline"]["estep_ms_includes"]
-    chk = r["multi_gpu_check"]
-    assert chk["globals_hash_equal"] and len(set(chk["globals_hash_per_rank"])) == 1, chk
+    detail = json.load(open(os.path.join(ROOT, r["detail"])))       # everything else: bench_detail.json next to the script
+    return r, detail
+
+
+def _common(r, detail, world):
+    assert r["n_gpus"] == world and r["steps"] == 4 and r["scaling"] == "strong" and r["value"] > 0
+    assert detail["value"] == pytest.approx(r["value"], rel=1e-5)
+    assert "host transport" in detail["config"]["collective"]
+    assert r["config"]["parallelism"].startswith(f"doc-shard x{world}")
+    chk, full = r["multi_gpu_check"], detail["multi_gpu_check"]
+    assert full["globals_hash_equal"] and len(set(full["globals_hash_per_rank"])) == 1 and len(full["globals_hash_per_rank"]) == world, full
     assert chk["iterations"] == 5 and chk["elbo_rel_vs_n1"] <= chk["elbo_rel_tolerance"], chk
     assert chk["pass"] is True
+    assert len(full["shard_nnz"]) == world and all(n > 0 for n in full["shard_nnz"])
     pl = r["elbo_plateau"]
     assert pl is not None and pl["iterations"] >= 1 and pl["elbo_last"] > pl["elbo_first"]
     assert r["roofline"]["frac"] > 0 and r["cpu_baseline"] is None       # the CPU leg and the parity block are N = 1 only
+
+
+def test_torchrun_two_ranks_on_one_gpu():
+    """default form: ONE all-reduce of the K*V+K buffer per iteration"""
+    r, detail = _launch(2)
+    _common(r, detail, 2)
+    assert r["multi_gpu_check"]["form"] == "single" and "ONE all-reduce" in detail["config"]["collective"]
+    assert detail["roofline"]["estep_ms_includes"] == "the E-step only"
+
+
+def test_torchrun_two_ranks_fused_form_opt_in():
+    r, detail = _launch(2, {"TMVB_FUSED_ALLREDUCE": "1"})
+    _common(r, detail, 2)
+    assert r["multi_gpu_check"]["form"] == "fused" and "all-reduce" in detail["roofline"]["estep_ms_includes"]
+
+
+def test_torchrun_eight_ranks_on_one_gpu():
+    """The driver's SCALE run is --gpus 8: the exact command line, eight ranks on ONE device through the host transport.  Eight distinct
+    nnz-balanced shards, bit-identical globals on all eight ranks, the ELBO trajectory of the sharded train! against the N = 1 run."""
+    r, detail = _launch(8, docs="16000")
+    _common(r, detail, 8)
+    full = detail["multi_gpu_check"]
+    assert r["multi_gpu_check"]["shard_nnz_max_over_min"] <= 1.02, full["shard_nnz"]
+    assert sum(full["shard_nnz"]) == detail["config"]["nnz"]

@@ -72,6 +72,8 @@ def _gloo_sum(dist):
 def _worker(rank, world, initfile, out_dir, slices, M, V, K, iters):
     if slices == 0:                                        # the three-call form inside train! (TMVB_FUSED_ALLREDUCE=0)
         os.environ["TMVB_FUSED_ALLREDUCE"] = "0"; slices = 1
+    else:
+        os.environ["TMVB_FUSED_ALLREDUCE"] = "1"          # opt-in since round 5 (the default is the single collective)
     os.environ["TMVB_AR_SLICES"] = str(slices)
     sys.path.insert(0, ROOT)
     import torch.distributed as dist

@@ -54,6 +54,7 @@ def cpu_line(kind, make, step, frac, sample_note, warm=1, timed=2, budget_s=12.0
     name = "value" if full else "value (sample, scaled)"
     out = {"value": omp * frac, "value_is": "full corpus" if full else "sample scaled by work fraction", "unit": "VB iters/sec",
            "cores": threads, "host_cpus": info, "kind": "port",
+           "sample_short": f"fp64 C oracle, {'FULL corpus' if full else f'sample x{frac:.3f}'}, {warm} warm-up + {n} timed iterations, OpenMP x{threads}",
            "sample": f"fp64 C oracle ({kind}), {sample_note}; {warm} warm-up + {n} timed iterations from the cold start on {threads} OpenMP "
                      f"threads" + (" (the oracle's own calls of the parity check's teacher-forced iterations)" if check else "")
                      + ("" if full else f"; {name} = sample iters/s x work fraction {frac:.4f}")}

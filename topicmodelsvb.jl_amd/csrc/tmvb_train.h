@@ -150,9 +150,11 @@ static int tmvb_train_group_loop(const char* who, H* const* hs, int n, int iter,
         ++done;
         bool fused = false;
         if constexpr (tmvb_has_estep_allreduce<Ops, H>::value) {
-            // (TMVB_FUSED_ALLREDUCE=0: the three-call form of rounds 2-3 -- one collective of the whole buffer on the context's stream -- for a
-            //  first run on hardware where the fused form's two streams of collectives would have to be ruled out as a suspect)
-            static const bool fuse = [] { const char* e = getenv("TMVB_FUSED_ALLREDUCE"); return !(e && atoi(e) == 0); }();
+            // DEFAULT: the three-call form -- estep, reduce_docs, ONE collective of the whole K*V+K buffer on the context's stream (north_star's
+            // "single RCCL all-reduce ... per outer iteration").  TMVB_FUSED_ALLREDUCE=1 opts into tmvb_lda_estep_allreduce (the Elogtheta_sum tail
+            // all-reduced early on a side stream, the statistics in slabs): two streams of collectives on one communicator, which no multi-rank
+            // RCCL run has validated yet (round-4 advice) -- opt-in until tests/test_multigpu_rccl.py has passed on a multi-GPU node.
+            static const bool fuse = [] { const char* e = getenv("TMVB_FUSED_ALLREDUCE"); return e && atoi(e) != 0; }();
             if (sharded && n == 1 && fuse) { if ((rc = ops.estep_allreduce(hs[0]))) return rc; fused = true; }
         }
         if (!fused) for (int i = 0; i < n; ++i) if ((rc = ops.estep(hs[i]))) return rc;
