@@ -1723,7 +1723,8 @@ static int ctm_launch_batch(tmvb_ctm* h, const CtmParams& p, double ntol)
     const int n_items = (int)((Mb + 63) / 64);
     static const bool persistent = [] { const char* e = getenv("TMVB_CTM_PERSISTENT"); return !(e && atoi(e) == 0); }();
     const size_t lds = (size_t)h->KP * 64 * (sizeof(double) + sizeof(float)) + 64 * sizeof(int32_t);   // vsq, CG solution / row staging, row ids
-    const int per_cu = (int)std::min<size_t>(4, (160 * 1024) / lds);      // one wave per SIMD, and what the CU's LDS holds
+    int per_cu = (int)std::min<size_t>(4, (160 * 1024) / lds);            // one wave per SIMD, and what the CU's LDS holds
+    if (const char* e = getenv("TMVB_CTM_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e)));   // diagnostics: fewer resident waves (contention experiments, profiles/r5_ctm_token_experiments.txt)
     const dim3 grid((unsigned)(persistent ? std::min(n_items, per_cu * ctx->num_cu) : n_items)), block(64);
     tb.next_item = (unsigned*)(h->d_cg_iters + 12); tb.n_items = n_items;
     if (h->reorder && h->keys_valid && !h->reorder_staged) {      // (staged: the last tmvb_ctm_estep already regrouped behind its statistics tail)
