@@ -111,6 +111,15 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    # Register / scratch budget of the kernels behind the benched numbers (tools/kernel_resources.py: the code objects' own metadata): a benched
+    # kernel that starts spilling to scratch -- or the CTM lane kernel growing past its recorded 428 B -- fails the build instead of the next profile.
+    kres = os.path.join(_ROOT, "tools", "kernel_resources.py")
+    if os.path.exists(kres) and not _VARIANT:
+        res = subprocess.run([sys.executable, kres, "--check", LIB_PATH], capture_output=True, text=True)
+        if res.returncode != 0:
+            raise EngineError("kernel resource check failed:\n" + res.stdout[-2000:])
+        if verbose:
+            print(res.stdout.strip().splitlines()[-1])
     LAST_BUILD = {"mode": "compiled", "compiled": compiled, "linked": True}
     return LIB_PATH
 
