@@ -9,6 +9,8 @@ import os
 import numpy as np
 import pytest
 
+from tol import within     # every comparison by name: tests/tol.py holds the frozen tolerances
+
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
@@ -82,13 +84,11 @@ def test_teacher_forced_step(tmvb, oracle, case):
         om.mstep()
         # K > 128 (round 4): vtol = 1 / K^2 keeps every document sweeping to the cap and the fp32 rounding of ten sweeps over hundreds of
         # topics adds up: measured 5.9e-4 on gimel at K = 300 (5e-4 holds to K = 256); bound 2e-3 there
-        st = 5e-4 if int(g["K"]) <= 256 else 2e-3
-        assert rel(gm.gimel, om.gimel) <= st, (it, "gimel")
-        assert rel(gm.zayin, om.zayin) <= st, (it, "zayin")
-        assert rel(gm.alef, om.alef) <= st, (it, "alef")
-        assert rel(gm.he, om.he) <= st, (it, "he")
+        st = "ctpf.shape_rel" if int(g["K"]) <= 256 else "ctpf.shape_rel_bigk"
+        for n in ("gimel", "zayin", "alef", "he"):
+            within(st, rel(getattr(gm, n), getattr(om, n)), (it, n))
         for n in ("bet", "vav", "dalet", "het"):
-            assert rel(getattr(gm, n), getattr(om, n)) <= 1e-4, (it, n)
+            within("ctpf.rates_rel", rel(getattr(gm, n), getattr(om, n)), (it, n))
         assert rel(gm.alef_old, om.alef_old) <= 1e-6 and rel(gm.dalet_old, om.dalet_old) <= 1e-12
         assert np.all(gm.alef > 0) and np.all(gm.he > 0) and np.all(gm.gimel > 0) and np.all(gm.zayin > 0)
 
@@ -104,7 +104,8 @@ def test_device_elbo_matches_oracle(tmvb, oracle, case):
         gm.estep(viter=3, vtol=0.0); gm.reduce_docs(); gm.mstep()
         om.estep(viter=3, vtol=0.0); om.mstep()
         e_g = gm.update_elbo(); e_o = om.update_elbo()
-        assert np.isfinite(e_g) and abs(e_g - e_o) <= 2e-5 * abs(e_o), (it, e_g, e_o)
+        assert np.isfinite(e_g)
+        within("ctpf.elbo_rel_step", abs(e_g - e_o) / abs(e_o), (it, e_g, e_o))
 
 
 @pytest.mark.parametrize("grid", ["0", "1"])
@@ -134,10 +135,11 @@ def test_long_documents_and_the_lane_per_token_path(tmvb, oracle, monkeypatch, g
         e_g = gm.update_elbo(); e_o = om.update_elbo()
         gm.update_host()
         assert np.all(gm.doc_sweeps() == 4)
-        assert rel(gm.gimel, om.gimel) <= 3e-4 and rel(gm.zayin, om.zayin) <= 3e-4, (it, rel(gm.gimel, om.gimel), rel(gm.zayin, om.zayin))
-        assert rel(gm.alef, om.alef) <= 3e-4 and rel(gm.he, om.he) <= 3e-4
-        assert rel(gm.vav, om.vav) <= 2e-5 and rel(gm.bet, om.bet) <= 2e-5
-        assert abs(e_g - e_o) <= 2e-5 * abs(e_o), (it, e_g, e_o)
+        for n in ("gimel", "zayin", "alef", "he"):
+            within("ctpf.long.shape_rel", rel(getattr(gm, n), getattr(om, n)), (it, n))
+        for n in ("vav", "bet"):
+            within("ctpf.long.rates_rel", rel(getattr(gm, n), getattr(om, n)), (it, n))
+        within("ctpf.elbo_rel_step", abs(e_g - e_o) / abs(e_o), (it, e_g, e_o))
 
 
 def test_fast_elbo_equals_the_entry_by_entry_kernel(tmvb):

@@ -17,6 +17,8 @@ import os
 import numpy as np
 import pytest
 
+from tol import within
+
 pytestmark = pytest.mark.gpu
 
 
@@ -132,10 +134,32 @@ def test_lda_free_running_k50_medium_corpus_tracks_the_oracle(tmvb, oracle):
     assert n >= 5
     dev = np.abs(t_g[:n] - t_o[:n]) / np.abs(t_o[:n])
     print("\n   LDA K=50 free running: iterations", len(t_g), len(t_o), "max ELBO rel", dev.max())
-    assert np.all(dev <= 1e-4), (t_g, t_o)
+    within("lda.elbo_rel_free", dev, (t_g, t_o))
     if len(t_g) == len(t_o):
-        assert (np.abs(gm.alpha - om.alpha) / om.alpha).max() <= 5e-3
-        assert np.abs(gm.beta - om.beta).max() <= 5e-4
+        within("lda.alpha_rel_free", np.abs(gm.alpha - om.alpha) / om.alpha)
+        within("lda.beta_abs_free", np.abs(gm.beta - om.beta))
+
+
+def test_lda_free_running_full_size_k50_tracks_the_oracle(tmvb, oracle):
+    """Round-4 review, missing #4: full size had been teacher-forced only.  Ten FREE-RUNNING iterations of config 2 (LDA K = 50, the whole SYN-NSF
+    corpus) through the library's train! -- the pipelined document pieces, the class-ordered statistics chunks, the queue order, as they run in the timed
+    window -- against the OpenMP fp64 oracle's train! loop from the same cold start (src/LDA.jl:169-187): ELBO rel per iteration, then the globals."""
+    pc = tmvb.syn_nsf()
+    K = 50
+    beta0 = tmvb.dirichlet_rows(K, pc.V, seed=7)
+    gm = tmvb.gpuLDA(pc, K)
+    gm.beta = np.asfortranarray(beta0); gm.beta_old = gm.beta.copy(order="F")
+    om = oracle.LDA(oracle.CSR(pc.doc_ptr, pc.terms, pc.counts, pc.V), K, beta0)
+    t_g = gm.train(iter=10, tol=0.0, checkelbo=1, printelbo=False)
+    nt = oracle.usable_cpus()
+    t_o = _oracle_train(om, lambda m: (m.estep(omp_threads=nt), m.update_beta(), m.update_alpha()), 10, tol=0.0)
+    oracle.lib().orc_omp_pool_free()
+    assert len(t_g) == len(t_o) == 10 and np.all(np.diff(t_o) > 0)
+    dev = np.abs(t_g - t_o) / np.abs(t_o)
+    print("\n   LDA K=50 FULL SIZE free running, 10 iterations: ELBO rel per iteration", ", ".join(f"{x:.2e}" for x in dev))
+    within("lda.elbo_rel_free_full", dev, (t_g, t_o))
+    within("lda.alpha_rel_free_full", np.abs(gm.alpha - om.alpha) / om.alpha)
+    within("lda.beta_abs_free_full", np.abs(gm.beta - om.beta))
 
 
 def test_ctpf_free_running_k50_medium_corpus_tracks_the_oracle(tmvb, oracle):
@@ -156,7 +180,7 @@ def test_ctpf_free_running_k50_medium_corpus_tracks_the_oracle(tmvb, oracle):
     assert n >= 5
     dev = np.abs(t_g[:n] - t_o[:n]) / np.abs(t_o[:n])
     print("\n   CTPF K=50 free running: iterations", len(t_g), len(t_o), "max ELBO rel", dev.max())
-    assert np.all(dev <= 1e-4), (t_g, t_o)
+    within("ctpf.elbo_rel_free", dev, (t_g, t_o))
     # the states after 25 free-running iterations: trajectories drift apart where a document leaves one sweep earlier or later
     # (measured on MI355X: rates up to 1.1e-2 relative on the smallest component); the drift is NOT an error of the operators -- from
     # the device's own final state one more teacher-forced iteration agrees with the oracle to the single-step tolerances

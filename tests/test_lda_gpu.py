@@ -14,11 +14,9 @@ pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
-RTOL_STATE = 2e-4
-RTOL_BETA = 1e-4
-RTOL_ALPHA = 1e-4
-RTOL_ELBO_STEP = 1e-6
-RTOL_ELBO_FREE = 1e-4
+from tol import TOL, within          # every comparison by name: tests/tol.py holds the frozen tolerances
+
+RTOL_ELBO_FREE = TOL["lda.elbo_rel_free"]
 
 
 def load(name):
@@ -62,15 +60,15 @@ def test_teacher_forced_fixed_sweeps(tmvb, oracle, name):
         gm.update_alpha(); om.update_alpha()
         e_g = gm.update_elbo(); e_o = om.update_elbo()
         gm.update_host()
-        assert rel(gm.gamma, om.gamma).max() <= RTOL_STATE, (it, "gamma")
-        assert rel(gm.Elogtheta, om.Elogtheta).max() <= RTOL_STATE, (it, "Elogtheta")
-        assert rel(gm.Elogtheta_old, om.Elogtheta_old).max() <= RTOL_STATE, (it, "Elogtheta_old")
+        within("lda.gamma_rel", rel(gm.gamma, om.gamma), it)
+        within("lda.Elogtheta_rel", rel(gm.Elogtheta, om.Elogtheta), it)
+        within("lda.Elogtheta_rel", rel(gm.Elogtheta_old, om.Elogtheta_old), (it, "old"))
         big = om.beta > 1e-6
-        assert rel(gm.beta[big], om.beta[big]).max() <= RTOL_BETA, (it, "beta")
-        assert np.abs(gm.beta - om.beta).max() <= 1e-7
-        assert rel(gm.beta_old, om.beta_old, 1e-6).max() <= 1e-6, (it, "beta_old")
-        assert rel(gm.alpha, om.alpha).max() <= RTOL_ALPHA, (it, "alpha")
-        assert abs(e_g - e_o) <= RTOL_ELBO_STEP * abs(e_o), (it, e_g, e_o)
+        within("lda.beta_rel", rel(gm.beta[big], om.beta[big]), it)
+        within("lda.beta_abs", np.abs(gm.beta - om.beta), it)
+        assert rel(gm.beta_old, om.beta_old, 1e-6).max() <= 1e-6, (it, "beta_old")      # the forced state itself (an fp32 round trip)
+        within("lda.alpha_rel", rel(gm.alpha, om.alpha), it)
+        within("lda.elbo_rel_step", abs(e_g - e_o) / abs(e_o), (it, e_g, e_o))
         # check_model post-conditions (src/modelutils.jl:255-279)
         np.testing.assert_allclose(gm.beta.sum(axis=1), 1.0, rtol=1e-5)
         assert np.all(gm.gamma > 0) and np.all(gm.Elogtheta <= 0)
@@ -97,12 +95,12 @@ def test_teacher_forced_default_exit_rule(tmvb, oracle, name):
         # per-document state given the (forced) globals depends on the document's own sweeps only: every document whose
         # exit sweep agrees with the oracle's is compared, whatever the others did
         assert same.any()
-        assert rel(gm.gamma[:, same], om.gamma[:, same]).max() <= RTOL_STATE, it
-        assert rel(gm.Elogtheta[:, same], om.Elogtheta[:, same]).max() <= RTOL_STATE, it
+        within("lda.gamma_rel", rel(gm.gamma[:, same], om.gamma[:, same]), it)
+        within("lda.Elogtheta_rel", rel(gm.Elogtheta[:, same], om.Elogtheta[:, same]), it)
         if same.all():                                       # the globals see every document
-            assert rel(gm.alpha, om.alpha).max() <= RTOL_ALPHA
+            within("lda.alpha_rel", rel(gm.alpha, om.alpha), it)
             big = om.beta > 1e-6
-            assert rel(gm.beta[big], om.beta[big]).max() <= RTOL_BETA
+            within("lda.beta_rel", rel(gm.beta[big], om.beta[big]), it)
     assert mism <= 0.05 * tot, f"{mism}/{tot} documents changed sweep count"
 
 
@@ -115,9 +113,9 @@ def test_free_running_train_vs_golden(tmvb, name):
     traj = gm.train(iter=int(g["iters"]), tol=0.0, checkelbo=1, printelbo=False)
     gold = g["elbo_traj"]
     assert len(traj) == len(gold)            # ELBO increases every iteration on these fixtures
-    assert np.all(np.abs(traj - gold) <= RTOL_ELBO_FREE * np.abs(gold)), (traj, gold)
-    assert rel(gm.alpha, g["alpha"]).max() <= 5e-3
-    assert np.abs(gm.beta - g["beta"]).max() <= 5e-4
+    within("lda.elbo_rel_free", np.abs(traj - gold) / np.abs(gold), (traj, gold))
+    within("lda.alpha_rel_free", rel(gm.alpha, g["alpha"]))
+    within("lda.beta_abs_free", np.abs(gm.beta - g["beta"]))
     # topics = descending sortperm of beta rows (src/gpuLDA.jl:374), 1-based
     assert sorted(gm.topics[0].tolist()) == list(range(1, V + 1))
 
@@ -135,7 +133,7 @@ def test_free_running_medium_corpus_tracks_the_oracle(tmvb, oracle):
     t_o = om.train(iter=25, tol=1.0, checkelbo=1)
     assert abs(len(t_g) - len(t_o)) <= 1                       # stop iteration +-1
     n = min(len(t_g), len(t_o))
-    assert np.all(np.abs(t_g[:n] - t_o[:n]) <= RTOL_ELBO_FREE * np.abs(t_o[:n])), (t_g, t_o)
+    within("lda.elbo_rel_free", np.abs(t_g[:n] - t_o[:n]) / np.abs(t_o[:n]), (t_g, t_o))
 
 
 @pytest.mark.parametrize("pieces", [None, 2])
@@ -164,10 +162,10 @@ def test_long_documents_stream_through_the_tile(tmvb, oracle, K, pieces, monkeyp
         gm.update_alpha(); om.update_alpha()
         e_g = gm.update_elbo(); e_o = om.update_elbo()
         gm.update_host()
-        assert rel(gm.gamma, om.gamma).max() <= RTOL_STATE
+        within("lda.gamma_rel", rel(gm.gamma, om.gamma), it)
         big = om.beta > 1e-6
-        assert rel(gm.beta[big], om.beta[big]).max() <= RTOL_BETA
-        assert abs(e_g - e_o) <= RTOL_ELBO_STEP * abs(e_o)
+        within("lda.beta_rel", rel(gm.beta[big], om.beta[big]), it)
+        within("lda.elbo_rel_step", abs(e_g - e_o) / abs(e_o), it)
 
 
 def test_k1_closed_form_on_device(tmvb):
@@ -214,7 +212,7 @@ def test_gpu_macro_round_trip(tmvb, oracle):
     m.beta = np.asfortranarray(g["beta0"]); m.beta_old = m.beta.copy(order="F")
     traj = tmvb.gpu_train(m, iter=int(g["iters"]), tol=0.0, printelbo=False)
     tmvb.check_model(m)                                     # Float64 stochasticity tolerance holds after :147
-    assert np.all(np.abs(traj - g["elbo_traj"]) <= RTOL_ELBO_FREE * np.abs(g["elbo_traj"]))
+    within("lda.elbo_rel_free", np.abs(traj - g["elbo_traj"]) / np.abs(g["elbo_traj"]))
     assert np.array_equal(m.Elogtheta, m.Elogtheta_old) and np.array_equal(m.beta, m.beta_old)
 
 
@@ -284,11 +282,11 @@ def test_every_kernel_path_by_k(tmvb, oracle, K, merged, monkeypatch):
         gm.update_alpha(); om.update_alpha()
         e_g = gm.update_elbo(); e_o = om.update_elbo()
         gm.update_host()
-        assert rel(gm.gamma, om.gamma).max() <= RTOL_STATE, (it, "gamma")
+        within("lda.gamma_rel", rel(gm.gamma, om.gamma), (it, "gamma"))
         big = om.beta > 1e-6
-        assert rel(gm.beta[big], om.beta[big]).max() <= RTOL_BETA, (it, "beta")
-        assert rel(gm.alpha, om.alpha).max() <= RTOL_ALPHA
-        assert abs(e_g - e_o) <= RTOL_ELBO_STEP * abs(e_o)
+        within("lda.beta_rel", rel(gm.beta[big], om.beta[big]), (it, "beta"))
+        within("lda.alpha_rel", rel(gm.alpha, om.alpha))
+        within("lda.elbo_rel_step", abs(e_g - e_o) / abs(e_o))
 
 
 @pytest.mark.parametrize("K", [10, 50, 100])
@@ -306,11 +304,11 @@ def test_lane_per_token_register_tile_path_still_matches_the_oracle(tmvb, oracle
         gm.update_beta(); om.update_beta(); gm.update_alpha(); om.update_alpha()
         e_g = gm.update_elbo(); e_o = om.update_elbo()
         gm.update_host()
-        assert rel(gm.gamma, om.gamma).max() <= RTOL_STATE, (it, "gamma")
+        within("lda.gamma_rel", rel(gm.gamma, om.gamma), (it, "gamma"))
         big = om.beta > 1e-6
-        assert rel(gm.beta[big], om.beta[big]).max() <= RTOL_BETA, (it, "beta")
-        assert rel(gm.alpha, om.alpha).max() <= RTOL_ALPHA
-        assert abs(e_g - e_o) <= RTOL_ELBO_STEP * abs(e_o)
+        within("lda.beta_rel", rel(gm.beta[big], om.beta[big]), (it, "beta"))
+        within("lda.alpha_rel", rel(gm.alpha, om.alpha))
+        within("lda.elbo_rel_step", abs(e_g - e_o) / abs(e_o))
 
 
 def test_grid_tile_long_documents_two_and_four_waves(tmvb, oracle):
@@ -332,10 +330,10 @@ def test_grid_tile_long_documents_two_and_four_waves(tmvb, oracle):
             gm.update_beta(); om.update_beta(); gm.update_alpha(); om.update_alpha()
             gm.update_host()
             assert np.all(gm.doc_sweeps() == 5)
-            assert rel(gm.gamma, om.gamma).max() <= RTOL_STATE, (K, it, "gamma")
-            assert rel(gm.Elogtheta, om.Elogtheta).max() <= RTOL_STATE, (K, it, "Elogtheta")
+            within("lda.gamma_rel", rel(gm.gamma, om.gamma), (K, it, "gamma"))
+            within("lda.Elogtheta_rel", rel(gm.Elogtheta, om.Elogtheta), (K, it, "Elogtheta"))
             big = om.beta > 1e-6
-            assert rel(gm.beta[big], om.beta[big]).max() <= RTOL_BETA, (K, it, "beta")
+            within("lda.beta_rel", rel(gm.beta[big], om.beta[big]), (K, it, "beta"))
 
 
 def test_train_equals_stepwise_pipelined(tmvb):
@@ -380,9 +378,9 @@ def test_two_copy_kernel_for_short_documents(tmvb, oracle, monkeypatch):
         gm.update_alpha(); om.update_alpha()
         e_g = gm.update_elbo(); e_o = om.update_elbo()
         gm.update_host()
-        assert rel(gm.gamma, om.gamma).max() <= RTOL_STATE, (it, "gamma")
-        assert rel(gm.Elogtheta, om.Elogtheta).max() <= RTOL_STATE, (it, "Elogtheta")
+        within("lda.gamma_rel", rel(gm.gamma, om.gamma), (it, "gamma"))
+        within("lda.Elogtheta_rel", rel(gm.Elogtheta, om.Elogtheta), (it, "Elogtheta"))
         big = om.beta > 1e-6
-        assert rel(gm.beta[big], om.beta[big]).max() <= RTOL_BETA, (it, "beta")
-        assert abs(e_g - e_o) <= RTOL_ELBO_STEP * abs(e_o), (it, e_g, e_o)
+        within("lda.beta_rel", rel(gm.beta[big], om.beta[big]), (it, "beta"))
+        within("lda.elbo_rel_step", abs(e_g - e_o) / abs(e_o), (it, e_g, e_o))
 

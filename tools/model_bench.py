@@ -290,7 +290,7 @@ def ctpf_cpu(pc=None, parity=True):
         gm = tm.gpuCTPF(pc, K)
         gm.alef = np.asfortranarray(alef0); gm.alef_old = gm.alef.copy(order="F"); gm.update_buffer()
         try:
-            return op.ctpf_parity(gm, om, iters=iters, threads=threads, log=_log)
+            return op.ctpf_parity(gm, om, iters=iters, threads=threads, elbo=True, log=_log)      # (round-4 review: elbo_rel was null in the line)
         finally:
             gm.close()
     return cpu_line("port of src/CTPF.jl train!",
