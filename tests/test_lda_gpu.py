@@ -168,6 +168,29 @@ def test_long_documents_stream_through_the_tile(tmvb, oracle, K, pieces, monkeyp
         within("lda.elbo_rel_step", abs(e_g - e_o) / abs(e_o), it)
 
 
+def test_epsilon_keeps_phi_defined_where_a_beta_column_is_zero(tmvb, oracle):
+    """update_phi! adds epsilon before normalising (src/LDA.jl:152): for a term whose beta column is all zero -- a vocabulary entry no training document
+    used, met by predict on new text -- phi = eps / (K eps) = 1 / K exactly, where 0 / 0 would poison gamma.  Known answer: a document made of that
+    term only gets gamma_i = alpha_i + C_d / K + eps; and the whole step against the oracle.  (The negative control of tests/test_mutants_gpu.py: the
+    library built with epsilon dropped must FAIL here.)"""
+    K, V = 5, 7
+    rng = np.random.default_rng(3)
+    beta0 = rng.random((K, V)); beta0[:, 3] = 0.0; beta0 /= beta0.sum(axis=1, keepdims=True)
+    docs = [([3], [4]), ([0, 3, 5], [2, 1, 3]), ([1, 2, 6], [1, 1, 2])]
+    doc_ptr = np.concatenate([[0], np.cumsum([len(t) for t, _ in docs])]).astype(np.int64)
+    terms = np.concatenate([t for t, _ in docs]).astype(np.int32); counts = np.concatenate([c for _, c in docs]).astype(np.int32)
+    g = dict(K=K, V=V, doc_ptr=doc_ptr, terms=terms, counts=counts, beta0=beta0)
+    gm, om = make_pair(tmvb, oracle, g)
+    gm.estep(viter=3, vtol=0.0); gm.reduce_docs(); om.estep(viter=3, vtol=0.0)
+    gm.update_host()
+    assert np.all(np.isfinite(gm.gamma)) and np.all(np.isfinite(gm.Elogtheta))
+    np.testing.assert_allclose(gm.gamma[:, 0], 1.0 + 4.0 / K, rtol=1e-6)          # alpha = 1 (constructor), phi uniform
+    within("lda.gamma_rel", rel(gm.gamma, om.gamma))
+    gm.update_beta(); om.update_beta(); gm.update_host()
+    assert np.all(np.isfinite(gm.beta))
+    within("lda.beta_abs", np.abs(gm.beta - om.beta))
+
+
 def test_k1_closed_form_on_device(tmvb):
     """K=1: phi == 1, gamma_d = alpha + C_d + eps, beta = empirical unigram distribution."""
     rng = np.random.default_rng(0)

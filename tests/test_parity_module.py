@@ -76,7 +76,8 @@ def _lda_pair(tmvb, oracle, K=7, **kw):
 def test_lda_sweep_mismatches_are_counted_and_fixed_up(tmvb, oracle):
     gm, om = _lda_pair(tmvb, oracle, vtol_scale=1.005)
     block, secs = parity.lda_parity(gm, om, iters=4, threads=2)
-    assert block["pass"], block["worst"]
+    # (the stand-in's mismatch rate is far above the frozen bound of a real device, 5e-3: everything else must hold)
+    assert all(v <= parity.LDA_TOL[k] for k, v in block["worst"].items() if v is not None and k != "sweep_mismatch_frac"), block["worst"]
     assert 0 < block["worst"]["sweep_mismatch_frac"] <= 0.05            # the stand-in did leave some documents a sweep apart
     # after the fix-up both sides ran the same sweeps on every document: fp64 agreement (summation order only)
     assert block["worst"]["gamma_rel_p999"] <= 1e-12 and block["worst"]["beta_rel_max"] <= 1e-10 and block["worst"]["elbo_rel"] <= 1e-13
@@ -97,7 +98,7 @@ def test_ctm_fix_up(tmvb, oracle):
     csr = oracle.CSR(pc.doc_ptr, pc.terms, pc.counts, pc.V)
     gm, om = StandCTM(oracle.CTM(csr, K, beta0), vtol_scale=1.003), oracle.CTM(csr, K, beta0)
     block, _ = parity.ctm_parity(gm, om, iters=3, threads=2)
-    assert block["pass"], block["worst"]
+    assert all(v <= parity.CTM_TOL[k] for k, v in block["worst"].items() if v is not None and k != "sweep_mismatch_frac"), block["worst"]
     assert block["worst"]["sweep_mismatch_frac"] > 0
     assert block["worst"]["lambda_err_p999"] <= 1e-6 and block["worst"]["beta_rel_max"] <= 1e-9 and block["worst"]["elbo_rel"] <= 1e-12
 

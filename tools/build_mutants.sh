@@ -1,0 +1,13 @@
+#!/bin/bash
+# The three deliberately WRONG libraries of tests/test_mutants_gpu.py (negative controls of the parity suite), each = the shipped objects with one
+# translation unit recompiled under a -DTMVB_MUTANT_* flag (csrc/tmvb_internal.h lists them):
+#   topicmodelsvb.jl_amd/libtmvb_hip_mut_lda_eps.so     epsilon dropped from LDA's phi / gamma            (src/LDA.jl:152, :145)
+#   topicmodelsvb.jl_amd/libtmvb_hip_mut_ctpf_bet.so    log bet for log vav in CTPF's xi                   (src/CTPF.jl:336 vs src/gpuCTPF.jl:624)
+#   topicmodelsvb.jl_amd/libtmvb_hip_mut_ctm_mu.so      update_sigma! centred on the new mu                (src/CTM.jl:207-208, quirk Q2)
+# Needs the shipped build first (python -c "import __graft_entry__ as g; g.build()").  ~4 minutes; the three run in parallel.
+cd "$(dirname "$0")/.." || exit 1
+tools/build_variant.sh mut_lda_eps tmvb_lda.hip -DTMVB_MUTANT_LDA_NO_EPS=1 &
+tools/build_variant.sh mut_ctpf_bet tmvb_ctpf.hip -DTMVB_MUTANT_CTPF_LOG_BET=1 &
+tools/build_variant.sh mut_ctm_mu tmvb_ctm.hip -DTMVB_MUTANT_CTM_SIGMA_NEW_MU=1 &
+wait
+ls -la topicmodelsvb.jl_amd/libtmvb_hip_mut_*.so

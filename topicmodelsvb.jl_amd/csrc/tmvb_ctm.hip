@@ -1186,6 +1186,11 @@ __global__ __launch_bounds__(256) void ctm_sigma_mu_kernel(int K, int KP, double
             const int a = min(i, j), b = max(i, j);            // upper triangle (a <= b)
             double v = (double)scatter[a * K + b];
             if (i == j) v += (double)sum_vsq[i];
+#ifdef TMVB_MUTANT_CTM_SIGMA_NEW_MU
+            // MUTANT (tests/test_mutants_gpu.py, never in a shipped build): the scatter matrix re-centred on the NEW mu = sum lambda / M, i.e. update_mu!
+            // before update_sigma! -- the reference runs them the other way round (quirk Q2, src/CTM.jl:207-208)
+            v -= Md * ((double)sum_lambda[i] / Md - mu_d[i]) * ((double)sum_lambda[j] / Md - mu_d[j]);
+#endif
             v /= Md;
             sm[i * K + j] = v;
             sigma_d[j * K + i] = v;                            // column-major (symmetric anyway)

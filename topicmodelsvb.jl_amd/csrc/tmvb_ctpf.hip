@@ -18,6 +18,14 @@
 // The scatters update_alef!(d) / update_he!(d) are gather-side statistics passes over the term and
 // the reader inverted indices (tmvb_termstats.h); HBM-bound like LDA.
 #include "tmvb_common_kernels.h"
+
+// xi's rate is `log vav` (src/CTPF.jl:336).  -DTMVB_MUTANT_CTPF_LOG_BET (tests/test_mutants_gpu.py, never in a shipped build) stores log bet in its place --
+// the reference's own OpenCL bug (src/gpuCTPF.jl:624) -- to prove that the parity tests notice.
+#ifdef TMVB_MUTANT_CTPF_LOG_BET
+#define TMVB_CTPF_XI_RATE(bet, vav) (bet)
+#else
+#define TMVB_CTPF_XI_RATE(bet, vav) (vav)
+#endif
 #include "tmvb_train.h"
 #include "tmvb_regtile.h"
 #include "tmvb_gridtile.h"
@@ -700,7 +708,7 @@ __global__ __launch_bounds__(64) void ctpf_rates_kernel(int K, double hb, double
         const double vav_n = (hf + sum_gimel[i] / dalet_n) + sum_zayin[i] / het_n;   // :290
         rates[4 * K + i] = bet; rates[5 * K + i] = vav; rates[6 * K + i] = dalet; rates[7 * K + i] = het;
         rates[i] = bet_n; rates[K + i] = vav_n; rates[2 * K + i] = dalet_n; rates[3 * K + i] = het_n;
-        lrates[i] = (float)log(bet_n); lrates[K + i] = (float)log(vav_n);
+        lrates[i] = (float)log(bet_n); lrates[K + i] = (float)log(TMVB_CTPF_XI_RATE(bet_n, vav_n));
         lrates[2 * K + i] = (float)log(dalet_n); lrates[3 * K + i] = (float)log(het_n);
     }
 }
@@ -840,7 +848,7 @@ __global__ __launch_bounds__(1024) void ctpf_mstep_kernel(CtpfMstepJob jh, CtpfM
     const double vav_n = (t.hf + tot[2] / dalet_n) + tot[3] / het_n;              // :290
     rates[4 * K + i] = bet; rates[5 * K + i] = vav; rates[6 * K + i] = dalet; rates[7 * K + i] = het;
     rates[i] = bet_n; rates[K + i] = vav_n; rates[2 * K + i] = dalet_n; rates[3 * K + i] = het_n;
-    lrates[i] = (float)log(bet_n); lrates[K + i] = (float)log(vav_n);
+    lrates[i] = (float)log(bet_n); lrates[K + i] = (float)log(TMVB_CTPF_XI_RATE(bet_n, vav_n));
     lrates[2 * K + i] = (float)log(dalet_n); lrates[3 * K + i] = (float)log(het_n);
 }
 
@@ -1462,6 +1470,9 @@ extern "C" int tmvb_ctpf_set_state(tmvb_ctpf* h, const double* hyper, const doub
         TMVB_REQUIRE(positive_finite(rv[r], K), TMVB_ENONFINITE, "%s must be positive.", rn[r]);
         std::vector<float> lg(K);
         for (size_t i = 0; i < K; ++i) lg[i] = (float)std::log(rv[r][i]);
+#ifdef TMVB_MUTANT_CTPF_LOG_BET
+        if (r == 1 && bet) for (size_t i = 0; i < K; ++i) lg[i] = (float)std::log(bet[i]);
+#endif
         TMVB_HIP(hipMemcpyAsync(h->d_rates + r * K, rv[r], K * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
         TMVB_HIP(hipMemcpyAsync(h->d_rates + (4 + r) * K, rv[r], K * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
         TMVB_HIP(hipMemcpyAsync(h->d_lrates + r * K, lg.data(), K * sizeof(float), hipMemcpyHostToDevice, ctx->stream));

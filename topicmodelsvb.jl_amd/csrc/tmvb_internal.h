@@ -150,7 +150,16 @@ int tmvb_comm_allreduce_on(tmvb_comm* c, void* dev_ptr, int64_t count, int32_t d
 int tmvb_corpus_reader_index(tmvb_corpus* c);
 
 // EPSILON of the reference (src/utils.jl:3) = 2^-99, exactly representable in fp32.
+// MUTANTS (tests/test_mutants_gpu.py; never defined in a shipped build): deliberately wrong variants of three operators, one -D flag each, built as
+// libtmvb_hip_<name>.so by tools/build_mutants.sh -- the negative controls of the parity suite: a named test must FAIL on each of them.
+//   TMVB_MUTANT_LDA_NO_EPS          epsilon dropped from LDA's phi / gamma (src/LDA.jl:152, :145)
+//   TMVB_MUTANT_CTPF_LOG_BET        `log bet` where xi needs `log vav` (the reference's own OpenCL bug, src/gpuCTPF.jl:624 vs src/CTPF.jl:336)
+//   TMVB_MUTANT_CTM_SIGMA_NEW_MU    update_sigma! centred on the NEW mu (quirk Q2: the reference updates sigma first, src/CTM.jl:207-208)
+#ifdef TMVB_MUTANT_LDA_NO_EPS
+#define TMVB_EPS_F 0.0f
+#else
 #define TMVB_EPS_F 1.5777218104420236e-30f
+#endif
 #define TMVB_EPS_D 1.5777218104420236e-30
 
 // host fp64 digamma (same published algorithm as the device version below)
