@@ -55,16 +55,16 @@ _T = {
     "ctpf.long.rates_rel":      (3e-06, 4.75e-07),
     "ctpf.elbo_rel_free":       (0.0001, 2.72e-05),
     # ---- random shapes (tests/test_random_shapes_gpu.py: K, M, V, U drawn at random, one-document and one-term corpora, long documents)
-    "rand.lda.gamma_rel":       (2e-4, None),
-    "rand.lda.beta_rel":        (2e-4, None),
-    "rand.lda.alpha_rel":       (1e-4, None),
-    "rand.lda.elbo_rel":        (2e-6, None),
-    "rand.ctm.lambda_err":      (2e-3, None),      # max |dlambda| / (1 + max |lambda|), default exit rules
-    "rand.ctm.vsq_rel":         (2e-3, None),
-    "rand.ctm.mu_abs":          (2e-4, None),
-    "rand.ctm.sigma_err":       (5e-4, None),
-    "rand.ctpf.shape_rel":      (5e-4, None),
-    "rand.ctpf.rates_rel":      (1e-4, None),
+    "rand.lda.gamma_rel":       (5e-06, 7.08e-07),
+    "rand.lda.beta_rel":        (5e-06, 9.56e-07),
+    "rand.lda.alpha_rel":       (0.0001, 1.43e-05),
+    "rand.lda.elbo_rel":        (5e-06, 1.13e-06),
+    "rand.ctm.lambda_err":      (5e-05, 6.17e-06),      # max |dlambda| / (1 + max |lambda|), default exit rules
+    "rand.ctm.vsq_rel":         (5e-05, 9.53e-06),
+    "rand.ctm.mu_abs":          (1e-05, 1.35e-06),
+    "rand.ctm.sigma_err":       (2e-05, 3.1e-06),
+    "rand.ctpf.shape_rel":      (3e-05, 4.63e-06),
+    "rand.ctpf.rates_rel":      (5e-06, 7.61e-07),
 }
 LAMBDA_ABS, LAMBDA_REL = 1.5e-5, 1.5e-5           # the bound ctm.lambda_err is measured against (round 4: 1.5e-4 + 1.5e-4 |lambda|, 11x looser than the worst case)
 
