@@ -220,6 +220,44 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
         partial[(int64_t)blockIdx.x * K + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
 }
 
+// The same with a SECOND buffer folded in on the way: X += Xb, Xb = 0, and the column sums are those of the merged values (LDA, round 5: the last
+// statistics pass of the pipelined E-step writes its own buffer so that it need not wait for the passes before it; update_beta! merges here, in the
+// pass over the statistics it makes anyway).  Same summation order as colsum_partial_kernel.
+template <int NSLOT>
+__global__ __launch_bounds__(256) void colsum_merge_partial_kernel(float* __restrict__ X, float* __restrict__ Xb, int64_t ncols, int K,
+                                                                   double* __restrict__ partial)
+{
+    __shared__ double red[4][64 * NSLOT];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t gw = (int64_t)blockIdx.x * 4 + wv, nw = (int64_t)gridDim.x * 4;
+    double acc[NSLOT];
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) acc[s] = 0.0;
+#pragma unroll 8
+    for (int64_t c = gw; c < ncols; c += nw) {
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+            int i = lane + 64 * s;
+            if (i < K) {
+                const float v = X[c * K + i] + Xb[c * K + i];
+                X[c * K + i] = v; Xb[c * K + i] = 0.0f;
+                acc[s] += (double)v;
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) red[wv][lane + 64 * s] = acc[s];
+    __syncthreads();
+    for (int i = threadIdx.x; i < K; i += 256)
+        partial[(int64_t)blockIdx.x * K + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+}
+// X += Xb, Xb = 0 (the merge alone, for the callers that hand the statistics out before update_beta!)
+static __global__ __launch_bounds__(256) void stats_merge_kernel(float* __restrict__ X, float* __restrict__ Xb, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += stride) { X[q] += Xb[q]; Xb[q] = 0.0f; }
+}
+
 // out_d[i] = sum_b partial[b][i]: one wave per output, fixed reduction tree (deterministic); optional fp32 copy
 static __global__ __launch_bounds__(256) void colsum_final_kernel(const double* __restrict__ partial, int nblocks, int K,
                                                            double* __restrict__ out_d, float* __restrict__ out_f)

@@ -1039,6 +1039,10 @@ struct tmvb_lda {
     float* d_beta[2] = {nullptr, nullptr};
     int cur = 0;                       // d_beta[cur] = beta, d_beta[cur^1] = beta_old
     float* d_stats = nullptr;          // S (K*V) | Elogtheta_sum (K)
+    // round 5: the LAST statistics pass of the pipelined E-step writes its own buffer (and its own multi-chunk partials), so that it starts behind the last
+    // document kernel instead of behind the passes before it (which accumulate in order on aux[0]); update_beta! merges (colsum_merge_partial_kernel)
+    float* d_stats_b = nullptr; float* d_ts_partial_b = nullptr;
+    bool stats_b_live = false;         // d_stats_b holds statistics that d_stats does not
     bool own_stats = true;
     float* d_gamma = nullptr;
     float* d_elog = nullptr;
@@ -1265,6 +1269,18 @@ static int lda_join_side(tmvb_lda* h)
     return TMVB_OK;
 }
 
+// the statistics as ONE buffer again (for whoever hands d_stats out before update_beta!, which merges on its own way)
+static int lda_merge_stats(tmvb_lda* h)
+{
+    if (!h->stats_b_live) return TMVB_OK;
+    const int64_t n = (int64_t)h->K * h->V;
+    const int nb = (int)std::min<int64_t>(2048, std::max<int64_t>(1, (n + 255) / 256));
+    hipLaunchKernelGGL(stats_merge_kernel, dim3(nb), dim3(256), 0, h->ctx->stream, h->d_stats, h->d_stats_b, n);
+    TMVB_HIP(hipGetLastError());
+    h->stats_b_live = false;
+    return TMVB_OK;
+}
+
 extern "C" int tmvb_lda_destroy(tmvb_lda* h)
 {
     if (!h) return TMVB_OK;
@@ -1272,6 +1288,7 @@ extern "C" int tmvb_lda_destroy(tmvb_lda* h)
     for (int a = 0; a < tmvb_lda::NAUX; ++a) if (h->aux[a]) (void)hipStreamSynchronize(h->aux[a]);
     if (h->ctx) (void)hipStreamSynchronize(h->ctx->stream);
     (void)hipFree(h->d_alpha_d); (void)hipFree(h->d_alpha_f); (void)hipFree(h->d_beta[0]); (void)hipFree(h->d_beta[1]);
+    (void)hipFree(h->d_stats_b); (void)hipFree(h->d_ts_partial_b);
     if (h->own_stats) (void)hipFree(h->d_stats);
     (void)hipFree(h->d_wtok); (void)hipFree(h->d_E); (void)hipFree(h->d_ts_partial);
     (void)hipFree(h->d_topic_of_lane); (void)hipFree(h->d_grid_topic_of_lane);
@@ -1571,10 +1588,26 @@ static int lda_estep_impl(tmvb_lda* h, int32_t viter, double vtol)
     tp.out = h->d_stats; tp.partial = h->d_ts_partial; tp.estride = h->e_padded ? h->estride : 0;
     // gather-side statistics of the documents whose kernels precede `after` on its stream:
     //   S[:, j] += beta[:, j] .* sum_tokens w E[:, doc] + eps sum w     (update_beta!(model, d))
-    auto stats_pass = [&](const tmvb_inv_index& ix, hipStream_t on) -> int {
+    auto stats_pass = [&](const tmvb_inv_index& ix, hipStream_t on, const TermStatsParams& tpp) -> int {
         if ((p.debug & 1) || ix.n_chunks <= 0) return TMVB_OK;
-        return tmvb_launch_termstats(ctx, h->nslot, h->KP, h->e_padded, ix, tp, on);
+        return tmvb_launch_termstats(ctx, h->nslot, h->KP, h->e_padded, ix, tpp, on);
     };
+    // Round 5: the passes before the last accumulate in order in d_stats on aux[0]; the LAST pass, on the context's stream behind the last document
+    // kernel, used to wait for them (round 4's timeline: last document kernel done at 589 us, pass 2 + its combine at 625 us, one cross-queue hop, last
+    // pass 637 - 705 us -- 48 us of a 750 us iteration with the chain waiting).  It now writes a buffer of its own (and its own multi-chunk partials) and
+    // starts at once; the join with aux[0] moves behind it, and update_beta!'s column-sum pass adds the two buffers on its way.  One context only (a
+    // sharded handle all-reduces d_stats); TMVB_LDA_SPLIT_OUT=0: the round-4 order.
+    static const bool split_out_env = [] { const char* e = getenv("TMVB_LDA_SPLIT_OUT"); return !(e && atoi(e) == 0); }();
+    bool split_out = split_out_env && shadow_stats && !h->distributed && h->comm == nullptr && !h->ar_live && !(p.debug & 1);
+    if (split_out && !h->d_stats_b) {
+        size_t slots = 1;
+        for (const tmvb_inv_index& ix : h->pieces) slots = std::max(slots, (size_t)ix.n_slots);
+        int arc = dmalloc(&h->d_stats_b, (size_t)h->K * h->V);
+        if (!arc) arc = dmalloc(&h->d_ts_partial_b, slots * (size_t)(h->K + 1));
+        if (arc) return arc;
+        TMVB_HIP(hipMemsetAsync(h->d_stats_b, 0, (size_t)h->K * h->V * sizeof(float), ctx->stream));
+    }
+    if (split_out) { int mrc = lda_merge_stats(h); if (mrc) return mrc; }      // (an E-step behind an E-step without update_beta!: keep what is there)
     int piece_open = 0;                                 // pieces [0, piece_open) have their statistics pass issued
     auto close_pieces = [&](int upto) -> int {          // document kernels of pieces < upto are all issued
         for (; piece_open < upto; ++piece_open) {
@@ -1589,7 +1622,7 @@ static int lda_estep_impl(tmvb_lda* h, int32_t viter, double vtol)
                     pass_st = h->aux[0];
                     TMVB_HIP(hipEventRecord(h->ev_piece[piece_open], chain_st));
                     TMVB_HIP(hipStreamWaitEvent(pass_st, h->ev_piece[piece_open], 0));
-                } else {                                 // the passes accumulate in order: the last one waits for aux[0]'s
+                } else if (!split_out) {                 // the passes accumulate in order: the last one waits for aux[0]'s
                     TMVB_HIP(hipEventRecord(h->ev_join[0], h->aux[0]));
                     TMVB_HIP(hipStreamWaitEvent(ctx->stream, h->ev_join[0], 0));
                 }
@@ -1605,7 +1638,17 @@ static int lda_estep_impl(tmvb_lda* h, int32_t viter, double vtol)
                 }
                 continue;
             }
-            int rc = stats_pass(piece_index(piece_open), pass_st);
+            if (split_out && piece_open == P - 1) {      // its own buffer, no wait; then the join with the passes before it
+                TermStatsParams tpb = tp;
+                tpb.out = h->d_stats_b; tpb.partial = h->d_ts_partial_b;
+                int rc = stats_pass(piece_index(piece_open), pass_st, tpb);
+                if (rc) return rc;
+                h->stats_b_live = true;
+                TMVB_HIP(hipEventRecord(h->ev_join[0], h->aux[0]));
+                TMVB_HIP(hipStreamWaitEvent(ctx->stream, h->ev_join[0], 0));
+                continue;
+            }
+            int rc = stats_pass(piece_index(piece_open), pass_st, tp);
             if (rc) return rc;
         }
         return TMVB_OK;
@@ -1832,6 +1875,7 @@ extern "C" int tmvb_lda_stats(tmvb_lda* h, void** dev_ptr, int64_t* n_f32)
     TMVB_REQUIRE(h && dev_ptr && n_f32, TMVB_EINVAL, "tmvb_lda_stats: NULL argument");
     TMVB_HIP(hipSetDevice(h->ctx->device));
     { int jrc = lda_join_side(h); if (jrc) return jrc; }
+    { int mrc = lda_merge_stats(h); if (mrc) return mrc; }
     *dev_ptr = h->d_stats;
     *n_f32 = (int64_t)h->K * h->V + h->K;
     return TMVB_OK;
@@ -1845,6 +1889,7 @@ extern "C" int tmvb_lda_bind_stats(tmvb_lda* h, void* dev_ptr, int64_t n_f32)
     h->mark_valid = false;
     TMVB_HIP(hipSetDevice(h->ctx->device));
     { int jrc = lda_join_side(h); if (jrc) return jrc; }
+    { int mrc = lda_merge_stats(h); if (mrc) return mrc; }
     TMVB_HIP(hipMemcpyAsync(dev_ptr, h->d_stats, (size_t)need * sizeof(float), hipMemcpyDeviceToDevice, h->ctx->stream));
     TMVB_HIP(hipStreamSynchronize(h->ctx->stream));
     if (h->own_stats) (void)hipFree(h->d_stats);
@@ -1874,8 +1919,23 @@ extern "C" int tmvb_lda_update_beta(tmvb_lda* h)
         TMVB_HIP(hipEventRecord(h->ev_mark, ctx->stream));
         h->mark_valid = true;
     }
-    int rc = colsum(h, h->d_stats, h->V, h->d_rowsum, nullptr);
-    if (rc) return rc;
+    int rc;
+    if (h->stats_b_live) {                                  // the last statistics pass's own buffer, folded in by the column-sum pass itself
+        const int nbc = tmvb_colsum_blocks(h->V);
+        rc = dispatch_nslot(h->nslot, [&](auto ns) -> int {
+            constexpr int NS = decltype(ns)::value;
+            hipLaunchKernelGGL((colsum_merge_partial_kernel<NS>), dim3(nbc), dim3(256), 0, ctx->stream, h->d_stats, h->d_stats_b, h->V, h->K, h->d_partial);
+            return TMVB_OK;
+        });
+        if (rc) return rc;
+        TMVB_HIP(hipGetLastError());
+        hipLaunchKernelGGL(colsum_final_kernel, dim3((h->K + 3) / 4), dim3(256), 0, ctx->stream, h->d_partial, nbc, h->K, h->d_rowsum, (float*)nullptr);
+        TMVB_HIP(hipGetLastError());
+        h->stats_b_live = false;
+    } else {
+        rc = colsum(h, h->d_stats, h->V, h->d_rowsum, nullptr);
+        if (rc) return rc;
+    }
     const int64_t total = (int64_t)h->KP * h->V;
     int nb = (int)std::min<int64_t>(2048, std::max<int64_t>(1, (total + 255) / 256));
     hipLaunchKernelGGL(beta_norm_kernel, dim3(nb), dim3(256), (size_t)h->K * sizeof(double), ctx->stream,
@@ -1996,7 +2056,7 @@ struct LdaTrainOps {
     int estep(tmvb_lda* h) { return tmvb_lda_estep(h, viter, vtol); }                 // src/LDA.jl:170-180
     int reduce(tmvb_lda* h) { return tmvb_lda_reduce_docs(h); }                       // :98
     int estep_allreduce(tmvb_lda* h) { return tmvb_lda_estep_allreduce(h, viter, vtol); }   // one process per GPU: the three steps with the collective sliced
-    int before_allreduce(tmvb_lda* h) { TMVB_HIP(hipSetDevice(h->ctx->device)); return lda_join_side(h); }
+    int before_allreduce(tmvb_lda* h) { TMVB_HIP(hipSetDevice(h->ctx->device)); int rc = lda_join_side(h); return rc ? rc : lda_merge_stats(h); }
     float* stats(tmvb_lda* h) { return h->d_stats; }
     int64_t stats_len(tmvb_lda* h) { return (int64_t)h->K * h->V + h->K; }
     int mstep(tmvb_lda* h) { int rc = tmvb_lda_update_beta(h); return rc ? rc : tmvb_lda_update_alpha(h, niter, ntol); }   // :181-182
