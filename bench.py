@@ -81,7 +81,7 @@ def pmc_traffic(K, M, nnz):
     passes of this same command, tools/pmc_summary.py), corrected as MI355X_MICROARCH.md's HBM section prescribes for
     gfx950 (2 x FETCH_SIZE; KB units).  Returned only when the summary was collected on this workload AND on the kernel
     sources this run is built from (source hash stamped into the summary); otherwise null with the reason."""
-    for name in ("r4_lda50_pmc.json", "r3_lda_k50_pmc.json", "r2_lda_k50_pmc.json", "r1_lda_k50_pmc.json"):
+    for name in ("r5_lda50_pmc.json", "r4_lda50_pmc.json", "r3_lda_k50_pmc.json", "r2_lda_k50_pmc.json", "r1_lda_k50_pmc.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             break

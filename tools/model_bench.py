@@ -76,20 +76,32 @@ def pmc_traffic(name):
     from bench import kernel_source_hash as _ksh
     fam = "lda" if name.startswith("lda") else name
     kernel_source_hash = lambda: _ksh(fam)
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", f"r4_{name}_pmc.json")
-    if not os.path.exists(path):
-        return None, f"no profiles/r4_{name}_pmc.json"
-    rows = json.load(open(path))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cands = [f"r5_{name}_pmc.json", f"r4_{name}_pmc.json"]
+    fname = next((c for c in cands if os.path.exists(os.path.join(root, "profiles", c))), None)
+    pmc_traffic.valu_issue_cycles = None
+    if fname is None:
+        return None, f"no profiles/r5_{name}_pmc.json"
+    rows = json.load(open(os.path.join(root, "profiles", fname)))
     meta = rows.get("_meta", {})
     if meta.get("kernel_source_hash") != kernel_source_hash():
-        return None, f"profiles/r4_{name}_pmc.json was collected on kernel sources {meta.get('kernel_source_hash')}, this build is {kernel_source_hash()} (stale)"
+        return None, f"profiles/{fname} was collected on kernel sources {meta.get('kernel_source_hash')}, this build is {kernel_source_hash()} (stale)"
     tot = sum((2.0 * r["fetch_kb_per_iteration"] + r["write_kb_per_iteration"]) * 1024.0 for k, r in rows.items() if k != "_meta")
-    return tot, f"profiles/r4_{name}_pmc.json (rocprofv3 --pmc, separate passes; 2*FETCH_SIZE+WRITE_SIZE over every dispatch of {meta.get('iterations')} iterations / that count)"
+    iss = [r.get("valu_issue_cycles_per_simd_per_iteration") for k, r in rows.items() if k != "_meta"]
+    pmc_traffic.valu_issue_cycles = sum(x for x in iss if x) if any(iss) else None     # VALU-issue cycles per SIMD of one iteration's kernels (third pass)
+    return tot, f"profiles/{fname} (rocprofv3 --pmc, separate passes; 2*FETCH_SIZE+WRITE_SIZE over every dispatch of {meta.get('iterations')} iterations / that count)"
 
 
-def _traffic_fields(name, B):
+def _traffic_fields(name, B, sec=None):
+    """traffic from the counters, and the SECOND yardstick beside the byte model (round-4 review: LDA K = 100 reports 0.98 of the HBM roofline on
+    ALGORITHMIC bytes, more than a copy achieves -- the byte model has saturated): valu_issue_frac = VALU-issue cycles per SIMD of one iteration's kernels
+    (4 x SQ_ACTIVE_INST_VALU / 1024 SIMDs, counters collected with the kernels serialised) / (this run's seconds per iteration x 2.4 GHz) -- the share of the
+    iteration during which an average SIMD issues a vector instruction.  It is bounded by 1 whatever the caches absorb."""
     t, src = pmc_traffic(name)
-    return {"traffic": t, "traffic_source": src, "traffic_over_algorithmic": (t / B) if t else None}
+    out = {"traffic": t, "traffic_source": src, "traffic_over_algorithmic": (t / B) if t else None}
+    iss = getattr(pmc_traffic, "valu_issue_cycles", None)
+    out["valu_issue_frac"] = (iss / (sec * 2.4e9)) if (iss and sec) else None
+    return out
 
 
 def window(fn, sync, burnin, warmup, steps):
@@ -123,7 +135,7 @@ def lda100(burnin=60, warmup=3, steps=20, cpu=True):
                                    f"{warmup} warm-up + {steps} timed", "M": pc.M, "V": pc.V, "nnz": pc.nnz, "sweep_hist_last_step": hist},
             "cold_start": {"value": 1.0 / cold, "ms_per_step": 1e3 * cold, "window": f"iterations {warmup + 1}..{warmup + steps} from the cold start"},
             "roofline": {"bound": "hbm", "achieved": B / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": B / sec / 1e9 / HBM_PEAK_GBS,
-                         "algorithmic_bytes_per_iteration": B, **_traffic_fields("lda100", B)}}
+                         "algorithmic_bytes_per_iteration": B, **_traffic_fields("lda100", B, sec)}}
     gm.close()
     if cpu:
         line["cpu_baseline"] = lda100_cpu(pc)
@@ -195,7 +207,7 @@ def ctm(burnin=60, warmup=2, steps=8, cpu=True, K=50):        # 60 burn-in itera
                          "executed_frac": (F_exec / sec / 1e12 / F32_PEAK_TFLOPS) if F_exec else None,
                          "executed_is": "64 lanes x (CG wave trips x (2 KP^2 + 12 KP) + Newton wave trips x (2 KP^2 + 24 KP)) + token phase; idle lanes of a trip included",
                          "hbm_GBs": B / sec / 1e9, "hbm_frac": B / sec / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_iteration": B,
-                         **(_traffic_fields("ctm", B) if K == 50 else {"traffic": None})}}
+                         **(_traffic_fields("ctm", B, sec) if K == 50 else {"traffic": None})}}
     gm.close()
     if cpu and K == 50:
         line["cpu_baseline"] = ctm_cpu(pc)
@@ -268,7 +280,7 @@ def ctpf(burnin=300, warmup=10, steps=200, cpu=True):
                        "M": pc.M, "V": pc.V, "U": pc.U, "nnz": pc.nnz, "nR": pc.nR, "sweep_hist_last_step": hist},
             "cold_start": {"value": 1.0 / cold, "ms_per_step": 1e3 * cold, "window": "iterations 6..55 from the cold start"},
             "roofline": {"bound": "hbm", "achieved": B / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": B / sec / 1e9 / HBM_PEAK_GBS,
-                         "algorithmic_bytes_per_iteration": B, **_traffic_fields("ctpf", B)},
+                         "algorithmic_bytes_per_iteration": B, **_traffic_fields("ctpf", B, sec)},
             "recommend": {"ms_scores": ms_s, "ms_rank": ms_r, "pairs": pc.M * pc.U}}
     gm.close()
     if cpu:
