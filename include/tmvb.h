@@ -228,8 +228,12 @@ int tmvb_lda_set_comm(tmvb_lda* h, tmvb_comm* comm, int64_t M_total);
  * instead of after the whole buffer; (2) with TMVB_AR_SLICES = S > 1 (default 1) the last statistics pass runs in S vocabulary
  * slices and the slab of S a slice completes is all-reduced on the side stream while the next slice's pass runs; (3) the last
  * (or only) slab on the context's stream.  The first call on a communicator is collective beyond that: the ranks sum their
- * postings per term (V doubles) to agree on the cuts and the order.  Every rank must call it the same number of times; results
- * are bit-identical to the three-call form's.  TMVB_EINVAL without a communicator. */
+ * postings per term (V doubles) to agree on the cuts and the order.  Every rank must call it the same number of times.  Results are
+ * identical on every rank, and equal to the three-call form's up to the fp32 summation order of the collective: bit for bit with one or two
+ * ranks (tests/test_sliced_allreduce_gpu.py), while with three or more the ring / tree chunking of RCCL depends on a buffer's offset and length, so
+ * the K-float tail and the slabs reduced as separate collectives may differ from ONE collective of K*V + K floats in the last bit.
+ * OPT-IN since round 5: the library's sharded train! and bench.py issue the three-call form (one collective per iteration) unless
+ * TMVB_FUSED_ALLREDUCE=1 -- two streams of collectives on one communicator have not run on multi-GPU hardware yet.  TMVB_EINVAL without a communicator. */
 int tmvb_lda_estep_allreduce(tmvb_lda* h, int32_t viter, double vtol);
 
 /* The slab plan tmvb_lda_estep_allreduce derives from the GLOBAL postings per term (host arithmetic only, no device: every rank
@@ -291,12 +295,15 @@ int tmvb_flda_last_estep_ms(tmvb_flda* h, float* ms);
 
 /* gpuCTM(corp, K) (src/gpuCTM.jl:45-98).  Constructor state as src/CTM.jl:37-48 (mu=0, sigma=invsigma=I,
  * lambda=0, vsq=1, logzeta=0.5); beta is uniform until tmvb_ctm_set_state (the reference draws it with
- * Julia's RNG).  K <= 128.  Three E-step kernels behind tmvb_ctm_estep: K <= 52 -- one LANE per
+ * Julia's RNG).  K <= 256 (CTM_MAX_K; beyond it the Julia shim trains on the reference's CPU model behind a warning).  E-step kernels behind
+ * tmvb_ctm_estep: K <= 52 -- one LANE per
  * document, invsigma streamed through scalar registers, the lambda Newton systems solved by Jacobi-preconditioned CG to
  * max(1e-4 |g|, 5 % of ntol); its documents of more than 2048 unique terms (and everything under TMVB_CTM_BATCH=0) -- one wave
  * per document, Gauss-Jordan in registers (lane = matrix row); 52 < K <= 128 -- one wave per document, lane = matrix row (two
  * topic slots per lane beyond 64), the same CG against one copy of invsigma in LDS per workgroup (TMVB_CTM_GENERIC_CG=0: round 1's
- * Gauss-Jordan through LDS, 30 times slower at K = 100). */
+ * Gauss-Jordan through LDS, 30 times slower at K = 100); 128 < K <= 256 -- four topic slots per lane, invsigma read from global memory by
+ * columns (L2-resident), the whole LDS for the tile windows, update_sigma!'s fp64 inversion in a global workspace, dense E rows and the
+ * scalar statistics kernel beyond KP / 4 = 64 chunks (K > 252).  fCTM: the same limits. */
 int tmvb_ctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb_ctm** out);
 int tmvb_ctm_destroy(tmvb_ctm* h);
 
@@ -387,7 +394,9 @@ int tmvb_fctm_doc_sweeps(tmvb_fctm* h, uint8_t* out);
 
 /* gpuCTPF(corp, K) (src/gpuCTPF.jl:68-152).  Constructor state as src/CTPF.jl:81-100 (he=1, rates=1, gimel=zayin=1,
  * hyper-parameters a..h = 0.1); alef is 1 until tmvb_ctpf_set_state (the reference draws it with Julia's RNG, :83).
- * K <= 128 (lane l owns topics l and l + 64); the grid-tile fast path (one topic slot per lane of a 16 x 4 lane grid) covers K <= 60. */
+ * K <= 512: the grid-tile fast path (one topic slot per lane of a 16 x 4 lane grid) covers K <= 60; beyond it one wave per document with
+ * 2 / 4 / 8 topic slots per lane (lane l owns topics l, l + 64, ...: K <= 128 / 256 / 512), rows of more than 64 chunks through dense E rows
+ * and the scalar statistics kernel. */
 int tmvb_ctpf_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb_ctpf** out);
 int tmvb_ctpf_destroy(tmvb_ctpf* h);
 /* update_buffer! state half (src/modelutils.jl:474-493).  hyper[8] = a..h; alef[K*V], he[K*U], bet/vav/dalet/het[K],

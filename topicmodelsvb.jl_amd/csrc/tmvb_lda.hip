@@ -1043,6 +1043,7 @@ struct tmvb_lda {
     // document kernel instead of behind the passes before it (which accumulate in order on aux[0]); update_beta! merges (colsum_merge_partial_kernel)
     float* d_stats_b = nullptr; float* d_ts_partial_b = nullptr;
     bool stats_b_live = false;         // d_stats_b holds statistics that d_stats does not
+    bool events_system_scope = false;  // a communicator was attached: the ordering events carry the system-scope fence (tmvb_lda_set_comm)
     bool own_stats = true;
     float* d_gamma = nullptr;
     float* d_elog = nullptr;
@@ -1810,7 +1811,7 @@ static int lda_ar_prepare(tmvb_lda* h)
                      (long long)slot.n_slots, (long long)old_slots);
         while ((int)h->ev_slice.size() < S) {
             hipEvent_t ev = nullptr;
-            TMVB_HIP(hipEventCreateWithFlags(&ev, tmvb_event_flags()));
+            TMVB_HIP(hipEventCreateWithFlags(&ev, h->events_system_scope ? (unsigned)hipEventDisableTiming : tmvb_event_flags()));
             h->ev_slice.push_back(ev);
         }
     }
@@ -2047,6 +2048,26 @@ extern "C" int tmvb_lda_set_comm(tmvb_lda* h, tmvb_comm* comm, int64_t M_total)
     if (rc) return rc;
     h->comm = comm;
     h->ar_comm = nullptr;                               // the plan is agreed anew on every attach (a new communicator may live at an old address)
+    if (comm != nullptr && !h->events_system_scope) {
+        // Round-4 advice: the events that order this device's kernels BEFORE a collective (ev_side / ev_docs / ev_chain / ev_join / ev_piece on the way to
+        // the statistics buffer, ev_slice behind a slab's pass) were created with tmvb_event_flags(), i.e. without the system-scope release a default
+        // event performs -- right between the streams of ONE device, unvalidated when a peer reads the send buffer directly over xGMI.  A handle with
+        // a communicator therefore gets them recreated as plain events (system-scope fence), once; single-device handles keep the cheap ones.
+        TMVB_HIP(hipSetDevice(h->ctx->device));
+        TMVB_HIP(hipStreamSynchronize(h->ctx->stream));
+        for (int a = 0; a < tmvb_lda::NAUX; ++a) if (h->aux[a]) TMVB_HIP(hipStreamSynchronize(h->aux[a]));
+        auto remake = [](hipEvent_t& ev) -> hipError_t {
+            if (!ev) return hipSuccess;
+            (void)hipEventDestroy(ev); ev = nullptr;
+            return hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        };
+        TMVB_HIP(remake(h->ev_fork)); TMVB_HIP(remake(h->ev_docs)); TMVB_HIP(remake(h->ev_side)); TMVB_HIP(remake(h->ev_chain));
+        for (int a = 0; a < tmvb_lda::NAUX; ++a) TMVB_HIP(remake(h->ev_join[a]));
+        for (hipEvent_t& ev : h->ev_piece) TMVB_HIP(remake(ev));
+        for (hipEvent_t& ev : h->ev_slice) TMVB_HIP(remake(ev));
+        h->side_pending = false; h->mark_valid = false;
+        h->events_system_scope = true;
+    }
     return TMVB_OK;
 }
 
