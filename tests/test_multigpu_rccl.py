@@ -55,10 +55,12 @@ K_OF = {"lda": 50, "ctm": 12, "ctpf": 20}
 ITERS = 4
 
 
-def _worker(rank, world, initfile, out_dir, model):
+def _worker(rank, world, initfile, out_dir, model, fused=None):
     """one process per GPU: device `rank`, RCCL communicator from a unique id published through the torch store"""
     sys.path.insert(0, ROOT)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if fused is not None:
+        os.environ["TMVB_FUSED_ALLREDUCE"] = fused            # read once per process by the library's train! (csrc/tmvb_train.h)
     import torch.distributed as dist
     import tmvb_amd
     dist.init_process_group("gloo", init_method=f"file://{initfile}", rank=rank, world_size=world)
@@ -189,3 +191,27 @@ def test_rccl_init_all_group_train_one_host_thread(tmvb, model):
     for g, c in zip(gms, comms):
         g.set_comm(None) if model == "ctpf" else g.set_comm(None, g.M)
         g.close(); c.close()
+
+
+@needs2
+def test_fused_allreduce_form_over_real_rccl_equals_the_single_collective(tmvb):
+    """Round-4 advice: the fused form of the sharded LDA iteration (tmvb_lda_estep_allreduce: the K-float tail all-reduced early on a side stream, the
+    statistics behind it -- two streams of collectives on ONE communicator) had only ever run over RCCL with one rank, where RCCL launches no collective
+    kernel at all.  It is opt-in (TMVB_FUSED_ALLREDUCE=1) until THIS test has passed on a multi-GPU node: both forms over real RCCL, one process per
+    GPU, the same corpus and start; identical globals on every rank within each form, and form against form bit for bit at two ranks (an all-reduce of two
+    addends has one summation order), to fp32 summation order beyond."""
+    import torch.multiprocessing as mp
+    world = _world()
+    out = {}
+    for fused in ("0", "1"):
+        with tempfile.TemporaryDirectory() as td:
+            mp.spawn(_worker, args=(world, os.path.join(td, "init"), td, "lda", fused), nprocs=world, join=True)
+            out[fused] = [dict(np.load(os.path.join(td, f"rank{r}.npz"))) for r in range(world)]
+        _check(tmvb, "lda", out[fused])
+    for r in range(world):
+        for n in ("alpha", "beta", "traj"):
+            a, b = out["0"][r][n], out["1"][r][n]
+            if world == 2:
+                assert np.array_equal(a, b), (r, n)
+            else:
+                np.testing.assert_allclose(a, b, rtol=2e-6, atol=1e-12)
