@@ -29,12 +29,22 @@ MUTANTS = {
 }
 
 
+def _source_hash():
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(PKG, "csrc")
+    for f in sorted(os.listdir(d)):                       # the order of the shell's `cat csrc/*` (C locale: plain byte order of these ASCII names)
+        h.update(open(os.path.join(d, f), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "tmvb.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _ensure(name):
     """the mutant library, built here if the tree does not carry a current one (tools/build_variant.sh links it from the shipped objects)"""
     unit, flag, _ = MUTANTS[name]
     lib = os.path.join(PKG, f"libtmvb_hip_{name}.so")
-    srcs = [os.path.join(PKG, "csrc", f) for f in os.listdir(os.path.join(PKG, "csrc"))]
-    if os.path.exists(lib) and all(os.path.getmtime(lib) >= os.path.getmtime(f) for f in srcs):
+    stamp = os.path.join(PKG, f"libtmvb_hip_{name}.stamp")      # written by tools/build_variant.sh: content hash of the sources + the flags
+    if os.path.exists(lib) and os.path.exists(stamp) and open(stamp).read().split() == [_source_hash(), unit, flag]:
         return lib
     if not os.path.exists(os.path.join(PKG, "build", unit + ".o")):
         import tmvb_amd

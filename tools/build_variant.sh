@@ -13,4 +13,7 @@ for o in "$P"/build/*.hip.o; do
   if [ "$(basename "$o")" = "$unit.o" ]; then objs="$objs $P/build/var_$name/$unit.o"; else objs="$objs $o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o "$P/libtmvb_hip_$name.so" $objs -ldl -Wl,-rpath,/opt/rocm/lib
+# stamp: what the variant was built from (content hash of the sources + the flags), so that a test can tell a current variant from a stale one without
+# trusting file times (a git checkout or a snapshot copy resets them)
+( cd "$R" && cat topicmodelsvb.jl_amd/csrc/* include/tmvb.h | sha256sum | cut -c1-16; echo "$unit $*" ) > "$P/libtmvb_hip_$name.stamp"
 echo "built $P/libtmvb_hip_$name.so"
