@@ -50,7 +50,7 @@ for step in "$@"; do
             python tools/counter_summary.py "$db" > "$O/pmc_$name.txt" 2>&1; head -30 "$O/pmc_$name.txt"
             [ -z "$KEEP_DB" ] && [ -z "$PMC_KEEP_DB" ] && find "$O/pmc_$name" -name "*.db" -delete ;;
     pmcbytes) # pmcbytes:<lda50|lda100|ctm|ctpf>: FETCH_SIZE and WRITE_SIZE in separate passes over tools/pmc_window.py <model> 20 6,
-            # summarised per kernel and per iteration with the kernel-source hash stamped in -> <model>_pmc.json / .txt (copy to profiles/r4_<model>_pmc.*)
+            # summarised per kernel and per iteration with the kernel-source hash stamped in -> <model>_pmc.json / .txt (copy to profiles/r5_<model>_pmc.*)
             for c in FETCH_SIZE WRITE_SIZE; do
               ( cd /tmp && timeout 900 rocprofv3 --pmc $c --kernel-trace -d "$O/pmcb_${arg}_$c" -- python $R/tools/pmc_window.py $arg 20 6 ) > "$O/pmcb_${arg}_$c.log" 2>&1; echo "rc=$?" >> "$O/pmcb_${arg}_$c.log"
             done
