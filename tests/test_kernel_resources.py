@@ -25,7 +25,7 @@ def test_every_benched_kernel_is_found_and_within_its_scratch_ceiling(rows):
     assert len(rows) > 300
     assert kr.check(rows) == []
     ctm = [r for r in rows if r["demangled"].startswith("ctm_estep_batch_kernel<52, false, false>")]
-    assert len(ctm) == 1 and ctm[0]["vgpr"] == 512 and 0 < ctm[0]["scratch"] <= 428       # the one benched kernel that spills: recorded, bounded
+    assert len(ctm) == 1 and ctm[0]["vgpr"] == 512 and 0 < ctm[0]["scratch"] <= 388       # the one benched kernel that spills: recorded, bounded
     lda = [r for r in rows if r["demangled"].startswith("lda_estep_grid_kernel<13,")]
     assert lda and all(r["scratch"] == 0 and r["vgpr_spills"] == 0 and r["vgpr"] <= 256 for r in lda)   # two waves per SIMD, no scratch
 

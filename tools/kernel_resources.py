@@ -23,14 +23,14 @@ READELF = os.environ.get("LLVM_READELF", "/opt/rocm/lib/llvm/bin/llvm-readelf")
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 
 # The kernels behind the numbers of bench.py's line (demangled-name prefixes) and the scratch bytes per lane each may use.  Everything that is
-# timed runs without scratch -- except the lane-per-document CTM kernel, whose 428 B are a measured fact of round 4 that round 5 could not remove
+# timed runs without scratch -- except the lane-per-document CTM kernel, whose 388 B (428 in round 4) round 5 could not remove
 # without losing time (profiles/r5_ctm_token_experiments.txt); its ceiling is that figure, so that it cannot silently grow.
 BENCHED = {
     # config 2 / 3: LDA K = 50 (13 chunks per row) and K = 100 (25)
     "lda_estep_grid_kernel<13,": 0, "lda_estep_grid_kernel<25,": 0, "lda_estep_grid_long_kernel<13,": 0, "lda_estep_grid_long_kernel<25,": 0,
     "termstats_recompute_kernel<13,": 0, "termstats_recompute_kernel<25,": 0, "termstats_multi_kernel": 0, "beta_norm_kernel": 0, "lda_alpha_kernel<": 0,
     # config 4: CTM K = 50
-    "ctm_estep_batch_kernel<52, false, false>": 428, "ctm_scatter_mfma_kernel": 0, "ctm_sigma_mu_kernel": 0,
+    "ctm_estep_batch_kernel<52, false, false>": 388, "ctm_scatter_mfma_kernel": 0, "ctm_sigma_mu_kernel": 0,
     # config 5: CTPF K = 50
     "ctpf_estep_grid_narrow_kernel<13>": 0, "ctpf_estep_grid_wide_kernel<13>": 0, "ctpf_estep_grid_long2_kernel<13>": 0, "termstats_recompute2_kernel<13": 0,
     "ctpf_mstep_kernel": 0,

@@ -449,11 +449,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     {
         const float* lam_in = CB_KARG(const float*, p.lambda);
         const float* vsq_in = CB_KARG(const float*, p.vsq);
+        {
+            // Round 5: KP - K <= 7, so only the last seven topics can be pads -- the K tests of this loop, of the lambda_old store / read-back and of the vsq groups
+            // fold at compile time for the other 45 (`i < R - 7 || i < K`), and the pad rows load through a clamped index and a select instead of a branch.
+            // 52 branches with spilled lane masks fewer per item and sweep: 207.6 -> 216.1 VB it/s (five alternating rounds, profiles/r5_ctm_token_experiments.txt (8)).
+            // The same fold in the gradient assembly and in the final stores measured worse or equal (another register allocation) and is NOT applied there.
+            const float* lrow = lam_in + (int64_t)d * K;
+            const float* vrow = vsq_in + (int64_t)d * K;
 #pragma unroll
-        for (int i = 0; i < R; ++i) {
-            const bool on = i < K;
-            LAM(i) = on ? (double)lam_in[(int64_t)d * K + i] : CB_LAM_PAD;    // pads: exp(pad + ...) == 0 exactly, no i < K tests downstream
-            VSF(i) = on ? vsq_in[(int64_t)d * K + i] : 1.0f;
+            for (int i = 0; i < R; ++i) {
+                if (i < R - 7) { LAM(i) = (double)lrow[i]; VSF(i) = vrow[i]; }
+                else {
+                    const bool on = i < K;
+                    const int ic = min(i, K - 1);
+                    const float lv = lrow[ic], vv = vrow[ic];
+                    LAM(i) = on ? (double)lv : CB_LAM_PAD;
+                    VSF(i) = on ? vv : 1.0f;
+                }
+            }
         }
         lz = (double)CB_KARG(const float*, p.logzeta)[d];
     }
@@ -477,7 +490,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         if (active) {
             float* lam_old_out = CB_KARG(float*, p.lambda_old);
 #pragma unroll
-            for (int i = 0; i < R; ++i) if (i < K) lam_old_out[(int64_t)d * K + i] = (float)LAM(i);
+            for (int i = 0; i < R; ++i) if (i < R - 7 || i < K) lam_old_out[(int64_t)d * K + i] = (float)LAM(i);
         }
         // ---- update_phi!  src/CTM.jl:175-178 in linear space, (phi * counts)_i = e_i sum_n w_n beta[i, t_n]
         float phic[R];
@@ -702,7 +715,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 const cb_v4f sd4 = cb_sload4_sync<i0>(tb.sdiag);
                 double lm[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { vs[u] = VSQ(i0 + u); lm[u] = LAM(i0 + u); act[u] = active && (i0 + u < K); }
+                for (int u = 0; u < 4; ++u) { vs[u] = VSQ(i0 + u); lm[u] = LAM(i0 + u); act[u] = active && ((i0 + u < R - 7) || (i0 + u < K)); }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) isd[u] = (double)sd4[u];
                 // (round 4, measured and dropped: the iterations far from the exit threshold in fp32 -- __expf, v_rcp_f32, a lane leaving the fp32
@@ -826,7 +839,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             float dist2 = 0.0f;
 #pragma unroll
             for (int i = 0; i < R; ++i) {
-                if (i < K) { const float df = (float)(LAM(i) - (double)lam_old_in[(int64_t)d * K + i]); dist2 = fmaf(df, df, dist2); }
+                if (i < R - 7 || i < K) { const float df = (float)(LAM(i) - (double)lam_old_in[(int64_t)d * K + i]); dist2 = fmaf(df, df, dist2); }
             }
             if (sqrtf(dist2) < (float)p.vtol) active = false;                                   // :200
         }
