@@ -452,6 +452,13 @@ static inline int tmvb_colsum2(tmvb_ctx* ctx, int K, tmvb_colsum_job j0, tmvb_co
 // gather-side statistics pass over an inverted index (tmvb_termstats.h)
 // true when the statistics pass recomputes the per-token weights (no wtok stores needed in the document kernels)
 static inline bool tmvb_termstats_recomputes(int KP, bool e_padded) { return e_padded && KP / 4 <= 32; }
+// column chunks per lane of the PAD form of the recompute pass (tmvb_termstats.h): default 1 at KP = 52 (the round-4 form), 4 at KP = 100;
+// TMVB_TS_CPL = 1 | 2 | 4 overrides (A/B)
+static inline int tmvb_termstats_cpl(int lpr)
+{
+    static const int env = [] { const char* e = getenv("TMVB_TS_CPL"); const int c = e ? atoi(e) : 0; return (c == 1 || c == 2 || c == 4) ? c : 0; }();
+    return env ? env : (lpr == 25 ? 4 : 1);
+}
 
 // slice >= 0: only the ids of vocabulary slice `slice` of an index built with id cuts (tmvb_inv_index::slice_*)
 static inline int tmvb_launch_termstats(tmvb_ctx* ctx, int nslot, int KP, bool e_padded, const tmvb_inv_index& ix,
@@ -479,7 +486,12 @@ static inline int tmvb_launch_termstats(tmvb_ctx* ctx, int nslot, int KP, bool e
             const int lanes = lpr <= 16 ? 16 : 32;
             const bool pad = tp.estride >= 4 * lanes && ix.n_docs < (1 << 24) && (uint64_t)ix.n_docs * (uint64_t)tp.estride * 4u < (1ull << 32) &&
                              !(getenv("TMVB_STATS_PAD") && atoi(getenv("TMVB_STATS_PAD")) == 0);
-            if (lpr == 13 && pad) hipLaunchKernelGGL((termstats_recompute_kernel<13, 16, true>), grid, block, 0, st, tp, lpr);
+            const int cpl = tmvb_termstats_cpl(lpr);
+            if (lpr == 13 && pad && cpl == 2) hipLaunchKernelGGL((termstats_recompute_kernel<13, 8, true, 2>), grid, block, 0, st, tp, lpr);
+            else if (lpr == 13 && pad && cpl == 4) hipLaunchKernelGGL((termstats_recompute_kernel<13, 4, true, 4>), grid, block, 0, st, tp, lpr);
+            else if (lpr == 25 && pad && cpl == 2) hipLaunchKernelGGL((termstats_recompute_kernel<25, 16, true, 2>), grid, block, 0, st, tp, lpr);
+            else if (lpr == 25 && pad && cpl == 4) hipLaunchKernelGGL((termstats_recompute_kernel<25, 8, true, 4>), grid, block, 0, st, tp, lpr);
+            else if (lpr == 13 && pad) hipLaunchKernelGGL((termstats_recompute_kernel<13, 16, true>), grid, block, 0, st, tp, lpr);
             else if (lpr == 25 && pad) hipLaunchKernelGGL((termstats_recompute_kernel<25, 32, true>), grid, block, 0, st, tp, lpr);
             else if (lpr == 13) hipLaunchKernelGGL((termstats_recompute_kernel<13, 16>), grid, block, 0, st, tp, lpr);
             else if (lpr == 25) hipLaunchKernelGGL((termstats_recompute_kernel<25, 32>), grid, block, 0, st, tp, lpr);
@@ -520,7 +532,10 @@ static inline int tmvb_launch_termstats2(tmvb_ctx* ctx, int nslot, int KP, const
     const int64_t nd = std::max(ix0.n_docs, ix1.n_docs);
     const bool pad = tp0.estride >= 4 * lanes && tp1.estride == tp0.estride && nd < (1 << 24) && (uint64_t)nd * (uint64_t)tp0.estride * 4u < (1ull << 32) &&
                      !(getenv("TMVB_STATS_PAD") && atoi(getenv("TMVB_STATS_PAD")) == 0);
-    if (lpr == 13 && pad) hipLaunchKernelGGL((termstats_recompute2_kernel<13, 16, true>), grid, block, 0, st, tp0, tp1, lpr);
+    const int cpl = tmvb_termstats_cpl(lpr);
+    if (lpr == 13 && pad && cpl == 2) hipLaunchKernelGGL((termstats_recompute2_kernel<13, 8, true, 2>), grid, block, 0, st, tp0, tp1, lpr);
+    else if (lpr == 13 && pad && cpl == 4) hipLaunchKernelGGL((termstats_recompute2_kernel<13, 4, true, 4>), grid, block, 0, st, tp0, tp1, lpr);
+    else if (lpr == 13 && pad) hipLaunchKernelGGL((termstats_recompute2_kernel<13, 16, true>), grid, block, 0, st, tp0, tp1, lpr);
     else if (lpr == 13) hipLaunchKernelGGL((termstats_recompute2_kernel<13, 16>), grid, block, 0, st, tp0, tp1, lpr);
     else if (lpr == 25) hipLaunchKernelGGL((termstats_recompute2_kernel<25, 32>), grid, block, 0, st, tp0, tp1, lpr);
     else if (lpr <= 16) hipLaunchKernelGGL((termstats_recompute2_kernel<0, 16>), grid, block, 0, st, tp0, tp1, lpr);

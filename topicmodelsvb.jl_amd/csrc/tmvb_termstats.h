@@ -166,6 +166,135 @@ __global__ __launch_bounds__(256) void termstats_chunk4_kernel(TermStatsParams p
     }
 }
 
+// PAD form of the recompute pass with CPL column chunks per lane (see termstats_recompute_body below for the algorithm and the PAD contract:
+// rows of E zero-padded to 4 * LANES * CPL floats, 32-bit byte offsets, keps > 0 or the select on the row).
+template <int LPR, int LANES, int CPL>
+__device__ __forceinline__ void termstats_recompute_cpl_body(const TermStatsParams& p)
+{
+    constexpr int SLOTS = 64 / LANES;
+#ifndef TMVB_TS_CPL_U
+#define TMVB_TS_CPL_U ((32 / SLOTS) < 2 ? 2 : ((32 / SLOTS) > 4 ? 4 : (32 / SLOTS)))
+#endif
+    constexpr int U = TMVB_TS_CPL_U;                     // row-slot groups in flight per wave: U * SLOTS rows, U * CPL loads per lane
+    static_assert(64 % (U * SLOTS) == 0, "the 64 staged tokens are whole groups");
+    __shared__ int2 dw_l[4][64];
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int c = blockIdx.x * 4 + wv;
+    const int rs = lane / LANES, cc = lane % LANES;
+    const bool active = c < p.n_chunks;
+    const int j = active ? p.chunk_id[c] : 0;
+    const int b = active ? p.chunk_begin[c] : 0, e = active ? p.chunk_end[c] : 0;
+    v2f tlo[CPL], thi[CPL], alo[CPL], ahi[CPL];
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+        float4 tj = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (active && cc + LANES * q < LPR) tj = *(const float4*)(p.T + (int64_t)j * p.tstride + 4 * (cc + LANES * q));
+        tlo[q] = v2f{tj.x, tj.y}; thi[q] = v2f{tj.z, tj.w};
+        alo[q] = v2f{0.f, 0.f}; ahi[q] = v2f{0.f, 0.f};
+    }
+    const char* __restrict__ Eb = (const char*)p.E;
+    const uint32_t esb = (uint32_t)p.estride * 4u, lane_off = 16u * (uint32_t)cc;
+    float wl = 0.0f;
+    for (int t0 = b; t0 < e; t0 += 64) {
+        const int tok = t0 + lane;
+        const bool valid = tok < e;
+        dw_l[wv][lane] = make_int2(valid ? p.tok_doc[tok] : 0, __builtin_bit_cast(int, valid ? p.tok_val[tok] : 0.0f));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int cnt = min(64, e - t0);
+        for (int k0 = 0; k0 < cnt; k0 += U * SLOTS) {
+            int2 dw[U];
+            float4 ev[U][CPL];
+#pragma unroll
+            for (int u = 0; u < U; ++u) dw[u] = dw_l[wv][k0 + u * SLOTS + rs];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t ro = __umul24((uint32_t)dw[u].x, esb) + lane_off;
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) ev[u][q] = *(const float4*)(Eb + (ro + 16u * (uint32_t)(LANES * q)));
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                v2f d2 = tlo[0] * v2f{ev[u][0].x, ev[u][0].y};
+                d2 = __builtin_elementwise_fma(thi[0], v2f{ev[u][0].z, ev[u][0].w}, d2);
+#pragma unroll
+                for (int q = 1; q < CPL; ++q) {
+                    d2 = __builtin_elementwise_fma(tlo[q], v2f{ev[u][q].x, ev[u][q].y}, d2);
+                    d2 = __builtin_elementwise_fma(thi[q], v2f{ev[u][q].z, ev[u][q].w}, d2);
+                }
+                float part = d2.x + d2.y;
+                part += dpp_f<0xB1>(part);
+                part += dpp_f<0x4E>(part);
+                if (LANES >= 8) part += dpp_f<0x141>(part);
+                if (LANES >= 16) part += dpp_f<0x140>(part);          // every lane of the slot holds s_n - keps
+                float wz = __builtin_bit_cast(float, dw[u].y) * __builtin_amdgcn_rcpf(part + p.keps);
+                wz = (k0 + u * SLOTS + rs < cnt) ? wz : 0.0f;
+                const v2f w2 = v2f{wz, wz};
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) {
+                    alo[q] = __builtin_elementwise_fma(w2, v2f{ev[u][q].x, ev[u][q].y}, alo[q]);
+                    ahi[q] = __builtin_elementwise_fma(w2, v2f{ev[u][q].z, ev[u][q].w}, ahi[q]);
+                }
+                wl += wz;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // combine the row slots (lanes cc, cc + LANES, ...) in a fixed order: within a 16-lane row by DPP rotations, across rows by lane exchange
+    float tot[CPL][4];
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) { tot[q][0] = alo[q].x; tot[q][1] = alo[q].y; tot[q][2] = ahi[q].x; tot[q][3] = ahi[q].y; }
+    float wsum = wl;
+    if (LANES <= 4) {
+#pragma unroll
+        for (int q = 0; q < CPL; ++q)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) tot[q][v] += dpp_f<0x124>(tot[q][v]);     // row_ror:4
+        wsum += dpp_f<0x124>(wsum);
+    }
+    if (LANES <= 8) {
+#pragma unroll
+        for (int q = 0; q < CPL; ++q)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) tot[q][v] += dpp_f<0x128>(tot[q][v]);     // row_ror:8
+        wsum += dpp_f<0x128>(wsum);
+    }
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {
+#pragma unroll
+        for (int q = 0; q < CPL; ++q)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) tot[q][v] += __shfl_xor(tot[q][v], o, 64);
+        wsum += __shfl_xor(wsum, o, 64);
+    }
+    if (!active || lane >= LANES) return;
+    const int slot = p.chunk_out[c];
+    const int K = p.K;
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+        const int ch = lane + LANES * q;
+        if (ch >= LPR) continue;
+        const float tjv[4] = {tlo[q].x, tlo[q].y, thi[q].x, thi[q].y};
+        if (slot < 0) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int i = 4 * ch + v;
+                if (i < K) p.out[(int64_t)j * p.ostride + i] += p.base + fmaf(tjv[v], tot[q][v], p.eps * wsum);
+            }
+        } else {
+            float* pr = p.partial + (int64_t)slot * (K + 1);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int i = 4 * ch + v;
+                if (i < K) pr[i] = tot[q][v];
+            }
+            if (ch == 0) pr[K] = wsum;
+        }
+    }
+}
+
 // Recompute variant for K <= 128 (LPR <= 32): the per-token weight w_n = val_n / s_n is NOT read from
 // memory -- a per-token value written in document order and read in id order has one scattered side,
 // and the scattered 4-byte stores cost 0.24 ms of the 0.9 ms document pass at NSF scale -- but
@@ -173,10 +302,19 @@ __global__ __launch_bounds__(256) void termstats_chunk4_kernel(TermStatsParams p
 // registers) and the document's E row, which this kernel fetches anyway.  LANES = 16 or 32 lanes per row
 // slot (LPR active), 64 / LANES row slots per wave instruction; the dot product is a 4-step DPP row reduction
 // (+ one v_permlane16_swap step joining the two 16-lane rows of a 32-lane slot).
-template <int LPR_T, int LANES, bool PAD = false>
+// Round 5 (CPL > 1, PAD form only): a lane owns CPL column chunks of its row slot (chunks cc, cc + LANES, ...), so a row slot needs only
+// LANES = ceil(LPR / CPL) rounded to 4 / 8 / 16 lanes and one wave instruction covers 64 / LANES rows; the per-row VALU work (reduction steps,
+// reciprocal, weight, bookkeeping) is shared by more rows with fewer DPP steps (K = 100, 8 lanes x 4 chunks: 8 rows per instruction instead of 2,
+// no v_permlane16_swap; 3.1 instead of ~15 VALU instructions per row).  Measured (profiles/r5_lda_experiments.txt (7)): K = 100 +1.6 % (860.0 /
+// 862.9 -> 875.2 / 875.3 VB it/s with CPL = 4, 870.7 / 874.7 with 2); K = 50 -1 % (CPL = 2) and -7 % (CPL = 4: twice the 128-byte lines per row and
+// instruction) -- the pass is bound by what the L2 delivers to the vector L1s (12 - 15 TB/s of gathered rows), not by its instructions, so the
+// default is CPL = 4 at KP = 100 and the round-4 form (CPL = 1) at KP = 52; TMVB_TS_CPL overrides.
+template <int LPR_T, int LANES, bool PAD = false, int CPL = 1>
 __device__ __forceinline__ void termstats_recompute_body(const TermStatsParams& p, int LPR_rt)
 {
-    static_assert(LANES == 16 || LANES == 32, "termstats_recompute_kernel: 16 or 32 lanes per row slot");
+    static_assert(LANES == 4 || LANES == 8 || LANES == 16 || LANES == 32, "termstats_recompute_kernel: 4, 8, 16 or 32 lanes per row slot");
+    static_assert(CPL == 1 || (PAD && LPR_T > 0 && LANES <= 16), "several chunks per lane: PAD form with a compile-time row length only");
+    if constexpr (CPL > 1) { termstats_recompute_cpl_body<LPR_T, LANES, CPL>(p); return; }
     constexpr int SLOTS = 64 / LANES;
     __shared__ int2 dw_l[4][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -325,18 +463,18 @@ __device__ __forceinline__ void termstats_recompute_body(const TermStatsParams& 
     }
 }
 
-template <int LPR_T, int LANES, bool PAD = false>
+template <int LPR_T, int LANES, bool PAD = false, int CPL = 1>
 __global__ __launch_bounds__(256) void termstats_recompute_kernel(TermStatsParams p, int LPR_rt)
 {
-    termstats_recompute_body<LPR_T, LANES, PAD>(p, LPR_rt);
+    termstats_recompute_body<LPR_T, LANES, PAD, CPL>(p, LPR_rt);
 }
 // Two independent passes (CTPF: the term index and the reader index) in ONE launch, blockIdx.y selects the pass: run on two streams
 // they cost a ~19 us cross-stream join in a 0.3 ms iteration.
-template <int LPR_T, int LANES, bool PAD = false>
+template <int LPR_T, int LANES, bool PAD = false, int CPL = 1>
 __global__ __launch_bounds__(256) void termstats_recompute2_kernel(TermStatsParams p0, TermStatsParams p1, int LPR_rt)
 {
-    if (blockIdx.y == 0) termstats_recompute_body<LPR_T, LANES, PAD>(p0, LPR_rt);
-    else termstats_recompute_body<LPR_T, LANES, PAD>(p1, LPR_rt);
+    if (blockIdx.y == 0) termstats_recompute_body<LPR_T, LANES, PAD, CPL>(p0, LPR_rt);
+    else termstats_recompute_body<LPR_T, LANES, PAD, CPL>(p1, LPR_rt);
 }
 
 // ids whose tokens span several chunks: one workgroup per id, its 4 waves sum interleaved partial
