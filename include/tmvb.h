@@ -252,6 +252,13 @@ int tmvb_lda_train_group(tmvb_lda* const* hs, int32_t n, int32_t iter, double to
  * themselves (out[M], corpus document order, saturating at 255). */
 int tmvb_lda_sweep_hist(tmvb_lda* h, int64_t* hist, int32_t nbins);
 int tmvb_lda_doc_sweeps(tmvb_lda* h, uint8_t* out);
+/* Which form the last tmvb_lda_update_elbo / check of tmvb_lda_train took (update_elbo!, src/LDA.jl:83-93): *form = 1 the decomposed form -- the
+ * iteration's own statistics passes left sum_n c_n log s_n per postings chunk, update_beta! left sum S (log beta_new - log beta_old), and one
+ * per-document kernel adds Elogptheta, sum_k (gamma_k - alpha_k)(Elogtheta_k - Elogtheta_old_k) and the Dirichlet entropy: no second walk over the
+ * corpus; taken by every iteration tmvb_lda_train checks (K <= 128) and, with TMVB_LDA_ELBO_PARTS=2 at tmvb_lda_create, by the stepwise operators too;
+ * *form = 0 the token walk (phi rebuilt from beta_old / Elogtheta_old per token: any state, e.g. right after tmvb_lda_set_state);
+ * TMVB_LDA_ELBO_PARTS=0 forces it.  Both evaluate the same sum; they differ by fp32 rounding only (tests/test_lda_elbo_parts_gpu.py). */
+int tmvb_lda_elbo_form(tmvb_lda* h, int32_t* form);
 /* Number of kernel launches one tmvb_lda_estep issues (one per document-length bucket). */
 int tmvb_lda_estep_launches(tmvb_lda* h, int32_t* n);
 /* Timing of the last tmvb_lda_estep on the context's stream, from HIP events (ms). */

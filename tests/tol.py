@@ -30,6 +30,7 @@ _T = {
     "lda.alpha_rel":            (2e-05, 2.65e-06),
     "lda.elbo_rel_step":        (1e-06, 2.4e-07),
     "lda.elbo_rel_free":        (2e-06, 2.39e-07),
+    "lda.elbo_forms_rel":       (5e-07, 5.15e-08),     # decomposed update_elbo! against the token walk on the same device state (tests/test_lda_elbo_parts_gpu.py)
     "lda.alpha_rel_free":       (5e-05, 5.65e-06),
     "lda.beta_abs_free":        (2e-05, 2.25e-06),
     # 10 free-running iterations of the FULL SYN-NSF corpus, K = 50

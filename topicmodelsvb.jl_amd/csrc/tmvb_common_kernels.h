@@ -284,9 +284,11 @@ static __global__ __launch_bounds__(256) void colsum_final_kernel(const double* 
 // S is dense [V][K]; beta_new is the padded gather layout [V][KP] (pad columns zero).
 // pw_partial (or NULL): per-block fp64 partial of sum_{i,j} S[j][i] * log(beta_new[j][i] + eps) = E_q[log p(w)] of the
 // ELBO (src/LDA.jl:65 summed over the corpus: sum_n c_n phi_in = S), fixed summation order per block.
+// beta_old (or NULL; the padded layout of the beta the E-step read): the partial becomes sum S * (log(beta_new + eps) - log(beta_old + eps)) -- the
+// statistics' share of E_q[log p(w)] - E_q[log q(z)] in the decomposed update_elbo! (lda_elbo_doc_kernel, tmvb_lda.hip).
 static __global__ __launch_bounds__(256) void beta_norm_kernel(float* __restrict__ S, const double* __restrict__ rowsum,
                                                             float* __restrict__ beta_new, int K, int KP, int64_t V,
-                                                            double* __restrict__ pw_partial, float eps)
+                                                            double* __restrict__ pw_partial, float eps, const float* __restrict__ beta_old = nullptr)
 {
     extern __shared__ double rinv[];
     __shared__ double red[4];
@@ -302,7 +304,7 @@ static __global__ __launch_bounds__(256) void beta_norm_kernel(float* __restrict
         if (i < K) {
             const float sv = S[j * K + i];
             o = (float)((double)sv * rinv[i]);
-            if (pw_partial) pw += (double)sv * (double)logf(o + eps);
+            if (pw_partial) pw += (double)sv * (beta_old ? (double)logf(o + eps) - (double)logf(beta_old[q] + eps) : (double)logf(o + eps));
             S[j * K + i] = 0.0f;
         }
         beta_new[q] = o;
@@ -477,6 +479,7 @@ static inline int tmvb_launch_termstats(tmvb_ctx* ctx, int nslot, int KP, bool e
     tp.tok_doc = ix.d_doc; tp.tok_pos = ix.d_pos; tp.chunk_id = ix.d_chunk_id + c0; tp.chunk_begin = ix.d_chunk_begin + c0;
     tp.chunk_end = ix.d_chunk_end + c0; tp.chunk_out = ix.d_chunk_out + c0; tp.n_chunks = (int)n_chunks;
     tp.tok_val = ix.d_val;
+    if (tp.logz) tp.logz += c0;                 // per chunk of the index
     int rc = dispatch_nslot(nslot, [&](auto ns) -> int {
         constexpr int NS = decltype(ns)::value;
         const dim3 grid((unsigned)((n_chunks + 3) / 4)), block(256);
@@ -487,16 +490,26 @@ static inline int tmvb_launch_termstats(tmvb_ctx* ctx, int nslot, int KP, bool e
             const bool pad = tp.estride >= 4 * lanes && ix.n_docs < (1 << 24) && (uint64_t)ix.n_docs * (uint64_t)tp.estride * 4u < (1ull << 32) &&
                              !(getenv("TMVB_STATS_PAD") && atoi(getenv("TMVB_STATS_PAD")) == 0);
             const int cpl = tmvb_termstats_cpl(lpr);
-            if (lpr == 13 && pad && cpl == 2) hipLaunchKernelGGL((termstats_recompute_kernel<13, 8, true, 2>), grid, block, 0, st, tp, lpr);
-            else if (lpr == 13 && pad && cpl == 4) hipLaunchKernelGGL((termstats_recompute_kernel<13, 4, true, 4>), grid, block, 0, st, tp, lpr);
-            else if (lpr == 25 && pad && cpl == 2) hipLaunchKernelGGL((termstats_recompute_kernel<25, 16, true, 2>), grid, block, 0, st, tp, lpr);
-            else if (lpr == 25 && pad && cpl == 4) hipLaunchKernelGGL((termstats_recompute_kernel<25, 8, true, 4>), grid, block, 0, st, tp, lpr);
-            else if (lpr == 13 && pad) hipLaunchKernelGGL((termstats_recompute_kernel<13, 16, true>), grid, block, 0, st, tp, lpr);
-            else if (lpr == 25 && pad) hipLaunchKernelGGL((termstats_recompute_kernel<25, 32, true>), grid, block, 0, st, tp, lpr);
-            else if (lpr == 13) hipLaunchKernelGGL((termstats_recompute_kernel<13, 16>), grid, block, 0, st, tp, lpr);
-            else if (lpr == 25) hipLaunchKernelGGL((termstats_recompute_kernel<25, 32>), grid, block, 0, st, tp, lpr);
-            else if (lpr <= 16) hipLaunchKernelGGL((termstats_recompute_kernel<0, 16>), grid, block, 0, st, tp, lpr);
-            else hipLaunchKernelGGL((termstats_recompute_kernel<0, 32>), grid, block, 0, st, tp, lpr);
+            // TS(...): the instantiation, or -- tp.logz set, translation units that define TMVB_TS_LOGZ (LDA) -- its LOGZ form, which also leaves the
+            // chunk's sum of val * log2(normaliser) for update_elbo!
+#ifdef TMVB_TS_LOGZ
+#define TS(LPRV, LANESV, PADV, CPLV) do { if (tp.logz) hipLaunchKernelGGL((termstats_recompute_kernel<LPRV, LANESV, PADV, CPLV, true>), grid, block, 0, st, tp, lpr); \
+                                          else hipLaunchKernelGGL((termstats_recompute_kernel<LPRV, LANESV, PADV, CPLV, false>), grid, block, 0, st, tp, lpr); } while (0)
+#else
+#define TS(LPRV, LANESV, PADV, CPLV) do { TMVB_REQUIRE(tp.logz == nullptr, TMVB_EINVAL, "statistics pass: no log-normaliser form in this translation unit"); \
+                                          hipLaunchKernelGGL((termstats_recompute_kernel<LPRV, LANESV, PADV, CPLV, false>), grid, block, 0, st, tp, lpr); } while (0)
+#endif
+            if (lpr == 13 && pad && cpl == 2) TS(13, 8, true, 2);
+            else if (lpr == 13 && pad && cpl == 4) TS(13, 4, true, 4);
+            else if (lpr == 25 && pad && cpl == 2) TS(25, 16, true, 2);
+            else if (lpr == 25 && pad && cpl == 4) TS(25, 8, true, 4);
+            else if (lpr == 13 && pad) TS(13, 16, true, 1);
+            else if (lpr == 25 && pad) TS(25, 32, true, 1);
+            else if (lpr == 13) TS(13, 16, false, 1);
+            else if (lpr == 25) TS(25, 32, false, 1);
+            else if (lpr <= 16) TS(0, 16, false, 1);
+            else TS(0, 32, false, 1);
+#undef TS
         } else if (e_padded) {
             if (lpr == 13) hipLaunchKernelGGL((termstats_chunk4_kernel<13>), grid, block, 0, st, tp, lpr);
             else if (lpr == 25) hipLaunchKernelGGL((termstats_chunk4_kernel<25>), grid, block, 0, st, tp, lpr);

@@ -77,20 +77,23 @@ static __global__ __launch_bounds__(64) void lda_alpha_kernel(int K, double Md, 
 }
 
 // elbo = sum_d doc_val[d] + M * (lgamma(sum alpha) - sum lgamma(alpha))   (src/LDA.jl:51, finite())
+// n_vals > 0: doc_val holds n_vals partial sums (lda_elbo_doc_kernel: one per block of documents) instead of one value per document
 static __global__ __launch_bounds__(1024) void lda_elbo_final_kernel(const double* __restrict__ doc_val, int64_t M, int K,
                                                               const double* __restrict__ alpha_d, double* __restrict__ out,
-                                                              const double* __restrict__ pw_partial, int pw_blocks, double pw_share)
+                                                              const double* __restrict__ pw_partial, int pw_blocks, double pw_share,
+                                                              int64_t n_vals = 0)
 {
+    const int64_t NV = n_vals > 0 ? n_vals : M;
     __shared__ double red[1024];
     // 16 loads in flight per thread, unconditional (a slot past the end reads element 0 and adds 0): the one block's 126 dependent
     // trips of one load each were most of this kernel's 40 us at M = 128 804 (round 4; fixed order: run-to-run bitwise)
     double s8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    for (int64_t d0 = threadIdx.x; d0 < M; d0 += 16 * 1024) {
+    for (int64_t d0 = threadIdx.x; d0 < NV; d0 += 16 * 1024) {
         double v[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) { const int64_t d = d0 + (int64_t)u * 1024; v[u] = doc_val[d < M ? d : 0]; }
+        for (int u = 0; u < 16; ++u) { const int64_t d = d0 + (int64_t)u * 1024; v[u] = doc_val[d < NV ? d : 0]; }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) { const int64_t d = d0 + (int64_t)u * 1024; s8[u & 7] += (d < M) ? v[u] : 0.0; }
+        for (int u = 0; u < 16; ++u) { const int64_t d = d0 + (int64_t)u * 1024; s8[u & 7] += (d < NV) ? v[u] : 0.0; }
     }
     double pwl = 0.0;                                             // E_q[log p(w)] partials of update_beta!, if in use
     if (pw_partial) for (int b = threadIdx.x; b < pw_blocks; b += 1024) pwl += pw_share * pw_partial[b];

@@ -27,6 +27,7 @@
 //
 // Roofline: HBM/gather-bound by byte count, VALU-issue bound in practice.  Algorithmic
 // bytes per outer iteration: nnz*(8 + 4K + 4K) + 12*M*K + 12*K*V + 4*(M+1).
+#define TMVB_TS_LOGZ 1            // this translation unit instantiates the log-normaliser forms of the statistics pass (update_elbo!)
 #include "tmvb_common_kernels.h"
 #include "tmvb_train.h"
 #include "tmvb_dirichlet.h"
@@ -954,6 +955,64 @@ __global__ __launch_bounds__(64) void lda_elbo_reg_kernel(int K, const int32_t* 
 // broadcast rows instead of 104 v_readlane per tile, packed arithmetic): 1.051 against 1.060 ms, i.e. nothing.  Neither the logarithms nor the
 // gather's shape bound it; one wave per document with two dependent global loads in front of the rows and an fp64 tail behind them does.)
 
+
+// Decomposed update_elbo! (round 5) -- the per-document half.  With x_nk = beta_old[k, v_n] e_old_k + eps, s_n = sum_k x_nk, phi_nk = x_nk / s_n
+// (src/LDA.jl:87-88) and pc_k = sum_n c_n phi_nk = gamma_k - alpha_k (update_gamma!, :145, with the alpha the E-step read), the token terms of a document
+//     sum_n c_n sum_k phi_nk (Elogtheta_k + log(beta_kv + eps) - log phi_nk)                                                       (:58, :65, :78)
+// separate, up to eps inside log x_nk (phi_nk log(1 + eps / (beta_old e_old)) <= eps / s_n ~ 1e-25 per term), into
+//     sum_k pc_k (Elogtheta_k - Elogtheta_old_k)                         this kernel, from the state the E-step left
+//   + sum_n c_n log s_n                                                  the statistics pass has s_n in a register: one v_log_f32 + FMA per posting,
+//                                                                        one partial per chunk (TermStatsParams::logz, log2 units)
+//   + sum_{v,k} S_vk (log(beta_new + eps) - log(beta_old + eps))         update_beta! reads S and writes beta_new: beta_norm_kernel's partial
+// so a checked iteration needs no second walk over the corpus (lda_elbo_reg_kernel: one gathered row and 2 K logarithms per token, 366 us on SYN-NSF
+// K = 50 against a 758 us iteration).  What is left per document is Elogptheta's dot product (:51), the sum above and the Dirichlet entropy (:72), one
+// psi / lgamma evaluation per (document, topic) in fp64 -- done here with ONE LANE PER DOCUMENT: the 64 documents' rows of gamma / Elogtheta /
+// Elogtheta_old are contiguous (64 K floats each), staged through LDS with coalesced loads, and a wave evaluates 64 (K + 1) special functions with
+// no cross-lane traffic and no redundant lane (lda_elbo_reg_kernel's lane = topic tail: 2 evaluations per document-wave with 50 of 64 lanes in
+// use).  A block also sums its slice of the statistics passes' log-normaliser partials.  One fp64 value per block, fixed order.
+__global__ __launch_bounds__(64) void lda_elbo_doc_kernel(int K, int64_t M, const double* __restrict__ alpha_new, const double* __restrict__ alpha_prev,
+                                                          const float* __restrict__ gamma, const float* __restrict__ elog,
+                                                          const float* __restrict__ elog_old, const float* __restrict__ logz, int64_t n_logz,
+                                                          double* __restrict__ block_val)
+{
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // [3][64 K]
+    const int lane = threadIdx.x;
+    const int64_t d0 = (int64_t)blockIdx.x * 64;
+    const int nd = (int)min((int64_t)64, M - d0);
+    const int n = nd * K, n4 = n >> 2;
+    float* sg = sm; float* se = sm + 64 * K; float* so = sm + 128 * K;
+    {
+        const float4* g4 = (const float4*)(gamma + d0 * K);       // 64 K floats per block: 16-byte aligned
+        const float4* e4 = (const float4*)(elog + d0 * K);
+        const float4* o4 = (const float4*)(elog_old + d0 * K);
+        for (int i = lane; i < n4; i += 64) { ((float4*)sg)[i] = g4[i]; ((float4*)se)[i] = e4[i]; ((float4*)so)[i] = o4[i]; }
+        for (int i = 4 * n4 + lane; i < n; i += 64) { sg[i] = gamma[d0 * K + i]; se[i] = elog[d0 * K + i]; so[i] = elog_old[d0 * K + i]; }
+    }
+    __syncthreads();
+    double acc = 0.0;
+    if (lane < nd) {
+        const float* rg = sg + lane * K; const float* re = se + lane * K; const float* ro = so + lane * K;
+        double g0 = 0.0;
+        for (int k = 0; k < K; ++k) {
+            const double g = (double)rg[k], el = (double)re[k];
+            acc = fma(alpha_new[k] - 1.0, el, acc);                                   // Elogptheta :51 (dot part)
+            acc = fma(g - alpha_prev[k], el - (double)ro[k], acc);                     // Elogpz - Elogqz: the per-document part (see above)
+            if (K > 1) { double ps, lg; digamma_lgamma_d(g, ps, lg); acc += lg - (g - 1.0) * ps; }   // -Elogqtheta :72 (utils.jl:172-176)
+            g0 += g;
+        }
+        if (K > 1) { double ps0, lg0; digamma_lgamma_d(g0, ps0, lg0); acc += -lg0 + (g0 - (double)K) * ps0; }
+    }
+    if (logz) {                                                  // this block's slice of the chunks' sum c log2 s
+        const int64_t per = (n_logz + gridDim.x - 1) / gridDim.x;
+        const int64_t b = (int64_t)blockIdx.x * per, e = min(n_logz, b + per);
+        double lz = 0.0;
+        for (int64_t i = b + lane; i < e; i += 64) lz += (double)logz[i];
+        acc = fma(lz, 0.6931471805599453, acc);
+    }
+    acc = wave_sum_d(acc);
+    if (lane == 0) block_val[blockIdx.x] = acc;
+}
+
 #define TMVB_REG_ANY_TILES 99   // bucket of register-tile documents with mixed tile counts (lda_estep_reg_any_kernel)
 #define TMVB_GRID_ANY_NP 99     // bucket of grid-tile documents with mixed lengths (lda_estep_grid_any_kernel)
 #define TMVB_GRID_TT_NP 1       // bucket of documents of <= 64 unique terms on the two-copy kernel (lda_estep_tt_kernel; KP <= 60)
@@ -1100,6 +1159,17 @@ struct tmvb_lda {
     int pw_blocks = 0;
     bool stats_fresh = false;          // S holds the statistics of an E-step that update_beta! has not consumed yet
     bool pw_valid = false;             // d_pw_partial belongs to the current (beta, beta_old, Elogtheta_old) state
+    // decomposed update_elbo! (lda_elbo_doc_kernel): an iteration that WILL be checked (train!: known before its E-step; TMVB_LDA_ELBO_PARTS=2: every
+    // iteration, =0: never) collects the chunks' log-normaliser sums in its statistics passes, keeps the alpha its E-step read, and has update_beta!
+    // leave sum S (log beta_new - log beta_old); update_elbo! then needs one per-document kernel instead of a second walk over the corpus.
+    bool want_parts = false;           // set for the coming iteration
+    int parts_env = 1;                 // TMVB_LDA_ELBO_PARTS at tmvb_lda_create: 0 never, 1 the iterations train! will check, 2 every E-step
+    float* d_logz = nullptr; size_t logz_cap = 0; int64_t n_logz = 0;
+    double* d_alpha_prev = nullptr;    // [K] alpha as the last E-step read it
+    bool logz_valid = false;           // d_logz[0, n_logz) belongs to the last E-step (every statistics pass of it)
+    bool alpha_prev_valid = false;     // d_alpha_prev was saved by the update_alpha! behind that E-step
+    bool pw_diff = false;              // d_pw_partial holds the (log beta_new - log beta_old) form
+    int elbo_form = 0;                 // the last update_elbo!: 1 decomposed, 0 token walk (tmvb_lda_elbo_form)
     bool side_pending = false;         // ev_side marks side-stream work the context's stream has not waited for yet
     // tmvb_lda_estep_allreduce (document-sharded run): the LAST statistics pass is issued in vocabulary slices, and the slab of S
     // a slice completes is all-reduced on aux[AR] while the next slice's pass runs on the context's stream.  Cuts and order are
@@ -1303,7 +1373,7 @@ extern "C" int tmvb_lda_destroy(tmvb_lda* h)
     if (h->ev_side) (void)hipEventDestroy(h->ev_side);
     if (h->ev_chain) (void)hipEventDestroy(h->ev_chain);
     if (h->ev_mark) (void)hipEventDestroy(h->ev_mark);
-    (void)hipFree(h->d_partial_side); (void)hipFree(h->d_pw_partial);
+    (void)hipFree(h->d_partial_side); (void)hipFree(h->d_pw_partial); (void)hipFree(h->d_logz); (void)hipFree(h->d_alpha_prev);
     for (tmvb_inv_index& ix : h->pieces) tmvb_free_inv_index(&ix);
     if (h->ar_index.built) tmvb_free_inv_index(&h->ar_index);
     for (hipEvent_t e : h->ev_slice) if (e) (void)hipEventDestroy(e);
@@ -1433,7 +1503,8 @@ extern "C" int tmvb_lda_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
     TMVB_HIP(hipEventCreateWithFlags(&h->ev_side, tmvb_event_flags()));
     TMVB_HIP(hipEventCreateWithFlags(&h->ev_chain, tmvb_event_flags()));
     TMVB_HIP(hipEventCreateWithFlags(&h->ev_mark, hipEventDisableTiming /* may sit behind a collective: keeps the system-scope fence */));
-    if ((rc = dmalloc(&h->d_partial_side, (size_t)TMVB_REDUCE_BLOCKS * K)) || (rc = dmalloc(&h->d_pw_partial, 2048))) return rc;
+    { const char* e = getenv("TMVB_LDA_ELBO_PARTS"); h->parts_env = e ? atoi(e) : 1; }
+    if ((rc = dmalloc(&h->d_partial_side, (size_t)TMVB_REDUCE_BLOCKS * K)) || (rc = dmalloc(&h->d_pw_partial, 2048)) || (rc = dmalloc(&h->d_alpha_prev, (size_t)K))) return rc;
     for (int a = 0; a < tmvb_lda::NAUX; ++a) {
         h->aux[a] = tmvb_pool_stream(ctx->device, 1 + a);
         TMVB_REQUIRE(h->aux[a] != nullptr, TMVB_EHIP, "hipStreamCreate failed");
@@ -1459,7 +1530,7 @@ extern "C" int tmvb_lda_set_state(tmvb_lda* h, const double* alpha, const double
                                   const double* elbo)
 {
     TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_lda_set_state: handle is NULL");
-    h->mark_valid = false; h->esum_fresh = false; h->esum_side = false; h->pw_valid = false; h->stats_fresh = false;
+    h->mark_valid = false; h->esum_fresh = false; h->esum_side = false; h->pw_valid = false; h->stats_fresh = false; h->logz_valid = false; h->alpha_prev_valid = false;
     tmvb_ctx* ctx = h->ctx;
     TMVB_HIP(hipSetDevice(ctx->device));
     { int jrc = lda_join_side(h); if (jrc) return jrc; }
@@ -1532,7 +1603,7 @@ extern "C" int tmvb_lda_estep(tmvb_lda* h, int32_t viter, double vtol)
         for (int a = 0; a < tmvb_lda::NAUX; ++a) if (h->aux[a]) (void)hipStreamSynchronize(h->aux[a]);
         (void)hipStreamSynchronize(h->ctx->stream);
         (void)hipGetLastError();
-        h->side_pending = false; h->esum_fresh = false; h->esum_side = false; h->stats_fresh = false; h->pw_valid = false; h->mark_valid = false;
+        h->side_pending = false; h->esum_fresh = false; h->esum_side = false; h->stats_fresh = false; h->pw_valid = false; h->mark_valid = false; h->logz_valid = false; h->alpha_prev_valid = false;
         tmvb_set_error("%s", msg.c_str());
     }
     return rc;
@@ -1593,6 +1664,25 @@ static int lda_estep_impl(tmvb_lda* h, int32_t viter, double vtol)
         if ((p.debug & 1) || ix.n_chunks <= 0) return TMVB_OK;
         return tmvb_launch_termstats(ctx, h->nslot, h->KP, h->e_padded, ix, tpp, on);
     };
+    // Decomposed update_elbo! (lda_elbo_doc_kernel): an iteration that will be checked has its statistics passes leave sum c log2 s per chunk
+    const int parts_env = h->parts_env;                          // TMVB_LDA_ELBO_PARTS, read per model
+    const bool collect = (parts_env == 2 || (parts_env != 0 && h->want_parts)) && tmvb_termstats_recomputes(h->KP, h->e_padded) && !(p.debug & 1);
+    std::vector<int64_t> logz_off((size_t)P + 1, 0);
+    auto stats_index = [&](int q) -> const tmvb_inv_index& {      // the index piece q's pass walks (tmvb_lda_estep_allreduce: its slice-major rebuild)
+        return (h->ar_live && q == P - 1 && h->pieces.empty()) ? h->ar_index : piece_index(q);
+    };
+    if (collect) {
+        for (int q = 0; q < P; ++q) logz_off[(size_t)q + 1] = logz_off[(size_t)q] + stats_index(q).n_chunks;
+        const size_t need = (size_t)std::max<int64_t>(logz_off[(size_t)P], 1);
+        if (need > h->logz_cap) {                                 // (first checked iteration of a plan; hipFree synchronises)
+            (void)hipFree(h->d_logz); h->d_logz = nullptr; h->logz_cap = 0;
+            int arc = dmalloc(&h->d_logz, need);
+            if (arc) return arc;
+            h->logz_cap = need;
+        }
+    }
+    h->logz_valid = false; h->alpha_prev_valid = false; h->pw_diff = false;
+    auto with_logz = [&](TermStatsParams t, int q) { t.logz = collect ? h->d_logz + logz_off[(size_t)q] : nullptr; return t; };
     // Round 5: the passes before the last accumulate in order in d_stats on aux[0]; the LAST pass, on the context's stream behind the last document
     // kernel, used to wait for them (round 4's timeline: last document kernel done at 589 us, pass 2 + its combine at 625 us, one cross-queue hop, last
     // pass 637 - 705 us -- 48 us of a 750 us iteration with the chain waiting).  It now writes a buffer of its own (and its own multi-chunk partials) and
@@ -1634,13 +1724,13 @@ static int lda_estep_impl(tmvb_lda* h, int32_t viter, double vtol)
             if (piece_open == P - 1 && h->ar_live) {     // tmvb_lda_estep_allreduce: slice by slice, an event behind each
                 const tmvb_inv_index& ix = h->pieces.empty() ? h->ar_index : h->pieces.back();
                 for (int k = 0; k < h->ar_slices; ++k) {
-                    if (!(p.debug & 1)) { int rc = tmvb_launch_termstats(ctx, h->nslot, h->KP, h->e_padded, ix, tp, pass_st, h->ar_order[(size_t)k]); if (rc) return rc; }
+                    if (!(p.debug & 1)) { int rc = tmvb_launch_termstats(ctx, h->nslot, h->KP, h->e_padded, ix, with_logz(tp, piece_open), pass_st, h->ar_order[(size_t)k]); if (rc) return rc; }
                     TMVB_HIP(hipEventRecord(h->ev_slice[(size_t)k], pass_st));
                 }
                 continue;
             }
             if (split_out && piece_open == P - 1) {      // its own buffer, no wait; then the join with the passes before it
-                TermStatsParams tpb = tp;
+                TermStatsParams tpb = with_logz(tp, piece_open);
                 tpb.out = h->d_stats_b; tpb.partial = h->d_ts_partial_b;
                 int rc = stats_pass(piece_index(piece_open), pass_st, tpb);
                 if (rc) return rc;
@@ -1649,7 +1739,7 @@ static int lda_estep_impl(tmvb_lda* h, int32_t viter, double vtol)
                 TMVB_HIP(hipStreamWaitEvent(ctx->stream, h->ev_join[0], 0));
                 continue;
             }
-            int rc = stats_pass(piece_index(piece_open), pass_st, tp);
+            int rc = stats_pass(piece_index(piece_open), pass_st, with_logz(tp, piece_open));
             if (rc) return rc;
         }
         return TMVB_OK;
@@ -1730,6 +1820,7 @@ static int lda_estep_impl(tmvb_lda* h, int32_t viter, double vtol)
         h->esum_fresh = true; h->esum_side = true;
     }
     h->stats_fresh = !(p.debug & 1); h->pw_valid = false;
+    h->logz_valid = collect; h->n_logz = collect ? logz_off[(size_t)P] : 0;
     if (h->timing) TMVB_HIP(hipEventRecord(h->ev1, ctx->stream));
     h->timed = true;
     return TMVB_OK;
@@ -1939,10 +2030,13 @@ extern "C" int tmvb_lda_update_beta(tmvb_lda* h)
     }
     const int64_t total = (int64_t)h->KP * h->V;
     int nb = (int)std::min<int64_t>(2048, std::max<int64_t>(1, (total + 255) / 256));
+    const bool parts = h->logz_valid && h->stats_fresh;     // the coming update_elbo! is the decomposed one: leave sum S (log beta_new - log beta_old)
     hipLaunchKernelGGL(beta_norm_kernel, dim3(nb), dim3(256), (size_t)h->K * sizeof(double), ctx->stream,
-                       h->d_stats, h->d_rowsum, h->d_beta[h->cur ^ 1], h->K, h->KP, h->V, h->d_pw_partial, TMVB_EPS_F);
+                       h->d_stats, h->d_rowsum, h->d_beta[h->cur ^ 1], h->K, h->KP, h->V, h->d_pw_partial, TMVB_EPS_F,
+                       parts ? (const float*)h->d_beta[h->cur] : (const float*)nullptr);
     TMVB_HIP(hipGetLastError());
     h->pw_blocks = nb;
+    h->pw_diff = parts;
     h->pw_valid = h->stats_fresh;
     h->stats_fresh = false;
     h->cur ^= 1;   // beta_old <- beta, beta <- new   (src/LDA.jl:122-123)
@@ -1969,6 +2063,10 @@ extern "C" int tmvb_lda_update_alpha(tmvb_lda* h, int32_t niter, double ntol)
         TMVB_HIP(hipStreamWaitEvent(side, h->ev_mark, 0));
     }
     h->mark_valid = false;
+    if (h->logz_valid && !h->alpha_prev_valid) {            // the alpha the E-step read: gamma - alpha is sum_n c_n phi_n (lda_elbo_doc_kernel)
+        TMVB_HIP(hipMemcpyAsync(h->d_alpha_prev, h->d_alpha_d, (size_t)h->K * sizeof(double), hipMemcpyDeviceToDevice, side));
+        h->alpha_prev_valid = true;
+    }
     int rc = dispatch_nslot(h->nslot, [&](auto ns) -> int {
         constexpr int NS = decltype(ns)::value;
         hipLaunchKernelGGL((lda_alpha_kernel<NS>), dim3(1), dim3(64), 0, side, h->K, (double)h->M_total, h->d_esum, ef,
@@ -1991,9 +2089,21 @@ static int lda_elbo_enqueue(tmvb_lda* h)
     TMVB_HIP(hipSetDevice(ctx->device));
     { int jrc = lda_join_side(h); if (jrc) return jrc; }
     bool use_pw = false;
-    if (h->M > 0 && h->reg_path && getenv("TMVB_LDA_ELBO_LEGACY") == nullptr) {
+    int64_t n_vals = 0;
+    h->elbo_form = 0;
+    if (h->M > 0 && h->logz_valid && h->alpha_prev_valid && h->pw_valid && h->pw_diff) {
+        // the decomposed form: everything per token was left behind by the iteration's own statistics passes and update_beta!
+        const unsigned nblk = (unsigned)((h->M + 63) / 64);
+        const size_t lds = (size_t)3 * 64 * (size_t)h->K * sizeof(float);
+        if (lds > 48 * 1024) TMVB_HIP(hipFuncSetAttribute((const void*)lda_elbo_doc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(lda_elbo_doc_kernel, dim3(nblk), dim3(64), lds, ctx->stream, h->K, h->M, h->d_alpha_d, h->d_alpha_prev, h->d_gamma, h->d_elog,
+                           h->d_elog_old, h->d_logz, h->n_logz, h->d_doc_val);
+        TMVB_HIP(hipGetLastError());
+        use_pw = true; n_vals = nblk;
+        h->elbo_form = 1;
+    } else if (h->M > 0 && h->reg_path && getenv("TMVB_LDA_ELBO_LEGACY") == nullptr) {
         const dim3 grid((unsigned)h->M), block(64);
-        use_pw = h->pw_valid && getenv("TMVB_LDA_ELBO_NO_PW") == nullptr;
+        use_pw = h->pw_valid && !h->pw_diff && getenv("TMVB_LDA_ELBO_NO_PW") == nullptr;
         switch (h->KP / 4) {
 #define LDA_ELBO_CASE(LPRV) case LPRV: \
             if (use_pw) hipLaunchKernelGGL((lda_elbo_reg_kernel<LPRV, false>), grid, block, 0, ctx->stream, h->K, h->d_doc_order, h->corp->d_doc_ptr, \
@@ -2022,7 +2132,7 @@ static int lda_elbo_enqueue(tmvb_lda* h)
     }
     hipLaunchKernelGGL(lda_elbo_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, h->d_doc_val, h->M, h->K, h->d_alpha_d, h->d_elbo,
                        use_pw ? h->d_pw_partial : (const double*)nullptr, h->pw_blocks,
-                       h->distributed && h->M_total > 0 ? (double)h->M / (double)h->M_total : 1.0);
+                       h->distributed && h->M_total > 0 ? (double)h->M / (double)h->M_total : 1.0, n_vals);
     TMVB_HIP(hipGetLastError());
     return TMVB_OK;
 }
@@ -2081,6 +2191,7 @@ struct LdaTrainOps {
     float* stats(tmvb_lda* h) { return h->d_stats; }
     int64_t stats_len(tmvb_lda* h) { return (int64_t)h->K * h->V + h->K; }
     int mstep(tmvb_lda* h) { int rc = tmvb_lda_update_beta(h); return rc ? rc : tmvb_lda_update_alpha(h, niter, ntol); }   // :181-182
+    void will_check(tmvb_lda* h, bool checked) { h->want_parts = checked; }           // the coming iteration ends in check_elbo!: collect update_elbo!'s parts on the way
     int elbo_local(tmvb_lda* h, double* s, double* once) { *once = 0.0; return tmvb_lda_update_elbo(h, s); }
     int elbo_enqueue(tmvb_lda* h, double* once) { *once = 0.0; TMVB_HIP(hipSetDevice(h->ctx->device)); return lda_elbo_enqueue(h); }   // -> elbo_dev(h), no sync
     double* elbo_dev(tmvb_lda* h) { return h->d_elbo; }
@@ -2116,6 +2227,13 @@ extern "C" int tmvb_lda_train(tmvb_lda* h, int32_t iter, double tol, int32_t nit
 {
     TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_lda_train: handle is NULL");
     return tmvb_lda_train_group(&h, 1, iter, tol, niter, ntol, viter, vtol, checkelbo, elbo_traj, iters_done, elbo_baseline);
+}
+
+extern "C" int tmvb_lda_elbo_form(tmvb_lda* h, int32_t* form)
+{
+    TMVB_REQUIRE(h && form, TMVB_EINVAL, "tmvb_lda_elbo_form: NULL argument");
+    *form = h->elbo_form;
+    return TMVB_OK;
 }
 
 // per-document sweep counts of the last E-step (document order of the corpus), for parity tests that compare the

@@ -36,6 +36,8 @@ struct TermStatsParams {
     float base;                  // value added to every written entry (CTPF priors a / e; else 0)
     float* out;                  // [n_ids][ostride]
     float* partial;              // [n_slots][K + 1]  raw (sum w E | sum w) of multi-chunk ids
+    float* logz = nullptr;       // [n_chunks] or NULL (LOGZ instantiations of the recompute kernels): per chunk sum_n val_n * log2(s_n), the token
+                                 // normalisers' share of update_elbo! (src/LDA.jl:78, :87-88; see lda_elbo_doc_kernel in tmvb_lda.hip)
 };
 
 template <int NSLOT>
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(256) void termstats_chunk4_kernel(TermStatsParams p
 
 // PAD form of the recompute pass with CPL column chunks per lane (see termstats_recompute_body below for the algorithm and the PAD contract:
 // rows of E zero-padded to 4 * LANES * CPL floats, 32-bit byte offsets, keps > 0 or the select on the row).
-template <int LPR, int LANES, int CPL>
+template <int LPR, int LANES, int CPL, bool LOGZ = false>
 __device__ __forceinline__ void termstats_recompute_cpl_body(const TermStatsParams& p)
 {
     constexpr int SLOTS = 64 / LANES;
@@ -195,7 +197,7 @@ __device__ __forceinline__ void termstats_recompute_cpl_body(const TermStatsPara
     }
     const char* __restrict__ Eb = (const char*)p.E;
     const uint32_t esb = (uint32_t)p.estride * 4u, lane_off = 16u * (uint32_t)cc;
-    float wl = 0.0f;
+    float wl = 0.0f, ll = 0.0f;
     for (int t0 = b; t0 < e; t0 += 64) {
         const int tok = t0 + lane;
         const bool valid = tok < e;
@@ -231,6 +233,7 @@ __device__ __forceinline__ void termstats_recompute_cpl_body(const TermStatsPara
                 if (LANES >= 16) part += dpp_f<0x140>(part);          // every lane of the slot holds s_n - keps
                 float wz = __builtin_bit_cast(float, dw[u].y) * __builtin_amdgcn_rcpf(part + p.keps);
                 wz = (k0 + u * SLOTS + rs < cnt) ? wz : 0.0f;
+                if constexpr (LOGZ) ll = fmaf(__builtin_bit_cast(float, dw[u].y), __builtin_amdgcn_logf(part + p.keps), ll);   // a slot past the end: value 0, s > 0
                 const v2f w2 = v2f{wz, wz};
 #pragma unroll
                 for (int q = 0; q < CPL; ++q) {
@@ -253,6 +256,7 @@ __device__ __forceinline__ void termstats_recompute_cpl_body(const TermStatsPara
 #pragma unroll
             for (int v = 0; v < 4; ++v) tot[q][v] += dpp_f<0x124>(tot[q][v]);     // row_ror:4
         wsum += dpp_f<0x124>(wsum);
+        if constexpr (LOGZ) ll += dpp_f<0x124>(ll);
     }
     if (LANES <= 8) {
 #pragma unroll
@@ -260,6 +264,7 @@ __device__ __forceinline__ void termstats_recompute_cpl_body(const TermStatsPara
 #pragma unroll
             for (int v = 0; v < 4; ++v) tot[q][v] += dpp_f<0x128>(tot[q][v]);     // row_ror:8
         wsum += dpp_f<0x128>(wsum);
+        if constexpr (LOGZ) ll += dpp_f<0x128>(ll);
     }
 #pragma unroll
     for (int o = 16; o <= 32; o <<= 1) {
@@ -268,8 +273,10 @@ __device__ __forceinline__ void termstats_recompute_cpl_body(const TermStatsPara
 #pragma unroll
             for (int v = 0; v < 4; ++v) tot[q][v] += __shfl_xor(tot[q][v], o, 64);
         wsum += __shfl_xor(wsum, o, 64);
+        if constexpr (LOGZ) ll += __shfl_xor(ll, o, 64);
     }
     if (!active || lane >= LANES) return;
+    if constexpr (LOGZ) { if (lane == 0) p.logz[c] = ll; }
     const int slot = p.chunk_out[c];
     const int K = p.K;
 #pragma unroll
@@ -309,12 +316,12 @@ __device__ __forceinline__ void termstats_recompute_cpl_body(const TermStatsPara
 // 862.9 -> 875.2 / 875.3 VB it/s with CPL = 4, 870.7 / 874.7 with 2); K = 50 -1 % (CPL = 2) and -7 % (CPL = 4: twice the 128-byte lines per row and
 // instruction) -- the pass is bound by what the L2 delivers to the vector L1s (12 - 15 TB/s of gathered rows), not by its instructions, so the
 // default is CPL = 4 at KP = 100 and the round-4 form (CPL = 1) at KP = 52; TMVB_TS_CPL overrides.
-template <int LPR_T, int LANES, bool PAD = false, int CPL = 1>
+template <int LPR_T, int LANES, bool PAD = false, int CPL = 1, bool LOGZ = false>
 __device__ __forceinline__ void termstats_recompute_body(const TermStatsParams& p, int LPR_rt)
 {
     static_assert(LANES == 4 || LANES == 8 || LANES == 16 || LANES == 32, "termstats_recompute_kernel: 4, 8, 16 or 32 lanes per row slot");
     static_assert(CPL == 1 || (PAD && LPR_T > 0 && LANES <= 16), "several chunks per lane: PAD form with a compile-time row length only");
-    if constexpr (CPL > 1) { termstats_recompute_cpl_body<LPR_T, LANES, CPL>(p); return; }
+    if constexpr (CPL > 1) { termstats_recompute_cpl_body<LPR_T, LANES, CPL, LOGZ>(p); return; }
     constexpr int SLOTS = 64 / LANES;
     __shared__ int2 dw_l[4][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -332,7 +339,7 @@ __device__ __forceinline__ void termstats_recompute_body(const TermStatsParams& 
     typedef float v2f __attribute__((ext_vector_type(2)));
     const v2f tlo = v2f{tj.x, tj.y}, thi = v2f{tj.z, tj.w};
     v2f alo = v2f{0.f, 0.f}, ahi = v2f{0.f, 0.f};          // packed fp32 accumulators (v_pk_fma_f32)
-    float wl = 0.0f;
+    float wl = 0.0f, ll = 0.0f;
     for (int t0 = b; t0 < e; t0 += 64) {
         const int tok = t0 + lane;
         const bool valid = tok < e;
@@ -383,6 +390,7 @@ __device__ __forceinline__ void termstats_recompute_body(const TermStatsParams& 
                     }
                     float wz = __builtin_bit_cast(float, dw[u].y) * __builtin_amdgcn_rcpf(part + p.keps);
                     wz = (k0 + u * SLOTS + rs < cnt) ? wz : 0.0f;
+                    if constexpr (LOGZ) ll = fmaf(__builtin_bit_cast(float, dw[u].y), __builtin_amdgcn_logf(part + p.keps), ll);   // a slot past the end: value 0, s > 0
                     const v2f w2 = v2f{wz, wz};
                     alo = __builtin_elementwise_fma(w2, elo, alo);
                     ahi = __builtin_elementwise_fma(w2, ehi, ahi);
@@ -423,6 +431,7 @@ __device__ __forceinline__ void termstats_recompute_body(const TermStatsParams& 
                     part += sib;                                  // every lane of the slot holds s_n - keps
                 }
                 const float wz = row_on ? fast_div(__builtin_bit_cast(float, dw[u].y), part + p.keps) : 0.0f;
+                if constexpr (LOGZ) ll += row_on ? __builtin_bit_cast(float, dw[u].y) * __builtin_amdgcn_logf(part + p.keps) : 0.0f;
                 const v2f w2 = v2f{wz, wz};
                 alo = __builtin_elementwise_fma(w2, elo, alo);
                 ahi = __builtin_elementwise_fma(w2, ehi, ahi);
@@ -440,8 +449,10 @@ __device__ __forceinline__ void termstats_recompute_body(const TermStatsParams& 
         tot.x += __shfl_xor(tot.x, o, 64); tot.y += __shfl_xor(tot.y, o, 64);
         tot.z += __shfl_xor(tot.z, o, 64); tot.w += __shfl_xor(tot.w, o, 64);
         wsum += __shfl_xor(wsum, o, 64);
+        if constexpr (LOGZ) ll += __shfl_xor(ll, o, 64);
     }
     if (!active || lane >= LPR) return;
+    if constexpr (LOGZ) { if (lane == 0) p.logz[c] = ll; }
     const float tv[4] = {tot.x, tot.y, tot.z, tot.w};
     const float tjv[4] = {tj.x, tj.y, tj.z, tj.w};
     const int slot = p.chunk_out[c];
@@ -463,10 +474,10 @@ __device__ __forceinline__ void termstats_recompute_body(const TermStatsParams& 
     }
 }
 
-template <int LPR_T, int LANES, bool PAD = false, int CPL = 1>
+template <int LPR_T, int LANES, bool PAD = false, int CPL = 1, bool LOGZ = false>
 __global__ __launch_bounds__(256) void termstats_recompute_kernel(TermStatsParams p, int LPR_rt)
 {
-    termstats_recompute_body<LPR_T, LANES, PAD, CPL>(p, LPR_rt);
+    termstats_recompute_body<LPR_T, LANES, PAD, CPL, LOGZ>(p, LPR_rt);
 }
 // Two independent passes (CTPF: the term index and the reader index) in ONE launch, blockIdx.y selects the pass: run on two streams
 // they cost a ~19 us cross-stream join in a 0.3 ms iteration.

@@ -69,6 +69,12 @@ template <class Ops, class H, class = void> struct tmvb_has_estep_allreduce : st
 template <class Ops, class H>
 struct tmvb_has_estep_allreduce<Ops, H, std::void_t<decltype(std::declval<Ops&>().estep_allreduce((H*)nullptr))>> : std::true_type {};
 
+// Ops may offer  void will_check(H*, bool): called before every iteration's E-step with whether check_elbo! will evaluate the ELBO behind it, so that the
+// iteration can leave update_elbo!'s per-token parts behind on its way (LDA) instead of walking the corpus a second time.
+template <class Ops, class H, class = void> struct tmvb_has_will_check : std::false_type {};
+template <class Ops, class H>
+struct tmvb_has_will_check<Ops, H, std::void_t<decltype(std::declval<Ops&>().will_check((H*)nullptr, true))>> : std::true_type {};
+
 template <class H, class Ops>
 static int tmvb_group_elbo(H* const* hs, int n, Ops& ops, double* out)
 {
@@ -148,6 +154,8 @@ static int tmvb_train_group_loop(const char* who, H* const* hs, int n, int iter,
     int done = 0;
     for (int k = 1; k <= iter; ++k) {
         ++done;
+        if constexpr (tmvb_has_will_check<Ops, H>::value)
+            for (int i = 0; i < n; ++i) ops.will_check(hs[i], checkelbo > 0 && (k % checkelbo) == 0);
         bool fused = false;
         if constexpr (tmvb_has_estep_allreduce<Ops, H>::value) {
             // DEFAULT: the three-call form -- estep, reduce_docs, ONE collective of the whole K*V+K buffer on the context's stream (north_star's
@@ -178,6 +186,7 @@ static int tmvb_train_group_loop(const char* who, H* const* hs, int n, int iter,
             if (delta < tol) break;                                             // signed, quirk Q4
         }
     }
+    if constexpr (tmvb_has_will_check<Ops, H>::value) for (int i = 0; i < n; ++i) ops.will_check(hs[i], false);
     for (int i = 0; i < n; ++i) if ((rc = ops.finish(hs[i]))) return rc;
     if (iters_done) *iters_done = done;
     return TMVB_OK;

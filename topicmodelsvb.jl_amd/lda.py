@@ -300,6 +300,12 @@ class gpuLDA:
         check(lib().tmvb_lda_estep_launches(self.handle, C.byref(n)))
         return n.value
 
+    def elbo_form(self) -> int:
+        """1 if the last update_elbo! took the decomposed form (parts left behind by the iteration itself), 0 for the token walk."""
+        f = C.c_int32(0)
+        check(lib().tmvb_lda_elbo_form(self.handle, C.byref(f)))
+        return f.value
+
     def doc_sweeps(self):
         """Sweeps each document ran in the last E-step (uint8 per document, corpus order)."""
         out = np.zeros(max(self.M, 1), dtype=np.uint8)
