@@ -255,7 +255,7 @@ int tmvb_lda_doc_sweeps(tmvb_lda* h, uint8_t* out);
 /* Which form the last tmvb_lda_update_elbo / check of tmvb_lda_train took (update_elbo!, src/LDA.jl:83-93): *form = 1 the decomposed form -- the
  * iteration's own statistics passes left sum_n c_n log s_n per postings chunk, update_beta! left sum S (log beta_new - log beta_old), and one
  * per-document kernel adds Elogptheta, sum_k (gamma_k - alpha_k)(Elogtheta_k - Elogtheta_old_k) and the Dirichlet entropy: no second walk over the
- * corpus; taken by every iteration tmvb_lda_train checks (K <= 128) and, with TMVB_LDA_ELBO_PARTS=2 at tmvb_lda_create, by the stepwise operators too;
+ * corpus; taken by every iteration tmvb_lda_train checks (K <= 124: the statistics pass recomputes the token weights up to KP = 124; viter > 0) and, with TMVB_LDA_ELBO_PARTS=2 at tmvb_lda_create, by the stepwise operators too;
  * *form = 0 the token walk (phi rebuilt from beta_old / Elogtheta_old per token: any state, e.g. right after tmvb_lda_set_state);
  * TMVB_LDA_ELBO_PARTS=0 forces it.  Both evaluate the same sum; they differ by fp32 rounding only (tests/test_lda_elbo_parts_gpu.py). */
 int tmvb_lda_elbo_form(tmvb_lda* h, int32_t* form);
@@ -346,6 +346,11 @@ int tmvb_ctm_update_sigma(tmvb_ctm* h);
 int tmvb_ctm_update_mu(tmvb_ctm* h);
 /* update_elbo! (src/CTM.jl:89-98) on the device; sum over this context's documents. */
 int tmvb_ctm_update_elbo(tmvb_ctm* h, double* elbo);
+/* As tmvb_lda_elbo_form: *form = 1 if the last tmvb_ctm_update_elbo took the decomposed form (the checked iteration's E-step kernels left
+ * sum_i (phi counts)_i (lambda_i - lambda_old_i) per document, its statistics pass sum_n c_n log s_n per postings chunk, update_beta!
+ * sum S (log(beta_new + eps) - log beta_old): no token loop), 0 for the token walk (any state).  Every iteration tmvb_ctm_train checks takes
+ * it (K <= 124, viter > 0); TMVB_CTM_ELBO_PARTS=2 at tmvb_ctm_create: the stepwise operators too, =0: never. */
+int tmvb_ctm_elbo_form(tmvb_ctm* h, int32_t* form);
 /* train! (src/gpuCTM.jl:487-519 signature, src/CTM.jl:185-213 semantics); elbo_baseline / communicator as for LDA. */
 int tmvb_ctm_train(tmvb_ctm* h, int32_t iter, double tol, int32_t niter, double ntol,
                    int32_t viter, double vtol, int32_t checkelbo, double* elbo_traj, int32_t* iters_done,

@@ -47,6 +47,7 @@ _T = {
     "ctm.invsigma_rel":         (1e-05, 1.57e-06),
     "ctm.elbo_rel_step":        (2e-07, 3.7e-08),
     "ctm.elbo_rel_free":        (1e-06, 1.06e-07),
+    "ctm.elbo_forms_rel":       (1.5e-07, 1.87e-08),     # decomposed update_elbo! against the token walk on the same device state (tests/test_ctm_elbo_parts_gpu.py)
     # ---- CTPF (tests/test_ctpf_gpu.py): shapes = gimel, zayin, alef, he (K <= 256; _bigk: K > 256); rates = bet, vav, dalet, het
     "ctpf.shape_rel":           (0.002, 0.000493),
     "ctpf.shape_rel_bigk":      (0.005, 0.000965),

@@ -288,8 +288,10 @@ static __global__ __launch_bounds__(256) void colsum_final_kernel(const double* 
 // statistics' share of E_q[log p(w)] - E_q[log q(z)] in the decomposed update_elbo! (lda_elbo_doc_kernel, tmvb_lda.hip).
 static __global__ __launch_bounds__(256) void beta_norm_kernel(float* __restrict__ S, const double* __restrict__ rowsum,
                                                             float* __restrict__ beta_new, int K, int KP, int64_t V,
-                                                            double* __restrict__ pw_partial, float eps, const float* __restrict__ beta_old = nullptr)
+                                                            double* __restrict__ pw_partial, float eps, const float* __restrict__ beta_old = nullptr,
+                                                            float eps_old = -1.0f)       // the epsilon inside log(beta_old + .): < 0 = eps (LDA), 0 for CTM
 {
+    if (eps_old < 0.0f) eps_old = eps;
     extern __shared__ double rinv[];
     __shared__ double red[4];
     for (int i = threadIdx.x; i < K; i += blockDim.x) rinv[i] = 1.0 / rowsum[i];
@@ -304,7 +306,9 @@ static __global__ __launch_bounds__(256) void beta_norm_kernel(float* __restrict
         if (i < K) {
             const float sv = S[j * K + i];
             o = (float)((double)sv * rinv[i]);
-            if (pw_partial) pw += (double)sv * (beta_old ? (double)logf(o + eps) - (double)logf(beta_old[q] + eps) : (double)logf(o + eps));
+            // (S = 0 contributes 0: CTM's phi has no epsilon, so a zero beta_old entry has S = 0 and log 0 must not meet it)
+            if (pw_partial) pw += beta_old ? (sv != 0.0f ? (double)sv * ((double)logf(o + eps) - (double)logf(beta_old[q] + eps_old)) : 0.0)
+                                           : (double)sv * (double)logf(o + eps);
             S[j * K + i] = 0.0f;
         }
         beta_new[q] = o;

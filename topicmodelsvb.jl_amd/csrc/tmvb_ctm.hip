@@ -24,6 +24,7 @@
 // M-step: the K x M * M x K scatter matrix sum_d (lambda_d - mu)(lambda_d - mu)^T runs on f32 MFMA
 // (v_mfma_f32_32x32x2_f32); sigma assembly, its inverse and log-determinant run in fp64 in one
 // workgroup.
+#define TMVB_TS_LOGZ 1            // the log-normaliser forms of the statistics pass (decomposed update_elbo!, see ctm_elbo_kernel)
 #include "tmvb_common_kernels.h"
 #include "tmvb_train.h"
 #include "tmvb_filtered.h"
@@ -72,6 +73,9 @@ struct CtmParams {
     int cg_maxit = 200;
     int tile_rows = 32;               // rows of a wave's topic tile window
     unsigned long long* cg_diag = nullptr;   // [0] CG trips, [1] Newton trips, [2] documents
+    // decomposed update_elbo! (ctm_elbo_doc_kernel): [M] or NULL -- sum_i (phi counts)_i (lambda_i - lambda_old_i) of each document's LAST executed sweep,
+    // the one quantity of the token terms that only the E-step kernel has (phi counts lives in its registers); CTM only
+    float* pdot = nullptr;
 };
 
 __device__ __forceinline__ float readlane_f(float v, int l)
@@ -371,6 +375,7 @@ __global__ __launch_bounds__(64) void ctm_estep_kernel(CtmParams p, int64_t firs
     };
 
     int sweeps = 0;
+    double pd_last = 0.0;                 // sum_i (phi counts)_i (lambda_i - lambda_old_i) of the last executed sweep (CtmParams::pdot)
     for (int v = 0; v < p.viter; ++v) {
         ++sweeps;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -417,8 +422,10 @@ __global__ __launch_bounds__(64) void ctm_estep_kernel(CtmParams p, int64_t firs
         else { run_vsq(); run_lambda(phic); }                                   // src/CTM.jl:198-199
         const double df = on ? lam - lam_old : 0.0;
         const double dist2 = wave_sum_d(df * df);
+        if constexpr (!FILT) { if (p.pdot) pd_last = wave_sum_d(phic * df); }
         if (sqrt(dist2) < p.vtol) break;                                        // :200 / :242
     }
+    if constexpr (!FILT) { if (p.pdot && lane == 0) p.pdot[d] = (float)pd_last; }
 
     if (sweeps > 0) {
         if (on) {
@@ -752,6 +759,7 @@ __global__ __launch_bounds__(64 * MAXW) void ctm_estep_generic_kernel(CtmParams 
 
     int sweeps = 0;
     unsigned nsteps = 0;
+    double pd_last = 0.0;                 // CtmParams::pdot
     for (int v = 0; v < p.viter; ++v) {
         ++sweeps;
         // update_phi!  src/CTM.jl:175-178, linear space (no epsilon)
@@ -1041,11 +1049,13 @@ __global__ __launch_bounds__(64 * MAXW) void ctm_estep_generic_kernel(CtmParams 
             if (sqrt(gn2) < p.ntol) break;                                                  // :138
         }
         if constexpr (FILT) run_vsq();                                                      // src/fCTM.jl:240
-        double d2l = 0.0;
+        double d2l = 0.0, pdl = 0.0;
 #pragma unroll
-        for (int s = 0; s < NS; ++s) if (on[s]) { const double df = lam[s] - lam_old[s]; d2l += df * df; }
+        for (int s = 0; s < NS; ++s) if (on[s]) { const double df = lam[s] - lam_old[s]; d2l += df * df; pdl = fma(phic[s], df, pdl); }
+        if constexpr (!FILT) { if (p.pdot) pd_last = wave_sum_d(pdl); }
         if (sqrt(wave_sum_d(d2l)) < p.vtol) break;                                          // :200
     }
+    if constexpr (!FILT) { if (p.pdot && lane == 0) p.pdot[d] = (float)pd_last; }
 
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -1245,7 +1255,13 @@ __global__ __launch_bounds__(256) void ctm_sigma_mu_kernel(int K, int KP, double
 
 // ------------------------------------------------------------------------------ ELBO
 // update_elbo!  src/CTM.jl:89-98 per document (terms :56-86).  One wave per document, lane l owns topics l + 64 s.
-template <int NS>
+// TOK = false -- the decomposed form (round 5).  With x_ni = beta_old[i, v_n] e_i, e_i = exp(lambda_old_i - max lambda_old), s_n = sum_i x_ni and
+// phi_ni = x_ni / s_n (:93), the token terms  sum_n c_n sum_i phi_ni (lambda_i + log(beta_iv + eps) - log phi_ni)  (:64, :71, :84) are
+//     sum_i (phi counts)_i (lambda_i - lambda_old_i)                    pdot[d]: left by the E-step kernel's exit test (CtmParams::pdot)
+//   + C_d max lambda_old + sum_n c_n log s_n                            the statistics pass recomputes s_n from the same e: one partial per chunk (logz)
+//   + sum_{v,i} S_vi (log(beta_new + eps) - log beta_old)               beta_norm_kernel's partial (update_beta! reads S and writes beta_new)
+// so this kernel skips its token loop (95 % of it: 1.51 -> see profiles/r5_elbo_forms.txt) and only sums the document's counts.
+template <int NS, bool TOK = true>
 __global__ __launch_bounds__(64) void ctm_elbo_kernel(int K, int KP, const int64_t* __restrict__ doc_ptr,
                                                       const int32_t* __restrict__ terms, const int32_t* __restrict__ counts,
                                                       const double* __restrict__ mu_d, const double* __restrict__ invsigma_d,
@@ -1253,7 +1269,7 @@ __global__ __launch_bounds__(64) void ctm_elbo_kernel(int K, int KP, const int64
                                                       const float* __restrict__ beta, const float* __restrict__ beta_old,
                                                       const float* __restrict__ lambda, const float* __restrict__ lambda_old,
                                                       const float* __restrict__ vsq, const float* __restrict__ logzeta,
-                                                      double* __restrict__ doc_val)
+                                                      double* __restrict__ doc_val, const float* __restrict__ pdot = nullptr)
 {
     const int lane = threadIdx.x;
     const int d = blockIdx.x;
@@ -1280,6 +1296,12 @@ __global__ __launch_bounds__(64) void ctm_elbo_kernel(int K, int KP, const int64
     }
     const double lz = (double)logzeta[d];
     double acc = 0.0, Cd = 0.0;
+    if constexpr (!TOK) {
+        float cl = 0.0f;                                                       // C_d (exact in fp32 up to 2^24, as the E-step kernels sum it)
+        for (int n = lane; n < N; n += 64) cl += (float)counts[off + n];
+        Cd = (double)wave_sum(cl);
+        if (lane == 0 && N > 0) acc = (double)pdot[d] + Cd * (double)lmax;
+    } else
     for (int n = 0; n < N; ++n) {
         const int t = terms[off + n];
         const float c = (float)counts[off + n];
@@ -1322,6 +1344,24 @@ __global__ __launch_bounds__(64) void ctm_elbo_kernel(int K, int KP, const int64
     tot -= Cd * (lz - 1.0);
     tot += 0.5 * (double)K * (1.0 + TWO_PI_LOG);
     if (lane == 0) doc_val[d] = tot;
+}
+
+// the decomposed update_elbo!: sum of the per-document values + ln 2 * the chunks' log2-normaliser sums + this shard's share of update_beta!'s partial
+__global__ __launch_bounds__(1024) void ctm_elbo_final_kernel(const double* __restrict__ doc_val, int64_t M, const float* __restrict__ logz, int64_t n_logz,
+                                                              const double* __restrict__ pw_partial, int pw_blocks, double pw_share, double* __restrict__ out)
+{
+    __shared__ double red[1024];
+    double s = 0.0, lz = 0.0, pw = 0.0;
+    for (int64_t d = threadIdx.x; d < M; d += 1024) s += doc_val[d];
+    for (int64_t i = threadIdx.x; i < n_logz; i += 1024) lz += (double)logz[i];
+    for (int b = threadIdx.x; b < pw_blocks; b += 1024) pw += pw_partial[b];
+    red[threadIdx.x] = s + 0.6931471805599453 * lz + pw_share * pw;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0];
 }
 
 __global__ __launch_bounds__(1024) void sum_docs_kernel(const double* __restrict__ doc_val, int64_t M, double* __restrict__ out)
@@ -1386,6 +1426,13 @@ struct tmvb_ctm {
     static constexpr int NAUX = 4;
     hipStream_t aux[NAUX] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[NAUX] = {nullptr, nullptr, nullptr, nullptr};
+    // decomposed update_elbo! (as LDA's, tmvb_lda.hip): an iteration that train! will check (or every one, TMVB_CTM_ELBO_PARTS=2 at tmvb_ctm_create;
+    // 0: never) has its statistics pass leave sum c log2 s per chunk (d_logz), its document kernels sum_i (phi counts)_i (lambda_i - lambda_old_i) per
+    // document (d_pdot), and update_beta! sum S (log(beta_new + eps) - log beta_old) (d_pw_partial); update_elbo! then skips its token loop.
+    int parts_env = 1; bool want_parts = false;
+    float* d_logz = nullptr; size_t logz_cap = 0; int64_t n_logz = 0; float* d_pdot = nullptr; double* d_pw_partial = nullptr; int pw_blocks = 0;
+    bool logz_valid = false, stats_fresh = false, pw_valid = false;
+    int elbo_form = 0;
     int64_t stats_len() const { return (int64_t)K * V + 2 * K + (int64_t)K * K; }
     float* tail() const { return d_stats + (size_t)K * V; }
 };
@@ -1409,7 +1456,7 @@ extern "C" int tmvb_ctm_destroy(tmvb_ctm* h)
     (void)hipFree(h->d_mu_f); (void)hipFree(h->d_sigma); (void)hipFree(h->d_invsigma); (void)hipFree(h->d_mu);
     (void)hipFree(h->d_logdet); (void)hipFree(h->d_scatter_partial); (void)hipFree(h->d_sweeps); (void)hipFree(h->d_doc_order);
     (void)hipFree(h->d_partial); (void)hipFree(h->d_partial_docs); (void)hipFree(h->d_partial_docs2); (void)hipFree(h->d_rowsum); (void)hipFree(h->d_doc_val); (void)hipFree(h->d_elbo);
-    (void)hipFree(h->d_newton); (void)hipFree(h->d_status);
+    (void)hipFree(h->d_newton); (void)hipFree(h->d_status); (void)hipFree(h->d_logz); (void)hipFree(h->d_pdot); (void)hipFree(h->d_pw_partial);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -1466,6 +1513,7 @@ extern "C" int tmvb_ctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
     tmvb_create_guard<tmvb_ctm, tmvb_ctm_destroy> guard{h};      // every early return below destroys h
     h->ctx = ctx; h->corp = corp; h->K = K; h->KP = tmvb_kpad(K);
     h->nslot = (K + 63) / 64; h->NB = (K + 31) / 32;
+    { const char* e = getenv("TMVB_CTM_ELBO_PARTS"); h->parts_env = e ? atoi(e) : 1; }
     h->generic = !ctm_kp_supported(h->KP) || [] { const char* e = getenv("TMVB_CTM_FORCE_GENERIC"); return e && atoi(e) != 0; }();   // (the env: measurements)
     h->M = corp->info.M; h->V = corp->info.V; h->M_total = h->M;
     const size_t KM = (size_t)K * h->M, KPV = (size_t)h->KP * h->V + 4;
@@ -1485,7 +1533,7 @@ extern "C" int tmvb_ctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
         (rc = dmalloc(&h->d_sweeps, (size_t)h->M)) || (rc = dmalloc(&h->d_doc_order, (size_t)h->M)) ||
         (rc = dmalloc(&h->d_partial, (size_t)TMVB_REDUCE_BLOCKS * K)) || (rc = dmalloc(&h->d_partial_docs, (size_t)TMVB_REDUCE_BLOCKS * K)) || (rc = dmalloc(&h->d_partial_docs2, (size_t)TMVB_REDUCE_BLOCKS * K)) ||
         (rc = dmalloc(&h->d_rowsum, K)) ||
-        (rc = dmalloc(&h->d_doc_val, (size_t)h->M)) || (rc = dmalloc(&h->d_elbo, 1)) || (rc = dmalloc(&h->d_newton, 1)) ||
+        (rc = dmalloc(&h->d_doc_val, (size_t)h->M)) || (rc = dmalloc(&h->d_pdot, (size_t)std::max<int64_t>(h->M, 1))) || (rc = dmalloc(&h->d_pw_partial, 2048)) || (rc = dmalloc(&h->d_elbo, 1)) || (rc = dmalloc(&h->d_newton, 1)) ||
         (rc = dmalloc(&h->d_status, 1)) ||
         (K > 128 && ((rc = dmalloc(&h->d_sigma_work, (size_t)K * K)) || (rc = dmalloc(&h->d_sigma_work_s, (size_t)K * K))))) {
         return rc;
@@ -1585,6 +1633,7 @@ extern "C" int tmvb_ctm_set_state(tmvb_ctm* h, const double* mu, const double* s
 {
     TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_ctm_set_state: handle is NULL");
     h->tail_fresh = false; h->sigma_staged = false;
+    h->logz_valid = false; h->stats_fresh = false; h->pw_valid = false;
     tmvb_ctx* ctx = h->ctx;
     TMVB_HIP(hipSetDevice(ctx->device));
     const size_t K = h->K, KP = h->KP, KM = K * (size_t)h->M;
@@ -1789,6 +1838,19 @@ extern "C" int tmvb_ctm_estep(tmvb_ctm* h, int32_t niter, double ntol, int32_t v
     p.niter = niter; p.ntol = ntol; p.viter = viter; p.vtol = vtol;
     { const char* dbg = getenv("TMVB_DEBUG_FLAGS"); p.debug = dbg ? atoi(dbg) : 0; }
     p.store_w = tmvb_termstats_recomputes(h->KP, h->KP / 4 <= 64) ? 0 : 1;
+    // decomposed update_elbo!: this iteration will be checked -- the document kernels leave pdot, the statistics pass the log-normaliser sums
+    const bool collect = (h->parts_env == 2 || (h->parts_env != 0 && h->want_parts)) && p.store_w == 0 && viter > 0 && !(p.debug & 1);
+    h->logz_valid = false; h->pw_valid = false; h->stats_fresh = false;
+    if (collect) {
+        const size_t need = (size_t)std::max<int64_t>(h->corp->term_index.n_chunks, 1);
+        if (need > h->logz_cap) {
+            (void)hipFree(h->d_logz); h->d_logz = nullptr; h->logz_cap = 0;
+            int arc = dmalloc(&h->d_logz, need);
+            if (arc) return arc;
+            h->logz_cap = need;
+        }
+        p.pdot = h->d_pdot;
+    }
     { int jrc = ctm_join_spec(h); if (jrc) return jrc; }        // the regrouped document order of the last E-step's side stream
     TMVB_HIP(hipEventRecord(h->ev0, ctx->stream));
     TMVB_HIP(hipMemsetAsync(h->d_newton, 0, sizeof(unsigned long long), ctx->stream));
@@ -1879,9 +1941,11 @@ extern "C" int tmvb_ctm_estep(tmvb_ctm* h, int32_t niter, double ntol, int32_t v
     tp.K = h->K; tp.tstride = h->KP; tp.ostride = h->K;
     tp.w = h->d_wtok; tp.E = h->d_E; tp.T = h->d_beta[h->cur]; tp.eps = 0.0f; tp.base = 0.0f; tp.keps = 0.0f;
     tp.out = h->d_stats; tp.partial = h->d_ts_partial;
+    tp.logz = collect ? h->d_logz : nullptr;
     int rc = tmvb_launch_termstats(ctx, h->nslot, h->KP, h->KP / 4 <= 64, h->corp->term_index, tp);
     if (folded) { TMVB_HIP(hipStreamWaitEvent(ctx->stream, h->ev_join[0], 0)); h->tail_fresh = (rc == TMVB_OK); }
     if (rc) return rc;
+    h->logz_valid = collect; h->n_logz = collect ? h->corp->term_index.n_chunks : 0; h->stats_fresh = true;
     TMVB_HIP(hipEventRecord(h->ev1, ctx->stream));
     h->timed = true;
     return TMVB_OK;
@@ -1971,9 +2035,12 @@ extern "C" int tmvb_ctm_update_beta(tmvb_ctm* h)
     if (rc) return rc;
     const int64_t total = (int64_t)h->KP * h->V;
     int nb = (int)std::min<int64_t>(2048, std::max<int64_t>(1, (total + 255) / 256));
+    const bool parts = h->logz_valid && h->stats_fresh;     // the coming update_elbo! is the decomposed one (src/CTM.jl:71 has the epsilon, :93 has none)
     hipLaunchKernelGGL(beta_norm_kernel, dim3(nb), dim3(256), (size_t)h->K * sizeof(double), ctx->stream,
-                       h->d_stats, h->d_rowsum, h->d_beta[h->cur ^ 1], h->K, h->KP, h->V, (double*)nullptr, 0.0f);
+                       h->d_stats, h->d_rowsum, h->d_beta[h->cur ^ 1], h->K, h->KP, h->V, parts ? h->d_pw_partial : (double*)nullptr, parts ? TMVB_EPS_F : 0.0f,
+                       parts ? (const float*)h->d_beta[h->cur] : (const float*)nullptr, 0.0f);
     TMVB_HIP(hipGetLastError());
+    h->pw_blocks = nb; h->pw_valid = parts; h->stats_fresh = false;
     h->cur ^= 1;
     return TMVB_OK;
 }
@@ -2040,6 +2107,16 @@ extern "C" int tmvb_ctm_update_elbo(tmvb_ctm* h, double* elbo)
     TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_ctm_update_elbo: handle is NULL");
     tmvb_ctx* ctx = h->ctx;
     TMVB_HIP(hipSetDevice(ctx->device));
+    const bool parts = h->logz_valid && h->pw_valid;         // everything per token was left behind by the iteration itself
+    h->elbo_form = parts ? 1 : 0;
+    if (parts && h->M > 0) {
+#define CTM_ELBO_DOC(NSV) hipLaunchKernelGGL((ctm_elbo_kernel<NSV, false>), dim3((unsigned)h->M), dim3(64), 0, ctx->stream, h->K, h->KP, h->corp->d_doc_ptr, \
+                               h->corp->d_terms, h->corp->d_counts, h->d_mu, h->d_invsigma, h->d_logdet, h->d_beta[h->cur], \
+                               h->d_beta[h->cur ^ 1], h->d_lambda, h->d_lambda_old, h->d_vsq, h->d_logzeta, h->d_doc_val, h->d_pdot)
+        if (h->nslot == 1) CTM_ELBO_DOC(1); else if (h->nslot == 2) CTM_ELBO_DOC(2); else CTM_ELBO_DOC(4);
+#undef CTM_ELBO_DOC
+        TMVB_HIP(hipGetLastError());
+    } else
     if (h->M > 0) {
         if (h->nslot == 1)
             hipLaunchKernelGGL((ctm_elbo_kernel<1>), dim3((unsigned)h->M), dim3(64), 0, ctx->stream, h->K, h->KP, h->corp->d_doc_ptr,
@@ -2055,7 +2132,11 @@ extern "C" int tmvb_ctm_update_elbo(tmvb_ctm* h, double* elbo)
                                h->d_beta[h->cur ^ 1], h->d_lambda, h->d_lambda_old, h->d_vsq, h->d_logzeta, h->d_doc_val);
         TMVB_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(sum_docs_kernel, dim3(1), dim3(1024), 0, ctx->stream, h->d_doc_val, h->M, h->d_elbo);
+    if (parts)
+        hipLaunchKernelGGL(ctm_elbo_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, h->d_doc_val, h->M, h->d_logz, h->n_logz, h->d_pw_partial, h->pw_blocks,
+                           h->distributed && h->M_total > 0 ? (double)h->M / (double)h->M_total : 1.0, h->d_elbo);
+    else
+        hipLaunchKernelGGL(sum_docs_kernel, dim3(1), dim3(1024), 0, ctx->stream, h->d_doc_val, h->M, h->d_elbo);
     TMVB_HIP(hipGetLastError());
     double v = 0.0;
     int st = 0;
@@ -2065,6 +2146,13 @@ extern "C" int tmvb_ctm_update_elbo(tmvb_ctm* h, double* elbo)
     TMVB_REQUIRE(st == 0, TMVB_ENONFINITE, "sigma must be positive-definite.");
     h->elbo = v;
     if (elbo) *elbo = v;
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_ctm_elbo_form(tmvb_ctm* h, int32_t* form)
+{
+    TMVB_REQUIRE(h && form, TMVB_EINVAL, "tmvb_ctm_elbo_form: NULL argument");
+    *form = h->elbo_form;
     return TMVB_OK;
 }
 
@@ -2093,6 +2181,7 @@ struct CtmTrainOps {
         return rc;
     }
     int elbo_local(tmvb_ctm* h, double* s, double* once) { *once = 0.0; return tmvb_ctm_update_elbo(h, s); }
+    void will_check(tmvb_ctm* h, bool checked) { h->want_parts = checked; }             // the coming iteration ends in check_elbo!
     double* elbo_dev(tmvb_ctm* h) { return h->d_elbo; }
     tmvb_comm* comm(tmvb_ctm* h) { return h->comm; }
     bool distributed(tmvb_ctm* h) { return h->distributed; }

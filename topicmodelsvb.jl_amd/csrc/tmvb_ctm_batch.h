@@ -363,6 +363,9 @@ __device__ __forceinline__ int cb_karg32()
 // E-step (ctm_rowpad_kernel, 4 us) -- a 208-byte row at a 208-byte stride straddles two or three 128-byte lines (2.5 on average),
 // at a 256-byte stride exactly two.  A/B in one process tree (tools/ctm_ab.py, three alternating rounds): 205.6 / 205.8 / 202.9 it/s
 // without, 208.8 / 208.1 / 203.8 with (+1 %).  -DTMVB_CTM_ROWPAD=0 builds the unpadded gather.
+#ifndef TMVB_CTM_PDOT
+#define TMVB_CTM_PDOT 1
+#endif
 #ifndef TMVB_CTM_ROWPAD
 #define TMVB_CTM_ROWPAD 1
 #endif
@@ -837,10 +840,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         if (active) {
             const float* lam_old_in = CB_KARG(const float*, p.lambda_old);
             float dist2 = 0.0f;
+#if TMVB_CTM_PDOT
+            // sum_i (phi counts)_i (lambda_i - lambda_old_i) of this sweep, for the decomposed update_elbo! (CtmParams::pdot): phic's last use was
+            // the gradient of the Newton loop just behind; one more FMA per topic here and one store per document and sweep
+            float pdot = 0.0f;
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                if (i < R - 7 || i < K) { const float df = (float)(LAM(i) - (double)lam_old_in[(int64_t)d * K + i]); dist2 = fmaf(df, df, dist2); pdot = fmaf(phic[i], df, pdot); }
+            }
+            if constexpr (!FILT) { float* pd_out = CB_KARG(float*, p.pdot); if (pd_out) pd_out[d] = pdot; }
+#else
 #pragma unroll
             for (int i = 0; i < R; ++i) {
                 if (i < R - 7 || i < K) { const float df = (float)(LAM(i) - (double)lam_old_in[(int64_t)d * K + i]); dist2 = fmaf(df, df, dist2); }
             }
+#endif
             if (sqrtf(dist2) < (float)p.vtol) active = false;                                   // :200
         }
     }

@@ -1666,7 +1666,8 @@ static int lda_estep_impl(tmvb_lda* h, int32_t viter, double vtol)
     };
     // Decomposed update_elbo! (lda_elbo_doc_kernel): an iteration that will be checked has its statistics passes leave sum c log2 s per chunk
     const int parts_env = h->parts_env;                          // TMVB_LDA_ELBO_PARTS, read per model
-    const bool collect = (parts_env == 2 || (parts_env != 0 && h->want_parts)) && tmvb_termstats_recomputes(h->KP, h->e_padded) && !(p.debug & 1);
+    const bool collect = (parts_env == 2 || (parts_env != 0 && h->want_parts)) && tmvb_termstats_recomputes(h->KP, h->e_padded) && !(p.debug & 1) &&
+                         viter > 0;                                 // (viter = 0: the document kernels leave E = 0, not the factor update_elbo! rebuilds phi from)
     std::vector<int64_t> logz_off((size_t)P + 1, 0);
     auto stats_index = [&](int q) -> const tmvb_inv_index& {      // the index piece q's pass walks (tmvb_lda_estep_allreduce: its slice-major rebuild)
         return (h->ar_live && q == P - 1 && h->pieces.empty()) ? h->ar_index : piece_index(q);

@@ -132,6 +132,12 @@ class gpuCTM:
         self.elbo = out.value
         return out.value
 
+    def elbo_form(self) -> int:
+        """1 if the last update_elbo! took the decomposed form (parts left behind by the iteration itself), 0 for the token walk."""
+        f = C.c_int32(0)
+        check(lib().tmvb_ctm_elbo_form(self.handle, C.byref(f)))
+        return f.value
+
     def stats(self):
         p, n = VP(), C.c_int64(0)
         check(lib().tmvb_ctm_stats(self.handle, C.byref(p), C.byref(n)))
