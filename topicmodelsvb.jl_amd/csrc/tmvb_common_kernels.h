@@ -289,9 +289,21 @@ static __global__ __launch_bounds__(256) void colsum_final_kernel(const double* 
 static __global__ __launch_bounds__(256) void beta_norm_kernel(float* __restrict__ S, const double* __restrict__ rowsum,
                                                             float* __restrict__ beta_new, int K, int KP, int64_t V,
                                                             double* __restrict__ pw_partial, float eps, const float* __restrict__ beta_old = nullptr,
-                                                            float eps_old = -1.0f)       // the epsilon inside log(beta_old + .): < 0 = eps (LDA), 0 for CTM
+                                                            float eps_old = -1.0f,       // the epsilon inside log(beta_old + .): < 0 = eps (LDA), 0 for CTM
+                                                            const float* __restrict__ logz = nullptr, int64_t n_logz = 0, double* __restrict__ lz_partial = nullptr)
 {
     if (eps_old < 0.0f) eps_old = eps;
+    if (lz_partial) {                            // this block's slice of the statistics passes' per-chunk sums of c log2 s (TermStatsParams::logz), fixed order
+        const int64_t per = (n_logz + gridDim.x - 1) / gridDim.x;
+        const int64_t b = (int64_t)blockIdx.x * per, e = b + per < n_logz ? b + per : n_logz;
+        double lz = 0.0;
+        for (int64_t i = b + threadIdx.x; i < e; i += blockDim.x) lz += (double)logz[i];
+        lz = wave_sum_d(lz);
+        __shared__ double lred[4];
+        if ((threadIdx.x & 63) == 0) lred[threadIdx.x >> 6] = lz;
+        __syncthreads();
+        if (threadIdx.x == 0) lz_partial[blockIdx.x] = (lred[0] + lred[1]) + (lred[2] + lred[3]);
+    }
     extern __shared__ double rinv[];
     __shared__ double red[4];
     for (int i = threadIdx.x; i < K; i += blockDim.x) rinv[i] = 1.0 / rowsum[i];

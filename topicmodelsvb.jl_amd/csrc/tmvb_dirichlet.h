@@ -81,7 +81,9 @@ static __global__ __launch_bounds__(64) void lda_alpha_kernel(int K, double Md, 
 static __global__ __launch_bounds__(1024) void lda_elbo_final_kernel(const double* __restrict__ doc_val, int64_t M, int K,
                                                               const double* __restrict__ alpha_d, double* __restrict__ out,
                                                               const double* __restrict__ pw_partial, int pw_blocks, double pw_share,
-                                                              int64_t n_vals = 0)
+                                                              int64_t n_vals = 0,
+                                                              const double* __restrict__ esum = nullptr,        // [K] sum_d Elogtheta_d of these documents, or NULL
+                                                              const double* __restrict__ lz_partial = nullptr)  // [pw_blocks] sums of c log2 s (beta_norm_kernel), or NULL
 {
     const int64_t NV = n_vals > 0 ? n_vals : M;
     __shared__ double red[1024];
@@ -97,6 +99,8 @@ static __global__ __launch_bounds__(1024) void lda_elbo_final_kernel(const doubl
     }
     double pwl = 0.0;                                             // E_q[log p(w)] partials of update_beta!, if in use
     if (pw_partial) for (int b = threadIdx.x; b < pw_blocks; b += 1024) pwl += pw_share * pw_partial[b];
+    if (lz_partial) for (int b = threadIdx.x; b < pw_blocks; b += 1024) pwl += 0.6931471805599453 * lz_partial[b];
+    if (esum && (int)threadIdx.x < K) pwl += (alpha_d[threadIdx.x] - 1.0) * esum[threadIdx.x];       // Elogptheta's dot product over the documents (src/LDA.jl:51)
     red[threadIdx.x] = (((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]))) + pwl;
     __syncthreads();
     for (int o = 512; o > 0; o >>= 1) {

@@ -962,21 +962,23 @@ __global__ __launch_bounds__(64) void lda_elbo_reg_kernel(int K, const int32_t* 
 // separate, up to eps inside log x_nk (phi_nk log(1 + eps / (beta_old e_old)) <= eps / s_n ~ 1e-25 per term), into
 //     sum_k pc_k (Elogtheta_k - Elogtheta_old_k)                         this kernel, from the state the E-step left
 //   + sum_n c_n log s_n                                                  the statistics pass has s_n in a register: one v_log_f32 + FMA per posting,
-//                                                                        one partial per chunk (TermStatsParams::logz, log2 units)
+//                                                                        one partial per chunk (TermStatsParams::logz, log2 units), summed by beta_norm_kernel
 //   + sum_{v,k} S_vk (log(beta_new + eps) - log(beta_old + eps))         update_beta! reads S and writes beta_new: beta_norm_kernel's partial
 // so a checked iteration needs no second walk over the corpus (lda_elbo_reg_kernel: one gathered row and 2 K logarithms per token, 366 us on SYN-NSF
-// K = 50 against a 758 us iteration).  What is left per document is Elogptheta's dot product (:51), the sum above and the Dirichlet entropy (:72), one
-// psi / lgamma evaluation per (document, topic) in fp64 -- done here with ONE LANE PER DOCUMENT: the 64 documents' rows of gamma / Elogtheta /
-// Elogtheta_old are contiguous (64 K floats each), staged through LDS with coalesced loads, and a wave evaluates 64 (K + 1) special functions with
-// no cross-lane traffic and no redundant lane (lda_elbo_reg_kernel's lane = topic tail: 2 evaluations per document-wave with 50 of 64 lanes in
-// use).  A block also sums its slice of the statistics passes' log-normaliser partials.  One fp64 value per block, fixed order.
-__global__ __launch_bounds__(64) void lda_elbo_doc_kernel(int K, int64_t M, const double* __restrict__ alpha_new, const double* __restrict__ alpha_prev,
-                                                          const float* __restrict__ gamma, const float* __restrict__ elog,
-                                                          const float* __restrict__ elog_old, const float* __restrict__ logz, int64_t n_logz,
-                                                          double* __restrict__ block_val)
+// K = 50 against a 758 us iteration).  What is left per document is the sum above and the Dirichlet entropy (:72), one psi / lgamma evaluation per
+// (document, topic) in fp64; Elogptheta's dot product (:51) sum_d (alpha - 1) . Elogtheta_d = (alpha - 1) . Elogtheta_sum needs the NEW alpha and goes to
+// lda_elbo_final_kernel.  Nothing here depends on the M-step, so the E-step enqueues this kernel on its side stream right behind the Elogtheta column sums,
+// under the statistics pass (alpha is still the one the E-step read: update_alpha! follows on the same stream).
+// Layout: 64 documents per block, FOUR LANES PER DOCUMENT (topics q, q + 4, ...): the documents' rows of gamma / Elogtheta / Elogtheta_old are contiguous
+// (64 K floats each), staged through LDS with coalesced loads; every lane evaluates ~K / 4 special functions, no cross-lane traffic but two quad steps for
+// sum_k gamma_k (lda_elbo_reg_kernel's lane = topic tail: 2 evaluations per document-wave with 50 of 64 lanes in use).  One fp64 value per block, fixed order.
+__global__ __launch_bounds__(256) void lda_elbo_doc_kernel(int K, int64_t M, const double* __restrict__ alpha_e,
+                                                           const float* __restrict__ gamma, const float* __restrict__ elog,
+                                                           const float* __restrict__ elog_old, double* __restrict__ block_val)
 {
     extern __shared__ __attribute__((aligned(16))) float sm[];   // [3][64 K]
-    const int lane = threadIdx.x;
+    __shared__ double red[4];
+    const int tid = threadIdx.x;
     const int64_t d0 = (int64_t)blockIdx.x * 64;
     const int nd = (int)min((int64_t)64, M - d0);
     const int n = nd * K, n4 = n >> 2;
@@ -985,32 +987,28 @@ __global__ __launch_bounds__(64) void lda_elbo_doc_kernel(int K, int64_t M, cons
         const float4* g4 = (const float4*)(gamma + d0 * K);       // 64 K floats per block: 16-byte aligned
         const float4* e4 = (const float4*)(elog + d0 * K);
         const float4* o4 = (const float4*)(elog_old + d0 * K);
-        for (int i = lane; i < n4; i += 64) { ((float4*)sg)[i] = g4[i]; ((float4*)se)[i] = e4[i]; ((float4*)so)[i] = o4[i]; }
-        for (int i = 4 * n4 + lane; i < n; i += 64) { sg[i] = gamma[d0 * K + i]; se[i] = elog[d0 * K + i]; so[i] = elog_old[d0 * K + i]; }
+        for (int i = tid; i < n4; i += 256) { ((float4*)sg)[i] = g4[i]; ((float4*)se)[i] = e4[i]; ((float4*)so)[i] = o4[i]; }
+        for (int i = 4 * n4 + tid; i < n; i += 256) { sg[i] = gamma[d0 * K + i]; se[i] = elog[d0 * K + i]; so[i] = elog_old[d0 * K + i]; }
     }
     __syncthreads();
-    double acc = 0.0;
-    if (lane < nd) {
-        const float* rg = sg + lane * K; const float* re = se + lane * K; const float* ro = so + lane * K;
-        double g0 = 0.0;
-        for (int k = 0; k < K; ++k) {
-            const double g = (double)rg[k], el = (double)re[k];
-            acc = fma(alpha_new[k] - 1.0, el, acc);                                   // Elogptheta :51 (dot part)
-            acc = fma(g - alpha_prev[k], el - (double)ro[k], acc);                     // Elogpz - Elogqz: the per-document part (see above)
+    const int dl = tid >> 2, q = tid & 3;
+    double acc = 0.0, g0 = 0.0;
+    if (dl < nd) {
+        const float* rg = sg + dl * K; const float* re = se + dl * K; const float* ro = so + dl * K;
+        for (int k = q; k < K; k += 4) {
+            const double g = (double)rg[k];
+            acc = fma(g - alpha_e[k], (double)re[k] - (double)ro[k], acc);             // Elogpz - Elogqz: the per-document part (see above)
             if (K > 1) { double ps, lg; digamma_lgamma_d(g, ps, lg); acc += lg - (g - 1.0) * ps; }   // -Elogqtheta :72 (utils.jl:172-176)
             g0 += g;
         }
-        if (K > 1) { double ps0, lg0; digamma_lgamma_d(g0, ps0, lg0); acc += -lg0 + (g0 - (double)K) * ps0; }
     }
-    if (logz) {                                                  // this block's slice of the chunks' sum c log2 s
-        const int64_t per = (n_logz + gridDim.x - 1) / gridDim.x;
-        const int64_t b = (int64_t)blockIdx.x * per, e = min(n_logz, b + per);
-        double lz = 0.0;
-        for (int64_t i = b + lane; i < e; i += 64) lz += (double)logz[i];
-        acc = fma(lz, 0.6931471805599453, acc);
-    }
+    g0 += __shfl_xor(g0, 1, 64);
+    g0 += __shfl_xor(g0, 2, 64);                                  // the quad's lanes hold sum_k gamma_k
+    if (K > 1 && dl < nd && q == 0) { double ps0, lg0; digamma_lgamma_d(g0, ps0, lg0); acc += -lg0 + (g0 - (double)K) * ps0; }
     acc = wave_sum_d(acc);
-    if (lane == 0) block_val[blockIdx.x] = acc;
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) block_val[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 #define TMVB_REG_ANY_TILES 99   // bucket of register-tile documents with mixed tile counts (lda_estep_reg_any_kernel)
@@ -1165,9 +1163,9 @@ struct tmvb_lda {
     bool want_parts = false;           // set for the coming iteration
     int parts_env = 1;                 // TMVB_LDA_ELBO_PARTS at tmvb_lda_create: 0 never, 1 the iterations train! will check, 2 every E-step
     float* d_logz = nullptr; size_t logz_cap = 0; int64_t n_logz = 0;
-    double* d_alpha_prev = nullptr;    // [K] alpha as the last E-step read it
-    bool logz_valid = false;           // d_logz[0, n_logz) belongs to the last E-step (every statistics pass of it)
-    bool alpha_prev_valid = false;     // d_alpha_prev was saved by the update_alpha! behind that E-step
+    double* d_lz_partial = nullptr;    // [2048] per-block sums of d_logz, by beta_norm_kernel
+    int64_t n_elbo_blocks = 0;         // d_doc_val[0, n_elbo_blocks): lda_elbo_doc_kernel's values, enqueued by that E-step on its side stream
+    bool logz_valid = false;           // d_logz[0, n_logz) and those values belong to the last E-step (every statistics pass of it)
     bool pw_diff = false;              // d_pw_partial holds the (log beta_new - log beta_old) form
     int elbo_form = 0;                 // the last update_elbo!: 1 decomposed, 0 token walk (tmvb_lda_elbo_form)
     bool side_pending = false;         // ev_side marks side-stream work the context's stream has not waited for yet
@@ -1373,7 +1371,7 @@ extern "C" int tmvb_lda_destroy(tmvb_lda* h)
     if (h->ev_side) (void)hipEventDestroy(h->ev_side);
     if (h->ev_chain) (void)hipEventDestroy(h->ev_chain);
     if (h->ev_mark) (void)hipEventDestroy(h->ev_mark);
-    (void)hipFree(h->d_partial_side); (void)hipFree(h->d_pw_partial); (void)hipFree(h->d_logz); (void)hipFree(h->d_alpha_prev);
+    (void)hipFree(h->d_partial_side); (void)hipFree(h->d_pw_partial); (void)hipFree(h->d_logz); (void)hipFree(h->d_lz_partial);
     for (tmvb_inv_index& ix : h->pieces) tmvb_free_inv_index(&ix);
     if (h->ar_index.built) tmvb_free_inv_index(&h->ar_index);
     for (hipEvent_t e : h->ev_slice) if (e) (void)hipEventDestroy(e);
@@ -1504,7 +1502,7 @@ extern "C" int tmvb_lda_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
     TMVB_HIP(hipEventCreateWithFlags(&h->ev_chain, tmvb_event_flags()));
     TMVB_HIP(hipEventCreateWithFlags(&h->ev_mark, hipEventDisableTiming /* may sit behind a collective: keeps the system-scope fence */));
     { const char* e = getenv("TMVB_LDA_ELBO_PARTS"); h->parts_env = e ? atoi(e) : 1; }
-    if ((rc = dmalloc(&h->d_partial_side, (size_t)TMVB_REDUCE_BLOCKS * K)) || (rc = dmalloc(&h->d_pw_partial, 2048)) || (rc = dmalloc(&h->d_alpha_prev, (size_t)K))) return rc;
+    if ((rc = dmalloc(&h->d_partial_side, (size_t)TMVB_REDUCE_BLOCKS * K)) || (rc = dmalloc(&h->d_pw_partial, 2048)) || (rc = dmalloc(&h->d_lz_partial, 2048))) return rc;
     for (int a = 0; a < tmvb_lda::NAUX; ++a) {
         h->aux[a] = tmvb_pool_stream(ctx->device, 1 + a);
         TMVB_REQUIRE(h->aux[a] != nullptr, TMVB_EHIP, "hipStreamCreate failed");
@@ -1530,7 +1528,7 @@ extern "C" int tmvb_lda_set_state(tmvb_lda* h, const double* alpha, const double
                                   const double* elbo)
 {
     TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_lda_set_state: handle is NULL");
-    h->mark_valid = false; h->esum_fresh = false; h->esum_side = false; h->pw_valid = false; h->stats_fresh = false; h->logz_valid = false; h->alpha_prev_valid = false;
+    h->mark_valid = false; h->esum_fresh = false; h->esum_side = false; h->pw_valid = false; h->stats_fresh = false; h->logz_valid = false;
     tmvb_ctx* ctx = h->ctx;
     TMVB_HIP(hipSetDevice(ctx->device));
     { int jrc = lda_join_side(h); if (jrc) return jrc; }
@@ -1603,7 +1601,7 @@ extern "C" int tmvb_lda_estep(tmvb_lda* h, int32_t viter, double vtol)
         for (int a = 0; a < tmvb_lda::NAUX; ++a) if (h->aux[a]) (void)hipStreamSynchronize(h->aux[a]);
         (void)hipStreamSynchronize(h->ctx->stream);
         (void)hipGetLastError();
-        h->side_pending = false; h->esum_fresh = false; h->esum_side = false; h->stats_fresh = false; h->pw_valid = false; h->mark_valid = false; h->logz_valid = false; h->alpha_prev_valid = false;
+        h->side_pending = false; h->esum_fresh = false; h->esum_side = false; h->stats_fresh = false; h->pw_valid = false; h->mark_valid = false; h->logz_valid = false;
         tmvb_set_error("%s", msg.c_str());
     }
     return rc;
@@ -1682,7 +1680,7 @@ static int lda_estep_impl(tmvb_lda* h, int32_t viter, double vtol)
             h->logz_cap = need;
         }
     }
-    h->logz_valid = false; h->alpha_prev_valid = false; h->pw_diff = false;
+    h->logz_valid = false; h->pw_diff = false;
     auto with_logz = [&](TermStatsParams t, int q) { t.logz = collect ? h->d_logz + logz_off[(size_t)q] : nullptr; return t; };
     // Round 5: the passes before the last accumulate in order in d_stats on aux[0]; the LAST pass, on the context's stream behind the last document
     // kernel, used to wait for them (round 4's timeline: last document kernel done at 589 us, pass 2 + its combine at 625 us, one cross-queue hop, last
@@ -1816,6 +1814,14 @@ static int lda_estep_impl(tmvb_lda* h, int32_t viter, double vtol)
         // lengthens it: period 186.8 us against 178.9 (timelines of run r4ag).  Stream priorities for the chain changed nothing either.)
         int rc = tmvb_colsum(ctx, h->nslot, h->K, h->d_elog, h->M, h->d_partial_side, h->d_esum, h->d_stats + (size_t)h->K * h->V, side);
         if (rc) return rc;
+        if (collect && h->M > 0) {        // update_elbo!'s per-document half, here: it needs the document kernels' output and the alpha they read, nothing else
+            const unsigned nblk = (unsigned)((h->M + 63) / 64);
+            const size_t lds = (size_t)3 * 64 * (size_t)h->K * sizeof(float);
+            if (lds > 48 * 1024) TMVB_HIP(hipFuncSetAttribute((const void*)lda_elbo_doc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(lda_elbo_doc_kernel, dim3(nblk), dim3(256), lds, side, h->K, h->M, h->d_alpha_d, h->d_gamma, h->d_elog, h->d_elog_old, h->d_doc_val);
+            TMVB_HIP(hipGetLastError());
+            h->n_elbo_blocks = nblk;
+        }
         TMVB_HIP(hipEventRecord(h->ev_side, side));
         h->side_pending = true;
         h->esum_fresh = true; h->esum_side = true;
@@ -2034,7 +2040,8 @@ extern "C" int tmvb_lda_update_beta(tmvb_lda* h)
     const bool parts = h->logz_valid && h->stats_fresh;     // the coming update_elbo! is the decomposed one: leave sum S (log beta_new - log beta_old)
     hipLaunchKernelGGL(beta_norm_kernel, dim3(nb), dim3(256), (size_t)h->K * sizeof(double), ctx->stream,
                        h->d_stats, h->d_rowsum, h->d_beta[h->cur ^ 1], h->K, h->KP, h->V, h->d_pw_partial, TMVB_EPS_F,
-                       parts ? (const float*)h->d_beta[h->cur] : (const float*)nullptr);
+                       parts ? (const float*)h->d_beta[h->cur] : (const float*)nullptr, -1.0f,
+                       parts ? (const float*)h->d_logz : (const float*)nullptr, h->n_logz, h->d_lz_partial);
     TMVB_HIP(hipGetLastError());
     h->pw_blocks = nb;
     h->pw_diff = parts;
@@ -2064,10 +2071,6 @@ extern "C" int tmvb_lda_update_alpha(tmvb_lda* h, int32_t niter, double ntol)
         TMVB_HIP(hipStreamWaitEvent(side, h->ev_mark, 0));
     }
     h->mark_valid = false;
-    if (h->logz_valid && !h->alpha_prev_valid) {            // the alpha the E-step read: gamma - alpha is sum_n c_n phi_n (lda_elbo_doc_kernel)
-        TMVB_HIP(hipMemcpyAsync(h->d_alpha_prev, h->d_alpha_d, (size_t)h->K * sizeof(double), hipMemcpyDeviceToDevice, side));
-        h->alpha_prev_valid = true;
-    }
     int rc = dispatch_nslot(h->nslot, [&](auto ns) -> int {
         constexpr int NS = decltype(ns)::value;
         hipLaunchKernelGGL((lda_alpha_kernel<NS>), dim3(1), dim3(64), 0, side, h->K, (double)h->M_total, h->d_esum, ef,
@@ -2092,15 +2095,11 @@ static int lda_elbo_enqueue(tmvb_lda* h)
     bool use_pw = false;
     int64_t n_vals = 0;
     h->elbo_form = 0;
-    if (h->M > 0 && h->logz_valid && h->alpha_prev_valid && h->pw_valid && h->pw_diff) {
-        // the decomposed form: everything per token was left behind by the iteration's own statistics passes and update_beta!
-        const unsigned nblk = (unsigned)((h->M + 63) / 64);
-        const size_t lds = (size_t)3 * 64 * (size_t)h->K * sizeof(float);
-        if (lds > 48 * 1024) TMVB_HIP(hipFuncSetAttribute((const void*)lda_elbo_doc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(lda_elbo_doc_kernel, dim3(nblk), dim3(64), lds, ctx->stream, h->K, h->M, h->d_alpha_d, h->d_alpha_prev, h->d_gamma, h->d_elog,
-                           h->d_elog_old, h->d_logz, h->n_logz, h->d_doc_val);
-        TMVB_HIP(hipGetLastError());
-        use_pw = true; n_vals = nblk;
+    const bool parts = h->M > 0 && h->logz_valid && h->pw_valid && h->pw_diff;
+    if (parts) {
+        // the decomposed form: the per-document values were enqueued by the E-step itself (side stream: joined above), everything per token was left
+        // behind by its statistics passes and by update_beta!
+        use_pw = true; n_vals = h->n_elbo_blocks;
         h->elbo_form = 1;
     } else if (h->M > 0 && h->reg_path && getenv("TMVB_LDA_ELBO_LEGACY") == nullptr) {
         const dim3 grid((unsigned)h->M), block(64);
@@ -2133,7 +2132,8 @@ static int lda_elbo_enqueue(tmvb_lda* h)
     }
     hipLaunchKernelGGL(lda_elbo_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, h->d_doc_val, h->M, h->K, h->d_alpha_d, h->d_elbo,
                        use_pw ? h->d_pw_partial : (const double*)nullptr, h->pw_blocks,
-                       h->distributed && h->M_total > 0 ? (double)h->M / (double)h->M_total : 1.0, n_vals);
+                       h->distributed && h->M_total > 0 ? (double)h->M / (double)h->M_total : 1.0, n_vals,
+                       parts ? h->d_esum : (const double*)nullptr, parts ? h->d_lz_partial : (const double*)nullptr);
     TMVB_HIP(hipGetLastError());
     return TMVB_OK;
 }
