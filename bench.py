@@ -182,6 +182,10 @@ def slim_line(result):
     pl = result.get("elbo_plateau")
     if pl:
         out["elbo_plateau"] = {k: pl.get(k) for k in ("reached", "seconds", "iterations", "elbo_first", "elbo_last", "last_delta")}
+        if pl.get("seconds_per_checked_iteration") is not None:      # train! checks after every iteration (checkelbo = 1): what one such iteration costs
+            out["elbo_plateau"]["ms_per_checked_iteration"] = round(1e3 * pl["seconds_per_checked_iteration"], 4)
+        if pl.get("elbo_form") is not None:
+            out["elbo_plateau"]["elbo_form"] = pl["elbo_form"]
     mg = result.get("multi_gpu_check")
     if mg:
         out["multi_gpu_check"] = {k: mg[k] for k in ("pass", "iterations", "globals_hash_equal", "elbo_rel_vs_n1", "elbo_rel_tolerance", "form", "fallback", "skipped",
@@ -665,6 +669,7 @@ def main():
                     "stop_rule": "delta_elbo < tol=1.0, signed (check_elbo!, src/modelutils.jl:574-585), checkelbo=1",
                     "last_delta": last_delta, "elbo_first": traj_all[0], "elbo_last": traj_all[-1],
                     "seconds_per_checked_iteration": t_plateau / max(n, 1),
+                    "elbo_form": ("decomposed" if eng2.model.elbo_form() == 1 else "token walk"),     # tmvb_lda_elbo_form of the last check
                     "elbo_vs_wallclock": [[round(stamps[i], 4), traj_all[i]] for i in idx],
                     "note": "wall clock includes one update_elbo! per iteration; timestamps are interpolated inside chunks of 50 iterations"}
         if comm2 is not None:
