@@ -7,12 +7,16 @@ kernel instead of a second walk over the corpus.  Both forms evaluate the refere
 fp32 rounding and each with the fp64 oracle inside the frozen tolerance, on every kernel path (statistics-pass instantiations by
 K, one pass and pipelined pieces, train! and the stepwise operators).
 """
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
 from tol import within
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
 def _pair(tmvb, oracle, pc, K, beta0):
@@ -105,3 +109,26 @@ def test_unchecked_iterations_collect_nothing(tmvb):
     assert g.elbo_form() == 0
     g.train(iter=3, tol=0.0, checkelbo=3, printelbo=False)      # only the third iteration is checked
     assert g.elbo_form() == 1
+
+
+@pytest.mark.parametrize("name", ["lda_m40_v60_k7", "lda_m30_v50_k70_empty"])
+def test_golden_fixtures_with_empty_documents_and_unused_terms(tmvb, oracle, monkeypatch, name):
+    """Empty documents (gamma = alpha, no postings) and vocabulary entries no document uses (S = 0 meets log beta_old) in the decomposed form; and
+    viter = 0 (the E-step leaves no responsibilities behind: the token walk has to take over)."""
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    g = {k: z[k] for k in z.files}
+    K, V = int(g["K"]), int(g["V"])
+    monkeypatch.setenv("TMVB_LDA_ELBO_PARTS", "2")
+    pc = tmvb.PackedCorpus(g["doc_ptr"], g["terms"], g["counts"], V)
+    gm, om = _pair(tmvb, oracle, pc, K, g["beta0"])
+    for it in range(3):
+        _force(gm, om)
+        om.estep(viter=3, vtol=0.0); om.update_beta(); om.update_alpha(); e_o = om.update_elbo()
+        gm.estep(viter=3, vtol=0.0); gm.reduce_docs(); gm.update_beta(); gm.update_alpha(); e_g = gm.update_elbo()
+        assert gm.elbo_form() == 1
+        within("lda.elbo_rel_step", abs(e_g - e_o) / abs(e_o), (name, it, e_g, e_o))
+    _force(gm, om)
+    om.estep(viter=0, vtol=0.0); om.update_beta(); om.update_alpha(); e_o = om.update_elbo()
+    gm.estep(viter=0, vtol=0.0); gm.reduce_docs(); gm.update_beta(); gm.update_alpha(); e_g = gm.update_elbo()
+    assert gm.elbo_form() == 0
+    assert np.isfinite(e_g)

@@ -562,13 +562,22 @@ static inline int tmvb_launch_termstats2(tmvb_ctx* ctx, int nslot, int KP, const
     const bool pad = tp0.estride >= 4 * lanes && tp1.estride == tp0.estride && nd < (1 << 24) && (uint64_t)nd * (uint64_t)tp0.estride * 4u < (1ull << 32) &&
                      !(getenv("TMVB_STATS_PAD") && atoi(getenv("TMVB_STATS_PAD")) == 0);
     const int cpl = tmvb_termstats_cpl(lpr);
-    if (lpr == 13 && pad && cpl == 2) hipLaunchKernelGGL((termstats_recompute2_kernel<13, 8, true, 2>), grid, block, 0, st, tp0, tp1, lpr);
-    else if (lpr == 13 && pad && cpl == 4) hipLaunchKernelGGL((termstats_recompute2_kernel<13, 4, true, 4>), grid, block, 0, st, tp0, tp1, lpr);
-    else if (lpr == 13 && pad) hipLaunchKernelGGL((termstats_recompute2_kernel<13, 16, true>), grid, block, 0, st, tp0, tp1, lpr);
-    else if (lpr == 13) hipLaunchKernelGGL((termstats_recompute2_kernel<13, 16>), grid, block, 0, st, tp0, tp1, lpr);
-    else if (lpr == 25) hipLaunchKernelGGL((termstats_recompute2_kernel<25, 32>), grid, block, 0, st, tp0, tp1, lpr);
-    else if (lpr <= 16) hipLaunchKernelGGL((termstats_recompute2_kernel<0, 16>), grid, block, 0, st, tp0, tp1, lpr);
-    else hipLaunchKernelGGL((termstats_recompute2_kernel<0, 32>), grid, block, 0, st, tp0, tp1, lpr);
+    TMVB_REQUIRE((tp0.logz == nullptr) == (tp1.logz == nullptr), TMVB_EINVAL, "statistics pass pair: log-normaliser sums for both indices or for neither");
+#ifdef TMVB_TS_LOGZ
+#define TS2(LPRV, LANESV, PADV, CPLV) do { if (tp0.logz) hipLaunchKernelGGL((termstats_recompute2_kernel<LPRV, LANESV, PADV, CPLV, true>), grid, block, 0, st, tp0, tp1, lpr); \
+                                           else hipLaunchKernelGGL((termstats_recompute2_kernel<LPRV, LANESV, PADV, CPLV, false>), grid, block, 0, st, tp0, tp1, lpr); } while (0)
+#else
+#define TS2(LPRV, LANESV, PADV, CPLV) do { TMVB_REQUIRE(tp0.logz == nullptr, TMVB_EINVAL, "statistics pass pair: no log-normaliser form in this translation unit"); \
+                                           hipLaunchKernelGGL((termstats_recompute2_kernel<LPRV, LANESV, PADV, CPLV, false>), grid, block, 0, st, tp0, tp1, lpr); } while (0)
+#endif
+    if (lpr == 13 && pad && cpl == 2) TS2(13, 8, true, 2);
+    else if (lpr == 13 && pad && cpl == 4) TS2(13, 4, true, 4);
+    else if (lpr == 13 && pad) TS2(13, 16, true, 1);
+    else if (lpr == 13) TS2(13, 16, false, 1);
+    else if (lpr == 25) TS2(25, 32, false, 1);
+    else if (lpr <= 16) TS2(0, 16, false, 1);
+    else TS2(0, 32, false, 1);
+#undef TS2
     TMVB_HIP(hipGetLastError());
     const int64_t nm = std::max(ix0.n_multi, ix1.n_multi);
     if (nm > 0) {

@@ -17,6 +17,7 @@
 // its reader rows; 2 fp32 digammas per topic per sweep instead of K (N_d + 2 R_d).
 // The scatters update_alef!(d) / update_he!(d) are gather-side statistics passes over the term and
 // the reader inverted indices (tmvb_termstats.h); HBM-bound like LDA.
+#define TMVB_TS_LOGZ 1            // the log-normaliser forms of the statistics pass (decomposed update_elbo!, ctpf_elbo_doc_parts_kernel)
 #include "tmvb_common_kernels.h"
 
 // xi's rate is `log vav` (src/CTPF.jl:336).  -DTMVB_MUTANT_CTPF_LOG_BET (tests/test_mutants_gpu.py, never in a shipped build) stores log bet in its place --
@@ -57,6 +58,8 @@ struct CtpfParams {
     int viter;
     float vtol;
     int store_w;                // KP > 128: the statistics passes read stored weights instead of recomputing them
+    float* shift = nullptr;     // [M][2] or NULL: the softmax shifts (max of the phi arguments, max of the xi arguments) behind E1 / E2 of the last executed
+                                // sweep -- the decomposed update_elbo! needs log of the UNSHIFTED normalisers (ctpf_elbo_doc_parts_kernel)
 };
 
 // NS = topic slots per lane (lane l owns topics l, l + 64, ...): NS = 1 for K <= 64, NS = 2 for K <= 128.
@@ -163,6 +166,7 @@ __global__ __launch_bounds__(64) void ctpf_estep_kernel(CtpfParams p, int64_t fi
     };
 
     int sweeps = 0;
+    float mx_last = 0.f, mab_last = 0.f;                 // CtpfParams::shift
     for (int v = 0; v < p.viter; ++v) {
         ++sweeps;
         float x[NS], a[NS], b[NS], mxl = -INFINITY, mabl = -INFINITY;
@@ -175,6 +179,7 @@ __global__ __launch_bounds__(64) void ctpf_estep_kernel(CtpfParams p, int64_t fi
         }
         const float mx = wave_max(mxl);
         const float mab = wave_max(mabl);
+        mx_last = mx; mab_last = mab;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             e[s] = on[s] ? expf(x[s] - mx) : 0.f;
@@ -242,6 +247,7 @@ __global__ __launch_bounds__(64) void ctpf_estep_kernel(CtpfParams p, int64_t fi
             if (on[s]) { p.E1[(int64_t)d * p.estride + i] = 0.f; p.E2[(int64_t)d * p.estride + i] = 0.f; }   // viter = 0
         }
     }
+    if (p.shift && lane == 0) { p.shift[2 * (int64_t)d] = mx_last; p.shift[2 * (int64_t)d + 1] = mab_last; }
     if (p.estride >= KP)                                                                        // dense rows (KP / 4 > 64) have no pads
         for (int i = K + lane; i < KP; i += 64) { p.E1[(int64_t)d * p.estride + i] = 0.f; p.E2[(int64_t)d * p.estride + i] = 0.f; }   // pads
     if (sweeps > 0 && single) {
@@ -314,6 +320,7 @@ __device__ __forceinline__ void ctpf_estep_reg_body(const CtpfParams& p, const i
     float gim = on ? p.gimel[(int64_t)d * K + mt] : 1.0f, zay = on ? p.zayin[(int64_t)d * K + mt] : 1.0f;
     float gim_old = gim, zay_old = zay;
     float e[1] = {0.f}, f[1] = {0.f}, ea = 0.f, eb = 0.f;
+    float mx_last = 0.f, mab_last = 0.f;                 // CtpfParams::shift
 
     int sweeps = 0;
     for (int v = 0; v < p.viter; ++v) {
@@ -323,6 +330,7 @@ __device__ __forceinline__ void ctpf_estep_reg_body(const CtpfParams& p, const i
         const float a = dg - ld - lv, b = dz - lh - lv;   // update_xi!  :336
         const float mx = wave_max(on ? x : -INFINITY);
         const float mab = wave_max(on ? fmaxf(a, b) : -INFINITY);
+        mx_last = mx; mab_last = mab;
         e[0] = on ? fast_exp(x - mx) : 0.f;
         ea = on ? fast_exp(a - mab) : 0.f;
         eb = on ? fast_exp(b - mab) : 0.f;
@@ -391,7 +399,10 @@ __device__ __forceinline__ void ctpf_estep_reg_body(const CtpfParams& p, const i
     } else {
         if (mine) { p.E1[(int64_t)d * p.estride + mytopic] = 0.f; p.E2[(int64_t)d * p.estride + mytopic] = 0.f; }   // viter = 0
     }
-    if (lane == 0) p.sweeps[d] = (uint8_t)min(sweeps, 255);
+    if (lane == 0) {
+        p.sweeps[d] = (uint8_t)min(sweeps, 255);
+        if (p.shift) { p.shift[2 * (int64_t)d] = mx_last; p.shift[2 * (int64_t)d + 1] = mab_last; }
+    }
 }
 
 template <int LPR, int T>
@@ -540,7 +551,10 @@ __device__ __forceinline__ void ctpf_estep_grid_body(const CtpfParams& p, const 
         } else {
             if (mine) { p.E1[(int64_t)d * p.estride + mytopic] = 0.f; p.E2[(int64_t)d * p.estride + mytopic] = 0.f; }   // viter = 0
         }
-        if (lane == 0) p.sweeps[d] = (uint8_t)min(sweeps, 255);
+        if (lane == 0) {
+            p.sweeps[d] = (uint8_t)min(sweeps, 255);
+            if (p.shift) { p.shift[2 * (int64_t)d] = mx; p.shift[2 * (int64_t)d + 1] = mab; }
+        }
     }
 }
 
@@ -1162,10 +1176,16 @@ __global__ __launch_bounds__(64) void ctpf_elbo_doc_fast_kernel(int K, int KP, c
 // global part over the entries of a K x n shape matrix X with rate vector `rate`:
 //   sum [ (prior_shape - 1)(psi(x) - log rate_i) - prior_rate x / rate_i + entropy(Gamma(x, 1/rate_i)) ]
 // (Elogpbeta - Elogqbeta :144-150,:198-204 with (a, b, alef, bet); Elogpeta - Elogqeta :162-168,:216-222 with (e, f, he, vav))
+// X_old (or NULL; the decomposed update_elbo!): + sum (x - prior_shape)(psi(x) - psi(x_old)) -- after the M-step x - prior_shape IS the statistics entry
+// sum_entries val * responsibility, so this is the entries' sum of val * sum_i phi_i (psi(X[i, id]) - psi(X_old[i, id])) without walking them.
+// all_rates / lrates_d (or NULL): block 0 also leaves the logarithms of the eight rate vectors for the per-document kernel behind it.
 __global__ __launch_bounds__(256) void ctpf_elbo_global_kernel(const float* __restrict__ X, int64_t n_ids, int K, const double* __restrict__ rate,
-                                                               double ps, double pr, double* __restrict__ partial)
+                                                               double ps, double pr, double* __restrict__ partial, const float* __restrict__ X_old = nullptr,
+                                                               const double* __restrict__ all_rates = nullptr, double* __restrict__ lrates_d = nullptr)
 {
     __shared__ double red[256];
+    if (lrates_d != nullptr && blockIdx.x == 0)
+        for (int q = threadIdx.x; q < 8 * K; q += blockDim.x) lrates_d[q] = log(all_rates[q]);
     double s = 0.0;
     const int64_t total = n_ids * K;
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
@@ -1174,6 +1194,7 @@ __global__ __launch_bounds__(256) void ctpf_elbo_global_kernel(const float* __re
         double psi, lg;
         digamma_lgamma_d(x, psi, lg);
         s += (ps - 1.0) * (psi - lr) - pr * x * tmvb_rcp_d(r) + (x - lr + lg + (1.0 - x) * psi);
+        if (X_old) s += (x - ps) * (psi - digamma_shift8_d((double)X_old[q]));
     }
     red[threadIdx.x] = s;
     __syncthreads();
@@ -1217,6 +1238,84 @@ __global__ __launch_bounds__(1024) void ctpf_elbo_final2_kernel(const double* __
     if (threadIdx.x == 0) { out[0] = red[0][0]; out[1] = red[1][0] + constant; }
 }
 
+// ---- the decomposed update_elbo! (round 5), as LDA's and CTM's (tmvb_lda.hip: lda_elbo_doc_kernel) -----------------------------------------------
+// After the cancellation above a term entry contributes  c [ sum_i phi_i (lt_i - log bet_i + psi(alef[i, t])) - sum_i phi_i log phi_i ] - lgamma(c + 1)  with
+// phi_i = TA_old[t][i] e_i / s_n, log(TA_old e_i) = psi(alef_old[i, t]) + x_i - mx (x = the sweep's softmax argument from gimel_old and the OLD rates, mx its
+// shift), and a reader entry the same over the 2 K components of xi.  Summed over a document's entries, with sum_n c_n phi_in + sum_u r_u xi_iu = gimel_i - c
+// and sum_u r_u xi_{K+i,u} = zayin_i - g (update_gimel! / update_zayin!, src/CTPF.jl:313, :322):
+//     per document   sum_i (gimel_i - c)(psi(gimel_i) - psi(gimel_old_i) - log dalet_i + log dalet_old_i)
+//                  + sum_i (zayin_i - g)(psi(zayin_i) - psi(zayin_old_i) - log het_i + log het_old_i - log vav_i + log vav_old_i)
+//                  + C_d mx + R_d mab                                       (the shifts the E-step kernel left in CtpfParams::shift; C_d, R_d = sums of counts / ratings)
+//     per chunk      sum c log s_n, sum r log s_u                            (the statistics passes' log-normaliser sums, TermStatsParams::logz)
+//     global         sum (alef - a)(psi(alef) - psi(alef_old)) + the same for he                          (ctpf_elbo_global_kernel)
+//                  - sum_i (log bet_i - log bet_old_i) PC_i - sum_i (log vav_i - log vav_old_i) PA_i      (ctpf_elbo_final_parts_kernel)
+//                    with PC_i = sum_d sum_n c phi = rowsum(alef)_i - V a  and  PA_i = sum_d (gimel_di - c) - PC_i  -- the split of gimel - c into its
+//                    term and reader halves is only needed summed over the documents, where the M-step has it.
+// No entry is walked: the two table kernels and the entry sums of ctpf_elbo_doc_fast_kernel (70 of its 109 us on SYN-CITEU) go away.
+template <int NS>
+__global__ __launch_bounds__(64) void ctpf_elbo_doc_parts_kernel(int K, const double* __restrict__ rates /* [8][K] */, const double* __restrict__ lrates_d,
+                                                                 const double* __restrict__ rs_alef, const double* __restrict__ rs_he,
+                                                                 const float* __restrict__ gimel, const float* __restrict__ gimel_old,
+                                                                 const float* __restrict__ zayin, const float* __restrict__ zayin_old,
+                                                                 const double* __restrict__ lg_doc, const double* __restrict__ crd /* [M][2] */,
+                                                                 const float* __restrict__ shift /* [M][2] */,
+                                                                 double hc, double hd, double hg, double hh, double doc_const, double* __restrict__ doc_val)
+{
+    const int lane = threadIdx.x;
+    const int d = blockIdx.x;
+    double acc = 0.0;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const bool on = lane + 64 * s < K;
+        const int i = on ? lane + 64 * s : 0;
+        const double bet = rates[i], vav = rates[K + i], dalet = rates[2 * K + i], het = rates[3 * K + i];
+        const double l_vav = lrates_d[K + i], l_dalet = lrates_d[2 * K + i], l_het = lrates_d[3 * K + i];
+        const double l_vav_o = lrates_d[5 * K + i], l_dalet_o = lrates_d[6 * K + i], l_het_o = lrates_d[7 * K + i];
+        const double gi = on ? (double)gimel[(int64_t)d * K + i] : 1.0, za = on ? (double)zayin[(int64_t)d * K + i] : 1.0;
+        const double gio = on ? (double)gimel_old[(int64_t)d * K + i] : 1.0, zao = on ? (double)zayin_old[(int64_t)d * K + i] : 1.0;
+        const double dgo = digamma_shift8_d(gio), dzo = digamma_shift8_d(zao);
+        double psi_g, lg_g, psi_z, lg_z;
+        digamma_lgamma_d(gi, psi_g, lg_g);
+        digamma_lgamma_d(za, psi_z, lg_z);
+        if (on) {
+            const double r_dalet = tmvb_rcp_d(dalet), r_het = tmvb_rcp_d(het), r_vav = tmvb_rcp_d(vav), r_bet = tmvb_rcp_d(bet);
+            acc -= (gi * r_dalet * r_vav + za * r_het * r_vav) * rs_he[i] + gi * r_dalet * r_bet * rs_alef[i];   // :112,:123,:134
+            acc += (hc - 1.0) * (psi_g - l_dalet) - hd * gi * r_dalet;            // Elogptheta :156
+            acc += (hg - 1.0) * (psi_z - l_het) - hh * za * r_het;                // Elogpepsilon :174
+            acc += (gi - l_dalet + lg_g + (1.0 - gi) * psi_g) + (za - l_het + lg_z + (1.0 - za) * psi_z);   // -Elogqtheta, -Elogqepsilon: Gamma entropies
+            acc += (gi - hc) * ((psi_g - dgo) - (l_dalet - l_dalet_o));           // the entries' per-document share (see above)
+            acc += (za - hg) * ((psi_z - dzo) - (l_het - l_het_o) - (l_vav - l_vav_o));
+        }
+    }
+    double tot = wave_sum_d(acc);
+    tot += doc_const - lg_doc[d] + crd[2 * (int64_t)d] * (double)shift[2 * (int64_t)d] + crd[2 * (int64_t)d + 1] * (double)shift[2 * (int64_t)d + 1];
+    if (lane == 0) doc_val[d] = tot;
+}
+
+// out[0] = sum doc_val + ln 2 * sum logz (the documents' part), out[1] = sum partial + constant - sum_i (dlog bet_i PC_i + dlog vav_i PA_i) (the global part)
+__global__ __launch_bounds__(1024) void ctpf_elbo_final_parts_kernel(const double* __restrict__ doc_val, int64_t M, const double* __restrict__ partial, int npartial,
+                                                                     double constant, const float* __restrict__ logz, int64_t n_logz,
+                                                                     const double* __restrict__ lrates_d, const double* __restrict__ rs_alef,
+                                                                     const double* __restrict__ sum_g, int K, double Va, double Mc, double* __restrict__ out)
+{
+    __shared__ double red[2][1024];
+    double s = 0.0, g = 0.0, lz = 0.0;
+    for (int64_t d = threadIdx.x; d < M; d += 1024) s += doc_val[d];
+    for (int64_t i = threadIdx.x; i < n_logz; i += 1024) lz += (double)logz[i];
+    for (int q = threadIdx.x; q < npartial; q += 1024) g += partial[q];
+    for (int i = threadIdx.x; i < K; i += 1024) {
+        const double pc = rs_alef[i] - Va, pa = (sum_g[i] - Mc) - pc;
+        g -= (lrates_d[i] - lrates_d[4 * K + i]) * pc + (lrates_d[K + i] - lrates_d[5 * K + i]) * pa;
+    }
+    red[0][threadIdx.x] = s + 0.6931471805599453 * lz; red[1][threadIdx.x] = g;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = red[0][0]; out[1] = red[1][0] + constant; }
+}
+
 // ------------------------------------------------------------------------------ host side
 struct tmvb_ctpf {
     tmvb_ctx* ctx = nullptr;
@@ -1233,6 +1332,10 @@ struct tmvb_ctpf {
     double* d_rates = nullptr; float* d_lrates = nullptr;          // [8][K], [4][K]
     double* d_lrates_d = nullptr;                                  // [8][K] log(rates) in fp64 for update_elbo! (filled per call)
     bool rs_fresh = false;                                         // d_rs_alef / d_rs_he are the row sums of the current alef / he
+    // decomposed update_elbo! (ctpf_elbo_doc_parts_kernel): TMVB_CTPF_ELBO_PARTS at creation -- 1 (default) the iterations train! will check, 2 every E-step,
+    // 0 never.  A collecting E-step leaves the softmax shifts (d_shift) and the statistics passes' log-normaliser sums (d_logz: term chunks, then reader chunks).
+    int parts_env = 1; bool want_parts = false; bool logz_valid = false; int msteps_after = 0; int elbo_form = 0;
+    float* d_shift = nullptr; float* d_logz = nullptr; int64_t n_logz = 0; double* d_crd = nullptr;
     unsigned int* d_mstep_counter = nullptr;                        // last-block-done counter of the fused M-step (zero between launches)
     bool docs_pending = false;                                     // tmvb_ctpf_reduce_docs was asked for and deferred into the fused M-step (K <= 64, one context)
     float* d_gimel = nullptr; float* d_gimel_old = nullptr; float* d_zayin = nullptr; float* d_zayin_old = nullptr;

@@ -233,7 +233,7 @@ __device__ __forceinline__ void termstats_recompute_cpl_body(const TermStatsPara
                 if (LANES >= 16) part += dpp_f<0x140>(part);          // every lane of the slot holds s_n - keps
                 float wz = __builtin_bit_cast(float, dw[u].y) * __builtin_amdgcn_rcpf(part + p.keps);
                 wz = (k0 + u * SLOTS + rs < cnt) ? wz : 0.0f;
-                if constexpr (LOGZ) ll = fmaf(__builtin_bit_cast(float, dw[u].y), __builtin_amdgcn_logf(part + p.keps), ll);   // a slot past the end: value 0, s > 0
+                if constexpr (LOGZ) ll += (k0 + u * SLOTS + rs < cnt) ? __builtin_bit_cast(float, dw[u].y) * __builtin_amdgcn_logf(part + p.keps) : 0.0f;
                 const v2f w2 = v2f{wz, wz};
 #pragma unroll
                 for (int q = 0; q < CPL; ++q) {
@@ -390,7 +390,7 @@ __device__ __forceinline__ void termstats_recompute_body(const TermStatsParams& 
                     }
                     float wz = __builtin_bit_cast(float, dw[u].y) * __builtin_amdgcn_rcpf(part + p.keps);
                     wz = (k0 + u * SLOTS + rs < cnt) ? wz : 0.0f;
-                    if constexpr (LOGZ) ll = fmaf(__builtin_bit_cast(float, dw[u].y), __builtin_amdgcn_logf(part + p.keps), ll);   // a slot past the end: value 0, s > 0
+                    if constexpr (LOGZ) ll += (k0 + u * SLOTS + rs < cnt) ? __builtin_bit_cast(float, dw[u].y) * __builtin_amdgcn_logf(part + p.keps) : 0.0f;
                     const v2f w2 = v2f{wz, wz};
                     alo = __builtin_elementwise_fma(w2, elo, alo);
                     ahi = __builtin_elementwise_fma(w2, ehi, ahi);
@@ -481,11 +481,11 @@ __global__ __launch_bounds__(256) void termstats_recompute_kernel(TermStatsParam
 }
 // Two independent passes (CTPF: the term index and the reader index) in ONE launch, blockIdx.y selects the pass: run on two streams
 // they cost a ~19 us cross-stream join in a 0.3 ms iteration.
-template <int LPR_T, int LANES, bool PAD = false, int CPL = 1>
+template <int LPR_T, int LANES, bool PAD = false, int CPL = 1, bool LOGZ = false>
 __global__ __launch_bounds__(256) void termstats_recompute2_kernel(TermStatsParams p0, TermStatsParams p1, int LPR_rt)
 {
-    if (blockIdx.y == 0) termstats_recompute_body<LPR_T, LANES, PAD, CPL>(p0, LPR_rt);
-    else termstats_recompute_body<LPR_T, LANES, PAD, CPL>(p1, LPR_rt);
+    if (blockIdx.y == 0) termstats_recompute_body<LPR_T, LANES, PAD, CPL, LOGZ>(p0, LPR_rt);
+    else termstats_recompute_body<LPR_T, LANES, PAD, CPL, LOGZ>(p1, LPR_rt);
 }
 
 // ids whose tokens span several chunks: one workgroup per id, its 4 waves sum interleaved partial
