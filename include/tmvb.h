@@ -441,6 +441,11 @@ int tmvb_ctpf_mstep(tmvb_ctpf* h);
  * entropies cancel identically in :243 and are not evaluated.  _parts returns the per-document part (sum over this
  * context's documents) and the global (beta, eta) part separately for document-sharded hosts. */
 int tmvb_ctpf_update_elbo(tmvb_ctpf* h, double* elbo);
+/* As tmvb_lda_elbo_form: *form = 1 if the last update_elbo! took the decomposed form -- no entry (token / reader) is walked: the checked iteration's document
+ * kernels left their softmax shifts, its statistics passes sum_n c_n log s_n per postings chunk, and the entries' remaining terms are sums the M-step already
+ * has (sum (alef - a)(psi(alef) - psi(alef_old)), the row sums of alef, sum_d gimel_d); *form = 0 the table form (any state).  Every iteration tmvb_ctpf_train
+ * checks on an unsharded handle takes it (K <= 124, viter > 0); TMVB_CTPF_ELBO_PARTS=2 at tmvb_ctpf_create: the stepwise operators too, =0: never. */
+int tmvb_ctpf_elbo_form(tmvb_ctpf* h, int32_t* form);
 int tmvb_ctpf_update_elbo_parts(tmvb_ctpf* h, double* doc_part, double* global_part);
 /* train! (src/gpuCTPF.jl:677-705 signature, src/CTPF.jl:344-376 semantics).  checkelbo <= 0 means Inf.
  * elbo_baseline / communicator as for LDA (the per-document ELBO part is all-reduced, the global part added once). */

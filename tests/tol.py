@@ -53,6 +53,7 @@ _T = {
     "ctpf.shape_rel_bigk":      (0.005, 0.000965),
     "ctpf.rates_rel":           (0.0003, 5.61e-05),
     "ctpf.elbo_rel_step":       (5e-07, 8.43e-08),
+    "ctpf.elbo_forms_rel":      (5e-07, 9.54e-08),     # decomposed update_elbo! against the table form on the same device state (tests/test_ctpf_elbo_parts_gpu.py)
     "ctpf.long.shape_rel":      (0.0001, 1.11e-05),
     "ctpf.long.rates_rel":      (3e-06, 4.75e-07),
     "ctpf.elbo_rel_free":       (0.0001, 2.72e-05),

@@ -65,13 +65,15 @@ def ctm(K=50, parts="2"):
     gm.close()
 
 
-def ctpf(K=50):
+def ctpf(K=50, parts="2"):
+    os.environ["TMVB_CTPF_ELBO_PARTS"] = parts
     pc = tm.syn_citeu()
     gm = tm.gpuCTPF(pc, K)
+    del os.environ["TMVB_CTPF_ELBO_PARTS"]
 
     def it():
         gm.estep(); gm.reduce_docs(); gm.mstep()
-    measure(f"ctpf K={K}", gm, it, burnin=50, n=50)
+    measure(f"ctpf K={K} TMVB_CTPF_ELBO_PARTS={parts}", gm, it, burnin=50, n=50)
     gm.close()
 
 
@@ -84,4 +86,4 @@ if __name__ == "__main__":
     if "ctm" in which:
         ctm(parts="2"); ctm(parts="0")
     if "ctpf" in which:
-        ctpf()
+        ctpf(parts="2"); ctpf(parts="0")

@@ -1382,6 +1382,7 @@ extern "C" int tmvb_ctpf_destroy(tmvb_ctpf* h)
     (void)hipFree(h->d_mstep_counter);
     (void)hipFree(h->d_sum_g); (void)hipFree(h->d_sum_z); (void)hipFree(h->d_doc_val); (void)hipFree(h->d_elbo_partial); (void)hipFree(h->d_elbo);
     (void)hipFree(h->d_TAo); (void)hipFree(h->d_DA); (void)hipFree(h->d_THo); (void)hipFree(h->d_DH); (void)hipFree(h->d_lg_doc);
+    (void)hipFree(h->d_shift); (void)hipFree(h->d_logz); (void)hipFree(h->d_crd);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -1519,6 +1520,7 @@ extern "C" int tmvb_ctpf_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmv
     // (the two timing events are default events -- time stamps and a system-scope release each -- on the stream the whole iteration runs on:
     //  recorded unconditionally they cost every 0.15 ms iteration two barrier packets; round 4, as LDA has it)
     { const char* t = getenv("TMVB_ESTEP_TIMING"); h->timing = t && atoi(t) != 0; }
+    { const char* e = getenv("TMVB_CTPF_ELBO_PARTS"); h->parts_env = e ? atoi(e) : 1; }
     TMVB_HIP(hipEventCreate(&h->ev0));
     TMVB_HIP(hipEventCreate(&h->ev1));
     TMVB_HIP(hipEventCreateWithFlags(&h->ev_fork, tmvb_event_flags()));
@@ -1558,6 +1560,7 @@ extern "C" int tmvb_ctpf_set_state(tmvb_ctpf* h, const double* hyper, const doub
         memcpy(h->hyper, hyper, sizeof(h->hyper));
     }
     if (alef || he) h->rs_fresh = false;
+    h->logz_valid = false;
     if (alef) {
         TMVB_REQUIRE(positive_finite(alef, KV), TMVB_ENONFINITE, "alef must be positive.");
         if ((rc = upload_f32(ctx, h->d_alef, alef, KV)) || (rc = upload_f32(ctx, h->d_alef_old, alef, KV))) return rc;
@@ -1603,6 +1606,7 @@ extern "C" int tmvb_ctpf_set_state_old(tmvb_ctpf* h, const double* alef_old, con
                                        const double* gimel_old, const double* zayin_old)
 {
     TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_ctpf_set_state_old: handle is NULL");
+    h->logz_valid = false;
     tmvb_ctx* ctx = h->ctx;
     TMVB_HIP(hipSetDevice(ctx->device));
     const size_t K = h->K, KM = K * (size_t)h->M, KV = K * (size_t)h->V, KU = K * (size_t)h->U;
@@ -1677,6 +1681,15 @@ extern "C" int tmvb_ctpf_estep(tmvb_ctpf* h, int32_t viter, double vtol)
     p.wtok = h->d_wtok; p.wrdr = h->d_wrdr; p.E1 = h->d_E1; p.E2 = h->d_E2; p.estride = h->estride; p.sweeps = h->d_sweeps;
     p.viter = viter; p.vtol = (float)vtol;
     p.store_w = tmvb_termstats_recomputes(h->KP, h->e_padded) ? 0 : 1;
+    // decomposed update_elbo!: this iteration will be checked -- the document kernels leave their softmax shifts, the statistics passes the log-normaliser sums
+    const bool collect = (h->parts_env == 2 || (h->parts_env != 0 && h->want_parts)) && p.store_w == 0 && viter > 0 && !h->distributed && h->M > 0;
+    h->logz_valid = false; h->msteps_after = 0;
+    const int64_t nct = h->corp->term_index.n_chunks, ncr = h->U > 0 ? h->corp->reader_index.n_chunks : 0;
+    if (collect) {
+        if (!h->d_shift) { int arc = dmalloc(&h->d_shift, 2 * (size_t)h->M); if (arc) return arc; }
+        if (!h->d_logz) { int arc = dmalloc(&h->d_logz, (size_t)std::max<int64_t>(nct + ncr, 1)); if (arc) return arc; }
+        p.shift = h->d_shift;
+    }
     if (h->timing) TMVB_HIP(hipEventRecord(h->ev0, ctx->stream));
     // stream plan as in tmvb_lda_estep for one statistics pass: the register-tile buckets run back to back on the
     // context's stream (the critical chain document kernels -> statistics -> M-step pays kernel boundaries, not ~20 us
@@ -1774,6 +1787,7 @@ extern "C" int tmvb_ctpf_estep(tmvb_ctpf* h, int32_t viter, double vtol)
     // reader pass on aux[0] under the term pass
     TermStatsParams tr = tp;
     tr.w = h->d_wrdr; tr.E = h->d_E2; tr.T = h->d_TH; tr.out = h->he_stats(); tr.partial = h->d_ts_partial2;
+    if (collect) { tp.logz = h->d_logz; tr.logz = h->d_logz + nct; }
     static const bool fuse_env = [] { const char* e = getenv("TMVB_CTPF_FUSE_STATS"); return !(e && atoi(e) == 0); }();
     int rc = TMVB_EINVAL;
     if (fuse_env && h->U > 0 && tmvb_termstats_recomputes(h->KP, h->e_padded))
@@ -1791,6 +1805,7 @@ extern "C" int tmvb_ctpf_estep(tmvb_ctpf* h, int32_t viter, double vtol)
     } else if (rc) {
         return rc;
     }
+    h->logz_valid = collect; h->n_logz = collect ? nct + ncr : 0;
     if (h->timing) TMVB_HIP(hipEventRecord(h->ev1, ctx->stream));
     h->timed = true;
     return TMVB_OK;
@@ -1872,6 +1887,7 @@ extern "C" int tmvb_ctpf_mstep(tmvb_ctpf* h)
     TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_ctpf_mstep: handle is NULL");
     tmvb_ctx* ctx = h->ctx;
     TMVB_HIP(hipSetDevice(ctx->device));
+    ++h->msteps_after;                                    // (the decomposed update_elbo! wants exactly one M-step behind the collecting E-step)
     int rc;
     if (h->distributed) {     // tail -> fp64 sums
         h->docs_pending = false;
@@ -1940,29 +1956,59 @@ extern "C" int tmvb_ctpf_update_elbo_parts(tmvb_ctpf* h, double* doc_part, doubl
     }
     const double* hy = h->hyper;
     double res[2] = {0.0, 0.0};
+    static const bool legacy_elbo = [] { const char* e = getenv("TMVB_CTPF_ELBO_LEGACY"); return e && atoi(e) != 0; }();
+    // the decomposed form: the last E-step collected its parts and exactly one M-step ran behind it (alef_old / he_old / the old rates are that E-step's)
+    const bool parts = h->M > 0 && !legacy_elbo && h->logz_valid && h->msteps_after == 1 && !h->distributed;
+    h->elbo_form = parts ? 1 : 0;
+    if (h->M > 0 && !legacy_elbo && !h->d_lg_doc) {       // first call: the corpus constants
+        if ((rc = dmalloc(&h->d_lrates_d, 8 * (size_t)h->K)) || (rc = dmalloc(&h->d_lg_doc, (size_t)h->M)) || (rc = dmalloc(&h->d_crd, 2 * (size_t)h->M))) return rc;
+        std::vector<double> lg((size_t)h->M, 0.0), crd(2 * (size_t)h->M, 0.0);
+        const tmvb_corpus* c = h->corp;
+        for (int64_t d = 0; d < h->M; ++d) {
+            double v = 0.0, cd = 0.0, rd = 0.0;
+            for (int64_t q = c->h_doc_ptr[d]; q < c->h_doc_ptr[d + 1]; ++q) { v += std::lgamma((double)c->h_counts[q] + 1.0); cd += (double)c->h_counts[q]; }
+            for (int64_t q = c->h_rdr_ptr[d]; q < c->h_rdr_ptr[d + 1]; ++q) { v += std::lgamma((double)c->h_ratings[q] + 1.0); rd += (double)c->h_ratings[q]; }
+            lg[(size_t)d] = v; crd[2 * (size_t)d] = cd; crd[2 * (size_t)d + 1] = rd;
+        }
+        TMVB_HIP(hipMemcpyAsync(h->d_lg_doc, lg.data(), lg.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        TMVB_HIP(hipMemcpyAsync(h->d_crd, crd.data(), crd.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        TMVB_HIP(hipStreamSynchronize(ctx->stream));
+    }
     // global part: partial sums now, added up by the one final kernel behind the per-document part (one copy, one synchronisation)
     const int nb = 256;
-    hipLaunchKernelGGL(ctpf_elbo_global_kernel, dim3(nb), dim3(256), 0, ctx->stream, h->d_alef, h->V, h->K, h->d_rates, hy[0], hy[1], h->d_elbo_partial);
-    hipLaunchKernelGGL(ctpf_elbo_global_kernel, dim3(nb), dim3(256), 0, ctx->stream, h->d_he, h->U, h->K, h->d_rates + h->K, hy[4], hy[5], h->d_elbo_partial + nb);
+    hipLaunchKernelGGL(ctpf_elbo_global_kernel, dim3(nb), dim3(256), 0, ctx->stream, h->d_alef, h->V, h->K, h->d_rates, hy[0], hy[1], h->d_elbo_partial,
+                       parts ? (const float*)h->d_alef_old : (const float*)nullptr, parts ? (const double*)h->d_rates : (const double*)nullptr,
+                       parts ? h->d_lrates_d : (double*)nullptr);
+    hipLaunchKernelGGL(ctpf_elbo_global_kernel, dim3(nb), dim3(256), 0, ctx->stream, h->d_he, h->U, h->K, h->d_rates + h->K, hy[4], hy[5], h->d_elbo_partial + nb,
+                       parts ? (const float*)h->d_he_old : (const float*)nullptr, (const double*)nullptr, (double*)nullptr);
     TMVB_HIP(hipGetLastError());
     const double cst = (double)h->V * h->K * (hy[0] * std::log(hy[1]) - std::lgamma(hy[0])) + (double)h->U * h->K * (hy[4] * std::log(hy[5]) - std::lgamma(hy[4]));
+    const double doc_cst = (double)h->K * (hy[2] * std::log(hy[3]) - std::lgamma(hy[2])) + (double)h->K * (hy[6] * std::log(hy[7]) - std::lgamma(hy[6]));
     // per-document part
-    static const bool legacy_elbo = [] { const char* e = getenv("TMVB_CTPF_ELBO_LEGACY"); return e && atoi(e) != 0; }();
+    if (parts) {
+        auto dp = [&](auto ns) {
+            constexpr int NS = decltype(ns)::value;
+            hipLaunchKernelGGL((ctpf_elbo_doc_parts_kernel<NS>), dim3((unsigned)h->M), dim3(64), 0, ctx->stream, h->K, (const double*)h->d_rates, (const double*)h->d_lrates_d,
+                               (const double*)h->d_rs_alef, (const double*)h->d_rs_he, h->d_gimel, h->d_gimel_old, h->d_zayin, h->d_zayin_old, (const double*)h->d_lg_doc,
+                               (const double*)h->d_crd, (const float*)h->d_shift, hy[2], hy[3], hy[6], hy[7], doc_cst, h->d_doc_val);
+        };
+        if (h->nslot == 1) dp(std::integral_constant<int, 1>()); else if (h->nslot == 2) dp(std::integral_constant<int, 2>());
+        else if (h->nslot <= 4) dp(std::integral_constant<int, 4>()); else dp(std::integral_constant<int, 8>());
+        TMVB_HIP(hipGetLastError());
+        hipLaunchKernelGGL(ctpf_elbo_final_parts_kernel, dim3(1), dim3(1024), 0, ctx->stream, h->d_doc_val, h->M, h->d_elbo_partial, 2 * nb, cst,
+                           (const float*)h->d_logz, h->n_logz, (const double*)h->d_lrates_d, (const double*)h->d_rs_alef, (const double*)h->d_sum_g, h->K,
+                           (double)h->V * hy[0], (double)h->M * hy[2], h->d_elbo);
+        TMVB_HIP(hipGetLastError());
+        TMVB_HIP(hipMemcpyAsync(res, h->d_elbo, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        TMVB_HIP(hipStreamSynchronize(ctx->stream));
+        if (doc_part) *doc_part = res[0];
+        if (global_part) *global_part = res[1];
+        return TMVB_OK;
+    }
     if (h->M > 0 && !legacy_elbo) {
-        if (!h->d_lg_doc) {                               // first call: tables and the corpus constants
+        if (!h->d_TAo) {                                  // first call of the table form: its tables
             const size_t na = (size_t)h->V * h->KP + 4, nh = (size_t)std::max<int64_t>(h->U, 1) * h->KP + 4;
-            if ((rc = dmalloc(&h->d_TAo, na)) || (rc = dmalloc(&h->d_DA, na)) || (rc = dmalloc(&h->d_THo, nh)) || (rc = dmalloc(&h->d_DH, nh)) ||
-                (rc = dmalloc(&h->d_lrates_d, 8 * (size_t)h->K)) || (rc = dmalloc(&h->d_lg_doc, (size_t)h->M))) return rc;
-            std::vector<double> lg((size_t)h->M, 0.0);
-            const tmvb_corpus* c = h->corp;
-            for (int64_t d = 0; d < h->M; ++d) {
-                double v = 0.0;
-                for (int64_t q = c->h_doc_ptr[d]; q < c->h_doc_ptr[d + 1]; ++q) v += std::lgamma((double)c->h_counts[q] + 1.0);
-                for (int64_t q = c->h_rdr_ptr[d]; q < c->h_rdr_ptr[d + 1]; ++q) v += std::lgamma((double)c->h_ratings[q] + 1.0);
-                lg[(size_t)d] = v;
-            }
-            TMVB_HIP(hipMemcpyAsync(h->d_lg_doc, lg.data(), lg.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-            TMVB_HIP(hipStreamSynchronize(ctx->stream));
+            if ((rc = dmalloc(&h->d_TAo, na)) || (rc = dmalloc(&h->d_DA, na)) || (rc = dmalloc(&h->d_THo, nh)) || (rc = dmalloc(&h->d_DH, nh))) return rc;
         }
         int nbt = (int)std::min<int64_t>(2048, std::max<int64_t>(1, ((int64_t)h->KP * h->V + 255) / 256));
         hipLaunchKernelGGL(ctpf_elbo_tables_kernel, dim3(nbt), dim3(256), 0, ctx->stream, h->d_alef, h->d_alef_old, h->d_TAo, h->d_DA, h->K, h->KP, h->V,
@@ -2006,6 +2052,13 @@ extern "C" int tmvb_ctpf_update_elbo_parts(tmvb_ctpf* h, double* doc_part, doubl
     return TMVB_OK;
 }
 
+extern "C" int tmvb_ctpf_elbo_form(tmvb_ctpf* h, int32_t* form)
+{
+    TMVB_REQUIRE(h && form, TMVB_EINVAL, "tmvb_ctpf_elbo_form: NULL argument");
+    *form = h->elbo_form;
+    return TMVB_OK;
+}
+
 extern "C" int tmvb_ctpf_update_elbo(tmvb_ctpf* h, double* elbo)
 {
     double dp = 0.0, gp = 0.0;
@@ -2037,6 +2090,7 @@ struct CtpfTrainOps {
     int mstep(tmvb_ctpf* h) { return tmvb_ctpf_mstep(h); }                            // :366-371
     // the per-document part adds up over the shards; the (beta, eta) part is global and identical on every rank
     int elbo_local(tmvb_ctpf* h, double* s, double* once) { return tmvb_ctpf_update_elbo_parts(h, s, once); }
+    void will_check(tmvb_ctpf* h, bool checked) { h->want_parts = checked; }          // the coming iteration ends in check_elbo!
     double* elbo_dev(tmvb_ctpf* h) { return h->d_elbo; }
     tmvb_comm* comm(tmvb_ctpf* h) { return h->comm; }
     bool distributed(tmvb_ctpf* h) { return h->distributed; }

@@ -126,6 +126,12 @@ class gpuCTPF:
     def reduce_docs(self): check(lib().tmvb_ctpf_reduce_docs(self.handle))
     def mstep(self): check(lib().tmvb_ctpf_mstep(self.handle))
 
+    def elbo_form(self) -> int:
+        """1 if the last update_elbo! took the decomposed form (parts left behind by the iteration itself), 0 for the table form."""
+        f = C.c_int32(0)
+        check(lib().tmvb_ctpf_elbo_form(self.handle, C.byref(f)))
+        return f.value
+
     def update_elbo(self) -> float:
         out = C.c_double(0.0)
         check(lib().tmvb_ctpf_update_elbo(self.handle, C.byref(out)))
