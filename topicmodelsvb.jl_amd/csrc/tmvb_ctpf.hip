@@ -1252,44 +1252,64 @@ __global__ __launch_bounds__(1024) void ctpf_elbo_final2_kernel(const double* __
 //                    with PC_i = sum_d sum_n c phi = rowsum(alef)_i - V a  and  PA_i = sum_d (gimel_di - c) - PC_i  -- the split of gimel - c into its
 //                    term and reader halves is only needed summed over the documents, where the M-step has it.
 // No entry is walked: the two table kernels and the entry sums of ctpf_elbo_doc_fast_kernel (70 of its 109 us on SYN-CITEU) go away.
-template <int NS>
-__global__ __launch_bounds__(64) void ctpf_elbo_doc_parts_kernel(int K, const double* __restrict__ rates /* [8][K] */, const double* __restrict__ lrates_d,
-                                                                 const double* __restrict__ rs_alef, const double* __restrict__ rs_he,
-                                                                 const float* __restrict__ gimel, const float* __restrict__ gimel_old,
-                                                                 const float* __restrict__ zayin, const float* __restrict__ zayin_old,
-                                                                 const double* __restrict__ lg_doc, const double* __restrict__ crd /* [M][2] */,
-                                                                 const float* __restrict__ shift /* [M][2] */,
-                                                                 double hc, double hd, double hg, double hh, double doc_const, double* __restrict__ doc_val)
+// Layout as lda_elbo_doc_kernel: CTPF_ELBO_DPB = 16 documents per block of 128 threads, EIGHT LANES PER DOCUMENT (topics q, q + 8, ...: four fp64 special
+// functions per (document, topic) are latency-bound chains -- with four lanes per document and one wave per SIMD the kernel took 40 us on SYN-CITEU); the rows of gimel / gimel_old /
+// zayin / zayin_old are contiguous and staged through LDS with coalesced loads, the per-topic coefficients (reciprocal rates times row sums, logarithms of the
+// rates and their changes) are computed once per block.  One fp64 value per document, summed by the final kernel.
+constexpr int CTPF_ELBO_LPD = 8, CTPF_ELBO_DPB = 128 / CTPF_ELBO_LPD;
+__global__ __launch_bounds__(128) void ctpf_elbo_doc_parts_kernel(int K, int64_t M, const double* __restrict__ rates /* [8][K] */, const double* __restrict__ lrates_d,
+                                                                  const double* __restrict__ rs_alef, const double* __restrict__ rs_he,
+                                                                  const float* __restrict__ gimel, const float* __restrict__ gimel_old,
+                                                                  const float* __restrict__ zayin, const float* __restrict__ zayin_old,
+                                                                  const double* __restrict__ lg_doc, const double* __restrict__ crd /* [M][2] */,
+                                                                  const float* __restrict__ shift /* [M][2] */,
+                                                                  double hc, double hd, double hg, double hh, double doc_const, double* __restrict__ doc_val)
 {
-    const int lane = threadIdx.x;
-    const int d = blockIdx.x;
+    extern __shared__ __attribute__((aligned(16))) double smd[];   // [6][K] coefficients, then [4][DPB K] floats
+    double* cA = smd; double* cZ = smd + K; double* lD = smd + 2 * K; double* lH = smd + 3 * K; double* dD = smd + 4 * K; double* dHV = smd + 5 * K;
+    constexpr int DPB = CTPF_ELBO_DPB, LPD = CTPF_ELBO_LPD;
+    float* sg = (float*)(smd + 6 * K); float* sgo = sg + DPB * K; float* sz = sg + 2 * DPB * K; float* szo = sg + 3 * DPB * K;
+    const int tid = threadIdx.x;
+    const int64_t d0 = (int64_t)blockIdx.x * DPB;
+    const int nd = (int)min((int64_t)DPB, M - d0);
+    for (int i = tid; i < K; i += 128) {
+        const double r_bet = tmvb_rcp_d(rates[i]), r_vav = tmvb_rcp_d(rates[K + i]), r_dalet = tmvb_rcp_d(rates[2 * K + i]), r_het = tmvb_rcp_d(rates[3 * K + i]);
+        cA[i] = r_dalet * r_vav * rs_he[i] + r_dalet * r_bet * rs_alef[i] + hd * r_dalet;     // :112, :134 and Elogptheta's rate term :156, per unit of gimel
+        cZ[i] = r_het * r_vav * rs_he[i] + hh * r_het;                                        // :123 and Elogpepsilon's :174, per unit of zayin
+        lD[i] = lrates_d[2 * K + i]; lH[i] = lrates_d[3 * K + i];
+        dD[i] = lrates_d[2 * K + i] - lrates_d[6 * K + i];
+        dHV[i] = (lrates_d[3 * K + i] - lrates_d[7 * K + i]) + (lrates_d[K + i] - lrates_d[5 * K + i]);
+    }
+    {
+        const int n = nd * K, n4 = n >> 2;                     // DPB K floats per block: 16-byte aligned
+        const float4* a4 = (const float4*)(gimel + d0 * K); const float4* b4 = (const float4*)(gimel_old + d0 * K);
+        const float4* c4 = (const float4*)(zayin + d0 * K); const float4* e4 = (const float4*)(zayin_old + d0 * K);
+        for (int i = tid; i < n4; i += 128) { ((float4*)sg)[i] = a4[i]; ((float4*)sgo)[i] = b4[i]; ((float4*)sz)[i] = c4[i]; ((float4*)szo)[i] = e4[i]; }
+        for (int i = 4 * n4 + tid; i < n; i += 128) { sg[i] = gimel[d0 * K + i]; sgo[i] = gimel_old[d0 * K + i]; sz[i] = zayin[d0 * K + i]; szo[i] = zayin_old[d0 * K + i]; }
+    }
+    __syncthreads();
+    const int dl = tid / LPD, q = tid % LPD;
     double acc = 0.0;
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const bool on = lane + 64 * s < K;
-        const int i = on ? lane + 64 * s : 0;
-        const double bet = rates[i], vav = rates[K + i], dalet = rates[2 * K + i], het = rates[3 * K + i];
-        const double l_vav = lrates_d[K + i], l_dalet = lrates_d[2 * K + i], l_het = lrates_d[3 * K + i];
-        const double l_vav_o = lrates_d[5 * K + i], l_dalet_o = lrates_d[6 * K + i], l_het_o = lrates_d[7 * K + i];
-        const double gi = on ? (double)gimel[(int64_t)d * K + i] : 1.0, za = on ? (double)zayin[(int64_t)d * K + i] : 1.0;
-        const double gio = on ? (double)gimel_old[(int64_t)d * K + i] : 1.0, zao = on ? (double)zayin_old[(int64_t)d * K + i] : 1.0;
-        const double dgo = digamma_shift8_d(gio), dzo = digamma_shift8_d(zao);
-        double psi_g, lg_g, psi_z, lg_z;
-        digamma_lgamma_d(gi, psi_g, lg_g);
-        digamma_lgamma_d(za, psi_z, lg_z);
-        if (on) {
-            const double r_dalet = tmvb_rcp_d(dalet), r_het = tmvb_rcp_d(het), r_vav = tmvb_rcp_d(vav), r_bet = tmvb_rcp_d(bet);
-            acc -= (gi * r_dalet * r_vav + za * r_het * r_vav) * rs_he[i] + gi * r_dalet * r_bet * rs_alef[i];   // :112,:123,:134
-            acc += (hc - 1.0) * (psi_g - l_dalet) - hd * gi * r_dalet;            // Elogptheta :156
-            acc += (hg - 1.0) * (psi_z - l_het) - hh * za * r_het;                // Elogpepsilon :174
-            acc += (gi - l_dalet + lg_g + (1.0 - gi) * psi_g) + (za - l_het + lg_z + (1.0 - za) * psi_z);   // -Elogqtheta, -Elogqepsilon: Gamma entropies
-            acc += (gi - hc) * ((psi_g - dgo) - (l_dalet - l_dalet_o));           // the entries' per-document share (see above)
-            acc += (za - hg) * ((psi_z - dzo) - (l_het - l_het_o) - (l_vav - l_vav_o));
+    if (dl < nd) {
+        for (int k = q; k < K; k += LPD) {
+            const double gi = (double)sg[dl * K + k], za = (double)sz[dl * K + k];
+            const double dgo = digamma_shift8_d((double)sgo[dl * K + k]), dzo = digamma_shift8_d((double)szo[dl * K + k]);
+            double psi_g, lg_g, psi_z, lg_z;
+            digamma_lgamma_d(gi, psi_g, lg_g);
+            digamma_lgamma_d(za, psi_z, lg_z);
+            acc -= gi * cA[k] + za * cZ[k];
+            acc += (hc - 1.0) * (psi_g - lD[k]) + (hg - 1.0) * (psi_z - lH[k]);            // Elogptheta :156, Elogpepsilon :174 (shape terms)
+            acc += (gi - lD[k] + lg_g + (1.0 - gi) * psi_g) + (za - lH[k] + lg_z + (1.0 - za) * psi_z);   // -Elogqtheta, -Elogqepsilon: Gamma entropies
+            acc += (gi - hc) * ((psi_g - dgo) - dD[k]);                                    // the entries' per-document share (see above)
+            acc += (za - hg) * ((psi_z - dzo) - dHV[k]);
         }
     }
-    double tot = wave_sum_d(acc);
-    tot += doc_const - lg_doc[d] + crd[2 * (int64_t)d] * (double)shift[2 * (int64_t)d] + crd[2 * (int64_t)d + 1] * (double)shift[2 * (int64_t)d + 1];
-    if (lane == 0) doc_val[d] = tot;
+#pragma unroll
+    for (int o = 1; o < LPD; o <<= 1) acc += __shfl_xor(acc, o, 64);
+    if (dl < nd && q == 0) {
+        const int64_t d = d0 + dl;
+        doc_val[d] = acc + doc_const - lg_doc[d] + crd[2 * d] * (double)shift[2 * d] + crd[2 * d + 1] * (double)shift[2 * d + 1];
+    }
 }
 
 // out[0] = sum doc_val + ln 2 * sum logz (the documents' part), out[1] = sum partial + constant - sum_i (dlog bet_i PC_i + dlog vav_i PA_i) (the global part)
@@ -1986,14 +2006,13 @@ extern "C" int tmvb_ctpf_update_elbo_parts(tmvb_ctpf* h, double* doc_part, doubl
     const double doc_cst = (double)h->K * (hy[2] * std::log(hy[3]) - std::lgamma(hy[2])) + (double)h->K * (hy[6] * std::log(hy[7]) - std::lgamma(hy[6]));
     // per-document part
     if (parts) {
-        auto dp = [&](auto ns) {
-            constexpr int NS = decltype(ns)::value;
-            hipLaunchKernelGGL((ctpf_elbo_doc_parts_kernel<NS>), dim3((unsigned)h->M), dim3(64), 0, ctx->stream, h->K, (const double*)h->d_rates, (const double*)h->d_lrates_d,
-                               (const double*)h->d_rs_alef, (const double*)h->d_rs_he, h->d_gimel, h->d_gimel_old, h->d_zayin, h->d_zayin_old, (const double*)h->d_lg_doc,
-                               (const double*)h->d_crd, (const float*)h->d_shift, hy[2], hy[3], hy[6], hy[7], doc_cst, h->d_doc_val);
-        };
-        if (h->nslot == 1) dp(std::integral_constant<int, 1>()); else if (h->nslot == 2) dp(std::integral_constant<int, 2>());
-        else if (h->nslot <= 4) dp(std::integral_constant<int, 4>()); else dp(std::integral_constant<int, 8>());
+        {
+            const size_t lds = (size_t)6 * h->K * sizeof(double) + (size_t)4 * CTPF_ELBO_DPB * h->K * sizeof(float);
+            if (lds > 48 * 1024) TMVB_HIP(hipFuncSetAttribute((const void*)ctpf_elbo_doc_parts_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(ctpf_elbo_doc_parts_kernel, dim3((unsigned)((h->M + CTPF_ELBO_DPB - 1) / CTPF_ELBO_DPB)), dim3(128), lds, ctx->stream, h->K, h->M, (const double*)h->d_rates,
+                               (const double*)h->d_lrates_d, (const double*)h->d_rs_alef, (const double*)h->d_rs_he, h->d_gimel, h->d_gimel_old, h->d_zayin,
+                               h->d_zayin_old, (const double*)h->d_lg_doc, (const double*)h->d_crd, (const float*)h->d_shift, hy[2], hy[3], hy[6], hy[7], doc_cst, h->d_doc_val);
+        }
         TMVB_HIP(hipGetLastError());
         hipLaunchKernelGGL(ctpf_elbo_final_parts_kernel, dim3(1), dim3(1024), 0, ctx->stream, h->d_doc_val, h->M, h->d_elbo_partial, 2 * nb, cst,
                            (const float*)h->d_logz, h->n_logz, (const double*)h->d_lrates_d, (const double*)h->d_rs_alef, (const double*)h->d_sum_g, h->K,
