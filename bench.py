@@ -198,6 +198,11 @@ def slim_line(result):
                 continue
             o = {k: ln.get(k) for k in ("metric", "value", "unit", "ms_per_step", "estep_ms", "dtype") if k in ln}
             o["dtype"] = str(o.get("dtype", "f32")).split(" ")[0]
+            # what an iteration costs with check_elbo! behind it (train!'s default checkelbo = 1), as train! runs it
+            if ln.get("ms_per_checked_step") is not None:
+                o["ms_per_checked_step"] = ln["ms_per_checked_step"]
+            elif isinstance(ln.get("checked"), dict):
+                o["ms_per_checked_step"] = ln["checked"].get("ms_per_checked_step")
             o["config"] = _slim_config(ln)
             o["roofline"] = _slim_roofline(ln.get("roofline"))
             o["cpu_baseline"] = _slim_cpu(ln.get("cpu_baseline"))

@@ -285,6 +285,8 @@ def test_ctpf_train_twice_equals_one_run(tmvb):
     two = fresh()
     t_a = two.train(iter=3, tol=0.0, checkelbo=1, printelbo=False, recs=False)
     t_b = two.train(iter=3, tol=0.0, checkelbo=1, printelbo=False, recs=False)
-    # the second call's baseline is the ELBO the first call ended on (fp32 state went through fp64 host arrays: exact)
-    np.testing.assert_allclose(two.elbo_baseline, t_a[-1], rtol=1e-10)
+    # the second call's baseline is the ELBO the first call ended on (fp32 state went through fp64 host arrays: exact) -- evaluated by the table form on the
+    # state the host set, where the first call's last check took the decomposed form of update_elbo! (round 5): the same sum to fp32 rounding
+    from tol import TOL
+    np.testing.assert_allclose(two.elbo_baseline, t_a[-1], rtol=TOL["ctpf.elbo_forms_rel"])
     np.testing.assert_allclose(np.concatenate([t_a, t_b]), t_one, rtol=1e-6)   # host-side log(rate) vs device, 1 ulp in fp32

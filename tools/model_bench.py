@@ -189,8 +189,30 @@ def ctm(burnin=60, warmup=2, steps=8, cpu=True, K=50):        # 60 burn-in itera
     # (the K > 52 kernel runs one wave per document: its trip counts are per document)
     per_trip = 64.0 if lane_kernel else 1.0
     F_exec = per_trip * (st["cg_trips"] * (2 * KP * KP + 12 * KP) + st["newton_trips"] * (2 * KP * KP + 24 * KP)) + tok if st["waves"] else None
+    # a checked iteration as train! runs it (checkelbo = 1): the same model with every E-step collecting the ELBO's parts (TMVB_CTM_ELBO_PARTS=2)
+    checked = None
+    if K == 50:
+        os.environ["TMVB_CTM_ELBO_PARTS"] = "2"
+        gc = tm.gpuCTM(pc, K)
+        del os.environ["TMVB_CTM_ELBO_PARTS"]
+        gc.beta = np.asfortranarray(beta0); gc.beta_old = gc.beta.copy(order="F"); gc.update_buffer()
+
+        def itc():
+            gc.estep(); gc.reduce_docs(); gc.update_beta(); gc.update_sigma(); gc.update_mu()
+        for _ in range(12):
+            itc()
+        gc.update_elbo(); gc.synchronize(); t0 = time.perf_counter()
+        for _ in range(6):
+            itc()
+        gc.synchronize(); t1 = time.perf_counter()
+        for _ in range(6):
+            itc(); gc.update_elbo()
+        gc.synchronize(); t2 = time.perf_counter()
+        checked = {"ms_per_step_same_window": 1e3 * (t1 - t0) / 6, "ms_per_checked_step": 1e3 * (t2 - t1) / 6,
+                   "elbo_form": "decomposed" if gc.elbo_form() == 1 else "token walk", "window": "iterations 13..18 / 19..24 from the cold start"}
+        gc.close()
     line = {"metric": f"VB iters/sec, CTM K={K} on NSF-shaped corpus" + (" (config 4)" if K == 50 else ""), "value": 1.0 / sec, "unit": "VB iters/sec",
-            "ms_per_step": 1e3 * sec, "estep_ms": es_ms, "dtype": "f32 (fp64 gradients / logzeta / vsq)", "data": "synthetic",
+            "ms_per_step": 1e3 * sec, "estep_ms": es_ms, "checked": checked, "dtype": "f32 (fp64 gradients / logzeta / vsq)", "data": "synthetic",
             "config": {"workload": f"CTM K={K}, SYN-NSF, train! defaults (niter=1000 ntol=1/K^2 viter=10 vtol=1/K^2), steady state: {burnin} untimed "
                                    f"iterations from the cold start, then {warmup} warm-up + {steps} timed",
                        "M": pc.M, "V": pc.V, "nnz": pc.nnz, "lambda_newton_steps_last_iteration": int(newton), "sweeps_last_iteration": sweeps,
@@ -265,16 +287,29 @@ def ctpf(burnin=300, warmup=10, steps=200, cpu=True):
         gt.reduce_docs(); gt.mstep()
     es_ms = float(np.mean(es))
     gt.close()
-    # a checked iteration (update_elbo! on the device after every M-step); the first call builds the per-document constants
-    gm.update_elbo()
-    gm.synchronize(); t0 = time.perf_counter()
-    for _ in range(10):
-        it(); gm.update_elbo()
-    gm.synchronize(); checked = (time.perf_counter() - t0) / 10
+    # a checked iteration as train! runs it under its default checkelbo = 1 (update_elbo! on the device after every M-step): a model whose every E-step
+    # collects the ELBO's parts, as train!'s checked iterations do (TMVB_CTPF_ELBO_PARTS=2), brought to the same state;
+    # the first call builds the per-document constants
+    os.environ["TMVB_CTPF_ELBO_PARTS"] = "2"
+    gc = tm.gpuCTPF(pc, K)
+    del os.environ["TMVB_CTPF_ELBO_PARTS"]
+
+    def itc():
+        gc.estep(); gc.reduce_docs(); gc.mstep()
+    for _ in range(60):
+        itc()
+    gc.update_elbo()
+    gc.synchronize(); t0 = time.perf_counter()
+    for _ in range(20):
+        itc(); gc.update_elbo()
+    gc.synchronize(); checked = (time.perf_counter() - t0) / 20
+    elbo_form = gc.elbo_form()
+    gc.close()
     B = pc.nnz * (8 + 8 * K) + pc.nR * (8 + 8 * K) + 16 * pc.M * K + 12 * K * (pc.V + pc.U)
     ms_s, ms_r = gm.recommend(scores=False)
     line = {"metric": "VB iters/sec, CTPF K=50 on CiteULike-shaped corpus (config 5)", "value": 1.0 / sec, "unit": "VB iters/sec",
-            "ms_per_step": 1e3 * sec, "estep_ms": es_ms, "ms_per_checked_step": 1e3 * checked, "dtype": "f32", "data": "synthetic",
+            "ms_per_step": 1e3 * sec, "estep_ms": es_ms, "ms_per_checked_step": 1e3 * checked, "checked_elbo_form": "decomposed" if elbo_form == 1 else "table form",
+            "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"CTPF K=50, SYN-CITEU with readers, train! defaults (viter=10 vtol=1/K^2 checkelbo=Inf), steady state: {burnin} untimed "
                                    f"iterations from the cold start, then {warmup} warm-up + {steps} timed",
                        "M": pc.M, "V": pc.V, "U": pc.U, "nnz": pc.nnz, "nR": pc.nR, "sweep_hist_last_step": hist},

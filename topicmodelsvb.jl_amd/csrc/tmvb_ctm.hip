@@ -1432,7 +1432,7 @@ struct tmvb_ctm {
     int parts_env = 1; bool want_parts = false;
     float* d_logz = nullptr; size_t logz_cap = 0; int64_t n_logz = 0; float* d_pdot = nullptr; double* d_pw_partial = nullptr; int pw_blocks = 0;
     bool logz_valid = false, stats_fresh = false, pw_valid = false;
-    int elbo_form = 0;
+    int elbo_form = 0; bool force_walk = false;
     int64_t stats_len() const { return (int64_t)K * V + 2 * K + (int64_t)K * K; }
     float* tail() const { return d_stats + (size_t)K * V; }
 };
@@ -2107,7 +2107,7 @@ extern "C" int tmvb_ctm_update_elbo(tmvb_ctm* h, double* elbo)
     TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_ctm_update_elbo: handle is NULL");
     tmvb_ctx* ctx = h->ctx;
     TMVB_HIP(hipSetDevice(ctx->device));
-    const bool parts = h->logz_valid && h->pw_valid;         // everything per token was left behind by the iteration itself
+    const bool parts = h->logz_valid && h->pw_valid && !h->force_walk;         // everything per token was left behind by the iteration itself
     h->elbo_form = parts ? 1 : 0;
     if (parts && h->M > 0) {
 #define CTM_ELBO_DOC(NSV) hipLaunchKernelGGL((ctm_elbo_kernel<NSV, false>), dim3((unsigned)h->M), dim3(64), 0, ctx->stream, h->K, h->KP, h->corp->d_doc_ptr, \
@@ -2181,6 +2181,8 @@ struct CtmTrainOps {
         return rc;
     }
     int elbo_local(tmvb_ctm* h, double* s, double* once) { *once = 0.0; return tmvb_ctm_update_elbo(h, s); }
+    int elbo_form(tmvb_ctm* h) { return h->elbo_form; }
+    void force_walk(tmvb_ctm* h, bool on) { h->force_walk = on; if (!on) h->elbo_form = 1; }   // (switched off behind the one evaluation that doubled a decomposed one)
     void will_check(tmvb_ctm* h, bool checked) { h->want_parts = checked; }             // the coming iteration ends in check_elbo!
     double* elbo_dev(tmvb_ctm* h) { return h->d_elbo; }
     tmvb_comm* comm(tmvb_ctm* h) { return h->comm; }

@@ -1354,7 +1354,7 @@ struct tmvb_ctpf {
     bool rs_fresh = false;                                         // d_rs_alef / d_rs_he are the row sums of the current alef / he
     // decomposed update_elbo! (ctpf_elbo_doc_parts_kernel): TMVB_CTPF_ELBO_PARTS at creation -- 1 (default) the iterations train! will check, 2 every E-step,
     // 0 never.  A collecting E-step leaves the softmax shifts (d_shift) and the statistics passes' log-normaliser sums (d_logz: term chunks, then reader chunks).
-    int parts_env = 1; bool want_parts = false; bool logz_valid = false; int msteps_after = 0; int elbo_form = 0;
+    int parts_env = 1; bool want_parts = false; bool logz_valid = false; int msteps_after = 0; int elbo_form = 0; bool force_walk = false;
     float* d_shift = nullptr; float* d_logz = nullptr; int64_t n_logz = 0; double* d_crd = nullptr;
     unsigned int* d_mstep_counter = nullptr;                        // last-block-done counter of the fused M-step (zero between launches)
     bool docs_pending = false;                                     // tmvb_ctpf_reduce_docs was asked for and deferred into the fused M-step (K <= 64, one context)
@@ -1978,7 +1978,7 @@ extern "C" int tmvb_ctpf_update_elbo_parts(tmvb_ctpf* h, double* doc_part, doubl
     double res[2] = {0.0, 0.0};
     static const bool legacy_elbo = [] { const char* e = getenv("TMVB_CTPF_ELBO_LEGACY"); return e && atoi(e) != 0; }();
     // the decomposed form: the last E-step collected its parts and exactly one M-step ran behind it (alef_old / he_old / the old rates are that E-step's)
-    const bool parts = h->M > 0 && !legacy_elbo && h->logz_valid && h->msteps_after == 1 && !h->distributed;
+    const bool parts = h->M > 0 && !legacy_elbo && h->logz_valid && h->msteps_after == 1 && !h->distributed && !h->force_walk;
     h->elbo_form = parts ? 1 : 0;
     if (h->M > 0 && !legacy_elbo && !h->d_lg_doc) {       // first call: the corpus constants
         if ((rc = dmalloc(&h->d_lrates_d, 8 * (size_t)h->K)) || (rc = dmalloc(&h->d_lg_doc, (size_t)h->M)) || (rc = dmalloc(&h->d_crd, 2 * (size_t)h->M))) return rc;
@@ -2109,6 +2109,8 @@ struct CtpfTrainOps {
     int mstep(tmvb_ctpf* h) { return tmvb_ctpf_mstep(h); }                            // :366-371
     // the per-document part adds up over the shards; the (beta, eta) part is global and identical on every rank
     int elbo_local(tmvb_ctpf* h, double* s, double* once) { return tmvb_ctpf_update_elbo_parts(h, s, once); }
+    int elbo_form(tmvb_ctpf* h) { return h->elbo_form; }
+    void force_walk(tmvb_ctpf* h, bool on) { h->force_walk = on; if (!on) h->elbo_form = 1; }   // (switched off behind the one evaluation that doubled a decomposed one)
     void will_check(tmvb_ctpf* h, bool checked) { h->want_parts = checked; }          // the coming iteration ends in check_elbo!
     double* elbo_dev(tmvb_ctpf* h) { return h->d_elbo; }
     tmvb_comm* comm(tmvb_ctpf* h) { return h->comm; }

@@ -1168,6 +1168,7 @@ struct tmvb_lda {
     bool logz_valid = false;           // d_logz[0, n_logz) and those values belong to the last E-step (every statistics pass of it)
     bool pw_diff = false;              // d_pw_partial holds the (log beta_new - log beta_old) form
     int elbo_form = 0;                 // the last update_elbo!: 1 decomposed, 0 token walk (tmvb_lda_elbo_form)
+    bool force_walk = false;           // train!'s like-with-like evaluation at the switch of forms (tmvb_train.h)
     bool side_pending = false;         // ev_side marks side-stream work the context's stream has not waited for yet
     // tmvb_lda_estep_allreduce (document-sharded run): the LAST statistics pass is issued in vocabulary slices, and the slab of S
     // a slice completes is all-reduced on aux[AR] while the next slice's pass runs on the context's stream.  Cuts and order are
@@ -2095,7 +2096,7 @@ static int lda_elbo_enqueue(tmvb_lda* h)
     bool use_pw = false;
     int64_t n_vals = 0;
     h->elbo_form = 0;
-    const bool parts = h->M > 0 && h->logz_valid && h->pw_valid && h->pw_diff;
+    const bool parts = h->M > 0 && h->logz_valid && h->pw_valid && h->pw_diff && !h->force_walk;
     if (parts) {
         // the decomposed form: the per-document values were enqueued by the E-step itself (side stream: joined above), everything per token was left
         // behind by its statistics passes and by update_beta!
@@ -2192,6 +2193,8 @@ struct LdaTrainOps {
     float* stats(tmvb_lda* h) { return h->d_stats; }
     int64_t stats_len(tmvb_lda* h) { return (int64_t)h->K * h->V + h->K; }
     int mstep(tmvb_lda* h) { int rc = tmvb_lda_update_beta(h); return rc ? rc : tmvb_lda_update_alpha(h, niter, ntol); }   // :181-182
+    int elbo_form(tmvb_lda* h) { return h->elbo_form; }
+    void force_walk(tmvb_lda* h, bool on) { h->force_walk = on; if (!on) h->elbo_form = 1; }   // (switched off behind the one evaluation that doubled a decomposed one)
     void will_check(tmvb_lda* h, bool checked) { h->want_parts = checked; }           // the coming iteration ends in check_elbo!: collect update_elbo!'s parts on the way
     int elbo_local(tmvb_lda* h, double* s, double* once) { *once = 0.0; return tmvb_lda_update_elbo(h, s); }
     int elbo_enqueue(tmvb_lda* h, double* once) { *once = 0.0; TMVB_HIP(hipSetDevice(h->ctx->device)); return lda_elbo_enqueue(h); }   // -> elbo_dev(h), no sync

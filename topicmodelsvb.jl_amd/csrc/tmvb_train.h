@@ -70,7 +70,8 @@ template <class Ops, class H>
 struct tmvb_has_estep_allreduce<Ops, H, std::void_t<decltype(std::declval<Ops&>().estep_allreduce((H*)nullptr))>> : std::true_type {};
 
 // Ops may offer  void will_check(H*, bool): called before every iteration's E-step with whether check_elbo! will evaluate the ELBO behind it, so that the
-// iteration can leave update_elbo!'s per-token parts behind on its way (LDA) instead of walking the corpus a second time.
+// iteration can leave update_elbo!'s per-token parts behind on its way instead of walking the corpus a second time; with it come
+// int elbo_form(H*) (1: the last evaluation took the decomposed form) and void force_walk(H*, bool) (evaluate by the token walk whatever is available).
 template <class Ops, class H, class = void> struct tmvb_has_will_check : std::false_type {};
 template <class Ops, class H>
 struct tmvb_has_will_check<Ops, H, std::void_t<decltype(std::declval<Ops&>().will_check((H*)nullptr, true))>> : std::true_type {};
@@ -152,6 +153,7 @@ static int tmvb_train_group_loop(const char* who, H* const* hs, int n, int iter,
     std::vector<void*> ptrs(n);
     std::vector<int64_t> counts(n);
     int done = 0;
+    bool old_parts = false;                  // e_old was evaluated by the decomposed form of update_elbo! (never true for the baseline: a state this call did not produce)
     for (int k = 1; k <= iter; ++k) {
         ++done;
         if constexpr (tmvb_has_will_check<Ops, H>::value)
@@ -180,8 +182,26 @@ static int tmvb_train_group_loop(const char* who, H* const* hs, int n, int iter,
             double e_new;
             if ((rc = tmvb_group_elbo(hs, n, ops, &e_new))) return rc;
             TMVB_REQUIRE(std::isfinite(e_new), TMVB_ENONFINITE, "elbo must be finite.");
+            double e_cmp = e_new;
+            if constexpr (tmvb_has_will_check<Ops, H>::value) {
+                // The two forms of update_elbo! evaluate the same sum with different fp32 roundings (5e-8 relative, i.e. ~5 at an ELBO of 1e8) and the stop
+                // rule compares a DIFFERENCE with tol = 1: e_old from the token walk (the baseline of this call, a state set by the host) and e_new from the
+                // decomposed form must not meet in one delta.  At the one switch of a call the new state is evaluated both ways: the walk's value against
+                // e_old, the decomposed one kept for the next delta (and reported).
+                const bool new_parts = ops.elbo_form(hs[0]) == 1;
+                if (new_parts && !old_parts) {
+                    for (int i = 0; i < n; ++i) ops.force_walk(hs[i], true);
+                    rc = tmvb_group_elbo(hs, n, ops, &e_cmp);
+                    for (int i = 0; i < n; ++i) { ops.force_walk(hs[i], false); ops.set_elbo(hs[i], e_new); }
+                    if (rc) return rc;
+                    TMVB_REQUIRE(std::isfinite(e_cmp), TMVB_ENONFINITE, "elbo must be finite.");
+                } else if (!new_parts && old_parts) {
+                    e_old = NAN;                                    // (cannot happen inside one call: every checked iteration collects; keep the rule visible)
+                }
+                old_parts = new_parts;
+            }
             if (elbo_traj) elbo_traj[k - 1] = e_new;
-            const double delta = e_new - e_old;
+            const double delta = std::isnan(e_old) ? INFINITY : e_cmp - e_old;
             e_old = e_new;
             if (delta < tol) break;                                             // signed, quirk Q4
         }
