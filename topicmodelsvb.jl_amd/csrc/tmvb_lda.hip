@@ -1815,6 +1815,7 @@ static int lda_estep_impl(tmvb_lda* h, int32_t viter, double vtol)
         // lengthens it: period 186.8 us against 178.9 (timelines of run r4ag).  Stream priorities for the chain changed nothing either.)
         int rc = tmvb_colsum(ctx, h->nslot, h->K, h->d_elog, h->M, h->d_partial_side, h->d_esum, h->d_stats + (size_t)h->K * h->V, side);
         if (rc) return rc;
+        h->n_elbo_blocks = 0;
         if (collect && h->M > 0) {        // update_elbo!'s per-document half, here: it needs the document kernels' output and the alpha they read, nothing else
             const unsigned nblk = (unsigned)((h->M + 63) / 64);
             const size_t lds = (size_t)3 * 64 * (size_t)h->K * sizeof(float);
@@ -2096,7 +2097,9 @@ static int lda_elbo_enqueue(tmvb_lda* h)
     bool use_pw = false;
     int64_t n_vals = 0;
     h->elbo_form = 0;
-    const bool parts = h->M > 0 && h->logz_valid && h->pw_valid && h->pw_diff && !h->force_walk;
+    // (no condition on this handle's own documents: every rank of a sharded run must take the same form -- train!'s evaluations are collectives -- and an
+    //  empty shard simply has nothing per document)
+    const bool parts = h->logz_valid && h->pw_valid && h->pw_diff && !h->force_walk;
     if (parts) {
         // the decomposed form: the per-document values were enqueued by the E-step itself (side stream: joined above), everything per token was left
         // behind by its statistics passes and by update_beta!
