@@ -967,11 +967,18 @@ __global__ __launch_bounds__(64) void lda_elbo_reg_kernel(int K, const int32_t* 
 // so a checked iteration needs no second walk over the corpus (lda_elbo_reg_kernel: one gathered row and 2 K logarithms per token, 366 us on SYN-NSF
 // K = 50 against a 758 us iteration).  What is left per document is the sum above and the Dirichlet entropy (:72), one psi / lgamma evaluation per
 // (document, topic) in fp64; Elogptheta's dot product (:51) sum_d (alpha - 1) . Elogtheta_d = (alpha - 1) . Elogtheta_sum needs the NEW alpha and goes to
-// lda_elbo_final_kernel.  Nothing here depends on the M-step, so the E-step enqueues this kernel on its side stream right behind the Elogtheta column sums,
-// under the statistics pass (alpha is still the one the E-step read: update_alpha! follows on the same stream).
+// lda_elbo_final_kernel.  Nothing here depends on the M-step, so the E-step enqueues this kernel itself, behind its document kernels on a stream of its own
+// (aux[ELBO]), under the statistics pass and beside the side chain (column sums of Elogtheta, update_alpha!): in a row with them it made that chain the
+// longest of a checked iteration (timeline: column sums 56 us + this kernel 70 us + update_alpha! 44 us against 135 us of statistics tail and M-step).
+// alpha_e is a copy of alpha taken at the start of the E-step (update_alpha! may run while this kernel does).
 // Layout: 64 documents per block, FOUR LANES PER DOCUMENT (topics q, q + 4, ...): the documents' rows of gamma / Elogtheta / Elogtheta_old are contiguous
 // (64 K floats each), staged through LDS with coalesced loads; every lane evaluates ~K / 4 special functions, no cross-lane traffic but two quad steps for
 // sum_k gamma_k (lda_elbo_reg_kernel's lane = topic tail: 2 evaluations per document-wave with 50 of 64 lanes in use).  One fp64 value per block, fixed order.
+__global__ __launch_bounds__(256) void lda_copy_d_kernel(const double* __restrict__ src, double* __restrict__ dst, int n)
+{
+    for (int i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
+}
+
 __global__ __launch_bounds__(256) void lda_elbo_doc_kernel(int K, int64_t M, const double* __restrict__ alpha_e,
                                                            const float* __restrict__ gamma, const float* __restrict__ elog,
                                                            const float* __restrict__ elog_old, double* __restrict__ block_val)
@@ -1164,6 +1171,10 @@ struct tmvb_lda {
     int parts_env = 1;                 // TMVB_LDA_ELBO_PARTS at tmvb_lda_create: 0 never, 1 the iterations train! will check, 2 every E-step
     float* d_logz = nullptr; size_t logz_cap = 0; int64_t n_logz = 0;
     double* d_lz_partial = nullptr;    // [2048] per-block sums of d_logz, by beta_norm_kernel
+    static constexpr int ELBO = 2;     // aux[2]: lda_elbo_doc_kernel's stream
+    double* d_alpha_e = nullptr;       // [K] alpha as the collecting E-step read it (copied at its start on the side stream: ev_acopy)
+    hipEvent_t ev_acopy = nullptr, ev_elbo = nullptr;
+    bool elbo_pending = false;         // ev_elbo marks lda_elbo_doc_kernel: whoever rewrites gamma / Elogtheta or reads its values waits for it (lda_join_side)
     int64_t n_elbo_blocks = 0;         // d_doc_val[0, n_elbo_blocks): lda_elbo_doc_kernel's values, enqueued by that E-step on its side stream
     bool logz_valid = false;           // d_logz[0, n_logz) and those values belong to the last E-step (every statistics pass of it)
     bool pw_diff = false;              // d_pw_partial holds the (log beta_new - log beta_old) form
@@ -1336,6 +1347,10 @@ static int lda_join_side(tmvb_lda* h)
         TMVB_HIP(hipStreamWaitEvent(h->ctx->stream, h->ev_side, 0));
         h->side_pending = false;
     }
+    if (h->elbo_pending) {                                  // lda_elbo_doc_kernel on aux[ELBO] reads gamma / Elogtheta / Elogtheta_old and writes d_doc_val
+        TMVB_HIP(hipStreamWaitEvent(h->ctx->stream, h->ev_elbo, 0));
+        h->elbo_pending = false;
+    }
     return TMVB_OK;
 }
 
@@ -1371,8 +1386,10 @@ extern "C" int tmvb_lda_destroy(tmvb_lda* h)
     if (h->ev_docs) (void)hipEventDestroy(h->ev_docs);
     if (h->ev_side) (void)hipEventDestroy(h->ev_side);
     if (h->ev_chain) (void)hipEventDestroy(h->ev_chain);
+    if (h->ev_acopy) (void)hipEventDestroy(h->ev_acopy);
+    if (h->ev_elbo) (void)hipEventDestroy(h->ev_elbo);
     if (h->ev_mark) (void)hipEventDestroy(h->ev_mark);
-    (void)hipFree(h->d_partial_side); (void)hipFree(h->d_pw_partial); (void)hipFree(h->d_logz); (void)hipFree(h->d_lz_partial);
+    (void)hipFree(h->d_partial_side); (void)hipFree(h->d_pw_partial); (void)hipFree(h->d_logz); (void)hipFree(h->d_lz_partial); (void)hipFree(h->d_alpha_e);
     for (tmvb_inv_index& ix : h->pieces) tmvb_free_inv_index(&ix);
     if (h->ar_index.built) tmvb_free_inv_index(&h->ar_index);
     for (hipEvent_t e : h->ev_slice) if (e) (void)hipEventDestroy(e);
@@ -1501,9 +1518,11 @@ extern "C" int tmvb_lda_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
     TMVB_HIP(hipEventCreateWithFlags(&h->ev_docs, tmvb_event_flags()));
     TMVB_HIP(hipEventCreateWithFlags(&h->ev_side, tmvb_event_flags()));
     TMVB_HIP(hipEventCreateWithFlags(&h->ev_chain, tmvb_event_flags()));
+    TMVB_HIP(hipEventCreateWithFlags(&h->ev_acopy, tmvb_event_flags()));
+    TMVB_HIP(hipEventCreateWithFlags(&h->ev_elbo, tmvb_event_flags()));
     TMVB_HIP(hipEventCreateWithFlags(&h->ev_mark, hipEventDisableTiming /* may sit behind a collective: keeps the system-scope fence */));
     { const char* e = getenv("TMVB_LDA_ELBO_PARTS"); h->parts_env = e ? atoi(e) : 1; }
-    if ((rc = dmalloc(&h->d_partial_side, (size_t)TMVB_REDUCE_BLOCKS * K)) || (rc = dmalloc(&h->d_pw_partial, 2048)) || (rc = dmalloc(&h->d_lz_partial, 2048))) return rc;
+    if ((rc = dmalloc(&h->d_partial_side, (size_t)TMVB_REDUCE_BLOCKS * K)) || (rc = dmalloc(&h->d_pw_partial, 2048)) || (rc = dmalloc(&h->d_lz_partial, 2048)) || (rc = dmalloc(&h->d_alpha_e, (size_t)K))) return rc;
     for (int a = 0; a < tmvb_lda::NAUX; ++a) {
         h->aux[a] = tmvb_pool_stream(ctx->device, 1 + a);
         TMVB_REQUIRE(h->aux[a] != nullptr, TMVB_EHIP, "hipStreamCreate failed");
@@ -1602,7 +1621,7 @@ extern "C" int tmvb_lda_estep(tmvb_lda* h, int32_t viter, double vtol)
         for (int a = 0; a < tmvb_lda::NAUX; ++a) if (h->aux[a]) (void)hipStreamSynchronize(h->aux[a]);
         (void)hipStreamSynchronize(h->ctx->stream);
         (void)hipGetLastError();
-        h->side_pending = false; h->esum_fresh = false; h->esum_side = false; h->stats_fresh = false; h->pw_valid = false; h->mark_valid = false; h->logz_valid = false;
+        h->side_pending = false; h->esum_fresh = false; h->esum_side = false; h->stats_fresh = false; h->pw_valid = false; h->mark_valid = false; h->logz_valid = false; h->elbo_pending = false;
         tmvb_set_error("%s", msg.c_str());
     }
     return rc;
@@ -1643,6 +1662,10 @@ static int lda_estep_impl(tmvb_lda* h, int32_t viter, double vtol)
     hipStream_t chain_st = (h->reg_path && (P == 1 || !chain_aux)) ? ctx->stream : h->aux[0];
     const bool shadow_stats = P > 1 && chain_st == ctx->stream;       // passes 0 .. P-2 on aux[0]
     if (chain_st == ctx->stream) { int jrc = lda_join_side(h); if (jrc) return jrc; }   // update_alpha! of the last iteration
+    if (h->elbo_pending) {                                  // (the chain on aux[0]: the document kernels there rewrite what lda_elbo_doc_kernel reads)
+        TMVB_HIP(hipStreamWaitEvent(ctx->stream, h->ev_elbo, 0));
+        h->elbo_pending = false;
+    }
     TMVB_HIP(hipEventRecord(h->ev_fork, ctx->stream));
     for (int a = 0; a < 2; ++a) {
         // every stream that carries document kernels waits for the fork event, i.e. for the previous iteration's M-step on
@@ -1817,11 +1840,24 @@ static int lda_estep_impl(tmvb_lda* h, int32_t viter, double vtol)
         if (rc) return rc;
         h->n_elbo_blocks = 0;
         if (collect && h->M > 0) {        // update_elbo!'s per-document half, here: it needs the document kernels' output and the alpha they read, nothing else
+            // the alpha this E-step read (update_alpha! may overtake the kernel): copied on the side stream, i.e. in front of this iteration's update_alpha!
+            // in stream order -- and enqueued HERE, behind every document-kernel launch in host order (a checked iteration starts with the host behind the
+            // device: whatever it enqueues first delays the first document kernel)
+            hipLaunchKernelGGL(lda_copy_d_kernel, dim3(1), dim3(256), 0, side, (const double*)h->d_alpha_d, h->d_alpha_e, h->K);
+            TMVB_HIP(hipGetLastError());
+            TMVB_HIP(hipEventRecord(h->ev_acopy, side));
             const unsigned nblk = (unsigned)((h->M + 63) / 64);
             const size_t lds = (size_t)3 * 64 * (size_t)h->K * sizeof(float);
             if (lds > 48 * 1024) TMVB_HIP(hipFuncSetAttribute((const void*)lda_elbo_doc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(lda_elbo_doc_kernel, dim3(nblk), dim3(256), lds, side, h->K, h->M, h->d_alpha_d, h->d_gamma, h->d_elog, h->d_elog_old, h->d_doc_val);
+            static const bool own_stream = [] { const char* e = getenv("TMVB_LDA_ELBO_STREAM"); return !(e && atoi(e) == 0); }();   // 0: in a row on the side stream (A/B)
+            hipStream_t es = own_stream ? h->aux[tmvb_lda::ELBO] : side;
+            TMVB_HIP(hipStreamWaitEvent(es, h->ev_chain, 0));     // every document kernel, as the side chain above
+            TMVB_HIP(hipStreamWaitEvent(es, h->ev_join[1], 0));
+            TMVB_HIP(hipStreamWaitEvent(es, h->ev_acopy, 0));
+            hipLaunchKernelGGL(lda_elbo_doc_kernel, dim3(nblk), dim3(256), lds, es, h->K, h->M, (const double*)h->d_alpha_e, h->d_gamma, h->d_elog, h->d_elog_old, h->d_doc_val);
             TMVB_HIP(hipGetLastError());
+            TMVB_HIP(hipEventRecord(h->ev_elbo, es));
+            h->elbo_pending = true;
             h->n_elbo_blocks = nblk;
         }
         TMVB_HIP(hipEventRecord(h->ev_side, side));
@@ -2180,7 +2216,7 @@ extern "C" int tmvb_lda_set_comm(tmvb_lda* h, tmvb_comm* comm, int64_t M_total)
         for (int a = 0; a < tmvb_lda::NAUX; ++a) TMVB_HIP(remake(h->ev_join[a]));
         for (hipEvent_t& ev : h->ev_piece) TMVB_HIP(remake(ev));
         for (hipEvent_t& ev : h->ev_slice) TMVB_HIP(remake(ev));
-        h->side_pending = false; h->mark_valid = false;
+        h->side_pending = false; h->mark_valid = false; h->elbo_pending = false;
         h->events_system_scope = true;
     }
     return TMVB_OK;
