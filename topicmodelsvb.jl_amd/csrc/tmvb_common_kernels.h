@@ -290,14 +290,14 @@ static __global__ __launch_bounds__(256) void beta_norm_kernel(float* __restrict
                                                             float* __restrict__ beta_new, int K, int KP, int64_t V,
                                                             double* __restrict__ pw_partial, float eps, const float* __restrict__ beta_old = nullptr,
                                                             float eps_old = -1.0f,       // the epsilon inside log(beta_old + .): < 0 = eps (LDA), 0 for CTM
-                                                            const float* __restrict__ logz = nullptr, int64_t n_logz = 0, double* __restrict__ lz_partial = nullptr)
+                                                            const double* __restrict__ logz = nullptr, int64_t n_logz = 0, double* __restrict__ lz_partial = nullptr)
 {
     if (eps_old < 0.0f) eps_old = eps;
     if (lz_partial) {                            // this block's slice of the statistics passes' per-chunk sums of c log2 s (TermStatsParams::logz), fixed order
         const int64_t per = (n_logz + gridDim.x - 1) / gridDim.x;
         const int64_t b = (int64_t)blockIdx.x * per, e = b + per < n_logz ? b + per : n_logz;
         double lz = 0.0;
-        for (int64_t i = b + threadIdx.x; i < e; i += blockDim.x) lz += (double)logz[i];
+        for (int64_t i = b + threadIdx.x; i < e; i += blockDim.x) lz += logz[i];
         lz = wave_sum_d(lz);
         __shared__ double lred[4];
         if ((threadIdx.x & 63) == 0) lred[threadIdx.x >> 6] = lz;
@@ -319,7 +319,9 @@ static __global__ __launch_bounds__(256) void beta_norm_kernel(float* __restrict
             const float sv = S[j * K + i];
             o = (float)((double)sv * rinv[i]);
             // (S = 0 contributes 0: CTM's phi has no epsilon, so a zero beta_old entry has S = 0 and log 0 must not meet it)
-            if (pw_partial) pw += beta_old ? (sv != 0.0f ? (double)sv * ((double)logf(o + eps) - (double)logf(beta_old[q] + eps_old)) : 0.0)
+            // (the decomposed form takes its two logarithms in fp64: S weighs them with up to 1e4 per entry, and fp32 logarithms left +- 0.2 of rounding
+            //  on an ELBO whose increments the stop rule compares with 1)
+            if (pw_partial) pw += beta_old ? (sv != 0.0f ? (double)sv * (log((double)(o + eps)) - log((double)(beta_old[q] + eps_old))) : 0.0)
                                            : (double)sv * (double)logf(o + eps);
             S[j * K + i] = 0.0f;
         }

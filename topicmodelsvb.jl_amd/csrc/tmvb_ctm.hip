@@ -1347,13 +1347,13 @@ __global__ __launch_bounds__(64) void ctm_elbo_kernel(int K, int KP, const int64
 }
 
 // the decomposed update_elbo!: sum of the per-document values + ln 2 * the chunks' log2-normaliser sums + this shard's share of update_beta!'s partial
-__global__ __launch_bounds__(1024) void ctm_elbo_final_kernel(const double* __restrict__ doc_val, int64_t M, const float* __restrict__ logz, int64_t n_logz,
+__global__ __launch_bounds__(1024) void ctm_elbo_final_kernel(const double* __restrict__ doc_val, int64_t M, const double* __restrict__ logz, int64_t n_logz,
                                                               const double* __restrict__ pw_partial, int pw_blocks, double pw_share, double* __restrict__ out)
 {
     __shared__ double red[1024];
     double s = 0.0, lz = 0.0, pw = 0.0;
     for (int64_t d = threadIdx.x; d < M; d += 1024) s += doc_val[d];
-    for (int64_t i = threadIdx.x; i < n_logz; i += 1024) lz += (double)logz[i];
+    for (int64_t i = threadIdx.x; i < n_logz; i += 1024) lz += logz[i];
     for (int b = threadIdx.x; b < pw_blocks; b += 1024) pw += pw_partial[b];
     red[threadIdx.x] = s + 0.6931471805599453 * lz + pw_share * pw;
     __syncthreads();
@@ -1430,7 +1430,7 @@ struct tmvb_ctm {
     // 0: never) has its statistics pass leave sum c log2 s per chunk (d_logz), its document kernels sum_i (phi counts)_i (lambda_i - lambda_old_i) per
     // document (d_pdot), and update_beta! sum S (log(beta_new + eps) - log beta_old) (d_pw_partial); update_elbo! then skips its token loop.
     int parts_env = 1; bool want_parts = false;
-    float* d_logz = nullptr; size_t logz_cap = 0; int64_t n_logz = 0; float* d_pdot = nullptr; double* d_pw_partial = nullptr; int pw_blocks = 0;
+    double* d_logz = nullptr; size_t logz_cap = 0; int64_t n_logz = 0; float* d_pdot = nullptr; double* d_pw_partial = nullptr; int pw_blocks = 0;
     bool logz_valid = false, stats_fresh = false, pw_valid = false;
     int elbo_form = 0; bool force_walk = false;
     int64_t stats_len() const { return (int64_t)K * V + 2 * K + (int64_t)K * K; }

@@ -1314,14 +1314,14 @@ __global__ __launch_bounds__(128) void ctpf_elbo_doc_parts_kernel(int K, int64_t
 
 // out[0] = sum doc_val + ln 2 * sum logz (the documents' part), out[1] = sum partial + constant - sum_i (dlog bet_i PC_i + dlog vav_i PA_i) (the global part)
 __global__ __launch_bounds__(1024) void ctpf_elbo_final_parts_kernel(const double* __restrict__ doc_val, int64_t M, const double* __restrict__ partial, int npartial,
-                                                                     double constant, const float* __restrict__ logz, int64_t n_logz,
+                                                                     double constant, const double* __restrict__ logz, int64_t n_logz,
                                                                      const double* __restrict__ lrates_d, const double* __restrict__ rs_alef,
                                                                      const double* __restrict__ sum_g, int K, double Va, double Mc, double* __restrict__ out)
 {
     __shared__ double red[2][1024];
     double s = 0.0, g = 0.0, lz = 0.0;
     for (int64_t d = threadIdx.x; d < M; d += 1024) s += doc_val[d];
-    for (int64_t i = threadIdx.x; i < n_logz; i += 1024) lz += (double)logz[i];
+    for (int64_t i = threadIdx.x; i < n_logz; i += 1024) lz += logz[i];
     for (int q = threadIdx.x; q < npartial; q += 1024) g += partial[q];
     for (int i = threadIdx.x; i < K; i += 1024) {
         const double pc = rs_alef[i] - Va, pa = (sum_g[i] - Mc) - pc;
@@ -1355,7 +1355,7 @@ struct tmvb_ctpf {
     // decomposed update_elbo! (ctpf_elbo_doc_parts_kernel): TMVB_CTPF_ELBO_PARTS at creation -- 1 (default) the iterations train! will check, 2 every E-step,
     // 0 never.  A collecting E-step leaves the softmax shifts (d_shift) and the statistics passes' log-normaliser sums (d_logz: term chunks, then reader chunks).
     int parts_env = 1; bool want_parts = false; bool logz_valid = false; int msteps_after = 0; int elbo_form = 0; bool force_walk = false;
-    float* d_shift = nullptr; float* d_logz = nullptr; int64_t n_logz = 0; double* d_crd = nullptr;
+    float* d_shift = nullptr; double* d_logz = nullptr; int64_t n_logz = 0; double* d_crd = nullptr;
     unsigned int* d_mstep_counter = nullptr;                        // last-block-done counter of the fused M-step (zero between launches)
     bool docs_pending = false;                                     // tmvb_ctpf_reduce_docs was asked for and deferred into the fused M-step (K <= 64, one context)
     float* d_gimel = nullptr; float* d_gimel_old = nullptr; float* d_zayin = nullptr; float* d_zayin_old = nullptr;
@@ -2015,7 +2015,7 @@ extern "C" int tmvb_ctpf_update_elbo_parts(tmvb_ctpf* h, double* doc_part, doubl
         }
         TMVB_HIP(hipGetLastError());
         hipLaunchKernelGGL(ctpf_elbo_final_parts_kernel, dim3(1), dim3(1024), 0, ctx->stream, h->d_doc_val, h->M, h->d_elbo_partial, 2 * nb, cst,
-                           (const float*)h->d_logz, h->n_logz, (const double*)h->d_lrates_d, (const double*)h->d_rs_alef, (const double*)h->d_sum_g, h->K,
+                           (const double*)h->d_logz, h->n_logz, (const double*)h->d_lrates_d, (const double*)h->d_rs_alef, (const double*)h->d_sum_g, h->K,
                            (double)h->V * hy[0], (double)h->M * hy[2], h->d_elbo);
         TMVB_HIP(hipGetLastError());
         TMVB_HIP(hipMemcpyAsync(res, h->d_elbo, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

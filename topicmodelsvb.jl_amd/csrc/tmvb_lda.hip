@@ -1169,7 +1169,7 @@ struct tmvb_lda {
     // leave sum S (log beta_new - log beta_old); update_elbo! then needs one per-document kernel instead of a second walk over the corpus.
     bool want_parts = false;           // set for the coming iteration
     int parts_env = 1;                 // TMVB_LDA_ELBO_PARTS at tmvb_lda_create: 0 never, 1 the iterations train! will check, 2 every E-step
-    float* d_logz = nullptr; size_t logz_cap = 0; int64_t n_logz = 0;
+    double* d_logz = nullptr; size_t logz_cap = 0; int64_t n_logz = 0;
     double* d_lz_partial = nullptr;    // [2048] per-block sums of d_logz, by beta_norm_kernel
     static constexpr int ELBO = 2;     // aux[2]: lda_elbo_doc_kernel's stream
     double* d_alpha_e = nullptr;       // [K] alpha as the collecting E-step read it (copied at its start on the side stream: ev_acopy)
@@ -2079,7 +2079,7 @@ extern "C" int tmvb_lda_update_beta(tmvb_lda* h)
     hipLaunchKernelGGL(beta_norm_kernel, dim3(nb), dim3(256), (size_t)h->K * sizeof(double), ctx->stream,
                        h->d_stats, h->d_rowsum, h->d_beta[h->cur ^ 1], h->K, h->KP, h->V, h->d_pw_partial, TMVB_EPS_F,
                        parts ? (const float*)h->d_beta[h->cur] : (const float*)nullptr, -1.0f,
-                       parts ? (const float*)h->d_logz : (const float*)nullptr, h->n_logz, h->d_lz_partial);
+                       parts ? (const double*)h->d_logz : (const double*)nullptr, h->n_logz, h->d_lz_partial);
     TMVB_HIP(hipGetLastError());
     h->pw_blocks = nb;
     h->pw_diff = parts;

@@ -36,8 +36,10 @@ struct TermStatsParams {
     float base;                  // value added to every written entry (CTPF priors a / e; else 0)
     float* out;                  // [n_ids][ostride]
     float* partial;              // [n_slots][K + 1]  raw (sum w E | sum w) of multi-chunk ids
-    float* logz = nullptr;       // [n_chunks] or NULL (LOGZ instantiations of the recompute kernels): per chunk sum_n val_n * log2(s_n), the token
-                                 // normalisers' share of update_elbo! (src/LDA.jl:78, :87-88; see lda_elbo_doc_kernel in tmvb_lda.hip)
+    double* logz = nullptr;      // [n_chunks] or NULL (LOGZ instantiations of the recompute kernels): per chunk sum_n val_n * log2(s_n), the token
+                                 // normalisers' share of update_elbo! (src/LDA.jl:78, :87-88; see lda_elbo_doc_kernel in tmvb_lda.hip).  Accumulated in
+                                 // fp64 from the fp32 products: in fp32 the chunk sums' rounding added up to +- 0.2 on an ELBO of -1e8 -- as much as the
+                                 // increments check_elbo!'s stop rule (delta < tol = 1) looks at near the plateau
 };
 
 template <int NSLOT>
@@ -197,7 +199,8 @@ __device__ __forceinline__ void termstats_recompute_cpl_body(const TermStatsPara
     }
     const char* __restrict__ Eb = (const char*)p.E;
     const uint32_t esb = (uint32_t)p.estride * 4u, lane_off = 16u * (uint32_t)cc;
-    float wl = 0.0f, ll = 0.0f;
+    float wl = 0.0f;
+    double ll = 0.0;
     for (int t0 = b; t0 < e; t0 += 64) {
         const int tok = t0 + lane;
         const bool valid = tok < e;
@@ -233,7 +236,7 @@ __device__ __forceinline__ void termstats_recompute_cpl_body(const TermStatsPara
                 if (LANES >= 16) part += dpp_f<0x140>(part);          // every lane of the slot holds s_n - keps
                 float wz = __builtin_bit_cast(float, dw[u].y) * __builtin_amdgcn_rcpf(part + p.keps);
                 wz = (k0 + u * SLOTS + rs < cnt) ? wz : 0.0f;
-                if constexpr (LOGZ) ll += (k0 + u * SLOTS + rs < cnt) ? __builtin_bit_cast(float, dw[u].y) * __builtin_amdgcn_logf(part + p.keps) : 0.0f;
+                if constexpr (LOGZ) ll += (k0 + u * SLOTS + rs < cnt) ? (double)(__builtin_bit_cast(float, dw[u].y) * __builtin_amdgcn_logf(part + p.keps)) : 0.0;
                 const v2f w2 = v2f{wz, wz};
 #pragma unroll
                 for (int q = 0; q < CPL; ++q) {
@@ -256,7 +259,7 @@ __device__ __forceinline__ void termstats_recompute_cpl_body(const TermStatsPara
 #pragma unroll
             for (int v = 0; v < 4; ++v) tot[q][v] += dpp_f<0x124>(tot[q][v]);     // row_ror:4
         wsum += dpp_f<0x124>(wsum);
-        if constexpr (LOGZ) ll += dpp_f<0x124>(ll);
+        if constexpr (LOGZ) ll += __shfl_xor(ll, 4, 64);          // (lanes cc, cc + 4, cc + 8, cc + 12 of a row, as the two rotations)
     }
     if (LANES <= 8) {
 #pragma unroll
@@ -264,7 +267,7 @@ __device__ __forceinline__ void termstats_recompute_cpl_body(const TermStatsPara
 #pragma unroll
             for (int v = 0; v < 4; ++v) tot[q][v] += dpp_f<0x128>(tot[q][v]);     // row_ror:8
         wsum += dpp_f<0x128>(wsum);
-        if constexpr (LOGZ) ll += dpp_f<0x128>(ll);
+        if constexpr (LOGZ) ll += __shfl_xor(ll, 8, 64);
     }
 #pragma unroll
     for (int o = 16; o <= 32; o <<= 1) {
@@ -339,7 +342,8 @@ __device__ __forceinline__ void termstats_recompute_body(const TermStatsParams& 
     typedef float v2f __attribute__((ext_vector_type(2)));
     const v2f tlo = v2f{tj.x, tj.y}, thi = v2f{tj.z, tj.w};
     v2f alo = v2f{0.f, 0.f}, ahi = v2f{0.f, 0.f};          // packed fp32 accumulators (v_pk_fma_f32)
-    float wl = 0.0f, ll = 0.0f;
+    float wl = 0.0f;
+    double ll = 0.0;
     for (int t0 = b; t0 < e; t0 += 64) {
         const int tok = t0 + lane;
         const bool valid = tok < e;
@@ -390,7 +394,7 @@ __device__ __forceinline__ void termstats_recompute_body(const TermStatsParams& 
                     }
                     float wz = __builtin_bit_cast(float, dw[u].y) * __builtin_amdgcn_rcpf(part + p.keps);
                     wz = (k0 + u * SLOTS + rs < cnt) ? wz : 0.0f;
-                    if constexpr (LOGZ) ll += (k0 + u * SLOTS + rs < cnt) ? __builtin_bit_cast(float, dw[u].y) * __builtin_amdgcn_logf(part + p.keps) : 0.0f;
+                    if constexpr (LOGZ) ll += (k0 + u * SLOTS + rs < cnt) ? (double)(__builtin_bit_cast(float, dw[u].y) * __builtin_amdgcn_logf(part + p.keps)) : 0.0;
                     const v2f w2 = v2f{wz, wz};
                     alo = __builtin_elementwise_fma(w2, elo, alo);
                     ahi = __builtin_elementwise_fma(w2, ehi, ahi);
@@ -431,7 +435,7 @@ __device__ __forceinline__ void termstats_recompute_body(const TermStatsParams& 
                     part += sib;                                  // every lane of the slot holds s_n - keps
                 }
                 const float wz = row_on ? fast_div(__builtin_bit_cast(float, dw[u].y), part + p.keps) : 0.0f;
-                if constexpr (LOGZ) ll += row_on ? __builtin_bit_cast(float, dw[u].y) * __builtin_amdgcn_logf(part + p.keps) : 0.0f;
+                if constexpr (LOGZ) ll += row_on ? (double)(__builtin_bit_cast(float, dw[u].y) * __builtin_amdgcn_logf(part + p.keps)) : 0.0;
                 const v2f w2 = v2f{wz, wz};
                 alo = __builtin_elementwise_fma(w2, elo, alo);
                 ahi = __builtin_elementwise_fma(w2, ehi, ahi);
