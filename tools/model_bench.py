@@ -192,24 +192,23 @@ def ctm(burnin=60, warmup=2, steps=8, cpu=True, K=50):        # 60 burn-in itera
     # a checked iteration as train! runs it (checkelbo = 1): the same model with every E-step collecting the ELBO's parts (TMVB_CTM_ELBO_PARTS=2)
     checked = None
     if K == 50:
-        os.environ["TMVB_CTM_ELBO_PARTS"] = "2"
+        import ctypes as C
         gc = tm.gpuCTM(pc, K)
-        del os.environ["TMVB_CTM_ELBO_PARTS"]
         gc.beta = np.asfortranarray(beta0); gc.beta_old = gc.beta.copy(order="F"); gc.update_buffer()
+        L = tm._lib.lib()
 
-        def itc():
-            gc.estep(); gc.reduce_docs(); gc.update_beta(); gc.update_sigma(); gc.update_mu()
-        for _ in range(12):
-            itc()
-        gc.update_elbo(); gc.synchronize(); t0 = time.perf_counter()
-        for _ in range(6):
-            itc()
+        def train_c(n, ce):                                     # the library's own train! loop (tmvb_ctm_train), no Python between the kernels
+            buf = np.full(n, np.nan); done, base = C.c_int32(0), C.c_double(0.0)
+            tm._lib.check(L.tmvb_ctm_train(gc.handle, C.c_int32(n), C.c_double(0.0), C.c_int32(1000), C.c_double(1.0 / K ** 2), C.c_int32(10),
+                                           C.c_double(1.0 / K ** 2), C.c_int32(ce), buf.ctypes.data_as(C.POINTER(C.c_double)), C.byref(done), C.byref(base)))
+        train_c(12, 0)
+        gc.synchronize(); t0 = time.perf_counter()
+        train_c(8, 0)
         gc.synchronize(); t1 = time.perf_counter()
-        for _ in range(6):
-            itc(); gc.update_elbo()
+        train_c(16, 1)                                          # (a call's baseline evaluation and its one doubled evaluation inside: 2 x 1.5 ms over 16 iterations)
         gc.synchronize(); t2 = time.perf_counter()
-        checked = {"ms_per_step_same_window": 1e3 * (t1 - t0) / 6, "ms_per_checked_step": 1e3 * (t2 - t1) / 6,
-                   "elbo_form": "decomposed" if gc.elbo_form() == 1 else "token walk", "window": "iterations 13..18 / 19..24 from the cold start"}
+        checked = {"ms_per_step_same_window": 1e3 * (t1 - t0) / 8, "ms_per_checked_step": 1e3 * (t2 - t1) / 16,
+                   "elbo_form": "decomposed" if gc.elbo_form() == 1 else "token walk", "window": "iterations 13..20 unchecked / 21..36 checked from the cold start"}
         gc.close()
     line = {"metric": f"VB iters/sec, CTM K={K} on NSF-shaped corpus" + (" (config 4)" if K == 50 else ""), "value": 1.0 / sec, "unit": "VB iters/sec",
             "ms_per_step": 1e3 * sec, "estep_ms": es_ms, "checked": checked, "dtype": "f32 (fp64 gradients / logzeta / vsq)", "data": "synthetic",
@@ -287,28 +286,30 @@ def ctpf(burnin=300, warmup=10, steps=200, cpu=True):
         gt.reduce_docs(); gt.mstep()
     es_ms = float(np.mean(es))
     gt.close()
-    # a checked iteration as train! runs it under its default checkelbo = 1 (update_elbo! on the device after every M-step): a model whose every E-step
-    # collects the ELBO's parts, as train!'s checked iterations do (TMVB_CTPF_ELBO_PARTS=2), brought to the same state;
-    # the first call builds the per-document constants
-    os.environ["TMVB_CTPF_ELBO_PARTS"] = "2"
+    # a checked iteration as train! runs it under its default checkelbo = 1 (update_elbo! on the device after every M-step): the
+    # library's own loop (tmvb_ctpf_train, no Python between the kernels) on a second model brought to the same steady state -- 200 unchecked, then 200 checked iterations; a call's baseline evaluation and its one doubled evaluation at the switch of forms (tmvb_train.h) are inside: < 1 %
+    import ctypes as C
     gc = tm.gpuCTPF(pc, K)
-    del os.environ["TMVB_CTPF_ELBO_PARTS"]
+    L = tm._lib.lib()
 
-    def itc():
-        gc.estep(); gc.reduce_docs(); gc.mstep()
-    for _ in range(60):
-        itc()
-    gc.update_elbo()
+    def train_c(n, ce):
+        buf = np.full(n, np.nan); done, base = C.c_int32(0), C.c_double(0.0)
+        tm._lib.check(L.tmvb_ctpf_train(gc.handle, C.c_int32(n), C.c_double(0.0), C.c_int32(10), C.c_double(1.0 / K ** 2), C.c_int32(ce),
+                                        buf.ctypes.data_as(C.POINTER(C.c_double)), C.byref(done), C.byref(base)))
+    train_c(burnin, 0); train_c(10, 1)                         # the same steady state as the window above (and the per-document constants)
     gc.synchronize(); t0 = time.perf_counter()
-    for _ in range(20):
-        itc(); gc.update_elbo()
-    gc.synchronize(); checked = (time.perf_counter() - t0) / 20
+    train_c(200, 0)
+    gc.synchronize(); t1 = time.perf_counter()
+    train_c(200, 1)
+    gc.synchronize(); t2 = time.perf_counter()
+    checked, unchecked_same = (t2 - t1) / 200, (t1 - t0) / 200
     elbo_form = gc.elbo_form()
     gc.close()
     B = pc.nnz * (8 + 8 * K) + pc.nR * (8 + 8 * K) + 16 * pc.M * K + 12 * K * (pc.V + pc.U)
     ms_s, ms_r = gm.recommend(scores=False)
     line = {"metric": "VB iters/sec, CTPF K=50 on CiteULike-shaped corpus (config 5)", "value": 1.0 / sec, "unit": "VB iters/sec",
-            "ms_per_step": 1e3 * sec, "estep_ms": es_ms, "ms_per_checked_step": 1e3 * checked, "checked_elbo_form": "decomposed" if elbo_form == 1 else "table form",
+            "ms_per_step": 1e3 * sec, "estep_ms": es_ms, "ms_per_checked_step": 1e3 * checked, "ms_per_step_train_loop": 1e3 * unchecked_same,
+            "checked_elbo_form": "decomposed" if elbo_form == 1 else "table form",
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"CTPF K=50, SYN-CITEU with readers, train! defaults (viter=10 vtol=1/K^2 checkelbo=Inf), steady state: {burnin} untimed "
                                    f"iterations from the cold start, then {warmup} warm-up + {steps} timed",
