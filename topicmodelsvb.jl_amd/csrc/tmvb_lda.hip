@@ -1826,6 +1826,14 @@ static int lda_estep_impl(tmvb_lda* h, int32_t viter, double vtol)
         // the side chain needs every document kernel: the chain's (ev_chain) and the long documents' (ev_join[1]) -- waited for
         // directly, not through ev_piece[P - 1], which the chain stream records only after ITS join with aux[1]: one cross-stream
         // hop (~20 us) less in front of update_alpha!, which on a small shard is what the next iteration waits for
+        if (collect && h->M > 0) {
+            // the alpha this E-step read, for lda_elbo_doc_kernel (update_alpha! may overtake that kernel): copied on the side stream, i.e. in front of this
+            // iteration's update_alpha! in stream order and in front of the side chain's waits -- and enqueued HERE, behind every document-kernel launch in
+            // host order (a checked iteration starts with the host behind the device: whatever it enqueues first delays the first document kernel)
+            hipLaunchKernelGGL(lda_copy_d_kernel, dim3(1), dim3(256), 0, side, (const double*)h->d_alpha_d, h->d_alpha_e, h->K);
+            TMVB_HIP(hipGetLastError());
+            TMVB_HIP(hipEventRecord(h->ev_acopy, side));
+        }
         TMVB_HIP(hipStreamWaitEvent(side, h->ev_chain, 0));
         TMVB_HIP(hipStreamWaitEvent(side, h->ev_join[1], 0));
     }
@@ -1840,12 +1848,7 @@ static int lda_estep_impl(tmvb_lda* h, int32_t viter, double vtol)
         if (rc) return rc;
         h->n_elbo_blocks = 0;
         if (collect && h->M > 0) {        // update_elbo!'s per-document half, here: it needs the document kernels' output and the alpha they read, nothing else
-            // the alpha this E-step read (update_alpha! may overtake the kernel): copied on the side stream, i.e. in front of this iteration's update_alpha!
-            // in stream order -- and enqueued HERE, behind every document-kernel launch in host order (a checked iteration starts with the host behind the
-            // device: whatever it enqueues first delays the first document kernel)
-            hipLaunchKernelGGL(lda_copy_d_kernel, dim3(1), dim3(256), 0, side, (const double*)h->d_alpha_d, h->d_alpha_e, h->K);
-            TMVB_HIP(hipGetLastError());
-            TMVB_HIP(hipEventRecord(h->ev_acopy, side));
+
             const unsigned nblk = (unsigned)((h->M + 63) / 64);
             const size_t lds = (size_t)3 * 64 * (size_t)h->K * sizeof(float);
             if (lds > 48 * 1024) TMVB_HIP(hipFuncSetAttribute((const void*)lda_elbo_doc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
