@@ -1252,34 +1252,29 @@ __global__ __launch_bounds__(1024) void ctpf_elbo_final2_kernel(const double* __
 //                    with PC_i = sum_d sum_n c phi = rowsum(alef)_i - V a  and  PA_i = sum_d (gimel_di - c) - PC_i  -- the split of gimel - c into its
 //                    term and reader halves is only needed summed over the documents, where the M-step has it.
 // No entry is walked: the two table kernels and the entry sums of ctpf_elbo_doc_fast_kernel (70 of its 109 us on SYN-CITEU) go away.
-// Layout as lda_elbo_doc_kernel: CTPF_ELBO_DPB = 16 documents per block of 128 threads, EIGHT LANES PER DOCUMENT (topics q, q + 8, ...: four fp64 special
-// functions per (document, topic) are latency-bound chains -- with four lanes per document and one wave per SIMD the kernel took 40 us on SYN-CITEU); the rows of gimel / gimel_old /
-// zayin / zayin_old are contiguous and staged through LDS with coalesced loads, the per-topic coefficients (reciprocal rates times row sums, logarithms of the
-// rates and their changes) are computed once per block.  One fp64 value per document, summed by the final kernel.
+// Everything per document that depends on the RATES is linear in per-topic coefficients times sum_d gimel_d / sum_d zayin_d, which the M-step has; what is left
+// per (document, topic) depends on gimel / gimel_old / zayin / zayin_old only:
+//     R = sum_{d,i} [ (c - 1) psi(gi) + (g - 1) psi(za) + gi + lgamma(gi) + (1 - gi) psi(gi) + za + lgamma(za) + (1 - za) psi(za)
+//                     + (gi - c)(psi(gi) - psi(gi_old)) + (za - g)(psi(za) - psi(za_old)) ]  +  sum_d [ doc_const - lg_doc[d] + C_d mx_d + R_d mab_d ]
+// so this kernel needs nothing of the M-step and the E-step enqueues it on a stream of its own behind its document kernels, under the statistics pass (as
+// lda_elbo_doc_kernel); ctpf_elbo_final_parts_kernel adds the rate terms in closed form.
+// Layout: CTPF_ELBO_DPB = 16 documents per block of 128 threads, EIGHT LANES PER DOCUMENT (topics q, q + 8, ...: four fp64 special functions per (document, topic)
+// are latency-bound chains -- with four lanes per document and one wave per SIMD the kernel took 40 us on SYN-CITEU); rows staged through LDS with coalesced
+// loads.  One fp64 value per block, fixed order.
 constexpr int CTPF_ELBO_LPD = 8, CTPF_ELBO_DPB = 128 / CTPF_ELBO_LPD;
-__global__ __launch_bounds__(128) void ctpf_elbo_doc_parts_kernel(int K, int64_t M, const double* __restrict__ rates /* [8][K] */, const double* __restrict__ lrates_d,
-                                                                  const double* __restrict__ rs_alef, const double* __restrict__ rs_he,
-                                                                  const float* __restrict__ gimel, const float* __restrict__ gimel_old,
+__global__ __launch_bounds__(128) void ctpf_elbo_doc_parts_kernel(int K, int64_t M, const float* __restrict__ gimel, const float* __restrict__ gimel_old,
                                                                   const float* __restrict__ zayin, const float* __restrict__ zayin_old,
                                                                   const double* __restrict__ lg_doc, const double* __restrict__ crd /* [M][2] */,
                                                                   const float* __restrict__ shift /* [M][2] */,
-                                                                  double hc, double hd, double hg, double hh, double doc_const, double* __restrict__ doc_val)
+                                                                  double hc, double hg, double doc_const, double* __restrict__ block_val)
 {
-    extern __shared__ __attribute__((aligned(16))) double smd[];   // [6][K] coefficients, then [4][DPB K] floats
-    double* cA = smd; double* cZ = smd + K; double* lD = smd + 2 * K; double* lH = smd + 3 * K; double* dD = smd + 4 * K; double* dHV = smd + 5 * K;
+    extern __shared__ __attribute__((aligned(16))) float smf[];   // [4][DPB K]
+    __shared__ double red[2];
     constexpr int DPB = CTPF_ELBO_DPB, LPD = CTPF_ELBO_LPD;
-    float* sg = (float*)(smd + 6 * K); float* sgo = sg + DPB * K; float* sz = sg + 2 * DPB * K; float* szo = sg + 3 * DPB * K;
+    float* sg = smf; float* sgo = sg + DPB * K; float* sz = sg + 2 * DPB * K; float* szo = sg + 3 * DPB * K;
     const int tid = threadIdx.x;
     const int64_t d0 = (int64_t)blockIdx.x * DPB;
     const int nd = (int)min((int64_t)DPB, M - d0);
-    for (int i = tid; i < K; i += 128) {
-        const double r_bet = tmvb_rcp_d(rates[i]), r_vav = tmvb_rcp_d(rates[K + i]), r_dalet = tmvb_rcp_d(rates[2 * K + i]), r_het = tmvb_rcp_d(rates[3 * K + i]);
-        cA[i] = r_dalet * r_vav * rs_he[i] + r_dalet * r_bet * rs_alef[i] + hd * r_dalet;     // :112, :134 and Elogptheta's rate term :156, per unit of gimel
-        cZ[i] = r_het * r_vav * rs_he[i] + hh * r_het;                                        // :123 and Elogpepsilon's :174, per unit of zayin
-        lD[i] = lrates_d[2 * K + i]; lH[i] = lrates_d[3 * K + i];
-        dD[i] = lrates_d[2 * K + i] - lrates_d[6 * K + i];
-        dHV[i] = (lrates_d[3 * K + i] - lrates_d[7 * K + i]) + (lrates_d[K + i] - lrates_d[5 * K + i]);
-    }
     {
         const int n = nd * K, n4 = n >> 2;                     // DPB K floats per block: 16-byte aligned
         const float4* a4 = (const float4*)(gimel + d0 * K); const float4* b4 = (const float4*)(gimel_old + d0 * K);
@@ -1297,35 +1292,47 @@ __global__ __launch_bounds__(128) void ctpf_elbo_doc_parts_kernel(int K, int64_t
             double psi_g, lg_g, psi_z, lg_z;
             digamma_lgamma_d(gi, psi_g, lg_g);
             digamma_lgamma_d(za, psi_z, lg_z);
-            acc -= gi * cA[k] + za * cZ[k];
-            acc += (hc - 1.0) * (psi_g - lD[k]) + (hg - 1.0) * (psi_z - lH[k]);            // Elogptheta :156, Elogpepsilon :174 (shape terms)
-            acc += (gi - lD[k] + lg_g + (1.0 - gi) * psi_g) + (za - lH[k] + lg_z + (1.0 - za) * psi_z);   // -Elogqtheta, -Elogqepsilon: Gamma entropies
-            acc += (gi - hc) * ((psi_g - dgo) - dD[k]);                                    // the entries' per-document share (see above)
-            acc += (za - hg) * ((psi_z - dzo) - dHV[k]);
+            acc += (hc - 1.0) * psi_g + (hg - 1.0) * psi_z;                                   // Elogptheta :156, Elogpepsilon :174 (the psi terms)
+            acc += (gi + lg_g + (1.0 - gi) * psi_g) + (za + lg_z + (1.0 - za) * psi_z);       // -Elogqtheta, -Elogqepsilon: Gamma entropies without the rates
+            acc += (gi - hc) * (psi_g - dgo) + (za - hg) * (psi_z - dzo);                     // the entries' per-document share (see above)
+        }
+        if (q == 0) {
+            const int64_t d = d0 + dl;
+            acc += doc_const - lg_doc[d] + crd[2 * d] * (double)shift[2 * d] + crd[2 * d + 1] * (double)shift[2 * d + 1];
         }
     }
-#pragma unroll
-    for (int o = 1; o < LPD; o <<= 1) acc += __shfl_xor(acc, o, 64);
-    if (dl < nd && q == 0) {
-        const int64_t d = d0 + dl;
-        doc_val[d] = acc + doc_const - lg_doc[d] + crd[2 * d] * (double)shift[2 * d] + crd[2 * d + 1] * (double)shift[2 * d + 1];
-    }
+    acc = wave_sum_d(acc);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) block_val[blockIdx.x] = red[0] + red[1];
 }
 
-// out[0] = sum doc_val + ln 2 * sum logz (the documents' part), out[1] = sum partial + constant - sum_i (dlog bet_i PC_i + dlog vav_i PA_i) (the global part)
-__global__ __launch_bounds__(1024) void ctpf_elbo_final_parts_kernel(const double* __restrict__ doc_val, int64_t M, const double* __restrict__ partial, int npartial,
-                                                                     double constant, const double* __restrict__ logz, int64_t n_logz,
-                                                                     const double* __restrict__ lrates_d, const double* __restrict__ rs_alef,
-                                                                     const double* __restrict__ sum_g, int K, double Va, double Mc, double* __restrict__ out)
+// out[0] = sum of the blocks' values + ln 2 * sum logz + the documents' rate terms in closed form (the documents' part),
+// out[1] = sum partial + constant - sum_i (dlog bet_i PC_i + dlog vav_i PA_i) (the global part).  With SG = sum_d gimel_d, SZ = sum_d zayin_d:
+//   - sum_i [ (SG_i / dalet_i)(rs_he_i / vav_i + rs_alef_i / bet_i + d) + (SZ_i / het_i)(rs_he_i / vav_i + h) ]              :112,:123,:134, :156, :174
+//   - M sum_i [ c log dalet_i + g log het_i ]                                        (Elogptheta / Elogpepsilon's and the Gamma entropies' log-rate terms)
+//   - sum_i (SG_i - M c)(log dalet_i - log dalet_old_i) - sum_i (SZ_i - M g)(log het_i - log het_old_i + log vav_i - log vav_old_i)
+__global__ __launch_bounds__(1024) void ctpf_elbo_final_parts_kernel(const double* __restrict__ block_val, int64_t n_blocks, double Md, const double* __restrict__ partial,
+                                                                     int npartial, double constant, const double* __restrict__ logz, int64_t n_logz,
+                                                                     const double* __restrict__ rates, const double* __restrict__ lrates_d,
+                                                                     const double* __restrict__ rs_alef, const double* __restrict__ rs_he,
+                                                                     const double* __restrict__ sum_g, const double* __restrict__ sum_z, int K, double Va,
+                                                                     double hc, double hd, double hg, double hh, double* __restrict__ out)
 {
     __shared__ double red[2][1024];
     double s = 0.0, g = 0.0, lz = 0.0;
-    for (int64_t d = threadIdx.x; d < M; d += 1024) s += doc_val[d];
+    for (int64_t b = threadIdx.x; b < n_blocks; b += 1024) s += block_val[b];
     for (int64_t i = threadIdx.x; i < n_logz; i += 1024) lz += logz[i];
     for (int q = threadIdx.x; q < npartial; q += 1024) g += partial[q];
     for (int i = threadIdx.x; i < K; i += 1024) {
-        const double pc = rs_alef[i] - Va, pa = (sum_g[i] - Mc) - pc;
-        g -= (lrates_d[i] - lrates_d[4 * K + i]) * pc + (lrates_d[K + i] - lrates_d[5 * K + i]) * pa;
+        const double r_bet = tmvb_rcp_d(rates[i]), r_vav = tmvb_rcp_d(rates[K + i]), r_dalet = tmvb_rcp_d(rates[2 * K + i]), r_het = tmvb_rcp_d(rates[3 * K + i]);
+        const double l_bet = lrates_d[i], l_vav = lrates_d[K + i], l_dalet = lrates_d[2 * K + i], l_het = lrates_d[3 * K + i];
+        const double SG = sum_g[i], SZ = sum_z[i];
+        s -= SG * r_dalet * (rs_he[i] * r_vav + rs_alef[i] * r_bet + hd) + SZ * r_het * (rs_he[i] * r_vav + hh);
+        s -= Md * (hc * l_dalet + hg * l_het);
+        s -= (SG - Md * hc) * (l_dalet - lrates_d[6 * K + i]) + (SZ - Md * hg) * ((l_het - lrates_d[7 * K + i]) + (l_vav - lrates_d[5 * K + i]));
+        const double pc = rs_alef[i] - Va, pa = (SG - Md * hc) - pc;
+        g -= (l_bet - lrates_d[4 * K + i]) * pc + (l_vav - lrates_d[5 * K + i]) * pa;
     }
     red[0][threadIdx.x] = s + 0.6931471805599453 * lz; red[1][threadIdx.x] = g;
     __syncthreads();
@@ -1356,6 +1363,10 @@ struct tmvb_ctpf {
     // 0 never.  A collecting E-step leaves the softmax shifts (d_shift) and the statistics passes' log-normaliser sums (d_logz: term chunks, then reader chunks).
     int parts_env = 1; bool want_parts = false; bool logz_valid = false; int msteps_after = 0; int elbo_form = 0; bool force_walk = false;
     float* d_shift = nullptr; double* d_logz = nullptr; int64_t n_logz = 0; double* d_crd = nullptr;
+    static constexpr int ELBO = 0;                                 // aux[0]: ctpf_elbo_doc_parts_kernel's stream (enqueued by the collecting E-step behind the join of
+                                                                   // the document kernels: aux[0] is idle by then.  aux[2] landed on the context stream's own hardware
+                                                                   // queue -- rocprofv3: the kernel ran IN FRONT of the statistics pass instead of beside it)
+    hipEvent_t ev_docs_done = nullptr, ev_elbo = nullptr; bool elbo_pending = false; int64_t n_elbo_blocks = 0;
     unsigned int* d_mstep_counter = nullptr;                        // last-block-done counter of the fused M-step (zero between launches)
     bool docs_pending = false;                                     // tmvb_ctpf_reduce_docs was asked for and deferred into the fused M-step (K <= 64, one context)
     float* d_gimel = nullptr; float* d_gimel_old = nullptr; float* d_zayin = nullptr; float* d_zayin_old = nullptr;
@@ -1406,6 +1417,8 @@ extern "C" int tmvb_ctpf_destroy(tmvb_ctpf* h)
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_docs_done) (void)hipEventDestroy(h->ev_docs_done);
+    if (h->ev_elbo) (void)hipEventDestroy(h->ev_elbo);
     for (int a = 0; a < tmvb_ctpf::NAUX; ++a) {
         if (h->ev_join[a]) (void)hipEventDestroy(h->ev_join[a]);
         tmvb_release_stream(h->aux[a]); h->aux[a] = nullptr;        // pooled streams stay (tmvb_pool_stream)
@@ -1544,6 +1557,8 @@ extern "C" int tmvb_ctpf_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmv
     TMVB_HIP(hipEventCreate(&h->ev0));
     TMVB_HIP(hipEventCreate(&h->ev1));
     TMVB_HIP(hipEventCreateWithFlags(&h->ev_fork, tmvb_event_flags()));
+    TMVB_HIP(hipEventCreateWithFlags(&h->ev_docs_done, tmvb_event_flags()));
+    TMVB_HIP(hipEventCreateWithFlags(&h->ev_elbo, tmvb_event_flags()));
     for (int a = 0; a < tmvb_ctpf::NAUX; ++a) {
         // aux[1] carries the few multi-wave (long) documents next to the chain's one big launch: at the default priority its 512-thread
         // workgroups find no CU with eight free wave slots until the chain's launch drains and then add their whole run time to the
@@ -1581,6 +1596,7 @@ extern "C" int tmvb_ctpf_set_state(tmvb_ctpf* h, const double* hyper, const doub
     }
     if (alef || he) h->rs_fresh = false;
     h->logz_valid = false;
+    if (h->elbo_pending) { TMVB_HIP(hipStreamWaitEvent(ctx->stream, h->ev_elbo, 0)); h->elbo_pending = false; }   // (it reads gimel / zayin)
     if (alef) {
         TMVB_REQUIRE(positive_finite(alef, KV), TMVB_ENONFINITE, "alef must be positive.");
         if ((rc = upload_f32(ctx, h->d_alef, alef, KV)) || (rc = upload_f32(ctx, h->d_alef_old, alef, KV))) return rc;
@@ -1628,6 +1644,7 @@ extern "C" int tmvb_ctpf_set_state_old(tmvb_ctpf* h, const double* alef_old, con
     TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_ctpf_set_state_old: handle is NULL");
     h->logz_valid = false;
     tmvb_ctx* ctx = h->ctx;
+    if (h->elbo_pending) { TMVB_HIP(hipSetDevice(ctx->device)); TMVB_HIP(hipStreamWaitEvent(ctx->stream, h->ev_elbo, 0)); h->elbo_pending = false; }
     TMVB_HIP(hipSetDevice(ctx->device));
     const size_t K = h->K, KM = K * (size_t)h->M, KV = K * (size_t)h->V, KU = K * (size_t)h->U;
     int rc;
@@ -1684,6 +1701,27 @@ extern "C" int tmvb_ctpf_get_state(tmvb_ctpf* h, double* alef, double* alef_old,
     return TMVB_OK;
 }
 
+// the corpus constants of update_elbo!: sum lgamma(count + 1) + sum lgamma(rating + 1), C_d, R_d per document (first use)
+static int ctpf_elbo_consts(tmvb_ctpf* h)
+{
+    if (h->d_lg_doc) return TMVB_OK;
+    tmvb_ctx* ctx = h->ctx;
+    int rc;
+    if ((rc = dmalloc(&h->d_lrates_d, 8 * (size_t)h->K)) || (rc = dmalloc(&h->d_lg_doc, (size_t)h->M)) || (rc = dmalloc(&h->d_crd, 2 * (size_t)h->M))) return rc;
+    std::vector<double> lg((size_t)h->M, 0.0), crd(2 * (size_t)h->M, 0.0);
+    const tmvb_corpus* c = h->corp;
+    for (int64_t d = 0; d < h->M; ++d) {
+        double v = 0.0, cd = 0.0, rd = 0.0;
+        for (int64_t q = c->h_doc_ptr[d]; q < c->h_doc_ptr[d + 1]; ++q) { v += std::lgamma((double)c->h_counts[q] + 1.0); cd += (double)c->h_counts[q]; }
+        for (int64_t q = c->h_rdr_ptr[d]; q < c->h_rdr_ptr[d + 1]; ++q) { v += std::lgamma((double)c->h_ratings[q] + 1.0); rd += (double)c->h_ratings[q]; }
+        lg[(size_t)d] = v; crd[2 * (size_t)d] = cd; crd[2 * (size_t)d + 1] = rd;
+    }
+    TMVB_HIP(hipMemcpyAsync(h->d_lg_doc, lg.data(), lg.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    TMVB_HIP(hipMemcpyAsync(h->d_crd, crd.data(), crd.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    TMVB_HIP(hipStreamSynchronize(ctx->stream));
+    return TMVB_OK;
+}
+
 extern "C" int tmvb_ctpf_estep(tmvb_ctpf* h, int32_t viter, double vtol)
 {
     TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_ctpf_estep: handle is NULL");
@@ -1705,7 +1743,12 @@ extern "C" int tmvb_ctpf_estep(tmvb_ctpf* h, int32_t viter, double vtol)
     const bool collect = (h->parts_env == 2 || (h->parts_env != 0 && h->want_parts)) && p.store_w == 0 && viter > 0 && !h->distributed && h->M > 0;
     h->logz_valid = false; h->msteps_after = 0;
     const int64_t nct = h->corp->term_index.n_chunks, ncr = h->U > 0 ? h->corp->reader_index.n_chunks : 0;
+    if (h->elbo_pending) {                                   // ctpf_elbo_doc_parts_kernel of the last collecting E-step still reads gimel / zayin
+        TMVB_HIP(hipStreamWaitEvent(ctx->stream, h->ev_elbo, 0));
+        h->elbo_pending = false;
+    }
     if (collect) {
+        { int crc = ctpf_elbo_consts(h); if (crc) return crc; }
         if (!h->d_shift) { int arc = dmalloc(&h->d_shift, 2 * (size_t)h->M); if (arc) return arc; }
         if (!h->d_logz) { int arc = dmalloc(&h->d_logz, (size_t)std::max<int64_t>(nct + ncr, 1)); if (arc) return arc; }
         p.shift = h->d_shift;
@@ -1798,6 +1841,23 @@ extern "C" int tmvb_ctpf_estep(tmvb_ctpf* h, int32_t viter, double vtol)
         if (a == 0 && !aux0_used) continue;                   // aux[0] carried nothing in this plan
         TMVB_HIP(hipEventRecord(h->ev_join[a], h->aux[a]));
         TMVB_HIP(hipStreamWaitEvent(ctx->stream, h->ev_join[a], 0));
+    }
+    h->n_elbo_blocks = 0;
+    if (collect) {                                           // update_elbo!'s per-document sums: everything they need is there now (every document kernel joined)
+        const double* hy = h->hyper;
+        const unsigned nblk = (unsigned)((h->M + CTPF_ELBO_DPB - 1) / CTPF_ELBO_DPB);
+        const size_t lds = (size_t)4 * CTPF_ELBO_DPB * h->K * sizeof(float);
+        hipStream_t es = h->aux[tmvb_ctpf::ELBO];
+        TMVB_HIP(hipEventRecord(h->ev_docs_done, ctx->stream));
+        TMVB_HIP(hipStreamWaitEvent(es, h->ev_docs_done, 0));
+        if (lds > 48 * 1024) TMVB_HIP(hipFuncSetAttribute((const void*)ctpf_elbo_doc_parts_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(ctpf_elbo_doc_parts_kernel, dim3(nblk), dim3(128), lds, es, h->K, h->M, (const float*)h->d_gimel, (const float*)h->d_gimel_old,
+                           (const float*)h->d_zayin, (const float*)h->d_zayin_old, (const double*)h->d_lg_doc, (const double*)h->d_crd, (const float*)h->d_shift,
+                           hy[2], hy[6], (double)h->K * (hy[2] * std::log(hy[3]) - std::lgamma(hy[2])) + (double)h->K * (hy[6] * std::log(hy[7]) - std::lgamma(hy[6])),
+                           h->d_doc_val);
+        TMVB_HIP(hipGetLastError());
+        TMVB_HIP(hipEventRecord(h->ev_elbo, es));
+        h->elbo_pending = true; h->n_elbo_blocks = nblk;
     }
     // update_alef!(model, d) / update_he!(model, d) (src/CTPF.jl:259-262, :274-277) as gather-side statistics
     TermStatsParams tp;
@@ -1980,20 +2040,7 @@ extern "C" int tmvb_ctpf_update_elbo_parts(tmvb_ctpf* h, double* doc_part, doubl
     // the decomposed form: the last E-step collected its parts and exactly one M-step ran behind it (alef_old / he_old / the old rates are that E-step's)
     const bool parts = h->M > 0 && !legacy_elbo && h->logz_valid && h->msteps_after == 1 && !h->distributed && !h->force_walk;
     h->elbo_form = parts ? 1 : 0;
-    if (h->M > 0 && !legacy_elbo && !h->d_lg_doc) {       // first call: the corpus constants
-        if ((rc = dmalloc(&h->d_lrates_d, 8 * (size_t)h->K)) || (rc = dmalloc(&h->d_lg_doc, (size_t)h->M)) || (rc = dmalloc(&h->d_crd, 2 * (size_t)h->M))) return rc;
-        std::vector<double> lg((size_t)h->M, 0.0), crd(2 * (size_t)h->M, 0.0);
-        const tmvb_corpus* c = h->corp;
-        for (int64_t d = 0; d < h->M; ++d) {
-            double v = 0.0, cd = 0.0, rd = 0.0;
-            for (int64_t q = c->h_doc_ptr[d]; q < c->h_doc_ptr[d + 1]; ++q) { v += std::lgamma((double)c->h_counts[q] + 1.0); cd += (double)c->h_counts[q]; }
-            for (int64_t q = c->h_rdr_ptr[d]; q < c->h_rdr_ptr[d + 1]; ++q) { v += std::lgamma((double)c->h_ratings[q] + 1.0); rd += (double)c->h_ratings[q]; }
-            lg[(size_t)d] = v; crd[2 * (size_t)d] = cd; crd[2 * (size_t)d + 1] = rd;
-        }
-        TMVB_HIP(hipMemcpyAsync(h->d_lg_doc, lg.data(), lg.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        TMVB_HIP(hipMemcpyAsync(h->d_crd, crd.data(), crd.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        TMVB_HIP(hipStreamSynchronize(ctx->stream));
-    }
+    if (h->M > 0 && !legacy_elbo && (rc = ctpf_elbo_consts(h))) return rc;
     // global part: partial sums now, added up by the one final kernel behind the per-document part (one copy, one synchronisation)
     const int nb = 256;
     hipLaunchKernelGGL(ctpf_elbo_global_kernel, dim3(nb), dim3(256), 0, ctx->stream, h->d_alef, h->V, h->K, h->d_rates, hy[0], hy[1], h->d_elbo_partial,
@@ -2003,20 +2050,16 @@ extern "C" int tmvb_ctpf_update_elbo_parts(tmvb_ctpf* h, double* doc_part, doubl
                        parts ? (const float*)h->d_he_old : (const float*)nullptr, (const double*)nullptr, (double*)nullptr);
     TMVB_HIP(hipGetLastError());
     const double cst = (double)h->V * h->K * (hy[0] * std::log(hy[1]) - std::lgamma(hy[0])) + (double)h->U * h->K * (hy[4] * std::log(hy[5]) - std::lgamma(hy[4]));
-    const double doc_cst = (double)h->K * (hy[2] * std::log(hy[3]) - std::lgamma(hy[2])) + (double)h->K * (hy[6] * std::log(hy[7]) - std::lgamma(hy[6]));
     // per-document part
     if (parts) {
-        {
-            const size_t lds = (size_t)6 * h->K * sizeof(double) + (size_t)4 * CTPF_ELBO_DPB * h->K * sizeof(float);
-            if (lds > 48 * 1024) TMVB_HIP(hipFuncSetAttribute((const void*)ctpf_elbo_doc_parts_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(ctpf_elbo_doc_parts_kernel, dim3((unsigned)((h->M + CTPF_ELBO_DPB - 1) / CTPF_ELBO_DPB)), dim3(128), lds, ctx->stream, h->K, h->M, (const double*)h->d_rates,
-                               (const double*)h->d_lrates_d, (const double*)h->d_rs_alef, (const double*)h->d_rs_he, h->d_gimel, h->d_gimel_old, h->d_zayin,
-                               h->d_zayin_old, (const double*)h->d_lg_doc, (const double*)h->d_crd, (const float*)h->d_shift, hy[2], hy[3], hy[6], hy[7], doc_cst, h->d_doc_val);
+        if (h->elbo_pending) {                               // the per-document sums, enqueued by the E-step on aux[ELBO]
+            TMVB_HIP(hipStreamWaitEvent(ctx->stream, h->ev_elbo, 0));
+            h->elbo_pending = false;
         }
-        TMVB_HIP(hipGetLastError());
-        hipLaunchKernelGGL(ctpf_elbo_final_parts_kernel, dim3(1), dim3(1024), 0, ctx->stream, h->d_doc_val, h->M, h->d_elbo_partial, 2 * nb, cst,
-                           (const double*)h->d_logz, h->n_logz, (const double*)h->d_lrates_d, (const double*)h->d_rs_alef, (const double*)h->d_sum_g, h->K,
-                           (double)h->V * hy[0], (double)h->M * hy[2], h->d_elbo);
+        hipLaunchKernelGGL(ctpf_elbo_final_parts_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const double*)h->d_doc_val, h->n_elbo_blocks, (double)h->M,
+                           (const double*)h->d_elbo_partial, 2 * nb, cst, (const double*)h->d_logz, h->n_logz, (const double*)h->d_rates, (const double*)h->d_lrates_d,
+                           (const double*)h->d_rs_alef, (const double*)h->d_rs_he, (const double*)h->d_sum_g, (const double*)h->d_sum_z, h->K,
+                           (double)h->V * hy[0], hy[2], hy[3], hy[6], hy[7], h->d_elbo);
         TMVB_HIP(hipGetLastError());
         TMVB_HIP(hipMemcpyAsync(res, h->d_elbo, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         TMVB_HIP(hipStreamSynchronize(ctx->stream));
