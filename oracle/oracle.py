@@ -120,6 +120,38 @@ def trigamma(x):
     return o.reshape(np.shape(x))
 
 
+# ---- oracle/_ref: the reference's own fp32 digamma (src/utils.jl:21-53, `const DIGAMMA_c`), compiled here from the reference tree
+_REF_DIR = os.path.join(_HERE, "_ref")
+_REF_LIB_PATH = os.path.join(_REF_DIR, "libref_digamma.so")
+_REFERENCE_ROOT = os.environ.get("TMVB_REFERENCE_ROOT", "/root/reference")
+_ref_lib = None
+
+
+def build_ref(force: bool = False):
+    """oracle/_ref/Makefile: cuts DIGAMMA_c out of <reference>/src/utils.jl into a temporary directory and compiles it unmodified.
+    Returns the library's path, or None when neither the reference tree nor a prebuilt library is there (the GPU box has only
+    the prebuilt file: it travels with the snapshot)."""
+    src = os.path.join(_REFERENCE_ROOT, "src", "utils.jl")
+    if os.path.exists(src) and (force or not os.path.exists(_REF_LIB_PATH)
+                                or os.path.getmtime(_REF_LIB_PATH) < max(os.path.getmtime(os.path.join(_HERE, "ref_digamma_wrap.c")),
+                                                                         os.path.getmtime(os.path.join(_REF_DIR, "Makefile")))):
+        subprocess.check_call(["make", "-C", _REF_DIR, "-s", "-B", "REF=" + _REFERENCE_ROOT])
+    return _REF_LIB_PATH if os.path.exists(_REF_LIB_PATH) else None
+
+
+def ref_digamma_f32(x):
+    """The reference's fp32 digamma helper itself, on an array (float32 in, float32 out)."""
+    global _ref_lib
+    if _ref_lib is None:
+        path = build_ref()
+        if path is None:
+            raise FileNotFoundError("oracle/_ref/libref_digamma.so is missing and there is no reference tree to build it from")
+        _ref_lib = C.CDLL(path)
+    flat = np.ascontiguousarray(np.asarray(x, dtype=np.float32).ravel()); o = np.empty_like(flat)
+    _ref_lib.ref_digamma_f32_vec(flat.ctypes.data_as(C.c_void_p), o.ctypes.data_as(C.c_void_p), c_i64(flat.size))
+    return o.reshape(np.shape(x))
+
+
 class CSR:
     """Packed corpus (0-based ids): doc_ptr int64[M+1], terms/counts int32[nnz], optional readers."""
 

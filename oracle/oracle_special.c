@@ -5,8 +5,9 @@
  * own fp32 OpenCL helper (src/utils.jl:21-53) spells out the same recurrence-to-x>=7 +
  * 8-coefficient asymptotic series, which anchors the digamma coefficients.
  *
- * TEST INFRASTRUCTURE ONLY (see tmvb_oracle.h).  PARITY UNPINNED (no reference vectors);
- * checked against mpmath to 1e-14 in tests/test_oracle_special.py.
+ * TEST INFRASTRUCTURE ONLY (see tmvb_oracle.h).  PARITY UNPINNED (no reference vectors) except orc_digamma, which
+ * tests/test_oracle_special.py checks at fp32 accuracy against that OpenCL helper compiled from the reference tree
+ * (oracle/_ref/Makefile); all three are checked against mpmath to 1e-14 there.
  */
 #include "tmvb_oracle.h"
 #include <float.h>

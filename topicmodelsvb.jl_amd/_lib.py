@@ -111,17 +111,40 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    # Register / scratch budget of the kernels behind the benched numbers (tools/kernel_resources.py: the code objects' own metadata): a benched
-    # kernel that starts spilling to scratch -- or the CTM lane kernel growing past its recorded 428 B -- fails the build instead of the next profile.
+    # Register / scratch budget of the kernels behind the benched numbers (tools/kernel_resources.py: the code objects' own metadata).  A performance
+    # DIAGNOSTIC, not a functional gate (round-5 advice): its ceilings are exact figures of one hipcc release, and an already linked, correct library
+    # must stay usable on another.  By default a finding is a warning on stderr; TMVB_STRICT_KERNEL_RESOURCES=1 (this repository's own rounds and CI:
+    # tests/test_kernel_resources.py asserts the same on the shipped library) turns it into a build failure.  Skipped without llvm-readelf or a demangler.
     kres = os.path.join(_ROOT, "tools", "kernel_resources.py")
     if os.path.exists(kres) and not _VARIANT:
+        LAST_BUILD_KRES = _kernel_resource_check(kres, verbose)
+    else:
+        LAST_BUILD_KRES = "skipped"
+    LAST_BUILD = {"mode": "compiled", "compiled": compiled, "linked": True, "kernel_resources": LAST_BUILD_KRES}
+    return LIB_PATH
+
+
+def _kernel_resource_check(kres: str, verbose: bool = False) -> str:
+    """Runs tools/kernel_resources.py --check on the linked library.  Returns "ok", "skipped (...)" or "warned"; raises only under
+    TMVB_STRICT_KERNEL_RESOURCES=1."""
+    import shutil
+    readelf = os.environ.get("LLVM_READELF", "/opt/rocm/lib/llvm/bin/llvm-readelf")
+    filt = any(os.path.exists(e) for e in ("/opt/rocm/lib/llvm/bin/llvm-cxxfilt", "/usr/bin/c++filt")) or shutil.which("c++filt")
+    if not (os.path.exists(readelf) or shutil.which(readelf)) or not filt:
+        return "skipped (no llvm-readelf / c++filt on this machine)"
+    try:
         res = subprocess.run([sys.executable, kres, "--check", LIB_PATH], capture_output=True, text=True)
-        if res.returncode != 0:
-            raise EngineError("kernel resource check failed:\n" + res.stdout[-2000:])
+    except OSError as e:
+        return f"skipped ({e})"
+    if res.returncode == 0:
         if verbose:
             print(res.stdout.strip().splitlines()[-1])
-    LAST_BUILD = {"mode": "compiled", "compiled": compiled, "linked": True}
-    return LIB_PATH
+        return "ok"
+    msg = "kernel resource check (tools/kernel_resources.py --check):\n" + (res.stdout[-2000:] + res.stderr[-2000:]).strip()
+    if os.environ.get("TMVB_STRICT_KERNEL_RESOURCES", "") not in ("", "0"):
+        raise EngineError(msg)
+    print("WARNING: " + msg + "\n(performance diagnostic only: the library is built and usable; TMVB_STRICT_KERNEL_RESOURCES=1 makes this fatal)", file=sys.stderr)
+    return "warned"
 
 
 _lib = None

@@ -2182,7 +2182,7 @@ struct CtmTrainOps {
     }
     int elbo_local(tmvb_ctm* h, double* s, double* once) { *once = 0.0; return tmvb_ctm_update_elbo(h, s); }
     int elbo_form(tmvb_ctm* h) { return h->elbo_form; }
-    void force_walk(tmvb_ctm* h, bool on) { h->force_walk = on; if (!on) h->elbo_form = 1; }   // (switched off behind the one evaluation that doubled a decomposed one)
+    void force_walk(tmvb_ctm* h, bool on, bool doubled = true) { h->force_walk = on; if (!on && doubled) h->elbo_form = 1; }   // (switched off behind the one evaluation that doubled a decomposed one)
     void will_check(tmvb_ctm* h, bool checked) { h->want_parts = checked; }             // the coming iteration ends in check_elbo!
     double* elbo_dev(tmvb_ctm* h) { return h->d_elbo; }
     tmvb_comm* comm(tmvb_ctm* h) { return h->comm; }

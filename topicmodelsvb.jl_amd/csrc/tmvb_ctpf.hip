@@ -1361,6 +1361,7 @@ struct tmvb_ctpf {
     bool rs_fresh = false;                                         // d_rs_alef / d_rs_he are the row sums of the current alef / he
     // decomposed update_elbo! (ctpf_elbo_doc_parts_kernel): TMVB_CTPF_ELBO_PARTS at creation -- 1 (default) the iterations train! will check, 2 every E-step,
     // 0 never.  A collecting E-step leaves the softmax shifts (d_shift) and the statistics passes' log-normaliser sums (d_logz: term chunks, then reader chunks).
+    int lds_limit = -1; int elbo_lds_set = 0;                      // the device's per-workgroup LDS limit (read once); dynamic-LDS attribute already set
     int parts_env = 1; bool want_parts = false; bool logz_valid = false; int msteps_after = 0; int elbo_form = 0; bool force_walk = false;
     float* d_shift = nullptr; double* d_logz = nullptr; int64_t n_logz = 0; double* d_crd = nullptr;
     static constexpr int ELBO = 0;                                 // aux[0]: ctpf_elbo_doc_parts_kernel's stream (enqueued by the collecting E-step behind the join of
@@ -1740,7 +1741,15 @@ extern "C" int tmvb_ctpf_estep(tmvb_ctpf* h, int32_t viter, double vtol)
     p.viter = viter; p.vtol = (float)vtol;
     p.store_w = tmvb_termstats_recomputes(h->KP, h->e_padded) ? 0 : 1;
     // decomposed update_elbo!: this iteration will be checked -- the document kernels leave their softmax shifts, the statistics passes the log-normaliser sums
-    const bool collect = (h->parts_env == 2 || (h->parts_env != 0 && h->want_parts)) && p.store_w == 0 && viter > 0 && !h->distributed && h->M > 0;
+    // ctpf_elbo_doc_parts_kernel stages 4 x CTPF_ELBO_DPB rows of K floats in dynamic LDS; a device whose per-workgroup limit is below that (K > 256 on a
+    // 64 KB part; gfx950: 160 KB) does not collect, and update_elbo! takes the table form (round-5 advice)
+    if (h->lds_limit < 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, ctx->device) != hipSuccess || v <= 0) { (void)hipGetLastError(); v = 64 * 1024; }
+        h->lds_limit = v;
+    }
+    const bool collect = (h->parts_env == 2 || (h->parts_env != 0 && h->want_parts)) && p.store_w == 0 && viter > 0 && !h->distributed && h->M > 0 &&
+                         (size_t)4 * CTPF_ELBO_DPB * h->K * sizeof(float) <= (size_t)h->lds_limit;
     h->logz_valid = false; h->msteps_after = 0;
     const int64_t nct = h->corp->term_index.n_chunks, ncr = h->U > 0 ? h->corp->reader_index.n_chunks : 0;
     if (h->elbo_pending) {                                   // ctpf_elbo_doc_parts_kernel of the last collecting E-step still reads gimel / zayin
@@ -1850,7 +1859,10 @@ extern "C" int tmvb_ctpf_estep(tmvb_ctpf* h, int32_t viter, double vtol)
         hipStream_t es = h->aux[tmvb_ctpf::ELBO];
         TMVB_HIP(hipEventRecord(h->ev_docs_done, ctx->stream));
         TMVB_HIP(hipStreamWaitEvent(es, h->ev_docs_done, 0));
-        if (lds > 48 * 1024) TMVB_HIP(hipFuncSetAttribute((const void*)ctpf_elbo_doc_parts_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (lds > 48 * 1024 && (int)lds > h->elbo_lds_set) {
+            TMVB_HIP(hipFuncSetAttribute((const void*)ctpf_elbo_doc_parts_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            h->elbo_lds_set = (int)lds;
+        }
         hipLaunchKernelGGL(ctpf_elbo_doc_parts_kernel, dim3(nblk), dim3(128), lds, es, h->K, h->M, (const float*)h->d_gimel, (const float*)h->d_gimel_old,
                            (const float*)h->d_zayin, (const float*)h->d_zayin_old, (const double*)h->d_lg_doc, (const double*)h->d_crd, (const float*)h->d_shift,
                            hy[2], hy[6], (double)h->K * (hy[2] * std::log(hy[3]) - std::lgamma(hy[2])) + (double)h->K * (hy[6] * std::log(hy[7]) - std::lgamma(hy[6])),
@@ -2153,7 +2165,7 @@ struct CtpfTrainOps {
     // the per-document part adds up over the shards; the (beta, eta) part is global and identical on every rank
     int elbo_local(tmvb_ctpf* h, double* s, double* once) { return tmvb_ctpf_update_elbo_parts(h, s, once); }
     int elbo_form(tmvb_ctpf* h) { return h->elbo_form; }
-    void force_walk(tmvb_ctpf* h, bool on) { h->force_walk = on; if (!on) h->elbo_form = 1; }   // (switched off behind the one evaluation that doubled a decomposed one)
+    void force_walk(tmvb_ctpf* h, bool on, bool doubled = true) { h->force_walk = on; if (!on && doubled) h->elbo_form = 1; }   // (switched off behind the one evaluation that doubled a decomposed one)
     void will_check(tmvb_ctpf* h, bool checked) { h->want_parts = checked; }          // the coming iteration ends in check_elbo!
     double* elbo_dev(tmvb_ctpf* h) { return h->d_elbo; }
     tmvb_comm* comm(tmvb_ctpf* h) { return h->comm; }

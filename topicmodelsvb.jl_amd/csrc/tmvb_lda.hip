@@ -1109,6 +1109,8 @@ struct tmvb_lda {
     bool stats_b_live = false;         // d_stats_b holds statistics that d_stats does not
     bool events_system_scope = false;  // a communicator was attached: the ordering events carry the system-scope fence (tmvb_lda_set_comm)
     bool own_stats = true;
+    int lds_limit = -1;                // hipDeviceAttributeMaxSharedMemoryPerBlock of the context's device (read once)
+    int elbo_doc_lds_set = 0;          // dynamic-LDS attribute already set on lda_elbo_doc_kernel
     float* d_gamma = nullptr;
     float* d_elog = nullptr;
     float* d_elog_old = nullptr;
@@ -1622,6 +1624,12 @@ extern "C" int tmvb_lda_estep(tmvb_lda* h, int32_t viter, double vtol)
         (void)hipStreamSynchronize(h->ctx->stream);
         (void)hipGetLastError();
         h->side_pending = false; h->esum_fresh = false; h->esum_side = false; h->stats_fresh = false; h->pw_valid = false; h->mark_valid = false; h->logz_valid = false; h->elbo_pending = false;
+        if (h->d_stats_b) {                                 // the last pass's own buffer may hold a partial pass: the next E-step's merge must not fold it in
+            (void)hipMemsetAsync(h->d_stats_b, 0, (size_t)h->K * h->V * sizeof(float), h->ctx->stream);
+            (void)hipStreamSynchronize(h->ctx->stream);
+            (void)hipGetLastError();
+        }
+        h->stats_b_live = false;
         tmvb_set_error("%s", msg.c_str());
     }
     return rc;
@@ -1688,8 +1696,17 @@ static int lda_estep_impl(tmvb_lda* h, int32_t viter, double vtol)
     };
     // Decomposed update_elbo! (lda_elbo_doc_kernel): an iteration that will be checked has its statistics passes leave sum c log2 s per chunk
     const int parts_env = h->parts_env;                          // TMVB_LDA_ELBO_PARTS, read per model
+    // lda_elbo_doc_kernel stages 3 x 64 rows of K floats in dynamic LDS (95 KB at K = 124; gfx950 has 160 KB per workgroup).  On a device whose limit is
+    // below that (round-5 advice) the iteration does not collect, and update_elbo! takes the token walk instead of failing with TMVB_EHIP.
+    const size_t elbo_doc_lds = (size_t)3 * 64 * (size_t)h->K * sizeof(float);
+    if (h->lds_limit < 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, ctx->device) != hipSuccess || v <= 0) { (void)hipGetLastError(); v = 64 * 1024; }
+        h->lds_limit = v;
+    }
     const bool collect = (parts_env == 2 || (parts_env != 0 && h->want_parts)) && tmvb_termstats_recomputes(h->KP, h->e_padded) && !(p.debug & 1) &&
-                         viter > 0;                                 // (viter = 0: the document kernels leave E = 0, not the factor update_elbo! rebuilds phi from)
+                         viter > 0 &&                               // (viter = 0: the document kernels leave E = 0, not the factor update_elbo! rebuilds phi from)
+                         elbo_doc_lds <= (size_t)h->lds_limit;
     std::vector<int64_t> logz_off((size_t)P + 1, 0);
     auto stats_index = [&](int q) -> const tmvb_inv_index& {      // the index piece q's pass walks (tmvb_lda_estep_allreduce: its slice-major rebuild)
         return (h->ar_live && q == P - 1 && h->pieces.empty()) ? h->ar_index : piece_index(q);
@@ -1712,7 +1729,9 @@ static int lda_estep_impl(tmvb_lda* h, int32_t viter, double vtol)
     // starts at once; the join with aux[0] moves behind it, and update_beta!'s column-sum pass adds the two buffers on its way.  One context only (a
     // sharded handle all-reduces d_stats); TMVB_LDA_SPLIT_OUT=0: the round-4 order.
     static const bool split_out_env = [] { const char* e = getenv("TMVB_LDA_SPLIT_OUT"); return !(e && atoi(e) == 0); }();
-    bool split_out = split_out_env && shadow_stats && !h->distributed && h->comm == nullptr && !h->ar_live && !(p.debug & 1);
+    // (round-5 advice) ... and only into the library's OWN statistics buffer: a host that bound its tensor (tmvb_lda_bind_stats, dist.py) may read it
+    // directly between estep and update_beta!, and must see the whole of S there, not S minus the last piece
+    bool split_out = split_out_env && shadow_stats && h->own_stats && !h->distributed && h->comm == nullptr && !h->ar_live && !(p.debug & 1);
     if (split_out && !h->d_stats_b) {
         size_t slots = 1;
         for (const tmvb_inv_index& ix : h->pieces) slots = std::max(slots, (size_t)ix.n_slots);
@@ -1830,6 +1849,9 @@ static int lda_estep_impl(tmvb_lda* h, int32_t viter, double vtol)
             // the alpha this E-step read, for lda_elbo_doc_kernel (update_alpha! may overtake that kernel): copied on the side stream, i.e. in front of this
             // iteration's update_alpha! in stream order and in front of the side chain's waits -- and enqueued HERE, behind every document-kernel launch in
             // host order (a checked iteration starts with the host behind the device: whatever it enqueues first delays the first document kernel)
+            // (round-5 advice) the previous collecting E-step's lda_elbo_doc_kernel may still be reading d_alpha_e on aux[ELBO] when no host-synchronising
+            // update_elbo! came in between (TMVB_LDA_ELBO_PARTS=2, or two E-steps in a row)
+            if (h->elbo_pending) TMVB_HIP(hipStreamWaitEvent(side, h->ev_elbo, 0));
             hipLaunchKernelGGL(lda_copy_d_kernel, dim3(1), dim3(256), 0, side, (const double*)h->d_alpha_d, h->d_alpha_e, h->K);
             TMVB_HIP(hipGetLastError());
             TMVB_HIP(hipEventRecord(h->ev_acopy, side));
@@ -1850,8 +1872,11 @@ static int lda_estep_impl(tmvb_lda* h, int32_t viter, double vtol)
         if (collect && h->M > 0) {        // update_elbo!'s per-document half, here: it needs the document kernels' output and the alpha they read, nothing else
 
             const unsigned nblk = (unsigned)((h->M + 63) / 64);
-            const size_t lds = (size_t)3 * 64 * (size_t)h->K * sizeof(float);
-            if (lds > 48 * 1024) TMVB_HIP(hipFuncSetAttribute((const void*)lda_elbo_doc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            const size_t lds = elbo_doc_lds;
+            if (lds > 48 * 1024 && (int)lds > h->elbo_doc_lds_set) {       // once per handle and size, not on every collecting E-step
+                TMVB_HIP(hipFuncSetAttribute((const void*)lda_elbo_doc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                h->elbo_doc_lds_set = (int)lds;
+            }
             static const bool own_stream = [] { const char* e = getenv("TMVB_LDA_ELBO_STREAM"); return !(e && atoi(e) == 0); }();   // 0: in a row on the side stream (A/B)
             hipStream_t es = own_stream ? h->aux[tmvb_lda::ELBO] : side;
             // the kernel starts behind the column sums of Elogtheta (ev_acopy re-recorded behind them) rather than with the end of the document kernels: right
@@ -2241,7 +2266,7 @@ struct LdaTrainOps {
     int64_t stats_len(tmvb_lda* h) { return (int64_t)h->K * h->V + h->K; }
     int mstep(tmvb_lda* h) { int rc = tmvb_lda_update_beta(h); return rc ? rc : tmvb_lda_update_alpha(h, niter, ntol); }   // :181-182
     int elbo_form(tmvb_lda* h) { return h->elbo_form; }
-    void force_walk(tmvb_lda* h, bool on) { h->force_walk = on; if (!on) h->elbo_form = 1; }   // (switched off behind the one evaluation that doubled a decomposed one)
+    void force_walk(tmvb_lda* h, bool on, bool doubled = true) { h->force_walk = on; if (!on && doubled) h->elbo_form = 1; }   // (switched off behind the one evaluation that doubled a decomposed one)
     void will_check(tmvb_lda* h, bool checked) { h->want_parts = checked; }           // the coming iteration ends in check_elbo!: collect update_elbo!'s parts on the way
     int elbo_local(tmvb_lda* h, double* s, double* once) { *once = 0.0; return tmvb_lda_update_elbo(h, s); }
     int elbo_enqueue(tmvb_lda* h, double* once) { *once = 0.0; TMVB_HIP(hipSetDevice(h->ctx->device)); return lda_elbo_enqueue(h); }   // -> elbo_dev(h), no sync

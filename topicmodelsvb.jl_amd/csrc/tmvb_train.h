@@ -146,7 +146,12 @@ static int tmvb_train_group_loop(const char* who, H* const* hs, int n, int iter,
     }
     double e_old = ops.get_elbo(hs[0]);
     if (checkelbo > 0 && checkelbo <= iter) {                                   // src/LDA.jl:167
-        if ((rc = tmvb_group_elbo(hs, n, ops, &e_old))) return rc;
+        // The baseline is ALWAYS the token walk (round-5 advice): a second tmvb_*_train on a handle with no set_state in between still has the last
+        // checked iteration's parts valid, and would otherwise take the decomposed form here while `old_parts` below says it did not.
+        if constexpr (tmvb_has_will_check<Ops, H>::value) for (int i = 0; i < n; ++i) ops.force_walk(hs[i], true);
+        rc = tmvb_group_elbo(hs, n, ops, &e_old);
+        if constexpr (tmvb_has_will_check<Ops, H>::value) for (int i = 0; i < n; ++i) ops.force_walk(hs[i], false, false);
+        if (rc) return rc;
     }
     if (elbo_baseline) *elbo_baseline = e_old;
     std::vector<tmvb_comm*> comms(n);
