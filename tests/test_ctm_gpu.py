@@ -484,3 +484,17 @@ def test_staged_sigma_is_dropped_when_the_state_changes(tmvb):
     c.lam = np.asfortranarray(lam2); c.update_buffer(); c.reduce_docs(); c.update_sigma(); c.update_mu(); c.update_host()
     assert np.array_equal(a.sigma, c.sigma) and np.array_equal(a.mu, c.mu)
     assert np.abs(a.sigma - b.sigma).max() > 0          # and it is not the sigma of the unchanged state
+
+
+@pytest.mark.gpu
+def test_one_wave_kernel_still_passes_its_parity_cases():
+    """Round 6 made the four-waves-per-item kernel (csrc/tmvb_ctm_quad.h) the default of the lane-per-document path; round 3's one-wave kernel
+    (csrc/tmvb_ctm_batch.h, still fCTM's kernel and the profiling build) stays selectable with TMVB_CTM_QUAD=0.  The switch is read once per
+    process, so its parity cases run in a child process: teacher-forced steps at every KP instantiation, viter = 0 and fixed sweep counts."""
+    import os, subprocess, sys
+    env = dict(os.environ, TMVB_CTM_QUAD="0")
+    res = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-x", os.path.abspath(__file__), "-k",
+                          "test_teacher_forced_step or test_lane_per_document_kernel_viter_zero_and_fixed_sweeps or test_lane_per_document_kernel_matches"],
+                         env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+    assert " passed" in res.stdout

@@ -96,12 +96,25 @@ def build(force: bool = False, verbose: bool = False) -> str:
     isa = os.path.join(objdir, "tmvb_ctm-hip-amdgcn-amd-amdhsa-gfx950.s")
     checker = os.path.join(_ROOT, "tools", "check_smem_inflight.py")
     if os.path.exists(isa) and os.path.exists(checker):
-        res = subprocess.run([sys.executable, checker, isa, "ctm_estep_batch"], capture_output=True, text=True)
+        res = subprocess.run([sys.executable, checker, isa, "ctm_estep"], capture_output=True, text=True)
         if res.returncode != 0:
             for o in objs:
                 if os.path.basename(o).startswith("tmvb_ctm.hip") and os.path.exists(o):
                     os.remove(o)
             raise EngineError("ISA check of the batched CTM kernel failed:\n" + res.stdout[-2000:])
+        if verbose:
+            print(res.stdout.strip().splitlines()[-1])
+    # The four-waves-per-item CTM kernel (csrc/tmvb_ctm_quad.h) issues the row gathers of its token loop as inline asm with hand-counted
+    # s_waitcnt vmcnt: the same kind of check for VGPRs -- nothing may touch a destination register between its load and the wait that lands it.
+    vchecker = os.path.join(_ROOT, "tools", "check_vmem_inflight.py")
+    if os.path.exists(isa) and os.path.exists(vchecker):
+        res = subprocess.run([sys.executable, vchecker, isa, "ctm_estep_quad_kernel"], capture_output=True, text=True)
+        if res.returncode != 0:
+            for o in objs:
+                if os.path.basename(o).startswith("tmvb_ctm.hip") and os.path.exists(o):
+                    os.remove(o)
+            raise EngineError("ISA check of the hand-scheduled token loop of ctm_estep_quad_kernel failed (build with -DTMVB_CTM_QASM=0 for the "
+                              "compiler-managed loop, or take the instantiation out of cq_asm_loop):\n" + res.stdout[-2000:])
         if verbose:
             print(res.stdout.strip().splitlines()[-1])
     rocm_lib = os.path.join(os.path.dirname(os.path.dirname(hipcc)), "lib")

@@ -454,6 +454,7 @@ __global__ __launch_bounds__(64) void ctm_estep_kernel(CtmParams p, int64_t firs
 }
 
 #include "tmvb_ctm_batch.h"
+#include "tmvb_ctm_quad.h"
 
 // 64-float padded copies of mu and of invsigma's diagonal for the batched kernel's block scalar loads
 // (and the launch's counters / work queue zeroed: one launch instead of a memset beside it)
@@ -464,6 +465,28 @@ __global__ __launch_bounds__(64) void ctm_batch_tabs_kernel(int K, int KP, const
     sdiag[i] = (i < KP) ? invsigma_f[i * KP + i] : 0.0f;
     muf[i] = (i < K) ? mu_f[i] : 0.0f;
     if (i < 16) counters16[i] = 0ull;
+}
+
+// Tables of the four-waves-per-item kernel (tmvb_ctm_quad.h): for wave w the H = KP / 4 rows [H w, H w + H) of invsigma as the flat sequence of
+// pairs t = jp * H + i -> {S[2 jp][H w + i], S[2 jp + 1][H w + i]} (one v_pk_fma_f32 each), NB 16-float blocks per wave, zero filled; the block's
+// diagonal and mu, 16 floats per wave (pads 0); and the launch's counters / work queue zeroed.
+__global__ __launch_bounds__(256) void ctm_quad_tabs_kernel(int K, int KP, const float* __restrict__ invsigma_f, const float* __restrict__ mu_f,
+                                                            float* __restrict__ Sq, float* __restrict__ sdq, float* __restrict__ muq,
+                                                            unsigned long long* __restrict__ counters16)
+{
+    const int H = KP / 4, npair = (KP / 2) * H, stride = ((2 * npair + 15) / 16) * 16;
+    for (int idx = threadIdx.x; idx < 4 * stride; idx += 256) {
+        const int w = idx / stride, f = idx - w * stride, t = f >> 1, e = f & 1;
+        float v = 0.0f;
+        if (t < npair) { const int jp = t / H, i = t - jp * H; v = invsigma_f[(2 * jp + e) * KP + H * w + i]; }
+        Sq[idx] = v;
+    }
+    if (threadIdx.x < 64) {
+        const int w = threadIdx.x >> 4, i = threadIdx.x & 15, g = H * w + i;
+        sdq[threadIdx.x] = (i < H) ? invsigma_f[g * KP + g] : 0.0f;
+        muq[threadIdx.x] = (i < H && g < K) ? mu_f[g] : 0.0f;
+    }
+    if (threadIdx.x < 16) counters16[threadIdx.x] = 0ull;
 }
 
 // tmvb_ctm_update_sigma with a staged result: the staging buffers over sigma / invsigma (fp64), invsigma (fp32, padded), its log-determinant
@@ -1406,6 +1429,7 @@ struct tmvb_ctm {
     uint16_t* d_doc_newton = nullptr; int32_t* d_doc_order0 = nullptr;
     int32_t* d_doc_order_q = nullptr; unsigned* d_wave_keys = nullptr; bool queue_sorted = false; hipEvent_t ev_spec2 = nullptr; bool spec2_pending = false;      // the lane-per-document launch's queue order (ctm_wave_sort_kernel), valid for the next E-step
     float* d_bt_sdiag = nullptr; float* d_bt_muf = nullptr; unsigned long long* d_cg_iters = nullptr;
+    float* d_q_S = nullptr; float* d_q_sd = nullptr; float* d_q_mu = nullptr; int beta_pad_cpr = 0;   // tables of the four-waves-per-item kernel (tmvb_ctm_quad.h)
     float cg_tol = 1e-4f, cg_abs = 0.05f;   // CG exit: relative residual, and the fraction of ntol it may stop at (TMVB_CTM_CG_TOL / _ABS)
     double* d_sigma = nullptr; double* d_invsigma = nullptr; double* d_mu = nullptr; double* d_logdet = nullptr;
     float* d_scatter_partial = nullptr; int n_scatter_waves = 0; int64_t docs_per_wave = 0;
@@ -1452,6 +1476,7 @@ extern "C" int tmvb_ctm_destroy(tmvb_ctm* h)
     (void)hipFree(h->d_lambda); (void)hipFree(h->d_lambda_old); (void)hipFree(h->d_vsq); (void)hipFree(h->d_logzeta);
     (void)hipFree(h->d_sigma_work); (void)hipFree(h->d_sigma_work_s);
     (void)hipFree(h->d_wtok); (void)hipFree(h->d_E); (void)hipFree(h->d_ts_partial); (void)hipFree(h->d_invsigma_f);
+    (void)hipFree(h->d_q_S); (void)hipFree(h->d_q_sd); (void)hipFree(h->d_q_mu);
     (void)hipFree(h->d_bt_sdiag); (void)hipFree(h->d_bt_muf); (void)hipFree(h->d_cg_iters); (void)hipFree(h->d_doc_newton); (void)hipFree(h->d_doc_order0); (void)hipFree(h->d_doc_order_q); (void)hipFree(h->d_wave_keys);
     (void)hipFree(h->d_mu_f); (void)hipFree(h->d_sigma); (void)hipFree(h->d_invsigma); (void)hipFree(h->d_mu);
     (void)hipFree(h->d_logdet); (void)hipFree(h->d_scatter_partial); (void)hipFree(h->d_sweeps); (void)hipFree(h->d_doc_order);
@@ -1550,6 +1575,7 @@ extern "C" int tmvb_ctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
         if (const char* t = getenv("TMVB_CTM_CG_TOL")) h->cg_tol = std::max(1e-7f, (float)atof(t));
         if (const char* t = getenv("TMVB_CTM_CG_ABS")) h->cg_abs = std::max(0.0f, (float)atof(t));
         if ((rc = dmalloc(&h->d_bt_sdiag, 64)) || (rc = dmalloc(&h->d_bt_muf, 64)) || (rc = dmalloc(&h->d_cg_iters, 16)) ||
+            (rc = dmalloc(&h->d_q_S, (size_t)4 * (((size_t)h->KP * h->KP / 4 + 15) / 16 * 16) + 64)) || (rc = dmalloc(&h->d_q_sd, 64)) || (rc = dmalloc(&h->d_q_mu, 64)) ||
             (rc = dmalloc(&h->d_doc_newton, (size_t)std::max<int64_t>(h->M, 1))) || (rc = dmalloc(&h->d_doc_order0, (size_t)std::max<int64_t>(h->M, 1))) || (rc = dmalloc(&h->d_doc_order_q, (size_t)std::max<int64_t>(h->M, 1))) || (rc = dmalloc(&h->d_wave_keys, CTM_WAVESORT_MAX)))
             return rc;
         // regrouping pays when a chunk of the length-sorted order is still homogeneous in length: corpora of >= 4 chunks
@@ -1758,6 +1784,69 @@ __global__ __launch_bounds__(256) void ctm_rowpad_kernel(const float4* __restric
     dst[q] = c < 13 ? src[v * 13 + c] : float4{0.f, 0.f, 0.f, 0.f};
 }
 
+// the same for any KP and any padded width: LPR 16-byte chunks per row in, CPR >= LPR chunks per row out, pads 0 (tmvb_ctm_quad.h: CPR = 4 ceil(LPR / 4),
+// a row is whole 64-byte slots, one 16-byte chunk per lane of a quad)
+__global__ __launch_bounds__(256) void ctm_rowpad_generic_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int64_t V, int LPR, int CPR)
+{
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= V * CPR) return;
+    const int64_t v = q / CPR; const int c = (int)(q - v * CPR);
+    dst[q] = c < LPR ? src[v * LPR + c] : float4{0.f, 0.f, 0.f, 0.f};
+}
+
+// launch of the four-waves-per-item kernel (tmvb_ctm_quad.h): CTM, KP <= 52
+static int ctm_launch_quad(tmvb_ctm* h, const CtmParams& p, double ntol)
+{
+    tmvb_ctx* ctx = h->ctx;
+    hipLaunchKernelGGL(ctm_quad_tabs_kernel, dim3(1), dim3(256), 0, ctx->stream, h->K, h->KP, h->d_invsigma_f, h->d_mu_f, h->d_q_S, h->d_q_sd, h->d_q_mu, h->d_cg_iters);
+    TMVB_HIP(hipGetLastError());
+    CtmBatchTabs tb;
+    tb.S = h->d_invsigma_f; tb.sdiag = h->d_bt_sdiag; tb.muf = h->d_bt_muf;
+    tb.Sq = h->d_q_S; tb.sdq = h->d_q_sd; tb.muq = h->d_q_mu;
+    tb.cg_tol2 = h->cg_tol * h->cg_tol; tb.cg_maxit = 4 * h->KP; tb.cg_iters = h->d_cg_iters;
+    { const double fl = h->cg_abs * std::min(ntol, 4e-4); tb.cg_abs2 = (float)(fl * fl); }
+    const int64_t Mb = h->M - h->n_long;
+    if (Mb <= 0) return TMVB_OK;
+    const int n_items = (int)((Mb + 63) / 64);
+    const int LPRv = h->KP / 4, CPR = 4 * ((LPRv + 3) / 4);
+    const size_t lds = (size_t)(3 * h->KP * 64 + 2 * 3 * 4 * 64) * 4 + (size_t)(2 * 4 * 64) * 8 + (5 * 64 + 4) * 4;
+    // two workgroups per CU: two waves per SIMD (TMVB_CTM_QUAD_PER_CU: diagnostics)
+    int per_cu = 2;
+    if (const char* e = getenv("TMVB_CTM_QUAD_PER_CU")) per_cu = std::max(1, std::min(4, atoi(e)));
+    const dim3 grid((unsigned)std::min(n_items, per_cu * ctx->num_cu)), block(256);
+    tb.next_item = (unsigned*)(h->d_cg_iters + 12); tb.n_items = n_items;
+    if (h->reorder && h->keys_valid && !h->reorder_staged) {
+        hipLaunchKernelGGL(ctm_reorder_kernel, dim3((unsigned)((Mb + CTM_REORDER_CHUNK - 1) / CTM_REORDER_CHUNK)), dim3(1024), 0, ctx->stream,
+                           h->d_doc_order0 + h->n_long, h->d_doc_newton, h->d_doc_order + h->n_long, Mb);
+        TMVB_HIP(hipGetLastError());
+    }
+    h->reorder_staged = false;
+    h->keys_valid = true;
+    CtmBatchArgs ba;
+    ba.p = p; ba.p.doc_order = h->queue_sorted ? h->d_doc_order_q : p.doc_order + h->n_long; ba.p.doc_newton = h->d_doc_newton; ba.tb = tb; ba.M = Mb;
+    if (!h->d_beta_pad || h->beta_pad_cpr != CPR) {
+        (void)hipFree(h->d_beta_pad); h->d_beta_pad = nullptr;
+        int prc = dmalloc(&h->d_beta_pad, (size_t)h->V * CPR * 4 + 64); if (prc) return prc;
+        h->beta_pad_cpr = CPR;
+    }
+    hipLaunchKernelGGL(ctm_rowpad_generic_kernel, dim3((unsigned)((h->V * CPR + 255) / 256)), dim3(256), 0, ctx->stream, (const float4*)p.beta, (float4*)h->d_beta_pad, h->V, LPRv, CPR);
+    TMVB_HIP(hipGetLastError());
+    ba.p.beta = h->d_beta_pad;
+    h->queue_sorted = false;
+#define CTM_QCASE(KPV) case KPV: { static bool attr_set = false; if (!attr_set && lds > 48 * 1024) { TMVB_HIP(hipFuncSetAttribute((const void*)ctm_estep_quad_kernel<KPV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; } \
+                                   hipLaunchKernelGGL((ctm_estep_quad_kernel<KPV, false>), grid, block, lds, ctx->stream, ba); } break;
+    static const bool qprof = [] { const char* e = getenv("TMVB_CTM_QPROF"); return e && atoi(e) != 0; }();
+    if (qprof && h->KP == 52) {
+        TMVB_HIP(hipFuncSetAttribute((const void*)ctm_estep_quad_kernel<52, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((ctm_estep_quad_kernel<52, true>), grid, block, lds, ctx->stream, ba);
+    } else
+    switch (h->KP) { CTM_QCASE(4) CTM_QCASE(12) CTM_QCASE(20) CTM_QCASE(28) CTM_QCASE(36) CTM_QCASE(44) CTM_QCASE(52)
+                     default: TMVB_REQUIRE(false, TMVB_EINVAL, "ctm_launch_quad: KP not instantiated"); }
+#undef CTM_QCASE
+    TMVB_HIP(hipGetLastError());
+    return TMVB_OK;
+}
+
 // launch of the lane-per-document kernel (tmvb_ctm_batch.h) for CTM (FILT = false) and fCTM (FILT = true)
 template <bool FILT>
 static int ctm_launch_batch(tmvb_ctm* h, const CtmParams& p, double ntol)
@@ -1879,7 +1968,10 @@ extern "C" int tmvb_ctm_estep(tmvb_ctm* h, int32_t niter, double ntol, int32_t v
         TMVB_HIP(hipGetLastError());
     }
     if (h->batch && h->M > 0) {
-        int brc = ctm_launch_batch<false>(h, p, ntol);
+        // round 6: four waves per wave-of-documents (tmvb_ctm_quad.h), two workgroups per CU; TMVB_CTM_QUAD=0 (or the profiling build of the
+        // one-wave kernel, TMVB_CTM_PROF=1) selects round 3's one-wave kernel
+        static const bool quad = [] { const char* e = getenv("TMVB_CTM_QUAD"); const char* pr = getenv("TMVB_CTM_PROF"); return !(e && atoi(e) == 0) && !(pr && atoi(pr) != 0); }();
+        int brc = quad ? ctm_launch_quad(h, p, ntol) : ctm_launch_batch<false>(h, p, ntol);
         if (brc) return brc;
     }
     if (naux > 0) {

@@ -38,6 +38,8 @@ struct CtmBatchTabs {
     unsigned* next_item = nullptr;            // work queue of the persistent launch: the next wave-of-documents to take (zeroed before the launch)
     int n_items = 0;                          // waves-of-documents in the queue (64 documents each)
     unsigned long long* wave_log = nullptr;   // PROF only (TMVB_CTM_WAVE_LOG): per wave [start, end] of the 100 MHz wall clock, HW_ID, longest document
+    // four-waves-per-item kernel (tmvb_ctm_quad.h): per wave w the row block [H w, H w + H) of invsigma in column-pair order, its diagonal and mu (16 floats each)
+    const float* Sq = nullptr; const float* sdq = nullptr; const float* muq = nullptr;
 };
 
 template <typename F, int... I>
