@@ -296,6 +296,13 @@ int tmvb_flda_set_comm(tmvb_flda* h, tmvb_comm* comm, int64_t M_total, int64_t C
 int tmvb_flda_train_group(tmvb_flda* const* hs, int32_t n, int32_t iter, double tol, int32_t niter, double ntol, int32_t viter,
                           double vtol, int32_t checkelbo, double* elbo_traj, int32_t* iters_done, double* elbo_baseline);
 int tmvb_flda_doc_sweeps(tmvb_flda* h, uint8_t* out);
+/* As tmvb_lda_elbo_form (update_elbo!, src/fLDA.jl:108-118): *form = 1 if the last tmvb_flda_update_elbo / check of tmvb_flda_train took the decomposed
+ * form -- the checked iteration's document kernel left per token the log-sum-exp of its last phi column and the exponent update_tau! forms
+ * (sum_i phi_in log(beta_old + eps), :184), update_beta! left sum S (log(beta_new + eps) - log(beta_old + eps)), and one elementwise pass per document adds
+ * c_n [lse_n + (tau_n - tau_old_n) A_n + (1 - tau_n) log(kappa + eps) + H(tau_n)], sum_i (gamma_i - alpha_i)(Elogtheta_i - Elogtheta_old_i), the Dirichlet
+ * terms and Elogpc: no phi is rebuilt; *form = 0 the token walk (any state, e.g. after tmvb_flda_set_state).  TMVB_FLDA_ELBO_PARTS at tmvb_flda_create:
+ * 0 never, 1 (default) the iterations tmvb_flda_train checks, 2 every E-step collects (the stepwise operators take the form too).  viter > 0. */
+int tmvb_flda_elbo_form(tmvb_flda* h, int32_t* form);
 int tmvb_flda_last_estep_ms(tmvb_flda* h, float* ms);
 
 /* ============================== CTM (src/gpuCTM.jl, oracle src/CTM.jl) ============================== */
@@ -401,6 +408,9 @@ int tmvb_fctm_train_group(tmvb_fctm* const* hs, int32_t n, int32_t iter, double 
                           double vtol, int32_t checkelbo, double* elbo_traj, int32_t* iters_done, double* elbo_baseline);
 int tmvb_fctm_sweep_hist(tmvb_fctm* h, int64_t* hist, int32_t nbins, int64_t* newton_steps);
 int tmvb_fctm_doc_sweeps(tmvb_fctm* h, uint8_t* out);
+/* As tmvb_flda_elbo_form for update_elbo! of src/fCTM.jl:105-115 (lambda for Elogtheta: the E-step kernels' exit test leaves
+ * sum_i (phi counts)_i (lambda_i - lambda_old_i) per document); TMVB_FCTM_ELBO_PARTS at tmvb_fctm_create. */
+int tmvb_fctm_elbo_form(tmvb_fctm* h, int32_t* form);
 
 /* ============================== CTPF (src/gpuCTPF.jl, oracle src/CTPF.jl) ============================== */
 

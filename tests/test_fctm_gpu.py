@@ -1,10 +1,8 @@
 """
 GPU parity tests for the filtered-CTM path (new device path; oracle src/fCTM.jl): HIP engine through the C ABI vs the fp64
-oracle and the committed golden fixture.  Tolerances (fp64 -> fp32 state; fp64 Newton gradients on device):
-  teacher-forced single step : lambda abs <= 2e-3 + rel 2e-3, vsq rel <= 2e-3, logzeta abs <= 1e-3, tau abs <= 5e-5,
-                               beta rel <= 1e-3 on entries > 1e-6, kappa rel <= 2e-3, mu abs <= 2e-4,
-                               sigma abs <= 5e-4 * max|sigma|, ELBO rel <= 5e-6
-  free running               : ELBO rel <= 3e-4 per iteration
+oracle and the committed golden fixture.  Tolerances (fp64 -> fp32 state; fp64 Newton gradients on device): the fctm.* keys of tests/tol.py --
+round 6: measured on MI355X and frozen at <= 10x (lambda in units of CTM's bound 1.5e-5 + 1.5e-5 |lambda|; round 5 they were literals up to 130x
+looser); tests/test_mutants_gpu.py holds the negative control (update_vsq! in front of update_lambda!: CTM's order instead of src/fCTM.jl:239-240).
 K <= 50 runs the lane-per-document kernel (FILT instantiation, CG Newton solves), 50 < K <= 60 the register Gauss-Jordan kernel,
 60 < K <= 128 the LDS Newton solve.
 """
@@ -15,6 +13,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+from tol import LAMBDA_ABS, LAMBDA_REL, within  # noqa: E402  (named tolerances of tests/tol.py, frozen at <= 10x their MI355X measurement)
 
 
 def load(name):
@@ -52,18 +52,18 @@ def synth_case(tmvb, K, M=60, V=300, seed=3):
                 kappa0=tmvb.dirichlet_rows(1, V, seed=9)[0])
 
 
-def compare(gm, om, it):
-    assert np.all(np.abs(gm.lam - om.lam) <= 2e-3 + 2e-3 * np.abs(om.lam)), (it, "lambda", np.abs(gm.lam - om.lam).max())
-    assert np.all(np.abs(gm.vsq - om.vsq) <= 2e-3 * om.vsq), (it, "vsq")
-    assert np.abs(gm.logzeta - om.logzeta).max() <= 1e-3, (it, "logzeta")
-    assert np.abs(gm.tau - om.tau).max(initial=0.0) <= 5e-5, (it, "tau", np.abs(gm.tau - om.tau).max())
-    assert np.abs(gm.tau_old - om.tau_old).max(initial=0.0) <= 5e-5, (it, "tau_old")
+def compare(gm, om, it, tag=""):
+    within("fctm.lambda_err" + tag, np.abs(gm.lam - om.lam) / (LAMBDA_ABS + LAMBDA_REL * np.abs(om.lam)), (it, "lambda", np.abs(gm.lam - om.lam).max()))
+    within("fctm.vsq_rel" + tag, np.abs(gm.vsq - om.vsq) / om.vsq, (it, "vsq"))
+    within("fctm.logzeta_abs" + tag, np.abs(gm.logzeta - om.logzeta).max(), (it, "logzeta"))
+    within("fctm.tau_abs" + tag, np.abs(gm.tau - om.tau).max(initial=0.0), (it, "tau"))
+    within("fctm.tau_abs" + tag, np.abs(gm.tau_old - om.tau_old).max(initial=0.0), (it, "tau_old"))
     big = om.beta > 1e-6
-    assert (np.abs(gm.beta[big] - om.beta[big]) / om.beta[big]).max() <= 1e-3, (it, "beta")
+    within("fctm.beta_rel" + tag, (np.abs(gm.beta[big] - om.beta[big]) / om.beta[big]).max(), (it, "beta"))
     bk = om.kappa > 1e-8
-    assert (np.abs(gm.kappa[bk] - om.kappa[bk]) / om.kappa[bk]).max() <= 2e-3, (it, "kappa")
-    assert np.abs(gm.mu - om.mu).max() <= 2e-4, (it, "mu")
-    assert np.abs(gm.sigma - om.sigma).max() <= 5e-4 * np.abs(om.sigma).max(), (it, "sigma")
+    within("fctm.kappa_rel" + tag, (np.abs(gm.kappa[bk] - om.kappa[bk]) / om.kappa[bk]).max(), (it, "kappa"))
+    within("fctm.mu_abs" + tag, np.abs(gm.mu - om.mu).max(), (it, "mu"))
+    within("fctm.sigma_rel" + tag, np.abs(gm.sigma - om.sigma).max() / np.abs(om.sigma).max(), (it, "sigma"))
     np.testing.assert_allclose(gm.beta.sum(axis=1), 1.0, rtol=1e-5)
     np.testing.assert_allclose(gm.kappa.sum(), 1.0, rtol=1e-5)
     assert np.all(gm.vsq > 0) and np.all((gm.tau >= 0) & (gm.tau <= 1))
@@ -81,12 +81,13 @@ def test_teacher_forced_step(tmvb, oracle, case):
         gm.update_host()
         same = gm.doc_sweeps() == np.asarray(sw_o)
         assert same.mean() >= 0.9, (it, same.mean())
+        big = "" if int(case.split("_k")[1]) <= 128 else ".bigk"      # K > 128: invsigma read from global memory, eight topic slots per lane
         if same.all():
-            compare(gm, om, it)
-            assert abs(e_g - e_o) <= 5e-6 * abs(e_o), (it, e_g, e_o)
+            compare(gm, om, it, big)
+            within("fctm.elbo_rel_step" + big, abs(e_g - e_o) / abs(e_o), (case, it, e_g, e_o))
         else:                               # a document at the vtol boundary took one sweep more or less: compare the rest
-            assert np.all(np.abs(gm.lam[:, same] - om.lam[:, same]) <= 2e-3 + 2e-3 * np.abs(om.lam[:, same])), it
-            assert abs(e_g - e_o) <= 2e-4 * abs(e_o), (it, e_g, e_o)
+            within("fctm.lambda_err" + big, np.abs(gm.lam[:, same] - om.lam[:, same]) / (LAMBDA_ABS + LAMBDA_REL * np.abs(om.lam[:, same])), (case, it))
+            assert abs(e_g - e_o) <= 2e-4 * abs(e_o), (it, e_g, e_o)      # (two ELBOs of states that differ by a sweep of one document: a sanity bound, not a parity tolerance; no flip occurs on MI355X today)
 
 
 @pytest.mark.parametrize("K", [5, 30, 70])
@@ -101,7 +102,7 @@ def test_teacher_forced_fixed_sweeps(tmvb, oracle, K):
         gm.update_host()
         assert np.all(gm.doc_sweeps() == 3)
         compare(gm, om, it)
-        assert abs(e_g - e_o) <= 5e-6 * abs(e_o), (it, e_g, e_o)
+        within("fctm.elbo_rel_step", abs(e_g - e_o) / abs(e_o), (K, it, e_g, e_o))
 
 
 def test_free_running_train_vs_golden(tmvb):
@@ -114,11 +115,12 @@ def test_free_running_train_vs_golden(tmvb):
     tmvb.check_model_fctm(m)
     gold = g["elbo_traj"]
     assert len(traj) == len(gold)
-    assert np.all(np.abs(traj - gold) <= 3e-4 * np.abs(gold)), (traj, gold)
+    within("fctm.elbo_rel_free", np.abs(traj - gold) / np.abs(gold), (traj, gold))
     assert m.eta == 0.5                                                     # update_eta! is not part of train! (src/fCTM.jl:253)
-    assert np.abs(m.mu - g["mu"]).max() <= 5e-3
-    assert np.abs(m.beta - g["beta"]).max() <= 1e-3 and np.abs(m.kappa - g["kappa"]).max() <= 2e-4
-    assert np.abs(m.tau - g["tau"]).max() <= 5e-3
+    within("fctm.mu_abs_free", np.abs(m.mu - g["mu"]).max())
+    within("fctm.beta_abs_free", np.abs(m.beta - g["beta"]).max())
+    within("fctm.kappa_abs_free", np.abs(m.kappa - g["kappa"]).max())
+    within("fctm.tau_abs_free", np.abs(m.tau - g["tau"]).max())
 
 
 def test_long_documents_stream_chunks(tmvb, oracle):

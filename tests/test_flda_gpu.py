@@ -1,9 +1,8 @@
 """
 GPU parity tests for the filtered-LDA path (new device path; oracle src/fLDA.jl): HIP engine through the C ABI vs the
-fp64 oracle and the committed golden fixtures.  Tolerances (fp64 -> fp32, one v_exp_f32 per (token, topic) per sweep):
-  teacher-forced single step : gamma, Elogtheta rel <= 5e-4; tau abs <= 2e-5; beta rel <= 5e-4 on entries > 1e-6;
-                               kappa rel <= 1e-3 (it sums (1 - tau_n) c_n: tau's absolute 2e-5 is a larger relative error where tau is near 1); alpha rel <= 2e-4; eta abs <= 1e-6; ELBO rel <= 2e-6
-  free running               : ELBO rel <= 2e-4 per iteration
+fp64 oracle and the committed golden fixtures.  Tolerances (fp64 -> fp32, one v_exp_f32 per (token, topic) per sweep): the flda.* keys of
+tests/tol.py -- round 6: measured on MI355X and frozen at <= 10x like LDA / CTM / CTPF's (round 5 they were literals 25 - 250x looser);
+tests/test_mutants_gpu.py holds the negative control (epsilon dropped from update_tau!'s log(beta + eps), src/fLDA.jl:184).
 """
 import os
 
@@ -12,6 +11,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+from tol import within  # noqa: E402  (every comparison below goes through a named tolerance of tests/tol.py, frozen at <= 10x its MI355X measurement)
 
 
 def load(name):
@@ -60,18 +61,18 @@ def test_teacher_forced_fixed_sweeps(tmvb, oracle, case):
         om.estep(viter=3, vtol=0.0); om.mstep()
         e_g = gm.update_elbo(); e_o = om.update_elbo()
         gm.update_host()
-        assert rel(gm.gamma, om.gamma) <= 5e-4, (it, "gamma")
-        assert rel(gm.Elogtheta, om.Elogtheta) <= 5e-4, (it, "Elogtheta")
-        assert np.abs(gm.tau - om.tau).max(initial=0.0) <= 2e-5, (it, "tau")
-        assert np.abs(gm.tau_old - om.tau_old).max(initial=0.0) <= 2e-5, (it, "tau_old")
+        within("flda.gamma_rel", rel(gm.gamma, om.gamma), (case, it))
+        within("flda.Elogtheta_rel", rel(gm.Elogtheta, om.Elogtheta), (case, it))
+        within("flda.tau_abs", np.abs(gm.tau - om.tau).max(initial=0.0), (case, it))
+        within("flda.tau_abs", np.abs(gm.tau_old - om.tau_old).max(initial=0.0), (case, it, "tau_old"))
         big = om.beta > 1e-6
-        assert rel(gm.beta[big], om.beta[big]) <= 5e-4, (it, "beta")
-        assert np.abs(gm.beta - om.beta).max() <= 1e-6
+        within("flda.beta_rel", rel(gm.beta[big], om.beta[big]), (case, it))
+        within("flda.beta_abs", np.abs(gm.beta - om.beta).max(), (case, it))
         bk = om.kappa > 1e-8
-        assert rel(gm.kappa[bk], om.kappa[bk]) <= 1e-3, (it, "kappa")
-        assert rel(gm.alpha, om.alpha) <= 2e-4, (it, "alpha")
-        assert abs(gm.eta - om.eta) <= 1e-6, (it, gm.eta, om.eta)
-        assert abs(e_g - e_o) <= 2e-6 * abs(e_o), (it, e_g, e_o)
+        within("flda.kappa_rel", rel(gm.kappa[bk], om.kappa[bk]), (case, it))
+        within("flda.alpha_rel", rel(gm.alpha, om.alpha), (case, it))
+        within("flda.eta_abs", abs(gm.eta - om.eta), (case, it, gm.eta, om.eta))
+        within("flda.elbo_rel_step", abs(e_g - e_o) / abs(e_o), (case, it, e_g, e_o))
         np.testing.assert_allclose(gm.beta.sum(axis=1), 1.0, rtol=1e-5)
         np.testing.assert_allclose(gm.kappa.sum(), 1.0, rtol=1e-5)
         assert np.all((gm.tau >= 0) & (gm.tau <= 1)) and np.all(gm.gamma > 0) and np.all(gm.Elogtheta <= 0)
@@ -91,7 +92,7 @@ def test_teacher_forced_default_exit_rule(tmvb, oracle, case):
         same = gm.doc_sweeps() == np.asarray(sw_o)
         mism += int((~same).sum()); tot += len(sw_o)
         assert same.any()
-        assert rel(gm.gamma[:, same], om.gamma[:, same]) <= 5e-4, it
+        within("flda.gamma_rel", rel(gm.gamma[:, same], om.gamma[:, same]), (case, it, "default exit rule"))
     assert mism <= 0.05 * tot, f"{mism}/{tot} documents changed sweep count"
 
 
@@ -106,10 +107,11 @@ def test_free_running_train_vs_golden(tmvb, name):
     tmvb.check_model_flda(m)
     gold = g["elbo_traj"]
     assert len(traj) == len(gold)
-    assert np.all(np.abs(traj - gold) <= 2e-4 * np.abs(gold)), (traj, gold)
-    assert abs(m.eta - float(g["eta"])) <= 1e-4
-    assert np.abs(m.beta - g["beta"]).max() <= 1e-3 and np.abs(m.kappa - g["kappa"]).max() <= 1e-4
-    assert rel(m.alpha, g["alpha"]) <= 5e-3
+    within("flda.elbo_rel_free", np.abs(traj - gold) / np.abs(gold), (name, traj, gold))
+    within("flda.eta_abs_free", abs(m.eta - float(g["eta"])), name)
+    within("flda.beta_abs_free", np.abs(m.beta - g["beta"]).max(), name)
+    within("flda.kappa_abs_free", np.abs(m.kappa - g["kappa"]).max(), name)
+    within("flda.alpha_rel_free", rel(m.alpha, g["alpha"]), name)
     assert sorted(m.topics[0].tolist()) == list(range(1, V + 1))
 
 
@@ -131,9 +133,11 @@ def test_long_documents_stream_chunks(tmvb, oracle):
         gm.estep(viter=4, vtol=0.0); gm.reduce_docs(); gm.mstep()
         om.estep(viter=4, vtol=0.0); om.mstep()
         gm.update_host()
-        assert rel(gm.gamma, om.gamma) <= 5e-4 and np.abs(gm.tau - om.tau).max() <= 2e-5
+        within("flda.gamma_rel", rel(gm.gamma, om.gamma), ("long", it))
+        within("flda.tau_abs", np.abs(gm.tau - om.tau).max(), ("long", it))
         big = om.beta > 1e-6
-        assert rel(gm.beta[big], om.beta[big]) <= 5e-4 and abs(gm.eta - om.eta) <= 1e-6
+        within("flda.beta_rel", rel(gm.beta[big], om.beta[big]), ("long", it))
+        within("flda.eta_abs", abs(gm.eta - om.eta), ("long", it))
 
 
 def test_errors_and_invariants(tmvb):
@@ -157,3 +161,28 @@ def test_errors_and_invariants(tmvb):
     gm.estep(); gm.update_host()
     # gamma_d = eps + alpha + phi * counts with stochastic phi columns: sum_i (gamma - alpha) = C_d  (src/fLDA.jl:175)
     np.testing.assert_allclose((gm.gamma - a[:, None]).sum(axis=0), pc.C, rtol=1e-4)
+
+
+def test_epsilon_keeps_phi_defined_where_a_beta_column_is_zero(tmvb, oracle):
+    """update_phi! and update_elbo! take log(@boink beta) (src/fLDA.jl:191, :112, :83): for a term whose beta column is all zero -- a vocabulary entry no
+    training document used, met by predict on new text -- every topic has the same log(eps), phi = softmax(Elogtheta) and everything stays finite, where
+    log(0) would give -inf - -inf = NaN.  (update_tau! forms beta^-phi from the raw beta, :184: tau of such a token is exactly 0 in the reference and
+    ~1e-27 on the device.)  The negative control of tests/test_mutants_gpu.py: the library whose log table has no epsilon must FAIL here."""
+    K, V = 5, 7
+    rng = np.random.default_rng(3)
+    beta0 = rng.random((K, V)); beta0[:, 3] = 0.0; beta0 /= beta0.sum(axis=1, keepdims=True)
+    kappa0 = np.full(V, 1.0 / V)
+    docs = [([3], [4]), ([0, 3, 5], [2, 1, 3]), ([1, 2, 6], [1, 1, 2])]
+    doc_ptr = np.concatenate([[0], np.cumsum([len(t) for t, _ in docs])]).astype(np.int64)
+    terms = np.concatenate([t for t, _ in docs]).astype(np.int32); counts = np.concatenate([c for _, c in docs]).astype(np.int32)
+    g = dict(K=K, V=V, doc_ptr=doc_ptr, terms=terms, counts=counts, beta0=beta0, kappa0=kappa0)
+    gm, om = make_pair(tmvb, oracle, g)
+    gm.estep(viter=3, vtol=0.0); gm.reduce_docs(); om.estep(viter=3, vtol=0.0)
+    gm.update_host()
+    assert np.all(np.isfinite(gm.gamma)) and np.all(np.isfinite(gm.Elogtheta)) and np.all(np.isfinite(gm.tau))
+    within("flda.gamma_rel", rel(gm.gamma, om.gamma), "zero column")
+    within("flda.tau_abs", np.abs(gm.tau - om.tau).max(), "zero column")
+    assert gm.tau[0] <= 1e-20                                                   # the token of the zero column is background
+    gm.mstep(); om.mstep(); gm.update_host()
+    assert np.all(np.isfinite(gm.beta)) and np.all(np.isfinite(gm.kappa))
+    within("flda.beta_abs", np.abs(gm.beta - om.beta).max(), "zero column")

@@ -162,6 +162,31 @@ def test_lda_free_running_full_size_k50_tracks_the_oracle(tmvb, oracle):
     within("lda.beta_abs_free_full", np.abs(gm.beta - om.beta))
 
 
+def test_ctm_free_running_full_size_k50_tracks_the_oracle(tmvb, oracle):
+    """Round-5 review: config 4 at full size had been ONE teacher-forced iteration.  Five FREE-RUNNING iterations of CTM K = 50 on the whole SYN-NSF corpus
+    through the library's train! (the four-waves-per-item kernel with its regrouping by Newton counts and its queue order, the staged sigma, the decomposed
+    update_elbo! of the checked iterations) against the OpenMP fp64 oracle's train! loop from the same cold start (src/CTM.jl:194-211): ELBO rel per
+    iteration, then the globals.  The lambda solve is inexact CG on the device and `\` in the oracle: the trajectories may separate by what the Newton
+    exit threshold ntol = 1 / K^2 allows, which is what the ctm.*_free_full tolerances measure."""
+    pc = tmvb.syn_nsf()
+    K = 50
+    beta0 = tmvb.dirichlet_rows(K, pc.V, seed=7)
+    gm = tmvb.gpuCTM(pc, K)
+    gm.beta = np.asfortranarray(beta0); gm.beta_old = gm.beta.copy(order="F")
+    om = oracle.CTM(oracle.CSR(pc.doc_ptr, pc.terms, pc.counts, pc.V), K, beta0)
+    t_g = gm.train(iter=5, tol=0.0, checkelbo=1, printelbo=False)
+    nt = oracle.usable_cpus()
+    t_o = _oracle_train(om, lambda m: (m.estep(omp_threads=nt), m.update_beta(), m.update_sigma_mu()), 5, tol=0.0)
+    oracle.lib().orc_omp_pool_free()
+    assert len(t_g) == len(t_o) == 5 and np.all(np.diff(t_o) > 0)
+    dev = np.abs(t_g - t_o) / np.abs(t_o)
+    print("\n   CTM K=50 FULL SIZE free running, 5 iterations: ELBO rel per iteration", ", ".join(f"{x:.2e}" for x in dev))
+    within("ctm.elbo_rel_free_full", dev, (t_g, t_o))
+    within("ctm.mu_abs_free_full", np.abs(gm.mu - om.mu))
+    within("ctm.sigma_rel_free_full", np.abs(gm.sigma - om.sigma).max() / np.abs(om.sigma).max())
+    within("ctm.beta_abs_free_full", np.abs(gm.beta - om.beta))
+
+
 def test_ctpf_free_running_k50_medium_corpus_tracks_the_oracle(tmvb, oracle):
     """CTPF K = 50, 1 500 CiteULike-shaped documents with readers, 25 free-running iterations through train!: ELBO rel <= 1e-4 at
     every iteration (measured on MI355X: <= 2.7e-5, the early iterations where the ELBO moves by 25 % per

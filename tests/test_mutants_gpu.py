@@ -1,11 +1,13 @@
 """
 NEGATIVE CONTROLS of the parity suite (round-4 review: "there is no deliberately wrong variant that must fail").
 
-Three mutant libraries -- the shipped objects with ONE translation unit recompiled under a -DTMVB_MUTANT_* flag (csrc/tmvb_internal.h, tools/build_mutants.sh) -- each
+Five mutant libraries (three of round 5, two of round 6 for the SURVEY.md section 8(f) rows) -- the shipped objects with ONE translation unit recompiled under a -DTMVB_MUTANT_* flag (csrc/tmvb_internal.h, tools/build_mutants.sh) -- each
 wrong in one operator, in a way a careless port of the reference would be:
   mut_lda_eps    epsilon dropped from LDA's update_phi! / update_gamma!            src/LDA.jl:152, :145
   mut_ctpf_bet   `log bet` where update_xi! needs `log vav`                         src/CTPF.jl:336 -- the reference's own OpenCL path has this bug, src/gpuCTPF.jl:624
   mut_ctm_mu     update_sigma! centred on the NEW mu (update_mu! first)            src/CTM.jl:207-208, quirk Q2
+  mut_flda_eps   log(beta) for log(beta + eps) in the filtered models' table        src/fLDA.jl:184, :191 (@boink)
+  mut_fctm_order fCTM's sweep in CTM's order (update_vsq! before update_lambda!)    src/fCTM.jl:239-240 against src/CTM.jl:198-199
 For each, a NAMED parity test is run in a fresh pytest process with TMVB_LIB_VARIANT=<mutant> and must FAIL with an assertion of that test (not an import
 error, not a crash), while the shipped library passes the same test in the ordinary suite.  A parity suite that stays green on these would have no teeth.
 """
@@ -26,6 +28,10 @@ MUTANTS = {
                      ["tests/test_ctpf_gpu.py::test_teacher_forced_step[syn_k12]", "tests/test_ctpf_gpu.py::test_teacher_forced_step[syn_k50]"]),
     "mut_ctm_mu": ("tmvb_ctm.hip", "-DTMVB_MUTANT_CTM_SIGMA_NEW_MU=1",
                    ["tests/test_ctm_gpu.py::test_sigma_uses_previous_mu_quirk_q2", "tests/test_ctm_gpu.py::test_teacher_forced_step[syn_k12]"]),
+    "mut_flda_eps": ("tmvb_flda.hip", "-DTMVB_MUTANT_FLDA_NO_EPS=1",
+                     ["tests/test_flda_gpu.py::test_epsilon_keeps_phi_defined_where_a_beta_column_is_zero"]),
+    "mut_fctm_order": ("tmvb_ctm.hip", "-DTMVB_MUTANT_FCTM_VSQ_FIRST=1",
+                       ["tests/test_fctm_gpu.py::test_teacher_forced_fixed_sweeps[5]", "tests/test_fctm_gpu.py::test_teacher_forced_step[syn_k12]"]),
 }
 
 
@@ -74,6 +80,7 @@ def test_the_parity_suite_fails_on_the_mutant(name):
 def test_the_same_tests_pass_on_the_shipped_library():
     """the control of the control: the subprocess harness itself is sound (one test of each family, shipped library)"""
     for test_id in ("tests/test_lda_gpu.py::test_epsilon_keeps_phi_defined_where_a_beta_column_is_zero",
-                    "tests/test_ctpf_gpu.py::test_teacher_forced_step[syn_k12]", "tests/test_ctm_gpu.py::test_sigma_uses_previous_mu_quirk_q2"):
+                    "tests/test_ctpf_gpu.py::test_teacher_forced_step[syn_k12]", "tests/test_ctm_gpu.py::test_sigma_uses_previous_mu_quirk_q2",
+                    "tests/test_flda_gpu.py::test_epsilon_keeps_phi_defined_where_a_beta_column_is_zero", "tests/test_fctm_gpu.py::test_teacher_forced_fixed_sweeps[5]"):
         r = _run(test_id, "")
         assert r.returncode == 0, (test_id, r.stdout[-2000:], r.stderr[-1000:])

@@ -5,6 +5,9 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+from tol import within  # noqa: E402  (named tolerances of tests/tol.py, frozen at <= 10x their MI355X measurement; q90 over the documents and the maximum,
+#                                       which a document whose exit sweep flips against the oracle's sets)
+
 
 def test_lda_predict_matches_oracle_estep(tmvb, oracle):
     K = 12
@@ -19,7 +22,7 @@ def test_lda_predict_matches_oracle_estep(tmvb, oracle):
     assert p.gamma.shape == (K, new.M)
     same = np.ones(new.M, bool)          # compare documents tightly; sweep-count flips are rare and bounded below
     r = np.abs(p.gamma - om.gamma) / om.gamma
-    assert np.quantile(r.max(axis=0), 0.9) <= 5e-4 and r.max() <= 5e-2
+    within("predict.lda.gamma_rel_q90", np.quantile(r.max(axis=0), 0.9)); within("predict.lda.gamma_rel_max", r.max())
     td = tmvb.topicdist(p, 1)
     np.testing.assert_allclose(td, p.gamma[:, 0] / p.gamma[:, 0].sum())
     assert abs(td.sum() - 1.0) < 1e-12 and len(tmvb.topicdist(p, range(1, 4))) == 3
@@ -44,7 +47,8 @@ def test_ctm_predict_matches_oracle_estep(tmvb, oracle):
     assert np.array_equal(np.isnan(p.lam), np.isnan(om.lam))          # same (absent) NaN pattern as the oracle
     ok = ~np.isnan(om.lam).any(axis=0)
     assert ok.sum() >= 30
-    assert np.quantile(np.abs(p.lam - om.lam)[:, ok].max(axis=0), 0.9) <= 5e-3
+    within("predict.ctm.lambda_abs_q90", np.quantile(np.abs(p.lam - om.lam)[:, ok].max(axis=0), 0.9))
+    within("predict.ctm.lambda_abs_max", np.abs(p.lam - om.lam)[:, ok].max())
     td = tmvb.topicdist_ctm(p, 2)
     assert abs(td.sum() - 1.0) < 1e-12 and np.all(td > 0)
 
@@ -65,8 +69,8 @@ def test_flda_predict_matches_oracle_estep(tmvb, oracle):
     sw = om.estep(viter=10)
     assert p.gamma.shape == (K, new.M) and p.tau.shape == (new.nnz,)
     r = np.abs(p.gamma - om.gamma) / om.gamma
-    assert np.quantile(r.max(axis=0), 0.9) <= 5e-4 and r.max() <= 5e-2
-    assert np.quantile(np.abs(p.tau - om.tau), 0.99) <= 5e-5 and np.all((p.tau >= 0) & (p.tau <= 1))
+    within("predict.flda.gamma_rel_q90", np.quantile(r.max(axis=0), 0.9)); within("predict.flda.gamma_rel_max", r.max())
+    within("predict.flda.tau_abs_q99", np.quantile(np.abs(p.tau - om.tau), 0.99)); assert np.all((p.tau >= 0) & (p.tau <= 1))
     td = tmvb.topicdist(p, 3)
     np.testing.assert_allclose(td, p.gamma[:, 2] / p.gamma[:, 2].sum())
     with pytest.raises(ValueError):
@@ -89,8 +93,9 @@ def test_fctm_predict_matches_oracle_estep(tmvb, oracle):
     om.mu[:] = m.mu; om.sigma[:] = m.sigma; om.invsigma[:] = m.invsigma
     om.estep(viter=10)
     assert np.all(np.isfinite(p.lam)) and np.all(np.isfinite(om.lam))       # the kappa mixture keeps every token's phi finite
-    assert np.quantile(np.abs(p.lam - om.lam).max(axis=0), 0.9) <= 5e-3
-    assert np.quantile(np.abs(p.tau - om.tau), 0.99) <= 2e-4
+    within("predict.fctm.lambda_abs_q90", np.quantile(np.abs(p.lam - om.lam).max(axis=0), 0.9))
+    within("predict.fctm.lambda_abs_max", np.abs(p.lam - om.lam).max())
+    within("predict.fctm.tau_abs_q99", np.quantile(np.abs(p.tau - om.tau), 0.99))
     td = tmvb.topicdist_ctm(p, 2)
     assert abs(td.sum() - 1.0) < 1e-12 and np.all(td > 0)
     with pytest.raises(ValueError):

@@ -3,7 +3,7 @@
 src/modelutils.jl:574-585, so the time to the ELBO plateau -- the second half of BASELINE.json's metric -- pays it per iteration.)
 For each model: a few iterations from the cold start, then 10 x (iteration) and 10 x (iteration + update_elbo!) between synchronisations,
 and update_elbo! alone.  LDA and CTM with TMVB_LDA_ELBO_PARTS / TMVB_CTM_ELBO_PARTS = 2 / 0 (decomposed form / token walk, see tests/test_lda_elbo_parts_gpu.py).
-Usage: python tools/elbo_cost_probe.py [lda50] [lda100] [ctm] [ctpf] [flda]     one JSON line per measurement on stdout."""
+Usage: python tools/elbo_cost_probe.py [lda50] [lda100] [ctm] [ctpf] [flda] [fctm]     one JSON line per measurement on stdout."""
 import json
 import os
 import sys
@@ -77,15 +77,31 @@ def ctpf(K=50, parts="2"):
     gm.close()
 
 
-def flda(K=50):
+def flda(K=50, parts="2"):
+    os.environ["TMVB_FLDA_ELBO_PARTS"] = parts
     pc = tm.syn_nsf()
     gm = tm.gpufLDA(pc, K)
+    del os.environ["TMVB_FLDA_ELBO_PARTS"]
     gm.beta = np.asfortranarray(tm.dirichlet_rows(K, pc.V, seed=7)); gm.beta_old = gm.beta.copy(order="F")
     gm.kappa = tm.dirichlet_rows(1, pc.V, seed=9)[0].copy(); gm.kappa_old = gm.kappa.copy(); gm.update_buffer()
 
     def it():
         gm.estep(10, 1.0 / K ** 2); gm.reduce_docs(); gm.update_beta(); gm.update_alpha(1000, 1.0 / K ** 2); gm.update_eta()
-    measure(f"flda K={K} (token walk: the filtered models have no decomposed form)", gm, it, burnin=15, n=10)
+    measure(f"flda K={K} TMVB_FLDA_ELBO_PARTS={parts}", gm, it, burnin=15, n=10)
+    gm.close()
+
+
+def fctm(K=50, parts="2"):
+    os.environ["TMVB_FCTM_ELBO_PARTS"] = parts
+    pc = tm.syn_nsf()
+    gm = tm.gpufCTM(pc, K)
+    del os.environ["TMVB_FCTM_ELBO_PARTS"]
+    gm.beta = np.asfortranarray(tm.dirichlet_rows(K, pc.V, seed=7)); gm.beta_old = gm.beta.copy(order="F")
+    gm.kappa = tm.dirichlet_rows(1, pc.V, seed=9)[0].copy(); gm.kappa_old = gm.kappa.copy(); gm.update_buffer()
+
+    def it():
+        gm.estep(); gm.reduce_docs(); gm.mstep()
+    measure(f"fctm K={K} TMVB_FCTM_ELBO_PARTS={parts}", gm, it, burnin=8, n=4)
     gm.close()
 
 
@@ -98,6 +114,8 @@ if __name__ == "__main__":
     if "ctm" in which:
         ctm(parts="2"); ctm(parts="0")
     if "flda" in which:
-        flda()
+        flda(parts="2"); flda(parts="0")
+    if "fctm" in which:
+        fctm(parts="2"); fctm(parts="0")
     if "ctpf" in which:
         ctpf(parts="2"); ctpf(parts="0")

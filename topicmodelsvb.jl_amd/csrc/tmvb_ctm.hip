@@ -65,6 +65,7 @@ struct CtmParams {
     const float* kappa = nullptr;     // [V]
     float eta = 0.5f;
     float* tau = nullptr; float* tau_old = nullptr; float* lse = nullptr;     // [nnz], CSR order
+    float* aold = nullptr;            // [nnz] or NULL: sum_i phi_in log(beta[i, t_n] + eps) of each sweep (the exponent update_tau! forms), for the decomposed update_elbo! of fCTM
     uint16_t* doc_newton = nullptr;   // [M] lambda-Newton steps of each document in this E-step (lane-per-document kernel: next E-step's grouping key)
     // ctm_estep_generic_kernel<.., CG = true> only: the document queue of the persistent launch and the CG stopping rule
     unsigned* queue = nullptr;        // next position of doc_order to take (zeroed before the launch)
@@ -306,6 +307,7 @@ __global__ __launch_bounds__(64) void ctm_estep_kernel(CtmParams p, int64_t firs
             const float tnew = p.eta / (TMVB_EPS_F + (p.eta + (1.0f - p.eta) * (p.kappa[t_l[n]] * prod)));
             tp_l[n] = tp; tn_l[n] = tnew; m_l[n] = m; w_l[n] = c_l[n] / s;
             if (store) { p.tau_old[off + c0 + n] = tp; p.tau[off + c0 + n] = tnew; p.lse[off + c0 + n] = m + __logf(s); }
+            if (p.aold) p.aold[off + c0 + n] = a / s;                    // every sweep (the last executed one remains): one float per token
         }
         WAVE_LDS_FENCE();
     };
@@ -418,14 +420,18 @@ __global__ __launch_bounds__(64) void ctm_estep_kernel(CtmParams p, int64_t firs
             const double m = wave_max_d(x);
             lz = m + log(wave_sum_d(on ? exp(x - m) : 0.0));
         }
+#ifdef TMVB_MUTANT_FCTM_VSQ_FIRST
+        run_vsq(); run_lambda(phic);                                            // MUTANT: fCTM's sweep in CTM's order (tests/test_mutants_gpu.py)
+#else
         if constexpr (FILT) { run_lambda(phic); run_vsq(); }                    // src/fCTM.jl:239-240
         else { run_vsq(); run_lambda(phic); }                                   // src/CTM.jl:198-199
+#endif
         const double df = on ? lam - lam_old : 0.0;
         const double dist2 = wave_sum_d(df * df);
-        if constexpr (!FILT) { if (p.pdot) pd_last = wave_sum_d(phic * df); }
+        if (p.pdot) pd_last = wave_sum_d(phic * df);
         if (sqrt(dist2) < p.vtol) break;                                        // :200 / :242
     }
-    if constexpr (!FILT) { if (p.pdot && lane == 0) p.pdot[d] = (float)pd_last; }
+    if (p.pdot && lane == 0) p.pdot[d] = (float)pd_last;
 
     if (sweeps > 0) {
         if (on) {
@@ -760,6 +766,7 @@ __global__ __launch_bounds__(64 * MAXW) void ctm_estep_generic_kernel(CtmParams 
             tp_l[n] = tp; m_l[n] = m; w_l[n] = c_l[n] / s;
             tn_l[n] = tnew;                                                                                 // (a resident tile is not loaded again)
             p.tau_old[off + c0 + n] = tp; p.tau[off + c0 + n] = tnew; p.lse[off + c0 + n] = m + __logf(s);   // streamed window: always stored
+            if (p.aold) p.aold[off + c0 + n] = a / s;
         }
         GEN_FENCE();
     };
@@ -1075,10 +1082,10 @@ __global__ __launch_bounds__(64 * MAXW) void ctm_estep_generic_kernel(CtmParams 
         double d2l = 0.0, pdl = 0.0;
 #pragma unroll
         for (int s = 0; s < NS; ++s) if (on[s]) { const double df = lam[s] - lam_old[s]; d2l += df * df; pdl = fma(phic[s], df, pdl); }
-        if constexpr (!FILT) { if (p.pdot) pd_last = wave_sum_d(pdl); }
+        if (p.pdot) pd_last = wave_sum_d(pdl);
         if (sqrt(wave_sum_d(d2l)) < p.vtol) break;                                          // :200
     }
-    if constexpr (!FILT) { if (p.pdot && lane == 0) p.pdot[d] = (float)pd_last; }
+    if (p.pdot && lane == 0) p.pdot[d] = (float)pd_last;
 
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -1429,6 +1436,7 @@ struct tmvb_ctm {
     uint16_t* d_doc_newton = nullptr; int32_t* d_doc_order0 = nullptr;
     int32_t* d_doc_order_q = nullptr; unsigned* d_wave_keys = nullptr; bool queue_sorted = false; hipEvent_t ev_spec2 = nullptr; bool spec2_pending = false;      // the lane-per-document launch's queue order (ctm_wave_sort_kernel), valid for the next E-step
     float* d_bt_sdiag = nullptr; float* d_bt_muf = nullptr; unsigned long long* d_cg_iters = nullptr;
+    bool filt_parts = false, filt_pw_valid = false;   // fCTM's collecting E-step ran / update_beta! left sum S (log(beta_new + eps) - log(beta_old + eps)) behind it
     float* d_q_S = nullptr; float* d_q_sd = nullptr; float* d_q_mu = nullptr; int beta_pad_cpr = 0;   // tables of the four-waves-per-item kernel (tmvb_ctm_quad.h)
     float cg_tol = 1e-4f, cg_abs = 0.05f;   // CG exit: relative residual, and the fraction of ntol it may stop at (TMVB_CTM_CG_TOL / _ABS)
     double* d_sigma = nullptr; double* d_invsigma = nullptr; double* d_mu = nullptr; double* d_logdet = nullptr;
@@ -1811,7 +1819,7 @@ static int ctm_launch_quad(tmvb_ctm* h, const CtmParams& p, double ntol)
     const int LPRv = h->KP / 4, CPR = 4 * ((LPRv + 3) / 4);
     const size_t lds = (size_t)(3 * h->KP * 64 + 2 * 3 * 4 * 64) * 4 + (size_t)(2 * 4 * 64) * 8 + (5 * 64 + 4) * 4;
     // two workgroups per CU: two waves per SIMD (TMVB_CTM_QUAD_PER_CU: diagnostics)
-    int per_cu = 2;
+    int per_cu = TMVB_CTM_QWAVES;
     if (const char* e = getenv("TMVB_CTM_QUAD_PER_CU")) per_cu = std::max(1, std::min(4, atoi(e)));
     const dim3 grid((unsigned)std::min(n_items, per_cu * ctx->num_cu)), block(256);
     tb.next_item = (unsigned*)(h->d_cg_iters + 12); tb.n_items = n_items;
@@ -2127,12 +2135,13 @@ extern "C" int tmvb_ctm_update_beta(tmvb_ctm* h)
     if (rc) return rc;
     const int64_t total = (int64_t)h->KP * h->V;
     int nb = (int)std::min<int64_t>(2048, std::max<int64_t>(1, (total + 255) / 256));
-    const bool parts = h->logz_valid && h->stats_fresh;     // the coming update_elbo! is the decomposed one (src/CTM.jl:71 has the epsilon, :93 has none)
+    const bool fparts = h->filt_parts;                      // fCTM (src/fCTM.jl:89, :109): both logarithms carry the epsilon
+    const bool parts = (h->logz_valid && h->stats_fresh) || fparts;     // the coming update_elbo! is the decomposed one (src/CTM.jl:71 has the epsilon, :93 has none)
     hipLaunchKernelGGL(beta_norm_kernel, dim3(nb), dim3(256), (size_t)h->K * sizeof(double), ctx->stream,
                        h->d_stats, h->d_rowsum, h->d_beta[h->cur ^ 1], h->K, h->KP, h->V, parts ? h->d_pw_partial : (double*)nullptr, parts ? TMVB_EPS_F : 0.0f,
-                       parts ? (const float*)h->d_beta[h->cur] : (const float*)nullptr, 0.0f);
+                       parts ? (const float*)h->d_beta[h->cur] : (const float*)nullptr, fparts ? TMVB_EPS_F : 0.0f);
     TMVB_HIP(hipGetLastError());
-    h->pw_blocks = nb; h->pw_valid = parts; h->stats_fresh = false;
+    h->pw_blocks = nb; h->pw_valid = parts && !fparts; h->stats_fresh = false; h->filt_pw_valid = fparts; h->filt_parts = false;
     h->cur ^= 1;
     return TMVB_OK;
 }
@@ -2454,12 +2463,84 @@ __global__ __launch_bounds__(64) void fctm_elbo_kernel(int K, int KP, const int6
     if (lane == 0) doc_val[d] = tot;
 }
 
+// update_elbo! of fCTM without rebuilding phi (round 6; the fLDA form, flda_elbo_doc_parts_kernel in tmvb_flda.hip, with lambda for Elogtheta): the token
+// terms of Elogpz (:82), Elogpw (:89) and -Elogqz (:108-111) are c_n [sum_i phi_in (lambda_i - lambda_old_i) + tau_n sum_i phi_in L_new - tau_old_n A_n + lse_n];
+// the first sum is pdot[d] of the E-step kernels' exit test (CtmParams::pdot), the second sum S L_new of update_beta! (its difference form also carries
+// -tau_n A_n), lse_n and A_n are per-token floats the E-step stores.  One wave per document: lane = token for the elementwise sum, lane = topic for
+// Elogpeta / the logzeta bound / the Gaussian entropy (as fctm_elbo_kernel).
+template <int NS>
+__global__ __launch_bounds__(64) void fctm_elbo_doc_parts_kernel(int K, const int64_t* __restrict__ doc_ptr, const int32_t* __restrict__ terms,
+                                                                 const int32_t* __restrict__ counts, const double* __restrict__ mu_d,
+                                                                 const double* __restrict__ invsigma_d, const double* __restrict__ logdet_inv, double eta,
+                                                                 const float* __restrict__ kappa, const float* __restrict__ lambda,
+                                                                 const float* __restrict__ vsq, const float* __restrict__ logzeta,
+                                                                 const float* __restrict__ tau, const float* __restrict__ tau_old,
+                                                                 const float* __restrict__ lse, const float* __restrict__ aold,
+                                                                 const float* __restrict__ pdot, double* __restrict__ doc_val)
+{
+    const int lane = threadIdx.x;
+    const int d = blockIdx.x;
+    const int64_t off = doc_ptr[d];
+    const int N = (int)(doc_ptr[d + 1] - off);
+    bool on[NS]; int ix[NS];
+    double l[NS], v[NS], df[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        on[s] = lane + 64 * s < K;
+        ix[s] = on[s] ? lane + 64 * s : 0;
+        l[s] = on[s] ? (double)lambda[(int64_t)d * K + ix[s]] : 0.0;
+        v[s] = on[s] ? (double)vsq[(int64_t)d * K + ix[s]] : 1.0;
+        df[s] = on[s] ? l[s] - mu_d[ix[s]] : 0.0;
+    }
+    const double lz = (double)logzeta[d];
+    double acc = 0.0, Cd = 0.0, ta = 0.0;
+    for (int n = lane; n < N; n += 64) {
+        const double c = (double)counts[off + n];
+        const double tn = (double)tau[off + n], to = (double)tau_old[off + n];
+        double x = (double)lse[off + n] + (tn - to) * (double)aold[off + n];
+        x += (1.0 - tn) * (double)logf(kappa[terms[off + n]] + TMVB_EPS_F);                    // Elogpw :89, background part
+        if (tn > 0.0 && tn < 1.0) x -= tn * log(tn) + (1.0 - tn) * log(1.0 - tn);             // -Elogqc :101-104
+        acc += c * x;
+        Cd += c; ta += tn * c;
+    }
+    Cd = wave_sum_d(Cd); ta = wave_sum_d(ta);
+    if (lane == 0 && N > 0) acc += (double)pdot[d];
+    // Elogpeta :69
+    double mv[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) mv[s] = 0.0;
+    for (int j = 0; j < K; ++j) {
+        double dj = 0.0;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) if ((j >> 6) == s) dj = readlane_d(df[s], j & 63);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) mv[s] = fma(on[s] ? invsigma_d[(int64_t)j * K + ix[s]] : 0.0, dj, mv[s]);
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        if (!on[s]) continue;
+        acc += -0.5 * (invsigma_d[(int64_t)ix[s] * K + ix[s]] * v[s] + df[s] * mv[s]);
+        acc -= Cd * exp(l[s] + 0.5 * v[s] - lz);                                               // Elogpz :82 (second part)
+        acc += 0.5 * log(v[s]);                                                                // -Elogqeta :95-97
+    }
+    double tot = wave_sum_d(acc);
+    const double TWO_PI_LOG = 1.8378770664093453;
+    tot += 0.5 * (*logdet_inv - (double)K * TWO_PI_LOG);
+    tot -= Cd * (lz - 1.0);
+    tot += 0.5 * (double)K * (1.0 + TWO_PI_LOG);
+    tot += log(TMVB_EPS_D + pow(eta, ta) * pow(1.0 - eta, Cd - ta));                           // Elogpc :74-77
+    if (lane == 0) doc_val[d] = tot;
+}
+
 struct tmvb_fctm {
     tmvb_ctm* base = nullptr;
     int64_t nnz = 0;
     double eta = 0.5;                     // update_eta! is commented out in the reference's train! (src/fCTM.jl:253): a parameter
     float* d_L = nullptr; float* d_kappa = nullptr; float* d_kappa_old = nullptr;
     float* d_tau = nullptr; float* d_tau_old = nullptr; float* d_lse = nullptr;
+    float* d_aold = nullptr;              // [nnz] decomposed update_elbo!: the per-token exponent of the last sweep (CtmParams::aold)
+    int parts_env = 1;                    // TMVB_FCTM_ELBO_PARTS at creation: 0 never, 1 the iterations train! checks, 2 every E-step collects
+    bool want_parts = false, force_walk = false; int elbo_form = 0;      // as tmvb_flda
     float* d_stats = nullptr;             // the base handle is bound to this buffer
     double* d_eta_scratch = nullptr; double* d_ksum = nullptr;
     int64_t stats_len() const { return base->stats_len() + base->V; }
@@ -2471,7 +2552,7 @@ extern "C" int tmvb_fctm_destroy(tmvb_fctm* h)
     if (!h) return TMVB_OK;
     if (h->base && h->base->ctx) { (void)hipSetDevice(h->base->ctx->device); (void)hipStreamSynchronize(h->base->ctx->stream); }
     (void)tmvb_ctm_destroy(h->base);      // does not free the bound statistics buffer
-    (void)hipFree(h->d_L); (void)hipFree(h->d_kappa); (void)hipFree(h->d_kappa_old); (void)hipFree(h->d_tau); (void)hipFree(h->d_tau_old);
+    (void)hipFree(h->d_aold); (void)hipFree(h->d_L); (void)hipFree(h->d_kappa); (void)hipFree(h->d_kappa_old); (void)hipFree(h->d_tau); (void)hipFree(h->d_tau_old);
     (void)hipFree(h->d_lse); (void)hipFree(h->d_stats); (void)hipFree(h->d_eta_scratch); (void)hipFree(h->d_ksum);
     delete h;
     return TMVB_OK;
@@ -2505,8 +2586,9 @@ extern "C" int tmvb_fctm_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmv
     const size_t V = (size_t)b->V, NZ = (size_t)h->nnz, KPV = (size_t)b->KP * b->V + 4;
     if ((rc = dmalloc(&h->d_L, KPV)) || (rc = dmalloc(&h->d_kappa, V)) || (rc = dmalloc(&h->d_kappa_old, V)) || (rc = dmalloc(&h->d_tau, NZ)) ||
         (rc = dmalloc(&h->d_tau_old, NZ)) || (rc = dmalloc(&h->d_lse, NZ)) || (rc = dmalloc(&h->d_stats, (size_t)h->stats_len())) ||
-        (rc = dmalloc(&h->d_eta_scratch, 1)) || (rc = dmalloc(&h->d_ksum, 1)))
+        (rc = dmalloc(&h->d_aold, std::max<size_t>(NZ, 1))) || (rc = dmalloc(&h->d_eta_scratch, 1)) || (rc = dmalloc(&h->d_ksum, 1)))
         return rc;
+    { const char* e = getenv("TMVB_FCTM_ELBO_PARTS"); h->parts_env = e ? atoi(e) : 1; }
     TMVB_HIP(hipMemsetAsync(h->d_stats, 0, (size_t)h->stats_len() * sizeof(float), ctx->stream));
     TMVB_HIP(hipMemsetAsync(h->d_lse, 0, std::max<size_t>(NZ, 1) * sizeof(float), ctx->stream));
     TMVB_HIP(hipStreamSynchronize(ctx->stream));
@@ -2532,6 +2614,7 @@ extern "C" int tmvb_fctm_set_state(tmvb_fctm* h, const double* eta, const double
     tmvb_ctx* ctx = b->ctx;
     int rc = tmvb_ctm_set_state(b, mu, sigma, invsigma, beta, beta_old, lambda, lambda_old, vsq, logzeta, elbo);
     if (rc) return rc;
+    b->filt_parts = false; b->filt_pw_valid = false;       // a state set by the host: update_elbo! takes the token walk
     const size_t V = (size_t)b->V, NZ = (size_t)h->nnz;
     if (eta) {
         TMVB_REQUIRE(*eta >= 0.0 && *eta <= 1.0, TMVB_ESHAPE, "eta must belong to the interval [0,1].");    // src/modelutils.jl:145
@@ -2589,6 +2672,11 @@ extern "C" int tmvb_fctm_estep(tmvb_fctm* h, int32_t niter, double ntol, int32_t
     p.wtok = b->d_wtok; p.E = b->d_E; p.estride = (b->KP / 4 <= 64) ? b->KP : b->K; p.sweeps = b->d_sweeps; p.newton_steps = b->d_newton;
     p.niter = niter; p.ntol = ntol; p.viter = viter; p.vtol = vtol; p.debug = 0; p.store_w = 0;
     p.L = h->d_L; p.kappa = h->d_kappa; p.eta = (float)h->eta; p.tau = h->d_tau; p.tau_old = h->d_tau_old; p.lse = h->d_lse;
+    // decomposed update_elbo! (fctm_elbo_doc_parts_kernel): an iteration that will be checked stores the per-token exponent and the per-document
+    // sum_i (phi counts)_i (lambda_i - lambda_old_i); viter = 0 leaves no responsibilities (token walk)
+    const bool collect = (h->parts_env == 2 || (h->parts_env != 0 && h->want_parts)) && viter > 0;
+    b->filt_parts = false; b->filt_pw_valid = false;
+    if (collect) { p.aold = h->d_aold; p.pdot = b->d_pdot; }
     TMVB_HIP(hipEventRecord(b->ev0, ctx->stream));
     TMVB_HIP(hipMemsetAsync(b->d_newton, 0, sizeof(unsigned long long), ctx->stream));
     if (b->generic && b->M > 0) {
@@ -2614,6 +2702,7 @@ extern "C" int tmvb_fctm_estep(tmvb_fctm* h, int32_t niter, double ntol, int32_t
     if (rc) return rc;
     TMVB_HIP(hipEventRecord(b->ev1, ctx->stream));
     b->timed = true;
+    b->filt_parts = collect;
     return TMVB_OK;
 }
 
@@ -2646,6 +2735,22 @@ extern "C" int tmvb_fctm_update_elbo(tmvb_fctm* h, double* elbo)
     tmvb_ctm* b = h->base;
     tmvb_ctx* ctx = b->ctx;
     TMVB_HIP(hipSetDevice(ctx->device));
+    const bool parts = b->filt_pw_valid && !h->force_walk && h->parts_env != 0;
+    h->elbo_form = parts ? 1 : 0;
+    if (parts) {
+        if (b->M > 0) {
+            const dim3 grid((unsigned)b->M), block(64);
+#define FCTM_PARTS(NSV) hipLaunchKernelGGL((fctm_elbo_doc_parts_kernel<NSV>), grid, block, 0, ctx->stream, b->K, b->corp->d_doc_ptr, b->corp->d_terms, b->corp->d_counts, \
+                               b->d_mu, b->d_invsigma, b->d_logdet, h->eta, h->d_kappa, b->d_lambda, b->d_vsq, b->d_logzeta, h->d_tau, h->d_tau_old, h->d_lse, \
+                               h->d_aold, b->d_pdot, b->d_doc_val)
+            if (b->nslot == 1) FCTM_PARTS(1); else if (b->nslot == 2) FCTM_PARTS(2); else FCTM_PARTS(4);
+#undef FCTM_PARTS
+            TMVB_HIP(hipGetLastError());
+        }
+        hipLaunchKernelGGL(ctm_elbo_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, b->d_doc_val, b->M, (const double*)nullptr, (int64_t)0, b->d_pw_partial, b->pw_blocks,
+                           b->distributed && b->M_total > 0 ? (double)b->M / (double)b->M_total : 1.0, b->d_elbo);
+        TMVB_HIP(hipGetLastError());
+    } else {
     if (b->M > 0) {
         const dim3 grid((unsigned)b->M), block(64);
         if (b->nslot == 1)
@@ -2664,6 +2769,7 @@ extern "C" int tmvb_fctm_update_elbo(tmvb_fctm* h, double* elbo)
     }
     hipLaunchKernelGGL(sum_docs_kernel, dim3(1), dim3(1024), 0, ctx->stream, b->d_doc_val, b->M, b->d_elbo);
     TMVB_HIP(hipGetLastError());
+    }
     double v = 0.0;
     int st = 0;
     TMVB_HIP(hipMemcpyAsync(&v, b->d_elbo, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -2672,6 +2778,13 @@ extern "C" int tmvb_fctm_update_elbo(tmvb_fctm* h, double* elbo)
     TMVB_REQUIRE(st == 0, TMVB_ENONFINITE, "sigma must be positive-definite.");
     b->elbo = v;
     if (elbo) *elbo = v;
+    return TMVB_OK;
+}
+
+extern "C" int tmvb_fctm_elbo_form(tmvb_fctm* h, int32_t* form)
+{
+    TMVB_REQUIRE(h && form, TMVB_EINVAL, "tmvb_fctm_elbo_form: NULL argument");
+    *form = h->elbo_form;
     return TMVB_OK;
 }
 
@@ -2697,6 +2810,9 @@ struct FctmTrainOps {
         return rc;
     }
     int elbo_local(tmvb_fctm* h, double* s, double* once) { *once = 0.0; return tmvb_fctm_update_elbo(h, s); }
+    int elbo_form(tmvb_fctm* h) { return h->elbo_form; }
+    void force_walk(tmvb_fctm* h, bool on, bool doubled = true) { h->force_walk = on; if (!on && doubled) h->elbo_form = 1; }   // (as LdaTrainOps)
+    void will_check(tmvb_fctm* h, bool checked) { h->want_parts = checked; }
     double* elbo_dev(tmvb_fctm* h) { return h->base->d_elbo; }
     tmvb_comm* comm(tmvb_fctm* h) { return h->base->comm; }
     bool distributed(tmvb_fctm* h) { return h->base->distributed; }

@@ -507,6 +507,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             float* tau = CB_KARG(float*, p.tau);
             float* tau_old = CB_KARG(float*, p.tau_old);
             float* lse = CB_KARG(float*, p.lse);
+            float* aold = CB_KARG(float*, p.aold);
             const float eta = a.p.eta;
             cb_v2f lf[R / 2], acc[R / 2];
 #pragma unroll
@@ -570,6 +571,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                     for (int i = 0; i < R / 2; ++i) acc[i] = __builtin_elementwise_fma(w2, x[i], acc[i]);
                     if (active && n0 + k < N) {
                         tau_old[off + n0 + k] = uq[k]; tau[off + n0 + k] = tnew; lse[off + n0 + k] = m + __logf(sn);
+                        if (aold) aold[off + n0 + k] = an / sn;                              // the decomposed update_elbo!'s per-token exponent
                     }
                 }
 #pragma unroll
@@ -836,8 +838,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         }
         };
         lap(1);
+#ifdef TMVB_MUTANT_FCTM_VSQ_FIRST
+        // MUTANT (tests/test_mutants_gpu.py, never in a shipped build): fCTM's sweep in CTM's order (update_vsq! in front of update_lambda!)
+        run_vsq(); lap(2); run_lambda();
+#else
         if constexpr (FILT) { run_lambda(); lap(2); run_vsq(); }                    // src/fCTM.jl:239-240
         else { run_vsq(); lap(2); run_lambda(); }                                   // src/CTM.jl:198-199
+#endif
         CB_VIEW();
         if (active) {
             const float* lam_old_in = CB_KARG(const float*, p.lambda_old);
@@ -850,7 +857,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             for (int i = 0; i < R; ++i) {
                 if (i < R - 7 || i < K) { const float df = (float)(LAM(i) - (double)lam_old_in[(int64_t)d * K + i]); dist2 = fmaf(df, df, dist2); pdot = fmaf(phic[i], df, pdot); }
             }
-            if constexpr (!FILT) { float* pd_out = CB_KARG(float*, p.pdot); if (pd_out) pd_out[d] = pdot; }
+            { float* pd_out = CB_KARG(float*, p.pdot); if (pd_out) pd_out[d] = pdot; }
 #else
 #pragma unroll
             for (int i = 0; i < R; ++i) {

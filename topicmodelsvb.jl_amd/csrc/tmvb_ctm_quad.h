@@ -21,6 +21,9 @@
 // (gradient, logzeta, the vsq Newton iterations, lambda itself) and the exit tests are unchanged.  CTM only (fCTM keeps the one-wave kernel).
 #pragma once
 
+#ifndef TMVB_CTM_QWAVES
+#define TMVB_CTM_QWAVES 2                 // workgroups per CU = waves per SIMD the kernel is compiled for (3: 168 registers, measured slower -- see DESIGN.md)
+#endif
 template <int R> struct cq_dim {
     static constexpr int H = R / 4;                      // topics per wave (R = 4 * odd)
     static constexpr int JP = R / 2;                     // column pairs
@@ -134,7 +137,7 @@ __device__ __forceinline__ void cq_vmwait_def(T& d) { asm volatile("" : "+v"(d))
 // PROF (TMVB_CTM_QPROF=1): wave 0 of every workgroup adds its shader cycles per phase to tb.cg_iters[3..11] (the slots of tmvb_ctm_solver_stats:
 // token incl. the wait for the slowest wave, logzeta, vsq, gradient assembly, CG, gradient mat-vec incl. its exchange, exit test; [11] the item)
 template <int R, bool PROF>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void ctm_estep_quad_kernel(CtmBatchArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMVB_CTM_QWAVES, TMVB_CTM_QWAVES))) void ctm_estep_quad_kernel(CtmBatchArgs a)
 {
     using DM = cq_dim<R>;
     constexpr int H = DM::H, JP = DM::JP, NS = DM::NS, LPR = DM::LPR;

@@ -144,7 +144,13 @@ static __global__ __launch_bounds__(256) void flda_logbeta_kernel(const float* _
     const int64_t total = V * KP;
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
         const int i = (int)(q % KP);
+#ifdef TMVB_MUTANT_FLDA_NO_EPS
+        // MUTANT (tests/test_mutants_gpu.py, never in a shipped build): the log table of the filtered models without the epsilon of @boink
+        // (src/fLDA.jl:191, :184; src/fCTM.jl:219): a term whose beta column is zero then has phi = softmax(-inf - -inf) = NaN
+        L[q] = (i < K) ? logf(beta[q]) : 0.0f;
+#else
         L[q] = (i < K) ? logf(beta[q] + TMVB_EPS_F) : 0.0f;
+#endif
     }
 }
 

@@ -41,12 +41,13 @@ struct FldaParams {
     float* gamma; float* elog; float* elog_old;    // [M][K]
     float* tau; float* tau_old;                    // [nnz] CSR order
     float* lse;                // [nnz] log-sum-exp of the last sweep's phi column (input of the statistics pass)
+    float* aold;               // [nnz] sum_i phi_in log(beta[i, t_n] + eps) of the last sweep (the exponent update_tau! forms): the decomposed update_elbo!'s per-token input
     uint8_t* sweeps;
     int viter;
     float vtol;
 };
 
-static size_t flda_tile_bytes(int rows, int KP) { return ((size_t)rows * KP + KP + 6 * (size_t)rows) * sizeof(float); }
+static size_t flda_tile_bytes(int rows, int KP) { return ((size_t)rows * KP + KP + 7 * (size_t)rows) * sizeof(float); }
 
 template <int NS>
 __global__ __launch_bounds__(64) void flda_estep_kernel(FldaParams p, int64_t first, int tile_rows)
@@ -61,7 +62,8 @@ __global__ __launch_bounds__(64) void flda_estep_kernel(FldaParams p, int64_t fi
     float* m_l = tn_l + tile_rows;                     // [tile_rows] column maximum
     float* w_l = m_l + tile_rows;                      // [tile_rows] c_n / s_n
     float* c_l = w_l + tile_rows;                      // [tile_rows] counts
-    int* t_l = (int*)(c_l + tile_rows);                // [tile_rows] term ids
+    float* a_l = c_l + tile_rows;                      // [tile_rows] sum_i phi_i log(beta_i + eps)
+    int* t_l = (int*)(a_l + tile_rows);                // [tile_rows] term ids
 
     const int d = p.doc_order[first + blockIdx.x];
     const int64_t off = p.doc_ptr[d];
@@ -122,9 +124,9 @@ __global__ __launch_bounds__(64) void flda_estep_kernel(FldaParams p, int64_t fi
             const float A = a / s;                                       // sum_i phi_i log(beta_i + eps) <= 0
             const float prod = __expf(fminf(-A, 87.0f));                 // prod_i beta^-phi  (:184)
             const float tnew = eta / (TMVB_EPS_F + (eta + (1.0f - eta) * (p.kappa[t_l[n]] * prod)));
-            tp_l[n] = tp; tn_l[n] = tnew; m_l[n] = m; w_l[n] = c_l[n] / s;
+            tp_l[n] = tp; tn_l[n] = tnew; m_l[n] = m; w_l[n] = c_l[n] / s; a_l[n] = A;
             if (store) {
-                p.tau_old[off + c0 + n] = tp; p.tau[off + c0 + n] = tnew; p.lse[off + c0 + n] = m + __logf(s);
+                p.tau_old[off + c0 + n] = tp; p.tau[off + c0 + n] = tnew; p.lse[off + c0 + n] = m + __logf(s); p.aold[off + c0 + n] = A;
             }
         }
         WAVE_LDS_FENCE();
@@ -208,6 +210,7 @@ __global__ __launch_bounds__(64) void flda_estep_kernel(FldaParams p, int64_t fi
             for (int n = lane; n < N; n += 64) {
                 p.tau_old[off + n] = tp_l[n]; p.tau[off + n] = tn_l[n];
                 p.lse[off + n] = m_l[n] + __logf(c_l[n] / w_l[n]);      // m + log s
+                p.aold[off + n] = a_l[n];
             }
     } else {
         for (int n = lane; n < N; n += 64) p.lse[off + n] = INFINITY;   // viter = 0: no responsibilities (phi = 0 in the statistics)
@@ -293,6 +296,60 @@ __global__ __launch_bounds__(64) void flda_elbo_kernel(int K, int KP, const int6
     if (lane == 0) doc_val[d] = tot;
 }
 
+// ------------------------------------------------------------------------------ ELBO, decomposed (round 6)
+// update_elbo! without rebuilding phi.  With x_in = tau_old_n L_old[i, t_n] + Elogtheta_old_i, lse_n = log sum_i e^{x_in} and
+// phi_in = e^{x_in - lse_n} (src/fLDA.jl:112), the token terms of Elogpz (:77), Elogpw (:83) and -Elogqz (:101-104) are
+//     c_n [ sum_i phi_in (Elogtheta_i - Elogtheta_old_i) + tau_n sum_i phi_in L_new[i, t_n] - tau_old_n A_n + lse_n ],   A_n = sum_i phi_in L_old[i, t_n],
+// and they separate into what the checked iteration already holds: sum_n c_n phi_in = gamma_i - alpha_i - eps (update_gamma!, :175, with the alpha the
+// E-step read), sum_n tau_n c_n phi_in = S (update_beta!(d), :161: update_beta! leaves sum S (log(beta_new + eps) - log(beta_old + eps)), which carries
+// -tau_n A_n as well), and per token the two floats the E-step kernel stores anyway (lse_n for the statistics pass, A_n = the exponent update_tau!
+// forms, :184).  What is left is elementwise: one wave per document adds c_n [lse_n + (tau_n - tau_old_n) A_n + (1 - tau_n) log(kappa + eps) + H(tau_n)]
+// over its tokens (lane = token), the Dirichlet terms over its topics (lane = topic), and Elogpc (:69-71).
+template <int NS>
+__global__ __launch_bounds__(64) void flda_elbo_doc_parts_kernel(int K, const int64_t* __restrict__ doc_ptr, const int32_t* __restrict__ terms,
+                                                                 const int32_t* __restrict__ counts, const double* __restrict__ alpha_d,
+                                                                 const float* __restrict__ alpha_e, const double* __restrict__ eta_d,
+                                                                 const float* __restrict__ kappa, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ elog, const float* __restrict__ elog_old,
+                                                                 const float* __restrict__ tau, const float* __restrict__ tau_old,
+                                                                 const float* __restrict__ lse, const float* __restrict__ aold,
+                                                                 double* __restrict__ doc_val)
+{
+    const int lane = threadIdx.x;
+    const int d = blockIdx.x;
+    const int64_t off = doc_ptr[d];
+    const int N = (int)(doc_ptr[d + 1] - off);
+    double acc = 0.0, ta = 0.0, Cd = 0.0;
+    for (int n = lane; n < N; n += 64) {
+        const double c = (double)counts[off + n];
+        const double tn = (double)tau[off + n], to = (double)tau_old[off + n];
+        double v = (double)lse[off + n] + (tn - to) * (double)aold[off + n];
+        v += (1.0 - tn) * (double)logf(kappa[terms[off + n]] + TMVB_EPS_F);                         // Elogpw :83, background part
+        if (tn > 0.0 && tn < 1.0) v -= tn * log(tn) + (1.0 - tn) * log(1.0 - tn);                  // -Elogqc :94-97
+        acc += c * v;
+        ta += tn * c; Cd += c;
+    }
+    double gl = 0.0;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int i = lane + 64 * s;
+        if (i >= K) continue;
+        const double el = (double)elog[(int64_t)d * K + i], elo = (double)elog_old[(int64_t)d * K + i];
+        const double g = (double)gamma[(int64_t)d * K + i];
+        acc += (alpha_d[i] - 1.0) * el;                                                             // Elogptheta :63 (dot part)
+        acc += (g - (double)alpha_e[i] - TMVB_EPS_D) * (el - elo);                                   // sum_n c_n phi_in (Elogtheta_i - Elogtheta_old_i)
+        if (K > 1) { double ps, lg; digamma_lgamma_d(g, ps, lg); acc += lg - (g - 1.0) * ps; }     // -Elogqtheta :89
+        gl += g;
+    }
+    const double g0 = wave_sum_d(gl);
+    double tot = wave_sum_d(acc);
+    ta = wave_sum_d(ta); Cd = wave_sum_d(Cd);
+    if (K > 1) { double ps0, lg0; digamma_lgamma_d(g0, ps0, lg0); tot += -lg0 + (g0 - (double)K) * ps0; }
+    const double eta = eta_d[0];
+    tot += log(TMVB_EPS_D + pow(eta, ta) * pow(1.0 - eta, Cd - ta));                                // Elogpc :69-71
+    if (lane == 0) doc_val[d] = tot;
+}
+
 // ------------------------------------------------------------------------------ host side
 struct tmvb_flda {
     tmvb_ctx* ctx = nullptr;
@@ -310,6 +367,15 @@ struct tmvb_flda {
     float* d_stats = nullptr;                                  // S (K*V) | kstat (V) | Elogtheta_sum (K)
     float* d_gamma = nullptr; float* d_elog = nullptr; float* d_elog_old = nullptr;
     float* d_tau = nullptr; float* d_tau_old = nullptr; float* d_lse = nullptr;
+    // decomposed update_elbo! (flda_elbo_doc_parts_kernel): the per-token exponent of the last sweep, the alpha the collecting E-step read, update_beta!'s
+    // partial sums of S (log beta_new - log beta_old)
+    float* d_aold = nullptr; float* d_alpha_e = nullptr; double* d_pw_partial = nullptr; int pw_blocks = 0;
+    int parts_env = 1;                 // TMVB_FLDA_ELBO_PARTS at creation: 0 never, 1 the iterations train! checks, 2 every E-step collects
+    bool want_parts = false;           // train!: the coming iteration ends in check_elbo!
+    bool parts_pending = false;        // the last E-step collected (aold, alpha_e belong to it) and update_beta! has not run behind it yet
+    bool parts_valid = false;          // ... it has: d_pw_partial belongs to that E-step too and nothing was set from outside since
+    bool force_walk = false;           // train!'s like-with-like evaluation at the switch of forms (tmvb_train.h)
+    int elbo_form = 0;                 // the last update_elbo!: 1 decomposed, 0 token walk (tmvb_flda_elbo_form)
     float* d_ts_partial = nullptr;
     uint8_t* d_sweeps = nullptr; int32_t* d_doc_order = nullptr;
     double* d_partial = nullptr; double* d_rowsum = nullptr; double* d_esum = nullptr; double* d_doc_val = nullptr; double* d_elbo = nullptr;
@@ -327,6 +393,7 @@ extern "C" int tmvb_flda_destroy(tmvb_flda* h)
 {
     if (!h) return TMVB_OK;
     if (h->ctx) { (void)hipSetDevice(h->ctx->device); (void)hipStreamSynchronize(h->ctx->stream); }
+    (void)hipFree(h->d_aold); (void)hipFree(h->d_alpha_e); (void)hipFree(h->d_pw_partial);
     (void)hipFree(h->d_alpha_d); (void)hipFree(h->d_alpha_f); (void)hipFree(h->d_beta[0]); (void)hipFree(h->d_beta[1]); (void)hipFree(h->d_L);
     (void)hipFree(h->d_kappa); (void)hipFree(h->d_kappa_old); (void)hipFree(h->d_eta); (void)hipFree(h->d_ksum); (void)hipFree(h->d_stats);
     (void)hipFree(h->d_gamma); (void)hipFree(h->d_elog); (void)hipFree(h->d_elog_old); (void)hipFree(h->d_tau); (void)hipFree(h->d_tau_old);
@@ -394,18 +461,20 @@ extern "C" int tmvb_flda_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmv
         (rc = dmalloc(&h->d_eta, 1)) || (rc = dmalloc(&h->d_ksum, 1)) || (rc = dmalloc(&h->d_stats, (size_t)h->stats_len())) ||
         (rc = dmalloc(&h->d_gamma, KM)) || (rc = dmalloc(&h->d_elog, KM)) || (rc = dmalloc(&h->d_elog_old, KM)) ||
         (rc = dmalloc(&h->d_tau, NZ)) || (rc = dmalloc(&h->d_tau_old, NZ)) || (rc = dmalloc(&h->d_lse, NZ)) ||
+        (rc = dmalloc(&h->d_aold, std::max<size_t>(NZ, 1))) || (rc = dmalloc(&h->d_alpha_e, K)) || (rc = dmalloc(&h->d_pw_partial, 2048)) ||
         (rc = dmalloc(&h->d_ts_partial, (size_t)corp->term_index.n_slots * (K + 1))) || (rc = dmalloc(&h->d_sweeps, (size_t)h->M)) ||
         (rc = dmalloc(&h->d_doc_order, (size_t)h->M)) || (rc = dmalloc(&h->d_partial, (size_t)TMVB_REDUCE_BLOCKS * K)) ||
         (rc = dmalloc(&h->d_rowsum, K)) || (rc = dmalloc(&h->d_esum, K)) || (rc = dmalloc(&h->d_doc_val, (size_t)h->M)) ||
         (rc = dmalloc(&h->d_elbo, 1)) || (rc = dmalloc(&h->d_iters, 1)))
         return rc;
+    { const char* e = getenv("TMVB_FLDA_ELBO_PARTS"); h->parts_env = e ? atoi(e) : 1; }
     std::vector<int32_t> order((size_t)h->M);
     std::iota(order.begin(), order.end(), 0);
     const std::vector<int64_t>& len = corp->h_doc_len;
     std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return len[x] > len[y]; });
     {   // LDS tile buckets with this kernel's per-row footprint (6 floats of per-token scratch): cap the tile at 32 KB
         std::vector<tmvb_bucket> bk;
-        tmvb_build_lds_buckets(len, order, h->M, h->KP + 3, -1, 3, bk, 32 * 1024);
+        tmvb_build_lds_buckets(len, order, h->M, h->KP + 4, -1, 3, bk, 32 * 1024);
         h->buckets = bk;
     }
     if (h->M) TMVB_HIP(hipMemcpyAsync(h->d_doc_order, order.data(), (size_t)h->M * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
@@ -475,6 +544,7 @@ extern "C" int tmvb_flda_set_state(tmvb_flda* h, const double* eta, const double
     }
     if (tau_old && (rc = upload_f32(ctx, h->d_tau_old, tau_old, NZ))) return rc;
     if (elbo) h->elbo = *elbo;
+    h->parts_pending = false; h->parts_valid = false;      // a state set by the host: update_elbo! takes the token walk
     TMVB_HIP(hipStreamSynchronize(ctx->stream));
     return TMVB_OK;
 }
@@ -516,8 +586,12 @@ extern "C" int tmvb_flda_estep(tmvb_flda* h, int32_t viter, double vtol)
     p.K = h->K; p.KP = h->KP; p.LPR = h->KP / 4; p.lpr_magic = (unsigned)(0x100000000ull / (unsigned)p.LPR) + 1u;
     p.doc_ptr = h->corp->d_doc_ptr; p.terms = h->corp->d_terms; p.counts = h->corp->d_counts; p.doc_order = h->d_doc_order;
     p.L = h->d_L; p.kappa = h->d_kappa; p.eta = h->d_eta; p.alpha = h->d_alpha_f;
-    p.gamma = h->d_gamma; p.elog = h->d_elog; p.elog_old = h->d_elog_old; p.tau = h->d_tau; p.tau_old = h->d_tau_old; p.lse = h->d_lse;
+    p.gamma = h->d_gamma; p.elog = h->d_elog; p.elog_old = h->d_elog_old; p.tau = h->d_tau; p.tau_old = h->d_tau_old; p.lse = h->d_lse; p.aold = h->d_aold;
     p.sweeps = h->d_sweeps; p.viter = viter; p.vtol = (float)vtol;
+    // decomposed update_elbo!: an iteration that will be checked keeps the alpha its update_gamma! adds (viter = 0 leaves no responsibilities: token walk)
+    const bool collect = (h->parts_env == 2 || (h->parts_env != 0 && h->want_parts)) && viter > 0;
+    h->parts_pending = false; h->parts_valid = false;
+    if (collect) TMVB_HIP(hipMemcpyAsync(h->d_alpha_e, h->d_alpha_f, (size_t)h->K * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
     TMVB_HIP(hipEventRecord(h->ev0, ctx->stream));
     for (const tmvb_bucket& b : h->buckets) {
         const size_t lds = flda_tile_bytes(b.tile_rows, h->KP);
@@ -540,6 +614,7 @@ extern "C" int tmvb_flda_estep(tmvb_flda* h, int32_t viter, double vtol)
     }
     TMVB_HIP(hipEventRecord(h->ev1, ctx->stream));
     h->timed = true;
+    h->parts_pending = collect;
     return TMVB_OK;
 }
 
@@ -585,9 +660,14 @@ extern "C" int tmvb_flda_update_beta(tmvb_flda* h)
     if (rc) return rc;
     const int64_t total = (int64_t)h->KP * h->V;
     const int nb = (int)std::min<int64_t>(2048, std::max<int64_t>(1, (total + 255) / 256));
+    // behind a collecting E-step: the partial sums of S (log(beta_new + eps) - log(beta_old + eps)), both logarithms in fp64 (tmvb_common_kernels.h);
+    // a sharded handle holds the all-reduced S here and contributes the share M / M_total of the global term (tmvb_flda_update_elbo)
+    const bool pw = h->parts_pending;
     hipLaunchKernelGGL(beta_norm_kernel, dim3(nb), dim3(256), (size_t)h->K * sizeof(double), ctx->stream,
-                       h->d_stats, h->d_rowsum, h->d_beta[h->cur ^ 1], h->K, h->KP, h->V, (double*)nullptr, 0.0f);
+                       h->d_stats, h->d_rowsum, h->d_beta[h->cur ^ 1], h->K, h->KP, h->V, pw ? h->d_pw_partial : (double*)nullptr, pw ? TMVB_EPS_F : 0.0f,
+                       pw ? (const float*)h->d_beta[h->cur] : (const float*)nullptr);
     TMVB_HIP(hipGetLastError());
+    h->pw_blocks = nb; h->parts_valid = pw; h->parts_pending = false;
     h->cur ^= 1;                                            // beta_old <- beta, beta <- new
     if ((rc = flda_refresh_L(h))) return rc;
     hipLaunchKernelGGL(flda_kappa_eta_kernel, dim3(1), dim3(1024), 0, ctx->stream, h->kstat(), h->d_kappa, h->d_kappa_old, h->V, h->C_total,
@@ -630,6 +710,29 @@ extern "C" int tmvb_flda_update_elbo(tmvb_flda* h, double* elbo)
     TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_flda_update_elbo: handle is NULL");
     tmvb_ctx* ctx = h->ctx;
     TMVB_HIP(hipSetDevice(ctx->device));
+    const bool parts = h->parts_valid && !h->force_walk && h->parts_env != 0;
+    h->elbo_form = parts ? 1 : 0;
+    if (parts) {
+        if (h->M > 0) {
+            const dim3 grid((unsigned)h->M), block(64);
+            (void)dispatch_nslot(h->nslot, [&](auto ns) -> int {
+                hipLaunchKernelGGL((flda_elbo_doc_parts_kernel<decltype(ns)::value>), grid, block, 0, ctx->stream, h->K, h->corp->d_doc_ptr, h->corp->d_terms,
+                                   h->corp->d_counts, h->d_alpha_d, h->d_alpha_e, h->d_eta, h->d_kappa, h->d_gamma, h->d_elog, h->d_elog_old, h->d_tau,
+                                   h->d_tau_old, h->d_lse, h->d_aold, h->d_doc_val);
+                return TMVB_OK;
+            });
+            TMVB_HIP(hipGetLastError());
+        }
+        hipLaunchKernelGGL(lda_elbo_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, h->d_doc_val, h->M, h->K, h->d_alpha_d, h->d_elbo,
+                           (const double*)h->d_pw_partial, h->pw_blocks, h->distributed && h->M_total > 0 ? (double)h->M / (double)h->M_total : 1.0);
+        TMVB_HIP(hipGetLastError());
+        double v = 0.0;
+        TMVB_HIP(hipMemcpyAsync(&v, h->d_elbo, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        TMVB_HIP(hipStreamSynchronize(ctx->stream));
+        h->elbo = v;
+        if (elbo) *elbo = v;
+        return TMVB_OK;
+    }
     if (h->M > 0) {
         const dim3 grid((unsigned)h->M), block(64);
         (void)dispatch_nslot(h->nslot, [&](auto ns) -> int {
@@ -667,6 +770,9 @@ struct FldaTrainOps {
         return rc;
     }
     int elbo_local(tmvb_flda* h, double* s, double* once) { *once = 0.0; return tmvb_flda_update_elbo(h, s); }
+    int elbo_form(tmvb_flda* h) { return h->elbo_form; }
+    void force_walk(tmvb_flda* h, bool on, bool doubled = true) { h->force_walk = on; if (!on && doubled) h->elbo_form = 1; }   // (as LdaTrainOps)
+    void will_check(tmvb_flda* h, bool checked) { h->want_parts = checked; }
     double* elbo_dev(tmvb_flda* h) { return h->d_elbo; }
     tmvb_comm* comm(tmvb_flda* h) { return h->comm; }
     bool distributed(tmvb_flda* h) { return h->distributed; }
@@ -700,6 +806,13 @@ extern "C" int tmvb_flda_train(tmvb_flda* h, int32_t iter, double tol, int32_t n
 {
     TMVB_REQUIRE(h != nullptr, TMVB_EINVAL, "tmvb_flda_train: handle is NULL");
     return tmvb_flda_train_group(&h, 1, iter, tol, niter, ntol, viter, vtol, checkelbo, elbo_traj, iters_done, elbo_baseline);
+}
+
+extern "C" int tmvb_flda_elbo_form(tmvb_flda* h, int32_t* form)
+{
+    TMVB_REQUIRE(h && form, TMVB_EINVAL, "tmvb_flda_elbo_form: NULL argument");
+    *form = h->elbo_form;
+    return TMVB_OK;
 }
 
 extern "C" int tmvb_flda_doc_sweeps(tmvb_flda* h, uint8_t* out)

@@ -155,6 +155,8 @@ int tmvb_corpus_reader_index(tmvb_corpus* c);
 //   TMVB_MUTANT_LDA_NO_EPS          epsilon dropped from LDA's phi / gamma (src/LDA.jl:152, :145)
 //   TMVB_MUTANT_CTPF_LOG_BET        `log bet` where xi needs `log vav` (the reference's own OpenCL bug, src/gpuCTPF.jl:624 vs src/CTPF.jl:336)
 //   TMVB_MUTANT_CTM_SIGMA_NEW_MU    update_sigma! centred on the NEW mu (quirk Q2: the reference updates sigma first, src/CTM.jl:207-208)
+//   TMVB_MUTANT_FLDA_NO_EPS         (round 6) the filtered models' log table without epsilon: log(beta) for log(beta + eps) (src/fLDA.jl:184, :191)
+//   TMVB_MUTANT_FCTM_VSQ_FIRST      (round 6) fCTM's sweep in CTM's order: update_vsq! in front of update_lambda! (src/fCTM.jl:239-240 against src/CTM.jl:198-199)
 #ifdef TMVB_MUTANT_LDA_NO_EPS
 #define TMVB_EPS_F 0.0f
 #else

@@ -114,6 +114,12 @@ class gpufCTM:
     def mstep(self):
         self.update_beta(); self.update_sigma(); self.update_mu()
 
+    def elbo_form(self) -> int:
+        """1 if the last update_elbo! took the decomposed form (tmvb_fctm_elbo_form: nothing per token rebuilt), 0 for the token walk."""
+        f = C.c_int32(0)
+        check(lib().tmvb_fctm_elbo_form(self.handle, C.byref(f)))
+        return f.value
+
     def update_elbo(self) -> float:
         out = C.c_double(0.0)
         check(lib().tmvb_fctm_update_elbo(self.handle, C.byref(out)))

@@ -110,6 +110,12 @@ class gpufLDA:
     def mstep(self, niter: int = 1000, ntol: float | None = None):
         self.update_beta(); self.update_alpha(niter, ntol); self.update_eta()
 
+    def elbo_form(self) -> int:
+        """1 if the last update_elbo! took the decomposed form (tmvb_flda_elbo_form: nothing per token rebuilt), 0 for the token walk."""
+        f = C.c_int32(0)
+        check(lib().tmvb_flda_elbo_form(self.handle, C.byref(f)))
+        return f.value
+
     def update_elbo(self) -> float:
         out = C.c_double(0.0)
         check(lib().tmvb_flda_update_elbo(self.handle, C.byref(out)))
