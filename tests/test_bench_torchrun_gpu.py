@@ -23,11 +23,11 @@ def _free_port():
     return p
 
 
-def _launch(world, extra_env=None, docs="6000"):
+def _launch(world, extra_env=None, docs="6000", K=None):
     env = dict(os.environ, TMVB_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "4", "--warmup", "1",
-           "--burnin", "3", "--docs", docs, "--clock-warmup", "0", "--plateau-cap", "100"]
+           "--burnin", "3", "--docs", docs, "--clock-warmup", "0", "--plateau-cap", "100"] + (["--K", str(K)] if K else [])
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=1500)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -67,11 +67,17 @@ def test_torchrun_two_ranks_fused_form_opt_in():
     assert r["multi_gpu_check"]["form"] == "fused" and "all-reduce" in detail["roofline"]["estep_ms_includes"]
 
 
-def test_torchrun_eight_ranks_on_one_gpu():
+@pytest.mark.parametrize("K", [50, 100])
+def test_torchrun_eight_ranks_on_one_gpu(K):
     """The driver's SCALE run is --gpus 8: the exact command line, eight ranks on ONE device through the host transport.  Eight distinct
-    nnz-balanced shards, bit-identical globals on all eight ranks, the ELBO trajectory of the sharded train! against the N = 1 run."""
-    r, detail = _launch(8, docs="16000")
+    nnz-balanced shards, bit-identical globals on all eight ranks, the ELBO trajectory of the sharded train! against the N = 1 run.
+    K = 100 is BASELINE.json configs[2] (LDA K = 100 doc-sharded over 8 GPUs) as the bench's own model; at K = 50 (the headline) the self-check
+    additionally runs config 3's model through set_comm + the sharded train! ("config3_k100")."""
+    r, detail = _launch(8, docs="16000", K=K)
     _common(r, detail, 8)
+    if K == 50:
+        c3 = r["multi_gpu_check"]["config3_k100"]
+        assert c3["K"] == 100 and c3["iterations"] == 5 and c3["globals_hash_equal"] and c3["pass"] is True and c3["elbo_rel_vs_n1"] <= c3["elbo_rel_tolerance"], c3
     full = detail["multi_gpu_check"]
     assert r["multi_gpu_check"]["shard_nnz_max_over_min"] <= 1.02, full["shard_nnz"]
     assert sum(full["shard_nnz"]) == detail["config"]["nnz"]

@@ -1317,8 +1317,11 @@ __global__ __launch_bounds__(1024) void ctpf_elbo_final_parts_kernel(const doubl
                                                                      const double* __restrict__ rates, const double* __restrict__ lrates_d,
                                                                      const double* __restrict__ rs_alef, const double* __restrict__ rs_he,
                                                                      const double* __restrict__ sum_g, const double* __restrict__ sum_z, int K, double Va,
-                                                                     double hc, double hd, double hg, double hh, double* __restrict__ out)
+                                                                     double hc, double hd, double hg, double hh, double* __restrict__ out, int sharded = 0)
 {
+    // sharded (round 6): the handle holds one document shard of M = Md documents, SG / SZ are the CORPUS' sums (the all-reduced statistics tail).  Every
+    // closed-form term is linear in (SG, SZ, Md): the SG / SZ shares go to the global part (identical on every rank, added once), the Md shares stay in the
+    // documents' part (the ranks' values add up to M_total's) -- the sum over the ranks of out[0] plus out[1] is the unsharded value.
     __shared__ double red[2][1024];
     double s = 0.0, g = 0.0, lz = 0.0;
     for (int64_t b = threadIdx.x; b < n_blocks; b += 1024) s += block_val[b];
@@ -1328,11 +1331,22 @@ __global__ __launch_bounds__(1024) void ctpf_elbo_final_parts_kernel(const doubl
         const double r_bet = tmvb_rcp_d(rates[i]), r_vav = tmvb_rcp_d(rates[K + i]), r_dalet = tmvb_rcp_d(rates[2 * K + i]), r_het = tmvb_rcp_d(rates[3 * K + i]);
         const double l_bet = lrates_d[i], l_vav = lrates_d[K + i], l_dalet = lrates_d[2 * K + i], l_het = lrates_d[3 * K + i];
         const double SG = sum_g[i], SZ = sum_z[i];
-        s -= SG * r_dalet * (rs_he[i] * r_vav + rs_alef[i] * r_bet + hd) + SZ * r_het * (rs_he[i] * r_vav + hh);
-        s -= Md * (hc * l_dalet + hg * l_het);
-        s -= (SG - Md * hc) * (l_dalet - lrates_d[6 * K + i]) + (SZ - Md * hg) * ((l_het - lrates_d[7 * K + i]) + (l_vav - lrates_d[5 * K + i]));
-        const double pc = rs_alef[i] - Va, pa = (SG - Md * hc) - pc;
-        g -= (l_bet - lrates_d[4 * K + i]) * pc + (l_vav - lrates_d[5 * K + i]) * pa;
+        const double dl_dalet = l_dalet - lrates_d[6 * K + i], dl_hv = (l_het - lrates_d[7 * K + i]) + (l_vav - lrates_d[5 * K + i]);
+        const double dl_bet = l_bet - lrates_d[4 * K + i], dl_vav = l_vav - lrates_d[5 * K + i];
+        const double pc = rs_alef[i] - Va;
+        if (sharded) {
+            g -= SG * r_dalet * (rs_he[i] * r_vav + rs_alef[i] * r_bet + hd) + SZ * r_het * (rs_he[i] * r_vav + hh);
+            g -= SG * dl_dalet + SZ * dl_hv;
+            g -= dl_bet * pc + dl_vav * (SG - pc);
+            s -= Md * (hc * l_dalet + hg * l_het);
+            s += Md * (hc * dl_dalet + hg * dl_hv) + Md * hc * dl_vav;
+        } else {
+            s -= SG * r_dalet * (rs_he[i] * r_vav + rs_alef[i] * r_bet + hd) + SZ * r_het * (rs_he[i] * r_vav + hh);
+            s -= Md * (hc * l_dalet + hg * l_het);
+            s -= (SG - Md * hc) * dl_dalet + (SZ - Md * hg) * dl_hv;
+            const double pa = (SG - Md * hc) - pc;
+            g -= dl_bet * pc + dl_vav * pa;
+        }
     }
     red[0][threadIdx.x] = s + 0.6931471805599453 * lz; red[1][threadIdx.x] = g;
     __syncthreads();
@@ -1748,9 +1762,13 @@ extern "C" int tmvb_ctpf_estep(tmvb_ctpf* h, int32_t viter, double vtol)
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, ctx->device) != hipSuccess || v <= 0) { (void)hipGetLastError(); v = 64 * 1024; }
         h->lds_limit = v;
     }
-    const bool collect = (h->parts_env == 2 || (h->parts_env != 0 && h->want_parts)) && p.store_w == 0 && viter > 0 && !h->distributed && h->M > 0 &&
-                         (size_t)4 * CTPF_ELBO_DPB * h->K * sizeof(float) <= (size_t)h->lds_limit;
+    // (round 6: sharded handles collect too -- the documents' part adds up over the shards, the closed-form rate terms go to the global part; which form a
+    //  handle takes must not depend on its shard: a shard WITHOUT documents has nothing to collect and takes the decomposed form with empty parts)
+    const bool would_collect = (h->parts_env == 2 || (h->parts_env != 0 && h->want_parts)) && p.store_w == 0 && viter > 0 &&
+                               (size_t)4 * CTPF_ELBO_DPB * h->K * sizeof(float) <= (size_t)h->lds_limit;
+    const bool collect = would_collect && h->M > 0;
     h->logz_valid = false; h->msteps_after = 0;
+    if (would_collect && h->M == 0 && h->distributed) { h->logz_valid = true; h->n_logz = 0; h->n_elbo_blocks = 0; }
     const int64_t nct = h->corp->term_index.n_chunks, ncr = h->U > 0 ? h->corp->reader_index.n_chunks : 0;
     if (h->elbo_pending) {                                   // ctpf_elbo_doc_parts_kernel of the last collecting E-step still reads gimel / zayin
         TMVB_HIP(hipStreamWaitEvent(ctx->stream, h->ev_elbo, 0));
@@ -1897,7 +1915,7 @@ extern "C" int tmvb_ctpf_estep(tmvb_ctpf* h, int32_t viter, double vtol)
     } else if (rc) {
         return rc;
     }
-    h->logz_valid = collect; h->n_logz = collect ? nct + ncr : 0;
+    h->logz_valid = collect || (would_collect && h->M == 0 && h->distributed); h->n_logz = collect ? nct + ncr : 0;
     if (h->timing) TMVB_HIP(hipEventRecord(h->ev1, ctx->stream));
     h->timed = true;
     return TMVB_OK;
@@ -2050,7 +2068,7 @@ extern "C" int tmvb_ctpf_update_elbo_parts(tmvb_ctpf* h, double* doc_part, doubl
     double res[2] = {0.0, 0.0};
     static const bool legacy_elbo = [] { const char* e = getenv("TMVB_CTPF_ELBO_LEGACY"); return e && atoi(e) != 0; }();
     // the decomposed form: the last E-step collected its parts and exactly one M-step ran behind it (alef_old / he_old / the old rates are that E-step's)
-    const bool parts = h->M > 0 && !legacy_elbo && h->logz_valid && h->msteps_after == 1 && !h->distributed && !h->force_walk;
+    const bool parts = (h->M > 0 || h->distributed) && !legacy_elbo && h->logz_valid && h->msteps_after == 1 && !h->force_walk;
     h->elbo_form = parts ? 1 : 0;
     if (h->M > 0 && !legacy_elbo && (rc = ctpf_elbo_consts(h))) return rc;
     // global part: partial sums now, added up by the one final kernel behind the per-document part (one copy, one synchronisation)
@@ -2071,7 +2089,7 @@ extern "C" int tmvb_ctpf_update_elbo_parts(tmvb_ctpf* h, double* doc_part, doubl
         hipLaunchKernelGGL(ctpf_elbo_final_parts_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const double*)h->d_doc_val, h->n_elbo_blocks, (double)h->M,
                            (const double*)h->d_elbo_partial, 2 * nb, cst, (const double*)h->d_logz, h->n_logz, (const double*)h->d_rates, (const double*)h->d_lrates_d,
                            (const double*)h->d_rs_alef, (const double*)h->d_rs_he, (const double*)h->d_sum_g, (const double*)h->d_sum_z, h->K,
-                           (double)h->V * hy[0], hy[2], hy[3], hy[6], hy[7], h->d_elbo);
+                           (double)h->V * hy[0], hy[2], hy[3], hy[6], hy[7], h->d_elbo, h->distributed ? 1 : 0);
         TMVB_HIP(hipGetLastError());
         TMVB_HIP(hipMemcpyAsync(res, h->d_elbo, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         TMVB_HIP(hipStreamSynchronize(ctx->stream));
