@@ -291,3 +291,40 @@ def test_train_equals_stepwise(tmvb):
     b.update_host()
     for n in ("alef", "he", "bet", "vav", "dalet", "het", "gimel", "zayin"):
         assert np.array_equal(getattr(a, n), getattr(b, n)), n
+
+
+def test_graph_replayed_iterations_equal_stepwise(tmvb):
+    """Round 6: with TMVB_TRAIN_GRAPH=1 train! captures an unchecked iteration into a hipGraph at its third occurrence in a row and replays it
+    (csrc/tmvb_train.h; >= 16 iterations left; opt-in: the replay measured slower than the ordinary enqueue, profiles/r6_ctpf_graph.txt).  40 iterations
+    through train! (37 of them replays) == 40 stepwise iterations with a synchronisation after each operator, bit for bit; then a run that mixes checked
+    and unchecked iterations (checkelbo = 8: the replay stops for the checked ones and resumes behind two plain ones).  The switch is read once per process:
+    the body runs in a child process."""
+    import os, subprocess, sys
+    if os.environ.get("TMVB_TRAIN_GRAPH", "") != "1":
+        env = dict(os.environ, TMVB_TRAIN_GRAPH="1")
+        res = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-x", os.path.abspath(__file__), "-k", "test_graph_replayed_iterations_equal_stepwise"],
+                             env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert res.returncode == 0 and "1 passed" in res.stdout, res.stdout[-3000:] + res.stderr[-2000:]
+        return
+    pc = tmvb.syn_citeu(M=5000, V=2500, U=700, seed=29)
+    K = 20
+    alef0 = np.asfortranarray(np.exp(tmvb.dirichlet_rows(K, pc.V, seed=4) - 0.5))
+
+    def fresh():
+        m = tmvb.gpuCTPF(pc, K)
+        m.alef = alef0.copy(order="F"); m.alef_old = alef0.copy(order="F"); m.update_buffer()
+        return m
+    a = fresh()
+    a.train(iter=40, tol=0.0, checkelbo=np.inf, printelbo=False, recs=False)
+    b = fresh()
+    for it in range(40):
+        b.estep(); b.synchronize(); b.reduce_docs(); b.synchronize(); b.mstep(); b.synchronize()
+    b.update_host()
+    for n in ("alef", "he", "bet", "vav", "dalet", "het", "gimel", "zayin"):
+        assert np.array_equal(getattr(a, n), getattr(b, n)), n
+    c = fresh()
+    traj = np.asarray(c.train(iter=40, tol=0.0, checkelbo=8, printelbo=False, recs=False))
+    chk = traj[np.isfinite(traj)]
+    assert len(chk) == 5 and np.all(np.diff(chk) > 0)
+    for n in ("alef", "he", "bet", "vav", "dalet", "het", "gimel", "zayin"):
+        assert np.array_equal(getattr(c, n), getattr(b, n)), n               # update_elbo! changes nothing of the state

@@ -2185,6 +2185,9 @@ struct CtpfTrainOps {
     int elbo_form(tmvb_ctpf* h) { return h->elbo_form; }
     void force_walk(tmvb_ctpf* h, bool on, bool doubled = true) { h->force_walk = on; if (!on && doubled) h->elbo_form = 1; }   // (switched off behind the one evaluation that doubled a decomposed one)
     void will_check(tmvb_ctpf* h, bool checked) { h->want_parts = checked; }          // the coming iteration ends in check_elbo!
+    // an unchecked iteration may be replayed from a hipGraph (tmvb_train.h): no pointer of the iteration alternates, no flag outlives it; not while an
+    // update_elbo! kernel of a checked iteration is still pending on its side stream (the E-step would wait for an event recorded outside the capture)
+    bool graph_ok(tmvb_ctpf* h) { return !h->distributed && !h->elbo_pending && !h->docs_pending && h->M > 0 && !h->timing; }
     double* elbo_dev(tmvb_ctpf* h) { return h->d_elbo; }
     tmvb_comm* comm(tmvb_ctpf* h) { return h->comm; }
     bool distributed(tmvb_ctpf* h) { return h->distributed; }

@@ -76,6 +76,22 @@ template <class Ops, class H, class = void> struct tmvb_has_will_check : std::fa
 template <class Ops, class H>
 struct tmvb_has_will_check<Ops, H, std::void_t<decltype(std::declval<Ops&>().will_check((H*)nullptr, true))>> : std::true_type {};
 
+// Ops may offer  bool graph_ok(H*): an UNCHECKED iteration of this handle (estep + reduce + mstep, one context, no communicator) enqueues the same launches with the
+// same arguments every time and leaves the handle's host-side flags as it found them, so it may be captured once into a hipGraph and replayed (round 6: CTPF -- seven
+// kernels and two cross-queue joins in ~130 us, ~20 us of it launch gaps and event hops).  MEASURED on MI355X / ROCm 7 (profiles/r6_ctpf_graph.txt): the replayed
+// iteration is 0.31 - 0.33 ms against 0.130 ms enqueued the ordinary way -- hipGraphLaunch of this ten-node, three-stream graph costs the host more than the launches it
+// replaces, and the device then waits for the host.  The replay is therefore OPT-IN (TMVB_TRAIN_GRAPH=1) and bit-identical (tests/test_ctpf_gpu.py).
+template <class Ops, class H, class = void> struct tmvb_has_graph_ok : std::false_type {};
+template <class Ops, class H>
+struct tmvb_has_graph_ok<Ops, H, std::void_t<decltype(std::declval<Ops&>().graph_ok((H*)nullptr))>> : std::true_type {};
+
+struct tmvb_iter_graph {
+    hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+    int plain_run = 0;            // unchecked iterations enqueued the ordinary way since the last checked one (lazy allocations and flags settle in the first two)
+    bool failed = false;
+    ~tmvb_iter_graph() { if (exec) (void)hipGraphExecDestroy(exec); if (graph) (void)hipGraphDestroy(graph); }
+};
+
 template <class H, class Ops>
 static int tmvb_group_elbo(H* const* hs, int n, Ops& ops, double* out)
 {
@@ -158,6 +174,7 @@ static int tmvb_train_group_loop(const char* who, H* const* hs, int n, int iter,
     std::vector<void*> ptrs(n);
     std::vector<int64_t> counts(n);
     int done = 0;
+    tmvb_iter_graph ig;
     bool old_parts = false;                  // e_old was evaluated by the decomposed form of update_elbo! (never true for the baseline: a state this call did not produce)
     for (int k = 1; k <= iter; ++k) {
         ++done;
@@ -171,6 +188,43 @@ static int tmvb_train_group_loop(const char* who, H* const* hs, int n, int iter,
             // RCCL run has validated yet (round-4 advice) -- opt-in until tests/test_multigpu_rccl.py has passed on a multi-GPU node.
             static const bool fuse = [] { const char* e = getenv("TMVB_FUSED_ALLREDUCE"); return e && atoi(e) != 0; }();
             if (sharded && n == 1 && fuse) { if ((rc = ops.estep_allreduce(hs[0]))) return rc; fused = true; }
+        }
+        if constexpr (tmvb_has_graph_ok<Ops, H>::value) {
+            // an unchecked iteration of one unsharded handle: captured into a hipGraph at its third occurrence in a row (enough of them left to pay for the
+            // capture), replayed from then on; a checked iteration in between runs the ordinary way and the replay resumes behind the next two plain ones
+            static const bool graph_env = [] { const char* e = getenv("TMVB_TRAIN_GRAPH"); return e && atoi(e) != 0; }();     // OPT-IN: measured slower (below)
+            const bool checked = checkelbo > 0 && (k % checkelbo) == 0;
+            if (checked) ig.plain_run = 0;
+            if (graph_env && !checked && !sharded && n == 1 && !ig.failed && ops.graph_ok(hs[0])) {
+                tmvb_ctx* c0 = ops.ctx(hs[0]);
+                TMVB_HIP(hipSetDevice(c0->device));
+                if (ig.exec && ig.plain_run >= 2) {
+                    TMVB_HIP(hipGraphLaunch(ig.exec, c0->stream));
+                    if (elbo_traj) elbo_traj[k - 1] = NAN;
+                    continue;
+                }
+                if (!ig.exec && ig.plain_run >= 2 && iter - k >= 16) {
+                    hipError_t ce = hipStreamBeginCapture(c0->stream, hipStreamCaptureModeThreadLocal);
+                    if (ce == hipSuccess) {
+                        int crc = ops.estep(hs[0]);
+                        if (!crc) crc = ops.reduce(hs[0]);
+                        if (!crc) crc = ops.mstep(hs[0]);
+                        hipGraph_t g = nullptr;
+                        ce = hipStreamEndCapture(c0->stream, &g);
+                        if (!crc && ce == hipSuccess && g && hipGraphInstantiate(&ig.exec, g, nullptr, nullptr, 0) == hipSuccess) {
+                            ig.graph = g;
+                            TMVB_HIP(hipGraphLaunch(ig.exec, c0->stream));
+                            if (elbo_traj) elbo_traj[k - 1] = NAN;
+                            continue;
+                        }
+                        if (g) (void)hipGraphDestroy(g);
+                        ig.exec = nullptr;
+                    }
+                    (void)hipGetLastError();
+                    ig.failed = true;                 // nothing of the attempt has executed: this iteration runs the ordinary way below
+                }
+                ++ig.plain_run;
+            }
         }
         if (!fused) for (int i = 0; i < n; ++i) if ((rc = ops.estep(hs[i]))) return rc;
         if (!fused) for (int i = 0; i < n; ++i) if ((rc = ops.reduce(hs[i]))) return rc;
