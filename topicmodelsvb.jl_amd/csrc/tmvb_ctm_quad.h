@@ -114,7 +114,49 @@ __device__ __forceinline__ cb_v16f cq_sload16_sync(const float* tab)
 #ifndef TMVB_CTM_QASM
 #define TMVB_CTM_QASM 1
 #endif
-template <int R> struct cq_asm_loop { static constexpr bool value = TMVB_CTM_QASM && (R == 52 || R == 44 || R == 36 || R == 4); };
+template <int R> struct cq_asm_loop { static constexpr bool value = TMVB_CTM_QASM != 0; };     // (round 6, with the id words in fixed registers: every instantiation passes)
+
+// An opaque copy of a lane-dependent index.  LDS addresses computed from `lane` itself are invariants of the item / sweep / Newton / CG loops: the compiler
+// hoists one address register per access out of all of them (the first build: ~40 of them computed in the kernel's prologue, spilled at once and reloaded
+// from scratch -- 80 MB of it across the device, i.e. from HBM -- in front of every use).  A value that passes through a volatile asm inside the loop is not
+// an invariant, and the one or two integer operations per address stay where the access is.
+#ifdef TMVB_CQ_NOOPQ
+__device__ __forceinline__ int cq_opq(int v) { return v; }
+#else
+__device__ __forceinline__ int cq_opq(int v) { asm volatile("" : "+v"(v)); return v; }
+#endif
+// fp64 constants as SGPR pairs defined at the point of use (for the same reason: 14 constants of cb_exp_n hoisted into VGPR pairs and spilled)
+#ifdef TMVB_CQ_NOK
+__device__ __forceinline__ double cq_k(double c) { return c; }
+#else
+__device__ __forceinline__ double cq_k(double c) { asm volatile("" : "+s"(c)); return c; }
+#endif
+template <int N>
+__device__ __forceinline__ void cq_exp_n(double (&a)[N])
+{
+#ifdef TMVB_CQ_OLDEXP
+    cb_exp_n<N>(a); return;
+#endif
+    double n[N], q[N];
+    const double il2 = cq_k(1.4426950408889634074), l2h = cq_k(-6.93147180369123816490e-01), l2l = cq_k(-1.90821492927058770002e-10);
+#pragma unroll
+    for (int u = 0; u < N; ++u) { a[u] = fmax(a[u], -745.0); n[u] = __builtin_rint(a[u] * il2); }
+#pragma unroll
+    for (int u = 0; u < N; ++u) a[u] = fma(n[u], l2h, a[u]);
+    const double c11 = cq_k(2.50521083854417187751e-08), c10 = cq_k(2.75573192239858906526e-07);
+#pragma unroll
+    for (int u = 0; u < N; ++u) { a[u] = fma(n[u], l2l, a[u]); q[u] = fma(c11, a[u], c10); }
+    const double c[9] = {2.75573192239858906526e-06, 2.48015873015873015873e-05, 1.98412698412698412698e-04, 1.38888888888888888889e-03,
+                         8.33333333333333333333e-03, 4.16666666666666666667e-02, 1.66666666666666666667e-01, 0.5, 1.0};
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const double ck = cq_k(c[k]);
+#pragma unroll
+        for (int u = 0; u < N; ++u) q[u] = fma(q[u], a[u], ck);
+    }
+#pragma unroll
+    for (int u = 0; u < N; ++u) a[u] = __builtin_ldexp(fma(q[u], a[u], 1.0), (int)n[u]);
+}
 
 // ---- vector-memory loads of the token loop as inline asm (see the loop): the destination is a read-write operand, so the loop-carried value keeps its
 // registers; the compiler inserts no waits for these loads -- cq_vmwait<N> is the hand-placed s_waitcnt vmcnt(N) and names the first register block that
@@ -124,9 +166,25 @@ __device__ __forceinline__ void cq_gload16(cb_v4f& d, unsigned voff, const __att
 {
     asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "+v"(d) : "v"(voff), "s"(sbase), "n"(OFF));
 }
+// The id / count words live in FIXED physical registers from their load to the wait that lands them (WHICH = 0 .. 3 -> v244 .. v247): as plain "+v"
+// operands the compiler twice chose to copy the (not yet landed) word out of its register, use the register as an address temporary and copy the stale
+// word back in front of the wait -- run-to-run different results (tools/check_vmem_inflight.py reports it; build() refuses such a library).  With the
+// register named in the constraint of the load, of the wait and of nothing else, the value has nowhere else to be.
+template <int WHICH>
 __device__ __forceinline__ void cq_gload4(int& d, unsigned voff, const __attribute__((address_space(1))) int32_t* sbase)
 {
-    asm volatile("global_load_dword %0, %1, %2" : "+v"(d) : "v"(voff), "s"(sbase));
+    if constexpr (WHICH == 0) asm volatile("global_load_dword %0, %1, %2" : "={v244}"(d) : "v"(voff), "s"(sbase));
+    else if constexpr (WHICH == 1) asm volatile("global_load_dword %0, %1, %2" : "={v245}"(d) : "v"(voff), "s"(sbase));
+    else if constexpr (WHICH == 2) asm volatile("global_load_dword %0, %1, %2" : "={v246}"(d) : "v"(voff), "s"(sbase));
+    else asm volatile("global_load_dword %0, %1, %2" : "={v247}"(d) : "v"(voff), "s"(sbase));
+}
+template <int WHICH>
+__device__ __forceinline__ void cq_vmwait_id(int& d)
+{
+    if constexpr (WHICH == 0) asm volatile("" : "+{v244}"(d));
+    else if constexpr (WHICH == 1) asm volatile("" : "+{v245}"(d));
+    else if constexpr (WHICH == 2) asm volatile("" : "+{v246}"(d));
+    else asm volatile("" : "+{v247}"(d));
 }
 template <int N, typename T>
 __device__ __forceinline__ void cq_vmwait(T& d) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(d) : "n"(N)); }
@@ -173,7 +231,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMVB_CTM_QW
         int64_t off;
         int N;
         { const int64_t* doc_ptr = CB_KARG(const int64_t*, p.doc_ptr); off = doc_ptr[d]; N = valid ? (int)(doc_ptr[d + 1] - off) : 0; }
-        if (w == 0) { dinfo[lane] = d; dinfo[64 + lane] = (int)off; dinfo[128 + lane] = N; }
+        int ln = cq_opq(lane);
+        if (w == 0) { dinfo[ln] = d; dinfo[64 + ln] = (int)off; dinfo[128 + ln] = N; }
         __syncthreads();
         // token lanes: lane (ds, qd) = quarter qd of document 16 w + ds
         const int tj = 16 * w + (lane >> 2), qd = lane & 3;
@@ -208,12 +267,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMVB_CTM_QW
                 const float lv = lrow[ic], vv = vrow[ic];
                 lam[i] = on ? (double)lv : -1.0e30;
                 vs[i] = on ? vv : 1.0f;
-                lam_l[(gt0 + i) * 64 + lane] = on ? lv : -1.0e30f;
+                lam_l[(gt0 + i) * 64 + ln] = on ? lv : -1.0e30f;
             }
             lz = (double)CB_KARG(const float*, p.logzeta)[d];
         }
         __syncthreads();
-        const double Cd = (double)((float*)dinfo)[256 + lane];
+        const double Cd = (double)((float*)dinfo)[256 + ln];
         bool active = valid && p_viter > 0;
         int sweeps = 0;
         unsigned nsteps = 0, ncg = 0, ntrip = 0;
@@ -223,6 +282,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMVB_CTM_QW
         auto lap = [&](int which) {
             if constexpr (PROF) { const long long now = __builtin_readcyclecounter(); cyc[which] += now - t_mark; t_mark = now; }
         };
+        // PROF: shader cycles wave 0 spends waiting in the workgroup barriers of the sweeps (slot 7 of the phase counters)
+#define CQ_SYNC() do { if constexpr (PROF) { const long long tb_ = __builtin_readcyclecounter(); __syncthreads(); cyc[7] += __builtin_readcyclecounter() - tb_; } else __syncthreads(); } while (0)
+
 
         for (int v = 0; v < p_viter; ++v) {
             if (!__any(active)) break;
@@ -233,12 +295,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMVB_CTM_QW
 #pragma unroll
                 for (int i = 0; i < H; ++i) if (gt0 + i < K) lam_old_out[gt0 + i] = (float)lam[i];
             }
-            if (w == 0) dinfo[192 + lane] = active ? 1 : 0;
-            __syncthreads();                                                         // (A) lam_l, active flags
+            ln = cq_opq(lane);
+            if (w == 0) dinfo[192 + ln] = active ? 1 : 0;
+            CQ_SYNC();                                                         // (A) lam_l, active flags
             // ---- update_phi!  src/CTM.jl:175-178 in linear space, (phi * counts)_i = e_i sum_n w_n beta[i, t_n]
             {
                 float* xw = xv0 + vpar * (R * 64);
-                const bool tact = dinfo[192 + tj] != 0;
+                const int tjo = cq_opq(tj);
+                const bool tact = dinfo[192 + tjo] != 0;
                 cb_v4f ec[NS], acc[NS];
                 float lmx = -INFINITY;
 #pragma unroll
@@ -246,7 +310,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMVB_CTM_QW
                     const int c = qd + 4 * s;
                     const bool ok = (4 * s + 3 < LPR) || (c < LPR);
                     const int cc = ok ? c : 0;
-                    ec[s] = cb_v4f{lam_l[(4 * cc) * 64 + tj], lam_l[(4 * cc + 1) * 64 + tj], lam_l[(4 * cc + 2) * 64 + tj], lam_l[(4 * cc + 3) * 64 + tj]};
+                    ec[s] = cb_v4f{lam_l[(4 * cc) * 64 + tjo], lam_l[(4 * cc + 1) * 64 + tjo], lam_l[(4 * cc + 2) * 64 + tjo], lam_l[(4 * cc + 3) * 64 + tjo]};
                     if (ok) lmx = fmaxf(lmx, fmaxf(fmaxf(ec[s].x, ec[s].y), fmaxf(ec[s].z, ec[s].w)));
                     acc[s] = cb_v4f{0.f, 0.f, 0.f, 0.f};
                 }
@@ -290,9 +354,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMVB_CTM_QW
                 int tq = 0, cq = 0, tn = 0, cn = 0, t2 = 0, c2 = 0;
                 if constexpr (cq_asm_loop<R>::value) {
                     asm volatile("; CQVM_BEGIN");
-                    cq_gload4(tn, id_off(0), terms); cq_gload4(cn, id_off(0), counts);
-                    cq_vmwait<0>(tn); cq_vmwait_def(cn);
-                    cq_gload4(t2, id_off(CH), terms); cq_gload4(c2, id_off(CH), counts);
+                    cq_gload4<2>(tn, id_off(0), terms); cq_gload4<3>(cn, id_off(0), counts);
+                    asm volatile("s_waitcnt vmcnt(0)"); cq_vmwait_id<2>(tn); cq_vmwait_id<3>(cn);
+                    cq_gload4<0>(t2, id_off(CH), terms); cq_gload4<1>(c2, id_off(CH), counts);
                     tmvb_static_for<CH>([&](auto tag) {
                         constexpr int u = decltype(tag)::value;
                         const int tb_ = __builtin_amdgcn_update_dpp(0, tn, u * 0x55, 0xF, 0xF, true);
@@ -306,9 +370,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMVB_CTM_QW
                             tmvb_static_for<NS>([&](auto st) { constexpr int s = decltype(st)::value; if constexpr (s > 0) cq_vmwait_def(buf[u][s]); });
                             if constexpr (u == 0) {
                                 // behind the round's first wait the words of round k + 1 are in: rotate, then fetch round k + 2's into the freed pair
-                                cq_vmwait_def(t2); cq_vmwait_def(c2);
+                                cq_vmwait_id<0>(t2); cq_vmwait_id<1>(c2);
                                 tq = tn; cq = cn; tn = t2; cn = c2;
-                                cq_gload4(t2, id_off(n0 + 2 * CH), terms); cq_gload4(c2, id_off(n0 + 2 * CH), counts);
+                                cq_gload4<0>(t2, id_off(n0 + 2 * CH), terms); cq_gload4<1>(c2, id_off(n0 + 2 * CH), counts);
                             }
                             cb_v2f s0 = cb_v2f{0.f, 0.f}, s1 = cb_v2f{0.f, 0.f};
     #pragma unroll
@@ -338,7 +402,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMVB_CTM_QW
                     cq_vmwait<0>(buf[0][0]);                                              // the rows fetched past the end land before their registers are reused
                     tmvb_static_for<CH>([&](auto tag) { constexpr int u = decltype(tag)::value;
                         tmvb_static_for<NS>([&](auto st) { constexpr int s = decltype(st)::value; cq_vmwait_def(buf[u][s]); }); });
-                    cq_vmwait_def(tn); cq_vmwait_def(cn); cq_vmwait_def(t2); cq_vmwait_def(c2);
+                    cq_vmwait_id<0>(t2); cq_vmwait_id<1>(c2);
                     asm volatile("; CQVM_END");
                 } else {
                     // the same loop with compiler-managed loads and waits (correct by construction; the instantiations whose hand-scheduled form
@@ -385,19 +449,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMVB_CTM_QW
                     const int c = qd + 4 * s;
                     const bool ok = (4 * s + 3 < LPR) || (c < LPR);
                     if (ok) {
-                        xw[(4 * c) * 64 + tj] = ec[s].x * acc[s].x; xw[(4 * c + 1) * 64 + tj] = ec[s].y * acc[s].y;
-                        xw[(4 * c + 2) * 64 + tj] = ec[s].z * acc[s].z; xw[(4 * c + 3) * 64 + tj] = ec[s].w * acc[s].w;
+                        xw[(4 * c) * 64 + tjo] = ec[s].x * acc[s].x; xw[(4 * c + 1) * 64 + tjo] = ec[s].y * acc[s].y;
+                        xw[(4 * c + 2) * 64 + tjo] = ec[s].z * acc[s].z; xw[(4 * c + 3) * 64 + tjo] = ec[s].w * acc[s].w;
                     }
                 }
-                __syncthreads();                                                     // (B) phi * counts
+                CQ_SYNC();                                                     // (B) phi * counts
                 vpar ^= 1;
             }
             lap(0);
             float phic[H];
+            ln = cq_opq(lane);
             {
                 const float* xr = xv0 + (vpar ^ 1) * (R * 64);
 #pragma unroll
-                for (int i = 0; i < H; ++i) phic[i] = xr[(gt0 + i) * 64 + lane];
+                for (int i = 0; i < H; ++i) phic[i] = xr[(gt0 + i) * 64 + ln];
             }
             // ---- update_logzeta!  src/CTM.jl:169-171
             {
@@ -405,9 +470,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMVB_CTM_QW
 #pragma unroll
                 for (int i = 0; i < H; ++i) mp = fmax(mp, lam[i] + 0.5 * (double)vs[i]);
                 double* b = xsd + spar * (4 * 64);
-                b[w * 64 + lane] = mp;
-                __syncthreads();
-                const double m = fmax(fmax(b[lane], b[64 + lane]), fmax(b[128 + lane], b[192 + lane]));
+                b[w * 64 + ln] = mp;
+                CQ_SYNC();
+                const double m = fmax(fmax(b[ln], b[64 + ln]), fmax(b[128 + ln], b[192 + ln]));
                 spar ^= 1;
                 double sp = 0.0;
                 tmvb_static_for<(H + 3) / 4>([&](auto tag) {
@@ -416,16 +481,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMVB_CTM_QW
                     double ax[NU];
 #pragma unroll
                     for (int u = 0; u < NU; ++u) ax[u] = lam[i0 + u] + 0.5 * (double)vs[i0 + u] - m;
-                    cb_exp_n<NU>(ax);
+                    cq_exp_n<NU>(ax);
 #pragma unroll
                     for (int u = 0; u < NU; ++u) sp += ax[u];                         // pads add exp(-1e30 - m) = +0
                 });
                 double* b2 = xsd + spar * (4 * 64);
-                b2[w * 64 + lane] = sp;
-                __syncthreads();
-                const double s = ((b2[lane] + b2[64 + lane]) + b2[128 + lane]) + b2[192 + lane];
+                b2[w * 64 + ln] = sp;
+                CQ_SYNC();
+                const double s = ((b2[ln] + b2[64 + ln]) + b2[128 + ln]) + b2[192 + ln];
                 spar ^= 1;
+                // log(s), 1 <= s <= KP: the fp32 logarithm and one Newton step of exp(y) = s in fp64 (error ~1e-14; the library's fp64 log brings six
+                // polynomial constants that the compiler hoists into VGPR pairs in the kernel's prologue and spills)
+#ifdef TMVB_CQ_OLDLOG
                 if (active) lz = m + log(s);
+#else
+                {
+                    const double y0 = (double)__logf((float)s);
+                    double e1[1] = {-y0};
+                    cq_exp_n<1>(e1);
+                    if (active) lz = m + (y0 + (s * e1[0] - 1.0));
+                }
+#endif
             }
             lap(1);
             // ---- update_vsq!  src/CTM.jl:146-165 (one scalar Newton iteration per topic; four topics per loop)
@@ -447,7 +523,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMVB_CTM_QW
                         double ex[NU], rv[NU], den[NU], ihd[NU], grad[NU], pp[NU], rho[NU];
 #pragma unroll
                         for (int u = 0; u < NU; ++u) ex[u] = lm[u] + 0.5 * vv[u] - lz;
-                        cb_exp_n<NU>(ex);
+                        cq_exp_n<NU>(ex);
                         cb_rcp_n<NU>(vv, rv);
 #pragma unroll
                         for (int u = 0; u < NU; ++u) {
@@ -487,17 +563,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMVB_CTM_QW
                     if (!__any(newt)) break;
                     ++ntrip;
                     if (newt) ++nsteps;
+                    ln = cq_opq(lane);
                     cb_v2f p2[JP];
                     {
                         // invsigma (mu - lambda), :134, in fp32 (tmvb_ctm_batch.h: what that costs and why it is enough)
                         float* xw = xv0 + vpar * (R * 64);
                         const cb_v16f mb = cq_sload16_sync<1>(muq_w);
 #pragma unroll
-                        for (int i = 0; i < H; ++i) xw[(gt0 + i) * 64 + lane] = (float)((double)mb[i] - lam[i]);
-                        __syncthreads();
+                        for (int i = 0; i < H; ++i) xw[(gt0 + i) * 64 + ln] = (float)((double)mb[i] - lam[i]);
+                        CQ_SYNC();
                         vpar ^= 1;
 #pragma unroll
-                        for (int jp = 0; jp < JP; ++jp) p2[jp] = cb_v2f{xw[(2 * jp) * 64 + lane], xw[(2 * jp + 1) * 64 + lane]};
+                        for (int jp = 0; jp < JP; ++jp) p2[jp] = cb_v2f{xw[(2 * jp) * 64 + ln], xw[(2 * jp + 1) * 64 + ln]};
                     }
                     float g[H], D[H], dinv[H];
                     double gn2p = 0.0;
@@ -512,7 +589,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMVB_CTM_QW
                             const cb_v4f sdg = cb_sload4_sync<i0>(sdq_w);
 #pragma unroll
                             for (int u = 0; u < NU; ++u) ex[u] = lam[i0 + u] + 0.5 * (double)vs[i0 + u] - lz;
-                            cb_exp_n<NU>(ex);
+                            cq_exp_n<NU>(ex);
 #pragma unroll
                             for (int u = 0; u < NU; ++u) {
                                 const int i = i0 + u;
@@ -536,18 +613,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMVB_CTM_QW
                         for (int i = 0; i < H; ++i) {
                             r[i] = g[i]; pv[i] = g[i] * dinv[i]; x[i] = 0.0f;
                             ggp = fmaf(g[i], g[i], ggp); rzp = fmaf(r[i], pv[i], rzp);
-                            xw[(gt0 + i) * 64 + lane] = pv[i];
+                            xw[(gt0 + i) * 64 + ln] = pv[i];
                         }
                         float* bf = xsf + spar * (3 * 4 * 64);
                         double* bd = xsd + spar * (4 * 64);
-                        bf[w * 64 + lane] = ggp; bf[(4 + w) * 64 + lane] = rzp; bd[w * 64 + lane] = gn2p;
-                        __syncthreads();
+                        bf[w * 64 + ln] = ggp; bf[(4 + w) * 64 + ln] = rzp; bd[w * 64 + ln] = gn2p;
+                        CQ_SYNC();
                         vpar ^= 1; spar ^= 1;
-                        gg = ((bf[lane] + bf[64 + lane]) + bf[128 + lane]) + bf[192 + lane];
-                        rz = ((bf[256 + lane] + bf[320 + lane]) + bf[384 + lane]) + bf[448 + lane];
-                        gn2 = ((bd[lane] + bd[64 + lane]) + bd[128 + lane]) + bd[192 + lane];
+                        gg = ((bf[ln] + bf[64 + ln]) + bf[128 + ln]) + bf[192 + ln];
+                        rz = ((bf[256 + ln] + bf[320 + ln]) + bf[384 + ln]) + bf[448 + ln];
+                        gn2 = ((bd[ln] + bd[64 + ln]) + bd[128 + ln]) + bd[192 + ln];
 #pragma unroll
-                        for (int jp = 0; jp < JP; ++jp) p2[jp] = cb_v2f{xw[(2 * jp) * 64 + lane], xw[(2 * jp + 1) * 64 + lane]};
+                        for (int jp = 0; jp < JP; ++jp) p2[jp] = cb_v2f{xw[(2 * jp) * 64 + ln], xw[(2 * jp + 1) * 64 + ln]};
                     }
                     lap(3);
                     thr = fmaxf(cg_tol2 * gg, cg_abs2);
@@ -555,6 +632,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMVB_CTM_QW
                     int trips = 0;
                     while (trips < cg_maxit && __any(live)) {
                         ++trips;
+                        ln = cq_opq(lane);
                         float y[H];
                         float pHp;
                         {
@@ -564,10 +642,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMVB_CTM_QW
 #pragma unroll
                             for (int i = 0; i < H; ++i) { y[i] = fmaf(D[i], pv[i], y2[i].x + y2[i].y); pp = fmaf(pv[i], y[i], pp); }
                             float* bf = xsf + spar * (3 * 4 * 64);
-                            bf[w * 64 + lane] = pp;
-                            __syncthreads();
+                            bf[w * 64 + ln] = pp;
+                            CQ_SYNC();
                             spar ^= 1;
-                            pHp = ((bf[lane] + bf[64 + lane]) + bf[128 + lane]) + bf[192 + lane];
+                            pHp = ((bf[ln] + bf[64 + ln]) + bf[128 + ln]) + bf[192 + ln];
                         }
                         const float alpha = (live && pHp > 0.0f) ? rz / pHp : 0.0f;
                         float rrp = 0.0f, rzp = 0.0f;
@@ -578,14 +656,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMVB_CTM_QW
                             r[i] = fmaf(-alpha, y[i], r[i]);
                             y[i] = r[i] * dinv[i];                                   // z
                             rrp = fmaf(r[i], r[i], rrp); rzp = fmaf(r[i], y[i], rzp);
-                            xw[(gt0 + i) * 64 + lane] = y[i];
+                            xw[(gt0 + i) * 64 + ln] = y[i];
                         }
                         float* bf = xsf + spar * (3 * 4 * 64);
-                        bf[w * 64 + lane] = rrp; bf[(4 + w) * 64 + lane] = rzp;
-                        __syncthreads();
+                        bf[w * 64 + ln] = rrp; bf[(4 + w) * 64 + ln] = rzp;
+                        CQ_SYNC();
                         vpar ^= 1; spar ^= 1;
-                        const float rr = ((bf[lane] + bf[64 + lane]) + bf[128 + lane]) + bf[192 + lane];
-                        const float rz_new = ((bf[256 + lane] + bf[320 + lane]) + bf[384 + lane]) + bf[448 + lane];
+                        const float rr = ((bf[ln] + bf[64 + ln]) + bf[128 + ln]) + bf[192 + ln];
+                        const float rz_new = ((bf[256 + ln] + bf[320 + ln]) + bf[384 + ln]) + bf[448 + ln];
                         if (rr <= thr) live = false;
                         const float beta = (live && rz > 0.0f) ? rz_new / rz : 0.0f;
                         rz = rz_new;
@@ -594,7 +672,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMVB_CTM_QW
                         for (int i = 0; i < H; ++i) pv[i] = fmaf(beta, pv[i], y[i]);
 #pragma unroll
                         for (int jp = 0; jp < JP; ++jp)
-                            p2[jp] = __builtin_elementwise_fma(b2, p2[jp], cb_v2f{xw[(2 * jp) * 64 + lane], xw[(2 * jp + 1) * 64 + lane]});
+                            p2[jp] = __builtin_elementwise_fma(b2, p2[jp], cb_v2f{xw[(2 * jp) * 64 + ln], xw[(2 * jp + 1) * 64 + ln]});
                     }
                     ncg += (unsigned)trips;
                     lap(4);
@@ -607,6 +685,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMVB_CTM_QW
             }
             // ---- exit test (:200), the decomposed update_elbo!'s sum_i (phi counts)_i (lambda_i - lambda_old_i), and lambda for the next token phase
             {
+                ln = cq_opq(lane);
                 float d2p = 0.0f, pdp = 0.0f;
                 const float* lam_old_in = CB_KARG(const float*, p.lambda_old) + (int64_t)d * K;
 #pragma unroll
@@ -615,14 +694,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMVB_CTM_QW
                     const float lo_ = (active && on) ? lam_old_in[gt0 + i] : 0.0f;
                     const float df = on ? (float)(lam[i] - (double)lo_) : 0.0f;
                     d2p = fmaf(df, df, d2p); pdp = fmaf(phic[i], df, pdp);
-                    lam_l[(gt0 + i) * 64 + lane] = on ? (float)lam[i] : -1.0e30f;
+                    lam_l[(gt0 + i) * 64 + ln] = on ? (float)lam[i] : -1.0e30f;
                 }
                 float* bf = xsf + spar * (3 * 4 * 64);
-                bf[w * 64 + lane] = d2p; bf[(4 + w) * 64 + lane] = pdp;
-                __syncthreads();
+                bf[w * 64 + ln] = d2p; bf[(4 + w) * 64 + ln] = pdp;
+                CQ_SYNC();
                 spar ^= 1;
-                const float dist2 = ((bf[lane] + bf[64 + lane]) + bf[128 + lane]) + bf[192 + lane];
-                const float pdot = ((bf[256 + lane] + bf[320 + lane]) + bf[384 + lane]) + bf[448 + lane];
+                const float dist2 = ((bf[ln] + bf[64 + ln]) + bf[128 + ln]) + bf[192 + ln];
+                const float pdot = ((bf[256 + ln] + bf[320 + ln]) + bf[384 + ln]) + bf[448 + ln];
                 if (active) {
                     if (w == 0) { float* pd_out = CB_KARG(float*, p.pdot); if (pd_out) pd_out[d] = pdot; }
                     if (sqrtf(dist2) < (float)p_vtol) active = false;
@@ -666,4 +745,5 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMVB_CTM_QW
             }
         }
     }   // next item
+#undef CQ_SYNC
 }
