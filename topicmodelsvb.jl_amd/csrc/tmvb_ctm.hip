@@ -1817,7 +1817,7 @@ static int ctm_launch_quad(tmvb_ctm* h, const CtmParams& p, double ntol)
     if (Mb <= 0) return TMVB_OK;
     const int n_items = (int)((Mb + 63) / 64);
     const int LPRv = h->KP / 4, CPR = 4 * ((LPRv + 3) / 4);
-    const size_t lds = (size_t)(3 * h->KP * 64 + 2 * 3 * 4 * 64) * 4 + (size_t)(2 * 4 * 64) * 8 + (5 * 64 + 4) * 4;
+    const size_t lds = (size_t)(5 * h->KP * 64 + 2 * 3 * 4 * 64) * 4 + (size_t)(2 * 4 * 64) * 8 + (5 * 64 + 4) * 4;      // = cq_dim<KP>::lds_bytes
     // two workgroups per CU: two waves per SIMD (TMVB_CTM_QUAD_PER_CU: diagnostics)
     int per_cu = TMVB_CTM_QWAVES;
     if (const char* e = getenv("TMVB_CTM_QUAD_PER_CU")) per_cu = std::max(1, std::min(4, atoi(e)));

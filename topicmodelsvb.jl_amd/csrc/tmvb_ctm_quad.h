@@ -35,7 +35,7 @@ template <int R> struct cq_dim {
     static constexpr unsigned ROWB = NS * 64u;           // bytes per row of the padded gather table (ctm_rowpad_generic_kernel)
     static constexpr int XSF = 2 * 3 * 4 * 64;           // floats of the scalar exchange: [parity][value][wave][lane]
     static constexpr int XSD = 2 * 1 * 4 * 64;           // doubles of the fp64 scalar exchange
-    static constexpr size_t lds_bytes = (size_t)(3 * R * 64 + XSF) * 4 + (size_t)XSD * 8 + (5 * 64 + 4) * 4;
+    static constexpr size_t lds_bytes = (size_t)(5 * R * 64 + XSF) * 4 + (size_t)XSD * 8 + (5 * 64 + 4) * 4;
 };
 
 // y += {s[lo], s[hi]} * p component-wise; PAIR = which of the 32 SGPR pairs of the two groups (tmvb_ctm_batch.h: cb_fx_regs)
@@ -207,7 +207,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMVB_CTM_QW
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* lam_l = lds;                                    // [R][64]  (float)lambda, for the token lanes
     float* xv0 = lds + R * 64;                             // [2][R][64] vector exchange (alternating: a buffer is rewritten two barriers after its last read)
-    float* xsf = lds + 3 * R * 64;                         // scalar exchange, fp32
+    // (phi * counts) and vsq in [topic][document] rows of their own: written / read by the wave that owns the topic (vsq) or handed from the token lanes to it
+    // (phi * counts); as 13 + 13 registers per lane across the Newton loop they -- and the doubles the compiler derived from them -- were what it spilled
+    float* ph_l = lds + 3 * R * 64;                        // [R][64]
+    float* vs_l = lds + 4 * R * 64;                        // [R][64]
+    float* xsf = lds + 5 * R * 64;                         // scalar exchange, fp32
     double* xsd = (double*)(xsf + DM::XSF);                // scalar exchange, fp64
     int* dinfo = (int*)(xsd + DM::XSD);                    // [64] document, [64] first token, [64] tokens, [64] active, [64] C_d
     int* item_l = dinfo + 5 * 64;
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMVB_CTM_QW
 
         // ---- Newton lanes: own topics of document `lane`
         double lam[H];
-        float vs[H];
+#define VS(i) vs_l[(gt0 + (i)) * 64 + ln]
         double lz;
         {
             const float* lrow = CB_KARG(const float*, p.lambda) + (int64_t)d * K;
@@ -266,7 +270,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMVB_CTM_QW
                 const int ic = min(gt0 + i, K - 1);
                 const float lv = lrow[ic], vv = vrow[ic];
                 lam[i] = on ? (double)lv : -1.0e30;
-                vs[i] = on ? vv : 1.0f;
+                VS(i) = on ? vv : 1.0f;
                 lam_l[(gt0 + i) * 64 + ln] = on ? lv : -1.0e30f;
             }
             lz = (double)CB_KARG(const float*, p.logzeta)[d];
@@ -300,7 +304,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMVB_CTM_QW
             CQ_SYNC();                                                         // (A) lam_l, active flags
             // ---- update_phi!  src/CTM.jl:175-178 in linear space, (phi * counts)_i = e_i sum_n w_n beta[i, t_n]
             {
-                float* xw = xv0 + vpar * (R * 64);
+                float* xw = ph_l;
                 const int tjo = cq_opq(tj);
                 const bool tact = dinfo[192 + tjo] != 0;
                 cb_v4f ec[NS], acc[NS];
@@ -454,21 +458,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMVB_CTM_QW
                     }
                 }
                 CQ_SYNC();                                                     // (B) phi * counts
-                vpar ^= 1;
             }
             lap(0);
-            float phic[H];
             ln = cq_opq(lane);
-            {
-                const float* xr = xv0 + (vpar ^ 1) * (R * 64);
-#pragma unroll
-                for (int i = 0; i < H; ++i) phic[i] = xr[(gt0 + i) * 64 + ln];
-            }
+#define PHIC(i) ph_l[(gt0 + (i)) * 64 + ln]
             // ---- update_logzeta!  src/CTM.jl:169-171
             {
                 double mp = -INFINITY;
 #pragma unroll
-                for (int i = 0; i < H; ++i) mp = fmax(mp, lam[i] + 0.5 * (double)vs[i]);
+                for (int i = 0; i < H; ++i) mp = fmax(mp, lam[i] + 0.5 * (double)VS(i));
                 double* b = xsd + spar * (4 * 64);
                 b[w * 64 + ln] = mp;
                 CQ_SYNC();
@@ -480,7 +478,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMVB_CTM_QW
                     constexpr int NU = (H - i0 < 4) ? H - i0 : 4;
                     double ax[NU];
 #pragma unroll
-                    for (int u = 0; u < NU; ++u) ax[u] = lam[i0 + u] + 0.5 * (double)vs[i0 + u] - m;
+                    for (int u = 0; u < NU; ++u) ax[u] = lam[i0 + u] + 0.5 * (double)VS(i0 + u) - m;
                     cq_exp_n<NU>(ax);
 #pragma unroll
                     for (int u = 0; u < NU; ++u) sp += ax[u];                         // pads add exp(-1e30 - m) = +0
@@ -514,7 +512,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMVB_CTM_QW
                     bool act[NU];
                     const cb_v4f sd4 = cb_sload4_sync<i0>(sdq_w);
 #pragma unroll
-                    for (int u = 0; u < NU; ++u) { vv[u] = (double)vs[i0 + u]; lm[u] = lam[i0 + u]; act[u] = active && (gt0 + i0 + u < K); isd[u] = (double)sd4[u]; }
+                    for (int u = 0; u < NU; ++u) { vv[u] = (double)VS(i0 + u); lm[u] = lam[i0 + u]; act[u] = active && (gt0 + i0 + u < K); isd[u] = (double)sd4[u]; }
                     for (int t = 0; t < p_niter; ++t) {
                         bool anyact = false;
 #pragma unroll
@@ -551,7 +549,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMVB_CTM_QW
 #pragma unroll
                     for (int u = 0; u < NU; ++u) {
                         if (active && gt0 + i0 + u < K) vv[u] += TMVB_EPS_D;                        // :164
-                        vs[i0 + u] = (float)vv[u];
+                        VS(i0 + u) = (float)vv[u];
                     }
                 });
             }
@@ -588,14 +586,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMVB_CTM_QW
                             double ex[NU];
                             const cb_v4f sdg = cb_sload4_sync<i0>(sdq_w);
 #pragma unroll
-                            for (int u = 0; u < NU; ++u) ex[u] = lam[i0 + u] + 0.5 * (double)vs[i0 + u] - lz;
+                            for (int u = 0; u < NU; ++u) ex[u] = lam[i0 + u] + 0.5 * (double)VS(i0 + u) - lz;
                             cq_exp_n<NU>(ex);
 #pragma unroll
                             for (int u = 0; u < NU; ++u) {
                                 const int i = i0 + u;
                                 const bool on = gt0 + i < K;
                                 const double mv = (double)(y2[i].x + y2[i].y);
-                                const double gd = on ? (mv + (double)phic[i] - Cd * ex[u]) : 0.0;       // :134
+                                const double gd = on ? (mv + (double)PHIC(i) - Cd * ex[u]) : 0.0;       // :134
                                 gn2p = fma(gd, gd, gn2p);
                                 const float dval = on ? (float)(Cd * ex[u]) : 1.0f;                     // pad rows: unit rows
                                 g[i] = (float)gd; D[i] = dval; dinv[i] = 1.0f / (sdg[u] + dval);        // 1 / -H_ii
@@ -693,7 +691,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMVB_CTM_QW
                     const bool on = gt0 + i < K;
                     const float lo_ = (active && on) ? lam_old_in[gt0 + i] : 0.0f;
                     const float df = on ? (float)(lam[i] - (double)lo_) : 0.0f;
-                    d2p = fmaf(df, df, d2p); pdp = fmaf(phic[i], df, pdp);
+                    d2p = fmaf(df, df, d2p); pdp = fmaf(PHIC(i), df, pdp);
                     lam_l[(gt0 + i) * 64 + ln] = on ? (float)lam[i] : -1.0e30f;
                 }
                 float* bf = xsf + spar * (3 * 4 * 64);
@@ -716,7 +714,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMVB_CTM_QW
                 float* vsq_out = CB_KARG(float*, p.vsq) + (int64_t)d * K;
 #pragma unroll
                 for (int i = 0; i < H; ++i) {
-                    if (gt0 + i < K) { lam_out[gt0 + i] = (float)lam[i]; vsq_out[gt0 + i] = vs[i]; }
+                    if (gt0 + i < K) { lam_out[gt0 + i] = (float)lam[i]; vsq_out[gt0 + i] = VS(i); }
                 }
                 if (w == 0) CB_KARG(float*, p.logzeta)[d] = (float)lz;
             } else {
@@ -746,4 +744,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMVB_CTM_QW
         }
     }   // next item
 #undef CQ_SYNC
+#undef VS
+#undef PHIC
 }
