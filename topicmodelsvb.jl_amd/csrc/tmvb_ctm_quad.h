@@ -166,6 +166,18 @@ __device__ __forceinline__ void cq_gload16(cb_v4f& d, unsigned voff, const __att
 {
     asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "+v"(d) : "v"(voff), "s"(sbase), "n"(OFF));
 }
+// the same for the LAST chunk slot of a row whose chunk count is not a multiple of four (KP = 52: 13 chunks, slot 3 holds chunk 12 in lane 0 of each quad and
+// pad in the other three): only the lanes of `mask` issue their 16 bytes -- the others keep whatever their registers held, which only ever meets e = 0
+#ifndef TMVB_CTM_QMASKED
+#define TMVB_CTM_QMASKED 1
+#endif
+template <int OFF>
+__device__ __forceinline__ void cq_gload16_masked(cb_v4f& d, unsigned voff, const __attribute__((address_space(1))) char* sbase, unsigned long long mask)
+{
+    unsigned long long sv;
+    asm volatile("s_mov_b64 %1, exec\n\ts_and_b64 exec, exec, %5\n\tglobal_load_dwordx4 %0, %2, %3 offset:%4\n\ts_mov_b64 exec, %1"
+                 : "+v"(d), "=&s"(sv) : "v"(voff), "s"(sbase), "n"(OFF), "s"(mask) : "scc");
+}
 // The id / count words live in FIXED physical registers from their load to the wait that lands them (WHICH = 0 .. 3 -> v244 .. v247): as plain "+v"
 // operands the compiler twice chose to copy the (not yet landed) word out of its register, use the register as an address temporary and copy the stale
 // word back in front of the wait -- run-to-run different results (tools/check_vmem_inflight.py reports it; build() refuses such a library).  With the
@@ -357,6 +369,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMVB_CTM_QW
                 cb_v4f buf[CH][NS];
                 int tq = 0, cq = 0, tn = 0, cn = 0, t2 = 0, c2 = 0;
                 if constexpr (cq_asm_loop<R>::value) {
+                    // lanes of a quad that hold a chunk of the row in the last slot: qd < LPR mod 4 (all four when LPR is a multiple of four: never masked then)
+                    constexpr unsigned long long qmask = 0x1111111111111111ull * ((1u << ((LPR & 3) ? (LPR & 3) : 4)) - 1u);
+                    // (the lanes a masked load never writes must hold finite values: they meet e = 0, and 0 * NaN is not 0 -- zeroed once, never written again)
+                    if constexpr (TMVB_CTM_QMASKED && (LPR & 3)) {
+#pragma unroll
+                        for (int u = 0; u < CH; ++u) buf[u][NS - 1] = cb_v4f{0.f, 0.f, 0.f, 0.f};
+                    }
                     asm volatile("; CQVM_BEGIN");
                     cq_gload4<2>(tn, id_off(0), terms); cq_gload4<3>(cn, id_off(0), counts);
                     asm volatile("s_waitcnt vmcnt(0)"); cq_vmwait_id<2>(tn); cq_vmwait_id<3>(cn);
@@ -365,7 +384,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMVB_CTM_QW
                         constexpr int u = decltype(tag)::value;
                         const int tb_ = __builtin_amdgcn_update_dpp(0, tn, u * 0x55, 0xF, 0xF, true);
                         const unsigned ab = __umul24((unsigned)((u < tN) ? tb_ : 0), DM::ROWB) + qb;      // row ids are < 2^24; row 0 past the document's end
-                        tmvb_static_for<NS>([&](auto st) { constexpr int s = decltype(st)::value; cq_gload16<64 * s>(buf[u][s], ab, beta); });
+                        tmvb_static_for<NS>([&](auto st) { constexpr int s = decltype(st)::value;
+                            if constexpr (TMVB_CTM_QMASKED && 4 * s + 3 >= LPR) cq_gload16_masked<64 * s>(buf[u][s], ab, beta, qmask); else cq_gload16<64 * s>(buf[u][s], ab, beta); });
                     });
                     for (int n0 = 0; n0 < Nmax16; n0 += CH) {
                         tmvb_static_for<CH>([&](auto tag) {
@@ -400,7 +420,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMVB_CTM_QW
                             const int tb_ = __builtin_amdgcn_update_dpp(0, tn, u * 0x55, 0xF, 0xF, true);
                             const unsigned ab = __umul24((unsigned)((n0 + CH + u < tN) ? tb_ : 0), DM::ROWB) + qb;
                             __builtin_amdgcn_sched_barrier(0);
-                            tmvb_static_for<NS>([&](auto st) { constexpr int s = decltype(st)::value; cq_gload16<64 * s>(buf[u][s], ab, beta); });      // step n0 + CH + u
+                            tmvb_static_for<NS>([&](auto st) { constexpr int s = decltype(st)::value;                                                     // step n0 + CH + u
+                                if constexpr (TMVB_CTM_QMASKED && 4 * s + 3 >= LPR) cq_gload16_masked<64 * s>(buf[u][s], ab, beta, qmask); else cq_gload16<64 * s>(buf[u][s], ab, beta); });
                         });
                     }
                     cq_vmwait<0>(buf[0][0]);                                              // the rows fetched past the end land before their registers are reused
