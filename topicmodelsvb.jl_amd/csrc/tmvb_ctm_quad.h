@@ -305,12 +305,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMVB_CTM_QW
         for (int v = 0; v < p_viter; ++v) {
             if (!__any(active)) break;
             if (active) ++sweeps;
-            // lambda_old of this sweep goes to its output array and is read back for the exit test (13 registers less across the Newton phases)
-            if (active) {
-                float* lam_old_out = CB_KARG(float*, p.lambda_old) + (int64_t)d * K;
-#pragma unroll
-                for (int i = 0; i < H; ++i) if (gt0 + i < K) lam_old_out[gt0 + i] = (float)lam[i];
-            }
+            // (lambda_old of this sweep = the fp32 lambda the token lanes read from lam_l: it stays there until the exit test, which stores it -- and the factor
+            //  e = exp(lambda_old - max) of the statistics pass -- once, for the document's LAST executed sweep, instead of every sweep)
             ln = cq_opq(lane);
             if (w == 0) dinfo[192 + ln] = active ? 1 : 0;
             CQ_SYNC();                                                         // (A) lam_l, active flags
@@ -337,8 +333,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMVB_CTM_QW
                     const bool ok = (4 * s + 3 < LPR) || (c < LPR);
                     const cb_v4f e4 = cb_v4f{expf(ec[s].x - lmx), expf(ec[s].y - lmx), expf(ec[s].z - lmx), expf(ec[s].w - lmx)};     // pads: expf(-1e30) = 0
                     ec[s] = ok ? e4 : cb_v4f{0.f, 0.f, 0.f, 0.f};
-                    // E keeps the LAST executed sweep's factor e = exp(lambda_old - max) for the statistics pass
-                    if (tact && ok) *(cb_v4f*)(CB_KARG(float*, p.E) + (int64_t)td * R + 4 * c) = ec[s];
                 }
                 typedef const __attribute__((address_space(1))) float* gfloat_p;
                 typedef const __attribute__((address_space(1))) int32_t* gint_p;
@@ -705,25 +699,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TMVB_CTM_QW
             // ---- exit test (:200), the decomposed update_elbo!'s sum_i (phi counts)_i (lambda_i - lambda_old_i), and lambda for the next token phase
             {
                 ln = cq_opq(lane);
-                float d2p = 0.0f, pdp = 0.0f;
-                const float* lam_old_in = CB_KARG(const float*, p.lambda_old) + (int64_t)d * K;
+                float d2p = 0.0f, pdp = 0.0f, lmp = -INFINITY;
+                float lo[H];
 #pragma unroll
                 for (int i = 0; i < H; ++i) {
                     const bool on = gt0 + i < K;
-                    const float lo_ = (active && on) ? lam_old_in[gt0 + i] : 0.0f;
-                    const float df = on ? (float)(lam[i] - (double)lo_) : 0.0f;
+                    lo[i] = lam_l[(gt0 + i) * 64 + ln];                                             // lambda_old (pads: -1e30)
+                    lmp = fmaxf(lmp, lo[i]);
+                    const float df = on ? (float)(lam[i] - (double)lo[i]) : 0.0f;
                     d2p = fmaf(df, df, d2p); pdp = fmaf(PHIC(i), df, pdp);
                     lam_l[(gt0 + i) * 64 + ln] = on ? (float)lam[i] : -1.0e30f;
                 }
                 float* bf = xsf + spar * (3 * 4 * 64);
-                bf[w * 64 + ln] = d2p; bf[(4 + w) * 64 + ln] = pdp;
+                bf[w * 64 + ln] = d2p; bf[(4 + w) * 64 + ln] = pdp; bf[(8 + w) * 64 + ln] = lmp;
                 CQ_SYNC();
                 spar ^= 1;
                 const float dist2 = ((bf[ln] + bf[64 + ln]) + bf[128 + ln]) + bf[192 + ln];
                 const float pdot = ((bf[256 + ln] + bf[320 + ln]) + bf[384 + ln]) + bf[448 + ln];
+                const float lmx = fmaxf(fmaxf(bf[512 + ln], bf[576 + ln]), fmaxf(bf[640 + ln], bf[704 + ln]));
+                const bool was = active;
                 if (active) {
                     if (w == 0) { float* pd_out = CB_KARG(float*, p.pdot); if (pd_out) pd_out[d] = pdot; }
                     if (sqrtf(dist2) < (float)p_vtol) active = false;
+                }
+                // the document's last executed sweep: lambda_old and E = exp(lambda_old - max) (the factor of the last phi, for the statistics pass) to memory
+                const bool fin = was && (!active || v == p_viter - 1);
+                if (__any(fin)) {
+                    if (fin) {
+                        float* lam_old_out = CB_KARG(float*, p.lambda_old) + (int64_t)d * K;
+                        float* E = CB_KARG(float*, p.E) + (int64_t)d * R;
+#pragma unroll
+                        for (int i = 0; i < H; ++i) {
+                            if (gt0 + i < K) lam_old_out[gt0 + i] = lo[i];
+                            E[gt0 + i] = expf(lo[i] - lmx);                                         // pads: expf(-1e30) = 0
+                        }
+                    }
                 }
             }
             lap(6);
