@@ -63,7 +63,7 @@ KERNEL_SOURCES = {
     # the sources the kernels of one configuration are compiled from (the statistics pass, the reductions and the shared headers
     # belong to every model); a PMC summary is valid for a build whose files of ITS model are unchanged
     "lda": ("tmvb_lda.hip", "tmvb_gridtile.h", "tmvb_regtile.h", "tmvb_termstats.h", "tmvb_common_kernels.h", "tmvb_internal.h"),
-    "ctm": ("tmvb_ctm.hip", "tmvb_ctm_batch.h", "tmvb_filtered.h", "tmvb_termstats.h", "tmvb_common_kernels.h", "tmvb_internal.h"),
+    "ctm": ("tmvb_ctm.hip", "tmvb_ctm_batch.h", "tmvb_ctm_quad.h", "tmvb_filtered.h", "tmvb_termstats.h", "tmvb_common_kernels.h", "tmvb_internal.h"),
     "ctpf": ("tmvb_ctpf.hip", "tmvb_gridtile.h", "tmvb_regtile.h", "tmvb_termstats.h", "tmvb_common_kernels.h", "tmvb_internal.h"),
 }
 
@@ -83,7 +83,7 @@ def pmc_traffic(K, M, nnz):
     passes of this same command, tools/pmc_summary.py), corrected as MI355X_MICROARCH.md's HBM section prescribes for
     gfx950 (2 x FETCH_SIZE; KB units).  Returned only when the summary was collected on this workload AND on the kernel
     sources this run is built from (source hash stamped into the summary); otherwise null with the reason."""
-    for name in ("r5_lda50_pmc.json", "r4_lda50_pmc.json", "r3_lda_k50_pmc.json", "r2_lda_k50_pmc.json", "r1_lda_k50_pmc.json"):
+    for name in ("r6_lda50_pmc.json", "r5_lda50_pmc.json", "r4_lda50_pmc.json", "r3_lda_k50_pmc.json", "r2_lda_k50_pmc.json", "r1_lda_k50_pmc.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             break

@@ -30,7 +30,7 @@ BENCHED = {
     "lda_estep_grid_kernel<13,": 0, "lda_estep_grid_kernel<25,": 0, "lda_estep_grid_long_kernel<13,": 0, "lda_estep_grid_long_kernel<25,": 0,
     "termstats_recompute_kernel<13,": 0, "termstats_recompute_kernel<25,": 0, "termstats_multi_kernel": 0, "beta_norm_kernel": 0, "lda_alpha_kernel<": 0,
     # config 4: CTM K = 50
-    "ctm_estep_batch_kernel<52, false, false>": 388, "ctm_estep_quad_kernel<52, false>": 620, "ctm_scatter_mfma_kernel": 0, "ctm_sigma_mu_kernel": 0,
+    "ctm_estep_batch_kernel<52, false, false>": 388, "ctm_estep_quad_kernel<52, false>": 96, "ctm_scatter_mfma_kernel": 0, "ctm_sigma_mu_kernel": 0,
     # config 5: CTPF K = 50
     "ctpf_estep_grid_narrow_kernel<13>": 0, "ctpf_estep_grid_wide_kernel<13>": 0, "ctpf_estep_grid_long2_kernel<13>": 0, "termstats_recompute2_kernel<13": 0,
     "ctpf_mstep_kernel": 0,

@@ -77,11 +77,11 @@ def pmc_traffic(name):
     fam = "lda" if name.startswith("lda") else name
     kernel_source_hash = lambda: _ksh(fam)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cands = [f"r5_{name}_pmc.json", f"r4_{name}_pmc.json"]
+    cands = [f"r6_{name}_pmc.json", f"r5_{name}_pmc.json", f"r4_{name}_pmc.json"]
     fname = next((c for c in cands if os.path.exists(os.path.join(root, "profiles", c))), None)
     pmc_traffic.valu_issue_cycles = None
     if fname is None:
-        return None, f"no profiles/r5_{name}_pmc.json"
+        return None, f"no profiles/r6_{name}_pmc.json"
     rows = json.load(open(os.path.join(root, "profiles", fname)))
     meta = rows.get("_meta", {})
     if meta.get("kernel_source_hash") != kernel_source_hash():
@@ -216,7 +216,9 @@ def ctm(burnin=60, warmup=2, steps=8, cpu=True, K=50):        # 60 burn-in itera
                                    f"iterations from the cold start, then {warmup} warm-up + {steps} timed",
                        "M": pc.M, "V": pc.V, "nnz": pc.nnz, "lambda_newton_steps_last_iteration": int(newton), "sweeps_last_iteration": sweeps,
                        "sweep_hist_last_step": [int(h) for h in hist],
-                       "kernel": ("ctm_estep_batch_kernel (lane per document, Jacobi-preconditioned CG Newton solves)" if lane_kernel else
+                       "kernel": (("ctm_estep_quad_kernel (lane per document, four waves per 64 documents: topic quarters in the Newton phases, four lanes per document in the token walk; Jacobi-preconditioned CG Newton solves)"
+                                   if os.environ.get("TMVB_CTM_QUAD", "1") != "0" and not os.environ.get("TMVB_CTM_PROF") else
+                                   "ctm_estep_batch_kernel (lane per document, one wave per 64 documents, Jacobi-preconditioned CG Newton solves)") if lane_kernel else
                                   "ctm_estep_generic_kernel<.., CG> (wave per document, lane = matrix row, CG against invsigma in LDS)") if st["waves"] else "wave per document",
                        "cg_wave_trips": st["cg_trips"], "newton_wave_trips": st["newton_trips"]},
             "cold_start": {"value": 1.0 / cold, "ms_per_step": 1e3 * cold, "window": f"iterations {warmup + 1}..{warmup + steps} from the cold start"},
@@ -226,7 +228,7 @@ def ctm(burnin=60, warmup=2, steps=8, cpu=True, K=50):        # 60 burn-in itera
                          "nominal_is": "SURVEY.md 8d: newton steps x (K^3/3 + 4K^2) + 6 K N_d per sweep -- the flops a direct factorisation per Newton step would execute",
                          "flops_per_iteration_executed": F_exec, "executed_TFLOPs": (F_exec / sec / 1e12) if F_exec else None,
                          "executed_frac": (F_exec / sec / 1e12 / F32_PEAK_TFLOPS) if F_exec else None,
-                         "executed_is": "64 lanes x (CG wave trips x (2 KP^2 + 12 KP) + Newton wave trips x (2 KP^2 + 24 KP)) + token phase; idle lanes of a trip included",
+                         "executed_is": "64 lanes x (CG item trips x (2 KP^2 + 12 KP) + Newton item trips x (2 KP^2 + 24 KP)) + token phase; idle lanes of a trip included (the trips are counted per 64-document item in both lane kernels)",
                          "hbm_GBs": B / sec / 1e9, "hbm_frac": B / sec / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_iteration": B,
                          **(_traffic_fields("ctm", B, sec) if K == 50 else {"traffic": None})}}
     gm.close()
