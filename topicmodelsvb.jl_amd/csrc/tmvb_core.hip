@@ -364,6 +364,12 @@ int tmvb_build_inv_index(tmvb_ctx* ctx, int64_t M, int64_t n_ids, const int64_t*
     int64_t slots = 0;
     int64_t ndocs = 0;
     for (int64_t d = 0; d < M; ++d) if (in_piece(d)) ++ndocs;
+    // postings per chunk (= per wave of the statistics pass): TMVB_CHUNK (256) for a corpus that fills the device with chunks of that size; a SMALL index (CTPF's
+    // SYN-CITEU, an 8-GPU LDA shard: ~1.2 M postings = 4 800 chunks of 256 for 1 024 SIMDs that could hold 16 waves each) is cut finer, so that the gather-latency-bound
+    // pass has more rows in flight (round 6; TMVB_CHUNK_SIZE overrides)
+    static const int chunk_env = [] { const char* e = getenv("TMVB_CHUNK_SIZE"); return e ? std::max(16, atoi(e)) : 0; }();
+    const int64_t n_post = nnz;                          // postings of this index (of this piece)
+    const int64_t CHUNK = chunk_env ? chunk_env : (n_post < TMVB_SMALL_INDEX_POSTINGS ? TMVB_CHUNK_SMALL : TMVB_CHUNK);
     static const int class_env = [] { const char* e = getenv("TMVB_STATS_CLASSES"); return e ? atoi(e) : -1; }();
     static const int64_t class_docs = [] { const char* e = getenv("TMVB_CLASS_DOCS"); return e ? (int64_t)atoi(e) : (int64_t)TMVB_CLASS_DOCS; }();
     static const int64_t class_min = [] { const char* e = getenv("TMVB_CLASS_MIN_POSTINGS"); return e ? (int64_t)atoi(e) : (int64_t)TMVB_CLASS_MIN_POSTINGS; }();
@@ -403,13 +409,13 @@ int tmvb_build_inv_index(tmvb_ctx* ctx, int64_t M, int64_t n_ids, const int64_t*
             int64_t nch = 0;
             for (size_t g = 0; g < seg.size(); ++g) {
                 const int64_t sa = seg[g].first, sb = g + 1 < seg.size() ? seg[g + 1].first : b;
-                nch += (sb - sa + TMVB_CHUNK - 1) / TMVB_CHUNK;
+                nch += (sb - sa + CHUNK - 1) / CHUNK;
             }
             if (nch > 1) { mid.push_back((int32_t)j); mfirst.push_back((int32_t)slots); mcount.push_back((int32_t)nch); }
             for (size_t g = 0; g < seg.size(); ++g) {
                 const int64_t sa = seg[g].first, sb = g + 1 < seg.size() ? seg[g + 1].first : b;
-                for (int64_t q = sa; q < sb; q += TMVB_CHUNK) {
-                    const Chunk ch{(int32_t)j, (int32_t)q, (int32_t)std::min<int64_t>(sb, q + TMVB_CHUNK), nch > 1 ? (int32_t)(slots++) : -1};
+                for (int64_t q = sa; q < sb; q += CHUNK) {
+                    const Chunk ch{(int32_t)j, (int32_t)q, (int32_t)std::min<int64_t>(sb, q + CHUNK), nch > 1 ? (int32_t)(slots++) : -1};
                     if (seg[g].second >= 0) cls[(size_t)seg[g].second].push_back(ch); else rare.push_back(ch);
                 }
             }

@@ -84,6 +84,8 @@ struct tmvb_bucket {
 // readers_sortperm / Y_cumsum (:443-472); used by the gather-side statistics kernels, which rebuild
 // phi .* counts' from (w_token, E_doc) instead of reading a materialised phi buffer.
 #define TMVB_CHUNK 256
+#define TMVB_CHUNK_SMALL 256                 // chunk size of an index of fewer than TMVB_SMALL_INDEX_POSTINGS postings (round 6: measured)
+#define TMVB_SMALL_INDEX_POSTINGS 3000000
 #define TMVB_CLASS_DOCS 8192            // documents per class of the statistics pass (tmvb_build_inv_index): 2 MB of 256-byte rows
 #define TMVB_CLASS_MIN_POSTINGS 1024    // ids with fewer postings are not cut at class boundaries
 struct tmvb_inv_index {
