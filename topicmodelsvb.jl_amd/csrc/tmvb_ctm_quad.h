@@ -15,10 +15,12 @@
 //     lane q of a quad loads the 16-byte chunks q, q + 4, q + 8, q + 12 of the document's row (a quad reads 64 contiguous bytes per load), the
 //     dot product closes with two quad_perm DPP adds, no LDS inside the loop.  exp(lambda - max) goes in and phi * counts comes out through
 //     the LDS in the [topic][document] layout the Newton phases use.
-//   * ~150 registers and 55 KB of LDS per workgroup: two workgroups per CU = two waves per SIMD, the second wave is what hides the first one's
-//     latencies; no scratch.  An item takes a quarter of the time: the launch ends with a shorter tail.
+//   * lambda (fp64) in registers; its fp32 image, phi * counts and vsq in LDS rows ([topic][document]); 256 registers, 88 B of scratch (none inside a
+//     phase's loops), 78 KB of LDS per workgroup: two workgroups per CU = two waves per SIMD, the second wave is what hides the first one's latencies.
+//     An item takes a quarter of the time: the launch ends with a shorter tail, and a 1/8 shard's E-step falls from 3.4 to 1.05 ms.
 // Arithmetic: the same operations as tmvb_ctm_batch.h in another summation order (mat-vec, dot products); the CG stopping rule, the fp64 parts
 // (gradient, logzeta, the vsq Newton iterations, lambda itself) and the exit tests are unchanged.  CTM only (fCTM keeps the one-wave kernel).
+// Measured: 296 - 299 VB it/s on SYN-NSF K = 50 against 205 - 212 for the one-wave kernel (profiles/r6_ctm_experiments.txt: the six steps and what each was worth).
 #pragma once
 
 #ifndef TMVB_CTM_QWAVES
