@@ -104,3 +104,60 @@ def test_built_library_passed_the_check():
     r = subprocess.run([sys.executable, CHECK, isa, "ctm_estep_batch"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-1500:]
     assert "streaming regions checked" in r.stdout and " 0 fixed-register" not in r.stdout
+
+
+# ---- round 6: tools/check_vmem_inflight.py -- the hand-scheduled token loop of ctm_estep_quad_kernel (inline-asm global loads, counted s_waitcnt vmcnt)
+VCHECK = os.path.join(ROOT, "tools", "check_vmem_inflight.py")
+
+_LOOP = """
+	; CQVM_BEGIN
+	global_load_dword v244, v10, s[8:9]
+	s_waitcnt vmcnt(0)
+	global_load_dword v245, v10, s[8:9]
+	global_load_dwordx4 v[0:3], v20, s[2:3] offset:0
+	global_load_dwordx4 v[4:7], v20, s[2:3] offset:0
+	global_load_dwordx4 v[8:11], v20, s[2:3] offset:0
+	global_load_dwordx4 v[12:15], v20, s[2:3] offset:0
+.LBB1_1:
+	s_waitcnt vmcnt(3)
+	v_mov_b32_e32 v30, v245
+%s
+	global_load_dword v245, v31, s[8:9]
+	v_pk_fma_f32 v[40:41], v[0:1], v[16:17], v[40:41]
+	global_load_dwordx4 v[0:3], v20, s[2:3] offset:0
+	s_waitcnt vmcnt(4)
+	v_pk_fma_f32 v[40:41], v[4:5], v[16:17], v[40:41]
+	global_load_dwordx4 v[4:7], v20, s[2:3] offset:0
+	s_waitcnt vmcnt(4)
+	v_pk_fma_f32 v[40:41], v[8:9], v[16:17], v[40:41]
+	global_load_dwordx4 v[8:11], v20, s[2:3] offset:0
+	s_waitcnt vmcnt(4)
+	v_pk_fma_f32 v[40:41], v[12:13], v[16:17], v[40:41]
+	global_load_dwordx4 v[12:15], v20, s[2:3] offset:0
+	s_cbranch_scc0 .LBB1_1
+	s_waitcnt vmcnt(0)
+	; CQVM_END"""
+
+
+def vrun(tmp_path, body):
+    p = tmp_path / "q.s"
+    p.write_text("\t.text\n_Z21ctm_estep_quad_kernelILi4ELb0EEv12CtmBatchArgs: ; @kernel\n" + body + "\n\ts_endpgm\n\t.end_amdhsa_kernel\n")
+    r = subprocess.run([sys.executable, VCHECK, str(p)], capture_output=True, text=True)
+    return r.returncode, r.stdout
+
+
+def test_vmem_clean_hand_scheduled_loop_passes(tmp_path):
+    rc, out = vrun(tmp_path, _LOOP % "\tv_add_u32_e32 v31, 4, v31")
+    assert rc == 0 and "0 finding(s)" in out, out
+
+
+def test_vmem_touch_of_an_in_flight_destination_is_flagged(tmp_path):
+    """what the compiler did during round 6: the id word's register (still in flight from the previous round) used as an address temporary in front of the wait"""
+    bad = _LOOP.replace("\ts_waitcnt vmcnt(3)\n\tv_mov_b32_e32 v30, v245", "\tv_mov_b32_e32 v30, v245\n\tv_add_u32_e32 v245, 4, v31\n\ts_waitcnt vmcnt(3)")
+    rc, out = vrun(tmp_path, bad % "\tv_add_u32_e32 v31, 4, v31")
+    assert rc == 1 and "is in flight" in out and "v245" in out.replace("[245]", "v245"), out
+
+
+def test_vmem_kernel_without_markers_is_not_checked(tmp_path):
+    rc, out = vrun(tmp_path, "\tglobal_load_dwordx4 v[0:3], v20, s[2:3]\n\tv_mov_b32_e32 v1, v0")
+    assert rc == 0 and "nothing to check" in out

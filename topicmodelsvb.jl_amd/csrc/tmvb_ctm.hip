@@ -1437,7 +1437,7 @@ struct tmvb_ctm {
     int32_t* d_doc_order_q = nullptr; unsigned* d_wave_keys = nullptr; bool queue_sorted = false; hipEvent_t ev_spec2 = nullptr; bool spec2_pending = false;      // the lane-per-document launch's queue order (ctm_wave_sort_kernel), valid for the next E-step
     float* d_bt_sdiag = nullptr; float* d_bt_muf = nullptr; unsigned long long* d_cg_iters = nullptr;
     bool filt_parts = false, filt_pw_valid = false;   // fCTM's collecting E-step ran / update_beta! left sum S (log(beta_new + eps) - log(beta_old + eps)) behind it
-    float* d_q_S = nullptr; float* d_q_sd = nullptr; float* d_q_mu = nullptr; int beta_pad_cpr = 0;   // tables of the four-waves-per-item kernel (tmvb_ctm_quad.h)
+    float* d_q_S = nullptr; float* d_q_sd = nullptr; float* d_q_mu = nullptr; int beta_pad_cpr = 0; bool quad_attr_set = false; int lds_limit = -1;   // tables of the four-waves-per-item kernel (tmvb_ctm_quad.h)
     float cg_tol = 1e-4f, cg_abs = 0.05f;   // CG exit: relative residual, and the fraction of ntol it may stop at (TMVB_CTM_CG_TOL / _ABS)
     double* d_sigma = nullptr; double* d_invsigma = nullptr; double* d_mu = nullptr; double* d_logdet = nullptr;
     float* d_scatter_partial = nullptr; int n_scatter_waves = 0; int64_t docs_per_wave = 0;
@@ -1841,7 +1841,8 @@ static int ctm_launch_quad(tmvb_ctm* h, const CtmParams& p, double ntol)
     TMVB_HIP(hipGetLastError());
     ba.p.beta = h->d_beta_pad;
     h->queue_sorted = false;
-#define CTM_QCASE(KPV) case KPV: { static bool attr_set = false; if (!attr_set && lds > 48 * 1024) { TMVB_HIP(hipFuncSetAttribute((const void*)ctm_estep_quad_kernel<KPV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; } \
+    // (the dynamic-LDS attribute once per HANDLE, not per process: one host thread may drive several devices, tmvb_ctm_train_group)
+#define CTM_QCASE(KPV) case KPV: { if (!h->quad_attr_set && lds > 48 * 1024) { TMVB_HIP(hipFuncSetAttribute((const void*)ctm_estep_quad_kernel<KPV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); h->quad_attr_set = true; } \
                                    hipLaunchKernelGGL((ctm_estep_quad_kernel<KPV, false>), grid, block, lds, ctx->stream, ba); } break;
     static const bool qprof = [] { const char* e = getenv("TMVB_CTM_QPROF"); return e && atoi(e) != 0; }();
     if (qprof && h->KP == 52) {
@@ -1979,7 +1980,14 @@ extern "C" int tmvb_ctm_estep(tmvb_ctm* h, int32_t niter, double ntol, int32_t v
         // round 6: four waves per wave-of-documents (tmvb_ctm_quad.h), two workgroups per CU; TMVB_CTM_QUAD=0 (or the profiling build of the
         // one-wave kernel, TMVB_CTM_PROF=1) selects round 3's one-wave kernel
         static const bool quad = [] { const char* e = getenv("TMVB_CTM_QUAD"); const char* pr = getenv("TMVB_CTM_PROF"); return !(e && atoi(e) == 0) && !(pr && atoi(pr) != 0); }();
-        int brc = quad ? ctm_launch_quad(h, p, ntol) : ctm_launch_batch<false>(h, p, ntol);
+        // (the four-waves kernel wants 78 KB of LDS per workgroup at KP = 52: on a device whose per-workgroup limit is below that the one-wave kernel -- 40 KB -- runs)
+        if (h->lds_limit < 0) {
+            int v = 0;
+            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, ctx->device) != hipSuccess || v <= 0) { (void)hipGetLastError(); v = 64 * 1024; }
+            h->lds_limit = v;
+        }
+        const size_t quad_lds = (size_t)(5 * h->KP * 64 + 2 * 3 * 4 * 64) * 4 + (size_t)(2 * 4 * 64) * 8 + (5 * 64 + 4) * 4;
+        int brc = (quad && quad_lds <= (size_t)h->lds_limit) ? ctm_launch_quad(h, p, ntol) : ctm_launch_batch<false>(h, p, ntol);
         if (brc) return brc;
     }
     if (naux > 0) {

@@ -1722,7 +1722,10 @@ static int ctpf_elbo_consts(tmvb_ctpf* h)
     if (h->d_lg_doc) return TMVB_OK;
     tmvb_ctx* ctx = h->ctx;
     int rc;
-    if ((rc = dmalloc(&h->d_lrates_d, 8 * (size_t)h->K)) || (rc = dmalloc(&h->d_lg_doc, (size_t)h->M)) || (rc = dmalloc(&h->d_crd, 2 * (size_t)h->M))) return rc;
+    // (a shard without documents -- sharded handles take the decomposed form whatever their shard holds -- still needs the rate logarithms: one element each)
+    if ((rc = dmalloc(&h->d_lrates_d, 8 * (size_t)h->K)) || (rc = dmalloc(&h->d_lg_doc, (size_t)std::max<int64_t>(h->M, 1))) ||
+        (rc = dmalloc(&h->d_crd, 2 * (size_t)std::max<int64_t>(h->M, 1)))) return rc;
+    if (h->M == 0) return TMVB_OK;
     std::vector<double> lg((size_t)h->M, 0.0), crd(2 * (size_t)h->M, 0.0);
     const tmvb_corpus* c = h->corp;
     for (int64_t d = 0; d < h->M; ++d) {
@@ -2070,7 +2073,7 @@ extern "C" int tmvb_ctpf_update_elbo_parts(tmvb_ctpf* h, double* doc_part, doubl
     // the decomposed form: the last E-step collected its parts and exactly one M-step ran behind it (alef_old / he_old / the old rates are that E-step's)
     const bool parts = (h->M > 0 || h->distributed) && !legacy_elbo && h->logz_valid && h->msteps_after == 1 && !h->force_walk;
     h->elbo_form = parts ? 1 : 0;
-    if (h->M > 0 && !legacy_elbo && (rc = ctpf_elbo_consts(h))) return rc;
+    if ((h->M > 0 || h->distributed) && !legacy_elbo && (rc = ctpf_elbo_consts(h))) return rc;
     // global part: partial sums now, added up by the one final kernel behind the per-document part (one copy, one synchronisation)
     const int nb = 256;
     hipLaunchKernelGGL(ctpf_elbo_global_kernel, dim3(nb), dim3(256), 0, ctx->stream, h->d_alef, h->V, h->K, h->d_rates, hy[0], hy[1], h->d_elbo_partial,
