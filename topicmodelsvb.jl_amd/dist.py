@@ -38,14 +38,22 @@ class HipLDAEngine:
         self.model.beta = np.asfortranarray(beta0); self.model.beta_old = self.model.beta.copy(order="F")
         self.model.update_buffer()
         n = K * shard_corpus.V + K
-        self.stats = torch.zeros(n, dtype=torch.float32, device=f"cuda:{device_index}")
-        self.model.bind_stats(self.stats.data_ptr(), n)
+        # Only a sharded engine binds a torch tensor (the collective has to see the buffer).  One context keeps the library's own buffer: a bound one
+        # switches off the E-step's split of the last statistics pass into a buffer of its own (tmvb_lda.hip: split_out needs own_stats -- a host that
+        # reads its tensor between estep and update_beta! must see all of S), which is the plan plain gpuLDA + train! runs with.
+        self.stats = None
+        if distributed:
+            self.stats = torch.zeros(n, dtype=torch.float32, device=f"cuda:{device_index}")
+            self.model.bind_stats(self.stats.data_ptr(), n)
         self.model.set_distributed(M_total, distributed)
-        self.device = self.stats.device
+        self.device = torch.device(f"cuda:{device_index}")
 
     def estep(self, viter, vtol): self.model.estep(viter, vtol)
     def reduce_docs(self): self.model.reduce_docs()
-    def stats_tensor(self): return self.stats
+    def stats_tensor(self):
+        if self.stats is None:
+            raise RuntimeError("HipLDAEngine(distributed=False) has no bound statistics tensor; use model.stats()")
+        return self.stats
     def update_beta(self): self.model.update_beta()
     def update_alpha(self, niter, ntol): self.model.update_alpha(niter, ntol)
     def local_elbo(self): return self.model.update_elbo()
