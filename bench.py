@@ -441,7 +441,28 @@ def main():
                 if comm is not None:
                     comm.close()
                 comm, use_lib = None, False
-        fused_form = os.environ.get("TMVB_FUSED_ALLREDUCE", "0") != "0"   # opt-in; DEFAULT = the three-call form, ONE collective per iteration (the library's train! default too)
+            if comm is not None:
+                # the communicator's FIRST collective, checked before anything depends on it (RCCL with more than one rank has never run on the
+                # development box): rank r contributes r + 1, every rank must read world (world + 1) / 2; a wrong sum or an error on ANY rank sends
+                # all of them to torch.distributed's collective instead
+                ok = 1
+                try:
+                    probe = torch.full((4096,), float(rank + 1), dtype=torch.float32, device=eng.device)
+                    torch.cuda.synchronize()
+                    comm.allreduce(probe.data_ptr(), probe.numel())
+                    eng.synchronize()
+                    if not bool((probe == float(world * (world + 1) // 2)).all().item()):
+                        log(f"[rank {rank}] in-library RCCL all-reduce returned a wrong sum ({float(probe[0].item())})")
+                        ok = 0
+                except Exception as e:
+                    log(f"[rank {rank}] in-library RCCL all-reduce failed: {e}")
+                    ok = 0
+                flag = torch.tensor([ok], dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) == 0:
+                    comm.close()
+                    comm, use_lib = None, False
+        fused_form =os.environ.get("TMVB_FUSED_ALLREDUCE", "0") != "0"   # opt-in; DEFAULT = the three-call form, ONE collective per iteration (the library's train! default too)
         if one_gpu_debug and not use_lib:
             def gsum(a):
                 t = torch.from_numpy(a); dist.all_reduce(t, op=dist.ReduceOp.SUM)
