@@ -47,6 +47,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <string>
+#include <thread>
 
 
 struct LdaParams {
@@ -1495,11 +1497,29 @@ extern "C" int tmvb_lda_create(tmvb_ctx* ctx, tmvb_corpus* corp, int32_t K, tmvb
             lda_cut_pieces(h, order, P, doc_piece);
             h->pieces.resize(P);
             h->ev_piece.assign(P, nullptr);
+            // the pieces' inverted indices are independent host work (a counting sort over the corpus each, ~50 ms at SYN-NSF's size): one thread per piece
+            // (tmvb_lda_create took 150-180 ms of a 265 ms gpuLDA(corp, K) call with them in a row, profiles/r6_train_end_to_end.txt; TMVB_CREATE_THREADS=0: in a row)
+            static const bool create_threads = [] { const char* e = getenv("TMVB_CREATE_THREADS"); return !(e && atoi(e) == 0); }();
+            std::vector<int> prc((size_t)P, TMVB_OK);
+            std::vector<std::string> pmsg((size_t)P);
+            auto build_piece = [&](int q) {
+                (void)hipSetDevice(ctx->device);
+                prc[(size_t)q] = tmvb_build_inv_index(ctx, h->M, h->V, corp->h_doc_ptr.data(), corp->h_terms.data(), corp->h_counts.data(),
+                                                      &h->pieces[(size_t)q], doc_piece.data(), q);
+                if (prc[(size_t)q]) pmsg[(size_t)q] = tmvb_last_error();          // (the error text is thread-local)
+            };
+            if (create_threads) {
+                std::vector<std::thread> workers;
+                for (int q = 1; q < P; ++q) workers.emplace_back(build_piece, q);
+                build_piece(0);
+                for (std::thread& t : workers) t.join();
+            } else {
+                for (int q = 0; q < P; ++q) build_piece(q);
+            }
             for (int q = 0; q < P && !rc; ++q) {
-                rc = tmvb_build_inv_index(ctx, h->M, h->V, corp->h_doc_ptr.data(), corp->h_terms.data(), corp->h_counts.data(),
-                                          &h->pieces[q], doc_piece.data(), q);
+                if (prc[(size_t)q]) { rc = prc[(size_t)q]; tmvb_set_error("%s", pmsg[(size_t)q].c_str()); break; }
                 slots = std::max(slots, (size_t)h->pieces[q].n_slots);
-                if (!rc && hipEventCreateWithFlags(&h->ev_piece[q], tmvb_event_flags()) != hipSuccess) rc = TMVB_EHIP;
+                if (hipEventCreateWithFlags(&h->ev_piece[q], tmvb_event_flags()) != hipSuccess) rc = TMVB_EHIP;
             }
         } else {
             rc = tmvb_corpus_term_index(corp);
