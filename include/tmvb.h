@@ -83,6 +83,11 @@ int tmvb_event_destroy(tmvb_event* ev);
  * which: 0 = digamma (x > 0; src/utils.jl:21-53's algorithm), 1 = exp as used for exp(Elogtheta) (x <= 0 in exact
  * arithmetic), 2 = the rcp-based reciprocal 1/x. */
 int tmvb_special_f32(tmvb_ctx* ctx, int32_t which, const float* x, float* y, int64_t n);
+/* model.topics behind every train! of the reference: topics[i] = reverse(sortperm(vec(beta[i,:]))) (src/gpuLDA.jl:374, src/gpuCTM.jl and
+ * src/gpuCTPF.jl alike; CTPF passes alef ./ bet).  beta: the model's K x V field, column-major, fp64, on the HOST; topics: K rows of V column
+ * ids, row-major, 1-based like the reference's, on the host.  One stable segmented sort on the device, read backwards: ties come out in the
+ * order sortperm + reverse gives them.  K * V < 2^31. */
+int tmvb_topic_order(tmvb_ctx* ctx, const double* beta, int32_t K, int64_t V, int32_t* topics);
 
 
 /* ---- communicator: document-sharded multi-GPU behind the C ABI (new: the reference is single-device, src/gpuLDA.jl:64;

@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libtmvb_hip.so")
 # experiments only (tools/build_variant.sh): TMVB_LIB_VARIANT=<name> loads libtmvb_hip_<name>.so, the same sources built with extra -D
 # flags, so that a compile-time variant can be timed against the shipped library inside ONE gpurun call (boxes differ by up to 8 %)
 _VARIANT = os.environ.get("TMVB_LIB_VARIANT", "")
-SOURCES = ["tmvb_core.hip", "tmvb_comm.hip", "tmvb_lda.hip", "tmvb_flda.hip", "tmvb_ctm.hip", "tmvb_ctpf.hip", "tmvb_ctpf_recs.hip"]
+SOURCES = ["tmvb_core.hip", "tmvb_comm.hip", "tmvb_lda.hip", "tmvb_flda.hip", "tmvb_ctm.hip", "tmvb_ctpf.hip", "tmvb_ctpf_recs.hip", "tmvb_topics.hip"]
 
 OK, EINVAL, ESHAPE, ECORPUS, ENOMEM, EHIP, ENONFINITE, ENODEVICE, ERCCL = range(9)
 

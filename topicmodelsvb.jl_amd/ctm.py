@@ -20,7 +20,7 @@ import numpy as np
 
 from ._lib import TopicModelError, check, lib, P_dbl, P_i64, VP
 from .corpus import dirichlet_rows
-from .lda import DeviceContext, DeviceCorpus, _F, _packed, _pd, _print_delbo, _validate_train_args
+from .lda import DeviceContext, DeviceCorpus, _F, _packed, _pd, _print_delbo, _topic_orders, _validate_train_args
 
 
 class CTM:
@@ -203,7 +203,7 @@ class gpuCTM:
             self.update_host()
         if printelbo and ce:
             _print_delbo(traj, base.value)
-        self.topics = [np.argsort(self.beta[i, :], kind="stable")[::-1] + 1 for i in range(self.K)]
+        self.topics = _topic_orders(self.ctx, self.beta)
         return traj
 
     def close(self):

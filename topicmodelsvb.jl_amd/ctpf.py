@@ -20,7 +20,7 @@ import numpy as np
 
 from ._lib import TopicModelError, check, lib, P_i64, VP
 from .corpus import dirichlet_rows
-from .lda import DeviceContext, DeviceCorpus, _F, _packed, _pd, _print_delbo, _validate_train_args
+from .lda import DeviceContext, DeviceCorpus, _F, _packed, _pd, _print_delbo, _topic_orders, _validate_train_args
 
 
 class CTPF:
@@ -218,7 +218,7 @@ class gpuCTPF:
         if printelbo and ce:
             _print_delbo(traj[:done.value], base.value)
         Ebeta = self.alef / self.bet[:, None]                                                     # :707-708
-        self.topics = [np.argsort(Ebeta[i, :], kind="stable")[::-1] + 1 for i in range(self.K)]   # reverse(sortperm(.))
+        self.topics = _topic_orders(self.ctx, Ebeta)   # reverse(sortperm(.))
         if recs:
             self.recommend()                                                                      # :711-731
         return traj[:done.value]

@@ -24,7 +24,7 @@ import numpy as np
 from ._lib import TopicModelError, check, lib, P_i64, VP
 from .corpus import dirichlet_rows
 from .ctm import CTM, check_model_ctm
-from .lda import DeviceContext, DeviceCorpus, _F, _pd, _print_delbo, _validate_train_args
+from .lda import DeviceContext, DeviceCorpus, _F, _pd, _print_delbo, _topic_orders, _validate_train_args
 
 
 class fCTM(CTM):
@@ -164,7 +164,7 @@ class gpufCTM:
             self.update_host()
         if printelbo and ce:
             _print_delbo(traj, base.value)
-        self.topics = [np.argsort(self.beta[i, :], kind="stable")[::-1] + 1 for i in range(self.K)]   # :260
+        self.topics = _topic_orders(self.ctx, self.beta)   # :260
         return traj
 
     def close(self):

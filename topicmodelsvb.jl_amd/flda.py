@@ -22,7 +22,7 @@ import numpy as np
 
 from ._lib import TopicModelError, check, lib, VP
 from .corpus import dirichlet_rows
-from .lda import LDA, DeviceContext, DeviceCorpus, _F, _pd, _print_delbo, _validate_train_args
+from .lda import LDA, DeviceContext, DeviceCorpus, _F, _pd, _print_delbo, _topic_orders, _validate_train_args
 
 
 class fLDA(LDA):
@@ -158,7 +158,7 @@ class gpufLDA:
             self.update_host()
         if printelbo and ce:
             _print_delbo(traj, base.value)
-        self.topics = [np.argsort(self.beta[i, :], kind="stable")[::-1] + 1 for i in range(self.K)]   # :245
+        self.topics = _topic_orders(self.ctx, self.beta)   # :245
         return traj
 
     def close(self):

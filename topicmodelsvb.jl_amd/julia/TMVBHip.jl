@@ -68,6 +68,15 @@ end
 tmvb_destroy_corpus(dcorp::Ptr{Cvoid}) = ccall((:tmvb_corpus_destroy, LIBTMVB), Cint, (Ptr{Cvoid},), dcorp)
 tmvb_destroy_context(ctx::Ptr{Cvoid}) = ccall((:tmvb_ctx_destroy, LIBTMVB), Cint, (Ptr{Cvoid},), ctx)
 
+# model.topics = [reverse(sortperm(vec(B[i,:]))) for i in 1:K] (src/gpuLDA.jl:374 and its siblings) as ONE stable segmented sort on the device,
+# read backwards (tmvb_topic_order): K = 50 sorts of V = 25 319 values one after the other were the largest host item of a train! call.
+function hip_topics(ctx::Ptr{Cvoid}, B::Matrix{Float64})
+	K, V = size(B)
+	out = Matrix{Int32}(undef, V, K)                 # the library's row-major [K][V] is this column-major V x K
+	tmvb_check(ccall((:tmvb_topic_order, LIBTMVB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int32, Int64, Ptr{Int32}), ctx, B, K, V, out))
+	[Int.(out[:, i]) for i in 1:K]
+end
+
 cols(m::Matrix{Float64}) = [m[:,d] for d in 1:size(m, 2)]
 checkelbo_arg(checkelbo::Real) = checkelbo == Inf ? Int32(0) : Int32(checkelbo)
 
@@ -238,7 +247,7 @@ function train!(model::hipLDA; iter::Integer=150, tol::Real=1.0, niter::Integer=
 		model.handle, iter, tol, niter, ntol, viter, vtol, checkelbo_arg(checkelbo), traj, done, base))
 	printelbo && print_delbo(traj, done[], base[])
 	(iter > 0) && update_host!(model)
-	model.topics = [reverse(sortperm(vec(model.beta[i,:]))) for i in 1:model.K]
+	model.topics = hip_topics(model.ctx, model.beta)                             # reverse(sortperm(.)) per topic
 	nothing
 end
 
@@ -259,7 +268,7 @@ function train!(models::Vector{hipLDA}; iter::Integer=150, tol::Real=1.0, niter:
 	printelbo && print_delbo(traj, done[], base[])
 	for m in models
 		(iter > 0) && update_host!(m)
-		m.topics = [reverse(sortperm(vec(m.beta[i,:]))) for i in 1:m.K]
+		m.topics = hip_topics(m.ctx, m.beta)
 	end
 	nothing
 end
@@ -373,7 +382,7 @@ function train!(model::hipCTM; iter::Integer=150, tol::Real=1.0, niter::Integer=
 		model.handle, iter, tol, niter, ntol, viter, vtol, checkelbo_arg(checkelbo), traj, done, base))
 	printelbo && print_delbo(traj, done[], base[])
 	(iter > 0) && update_host!(model)
-	model.topics = [reverse(sortperm(vec(model.beta[i,:]))) for i in 1:model.K]
+	model.topics = hip_topics(model.ctx, model.beta)                             # reverse(sortperm(.)) per topic
 	nothing
 end
 
@@ -388,7 +397,7 @@ function train!(models::Vector{hipCTM}; iter::Integer=150, tol::Real=1.0, niter:
 	printelbo && print_delbo(traj, done[], base[])
 	for m in models
 		(iter > 0) && update_host!(m)
-		m.topics = [reverse(sortperm(vec(m.beta[i,:]))) for i in 1:m.K]
+		m.topics = hip_topics(m.ctx, m.beta)
 	end
 	nothing
 end
@@ -529,7 +538,7 @@ function train!(model::hipCTPF; iter::Integer=150, tol::Real=1.0, viter::Integer
 	printelbo && print_delbo(traj, done[], base[])
 	(iter > 0) && update_host!(model)
 	Ebeta = model.alef ./ model.bet
-	model.topics = [reverse(sortperm(vec(Ebeta[i,:]))) for i in 1:model.K]      # src/CTPF.jl:376-377
+	model.topics = hip_topics(model.ctx, Matrix{Float64}(Ebeta))                # reverse(sortperm(.)) per topic, src/CTPF.jl:376-377
 	(model.comm === nothing) && update_recs!(model)                             # :379-399 (a shard ranks only its own documents)
 	nothing
 end
@@ -631,7 +640,7 @@ function train!(model::hipfLDA; iter::Integer=150, tol::Real=1.0, niter::Integer
 		model.handle, iter, tol, niter, ntol, viter, vtol, checkelbo_arg(checkelbo), traj, done, base))
 	printelbo && print_delbo(traj, done[], base[])
 	(iter > 0) && update_host!(model)
-	model.topics = [reverse(sortperm(vec(model.beta[i,:]))) for i in 1:model.K]
+	model.topics = hip_topics(model.ctx, model.beta)                             # reverse(sortperm(.)) per topic
 	nothing
 end
 
@@ -646,7 +655,7 @@ function train!(models::Vector{hipfLDA}; iter::Integer=150, tol::Real=1.0, niter
 	printelbo && print_delbo(traj, done[], base[])
 	for m in models
 		(iter > 0) && update_host!(m)
-		m.topics = [reverse(sortperm(vec(m.beta[i,:]))) for i in 1:m.K]
+		m.topics = hip_topics(m.ctx, m.beta)
 	end
 	nothing
 end
@@ -762,7 +771,7 @@ function train!(model::hipfCTM; iter::Integer=150, tol::Real=1.0, niter::Integer
 		model.handle, iter, tol, niter, ntol, viter, vtol, checkelbo_arg(checkelbo), traj, done, base))
 	printelbo && print_delbo(traj, done[], base[])
 	(iter > 0) && update_host!(model)
-	model.topics = [reverse(sortperm(vec(model.beta[i,:]))) for i in 1:model.K]
+	model.topics = hip_topics(model.ctx, model.beta)                             # reverse(sortperm(.)) per topic
 	nothing
 end
 
@@ -777,7 +786,7 @@ function train!(models::Vector{hipfCTM}; iter::Integer=150, tol::Real=1.0, niter
 	printelbo && print_delbo(traj, done[], base[])
 	for m in models
 		(iter > 0) && update_host!(m)
-		m.topics = [reverse(sortperm(vec(m.beta[i,:]))) for i in 1:m.K]
+		m.topics = hip_topics(m.ctx, m.beta)
 	end
 	nothing
 end
