@@ -17,6 +17,8 @@
 #include <numeric>
 #include <map>
 #include <mutex>
+#include <thread>
+#include <vector>
 
 static thread_local std::string g_last_error;
 
@@ -332,25 +334,69 @@ int tmvb_build_inv_index(tmvb_ctx* ctx, int64_t M, int64_t n_ids, const int64_t*
     const int64_t nnz_all = h_ptr[M];
     TMVB_REQUIRE(nnz_all < (int64_t)INT32_MAX, TMVB_EINVAL, "inverted index: token count must fit int32");
     auto in_piece = [&](int64_t d) { return doc_piece == nullptr || doc_piece[d] == piece; };
+    // The postings sorted by id, documents in order within an id: a counting sort.  Large indices (round 6: the index build was most of the 200 - 300 ms a
+    // gpuLDA / gpuCTM constructor takes on SYN-NSF) split the documents into T contiguous ranges of equal postings, one host thread each: per-range histograms,
+    // one prefix over (id, range), then every range scatters its own documents from its own cursors -- the same positions the one-thread loop assigns
+    // (TMVB_CREATE_THREADS=0, or fewer than 2^20 postings: one thread).
+    static const int thread_env = [] { const char* e = getenv("TMVB_CREATE_THREADS"); return e ? atoi(e) : -1; }();
+    int T = 1;
+    if (thread_env != 0 && nnz_all >= (1 << 20)) {
+        const unsigned hw = std::thread::hardware_concurrency();
+        T = (int)std::min<unsigned>(thread_env > 0 ? (unsigned)thread_env : 8u, hw ? hw : 1u);
+        T = std::max(1, std::min(T, 16));
+    }
+    std::vector<int64_t> dcut((size_t)T + 1, M);                       // document ranges [dcut[t], dcut[t + 1])
+    dcut[0] = 0;
+    for (int t = 1; t < T; ++t) {
+        const int64_t target = nnz_all / T * t;
+        dcut[(size_t)t] = std::lower_bound(h_ptr, h_ptr + M + 1, target) - h_ptr;
+        dcut[(size_t)t] = std::min<int64_t>(std::max(dcut[(size_t)t], dcut[(size_t)t - 1]), M);
+    }
+    std::vector<std::vector<int32_t>> hist((size_t)T);
+    auto count_range = [&](int t) {
+        std::vector<int32_t>& H = hist[(size_t)t];
+        H.assign((size_t)n_ids, 0);
+        for (int64_t d = dcut[(size_t)t]; d < dcut[(size_t)t + 1]; ++d)
+            if (in_piece(d))
+                for (int64_t q = h_ptr[d]; q < h_ptr[d + 1]; ++q) H[(size_t)h_ids[q]]++;
+    };
+    auto run_ranges = [&](auto&& fn) {
+        std::vector<std::thread> workers;
+        for (int t = 1; t < T; ++t) workers.emplace_back(fn, t);
+        fn(0);
+        for (std::thread& w : workers) w.join();
+    };
+    run_ranges(count_range);
     std::vector<int64_t> cnt(n_ids + 1, 0);
-    for (int64_t d = 0; d < M; ++d)
-        if (in_piece(d))
-            for (int64_t q = h_ptr[d]; q < h_ptr[d + 1]; ++q) cnt[h_ids[q] + 1]++;
-    for (int64_t j = 0; j < n_ids; ++j) cnt[j + 1] += cnt[j];
+    for (int64_t j = 0; j < n_ids; ++j) {
+        int64_t c = 0;
+        for (int t = 0; t < T; ++t) c += hist[(size_t)t][(size_t)j];
+        cnt[j + 1] = cnt[j] + c;
+    }
     const int64_t nnz = cnt[n_ids];
     ix->n_ids = n_ids; ix->nnz = nnz; ix->n_docs = M;
     std::vector<int32_t> doc(nnz), pos(nnz), inv(doc_piece ? 0 : nnz_all);
     std::vector<float> val(nnz);
     {
-        std::vector<int64_t> cur(cnt.begin(), cnt.end() - 1);
-        for (int64_t d = 0; d < M; ++d) {
-            if (!in_piece(d)) continue;
-            for (int64_t q = h_ptr[d]; q < h_ptr[d + 1]; ++q) {
-                int64_t w = cur[h_ids[q]]++;
-                doc[w] = (int32_t)d; pos[w] = (int32_t)q; val[w] = (float)h_vals[q];
-                if (!doc_piece) inv[q] = (int32_t)w;
-            }
+        // cursors of range t: behind the postings of the same id in the ranges before it
+        std::vector<std::vector<int64_t>> cur((size_t)T);
+        for (int t = 0; t < T; ++t) cur[(size_t)t].resize((size_t)n_ids);
+        for (int64_t j = 0; j < n_ids; ++j) {
+            int64_t w = cnt[j];
+            for (int t = 0; t < T; ++t) { cur[(size_t)t][(size_t)j] = w; w += hist[(size_t)t][(size_t)j]; }
         }
+        auto scatter_range = [&](int t) {
+            std::vector<int64_t>& cu = cur[(size_t)t];
+            for (int64_t d = dcut[(size_t)t]; d < dcut[(size_t)t + 1]; ++d) {
+                if (!in_piece(d)) continue;
+                for (int64_t q = h_ptr[d]; q < h_ptr[d + 1]; ++q) {
+                    const int64_t w = cu[(size_t)h_ids[q]]++;
+                    doc[w] = (int32_t)d; pos[w] = (int32_t)q; val[w] = (float)h_vals[q];
+                    if (!doc_piece) inv[q] = (int32_t)w;
+                }
+            }
+        };
+        run_ranges(scatter_range);
     }
     // Chunks (one wave each, 4 per workgroup) and their ORDER.  The statistics pass gathers one row of per-document factors per
     // posting: 33 MB of rows on SYN-NSF against 4 MB of L2 per XCD, 20 % L2 hits (TCC_HIT / TCC_REQ), the rest from the Infinity
